@@ -1,0 +1,184 @@
+#!/usr/bin/env python
+"""bench.py -- L-BFGS iterations/s on MI355X (BASELINE.json metric) + roofline + CPU baseline.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one full L-BFGS iteration (line search with the fused trial kernel, the post-line-search
+pass, history commit and the 2m+1-launch two-loop recursion) on the north-star workload: extended
+Rosenbrock, n = 1e8, m = 10, f64, LineSearchMoreThuente, inputs generated in HBM from a counter hash
+(no host copy of any n-vector).  For N > 1 every rank solves its own independent problem of that size on
+its own GPU (the path shards by independent minimisations; no data-path collective) and the aggregate
+iterations/s is reported ("scaling": "weak"); RCCL is used only for the barriers / final gather.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (about 6.3 TB/s achievable)
+
+
+def cpu_baseline(args):
+    """Reference (unmodified headers + eigen_shim, native accumulators) on ONE host core, bounded sample."""
+    import numpy as np
+
+    import oracle_lib as O
+    fam, kind = ("ref", "reference") if O.available("ref", "native") else ("port", "port")
+    if not O.available(fam, "native"):
+        return None
+    orc = O.Oracle(fam, "native")
+    n = int(args.cpu_n)
+    warm, timed = args.m + 2, args.cpu_steps
+    x0 = O.rosen_x0(n)
+    # two runs that differ only in max_iterations: the difference isolates `timed` steady-state iterations
+    p1 = O.lbfgs_params(m=args.m, epsilon=0, epsilon_rel=0, max_iterations=warm)
+    p2 = O.lbfgs_params(m=args.m, epsilon=0, epsilon_rel=0, max_iterations=warm + timed)
+    t0 = time.perf_counter()
+    _, r1 = orc.lbfgs(O.F64, O.LS_MT, O.OBJ_ROSEN, x0, p1)
+    t1 = time.perf_counter()
+    _, r2 = orc.lbfgs(O.F64, O.LS_MT, O.OBJ_ROSEN, x0, p2)
+    t2 = time.perf_counter()
+    dt = (t2 - t1) - (t1 - t0)
+    its = (r2.niter - r1.niter) / dt
+    scale = n / float(args.n)
+    return {"value": its * scale, "unit": "iterations/s", "cores": 1, "kind": kind,
+            "sample": "same workload at n=%d (%.3g of n), %d timed iterations after %d warm-up, %.1f s of CPU; "
+                      "measured %.4g it/s scaled linearly by n ratio; host has %d cores"
+                      % (n, scale, r2.niter - r1.niter, r1.niter, t2 - t0, its, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=12)
+    ap.add_argument("--n", type=float, default=1e8)
+    ap.add_argument("--m", type=int, default=10)
+    ap.add_argument("--objective", default="rosenbrock", choices=["rosenbrock", "quadratic"])
+    ap.add_argument("--cpu-n", type=float, default=4e6)
+    ap.add_argument("--cpu-steps", type=int, default=12)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch  # noqa: F401  (first: its bundled HIP runtime must be the process-wide one)
+    import torch.distributed as dist
+
+    import lbfgspp_amd as A
+    from lbfgspp_amd import _lib as L
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    core, _ = A.load()
+    if core.lbfgsx_device_count() < 1:
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+
+    n, m, K, W = int(args.n), args.m, args.steps, max(args.warmup, 0)
+    ls = A.LS_MORE_THUENTE if args.objective == "rosenbrock" else A.LS_NOCEDAL_WRIGHT
+    par = A.LBFGSParam(m=m, epsilon=0.0, epsilon_rel=0.0, past=0, max_iterations=W + K + 1)
+    solver = A.LBFGSSolver(par, linesearch=ls, dtype="float64", device=local)
+    ctx = solver.prepare(n)
+    if args.objective == "rosenbrock":
+        L.check(core.lbfgsx_gen_rosen_x0(ctx, 7 + rank))
+        f = A.ExtendedRosenbrock()
+    else:
+        L.check(core.lbfgsx_gen_diag_quad(ctx, 10.0, 1 + rank))
+        L.check(core.lbfgsx_fill(ctx, L.VEC_X, 0.0))
+        f = A.DiagQuadratic()
+    L.check(core.lbfgsx_sync(ctx))
+
+    def barrier():
+        L.check(core.lbfgsx_sync(ctx))
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    marks = {}
+
+    def hook(k):
+        if k == W:
+            barrier()
+            L.check(core.lbfgsx_timing_enable(ctx, 1))
+            marks["t0"] = time.perf_counter()
+            marks["nfev0"] = None
+        elif k == W + K:
+            barrier()
+            marks["t1"] = time.perf_counter()
+            tl_ms, tl_n, hv_ms, hv_n = C.c_double(), C.c_int64(), C.c_double(), C.c_int64()
+            L.check(core.lbfgsx_timing_read(ctx, C.byref(tl_ms), C.byref(tl_n), C.byref(hv_ms), C.byref(hv_n)))
+            marks["tl"] = (tl_ms.value, tl_n.value, hv_ms.value, hv_n.value)
+            L.check(core.lbfgsx_timing_enable(ctx, 0))
+
+    if W == 0:
+        hook(0)
+    solver.set_iteration_hook(hook)
+    niter, fx = solver.minimize_resident(f, n)
+    if "t1" not in marks:
+        raise SystemExit("solver stopped after %d iterations, before the timed window ended" % niter)
+    elapsed = marks["t1"] - marks["t0"]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    copy_gbs, triad_gbs = C.c_double(), C.c_double()
+    L.check(core.lbfgsx_stream_probe(ctx, 10, C.byref(copy_gbs), C.byref(triad_gbs)))
+
+    if rank == 0:
+        tl_ms, tl_n, hv_ms, hv_n = marks["tl"]
+        esz = 8
+        hv_bytes = (8 * m + 1) * n * esz  # algorithmic bytes per apply_Hv call, history full
+        per_launch_bytes = hv_bytes / float(2 * m + 1)
+        avg_launch_s = (tl_ms / max(tl_n, 1)) * 1e-3
+        achieved = per_launch_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        out = {
+            "metric": "L-BFGS iterations/sec at n=10^8, m=10; achieved HBM GB/s vs peak",
+            "value": world * K / elapsed,
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "north-star: extended Rosenbrock n=%d m=%d f64 LineSearchMoreThuente, x0 from counter hash"
+                                   % (n, m) if args.objective == "rosenbrock" else
+                                   "diag quadratic kappa=10 n=%d m=%d f64 LineSearchNocedalWright" % (n, m),
+                       "n": n, "m": m, "problems_per_gpu": 1,
+                       "fevals_total": solver.last.nfev, "iterations_total": niter},
+            "roofline": {"bound": "hbm", "kernel": "k_twoloop (two-loop recursion step: axpy + dot)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None,
+                         "algorithmic_bytes_per_launch": per_launch_bytes,
+                         "avg_launch_ms": avg_launch_s * 1e3, "launches_timed": tl_n,
+                         "apply_Hv_ms": hv_ms / max(hv_n, 1), "apply_Hv_GBs": hv_bytes / (hv_ms / max(hv_n, 1) * 1e-3) / 1e9,
+                         "stream_copy_GBs": copy_gbs.value, "stream_triad_GBs": triad_gbs.value,
+                         "frac_of_stream_copy": achieved / copy_gbs.value if copy_gbs.value else None},
+        }
+        if not args.no_cpu:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args)
+            except Exception as e:  # the baseline is reported, never required
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

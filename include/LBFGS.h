@@ -1,0 +1,160 @@
+// include/LBFGS.h -- drop-in LBFGSpp::LBFGSSolver whose O(n) work runs on an MI355X.
+//
+// Same class template, constructor, minimize() return value and getters as the reference driver
+// (/root/reference/include/LBFGS.h:20-23,59-63,78-173,182-187).  Scalar control flow (convergence tests
+// :100-103,137-154, curvature test :161, step reset :168) stays on the host; every vector statement
+// goes through the C ABI of liblbfgsx.so:
+//     :91-92  f(x,grad), grad.norm()                -> lbfgsx_eval            (kernel K0)
+//     :106-108 drt = -grad, 1/drt.norm()            -> lbfgsx_apply_Hv with an empty history
+//     :121-123 xp = x, gradp = grad, grad.dot(drt)  -> lbfgsx_ls_begin (rotation) + dot fused into K1
+//     :127    line search                           -> LineSearch policies over lbfgsx_trial (K2)
+//     :130,137,159-161 norms, s, y, s.y, y.y        -> lbfgsx_post_linesearch (K3)
+//     :162    add_correction                        -> lbfgsx_commit_correction (index rotation)
+//     :165    apply_Hv                              -> lbfgsx_apply_Hv          (2c+1 launches of K1)
+// `Foo` may be a BuiltinObjective (fused kernels), a device functor
+// `Scalar(const DeviceVector<Scalar>&, DeviceVector<Scalar>&)`, or a host functor on `Vec` (compatibility
+// path, stages x/grad through host memory at every evaluation).
+#ifndef LBFGSX_DROPIN_LBFGS_H
+#define LBFGSX_DROPIN_LBFGS_H
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <vector>
+
+#include "LBFGSpp/Device.h"
+#include "LBFGSpp/LineSearchBacktracking.h"
+#include "LBFGSpp/LineSearchBracketing.h"
+#include "LBFGSpp/LineSearchMoreThuente.h"
+#include "LBFGSpp/LineSearchNocedalWright.h"
+#include "LBFGSpp/Param.h"
+
+namespace LBFGSpp {
+
+template <typename Scalar, template <class> class LineSearch = LineSearchNocedalWright>
+class LBFGSSolver
+{
+    const LBFGSParam<Scalar>& m_param;  // non-owning, like the reference (LBFGS.h:29)
+    DeviceState<Scalar> m_dev;
+    std::vector<Scalar> m_fx;           // ring of past objective values
+    std::vector<Scalar> m_grad_host;    // filled lazily by final_grad()
+    Scalar m_gnorm = Scalar(0);
+    int m_device = 0;
+    int m_nfev = 0;
+    std::function<void(int, Scalar, DeviceState<Scalar>&)> m_trace;
+    std::function<void(int)> m_iter_hook;
+
+    template <typename Foo, typename HostVec>
+    int run(Foo& f, Scalar& fx)
+    {
+        using std::abs;
+        using std::sqrt;
+        detail::Evaluator<Scalar, Foo, HostVec> ev(f, m_dev);
+        if (m_trace)
+            ev.on_eval = [this](int k, Scalar v) { m_trace(k, v, m_dev); };
+        lbfgsx_ctx* c = m_dev.ctx();
+        detail::check(lbfgsx_bfgs_reset(c));
+        ev.prepare();
+
+        const int fpast = m_param.past;
+        if (fpast > 0)
+            m_fx.assign(size_t(fpast), Scalar(0));
+
+        Scalar gnorm2, xnorm2;
+        ev.initial(fx, gnorm2, xnorm2);
+        m_gnorm = sqrt(gnorm2);
+        if (fpast > 0)
+            m_fx[0] = fx;
+        m_nfev = ev.nfev();
+        if (m_gnorm <= m_param.epsilon || m_gnorm <= m_param.epsilon_rel * sqrt(xnorm2))
+            return 1;
+
+        // drt = -grad (empty history => H = I); |drt| == |grad| exactly, so step = 1/|grad|
+        double dgd = 0;
+        detail::check(lbfgsx_apply_Hv(c, LBFGSX_VEC_G, -1.0, &dgd));
+        Scalar dg = Scalar(dgd);
+        Scalar step = Scalar(1) / m_gnorm;
+        constexpr Scalar eps = std::numeric_limits<Scalar>::epsilon();
+
+        int k = 1;
+        for (;;)
+        {
+            detail::check(lbfgsx_ls_begin(c));
+            const Scalar step_max = m_param.max_step;
+            LineSearch<Scalar>::LineSearch(ev, m_param, step_max, step, fx, dg);
+            m_nfev = ev.nfev();
+
+            double g2 = 0, x2 = 0, syd = 0, yyd = 0;
+            detail::check(lbfgsx_post_linesearch(c, &g2, &x2, &syd, &yyd));
+            m_gnorm = sqrt(Scalar(g2));
+            if (m_gnorm <= m_param.epsilon || m_gnorm <= m_param.epsilon_rel * sqrt(Scalar(x2)))
+                return k;
+            if (fpast > 0)
+            {
+                const Scalar old = m_fx[size_t(k % fpast)];
+                if (k >= fpast && abs(old - fx) <= m_param.delta * std::max(std::max(abs(fx), abs(old)), Scalar(1)))
+                    return k;
+                m_fx[size_t(k % fpast)] = fx;
+            }
+            if (m_param.max_iterations != 0 && k >= m_param.max_iterations)
+                return k;
+
+            if (Scalar(syd) > eps * Scalar(yyd))
+                detail::check(lbfgsx_commit_correction(c));
+
+            detail::check(lbfgsx_apply_Hv(c, LBFGSX_VEC_G, -1.0, &dgd));
+            dg = Scalar(dgd);
+            step = Scalar(1);
+            if (m_iter_hook)
+                m_iter_hook(k);  // iteration k complete (new direction included)
+            k++;
+        }
+    }
+
+public:
+    LBFGSSolver(const LBFGSParam<Scalar>& param) : m_param(param) { m_param.check_param(); }
+
+    // choose the GPU of this solver (default 0); takes effect at the next minimize()
+    void set_device(int device) { m_device = device; }
+    // parity tracing: called after every objective evaluation with (index, fx, device state)
+    void set_trace(std::function<void(int, Scalar, DeviceState<Scalar>&)> cb) { m_trace = std::move(cb); }
+    // progress/timing hook: called with k after iteration k has produced the next search direction
+    void set_iteration_hook(std::function<void(int)> cb) { m_iter_hook = std::move(cb); }
+    DeviceState<Scalar>& device_state() { return m_dev; }
+    int num_evaluations() const { return m_nfev; }
+
+    // Reference signature (LBFGS.h:78-79): x is a host vector (anything with data()/size()), in/out.
+    template <typename Foo, typename Vec>
+    inline int minimize(Foo& f, Vec& x, Scalar& fx)
+    {
+        const std::int64_t n = std::int64_t(x.size());
+        m_dev.ensure(n, m_param.m, 0, m_device);
+        m_dev.upload(LBFGSX_VEC_X, x.data());
+        const int k = run<Foo, Vec>(f, fx);
+        m_dev.download(LBFGSX_VEC_X, x.data());
+        return k;
+    }
+
+    // Device-resident variant: x0 already sits in LBFGSX_VEC_X of device_state() (e.g. generated there);
+    // the minimiser is left in LBFGSX_VEC_X.  No host copy of any n-vector is made.
+    template <typename Foo>
+    inline int minimize_resident(Foo& f, std::int64_t n, Scalar& fx)
+    {
+        m_dev.ensure(n, m_param.m, 0, m_device);
+        return run<Foo, std::vector<Scalar> >(f, fx);
+    }
+    void prepare_resident(std::int64_t n) { m_dev.ensure(n, m_param.m, 0, m_device); }
+
+    // final_grad(): copied back on demand (the reference returns its host member, LBFGS.h:182)
+    const std::vector<Scalar>& final_grad()
+    {
+        m_grad_host.resize(size_t(m_dev.size()));
+        m_dev.download(LBFGSX_VEC_G, m_grad_host.data());
+        return m_grad_host;
+    }
+    Scalar final_grad_norm() const { return m_gnorm; }
+};
+
+}  // namespace LBFGSpp
+
+#endif  // LBFGSX_DROPIN_LBFGS_H

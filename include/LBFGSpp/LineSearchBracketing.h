@@ -1,0 +1,72 @@
+// include/LBFGSpp/LineSearchBracketing.h -- bisection/expansion bracketing search, host scalar logic over
+// the fused device trial primitive.  Same decisions and exception messages as the reference policy
+// (/root/reference/include/LBFGSpp/LineSearchBracketing.h:48-128).
+#ifndef LBFGSX_DROPIN_LS_BRACKETING_H
+#define LBFGSX_DROPIN_LS_BRACKETING_H
+
+#include <cmath>
+#include <limits>
+#include <stdexcept>
+
+#include "Param.h"
+
+namespace LBFGSpp {
+
+template <typename Scalar>
+class LineSearchBracketing
+{
+public:
+    template <typename Eval>
+    static void LineSearch(Eval& ev, const LBFGSParam<Scalar>& param, const Scalar& /*step_max*/, Scalar& step,
+                           Scalar& fx, Scalar& dg)
+    {
+        if (step <= Scalar(0))
+            throw std::invalid_argument("'step' must be positive");
+        const Scalar f0 = fx, g0 = dg;
+        if (g0 > 0)
+            throw std::logic_error("the moving direction increases the objective function value");
+        const Scalar armijo = param.ftol * g0;
+        Scalar lo = 0, hi = std::numeric_limits<Scalar>::infinity();
+
+        for (int it = 0; it < param.max_linesearch; it++)
+        {
+            Scalar dg_t;
+            ev.trial(step, fx, dg_t);
+            if (fx > f0 + step * armijo || !std::isfinite(fx))
+                hi = step;
+            else
+            {
+                dg = dg_t;
+                bool done = (param.linesearch == LBFGS_LINESEARCH_BACKTRACKING_ARMIJO);
+                if (!done)
+                {
+                    if (dg < param.wolfe * g0)
+                        lo = step;
+                    else if (param.linesearch == LBFGS_LINESEARCH_BACKTRACKING_WOLFE)
+                        done = true;
+                    else if (dg > -param.wolfe * g0)
+                        hi = step;
+                    else
+                        done = true;
+                }
+                if (done)
+                {
+                    ev.finish(false);
+                    return;
+                }
+            }
+            if (lo > hi)
+                throw std::runtime_error("the lower bound of the bracketing interval becomes larger than the upper bound");
+            if (step < param.min_step)
+                throw std::runtime_error("the line search step became smaller than the minimum value allowed");
+            if (step > param.max_step)
+                throw std::runtime_error("the line search step became larger than the maximum value allowed");
+            step = std::isinf(hi) ? 2 * step : lo / 2 + hi / 2;
+        }
+        throw std::runtime_error("the line search routine reached the maximum number of iterations");
+    }
+};
+
+}  // namespace LBFGSpp
+
+#endif  // LBFGSX_DROPIN_LS_BRACKETING_H

@@ -1,0 +1,81 @@
+/* include/lbfgsx_solver.h -- C ABI of liblbfgsx_solver.so: the drop-in C++ solvers (include/LBFGS.h,
+ * include/LBFGSB.h) instantiated for the built-in device objectives, for callers without a C++ compiler
+ * (ctypes / cgo / JNI ...).  Mirrors LBFGSSolver<T, LineSearch>::minimize (reference LBFGS.h:78-173) and
+ * LBFGSBSolver<T>::minimize (reference LBFGSB.h:116-262): same parameters (LBFGSParam / LBFGSBParam fields),
+ * same return value (iteration count), exceptions mapped to status codes + message.
+ */
+#ifndef LBFGSX_SOLVER_H
+#define LBFGSX_SOLVER_H
+
+#include <stdint.h>
+
+#include "lbfgsx.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum
+{
+    LBFGSX_LS_NOCEDAL_WRIGHT = 0,
+    LBFGSX_LS_MORE_THUENTE = 1,
+    LBFGSX_LS_BACKTRACKING = 2,
+    LBFGSX_LS_BRACKETING = 3
+};
+enum { LBFGSX_ALGO_LBFGS = 0, LBFGSX_ALGO_LBFGSB = 1 };
+
+/* LBFGSParam / LBFGSBParam fields (reference Param.h:79-161, 236-320); doubles are cast to the scalar type */
+typedef struct
+{
+    int m;
+    double epsilon, epsilon_rel;
+    int past;
+    double delta;
+    int max_iterations;
+    int linesearch;
+    int max_linesearch;
+    double min_step, max_step, ftol, wolfe;
+    int max_submin;
+} lbfgsx_params;
+
+typedef struct
+{
+    int niter;    /* minimize() return value */
+    int nfev;     /* objective evaluations */
+    double fx;    /* final objective value */
+    double gnorm; /* final_grad_norm() */
+    int status;   /* 0, or LBFGSX_E_* of the exception the reference API would have thrown */
+    char msg[200];
+} lbfgsx_result;
+
+/* optional per-evaluation trace (parity testing): fx[k] and x[0::stride] at the k-th objective evaluation */
+typedef struct
+{
+    int cap;
+    int count;
+    double* fx;
+    int64_t stride;
+    int64_t nsamp;
+    double* xs;
+} lbfgsx_trace;
+
+typedef struct lbfgsx_solver lbfgsx_solver;
+
+/* constructor of LBFGSSolver / LBFGSBSolver: validates the parameters (check_param) */
+int lbfgsx_solver_create(lbfgsx_solver** out, int algo, int dtype, int linesearch, const lbfgsx_params* p, int device);
+const char* lbfgsx_solver_create_error(void); /* message of a failed lbfgsx_solver_create */
+void lbfgsx_solver_destroy(lbfgsx_solver* s);
+/* allocate device state for dimension n and expose it (to generate / upload resident inputs) */
+int lbfgsx_solver_prepare(lbfgsx_solver* s, int64_t n);
+lbfgsx_ctx* lbfgsx_solver_ctx(lbfgsx_solver* s);
+/* progress hook: fn(k, user) runs on the host after iteration k has produced the next search direction */
+int lbfgsx_solver_set_iteration_hook(lbfgsx_solver* s, void (*fn)(int, void*), void* user);
+/* minimize(): objective = LBFGSX_OBJ_*; a/b host arrays or NULL (resident); x host in/out or NULL (resident:
+ * start point in LBFGSX_VEC_X, result left there); lb/ub host arrays or NULL (resident), L-BFGS-B only */
+int lbfgsx_solver_minimize(lbfgsx_solver* s, int objective, int64_t n, const void* a, const void* b, void* x,
+                           const void* lb, const void* ub, lbfgsx_trace* trace, lbfgsx_result* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

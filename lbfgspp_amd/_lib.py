@@ -1,0 +1,127 @@
+"""ctypes bindings of liblbfgsx.so / liblbfgsx_solver.so (the product path; never touches oracle/)."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+F64, F32 = 0, 1
+OBJ_DIAG_QUAD, OBJ_EXT_ROSENBROCK = 0, 1
+LS_NOCEDAL_WRIGHT, LS_MORE_THUENTE, LS_BACKTRACKING, LS_BRACKETING = 0, 1, 2, 3
+ALGO_LBFGS, ALGO_LBFGSB = 0, 1
+FLAG_BOUNDED = 1
+(VEC_X, VEC_G, VEC_XP, VEC_GP, VEC_D, VEC_XT, VEC_GT, VEC_A, VEC_B, VEC_LB, VEC_UB, VEC_XCP) = range(12)
+E_INVALID, E_LOGIC, E_RUNTIME, E_HIP, E_NOGPU = -1, -2, -3, -4, -5
+
+
+class Params(C.Structure):
+    _fields_ = [("m", C.c_int), ("epsilon", C.c_double), ("epsilon_rel", C.c_double), ("past", C.c_int),
+                ("delta", C.c_double), ("max_iterations", C.c_int), ("linesearch", C.c_int),
+                ("max_linesearch", C.c_int), ("min_step", C.c_double), ("max_step", C.c_double),
+                ("ftol", C.c_double), ("wolfe", C.c_double), ("max_submin", C.c_int)]
+
+
+class Result(C.Structure):
+    _fields_ = [("niter", C.c_int), ("nfev", C.c_int), ("fx", C.c_double), ("gnorm", C.c_double),
+                ("status", C.c_int), ("msg", C.c_char * 200)]
+
+
+class Trace(C.Structure):
+    _fields_ = [("cap", C.c_int), ("count", C.c_int), ("fx", C.POINTER(C.c_double)), ("stride", C.c_int64),
+                ("nsamp", C.c_int64), ("xs", C.POINTER(C.c_double))]
+
+
+ITER_HOOK = C.CFUNCTYPE(None, C.c_int, C.c_void_p)
+
+_core = None
+_solver = None
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Load both native libraries.  Fails loudly when they are missing: there is no fallback path."""
+    global _core, _solver
+    if _core is not None:
+        return _core, _solver
+    try:
+        # When torch is (or will be) in the process its bundled HIP runtime (soname libamdhip64.so.7) must be
+        # the one and only runtime, so it has to be loaded before ours resolves the same soname.
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover
+        pass
+    p_core = os.path.join(HERE, "liblbfgsx.so")
+    p_sol = os.path.join(HERE, "liblbfgsx_solver.so")
+    for p in (p_core, p_sol):
+        if not os.path.exists(p):
+            raise NativeLibraryMissing(
+                "%s not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()')" % p)
+    core = C.CDLL(p_core, mode=C.RTLD_GLOBAL)
+    sol = C.CDLL(p_sol, mode=C.RTLD_GLOBAL)
+    vp, i64, dbl, i32 = C.c_void_p, C.c_int64, C.c_double, C.c_int
+    pd = C.POINTER(C.c_double)
+
+    def sig(lib, name, res, *args):
+        f = getattr(lib, name)
+        f.restype = res
+        f.argtypes = list(args)
+        return f
+
+    sig(core, "lbfgsx_last_error", C.c_char_p)
+    sig(core, "lbfgsx_version", C.c_char_p)
+    sig(core, "lbfgsx_device_count", i32)
+    sig(core, "lbfgsx_create", i32, C.POINTER(vp), i32, i64, i32, i32, i32)
+    sig(core, "lbfgsx_destroy", None, vp)
+    sig(core, "lbfgsx_set_stream", i32, vp, vp)
+    sig(core, "lbfgsx_sync", i32, vp)
+    sig(core, "lbfgsx_n", i64, vp)
+    sig(core, "lbfgsx_vec", vp, vp, i32)
+    sig(core, "lbfgsx_upload", i32, vp, i32, vp)
+    sig(core, "lbfgsx_download", i32, vp, i32, vp)
+    sig(core, "lbfgsx_gather", i32, vp, i32, i64, pd)
+    sig(core, "lbfgsx_gen_diag_quad", i32, vp, dbl, C.c_uint64)
+    sig(core, "lbfgsx_gen_rosen_x0", i32, vp, C.c_uint64)
+    sig(core, "lbfgsx_fill", i32, vp, i32, dbl)
+    sig(core, "lbfgsx_bfgs_reset", i32, vp)
+    sig(core, "lbfgsx_bfgs_ncorr", i32, vp)
+    sig(core, "lbfgsx_bfgs_theta", dbl, vp)
+    sig(core, "lbfgsx_bfgs_add_correction_host", i32, vp, vp, vp)
+    sig(core, "lbfgsx_apply_Hv", i32, vp, i32, dbl, pd)
+    sig(core, "lbfgsx_eval", i32, vp, i32, pd, pd, pd)
+    sig(core, "lbfgsx_norms", i32, vp, pd, pd)
+    sig(core, "lbfgsx_ls_begin", i32, vp)
+    sig(core, "lbfgsx_trial", i32, vp, i32, dbl, pd, pd)
+    sig(core, "lbfgsx_trial_point", i32, vp, dbl)
+    sig(core, "lbfgsx_trial_dg", i32, vp, pd)
+    sig(core, "lbfgsx_ls_keep_trial_as_lo", i32, vp)
+    sig(core, "lbfgsx_ls_end", i32, vp, i32)
+    sig(core, "lbfgsx_post_linesearch", i32, vp, pd, pd, pd, pd)
+    sig(core, "lbfgsx_commit_correction", i32, vp)
+    sig(core, "lbfgsx_timing_enable", i32, vp, i32)
+    sig(core, "lbfgsx_timing_read", i32, vp, pd, C.POINTER(i64), pd, C.POINTER(i64))
+    sig(core, "lbfgsx_stream_probe", i32, vp, i32, pd, pd)
+
+    sig(sol, "lbfgsx_solver_create", i32, C.POINTER(vp), i32, i32, i32, C.POINTER(Params), i32)
+    sig(sol, "lbfgsx_solver_create_error", C.c_char_p)
+    sig(sol, "lbfgsx_solver_destroy", None, vp)
+    sig(sol, "lbfgsx_solver_prepare", i32, vp, i64)
+    sig(sol, "lbfgsx_solver_ctx", vp, vp)
+    sig(sol, "lbfgsx_solver_set_iteration_hook", i32, vp, ITER_HOOK, vp)
+    sig(sol, "lbfgsx_solver_minimize", i32, vp, i32, i64, vp, vp, vp, vp, vp, C.POINTER(Trace), C.POINTER(Result))
+    _core, _solver = core, sol
+    return core, sol
+
+
+def last_error():
+    core, _ = load()
+    return core.lbfgsx_last_error().decode()
+
+
+_EXC = {E_INVALID: ValueError, E_LOGIC: ArithmeticError, E_RUNTIME: RuntimeError, E_HIP: RuntimeError,
+        E_NOGPU: RuntimeError}
+
+
+def check(rc, msg=None):
+    if rc != 0:
+        raise _EXC.get(rc, RuntimeError)(msg if msg is not None else last_error())

@@ -1,0 +1,104 @@
+// lbfgspp_amd/csrc/ctx.hpp -- host-side state of one solver context (internal to liblbfgsx.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/lbfgsx.h"
+#include "reduce.cuh"
+
+namespace lbfgsx {
+
+void set_error(const std::string& msg);
+
+#define LBFGSX_HIP(expr)                                                                      \
+    do                                                                                        \
+    {                                                                                         \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+        {                                                                                     \
+            lbfgsx::set_error(std::string(#expr) + ": " + hipGetErrorString(e_));            \
+            return LBFGSX_E_HIP;                                                              \
+        }                                                                                     \
+    } while (0)
+
+// indices into the device scalar array (element type T)
+struct ScLayout
+{
+    int m;
+    int ys(int col) const { return col; }                    // s.y of physical column col   [m+1]
+    int theta(int col) const { return (m + 1) + col; }       // y.y / s.y of that column     [m+1]
+    int one() const { return 2 * (m + 1); }                  // constant 1
+    int dot(int k) const { return 2 * (m + 1) + 1 + k; }     // two-loop dot products        [2m+2]
+    int out(int k) const { return 2 * (m + 1) + 1 + (2 * m + 2) + k; }  // kernel outputs     [16]
+    int total() const { return out(16); }
+};
+
+struct EventPair
+{
+    hipEvent_t a, b;
+};
+
+}  // namespace lbfgsx
+
+struct lbfgsx_ctx
+{
+    int dtype = LBFGSX_F64;
+    size_t esz = 8;
+    int64_t n = 0, ld = 0;
+    int m = 0, device = 0, flags = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+
+    // three (x, g) points + direction + objective data
+    void* xb[3] = {nullptr, nullptr, nullptr};
+    void* gb[3] = {nullptr, nullptr, nullptr};
+    int cur = 0, xp = 0, lo = 0, trial = 1;
+    void* d = nullptr;
+    void* a = nullptr;
+    void* b = nullptr;
+
+    // history: (m+1) physical columns each
+    void* S = nullptr;
+    void* Y = nullptr;
+    std::vector<int> phys;  // logical slot (reference storage order, BFGSMat.h:83) -> physical column
+    int spare = 0;
+    int ncorr = 0, ptr = 0;
+    bool pending = false;     // spare column holds an uncommitted (s, y) pair
+    double theta = 1.0;       // host mirror (BFGSMat.h:36)
+    double pend_sy = 0.0, pend_yy = 0.0;
+    std::vector<double> ys_host;  // per logical slot
+
+    // scalars
+    lbfgsx::ScLayout sl;
+    void* sc = nullptr;      // device, T[sl.total()]
+    void* hout = nullptr;    // pinned host staging
+    lbfgsx::RedWs ws;
+    int grid_cap = 2048;
+
+    // L-BFGS-B work set (allocated with LBFGSX_FLAG_BOUNDED) lives in lbfgsb part
+    void* lb = nullptr;
+    void* ub = nullptr;
+    void* xcp = nullptr;
+    struct lbfgsb_state* bstate = nullptr;
+
+    // instrumentation
+    bool timing = false;
+    std::vector<lbfgsx::EventPair> ev_twoloop, ev_hv;
+    void* gather_tmp = nullptr;
+    int64_t gather_cap = 0;
+
+    void* col(void* base, int c) const { return static_cast<char*>(base) + size_t(c) * size_t(ld) * esz; }
+    int grid_for(int64_t nelem) const
+    {
+        const int64_t w = (dtype == LBFGSX_F64) ? 2 : 4;
+        int64_t blocks = (nelem / w + lbfgsx::kBlock - 1) / lbfgsx::kBlock;
+        if (blocks < 1)
+            blocks = 1;
+        if (blocks > grid_cap)
+            blocks = grid_cap;
+        return int(blocks);
+    }
+};

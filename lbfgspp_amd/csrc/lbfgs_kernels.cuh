@@ -1,0 +1,367 @@
+// lbfgspp_amd/csrc/lbfgs_kernels.cuh -- CDNA4 kernels of the unconstrained L-BFGS hot path.
+//
+// Kernel map:
+//   K0 k_eval        f(x), g(x), |g|^2, |x|^2                          LBFGS.h:91-92,100
+//   K1 k_twoloop     one fused "axpy(prev) + dot(next)" step of the two-loop recursion
+//                                                                     BFGSMat.h:276-302
+//   K2 k_trial       x = xp + step*d ; f,g at x ; dg = g.d             LineSearchMoreThuente.h:412-414,
+//                                                                     LineSearchNocedalWright.h:146-148,219-221
+//   K3 k_post        s = x-xp, y = g-gp written into the spare history column;
+//                    |g|^2, |x|^2, s.y, y.y                            LBFGS.h:130,137,159-161; BFGSMat.h:85-92
+// All element-wise arithmetic is IEEE without contraction (the TU is built with -ffp-contract=off),
+// mirroring the statement-by-statement evaluation of the reference's Eigen expressions.
+#pragma once
+#include "reduce.cuh"
+
+namespace lbfgsx {
+
+enum { OBJ_DIAG_QUAD = 0, OBJ_EXT_ROSENBROCK = 1 };
+
+// ---------------------------------------------------------------- built-in device objectives
+// Each objective processes one 16-byte pack (2 doubles / 4 floats, i.e. whole Rosenbrock pairs).
+template <class T>
+struct ObjQuad  // f = 0.5*sum (a_i x_i - b_i)^2
+{
+    const T* a;
+    const T* b;
+    template <class A>
+    __device__ __forceinline__ void pack(int64_t vi, const Pack<T>& x, Pack<T>& g, A& fx) const
+    {
+        const Pack<T> pa = ldv(a, vi), pb = ldv(b, vi);
+#pragma unroll
+        for (int k = 0; k < Vec16<T>::W; k++)
+        {
+            const T r = pa.e[k] * x.e[k] - pb.e[k];
+            g.e[k] = pa.e[k] * r;
+            fx.add(r * r);
+        }
+    }
+    __device__ __forceinline__ T finish(T sum) const { return T(0.5) * sum; }
+    // scalar tail (n not a multiple of the pack width)
+    template <class A>
+    __device__ __forceinline__ void tail(int64_t i, int64_t, const T* x, T* g, A& fx) const
+    {
+        const T r = a[i] * x[i] - b[i];
+        g[i] = a[i] * r;
+        fx.add(r * r);
+    }
+};
+
+template <class T>
+struct ObjRosen  // pairs (x[2k], x[2k+1]) in the reference's example form (example-rosenbrock.cpp:18-25)
+{
+    template <class A>
+    __device__ __forceinline__ void pack(int64_t, const Pack<T>& x, Pack<T>& g, A& fx) const
+    {
+#pragma unroll
+        for (int k = 0; k < Vec16<T>::W; k += 2)
+        {
+            const T t1 = T(1) - x.e[k];
+            const T t2 = T(10) * (x.e[k + 1] - x.e[k] * x.e[k]);
+            g.e[k + 1] = T(20) * t2;
+            g.e[k] = T(-2) * (x.e[k] * g.e[k + 1] + t1);
+            fx.add(t1 * t1 + t2 * t2);
+        }
+    }
+    __device__ __forceinline__ T finish(T sum) const { return sum; }
+    template <class A>
+    __device__ __forceinline__ void tail(int64_t i, int64_t n, const T* x, T* g, A& fx) const
+    {
+        if ((i & 1) == 0 && i + 1 < n)
+        {
+            const T t1 = T(1) - x[i];
+            const T t2 = T(10) * (x[i + 1] - x[i] * x[i]);
+            g[i + 1] = T(20) * t2;
+            g[i] = T(-2) * (x[i] * g[i + 1] + t1);
+            fx.add(t1 * t1 + t2 * t2);
+        }
+    }
+};
+
+// ---------------------------------------------------------------- K0: evaluate at x
+// out[0] = f(x), out[1] = g.g, out[2] = x.x
+template <class T, class OBJ>
+__global__ void __launch_bounds__(kBlock) k_eval(const T* __restrict__ x, T* __restrict__ g, int64_t n, OBJ obj,
+                                                 RedWs ws, T* __restrict__ out)
+{
+    typedef typename AccOf<T>::type A;
+    constexpr int W = Vec16<T>::W;
+    A acc[3];
+    const int64_t nv = n / W;
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t vi = int64_t(blockIdx.x) * kBlock + threadIdx.x; vi < nv; vi += stride)
+    {
+        const Pack<T> px = ldv(x, vi);
+        Pack<T> pg;
+        obj.pack(vi, px, pg, acc[0]);
+        stv(g, vi, pg);
+#pragma unroll
+        for (int k = 0; k < W; k++)
+        {
+            acc[1].add_prod(pg.e[k], pg.e[k]);
+            acc[2].add_prod(px.e[k], px.e[k]);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int64_t i = nv * W; i < n; i++)
+        {
+            obj.tail(i, n, x, g, acc[0]);
+            acc[1].add_prod(g[i], g[i]);
+            acc[2].add_prod(x[i], x[i]);
+        }
+    if (grid_reduce<3>(acc, ws) && threadIdx.x == 0)
+    {
+        out[0] = obj.finish(T(acc[0].value()));
+        out[1] = T(acc[1].value());
+        out[2] = T(acc[2].value());
+    }
+}
+
+// ---------------------------------------------------------------- K2: line-search trial
+// x = xp + step*d ; g = grad f(x) ; out[0] = f(x), out[1] = g.d
+template <class T, class OBJ>
+__global__ void __launch_bounds__(kBlock) k_trial(const T* __restrict__ xp, const T* __restrict__ d, T step,
+                                                  T* __restrict__ x, T* __restrict__ g, int64_t n, OBJ obj,
+                                                  RedWs ws, T* __restrict__ out)
+{
+    typedef typename AccOf<T>::type A;
+    constexpr int W = Vec16<T>::W;
+    A acc[2];
+    const int64_t nv = n / W;
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t vi = int64_t(blockIdx.x) * kBlock + threadIdx.x; vi < nv; vi += stride)
+    {
+        const Pack<T> pxp = ldv(xp, vi), pd = ldv(d, vi);
+        Pack<T> px, pg;
+#pragma unroll
+        for (int k = 0; k < W; k++)
+            px.e[k] = pxp.e[k] + step * pd.e[k];
+        obj.pack(vi, px, pg, acc[0]);
+        stv(x, vi, px);
+        stv(g, vi, pg);
+#pragma unroll
+        for (int k = 0; k < W; k++)
+            acc[1].add_prod(pg.e[k], pd.e[k]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+    {
+        for (int64_t i = nv * W; i < n; i++)
+            x[i] = xp[i] + step * d[i];
+        for (int64_t i = nv * W; i < n; i++)
+        {
+            obj.tail(i, n, x, g, acc[0]);
+            acc[1].add_prod(g[i], d[i]);
+        }
+    }
+    if (grid_reduce<2>(acc, ws) && threadIdx.x == 0)
+    {
+        out[0] = obj.finish(T(acc[0].value()));
+        out[1] = T(acc[1].value());
+    }
+}
+
+// generic-functor path: x = xp + step*d only (user kernel evaluates f,g), and g.d
+template <class T>
+__global__ void __launch_bounds__(kBlock) k_axpy_point(const T* __restrict__ xp, const T* __restrict__ d, T step,
+                                                       T* __restrict__ x, int64_t n)
+{
+    constexpr int W = Vec16<T>::W;
+    const int64_t nv = n / W;
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t vi = int64_t(blockIdx.x) * kBlock + threadIdx.x; vi < nv; vi += stride)
+    {
+        const Pack<T> pxp = ldv(xp, vi), pd = ldv(d, vi);
+        Pack<T> px;
+#pragma unroll
+        for (int k = 0; k < W; k++)
+            px.e[k] = pxp.e[k] + step * pd.e[k];
+        stv(x, vi, px);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int64_t i = nv * W; i < n; i++)
+            x[i] = xp[i] + step * d[i];
+}
+
+// out[0] = u.v ; if w != nullptr also out[1] = w.w
+template <class T>
+__global__ void __launch_bounds__(kBlock) k_dot(const T* __restrict__ u, const T* __restrict__ v,
+                                                const T* __restrict__ w, int64_t n, RedWs ws,
+                                                T* __restrict__ out)
+{
+    typedef typename AccOf<T>::type A;
+    constexpr int W = Vec16<T>::W;
+    A acc[2];
+    const int64_t nv = n / W;
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t vi = int64_t(blockIdx.x) * kBlock + threadIdx.x; vi < nv; vi += stride)
+    {
+        const Pack<T> pu = ldv(u, vi), pv = ldv(v, vi);
+#pragma unroll
+        for (int k = 0; k < W; k++)
+            acc[0].add_prod(pu.e[k], pv.e[k]);
+        if (w)
+        {
+            const Pack<T> pw = ldv(w, vi);
+#pragma unroll
+            for (int k = 0; k < W; k++)
+                acc[1].add_prod(pw.e[k], pw.e[k]);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int64_t i = nv * W; i < n; i++)
+        {
+            acc[0].add_prod(u[i], v[i]);
+            if (w)
+                acc[1].add_prod(w[i], w[i]);
+        }
+    if (grid_reduce<2>(acc, ws) && threadIdx.x == 0)
+    {
+        out[0] = T(acc[0].value());
+        out[1] = T(acc[1].value());
+    }
+}
+
+// ---------------------------------------------------------------- K3: after the line search
+// s = x - xp, y = g - gp (into the spare history column); out = {g.g, x.x, s.y, y.y}; additionally
+// ys_slot = s.y and theta_slot = y.y / s.y are stored for the column (BFGSMat.h:89-92), so a later
+// commit is a pure index rotation.
+template <class T>
+__global__ void __launch_bounds__(kBlock) k_post(const T* __restrict__ x, const T* __restrict__ xp,
+                                                 const T* __restrict__ g, const T* __restrict__ gp,
+                                                 T* __restrict__ s, T* __restrict__ y, int64_t n, RedWs ws,
+                                                 T* __restrict__ out, T* __restrict__ ys_slot,
+                                                 T* __restrict__ theta_slot)
+{
+    typedef typename AccOf<T>::type A;
+    constexpr int W = Vec16<T>::W;
+    A acc[4];
+    const int64_t nv = n / W;
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t vi = int64_t(blockIdx.x) * kBlock + threadIdx.x; vi < nv; vi += stride)
+    {
+        const Pack<T> px = ldv(x, vi), pxp = ldv(xp, vi), pg = ldv(g, vi), pgp = ldv(gp, vi);
+        Pack<T> ps, py;
+#pragma unroll
+        for (int k = 0; k < W; k++)
+        {
+            ps.e[k] = px.e[k] - pxp.e[k];
+            py.e[k] = pg.e[k] - pgp.e[k];
+            acc[0].add_prod(pg.e[k], pg.e[k]);
+            acc[1].add_prod(px.e[k], px.e[k]);
+            acc[2].add_prod(ps.e[k], py.e[k]);
+            acc[3].add_prod(py.e[k], py.e[k]);
+        }
+        stv(s, vi, ps);
+        stv(y, vi, py);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int64_t i = nv * W; i < n; i++)
+        {
+            const T si = x[i] - xp[i], yi = g[i] - gp[i];
+            s[i] = si;
+            y[i] = yi;
+            acc[0].add_prod(g[i], g[i]);
+            acc[1].add_prod(x[i], x[i]);
+            acc[2].add_prod(si, yi);
+            acc[3].add_prod(yi, yi);
+        }
+    if (grid_reduce<4>(acc, ws) && threadIdx.x == 0)
+    {
+        const T sy = T(acc[2].value()), yy = T(acc[3].value());
+        out[0] = T(acc[0].value());
+        out[1] = T(acc[1].value());
+        out[2] = sy;
+        out[3] = yy;
+        *ys_slot = sy;
+        *theta_slot = yy / sy;
+    }
+}
+
+// ---------------------------------------------------------------- K1: two-loop recursion step
+// One launch = update q with the previous step's coefficient and reduce the next dot product.
+// The coefficients are recomputed from the raw device-resident scalars by every thread (uniform
+// scalar loads), so the 2c+1 launches of apply_Hv are enqueued back to back with no host round trip.
+enum { TL_INIT = 0, TL_SUB = 1, TL_SUBDIV = 2, TL_ADD = 3 };
+
+struct TwoLoopArgs
+{
+    int i_num;    // sc[i_num] / sc[i_den] = alpha_j            (TL_SUB, TL_SUBDIV, TL_ADD)
+    int i_den;    // ys_j
+    int i_num2;   // sc[i_num2] / sc[i_den] = beta             (TL_ADD)
+    int i_theta;  // TL_SUBDIV: q /= sc[i_theta]
+    int i_out;    // where the reduced dot goes
+};
+
+template <class T, int MODE>
+__global__ void __launch_bounds__(kBlock) k_twoloop(T* __restrict__ q, const T* __restrict__ vin, T a,
+                                                    const T* __restrict__ u, const T* __restrict__ w, int64_t n,
+                                                    T* __restrict__ sc, TwoLoopArgs args, RedWs ws)
+{
+    typedef typename AccOf<T>::type A;
+    constexpr int W = Vec16<T>::W;
+    T coef = T(0), theta = T(1);
+    if (MODE == TL_SUB || MODE == TL_SUBDIV)
+        coef = sc[args.i_num] / sc[args.i_den];                                    // alpha_j (BFGSMat.h:288)
+    if (MODE == TL_ADD)
+        coef = sc[args.i_num] / sc[args.i_den] - sc[args.i_num2] / sc[args.i_den];  // alpha_j - beta (:298-299)
+    if (MODE == TL_SUBDIV)
+        theta = sc[args.i_theta];
+
+    A acc[1];
+    const int64_t nv = n / W;
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t vi = int64_t(blockIdx.x) * kBlock + threadIdx.x; vi < nv; vi += stride)
+    {
+        Pack<T> pq;
+        if (MODE == TL_INIT)
+        {
+            const Pack<T> pv = ldv(vin, vi);
+#pragma unroll
+            for (int k = 0; k < W; k++)
+                pq.e[k] = a * pv.e[k];  // res = a*v (BFGSMat.h:283)
+        }
+        else
+        {
+            pq = ldv(q, vi);
+            const Pack<T> pu = ldv(u, vi);
+#pragma unroll
+            for (int k = 0; k < W; k++)
+            {
+                if (MODE == TL_ADD)
+                    pq.e[k] = pq.e[k] + coef * pu.e[k];  // res += (alpha-beta)*s_j (:299)
+                else
+                    pq.e[k] = pq.e[k] - coef * pu.e[k];  // res -= alpha*y_j (:289)
+                if (MODE == TL_SUBDIV)
+                    pq.e[k] = pq.e[k] / theta;  // res /= theta (:293)
+            }
+        }
+        stv(q, vi, pq);
+        const Pack<T> pw = ldv(w, vi);
+#pragma unroll
+        for (int k = 0; k < W; k++)
+            acc[0].add_prod(pw.e[k], pq.e[k]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int64_t i = nv * W; i < n; i++)
+        {
+            T qi;
+            if (MODE == TL_INIT)
+                qi = a * vin[i];
+            else
+            {
+                qi = q[i];
+                if (MODE == TL_ADD)
+                    qi = qi + coef * u[i];
+                else
+                    qi = qi - coef * u[i];
+                if (MODE == TL_SUBDIV)
+                    qi = qi / theta;
+            }
+            q[i] = qi;
+            acc[0].add_prod(w[i], qi);
+        }
+    if (grid_reduce<1>(acc, ws) && threadIdx.x == 0)
+        sc[args.i_out] = T(acc[0].value());
+}
+
+}  // namespace lbfgsx

@@ -1,0 +1,802 @@
+// lbfgspp_amd/csrc/lbfgsx.hip -- C ABI (include/lbfgsx.h) over the CDNA4 kernels: context, history
+// bookkeeping, unconstrained L-BFGS statements.  Built with hipcc --offload-arch=gfx950 -ffp-contract=off.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "ctx.hpp"
+#include "lbfgs_kernels.cuh"
+
+namespace lbfgsx {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+
+#define DISPATCH_T(c, ...)            \
+    do                                \
+    {                                 \
+        if ((c)->dtype == LBFGSX_F64) \
+        {                             \
+            typedef double T;         \
+            __VA_ARGS__               \
+        }                             \
+        else                          \
+        {                             \
+            typedef float T;          \
+            __VA_ARGS__               \
+        }                             \
+    } while (0)
+
+template <class T>
+static inline T* P(void* p) { return static_cast<T*>(p); }
+
+// ---- small utility kernels -------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ double u01(uint64_t i, uint64_t seed)
+{
+    return double(splitmix64(i + seed * 0x9E3779B97F4A7C15ull) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+template <class T>
+__global__ void k_gen_quad(T* a, T* b, int64_t n, double kappa, uint64_t seed)
+{
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride)
+    {
+        const double ai = (n > 1) ? 1.0 + (kappa - 1.0) * (double(i) / double(n - 1)) : 1.0;
+        a[i] = T(ai);
+        b[i] = T(ai * (4.0 * u01(uint64_t(i), seed) - 2.0));
+    }
+}
+template <class T>
+__global__ void k_gen_rosen(T* x, int64_t n, uint64_t seed)
+{
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride)
+        x[i] = T(((i & 1) ? 1.0 : -1.2) + 0.4 * u01(uint64_t(i), seed));
+}
+template <class T>
+__global__ void k_fill(T* x, int64_t n, T v)
+{
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride)
+        x[i] = v;
+}
+template <class T>
+__global__ void k_gather(const T* x, int64_t nsamp, int64_t stride_e, double* out)
+{
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t k = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; k < nsamp; k += stride)
+        out[k] = double(x[k * stride_e]);
+}
+template <class T>
+__global__ void __launch_bounds__(kBlock) k_copy(const T* __restrict__ x, T* __restrict__ y, int64_t n)
+{
+    constexpr int W = Vec16<T>::W;
+    const int64_t nv = n / W, stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t vi = int64_t(blockIdx.x) * kBlock + threadIdx.x; vi < nv; vi += stride)
+        stv(y, vi, ldv(x, vi));
+}
+template <class T>
+__global__ void __launch_bounds__(kBlock) k_triad(const T* __restrict__ x, const T* __restrict__ z, T s,
+                                                  T* __restrict__ y, int64_t n)
+{
+    constexpr int W = Vec16<T>::W;
+    const int64_t nv = n / W, stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t vi = int64_t(blockIdx.x) * kBlock + threadIdx.x; vi < nv; vi += stride)
+    {
+        const Pack<T> px = ldv(x, vi), pz = ldv(z, vi);
+        Pack<T> py;
+#pragma unroll
+        for (int k = 0; k < W; k++)
+            py.e[k] = px.e[k] + s * pz.e[k];
+        stv(y, vi, py);
+    }
+}
+
+// read k scalars (type T) starting at device index idx into doubles; synchronises the stream
+template <class T>
+static int fetch_scalars(lbfgsx_ctx* c, int idx, int k, double* out)
+{
+    LBFGSX_HIP(hipMemcpyAsync(c->hout, P<T>(c->sc) + idx, sizeof(T) * size_t(k), hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    const T* h = static_cast<const T*>(c->hout);
+    for (int i = 0; i < k; i++)
+        out[i] = double(h[i]);
+    return LBFGSX_OK;
+}
+
+static void* vec_ptr(lbfgsx_ctx* c, int which)
+{
+    switch (which)
+    {
+    case LBFGSX_VEC_X: return c->xb[c->cur];
+    case LBFGSX_VEC_G: return c->gb[c->cur];
+    case LBFGSX_VEC_XP: return c->xb[c->xp];
+    case LBFGSX_VEC_GP: return c->gb[c->xp];
+    case LBFGSX_VEC_D: return c->d;
+    case LBFGSX_VEC_XT: return c->xb[c->trial];
+    case LBFGSX_VEC_GT: return c->gb[c->trial];
+    case LBFGSX_VEC_A: return c->a;
+    case LBFGSX_VEC_B: return c->b;
+    case LBFGSX_VEC_LB: return c->lb;
+    case LBFGSX_VEC_UB: return c->ub;
+    case LBFGSX_VEC_XCP: return c->xcp;
+    default: return nullptr;
+    }
+}
+
+static int third_point(int p, int q)
+{
+    for (int k = 0; k < 3; k++)
+        if (k != p && k != q)
+            return k;
+    return 0;
+}
+
+}  // namespace lbfgsx
+
+using namespace lbfgsx;
+
+extern "C" {
+
+const char* lbfgsx_last_error(void) { return g_err.c_str(); }
+const char* lbfgsx_version(void) { return "lbfgsx 0.1 (gfx950)"; }
+
+int lbfgsx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+int lbfgsx_create(lbfgsx_ctx** out, int dtype, int64_t n, int m, int device, int flags)
+{
+    if (!out || n <= 0 || m <= 0 || (dtype != LBFGSX_F64 && dtype != LBFGSX_F32))
+    {
+        set_error("lbfgsx_create: invalid argument");
+        return LBFGSX_E_INVALID;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    {
+        set_error("lbfgsx_create: no HIP device available (this library has no CPU fallback)");
+        return LBFGSX_E_NOGPU;
+    }
+    if (device < 0 || device >= ndev)
+    {
+        set_error("lbfgsx_create: device index out of range");
+        return LBFGSX_E_INVALID;
+    }
+    LBFGSX_HIP(hipSetDevice(device));
+    lbfgsx_ctx* c = new lbfgsx_ctx();
+    c->dtype = dtype;
+    c->esz = (dtype == LBFGSX_F64) ? 8 : 4;
+    c->n = n;
+    c->ld = (n + 63) / 64 * 64;
+    c->m = m;
+    c->device = device;
+    c->flags = flags;
+    c->sl.m = m;
+    if (const char* e = getenv("LBFGSX_GRID_CAP"))
+        c->grid_cap = atoi(e) > 0 ? atoi(e) : c->grid_cap;
+    if (c->grid_cap > 8192)
+        c->grid_cap = 8192;
+    LBFGSX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+    const size_t vbytes = size_t(c->ld) * c->esz;
+    for (int k = 0; k < 3; k++)
+    {
+        LBFGSX_HIP(hipMalloc(&c->xb[k], vbytes));
+        LBFGSX_HIP(hipMalloc(&c->gb[k], vbytes));
+    }
+    LBFGSX_HIP(hipMalloc(&c->d, vbytes));
+    LBFGSX_HIP(hipMalloc(&c->a, vbytes));
+    LBFGSX_HIP(hipMalloc(&c->b, vbytes));
+    LBFGSX_HIP(hipMalloc(&c->S, vbytes * size_t(m + 1)));
+    LBFGSX_HIP(hipMalloc(&c->Y, vbytes * size_t(m + 1)));
+    LBFGSX_HIP(hipMalloc(&c->sc, sizeof(double) * size_t(c->sl.total())));
+    LBFGSX_HIP(hipMemset(c->sc, 0, sizeof(double) * size_t(c->sl.total())));
+    LBFGSX_HIP(hipHostMalloc(&c->hout, sizeof(double) * 64, hipHostMallocDefault));
+    c->ws.maxGrid = 8192;
+    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&c->ws.partials), sizeof(double) * size_t(kMaxRed) * 2 * size_t(c->ws.maxGrid)));
+    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&c->ws.ticket), sizeof(unsigned) * 4));
+    LBFGSX_HIP(hipMemset(c->ws.ticket, 0, sizeof(unsigned) * 4));
+    c->phys.assign(size_t(m), 0);
+    c->ys_host.assign(size_t(m), 0.0);
+    *out = c;
+    int rc = lbfgsx_bfgs_reset(c);
+    if (rc != LBFGSX_OK)
+        return rc;
+    if (flags & LBFGSX_FLAG_BOUNDED)
+    {
+        LBFGSX_HIP(hipMalloc(&c->lb, vbytes));
+        LBFGSX_HIP(hipMalloc(&c->ub, vbytes));
+        LBFGSX_HIP(hipMalloc(&c->xcp, vbytes));
+    }
+    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    return LBFGSX_OK;
+}
+
+void lbfgsx_destroy(lbfgsx_ctx* c)
+{
+    if (!c)
+        return;
+    (void) hipSetDevice(c->device);
+    (void) hipStreamSynchronize(c->stream);
+    for (int k = 0; k < 3; k++)
+    {
+        (void) hipFree(c->xb[k]);
+        (void) hipFree(c->gb[k]);
+    }
+    (void) hipFree(c->d);
+    (void) hipFree(c->a);
+    (void) hipFree(c->b);
+    (void) hipFree(c->S);
+    (void) hipFree(c->Y);
+    (void) hipFree(c->sc);
+    (void) hipHostFree(c->hout);
+    (void) hipFree(c->ws.partials);
+    (void) hipFree(c->ws.ticket);
+    (void) hipFree(c->lb);
+    (void) hipFree(c->ub);
+    (void) hipFree(c->xcp);
+    (void) hipFree(c->gather_tmp);
+    for (auto& e : c->ev_twoloop)
+    {
+        (void) hipEventDestroy(e.a);
+        (void) hipEventDestroy(e.b);
+    }
+    for (auto& e : c->ev_hv)
+    {
+        (void) hipEventDestroy(e.a);
+        (void) hipEventDestroy(e.b);
+    }
+    if (c->own_stream)
+        (void) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int lbfgsx_set_stream(lbfgsx_ctx* c, void* hip_stream)
+{
+    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    if (c->own_stream)
+        LBFGSX_HIP(hipStreamDestroy(c->stream));
+    c->stream = static_cast<hipStream_t>(hip_stream);
+    c->own_stream = false;
+    return LBFGSX_OK;
+}
+
+int lbfgsx_sync(lbfgsx_ctx* c)
+{
+    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    return LBFGSX_OK;
+}
+
+int64_t lbfgsx_n(const lbfgsx_ctx* c) { return c->n; }
+void* lbfgsx_vec(lbfgsx_ctx* c, int which) { return vec_ptr(c, which); }
+
+int lbfgsx_upload(lbfgsx_ctx* c, int which, const void* host)
+{
+    void* p = vec_ptr(c, which);
+    if (!p || !host)
+    {
+        set_error("lbfgsx_upload: unknown vector or null host pointer");
+        return LBFGSX_E_INVALID;
+    }
+    LBFGSX_HIP(hipMemcpyAsync(p, host, size_t(c->n) * c->esz, hipMemcpyHostToDevice, c->stream));
+    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    return LBFGSX_OK;
+}
+
+int lbfgsx_download(lbfgsx_ctx* c, int which, void* host)
+{
+    void* p = vec_ptr(c, which);
+    if (!p || !host)
+    {
+        set_error("lbfgsx_download: unknown vector or null host pointer");
+        return LBFGSX_E_INVALID;
+    }
+    LBFGSX_HIP(hipMemcpyAsync(host, p, size_t(c->n) * c->esz, hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    return LBFGSX_OK;
+}
+
+int lbfgsx_gather(lbfgsx_ctx* c, int which, int64_t stride, double* host)
+{
+    void* p = vec_ptr(c, which);
+    if (!p || !host || stride < 1)
+    {
+        set_error("lbfgsx_gather: invalid argument");
+        return LBFGSX_E_INVALID;
+    }
+    const int64_t nsamp = (c->n + stride - 1) / stride;
+    if (nsamp > c->gather_cap)
+    {
+        if (c->gather_tmp)
+            LBFGSX_HIP(hipFree(c->gather_tmp));
+        LBFGSX_HIP(hipMalloc(&c->gather_tmp, sizeof(double) * size_t(nsamp)));
+        c->gather_cap = nsamp;
+    }
+    const int grid = int(std::min<int64_t>((nsamp + 255) / 256, 1024));
+    DISPATCH_T(c, { hipLaunchKernelGGL(k_gather<T>, dim3(grid), dim3(256), 0, c->stream, P<T>(p), nsamp, stride,
+                                       static_cast<double*>(c->gather_tmp)); });
+    LBFGSX_HIP(hipMemcpyAsync(host, c->gather_tmp, sizeof(double) * size_t(nsamp), hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    return LBFGSX_OK;
+}
+
+int lbfgsx_gen_diag_quad(lbfgsx_ctx* c, double kappa, uint64_t seed)
+{
+    DISPATCH_T(c, { hipLaunchKernelGGL(k_gen_quad<T>, dim3(2048), dim3(256), 0, c->stream, P<T>(c->a), P<T>(c->b),
+                                       c->n, kappa, seed); });
+    LBFGSX_HIP(hipGetLastError());
+    return LBFGSX_OK;
+}
+
+int lbfgsx_gen_rosen_x0(lbfgsx_ctx* c, uint64_t seed)
+{
+    DISPATCH_T(c, { hipLaunchKernelGGL(k_gen_rosen<T>, dim3(2048), dim3(256), 0, c->stream, P<T>(c->xb[c->cur]),
+                                       c->n, seed); });
+    LBFGSX_HIP(hipGetLastError());
+    return LBFGSX_OK;
+}
+
+int lbfgsx_fill(lbfgsx_ctx* c, int which, double value)
+{
+    void* p = vec_ptr(c, which);
+    if (!p)
+    {
+        set_error("lbfgsx_fill: unknown vector");
+        return LBFGSX_E_INVALID;
+    }
+    DISPATCH_T(c, { hipLaunchKernelGGL(k_fill<T>, dim3(2048), dim3(256), 0, c->stream, P<T>(p), c->n, T(value)); });
+    LBFGSX_HIP(hipGetLastError());
+    return LBFGSX_OK;
+}
+
+// ---- BFGSMat ---------------------------------------------------------------------------------------
+int lbfgsx_bfgs_reset(lbfgsx_ctx* c)
+{
+    // BFGSMat.h:61-78
+    c->theta = 1.0;
+    c->ncorr = 0;
+    c->ptr = c->m;
+    c->pending = false;
+    for (int j = 0; j < c->m; j++)
+        c->phys[size_t(j)] = j;
+    c->spare = c->m;
+    // sc[one] = 1
+    DISPATCH_T(c, {
+        T one = T(1);
+        LBFGSX_HIP(hipMemcpyAsync(P<T>(c->sc) + c->sl.one(), &one, sizeof(T), hipMemcpyHostToDevice, c->stream));
+        LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    });
+    return LBFGSX_OK;
+}
+
+int lbfgsx_bfgs_ncorr(const lbfgsx_ctx* c) { return c->ncorr; }
+double lbfgsx_bfgs_theta(const lbfgsx_ctx* c) { return c->theta; }
+
+int lbfgsx_commit_correction(lbfgsx_ctx* c)
+{
+    if (!c->pending)
+    {
+        set_error("lbfgsx_commit_correction: no pending (s, y) pair");
+        return LBFGSX_E_LOGIC;
+    }
+    // BFGSMat.h:83-97 -- the pair already sits in the spare column, so adding it is an index rotation:
+    // slot loc takes the spare column and its old column becomes the new spare.
+    const int loc = c->ptr % c->m;
+    const int old = c->phys[size_t(loc)];
+    c->phys[size_t(loc)] = c->spare;
+    c->spare = old;
+    c->ys_host[size_t(loc)] = c->pend_sy;
+    DISPATCH_T(c, { c->theta = double(T(T(c->pend_yy) / T(c->pend_sy))); });
+    if (c->ncorr < c->m)
+        c->ncorr++;
+    c->ptr = loc + 1;
+    c->pending = false;
+    return LBFGSX_OK;
+}
+
+int lbfgsx_bfgs_add_correction_host(lbfgsx_ctx* c, const void* s, const void* y)
+{
+    void* sp = c->col(c->S, c->spare);
+    void* yp = c->col(c->Y, c->spare);
+    LBFGSX_HIP(hipMemcpyAsync(sp, s, size_t(c->n) * c->esz, hipMemcpyHostToDevice, c->stream));
+    LBFGSX_HIP(hipMemcpyAsync(yp, y, size_t(c->n) * c->esz, hipMemcpyHostToDevice, c->stream));
+    const int grid = c->grid_for(c->n);
+    double r[2];
+    DISPATCH_T(c, {
+        hipLaunchKernelGGL((k_dot<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(sp), P<T>(yp), P<T>(yp), c->n,
+                           c->ws, P<T>(c->sc) + c->sl.out(0));
+        int rc = fetch_scalars<T>(c, c->sl.out(0), 2, r);
+        if (rc)
+            return rc;
+        T vals[2] = {T(r[0]), T(T(r[1]) / T(r[0]))};
+        LBFGSX_HIP(hipMemcpyAsync(P<T>(c->sc) + c->sl.ys(c->spare), &vals[0], sizeof(T), hipMemcpyHostToDevice, c->stream));
+        LBFGSX_HIP(hipMemcpyAsync(P<T>(c->sc) + c->sl.theta(c->spare), &vals[1], sizeof(T), hipMemcpyHostToDevice, c->stream));
+        LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    });
+    c->pend_sy = r[0];
+    c->pend_yy = r[1];
+    c->pending = true;
+    return lbfgsx_commit_correction(c);
+}
+
+}  // extern "C"
+template <class T>
+static int apply_Hv_t(lbfgsx_ctx* c, const T* v, T a, double* dg)
+{
+    const int cn = c->ncorr, m = c->m;
+    const int grid = c->grid_for(c->n);
+    T* q = P<T>(c->d);
+    T* sc = P<T>(c->sc);
+    const T* gcur = P<T>(c->gb[c->cur]);
+    const ScLayout& sl = c->sl;
+    // physical columns newest -> oldest (BFGSMat.h:284-287)
+    int pcol[64];
+    {
+        int j = c->ptr % m;
+        for (int i = 0; i < cn; i++)
+        {
+            j = (j + m - 1) % m;
+            pcol[i] = c->phys[size_t(j)];
+        }
+    }
+    EventPair hv;
+    if (c->timing)
+    {
+        LBFGSX_HIP(hipEventCreate(&hv.a));
+        LBFGSX_HIP(hipEventCreate(&hv.b));
+        LBFGSX_HIP(hipEventRecord(hv.a, c->stream));
+    }
+    auto launch = [&](int mode, const T* u, const T* w, TwoLoopArgs args) -> int {
+        EventPair ev;
+        if (c->timing)
+        {
+            LBFGSX_HIP(hipEventCreate(&ev.a));
+            LBFGSX_HIP(hipEventCreate(&ev.b));
+            LBFGSX_HIP(hipEventRecord(ev.a, c->stream));
+        }
+        switch (mode)
+        {
+        case TL_INIT:
+            hipLaunchKernelGGL((k_twoloop<T, TL_INIT>), dim3(grid), dim3(kBlock), 0, c->stream, q, v, a, u, w, c->n, sc, args, c->ws);
+            break;
+        case TL_SUB:
+            hipLaunchKernelGGL((k_twoloop<T, TL_SUB>), dim3(grid), dim3(kBlock), 0, c->stream, q, v, a, u, w, c->n, sc, args, c->ws);
+            break;
+        case TL_SUBDIV:
+            hipLaunchKernelGGL((k_twoloop<T, TL_SUBDIV>), dim3(grid), dim3(kBlock), 0, c->stream, q, v, a, u, w, c->n, sc, args, c->ws);
+            break;
+        default:
+            hipLaunchKernelGGL((k_twoloop<T, TL_ADD>), dim3(grid), dim3(kBlock), 0, c->stream, q, v, a, u, w, c->n, sc, args, c->ws);
+            break;
+        }
+        if (c->timing)
+        {
+            LBFGSX_HIP(hipEventRecord(ev.b, c->stream));
+            c->ev_twoloop.push_back(ev);
+        }
+        return LBFGSX_OK;
+    };
+    auto Scol = [&](int i) { return static_cast<const T*>(c->col(c->S, pcol[i])); };
+    auto Ycol = [&](int i) { return static_cast<const T*>(c->col(c->Y, pcol[i])); };
+    int rc;
+    TwoLoopArgs args = {0, 0, 0, 0, 0};
+    if (cn == 0)
+    {
+        // res = a*v; res /= theta with theta == 1 is the identity (BFGSMat.h:283,293)
+        args.i_out = sl.dot(0);
+        if ((rc = launch(TL_INIT, nullptr, gcur, args)))
+            return rc;
+    }
+    else
+    {
+        args.i_out = sl.dot(0);
+        if ((rc = launch(TL_INIT, nullptr, Scol(0), args)))
+            return rc;
+        for (int i = 1; i < cn; i++)
+        {
+            args.i_num = sl.dot(i - 1);
+            args.i_den = sl.ys(pcol[i - 1]);
+            args.i_out = sl.dot(i);
+            if ((rc = launch(TL_SUB, Ycol(i - 1), Scol(i), args)))
+                return rc;
+        }
+        args.i_num = sl.dot(cn - 1);
+        args.i_den = sl.ys(pcol[cn - 1]);
+        args.i_theta = sl.theta(pcol[0]);
+        args.i_out = sl.dot(cn);
+        if ((rc = launch(TL_SUBDIV, Ycol(cn - 1), Ycol(cn - 1), args)))
+            return rc;
+        for (int t = 0; t < cn; t++)
+        {
+            const int i = cn - 1 - t, L = cn + 1 + t;
+            args.i_num = sl.dot(i);
+            args.i_num2 = sl.dot(L - 1);
+            args.i_den = sl.ys(pcol[i]);
+            args.i_out = sl.dot(L);
+            if ((rc = launch(TL_ADD, Scol(i), (t < cn - 1) ? Ycol(i - 1) : gcur, args)))
+                return rc;
+        }
+    }
+    LBFGSX_HIP(hipGetLastError());
+    if (c->timing)
+    {
+        LBFGSX_HIP(hipEventRecord(hv.b, c->stream));
+        c->ev_hv.push_back(hv);
+    }
+    if (dg)
+        return fetch_scalars<T>(c, sl.dot(2 * cn), 1, dg);
+    return LBFGSX_OK;
+}
+extern "C" {
+
+int lbfgsx_apply_Hv(lbfgsx_ctx* c, int v_which, double a, double* dg)
+{
+    void* v = vec_ptr(c, v_which);
+    if (!v || v == c->d)
+    {
+        set_error("lbfgsx_apply_Hv: invalid source vector");
+        return LBFGSX_E_INVALID;
+    }
+    if (c->m > 31)
+    {
+        set_error("lbfgsx_apply_Hv: m > 31 not supported");
+        return LBFGSX_E_INVALID;
+    }
+    DISPATCH_T(c, { return apply_Hv_t<T>(c, P<T>(v), T(a), dg); });
+    return LBFGSX_OK;
+}
+
+// ---- driver statements ------------------------------------------------------------------------------
+}  // extern "C"
+template <class T, class OBJ>
+static int eval_t(lbfgsx_ctx* c, OBJ obj, double* out3)
+{
+    const int grid = c->grid_for(c->n);
+    hipLaunchKernelGGL((k_eval<T, OBJ>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]),
+                       P<T>(c->gb[c->cur]), c->n, obj, c->ws, P<T>(c->sc) + c->sl.out(0));
+    LBFGSX_HIP(hipGetLastError());
+    return fetch_scalars<T>(c, c->sl.out(0), 3, out3);
+}
+extern "C" {
+
+int lbfgsx_eval(lbfgsx_ctx* c, int objective, double* fx, double* gnorm2, double* xnorm2)
+{
+    double r[3];
+    int rc = LBFGSX_E_INVALID;
+    if (objective == LBFGSX_OBJ_EXT_ROSENBROCK && (c->n & 1))
+    {
+        set_error("extended Rosenbrock needs an even dimension");
+        return LBFGSX_E_INVALID;
+    }
+    DISPATCH_T(c, {
+        if (objective == LBFGSX_OBJ_DIAG_QUAD)
+            rc = eval_t<T>(c, ObjQuad<T>{P<T>(c->a), P<T>(c->b)}, r);
+        else if (objective == LBFGSX_OBJ_EXT_ROSENBROCK)
+            rc = eval_t<T>(c, ObjRosen<T>{}, r);
+        else
+            set_error("lbfgsx_eval: unknown objective");
+    });
+    if (rc)
+        return rc;
+    if (fx) *fx = r[0];
+    if (gnorm2) *gnorm2 = r[1];
+    if (xnorm2) *xnorm2 = r[2];
+    return LBFGSX_OK;
+}
+
+int lbfgsx_norms(lbfgsx_ctx* c, double* gnorm2, double* xnorm2)
+{
+    const int grid = c->grid_for(c->n);
+    double r[2];
+    DISPATCH_T(c, {
+        const T* g = P<T>(c->gb[c->cur]);
+        hipLaunchKernelGGL((k_dot<T>), dim3(grid), dim3(kBlock), 0, c->stream, g, g, P<T>(c->xb[c->cur]), c->n, c->ws,
+                           P<T>(c->sc) + c->sl.out(0));
+        int rc = fetch_scalars<T>(c, c->sl.out(0), 2, r);
+        if (rc)
+            return rc;
+    });
+    if (gnorm2) *gnorm2 = r[0];
+    if (xnorm2) *xnorm2 = r[1];
+    return LBFGSX_OK;
+}
+
+int lbfgsx_ls_begin(lbfgsx_ctx* c)
+{
+    c->xp = c->cur;
+    c->lo = c->xp;
+    c->trial = (c->xp + 1) % 3;
+    return LBFGSX_OK;
+}
+
+}  // extern "C"
+template <class T, class OBJ>
+static int trial_t(lbfgsx_ctx* c, OBJ obj, T step, double* out2)
+{
+    const int grid = c->grid_for(c->n);
+    hipLaunchKernelGGL((k_trial<T, OBJ>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->xp]), P<T>(c->d), step,
+                       P<T>(c->xb[c->trial]), P<T>(c->gb[c->trial]), c->n, obj, c->ws, P<T>(c->sc) + c->sl.out(0));
+    LBFGSX_HIP(hipGetLastError());
+    return fetch_scalars<T>(c, c->sl.out(0), 2, out2);
+}
+extern "C" {
+
+int lbfgsx_trial(lbfgsx_ctx* c, int objective, double step, double* fx, double* dg)
+{
+    double r[2];
+    int rc = LBFGSX_E_INVALID;
+    DISPATCH_T(c, {
+        if (objective == LBFGSX_OBJ_DIAG_QUAD)
+            rc = trial_t<T>(c, ObjQuad<T>{P<T>(c->a), P<T>(c->b)}, T(step), r);
+        else if (objective == LBFGSX_OBJ_EXT_ROSENBROCK)
+            rc = trial_t<T>(c, ObjRosen<T>{}, T(step), r);
+        else
+            set_error("lbfgsx_trial: unknown objective");
+    });
+    if (rc)
+        return rc;
+    if (fx) *fx = r[0];
+    if (dg) *dg = r[1];
+    return LBFGSX_OK;
+}
+
+int lbfgsx_trial_point(lbfgsx_ctx* c, double step)
+{
+    const int grid = c->grid_for(c->n);
+    DISPATCH_T(c, {
+        hipLaunchKernelGGL((k_axpy_point<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->xp]), P<T>(c->d),
+                           T(step), P<T>(c->xb[c->trial]), c->n);
+    });
+    LBFGSX_HIP(hipGetLastError());
+    return LBFGSX_OK;
+}
+
+int lbfgsx_trial_dg(lbfgsx_ctx* c, double* dg)
+{
+    const int grid = c->grid_for(c->n);
+    DISPATCH_T(c, {
+        hipLaunchKernelGGL((k_dot<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->gb[c->trial]), P<T>(c->d),
+                           static_cast<const T*>(nullptr), c->n, c->ws, P<T>(c->sc) + c->sl.out(0));
+        LBFGSX_HIP(hipGetLastError());
+        return fetch_scalars<T>(c, c->sl.out(0), 1, dg);
+    });
+    return LBFGSX_OK;
+}
+
+int lbfgsx_ls_keep_trial_as_lo(lbfgsx_ctx* c)
+{
+    if (c->lo == c->xp)
+    {
+        c->lo = c->trial;
+        c->trial = third_point(c->xp, c->lo);
+    }
+    else
+        std::swap(c->lo, c->trial);
+    return LBFGSX_OK;
+}
+
+int lbfgsx_ls_end(lbfgsx_ctx* c, int use_lo)
+{
+    c->cur = use_lo ? c->lo : c->trial;
+    return LBFGSX_OK;
+}
+
+int lbfgsx_post_linesearch(lbfgsx_ctx* c, double* gnorm2, double* xnorm2, double* sy, double* yy)
+{
+    const int grid = c->grid_for(c->n);
+    double r[4];
+    DISPATCH_T(c, {
+        hipLaunchKernelGGL((k_post<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]), P<T>(c->xb[c->xp]),
+                           P<T>(c->gb[c->cur]), P<T>(c->gb[c->xp]), P<T>(c->col(c->S, c->spare)),
+                           P<T>(c->col(c->Y, c->spare)), c->n, c->ws, P<T>(c->sc) + c->sl.out(0),
+                           P<T>(c->sc) + c->sl.ys(c->spare), P<T>(c->sc) + c->sl.theta(c->spare));
+        LBFGSX_HIP(hipGetLastError());
+        int rc = fetch_scalars<T>(c, c->sl.out(0), 4, r);
+        if (rc)
+            return rc;
+    });
+    c->pend_sy = r[2];
+    c->pend_yy = r[3];
+    c->pending = true;
+    if (gnorm2) *gnorm2 = r[0];
+    if (xnorm2) *xnorm2 = r[1];
+    if (sy) *sy = r[2];
+    if (yy) *yy = r[3];
+    return LBFGSX_OK;
+}
+
+// ---- instrumentation ----------------------------------------------------------------------------------
+int lbfgsx_timing_enable(lbfgsx_ctx* c, int on)
+{
+    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    for (auto& e : c->ev_twoloop)
+    {
+        (void) hipEventDestroy(e.a);
+        (void) hipEventDestroy(e.b);
+    }
+    for (auto& e : c->ev_hv)
+    {
+        (void) hipEventDestroy(e.a);
+        (void) hipEventDestroy(e.b);
+    }
+    c->ev_twoloop.clear();
+    c->ev_hv.clear();
+    c->timing = (on != 0);
+    return LBFGSX_OK;
+}
+
+int lbfgsx_timing_read(lbfgsx_ctx* c, double* twoloop_ms_total, int64_t* twoloop_launches, double* applyhv_ms_total,
+                       int64_t* applyhv_calls)
+{
+    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    double t1 = 0.0, t2 = 0.0;
+    for (auto& e : c->ev_twoloop)
+    {
+        float ms = 0.f;
+        LBFGSX_HIP(hipEventElapsedTime(&ms, e.a, e.b));
+        t1 += ms;
+    }
+    for (auto& e : c->ev_hv)
+    {
+        float ms = 0.f;
+        LBFGSX_HIP(hipEventElapsedTime(&ms, e.a, e.b));
+        t2 += ms;
+    }
+    if (twoloop_ms_total) *twoloop_ms_total = t1;
+    if (twoloop_launches) *twoloop_launches = int64_t(c->ev_twoloop.size());
+    if (applyhv_ms_total) *applyhv_ms_total = t2;
+    if (applyhv_calls) *applyhv_calls = int64_t(c->ev_hv.size());
+    return LBFGSX_OK;
+}
+
+int lbfgsx_stream_probe(lbfgsx_ctx* c, int reps, double* copy_gbs, double* triad_gbs)
+{
+    if (reps < 1)
+        reps = 1;
+    const int grid = c->grid_for(c->n);
+    hipEvent_t e0, e1, e2;
+    LBFGSX_HIP(hipEventCreate(&e0));
+    LBFGSX_HIP(hipEventCreate(&e1));
+    LBFGSX_HIP(hipEventCreate(&e2));
+    // scratch: the two non-current points and the spare history column are free between iterations
+    void* src = c->col(c->S, c->spare);
+    void* dst = c->col(c->Y, c->spare);
+    void* z = c->xb[(c->cur + 1) % 3];
+    DISPATCH_T(c, {
+        hipLaunchKernelGGL((k_copy<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(src), P<T>(dst), c->n);  // warm-up
+        LBFGSX_HIP(hipEventRecord(e0, c->stream));
+        for (int r = 0; r < reps; r++)
+            hipLaunchKernelGGL((k_copy<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(src), P<T>(dst), c->n);
+        LBFGSX_HIP(hipEventRecord(e1, c->stream));
+        for (int r = 0; r < reps; r++)
+            hipLaunchKernelGGL((k_triad<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(src), P<T>(z), T(0.5), P<T>(dst), c->n);
+        LBFGSX_HIP(hipEventRecord(e2, c->stream));
+    });
+    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    float ms_c = 0.f, ms_t = 0.f;
+    LBFGSX_HIP(hipEventElapsedTime(&ms_c, e0, e1));
+    LBFGSX_HIP(hipEventElapsedTime(&ms_t, e1, e2));
+    const double bytes = double(c->n) * double(c->esz);
+    if (copy_gbs) *copy_gbs = 2.0 * bytes * reps / (ms_c * 1e-3) / 1e9;
+    if (triad_gbs) *triad_gbs = 3.0 * bytes * reps / (ms_t * 1e-3) / 1e9;
+    (void) hipEventDestroy(e0);
+    (void) hipEventDestroy(e1);
+    (void) hipEventDestroy(e2);
+    return LBFGSX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,35 @@
+// oracle/objectives.h -- TEST INFRASTRUCTURE ONLY.  The two built-in objectives on raw arrays.
+//   diag quadratic  f = 0.5*sum (a_i x_i - b_i)^2             
+//   ext. Rosenbrock pair form of /root/reference/examples/example-rosenbrock.cpp:18-25
+// Element-wise arithmetic in T without contraction; the fx sum uses the oracle accumulator.
+#ifndef LBFGSX_ORACLE_OBJECTIVES_H
+#define LBFGSX_ORACLE_OBJECTIVES_H
+#include "acc.h"
+#include "problems.h"
+namespace oracle {
+template <class T>
+T eval_objective(int obj, long n, const T* a, const T* b, const T* x, T* g)
+{
+    Acc<T> acc;
+    if (obj == OBJ_DIAG_QUAD)
+    {
+        for (long i = 0; i < n; i++)
+        {
+            const T r = a[i] * x[i] - b[i];
+            g[i] = a[i] * r;
+            acc.add(r * r);
+        }
+        return T(0.5) * acc.value();
+    }
+    for (long i = 0; i + 1 < n; i += 2)
+    {
+        const T t1 = T(1) - x[i];
+        const T t2 = T(10) * (x[i + 1] - x[i] * x[i]);
+        g[i + 1] = T(20) * t2;
+        g[i] = T(-2) * (x[i] * g[i + 1] + t1);
+        acc.add(t1 * t1 + t2 * t2);
+    }
+    return acc.value();
+}
+}  // namespace oracle
+#endif
