@@ -76,7 +76,11 @@ struct lbfgsx_ctx
     void* sc = nullptr;      // device, T[sl.total()]
     void* hout = nullptr;    // pinned host staging
     lbfgsx::RedWs ws;
-    int grid_cap = 2048;
+    int grid_cap = 1024;     // blocks per launch of the streaming kernels (4 per CU; tuned on MI355X, see profiles/)
+    int grid_cap_twoloop = 512;
+    int unroll = 4;   // 16-byte loads in flight per stream per thread in the two-loop kernels
+    bool nt = true;   // non-temporal hints on the streaming accesses (+8% on MI355X)
+    bool chunked = false;  // contiguous slab per block instead of grid-stride tiles
 
     // L-BFGS-B work set (allocated with LBFGSX_FLAG_BOUNDED) lives in lbfgsb part
     void* lb = nullptr;
@@ -91,10 +95,11 @@ struct lbfgsx_ctx
     int64_t gather_cap = 0;
 
     void* col(void* base, int c) const { return static_cast<char*>(base) + size_t(c) * size_t(ld) * esz; }
-    int grid_for(int64_t nelem) const
+    int grid_for(int64_t nelem, int unroll_ = 1) const
     {
         const int64_t w = (dtype == LBFGSX_F64) ? 2 : 4;
-        int64_t blocks = (nelem / w + lbfgsx::kBlock - 1) / lbfgsx::kBlock;
+        const int64_t tile = int64_t(lbfgsx::kBlock) * unroll_;
+        int64_t blocks = (nelem / w + tile - 1) / tile;
         if (blocks < 1)
             blocks = 1;
         if (blocks > grid_cap)

@@ -285,6 +285,7 @@ enum { TL_INIT = 0, TL_SUB = 1, TL_SUBDIV = 2, TL_ADD = 3 };
 
 struct TwoLoopArgs
 {
+    int chunked;  // 1: each block streams one contiguous slab (DRAM-page friendly); 0: grid-stride tiles
     int i_num;    // sc[i_num] / sc[i_den] = alpha_j            (TL_SUB, TL_SUBDIV, TL_ADD)
     int i_den;    // ys_j
     int i_num2;   // sc[i_num2] / sc[i_den] = beta             (TL_ADD)
@@ -292,7 +293,7 @@ struct TwoLoopArgs
     int i_out;    // where the reduced dot goes
 };
 
-template <class T, int MODE>
+template <class T, int MODE, int U, bool NT>
 __global__ void __launch_bounds__(kBlock) k_twoloop(T* __restrict__ q, const T* __restrict__ vin, T a,
                                                     const T* __restrict__ u, const T* __restrict__ w, int64_t n,
                                                     T* __restrict__ sc, TwoLoopArgs args, RedWs ws)
@@ -309,37 +310,66 @@ __global__ void __launch_bounds__(kBlock) k_twoloop(T* __restrict__ q, const T* 
 
     A acc[1];
     const int64_t nv = n / W;
-    const int64_t stride = int64_t(gridDim.x) * kBlock;
-    for (int64_t vi = int64_t(blockIdx.x) * kBlock + threadIdx.x; vi < nv; vi += stride)
+    const int64_t tile = int64_t(kBlock) * U;
+    int64_t first, last, stride;
+    if (args.chunked)
     {
-        Pack<T> pq;
-        if (MODE == TL_INIT)
-        {
-            const Pack<T> pv = ldv(vin, vi);
+        const int64_t slab = ((nv + gridDim.x - 1) / gridDim.x + tile - 1) / tile * tile;
+        first = int64_t(blockIdx.x) * slab;
+        last = first + slab < nv ? first + slab : nv;
+        stride = tile;
+    }
+    else
+    {
+        first = int64_t(blockIdx.x) * tile;
+        last = nv;
+        stride = int64_t(gridDim.x) * tile;
+    }
+    for (int64_t base = first + threadIdx.x; base < last; base += stride)
+    {
+        Pack<T> pq[U], pu[U], pw[U];
+        // issue every load of the tile before the first use (U independent 16-byte loads per stream)
 #pragma unroll
-            for (int k = 0; k < W; k++)
-                pq.e[k] = a * pv.e[k];  // res = a*v (BFGSMat.h:283)
-        }
-        else
+        for (int k = 0; k < U; k++)
         {
-            pq = ldv(q, vi);
-            const Pack<T> pu = ldv(u, vi);
-#pragma unroll
-            for (int k = 0; k < W; k++)
+            const int64_t vi = base + int64_t(k) * kBlock;
+            if (vi < last)
             {
-                if (MODE == TL_ADD)
-                    pq.e[k] = pq.e[k] + coef * pu.e[k];  // res += (alpha-beta)*s_j (:299)
+                if (MODE == TL_INIT)
+                    pq[k] = ldv<T, NT>(vin, vi);
                 else
-                    pq.e[k] = pq.e[k] - coef * pu.e[k];  // res -= alpha*y_j (:289)
-                if (MODE == TL_SUBDIV)
-                    pq.e[k] = pq.e[k] / theta;  // res /= theta (:293)
+                {
+                    pq[k] = ldv<T, NT>(q, vi);
+                    pu[k] = ldv<T, NT>(u, vi);
+                }
+                if (MODE != TL_SUBDIV)  // TL_SUBDIV reduces against the column it just subtracted
+                    pw[k] = ldv<T, NT>(w, vi);
             }
         }
-        stv(q, vi, pq);
-        const Pack<T> pw = ldv(w, vi);
 #pragma unroll
-        for (int k = 0; k < W; k++)
-            acc[0].add_prod(pw.e[k], pq.e[k]);
+        for (int k = 0; k < U; k++)
+        {
+            const int64_t vi = base + int64_t(k) * kBlock;
+            if (vi < last)
+            {
+#pragma unroll
+                for (int e = 0; e < W; e++)
+                {
+                    if (MODE == TL_INIT)
+                        pq[k].e[e] = a * pq[k].e[e];  // res = a*v (BFGSMat.h:283)
+                    else if (MODE == TL_ADD)
+                        pq[k].e[e] = pq[k].e[e] + coef * pu[k].e[e];  // res += (alpha-beta)*s_j (:299)
+                    else
+                        pq[k].e[e] = pq[k].e[e] - coef * pu[k].e[e];  // res -= alpha*y_j (:289)
+                    if (MODE == TL_SUBDIV)
+                        pq[k].e[e] = pq[k].e[e] / theta;  // res /= theta (:293)
+                }
+                stv<T, NT>(q, vi, pq[k]);
+#pragma unroll
+                for (int e = 0; e < W; e++)
+                    acc[0].add_prod(MODE == TL_SUBDIV ? pu[k].e[e] : pw[k].e[e], pq[k].e[e]);
+            }
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0)
         for (int64_t i = nv * W; i < n; i++)
@@ -358,7 +388,7 @@ __global__ void __launch_bounds__(kBlock) k_twoloop(T* __restrict__ q, const T* 
                     qi = qi / theta;
             }
             q[i] = qi;
-            acc[0].add_prod(w[i], qi);
+            acc[0].add_prod(MODE == TL_SUBDIV ? u[i] : w[i], qi);
         }
     if (grid_reduce<1>(acc, ws) && threadIdx.x == 0)
         sc[args.i_out] = T(acc[0].value());

@@ -1,5 +1,6 @@
 // lbfgspp_amd/csrc/lbfgsx.hip -- C ABI (include/lbfgsx.h) over the CDNA4 kernels: context, history
 // bookkeeping, unconstrained L-BFGS statements.  Built with hipcc --offload-arch=gfx950 -ffp-contract=off.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -190,6 +191,14 @@ int lbfgsx_create(lbfgsx_ctx** out, int dtype, int64_t n, int m, int device, int
         c->grid_cap = atoi(e) > 0 ? atoi(e) : c->grid_cap;
     if (c->grid_cap > 8192)
         c->grid_cap = 8192;
+    if (const char* e = getenv("LBFGSX_GRID_CAP_TWOLOOP"))
+        c->grid_cap_twoloop = atoi(e) > 0 ? std::min(atoi(e), 8192) : c->grid_cap_twoloop;
+    if (const char* e = getenv("LBFGSX_UNROLL"))
+        c->unroll = (atoi(e) == 1 || atoi(e) == 2 || atoi(e) == 8) ? atoi(e) : 4;
+    if (const char* e = getenv("LBFGSX_NT"))
+        c->nt = atoi(e) != 0;
+    if (const char* e = getenv("LBFGSX_CHUNKED"))
+        c->chunked = atoi(e) != 0;
     LBFGSX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->own_stream = true;
     const size_t vbytes = size_t(c->ld) * c->esz;
@@ -438,7 +447,7 @@ template <class T>
 static int apply_Hv_t(lbfgsx_ctx* c, const T* v, T a, double* dg)
 {
     const int cn = c->ncorr, m = c->m;
-    const int grid = c->grid_for(c->n);
+    const int grid = std::min(c->grid_for(c->n, c->unroll), c->grid_cap_twoloop);
     T* q = P<T>(c->d);
     T* sc = P<T>(c->sc);
     const T* gcur = P<T>(c->gb[c->cur]);
@@ -468,21 +477,35 @@ static int apply_Hv_t(lbfgsx_ctx* c, const T* v, T a, double* dg)
             LBFGSX_HIP(hipEventCreate(&ev.b));
             LBFGSX_HIP(hipEventRecord(ev.a, c->stream));
         }
+#define TL_LAUNCH(MODE, U, NT) \
+    hipLaunchKernelGGL((k_twoloop<T, MODE, U, NT>), dim3(grid), dim3(kBlock), 0, c->stream, q, v, a, u, w, c->n, sc, args, c->ws)
+#define TL_VARIANT(MODE)                                         \
+    do                                                           \
+    {                                                            \
+        if (c->nt)                                               \
+        {                                                        \
+            if (c->unroll == 1) TL_LAUNCH(MODE, 1, true);        \
+            else if (c->unroll == 2) TL_LAUNCH(MODE, 2, true);   \
+            else if (c->unroll == 8) TL_LAUNCH(MODE, 8, true);   \
+            else TL_LAUNCH(MODE, 4, true);                       \
+        }                                                        \
+        else                                                     \
+        {                                                        \
+            if (c->unroll == 1) TL_LAUNCH(MODE, 1, false);       \
+            else if (c->unroll == 2) TL_LAUNCH(MODE, 2, false);  \
+            else if (c->unroll == 8) TL_LAUNCH(MODE, 8, false);  \
+            else TL_LAUNCH(MODE, 4, false);                      \
+        }                                                        \
+    } while (0)
         switch (mode)
         {
-        case TL_INIT:
-            hipLaunchKernelGGL((k_twoloop<T, TL_INIT>), dim3(grid), dim3(kBlock), 0, c->stream, q, v, a, u, w, c->n, sc, args, c->ws);
-            break;
-        case TL_SUB:
-            hipLaunchKernelGGL((k_twoloop<T, TL_SUB>), dim3(grid), dim3(kBlock), 0, c->stream, q, v, a, u, w, c->n, sc, args, c->ws);
-            break;
-        case TL_SUBDIV:
-            hipLaunchKernelGGL((k_twoloop<T, TL_SUBDIV>), dim3(grid), dim3(kBlock), 0, c->stream, q, v, a, u, w, c->n, sc, args, c->ws);
-            break;
-        default:
-            hipLaunchKernelGGL((k_twoloop<T, TL_ADD>), dim3(grid), dim3(kBlock), 0, c->stream, q, v, a, u, w, c->n, sc, args, c->ws);
-            break;
+        case TL_INIT: TL_VARIANT(TL_INIT); break;
+        case TL_SUB: TL_VARIANT(TL_SUB); break;
+        case TL_SUBDIV: TL_VARIANT(TL_SUBDIV); break;
+        default: TL_VARIANT(TL_ADD); break;
         }
+#undef TL_VARIANT
+#undef TL_LAUNCH
         if (c->timing)
         {
             LBFGSX_HIP(hipEventRecord(ev.b, c->stream));
@@ -493,7 +516,7 @@ static int apply_Hv_t(lbfgsx_ctx* c, const T* v, T a, double* dg)
     auto Scol = [&](int i) { return static_cast<const T*>(c->col(c->S, pcol[i])); };
     auto Ycol = [&](int i) { return static_cast<const T*>(c->col(c->Y, pcol[i])); };
     int rc;
-    TwoLoopArgs args = {0, 0, 0, 0, 0};
+    TwoLoopArgs args = {c->chunked ? 1 : 0, 0, 0, 0, 0, 0};
     if (cn == 0)
     {
         // res = a*v; res /= theta with theta == 1 is the identity (BFGSMat.h:283,293)

@@ -188,15 +188,17 @@ __device__ __forceinline__ bool grid_reduce(A (&acc)[NRED], const RedWs& ws)
 }
 
 // ---------------------------------------------------------------- 16-byte vector access
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
 template <class T> struct Vec16;
 template <> struct Vec16<double>
 {
-    typedef double2 type;
+    typedef d2_t type;
     static constexpr int W = 2;
 };
 template <> struct Vec16<float>
 {
-    typedef float4 type;
+    typedef f4_t type;
     static constexpr int W = 4;
 };
 
@@ -205,19 +207,30 @@ union Pack
 {
     typename Vec16<T>::type v;
     T e[Vec16<T>::W];
+    __device__ __forceinline__ Pack() {}
 };
 
-template <class T>
+// NT = non-temporal (streaming) hint: every n-vector of this path is far larger than the caches and is
+// touched once per launch.
+template <class T, bool NT = false>
 __device__ __forceinline__ Pack<T> ldv(const T* p, int64_t vecIdx)
 {
     Pack<T> r;
-    r.v = reinterpret_cast<const typename Vec16<T>::type*>(p)[vecIdx];
+    const typename Vec16<T>::type* vp = reinterpret_cast<const typename Vec16<T>::type*>(p) + vecIdx;
+    if (NT)
+        r.v = __builtin_nontemporal_load(vp);
+    else
+        r.v = *vp;
     return r;
 }
-template <class T>
+template <class T, bool NT = false>
 __device__ __forceinline__ void stv(T* p, int64_t vecIdx, const Pack<T>& r)
 {
-    reinterpret_cast<typename Vec16<T>::type*>(p)[vecIdx] = r.v;
+    typename Vec16<T>::type* vp = reinterpret_cast<typename Vec16<T>::type*>(p) + vecIdx;
+    if (NT)
+        __builtin_nontemporal_store(r.v, vp);
+    else
+        *vp = r.v;
 }
 
 }  // namespace lbfgsx

@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""Condense gpurun_out/prof_<round>/ (rocprofv3 kernel-trace stats + FETCH_SIZE / WRITE_SIZE passes) into
+profiles/<round>_*.  HBM bytes follow MI355X_MICROARCH.md "HBM": counters are in KiB and FETCH_SIZE
+reports exactly half of a wide coalesced read stream on gfx950 (calibrated here on k_copy, whose byte
+count is known), so  hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024."""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r1"
+src = os.path.join("gpurun_out", "prof_" + rnd)
+os.makedirs("profiles", exist_ok=True)
+shutil.copy(os.path.join(src, "trace", "bench_kernel_stats.csv"), os.path.join("profiles", rnd + "_kernel_stats.csv"))
+
+
+def short(name):
+    n = name.split("(")[0].replace("void lbfgsx::", "")
+    return n
+
+
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for which in ("pmc_fetch", "pmc_write"):
+    with open(os.path.join(src, which, "bench_counter_collection.csv")) as f:
+        for r in csv.DictReader(f):
+            agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+stats = {}
+with open(os.path.join(src, "trace", "bench_kernel_stats.csv")) as f:
+    for r in csv.DictReader(f):
+        stats[short(r["Name"])] = (int(r["Calls"]), float(r["AverageNs"]))
+
+out = {"round": rnd, "command": "rocprofv3 {--kernel-trace --stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE} "
+                                "--output-format csv -- python bench.py --no-cpu --steps 10 --warmup 11",
+       "units": "FETCH_SIZE/WRITE_SIZE in KiB; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 correction)",
+       "kernels": {}}
+for k, c in sorted(agg.items()):
+    if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+        continue
+    fetch = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"])
+    write = sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"])
+    hbm = (2.0 * fetch + write) * 1024.0
+    calls, avg_ns = stats.get(k, (0, 0.0))
+    out["kernels"][k] = {"calls": calls, "avg_ms": avg_ns * 1e-6, "fetch_KiB_raw": fetch, "write_KiB": write,
+                         "hbm_bytes_per_launch": hbm,
+                         "hbm_GBs": (hbm / (avg_ns * 1e-9) / 1e9) if avg_ns else None}
+# launch-weighted two-loop figures (what bench.py's roofline object quotes)
+tl = {k: v for k, v in out["kernels"].items() if k.startswith("k_twoloop")}
+calls = sum(v["calls"] for v in tl.values())
+if calls:
+    out["twoloop_avg_hbm_bytes_per_launch"] = sum(v["hbm_bytes_per_launch"] * v["calls"] for v in tl.values()) / calls
+    out["twoloop_avg_ms"] = sum(v["avg_ms"] * v["calls"] for v in tl.values()) / calls
+with open(os.path.join("profiles", rnd + "_pmc_summary.json"), "w") as f:
+    json.dump(out, f, indent=1)
+print(json.dumps({k: v for k, v in out.items() if k != "kernels"}, indent=1))
+for k, v in out["kernels"].items():
+    print("%-40s calls %4d avg %.4f ms  hbm %.4g B  %.0f GB/s" % (k[:40], v["calls"], v["avg_ms"], v["hbm_bytes_per_launch"], v["hbm_GBs"] or 0))

@@ -222,13 +222,12 @@ def test_large_n_properties(A):
     assert fxs[0] == fxs[1], "run-to-run results must be bit-reproducible"
     # linearity of v -> H v with the final history: H(2v) == 2 H(v) exactly (scaling by 2 is exact)
     h = s.ctx
-    d1 = np.empty(4096)
     dg1, dg2 = C.c_double(), C.c_double()
     L.check(core.lbfgsx_apply_Hv(h, L.VEC_G, -1.0, C.byref(dg1)))
-    g1 = np.empty(n // 4096 + 1)
+    g1 = np.empty(n // 4096)
     L.check(core.lbfgsx_gather(h, L.VEC_D, 4096, g1.ctypes.data_as(C.POINTER(C.c_double))))
     L.check(core.lbfgsx_apply_Hv(h, L.VEC_G, -2.0, C.byref(dg2)))
-    g2 = np.empty(n // 4096 + 1)
+    g2 = np.empty(n // 4096)
     L.check(core.lbfgsx_gather(h, L.VEC_D, 4096, g2.ctypes.data_as(C.POINTER(C.c_double))))
     assert np.array_equal(2.0 * g1, g2) and dg2.value == 2.0 * dg1.value
     assert dg1.value < 0  # -H g is a descent direction
