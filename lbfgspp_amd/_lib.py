@@ -1,4 +1,4 @@
-"""ctypes bindings of liblbfgsx.so / liblbfgsx_solver.so (the product path; never touches oracle/)."""
+"""ctypes bindings of liblbfgsx.so / liblbfgsx_solver.so (the product path: native HIP only)."""
 import ctypes as C
 import os
 

@@ -1,0 +1,68 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.json from the reference itself (oracle/_ref = unmodified reference headers +
+oracle/eigen_shim, double-double accumulators).  Run in the build container where /root/reference exists:
+
+    make -C oracle ref && python tests/golden/make_golden.py
+
+The fixtures pin (a) the known answers quoted in SURVEY.md 8(c) / the reference's README and examples and
+(b) seeded trajectories (per-evaluation fx, sampled x) that the restatement (oracle/lbfgs_oracle.cpp) and the
+HIP path must reproduce.  Floats are stored as hex strings (bit-exact)."""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import oracle_lib as O  # noqa: E402
+
+
+def hx(a):
+    return [float(v).hex() for v in np.asarray(a, dtype=np.float64).ravel()]
+
+
+def lbfgs_case(orc, name, dtype, ls, obj, n, m, iters, seed=7, kappa=10.0, stride=None, **pk):
+    if obj == O.OBJ_ROSEN:
+        x0 = O.rosen_x0(n, seed, dtype) if pk.pop("hash_x0", True) else np.zeros(n, O.NPDT[dtype])
+        a = b = None
+    else:
+        x0 = np.zeros(n, O.NPDT[dtype])
+        a, b = O.quad_problem(n, kappa, 1, dtype)
+        pk.pop("hash_x0", None)
+    p = O.lbfgs_params(m=m, max_iterations=iters, **pk)
+    stride = stride or max(1, n // 64)
+    tr = O.TraceBuf(n, cap=1024, stride=stride)
+    x, r = orc.lbfgs(dtype, ls, obj, x0, p, a=a, b=b, trace=tr)
+    k = tr.count
+    return dict(name=name, algo="lbfgs", dtype=dtype, ls=ls, obj=obj, n=n, m=m, max_iterations=iters, seed=seed,
+                kappa=kappa, params={k_: getattr(p, k_) for k_, _ in p._fields_}, hash_x0=bool(obj == O.OBJ_ROSEN and np.any(x0 != 0)),
+                niter=r.niter, nfev=r.nfev, status=r.status, msg=r.msg.decode(), fx=float(r.fx).hex(),
+                gnorm=float(r.gnorm).hex(), stride=stride, trace_fx=hx(tr.fx[:k]), trace_xs=hx(tr.xs[:k]),
+                x_sample=hx(x[::stride]))
+
+
+def main():
+    orc = O.Oracle("ref", "dd")
+    cases = []
+    # README / example known answers: Rosenbrock n=10, x0=0
+    for ls, nm in ((O.LS_NW, "nw"), (O.LS_MT, "mt"), (O.LS_BT, "bt"), (O.LS_BR, "br")):
+        cases.append(lbfgs_case(orc, "readme_rosen10_f64_" + nm, O.F64, ls, O.OBJ_ROSEN, 10, 6, 100, hash_x0=False,
+                                epsilon=1e-6, stride=1))
+    cases.append(lbfgs_case(orc, "readme_rosen10_f64_nw_epsrel0", O.F64, O.LS_NW, O.OBJ_ROSEN, 10, 6, 100,
+                            hash_x0=False, epsilon=1e-6, epsilon_rel=0.0, stride=1))
+    cases.append(lbfgs_case(orc, "example_rosen10_f32_nw", O.F32, O.LS_NW, O.OBJ_ROSEN, 10, 6, 0, hash_x0=False, stride=1))
+    # seeded trajectories (fixed work: epsilon = epsilon_rel = 0)
+    for ls, nm in ((O.LS_NW, "nw"), (O.LS_MT, "mt")):
+        cases.append(lbfgs_case(orc, "rosen_n4096_m6_f64_" + nm, O.F64, ls, O.OBJ_ROSEN, 4096, 6, 25, epsilon=0.0, epsilon_rel=0.0))
+        cases.append(lbfgs_case(orc, "quad_n5001_m10_f64_" + nm, O.F64, ls, O.OBJ_QUAD, 5001, 10, 25, epsilon=0.0, epsilon_rel=0.0))
+        cases.append(lbfgs_case(orc, "rosen_n4098_m5_f32_" + nm, O.F32, ls, O.OBJ_ROSEN, 4098, 5, 12, seed=1000, epsilon=0.0, epsilon_rel=0.0))
+    with open(os.path.join(HERE, "lbfgs_golden.json"), "w") as f:
+        json.dump(dict(generator="tests/golden/make_golden.py", oracle=orc.description, cases=cases), f, indent=0)
+    print("wrote", len(cases), "L-BFGS cases")
+    for c in cases:
+        print(" ", c["name"], c["niter"], c["nfev"], c["status"], float.fromhex(c["fx"]))
+
+
+if __name__ == "__main__":
+    main()

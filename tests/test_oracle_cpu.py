@@ -1,0 +1,94 @@
+"""CPU suite, part 1: the oracle itself.
+
+* the restatement (oracle/lbfgs_oracle.cpp) must reproduce every committed golden fixture bit for bit;
+  the fixtures were generated from the reference itself (unmodified headers + eigen_shim), see
+  tests/golden/make_golden.py;
+* where oracle/_ref is present (build container) the restatement and the reference-derived oracle must agree
+  bit for bit on fresh seeded inputs, and the double-double build must agree with the __float128 build.
+"""
+import numpy as np
+import pytest
+
+import golden_util as G
+import oracle_lib as O
+
+GOLD = G.load()
+
+
+def _port():
+    if not O.available("port", "dd"):
+        pytest.skip("oracle port not built (make -C oracle port)")
+    return O.Oracle("port", "dd")
+
+
+@pytest.mark.parametrize("case", GOLD["cases"], ids=[c["name"] for c in GOLD["cases"]])
+def test_restatement_reproduces_golden(case):
+    orc = _port()
+    x0, a, b = G.case_inputs(case)
+    p = O.Params(**case["params"])
+    tr = O.TraceBuf(case["n"], cap=1024, stride=case["stride"])
+    x, r = orc.lbfgs(case["dtype"], case["ls"], case["obj"], x0, p, a=a, b=b, trace=tr)
+    assert (r.niter, r.nfev, r.status) == (case["niter"], case["nfev"], case["status"])
+    assert r.fx == float.fromhex(case["fx"]) and r.gnorm == float.fromhex(case["gnorm"])
+    k = tr.count
+    assert np.array_equal(tr.fx[:k], G.unhex(case["trace_fx"]))
+    assert np.array_equal(tr.xs[:k].ravel(), G.unhex(case["trace_xs"]))
+    assert np.array_equal(np.asarray(x[::case["stride"]], np.float64), G.unhex(case["x_sample"]))
+
+
+def test_known_answers_from_reference_docs():
+    """iteration / evaluation counts of the README problem for the four line searches."""
+    by = {c["name"]: c for c in GOLD["cases"]}
+    assert (by["readme_rosen10_f64_nw"]["niter"], by["readme_rosen10_f64_nw"]["nfev"]) == (22, 36)
+    assert (by["readme_rosen10_f64_mt"]["niter"], by["readme_rosen10_f64_mt"]["nfev"]) == (21, 28)
+    assert (by["readme_rosen10_f64_bt"]["niter"], by["readme_rosen10_f64_bt"]["nfev"]) == (22, 31)
+    assert (by["readme_rosen10_f64_br"]["niter"], by["readme_rosen10_f64_br"]["nfev"]) == (22, 31)
+    # README.md:89-95 "23 iterations" is reproduced with epsilon_rel = 0 (the README predates epsilon_rel)
+    assert by["readme_rosen10_f64_nw_epsrel0"]["niter"] == 23
+
+
+@pytest.mark.skipif(not O.available("ref", "dd"), reason="oracle/_ref only exists where /root/reference does")
+@pytest.mark.parametrize("dtype", [O.F64, O.F32])
+@pytest.mark.parametrize("ls", [O.LS_NW, O.LS_MT, O.LS_BT, O.LS_BR])
+def test_restatement_equals_reference_build(dtype, ls):
+    ref, port = O.Oracle("ref", "dd"), _port()
+    for obj, n in ((O.OBJ_ROSEN, 1500), (O.OBJ_QUAD, 2001)):
+        x0 = O.rosen_x0(n, 11, dtype) if obj == O.OBJ_ROSEN else np.zeros(n, O.NPDT[dtype])
+        a, b = O.quad_problem(n, 50.0, 3, dtype) if obj == O.OBJ_QUAD else (None, None)
+        p = O.lbfgs_params(m=7, epsilon=0, epsilon_rel=0, max_iterations=40)
+        t1, t2 = O.TraceBuf(n, cap=600), O.TraceBuf(n, cap=600)
+        x1, r1 = ref.lbfgs(dtype, ls, obj, x0, p, a=a, b=b, trace=t1)
+        x2, r2 = port.lbfgs(dtype, ls, obj, x0, p, a=a, b=b, trace=t2)
+        assert (r1.niter, r1.nfev, r1.status, r1.msg) == (r2.niter, r2.nfev, r2.status, r2.msg)
+        assert np.array_equal(x1, x2) and np.array_equal(t1.xs[:t1.count], t2.xs[:t2.count])
+
+
+@pytest.mark.skipif(not (O.available("ref", "dd") and O.available("ref", "quad")), reason="needs oracle/_ref")
+def test_double_double_equals_float128_accumulation():
+    """The parity oracle's double-double reductions give the same trajectories as __float128 reductions:
+    both are correctly rounded sums, hence independent of the summation order."""
+    dd, quad = O.Oracle("ref", "dd"), O.Oracle("ref", "quad")
+    n = 6000
+    x0 = O.rosen_x0(n)
+    p = O.lbfgs_params(m=8, epsilon=0, epsilon_rel=0, max_iterations=40)
+    x1, r1 = dd.lbfgs(O.F64, O.LS_MT, O.OBJ_ROSEN, x0, p)
+    x2, r2 = quad.lbfgs(O.F64, O.LS_MT, O.OBJ_ROSEN, x0, p)
+    assert (r1.niter, r1.nfev) == (r2.niter, r2.nfev) and np.array_equal(x1, x2)
+    a, b = O.quad_problem(n)
+    pb = O.lbfgsb_params(m=8, epsilon=0, epsilon_rel=0, max_iterations=15, past=0)
+    x1, r1 = dd.lbfgsb(O.F64, O.OBJ_QUAD, np.zeros(n), -np.ones(n), np.ones(n), pb, a=a, b=b)
+    x2, r2 = quad.lbfgsb(O.F64, O.OBJ_QUAD, np.zeros(n), -np.ones(n), np.ones(n), pb, a=a, b=b)
+    assert (r1.niter, r1.nfev) == (r2.niter, r2.nfev) and np.array_equal(x1, x2)
+
+
+@pytest.mark.skipif(not O.available("ref", "dd"), reason="needs oracle/_ref")
+def test_apply_Hv_restatement_equals_reference():
+    ref, port = O.Oracle("ref", "dd"), _port()
+    rng = np.random.default_rng(5)
+    for dtype in (O.F64, O.F32):
+        for n, m, k in ((257, 6, 0), (257, 6, 4), (1001, 5, 12)):
+            S = rng.standard_normal((max(k, 1), n))[:k]
+            Y = (S * (1 + rng.random((k, n)))) if k else S
+            v = rng.standard_normal(n)
+            assert np.array_equal(ref.apply_Hv(dtype, m, S.reshape(k, n), Y.reshape(k, n), v, -1.0),
+                                  port.apply_Hv(dtype, m, S.reshape(k, n), Y.reshape(k, n), v, -1.0))
