@@ -1,0 +1,192 @@
+// include/LBFGSB.h -- drop-in LBFGSpp::LBFGSBSolver whose O(n) work runs on an MI355X.
+//
+// Same class template, constructor, minimize() contract and getters as the reference driver
+// (/root/reference/include/LBFGSB.h:21-23,95-99,116-262,271-279).  Host: convergence tests (:146-149,213-230),
+// recovery rule (:188-197), step clamp (:200-202), curvature test (:237), 2m x 2m algebra.  Device (C ABI):
+//     :128,240 force_bounds                  -> lbfgsx_b_force_bounds
+//     :137-138 f(x,grad), proj_grad_norm     -> lbfgsx_b_eval
+//     :154,241 Cauchy::get_cauchy_point      -> LBFGSpp::Cauchy  (lbfgsx_b_cauchy_*)
+//     :163-164,191 drt = xcp - x [normalize] -> lbfgsx_b_dir_from_xcp
+//     :174-179 xp=x, gradp=grad, dg, step_max-> lbfgsx_ls_begin (rotation) + lbfgsx_b_dg_maxstep
+//     :203    LineSearchMoreThuente          -> LineSearch policy over lbfgsx_trial
+//     :206,235-237 proj norm, s, y, s.y, y.y -> lbfgsx_b_post_linesearch
+//     :238    add_correction                 -> BFGSMatB::add_correction (commit + lbfgsx_b_correction_dots)
+//     :249    SubspaceMin::subspace_minimize -> LBFGSpp::SubspaceMin (lbfgsx_b_wtv / _gram / _wcombine / ...)
+#ifndef LBFGSX_DROPIN_LBFGSB_H
+#define LBFGSX_DROPIN_LBFGSB_H
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <stdexcept>
+#include <vector>
+
+#include "LBFGSpp/BFGSMat.h"
+#include "LBFGSpp/Cauchy.h"
+#include "LBFGSpp/Device.h"
+#include "LBFGSpp/LineSearchMoreThuente.h"
+#include "LBFGSpp/Param.h"
+#include "LBFGSpp/SubspaceMin.h"
+
+namespace LBFGSpp {
+
+template <typename Scalar, template <class> class LineSearch = LineSearchMoreThuente>
+class LBFGSBSolver
+{
+    const LBFGSBParam<Scalar>& m_param;
+    DeviceState<Scalar> m_dev;
+    BFGSMatB<Scalar> m_bfgs;
+    std::vector<Scalar> m_fx;
+    std::vector<Scalar> m_grad_host;
+    Scalar m_projgnorm = Scalar(0);
+    int m_device = 0;
+    int m_nfev = 0;
+    std::function<void(int, Scalar, DeviceState<Scalar>&)> m_trace;
+    std::function<void(int)> m_iter_hook;
+
+public:
+    struct Stats  // instrumentation of the last minimize()
+    {
+        long long gcp_crossings = 0;
+        long long submin_sweeps = 0;
+        long long submin_calls = 0;
+        long long submin_unconverged = 0;
+        long long resets = 0;
+    };
+
+private:
+    Stats m_stats;
+
+    template <typename Foo, typename HostVec>
+    int run(Foo& f, Scalar& fx)
+    {
+        using std::abs;
+        using std::sqrt;
+        detail::Evaluator<Scalar, Foo, HostVec> ev(f, m_dev);
+        if (m_trace)
+            ev.on_eval = [this](int k, Scalar v) { m_trace(k, v, m_dev); };
+        lbfgsx_ctx* c = m_dev.ctx();
+        m_stats = Stats();
+
+        detail::check(lbfgsx_b_force_bounds(c));                        // (:128)
+        m_bfgs.reset(c, m_param.m);                                     // (:131)
+        ev.prepare();
+        const int fpast = m_param.past;
+        if (fpast > 0)
+            m_fx.assign(size_t(fpast), Scalar(0));
+
+        Scalar xnorm2;
+        ev.initial_bounded(fx, m_projgnorm, xnorm2);                    // (:137-138)
+        if (fpast > 0)
+            m_fx[0] = fx;
+        m_nfev = ev.nfev();
+        if (m_projgnorm <= m_param.epsilon || m_projgnorm <= m_param.epsilon_rel * sqrt(xnorm2))
+            return 1;
+
+        typename Cauchy<Scalar>::Result gcp;
+        Cauchy<Scalar>::get_cauchy_point(m_bfgs, gcp);                  // (:154)
+        m_stats.gcp_crossings += gcp.crossings;
+        detail::check(lbfgsx_b_dir_from_xcp(c, 1));                     // drt = normalize(xcp - x) (:163-164)
+        constexpr Scalar eps = std::numeric_limits<Scalar>::epsilon();
+
+        int k = 1;
+        for (;;)
+        {
+            detail::check(lbfgsx_ls_begin(c));                          // xp = x; gradp = grad (:174-175)
+            double dgd = 0, smax = 0;
+            detail::check(lbfgsx_b_dg_maxstep(c, &dgd, &smax));         // (:176-179)
+            Scalar dg = Scalar(dgd), step_max = Scalar(smax);
+            if (dg >= Scalar(0) || step_max <= m_param.min_step)        // pathological direction (:188-197)
+            {
+                detail::check(lbfgsx_b_dir_from_xcp(c, 0));
+                m_bfgs.reset(c, m_param.m);
+                detail::check(lbfgsx_b_dg_maxstep(c, &dgd, &smax));
+                dg = Scalar(dgd);
+                step_max = Scalar(smax);
+                m_stats.resets++;
+            }
+            step_max = std::min(m_param.max_step, step_max);            // (:200-202)
+            Scalar step = Scalar(1);
+            step = std::min(step, step_max);
+            LineSearch<Scalar>::LineSearch(ev, m_param, step_max, step, fx, dg);
+            m_nfev = ev.nfev();
+
+            double pg = 0, x2 = 0, syd = 0, yyd = 0;
+            detail::check(lbfgsx_b_post_linesearch(c, &pg, &x2, &syd, &yyd));   // (:206,235-237)
+            m_projgnorm = Scalar(pg);
+            if (m_projgnorm <= m_param.epsilon || m_projgnorm <= m_param.epsilon_rel * sqrt(Scalar(x2)))
+                return k;
+            if (fpast > 0)
+            {
+                const Scalar old = m_fx[size_t(k % fpast)];
+                if (k >= fpast && abs(old - fx) <= m_param.delta * std::max(std::max(abs(fx), abs(old)), Scalar(1)))
+                    return k;
+                m_fx[size_t(k % fpast)] = fx;
+            }
+            if (m_param.max_iterations != 0 && k >= m_param.max_iterations)
+                return k;
+
+            if (Scalar(syd) > eps * Scalar(yyd))                        // (:237-238)
+                m_bfgs.add_correction(Scalar(syd), Scalar(yyd));
+
+            detail::check(lbfgsx_b_force_bounds(c));                    // (:240)
+            Cauchy<Scalar>::get_cauchy_point(m_bfgs, gcp);              // (:241)
+            m_stats.gcp_crossings += gcp.crossings;
+            typename SubspaceMin<Scalar>::Stats st;
+            SubspaceMin<Scalar>::subspace_minimize(m_bfgs, gcp, m_param.max_submin, &st);  // (:249-250)
+            m_stats.submin_calls++;
+            m_stats.submin_sweeps += st.sweeps;
+            m_stats.submin_unconverged += st.converged ? 0 : 1;
+            if (m_iter_hook)
+                m_iter_hook(k);
+            k++;
+        }
+    }
+
+public:
+    LBFGSBSolver(const LBFGSBParam<Scalar>& param) : m_param(param) { m_param.check_param(); }
+
+    void set_device(int device) { m_device = device; }
+    void set_trace(std::function<void(int, Scalar, DeviceState<Scalar>&)> cb) { m_trace = std::move(cb); }
+    void set_iteration_hook(std::function<void(int)> cb) { m_iter_hook = std::move(cb); }
+    DeviceState<Scalar>& device_state() { return m_dev; }
+    int num_evaluations() const { return m_nfev; }
+    const Stats& stats() const { return m_stats; }
+
+    // Reference signature (LBFGSB.h:116-117); x, lb, ub: host vectors with data()/size()
+    template <typename Foo, typename Vec>
+    inline int minimize(Foo& f, Vec& x, Scalar& fx, const Vec& lb, const Vec& ub)
+    {
+        const std::int64_t n = std::int64_t(x.size());
+        if (std::int64_t(lb.size()) != n || std::int64_t(ub.size()) != n)
+            throw std::invalid_argument("'lb' and 'ub' must have the same size as 'x'");
+        m_dev.ensure(n, m_param.m, LBFGSX_FLAG_BOUNDED, m_device);
+        m_dev.upload(LBFGSX_VEC_X, x.data());
+        m_dev.upload(LBFGSX_VEC_LB, lb.data());
+        m_dev.upload(LBFGSX_VEC_UB, ub.data());
+        const int k = run<Foo, Vec>(f, fx);
+        m_dev.download(LBFGSX_VEC_X, x.data());
+        return k;
+    }
+
+    // Device-resident variant: x0, lb, ub already in LBFGSX_VEC_X / _LB / _UB of device_state()
+    template <typename Foo>
+    inline int minimize_resident(Foo& f, std::int64_t n, Scalar& fx)
+    {
+        m_dev.ensure(n, m_param.m, LBFGSX_FLAG_BOUNDED, m_device);
+        return run<Foo, std::vector<Scalar> >(f, fx);
+    }
+    void prepare_resident(std::int64_t n) { m_dev.ensure(n, m_param.m, LBFGSX_FLAG_BOUNDED, m_device); }
+
+    const std::vector<Scalar>& final_grad()
+    {
+        m_grad_host.resize(size_t(m_dev.size()));
+        m_dev.download(LBFGSX_VEC_G, m_grad_host.data());
+        return m_grad_host;
+    }
+    Scalar final_grad_norm() const { return m_projgnorm; }
+};
+
+}  // namespace LBFGSpp
+
+#endif  // LBFGSX_DROPIN_LBFGSB_H

@@ -1,0 +1,183 @@
+// include/LBFGSpp/BFGSMat.h -- host half of the limited-memory matrix for L-BFGS-B.
+//
+// The reference's BFGSMat<Scalar, true> (/root/reference/include/LBFGSpp/BFGSMat.h) owns the n x m stores
+// S, Y *and* the small compact-form objects.  Here S, Y (and ys, theta used by the two-loop recursion) live
+// in HBM inside the device context; this class keeps only the O(m^2) part on the host:
+//   m_permMinv (2m x 2m, storage-slot order, un-scaled S'S block)      BFGSMat.h:51,74-76,99-146
+//   its Bunch-Kaufman factorisation and apply_Mv                        BFGSMat.h:144,361-376
+//   the `mid` matrix assembly of solve_PtBP                            BFGSMat.h:539-563
+// and drives the O(n) operators through the C ABI (lbfgsx_b_*).
+#ifndef LBFGSX_DROPIN_BFGSMAT_H
+#define LBFGSX_DROPIN_BFGSMAT_H
+
+#include <vector>
+
+#include "BKLDLT.h"
+#include "Device.h"
+
+namespace LBFGSpp {
+
+template <typename Scalar>
+class BFGSMatB
+{
+    int m_m = 0, m_ncorr = 0, m_ptr = 0;
+    Scalar m_theta = Scalar(1);
+    std::vector<Scalar> m_permMinv;  // column-major 2m x 2m
+    BKLDLT<Scalar> m_solver;
+    lbfgsx_ctx* m_c = nullptr;
+
+    Scalar& Minv(int i, int j) { return m_permMinv[size_t(j) * size_t(2 * m_m) + size_t(i)]; }
+    const Scalar& Minv(int i, int j) const { return m_permMinv[size_t(j) * size_t(2 * m_m) + size_t(i)]; }
+
+public:
+    // BFGSMat::reset (BFGSMat.h:61-78) -- host part; the device part is lbfgsx_bfgs_reset
+    void reset(lbfgsx_ctx* c, int m)
+    {
+        m_c = c;
+        m_m = m;
+        m_theta = Scalar(1);
+        m_ncorr = 0;
+        m_ptr = m;
+        m_permMinv.assign(size_t(4) * size_t(m) * size_t(m), Scalar(0));
+        for (int i = 0; i < 2 * m; i++)
+            Minv(i, i) = Scalar(1);
+        detail::check(lbfgsx_bfgs_reset(c));
+    }
+
+    Scalar theta() const { return m_theta; }
+    int num_corrections() const { return m_ncorr; }
+    int m() const { return m_m; }
+
+    // BFGSMat::add_correction (BFGSMat.h:81-147).  The pair (s, y) already sits in the device's spare history
+    // column with ys = s.y and theta = y.y/s.y computed by the post-line-search kernel; the device commit is an
+    // index rotation.  The LBFGSB tail needs S's_new and the s_new.y_j row: one masked multi-dot pass.
+    void add_correction(Scalar sy, Scalar yy)
+    {
+        const int loc = m_ptr % m_m;
+        detail::check(lbfgsx_commit_correction(m_c));
+        m_theta = yy / sy;
+        if (m_ncorr < m_m)
+            m_ncorr++;
+        m_ptr = loc + 1;
+
+        double sd[64], yd[64];
+        detail::check(lbfgsx_b_correction_dots(m_c, sd, yd));
+
+        Minv(loc, loc) = -sy;                                   // -D                        (:107)
+        for (int j = 0; j < m_ncorr; j++)                       // S'S row and column of loc (:111-113)
+        {
+            Minv(m_m + loc, m_m + j) = Scalar(sd[j]);
+            Minv(m_m + j, m_m + loc) = Scalar(sd[j]);
+        }
+        const int len = m_ncorr - 1;
+        if (m_ncorr >= m_m)                                     // forget the overwritten y    (:129-130)
+            for (int i = 0; i < m_m; i++)
+                Minv(m_m + i, loc) = Scalar(0);
+        int yloc = (loc + m_m - 1) % m_m;                       // row of L for the new s      (:135-140)
+        for (int i = 0; i < len; i++)
+        {
+            Minv(m_m + loc, yloc) = Scalar(yd[yloc]);
+            yloc = (yloc + m_m - 1) % m_m;
+        }
+        // factorise with the S'S block scaled by theta, then undo the scaling (:143-145)
+        for (int j = 0; j < m_m; j++)
+            for (int i = 0; i < m_m; i++)
+                Minv(m_m + i, m_m + j) *= m_theta;
+        m_solver.compute(m_permMinv.data(), 2 * m_m, 2 * m_m);
+        for (int j = 0; j < m_m; j++)
+            for (int i = 0; i < m_m; i++)
+                Minv(m_m + i, m_m + j) /= m_theta;
+    }
+
+    // apply_Mv (BFGSMat.h:361-376): pad the 2c-vector to 2m, solve, un-pad
+    void apply_Mv(const std::vector<Scalar>& v, std::vector<Scalar>& res) const
+    {
+        res.assign(size_t(2 * m_ncorr), Scalar(0));
+        if (m_ncorr < 1)
+            return;
+        std::vector<Scalar> pad(size_t(2 * m_m), Scalar(0));
+        for (int j = 0; j < m_ncorr; j++)
+        {
+            pad[size_t(j)] = v[size_t(j)];
+            pad[size_t(m_m + j)] = v[size_t(m_ncorr + j)];
+        }
+        m_solver.solve_inplace(pad.data());
+        for (int j = 0; j < m_ncorr; j++)
+        {
+            res[size_t(j)] = pad[size_t(j)];
+            res[size_t(m_ncorr + j)] = pad[size_t(m_m + j)];
+        }
+    }
+
+    // raw masked W'v from the device, then the theta scaling of the S half:
+    //   theta_first = true : tail = theta * (S'v)   (apply_Wtv, BFGSMat.h:319)
+    //   theta_first = false: tail = (S'v) * theta   (apply_WtPv :428, compute_FtBAb :517, apply_PtBQv :609)
+    void Wtv(int vsel, int mask, bool theta_first, std::vector<Scalar>& res, std::int64_t* nnz = nullptr) const
+    {
+        res.assign(size_t(2 * m_ncorr), Scalar(0));
+        double raw[80];
+        detail::check(lbfgsx_b_wtv(m_c, vsel, mask, raw, nnz));
+        for (int j = 0; j < m_ncorr; j++)
+        {
+            res[size_t(j)] = Scalar(raw[j]);
+            const Scalar sj = Scalar(raw[m_ncorr + j]);
+            res[size_t(m_ncorr + j)] = theta_first ? (m_theta * sj) : (sj * m_theta);
+        }
+    }
+
+    // M*v with the theta scaling of the S half that precedes a W_P * (.) product (:446,475,591,612)
+    void Mv_scaled(const std::vector<Scalar>& v, std::vector<double>& coef) const
+    {
+        std::vector<Scalar> r;
+        apply_Mv(v, r);
+        coef.assign(size_t(2 * m_ncorr), 0.0);
+        for (int j = 0; j < m_ncorr; j++)
+        {
+            coef[size_t(j)] = double(r[size_t(j)]);
+            coef[size_t(m_ncorr + j)] = double(r[size_t(m_ncorr + j)] * m_theta);
+        }
+    }
+
+    // solve_PtBP (BFGSMat.h:529-565) on the coordinates selected by `mask`; v is a device-side selector.
+    // Result goes to vecy on those coordinates.
+    void solve_PtBP(int mask, std::int64_t nP, int vsel) const
+    {
+        if (m_ncorr < 1 || nP < 1)
+        {
+            detail::check(lbfgsx_b_wcombine(m_c, LBFGSX_CB_SOLVE, mask, vsel, nullptr, double(m_theta)));
+            return;
+        }
+        const int c = m_ncorr, t = 2 * c;
+        std::vector<double> G(size_t(t) * size_t(t), 0.0);
+        detail::check(lbfgsx_b_gram(m_c, mask, G.data()));
+        auto Gm = [&](int i, int j) { return Scalar(G[size_t(i) * size_t(t) + size_t(j)]); };
+        std::vector<Scalar> mid(size_t(t) * size_t(t), Scalar(0));
+        auto Mid = [&](int i, int j) -> Scalar& { return mid[size_t(j) * size_t(t) + size_t(i)]; };
+        for (int j = 0; j < c; j++)
+            for (int i = j; i < c; i++)
+                Mid(i, j) = Minv(i, j) - Gm(i, j) / m_theta;                        // (:543-547)
+        for (int j = 0; j < c; j++)
+            for (int i = 0; i < c; i++)
+                Mid(c + i, j) = Minv(m_m + i, j) - Gm(c + i, j);                     // (:549-550)
+        for (int j = 0; j < c; j++)
+            for (int i = j; i < c; i++)
+                Mid(c + i, c + j) = m_theta * (Minv(m_m + i, m_m + j) - Gm(c + i, c + j));  // (:552-556)
+        BKLDLT<Scalar> midsolver(mid.data(), t, t);
+        std::vector<Scalar> WPv;
+        Wtv(vsel, mask, false, WPv);          // WP'v ; tail *= theta        (:560-561)
+        midsolver.solve_inplace(WPv.data());
+        std::vector<double> coef(static_cast<size_t>(t));
+        for (int j = 0; j < c; j++)
+        {
+            coef[size_t(j)] = double(WPv[size_t(j)]);
+            coef[size_t(c + j)] = double(WPv[size_t(c + j)] * m_theta);              // (:563)
+        }
+        detail::check(lbfgsx_b_wcombine(m_c, LBFGSX_CB_SOLVE, mask, vsel, coef.data(), double(m_theta)));
+    }
+
+    lbfgsx_ctx* ctx() const { return m_c; }
+};
+
+}  // namespace LBFGSpp
+
+#endif  // LBFGSX_DROPIN_BFGSMAT_H

@@ -1,0 +1,173 @@
+// include/LBFGSpp/Cauchy.h -- generalized Cauchy point for L-BFGS-B with the O(n) work on the device.
+//
+// Reference: /root/reference/include/LBFGSpp/Cauchy.h:86-284.  Split used here:
+//   device  (lbfgsx_b_cauchy_build)  break points, vecd, xcp = x0, d.d, W'd, radix sort of the finite positive
+//                                    break points (replaces the host loop :111-129 and std::sort :132-133)
+//   host    (this file)              the piecewise-quadratic search over the *crossed* break points (:183-256):
+//                                    a strictly sequential O(#crossed * m^2) scalar recurrence, fed by chunks of
+//                                    the sorted list gathered on the device (brk, g, z, W row) -- typically a few
+//                                    hundred crossings per call after the first iterations
+//   device  (lbfgsx_b_cauchy_finish) xcp on crossed / free coordinates and the free / newly-active state byte
+//                                    from the crossing threshold (:201-206,219-233,265-282)
+// Scalars keep the reference's evaluation order; short dot products use the order-independent host accumulator.
+#ifndef LBFGSX_DROPIN_CAUCHY_H
+#define LBFGSX_DROPIN_CAUCHY_H
+
+#include <algorithm>
+#include <cstdint>
+#include <limits>
+#include <vector>
+
+#include "BFGSMat.h"
+
+namespace LBFGSpp {
+
+template <typename Scalar>
+class Cauchy
+{
+    // sorted break points streamed from the device in geometrically growing chunks
+    class Stream
+    {
+        lbfgsx_ctx* m_c;
+        std::int64_t m_nord, m_have = 0;
+        int m_nc;
+        std::vector<double> m_brk, m_g, m_z, m_w;
+        std::int64_t m_next_chunk = 512;
+
+    public:
+        Stream(lbfgsx_ctx* c, std::int64_t nord, int ncorr) : m_c(c), m_nord(nord), m_nc(ncorr) {}
+        void need(std::int64_t k)
+        {
+            while (k >= m_have && m_have < m_nord)
+            {
+                const std::int64_t cnt = std::min<std::int64_t>(m_next_chunk, m_nord - m_have);
+                m_brk.resize(size_t(m_have + cnt));
+                m_g.resize(size_t(m_have + cnt));
+                m_z.resize(size_t(m_have + cnt));
+                m_w.resize(size_t(m_have + cnt) * size_t(2 * m_nc));
+                detail::check(lbfgsx_b_cauchy_chunk(m_c, m_have, cnt, m_brk.data() + m_have, m_g.data() + m_have,
+                                                    m_z.data() + m_have, nullptr,
+                                                    m_nc ? m_w.data() + size_t(m_have) * size_t(2 * m_nc) : nullptr));
+                m_have += cnt;
+                m_next_chunk = std::min<std::int64_t>(m_next_chunk * 8, std::int64_t(1) << 22);
+            }
+        }
+        Scalar brk(std::int64_t k) { need(k); return Scalar(m_brk[size_t(k)]); }
+        Scalar g(std::int64_t k) { need(k); return Scalar(m_g[size_t(k)]); }
+        Scalar z(std::int64_t k) { need(k); return Scalar(m_z[size_t(k)]); }
+        const double* w(std::int64_t k) { need(k); return m_w.data() + size_t(k) * size_t(2 * m_nc); }
+    };
+
+public:
+    struct Result
+    {
+        std::vector<Scalar> vecc;      // c = W'(xcp - x0), 2*ncorr entries
+        std::int64_t nact = 0;         // |newact_set|
+        std::int64_t nfree = 0;        // |fv_set|
+        std::int64_t crossings = 0;    // break points crossed (instrumentation)
+    };
+
+    // xcp and the state byte are left on the device; vecc and the set sizes are returned
+    static void get_cauchy_point(const BFGSMatB<Scalar>& bfgs, Result& out)
+    {
+        lbfgsx_ctx* c = bfgs.ctx();
+        const int ncorr = bfgs.num_corrections();
+        const Scalar theta = bfgs.theta();
+        const Scalar inf = std::numeric_limits<Scalar>::infinity();
+        out.vecc.assign(size_t(2 * ncorr), Scalar(0));
+        out.nact = out.nfree = out.crossings = 0;
+
+        std::int64_t nfree = 0, nord = 0;
+        double dd = 0;
+        double wtd[80];
+        detail::check(lbfgsx_b_cauchy_build(c, &nfree, &nord, &dd, wtd));
+        if (nfree < 1 && nord < 1)
+        {
+            // every coordinate sits on its bound: xcp = x0, empty sets (:140-145)
+            detail::check(lbfgsx_b_cauchy_finish(c, 0.0, 0.0, 0, &out.nact, &out.nfree));
+            return;
+        }
+
+        // p = W'd (:152), f' = -d'd (:154), f'' = -theta f' - p'Mp (:156-158)
+        std::vector<Scalar> vecp(size_t(2 * ncorr)), cache, wact(size_t(2 * ncorr));
+        for (int j = 0; j < ncorr; j++)
+        {
+            vecp[size_t(j)] = Scalar(wtd[j]);
+            vecp[size_t(ncorr + j)] = theta * Scalar(wtd[ncorr + j]);
+        }
+        Scalar fp = -Scalar(dd);
+        bfgs.apply_Mv(vecp, cache);
+        Scalar fpp = -theta * fp - detail::host_dot(vecp.data(), cache.data(), 2 * ncorr);
+        Scalar deltatmin = -fp / fpp;
+
+        Stream ord(c, nord, ncorr);
+        Scalar il = Scalar(0);
+        std::int64_t b = 0;
+        Scalar iu = (nord < 1) ? inf : ord.brk(0);
+        Scalar deltat = iu - il;
+        bool crossed_all = false;
+        Scalar t_cross = Scalar(0);
+
+        while (deltatmin >= deltat)
+        {
+            for (int j = 0; j < 2 * ncorr; j++)                       // vecc += deltat * vecp (:186)
+                out.vecc[size_t(j)] = out.vecc[size_t(j)] + deltat * vecp[size_t(j)];
+            // tie group [b, e] of break points equal to iu (:193-194)
+            std::int64_t e = b;
+            while (e < nord && !(ord.brk(e) > iu))
+                e++;
+            e -= 1;
+            if (nfree == 0 && e == nord - 1)                          // everything crossed (:198-213)
+            {
+                crossed_all = true;
+                t_cross = iu;
+                out.crossings += (e - b + 1);
+                break;
+            }
+            fp += deltat * fpp;                                        // (:218)
+            for (std::int64_t i = b; i <= e; i++)                      // (:219-235)
+            {
+                const Scalar zact = ord.z(i), gact = ord.g(i), ggact = gact * gact;
+                const double* w = ord.w(i);
+                for (int j = 0; j < ncorr; j++)
+                {
+                    wact[size_t(j)] = Scalar(w[j]);
+                    wact[size_t(ncorr + j)] = Scalar(w[ncorr + j]) * theta;   // Wb(): tail *= theta (BFGSMat.h:333)
+                }
+                bfgs.apply_Mv(wact, cache);
+                fp += ggact + theta * gact * zact - gact * detail::host_dot(cache.data(), out.vecc.data(), 2 * ncorr);
+                fpp -= (theta * ggact + 2 * gact * detail::host_dot(cache.data(), vecp.data(), 2 * ncorr) +
+                        ggact * detail::host_dot(cache.data(), wact.data(), 2 * ncorr));
+                for (int j = 0; j < 2 * ncorr; j++)
+                    vecp[size_t(j)] = vecp[size_t(j)] + gact * wact[size_t(j)];
+            }
+            out.crossings += (e - b + 1);
+            deltatmin = -fp / fpp;                                     // (:240)
+            il = iu;
+            t_cross = iu;
+            b = e + 1;
+            if (b >= nord)
+                break;
+            iu = ord.brk(b);
+            deltat = iu - il;
+        }
+
+        const Scalar eps = std::numeric_limits<Scalar>::epsilon();
+        if (fpp < eps)                                                 // (:260-262)
+            deltatmin = -fp / eps;
+
+        Scalar tfinal = Scalar(0);
+        if (!crossed_all)                                              // (:265-282)
+        {
+            deltatmin = std::max(deltatmin, Scalar(0));
+            for (int j = 0; j < 2 * ncorr; j++)
+                out.vecc[size_t(j)] = out.vecc[size_t(j)] + deltatmin * vecp[size_t(j)];
+            tfinal = il + deltatmin;
+        }
+        detail::check(lbfgsx_b_cauchy_finish(c, double(t_cross), double(tfinal), crossed_all ? 1 : 0, &out.nact, &out.nfree));
+    }
+};
+
+}  // namespace LBFGSpp
+
+#endif  // LBFGSX_DROPIN_CAUCHY_H

@@ -192,6 +192,25 @@ public:
         if (on_eval) on_eval(m_nfev, fx);
         m_nfev++;
     }
+    // fx = f(x, grad); ||P(x-g,l,u)-x||_inf; |x|^2     (LBFGSB.h:137-138,146)
+    void initial_bounded(Scalar& fx, Scalar& projgnorm, Scalar& xnorm2)
+    {
+        double r0 = 0, r1 = 0, r2 = 0;
+        if constexpr (is_builtin)
+        {
+            check(lbfgsx_b_eval(m_s.ctx(), m_f.id, &r0, &r1, &r2));
+        }
+        else
+        {
+            r0 = double(call_user(LBFGSX_VEC_X, LBFGSX_VEC_G));
+            check(lbfgsx_b_norms(m_s.ctx(), &r1, &r2));
+        }
+        fx = Scalar(r0);
+        projgnorm = Scalar(r1);
+        xnorm2 = Scalar(r2);
+        if (on_eval) on_eval(m_nfev, fx);
+        m_nfev++;
+    }
     // x = xp + step*drt; fx = f(x, grad); dg = grad.dot(drt)
     void trial(Scalar step, Scalar& fx, Scalar& dg)
     {

@@ -1,0 +1,154 @@
+// include/LBFGSpp/SubspaceMin.h -- exact box-constrained subspace minimisation (BOXCQP) for L-BFGS-B, host
+// control flow over masked device operators.
+//
+// Reference: /root/reference/include/LBFGSpp/SubspaceMin.h:122-302 (and the BFGSMat operators it calls:
+// compute_FtBAb :486-522, solve_PtBP :529-565, apply_PtBQv :570-594, apply_WtPv :382-430,
+// apply_PtWMv :435-460).  The reference gathers rows of W for every index set (Wb(IndexSet), :338-358) and
+// works on compacted vectors; here the sets F/L/U/P are bits of a per-coordinate state byte, the vectors stay
+// full length in HBM and each operator is one coalesced pass over the S/Y columns:
+//   W_set' v      -> lbfgsx_b_wtv      (2c order-independent dot products)
+//   W_P' W_P      -> lbfgsx_b_gram     (masked Gram, 4x4 register tiles)
+//   W_set * coef  -> lbfgsx_b_wcombine (row-wise, with the reference's element-wise epilogue fused in)
+// The 2c x 2c algebra (M, mid, their LDL' solves) is host scalar work in BFGSMatB.
+#ifndef LBFGSX_DROPIN_SUBSPACE_MIN_H
+#define LBFGSX_DROPIN_SUBSPACE_MIN_H
+
+#include <cstdint>
+#include <limits>
+#include <vector>
+
+#include "BFGSMat.h"
+#include "Cauchy.h"
+
+namespace LBFGSpp {
+
+template <typename Scalar>
+class SubspaceMin
+{
+    // -F'W M (W'AA'd) then + g_F  -> vecc on the free set   (SubspaceMin.h:144-156, BFGSMat.h:486-522)
+    static void linear_term(const BFGSMatB<Scalar>& bfgs, const typename Cauchy<Scalar>::Result& gcp)
+    {
+        lbfgsx_ctx* c = bfgs.ctx();
+        const int nc = bfgs.num_corrections();
+        if (nc < 1 || gcp.nact < 1 || gcp.nfree < 1)
+        {
+            detail::check(lbfgsx_b_wcombine(c, LBFGSX_CB_LINEAR, LBFGSX_ST_FREE, 0, nullptr, double(bfgs.theta())));
+            return;
+        }
+        std::vector<Scalar> rhs;
+        if (gcp.nact <= gcp.nfree)
+            bfgs.Wtv(LBFGSX_VS_DRT, LBFGSX_ST_NEWACT, false, rhs);      // W_A'(A'd)            (:503-507)
+        else
+        {
+            bfgs.Wtv(LBFGSX_VS_DRT, LBFGSX_ST_FREE, false, rhs);        // W'd - W_F'(F'd)      (:511-518)
+            for (int j = 0; j < 2 * nc; j++)
+                rhs[size_t(j)] = gcp.vecc[size_t(j)] - rhs[size_t(j)];
+        }
+        std::vector<double> coef;
+        bfgs.Mv_scaled(rhs, coef);
+        detail::check(lbfgsx_b_wcombine(c, LBFGSX_CB_LINEAR, LBFGSX_ST_FREE, 0, coef.data(), double(bfgs.theta())));
+    }
+
+    // rhs += P'B Q v  for Q = L (v = vecl) or Q = U (v = vecu)   (SubspaceMin.h:236-241, BFGSMat.h:570-594)
+    static void add_PtBQv(const BFGSMatB<Scalar>& bfgs, int qmask, int vsel, std::int64_t nP, std::int64_t nQ)
+    {
+        if (bfgs.num_corrections() < 1 || nP < 1 || nQ < 1)
+            return;
+        std::vector<Scalar> WQtv;
+        std::int64_t nnz = 0;
+        bfgs.Wtv(vsel, qmask, false, WQtv, &nnz);
+        if (nnz < 1)  // test_zero: every v entry is zero -> the product is known to be zero (:388-412)
+            return;
+        std::vector<double> coef;
+        bfgs.Mv_scaled(WQtv, coef);
+        detail::check(lbfgsx_b_wcombine(bfgs.ctx(), LBFGSX_CB_RHS_ADD, LBFGSX_ST_P, 0, coef.data(), double(bfgs.theta())));
+    }
+
+public:
+    struct Stats
+    {
+        int sweeps = 0;
+        bool converged = true;
+    };
+
+    // On entry xcp / state byte / vecc describe the generalized Cauchy point; on exit the device's drt holds
+    // xsm - x0.  `maxit` = LBFGSBParam::max_submin.
+    static void subspace_minimize(const BFGSMatB<Scalar>& bfgs, const typename Cauchy<Scalar>::Result& gcp, int maxit,
+                                  Stats* stats = nullptr)
+    {
+        lbfgsx_ctx* c = bfgs.ctx();
+        const Scalar theta = bfgs.theta();
+        detail::check(lbfgsx_b_sub_begin(c));                           // drt = xcp - x0 (:130)
+        const std::int64_t nfree = gcp.nfree;
+        if (nfree < 1)
+            return;
+
+        linear_term(bfgs, gcp);                                         // vecc (:144-156)
+        bfgs.solve_PtBP(LBFGSX_ST_FREE, nfree, LBFGSX_VS_NEG_CF);       // vecy = -inv(B[F,F]) c (:159)
+        std::int64_t cnt[4];
+        detail::check(lbfgsx_b_sub_check(c, cnt));
+        if (cnt[0] == 0)                                                // in_bounds (:162-166)
+        {
+            detail::check(lbfgsx_b_sub_op(c, LBFGSX_SO_ASSIGN_Y));
+            return;
+        }
+        detail::check(lbfgsx_b_sub_op(c, LBFGSX_SO_SAVE_FALLBACK));     // yfallback, lambda = mu = 0 (:170-172)
+
+        int k;
+        for (k = 0; k < maxit; k++)
+        {
+            std::int64_t nL = 0, nU = 0, nP = 0;
+            detail::check(lbfgsx_b_sub_partition(c, &nL, &nU, &nP));    // (:194-219)
+            if (nP > 0)                                                 // (:229-245)
+            {
+                detail::check(lbfgsx_b_sub_op(c, LBFGSX_SO_RHS_INIT));
+                add_PtBQv(bfgs, LBFGSX_ST_L, LBFGSX_VS_LBOUND, nP, nL);
+                add_PtBQv(bfgs, LBFGSX_ST_U, LBFGSX_VS_UBOUND, nP, nU);
+                bfgs.solve_PtBP(LBFGSX_ST_P, nP, LBFGSX_VS_NEG_RHS);
+            }
+            if (nL > 0 || nU > 0)                                       // multipliers (:247-268)
+            {
+                std::vector<Scalar> Fy;
+                bfgs.Wtv(LBFGSX_VS_Y, LBFGSX_ST_FREE, false, Fy);
+                std::vector<double> coef;
+                bfgs.Mv_scaled(Fy, coef);
+                const double* cf = (bfgs.num_corrections() < 1) ? nullptr : coef.data();
+                if (nL > 0)
+                    detail::check(lbfgsx_b_wcombine(c, LBFGSX_CB_LAMBDA, LBFGSX_ST_L, 0, cf, double(theta)));
+                if (nU > 0)
+                    detail::check(lbfgsx_b_wcombine(c, LBFGSX_CB_MU, LBFGSX_ST_U, 0, cf, double(theta)));
+            }
+            detail::check(lbfgsx_b_sub_check(c, cnt));                  // (:271)
+            if (cnt[1] == 0 && cnt[2] == 0 && cnt[3] == 0)
+                break;
+        }
+        if (stats)
+        {
+            stats->sweeps = (k < maxit) ? k + 1 : maxit;
+            stats->converged = (k < maxit);
+        }
+
+        if (k >= maxit)                                                 // fallback ladder (:276-296)
+        {
+            const Scalar eps = std::numeric_limits<Scalar>::epsilon();
+            double dg = 0;
+            detail::check(lbfgsx_b_sub_op(c, LBFGSX_SO_CLAMP_Y));
+            detail::check(lbfgsx_b_sub_op(c, LBFGSX_SO_ASSIGN_Y));
+            detail::check(lbfgsx_b_dot_drt_g(c, &dg));
+            if (Scalar(dg) <= -eps)
+                return;
+            detail::check(lbfgsx_b_sub_op(c, LBFGSX_SO_CLAMP_FB));
+            detail::check(lbfgsx_b_sub_op(c, LBFGSX_SO_ASSIGN_Y));
+            detail::check(lbfgsx_b_dot_drt_g(c, &dg));
+            if (Scalar(dg) <= -eps)
+                return;
+            detail::check(lbfgsx_b_sub_op(c, LBFGSX_SO_ASSIGN_FB));
+            return;
+        }
+        detail::check(lbfgsx_b_sub_op(c, LBFGSX_SO_ASSIGN_Y));         // (:301)
+    }
+};
+
+}  // namespace LBFGSpp
+
+#endif  // LBFGSX_DROPIN_SUBSPACE_MIN_H

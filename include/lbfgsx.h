@@ -86,6 +86,8 @@ int lbfgsx_bfgs_ncorr(const lbfgsx_ctx* c);
 double lbfgsx_bfgs_theta(const lbfgsx_ctx* c);
 /* BFGSMat::add_correction (BFGSMat.h:81-97) from host-provided s, y (testing / generic callers) */
 int lbfgsx_bfgs_add_correction_host(lbfgsx_ctx* c, const void* s, const void* y);
+/* same, but only stages the pair in the spare column (s.y and y.y returned); lbfgsx_commit_correction adds it */
+int lbfgsx_bfgs_stage_correction_host(lbfgsx_ctx* c, const void* s, const void* y, double* sy, double* yy);
 /* BFGSMat::apply_Hv (BFGSMat.h:276-302): D = a * H * v where v is a named vector; also returns
  * dg = G . D fused into the last pass when v == LBFGSX_VEC_G (LBFGS.h:123 of the next iteration). */
 int lbfgsx_apply_Hv(lbfgsx_ctx* c, int v_which, double a, double* dg);
@@ -114,6 +116,78 @@ int lbfgsx_ls_end(lbfgsx_ctx* c, int use_lo);
 int lbfgsx_post_linesearch(lbfgsx_ctx* c, double* gnorm2, double* xnorm2, double* sy, double* yy);
 /* BFGSMat::add_correction of the pair just formed (BFGSMat.h:81-97): index rotation only */
 int lbfgsx_commit_correction(lbfgsx_ctx* c);
+
+/* ---- L-BFGS-B device operators (contexts created with LBFGSX_FLAG_BOUNDED) ------------------------------
+ * Index sets of the reference (fv_set, newact_set, BOXCQP's L/U/P: std::vector<int>) are a per-coordinate
+ * state byte on the device; every operator streams the column-contiguous S/Y once and applies the mask. */
+enum /* state-byte masks */
+{
+    LBFGSX_ST_FREE = 1, LBFGSX_ST_NEWACT = 2, LBFGSX_ST_L = 4, LBFGSX_ST_U = 8, LBFGSX_ST_P = 16
+};
+enum /* vectors formed on the fly inside masked operators */
+{
+    LBFGSX_VS_DRT = 0,      /* drt = xcp - x0                 (SubspaceMin.h:130)   */
+    LBFGSX_VS_NEG_CF = 1,   /* -vecc                          (SubspaceMin.h:159)   */
+    LBFGSX_VS_NEG_RHS = 2,  /* -rhs                           (SubspaceMin.h:243)   */
+    LBFGSX_VS_LBOUND = 3,   /* vecl = lb - x0                 (SubspaceMin.h:153)   */
+    LBFGSX_VS_UBOUND = 4,   /* vecu = ub - x0                 (SubspaceMin.h:154)   */
+    LBFGSX_VS_Y = 5         /* vecy                                                   */
+};
+enum /* lbfgsx_b_wcombine modes: element-wise epilogue around (W_mask * coef)(i) */
+{
+    LBFGSX_CB_LINEAR = 0,   /* vecc = -W_F M (W'AA'd) + g_F   (BFGSMat.h:521 + SubspaceMin.h:155)        */
+    LBFGSX_CB_SOLVE = 1,    /* vecy = v/theta + W_P coef/theta^2   (BFGSMat.h:535,564)                    */
+    LBFGSX_CB_RHS_ADD = 2,  /* rhs += -W_P coef               (BFGSMat.h:592 + SubspaceMin.h:236-241)    */
+    LBFGSX_CB_LAMBDA = 3,   /* lambda_L = -W_L coef + vecc_L + theta*vecy_L   (SubspaceMin.h:256-258)    */
+    LBFGSX_CB_MU = 4        /* mu_U = -( -W_U coef + vecc_U + theta*vecy_U )  (SubspaceMin.h:265-267)    */
+};
+enum /* lbfgsx_b_sub_op */
+{
+    LBFGSX_SO_SAVE_FALLBACK = 0, LBFGSX_SO_RHS_INIT = 1, LBFGSX_SO_ASSIGN_Y = 2, LBFGSX_SO_CLAMP_Y = 3,
+    LBFGSX_SO_CLAMP_FB = 4, LBFGSX_SO_ASSIGN_FB = 5
+};
+/* force_bounds: x = x.cwiseMax(lb).cwiseMin(ub)  (LBFGSB.h:55-58,128,240) */
+int lbfgsx_b_force_bounds(lbfgsx_ctx* c);
+/* fx = f(x,grad); ||P(x-g,l,u)-x||_inf; x.x   (LBFGSB.h:137-138,146) */
+int lbfgsx_b_eval(lbfgsx_ctx* c, int objective, double* fx, double* projgnorm, double* xnorm2);
+/* the two reductions alone, for objectives evaluated by the caller (device / host functors) */
+int lbfgsx_b_norms(lbfgsx_ctx* c, double* projgnorm, double* xnorm2);
+/* dg = grad.dot(drt); step_max = max_step_size(x,drt,lb,ub)   (LBFGSB.h:68-86,176-179,195-196) */
+int lbfgsx_b_dg_maxstep(lbfgsx_ctx* c, double* dg, double* step_max);
+/* after the line search: proj_grad_norm, x.x, s, y (into the spare column), s.y, y.y  (LBFGSB.h:206,213,235-237) */
+int lbfgsx_b_post_linesearch(lbfgsx_ctx* c, double* projgnorm, double* xnorm2, double* sy, double* yy);
+/* add_correction tail: sdots[j] = S_j.s_new, ydots[j] = Y_j.s_new for slots j < ncorr  (BFGSMat.h:111,138) */
+int lbfgsx_b_correction_dots(lbfgsx_ctx* c, double* sdots, double* ydots);
+/* GCP build: break points, vecd, xcp = x0, radix sort of the finite positive break points; returns the counts
+ * of free (brk = inf) and ordered coordinates, d.d, and the raw W'd dots [Y'd, S'd]  (Cauchy.h:93-133,152-154) */
+int lbfgsx_b_cauchy_build(lbfgsx_ctx* c, int64_t* nfree, int64_t* nord, double* dd, double* wtd);
+/* sorted break points [first, first+count): brk, g, z = bound - x0, index, W row [y_0..y_{c-1}, s_0..s_{c-1}]
+ * for the sequential piecewise-quadratic scan kept on the host (Cauchy.h:183-256) */
+int lbfgsx_b_cauchy_chunk(lbfgsx_ctx* c, int64_t first, int64_t count, double* brk, double* g, double* z, int* idx,
+                          double* wrows);
+/* xcp and the free / newly-active sets from the crossing threshold (Cauchy.h:201-206,219-233,265-282) */
+int lbfgsx_b_cauchy_finish(lbfgsx_ctx* c, double t_cross, double tfinal, int crossed_all, int64_t* nact, int64_t* nfree);
+/* drt = xcp - x0 (SubspaceMin.h:130) */
+int lbfgsx_b_sub_begin(lbfgsx_ctx* c);
+/* raw masked W'v: out[0..c) = Y_j.v, out[c..2c) = S_j.v over coordinates whose state has `mask` bits
+ * (apply_Wtv / apply_WtPv, BFGSMat.h:315-320,382-430); nnz = non-zero entries of v inside the mask */
+int lbfgsx_b_wtv(lbfgsx_ctx* c, int vsel, int mask, double* out, int64_t* nnz);
+/* masked Gram of [Y_P, S_P] (2c x 2c, row-major, symmetric) for solve_PtBP (BFGSMat.h:543-556) */
+int lbfgsx_b_gram(lbfgsx_ctx* c, int mask, double* gram);
+/* masked combine with element-wise epilogue, see LBFGSX_CB_*; coef = NULL means "W term absent" */
+int lbfgsx_b_wcombine(lbfgsx_ctx* c, int mode, int mask, int vsel, const double* coef, double theta);
+/* BOXCQP partition of the free set into L/U/P with the value/multiplier updates (SubspaceMin.h:194-219) */
+int lbfgsx_b_sub_partition(lbfgsx_ctx* c, int64_t* nL, int64_t* nU, int64_t* nP);
+/* counts = {#F outside [l,u], #P outside [l,u], #L with lambda<0, #U with mu<0}  (SubspaceMin.h:60-108) */
+int lbfgsx_b_sub_check(lbfgsx_ctx* c, int64_t counts[4]);
+/* element-wise statements of SubspaceMin.h selected by LBFGSX_SO_* */
+int lbfgsx_b_sub_op(lbfgsx_ctx* c, int op);
+/* copy the per-coordinate state byte (LBFGSX_ST_* bits) to the host: n bytes */
+int lbfgsx_b_download_state(lbfgsx_ctx* c, unsigned char* host);
+/* drt.dot(g) (SubspaceMin.h:281,289) */
+int lbfgsx_b_dot_drt_g(lbfgsx_ctx* c, double* dg);
+/* drt = xcp - x [, drt.normalize()]  (LBFGSB.h:163-164,191) */
+int lbfgsx_b_dir_from_xcp(lbfgsx_ctx* c, int normalize);
 
 /* ---- instrumentation ----------------------------------------------------------------------------------*/
 /* average duration (ms) of the two-loop step kernels since the last reset, measured with HIP events on

@@ -70,6 +70,14 @@ int lbfgsx_solver_prepare(lbfgsx_solver* s, int64_t n);
 lbfgsx_ctx* lbfgsx_solver_ctx(lbfgsx_solver* s);
 /* progress hook: fn(k, user) runs on the host after iteration k has produced the next search direction */
 int lbfgsx_solver_set_iteration_hook(lbfgsx_solver* s, void (*fn)(int, void*), void* user);
+/* test entry: Cauchy::get_cauchy_point + SubspaceMin::subspace_minimize of the drop-in headers on a history of
+ * npairs host-provided corrections; counts = {|newact|, |free|, crossings, BOXCQP sweeps} */
+int lbfgsx_test_cauchy_subspace(int dtype, int64_t n, int m, int npairs, const void* S, const void* Y, const void* x0,
+                                const void* g, const void* lb, const void* ub, int max_submin, void* xcp, double* vecc,
+                                unsigned char* state, void* drt, long long counts[4], char* errbuf, int errlen);
+/* L-BFGS-B instrumentation of the last minimize(): {GCP break points crossed, BOXCQP sweeps, subspace calls,
+ * unconverged subspace calls, BFGS resets, 0, 0, 0} */
+int lbfgsx_solver_stats(lbfgsx_solver* s, long long out[8]);
 /* minimize(): objective = LBFGSX_OBJ_*; a/b host arrays or NULL (resident); x host in/out or NULL (resident:
  * start point in LBFGSX_VEC_X, result left there); lb/ub host arrays or NULL (resident), L-BFGS-B only */
 int lbfgsx_solver_minimize(lbfgsx_solver* s, int objective, int64_t n, const void* a, const void* b, void* x,

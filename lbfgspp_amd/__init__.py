@@ -5,8 +5,9 @@ solver.py        Python mirror of LBFGSSolver / LBFGSBSolver / LBFGSParam over t
 """
 from ._lib import (F32, F64, LS_BACKTRACKING, LS_BRACKETING, LS_MORE_THUENTE, LS_NOCEDAL_WRIGHT,
                    NativeLibraryMissing, load)
-from .solver import (DiagQuadratic, ExtendedRosenbrock, LBFGSBParam, LBFGSParam, LBFGSSolver, TraceBuffer)
+from .solver import (DiagQuadratic, ExtendedRosenbrock, LBFGSBParam, LBFGSBSolver, LBFGSParam, LBFGSSolver,
+                     TraceBuffer)
 
 __all__ = ["F32", "F64", "LS_BACKTRACKING", "LS_BRACKETING", "LS_MORE_THUENTE", "LS_NOCEDAL_WRIGHT",
            "NativeLibraryMissing", "load", "DiagQuadratic", "ExtendedRosenbrock", "LBFGSBParam", "LBFGSParam",
-           "LBFGSSolver", "TraceBuffer"]
+           "LBFGSSolver", "LBFGSBSolver", "TraceBuffer"]

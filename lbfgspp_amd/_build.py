@@ -35,17 +35,17 @@ def _glob(d, exts):
 def build(force=False, verbose=False):
     inc = os.path.join(os.path.dirname(HERE), "include")
     hip_src = sorted(f for f in _glob(CSRC, (".hip",)))
-    deps = _glob(CSRC, (".hip", ".cuh", ".hpp", ".cpp")) + _glob(inc, (".h",))
+    deps = _glob(CSRC, (".hip", ".cuh", ".hpp", ".cpp", ".map")) + _glob(inc, (".h",))
     lib = os.path.join(HERE, "liblbfgsx.so")
     if force or _stale(lib, deps):
-        cmd = [HIPCC] + HIP_FLAGS + hip_src + ["-o", lib]
+        cmd = [HIPCC] + HIP_FLAGS + hip_src + ["-o", lib, "-Wl,--version-script=" + os.path.join(CSRC, "export.map")]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
     sol = os.path.join(HERE, "liblbfgsx_solver.so")
     if force or _stale(sol, deps + [lib]):
         cmd = ["g++"] + CXX_FLAGS + [os.path.join(CSRC, "solver_capi.cpp"), "-o", sol, "-L" + HERE, "-llbfgsx",
-                                     "-Wl,-rpath,$ORIGIN"]
+                                     "-Wl,-rpath,$ORIGIN", "-Wl,--version-script=" + os.path.join(CSRC, "export.map")]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -57,8 +57,8 @@ def load():
         if not os.path.exists(p):
             raise NativeLibraryMissing(
                 "%s not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()')" % p)
-    core = C.CDLL(p_core, mode=C.RTLD_GLOBAL)
-    sol = C.CDLL(p_sol, mode=C.RTLD_GLOBAL)
+    core = C.CDLL(p_core)
+    sol = C.CDLL(p_sol)
     vp, i64, dbl, i32 = C.c_void_p, C.c_int64, C.c_double, C.c_int
     pd = C.POINTER(C.c_double)
 
@@ -108,6 +108,7 @@ def load():
     sig(sol, "lbfgsx_solver_prepare", i32, vp, i64)
     sig(sol, "lbfgsx_solver_ctx", vp, vp)
     sig(sol, "lbfgsx_solver_set_iteration_hook", i32, vp, ITER_HOOK, vp)
+    sig(sol, "lbfgsx_solver_stats", i32, vp, C.POINTER(C.c_longlong * 8))
     sig(sol, "lbfgsx_solver_minimize", i32, vp, i32, i64, vp, vp, vp, vp, vp, C.POINTER(Trace), C.POINTER(Result))
     _core, _solver = core, sol
     return core, sol

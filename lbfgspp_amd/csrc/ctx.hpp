@@ -9,6 +9,7 @@
 #include "../../include/lbfgsx.h"
 #include "reduce.cuh"
 
+struct lbfgsx_ctx;
 namespace lbfgsx {
 
 void set_error(const std::string& msg);
@@ -35,6 +36,9 @@ struct ScLayout
     int out(int k) const { return 2 * (m + 1) + 1 + (2 * m + 2) + k; }  // kernel outputs     [16]
     int total() const { return out(16); }
 };
+
+int bounded_alloc(lbfgsx_ctx* c);   // lbfgsb.hip
+void bounded_free(lbfgsx_ctx* c);
 
 struct EventPair
 {

@@ -1,0 +1,717 @@
+// lbfgspp_amd/csrc/lbfgsb.hip -- C ABI of the L-BFGS-B device operators (include/lbfgsx.h, "L-BFGS-B" block).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "ctx.hpp"
+#include "lbfgs_kernels.cuh"
+#include "lbfgsb_kernels.cuh"
+
+struct lbfgsb_state
+{
+    void *brk = nullptr, *dvec = nullptr, *cF = nullptr, *y = nullptr, *yfb = nullptr, *lam = nullptr, *mu = nullptr,
+         *rhs = nullptr;
+    unsigned char* st = nullptr;
+    void *keys_in = nullptr, *keys_out = nullptr;
+    int *vals_in = nullptr, *vals_out = nullptr;
+    void* sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    int* phys_dev = nullptr;          // logical slot -> physical column, device copy
+    double* dout = nullptr;           // device staging for double outputs [64]
+    void* coef_dev = nullptr;         // T[80]
+    unsigned long long* mslot = nullptr;  // max / min slots
+    // chunk staging for the sequential GCP scan
+    double *g_brk = nullptr, *g_g = nullptr, *g_z = nullptr, *g_w = nullptr;
+    int* g_idx = nullptr;
+    int64_t g_cap = 0;
+    int g_ncorr = 0;
+};
+
+namespace lbfgsx {
+
+#define DISPATCH_T(c, ...)            \
+    do                                \
+    {                                 \
+        if ((c)->dtype == LBFGSX_F64) \
+        {                             \
+            typedef double T;         \
+            __VA_ARGS__               \
+        }                             \
+        else                          \
+        {                             \
+            typedef float T;          \
+            __VA_ARGS__               \
+        }                             \
+    } while (0)
+
+template <class T>
+static inline T* P(void* p) { return static_cast<T*>(p); }
+
+template <class T>
+static BVecs<T> bvecs(lbfgsx_ctx* c)
+{
+    lbfgsb_state* b = c->bstate;
+    BVecs<T> v;
+    v.x0 = P<T>(c->xb[c->cur]);
+    v.g = P<T>(c->gb[c->cur]);
+    v.lb = P<T>(c->lb);
+    v.ub = P<T>(c->ub);
+    v.xcp = P<T>(c->xcp);
+    v.drt = P<T>(c->d);
+    v.brk = P<T>(b->brk);
+    v.dvec = P<T>(b->dvec);
+    v.cF = P<T>(b->cF);
+    v.y = P<T>(b->y);
+    v.yfb = P<T>(b->yfb);
+    v.lam = P<T>(b->lam);
+    v.mu = P<T>(b->mu);
+    v.rhs = P<T>(b->rhs);
+    v.st = b->st;
+    return v;
+}
+
+static int need_bounded(lbfgsx_ctx* c)
+{
+    if (!c->bstate)
+    {
+        set_error("this context was not created with LBFGSX_FLAG_BOUNDED");
+        return LBFGSX_E_LOGIC;
+    }
+    return LBFGSX_OK;
+}
+
+static int upload_phys(lbfgsx_ctx* c)
+{
+    LBFGSX_HIP(hipMemcpyAsync(c->bstate->phys_dev, c->phys.data(), sizeof(int) * size_t(c->m), hipMemcpyHostToDevice, c->stream));
+    return LBFGSX_OK;
+}
+
+static int fetch_doubles(lbfgsx_ctx* c, int k, double* out)
+{
+    LBFGSX_HIP(hipMemcpyAsync(c->hout, c->bstate->dout, sizeof(double) * size_t(k), hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    std::memcpy(out, c->hout, sizeof(double) * size_t(k));
+    return LBFGSX_OK;
+}
+
+template <class T>
+static int fetch_T(lbfgsx_ctx* c, int idx, int k, double* out)
+{
+    LBFGSX_HIP(hipMemcpyAsync(c->hout, P<T>(c->sc) + idx, sizeof(T) * size_t(k), hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    const T* h = static_cast<const T*>(c->hout);
+    for (int i = 0; i < k; i++)
+        out[i] = double(h[i]);
+    return LBFGSX_OK;
+}
+
+static int read_slot(lbfgsx_ctx* c, double* v)
+{
+    unsigned long long bits = 0;
+    LBFGSX_HIP(hipMemcpyAsync(&bits, c->bstate->mslot, sizeof(bits), hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    std::memcpy(v, &bits, sizeof(double));
+    return LBFGSX_OK;
+}
+static int arm_slot(lbfgsx_ctx* c, bool for_min)
+{
+    // max slots start at +0.0, min slots at +inf (bit patterns of non-negative doubles are order preserving)
+    LBFGSX_HIP(hipMemsetAsync(c->bstate->mslot, 0, sizeof(unsigned long long), c->stream));
+    if (for_min)
+    {
+        static const unsigned long long inf_bits = 0x7FF0000000000000ull;
+        LBFGSX_HIP(hipMemcpyAsync(c->bstate->mslot, &inf_bits, sizeof(inf_bits), hipMemcpyHostToDevice, c->stream));
+    }
+    return LBFGSX_OK;
+}
+
+int bounded_alloc(lbfgsx_ctx* c)
+{
+    lbfgsb_state* b = new lbfgsb_state();
+    c->bstate = b;
+    const size_t vbytes = size_t(c->ld) * c->esz;
+    void** vecs[] = {&b->brk, &b->dvec, &b->cF, &b->y, &b->yfb, &b->lam, &b->mu, &b->rhs, &b->keys_in, &b->keys_out};
+    for (void** v : vecs)
+        LBFGSX_HIP(hipMalloc(v, vbytes));
+    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->st), size_t(c->ld)));
+    LBFGSX_HIP(hipMemset(b->st, 0, size_t(c->ld)));
+    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->vals_in), sizeof(int) * size_t(c->ld)));
+    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->vals_out), sizeof(int) * size_t(c->ld)));
+    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->phys_dev), sizeof(int) * size_t(c->m + 1)));
+    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->dout), sizeof(double) * 64));
+    LBFGSX_HIP(hipMalloc(&b->coef_dev, sizeof(double) * 80));
+    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->mslot), sizeof(unsigned long long) * 2));
+    // radix sort temporary storage
+    size_t bytes = 0;
+    if (c->dtype == LBFGSX_F64)
+        (void) rocprim::radix_sort_pairs(nullptr, bytes, P<double>(b->keys_in), P<double>(b->keys_out), b->vals_in,
+                                         b->vals_out, size_t(c->n), 0, 64, c->stream);
+    else
+        (void) rocprim::radix_sort_pairs(nullptr, bytes, P<float>(b->keys_in), P<float>(b->keys_out), b->vals_in,
+                                         b->vals_out, size_t(c->n), 0, 32, c->stream);
+    b->sort_tmp_bytes = bytes;
+    LBFGSX_HIP(hipMalloc(&b->sort_tmp, bytes ? bytes : 16));
+    return LBFGSX_OK;
+}
+
+void bounded_free(lbfgsx_ctx* c)
+{
+    lbfgsb_state* b = c->bstate;
+    if (!b)
+        return;
+    void* ptrs[] = {b->brk, b->dvec, b->cF, b->y, b->yfb, b->lam, b->mu, b->rhs, b->keys_in, b->keys_out, b->st,
+                    b->vals_in, b->vals_out, b->phys_dev, b->dout, b->coef_dev, b->mslot, b->sort_tmp, b->g_brk,
+                    b->g_g, b->g_z, b->g_w, b->g_idx};
+    for (void* p : ptrs)
+        (void) hipFree(p);
+    delete b;
+    c->bstate = nullptr;
+}
+
+// logical-slot column pointer lists
+template <class T, int NC>
+static Cols<T, NC> col_list(lbfgsx_ctx* c, const int* which /* 0..2c-1: Y slots then S slots */, int count)
+{
+    Cols<T, NC> cl;
+    for (int k = 0; k < NC; k++)
+    {
+        if (k < count)
+        {
+            const int w = which[k];
+            const int slot = (w < c->ncorr) ? w : w - c->ncorr;
+            void* base = (w < c->ncorr) ? c->Y : c->S;
+            cl.p[k] = static_cast<const T*>(c->col(base, c->phys[size_t(slot)]));
+        }
+        else
+            cl.p[k] = nullptr;
+    }
+    return cl;
+}
+
+// raw masked W'v for all 2*ncorr columns: out[0..c) = Y_j . v, out[c..2c) = S_j . v ; nnz of v inside the mask
+template <class T>
+static int wtv_t(lbfgsx_ctx* c, int vsel_id, const T* vcol, int mask, double* out, int64_t* nnz)
+{
+    constexpr int NC = 8;
+    const int total = 2 * c->ncorr;
+    const int grid = c->grid_for(c->n);
+    BVecs<T> b = bvecs<T>(c);
+    if (total == 0 && nnz)
+    {
+        // still count the non-zeros
+        int dummy = 0;
+        Cols<T, NC> cl = col_list<T, NC>(c, &dummy, 0);
+        hipLaunchKernelGGL((k_multidot<T, NC>), dim3(grid), dim3(kBlock), 0, c->stream, cl, 0, b, vsel_id, vcol, mask, c->n,
+                           c->ws, c->bstate->dout);
+        double r[NC + 1];
+        int rc = fetch_doubles(c, NC + 1, r);
+        if (rc)
+            return rc;
+        *nnz = int64_t(r[NC]);
+        return LBFGSX_OK;
+    }
+    for (int first = 0; first < total; first += NC)
+    {
+        const int cnt = std::min(NC, total - first);
+        int which[NC];
+        for (int k = 0; k < cnt; k++)
+            which[k] = first + k;
+        Cols<T, NC> cl = col_list<T, NC>(c, which, cnt);
+        hipLaunchKernelGGL((k_multidot<T, NC>), dim3(grid), dim3(kBlock), 0, c->stream, cl, cnt, b, vsel_id, vcol, mask, c->n,
+                           c->ws, c->bstate->dout);
+        LBFGSX_HIP(hipGetLastError());
+        double r[NC + 1];
+        int rc = fetch_doubles(c, NC + 1, r);
+        if (rc)
+            return rc;
+        for (int k = 0; k < cnt; k++)
+            out[first + k] = r[k];
+        if (nnz)
+            *nnz = int64_t(r[NC]);
+    }
+    return LBFGSX_OK;
+}
+
+}  // namespace lbfgsx
+
+namespace lbfgsx {
+#define CB_LAUNCH(M) \
+    hipLaunchKernelGGL((k_wcombine<T, M>), dim3(grid), dim3(kBlock), 0, c->stream, bv, S, Y, c->ld, ph, c->ncorr, cf, has_w, mask, vsel_id, T(theta), c->n)
+template <class T>
+static int wcombine_t(lbfgsx_ctx* c, int mode, int mask, int vsel_id, const double* coef, double theta)
+{
+    const int grid = c->grid_for(c->n);
+    const int has_w = (coef != nullptr && c->ncorr > 0) ? 1 : 0;
+    T hc[80];
+    for (int k = 0; k < 2 * c->ncorr; k++)
+        hc[k] = has_w ? T(coef[k]) : T(0);
+    if (has_w)
+        LBFGSX_HIP(hipMemcpyAsync(c->bstate->coef_dev, hc, sizeof(T) * size_t(2 * c->ncorr), hipMemcpyHostToDevice, c->stream));
+    LBFGSX_HIP(hipStreamSynchronize(c->stream));  // hc lives on this stack frame
+    BVecs<T> bv = bvecs<T>(c);
+    const T* S = P<T>(c->S);
+    const T* Y = P<T>(c->Y);
+    const T* cf = P<T>(c->bstate->coef_dev);
+    const int* ph = c->bstate->phys_dev;
+    switch (mode)
+    {
+    case CB_LINEAR: CB_LAUNCH(CB_LINEAR); break;
+    case CB_SOLVE: CB_LAUNCH(CB_SOLVE); break;
+    case CB_RHS_ADD: CB_LAUNCH(CB_RHS_ADD); break;
+    case CB_LAMBDA: CB_LAUNCH(CB_LAMBDA); break;
+    default: CB_LAUNCH(CB_MU); break;
+    }
+    LBFGSX_HIP(hipGetLastError());
+    return LBFGSX_OK;
+}
+#undef CB_LAUNCH
+}  // namespace lbfgsx
+
+using namespace lbfgsx;
+
+extern "C" {
+
+int lbfgsx_b_force_bounds(lbfgsx_ctx* c)
+{
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    const int grid = c->grid_for(c->n);
+    DISPATCH_T(c, {
+        hipLaunchKernelGGL((k_force_bounds<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]), P<T>(c->lb),
+                           P<T>(c->ub), c->n);
+    });
+    LBFGSX_HIP(hipGetLastError());
+    return LBFGSX_OK;
+}
+}
+
+namespace lbfgsx {
+template <class T, class OBJ>
+static int b_eval_t(lbfgsx_ctx* c, OBJ obj, double* r3)
+{
+    const int grid = c->grid_for(c->n);
+    int rc = arm_slot(c, false);
+    if (rc)
+        return rc;
+    hipLaunchKernelGGL((k_b_eval<T, OBJ>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]), P<T>(c->gb[c->cur]),
+                       P<T>(c->lb), P<T>(c->ub), c->n, obj, c->ws, P<T>(c->sc) + c->sl.out(0), c->bstate->mslot);
+    LBFGSX_HIP(hipGetLastError());
+    rc = fetch_T<T>(c, c->sl.out(0), 2, r3);
+    if (rc)
+        return rc;
+    return read_slot(c, &r3[2]);
+}
+}  // namespace lbfgsx
+
+extern "C" {
+
+int lbfgsx_b_eval(lbfgsx_ctx* c, int objective, double* fx, double* projgnorm, double* xnorm2)
+{
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    double r[3];
+    rc = LBFGSX_E_INVALID;
+    DISPATCH_T(c, {
+        if (objective == LBFGSX_OBJ_DIAG_QUAD)
+            rc = b_eval_t<T>(c, ObjQuad<T>{P<T>(c->a), P<T>(c->b)}, r);
+        else if (objective == LBFGSX_OBJ_EXT_ROSENBROCK)
+            rc = b_eval_t<T>(c, ObjRosen<T>{}, r);
+        else
+            set_error("lbfgsx_b_eval: unknown objective");
+    });
+    if (rc)
+        return rc;
+    if (fx) *fx = r[0];
+    if (xnorm2) *xnorm2 = r[1];
+    if (projgnorm) *projgnorm = r[2];
+    return LBFGSX_OK;
+}
+
+int lbfgsx_b_norms(lbfgsx_ctx* c, double* projgnorm, double* xnorm2)
+{
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    const int grid = c->grid_for(c->n);
+    rc = arm_slot(c, false);
+    if (rc)
+        return rc;
+    double r[1];
+    DISPATCH_T(c, {
+        hipLaunchKernelGGL((k_b_norms<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]), P<T>(c->gb[c->cur]),
+                           P<T>(c->lb), P<T>(c->ub), c->n, c->ws, P<T>(c->sc) + c->sl.out(0), c->bstate->mslot);
+        LBFGSX_HIP(hipGetLastError());
+        rc = fetch_T<T>(c, c->sl.out(0), 1, r);
+    });
+    if (rc)
+        return rc;
+    if (xnorm2) *xnorm2 = r[0];
+    return read_slot(c, projgnorm);
+}
+
+int lbfgsx_b_dg_maxstep(lbfgsx_ctx* c, double* dg, double* step_max)
+{
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    const int grid = c->grid_for(c->n);
+    rc = arm_slot(c, true);
+    if (rc)
+        return rc;
+    double r[1];
+    DISPATCH_T(c, {
+        hipLaunchKernelGGL((k_b_dg_maxstep<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]),
+                           P<T>(c->gb[c->cur]), P<T>(c->d), P<T>(c->lb), P<T>(c->ub), c->n, c->ws,
+                           P<T>(c->sc) + c->sl.out(0), c->bstate->mslot);
+        LBFGSX_HIP(hipGetLastError());
+        rc = fetch_T<T>(c, c->sl.out(0), 1, r);
+    });
+    if (rc)
+        return rc;
+    if (dg) *dg = r[0];
+    return read_slot(c, step_max);
+}
+
+int lbfgsx_b_post_linesearch(lbfgsx_ctx* c, double* projgnorm, double* xnorm2, double* sy, double* yy)
+{
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    const int grid = c->grid_for(c->n);
+    rc = arm_slot(c, false);
+    if (rc)
+        return rc;
+    double r[3];
+    DISPATCH_T(c, {
+        hipLaunchKernelGGL((k_b_post<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]), P<T>(c->xb[c->xp]),
+                           P<T>(c->gb[c->cur]), P<T>(c->gb[c->xp]), P<T>(c->lb), P<T>(c->ub), P<T>(c->col(c->S, c->spare)),
+                           P<T>(c->col(c->Y, c->spare)), c->n, c->ws, P<T>(c->sc) + c->sl.out(0),
+                           P<T>(c->sc) + c->sl.ys(c->spare), P<T>(c->sc) + c->sl.theta(c->spare), c->bstate->mslot);
+        LBFGSX_HIP(hipGetLastError());
+        rc = fetch_T<T>(c, c->sl.out(0), 3, r);
+    });
+    if (rc)
+        return rc;
+    c->pend_sy = r[1];
+    c->pend_yy = r[2];
+    c->pending = true;
+    if (xnorm2) *xnorm2 = r[0];
+    if (sy) *sy = r[1];
+    if (yy) *yy = r[2];
+    return read_slot(c, projgnorm);
+}
+
+int lbfgsx_b_correction_dots(lbfgsx_ctx* c, double* sdots, double* ydots)
+{
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    if (c->ncorr < 1)
+        return LBFGSX_OK;
+    const int newest = (c->ptr + c->m - 1) % c->m;  // slot written by the last commit (BFGSMat.h:83,97)
+    double raw[80];
+    DISPATCH_T(c, {
+        const T* snew = static_cast<const T*>(c->col(c->S, c->phys[size_t(newest)]));
+        rc = wtv_t<T>(c, 0, snew, 0, raw, nullptr);
+    });
+    if (rc)
+        return rc;
+    for (int j = 0; j < c->ncorr; j++)
+    {
+        ydots[j] = raw[j];
+        sdots[j] = raw[c->ncorr + j];
+    }
+    return LBFGSX_OK;
+}
+
+int lbfgsx_b_cauchy_build(lbfgsx_ctx* c, int64_t* nfree, int64_t* nord, double* dd, double* wtd)
+{
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    lbfgsb_state* b = c->bstate;
+    const int grid = c->grid_for(c->n);
+    double r[3];
+    DISPATCH_T(c, {
+        BVecs<T> bv = bvecs<T>(c);
+        hipLaunchKernelGGL((k_cauchy_build<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, P<T>(b->keys_in), b->vals_in, c->n,
+                           c->ws, b->dout);
+        LBFGSX_HIP(hipGetLastError());
+        rc = fetch_doubles(c, 3, r);
+        if (rc)
+            return rc;
+        if (r[2] > 0)
+        {
+            size_t bytes = b->sort_tmp_bytes;
+            LBFGSX_HIP(rocprim::radix_sort_pairs(b->sort_tmp, bytes, P<T>(b->keys_in), P<T>(b->keys_out), b->vals_in,
+                                                 b->vals_out, size_t(c->n), 0, int(sizeof(T) * 8), c->stream));
+        }
+        // p = W'd raw dots (Cauchy.h:152)
+        if (wtd && c->ncorr > 0)
+        {
+            rc = wtv_t<T>(c, 0, static_cast<const T*>(b->dvec), 0, wtd, nullptr);
+            if (rc)
+                return rc;
+        }
+    });
+    if (dd) *dd = r[0];
+    if (nfree) *nfree = int64_t(r[1]);
+    if (nord) *nord = int64_t(r[2]);
+    return LBFGSX_OK;
+}
+
+int lbfgsx_b_cauchy_chunk(lbfgsx_ctx* c, int64_t first, int64_t count, double* brk, double* g, double* z, int* idx,
+                          double* wrows)
+{
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    lbfgsb_state* b = c->bstate;
+    if (count <= 0)
+        return LBFGSX_OK;
+    const int nc = c->ncorr;
+    if (count > b->g_cap || nc != b->g_ncorr)
+    {
+        void* old[] = {b->g_brk, b->g_g, b->g_z, b->g_w, b->g_idx};
+        for (void* p : old)
+            (void) hipFree(p);
+        const int64_t cap = std::max<int64_t>(count, b->g_cap);
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->g_brk), sizeof(double) * size_t(cap)));
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->g_g), sizeof(double) * size_t(cap)));
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->g_z), sizeof(double) * size_t(cap)));
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->g_idx), sizeof(int) * size_t(cap)));
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->g_w), sizeof(double) * size_t(cap) * size_t(std::max(2 * nc, 1))));
+        b->g_cap = cap;
+        b->g_ncorr = nc;
+    }
+    rc = upload_phys(c);
+    if (rc)
+        return rc;
+    const int grid = int(std::min<int64_t>((count + 255) / 256, 2048));
+    DISPATCH_T(c, {
+        BVecs<T> bv = bvecs<T>(c);
+        hipLaunchKernelGGL((k_cauchy_gather<T>), dim3(grid), dim3(256), 0, c->stream, bv, P<T>(b->keys_out), b->vals_out, first,
+                           count, P<T>(c->S), P<T>(c->Y), c->ld, b->phys_dev, nc, b->g_brk, b->g_g, b->g_z, b->g_idx, b->g_w);
+    });
+    LBFGSX_HIP(hipGetLastError());
+    LBFGSX_HIP(hipMemcpyAsync(brk, b->g_brk, sizeof(double) * size_t(count), hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(hipMemcpyAsync(g, b->g_g, sizeof(double) * size_t(count), hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(hipMemcpyAsync(z, b->g_z, sizeof(double) * size_t(count), hipMemcpyDeviceToHost, c->stream));
+    if (idx)
+        LBFGSX_HIP(hipMemcpyAsync(idx, b->g_idx, sizeof(int) * size_t(count), hipMemcpyDeviceToHost, c->stream));
+    if (nc > 0 && wrows)
+        LBFGSX_HIP(hipMemcpyAsync(wrows, b->g_w, sizeof(double) * size_t(count) * size_t(2 * nc), hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    return LBFGSX_OK;
+}
+
+int lbfgsx_b_cauchy_finish(lbfgsx_ctx* c, double t_cross, double tfinal, int crossed_all, int64_t* nact, int64_t* nfree)
+{
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    const int grid = c->grid_for(c->n);
+    double r[2];
+    DISPATCH_T(c, {
+        BVecs<T> bv = bvecs<T>(c);
+        hipLaunchKernelGGL((k_cauchy_finish<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, T(t_cross), T(tfinal), crossed_all,
+                           c->n, c->ws, c->bstate->dout);
+    });
+    LBFGSX_HIP(hipGetLastError());
+    rc = fetch_doubles(c, 2, r);
+    if (rc)
+        return rc;
+    if (nact) *nact = int64_t(r[0]);
+    if (nfree) *nfree = int64_t(r[1]);
+    return LBFGSX_OK;
+}
+
+int lbfgsx_b_sub_begin(lbfgsx_ctx* c)
+{
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    const int grid = c->grid_for(c->n);
+    DISPATCH_T(c, {
+        BVecs<T> bv = bvecs<T>(c);
+        hipLaunchKernelGGL((k_sub_begin<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, c->n);
+    });
+    LBFGSX_HIP(hipGetLastError());
+    return LBFGSX_OK;
+}
+
+int lbfgsx_b_wtv(lbfgsx_ctx* c, int vsel_id, int mask, double* out, int64_t* nnz)
+{
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    DISPATCH_T(c, { rc = wtv_t<T>(c, vsel_id, static_cast<const T*>(nullptr), mask, out, nnz); });
+    return rc;
+}
+
+int lbfgsx_b_gram(lbfgsx_ctx* c, int mask, double* gram)
+{
+    // lower triangle (and everything else, by symmetry) of the 2c x 2c Gram of [Y_P, S_P] in logical slot order
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    constexpr int TB = 4;
+    const int tot = 2 * c->ncorr;
+    const int grid = c->grid_for(c->n);
+    for (int bi = 0; bi < tot; bi += TB)
+        for (int bj = 0; bj <= bi; bj += TB)
+        {
+            const int ni = std::min(TB, tot - bi), nj = std::min(TB, tot - bj);
+            int wi[TB], wj[TB];
+            for (int k = 0; k < ni; k++)
+                wi[k] = bi + k;
+            for (int k = 0; k < nj; k++)
+                wj[k] = bj + k;
+            double r[TB * TB];
+            DISPATCH_T(c, {
+                Cols<T, TB> ci = col_list<T, TB>(c, wi, ni), cj = col_list<T, TB>(c, wj, nj);
+                hipLaunchKernelGGL((k_gram<T, TB>), dim3(grid), dim3(kBlock), 0, c->stream, ci, ni, cj, nj, c->bstate->st, mask,
+                                   c->n, c->ws, c->bstate->dout);
+            });
+            LBFGSX_HIP(hipGetLastError());
+            rc = fetch_doubles(c, TB * TB, r);
+            if (rc)
+                return rc;
+            for (int a = 0; a < ni; a++)
+                for (int b2 = 0; b2 < nj; b2++)
+                {
+                    gram[(bi + a) * tot + (bj + b2)] = r[a * TB + b2];
+                    gram[(bj + b2) * tot + (bi + a)] = r[a * TB + b2];
+                }
+        }
+    return LBFGSX_OK;
+}
+
+int lbfgsx_b_wcombine(lbfgsx_ctx* c, int mode, int mask, int vsel_id, const double* coef, double theta)
+{
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    if (mode < CB_LINEAR || mode > CB_MU)
+    {
+        set_error("lbfgsx_b_wcombine: unknown mode");
+        return LBFGSX_E_INVALID;
+    }
+    rc = upload_phys(c);
+    if (rc)
+        return rc;
+    DISPATCH_T(c, { rc = wcombine_t<T>(c, mode, mask, vsel_id, coef, theta); });
+    return rc;
+}
+
+int lbfgsx_b_sub_partition(lbfgsx_ctx* c, int64_t* nL, int64_t* nU, int64_t* nP)
+{
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    const int grid = c->grid_for(c->n);
+    double r[3];
+    DISPATCH_T(c, {
+        BVecs<T> bv = bvecs<T>(c);
+        hipLaunchKernelGGL((k_sub_partition<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, c->n, c->ws, c->bstate->dout);
+    });
+    LBFGSX_HIP(hipGetLastError());
+    rc = fetch_doubles(c, 3, r);
+    if (rc)
+        return rc;
+    *nL = int64_t(r[0]);
+    *nU = int64_t(r[1]);
+    *nP = int64_t(r[2]);
+    return LBFGSX_OK;
+}
+
+int lbfgsx_b_sub_check(lbfgsx_ctx* c, int64_t counts[4])
+{
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    const int grid = c->grid_for(c->n);
+    double r[4];
+    DISPATCH_T(c, {
+        BVecs<T> bv = bvecs<T>(c);
+        hipLaunchKernelGGL((k_sub_check<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, c->n, c->ws, c->bstate->dout);
+    });
+    LBFGSX_HIP(hipGetLastError());
+    rc = fetch_doubles(c, 4, r);
+    if (rc)
+        return rc;
+    for (int k = 0; k < 4; k++)
+        counts[k] = int64_t(r[k]);
+    return LBFGSX_OK;
+}
+
+int lbfgsx_b_sub_op(lbfgsx_ctx* c, int op)
+{
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    const int grid = c->grid_for(c->n);
+    DISPATCH_T(c, {
+        BVecs<T> bv = bvecs<T>(c);
+        hipLaunchKernelGGL((k_sub_op<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, op, c->n);
+    });
+    LBFGSX_HIP(hipGetLastError());
+    return LBFGSX_OK;
+}
+
+int lbfgsx_b_download_state(lbfgsx_ctx* c, unsigned char* host)
+{
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    LBFGSX_HIP(hipMemcpyAsync(host, c->bstate->st, size_t(c->n), hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    return LBFGSX_OK;
+}
+
+int lbfgsx_b_dot_drt_g(lbfgsx_ctx* c, double* dg)
+{
+    const int grid = c->grid_for(c->n);
+    double r[2];
+    DISPATCH_T(c, {
+        hipLaunchKernelGGL((k_dot<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->d), P<T>(c->gb[c->cur]),
+                           static_cast<const T*>(nullptr), c->n, c->ws, P<T>(c->sc) + c->sl.out(0));
+        LBFGSX_HIP(hipGetLastError());
+        int rc = fetch_T<T>(c, c->sl.out(0), 1, r);
+        if (rc)
+            return rc;
+    });
+    *dg = r[0];
+    return LBFGSX_OK;
+}
+
+int lbfgsx_b_dir_from_xcp(lbfgsx_ctx* c, int normalize)
+{
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    const int grid = c->grid_for(c->n);
+    double r[1];
+    DISPATCH_T(c, {
+        hipLaunchKernelGGL((k_b_dir_from_xcp<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xcp), P<T>(c->xb[c->cur]),
+                           P<T>(c->d), c->n, c->ws, P<T>(c->sc) + c->sl.out(0));
+        LBFGSX_HIP(hipGetLastError());
+        if (normalize)
+        {
+            rc = fetch_T<T>(c, c->sl.out(0), 1, r);
+            if (rc)
+                return rc;
+            const T z = T(r[0]);
+            if (z > T(0))  // Eigen normalize(): divide only when the squared norm is positive
+                hipLaunchKernelGGL((k_b_scale_div<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->d), T(std::sqrt(z)), c->n);
+        }
+    });
+    LBFGSX_HIP(hipGetLastError());
+    return LBFGSX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,633 @@
+// lbfgspp_amd/csrc/lbfgsb_kernels.cuh -- CDNA4 kernels of the L-BFGS-B path.
+//
+// Index sets of the reference (fv_set, newact_set, L/U/P sets: std::vector<int>) become one state byte per
+// coordinate; row gathers `Wb(IndexSet)` (BFGSMat.h:338-358) disappear: every operator streams the
+// column-contiguous S/Y columns once, coalesced, and applies the mask.  Reductions use the same
+// order-independent accumulators as the L-BFGS path.
+#pragma once
+#include "reduce.cuh"
+
+namespace lbfgsx {
+
+// state byte
+enum : unsigned char
+{
+    ST_FREE = 1,    // in fv_set (Cauchy.h:125-126, 276-281)
+    ST_NEWACT = 2,  // in newact_set (Cauchy.h:205, 233)
+    ST_L = 4,       // BOXCQP lower set (SubspaceMin.h:198-204)
+    ST_U = 8,       // BOXCQP upper set (:205-211)
+    ST_P = 16       // BOXCQP interior set (:212-218)
+};
+
+// vectors computed on the fly for the masked operators
+enum { VS_DRT = 0, VS_NEG_CF = 1, VS_NEG_RHS = 2, VS_LBOUND = 3, VS_UBOUND = 4, VS_Y = 5 };
+
+template <class T>
+struct BVecs
+{
+    const T* x0;   // current iterate (projected)
+    const T* g;    // gradient at x0
+    const T* lb;
+    const T* ub;
+    T* xcp;
+    T* drt;        // search direction / d = xcp - x0
+    T* brk;        // break points
+    T* dvec;       // vecd of Cauchy.h
+    T* cF;         // vecc of SubspaceMin.h (linear term on the free set)
+    T* y;          // vecy
+    T* yfb;        // yfallback
+    T* lam;
+    T* mu;
+    T* rhs;
+    unsigned char* st;
+};
+
+template <class T>
+__device__ __forceinline__ T vsel(const BVecs<T>& b, int sel, int64_t i)
+{
+    switch (sel)
+    {
+    case VS_DRT: return b.drt[i];
+    case VS_NEG_CF: return -b.cF[i];
+    case VS_NEG_RHS: return -b.rhs[i];
+    case VS_LBOUND: return b.lb[i] - b.x0[i];
+    case VS_UBOUND: return b.ub[i] - b.x0[i];
+    default: return b.y[i];
+    }
+}
+
+template <class T, int NC>
+struct Cols
+{
+    const T* p[NC];
+};
+
+// order-preserving max/min of non-negative values through integer atomics (exact, order independent)
+__device__ __forceinline__ void atomic_max_nonneg(unsigned long long* slot, double v)
+{
+    __hip_atomic_fetch_max(slot, (unsigned long long) __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void atomic_min_nonneg(unsigned long long* slot, double v)
+{
+    __hip_atomic_fetch_min(slot, (unsigned long long) __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// block-level max of a non-negative value, one atomic per block
+__device__ __forceinline__ void block_atomic_max(unsigned long long* slot, double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v = fmax(v, __shfl_down(v, off, 64));
+    if ((threadIdx.x & 63) == 0)
+        atomic_max_nonneg(slot, v);
+}
+__device__ __forceinline__ void block_atomic_min(unsigned long long* slot, double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v = fmin(v, __shfl_down(v, off, 64));
+    if ((threadIdx.x & 63) == 0)
+        atomic_min_nonneg(slot, v);
+}
+
+// ---------------------------------------------------------------- LBFGSB.h:55-58  x = x.cwiseMax(lb).cwiseMin(ub)
+template <class T>
+__global__ void __launch_bounds__(kBlock) k_force_bounds(T* __restrict__ x, const T* __restrict__ lb,
+                                                         const T* __restrict__ ub, int64_t n)
+{
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
+    {
+        T v = x[i];
+        v = (v < lb[i]) ? lb[i] : v;
+        v = (ub[i] < v) ? ub[i] : v;
+        x[i] = v;
+    }
+}
+
+// projected-gradient term |clamp(x - g, lb, ub) - x|  (LBFGSB.h:62-65)
+template <class T>
+__device__ __forceinline__ T projg_term(T x, T g, T lb, T ub)
+{
+    T v = x - g;
+    v = (v < lb) ? lb : v;
+    v = (ub < v) ? ub : v;
+    v = v - x;
+    return v < T(0) ? -v : v;
+}
+
+// ---------------------------------------------------------------- evaluation with the projected-gradient norm
+// out[0] = f(x), out[1] = x.x ; *maxslot = ||P(x-g)-x||_inf  (LBFGSB.h:137-138,146)
+template <class T, class OBJ>
+__global__ void __launch_bounds__(kBlock) k_b_eval(const T* __restrict__ x, T* __restrict__ g,
+                                                   const T* __restrict__ lb, const T* __restrict__ ub, int64_t n,
+                                                   OBJ obj, RedWs ws, T* __restrict__ out,
+                                                   unsigned long long* maxslot)
+{
+    typedef typename AccOf<T>::type A;
+    constexpr int W = Vec16<T>::W;
+    A acc[2];
+    double pg = 0.0;
+    const int64_t nv = n / W;
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t vi = int64_t(blockIdx.x) * kBlock + threadIdx.x; vi < nv; vi += stride)
+    {
+        const Pack<T> px = ldv(x, vi), pl = ldv(lb, vi), pu = ldv(ub, vi);
+        Pack<T> pgv;
+        obj.pack(vi, px, pgv, acc[0]);
+        stv(g, vi, pgv);
+#pragma unroll
+        for (int k = 0; k < W; k++)
+        {
+            acc[1].add_prod(px.e[k], px.e[k]);
+            pg = fmax(pg, double(projg_term(px.e[k], pgv.e[k], pl.e[k], pu.e[k])));
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int64_t i = nv * W; i < n; i++)
+        {
+            obj.tail(i, n, x, g, acc[0]);
+            acc[1].add_prod(x[i], x[i]);
+            pg = fmax(pg, double(projg_term(x[i], g[i], lb[i], ub[i])));
+        }
+    block_atomic_max(maxslot, pg);
+    if (grid_reduce<2>(acc, ws) && threadIdx.x == 0)
+    {
+        out[0] = obj.finish(T(acc[0].value()));
+        out[1] = T(acc[1].value());
+    }
+}
+
+// projected-gradient norm and x.x for objectives evaluated by the caller (device / host functors)
+template <class T>
+__global__ void __launch_bounds__(kBlock) k_b_norms(const T* __restrict__ x, const T* __restrict__ g,
+                                                    const T* __restrict__ lb, const T* __restrict__ ub, int64_t n,
+                                                    RedWs ws, T* __restrict__ out, unsigned long long* maxslot)
+{
+    typedef typename AccOf<T>::type A;
+    A acc[1];
+    double pg = 0.0;
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
+    {
+        acc[0].add_prod(x[i], x[i]);
+        pg = fmax(pg, double(projg_term(x[i], g[i], lb[i], ub[i])));
+    }
+    block_atomic_max(maxslot, pg);
+    if (grid_reduce<1>(acc, ws) && threadIdx.x == 0)
+        out[0] = T(acc[0].value());
+}
+
+// dg = g.d ; step_max = max feasible step (LBFGSB.h:68-86,176-179)
+template <class T>
+__global__ void __launch_bounds__(kBlock) k_b_dg_maxstep(const T* __restrict__ x, const T* __restrict__ g,
+                                                         const T* __restrict__ d, const T* __restrict__ lb,
+                                                         const T* __restrict__ ub, int64_t n, RedWs ws,
+                                                         T* __restrict__ out, unsigned long long* minslot)
+{
+    typedef typename AccOf<T>::type A;
+    A acc[1];
+    double smin = __longlong_as_double(0x7FF0000000000000ll);
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
+    {
+        const T di = d[i];
+        acc[0].add_prod(g[i], di);
+        if (di > T(0))
+            smin = fmin(smin, double((ub[i] - x[i]) / di) + 0.0);
+        else if (di < T(0))
+            smin = fmin(smin, double((lb[i] - x[i]) / di) + 0.0);
+    }
+    block_atomic_min(minslot, smin);
+    if (grid_reduce<1>(acc, ws) && threadIdx.x == 0)
+        out[0] = T(acc[0].value());
+}
+
+// after the line search (LBFGSB.h:206,213,235-237): projected-gradient norm, x.x, s, y, s.y, y.y
+template <class T>
+__global__ void __launch_bounds__(kBlock) k_b_post(const T* __restrict__ x, const T* __restrict__ xp,
+                                                   const T* __restrict__ g, const T* __restrict__ gp,
+                                                   const T* __restrict__ lb, const T* __restrict__ ub,
+                                                   T* __restrict__ s, T* __restrict__ y, int64_t n, RedWs ws,
+                                                   T* __restrict__ out, T* __restrict__ ys_slot,
+                                                   T* __restrict__ theta_slot, unsigned long long* maxslot)
+{
+    typedef typename AccOf<T>::type A;
+    A acc[3];
+    double pg = 0.0;
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
+    {
+        const T xi = x[i], gi = g[i];
+        const T si = xi - xp[i], yi = gi - gp[i];
+        s[i] = si;
+        y[i] = yi;
+        acc[0].add_prod(xi, xi);
+        acc[1].add_prod(si, yi);
+        acc[2].add_prod(yi, yi);
+        pg = fmax(pg, double(projg_term(xi, gi, lb[i], ub[i])));
+    }
+    block_atomic_max(maxslot, pg);
+    if (grid_reduce<3>(acc, ws) && threadIdx.x == 0)
+    {
+        const T sy = T(acc[1].value()), yy = T(acc[2].value());
+        out[0] = T(acc[0].value());
+        out[1] = sy;
+        out[2] = yy;
+        *ys_slot = sy;
+        *theta_slot = yy / sy;
+    }
+}
+
+// ---------------------------------------------------------------- masked multi-dot: out[k] = sum_{i in mask} col_k[i] * v[i]
+// (BFGSMat.h:111,138 add_correction tail; :315-320 apply_Wtv; :382-430 apply_WtPv; :560 WP'v)
+// mask == 0 means "all coordinates"; vcol != nullptr overrides the selector (v is a plain vector)
+template <class T, int NC>
+__global__ void __launch_bounds__(kBlock) k_multidot(Cols<T, NC> cols, int ncols, BVecs<T> b, int vsel_id,
+                                                     const T* __restrict__ vcol, int mask, int64_t n, RedWs ws,
+                                                     double* __restrict__ out)
+{
+    typedef typename AccOf<T>::type A;
+    A acc[NC + 1];  // last: number of non-zero v entries inside the mask (test_zero of apply_WtPv)
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
+    {
+        if (mask && !(b.st[i] & mask))
+            continue;
+        const T v = vcol ? vcol[i] : vsel(b, vsel_id, i);
+        if (v != T(0))
+            acc[NC].add(T(1));
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+            if (k < ncols)
+                acc[k].add_prod(cols.p[k][i], v);
+    }
+    if (grid_reduce<NC + 1>(acc, ws) && threadIdx.x == 0)
+        for (int k = 0; k <= NC; k++)
+            out[k] = double(T(acc[k].value()));
+}
+
+// ---------------------------------------------------------------- masked Gram block: out[a*TB+c] = sum_{i in mask} I_a[i] * J_c[i]
+// (BFGSMat.h:543-556: WP'WP blocks of solve_PtBP)
+template <class T, int TB>
+__global__ void __launch_bounds__(kBlock) k_gram(Cols<T, TB> ci, int ni, Cols<T, TB> cj, int nj,
+                                                 const unsigned char* __restrict__ st, int mask, int64_t n,
+                                                 RedWs ws, double* __restrict__ out)
+{
+    typedef typename AccOf<T>::type A;
+    A acc[TB * TB];
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
+    {
+        if (mask && !(st[i] & mask))
+            continue;
+        T vi[TB], vj[TB];
+#pragma unroll
+        for (int a = 0; a < TB; a++)
+        {
+            vi[a] = (a < ni) ? ci.p[a][i] : T(0);
+            vj[a] = (a < nj) ? cj.p[a][i] : T(0);
+        }
+#pragma unroll
+        for (int a = 0; a < TB; a++)
+#pragma unroll
+            for (int c = 0; c < TB; c++)
+                acc[a * TB + c].add_prod(vi[a], vj[c]);
+    }
+    if (grid_reduce<TB * TB>(acc, ws) && threadIdx.x == 0)
+        for (int k = 0; k < TB * TB; k++)
+            out[k] = double(T(acc[k].value()));
+}
+
+// ---------------------------------------------------------------- Cauchy build (Cauchy.h:111-129,154)
+// brk, vecd, sort keys/values; out[0] = d.d, out[1] = #free (brk = inf), out[2] = #ord (0 < brk < inf)
+template <class T>
+__global__ void __launch_bounds__(kBlock) k_cauchy_build(BVecs<T> b, T* __restrict__ keys, int* __restrict__ vals,
+                                                         int64_t n, RedWs ws, double* __restrict__ out)
+{
+    typedef typename AccOf<T>::type A;
+    A acc[3];
+    const T inf = T(__longlong_as_double(0x7FF0000000000000ll));
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
+    {
+        const T gi = b.g[i], xi = b.x0[i], lo = b.lb[i], up = b.ub[i];
+        T t;
+        if (lo == up)
+            t = T(0);
+        else if (gi < T(0))
+            t = (xi - up) / gi;
+        else if (gi > T(0))
+            t = (xi - lo) / gi;
+        else
+            t = inf;
+        const bool iszero = (t == T(0));
+        const T di = iszero ? T(0) : -gi;
+        b.brk[i] = t;
+        b.dvec[i] = di;
+        b.xcp[i] = xi;  // xcp = x0 (Cauchy.h:95)
+        acc[0].add_prod(di, di);
+        const bool isfree = (t == inf);
+        const bool isord = !isfree && !iszero;
+        if (isfree)
+            acc[1].add(T(1));
+        if (isord)
+            acc[2].add(T(1));
+        keys[i] = isord ? t : inf;  // non-candidates sort to the end
+        vals[i] = int(i);
+    }
+    if (grid_reduce<3>(acc, ws) && threadIdx.x == 0)
+    {
+        out[0] = double(T(acc[0].value()));
+        out[1] = acc[1].value();
+        out[2] = acc[2].value();
+    }
+}
+
+// gather the data the sequential GCP scan needs for sorted positions [first, first+count)
+// (Cauchy.h:203-231: brk, g, z = bound - x0, W row = [y_0..y_{c-1}, s_0..s_{c-1}] un-scaled)
+template <class T>
+__global__ void k_cauchy_gather(BVecs<T> b, const T* __restrict__ keys, const int* __restrict__ vals,
+                                int64_t first, int64_t count, const T* __restrict__ S, const T* __restrict__ Y,
+                                int64_t ld, const int* __restrict__ phys, int ncorr, double* __restrict__ o_brk,
+                                double* __restrict__ o_g, double* __restrict__ o_z, int* __restrict__ o_idx,
+                                double* __restrict__ o_w)
+{
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t k = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; k < count; k += stride)
+    {
+        const int idx = vals[first + k];
+        o_brk[k] = double(keys[first + k]);
+        o_g[k] = double(b.g[idx]);
+        const T bound = (b.dvec[idx] > T(0)) ? b.ub[idx] : b.lb[idx];
+        o_z[k] = double(bound - b.x0[idx]);
+        o_idx[k] = idx;
+        for (int j = 0; j < ncorr; j++)
+        {
+            o_w[k * 2 * ncorr + j] = double(Y[int64_t(phys[j]) * ld + idx]);
+            o_w[k * 2 * ncorr + ncorr + j] = double(S[int64_t(phys[j]) * ld + idx]);
+        }
+    }
+}
+
+// xcp and the free / newly-active state from the crossing threshold (Cauchy.h:201-206,219-233,265-282)
+// out[0] = #newact, out[1] = #free
+template <class T>
+__global__ void __launch_bounds__(kBlock) k_cauchy_finish(BVecs<T> b, T t_cross, T tfinal, int crossed_all, int64_t n,
+                                                          RedWs ws, double* __restrict__ out)
+{
+    typedef typename AccOf<T>::type A;
+    A acc[2];
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
+    {
+        const T t = b.brk[i];
+        unsigned char s = 0;
+        if (t == T(0))
+            s = 0;  // on its bound from the start: neither free nor newly active; xcp = x0
+        else if (t <= t_cross)
+        {
+            b.xcp[i] = (b.dvec[i] > T(0)) ? b.ub[i] : b.lb[i];
+            s = ST_NEWACT;
+            acc[0].add(T(1));
+        }
+        else
+        {
+            if (!crossed_all)
+                b.xcp[i] = b.x0[i] + tfinal * b.dvec[i];
+            s = ST_FREE;
+            acc[1].add(T(1));
+        }
+        b.st[i] = s;
+    }
+    if (grid_reduce<2>(acc, ws) && threadIdx.x == 0)
+    {
+        out[0] = acc[0].value();
+        out[1] = acc[1].value();
+    }
+}
+
+// ---------------------------------------------------------------- subspace minimisation element-wise pieces
+// drt = xcp - x0 (SubspaceMin.h:130)
+template <class T>
+__global__ void __launch_bounds__(kBlock) k_sub_begin(BVecs<T> b, int64_t n)
+{
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
+        b.drt[i] = b.xcp[i] - b.x0[i];
+}
+
+// combine modes: out_i = epilogue(sum_j W(i,j) * coef_j) over coordinates in `mask`
+enum
+{
+    CB_LINEAR = 0,   // cF_i = (-1 * acc) + g_i            compute_FtBAb + SubspaceMin.h:155   (has_w = 0: cF_i = 0 + g_i)
+    CB_SOLVE = 1,    // y_i = v_i/theta + acc/(theta*theta)  BFGSMat.h:564  (has_w = 0: y_i = v_i/theta, :535)
+    CB_RHS_ADD = 2,  // rhs_i += -acc                       apply_PtBQv :592 + SubspaceMin.h:236-241
+    CB_LAMBDA = 3,   // lam_i = (-1*accp) + (cF_i + theta*y_i)      SubspaceMin.h:256-258 (paired order, BFGSMat.h:447-458)
+    CB_MU = 4        // mu_i = -((-1*accp) + (cF_i + theta*y_i))    SubspaceMin.h:265-267
+};
+
+template <class T, int MODE>
+__global__ void __launch_bounds__(kBlock) k_wcombine(BVecs<T> b, const T* __restrict__ S, const T* __restrict__ Y,
+                                                     int64_t ld, const int* __restrict__ phys, int ncorr,
+                                                     const T* __restrict__ coef, int has_w, int mask, int vsel_id,
+                                                     T theta, int64_t n)
+{
+    __shared__ T sc[80];
+    __shared__ int sp[40];
+    if (threadIdx.x < 2 * ncorr)
+        sc[threadIdx.x] = coef[threadIdx.x];
+    if (threadIdx.x < ncorr)
+        sp[threadIdx.x] = phys[threadIdx.x];
+    __syncthreads();
+    const T theta2 = theta * theta;
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
+    {
+        if (!(b.st[i] & mask))
+            continue;
+        T acc = T(0);
+        if (has_w)
+        {
+            if (MODE == CB_LAMBDA || MODE == CB_MU)
+            {
+                // res[i] += Mvy*y(row,j) + Mvs*s(row,j), j ascending (BFGSMat.h:447-457)
+                for (int j = 0; j < ncorr; j++)
+                    acc = acc + (sc[j] * Y[int64_t(sp[j]) * ld + i] + sc[ncorr + j] * S[int64_t(sp[j]) * ld + i]);
+            }
+            else
+            {
+                // (WP * v)(i): columns Y_0..Y_{c-1}, S_0..S_{c-1} in order, plain accumulation
+                for (int j = 0; j < ncorr; j++)
+                    acc = acc + Y[int64_t(sp[j]) * ld + i] * sc[j];
+                for (int j = 0; j < ncorr; j++)
+                    acc = acc + S[int64_t(sp[j]) * ld + i] * sc[ncorr + j];
+            }
+        }
+        if (MODE == CB_LINEAR)
+            b.cF[i] = (has_w ? (T(-1) * acc) : T(0)) + b.g[i];
+        else if (MODE == CB_SOLVE)
+        {
+            const T v = vsel(b, vsel_id, i);
+            b.y[i] = has_w ? (v / theta + acc / theta2) : (v / theta);
+        }
+        else if (MODE == CB_RHS_ADD)
+            b.rhs[i] = b.rhs[i] + (-acc);
+        else
+        {
+            const T r = (T(-1) * acc) + (b.cF[i] + theta * b.y[i]);
+            if (MODE == CB_LAMBDA)
+                b.lam[i] = r;
+            else
+                b.mu[i] = -r;
+        }
+    }
+}
+
+// BOXCQP partition (SubspaceMin.h:194-219); out = {#L, #U, #P}
+template <class T>
+__global__ void __launch_bounds__(kBlock) k_sub_partition(BVecs<T> b, int64_t n, RedWs ws, double* __restrict__ out)
+{
+    typedef typename AccOf<T>::type A;
+    A acc[3];
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
+    {
+        unsigned char s = b.st[i];
+        if (!(s & ST_FREE))
+            continue;
+        s &= (unsigned char) ~(ST_L | ST_U | ST_P);
+        const T li = b.lb[i] - b.x0[i], ui = b.ub[i] - b.x0[i];
+        const T yi = b.y[i];
+        if ((yi < li) || (yi == li && b.lam[i] >= T(0)))
+        {
+            s |= ST_L;
+            b.y[i] = li;
+            b.mu[i] = T(0);
+            acc[0].add(T(1));
+        }
+        else if ((yi > ui) || (yi == ui && b.mu[i] >= T(0)))
+        {
+            s |= ST_U;
+            b.y[i] = ui;
+            b.lam[i] = T(0);
+            acc[1].add(T(1));
+        }
+        else
+        {
+            s |= ST_P;
+            b.lam[i] = T(0);
+            b.mu[i] = T(0);
+            acc[2].add(T(1));
+        }
+        b.st[i] = s;
+    }
+    if (grid_reduce<3>(acc, ws) && threadIdx.x == 0)
+        for (int k = 0; k < 3; k++)
+            out[k] = acc[k].value();
+}
+
+// violation counts: out[0] = #{i in F: y outside [l,u]}   (in_bounds, SubspaceMin.h:60-69,162)
+//                   out[1] = #{i in P: y outside [l,u]}   (P_converged :72-82)
+//                   out[2] = #{i in L: lam < 0}           (L_converged :85-95)
+//                   out[3] = #{i in U: mu < 0}            (U_converged :98-108)
+template <class T>
+__global__ void __launch_bounds__(kBlock) k_sub_check(BVecs<T> b, int64_t n, RedWs ws, double* __restrict__ out)
+{
+    typedef typename AccOf<T>::type A;
+    A acc[4];
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
+    {
+        const unsigned char s = b.st[i];
+        if (!(s & ST_FREE))
+            continue;
+        const T li = b.lb[i] - b.x0[i], ui = b.ub[i] - b.x0[i];
+        const T yi = b.y[i];
+        const bool outside = (yi < li || yi > ui);
+        if (outside)
+            acc[0].add(T(1));
+        if ((s & ST_P) && outside)
+            acc[1].add(T(1));
+        if ((s & ST_L) && b.lam[i] < T(0))
+            acc[2].add(T(1));
+        if ((s & ST_U) && b.mu[i] < T(0))
+            acc[3].add(T(1));
+    }
+    if (grid_reduce<4>(acc, ws) && threadIdx.x == 0)
+        for (int k = 0; k < 4; k++)
+            out[k] = acc[k].value();
+}
+
+// misc element-wise statements of SubspaceMin.h, selected by `op`
+enum
+{
+    SO_SAVE_FALLBACK = 0,  // yfallback = vecy; lambda = mu = 0            (:170-172)
+    SO_RHS_INIT = 1,       // rhs = subvec(vecc, yP_set)                   (:232)
+    SO_ASSIGN_Y = 2,       // subvec_assign(drt, fv_set, vecy)             (:164, :279, :301)
+    SO_CLAMP_Y = 3,        // vecy = vecy.cwiseMax(vecl).cwiseMin(vecu)    (:278)
+    SO_CLAMP_FB = 4,       // vecy = yfallback.cwiseMax(vecl).cwiseMin(vecu) (:287)
+    SO_ASSIGN_FB = 5       // subvec_assign(drt, fv_set, yfallback)        (:294)
+};
+template <class T>
+__global__ void __launch_bounds__(kBlock) k_sub_op(BVecs<T> b, int op, int64_t n)
+{
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
+    {
+        const unsigned char s = b.st[i];
+        if (!(s & ST_FREE))
+            continue;
+        switch (op)
+        {
+        case SO_SAVE_FALLBACK:
+            b.yfb[i] = b.y[i];
+            b.lam[i] = T(0);
+            b.mu[i] = T(0);
+            break;
+        case SO_RHS_INIT:
+            if (s & ST_P)
+                b.rhs[i] = b.cF[i];
+            break;
+        case SO_ASSIGN_Y: b.drt[i] = b.y[i]; break;
+        case SO_CLAMP_Y:
+        case SO_CLAMP_FB:
+        {
+            const T li = b.lb[i] - b.x0[i], ui = b.ub[i] - b.x0[i];
+            T v = (op == SO_CLAMP_Y) ? b.y[i] : b.yfb[i];
+            v = (v < li) ? li : v;
+            v = (ui < v) ? ui : v;
+            b.y[i] = v;
+            break;
+        }
+        default: b.drt[i] = b.yfb[i]; break;
+        }
+    }
+}
+
+// drt = xcp - x (recovery direction, LBFGSB.h:191) / normalise (LBFGSB.h:163-164)
+template <class T>
+__global__ void __launch_bounds__(kBlock) k_b_dir_from_xcp(const T* __restrict__ xcp, const T* __restrict__ x,
+                                                           T* __restrict__ d, int64_t n, RedWs ws, T* __restrict__ out)
+{
+    typedef typename AccOf<T>::type A;
+    A acc[1];
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
+    {
+        const T di = xcp[i] - x[i];
+        d[i] = di;
+        acc[0].add_prod(di, di);
+    }
+    if (grid_reduce<1>(acc, ws) && threadIdx.x == 0)
+        out[0] = T(acc[0].value());
+}
+template <class T>
+__global__ void __launch_bounds__(kBlock) k_b_scale_div(T* __restrict__ d, T s, int64_t n)
+{
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
+        d[i] = d[i] / s;
+}
+
+}  // namespace lbfgsx

@@ -230,6 +230,9 @@ int lbfgsx_create(lbfgsx_ctx** out, int dtype, int64_t n, int m, int device, int
         LBFGSX_HIP(hipMalloc(&c->lb, vbytes));
         LBFGSX_HIP(hipMalloc(&c->ub, vbytes));
         LBFGSX_HIP(hipMalloc(&c->xcp, vbytes));
+        rc = bounded_alloc(c);
+        if (rc != LBFGSX_OK)
+            return rc;
     }
     LBFGSX_HIP(hipStreamSynchronize(c->stream));
     return LBFGSX_OK;
@@ -259,6 +262,7 @@ void lbfgsx_destroy(lbfgsx_ctx* c)
     (void) hipFree(c->ub);
     (void) hipFree(c->xcp);
     (void) hipFree(c->gather_tmp);
+    bounded_free(c);
     for (auto& e : c->ev_twoloop)
     {
         (void) hipEventDestroy(e.a);
@@ -417,7 +421,7 @@ int lbfgsx_commit_correction(lbfgsx_ctx* c)
     return LBFGSX_OK;
 }
 
-int lbfgsx_bfgs_add_correction_host(lbfgsx_ctx* c, const void* s, const void* y)
+int lbfgsx_bfgs_stage_correction_host(lbfgsx_ctx* c, const void* s, const void* y, double* sy, double* yy)
 {
     void* sp = c->col(c->S, c->spare);
     void* yp = c->col(c->Y, c->spare);
@@ -439,6 +443,16 @@ int lbfgsx_bfgs_add_correction_host(lbfgsx_ctx* c, const void* s, const void* y)
     c->pend_sy = r[0];
     c->pend_yy = r[1];
     c->pending = true;
+    if (sy) *sy = r[0];
+    if (yy) *yy = r[1];
+    return LBFGSX_OK;
+}
+
+int lbfgsx_bfgs_add_correction_host(lbfgsx_ctx* c, const void* s, const void* y)
+{
+    int rc = lbfgsx_bfgs_stage_correction_host(c, s, y, nullptr, nullptr);
+    if (rc)
+        return rc;
     return lbfgsx_commit_correction(c);
 }
 

@@ -19,7 +19,7 @@ namespace lbfgsx {
 
 constexpr int kBlock = 256;      // 4 waves of 64
 constexpr int kWaves = kBlock / 64;
-constexpr int kMaxRed = 6;       // max simultaneous reductions per kernel
+constexpr int kMaxRed = 16;      // max simultaneous reductions per kernel (4x4 Gram tile)
 
 // ---------------------------------------------------------------- accumulators
 struct DD

@@ -5,6 +5,7 @@
 #include <memory>
 
 #include "../../include/LBFGS.h"
+#include "../../include/LBFGSB.h"
 #include "../../include/lbfgsx_solver.h"
 
 using namespace LBFGSpp;
@@ -15,6 +16,7 @@ struct lbfgsx_solver
     virtual void prepare(int64_t n) = 0;
     virtual lbfgsx_ctx* ctx() = 0;
     virtual void set_hook(void (*fn)(int, void*), void* user) = 0;
+    long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     virtual void minimize(int objective, int64_t n, const void* a, const void* b, void* x, const void* lb,
                           const void* ub, lbfgsx_trace* tr, lbfgsx_result* out) = 0;
 };
@@ -122,6 +124,66 @@ struct LbfgsImpl : lbfgsx_solver
 };
 
 template <class Scalar>
+struct LbfgsbImpl : lbfgsx_solver
+{
+    LBFGSBParam<Scalar> param;
+    std::unique_ptr<LBFGSBSolver<Scalar> > solver;
+    LbfgsbImpl(const lbfgsx_params* p, int device)
+    {
+        fill_common<Scalar>(param, p);
+        param.max_submin = p->max_submin;
+        solver.reset(new LBFGSBSolver<Scalar>(param));
+        solver->set_device(device);
+    }
+    void prepare(int64_t n) override { solver->prepare_resident(n); }
+    lbfgsx_ctx* ctx() override { return solver->device_state().ctx(); }
+    void set_hook(void (*fn)(int, void*), void* user) override
+    {
+        if (fn)
+            solver->set_iteration_hook([fn, user](int k) { fn(k, user); });
+        else
+            solver->set_iteration_hook(nullptr);
+    }
+    void minimize(int objective, int64_t n, const void* a, const void* b, void* x, const void* lb, const void* ub,
+                  lbfgsx_trace* tr, lbfgsx_result* out) override
+    {
+        BuiltinObjective<Scalar> f(objective, static_cast<const Scalar*>(a), static_cast<const Scalar*>(b));
+        std::function<void(int, Scalar, DeviceState<Scalar>&)> cb;
+        install_trace<Scalar>(tr, cb);
+        solver->set_trace(cb);
+        Scalar fx = Scalar(0);
+        try
+        {
+            if (x)
+            {
+                if (!lb || !ub)
+                    throw std::invalid_argument("'lb' and 'ub' must have the same size as 'x'");
+                HostSpan<Scalar> xv = {static_cast<Scalar*>(x), n};
+                const HostSpan<Scalar> lv = {const_cast<Scalar*>(static_cast<const Scalar*>(lb)), n};
+                const HostSpan<Scalar> uv = {const_cast<Scalar*>(static_cast<const Scalar*>(ub)), n};
+                out->niter = solver->minimize(f, xv, fx, lv, uv);
+            }
+            else
+                out->niter = solver->minimize_resident(f, n, fx);
+        }
+        catch (...)
+        {
+            out->nfev = solver->num_evaluations();
+            throw;
+        }
+        out->fx = double(fx);
+        out->gnorm = double(solver->final_grad_norm());
+        out->nfev = solver->num_evaluations();
+        const auto& st = solver->stats();
+        stats[0] = st.gcp_crossings;
+        stats[1] = st.submin_sweeps;
+        stats[2] = st.submin_calls;
+        stats[3] = st.submin_unconverged;
+        stats[4] = st.resets;
+    }
+};
+
+template <class Scalar>
 lbfgsx_solver* make_lbfgs(int ls, const lbfgsx_params* p, int device)
 {
     switch (ls)
@@ -180,6 +242,13 @@ int lbfgsx_solver_create(lbfgsx_solver** out, int algo, int dtype, int linesearc
             throw std::invalid_argument("unknown dtype");
         if (algo == LBFGSX_ALGO_LBFGS)
             *out = (dtype == LBFGSX_F64) ? make_lbfgs<double>(linesearch, p, device) : make_lbfgs<float>(linesearch, p, device);
+        else if (algo == LBFGSX_ALGO_LBFGSB)
+        {
+            if (linesearch != LBFGSX_LS_MORE_THUENTE)
+                throw std::invalid_argument("LBFGSBSolver is instantiated with LineSearchMoreThuente only");
+            *out = (dtype == LBFGSX_F64) ? static_cast<lbfgsx_solver*>(new LbfgsbImpl<double>(p, device))
+                                         : static_cast<lbfgsx_solver*>(new LbfgsbImpl<float>(p, device));
+        }
         else
             throw std::invalid_argument("unknown algorithm");
     });
@@ -196,6 +265,67 @@ int lbfgsx_solver_prepare(lbfgsx_solver* s, int64_t n)
 }
 
 lbfgsx_ctx* lbfgsx_solver_ctx(lbfgsx_solver* s) { return s->ctx(); }
+
+// Test entry: feed `npairs` corrections into a fresh L-BFGS-B matrix, then run Cauchy::get_cauchy_point and
+// SubspaceMin::subspace_minimize of the drop-in headers at (x0, g, lb, ub).  Outputs are host arrays.
+int lbfgsx_test_cauchy_subspace(int dtype, int64_t n, int m, int npairs, const void* S, const void* Y, const void* x0,
+                                const void* g, const void* lb, const void* ub, int max_submin, void* xcp, double* vecc,
+                                unsigned char* state, void* drt, long long counts[4], char* errbuf, int errlen)
+{
+    lbfgsx_result r;
+    int rc = guarded(&r, [&]() {
+        auto body = [&](auto tag) {
+            typedef decltype(tag) T;
+            DeviceState<T> dev;
+            dev.ensure(n, m, LBFGSX_FLAG_BOUNDED, 0);
+            lbfgsx_ctx* c = dev.ctx();
+            BFGSMatB<T> bfgs;
+            bfgs.reset(c, m);
+            for (int k = 0; k < npairs; k++)
+            {
+                double sy = 0, yy = 0;
+                detail::check(lbfgsx_bfgs_stage_correction_host(c, static_cast<const T*>(S) + size_t(k) * size_t(n),
+                                                                static_cast<const T*>(Y) + size_t(k) * size_t(n), &sy, &yy));
+                bfgs.add_correction(T(sy), T(yy));
+            }
+            dev.upload(LBFGSX_VEC_X, static_cast<const T*>(x0));
+            dev.upload(LBFGSX_VEC_G, static_cast<const T*>(g));
+            dev.upload(LBFGSX_VEC_LB, static_cast<const T*>(lb));
+            dev.upload(LBFGSX_VEC_UB, static_cast<const T*>(ub));
+            typename Cauchy<T>::Result gcp;
+            Cauchy<T>::get_cauchy_point(bfgs, gcp);
+            dev.download(LBFGSX_VEC_XCP, static_cast<T*>(xcp));
+            for (size_t j = 0; j < gcp.vecc.size(); j++)
+                vecc[j] = double(gcp.vecc[j]);
+            counts[0] = gcp.nact;
+            counts[1] = gcp.nfree;
+            counts[2] = gcp.crossings;
+            if (state)
+                detail::check(lbfgsx_b_download_state(c, state));
+            if (drt)
+            {
+                typename SubspaceMin<T>::Stats st;
+                SubspaceMin<T>::subspace_minimize(bfgs, gcp, max_submin, &st);
+                counts[3] = st.sweeps;
+                dev.download(LBFGSX_VEC_D, static_cast<T*>(drt));
+            }
+        };
+        if (dtype == LBFGSX_F64)
+            body(double());
+        else
+            body(float());
+    });
+    if (errbuf && errlen > 0)
+        std::snprintf(errbuf, size_t(errlen), "%s", r.msg);
+    return rc;
+}
+
+int lbfgsx_solver_stats(lbfgsx_solver* s, long long out[8])
+{
+    for (int k = 0; k < 8; k++)
+        out[k] = s->stats[k];
+    return LBFGSX_OK;
+}
 
 int lbfgsx_solver_set_iteration_hook(lbfgsx_solver* s, void (*fn)(int, void*), void* user)
 {

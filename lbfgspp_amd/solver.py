@@ -165,3 +165,37 @@ class LBFGSSolver(_SolverBase):
 
     def final_grad_norm(self):
         return self.last.gnorm
+
+
+class LBFGSBSolver(_SolverBase):
+    """LBFGSBSolver<Scalar> with LineSearchMoreThuente (reference LBFGSB.h:21-23)."""
+    _algo = L.ALGO_LBFGSB
+
+    def __init__(self, param, dtype=np.float64, device=0):
+        super().__init__(param, linesearch=L.LS_MORE_THUENTE, dtype=dtype, device=device)
+
+    def minimize(self, f, x, lb, ub, trace=None):
+        """minimize(f, x, fx, lb, ub): x updated in place; raises ValueError when lb/ub sizes differ from x."""
+        dt = _NP[self.dtype]
+        xx = np.ascontiguousarray(x, dt)
+        lbv, ubv = np.ascontiguousarray(lb, dt), np.ascontiguousarray(ub, dt)
+        if lbv.size != xx.size or ubv.size != xx.size:
+            raise ValueError("'lb' and 'ub' must have the same size as 'x'")
+        r = self._minimize(f, xx.size, xx, lbv, ubv, trace)
+        if xx is not x:
+            x[...] = xx
+        return r.niter, r.fx
+
+    def minimize_resident(self, f, n, trace=None):
+        """x0, lb, ub already in VEC_X / VEC_LB / VEC_UB of the device state (see prepare())."""
+        r = self._minimize(f, n, None, None, None, trace)
+        return r.niter, r.fx
+
+    def final_grad_norm(self):
+        return self.last.gnorm
+
+    def stats(self):
+        arr = (C.c_longlong * 8)()
+        L.check(self._sol.lbfgsx_solver_stats(self._h, C.byref(arr)))
+        keys = ("gcp_crossings", "submin_sweeps", "submin_calls", "submin_unconverged", "resets")
+        return dict(zip(keys, list(arr)[:5]))

@@ -1,0 +1,57 @@
+#!/usr/bin/env python
+"""cfg4 of BASELINE.json: L-BFGS-B on the box-constrained diag quadratic, lb=-1, ub=1 (run on the GPU box)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=float, default=1e7)
+    ap.add_argument("--m", type=int, default=10)
+    ap.add_argument("--iters", type=int, default=40)
+    ap.add_argument("--cpu-n", type=float, default=0)
+    args = ap.parse_args()
+    import torch  # noqa: F401
+    import lbfgspp_amd as A
+    from lbfgspp_amd import _lib as L
+    core, _ = A.load()
+    n = int(args.n)
+    s = A.LBFGSBSolver(A.LBFGSBParam(m=args.m, epsilon=0, epsilon_rel=0, past=0, max_iterations=args.iters))
+    ctx = s.prepare(n)
+    L.check(core.lbfgsx_gen_diag_quad(ctx, 10.0, 1))
+    L.check(core.lbfgsx_fill(ctx, L.VEC_X, 0.0))
+    L.check(core.lbfgsx_fill(ctx, L.VEC_LB, -1.0))
+    L.check(core.lbfgsx_fill(ctx, L.VEC_UB, 1.0))
+    L.check(core.lbfgsx_sync(ctx))
+    stamps = []
+    s.set_iteration_hook(lambda k: stamps.append(time.perf_counter()))
+    t0 = time.perf_counter()
+    niter, fx = s.minimize_resident(A.DiagQuadratic(), n)
+    t1 = time.perf_counter()
+    per = np.diff(np.array([t0] + stamps))
+    out = dict(n=n, m=args.m, niter=niter, nfev=s.last.nfev, fx=fx, total_s=t1 - t0, it_per_s=niter / (t1 - t0),
+               steady_it_per_s=float(1.0 / np.median(per[len(per) // 2:])) if len(per) > 4 else None,
+               per_iter_ms=[round(1e3 * v, 2) for v in per], stats=s.stats())
+    if args.cpu_n:
+        import oracle_lib as O
+        orc = O.Oracle("ref", "native")
+        cn = int(args.cpu_n)
+        a, b = O.quad_problem(cn)
+        p = O.lbfgsb_params(m=args.m, epsilon=0, epsilon_rel=0, past=0, max_iterations=args.iters)
+        t = time.perf_counter()
+        _, r = orc.lbfgsb(O.F64, O.OBJ_QUAD, np.zeros(cn), -np.ones(cn), np.ones(cn), p, a=a, b=b)
+        dt = time.perf_counter() - t
+        out["cpu_reference"] = dict(n=cn, niter=r.niter, nfev=r.nfev, seconds=dt, it_per_s=r.niter / dt)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

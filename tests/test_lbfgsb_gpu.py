@@ -1,0 +1,162 @@
+"""-m gpu: L-BFGS-B device path (Cauchy point, subspace minimisation, driver) against the CPU oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def A():
+    import lbfgspp_amd as A
+    core, _ = A.load()
+    assert core.lbfgsx_device_count() >= 1
+    return A
+
+
+def _device_cauchy_subspace(A, dtype, m, S, Y, x0, g, lb, ub, max_submin=10, subspace=True):
+    _, sol = A.load()
+    dt = O.NPDT[dtype]
+    n = x0.size
+    S = np.ascontiguousarray(S, dt).reshape(-1, n)
+    Y = np.ascontiguousarray(Y, dt).reshape(-1, n)
+    npairs = S.shape[0]
+    xcp = np.empty(n, dt)
+    drt = np.empty(n, dt) if subspace else None
+    vecc = np.zeros(2 * m, np.float64)
+    state = np.zeros(n, np.uint8)
+    counts = (C.c_longlong * 4)()
+    err = C.create_string_buffer(256)
+    f = sol.lbfgsx_test_cauchy_subspace
+    f.restype = C.c_int
+    f.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p, C.c_void_p,
+                                                                               C.c_void_p, C.c_void_p, C.c_void_p,
+                                                                               C.c_char_p, C.c_int]
+    p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    args = [np.ascontiguousarray(v, dt) for v in (x0, g, lb, ub)]
+    rc = f(dtype, n, m, npairs, p(S), p(Y), p(args[0]), p(args[1]), p(args[2]), p(args[3]), max_submin, p(xcp), p(vecc),
+           p(state), p(drt), C.cast(counts, C.c_void_p), err, 256)
+    assert rc == 0, err.value
+    return dict(xcp=xcp, vecc=vecc[:2 * min(npairs, m)], state=state, drt=drt, nact=counts[0], nfree=counts[1],
+                crossings=counts[2], sweeps=counts[3])
+
+
+def _instance(rng, n, npairs, dtype, mode):
+    dt = O.NPDT[dtype]
+    S = rng.standard_normal((max(npairs, 1), n))[:npairs]
+    Y = S * (1.0 + rng.random((npairs, n))) + 0.05 * rng.standard_normal((npairs, n))
+    lb = -1.0 - rng.random(n)
+    ub = 1.0 + rng.random(n)
+    x0 = np.clip(rng.standard_normal(n), lb, ub)
+    g = rng.standard_normal(n) * (10.0 if mode != "gentle" else 0.3)
+    if mode == "edge":
+        fixed = rng.random(n) < 0.05
+        ub[fixed] = lb[fixed]
+        x0[fixed] = lb[fixed]
+        g[rng.random(n) < 0.05] = 0.0                # free forever (brk = inf)
+        onb = rng.random(n) < 0.05
+        x0[onb] = ub[onb]                            # start on a bound
+        tie = rng.random(n) < 0.1                    # a tie group of equal break points
+        x0[tie], lb[tie], ub[tie], g[tie] = 0.0, -1.0, 1.0, 4.0
+    return (S.astype(dt), Y.astype(dt), x0.astype(dt), g.astype(dt), lb.astype(dt), ub.astype(dt))
+
+
+@pytest.mark.parametrize("dtype", [O.F64])
+@pytest.mark.parametrize("n,m,npairs,mode", [(3000, 6, 0, "hard"), (3000, 6, 4, "hard"), (5000, 6, 9, "edge"),
+                                             (4096, 8, 8, "gentle"), (2500, 5, 5, "edge"), (64, 3, 2, "hard")])
+def test_cauchy_and_subspace_match_oracle(A, oracle, dtype, n, m, npairs, mode):
+    rng = np.random.default_rng(100 + n + npairs)
+    S, Y, x0, g, lb, ub = _instance(rng, n, npairs, dtype, mode)
+    ref = oracle.cauchy_subspace(dtype, m, S, Y, x0, g, lb, ub, max_submin=10)
+    got = _device_cauchy_subspace(A, dtype, m, S, Y, x0, g, lb, ub, max_submin=10)
+    # identical index sets (the device keeps them as a state byte)
+    newact = np.zeros(n, bool)
+    newact[ref["newact"]] = True
+    free = np.zeros(n, bool)
+    free[ref["fv"]] = True
+    assert got["nact"] == newact.sum() and got["nfree"] == free.sum()
+    assert np.array_equal((got["state"] & 2) != 0, newact)
+    assert np.array_equal((got["state"] & 1) != 0, free)
+    scale = max(1.0, np.abs(ref["xcp"]).max())
+    assert np.abs(got["xcp"] - ref["xcp"]).max() <= 1e-12 * scale
+    if ref["vecc"].size:
+        assert np.abs(got["vecc"] - ref["vecc"]).max() <= 1e-11 * max(1.0, np.abs(ref["vecc"]).max())
+    dscale = max(1.0, np.abs(ref["drt"]).max())
+    assert np.abs(got["drt"] - ref["drt"]).max() <= 1e-9 * dscale
+
+
+def test_cauchy_all_on_bounds(A, oracle):
+    """nfree < 1 and nord < 1: xcp = x0, empty sets (reference Cauchy.h:140-145)."""
+    n, m = 100, 4
+    x0 = np.ones(n)
+    lb, ub = np.ones(n), np.ones(n)
+    g = np.linspace(-1, 1, n)
+    got = _device_cauchy_subspace(A, O.F64, m, np.zeros((0, n)), np.zeros((0, n)), x0, g, lb, ub)
+    assert got["nact"] == 0 and got["nfree"] == 0 and np.array_equal(got["xcp"], x0)
+    assert np.array_equal(got["drt"], np.zeros(n))
+
+
+def _traj(A, oracle, n, m, iters, kappa=10.0, dtype=O.F64, bound=1.0):
+    a, b = O.quad_problem(n, kappa, 1, dtype)
+    dt = O.NPDT[dtype]
+    lb, ub = -bound * np.ones(n, dt), bound * np.ones(n, dt)
+    p = O.lbfgsb_params(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters)
+    tr_ref = O.TraceBuf(n, cap=1024)
+    x_ref, r_ref = oracle.lbfgsb(dtype, O.OBJ_QUAD, np.zeros(n, dt), lb, ub, p, a=a, b=b, trace=tr_ref)
+    s = A.LBFGSBSolver(A.LBFGSBParam(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters), dtype=dt)
+    tr = A.TraceBuffer(n, cap=1024)
+    x = np.zeros(n, dt)
+    niter, fx = s.minimize(A.DiagQuadratic(a, b), x, lb, ub, trace=tr)
+    return dict(x=x, niter=niter, fx=fx, nfev=s.last.nfev, tr=tr, x_ref=x_ref, r_ref=r_ref, tr_ref=tr_ref, stats=s.stats())
+
+
+@pytest.mark.parametrize("n,m,iters", [(2000, 6, 15), (20000, 10, 25)])
+def test_trajectory_box_quadratic_f64(A, oracle, n, m, iters):
+    r = _traj(A, oracle, n, m, iters)
+    assert (r["niter"], r["nfev"]) == (r["r_ref"].niter, r["r_ref"].nfev)
+    k = r["tr_ref"].count
+    assert r["tr"].count == k
+    err = np.abs(r["tr"].xs[:k] - r["tr_ref"].xs[:k]).max()
+    assert err <= 1e-10, "iterates deviate by %.3g" % err
+    assert np.abs(r["x"] - r["x_ref"]).max() <= 1e-10
+    # same active set at the end
+    assert np.array_equal(np.abs(r["x"]) == 1.0, np.abs(r["x_ref"]) == 1.0)
+    assert abs(r["fx"] - r["r_ref"].fx) <= 1e-12 * abs(r["r_ref"].fx)
+
+
+def test_box_quadratic_converges_to_projected_solution(A):
+    """property check without the oracle: the minimiser of the separable box QP is clip(b/a, lb, ub)."""
+    n = 50000
+    a, b = O.quad_problem(n, 10.0, 1)
+    lb, ub = -np.ones(n), np.ones(n)
+    s = A.LBFGSBSolver(A.LBFGSBParam(m=10, epsilon=1e-5, epsilon_rel=0.0, past=0, max_iterations=400))
+    x = np.zeros(n)
+    niter, fx = s.minimize(A.DiagQuadratic(a, b), x, lb, ub)
+    assert niter < 400
+    assert np.abs(x - np.clip(b / a, lb, ub)).max() < 1e-4
+    assert s.final_grad_norm() <= 1e-5
+
+
+def test_lbfgsb_argument_errors(A):
+    s = A.LBFGSBSolver(A.LBFGSBParam())
+    with pytest.raises(ValueError, match="'lb' and 'ub' must have the same size as 'x'"):
+        s.minimize(A.DiagQuadratic(np.ones(4), np.ones(4)), np.zeros(4), -np.ones(3), np.ones(4))
+    with pytest.raises(ValueError, match="'max_submin' must be non-negative"):
+        A.LBFGSBSolver(A.LBFGSBParam(max_submin=-1))
+
+
+def test_lbfgsb_start_outside_bounds_is_projected(A, oracle):
+    n = 3000
+    a, b = O.quad_problem(n)
+    lb, ub = -0.5 * np.ones(n), 0.5 * np.ones(n)
+    x0 = np.linspace(-3, 3, n)
+    p = O.lbfgsb_params(m=5, max_iterations=12, epsilon=0, epsilon_rel=0, past=0)
+    x_ref, r_ref = oracle.lbfgsb(O.F64, O.OBJ_QUAD, x0, lb, ub, p, a=a, b=b)
+    s = A.LBFGSBSolver(A.LBFGSBParam(m=5, max_iterations=12, epsilon=0, epsilon_rel=0, past=0))
+    x = x0.copy()
+    niter, fx = s.minimize(A.DiagQuadratic(a, b), x, lb, ub)
+    assert niter == r_ref.niter and s.last.nfev == r_ref.nfev
+    assert np.abs(x - x_ref).max() <= 1e-10
