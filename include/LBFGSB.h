@@ -52,6 +52,7 @@ public:
         long long submin_calls = 0;
         long long submin_unconverged = 0;
         long long resets = 0;
+        double gcp_build_s = 0, gcp_fetch_s = 0, gcp_total_s = 0, submin_s = 0;
     };
 
 private:
@@ -86,6 +87,9 @@ private:
         typename Cauchy<Scalar>::Result gcp;
         Cauchy<Scalar>::get_cauchy_point(m_bfgs, gcp);                  // (:154)
         m_stats.gcp_crossings += gcp.crossings;
+        m_stats.gcp_build_s += gcp.t_build;
+        m_stats.gcp_fetch_s += gcp.t_fetch;
+        m_stats.gcp_total_s += gcp.t_total;
         detail::check(lbfgsx_b_dir_from_xcp(c, 1));                     // drt = normalize(xcp - x) (:163-164)
         constexpr Scalar eps = std::numeric_limits<Scalar>::epsilon();
 
@@ -132,8 +136,13 @@ private:
             detail::check(lbfgsx_b_force_bounds(c));                    // (:240)
             Cauchy<Scalar>::get_cauchy_point(m_bfgs, gcp);              // (:241)
             m_stats.gcp_crossings += gcp.crossings;
+            m_stats.gcp_build_s += gcp.t_build;
+            m_stats.gcp_fetch_s += gcp.t_fetch;
+            m_stats.gcp_total_s += gcp.t_total;
             typename SubspaceMin<Scalar>::Stats st;
+            const auto t_sub = std::chrono::steady_clock::now();
             SubspaceMin<Scalar>::subspace_minimize(m_bfgs, gcp, m_param.max_submin, &st);  // (:249-250)
+            m_stats.submin_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_sub).count();
             m_stats.submin_calls++;
             m_stats.submin_sweeps += st.sweeps;
             m_stats.submin_unconverged += st.converged ? 0 : 1;

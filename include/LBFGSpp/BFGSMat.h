@@ -25,6 +25,7 @@ class BFGSMatB
     std::vector<Scalar> m_permMinv;  // column-major 2m x 2m
     BKLDLT<Scalar> m_solver;
     lbfgsx_ctx* m_c = nullptr;
+    mutable std::vector<Scalar> m_pad;  // scratch of apply_Mv
 
     Scalar& Minv(int i, int j) { return m_permMinv[size_t(j) * size_t(2 * m_m) + size_t(i)]; }
     const Scalar& Minv(int i, int j) const { return m_permMinv[size_t(j) * size_t(2 * m_m) + size_t(i)]; }
@@ -95,7 +96,8 @@ public:
         res.assign(size_t(2 * m_ncorr), Scalar(0));
         if (m_ncorr < 1)
             return;
-        std::vector<Scalar> pad(size_t(2 * m_m), Scalar(0));
+        std::vector<Scalar>& pad = m_pad;
+        pad.assign(size_t(2 * m_m), Scalar(0));
         for (int j = 0; j < m_ncorr; j++)
         {
             pad[size_t(j)] = v[size_t(j)];

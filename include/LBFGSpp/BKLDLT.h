@@ -58,6 +58,11 @@ class BKLDLT
     std::vector<Scalar> m_a;   // dense column-major n x n, entries (i,j) with i >= j are meaningful
     std::vector<int> m_perm;   // >= 0: 1x1 pivot exchanged with that row; < 0: part of a 2x2 block (-row-1)
     std::vector<std::pair<int, int> > m_swaps;
+    // rows t > j with L(t, j) != 0, ascending.  The padded 2m x 2m system of apply_Mv carries identity rows
+    // for unused history slots (BFGSMat.h:74-76), so most of L is exactly zero while the history fills up;
+    // skipping exact zeros leaves every result bit unchanged (x - 0*v == x, and a zero product adds nothing
+    // to the accumulator) and makes the per-break-point solve of the GCP scan O(c^2) instead of O(m^2).
+    std::vector<std::vector<int> > m_nz;
     bool m_computed = false;
     int m_info = NOT_COMPUTED;
 
@@ -208,6 +213,17 @@ class BKLDLT
         return SUCCESSFUL;
     }
 
+    // sum over rows t >= first of x[t] * L(t, col), skipping exact zeros of L
+    Scalar sparse_dot(const Scalar* x, int col, int first) const
+    {
+        detail::HostAcc<Scalar> acc;
+        const std::vector<int>& nz = m_nz[size_t(col)];
+        for (size_t q = 0; q < nz.size(); q++)
+            if (nz[q] >= first)
+                acc.add_prod(x[nz[q]], at(nz[q], col));
+        return acc.value();
+    }
+
 public:
     BKLDLT() {}
     // `mat` is a dense column-major n x n array with leading dimension `ld`; only its lower triangle is read
@@ -253,6 +269,11 @@ public:
             if (p != i)
                 m_swaps.push_back(std::make_pair(i, p));
         }
+        m_nz.assign(size_t(n), std::vector<int>());
+        for (int j = 0; j < n; j++)
+            for (int t = j + 1; t < n; t++)
+                if (at(t, j) != Scalar(0))
+                    m_nz[size_t(j)].push_back(t);
         m_computed = true;
     }
 
@@ -268,19 +289,37 @@ public:
         const int end = (m_perm[size_t(n - 1)] < 0) ? (n - 3) : (n - 2);
         for (int i = 0; i <= end; i++)
         {
-            const int b1 = n - i - 1, b2 = b1 - 1;
             if (m_perm[size_t(i)] >= 0)
             {
-                const Scalar* l = &at(i + 1, i);
-                for (int t = 0; t < b1; t++)
-                    x[i + 1 + t] = x[i + 1 + t] - l[t] * x[i];
+                const std::vector<int>& nz = m_nz[size_t(i)];
+                for (size_t q = 0; q < nz.size(); q++)
+                {
+                    const int t = nz[q];
+                    x[t] = x[t] - at(t, i) * x[i];
+                }
             }
             else
             {
-                const Scalar* l1 = &at(i + 2, i);
-                const Scalar* l2 = &at(i + 2, i + 1);
-                for (int t = 0; t < b2; t++)
-                    x[i + 2 + t] = x[i + 2 + t] - (l1[t] * x[i] + l2[t] * x[i + 1]);
+                // rows t >= i+2 of the column pair (i, i+1); union of the two sparsity patterns
+                const std::vector<int>& n1 = m_nz[size_t(i)];
+                const std::vector<int>& n2 = m_nz[size_t(i + 1)];
+                size_t q1 = 0, q2 = 0;
+                while (q1 < n1.size() && n1[q1] < i + 2)
+                    q1++;
+                while (q1 < n1.size() || q2 < n2.size())
+                {
+                    int t;
+                    if (q2 >= n2.size() || (q1 < n1.size() && n1[q1] <= n2[q2]))
+                    {
+                        t = n1[q1];
+                        if (q2 < n2.size() && n2[q2] == t)
+                            q2++;
+                        q1++;
+                    }
+                    else
+                        t = n2[q2++];
+                    x[t] = x[t] - (at(t, i) * x[i] + at(t, i + 1) * x[i + 1]);
+                }
                 i++;
             }
         }
@@ -301,11 +340,10 @@ public:
         int i = (m_perm[size_t(n - 1)] < 0) ? (n - 3) : (n - 2);
         for (; i >= 0; i--)
         {
-            const int ld = n - i - 1;
-            x[i] -= detail::host_dot(x + i + 1, &at(i + 1, i), ld);
+            x[i] -= sparse_dot(x, i, i + 1);
             if (m_perm[size_t(i)] < 0)
             {
-                x[i - 1] -= detail::host_dot(x + i + 1, &at(i + 1, i - 1), ld);
+                x[i - 1] -= sparse_dot(x, i - 1, i + 1);
                 i--;
             }
         }

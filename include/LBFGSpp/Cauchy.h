@@ -14,6 +14,7 @@
 #define LBFGSX_DROPIN_CAUCHY_H
 
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <limits>
 #include <vector>
@@ -35,12 +36,14 @@ class Cauchy
         std::int64_t m_next_chunk = 512;
 
     public:
+        double fetch_seconds = 0.0;
         Stream(lbfgsx_ctx* c, std::int64_t nord, int ncorr) : m_c(c), m_nord(nord), m_nc(ncorr) {}
         void need(std::int64_t k)
         {
             while (k >= m_have && m_have < m_nord)
             {
                 const std::int64_t cnt = std::min<std::int64_t>(m_next_chunk, m_nord - m_have);
+                const auto t0 = std::chrono::steady_clock::now();
                 m_brk.resize(size_t(m_have + cnt));
                 m_g.resize(size_t(m_have + cnt));
                 m_z.resize(size_t(m_have + cnt));
@@ -49,13 +52,14 @@ class Cauchy
                                                     m_z.data() + m_have, nullptr,
                                                     m_nc ? m_w.data() + size_t(m_have) * size_t(2 * m_nc) : nullptr));
                 m_have += cnt;
+                fetch_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                 m_next_chunk = std::min<std::int64_t>(m_next_chunk * 8, std::int64_t(1) << 22);
             }
         }
-        Scalar brk(std::int64_t k) { need(k); return Scalar(m_brk[size_t(k)]); }
-        Scalar g(std::int64_t k) { need(k); return Scalar(m_g[size_t(k)]); }
-        Scalar z(std::int64_t k) { need(k); return Scalar(m_z[size_t(k)]); }
-        const double* w(std::int64_t k) { need(k); return m_w.data() + size_t(k) * size_t(2 * m_nc); }
+        Scalar brk(std::int64_t k) { if (k >= m_have) need(k); return Scalar(m_brk[size_t(k)]); }
+        Scalar g(std::int64_t k) { if (k >= m_have) need(k); return Scalar(m_g[size_t(k)]); }
+        Scalar z(std::int64_t k) { if (k >= m_have) need(k); return Scalar(m_z[size_t(k)]); }
+        const double* w(std::int64_t k) { if (k >= m_have) need(k); return m_w.data() + size_t(k) * size_t(2 * m_nc); }
     };
 
 public:
@@ -65,6 +69,7 @@ public:
         std::int64_t nact = 0;         // |newact_set|
         std::int64_t nfree = 0;        // |fv_set|
         std::int64_t crossings = 0;    // break points crossed (instrumentation)
+        double t_build = 0, t_fetch = 0, t_total = 0;  // seconds (instrumentation)
     };
 
     // xcp and the state byte are left on the device; vecc and the set sizes are returned
@@ -80,7 +85,9 @@ public:
         std::int64_t nfree = 0, nord = 0;
         double dd = 0;
         double wtd[80];
+        const auto t_begin = std::chrono::steady_clock::now();
         detail::check(lbfgsx_b_cauchy_build(c, &nfree, &nord, &dd, wtd));
+        out.t_build = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
         if (nfree < 1 && nord < 1)
         {
             // every coordinate sits on its bound: xcp = x0, empty sets (:140-145)
@@ -134,10 +141,18 @@ public:
                     wact[size_t(j)] = Scalar(w[j]);
                     wact[size_t(ncorr + j)] = Scalar(w[ncorr + j]) * theta;   // Wb(): tail *= theta (BFGSMat.h:333)
                 }
-                bfgs.apply_Mv(wact, cache);
-                fp += ggact + theta * gact * zact - gact * detail::host_dot(cache.data(), out.vecc.data(), 2 * ncorr);
-                fpp -= (theta * ggact + 2 * gact * detail::host_dot(cache.data(), vecp.data(), 2 * ncorr) +
-                        ggact * detail::host_dot(cache.data(), wact.data(), 2 * ncorr));
+                // with an empty history W has no columns: the three dot products are exact zeros, so the
+                // statements below reduce to the same arithmetic without the (no-op) M solve
+                Scalar d_c = Scalar(0), d_p = Scalar(0), d_w = Scalar(0);
+                if (ncorr > 0)
+                {
+                    bfgs.apply_Mv(wact, cache);
+                    d_c = detail::host_dot(cache.data(), out.vecc.data(), 2 * ncorr);
+                    d_p = detail::host_dot(cache.data(), vecp.data(), 2 * ncorr);
+                    d_w = detail::host_dot(cache.data(), wact.data(), 2 * ncorr);
+                }
+                fp += ggact + theta * gact * zact - gact * d_c;
+                fpp -= (theta * ggact + 2 * gact * d_p + ggact * d_w);
                 for (int j = 0; j < 2 * ncorr; j++)
                     vecp[size_t(j)] = vecp[size_t(j)] + gact * wact[size_t(j)];
             }
@@ -165,6 +180,8 @@ public:
             tfinal = il + deltatmin;
         }
         detail::check(lbfgsx_b_cauchy_finish(c, double(t_cross), double(tfinal), crossed_all ? 1 : 0, &out.nact, &out.nfree));
+        out.t_fetch = ord.fetch_seconds;
+        out.t_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     }
 };
 

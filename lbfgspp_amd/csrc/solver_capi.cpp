@@ -17,6 +17,7 @@ struct lbfgsx_solver
     virtual lbfgsx_ctx* ctx() = 0;
     virtual void set_hook(void (*fn)(int, void*), void* user) = 0;
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long stats_submin_us = 0;
     virtual void minimize(int objective, int64_t n, const void* a, const void* b, void* x, const void* lb,
                           const void* ub, lbfgsx_trace* tr, lbfgsx_result* out) = 0;
 };
@@ -180,6 +181,10 @@ struct LbfgsbImpl : lbfgsx_solver
         stats[2] = st.submin_calls;
         stats[3] = st.submin_unconverged;
         stats[4] = st.resets;
+        stats[5] = (long long) (st.gcp_build_s * 1e6);
+        stats[6] = (long long) (st.gcp_fetch_s * 1e6);
+        stats[7] = (long long) (st.gcp_total_s * 1e6);
+        stats_submin_us = (long long) (st.submin_s * 1e6);
     }
 };
 

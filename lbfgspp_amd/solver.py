@@ -197,5 +197,6 @@ class LBFGSBSolver(_SolverBase):
     def stats(self):
         arr = (C.c_longlong * 8)()
         L.check(self._sol.lbfgsx_solver_stats(self._h, C.byref(arr)))
-        keys = ("gcp_crossings", "submin_sweeps", "submin_calls", "submin_unconverged", "resets")
-        return dict(zip(keys, list(arr)[:5]))
+        keys = ("gcp_crossings", "submin_sweeps", "submin_calls", "submin_unconverged", "resets", "gcp_build_us",
+                "gcp_fetch_us", "gcp_total_us")
+        return dict(zip(keys, list(arr)))

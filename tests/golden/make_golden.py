@@ -42,6 +42,51 @@ def lbfgs_case(orc, name, dtype, ls, obj, n, m, iters, seed=7, kappa=10.0, strid
                 x_sample=hx(x[::stride]))
 
 
+def lbfgsb_instance(seed, n, npairs, mode):
+    """Deterministic Cauchy/subspace test instance (same generator as tests/test_lbfgsb_gpu.py)."""
+    rng = np.random.default_rng(seed)
+    S = rng.standard_normal((max(npairs, 1), n))[:npairs]
+    Y = S * (1.0 + rng.random((npairs, n))) + 0.05 * rng.standard_normal((npairs, n))
+    lb = -1.0 - rng.random(n)
+    ub = 1.0 + rng.random(n)
+    x0 = np.clip(rng.standard_normal(n), lb, ub)
+    g = rng.standard_normal(n) * (10.0 if mode != "gentle" else 0.3)
+    if mode == "edge":
+        fixed = rng.random(n) < 0.05
+        ub[fixed] = lb[fixed]
+        x0[fixed] = lb[fixed]
+        g[rng.random(n) < 0.05] = 0.0
+        onb = rng.random(n) < 0.05
+        x0[onb] = ub[onb]
+        tie = rng.random(n) < 0.1
+        x0[tie], lb[tie], ub[tie], g[tie] = 0.0, -1.0, 1.0, 4.0
+    return S, Y, x0, g, lb, ub
+
+
+def make_lbfgsb(orc):
+    out = dict(generator="tests/golden/make_golden.py", oracle=orc.description, trajectories=[], instances=[])
+    for name, n, m, iters, stride in (("boxquad_n2000_m6", 2000, 6, 15, 4), ("boxquad_n6000_m10", 6000, 10, 20, 16)):
+        a, b = O.quad_problem(n)
+        p = O.lbfgsb_params(m=m, epsilon=0.0, epsilon_rel=0.0, past=0, max_iterations=iters)
+        tr = O.TraceBuf(n, cap=1024, stride=stride)
+        x, r = orc.lbfgsb(O.F64, O.OBJ_QUAD, np.zeros(n), -np.ones(n), np.ones(n), p, a=a, b=b, trace=tr)
+        k = tr.count
+        out["trajectories"].append(dict(name=name, n=n, m=m, max_iterations=iters, stride=stride, niter=r.niter,
+                                        nfev=r.nfev, fx=float(r.fx).hex(), gnorm=float(r.gnorm).hex(),
+                                        trace_fx=hx(tr.fx[:k]), trace_xs=hx(tr.xs[:k]), x_sample=hx(x[::stride])))
+    for seed, n, m, npairs, mode in ((1, 512, 6, 0, "hard"), (2, 512, 6, 4, "hard"), (3, 768, 5, 9, "edge"),
+                                     (4, 640, 8, 8, "gentle")):
+        S, Y, x0, g, lb, ub = lbfgsb_instance(seed, n, npairs, mode)
+        res = orc.cauchy_subspace(O.F64, m, S, Y, x0, g, lb, ub, max_submin=10)
+        out["instances"].append(dict(seed=seed, n=n, m=m, npairs=npairs, mode=mode, xcp=hx(res["xcp"]),
+                                     vecc=hx(res["vecc"]), drt=hx(res["drt"]), newact=[int(v) for v in res["newact"]],
+                                     fv=[int(v) for v in res["fv"]]))
+    with open(os.path.join(HERE, "lbfgsb_golden.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    print("wrote L-BFGS-B golden:", [(t["name"], t["niter"], t["nfev"]) for t in out["trajectories"]],
+          [(i["seed"], len(i["newact"]), len(i["fv"])) for i in out["instances"]])
+
+
 def main():
     orc = O.Oracle("ref", "dd")
     cases = []
@@ -57,6 +102,7 @@ def main():
         cases.append(lbfgs_case(orc, "rosen_n4096_m6_f64_" + nm, O.F64, ls, O.OBJ_ROSEN, 4096, 6, 25, epsilon=0.0, epsilon_rel=0.0))
         cases.append(lbfgs_case(orc, "quad_n5001_m10_f64_" + nm, O.F64, ls, O.OBJ_QUAD, 5001, 10, 25, epsilon=0.0, epsilon_rel=0.0))
         cases.append(lbfgs_case(orc, "rosen_n4098_m5_f32_" + nm, O.F32, ls, O.OBJ_ROSEN, 4098, 5, 12, seed=1000, epsilon=0.0, epsilon_rel=0.0))
+    make_lbfgsb(orc)
     with open(os.path.join(HERE, "lbfgs_golden.json"), "w") as f:
         json.dump(dict(generator="tests/golden/make_golden.py", oracle=orc.description, cases=cases), f, indent=0)
     print("wrote", len(cases), "L-BFGS cases")

@@ -96,6 +96,14 @@ class Oracle:
         self._cs.argtypes = [C.c_int, C.c_long, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp,
                              C.POINTER(C.c_int), vp, C.POINTER(C.c_int), vp]
 
+    @property
+    def supports_lbfgsb(self):
+        """False for the restatement until its L-BFGS-B part is built (entry points answer -1000)."""
+        x = np.zeros(2)
+        _, r = self.lbfgsb(F64, OBJ_QUAD, x, -np.ones(2), np.ones(2), lbfgsb_params(max_iterations=1),
+                           a=np.ones(2), b=np.ones(2))
+        return r.status != -1000
+
     @staticmethod
     def _p(arr):
         return None if arr is None else arr.ctypes.data_as(C.c_void_p)

@@ -231,3 +231,29 @@ def test_large_n_properties(A):
     L.check(core.lbfgsx_gather(h, L.VEC_D, 4096, g2.ctypes.data_as(C.POINTER(C.c_double))))
     assert np.array_equal(2.0 * g1, g2) and dg2.value == 2.0 * dg1.value
     assert dg1.value < 0  # -H g is a descent direction
+
+
+# ---------------------------------------------------------------- golden fixtures (need no oracle library)
+import golden_util as G  # noqa: E402
+
+_GOLD = G.load("lbfgs_golden.json")
+
+
+@pytest.mark.parametrize("case", _GOLD["cases"], ids=[c["name"] for c in _GOLD["cases"]])
+def test_lbfgs_golden(A, case):
+    x0, a, b = G.case_inputs(case)
+    pr = case["params"]
+    par = A.LBFGSParam(**{k: pr[k] for k in ("m", "epsilon", "epsilon_rel", "past", "delta", "max_iterations",
+                                             "linesearch", "max_linesearch", "min_step", "max_step", "ftol", "wolfe")})
+    s = A.LBFGSSolver(par, linesearch=case["ls"], dtype=O.NPDT[case["dtype"]])
+    tr = A.TraceBuffer(case["n"], cap=1024, stride=case["stride"])
+    x = x0.copy()
+    f = A.DiagQuadratic(a, b) if case["obj"] == O.OBJ_QUAD else A.ExtendedRosenbrock()
+    niter, fx = s.minimize(f, x, trace=tr)
+    assert (niter, s.last.nfev) == (case["niter"], case["nfev"])
+    k = tr.count
+    tol = TOL[case["dtype"]]
+    assert np.abs(tr.xs[:k].ravel() - G.unhex(case["trace_xs"])).max() <= tol
+    assert np.abs(np.asarray(x[::case["stride"]], np.float64) - G.unhex(case["x_sample"])).max() <= tol
+    # with order-independent reductions the HIP path is expected to reproduce the reference bit for bit
+    assert fx == float.fromhex(case["fx"])

@@ -6,7 +6,17 @@ import pytest
 
 import oracle_lib as O
 
+import golden_util as G
+
 pytestmark = pytest.mark.gpu
+GOLD = G.load("lbfgsb_golden.json")
+
+
+@pytest.fixture(scope="module")
+def boracle(oracle):
+    if not oracle.supports_lbfgsb:
+        pytest.skip("this oracle build has no L-BFGS-B entry points; golden fixtures cover the path")
+    return oracle
 
 
 @pytest.fixture(scope="module")
@@ -67,10 +77,10 @@ def _instance(rng, n, npairs, dtype, mode):
 @pytest.mark.parametrize("dtype", [O.F64])
 @pytest.mark.parametrize("n,m,npairs,mode", [(3000, 6, 0, "hard"), (3000, 6, 4, "hard"), (5000, 6, 9, "edge"),
                                              (4096, 8, 8, "gentle"), (2500, 5, 5, "edge"), (64, 3, 2, "hard")])
-def test_cauchy_and_subspace_match_oracle(A, oracle, dtype, n, m, npairs, mode):
+def test_cauchy_and_subspace_match_oracle(A, boracle, dtype, n, m, npairs, mode):
     rng = np.random.default_rng(100 + n + npairs)
     S, Y, x0, g, lb, ub = _instance(rng, n, npairs, dtype, mode)
-    ref = oracle.cauchy_subspace(dtype, m, S, Y, x0, g, lb, ub, max_submin=10)
+    ref = boracle.cauchy_subspace(dtype, m, S, Y, x0, g, lb, ub, max_submin=10)
     got = _device_cauchy_subspace(A, dtype, m, S, Y, x0, g, lb, ub, max_submin=10)
     # identical index sets (the device keeps them as a state byte)
     newact = np.zeros(n, bool)
@@ -88,7 +98,7 @@ def test_cauchy_and_subspace_match_oracle(A, oracle, dtype, n, m, npairs, mode):
     assert np.abs(got["drt"] - ref["drt"]).max() <= 1e-9 * dscale
 
 
-def test_cauchy_all_on_bounds(A, oracle):
+def test_cauchy_all_on_bounds(A):
     """nfree < 1 and nord < 1: xcp = x0, empty sets (reference Cauchy.h:140-145)."""
     n, m = 100, 4
     x0 = np.ones(n)
@@ -114,8 +124,8 @@ def _traj(A, oracle, n, m, iters, kappa=10.0, dtype=O.F64, bound=1.0):
 
 
 @pytest.mark.parametrize("n,m,iters", [(2000, 6, 15), (20000, 10, 25)])
-def test_trajectory_box_quadratic_f64(A, oracle, n, m, iters):
-    r = _traj(A, oracle, n, m, iters)
+def test_trajectory_box_quadratic_f64(A, boracle, n, m, iters):
+    r = _traj(A, boracle, n, m, iters)
     assert (r["niter"], r["nfev"]) == (r["r_ref"].niter, r["r_ref"].nfev)
     k = r["tr_ref"].count
     assert r["tr"].count == k
@@ -148,7 +158,8 @@ def test_lbfgsb_argument_errors(A):
         A.LBFGSBSolver(A.LBFGSBParam(max_submin=-1))
 
 
-def test_lbfgsb_start_outside_bounds_is_projected(A, oracle):
+def test_lbfgsb_start_outside_bounds_is_projected(A, boracle):
+    oracle = boracle
     n = 3000
     a, b = O.quad_problem(n)
     lb, ub = -0.5 * np.ones(n), 0.5 * np.ones(n)
@@ -160,3 +171,57 @@ def test_lbfgsb_start_outside_bounds_is_projected(A, oracle):
     niter, fx = s.minimize(A.DiagQuadratic(a, b), x, lb, ub)
     assert niter == r_ref.niter and s.last.nfev == r_ref.nfev
     assert np.abs(x - x_ref).max() <= 1e-10
+
+
+# ---------------------------------------------------------------- golden fixtures (need no oracle library)
+def _golden_instance(seed, n, npairs, mode):
+    rng = np.random.default_rng(seed)
+    S = rng.standard_normal((max(npairs, 1), n))[:npairs]
+    Y = S * (1.0 + rng.random((npairs, n))) + 0.05 * rng.standard_normal((npairs, n))
+    lb = -1.0 - rng.random(n)
+    ub = 1.0 + rng.random(n)
+    x0 = np.clip(rng.standard_normal(n), lb, ub)
+    g = rng.standard_normal(n) * (10.0 if mode != "gentle" else 0.3)
+    if mode == "edge":
+        fixed = rng.random(n) < 0.05
+        ub[fixed] = lb[fixed]
+        x0[fixed] = lb[fixed]
+        g[rng.random(n) < 0.05] = 0.0
+        onb = rng.random(n) < 0.05
+        x0[onb] = ub[onb]
+        tie = rng.random(n) < 0.1
+        x0[tie], lb[tie], ub[tie], g[tie] = 0.0, -1.0, 1.0, 4.0
+    return S, Y, x0, g, lb, ub
+
+
+@pytest.mark.parametrize("inst", GOLD["instances"], ids=["seed%d" % i["seed"] for i in GOLD["instances"]])
+def test_cauchy_subspace_golden(A, inst):
+    n, m = inst["n"], inst["m"]
+    S, Y, x0, g, lb, ub = _golden_instance(inst["seed"], n, inst["npairs"], inst["mode"])
+    got = _device_cauchy_subspace(A, O.F64, m, S, Y, x0, g, lb, ub, max_submin=10)
+    newact = np.zeros(n, bool)
+    newact[inst["newact"]] = True
+    free = np.zeros(n, bool)
+    free[inst["fv"]] = True
+    assert np.array_equal((got["state"] & 2) != 0, newact) and np.array_equal((got["state"] & 1) != 0, free)
+    xcp, drt, vecc = G.unhex(inst["xcp"]), G.unhex(inst["drt"]), G.unhex(inst["vecc"])
+    assert np.abs(got["xcp"] - xcp).max() <= 1e-12 * max(1.0, np.abs(xcp).max())
+    if vecc.size:
+        assert np.abs(got["vecc"] - vecc).max() <= 1e-11 * max(1.0, np.abs(vecc).max())
+    assert np.abs(got["drt"] - drt).max() <= 1e-9 * max(1.0, np.abs(drt).max())
+
+
+@pytest.mark.parametrize("case", GOLD["trajectories"], ids=[c["name"] for c in GOLD["trajectories"]])
+def test_lbfgsb_trajectory_golden(A, case):
+    n, m = case["n"], case["m"]
+    a, b = O.quad_problem(n)
+    s = A.LBFGSBSolver(A.LBFGSBParam(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=case["max_iterations"]))
+    tr = A.TraceBuffer(n, cap=1024, stride=case["stride"])
+    x = np.zeros(n)
+    niter, fx = s.minimize(A.DiagQuadratic(a, b), x, -np.ones(n), np.ones(n), trace=tr)
+    assert (niter, s.last.nfev) == (case["niter"], case["nfev"])
+    k = tr.count
+    xs = G.unhex(case["trace_xs"]).reshape(k, -1)
+    assert np.abs(tr.xs[:k] - xs).max() <= 1e-10
+    assert np.abs(x[::case["stride"]] - G.unhex(case["x_sample"])).max() <= 1e-10
+    assert abs(fx - float.fromhex(case["fx"])) <= 1e-12 * abs(fx)
