@@ -83,6 +83,21 @@ int lbfgsx_solver_stats(lbfgsx_solver* s, long long out[8]);
 int lbfgsx_solver_minimize(lbfgsx_solver* s, int objective, int64_t n, const void* a, const void* b, void* x,
                            const void* lb, const void* ub, lbfgsx_trace* trace, lbfgsx_result* out);
 
+/* ---- batched mode (BASELINE.json cfg5): many independent minimisations on one GPU ------------------------
+ * Problem `id` is the extended Rosenbrock (or diag quadratic) instance generated on the device from seed
+ * `seed_base + id`.  `nthreads` host workers each own one solver/context/stream and pull
+ * problem ids from a shared counter, so up to `nthreads` problems are resident and overlap on the GPU; there is
+ * no reference counterpart (the reference solves one problem per call).  One process per GPU shards a larger
+ * batch by giving each rank its own [first, first+count) range: no inter-GPU traffic on the critical path. */
+typedef struct
+{
+    int niter, nfev, status;
+    double fx, gnorm;
+} lbfgsx_batch_item;
+int lbfgsx_batch_minimize(int algo, int dtype, int linesearch, const lbfgsx_params* p, int objective, int64_t n,
+                          int64_t first, int64_t count, uint64_t seed_base, int device, int nthreads,
+                          lbfgsx_batch_item* out);
+
 #ifdef __cplusplus
 }
 #endif

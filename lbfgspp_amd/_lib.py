@@ -25,6 +25,10 @@ class Result(C.Structure):
                 ("status", C.c_int), ("msg", C.c_char * 200)]
 
 
+class BatchItem(C.Structure):
+    _fields_ = [("niter", C.c_int), ("nfev", C.c_int), ("status", C.c_int), ("fx", C.c_double), ("gnorm", C.c_double)]
+
+
 class Trace(C.Structure):
     _fields_ = [("cap", C.c_int), ("count", C.c_int), ("fx", C.POINTER(C.c_double)), ("stride", C.c_int64),
                 ("nsamp", C.c_int64), ("xs", C.POINTER(C.c_double))]
@@ -108,6 +112,8 @@ def load():
     sig(sol, "lbfgsx_solver_prepare", i32, vp, i64)
     sig(sol, "lbfgsx_solver_ctx", vp, vp)
     sig(sol, "lbfgsx_solver_set_iteration_hook", i32, vp, ITER_HOOK, vp)
+    sig(sol, "lbfgsx_batch_minimize", i32, i32, i32, i32, C.POINTER(Params), i32, i64, i64, i64, C.c_uint64, i32, i32,
+        C.POINTER(BatchItem))
     sig(sol, "lbfgsx_solver_stats", i32, vp, C.POINTER(C.c_longlong * 8))
     sig(sol, "lbfgsx_solver_minimize", i32, vp, i32, i64, vp, vp, vp, vp, vp, C.POINTER(Trace), C.POINTER(Result))
     _core, _solver = core, sol

@@ -1,0 +1,64 @@
+"""Batched-problems mode (BASELINE.json cfg5): many independent minimisations, sharded over GPUs.
+
+One process per GPU.  Rank r of W solves the contiguous block of problem ids returned by `shard_range`; the
+hot path has no inter-GPU traffic at all.  The only collective is the final gather of the per-problem
+{niter, nfev, status, fx, gnorm} records (about 32 B per problem), done with torch.distributed -- backend
+"nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+RECORD = np.dtype([("niter", np.int32), ("nfev", np.int32), ("status", np.int32), ("fx", np.float64),
+                   ("gnorm", np.float64)])
+
+
+def shard_range(nproblems, rank, world):
+    """Contiguous, balanced block [first, first+count) of problem ids for `rank` (remainder to the low ranks)."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    base, rem = divmod(nproblems, world)
+    count = base + (1 if rank < rem else 0)
+    first = rank * base + min(rank, rem)
+    return first, count
+
+
+def solve_local(param, objective, n, first, count, seed_base=1000, algo=L.ALGO_LBFGS, linesearch=L.LS_MORE_THUENTE,
+                dtype=np.float32, device=0, nthreads=16):
+    """Solve problems [first, first+count) on one GPU; returns a RECORD array of length count."""
+    _, sol = L.load()
+    items = (L.BatchItem * max(count, 1))()
+    cp = param._c()
+    dt = L.F64 if np.dtype(dtype) == np.float64 else L.F32
+    rc = sol.lbfgsx_batch_minimize(algo, dt, linesearch, C.byref(cp), objective, n, first, count, seed_base, device,
+                                   nthreads, items)
+    L.check(rc, "lbfgsx_batch_minimize failed (worker could not create its solver)")
+    out = np.zeros(count, dtype=RECORD)
+    for k in range(count):
+        out[k] = (items[k].niter, items[k].nfev, items[k].status, items[k].fx, items[k].gnorm)
+    return out
+
+
+def gather_records(local, nproblems, rank, world, dist=None, device=None):
+    """All ranks obtain the full RECORD array in problem-id order.  `dist` is torch.distributed (initialised)."""
+    if world == 1 or dist is None:
+        return local
+    import torch
+    base = -(-nproblems // world)  # padded block length
+    buf = np.zeros((base, 5), dtype=np.float64)
+    for j, name in enumerate(RECORD.names):
+        buf[:len(local), j] = local[name]
+    t = torch.from_numpy(buf)
+    if device is not None:
+        t = t.to(device)
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t)
+    out = np.zeros(nproblems, dtype=RECORD)
+    for r in range(world):
+        first, count = shard_range(nproblems, r, world)
+        arr = parts[r].cpu().numpy()
+        for j, name in enumerate(RECORD.names):
+            out[name][first:first + count] = arr[:count, j]
+    return out

@@ -2,7 +2,9 @@
 // for the built-in objectives behind include/lbfgsx_solver.h.  Plain host C++ (g++), links liblbfgsx.so.
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <memory>
+#include <thread>
 
 #include "../../include/LBFGS.h"
 #include "../../include/LBFGSB.h"
@@ -323,6 +325,71 @@ int lbfgsx_test_cauchy_subspace(int dtype, int64_t n, int m, int npairs, const v
     if (errbuf && errlen > 0)
         std::snprintf(errbuf, size_t(errlen), "%s", r.msg);
     return rc;
+}
+
+int lbfgsx_batch_minimize(int algo, int dtype, int linesearch, const lbfgsx_params* p, int objective, int64_t n,
+                          int64_t first, int64_t count, uint64_t seed_base, int device, int nthreads,
+                          lbfgsx_batch_item* out)
+{
+    if (count <= 0)
+        return LBFGSX_OK;
+    if (nthreads < 1)
+        nthreads = 1;
+    if (nthreads > count)
+        nthreads = int(count);
+    std::atomic<int64_t> next(0);
+    std::atomic<int> fatal(0);
+    auto worker = [&]() {
+        lbfgsx_solver* s = nullptr;
+        if (lbfgsx_solver_create(&s, algo, dtype, linesearch, p, device) != 0 || lbfgsx_solver_prepare(s, n) != 0)
+        {
+            fatal.store(LBFGSX_E_RUNTIME);
+            if (s)
+                lbfgsx_solver_destroy(s);
+            return;
+        }
+        lbfgsx_ctx* c = lbfgsx_solver_ctx(s);
+        for (;;)
+        {
+            const int64_t k = next.fetch_add(1);
+            if (k >= count)
+                break;
+            const uint64_t seed = seed_base + uint64_t(first + k);
+            int rc = 0;
+            if (objective == LBFGSX_OBJ_EXT_ROSENBROCK)
+                rc = lbfgsx_gen_rosen_x0(c, seed);
+            else
+            {
+                rc = lbfgsx_gen_diag_quad(c, 10.0, seed);
+                if (!rc)
+                    rc = lbfgsx_fill(c, LBFGSX_VEC_X, 0.0);
+            }
+            if (!rc && algo == LBFGSX_ALGO_LBFGSB)
+            {
+                rc = lbfgsx_fill(c, LBFGSX_VEC_LB, -1.0);
+                if (!rc)
+                    rc = lbfgsx_fill(c, LBFGSX_VEC_UB, 1.0);
+            }
+            lbfgsx_result r;
+            std::memset(&r, 0, sizeof(r));
+            if (!rc)
+                lbfgsx_solver_minimize(s, objective, n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &r);
+            else
+                r.status = rc;
+            out[k].niter = r.niter;
+            out[k].nfev = r.nfev;
+            out[k].status = r.status;
+            out[k].fx = r.fx;
+            out[k].gnorm = r.gnorm;
+        }
+        lbfgsx_solver_destroy(s);
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nthreads; t++)
+        pool.emplace_back(worker);
+    for (auto& th : pool)
+        th.join();
+    return fatal.load();
 }
 
 int lbfgsx_solver_stats(lbfgsx_solver* s, long long out[8])

@@ -1,0 +1,41 @@
+"""-m gpu: batched mode (cfg5 shape, scaled down) -- every problem of a batch equals its stand-alone solve."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_batched_equals_single_solves_and_oracle(oracle):
+    import lbfgspp_amd as A
+    from lbfgspp_amd import batched as B
+    n, m, iters, count = 2048, 10, 12, 12
+    par = A.LBFGSParam(m=m, epsilon=0.0, epsilon_rel=0.0, max_iterations=iters)
+    recs = B.solve_local(par, A.ExtendedRosenbrock.objective, n, first=5, count=count, seed_base=1000,
+                         dtype=np.float32, nthreads=4)
+    assert len(recs) == count
+    s = A.LBFGSSolver(par, linesearch=A.LS_MORE_THUENTE, dtype=np.float32)
+    p = O.lbfgs_params(m=m, epsilon=0, epsilon_rel=0, max_iterations=iters)
+    for k in range(count):
+        x0 = O.rosen_x0(n, 1000 + 5 + k, O.F32)
+        x = x0.copy()
+        try:
+            niter, fx = s.minimize(A.ExtendedRosenbrock(), x)
+            status = 0
+        except (RuntimeError, ArithmeticError, ValueError):
+            status, niter, fx = s.last.status, s.last.niter, s.last.fx
+        assert (recs["niter"][k], recs["nfev"][k], recs["status"][k]) == (niter, s.last.nfev, status)
+        if status == 0:
+            assert recs["fx"][k] == fx
+            _, r = oracle.lbfgs(O.F32, O.LS_MT, O.OBJ_ROSEN, x0, p)
+            assert r.niter == niter and abs(r.fx - fx) <= 1e-4 * max(1.0, abs(fx))
+
+
+def test_batched_is_deterministic_across_thread_counts():
+    import lbfgspp_amd as A
+    from lbfgspp_amd import batched as B
+    par = A.LBFGSParam(m=6, epsilon=0.0, epsilon_rel=0.0, max_iterations=8)
+    a = B.solve_local(par, A.ExtendedRosenbrock.objective, 4096, 0, 16, dtype=np.float32, nthreads=1)
+    b = B.solve_local(par, A.ExtendedRosenbrock.objective, 4096, 0, 16, dtype=np.float32, nthreads=8)
+    assert np.array_equal(a, b)
