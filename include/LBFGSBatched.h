@@ -1,0 +1,358 @@
+// include/LBFGSBatched.h -- lock-step batched L-BFGS: P independent problems, one kernel launch per statement
+// for the whole batch (BASELINE.json cfg5).  Host control flow per problem is that of LBFGSSolver::minimize
+// (/root/reference/include/LBFGS.h:78-173) with LineSearchMoreThuente; problems that converge, fail or finish a
+// line search early simply sit out of the following launches.  Per problem the arithmetic is identical to the
+// single-problem path, so results are bit-identical to LBFGSSolver<Scalar, LineSearchMoreThuente>.
+#ifndef LBFGSX_DROPIN_LBFGS_BATCHED_H
+#define LBFGSX_DROPIN_LBFGS_BATCHED_H
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <limits>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "LBFGSpp/Device.h"
+#include "LBFGSpp/LineSearchMoreThuente.h"
+#include "LBFGSpp/Param.h"
+
+namespace LBFGSpp {
+
+template <typename Scalar>
+class LBFGSBatchedSolver
+{
+public:
+    struct Item
+    {
+        int niter = 0, nfev = 0, status = 0;  // status: 0 or LBFGSX_E_* of the exception a single solve would throw
+        Scalar fx = Scalar(0), gnorm = Scalar(0);
+        std::string msg;
+    };
+
+private:
+    typedef typename LineSearchMoreThuente<Scalar>::Machine Machine;
+    const LBFGSParam<Scalar>& m_param;
+
+    struct Prob
+    {
+        bool done = false, in_ls = false;
+        int cur = 0, xp = 0, lo = 0, trial = 1;
+        int ncorr = 0, ptr = 0, spare = 0;
+        std::vector<int> phys;
+        std::vector<Scalar> fxh;
+        Scalar fx = 0, gnorm = 0, dg = 0, step = 0;
+        Machine mt;
+    };
+
+    static int third(int a, int b)
+    {
+        for (int k = 0; k < 3; k++)
+            if (k != a && k != b)
+                return k;
+        return 0;
+    }
+    void fail(Prob& pr, Item& it, int status, const char* what, int k)
+    {
+        pr.done = true;
+        pr.in_ls = false;
+        it.status = status;
+        it.msg = what;
+        it.niter = k;
+    }
+
+public:
+    LBFGSBatchedSolver(const LBFGSParam<Scalar>& param) : m_param(param) { m_param.check_param(); }
+
+    // problems first .. first+count-1, problem id -> extended-Rosenbrock start point of seed seed_base + id
+    // optional x_out: count*n scalars, the final iterates
+    void minimize(std::int64_t n, std::uint64_t seed_base, std::int64_t first, int count, int device, std::vector<Item>& out,
+                  Scalar* x_out = nullptr)
+    {
+        using std::abs;
+        using std::sqrt;
+        out.assign(size_t(count), Item());
+        if (count <= 0)
+            return;
+        const int m = m_param.m, P = count;
+        lbfgsx_batch* c = nullptr;
+        detail::check(lbfgsx_bat_create(&c, detail::dtype_of<Scalar>::value, n, m, P, device));
+        struct Guard
+        {
+            lbfgsx_batch* c;
+            ~Guard() { lbfgsx_bat_destroy(c); }
+        } guard{c};
+        auto YS = [&](int col) { return lbfgsx_bat_scalar_index(c, 0, col); };
+        auto TH = [&](int col) { return lbfgsx_bat_scalar_index(c, 1, col); };
+        auto DOT = [&](int k) { return lbfgsx_bat_scalar_index(c, 2, k); };
+        const int OUT0 = lbfgsx_bat_scalar_index(c, 3, 0);
+        const int fpast = m_param.past;
+        constexpr Scalar eps = std::numeric_limits<Scalar>::epsilon();
+
+        std::vector<Prob> pr(static_cast<size_t>(P));
+        for (int p = 0; p < P; p++)
+        {
+            pr[size_t(p)].phys.resize(size_t(m));
+            for (int j = 0; j < m; j++)
+                pr[size_t(p)].phys[size_t(j)] = j;
+            pr[size_t(p)].spare = m;
+            pr[size_t(p)].ptr = m;
+            if (fpast > 0)
+                pr[size_t(p)].fxh.assign(size_t(fpast), Scalar(0));
+        }
+        std::vector<lbfgsx_bat_desc> desc(static_cast<size_t>(P));
+        std::vector<double> res(size_t(P) * 4);
+        auto clear_desc = [&]() {
+            for (auto& d : desc)
+            {
+                d = lbfgsx_bat_desc();
+                d.i_out = OUT0;
+            }
+        };
+
+        // two-loop recursion for every active problem: drt = -H grad, dg = grad.drt   (LBFGS.h:106,123,165)
+        auto apply_Hv = [&]() {
+            int lmax = 0;
+            for (int p = 0; p < P; p++)
+                if (!pr[size_t(p)].done)
+                    lmax = std::max(lmax, 2 * pr[size_t(p)].ncorr + 1);
+            std::vector<int> pc(static_cast<size_t>(m));
+            for (int L = 0; L < lmax; L++)
+            {
+                clear_desc();
+                for (int p = 0; p < P; p++)
+                {
+                    Prob& q = pr[size_t(p)];
+                    const int cn = q.ncorr;
+                    if (q.done || L > 2 * cn)
+                        continue;
+                    int j = q.ptr % m;
+                    for (int i = 0; i < cn; i++)
+                    {
+                        j = (j + m - 1) % m;
+                        pc[size_t(i)] = q.phys[size_t(j)];
+                    }
+                    lbfgsx_bat_desc& d = desc[size_t(p)];
+                    d.active = 1;
+                    d.x_in = q.cur;
+                    d.i_out = DOT(L);
+                    if (L == 0)
+                    {
+                        d.mode = 0;
+                        d.step = -1.0;
+                        d.col_w = cn > 0 ? pc[0] : -1;
+                    }
+                    else if (L < cn)
+                    {
+                        d.mode = 1;
+                        d.col_u = pc[size_t(L - 1)];
+                        d.col_w = pc[size_t(L)];
+                        d.i_num = DOT(L - 1);
+                        d.i_den = YS(pc[size_t(L - 1)]);
+                    }
+                    else if (L == cn)
+                    {
+                        d.mode = 2;
+                        d.col_u = d.col_w = pc[size_t(cn - 1)];
+                        d.i_num = DOT(cn - 1);
+                        d.i_den = YS(pc[size_t(cn - 1)]);
+                        d.i_theta = TH(pc[0]);
+                    }
+                    else
+                    {
+                        const int t = L - cn - 1, i = cn - 1 - t;
+                        d.mode = 3;
+                        d.col_u = pc[size_t(i)];
+                        d.col_w = (t < cn - 1) ? pc[size_t(i - 1)] : -1;
+                        d.i_num = DOT(i);
+                        d.i_num2 = DOT(L - 1);
+                        d.i_den = YS(pc[size_t(i)]);
+                    }
+                }
+                detail::check(lbfgsx_bat_launch(c, LBFGSX_BAT_TWOLOOP, LBFGSX_OBJ_EXT_ROSENBROCK, desc.data(), 0, nullptr));
+            }
+            std::vector<int> idx(static_cast<size_t>(P));
+            std::vector<double> dg(static_cast<size_t>(P));
+            for (int p = 0; p < P; p++)
+                idx[size_t(p)] = DOT(2 * pr[size_t(p)].ncorr);
+            detail::check(lbfgsx_bat_fetch(c, idx.data(), dg.data()));
+            for (int p = 0; p < P; p++)
+                pr[size_t(p)].dg = Scalar(dg[size_t(p)]);
+        };
+
+        // fx = f(x, grad); gnorm                                                   (LBFGS.h:91-103)
+        detail::check(lbfgsx_bat_gen_rosen_x0(c, seed_base + std::uint64_t(first)));
+        clear_desc();
+        for (auto& d : desc)
+            d.active = 1;
+        detail::check(lbfgsx_bat_launch(c, LBFGSX_BAT_EVAL, LBFGSX_OBJ_EXT_ROSENBROCK, desc.data(), 3, res.data()));
+        int remaining = 0;
+        for (int p = 0; p < P; p++)
+        {
+            Prob& q = pr[size_t(p)];
+            Item& it = out[size_t(p)];
+            q.fx = Scalar(res[size_t(p) * 3 + 0]);
+            q.gnorm = sqrt(Scalar(res[size_t(p) * 3 + 1]));
+            it.nfev = 1;
+            if (fpast > 0)
+                q.fxh[0] = q.fx;
+            if (q.gnorm <= m_param.epsilon || q.gnorm <= m_param.epsilon_rel * sqrt(Scalar(res[size_t(p) * 3 + 2])))
+            {
+                q.done = true;
+                it.niter = 1;
+            }
+            else
+                remaining++;
+        }
+        if (remaining)
+            apply_Hv();
+        for (int p = 0; p < P; p++)
+            pr[size_t(p)].step = Scalar(1) / pr[size_t(p)].gnorm;
+
+        for (int k = 1; remaining > 0; k++)
+        {
+            // ---- line searches, one trial per launch for every problem still searching (LBFGS.h:121-127)
+            int searching = 0;
+            for (int p = 0; p < P; p++)
+            {
+                Prob& q = pr[size_t(p)];
+                if (q.done)
+                    continue;
+                q.xp = q.cur;
+                q.lo = q.xp;
+                q.trial = (q.xp + 1) % 3;
+                try
+                {
+                    q.mt.start(m_param, m_param.max_step, q.step, q.fx, q.dg);
+                    q.in_ls = true;
+                    searching++;
+                }
+                catch (const std::invalid_argument& e) { fail(q, out[size_t(p)], LBFGSX_E_INVALID, e.what(), k); remaining--; }
+                catch (const std::logic_error& e) { fail(q, out[size_t(p)], LBFGSX_E_LOGIC, e.what(), k); remaining--; }
+            }
+            while (searching > 0)
+            {
+                clear_desc();
+                for (int p = 0; p < P; p++)
+                {
+                    Prob& q = pr[size_t(p)];
+                    if (!q.in_ls)
+                        continue;
+                    lbfgsx_bat_desc& d = desc[size_t(p)];
+                    d.active = 1;
+                    d.x_in = q.xp;
+                    d.x_out = q.trial;
+                    d.step = double(q.mt.step());
+                }
+                detail::check(lbfgsx_bat_launch(c, LBFGSX_BAT_TRIAL, LBFGSX_OBJ_EXT_ROSENBROCK, desc.data(), 2, res.data()));
+                for (int p = 0; p < P; p++)
+                {
+                    Prob& q = pr[size_t(p)];
+                    if (!q.in_ls)
+                        continue;
+                    out[size_t(p)].nfev++;
+                    const Scalar fx = Scalar(res[size_t(p) * 2 + 0]), dg = Scalar(res[size_t(p) * 2 + 1]);
+                    bool keep = false;
+                    const typename Machine::Action a = q.mt.feed(fx, dg, keep);
+                    if (keep)
+                    {
+                        if (q.lo == q.xp)
+                        {
+                            q.lo = q.trial;
+                            q.trial = third(q.xp, q.lo);
+                        }
+                        else
+                            std::swap(q.lo, q.trial);
+                    }
+                    if (a == Machine::TRIAL)
+                        continue;
+                    q.in_ls = false;
+                    searching--;
+                    if (a == Machine::DONE_TRIAL)
+                    {
+                        q.cur = q.trial;
+                        q.fx = fx;
+                        q.dg = dg;
+                    }
+                    else
+                    {
+                        q.cur = q.lo;
+                        q.fx = q.mt.fx();
+                        q.dg = q.mt.dg();
+                    }
+                }
+            }
+            if (remaining <= 0)
+                break;
+
+            // ---- gnorm, x.norm, s, y, s.y, y.y                                            (LBFGS.h:130,137,159-161)
+            clear_desc();
+            for (int p = 0; p < P; p++)
+            {
+                Prob& q = pr[size_t(p)];
+                if (q.done)
+                    continue;
+                lbfgsx_bat_desc& d = desc[size_t(p)];
+                d.active = 1;
+                d.x_in = q.xp;
+                d.x_out = q.cur;
+                d.col_u = q.spare;
+                d.i_den = YS(q.spare);
+                d.i_theta = TH(q.spare);
+            }
+            detail::check(lbfgsx_bat_launch(c, LBFGSX_BAT_POST, LBFGSX_OBJ_EXT_ROSENBROCK, desc.data(), 4, res.data()));
+            for (int p = 0; p < P; p++)
+            {
+                Prob& q = pr[size_t(p)];
+                if (q.done)
+                    continue;
+                Item& it = out[size_t(p)];
+                const Scalar g2 = Scalar(res[size_t(p) * 4 + 0]), x2 = Scalar(res[size_t(p) * 4 + 1]);
+                const Scalar sy = Scalar(res[size_t(p) * 4 + 2]), yy = Scalar(res[size_t(p) * 4 + 3]);
+                q.gnorm = sqrt(g2);
+                bool stop = (q.gnorm <= m_param.epsilon || q.gnorm <= m_param.epsilon_rel * sqrt(x2));
+                if (!stop && fpast > 0)
+                {
+                    const Scalar old = q.fxh[size_t(k % fpast)];
+                    if (k >= fpast && abs(old - q.fx) <= m_param.delta * std::max(std::max(abs(q.fx), abs(old)), Scalar(1)))
+                        stop = true;
+                    else
+                        q.fxh[size_t(k % fpast)] = q.fx;
+                }
+                if (!stop && m_param.max_iterations != 0 && k >= m_param.max_iterations)
+                    stop = true;
+                if (stop)
+                {
+                    q.done = true;
+                    it.niter = k;
+                    remaining--;
+                    continue;
+                }
+                if (sy > eps * yy)  // add_correction: index rotation (BFGSMat.h:83-97)
+                {
+                    const int loc = q.ptr % m;
+                    std::swap(q.phys[size_t(loc)], q.spare);
+                    if (q.ncorr < m)
+                        q.ncorr++;
+                    q.ptr = loc + 1;
+                }
+                q.step = Scalar(1);
+            }
+            if (remaining > 0)
+                apply_Hv();
+        }
+
+        for (int p = 0; p < P; p++)
+        {
+            out[size_t(p)].fx = pr[size_t(p)].fx;
+            out[size_t(p)].gnorm = pr[size_t(p)].gnorm;
+            if (x_out)
+                detail::check(lbfgsx_bat_download_x(c, p, pr[size_t(p)].cur, x_out + std::int64_t(p) * n));
+        }
+    }
+};
+
+}  // namespace LBFGSpp
+
+#endif  // LBFGSX_DROPIN_LBFGS_BATCHED_H

@@ -35,9 +35,15 @@ template <> struct HostAcc<double>
 };
 template <> struct HostAcc<float>
 {
-    double v = 0.0;
-    inline void add_prod(float a, float b) { v += double(a) * double(b); }
-    inline float value() const { return float(v); }
+    double hi = 0.0, lo = 0.0;
+    inline void add_prod(float a, float b)
+    {
+        const double p = double(a) * double(b);  // exact
+        const double s = hi + p, bb = s - hi;
+        lo += (hi - (s - bb)) + (p - bb);
+        hi = s;
+    }
+    inline float value() const { return float(hi + lo); }
 };
 template <typename Scalar>
 inline Scalar host_dot(const Scalar* a, const Scalar* b, int n)

@@ -115,112 +115,172 @@ class LineSearchMoreThuente
     }
 
 public:
-    template <typename Eval, typename SolverParam>
-    static void LineSearch(Eval& ev, const SolverParam& param, const Scalar& step_max, Scalar& step, Scalar& fx,
-                           Scalar& dg)
+    // The search as a resumable state machine: start() validates and arms it, step() is the trial to evaluate
+    // next, feed() consumes phi(step), phi'(step) and says what to do.  The blocking LineSearch() below and the
+    // lock-step batched solver (many problems advancing one trial per kernel launch) share this one
+    // implementation of the reference logic.
+    class Machine
     {
-        using std::abs;
-        const Scalar step_min = param.min_step;
-        if (step <= Scalar(0))
-            throw std::invalid_argument("'step' must be positive");
-        if (step < step_min)
-            throw std::invalid_argument("'step' is smaller than 'param.min_step'");
-        if (step > step_max)
-            throw std::invalid_argument("'step' exceeds 'step_max'");
-
-        const Scalar f0 = fx, g0 = dg;
-        if (g0 >= Scalar(0))
-            throw std::logic_error("the moving direction does not decrease the objective function value");
-
-        const Scalar armijo = param.ftol * g0, curvature = -param.wolfe * g0;
-        const Scalar inf = std::numeric_limits<Scalar>::infinity();
-
-        Sample lo = {Scalar(0), Scalar(0), (Scalar(1) - param.ftol) * g0};  // in terms of psi
-        Sample hi = {inf, inf, inf};
-        Scalar psi_lo = Scalar(0);
-        Scalar f_best = f0, g_best = g0;  // phi, phi' at lo.t
-
-        bool bracketed = false, guard_min = (step_min > Scalar(0));
-        Scalar width = inf, width_prev = inf;
-        int stalls = 0;
-        const Scalar grow = Scalar(1.1), contract = Scalar(7) / Scalar(12), shrink = Scalar(0.66);
-
-        for (int it = 0; it < param.max_linesearch; it++)
+    public:
+        enum Action
         {
-            ev.trial(step, fx, dg);
-            const Scalar psi = fx - f0 - step * armijo, dpsi = dg - armijo;
+            TRIAL,       // evaluate step() next
+            DONE_TRIAL,  // finished: the accepted point is the last trial
+            DONE_LO      // finished (trials exhausted): the accepted point is the saved _lo point
+        };
 
-            if (psi <= Scalar(0) && abs(dg) <= curvature)
-            {
-                ev.finish(false);
-                return;
-            }
-            if (step <= step_min && (psi > Scalar(0) || dpsi >= Scalar(0)))
-            {
-                ev.finish(false);
-                return;
-            }
-            if (step >= step_max && (psi <= Scalar(0) && dpsi < Scalar(0)))
-            {
-                ev.finish(false);
-                return;
-            }
+    private:
+        Scalar m_step = 0, m_step_min = 0, m_step_max = 0, m_f0 = 0, m_armijo = 0, m_curvature = 0;
+        Sample m_lo, m_hi;
+        Scalar m_psi_lo = 0, m_f_best = 0, m_g_best = 0, m_width = 0, m_width_prev = 0;
+        Scalar m_fx = 0, m_dg = 0;
+        bool m_bracketed = false, m_guard_min = false;
+        int m_stalls = 0, m_it = 0, m_max_it = 0;
+
+    public:
+        Scalar step() const { return m_step; }
+        Scalar fx() const { return m_fx; }
+        Scalar dg() const { return m_dg; }
+
+        template <typename SolverParam>
+        void start(const SolverParam& param, Scalar step_max, Scalar step, Scalar fx, Scalar dg)
+        {
+            m_step_min = param.min_step;
+            if (step <= Scalar(0))
+                throw std::invalid_argument("'step' must be positive");
+            if (step < m_step_min)
+                throw std::invalid_argument("'step' is smaller than 'param.min_step'");
+            if (step > step_max)
+                throw std::invalid_argument("'step' exceeds 'step_max'");
+            if (dg >= Scalar(0))
+                throw std::logic_error("the moving direction does not decrease the objective function value");
+            const Scalar inf = std::numeric_limits<Scalar>::infinity();
+            m_step = step;
+            m_step_max = step_max;
+            m_f0 = fx;
+            m_armijo = param.ftol * dg;
+            m_curvature = -param.wolfe * dg;
+            m_lo = Sample{Scalar(0), Scalar(0), (Scalar(1) - param.ftol) * dg};  // in terms of psi
+            m_hi = Sample{inf, inf, inf};
+            m_psi_lo = Scalar(0);
+            m_f_best = fx;  // phi, phi' at lo.t
+            m_g_best = dg;
+            m_bracketed = false;
+            m_guard_min = (m_step_min > Scalar(0));
+            m_width = m_width_prev = inf;
+            m_stalls = 0;
+            m_it = 0;
+            m_max_it = param.max_linesearch;
+        }
+
+        // fx, dg: objective and directional derivative at step().  keep_lo is set when the point just evaluated
+        // must be saved as the new _lo point (x_lo.swap(x); grad_lo.swap(grad)).
+        Action feed(Scalar fx, Scalar dg, bool& keep_lo)
+        {
+            using std::abs;
+            keep_lo = false;
+            m_fx = fx;
+            m_dg = dg;
+            const Scalar inf = std::numeric_limits<Scalar>::infinity();
+            const Scalar grow = Scalar(1.1), contract = Scalar(7) / Scalar(12), shrink = Scalar(0.66);
+            const Scalar step = m_step;
+            const Scalar psi = fx - m_f0 - step * m_armijo, dpsi = dg - m_armijo;
+
+            if (psi <= Scalar(0) && abs(dg) <= m_curvature)
+                return DONE_TRIAL;
+            if (step <= m_step_min && (psi > Scalar(0) || dpsi >= Scalar(0)))
+                return DONE_TRIAL;
+            if (step >= m_step_max && (psi <= Scalar(0) && dpsi < Scalar(0)))
+                return DONE_TRIAL;
 
             const Sample tr = {step, psi, dpsi};
-            if (guard_min && (psi <= Scalar(0) && dpsi < Scalar(0)))
-                guard_min = false;
+            if (m_guard_min && (psi <= Scalar(0) && dpsi < Scalar(0)))
+                m_guard_min = false;
 
-            const bool extend = (psi <= psi_lo) && (dpsi * (lo.t - step) > Scalar(0));  // "case II"
+            const bool extend = (psi <= m_psi_lo) && (dpsi * (m_lo.t - step) > Scalar(0));  // "case II"
             Scalar next;
             if (extend)
-                next = (std::min)(step_max, step + grow * (step - lo.t));
+                next = (std::min)(m_step_max, step + grow * (step - m_lo.t));
             else
             {
-                next = next_step(lo, hi, tr);
-                next = (std::max)(next, step_min);
-                next = (std::min)(next, step_max);
-                if (guard_min)
+                next = next_step(m_lo, m_hi, tr);
+                next = (std::max)(next, m_step_min);
+                next = (std::min)(next, m_step_max);
+                if (m_guard_min)
                 {
-                    const Scalar cap = (std::max)(step_min, contract * step);
-                    next = (std::max)(next, step_min);
+                    const Scalar cap = (std::max)(m_step_min, contract * step);
+                    next = (std::max)(next, m_step_min);
                     next = (std::min)(next, cap);
                 }
             }
 
-            if (psi > psi_lo)  // "case I": trial becomes the far end
-                hi = tr;
+            if (psi > m_psi_lo)  // "case I": trial becomes the far end
+                m_hi = tr;
             else
             {
                 if (!extend)  // "case III": old near end becomes the far end
-                    hi = lo;
-                lo = tr;
-                psi_lo = psi;
-                ev.keep_trial_as_lo();
-                f_best = fx;
-                g_best = dg;
+                    m_hi = m_lo;
+                m_lo = tr;
+                m_psi_lo = psi;
+                keep_lo = true;
+                m_f_best = fx;
+                m_g_best = dg;
             }
 
-            if (!bracketed && !extend)
-                bracketed = ((std::min)(lo.t, hi.t) >= step_min && (std::max)(lo.t, hi.t) <= step_max);
-            if (bracketed)
+            if (!m_bracketed && !extend)
+                m_bracketed = ((std::min)(m_lo.t, m_hi.t) >= m_step_min && (std::max)(m_lo.t, m_hi.t) <= m_step_max);
+            if (m_bracketed)
             {
-                width_prev = width;
-                width = abs(hi.t - lo.t);
-                stalls = (width_prev < inf && width > shrink * width_prev) ? stalls + 1 : 0;
-                if (stalls >= 2)
+                m_width_prev = m_width;
+                m_width = abs(m_hi.t - m_lo.t);
+                m_stalls = (m_width_prev < inf && m_width > shrink * m_width_prev) ? m_stalls + 1 : 0;
+                if (m_stalls >= 2)
                 {
-                    next = (lo.t + hi.t) / Scalar(2);
-                    stalls = 0;
+                    next = (m_lo.t + m_hi.t) / Scalar(2);
+                    m_stalls = 0;
                 }
             }
-            step = next;
+            m_step = next;
+            if (++m_it >= m_max_it)
+            {
+                // out of trials: hand back the best point seen
+                m_step = m_lo.t;
+                m_fx = m_f_best;
+                m_dg = m_g_best;
+                return DONE_LO;
+            }
+            return TRIAL;
         }
+    };
 
-        // out of trials: hand back the best point seen
-        step = lo.t;
-        fx = f_best;
-        dg = g_best;
-        ev.finish(true);
+    template <typename Eval, typename SolverParam>
+    static void LineSearch(Eval& ev, const SolverParam& param, const Scalar& step_max, Scalar& step, Scalar& fx,
+                           Scalar& dg)
+    {
+        Machine mt;
+        mt.start(param, step_max, step, fx, dg);
+        for (;;)
+        {
+            step = mt.step();
+            ev.trial(step, fx, dg);
+            bool keep_lo = false;
+            const typename Machine::Action a = mt.feed(fx, dg, keep_lo);
+            if (keep_lo)
+                ev.keep_trial_as_lo();
+            if (a == Machine::DONE_TRIAL)
+            {
+                ev.finish(false);
+                return;
+            }
+            if (a == Machine::DONE_LO)
+            {
+                step = mt.step();
+                fx = mt.fx();
+                dg = mt.dg();
+                ev.finish(true);
+                return;
+            }
+        }
     }
 };
 

@@ -189,6 +189,39 @@ int lbfgsx_b_dot_drt_g(lbfgsx_ctx* c, double* dg);
 /* drt = xcp - x [, drt.normalize()]  (LBFGSB.h:163-164,191) */
 int lbfgsx_b_dir_from_xcp(lbfgsx_ctx* c, int normalize);
 
+/* ---- lock-step batch (BASELINE.json cfg5) ------------------------------------------------------------
+ * P independent problems of equal dimension advance together: one kernel launch per reference statement for the
+ * whole batch, grid = (chunks, problems), per-problem scalars / reduction workspace / buffer roles / history ring.
+ * The host (include/LBFGSBatched.h) keeps one line-search state machine per problem and fills one descriptor per
+ * problem and launch.  No reference counterpart (the reference solves one problem per call); per problem the
+ * arithmetic is that of LBFGS.h:78-173 with LineSearchMoreThuente. */
+typedef struct lbfgsx_batch lbfgsx_batch;
+typedef struct
+{
+    int active;   /* 0: this problem sits out of the launch */
+    int mode;     /* two-loop step kind: 0 INIT q=a*g, 1 SUB q-=alpha*y, 2 SUBDIV (q-alpha*y)/theta, 3 ADD q+=(alpha-beta)*s */
+    int x_in;     /* point index (0..2): xp for a trial / post, the current point for eval / two-loop */
+    int x_out;    /* point index written by a trial; the accepted point for post */
+    int col_u;    /* physical history column of the update vector (post: the spare column to fill) */
+    int col_w;    /* physical history column of the dot product, -1 = gradient at x_in */
+    int i_num, i_den, i_num2, i_theta, i_out; /* indices into the problem's scalar table */
+    float pad;
+    double step;  /* trial step, or the scale a of the two-loop INIT */
+} lbfgsx_bat_desc;
+enum { LBFGSX_BAT_EVAL = 0, LBFGSX_BAT_TRIAL = 1, LBFGSX_BAT_POST = 2, LBFGSX_BAT_TWOLOOP = 3 };
+int lbfgsx_bat_create(lbfgsx_batch** out, int dtype, int64_t n, int m, int nproblems, int device);
+void lbfgsx_bat_destroy(lbfgsx_batch* c);
+/* index of a scalar inside a problem's table: kind 0 = ys[col], 1 = theta[col], 2 = two-loop dot k, 3 = output k */
+int lbfgsx_bat_scalar_index(const lbfgsx_batch* c, int kind, int k);
+/* x0 of problem p (point 0) = extended-Rosenbrock start for seed seed0 + p */
+int lbfgsx_bat_gen_rosen_x0(lbfgsx_batch* c, uint64_t seed0);
+/* one launch for the whole batch; desc = P descriptors; then out[p*nout + k] = scalar (desc[p].i_out + k) */
+int lbfgsx_bat_launch(lbfgsx_batch* c, int kind, int objective, const lbfgsx_bat_desc* desc, int nout, double* out);
+/* out[p] = scalar idx[p] of problem p */
+int lbfgsx_bat_fetch(lbfgsx_batch* c, const int* idx, double* out);
+int lbfgsx_bat_download_x(lbfgsx_batch* c, int p, int point, void* host);
+int lbfgsx_bat_sync(lbfgsx_batch* c);
+
 /* ---- instrumentation ----------------------------------------------------------------------------------*/
 /* average duration (ms) of the two-loop step kernels since the last reset, measured with HIP events on
  * the context's stream; count = number of timed launches */

@@ -97,6 +97,12 @@ typedef struct
 int lbfgsx_batch_minimize(int algo, int dtype, int linesearch, const lbfgsx_params* p, int objective, int64_t n,
                           int64_t first, int64_t count, uint64_t seed_base, int device, int nthreads,
                           lbfgsx_batch_item* out);
+/* lock-step variant (include/LBFGSBatched.h): all `count` problems resident at once and advanced together, one
+ * kernel launch per statement for the whole batch; L-BFGS + LineSearchMoreThuente + extended Rosenbrock.
+ * x_out (optional): count*n scalars receiving the final iterates. */
+int lbfgsx_batch_minimize_lockstep(int dtype, const lbfgsx_params* p, int64_t n, int64_t first, int count,
+                                   uint64_t seed_base, int device, lbfgsx_batch_item* out, void* x_out, char* errbuf,
+                                   int errlen);
 
 #ifdef __cplusplus
 }

@@ -114,6 +114,8 @@ def load():
     sig(sol, "lbfgsx_solver_set_iteration_hook", i32, vp, ITER_HOOK, vp)
     sig(sol, "lbfgsx_batch_minimize", i32, i32, i32, i32, C.POINTER(Params), i32, i64, i64, i64, C.c_uint64, i32, i32,
         C.POINTER(BatchItem))
+    sig(sol, "lbfgsx_batch_minimize_lockstep", i32, i32, C.POINTER(Params), i64, i64, i32, C.c_uint64, i32,
+        C.POINTER(BatchItem), vp, C.c_char_p, i32)
     sig(sol, "lbfgsx_solver_stats", i32, vp, C.POINTER(C.c_longlong * 8))
     sig(sol, "lbfgsx_solver_minimize", i32, vp, i32, i64, vp, vp, vp, vp, vp, C.POINTER(Trace), C.POINTER(Result))
     _core, _solver = core, sol

@@ -1,0 +1,577 @@
+// lbfgspp_amd/csrc/batched.hip -- lock-step batched L-BFGS kernels (BASELINE.json cfg5): P independent problems
+// of equal dimension advance together, one kernel launch per statement for the whole batch.
+//
+// Grid = (chunks per problem, problems).  Every problem has its own scalars, its own reduction partials and
+// ticket, its own buffer roles and history ring, so the arithmetic of problem p is exactly the arithmetic of
+// a stand-alone solve (same kernels' element-wise code, same order-independent reductions): results are
+// bit-identical to the single-problem path.  Inactive problems (converged, failed, or already done with the
+// current line search) are skipped by a per-problem flag.  A vector of n = 1e5 floats is only 0.4 MB, so the
+// single-problem path is launch-latency bound there; batching restores the HBM-bound regime.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "ctx.hpp"
+#include "lbfgs_kernels.cuh"
+
+namespace lbfgsx {
+
+typedef lbfgsx_bat_desc BatDesc;  // per-problem description of one launch (include/lbfgsx.h)
+
+struct BatWs
+{
+    double* partials;  // [P][kMaxRedB][2][GX]
+    unsigned* ticket;  // [P]
+    int gx;
+};
+constexpr int kMaxRedB = 4;
+
+// per-problem grid reduction (same protocol as grid_reduce, with blockIdx.y-indexed workspace)
+template <int NRED, class A>
+__device__ __forceinline__ bool bat_reduce(A (&acc)[NRED], const BatWs& ws)
+{
+    __shared__ double sh[NRED][2][kWaves];
+    __shared__ int s_last;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int G = gridDim.x, p = blockIdx.y;
+    double* part = ws.partials + size_t(p) * kMaxRedB * 2 * ws.gx;
+#pragma unroll
+    for (int r = 0; r < NRED; r++)
+    {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+        {
+            const double ohi = __shfl_down(acc[r].hi, off, 64);
+            const double olo = __shfl_down(acc_lo(acc[r]), off, 64);
+            acc[r].merge(ohi, olo);
+        }
+        if (lane == 0)
+        {
+            sh[r][0][wave] = acc[r].hi;
+            sh[r][1][wave] = acc_lo(acc[r]);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+#pragma unroll
+        for (int r = 0; r < NRED; r++)
+        {
+            A t;
+            for (int w = 0; w < kWaves; w++)
+                t.merge(sh[r][0][w], sh[r][1][w]);
+            st_agent(part + (size_t(r) * 2 + 0) * ws.gx + blockIdx.x, t.hi);
+            st_agent(part + (size_t(r) * 2 + 1) * ws.gx + blockIdx.x, acc_lo(t));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // partials are sc1 stores: drain, then ticket (R1 form)
+        const unsigned old = __hip_atomic_fetch_add(ws.ticket + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (old == unsigned(G - 1));
+        if (last)
+            __threadfence();
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last)
+        return false;
+#pragma unroll
+    for (int r = 0; r < NRED; r++)
+    {
+        A t;
+        for (int b = threadIdx.x; b < G; b += kBlock)
+            t.merge(ld_agent(part + (size_t(r) * 2 + 0) * ws.gx + b), ld_agent(part + (size_t(r) * 2 + 1) * ws.gx + b));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+        {
+            const double ohi = __shfl_down(t.hi, off, 64);
+            const double olo = __shfl_down(acc_lo(t), off, 64);
+            t.merge(ohi, olo);
+        }
+        acc[r] = t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < NRED; r++)
+        if (lane == 0)
+        {
+            sh[r][0][wave] = acc[r].hi;
+            sh[r][1][wave] = acc_lo(acc[r]);
+        }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+#pragma unroll
+        for (int r = 0; r < NRED; r++)
+        {
+            A t;
+            for (int w = 0; w < kWaves; w++)
+                t.merge(sh[r][0][w], sh[r][1][w]);
+            acc[r] = t;
+        }
+        __hip_atomic_store(ws.ticket + p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return true;
+}
+
+template <class T>
+struct BatBufs
+{
+    T* X;    // [3][P][ld]
+    T* G;    // [3][P][ld]
+    T* D;    // [P][ld]
+    T* S;    // [m+1][P][ld]
+    T* Y;    // [m+1][P][ld]
+    T* sc;   // [P][scn]
+    int64_t ld;
+    int P, scn;
+    __device__ __forceinline__ T* x(int pt, int p) const { return X + (int64_t(pt) * P + p) * ld; }
+    __device__ __forceinline__ T* g(int pt, int p) const { return G + (int64_t(pt) * P + p) * ld; }
+    __device__ __forceinline__ T* d(int p) const { return D + int64_t(p) * ld; }
+    __device__ __forceinline__ T* s(int col, int p) const { return S + (int64_t(col) * P + p) * ld; }
+    __device__ __forceinline__ T* y(int col, int p) const { return Y + (int64_t(col) * P + p) * ld; }
+    __device__ __forceinline__ T* scal(int p) const { return sc + int64_t(p) * scn; }
+};
+
+__device__ __forceinline__ uint64_t b_splitmix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// x0 of problem p = Rosenbrock start for seed (seed_base + first + p)
+template <class T>
+__global__ void __launch_bounds__(kBlock) kb_gen_rosen(BatBufs<T> b, int64_t n, uint64_t seed0)
+{
+    const int p = blockIdx.y;
+    T* x = b.x(0, p);
+    const uint64_t seed = seed0 + uint64_t(p);
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
+    {
+        const double u = double(b_splitmix64(uint64_t(i) + seed * 0x9E3779B97F4A7C15ull) >> 11) * (1.0 / 9007199254740992.0);
+        x[i] = T(((i & 1) ? 1.0 : -1.2) + 0.4 * u);
+    }
+}
+
+// out (per problem, at sc[i_out..]): f(x), g.g, x.x at point x_in
+template <class T, class OBJ>
+__global__ void __launch_bounds__(kBlock) kb_eval(BatBufs<T> b, const BatDesc* __restrict__ desc, int64_t n, OBJ obj, BatWs ws)
+{
+    const int p = blockIdx.y;
+    const BatDesc de = desc[p];
+    if (!de.active)
+        return;
+    typedef typename AccOf<T>::type A;
+    constexpr int W = Vec16<T>::W;
+    const T* x = b.x(de.x_in, p);
+    T* g = b.g(de.x_in, p);
+    A acc[3];
+    const int64_t nv = n / W, stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t vi = int64_t(blockIdx.x) * kBlock + threadIdx.x; vi < nv; vi += stride)
+    {
+        const Pack<T> px = ldv(x, vi);
+        Pack<T> pg;
+        obj.pack(vi, px, pg, acc[0]);
+        stv(g, vi, pg);
+#pragma unroll
+        for (int k = 0; k < W; k++)
+        {
+            acc[1].add_prod(pg.e[k], pg.e[k]);
+            acc[2].add_prod(px.e[k], px.e[k]);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int64_t i = nv * W; i < n; i++)
+        {
+            obj.tail(i, n, x, g, acc[0]);
+            acc[1].add_prod(g[i], g[i]);
+            acc[2].add_prod(x[i], x[i]);
+        }
+    if (bat_reduce<3>(acc, ws) && threadIdx.x == 0)
+    {
+        T* o = b.scal(p) + de.i_out;
+        o[0] = obj.finish(T(acc[0].value()));
+        o[1] = T(acc[1].value());
+        o[2] = T(acc[2].value());
+    }
+}
+
+// x_out = x_in + step*d ; g_out = grad f ; out = {f, g.d}
+template <class T, class OBJ>
+__global__ void __launch_bounds__(kBlock) kb_trial(BatBufs<T> b, const BatDesc* __restrict__ desc, int64_t n, OBJ obj, BatWs ws)
+{
+    const int p = blockIdx.y;
+    const BatDesc de = desc[p];
+    if (!de.active)
+        return;
+    typedef typename AccOf<T>::type A;
+    constexpr int W = Vec16<T>::W;
+    const T* xp = b.x(de.x_in, p);
+    const T* d = b.d(p);
+    T* x = b.x(de.x_out, p);
+    T* g = b.g(de.x_out, p);
+    const T step = T(de.step);
+    A acc[2];
+    const int64_t nv = n / W, stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t vi = int64_t(blockIdx.x) * kBlock + threadIdx.x; vi < nv; vi += stride)
+    {
+        const Pack<T> pxp = ldv(xp, vi), pd = ldv(d, vi);
+        Pack<T> px, pg;
+#pragma unroll
+        for (int k = 0; k < W; k++)
+            px.e[k] = pxp.e[k] + step * pd.e[k];
+        obj.pack(vi, px, pg, acc[0]);
+        stv(x, vi, px);
+        stv(g, vi, pg);
+#pragma unroll
+        for (int k = 0; k < W; k++)
+            acc[1].add_prod(pg.e[k], pd.e[k]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+    {
+        for (int64_t i = nv * W; i < n; i++)
+            x[i] = xp[i] + step * d[i];
+        for (int64_t i = nv * W; i < n; i++)
+        {
+            obj.tail(i, n, x, g, acc[0]);
+            acc[1].add_prod(g[i], d[i]);
+        }
+    }
+    if (bat_reduce<2>(acc, ws) && threadIdx.x == 0)
+    {
+        T* o = b.scal(p) + de.i_out;
+        o[0] = obj.finish(T(acc[0].value()));
+        o[1] = T(acc[1].value());
+    }
+}
+
+// s = x - xp, y = g - gp into column col_u ; out = {g.g, x.x, s.y, y.y}; ys/theta slots of that column
+template <class T>
+__global__ void __launch_bounds__(kBlock) kb_post(BatBufs<T> b, const BatDesc* __restrict__ desc, int64_t n, BatWs ws)
+{
+    const int p = blockIdx.y;
+    const BatDesc de = desc[p];
+    if (!de.active)
+        return;
+    typedef typename AccOf<T>::type A;
+    constexpr int W = Vec16<T>::W;
+    const T* x = b.x(de.x_out, p);
+    const T* xp = b.x(de.x_in, p);
+    const T* g = b.g(de.x_out, p);
+    const T* gp = b.g(de.x_in, p);
+    T* s = b.s(de.col_u, p);
+    T* y = b.y(de.col_u, p);
+    A acc[4];
+    const int64_t nv = n / W, stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t vi = int64_t(blockIdx.x) * kBlock + threadIdx.x; vi < nv; vi += stride)
+    {
+        const Pack<T> px = ldv(x, vi), pxp = ldv(xp, vi), pg = ldv(g, vi), pgp = ldv(gp, vi);
+        Pack<T> ps, py;
+#pragma unroll
+        for (int k = 0; k < W; k++)
+        {
+            ps.e[k] = px.e[k] - pxp.e[k];
+            py.e[k] = pg.e[k] - pgp.e[k];
+            acc[0].add_prod(pg.e[k], pg.e[k]);
+            acc[1].add_prod(px.e[k], px.e[k]);
+            acc[2].add_prod(ps.e[k], py.e[k]);
+            acc[3].add_prod(py.e[k], py.e[k]);
+        }
+        stv(s, vi, ps);
+        stv(y, vi, py);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int64_t i = nv * W; i < n; i++)
+        {
+            const T si = x[i] - xp[i], yi = g[i] - gp[i];
+            s[i] = si;
+            y[i] = yi;
+            acc[0].add_prod(g[i], g[i]);
+            acc[1].add_prod(x[i], x[i]);
+            acc[2].add_prod(si, yi);
+            acc[3].add_prod(yi, yi);
+        }
+    if (bat_reduce<4>(acc, ws) && threadIdx.x == 0)
+    {
+        T* sc = b.scal(p);
+        const T sy = T(acc[2].value()), yy = T(acc[3].value());
+        sc[de.i_out + 0] = T(acc[0].value());
+        sc[de.i_out + 1] = T(acc[1].value());
+        sc[de.i_out + 2] = sy;
+        sc[de.i_out + 3] = yy;
+        sc[de.i_den] = sy;           // ys slot of the column
+        sc[de.i_theta] = yy / sy;    // theta slot of the column
+    }
+}
+
+// one two-loop step for every problem, each with its own mode / columns / scalar indices
+template <class T>
+__global__ void __launch_bounds__(kBlock) kb_twoloop(BatBufs<T> b, const BatDesc* __restrict__ desc, int64_t n, BatWs ws)
+{
+    const int p = blockIdx.y;
+    const BatDesc de = desc[p];
+    if (!de.active)
+        return;
+    typedef typename AccOf<T>::type A;
+    constexpr int W = Vec16<T>::W;
+    T* sc = b.scal(p);
+    T* q = b.d(p);
+    const T* gcur = b.g(de.x_in, p);
+    const int mode = de.mode;
+    const T a = T(de.step);
+    T coef = T(0), theta = T(1);
+    if (mode == TL_SUB || mode == TL_SUBDIV)
+        coef = sc[de.i_num] / sc[de.i_den];
+    if (mode == TL_ADD)
+        coef = sc[de.i_num] / sc[de.i_den] - sc[de.i_num2] / sc[de.i_den];
+    if (mode == TL_SUBDIV)
+        theta = sc[de.i_theta];
+    const T* u = (mode == TL_ADD) ? b.s(de.col_u, p) : b.y(de.col_u, p);
+    // the dot runs against: the gradient (col_w < 0), else S (first loop / INIT) or Y (second loop)
+    const T* w = (de.col_w < 0) ? gcur : ((mode == TL_INIT || mode == TL_SUB) ? b.s(de.col_w, p) : b.y(de.col_w, p));
+
+    A acc[1];
+    constexpr int U = 4;
+    const int64_t nv = n / W, tile = int64_t(kBlock) * U;
+    const int64_t first = int64_t(blockIdx.x) * tile, stride = int64_t(gridDim.x) * tile;
+    const bool tail = (blockIdx.x == 0 && threadIdx.x == 0);
+    switch (mode)  // uniform per problem (per blockIdx.y): no divergence
+    {
+    case TL_INIT: twoloop_body<T, TL_INIT, U, true>(q, gcur, a, u, w, n, coef, theta, first, nv, stride, tail, acc[0]); break;
+    case TL_SUB: twoloop_body<T, TL_SUB, U, true>(q, gcur, a, u, w, n, coef, theta, first, nv, stride, tail, acc[0]); break;
+    case TL_SUBDIV: twoloop_body<T, TL_SUBDIV, U, true>(q, gcur, a, u, w, n, coef, theta, first, nv, stride, tail, acc[0]); break;
+    default: twoloop_body<T, TL_ADD, U, true>(q, gcur, a, u, w, n, coef, theta, first, nv, stride, tail, acc[0]); break;
+    }
+    if (bat_reduce<1>(acc, ws) && threadIdx.x == 0)
+        sc[de.i_out] = T(acc[0].value());
+}
+
+}  // namespace lbfgsx
+
+using namespace lbfgsx;
+
+struct lbfgsx_batch
+{
+    int dtype = LBFGSX_F64, device = 0, m = 0, P = 0, gx = 1, scn = 0;
+    size_t esz = 8;
+    int64_t n = 0, ld = 0;
+    hipStream_t stream = nullptr;
+    void *X = nullptr, *G = nullptr, *D = nullptr, *S = nullptr, *Y = nullptr, *sc = nullptr;
+    BatWs ws;
+    BatDesc* desc_dev = nullptr;
+    void* hout = nullptr;  // pinned staging for the scalar table
+    size_t hout_cap = 0;
+    lbfgsx_bat_desc* hdesc = nullptr;  // pinned staging for the descriptors
+    ScLayout sl;
+};
+
+#define BAT_DISPATCH(c, ...)          \
+    do                                \
+    {                                 \
+        if ((c)->dtype == LBFGSX_F64) \
+        {                             \
+            typedef double T;         \
+            __VA_ARGS__               \
+        }                             \
+        else                          \
+        {                             \
+            typedef float T;          \
+            __VA_ARGS__               \
+        }                             \
+    } while (0)
+
+namespace lbfgsx {
+template <class T>
+static BatBufs<T> bufs(lbfgsx_batch* c)
+{
+    BatBufs<T> b;
+    b.X = static_cast<T*>(c->X);
+    b.G = static_cast<T*>(c->G);
+    b.D = static_cast<T*>(c->D);
+    b.S = static_cast<T*>(c->S);
+    b.Y = static_cast<T*>(c->Y);
+    b.sc = static_cast<T*>(c->sc);
+    b.ld = c->ld;
+    b.P = c->P;
+    b.scn = c->scn;
+    return b;
+}
+}  // namespace lbfgsx
+
+extern "C" {
+
+int lbfgsx_bat_create(lbfgsx_batch** out, int dtype, int64_t n, int m, int nproblems, int device)
+{
+    if (!out || n <= 0 || m <= 0 || m > 31 || nproblems <= 0 || (dtype != LBFGSX_F64 && dtype != LBFGSX_F32))
+    {
+        set_error("lbfgsx_bat_create: invalid argument");
+        return LBFGSX_E_INVALID;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    {
+        set_error("lbfgsx_bat_create: no HIP device available (this library has no CPU fallback)");
+        return LBFGSX_E_NOGPU;
+    }
+    LBFGSX_HIP(hipSetDevice(device));
+    lbfgsx_batch* c = new lbfgsx_batch();
+    c->dtype = dtype;
+    c->esz = (dtype == LBFGSX_F64) ? 8 : 4;
+    c->n = n;
+    c->ld = (n + 63) / 64 * 64;
+    c->m = m;
+    c->P = nproblems;
+    c->device = device;
+    c->sl.m = m;
+    c->scn = (c->sl.total() + 15) / 16 * 16;
+    const int64_t w = (dtype == LBFGSX_F64) ? 2 : 4;
+    // Blocks per problem.  Every extra block of a problem costs an inter-block reduction tail, which is large
+    // next to the ~10 us a 0.4 MB vector needs, so use the fewest blocks that still fill the chip: about 1024
+    // blocks per launch (4 per CU) in total, never more than one block per 4 tiles of 4 x 256 16-byte vectors.
+    // Measured on MI355X (P = 1024, n = 1e5, f32): 1 / 2 / 4 / 14 blocks per problem -> 0.38 / 0.45 / 0.58 / 0.84 s.
+    int64_t gx_n = (n / w + 4 * kBlock - 1) / (4 * kBlock);
+    gx_n = std::max<int64_t>(1, std::min<int64_t>((gx_n + 3) / 4, 64));
+    int64_t gx = std::max<int64_t>(1, std::min<int64_t>(gx_n, 1024 / std::max(nproblems, 1)));
+    if (const char* e = getenv("LBFGSX_BAT_GX"))
+        gx = std::max(1, std::min(atoi(e), 256));
+    c->gx = int(gx);
+    LBFGSX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const size_t vb = size_t(c->ld) * c->esz * size_t(nproblems);
+    LBFGSX_HIP(hipMalloc(&c->X, 3 * vb));
+    LBFGSX_HIP(hipMalloc(&c->G, 3 * vb));
+    LBFGSX_HIP(hipMalloc(&c->D, vb));
+    LBFGSX_HIP(hipMalloc(&c->S, size_t(m + 1) * vb));
+    LBFGSX_HIP(hipMalloc(&c->Y, size_t(m + 1) * vb));
+    LBFGSX_HIP(hipMalloc(&c->sc, sizeof(double) * size_t(c->scn) * size_t(nproblems)));
+    LBFGSX_HIP(hipMemset(c->sc, 0, sizeof(double) * size_t(c->scn) * size_t(nproblems)));
+    c->ws.gx = c->gx;
+    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&c->ws.partials), sizeof(double) * size_t(nproblems) * kMaxRedB * 2 * size_t(c->gx)));
+    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&c->ws.ticket), sizeof(unsigned) * size_t(nproblems)));
+    LBFGSX_HIP(hipMemset(c->ws.ticket, 0, sizeof(unsigned) * size_t(nproblems)));
+    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&c->desc_dev), sizeof(BatDesc) * size_t(nproblems)));
+    LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->hdesc), sizeof(BatDesc) * size_t(nproblems), hipHostMallocDefault));
+    *out = c;
+    return LBFGSX_OK;
+}
+
+void lbfgsx_bat_destroy(lbfgsx_batch* c)
+{
+    if (!c)
+        return;
+    (void) hipSetDevice(c->device);
+    (void) hipStreamSynchronize(c->stream);
+    void* ptrs[] = {c->X, c->G, c->D, c->S, c->Y, c->sc, c->ws.partials, c->ws.ticket, c->desc_dev};
+    for (void* p : ptrs)
+        (void) hipFree(p);
+    (void) hipHostFree(c->hout);
+    (void) hipHostFree(c->hdesc);
+    (void) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int lbfgsx_bat_scalar_index(const lbfgsx_batch* c, int kind, int k)
+{
+    switch (kind)
+    {
+    case 0: return c->sl.ys(k);
+    case 1: return c->sl.theta(k);
+    case 2: return c->sl.dot(k);
+    default: return c->sl.out(k);
+    }
+}
+
+int lbfgsx_bat_gen_rosen_x0(lbfgsx_batch* c, uint64_t seed0)
+{
+    const dim3 grid(unsigned(std::max(c->gx, 8)), unsigned(c->P));
+    BAT_DISPATCH(c, { hipLaunchKernelGGL((kb_gen_rosen<T>), grid, dim3(kBlock), 0, c->stream, bufs<T>(c), c->n, seed0); });
+    LBFGSX_HIP(hipGetLastError());
+    return LBFGSX_OK;
+}
+
+// kind: 0 eval, 1 trial, 2 post, 3 two-loop step.  `desc` = host array of P descriptors (uploaded here).
+// After the launch `nout` scalars starting at each problem's desc.i_out are copied back into out[p*nout + k].
+int lbfgsx_bat_launch(lbfgsx_batch* c, int kind, int objective, const lbfgsx_bat_desc* desc, int nout, double* out)
+{
+    LBFGSX_HIP(hipStreamSynchronize(c->stream));  // the pinned descriptor staging may still be in flight
+    std::memcpy(c->hdesc, desc, sizeof(BatDesc) * size_t(c->P));
+    LBFGSX_HIP(hipMemcpyAsync(c->desc_dev, c->hdesc, sizeof(BatDesc) * size_t(c->P), hipMemcpyHostToDevice, c->stream));
+    const dim3 grid(unsigned(c->gx), unsigned(c->P));
+    if (kind != 3 && kind != 2 && objective != LBFGSX_OBJ_EXT_ROSENBROCK)
+    {
+        set_error("lbfgsx_bat_launch: the lock-step batch supports the extended Rosenbrock objective");
+        return LBFGSX_E_INVALID;
+    }
+    BAT_DISPATCH(c, {
+        BatBufs<T> b = bufs<T>(c);
+        switch (kind)
+        {
+        case 0: hipLaunchKernelGGL((kb_eval<T, ObjRosen<T> >), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n, ObjRosen<T>{}, c->ws); break;
+        case 1: hipLaunchKernelGGL((kb_trial<T, ObjRosen<T> >), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n, ObjRosen<T>{}, c->ws); break;
+        case 2: hipLaunchKernelGGL((kb_post<T>), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n, c->ws); break;
+        default: hipLaunchKernelGGL((kb_twoloop<T>), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n, c->ws); break;
+        }
+    });
+    LBFGSX_HIP(hipGetLastError());
+    if (nout > 0 && out)
+    {
+        // one contiguous copy of the whole per-problem scalar table (P * scn scalars, a few hundred KB): far
+        // cheaper than a strided copy of P tiny rows
+        const BatDesc* hd = desc;
+        BAT_DISPATCH(c, {
+            const size_t tot = size_t(c->P) * size_t(c->scn);
+            if (c->hout_cap < tot * sizeof(T))
+            {
+                if (c->hout)
+                    LBFGSX_HIP(hipHostFree(c->hout));
+                LBFGSX_HIP(hipHostMalloc(&c->hout, tot * sizeof(T), hipHostMallocDefault));
+                c->hout_cap = tot * sizeof(T);
+            }
+            LBFGSX_HIP(hipMemcpyAsync(c->hout, c->sc, tot * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+            LBFGSX_HIP(hipStreamSynchronize(c->stream));
+            const T* tab = static_cast<const T*>(c->hout);
+            for (int p = 0; p < c->P; p++)
+                for (int k = 0; k < nout; k++)
+                    out[size_t(p) * nout + k] = double(tab[size_t(p) * size_t(c->scn) + size_t(hd[p].i_out + k)]);
+        });
+    }
+    return LBFGSX_OK;
+}
+
+int lbfgsx_bat_fetch(lbfgsx_batch* c, const int* idx, double* out)
+{
+    BAT_DISPATCH(c, {
+        const size_t tot = size_t(c->P) * size_t(c->scn);
+        if (c->hout_cap < tot * sizeof(T))
+        {
+            if (c->hout)
+                LBFGSX_HIP(hipHostFree(c->hout));
+            LBFGSX_HIP(hipHostMalloc(&c->hout, tot * sizeof(T), hipHostMallocDefault));
+            c->hout_cap = tot * sizeof(T);
+        }
+        LBFGSX_HIP(hipMemcpyAsync(c->hout, c->sc, tot * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+        LBFGSX_HIP(hipStreamSynchronize(c->stream));
+        const T* tab = static_cast<const T*>(c->hout);
+        for (int p = 0; p < c->P; p++)
+            out[p] = double(tab[size_t(p) * size_t(c->scn) + size_t(idx[p])]);
+    });
+    return LBFGSX_OK;
+}
+
+// copy the current iterate of problem p (point index pt) to the host (n elements)
+int lbfgsx_bat_download_x(lbfgsx_batch* c, int p, int pt, void* host)
+{
+    const char* base = static_cast<const char*>(c->X) + (size_t(pt) * c->P + size_t(p)) * size_t(c->ld) * c->esz;
+    LBFGSX_HIP(hipMemcpyAsync(host, base, size_t(c->n) * c->esz, hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    return LBFGSX_OK;
+}
+
+int lbfgsx_bat_sync(lbfgsx_batch* c)
+{
+    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    return LBFGSX_OK;
+}
+}

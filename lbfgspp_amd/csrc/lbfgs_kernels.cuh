@@ -293,38 +293,14 @@ struct TwoLoopArgs
     int i_out;    // where the reduced dot goes
 };
 
-template <class T, int MODE, int U, bool NT>
-__global__ void __launch_bounds__(kBlock) k_twoloop(T* __restrict__ q, const T* __restrict__ vin, T a,
-                                                    const T* __restrict__ u, const T* __restrict__ w, int64_t n,
-                                                    T* __restrict__ sc, TwoLoopArgs args, RedWs ws)
+// The streaming body shared by the single-problem and the lock-step batched kernels: vectors [first, last) in
+// tiles of U independent 16-byte accesses per stream, then (do_tail) the scalar remainder.
+template <class T, int MODE, int U, bool NT, class A>
+__device__ __forceinline__ void twoloop_body(T* __restrict__ q, const T* __restrict__ vin, T a, const T* __restrict__ u,
+                                             const T* __restrict__ w, int64_t n, T coef, T theta, int64_t first,
+                                             int64_t last, int64_t stride, bool do_tail, A& acc)
 {
-    typedef typename AccOf<T>::type A;
     constexpr int W = Vec16<T>::W;
-    T coef = T(0), theta = T(1);
-    if (MODE == TL_SUB || MODE == TL_SUBDIV)
-        coef = sc[args.i_num] / sc[args.i_den];                                    // alpha_j (BFGSMat.h:288)
-    if (MODE == TL_ADD)
-        coef = sc[args.i_num] / sc[args.i_den] - sc[args.i_num2] / sc[args.i_den];  // alpha_j - beta (:298-299)
-    if (MODE == TL_SUBDIV)
-        theta = sc[args.i_theta];
-
-    A acc[1];
-    const int64_t nv = n / W;
-    const int64_t tile = int64_t(kBlock) * U;
-    int64_t first, last, stride;
-    if (args.chunked)
-    {
-        const int64_t slab = ((nv + gridDim.x - 1) / gridDim.x + tile - 1) / tile * tile;
-        first = int64_t(blockIdx.x) * slab;
-        last = first + slab < nv ? first + slab : nv;
-        stride = tile;
-    }
-    else
-    {
-        first = int64_t(blockIdx.x) * tile;
-        last = nv;
-        stride = int64_t(gridDim.x) * tile;
-    }
     for (int64_t base = first + threadIdx.x; base < last; base += stride)
     {
         Pack<T> pq[U], pu[U], pw[U];
@@ -367,12 +343,12 @@ __global__ void __launch_bounds__(kBlock) k_twoloop(T* __restrict__ q, const T* 
                 stv<T, NT>(q, vi, pq[k]);
 #pragma unroll
                 for (int e = 0; e < W; e++)
-                    acc[0].add_prod(MODE == TL_SUBDIV ? pu[k].e[e] : pw[k].e[e], pq[k].e[e]);
+                    acc.add_prod(MODE == TL_SUBDIV ? pu[k].e[e] : pw[k].e[e], pq[k].e[e]);
             }
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        for (int64_t i = nv * W; i < n; i++)
+    if (do_tail)
+        for (int64_t i = (n / W) * W; i < n; i++)
         {
             T qi;
             if (MODE == TL_INIT)
@@ -388,8 +364,44 @@ __global__ void __launch_bounds__(kBlock) k_twoloop(T* __restrict__ q, const T* 
                     qi = qi / theta;
             }
             q[i] = qi;
-            acc[0].add_prod(MODE == TL_SUBDIV ? u[i] : w[i], qi);
+            acc.add_prod(MODE == TL_SUBDIV ? u[i] : w[i], qi);
         }
+}
+
+template <class T, int MODE, int U, bool NT>
+__global__ void __launch_bounds__(kBlock) k_twoloop(T* __restrict__ q, const T* __restrict__ vin, T a,
+                                                    const T* __restrict__ u, const T* __restrict__ w, int64_t n,
+                                                    T* __restrict__ sc, TwoLoopArgs args, RedWs ws)
+{
+    typedef typename AccOf<T>::type A;
+    constexpr int W = Vec16<T>::W;
+    T coef = T(0), theta = T(1);
+    if (MODE == TL_SUB || MODE == TL_SUBDIV)
+        coef = sc[args.i_num] / sc[args.i_den];                                    // alpha_j (BFGSMat.h:288)
+    if (MODE == TL_ADD)
+        coef = sc[args.i_num] / sc[args.i_den] - sc[args.i_num2] / sc[args.i_den];  // alpha_j - beta (:298-299)
+    if (MODE == TL_SUBDIV)
+        theta = sc[args.i_theta];
+
+    A acc[1];
+    const int64_t nv = n / W;
+    const int64_t tile = int64_t(kBlock) * U;
+    int64_t first, last, stride;
+    if (args.chunked)
+    {
+        const int64_t slab = ((nv + gridDim.x - 1) / gridDim.x + tile - 1) / tile * tile;
+        first = int64_t(blockIdx.x) * slab;
+        last = first + slab < nv ? first + slab : nv;
+        stride = tile;
+    }
+    else
+    {
+        first = int64_t(blockIdx.x) * tile;
+        last = nv;
+        stride = int64_t(gridDim.x) * tile;
+    }
+    twoloop_body<T, MODE, U, NT>(q, vin, a, u, w, n, coef, theta, first, last, stride,
+                                 blockIdx.x == 0 && threadIdx.x == 0, acc[0]);
     if (grid_reduce<1>(acc, ws) && threadIdx.x == 0)
         sc[args.i_out] = T(acc[0].value());
 }

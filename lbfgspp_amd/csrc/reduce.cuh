@@ -58,14 +58,30 @@ struct DD
     __device__ __forceinline__ double value() const { return hi + lo; }
 };
 
-struct D1  // f64 accumulator for f32 data (products of floats are exact in double)
+struct D1  // accumulator for f32 data: products of floats are exact in double, the double sum is compensated
 {
-    double hi;
-    __device__ __forceinline__ D1() : hi(0.0) {}
-    __device__ __forceinline__ void add_prod(float a, float b) { hi += double(a) * double(b); }
-    __device__ __forceinline__ void add(float p) { hi += double(p); }
-    __device__ __forceinline__ void merge(double ohi, double) { hi += ohi; }
-    __device__ __forceinline__ double value() const { return hi; }
+    double hi, lo;
+    __device__ __forceinline__ D1() : hi(0.0), lo(0.0) {}
+    __device__ __forceinline__ void add(double p)
+    {
+        const double s = hi + p;
+        const double bb = s - hi;
+        lo += (hi - (s - bb)) + (p - bb);
+        hi = s;
+    }
+    __device__ __forceinline__ void add_prod(float a, float b) { add(double(a) * double(b)); }
+    __device__ __forceinline__ void add(float p) { add(double(p)); }
+    __device__ __forceinline__ void merge(double ohi, double olo)
+    {
+        const double s = hi + ohi;
+        const double bb = s - hi;
+        lo += ((hi - (s - bb)) + (ohi - bb)) + olo;
+        hi = s;
+        const double t = hi + lo;
+        lo = lo - (t - hi);
+        hi = t;
+    }
+    __device__ __forceinline__ double value() const { return hi + lo; }
 };
 
 template <class T> struct AccOf;
@@ -73,7 +89,7 @@ template <> struct AccOf<double> { typedef DD type; static constexpr int words =
 template <> struct AccOf<float> { typedef D1 type; static constexpr int words = 1; };
 
 __device__ __forceinline__ double acc_lo(const DD& a) { return a.lo; }
-__device__ __forceinline__ double acc_lo(const D1&) { return 0.0; }
+__device__ __forceinline__ double acc_lo(const D1& a) { return a.lo; }
 
 // max / min accumulators for the L-BFGS-B reductions (order independent by nature)
 struct RedSum {};
@@ -135,7 +151,10 @@ __device__ __forceinline__ bool grid_reduce(A (&acc)[NRED], const RedWs& ws)
             st_agent(ws.partials + (size_t(r) * 2 + 0) * ws.maxGrid + blockIdx.x, t.hi);
             st_agent(ws.partials + (size_t(r) * 2 + 1) * ws.maxGrid + blockIdx.x, acc_lo(t));
         }
-        __threadfence();  // release: partials visible at agent scope before the ticket
+        // release: the partials were stored write-through at agent scope (sc1), so draining this wave's
+        // stores orders them before the ticket; a full release fence would write back the whole XCD L2 --
+        // all the streaming data this launch just produced -- once per block (MI355X_MICROARCH.md, R1 form)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned old = __hip_atomic_fetch_add(ws.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = (old == unsigned(G - 1));
         if (last)

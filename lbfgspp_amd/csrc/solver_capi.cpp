@@ -8,6 +8,7 @@
 
 #include "../../include/LBFGS.h"
 #include "../../include/LBFGSB.h"
+#include "../../include/LBFGSBatched.h"
 #include "../../include/lbfgsx_solver.h"
 
 using namespace LBFGSpp;
@@ -390,6 +391,40 @@ int lbfgsx_batch_minimize(int algo, int dtype, int linesearch, const lbfgsx_para
     for (auto& th : pool)
         th.join();
     return fatal.load();
+}
+
+// lock-step batch (include/LBFGSBatched.h): L-BFGS + More-Thuente + extended Rosenbrock
+int lbfgsx_batch_minimize_lockstep(int dtype, const lbfgsx_params* p, int64_t n, int64_t first, int count,
+                                   uint64_t seed_base, int device, lbfgsx_batch_item* out, void* x_out, char* errbuf,
+                                   int errlen)
+{
+    lbfgsx_result r;
+    int rc = guarded(&r, [&]() {
+        auto body = [&](auto tag) {
+            typedef decltype(tag) T;
+            LBFGSParam<T> param;
+            fill_common<T>(param, p);
+            param.linesearch = p->linesearch;
+            LBFGSBatchedSolver<T> solver(param);
+            std::vector<typename LBFGSBatchedSolver<T>::Item> items;
+            solver.minimize(n, seed_base, first, count, device, items, static_cast<T*>(x_out));
+            for (int k = 0; k < count; k++)
+            {
+                out[k].niter = items[size_t(k)].niter;
+                out[k].nfev = items[size_t(k)].nfev;
+                out[k].status = items[size_t(k)].status;
+                out[k].fx = double(items[size_t(k)].fx);
+                out[k].gnorm = double(items[size_t(k)].gnorm);
+            }
+        };
+        if (dtype == LBFGSX_F64)
+            body(double());
+        else
+            body(float());
+    });
+    if (errbuf && errlen > 0)
+        std::snprintf(errbuf, size_t(errlen), "%s", r.msg);
+    return rc;
 }
 
 int lbfgsx_solver_stats(lbfgsx_solver* s, long long out[8])

@@ -51,13 +51,27 @@ struct Acc<double>
 #endif
 #if ORACLE_ACC != 0
 template <>
-struct Acc<float>
+struct Acc<float>  // float products are exact in double; the double sum is compensated (order independent)
 {
-    double v;
+#if ORACLE_ACC == 2
+    __float128 v;
     Acc() : v(0) {}
-    inline void add_prod(float a, float b) { v += double(a) * double(b); }
-    inline void add(float a) { v += double(a); }
-    inline float value() const { return float(v); }
+    inline void add_prod(float a, float b) { v += (__float128) (double(a) * double(b)); }
+    inline void add(float a) { v += (__float128) a; }
+    inline float value() const { return float(double(v)); }
+#else
+    double hi, lo;
+    Acc() : hi(0.0), lo(0.0) {}
+    inline void add_d(double p)
+    {
+        const double s = hi + p, bb = s - hi;
+        lo += (hi - (s - bb)) + (p - bb);
+        hi = s;
+    }
+    inline void add_prod(float a, float b) { add_d(double(a) * double(b)); }
+    inline void add(float a) { add_d(double(a)); }
+    inline float value() const { return float(hi + lo); }
+#endif
 };
 #endif
 }  // namespace oracle

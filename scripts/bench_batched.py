@@ -38,6 +38,13 @@ def main():
         bytes_ = (its * (8 * args.m + 12) + (fev - its) * 4) * n * 4.0
         out["runs"].append(dict(threads=t, seconds=dt, problem_iterations_per_s=its / dt, fevals=fev, iterations=its,
                                 failed=int((recs["status"] != 0).sum()), algorithmic_GBs=bytes_ / dt / 1e9))
+    t0 = time.perf_counter()
+    recs = B.solve_local_lockstep(par, n, 0, args.count, seed_base=1000, dtype=np.float32)
+    dt = time.perf_counter() - t0
+    its, fev = int(recs["niter"].sum()), int(recs["nfev"].sum())
+    bytes_ = (its * (8 * args.m + 12) + (fev - its) * 4) * n * 4.0
+    out["lockstep"] = dict(seconds=dt, problem_iterations_per_s=its / dt, fevals=fev, iterations=its,
+                           failed=int((recs["status"] != 0).sum()), algorithmic_GBs=bytes_ / dt / 1e9)
     print(json.dumps(out))
 
 

@@ -39,3 +39,37 @@ def test_batched_is_deterministic_across_thread_counts():
     a = B.solve_local(par, A.ExtendedRosenbrock.objective, 4096, 0, 16, dtype=np.float32, nthreads=1)
     b = B.solve_local(par, A.ExtendedRosenbrock.objective, 4096, 0, 16, dtype=np.float32, nthreads=8)
     assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("dtype,n,m,iters,count", [(np.float32, 4098, 10, 14, 9), (np.float64, 2048, 5, 20, 5),
+                                                   (np.float32, 1000, 3, 40, 17)])
+def test_lockstep_batch_is_bit_identical_to_single_solves(dtype, n, m, iters, count):
+    """every problem of the lock-step batch == LBFGSSolver<T, LineSearchMoreThuente> on the same start point,
+    including problems that hit max_linesearch / converge at different iterations"""
+    import lbfgspp_amd as A
+    from lbfgspp_amd import batched as B
+    par = A.LBFGSParam(m=m, epsilon=1e-3, epsilon_rel=0.0, max_iterations=iters, max_linesearch=6)
+    recs, xs = B.solve_local_lockstep(par, n, first=3, count=count, seed_base=1000, dtype=dtype, return_x=True)
+    s = A.LBFGSSolver(par, linesearch=A.LS_MORE_THUENTE, dtype=dtype)
+    dt = O.F64 if dtype == np.float64 else O.F32
+    for k in range(count):
+        x = O.rosen_x0(n, 1000 + 3 + k, dt)
+        try:
+            niter, fx = s.minimize(A.ExtendedRosenbrock(), x)
+            status = 0
+        except (RuntimeError, ArithmeticError, ValueError):
+            status, niter, fx = s.last.status, recs["niter"][k], s.last.fx
+        assert recs["status"][k] == status
+        if status == 0:
+            assert (recs["niter"][k], recs["nfev"][k]) == (niter, s.last.nfev)
+            assert recs["fx"][k] == fx and recs["gnorm"][k] == s.last.gnorm
+            assert np.array_equal(xs[k], x)
+
+
+def test_lockstep_equals_threaded_batch():
+    import lbfgspp_amd as A
+    from lbfgspp_amd import batched as B
+    par = A.LBFGSParam(m=6, epsilon=0.0, epsilon_rel=0.0, max_iterations=10)
+    a = B.solve_local(par, A.ExtendedRosenbrock.objective, 4096, 0, 24, dtype=np.float32, nthreads=4)
+    b = B.solve_local_lockstep(par, 4096, 0, 24, dtype=np.float32)
+    assert np.array_equal(a, b)
