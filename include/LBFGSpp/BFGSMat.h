@@ -151,7 +151,11 @@ public:
         }
         const int c = m_ncorr, t = 2 * c;
         std::vector<double> G(size_t(t) * size_t(t), 0.0);
-        detail::check(lbfgsx_b_gram(m_c, mask, G.data()));
+        double raw[80];
+        // one pass on the matrix cores for W_P'W_P and W_P'v; the tiled VALU Gram is the fallback
+        const bool fused = (lbfgsx_b_gram_fused(m_c, mask, vsel, G.data(), raw) == LBFGSX_OK);
+        if (!fused)
+            detail::check(lbfgsx_b_gram(m_c, mask, G.data()));
         auto Gm = [&](int i, int j) { return Scalar(G[size_t(i) * size_t(t) + size_t(j)]); };
         std::vector<Scalar> mid(size_t(t) * size_t(t), Scalar(0));
         auto Mid = [&](int i, int j) -> Scalar& { return mid[size_t(j) * size_t(t) + size_t(i)]; };
@@ -166,7 +170,17 @@ public:
                 Mid(c + i, c + j) = m_theta * (Minv(m_m + i, m_m + j) - Gm(c + i, c + j));  // (:552-556)
         BKLDLT<Scalar> midsolver(mid.data(), t, t);
         std::vector<Scalar> WPv;
-        Wtv(vsel, mask, false, WPv);          // WP'v ; tail *= theta        (:560-561)
+        if (fused)                            // WP'v ; tail *= theta        (:560-561)
+        {
+            WPv.assign(size_t(t), Scalar(0));
+            for (int j = 0; j < c; j++)
+            {
+                WPv[size_t(j)] = Scalar(raw[j]);
+                WPv[size_t(c + j)] = Scalar(raw[c + j]) * m_theta;
+            }
+        }
+        else
+            Wtv(vsel, mask, false, WPv);
         midsolver.solve_inplace(WPv.data());
         std::vector<double> coef(static_cast<size_t>(t));
         for (int j = 0; j < c; j++)

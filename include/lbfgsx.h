@@ -174,6 +174,12 @@ int lbfgsx_b_sub_begin(lbfgsx_ctx* c);
 int lbfgsx_b_wtv(lbfgsx_ctx* c, int vsel, int mask, double* out, int64_t* nnz);
 /* masked Gram of [Y_P, S_P] (2c x 2c, row-major, symmetric) for solve_PtBP (BFGSMat.h:543-556) */
 int lbfgsx_b_gram(lbfgsx_ctx* c, int mask, double* gram);
+/* the same Gram plus W_P'v (v = on-the-fly vector `vsel`, or -1) in ONE pass on the matrix cores
+ * (v_mfma_f64_16x16x4_f64 over LDS-staged slabs, ~9x faster than the tiled VALU Gram).  Entries are accurate to
+ * about 1 ulp but not correctly rounded, which ill-conditioned subspace systems amplify beyond the 1e-10
+ * iterate-parity contract, so the path is opt-in: environment LBFGSX_GRAM=mfma at context creation.  Returns
+ * LBFGSX_E_INVALID when not enabled or 2c+1 > 32 -- callers then use lbfgsx_b_gram + lbfgsx_b_wtv. */
+int lbfgsx_b_gram_fused(lbfgsx_ctx* c, int mask, int vsel, double* gram, double* wtv);
 /* masked combine with element-wise epilogue, see LBFGSX_CB_*; coef = NULL means "W term absent" */
 int lbfgsx_b_wcombine(lbfgsx_ctx* c, int mode, int mask, int vsel, const double* coef, double theta);
 /* BOXCQP partition of the free set into L/U/P with the value/multiplier updates (SubspaceMin.h:194-219) */

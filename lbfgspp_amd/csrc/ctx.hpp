@@ -20,7 +20,7 @@ void set_error(const std::string& msg);
         hipError_t e_ = (expr);                                                               \
         if (e_ != hipSuccess)                                                                 \
         {                                                                                     \
-            lbfgsx::set_error(std::string(#expr) + ": " + hipGetErrorString(e_));            \
+            lbfgsx::set_error(std::string(#expr) + ": " + hipGetErrorString(e_) + " [" + __FILE__ + ":" + std::to_string(__LINE__) + "]");            \
             return LBFGSX_E_HIP;                                                              \
         }                                                                                     \
     } while (0)

@@ -1,6 +1,7 @@
 // lbfgspp_amd/csrc/lbfgsb.hip -- C ABI of the L-BFGS-B device operators (include/lbfgsx.h, "L-BFGS-B" block).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -27,6 +28,10 @@ struct lbfgsb_state
     int* g_idx = nullptr;
     int64_t g_cap = 0;
     int g_ncorr = 0;
+    double* gram_partial = nullptr;   // [gram_blocks][3][256][2]
+    double* gram_out = nullptr;       // [3][256]
+    int gram_blocks = 512;
+    bool gram_mfma = false;  // opt-in (LBFGSX_GRAM=mfma): ~1 ulp per entry instead of the correctly rounded sums
 };
 
 namespace lbfgsx {
@@ -151,6 +156,10 @@ int bounded_alloc(lbfgsx_ctx* c)
     else
         (void) rocprim::radix_sort_pairs(nullptr, bytes, P<float>(b->keys_in), P<float>(b->keys_out), b->vals_in,
                                          b->vals_out, size_t(c->n), 0, 32, c->stream);
+    if (const char* e = getenv("LBFGSX_GRAM"))
+        b->gram_mfma = (std::strcmp(e, "mfma") == 0);
+    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->gram_partial), sizeof(double) * size_t(b->gram_blocks) * 3 * 256 * 2));
+    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->gram_out), sizeof(double) * 3 * 256));
     b->sort_tmp_bytes = bytes;
     LBFGSX_HIP(hipMalloc(&b->sort_tmp, bytes ? bytes : 16));
     return LBFGSX_OK;
@@ -163,7 +172,7 @@ void bounded_free(lbfgsx_ctx* c)
         return;
     void* ptrs[] = {b->brk, b->dvec, b->cF, b->y, b->yfb, b->lam, b->mu, b->rhs, b->keys_in, b->keys_out, b->st,
                     b->vals_in, b->vals_out, b->phys_dev, b->dout, b->coef_dev, b->mslot, b->sort_tmp, b->g_brk,
-                    b->g_g, b->g_z, b->g_w, b->g_idx};
+                    b->g_g, b->g_z, b->g_w, b->g_idx, b->gram_partial, b->gram_out};
     for (void* p : ptrs)
         (void) hipFree(p);
     delete b;
@@ -588,6 +597,55 @@ int lbfgsx_b_gram(lbfgsx_ctx* c, int mask, double* gram)
                     gram[(bj + b2) * tot + (bi + a)] = r[a * TB + b2];
                 }
         }
+    return LBFGSX_OK;
+}
+
+// Gram of [Y_P S_P v_P] in one pass on the matrix cores; gram = 2c x 2c row-major, wtv = [Y'v, S'v] raw.
+// Returns LBFGSX_E_INVALID (and leaves the outputs untouched) when the MFMA path is disabled or 2c+1 > 32.
+int lbfgsx_b_gram_fused(lbfgsx_ctx* c, int mask, int vsel_id, double* gram, double* wtv)
+{
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    lbfgsb_state* b = c->bstate;
+    const int tot = 2 * c->ncorr;
+    if (!b->gram_mfma || tot + 1 > 32 || tot < 1)
+    {
+        set_error("lbfgsx_b_gram_fused: MFMA Gram not applicable");
+        return LBFGSX_E_INVALID;
+    }
+    const int64_t ntiles = (c->n + kGramRows - 1) / kGramRows;
+    const int blocks = int(std::min<int64_t>(b->gram_blocks, ntiles));
+    DISPATCH_T(c, {
+        int which[32];
+        for (int k = 0; k < tot; k++)
+            which[k] = k;
+        Cols<T, 32> cl = col_list<T, 32>(c, which, tot);
+        hipLaunchKernelGGL((k_gram_mfma<T>), dim3(blocks), dim3(kBlock), 0, c->stream, cl, tot, bvecs<T>(c), vsel_id, mask, c->n,
+                           b->gram_partial);
+    });
+    hipLaunchKernelGGL(k_gram_finish, dim3(3), dim3(kBlock), 0, c->stream, b->gram_partial, blocks, b->gram_out);
+    LBFGSX_HIP(hipGetLastError());
+    double h[3 * 256];
+    LBFGSX_HIP(hipMemcpyAsync(h, b->gram_out, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    // entry (I, J), I >= J, of the padded 32 x 32 Gram
+    auto G = [&](int I, int J) {
+        const int tb = (I < 16) ? 0 : (J < 16 ? 1 : 2);
+        const int mrow = I & 15, ncol = J & 15;
+        const int reg = mrow >> 2, lane = ((mrow & 3) << 4) | ncol;
+        return h[tb * 256 + reg * 64 + lane];
+    };
+    for (int i = 0; i < tot; i++)
+        for (int j = 0; j <= i; j++)
+        {
+            const double v = G(i, j);
+            gram[i * tot + j] = v;
+            gram[j * tot + i] = v;
+        }
+    if (wtv && vsel_id >= 0)
+        for (int j = 0; j < tot; j++)
+            wtv[j] = G(tot, j);
     return LBFGSX_OK;
 }
 
