@@ -73,6 +73,80 @@ def cpu_baseline(args):
                       % (n, scale, r2.niter - r1.niter, r1.niter, t2 - t0, its, os.cpu_count())}
 
 
+def init_dist():
+    """One process per GPU (torchrun env).  Backend nccl (= RCCL over xGMI); LBFGSX_BENCH_BACKEND=gloo and
+    LBFGSX_BENCH_FORCE_DEVICE=k exist only to exercise the N > 1 code path on a single-GPU box."""
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = int(os.environ.get("LBFGSX_BENCH_FORCE_DEVICE", local))
+    backend = os.environ.get("LBFGSX_BENCH_BACKEND", "nccl")
+    comm_dev = torch.device("cpu")
+    if world > 1:
+        if backend == "nccl":
+            torch.cuda.set_device(dev)
+            comm_dev = torch.device("cuda", dev)
+            dist.init_process_group("nccl", device_id=comm_dev)
+        else:
+            dist.init_process_group(backend)
+    return rank, world, dev, comm_dev, dist
+
+
+def main_batched(args):
+    """BASELINE.json cfg5: independent extended-Rosenbrock problems n=1e5, m=10, f32, LineSearchMoreThuente, fixed
+    budget of `steps` iterations per problem; every rank solves its own contiguous shard of problem ids in the
+    lock-step batch (no data-path collective) and the per-problem records are all-gathered at the end."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import lbfgspp_amd as A
+    from lbfgspp_amd import batched as B
+    rank, world, local, comm_dev, dist = init_dist()
+    n, m, P = 100000, 10, args.problems_per_gpu
+    total = P * world
+    first, count = B.shard_range(total, rank, world)
+    par = A.LBFGSParam(m=m, epsilon=0.0, epsilon_rel=0.0, max_iterations=args.steps)
+    for _ in range(max(1, min(args.warmup, 2))):  # warm-up: allocator, code objects
+        B.solve_local_lockstep(par, n, first, min(count, 64), dtype=np.float32, device=local)
+    if world > 1:
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    recs = B.solve_local_lockstep(par, n, first, count, seed_base=1000, dtype=np.float32, device=local)
+    if world > 1:
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    full = B.gather_records(recs, total, rank, world, dist=dist if world > 1 else None,
+                            device=comm_dev if world > 1 else None)
+    if rank == 0:
+        its, fev = int(full["niter"].sum()), int(full["nfev"].sum())
+        bytes_ = (its * (8 * m + 12) + (fev - its) * 4) * n * 4.0
+        print(json.dumps({
+            "metric": "batched L-BFGS problem-iterations/sec (cfg5: n=1e5, m=10, f32)", "value": its / elapsed,
+            "unit": "problem-iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cfg5: %d independent extended-Rosenbrock problems per GPU, n=1e5, m=10, f32, "
+                                   "LineSearchMoreThuente, %d iterations each, lock-step batch" % (P, args.steps),
+                       "problems_total": total, "fevals_total": fev, "failed": int((full["status"] != 0).sum())},
+            "roofline": {"bound": "hbm", "achieved": bytes_ / elapsed / 1e9 / world, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": bytes_ / elapsed / 1e9 / world / HBM_PEAK_GBS, "traffic": None,
+                         "note": "whole-solve algorithmic bytes per GPU / wall time (includes host control flow)"}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,7 +158,12 @@ def main():
     ap.add_argument("--cpu-n", type=float, default=4e6)
     ap.add_argument("--cpu-steps", type=int, default=12)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--workload", default="north-star", choices=["north-star", "cfg5-batched"],
+                    help="north-star (default, the BASELINE.json metric) or the batched cfg5 shard per GPU")
+    ap.add_argument("--problems-per-gpu", type=int, default=1024)
     args = ap.parse_args()
+    if args.workload == "cfg5-batched":
+        return main_batched(args)
 
     import torch  # noqa: F401  (first: its bundled HIP runtime must be the process-wide one)
     import torch.distributed as dist
@@ -92,12 +171,7 @@ def main():
     import lbfgspp_amd as A
     from lbfgspp_amd import _lib as L
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    rank, world, local, comm_dev, dist = init_dist()
     core, _ = A.load()
     if core.lbfgsx_device_count() < 1:
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
@@ -147,7 +221,7 @@ def main():
         raise SystemExit("solver stopped after %d iterations, before the timed window ended" % niter)
     elapsed = marks["t1"] - marks["t0"]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
