@@ -92,3 +92,63 @@ def test_apply_Hv_restatement_equals_reference():
             v = rng.standard_normal(n)
             assert np.array_equal(ref.apply_Hv(dtype, m, S.reshape(k, n), Y.reshape(k, n), v, -1.0),
                                   port.apply_Hv(dtype, m, S.reshape(k, n), Y.reshape(k, n), v, -1.0))
+
+
+# ---------------------------------------------------------------- L-BFGS-B part of the restatement
+GOLDB = G.load("lbfgsb_golden.json")
+
+
+def _gold_instance(seed, n, npairs, mode):
+    from golden.make_golden import lbfgsb_instance
+    return lbfgsb_instance(seed, n, npairs, mode)
+
+
+@pytest.mark.parametrize("case", GOLDB["trajectories"], ids=[c["name"] for c in GOLDB["trajectories"]])
+def test_lbfgsb_restatement_reproduces_golden_trajectory(case):
+    orc = _port()
+    n = case["n"]
+    a, b = O.quad_problem(n)
+    p = O.lbfgsb_params(m=case["m"], epsilon=0.0, epsilon_rel=0.0, past=0, max_iterations=case["max_iterations"])
+    tr = O.TraceBuf(n, cap=1024, stride=case["stride"])
+    x, r = orc.lbfgsb(O.F64, O.OBJ_QUAD, np.zeros(n), -np.ones(n), np.ones(n), p, a=a, b=b, trace=tr)
+    assert (r.niter, r.nfev, r.status) == (case["niter"], case["nfev"], 0)
+    k = tr.count
+    assert np.array_equal(tr.xs[:k].ravel(), G.unhex(case["trace_xs"]))
+    assert np.array_equal(x[::case["stride"]], G.unhex(case["x_sample"]))
+    assert r.fx == float.fromhex(case["fx"]) and r.gnorm == float.fromhex(case["gnorm"])
+
+
+@pytest.mark.parametrize("inst", GOLDB["instances"], ids=["seed%d" % i["seed"] for i in GOLDB["instances"]])
+def test_cauchy_subspace_restatement_reproduces_golden(inst):
+    orc = _port()
+    S, Y, x0, g, lb, ub = _gold_instance(inst["seed"], inst["n"], inst["npairs"], inst["mode"])
+    res = orc.cauchy_subspace(O.F64, inst["m"], S, Y, x0, g, lb, ub, max_submin=10)
+    assert np.array_equal(res["xcp"], G.unhex(inst["xcp"])) and np.array_equal(res["drt"], G.unhex(inst["drt"]))
+    assert np.array_equal(res["vecc"], G.unhex(inst["vecc"]))
+    assert list(res["newact"]) == inst["newact"] and list(res["fv"]) == inst["fv"]
+
+
+@pytest.mark.skipif(not O.available("ref", "dd"), reason="oracle/_ref only exists where /root/reference does")
+@pytest.mark.parametrize("dtype", [O.F64, O.F32])
+def test_lbfgsb_restatement_equals_reference_build(dtype):
+    ref, port = O.Oracle("ref", "dd"), _port()
+    dt = O.NPDT[dtype]
+    for n, m, iters, bound in ((400, 4, 25, 1.0), (3001, 7, 18, 0.5)):
+        a, b = O.quad_problem(n, 30.0, 5, dtype)
+        lb, ub = -bound * np.ones(n, dt), bound * np.ones(n, dt)
+        x0 = np.linspace(-2, 2, n).astype(dt)  # starts outside the box: exercises force_bounds
+        p = O.lbfgsb_params(m=m, epsilon=0, epsilon_rel=0, max_iterations=iters)  # default past = 1, delta = 1e-10
+        t1, t2 = O.TraceBuf(n, cap=600), O.TraceBuf(n, cap=600)
+        x1, r1 = ref.lbfgsb(dtype, O.OBJ_QUAD, x0, lb, ub, p, a=a, b=b, trace=t1)
+        x2, r2 = port.lbfgsb(dtype, O.OBJ_QUAD, x0, lb, ub, p, a=a, b=b, trace=t2)
+        assert (r1.niter, r1.nfev, r1.status, r1.msg) == (r2.niter, r2.nfev, r2.status, r2.msg)
+        assert np.array_equal(x1, x2) and np.array_equal(t1.xs[:t1.count], t2.xs[:t2.count])
+    # mixed infinite bounds on the Rosenbrock objective
+    n = 600
+    x0 = O.rosen_x0(n, 3, dtype)
+    lb = np.where(np.arange(n) % 3 == 0, -np.inf, -0.5).astype(dt)
+    ub = np.where(np.arange(n) % 5 == 0, np.inf, 0.9).astype(dt)
+    p = O.lbfgsb_params(m=5, max_iterations=40)
+    x1, r1 = ref.lbfgsb(dtype, O.OBJ_ROSEN, x0, lb, ub, p)
+    x2, r2 = port.lbfgsb(dtype, O.OBJ_ROSEN, x0, lb, ub, p)
+    assert (r1.niter, r1.nfev, r1.status) == (r2.niter, r2.nfev, r2.status) and np.array_equal(x1, x2)
