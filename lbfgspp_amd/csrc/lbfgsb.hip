@@ -29,8 +29,9 @@ struct lbfgsb_state
     int64_t g_cap = 0;
     int g_ncorr = 0;
     double* gram_partial = nullptr;   // [gram_blocks][3][256][2]
+    double* gram_partial2 = nullptr;  // [32][3][256][2]
     double* gram_out = nullptr;       // [3][256]
-    int gram_blocks = 512;
+    int gram_blocks = 1024;  // 4 resident blocks per CU (33 KB of LDS each)
     bool gram_mfma = false;  // opt-in (LBFGSX_GRAM=mfma): ~1 ulp per entry instead of the correctly rounded sums
 };
 
@@ -158,7 +159,10 @@ int bounded_alloc(lbfgsx_ctx* c)
                                          b->vals_out, size_t(c->n), 0, 32, c->stream);
     if (const char* e = getenv("LBFGSX_GRAM"))
         b->gram_mfma = (std::strcmp(e, "mfma") == 0);
+    if (const char* e = getenv("LBFGSX_GRAM_BLOCKS"))
+        b->gram_blocks = std::max(64, std::min(atoi(e), 4096));
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->gram_partial), sizeof(double) * size_t(b->gram_blocks) * 3 * 256 * 2));
+    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->gram_partial2), sizeof(double) * 32 * 3 * 256 * 2));
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->gram_out), sizeof(double) * 3 * 256));
     b->sort_tmp_bytes = bytes;
     LBFGSX_HIP(hipMalloc(&b->sort_tmp, bytes ? bytes : 16));
@@ -172,7 +176,7 @@ void bounded_free(lbfgsx_ctx* c)
         return;
     void* ptrs[] = {b->brk, b->dvec, b->cF, b->y, b->yfb, b->lam, b->mu, b->rhs, b->keys_in, b->keys_out, b->st,
                     b->vals_in, b->vals_out, b->phys_dev, b->dout, b->coef_dev, b->mslot, b->sort_tmp, b->g_brk,
-                    b->g_g, b->g_z, b->g_w, b->g_idx, b->gram_partial, b->gram_out};
+                    b->g_g, b->g_z, b->g_w, b->g_idx, b->gram_partial, b->gram_partial2, b->gram_out};
     for (void* p : ptrs)
         (void) hipFree(p);
     delete b;
@@ -624,7 +628,10 @@ int lbfgsx_b_gram_fused(lbfgsx_ctx* c, int mask, int vsel_id, double* gram, doub
         hipLaunchKernelGGL((k_gram_mfma<T>), dim3(blocks), dim3(kBlock), 0, c->stream, cl, tot, bvecs<T>(c), vsel_id, mask, c->n,
                            b->gram_partial);
     });
-    hipLaunchKernelGGL(k_gram_finish, dim3(3), dim3(kBlock), 0, c->stream, b->gram_partial, blocks, b->gram_out);
+    // two-level sum of the per-block partials: 32 chunks in parallel, then the final rounding
+    const int nch = std::min(blocks, 32);
+    hipLaunchKernelGGL(k_gram_finish, dim3(3, nch), dim3(kBlock), 0, c->stream, b->gram_partial, blocks, b->gram_partial2, 0);
+    hipLaunchKernelGGL(k_gram_finish, dim3(3, 1), dim3(kBlock), 0, c->stream, b->gram_partial2, nch, b->gram_out, 1);
     LBFGSX_HIP(hipGetLastError());
     double h[3 * 256];
     LBFGSX_HIP(hipMemcpyAsync(h, b->gram_out, sizeof(h), hipMemcpyDeviceToHost, c->stream));

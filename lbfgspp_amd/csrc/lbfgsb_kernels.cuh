@@ -341,8 +341,19 @@ __global__ void __launch_bounds__(kBlock) k_gram_mfma(Cols<T, 32> cols, int ncol
             if (col < ncols)
             {
                 const T* p = cols.p[col];
-                if (ok0) v0 = double(p[r]);
-                if (ok1) v1 = double(p[r + 1]);
+                if (r + 1 < n)
+                {
+                    // rows r, r+1 of one column: r is even and the column base is 16-byte aligned
+                    T two[2];
+                    if (sizeof(T) == 8)
+                        *reinterpret_cast<d2_t*>(two) = *reinterpret_cast<const d2_t*>(p + r);
+                    else
+                        *reinterpret_cast<float2*>(two) = *reinterpret_cast<const float2*>(p + r);
+                    if (ok0) v0 = double(two[0]);
+                    if (ok1) v1 = double(two[1]);
+                }
+                else if (ok0)
+                    v0 = double(p[r]);
             }
             else
             {
@@ -398,17 +409,28 @@ __global__ void __launch_bounds__(kBlock) k_gram_mfma(Cols<T, 32> cols, int ncol
     }
 }
 
-// sum the per-block partial tiles; out[tb*256 + e], e = reg*64 + lane  <->  Gram row (lane>>4) + 4*reg, col lane&15
-__global__ void __launch_bounds__(kBlock) k_gram_finish(const double* __restrict__ partial, int nblocks, double* __restrict__ out)
+// Sum per-block partial tiles.  grid = (3 tiles, nchunks): block (tb, ch) adds the partials of input blocks
+// ch, ch + nchunks, ... for its 256 entries.  final = 0: writes a double-double partial per chunk (second level
+// input); final = 1 (nchunks == 1): writes the rounded entries out[tb*256 + e], e = reg*64 + lane  <->  Gram row
+// (lane>>4) + 4*reg, column lane&15.
+__global__ void __launch_bounds__(kBlock) k_gram_finish(const double* __restrict__ partial, int nblocks,
+                                                        double* __restrict__ out, int final)
 {
-    const int tb = blockIdx.x, e = threadIdx.x;
+    const int tb = blockIdx.x, ch = blockIdx.y, nch = gridDim.y, e = threadIdx.x;
     DD t;
-    for (int bk = 0; bk < nblocks; bk++)
+    for (int bk = ch; bk < nblocks; bk += nch)
     {
         const double* p = partial + (size_t(bk) * 3 * 256 + size_t(tb) * 256 + e) * 2;
         t.merge(p[0], p[1]);
     }
-    out[tb * 256 + e] = t.value();
+    if (final)
+        out[tb * 256 + e] = t.value();
+    else
+    {
+        double* q = out + (size_t(ch) * 3 * 256 + size_t(tb) * 256 + e) * 2;
+        q[0] = t.hi;
+        q[1] = t.lo;
+    }
 }
 
 // ---------------------------------------------------------------- Cauchy build (Cauchy.h:111-129,154)

@@ -7,4 +7,15 @@ CMD="python bench.py --no-cpu --steps 10 --warmup 11"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- $CMD > $O/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o bench -- $CMD > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o bench -- $CMD > $O/pmc_write.log 2>&1
-find $O -type f | head -30
+# secondary workloads: kernel-trace stats only
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/lbfgsb -o b -- python scripts/bench_lbfgsb.py --n 1e7 --iters 40 > $O/lbfgsb.log 2>&1
+LBFGSX_GRAM=mfma rocprofv3 --kernel-trace --stats --output-format csv -d $O/lbfgsb_mfma -o b -- python scripts/bench_lbfgsb.py --n 1e7 --iters 40 > $O/lbfgsb_mfma.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/batched -o b -- python bench.py --workload cfg5-batched --steps 50 > $O/batched.log 2>&1
+# plain (un-profiled) numbers
+python bench.py > $O/bench_northstar.json 2> /dev/null
+python bench.py --m 20 --steps 10 --warmup 22 --no-cpu > $O/bench_cfg3_m20.json 2> /dev/null
+python bench.py --objective quadratic --n 10000000 --no-cpu > $O/bench_cfg2_quad1e7.json 2> /dev/null
+python bench.py --workload cfg5-batched --steps 50 > $O/bench_cfg5_batched.json 2> /dev/null
+python scripts/bench_lbfgsb.py --n 1e7 --iters 40 --cpu-n 2e5 > $O/bench_cfg4_lbfgsb.json 2> /dev/null
+LBFGSX_GRAM=mfma python scripts/bench_lbfgsb.py --n 1e7 --iters 40 > $O/bench_cfg4_lbfgsb_mfma.json 2> /dev/null
+find $O -type f | wc -l
