@@ -81,7 +81,15 @@ class LBFGSSolver
         {
             detail::check(lbfgsx_ls_begin(c));
             const Scalar step_max = m_param.max_step;
-            LineSearch<Scalar>::LineSearch(ev, m_param, step_max, step, fx, dg);
+            try
+            {
+                LineSearch<Scalar>::LineSearch(ev, m_param, step_max, step, fx, dg);
+            }
+            catch (...)
+            {
+                m_nfev = ev.nfev();  // keep the evaluation count truthful when the search throws
+                throw;
+            }
             m_nfev = ev.nfev();
 
             double g2 = 0, x2 = 0, syd = 0, yyd = 0;

@@ -112,7 +112,15 @@ private:
             step_max = std::min(m_param.max_step, step_max);            // (:200-202)
             Scalar step = Scalar(1);
             step = std::min(step, step_max);
-            LineSearch<Scalar>::LineSearch(ev, m_param, step_max, step, fx, dg);
+            try
+            {
+                LineSearch<Scalar>::LineSearch(ev, m_param, step_max, step, fx, dg);
+            }
+            catch (...)
+            {
+                m_nfev = ev.nfev();  // keep the evaluation count truthful when the search throws
+                throw;
+            }
             m_nfev = ev.nfev();
 
             double pg = 0, x2 = 0, syd = 0, yyd = 0;

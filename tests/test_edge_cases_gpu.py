@@ -1,0 +1,172 @@
+"""-m gpu: edge cases the reference's examples and parameter space imply -- tiny / odd dimensions, m larger than
+the iteration count, infinite and degenerate bounds, f32 L-BFGS-B, exhausted line searches, early exits."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def A():
+    import lbfgspp_amd as A
+    A.load()
+    return A
+
+
+def _run_lbfgs(A, dtype, ls, obj, x0, a=None, b=None, **pk):
+    s = A.LBFGSSolver(A.LBFGSParam(**pk), linesearch=ls, dtype=O.NPDT[dtype])
+    x = np.array(x0, dtype=O.NPDT[dtype])
+    f = A.DiagQuadratic(a, b) if obj == O.OBJ_QUAD else A.ExtendedRosenbrock()
+    try:
+        niter, fx = s.minimize(f, x)
+        return x, niter, s.last.nfev, 0, fx, ""
+    except (RuntimeError, ArithmeticError, ValueError) as e:
+        return x, s.last.niter, s.last.nfev, s.last.status, s.last.fx, str(e)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 63, 64, 65, 255, 257])
+@pytest.mark.parametrize("dtype", [O.F64, O.F32])
+def test_small_and_ragged_dimensions_quadratic(A, oracle, n, dtype):
+    a, b = O.quad_problem(n, 7.0, 2, dtype)
+    x0 = np.linspace(-1, 1, n).astype(O.NPDT[dtype])
+    p = O.lbfgs_params(m=4, max_iterations=30)
+    x_ref, r = oracle.lbfgs(dtype, O.LS_NW, O.OBJ_QUAD, x0, p, a=a, b=b)
+    x, niter, nfev, status, fx, msg = _run_lbfgs(A, dtype, O.LS_NW, O.OBJ_QUAD, x0, a, b, m=4, max_iterations=30)
+    assert (status != 0) == (r.status != 0)
+    if r.status == 0:
+        assert (niter, nfev) == (r.niter, r.nfev)
+        assert np.array_equal(x, x_ref)
+    else:
+        assert msg == r.msg.decode()
+
+
+def test_rosenbrock_requires_even_dimension(A):
+    s = A.LBFGSSolver(A.LBFGSParam())
+    with pytest.raises(ValueError, match="even dimension"):
+        s.minimize(A.ExtendedRosenbrock(), np.zeros(7))
+
+
+def test_history_longer_than_run(A, oracle):
+    n = 500
+    x0 = O.rosen_x0(n)
+    p = O.lbfgs_params(m=25, epsilon=0, epsilon_rel=0, max_iterations=8)
+    x_ref, r = oracle.lbfgs(O.F64, O.LS_MT, O.OBJ_ROSEN, x0, p)
+    x, niter, nfev, status, fx, _ = _run_lbfgs(A, O.F64, O.LS_MT, O.OBJ_ROSEN, x0, m=25, epsilon=0, epsilon_rel=0,
+                                              max_iterations=8)
+    assert status == 0 and (niter, nfev) == (r.niter, r.nfev) and np.array_equal(x, x_ref)
+
+
+def test_m_equal_one(A, oracle):
+    n = 2000
+    a, b = O.quad_problem(n)
+    p = O.lbfgs_params(m=1, epsilon=0, epsilon_rel=0, max_iterations=25)
+    x_ref, r = oracle.lbfgs(O.F64, O.LS_NW, O.OBJ_QUAD, np.zeros(n), p, a=a, b=b)
+    x, niter, nfev, status, fx, _ = _run_lbfgs(A, O.F64, O.LS_NW, O.OBJ_QUAD, np.zeros(n), a, b, m=1, epsilon=0,
+                                              epsilon_rel=0, max_iterations=25)
+    assert (niter, nfev) == (r.niter, r.nfev) and np.array_equal(x, x_ref)
+
+
+def test_start_at_the_minimiser_returns_one_iteration(A):
+    """early exit, reference LBFGS.h:100-103"""
+    s = A.LBFGSSolver(A.LBFGSParam())
+    x = np.ones(10)
+    niter, fx = s.minimize(A.ExtendedRosenbrock(), x)
+    assert niter == 1 and fx == 0.0 and s.last.nfev == 1 and np.array_equal(x, np.ones(10))
+
+
+@pytest.mark.parametrize("ls", [O.LS_NW, O.LS_MT, O.LS_BT, O.LS_BR])
+def test_exhausted_line_search_behaves_like_reference(A, oracle, ls):
+    """max_linesearch = 1..2: MoreThuente / NocedalWright hand back the best point, Backtracking / Bracketing throw."""
+    n = 200
+    x0 = O.rosen_x0(n)
+    for mls in (1, 2):
+        p = O.lbfgs_params(m=5, max_iterations=10, max_linesearch=mls)
+        x_ref, r = oracle.lbfgs(O.F64, ls, O.OBJ_ROSEN, x0, p)
+        x, niter, nfev, status, fx, msg = _run_lbfgs(A, O.F64, ls, O.OBJ_ROSEN, x0, m=5, max_iterations=10,
+                                                    max_linesearch=mls)
+        assert (status != 0) == (r.status != 0), (ls, mls, msg, r.msg)
+        assert nfev == r.nfev
+        if r.status == 0:
+            assert niter == r.niter and np.array_equal(x, x_ref)
+        else:
+            assert msg == r.msg.decode()
+
+
+def test_past_delta_stopping_rule(A, oracle):
+    n = 3000
+    a, b = O.quad_problem(n)
+    for past, delta in ((1, 1e-4), (3, 1e-6)):
+        p = O.lbfgs_params(m=6, epsilon=0, epsilon_rel=0, past=past, delta=delta, max_iterations=200)
+        x_ref, r = oracle.lbfgs(O.F64, O.LS_NW, O.OBJ_QUAD, np.zeros(n), p, a=a, b=b)
+        x, niter, nfev, status, fx, _ = _run_lbfgs(A, O.F64, O.LS_NW, O.OBJ_QUAD, np.zeros(n), a, b, m=6, epsilon=0,
+                                                  epsilon_rel=0, past=past, delta=delta, max_iterations=200)
+        assert r.niter < 200 and (niter, nfev) == (r.niter, r.nfev) and np.array_equal(x, x_ref)
+
+
+# ------------------------------------------------------------------ L-BFGS-B
+def _run_lbfgsb(A, dtype, obj, x0, lb, ub, a=None, b=None, **pk):
+    s = A.LBFGSBSolver(A.LBFGSBParam(**pk), dtype=O.NPDT[dtype])
+    x = np.array(x0, dtype=O.NPDT[dtype])
+    f = A.DiagQuadratic(a, b) if obj == O.OBJ_QUAD else A.ExtendedRosenbrock()
+    niter, fx = s.minimize(f, x, lb, ub)
+    return x, niter, s.last.nfev, fx, s
+
+
+def test_lbfgsb_mixed_infinite_bounds_rosenbrock(A, oracle):
+    """bounds pattern of the reference's example-rosenbrock-box.cpp (some coordinates unbounded, some starting on
+    their bound) on the pair-form Rosenbrock objective"""
+    if not oracle.supports_lbfgsb:
+        pytest.skip("oracle without L-BFGS-B")
+    n = 600
+    x0 = O.rosen_x0(n, 3)
+    lb = np.where(np.arange(n) % 3 == 0, -np.inf, -0.5)
+    ub = np.where(np.arange(n) % 5 == 0, np.inf, 0.9)
+    x0 = np.clip(x0, lb, ub)
+    x0[7], x0[11] = ub[7], lb[11]
+    p = O.lbfgsb_params(m=5, max_iterations=25)
+    x_ref, r = oracle.lbfgsb(O.F64, O.OBJ_ROSEN, x0, lb, ub, p)
+    x, niter, nfev, fx, s = _run_lbfgsb(A, O.F64, O.OBJ_ROSEN, x0, lb, ub, m=5, max_iterations=25)
+    assert (niter, nfev) == (r.niter, r.nfev)
+    assert np.abs(x - x_ref).max() <= 1e-10
+    assert np.all(x >= lb) and np.all(x <= ub)
+
+
+def test_lbfgsb_fixed_variables_and_tiny_problems(A, oracle):
+    if not oracle.supports_lbfgsb:
+        pytest.skip("oracle without L-BFGS-B")
+    for n in (1, 2, 9, 130):
+        a, b = O.quad_problem(n, 5.0, 4)
+        lb, ub = -0.3 * np.ones(n), 0.4 * np.ones(n)
+        lb[::4] = ub[::4] = 0.1  # fixed coordinates (lb == ub)
+        x0 = np.zeros(n)
+        p = O.lbfgsb_params(m=3, max_iterations=30)
+        x_ref, r = oracle.lbfgsb(O.F64, O.OBJ_QUAD, x0, lb, ub, p, a=a, b=b)
+        x, niter, nfev, fx, s = _run_lbfgsb(A, O.F64, O.OBJ_QUAD, x0, lb, ub, a, b, m=3, max_iterations=30)
+        assert (niter, nfev) == (r.niter, r.nfev)
+        assert np.abs(x - x_ref).max() <= 1e-10 and np.all(x[::4] == 0.1)
+
+
+def test_lbfgsb_float32(A, oracle):
+    if not oracle.supports_lbfgsb:
+        pytest.skip("oracle without L-BFGS-B")
+    n = 4000
+    a, b = O.quad_problem(n, 10.0, 1, O.F32)
+    lb, ub = -np.ones(n, np.float32), np.ones(n, np.float32)
+    p = O.lbfgsb_params(m=6, epsilon=0, epsilon_rel=0, past=0, max_iterations=8)
+    x_ref, r = oracle.lbfgsb(O.F32, O.OBJ_QUAD, np.zeros(n, np.float32), lb, ub, p, a=a, b=b)
+    x, niter, nfev, fx, s = _run_lbfgsb(A, O.F32, O.OBJ_QUAD, np.zeros(n, np.float32), lb, ub, a, b, m=6, epsilon=0,
+                                        epsilon_rel=0, past=0, max_iterations=8)
+    assert niter == r.niter
+    assert np.abs(x.astype(np.float64) - x_ref.astype(np.float64)).max() <= 1e-4
+
+
+def test_lbfgsb_unconstrained_limit_matches_free_solution(A):
+    """with bounds far away L-BFGS-B must reach the unconstrained minimiser b/a"""
+    n = 5000
+    a, b = O.quad_problem(n)
+    s = A.LBFGSBSolver(A.LBFGSBParam(m=8, epsilon=1e-8, epsilon_rel=0.0, past=0, max_iterations=300))
+    x = np.zeros(n)
+    niter, fx = s.minimize(A.DiagQuadratic(a, b), x, -1e6 * np.ones(n), 1e6 * np.ones(n))
+    assert niter < 300 and np.abs(x - b / a).max() < 1e-6
