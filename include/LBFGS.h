@@ -22,6 +22,8 @@
 #include <limits>
 #include <vector>
 
+#include "LBFGSpp/BKLDLT.h"
+#include "LBFGSpp/DenseHessian.h"
 #include "LBFGSpp/Device.h"
 #include "LBFGSpp/LineSearchBacktracking.h"
 #include "LBFGSpp/LineSearchBracketing.h"
@@ -161,6 +163,17 @@ public:
         return m_grad_host;
     }
     Scalar final_grad_norm() const { return m_gnorm; }
+
+    // final_approx_hessian() / final_approx_inverse_hessian() (LBFGS.h:192-197): explicit n x n matrices built on
+    // the host from a copy of the history -- a debugging aid for small n, exactly as in the reference
+    DenseMatrix<Scalar> final_approx_hessian()
+    {
+        return detail::dense_B(detail::fetch_history<Scalar>(m_dev.ctx(), int(m_dev.size()), m_param.m));
+    }
+    DenseMatrix<Scalar> final_approx_inverse_hessian()
+    {
+        return detail::dense_H(detail::fetch_history<Scalar>(m_dev.ctx(), int(m_dev.size()), m_param.m));
+    }
 };
 
 }  // namespace LBFGSpp

@@ -88,6 +88,10 @@ double lbfgsx_bfgs_theta(const lbfgsx_ctx* c);
 int lbfgsx_bfgs_add_correction_host(lbfgsx_ctx* c, const void* s, const void* y);
 /* same, but only stages the pair in the spare column (s.y and y.y returned); lbfgsx_commit_correction adds it */
 int lbfgsx_bfgs_stage_correction_host(lbfgsx_ctx* c, const void* s, const void* y, double* sy, double* yy);
+/* storage-slot order copy of the history for the dense debugging getters (BFGSMat::get_Bmat / get_Hmat,
+ * BFGSMat.h:150-271): S_out, Y_out receive ncorr columns of n elements (column j = storage slot j); ptr as in
+ * BFGSMat.h:42-48.  Meant for small n only. */
+int lbfgsx_bfgs_download_history(lbfgsx_ctx* c, void* S_out, void* Y_out, int* ncorr, int* ptr, double* theta);
 /* BFGSMat::apply_Hv (BFGSMat.h:276-302): D = a * H * v where v is a named vector; also returns
  * dg = G . D fused into the last pass when v == LBFGSX_VEC_G (LBFGS.h:123 of the next iteration). */
 int lbfgsx_apply_Hv(lbfgsx_ctx* c, int v_which, double a, double* dg);

@@ -75,6 +75,9 @@ int lbfgsx_solver_set_iteration_hook(lbfgsx_solver* s, void (*fn)(int, void*), v
 int lbfgsx_test_cauchy_subspace(int dtype, int64_t n, int m, int npairs, const void* S, const void* Y, const void* x0,
                                 const void* g, const void* lb, const void* ub, int max_submin, void* xcp, double* vecc,
                                 unsigned char* state, void* drt, long long counts[4], char* errbuf, int errlen);
+/* final_approx_hessian() / final_approx_inverse_hessian() of the last L-BFGS minimize() (reference LBFGS.h:192-197):
+ * column-major n x n doubles; small n only */
+int lbfgsx_solver_hessians(lbfgsx_solver* s, double* B, double* H);
 /* L-BFGS-B instrumentation of the last minimize(): {GCP break points crossed, BOXCQP sweeps, subspace calls,
  * unconverged subspace calls, BFGS resets, 0, 0, 0} */
 int lbfgsx_solver_stats(lbfgsx_solver* s, long long out[8]);

@@ -91,6 +91,7 @@ def load():
     sig(core, "lbfgsx_bfgs_ncorr", i32, vp)
     sig(core, "lbfgsx_bfgs_theta", dbl, vp)
     sig(core, "lbfgsx_bfgs_add_correction_host", i32, vp, vp, vp)
+    sig(core, "lbfgsx_bfgs_download_history", i32, vp, vp, vp, C.POINTER(i32), C.POINTER(i32), pd)
     sig(core, "lbfgsx_apply_Hv", i32, vp, i32, dbl, pd)
     sig(core, "lbfgsx_eval", i32, vp, i32, pd, pd, pd)
     sig(core, "lbfgsx_norms", i32, vp, pd, pd)
@@ -116,6 +117,7 @@ def load():
         C.POINTER(BatchItem))
     sig(sol, "lbfgsx_batch_minimize_lockstep", i32, i32, C.POINTER(Params), i64, i64, i32, C.c_uint64, i32,
         C.POINTER(BatchItem), vp, C.c_char_p, i32)
+    sig(sol, "lbfgsx_solver_hessians", i32, vp, vp, vp)
     sig(sol, "lbfgsx_solver_stats", i32, vp, C.POINTER(C.c_longlong * 8))
     sig(sol, "lbfgsx_solver_minimize", i32, vp, i32, i64, vp, vp, vp, vp, vp, C.POINTER(Trace), C.POINTER(Result))
     _core, _solver = core, sol

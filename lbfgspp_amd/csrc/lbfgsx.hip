@@ -399,6 +399,23 @@ int lbfgsx_bfgs_reset(lbfgsx_ctx* c)
 int lbfgsx_bfgs_ncorr(const lbfgsx_ctx* c) { return c->ncorr; }
 double lbfgsx_bfgs_theta(const lbfgsx_ctx* c) { return c->theta; }
 
+int lbfgsx_bfgs_download_history(lbfgsx_ctx* c, void* S_out, void* Y_out, int* ncorr, int* ptr, double* theta)
+{
+    for (int j = 0; j < c->ncorr; j++)
+    {
+        const size_t bytes = size_t(c->n) * c->esz;
+        LBFGSX_HIP(hipMemcpyAsync(static_cast<char*>(S_out) + size_t(j) * bytes, c->col(c->S, c->phys[size_t(j)]), bytes,
+                                  hipMemcpyDeviceToHost, c->stream));
+        LBFGSX_HIP(hipMemcpyAsync(static_cast<char*>(Y_out) + size_t(j) * bytes, c->col(c->Y, c->phys[size_t(j)]), bytes,
+                                  hipMemcpyDeviceToHost, c->stream));
+    }
+    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    if (ncorr) *ncorr = c->ncorr;
+    if (ptr) *ptr = c->ptr;
+    if (theta) *theta = c->theta;
+    return LBFGSX_OK;
+}
+
 int lbfgsx_commit_correction(lbfgsx_ctx* c)
 {
     if (!c->pending)

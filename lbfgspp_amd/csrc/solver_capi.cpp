@@ -19,6 +19,7 @@ struct lbfgsx_solver
     virtual void prepare(int64_t n) = 0;
     virtual lbfgsx_ctx* ctx() = 0;
     virtual void set_hook(void (*fn)(int, void*), void* user) = 0;
+    virtual int hessians(double*, double*) { return LBFGSX_E_INVALID; }
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long stats_submin_us = 0;
     virtual void minimize(int objective, int64_t n, const void* a, const void* b, void* x, const void* lb,
@@ -97,6 +98,18 @@ struct LbfgsImpl : lbfgsx_solver
             solver->set_iteration_hook([fn, user](int k) { fn(k, user); });
         else
             solver->set_iteration_hook(nullptr);
+    }
+    int hessians(double* B, double* H) override
+    {
+        const DenseMatrix<Scalar> mb = solver->final_approx_hessian(), mh = solver->final_approx_inverse_hessian();
+        const int n = mb.rows();
+        for (int j = 0; j < n; j++)
+            for (int i = 0; i < n; i++)
+            {
+                B[size_t(j) * size_t(n) + size_t(i)] = double(mb(i, j));
+                H[size_t(j) * size_t(n) + size_t(i)] = double(mh(i, j));
+            }
+        return LBFGSX_OK;
     }
     void minimize(int objective, int64_t n, const void* a, const void* b, void* x, const void*, const void*,
                   lbfgsx_trace* tr, lbfgsx_result* out) override
@@ -425,6 +438,14 @@ int lbfgsx_batch_minimize_lockstep(int dtype, const lbfgsx_params* p, int64_t n,
     if (errbuf && errlen > 0)
         std::snprintf(errbuf, size_t(errlen), "%s", r.msg);
     return rc;
+}
+
+int lbfgsx_solver_hessians(lbfgsx_solver* s, double* B, double* H)
+{
+    lbfgsx_result r;
+    int rc = LBFGSX_OK;
+    const int g = guarded(&r, [&]() { rc = s->hessians(B, H); });
+    return g ? g : rc;
 }
 
 int lbfgsx_solver_stats(lbfgsx_solver* s, long long out[8])

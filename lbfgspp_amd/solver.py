@@ -166,6 +166,13 @@ class LBFGSSolver(_SolverBase):
     def final_grad_norm(self):
         return self.last.gnorm
 
+    def final_approx_hessians(self, n):
+        """(final_approx_hessian(), final_approx_inverse_hessian()) as dense n x n arrays (small n only)."""
+        B = np.zeros((n, n), order="F")
+        H = np.zeros((n, n), order="F")
+        L.check(self._sol.lbfgsx_solver_hessians(self._h, B.ctypes.data_as(C.c_void_p), H.ctypes.data_as(C.c_void_p)))
+        return B, H
+
 
 class LBFGSBSolver(_SolverBase):
     """LBFGSBSolver<Scalar> with LineSearchMoreThuente (reference LBFGSB.h:21-23)."""

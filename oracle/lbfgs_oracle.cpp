@@ -719,6 +719,15 @@ double oracle_port_eval(int dtype, int obj, long n, const void* a, const void* b
                                                 static_cast<const float*>(x), static_cast<float*>(grad)));
 }
 
+int oracle_port_lbfgs_hessians(int, int, int, long, const void*, const void*, void*, const oracle_params*, double*, double*,
+                               oracle_result* out)
+{
+    // the dense getters (BFGSMat.h:150-271) are outside the hot path; only oracle/_ref and the golden fixture cover them
+    std::memset(out, 0, sizeof(*out));
+    out->status = -1000;
+    return out->status;
+}
+
 const char* oracle_port_describe(void)
 {
 #if ORACLE_ACC == 0

@@ -68,6 +68,10 @@ typedef struct
                                  const void* x0, const void* g, const void* lb, const void* ub, int max_submin,   \
                                  void* xcp, void* vecc, int* newact, int* n_newact, int* fv, int* n_fv,           \
                                  void* drt);                                                                      \
+    /* minimize() followed by final_approx_hessian() / final_approx_inverse_hessian() (LBFGS.h:192-197),           \
+       B and H column-major n x n doubles; -1000 when the implementation has no dense getters */                    \
+    int prefix##_lbfgs_hessians(int dtype, int ls, int obj, long n, const void* a, const void* b, void* x,        \
+                                const oracle_params* p, double* B, double* H, oracle_result* out);                \
     const char* prefix##_describe(void);
 
 ORACLE_DECL(oracle_ref)

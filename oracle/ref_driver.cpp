@@ -121,6 +121,36 @@ void run_lbfgs(int obj, long n, const T* a, const T* b, T* x, const oracle_param
     std::memcpy(x, xv.data(), sizeof(T) * size_t(n));
 }
 
+template <class T, template <class> class LS>
+void run_lbfgs_hess(int obj, long n, const T* a, const T* b, T* x, const oracle_params* p, double* B, double* H,
+                    oracle_result* out)
+{
+    typedef Eigen::Matrix<T, Eigen::Dynamic, 1> Vec;
+    typedef Eigen::Matrix<T, Eigen::Dynamic, Eigen::Dynamic> Mat;
+    LBFGSParam<T> q;
+    fill_common<T>(q, p);
+    q.linesearch = p->linesearch;
+    Functor<T> f = {obj, n, a, b, nullptr, 0};
+    Vec xv(n);
+    std::memcpy(xv.data(), x, sizeof(T) * size_t(n));
+    T fx = T(0);
+    guarded(out, [&]() {
+        LBFGSSolver<T, LS> solver(q);
+        out->niter = solver.minimize(f, xv, fx);
+        out->gnorm = double(solver.final_grad_norm());
+        const Mat mb = solver.final_approx_hessian(), mh = solver.final_approx_inverse_hessian();
+        for (long j = 0; j < n; j++)
+            for (long i = 0; i < n; i++)
+            {
+                B[size_t(j) * size_t(n) + size_t(i)] = double(mb(i, j));
+                H[size_t(j) * size_t(n) + size_t(i)] = double(mh(i, j));
+            }
+    });
+    out->nfev = f.nfev;
+    out->fx = double(fx);
+    std::memcpy(x, xv.data(), sizeof(T) * size_t(n));
+}
+
 template <class T>
 void run_lbfgs_ls(int ls, int obj, long n, const void* a, const void* b, void* x, const oracle_params* p,
                   oracle_trace* tr, oracle_result* out)
@@ -255,6 +285,26 @@ int oracle_ref_apply_Hv(int dtype, long n, int m, int npairs, const void* S, con
     else
         apply_Hv_t<float>(n, m, npairs, S, Y, v, alpha, res);
     return 0;
+}
+
+int oracle_ref_lbfgs_hessians(int dtype, int ls, int obj, long n, const void* a, const void* b, void* x,
+                              const oracle_params* p, double* B, double* H, oracle_result* out)
+{
+    if (dtype == ORACLE_F64)
+    {
+        if (ls == ORACLE_LS_MORE_THUENTE)
+            run_lbfgs_hess<double, LineSearchMoreThuente>(obj, n, static_cast<const double*>(a), static_cast<const double*>(b), static_cast<double*>(x), p, B, H, out);
+        else
+            run_lbfgs_hess<double, LineSearchNocedalWright>(obj, n, static_cast<const double*>(a), static_cast<const double*>(b), static_cast<double*>(x), p, B, H, out);
+    }
+    else
+    {
+        if (ls == ORACLE_LS_MORE_THUENTE)
+            run_lbfgs_hess<float, LineSearchMoreThuente>(obj, n, static_cast<const float*>(a), static_cast<const float*>(b), static_cast<float*>(x), p, B, H, out);
+        else
+            run_lbfgs_hess<float, LineSearchNocedalWright>(obj, n, static_cast<const float*>(a), static_cast<const float*>(b), static_cast<float*>(x), p, B, H, out);
+    }
+    return out->status;
 }
 
 double oracle_ref_eval(int dtype, int obj, long n, const void* a, const void* b, const void* x, void* grad)

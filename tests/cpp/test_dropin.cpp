@@ -136,6 +136,22 @@ int main()
         std::printf("rosenbrock(host functor): %d iterations, %d calls, f=%g\n", niter, f.calls, fx);
         EXPECT(niter == 22 && f.calls == 36);
         EXPECT(solver.final_grad().size() == 10);
+        // README prints final_approx_hessian / final_approx_inverse_hessian: B symmetric, B*H = I
+        const DenseMatrix<double> B = solver.final_approx_hessian(), H = solver.final_approx_inverse_hessian();
+        EXPECT(B.rows() == 10 && B.cols() == 10 && H.rows() == 10);
+        double worst = 0.0, asym = 0.0;
+        for (int i = 0; i < 10; i++)
+            for (int j = 0; j < 10; j++)
+            {
+                double acc = 0.0;
+                for (int k = 0; k < 10; k++)
+                    acc += B(i, k) * H(k, j);
+                worst = std::fmax(worst, std::fabs(acc - (i == j ? 1.0 : 0.0)));
+                asym = std::fmax(asym, std::fabs(B(i, j) - B(j, i)));
+            }
+        std::printf("dense getters: |B*H - I|max = %.3g, |B - B'|max = %.3g, B(0,0) = %.10g\n", worst, asym, B(0, 0));
+        EXPECT(worst < 1e-9 && asym < 1e-9);
+        EXPECT(std::fabs(B(0, 0) - 657.58964513) < 1e-6);
         LBFGSSolver<double, LineSearchMoreThuente> s2(param);
         RosenbrockPairs f2{10};
         Vec x2(10, 0.0);

@@ -87,8 +87,31 @@ def make_lbfgsb(orc):
           [(i["seed"], len(i["newact"]), len(i["fv"])) for i in out["instances"]])
 
 
+def make_hessians(orc):
+    """final_approx_hessian() / final_approx_inverse_hessian() after minimize() (reference LBFGS.h:192-197,
+    BFGSMat.h:150-271): the README example (n=10, x0=0) and two seeded cases with a wrapped history."""
+    out = dict(generator="tests/golden/make_golden.py", oracle=orc.description, cases=[])
+    for name, ls, obj, n, m, iters, hashed in (("readme_rosen10_nw", O.LS_NW, O.OBJ_ROSEN, 10, 6, 100, False),
+                                               ("rosen12_mt_m3_wrapped", O.LS_MT, O.OBJ_ROSEN, 12, 3, 8, True),
+                                               ("quad9_nw_m4_short", O.LS_NW, O.OBJ_QUAD, 9, 4, 2, False)):
+        if obj == O.OBJ_ROSEN:
+            x0 = O.rosen_x0(n, 7, O.F64) if hashed else np.zeros(n)
+            a = b = None
+        else:
+            x0 = np.zeros(n)
+            a, b = O.quad_problem(n, 10.0, 1, O.F64)
+        p = O.lbfgs_params(m=m, max_iterations=iters, epsilon=1e-6)
+        x, r, B, H = orc.lbfgs_hessians(O.F64, ls, obj, x0, p, a=a, b=b)
+        out["cases"].append(dict(name=name, ls=ls, obj=obj, n=n, m=m, max_iterations=iters, hash_x0=hashed, niter=r.niter,
+                                 B=hx(B.ravel(order="F")), H=hx(H.ravel(order="F"))))
+    with open(os.path.join(HERE, "hessian_golden.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    print("wrote hessian golden:", [(c["name"], c["niter"]) for c in out["cases"]])
+
+
 def main():
     orc = O.Oracle("ref", "dd")
+    make_hessians(orc)
     cases = []
     # README / example known answers (SURVEY.md 8(c)): Rosenbrock n=10, x0=0
     for ls, nm in ((O.LS_NW, "nw"), (O.LS_MT, "mt"), (O.LS_BT, "bt"), (O.LS_BR, "br")):

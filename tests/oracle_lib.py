@@ -83,6 +83,7 @@ class Oracle:
         self._eval = getattr(self.lib, pre + "_eval")
         self._eval.restype = C.c_double
         self._cs = getattr(self.lib, pre + "_cauchy_subspace")
+        self._hess = getattr(self.lib, pre + "_lbfgs_hessians")
         d = getattr(self.lib, pre + "_describe")
         d.restype = C.c_char_p
         self.description = d().decode()
@@ -121,6 +122,21 @@ class Oracle:
         self._lbfgsb(dtype, obj, x.size, self._p(a), self._p(b), self._p(lb), self._p(ub), self._p(x),
                      C.byref(params), C.byref(trace.c) if trace else None, C.byref(res))
         return x, res
+
+    def lbfgs_hessians(self, dtype, ls, obj, x0, params, a=None, b=None):
+        """minimize() then (final_approx_hessian, final_approx_inverse_hessian); None when unsupported."""
+        x = np.ascontiguousarray(x0, dtype=NPDT[dtype]).copy()
+        n = x.size
+        B = np.zeros((n, n), order="F")
+        H = np.zeros((n, n), order="F")
+        res = Result()
+        self._hess.argtypes = [C.c_int, C.c_int, C.c_int, C.c_long] + [C.c_void_p] * 3 + [C.POINTER(Params), C.c_void_p,
+                                                                                       C.c_void_p, C.POINTER(Result)]
+        rc = self._hess(dtype, ls, obj, n, self._p(a), self._p(b), self._p(x), C.byref(params), self._p(B), self._p(H),
+                        C.byref(res))
+        if rc == -1000:
+            return None
+        return x, res, B, H
 
     def apply_Hv(self, dtype, m, S, Y, v, alpha):
         """S, Y: [npairs, n] arrays (row k = k-th correction pair fed to add_correction)."""

@@ -152,3 +152,27 @@ def test_lbfgsb_restatement_equals_reference_build(dtype):
     x1, r1 = ref.lbfgsb(dtype, O.OBJ_ROSEN, x0, lb, ub, p)
     x2, r2 = port.lbfgsb(dtype, O.OBJ_ROSEN, x0, lb, ub, p)
     assert (r1.niter, r1.nfev, r1.status) == (r2.niter, r2.nfev, r2.status) and np.array_equal(x1, x2)
+
+
+def test_hessian_fixture_is_consistent_and_reproducible():
+    """tests/golden/hessian_golden.json: B symmetric, B*H = I; oracle/_ref reproduces it bit for bit when present."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hessian_golden.json")) as f:
+        cases = json.load(f)["cases"]
+    assert len(cases) >= 3
+    for c in cases:
+        n = c["n"]
+        B = np.array([float.fromhex(v) for v in c["B"]]).reshape(n, n, order="F")
+        H = np.array([float.fromhex(v) for v in c["H"]]).reshape(n, n, order="F")
+        assert np.abs(B - B.T).max() <= 1e-12 * np.abs(B).max()
+        assert np.abs(B @ H - np.eye(n)).max() < 1e-9
+    try:
+        ref = O.Oracle("ref", "dd")
+    except OSError:
+        return
+    c = cases[0]
+    x, r, B, H = ref.lbfgs_hessians(O.F64, c["ls"], c["obj"], np.zeros(c["n"]),
+                                    O.lbfgs_params(m=c["m"], max_iterations=c["max_iterations"], epsilon=1e-6))
+    assert r.niter == c["niter"]
+    assert [float(v).hex() for v in B.ravel(order="F")] == c["B"]
