@@ -309,7 +309,8 @@ __global__ void __launch_bounds__(kBlock) kb_post(BatBufs<T> b, const BatDesc* _
 
 // one two-loop step for every problem, each with its own mode / columns / scalar indices
 template <class T>
-__global__ void __launch_bounds__(kBlock) kb_twoloop(BatBufs<T> b, const BatDesc* __restrict__ desc, int64_t n, BatWs ws)
+__global__ void __launch_bounds__(kBlock) kb_twoloop(BatBufs<T> b, const BatDesc* __restrict__ desc, int64_t n, BatWs ws,
+                                                     int rev)
 {
     const int p = blockIdx.y;
     const BatDesc de = desc[p];
@@ -338,12 +339,14 @@ __global__ void __launch_bounds__(kBlock) kb_twoloop(BatBufs<T> b, const BatDesc
     const int64_t nv = n / W, tile = int64_t(kBlock) * U;
     const int64_t first = int64_t(blockIdx.x) * tile, stride = int64_t(gridDim.x) * tile;
     const bool tail = (blockIdx.x == 0 && threadIdx.x == 0);
+    // consecutive steps walk each problem's q in opposite directions (memory-side cache reuse, see TwoLoopArgs::rev)
+    const int64_t rev_top = rev ? ((nv + tile - 1) / tile - 1) * tile : int64_t(-1);
     switch (mode)  // uniform per problem (per blockIdx.y): no divergence
     {
-    case TL_INIT: twoloop_body<T, TL_INIT, U, true>(q, gcur, a, u, w, n, coef, theta, first, nv, stride, tail, acc[0]); break;
-    case TL_SUB: twoloop_body<T, TL_SUB, U, true>(q, gcur, a, u, w, n, coef, theta, first, nv, stride, tail, acc[0]); break;
-    case TL_SUBDIV: twoloop_body<T, TL_SUBDIV, U, true>(q, gcur, a, u, w, n, coef, theta, first, nv, stride, tail, acc[0]); break;
-    default: twoloop_body<T, TL_ADD, U, true>(q, gcur, a, u, w, n, coef, theta, first, nv, stride, tail, acc[0]); break;
+    case TL_INIT: twoloop_body<T, TL_INIT, U, true, 0>(q, gcur, a, u, w, n, coef, theta, first, nv, stride, nv, rev_top, tail, acc[0]); break;
+    case TL_SUB: twoloop_body<T, TL_SUB, U, true, 0>(q, gcur, a, u, w, n, coef, theta, first, nv, stride, nv, rev_top, tail, acc[0]); break;
+    case TL_SUBDIV: twoloop_body<T, TL_SUBDIV, U, true, 0>(q, gcur, a, u, w, n, coef, theta, first, nv, stride, nv, rev_top, tail, acc[0]); break;
+    default: twoloop_body<T, TL_ADD, U, true, 0>(q, gcur, a, u, w, n, coef, theta, first, nv, stride, nv, rev_top, tail, acc[0]); break;
     }
     if (bat_reduce<1>(acc, ws) && threadIdx.x == 0)
         sc[de.i_out] = T(acc[0].value());
@@ -366,6 +369,8 @@ struct lbfgsx_batch
     size_t hout_cap = 0;
     lbfgsx_bat_desc* hdesc = nullptr;  // pinned staging for the descriptors
     ScLayout sl;
+    bool zigzag = true;
+    unsigned tl_step = 0;
 };
 
 #define BAT_DISPATCH(c, ...)          \
@@ -435,6 +440,8 @@ int lbfgsx_bat_create(lbfgsx_batch** out, int dtype, int64_t n, int m, int nprob
     int64_t gx_n = (n / w + 4 * kBlock - 1) / (4 * kBlock);
     gx_n = std::max<int64_t>(1, std::min<int64_t>((gx_n + 3) / 4, 64));
     int64_t gx = std::max<int64_t>(1, std::min<int64_t>(gx_n, 1024 / std::max(nproblems, 1)));
+    if (const char* e = getenv("LBFGSX_ZIGZAG"))
+        c->zigzag = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_BAT_GX"))
         gx = std::max(1, std::min(atoi(e), 256));
     c->gx = int(gx);
@@ -511,7 +518,8 @@ int lbfgsx_bat_launch(lbfgsx_batch* c, int kind, int objective, const lbfgsx_bat
         case 0: hipLaunchKernelGGL((kb_eval<T, ObjRosen<T> >), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n, ObjRosen<T>{}, c->ws); break;
         case 1: hipLaunchKernelGGL((kb_trial<T, ObjRosen<T> >), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n, ObjRosen<T>{}, c->ws); break;
         case 2: hipLaunchKernelGGL((kb_post<T>), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n, c->ws); break;
-        default: hipLaunchKernelGGL((kb_twoloop<T>), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n, c->ws); break;
+        default: hipLaunchKernelGGL((kb_twoloop<T>), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n, c->ws,
+                                    (c->zigzag && (c->tl_step++ & 1u)) ? 1 : 0); break;
         }
     });
     LBFGSX_HIP(hipGetLastError());

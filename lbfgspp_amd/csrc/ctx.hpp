@@ -85,6 +85,10 @@ struct lbfgsx_ctx
     int unroll = 4;   // 16-byte loads in flight per stream per thread in the two-loop kernels
     bool nt = true;   // non-temporal hints on the streaming accesses (+8% on MI355X)
     bool chunked = false;  // contiguous slab per block instead of grid-stride tiles
+    int q_policy = 0;      // non-temporal hint on q itself (bit 0 loads, bit 1 stores).  q is the vector every two-loop
+                           // step re-reads, so it stays eligible for the memory-side cache by default
+    bool zigzag = true;    // alternate the traversal direction of consecutive two-loop steps (MALL reuse of q's tail)
+    unsigned tl_step = 0;  // launches issued so far (parity selects the direction)
 
     // L-BFGS-B work set (allocated with LBFGSX_FLAG_BOUNDED) lives in lbfgsb part
     void* lb = nullptr;

@@ -122,26 +122,46 @@ __global__ void __launch_bounds__(kBlock) k_eval(const T* __restrict__ x, T* __r
 template <class T, class OBJ>
 __global__ void __launch_bounds__(kBlock) k_trial(const T* __restrict__ xp, const T* __restrict__ d, T step,
                                                   T* __restrict__ x, T* __restrict__ g, int64_t n, OBJ obj,
-                                                  RedWs ws, T* __restrict__ out)
+                                                  RedWs ws, T* __restrict__ out, int rev)
 {
     typedef typename AccOf<T>::type A;
     constexpr int W = Vec16<T>::W;
     A acc[2];
     const int64_t nv = n / W;
-    const int64_t stride = int64_t(gridDim.x) * kBlock;
-    for (int64_t vi = int64_t(blockIdx.x) * kBlock + threadIdx.x; vi < nv; vi += stride)
+    // tiles of U x kBlock vectors; both loads of every vector are issued before the first use.  The tile order
+    // alternates between launches (TwoLoopArgs::rev)
+    constexpr int U = 2;
+    const int64_t tile = int64_t(kBlock) * U;
+    const int64_t top = ((nv + tile - 1) / tile - 1) * tile;
+    for (int64_t t0 = int64_t(blockIdx.x) * tile; t0 < nv; t0 += int64_t(gridDim.x) * tile)
     {
-        const Pack<T> pxp = ldv(xp, vi), pd = ldv(d, vi);
-        Pack<T> px, pg;
+        const int64_t base = (rev ? top - t0 : t0) + threadIdx.x;
+        Pack<T> pxp[U], pd[U];
 #pragma unroll
-        for (int k = 0; k < W; k++)
-            px.e[k] = pxp.e[k] + step * pd.e[k];
-        obj.pack(vi, px, pg, acc[0]);
-        stv(x, vi, px);
-        stv(g, vi, pg);
+        for (int u = 0; u < U; u++)
+            if (base + u * kBlock < nv)
+            {
+                pxp[u] = ldv(xp, base + u * kBlock);
+                pd[u] = ldv(d, base + u * kBlock);
+            }
 #pragma unroll
-        for (int k = 0; k < W; k++)
-            acc[1].add_prod(pg.e[k], pd.e[k]);
+        for (int u = 0; u < U; u++)
+        {
+            const int64_t vi = base + u * kBlock;
+            if (vi < nv)
+            {
+                Pack<T> px, pg;
+#pragma unroll
+                for (int k = 0; k < W; k++)
+                    px.e[k] = pxp[u].e[k] + step * pd[u].e[k];
+                obj.pack(vi, px, pg, acc[0]);
+                stv(x, vi, px);
+                stv(g, vi, pg);
+#pragma unroll
+                for (int k = 0; k < W; k++)
+                    acc[1].add_prod(pg.e[k], pd[u].e[k]);
+            }
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0)
     {
@@ -230,15 +250,16 @@ __global__ void __launch_bounds__(kBlock) k_post(const T* __restrict__ x, const 
                                                  const T* __restrict__ g, const T* __restrict__ gp,
                                                  T* __restrict__ s, T* __restrict__ y, int64_t n, RedWs ws,
                                                  T* __restrict__ out, T* __restrict__ ys_slot,
-                                                 T* __restrict__ theta_slot)
+                                                 T* __restrict__ theta_slot, int rev)
 {
     typedef typename AccOf<T>::type A;
     constexpr int W = Vec16<T>::W;
     A acc[4];
     const int64_t nv = n / W;
     const int64_t stride = int64_t(gridDim.x) * kBlock;
-    for (int64_t vi = int64_t(blockIdx.x) * kBlock + threadIdx.x; vi < nv; vi += stride)
+    for (int64_t v0 = int64_t(blockIdx.x) * kBlock + threadIdx.x; v0 < nv; v0 += stride)
     {
+        const int64_t vi = rev ? nv - 1 - v0 : v0;
         const Pack<T> px = ldv(x, vi), pxp = ldv(xp, vi), pg = ldv(g, vi), pgp = ldv(gp, vi);
         Pack<T> ps, py;
 #pragma unroll
@@ -291,31 +312,39 @@ struct TwoLoopArgs
     int i_num2;   // sc[i_num2] / sc[i_den] = beta             (TL_ADD)
     int i_theta;  // TL_SUBDIV: q /= sc[i_theta]
     int i_out;    // where the reduced dot goes
+    int rev;      // 1: walk the tiles from the top of the vector down.  Alternating the direction between consecutive
+                  // steps lets the step k+1 start on the part of q that step k wrote last, i.e. the part still held
+                  // by the memory-side cache (256 MB MALL), instead of evicting it before it is reused
 };
 
-// The streaming body shared by the single-problem and the lock-step batched kernels: vectors [first, last) in
-// tiles of U independent 16-byte accesses per stream, then (do_tail) the scalar remainder.
-template <class T, int MODE, int U, bool NT, class A>
+// The streaming body shared by the single-problem and the lock-step batched kernels: tile bases first, first+stride,
+// ... < last (in 16-byte vectors), each tile U independent 16-byte accesses per stream, then (do_tail) the scalar
+// remainder.  rev_top >= 0 mirrors the tile order (tile base b -> rev_top - b); limit bounds the vector index.
+// NT: non-temporal hint on the history / gradient streams (read once per launch); QPOL: the same hint on q itself,
+// bit 0 = its loads, bit 1 = its stores (q is re-read by the next step).
+template <class T, int MODE, int U, bool NT, int QPOL, class A>
 __device__ __forceinline__ void twoloop_body(T* __restrict__ q, const T* __restrict__ vin, T a, const T* __restrict__ u,
                                              const T* __restrict__ w, int64_t n, T coef, T theta, int64_t first,
-                                             int64_t last, int64_t stride, bool do_tail, A& acc)
+                                             int64_t last, int64_t stride, int64_t limit, int64_t rev_top, bool do_tail,
+                                             A& acc)
 {
     constexpr int W = Vec16<T>::W;
-    for (int64_t base = first + threadIdx.x; base < last; base += stride)
+    for (int64_t off = first; off < last; off += stride)
     {
+        const int64_t base = (rev_top >= 0 ? rev_top - off : off) + threadIdx.x;
         Pack<T> pq[U], pu[U], pw[U];
         // issue every load of the tile before the first use (U independent 16-byte loads per stream)
 #pragma unroll
         for (int k = 0; k < U; k++)
         {
             const int64_t vi = base + int64_t(k) * kBlock;
-            if (vi < last)
+            if (vi < limit)
             {
                 if (MODE == TL_INIT)
                     pq[k] = ldv<T, NT>(vin, vi);
                 else
                 {
-                    pq[k] = ldv<T, NT>(q, vi);
+                    pq[k] = ldv<T, (QPOL & 1) != 0>(q, vi);
                     pu[k] = ldv<T, NT>(u, vi);
                 }
                 if (MODE != TL_SUBDIV)  // TL_SUBDIV reduces against the column it just subtracted
@@ -326,7 +355,7 @@ __device__ __forceinline__ void twoloop_body(T* __restrict__ q, const T* __restr
         for (int k = 0; k < U; k++)
         {
             const int64_t vi = base + int64_t(k) * kBlock;
-            if (vi < last)
+            if (vi < limit)
             {
 #pragma unroll
                 for (int e = 0; e < W; e++)
@@ -340,7 +369,7 @@ __device__ __forceinline__ void twoloop_body(T* __restrict__ q, const T* __restr
                     if (MODE == TL_SUBDIV)
                         pq[k].e[e] = pq[k].e[e] / theta;  // res /= theta (:293)
                 }
-                stv<T, NT>(q, vi, pq[k]);
+                stv<T, (QPOL & 2) != 0>(q, vi, pq[k]);
 #pragma unroll
                 for (int e = 0; e < W; e++)
                     acc.add_prod(MODE == TL_SUBDIV ? pu[k].e[e] : pw[k].e[e], pq[k].e[e]);
@@ -368,7 +397,12 @@ __device__ __forceinline__ void twoloop_body(T* __restrict__ q, const T* __restr
         }
 }
 
-template <class T, int MODE, int U, bool NT>
+__device__ __forceinline__ int64_t slab_of(int64_t nv, int64_t tile, int64_t blocks)
+{
+    return ((nv + blocks - 1) / blocks + tile - 1) / tile * tile;
+}
+
+template <class T, int MODE, int U, bool NT, int QPOL>
 __global__ void __launch_bounds__(kBlock) k_twoloop(T* __restrict__ q, const T* __restrict__ vin, T a,
                                                     const T* __restrict__ u, const T* __restrict__ w, int64_t n,
                                                     T* __restrict__ sc, TwoLoopArgs args, RedWs ws)
@@ -389,7 +423,7 @@ __global__ void __launch_bounds__(kBlock) k_twoloop(T* __restrict__ q, const T* 
     int64_t first, last, stride;
     if (args.chunked)
     {
-        const int64_t slab = ((nv + gridDim.x - 1) / gridDim.x + tile - 1) / tile * tile;
+        const int64_t slab = slab_of(nv, tile, gridDim.x);
         first = int64_t(blockIdx.x) * slab;
         last = first + slab < nv ? first + slab : nv;
         stride = tile;
@@ -400,8 +434,12 @@ __global__ void __launch_bounds__(kBlock) k_twoloop(T* __restrict__ q, const T* 
         last = nv;
         stride = int64_t(gridDim.x) * tile;
     }
-    twoloop_body<T, MODE, U, NT>(q, vin, a, u, w, n, coef, theta, first, last, stride,
-                                 blockIdx.x == 0 && threadIdx.x == 0, acc[0]);
+    int64_t rev_top = -1;
+    if (args.rev)
+        rev_top = args.chunked ? (int64_t(gridDim.x) * (slab_of(nv, tile, gridDim.x) / tile) - 1) * tile
+                               : ((nv + tile - 1) / tile - 1) * tile;
+    twoloop_body<T, MODE, U, NT, QPOL>(q, vin, a, u, w, n, coef, theta, first, last, stride, nv, rev_top,
+                                      blockIdx.x == 0 && threadIdx.x == 0, acc[0]);
     if (grid_reduce<1>(acc, ws) && threadIdx.x == 0)
         sc[args.i_out] = T(acc[0].value());
 }

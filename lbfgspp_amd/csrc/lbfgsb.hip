@@ -33,6 +33,8 @@ struct lbfgsb_state
     double* gram_out = nullptr;       // [3][256]
     int gram_blocks = 1024;  // 4 resident blocks per CU (33 KB of LDS each)
     bool gram_mfma = false;  // opt-in (LBFGSX_GRAM=mfma): ~1 ulp per entry instead of the correctly rounded sums
+    int gram_mode = 0;       // 2 (LBFGSX_GRAM=blocked): force the multi-launch blocked Gram + separate W'v
+    int gram_dd_blocks = 512;
 };
 
 namespace lbfgsx {
@@ -158,7 +160,10 @@ int bounded_alloc(lbfgsx_ctx* c)
         (void) rocprim::radix_sort_pairs(nullptr, bytes, P<float>(b->keys_in), P<float>(b->keys_out), b->vals_in,
                                          b->vals_out, size_t(c->n), 0, 32, c->stream);
     if (const char* e = getenv("LBFGSX_GRAM"))
+    {
         b->gram_mfma = (std::strcmp(e, "mfma") == 0);
+        b->gram_mode = (std::strcmp(e, "blocked") == 0) ? 2 : 0;
+    }
     if (const char* e = getenv("LBFGSX_GRAM_BLOCKS"))
         b->gram_blocks = std::max(64, std::min(atoi(e), 4096));
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->gram_partial), sizeof(double) * size_t(b->gram_blocks) * 3 * 256 * 2));
@@ -604,8 +609,23 @@ int lbfgsx_b_gram(lbfgsx_ctx* c, int mask, double* gram)
     return LBFGSX_OK;
 }
 
-// Gram of [Y_P S_P v_P] in one pass on the matrix cores; gram = 2c x 2c row-major, wtv = [Y'v, S'v] raw.
-// Returns LBFGSX_E_INVALID (and leaves the outputs untouched) when the MFMA path is disabled or 2c+1 > 32.
+// Gram of [Y_P S_P v_P] in ONE pass over the history; gram = 2c x 2c row-major, wtv = [Y'v, S'v] raw.
+// Default: k_gram_dd (correctly rounded double-double sums, 2c+1 <= 31).  LBFGSX_GRAM=mfma selects the matrix-core
+// kernel (~1 ulp per entry, 2c+1 <= 32).  Returns LBFGSX_E_INVALID (outputs untouched) when neither applies; the
+// caller then falls back to lbfgsx_b_gram + lbfgsx_b_wtv.
+}  // extern "C"
+template <class T, int KP>
+static void launch_gram_dd(lbfgsx_ctx* c, int blocks, int tot, int vsel_id, int mask)
+{
+    int which[32];
+    for (int k = 0; k < tot; k++)
+        which[k] = k;
+    Cols<T, 32> cl = col_list<T, 32>(c, which, tot);
+    hipLaunchKernelGGL((k_gram_dd<T, KP>), dim3(blocks), dim3(kBlock), 0, c->stream, cl, tot, bvecs<T>(c), vsel_id, mask,
+                       c->n, c->bstate->gram_partial);
+}
+extern "C" {
+
 int lbfgsx_b_gram_fused(lbfgsx_ctx* c, int mask, int vsel_id, double* gram, double* wtv)
 {
     int rc = need_bounded(c);
@@ -613,46 +633,81 @@ int lbfgsx_b_gram_fused(lbfgsx_ctx* c, int mask, int vsel_id, double* gram, doub
         return rc;
     lbfgsb_state* b = c->bstate;
     const int tot = 2 * c->ncorr;
-    if (!b->gram_mfma || tot + 1 > 32 || tot < 1)
+    const int ntot = tot + (vsel_id >= 0 ? 1 : 0);
+    if (tot < 1 || (b->gram_mfma ? tot + 1 > 32 : ntot > kGramDDCS) || b->gram_mode == 2)
     {
-        set_error("lbfgsx_b_gram_fused: MFMA Gram not applicable");
+        set_error("lbfgsx_b_gram_fused: one-pass Gram not applicable");
         return LBFGSX_E_INVALID;
     }
-    const int64_t ntiles = (c->n + kGramRows - 1) / kGramRows;
-    const int blocks = int(std::min<int64_t>(b->gram_blocks, ntiles));
-    DISPATCH_T(c, {
-        int which[32];
-        for (int k = 0; k < tot; k++)
-            which[k] = k;
-        Cols<T, 32> cl = col_list<T, 32>(c, which, tot);
-        hipLaunchKernelGGL((k_gram_mfma<T>), dim3(blocks), dim3(kBlock), 0, c->stream, cl, tot, bvecs<T>(c), vsel_id, mask, c->n,
-                           b->gram_partial);
-    });
-    // two-level sum of the per-block partials: 32 chunks in parallel, then the final rounding
-    const int nch = std::min(blocks, 32);
-    hipLaunchKernelGGL(k_gram_finish, dim3(3, nch), dim3(kBlock), 0, c->stream, b->gram_partial, blocks, b->gram_partial2, 0);
-    hipLaunchKernelGGL(k_gram_finish, dim3(3, 1), dim3(kBlock), 0, c->stream, b->gram_partial2, nch, b->gram_out, 1);
-    LBFGSX_HIP(hipGetLastError());
     double h[3 * 256];
-    LBFGSX_HIP(hipMemcpyAsync(h, b->gram_out, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    if (b->gram_mfma)
+    {
+        const int64_t ntiles = (c->n + kGramRows - 1) / kGramRows;
+        const int blocks = int(std::min<int64_t>(b->gram_blocks, ntiles));
+        DISPATCH_T(c, {
+            int which[32];
+            for (int k = 0; k < tot; k++)
+                which[k] = k;
+            Cols<T, 32> cl = col_list<T, 32>(c, which, tot);
+            hipLaunchKernelGGL((k_gram_mfma<T>), dim3(blocks), dim3(kBlock), 0, c->stream, cl, tot, bvecs<T>(c), vsel_id, mask,
+                               c->n, b->gram_partial);
+        });
+        // two-level sum of the per-block partials: 32 chunks in parallel, then the final rounding
+        const int nch = std::min(blocks, 32);
+        hipLaunchKernelGGL(k_gram_finish, dim3(3, nch), dim3(kBlock), 0, c->stream, b->gram_partial, blocks, b->gram_partial2, 0);
+        hipLaunchKernelGGL(k_gram_finish, dim3(3, 1), dim3(kBlock), 0, c->stream, b->gram_partial2, nch, b->gram_out, 1);
+        LBFGSX_HIP(hipGetLastError());
+        LBFGSX_HIP(hipMemcpyAsync(h, b->gram_out, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        LBFGSX_HIP(hipStreamSynchronize(c->stream));
+        // entry (I, J), I >= J, of the padded 32 x 32 Gram
+        auto G = [&](int I, int J) {
+            const int tb = (I < 16) ? 0 : (J < 16 ? 1 : 2);
+            const int mrow = I & 15, ncol = J & 15;
+            const int reg = mrow >> 2, lane = ((mrow & 3) << 4) | ncol;
+            return h[tb * 256 + reg * 64 + lane];
+        };
+        for (int i = 0; i < tot; i++)
+            for (int j = 0; j <= i; j++)
+            {
+                const double v = G(i, j);
+                gram[i * tot + j] = v;
+                gram[j * tot + i] = v;
+            }
+        if (wtv && vsel_id >= 0)
+            for (int j = 0; j < tot; j++)
+                wtv[j] = G(tot, j);
+        return LBFGSX_OK;
+    }
+    const int npairs = ntot * (ntot + 1) / 2;
+    const int kp = (npairs + 63) / 64;  // pairs per lane: 1, 2, 4, 6 or 8 (ntot <= 31 -> 496 pairs)
+    const int64_t nbatch = (c->n + kGramDDRows - 1) / kGramDDRows;
+    // 2 blocks (64 KB of LDS each) are resident per CU: one persistent wave set per slot
+    const int blocks = int(std::max<int64_t>(1, std::min<int64_t>(b->gram_dd_blocks, (nbatch + 3) / 4)));
+    DISPATCH_T(c, {
+        if (kp <= 1) launch_gram_dd<T, 1>(c, blocks, tot, vsel_id, mask);
+        else if (kp <= 2) launch_gram_dd<T, 2>(c, blocks, tot, vsel_id, mask);
+        else if (kp <= 4) launch_gram_dd<T, 4>(c, blocks, tot, vsel_id, mask);
+        else if (kp <= 6) launch_gram_dd<T, 6>(c, blocks, tot, vsel_id, mask);
+        else launch_gram_dd<T, 8>(c, blocks, tot, vsel_id, mask);
+    });
+    const int kpt = kp <= 1 ? 1 : kp <= 2 ? 2 : kp <= 4 ? 4 : kp <= 6 ? 6 : 8;
+    const int ntile = (64 * kpt + 255) / 256;
+    const int nch = std::min(blocks, 32);
+    hipLaunchKernelGGL(k_gram_finish, dim3(ntile, nch), dim3(kBlock), 0, c->stream, b->gram_partial, blocks, b->gram_partial2, 0);
+    hipLaunchKernelGGL(k_gram_finish, dim3(ntile, 1), dim3(kBlock), 0, c->stream, b->gram_partial2, nch, b->gram_out, 1);
+    LBFGSX_HIP(hipGetLastError());
+    LBFGSX_HIP(hipMemcpyAsync(h, b->gram_out, sizeof(double) * size_t(ntile) * 256, hipMemcpyDeviceToHost, c->stream));
     LBFGSX_HIP(hipStreamSynchronize(c->stream));
-    // entry (I, J), I >= J, of the padded 32 x 32 Gram
-    auto G = [&](int I, int J) {
-        const int tb = (I < 16) ? 0 : (J < 16 ? 1 : 2);
-        const int mrow = I & 15, ncol = J & 15;
-        const int reg = mrow >> 2, lane = ((mrow & 3) << 4) | ncol;
-        return h[tb * 256 + reg * 64 + lane];
-    };
     for (int i = 0; i < tot; i++)
         for (int j = 0; j <= i; j++)
         {
-            const double v = G(i, j);
+            const double v = h[i * (i + 1) / 2 + j];
             gram[i * tot + j] = v;
             gram[j * tot + i] = v;
         }
     if (wtv && vsel_id >= 0)
         for (int j = 0; j < tot; j++)
-            wtv[j] = G(tot, j);
+            wtv[j] = h[tot * (tot + 1) / 2 + j];
     return LBFGSX_OK;
 }
 

@@ -409,6 +409,127 @@ __global__ void __launch_bounds__(kBlock) k_gram_mfma(Cols<T, 32> cols, int ncol
     }
 }
 
+// ---------------------------------------------------------------- masked Gram, correctly rounded, ONE pass (default K6)
+// Same matrix as k_gram_mfma, G = [Y_P S_P v_P]' [Y_P S_P v_P] with ntot = 2c (+1) <= 31 columns, but every entry
+// is a double-double sum of error-free products (TwoProd + TwoSum), i.e. the order-independent result the parity
+// contract is written against.  The columns are read exactly once (algorithmic traffic ntot * n elements); the
+// npairs = ntot (ntot + 1) / 2 products per row make the kernel VALU-bound (~10 f64 instructions per product), so
+// the work is laid out for the vector ALUs rather than for bandwidth:
+//   * each wavefront owns batches of 64 consecutive rows: lane l loads row l of every column (coalesced 512-byte
+//     column segments), rows outside the mask are dropped by a ballot/prefix compaction, the surviving rows go
+//     to a wave-private LDS tile [row][col] (odd row stride: conflict-free);
+//   * lane l then owns the KP pairs e = l*KP .. l*KP+KP-1 (e = I (I + 1) / 2 + J, I >= J) and walks the compacted
+//     rows: two LDS reads (all lanes read the same row -> distinct banks or broadcast) and one compensated
+//     accumulate per pair per row.  The work is proportional to |P|, not n.
+// No __syncthreads in the main loop (tiles are wave private); per-block partials are summed by k_gram_finish.
+constexpr int kGramDDRows = 64;
+constexpr int kGramDDCS = 31;  // tile row stride (doubles): odd, >= ntot
+
+template <class T, int KP>
+__global__ void __launch_bounds__(kBlock) k_gram_dd(Cols<T, 32> cols, int ncols, BVecs<T> b, int vsel_id, int mask,
+                                                    int64_t n, double* __restrict__ partial)
+{
+    __shared__ double tile[(kBlock / 64) * kGramDDRows * kGramDDCS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ntot = ncols + (vsel_id >= 0 ? 1 : 0);
+    const int npairs = ntot * (ntot + 1) / 2;
+    double* tl = tile + wv * (kGramDDRows * kGramDDCS);
+    int pi[KP], pj[KP];
+#pragma unroll
+    for (int k = 0; k < KP; k++)
+    {
+        int e = lane * KP + k;
+        if (e >= npairs)
+            e = 0;  // idle slot: accumulates G(0,0) again, never read back
+        int I = 0;
+        while ((I + 1) * (I + 2) / 2 <= e)
+            I++;
+        pi[k] = I;
+        pj[k] = e - I * (I + 1) / 2;
+    }
+    DD acc0[KP], acc1[KP];
+    const int64_t nbatch = (n + kGramDDRows - 1) / kGramDDRows;
+    const int64_t nwaves = int64_t(gridDim.x) * (kBlock / 64);
+    for (int64_t bt = int64_t(blockIdx.x) * (kBlock / 64) + wv; bt < nbatch; bt += nwaves)
+    {
+        const int64_t r = bt * kGramDDRows + lane;
+        const bool keep = r < n && (!mask || (b.st[r] & mask));
+        const unsigned long long bal = __ballot(keep);
+        const int cnt = __popcll(bal);
+        if (cnt == 0)
+            continue;
+        const int pos = __popcll(bal & ((1ull << lane) - 1ull));
+        if (keep)
+        {
+            double* row = tl + pos * kGramDDCS;
+            for (int c0 = 0; c0 < ncols; c0 += 8)
+            {
+                // eight independent loads in flight per lane
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    v[u] = (c0 + u < ncols) ? double(cols.p[c0 + u][r]) : 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (c0 + u < ncols)
+                        row[c0 + u] = v[u];
+            }
+            if (vsel_id >= 0)
+                row[ncols] = double(vsel(b, vsel_id, r));
+        }
+        // wave-private tile: LDS operations of one wavefront execute in order, the barrier only pins the compiler
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int rr = 0;
+        for (; rr + 1 < cnt; rr += 2)
+        {
+            const double* ra = tl + rr * kGramDDCS;
+            const double* rb = ra + kGramDDCS;
+#pragma unroll
+            for (int k = 0; k < KP; k++)
+            {
+                acc0[k].add_prod(ra[pi[k]], ra[pj[k]]);
+                acc1[k].add_prod(rb[pi[k]], rb[pj[k]]);
+            }
+        }
+        if (rr < cnt)
+        {
+            const double* ra = tl + rr * kGramDDCS;
+#pragma unroll
+            for (int k = 0; k < KP; k++)
+                acc0[k].add_prod(ra[pi[k]], ra[pj[k]]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // block reduction: the 4 waves hold partial sums of the same pairs
+    __syncthreads();
+    double* scr = tile;  // [wave][KP][64][2]
+#pragma unroll
+    for (int k = 0; k < KP; k++)
+    {
+        acc0[k].merge(acc1[k].hi, acc1[k].lo);
+        scr[((wv * KP + k) * 64 + lane) * 2 + 0] = acc0[k].hi;
+        scr[((wv * KP + k) * 64 + lane) * 2 + 1] = acc0[k].lo;
+    }
+    __syncthreads();
+    constexpr int NE = (64 * KP + 255) / 256 * 256;
+    double* part = partial + size_t(blockIdx.x) * 3 * 256 * 2;
+    for (int e = tid; e < NE; e += kBlock)
+    {
+        DD t;
+        if (e < 64 * KP)
+        {
+            const int l = e / KP, k = e % KP;
+            for (int w = 0; w < kBlock / 64; w++)
+                t.merge(scr[((w * KP + k) * 64 + l) * 2 + 0], scr[((w * KP + k) * 64 + l) * 2 + 1]);
+        }
+        part[e * 2 + 0] = t.hi;
+        part[e * 2 + 1] = t.lo;
+    }
+}
+
 // Sum per-block partial tiles.  grid = (3 tiles, nchunks): block (tb, ch) adds the partials of input blocks
 // ch, ch + nchunks, ... for its 256 entries.  final = 0: writes a double-double partial per chunk (second level
 // input); final = 1 (nchunks == 1): writes the rounded entries out[tb*256 + e], e = reg*64 + lane  <->  Gram row

@@ -199,6 +199,10 @@ int lbfgsx_create(lbfgsx_ctx** out, int dtype, int64_t n, int m, int device, int
         c->nt = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_CHUNKED"))
         c->chunked = atoi(e) != 0;
+    if (const char* e = getenv("LBFGSX_Q_POLICY"))
+        c->q_policy = atoi(e) & 3;
+    if (const char* e = getenv("LBFGSX_ZIGZAG"))
+        c->zigzag = atoi(e) != 0;
     LBFGSX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->own_stream = true;
     const size_t vbytes = size_t(c->ld) * c->esz;
@@ -502,31 +506,30 @@ static int apply_Hv_t(lbfgsx_ctx* c, const T* v, T a, double* dg)
     }
     auto launch = [&](int mode, const T* u, const T* w, TwoLoopArgs args) -> int {
         EventPair ev;
+        args.rev = (c->zigzag && (c->tl_step++ & 1u)) ? 1 : 0;
         if (c->timing)
         {
             LBFGSX_HIP(hipEventCreate(&ev.a));
             LBFGSX_HIP(hipEventCreate(&ev.b));
             LBFGSX_HIP(hipEventRecord(ev.a, c->stream));
         }
-#define TL_LAUNCH(MODE, U, NT) \
-    hipLaunchKernelGGL((k_twoloop<T, MODE, U, NT>), dim3(grid), dim3(kBlock), 0, c->stream, q, v, a, u, w, c->n, sc, args, c->ws)
-#define TL_VARIANT(MODE)                                         \
-    do                                                           \
-    {                                                            \
-        if (c->nt)                                               \
-        {                                                        \
-            if (c->unroll == 1) TL_LAUNCH(MODE, 1, true);        \
-            else if (c->unroll == 2) TL_LAUNCH(MODE, 2, true);   \
-            else if (c->unroll == 8) TL_LAUNCH(MODE, 8, true);   \
-            else TL_LAUNCH(MODE, 4, true);                       \
-        }                                                        \
-        else                                                     \
-        {                                                        \
-            if (c->unroll == 1) TL_LAUNCH(MODE, 1, false);       \
-            else if (c->unroll == 2) TL_LAUNCH(MODE, 2, false);  \
-            else if (c->unroll == 8) TL_LAUNCH(MODE, 8, false);  \
-            else TL_LAUNCH(MODE, 4, false);                      \
-        }                                                        \
+#define TL_LAUNCH(MODE, U, NT, QPOL)                                                                                  \
+    hipLaunchKernelGGL((k_twoloop<T, MODE, U, NT, QPOL>), dim3(grid), dim3(kBlock), 0, c->stream, q, v, a, u, w, c->n, \
+                       sc, args, c->ws)
+#define TL_POLICY(MODE, U)                                        \
+    do                                                            \
+    {                                                             \
+        if (!c->nt) TL_LAUNCH(MODE, U, false, 0);                 \
+        else if (c->q_policy == 3) TL_LAUNCH(MODE, U, true, 3);   \
+        else if (c->q_policy == 2) TL_LAUNCH(MODE, U, true, 2);   \
+        else if (c->q_policy == 1) TL_LAUNCH(MODE, U, true, 1);   \
+        else TL_LAUNCH(MODE, U, true, 0);                         \
+    } while (0)
+#define TL_VARIANT(MODE)                          \
+    do                                            \
+    {                                             \
+        if (c->unroll == 8) TL_POLICY(MODE, 8);   \
+        else TL_POLICY(MODE, 4);                  \
     } while (0)
         switch (mode)
         {
@@ -536,6 +539,7 @@ static int apply_Hv_t(lbfgsx_ctx* c, const T* v, T a, double* dg)
         default: TL_VARIANT(TL_ADD); break;
         }
 #undef TL_VARIANT
+#undef TL_POLICY
 #undef TL_LAUNCH
         if (c->timing)
         {
@@ -547,7 +551,7 @@ static int apply_Hv_t(lbfgsx_ctx* c, const T* v, T a, double* dg)
     auto Scol = [&](int i) { return static_cast<const T*>(c->col(c->S, pcol[i])); };
     auto Ycol = [&](int i) { return static_cast<const T*>(c->col(c->Y, pcol[i])); };
     int rc;
-    TwoLoopArgs args = {c->chunked ? 1 : 0, 0, 0, 0, 0, 0};
+    TwoLoopArgs args = {c->chunked ? 1 : 0, 0, 0, 0, 0, 0, 0};
     if (cn == 0)
     {
         // res = a*v; res /= theta with theta == 1 is the identity (BFGSMat.h:283,293)
@@ -683,7 +687,8 @@ static int trial_t(lbfgsx_ctx* c, OBJ obj, T step, double* out2)
 {
     const int grid = c->grid_for(c->n);
     hipLaunchKernelGGL((k_trial<T, OBJ>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->xp]), P<T>(c->d), step,
-                       P<T>(c->xb[c->trial]), P<T>(c->gb[c->trial]), c->n, obj, c->ws, P<T>(c->sc) + c->sl.out(0));
+                       P<T>(c->xb[c->trial]), P<T>(c->gb[c->trial]), c->n, obj, c->ws, P<T>(c->sc) + c->sl.out(0),
+                       (c->zigzag && (c->tl_step++ & 1u)) ? 1 : 0);
     LBFGSX_HIP(hipGetLastError());
     return fetch_scalars<T>(c, c->sl.out(0), 2, out2);
 }
@@ -757,7 +762,8 @@ int lbfgsx_post_linesearch(lbfgsx_ctx* c, double* gnorm2, double* xnorm2, double
         hipLaunchKernelGGL((k_post<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]), P<T>(c->xb[c->xp]),
                            P<T>(c->gb[c->cur]), P<T>(c->gb[c->xp]), P<T>(c->col(c->S, c->spare)),
                            P<T>(c->col(c->Y, c->spare)), c->n, c->ws, P<T>(c->sc) + c->sl.out(0),
-                           P<T>(c->sc) + c->sl.ys(c->spare), P<T>(c->sc) + c->sl.theta(c->spare));
+                           P<T>(c->sc) + c->sl.ys(c->spare), P<T>(c->sc) + c->sl.theta(c->spare),
+                           (c->zigzag && (c->tl_step++ & 1u)) ? 1 : 0);
         LBFGSX_HIP(hipGetLastError());
         int rc = fetch_scalars<T>(c, c->sl.out(0), 4, r);
         if (rc)
