@@ -3,10 +3,13 @@
 // Reference: /root/reference/include/LBFGSpp/Cauchy.h:86-284.  Split used here:
 //   device  (lbfgsx_b_cauchy_build)  break points, vecd, xcp = x0, d.d, W'd, radix sort of the finite positive
 //                                    break points (replaces the host loop :111-129 and std::sort :132-133)
-//   host    (this file)              the piecewise-quadratic search over the *crossed* break points (:183-256):
-//                                    a strictly sequential O(#crossed * m^2) scalar recurrence, fed by chunks of
-//                                    the sorted list gathered on the device (brk, g, z, W row) -- typically a few
-//                                    hundred crossings per call after the first iterations
+//   host    (this file)              the piecewise-quadratic search over the *crossed* break points (:183-256)
+//                                    in the reference's sequential form, fed by chunks of the sorted list gathered
+//                                    on the device (brk, g, z, W row) -- typically a few hundred crossings per
+//                                    call after the first iterations
+//   device  (lbfgsx_b_cauchy_scan)   the same search as prefix sums (csrc/gcp_scan.cuh) once more than
+//                                    device_switch() break points have been crossed (f64, 2c <= 32): the early
+//                                    iterations of a large problem cross 10^5..10^6 of them
 //   device  (lbfgsx_b_cauchy_finish) xcp on crossed / free coordinates and the free / newly-active state byte
 //                                    from the crossing threshold (:201-206,219-233,265-282)
 // Scalars keep the reference's evaluation order; short dot products use the order-independent host accumulator.
@@ -16,6 +19,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdint>
+#include <cstdlib>
 #include <limits>
 #include <vector>
 
@@ -62,6 +66,19 @@ class Cauchy
         const double* w(std::int64_t k) { if (k >= m_have) need(k); return m_w.data() + size_t(k) * size_t(2 * m_nc); }
     };
 
+    // Crossings handled in the reference's sequential form before the search moves to the device
+    // (LBFGSX_GCP_DEVICE_MIN; negative: never).  f' is a long cancelling sum (it starts at -d'd and ends near the
+    // root), so its low bits depend on the summation order: a tree-order sum agrees with the left-to-right one to
+    // ~1e-13 relative on the step, which an L-BFGS-B trajectory then amplifies (measured 1.6e-10 after 20 iterations
+    // at n = 6000).  The sequential form therefore stays in charge of every search the 1e-10 parity contract is
+    // checked on; the device takes over only past 65536 crossings, where the sequential order's own rounding noise
+    // (~N eps) is already of that size and the host loop would cost milliseconds per search.
+    static std::int64_t device_switch()
+    {
+        const char* e = std::getenv("LBFGSX_GCP_DEVICE_MIN");
+        return e ? std::atoll(e) : std::int64_t(65536);
+    }
+
 public:
     struct Result
     {
@@ -69,6 +86,7 @@ public:
         std::int64_t nact = 0;         // |newact_set|
         std::int64_t nfree = 0;        // |fv_set|
         std::int64_t crossings = 0;    // break points crossed (instrumentation)
+        std::int64_t dev_crossings = 0;  // ... of which by the device search
         double t_build = 0, t_fetch = 0, t_total = 0;  // seconds (instrumentation)
     };
 
@@ -80,7 +98,7 @@ public:
         const Scalar theta = bfgs.theta();
         const Scalar inf = std::numeric_limits<Scalar>::infinity();
         out.vecc.assign(size_t(2 * ncorr), Scalar(0));
-        out.nact = out.nfree = out.crossings = 0;
+        out.nact = out.nfree = out.crossings = out.dev_crossings = 0;
 
         std::int64_t nfree = 0, nord = 0;
         double dd = 0;
@@ -115,8 +133,71 @@ public:
         bool crossed_all = false;
         Scalar t_cross = Scalar(0);
 
+        const std::int64_t dev_min = device_switch();
+        bool dev_ok = sizeof(Scalar) == sizeof(double) && 2 * ncorr <= 32 && dev_min >= 0;
+
         while (deltatmin >= deltat)
         {
+            if (dev_ok && b >= dev_min)
+            {
+                // hand the rest of the search to the device: state = (p, c, f', f''), the group starting at b is
+                // known to be crossed.  Explicit M = apply_Mv on the unit vectors.
+                const int t = 2 * ncorr;
+                std::vector<double> Mmat(size_t(t) * size_t(t) + 1, 0.0), st_in(size_t(2 * t + 2)), st_out(size_t(2 * t + 3));
+                std::vector<Scalar> unit(size_t(t), Scalar(0));
+                for (int j = 0; j < t; j++)
+                {
+                    unit[size_t(j)] = Scalar(1);
+                    bfgs.apply_Mv(unit, cache);
+                    unit[size_t(j)] = Scalar(0);
+                    for (int i = 0; i < t; i++)
+                        Mmat[size_t(j) * size_t(t) + size_t(i)] = double(cache[size_t(i)]);
+                }
+                for (int j = 0; j < t; j++)
+                {
+                    st_in[size_t(j)] = double(vecp[size_t(j)]);
+                    st_in[size_t(t + j)] = double(out.vecc[size_t(j)]);
+                }
+                st_in[size_t(2 * t)] = double(fp);
+                st_in[size_t(2 * t + 1)] = double(fpp);
+                std::int64_t chunk = std::int64_t(1) << 16;
+                bool finished = false;
+                while (!finished)
+                {
+                    const std::int64_t cnt = std::min<std::int64_t>(chunk, nord - b);
+                    std::int64_t ex = -1;
+                    const int rc = lbfgsx_b_cauchy_scan(c, b, cnt, nord, Mmat.data(), double(theta), double(il),
+                                                        st_in.data(), &ex, st_out.data());
+                    if (rc == LBFGSX_E_INVALID && out.dev_crossings == 0)
+                    {
+                        dev_ok = false;  // not applicable: stay with the host form
+                        break;
+                    }
+                    detail::check(rc);
+                    const std::int64_t done = (ex >= 0) ? ex - b + 1 : cnt;
+                    out.crossings += done;
+                    out.dev_crossings += done;
+                    il = Scalar(st_out[size_t(2 * t + 2)]);
+                    t_cross = il;
+                    b += done;
+                    std::copy(st_out.begin(), st_out.begin() + (2 * t + 2), st_in.begin());
+                    finished = (ex >= 0) || b >= nord;
+                    chunk = std::min<std::int64_t>(chunk * 4, std::int64_t(1) << 20);
+                }
+                if (!dev_ok)
+                    continue;
+                for (int j = 0; j < t; j++)
+                {
+                    vecp[size_t(j)] = Scalar(st_in[size_t(j)]);
+                    out.vecc[size_t(j)] = Scalar(st_in[size_t(t + j)]);
+                }
+                fp = Scalar(st_in[size_t(2 * t)]);
+                fpp = Scalar(st_in[size_t(2 * t + 1)]);
+                deltatmin = -fp / fpp;                                 // (:240)
+                if (nfree == 0 && b >= nord)                           // everything crossed (:198-213)
+                    crossed_all = true;
+                break;
+            }
             for (int j = 0; j < 2 * ncorr; j++)                       // vecc += deltat * vecp (:186)
                 out.vecc[size_t(j)] = out.vecc[size_t(j)] + deltat * vecp[size_t(j)];
             // tie group [b, e] of break points equal to iu (:193-194)

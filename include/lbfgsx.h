@@ -169,6 +169,15 @@ int lbfgsx_b_cauchy_build(lbfgsx_ctx* c, int64_t* nfree, int64_t* nord, double* 
  * for the sequential piecewise-quadratic scan kept on the host (Cauchy.h:183-256) */
 int lbfgsx_b_cauchy_chunk(lbfgsx_ctx* c, int64_t first, int64_t count, double* brk, double* g, double* z, int* idx,
                           double* wrows);
+/* Device form of the break-point search (reference Cauchy.h:183-256) over sorted positions [first, first+count) of
+ * the list produced by lbfgsx_b_cauchy_build: three dependent prefix sums (p; c and f''; f') and a min-index exit
+ * test, see lbfgspp_amd/csrc/gcp_scan.cuh.  Mmat: explicit 2c x 2c matrix of apply_Mv (BFGSMat.h:361-376), column
+ * major; state_in = [p (2c), c (2c), f', f'']; t_prev = break point of the last crossing already processed (0 at
+ * the start).  On return *exit_at = sorted index of the group end at which the search stops (-1: not inside this
+ * range) and state_out = [p, c, f', f'', brk] after that crossing (after the last crossing of the range when -1).
+ * f64 problems with 2c <= 32 only (LBFGSX_E_INVALID otherwise: the caller keeps the host form). */
+int lbfgsx_b_cauchy_scan(lbfgsx_ctx* ctx, int64_t first, int64_t count, int64_t nord, const double* Mmat, double theta,
+                         double t_prev, const double* state_in, int64_t* exit_at, double* state_out);
 /* xcp and the free / newly-active sets from the crossing threshold (Cauchy.h:201-206,219-233,265-282) */
 int lbfgsx_b_cauchy_finish(lbfgsx_ctx* c, double t_cross, double tfinal, int crossed_all, int64_t* nact, int64_t* nfree);
 /* drt = xcp - x0 (SubspaceMin.h:130) */

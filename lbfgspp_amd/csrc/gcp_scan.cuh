@@ -1,0 +1,374 @@
+// lbfgspp_amd/csrc/gcp_scan.cuh -- K7b: the generalized-Cauchy-point search over the sorted break points as
+// prefix sums on the device (f64 problems).
+//
+// Reference loop: /root/reference/include/LBFGSpp/Cauchy.h:183-256.  Per crossed break point k (sorted order), with
+// w_k = W row of the coordinate (tail scaled by theta, BFGSMat.h:333), g_k, z_k and dt_k = brk_k - brk_{k-1}
+// (0 inside a group of ties, so the statements the reference executes once per group are exact no-ops for the
+// non-leading members):
+//     c_k   = c_{k-1}   + dt_k p_{k-1}                                                      (:186)
+//     f'_k  = f'_{k-1}  + dt_k f''_{k-1} + g_k^2 + theta g_k z_k - g_k (M w_k).c_k           (:218,227)
+//     f''_k = f''_{k-1} - (theta g_k^2 + 2 g_k (M w_k).p_{k-1} + g_k^2 w_k.(M w_k))          (:228)
+//     p_k   = p_{k-1}   + g_k w_k                                                           (:230)
+// and the search stops at the first group end k with  !(-f'_k / f''_k >= brk_{k+1} - brk_k)  (:183,240-256).
+// The recurrences are three dependent prefix sums:  A: p  ->  B: c and f''  ->  C: f'.  Each is a deterministic
+// reduce-then-scan over tiles of 256 crossings (fixed association order: the result does not depend on timing):
+//     k_gcp_a1          tile totals of g w
+//     k_gcp_tiles       exclusive scan of the tile totals (one block)
+//     k_gcp_a3b1        p_{k-1} (stored), tile totals of [dt p_{k-1}, f'' increments]
+//     k_gcp_tiles
+//     k_gcp_b3c1        c_k and f''_k (stored), f' increments (stored), their tile totals
+//     k_gcp_tiles
+//     k_gcp_c3          f'_k (stored), first group end that fails the continuation test (atomic min)
+//     k_gcp_extract     state (p, c, f', f'') after the exit group (or after the last crossing of the chunk)
+// M w_k uses the explicit 2c x 2c matrix M (apply_Mv applied to the unit vectors on the host).  The sums are plain
+// f64 in tree order, i.e. not the reference's left-to-right order: agreement with the sequential search is to
+// rounding (the host keeps the sequential form for short searches and for f32 problems, see Cauchy.h).
+#ifndef LBFGSX_GCP_SCAN_CUH
+#define LBFGSX_GCP_SCAN_CUH
+
+#include "lbfgsb_kernels.cuh"
+
+namespace lbfgsx {
+
+constexpr int kGcpTile = 256;
+
+struct GcpBufs
+{
+    const double* brk;  // [cap + 1] sorted break points of the chunk (+ the next one, when it exists)
+    const double* g;    // [cap]
+    const double* z;    // [cap]
+    const double* W;    // [NC][cap] component-major W rows, un-scaled: y part then s part
+    double* P;          // [NC][cap]  p_{k-1}
+    double* C;          // [NC][cap]  c_k
+    double* fpp;        // [cap] f''_k
+    double* dfp;        // [cap] f' increments
+    double* fp;         // [cap] f'_k
+    int64_t cap;
+};
+
+// inclusive (v) and exclusive (ex) prefix of v over the 256 threads of the block, and the block total.
+// lds: NCOMP * 4 doubles.  Fixed order: in-wave Hillis-Steele, then the wave totals left to right.
+template <int NCOMP>
+__device__ __forceinline__ void block_scan(double (&v)[NCOMP], double (&ex)[NCOMP], double (&total)[NCOMP], double* lds)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < NCOMP; j++)
+    {
+        double x = v[j];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1)
+        {
+            const double y = __shfl_up(x, off, 64);
+            if (lane >= off)
+                x = x + y;
+        }
+        const double xe = __shfl_up(x, 1, 64);
+        v[j] = x;
+        ex[j] = lane ? xe : 0.0;
+        if (lane == 63)
+            lds[j * 4 + wv] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NCOMP; j++)
+    {
+        double add = 0.0, run = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; w++)
+        {
+            if (w == wv)
+                add = run;
+            run = run + lds[j * 4 + w];
+        }
+        v[j] = add + v[j];
+        ex[j] = add + ex[j];
+        total[j] = run;
+    }
+    __syncthreads();
+}
+
+// w_k (scaled), g_k for crossing k of the chunk; zeros outside the chunk
+template <int NC>
+__device__ __forceinline__ void gcp_load_w(const GcpBufs& b, int64_t k, int64_t count, int ncorr, double theta,
+                                           double (&w)[NC], double& g)
+{
+    const bool ok = k < count;
+    g = ok ? b.g[k] : 0.0;
+#pragma unroll
+    for (int j = 0; j < NC; j++)
+    {
+        double x = (ok && j < 2 * ncorr) ? b.W[int64_t(j) * b.cap + k] : 0.0;
+        if (j >= ncorr)
+            x = x * theta;  // Wb(): tail *= theta (BFGSMat.h:333)
+        w[j] = x;
+    }
+}
+
+template <int NC>
+__global__ void __launch_bounds__(kGcpTile) k_gcp_a1(GcpBufs b, int64_t count, int ncorr, double theta,
+                                                     double* __restrict__ ts)
+{
+    __shared__ double lds[NC * 4];
+    const int64_t k = int64_t(blockIdx.x) * kGcpTile + threadIdx.x;
+    double w[NC], ex[NC], tot[NC], g;
+    gcp_load_w<NC>(b, k, count, ncorr, theta, w, g);
+#pragma unroll
+    for (int j = 0; j < NC; j++)
+        w[j] = g * w[j];
+    block_scan<NC>(w, ex, tot, lds);
+    if (threadIdx.x < NC)
+    {
+        double t = 0.0;
+#pragma unroll
+        for (int j = 0; j < NC; j++)
+            if (j == threadIdx.x)
+                t = tot[j];
+        ts[int64_t(blockIdx.x) * NC + threadIdx.x] = t;
+    }
+}
+
+// off[t][j] = init[j] + sum_{t' < t} ts[t'][j]  (left to right);  fin[j] = the grand total including init
+__global__ void k_gcp_tiles(const double* __restrict__ ts, double* __restrict__ off, int ntiles, int ncomp,
+                            const double* __restrict__ init, double* __restrict__ fin)
+{
+    const int j = threadIdx.x;
+    if (j >= ncomp)
+        return;
+    double run = init[j];
+    constexpr int B = 16;  // independent loads in flight; the additions stay strictly left to right
+    for (int t0 = 0; t0 < ntiles; t0 += B)
+    {
+        double v[B];
+#pragma unroll
+        for (int u = 0; u < B; u++)
+            v[u] = (t0 + u < ntiles) ? ts[int64_t(t0 + u) * ncomp + j] : 0.0;
+#pragma unroll
+        for (int u = 0; u < B; u++)
+            if (t0 + u < ntiles)
+            {
+                off[int64_t(t0 + u) * ncomp + j] = run;
+                run = run + v[u];
+            }
+    }
+    fin[j] = run;
+}
+
+// the f'' increment and dt p_{k-1} of one crossing (shared by a3b1 and b3c1 so that both evaluate the same
+// IEEE operations in the same order)
+template <int NC>
+__device__ __forceinline__ void gcp_stage_b(const double (&w)[NC], const double (&pprev)[NC], double g, double dt,
+                                            double theta, const double* __restrict__ M, double (&inc)[NC + 1])
+{
+    double d_p = 0.0, d_w = 0.0;
+#pragma unroll
+    for (int i = 0; i < NC; i++)
+    {
+        double u = 0.0;  // (M w)_i
+#pragma unroll
+        for (int j = 0; j < NC; j++)
+            u = u + M[i * NC + j] * w[j];
+        d_p = d_p + u * pprev[i];
+        d_w = d_w + u * w[i];
+    }
+    const double gg = g * g;
+#pragma unroll
+    for (int j = 0; j < NC; j++)
+        inc[j] = dt * pprev[j];
+    inc[NC] = -(theta * gg + 2 * g * d_p + gg * d_w);
+}
+
+__device__ __forceinline__ double gcp_dt(const GcpBufs& b, int64_t k, int64_t count, double t_prev)
+{
+    if (k >= count)
+        return 0.0;
+    return b.brk[k] - (k ? b.brk[k - 1] : t_prev);
+}
+
+template <int NC>
+__global__ void __launch_bounds__(kGcpTile) k_gcp_a3b1(GcpBufs b, int64_t count, int ncorr, double theta, double t_prev,
+                                                       const double* __restrict__ Mg, const double* __restrict__ offA,
+                                                       double* __restrict__ tsB)
+{
+    __shared__ double lds[(NC + 1) * 4];
+    __shared__ double M[NC * NC];
+    for (int i = threadIdx.x; i < NC * NC; i += kGcpTile)
+        M[i] = Mg[i];
+    const int64_t k = int64_t(blockIdx.x) * kGcpTile + threadIdx.x;
+    double w[NC], gw[NC], pprev[NC], tot[NC], g;
+    gcp_load_w<NC>(b, k, count, ncorr, theta, w, g);
+#pragma unroll
+    for (int j = 0; j < NC; j++)
+        gw[j] = g * w[j];
+    block_scan<NC>(gw, pprev, tot, lds);  // also orders the M staging before its use
+#pragma unroll
+    for (int j = 0; j < NC; j++)
+    {
+        pprev[j] = offA[int64_t(blockIdx.x) * NC + j] + pprev[j];
+        if (k < count)
+            b.P[int64_t(j) * b.cap + k] = pprev[j];
+    }
+    double inc[NC + 1], ex[NC + 1], tb[NC + 1];
+    gcp_stage_b<NC>(w, pprev, g, gcp_dt(b, k, count, t_prev), theta, M, inc);
+    if (k >= count)
+    {
+#pragma unroll
+        for (int j = 0; j <= NC; j++)
+            inc[j] = 0.0;
+    }
+    block_scan<NC + 1>(inc, ex, tb, lds);
+    if (threadIdx.x <= NC)
+    {
+        double t = 0.0;
+#pragma unroll
+        for (int j = 0; j <= NC; j++)
+            if (j == threadIdx.x)
+                t = tb[j];
+        tsB[int64_t(blockIdx.x) * (NC + 1) + threadIdx.x] = t;
+    }
+}
+
+template <int NC>
+__global__ void __launch_bounds__(kGcpTile) k_gcp_b3c1(GcpBufs b, int64_t count, int ncorr, double theta, double t_prev,
+                                                       const double* __restrict__ Mg, const double* __restrict__ offB,
+                                                       double* __restrict__ tsC)
+{
+    __shared__ double lds[(NC + 1) * 4];
+    __shared__ double M[NC * NC];
+    for (int i = threadIdx.x; i < NC * NC; i += kGcpTile)
+        M[i] = Mg[i];
+    __syncthreads();
+    const int64_t k = int64_t(blockIdx.x) * kGcpTile + threadIdx.x;
+    double w[NC], pprev[NC], g;
+    gcp_load_w<NC>(b, k, count, ncorr, theta, w, g);
+#pragma unroll
+    for (int j = 0; j < NC; j++)
+        pprev[j] = (k < count) ? b.P[int64_t(j) * b.cap + k] : 0.0;
+    const double dt = gcp_dt(b, k, count, t_prev);
+    double inc[NC + 1], ex[NC + 1], tb[NC + 1];
+    gcp_stage_b<NC>(w, pprev, g, dt, theta, M, inc);
+    if (k >= count)
+    {
+#pragma unroll
+        for (int j = 0; j <= NC; j++)
+            inc[j] = 0.0;
+    }
+    block_scan<NC + 1>(inc, ex, tb, lds);
+    // c_k (inclusive), f''_k (inclusive), f''_{k-1} (exclusive)
+    double d_c = 0.0;
+#pragma unroll
+    for (int i = 0; i < NC; i++)
+    {
+        const double ck = offB[int64_t(blockIdx.x) * (NC + 1) + i] + inc[i];
+        inc[i] = ck;
+        if (k < count)
+            b.C[int64_t(i) * b.cap + k] = ck;
+    }
+#pragma unroll
+    for (int i = 0; i < NC; i++)
+    {
+        double u = 0.0;
+#pragma unroll
+        for (int j = 0; j < NC; j++)
+            u = u + M[i * NC + j] * w[j];
+        d_c = d_c + u * inc[i];
+    }
+    const double fpp_k = offB[int64_t(blockIdx.x) * (NC + 1) + NC] + inc[NC];
+    const double fpp_prev = offB[int64_t(blockIdx.x) * (NC + 1) + NC] + ex[NC];
+    double dfp[1], e1[1], t1[1];
+    dfp[0] = 0.0;
+    if (k < count)
+    {
+        b.fpp[k] = fpp_k;
+        // fp += deltat * fpp (:218);  fp += ggact + theta*gact*zact - gact * (Mw).c (:227)
+        dfp[0] = dt * fpp_prev + (g * g + theta * g * b.z[k] - g * d_c);
+        b.dfp[k] = dfp[0];
+    }
+    block_scan<1>(dfp, e1, t1, lds);
+    if (threadIdx.x == 0)
+        tsC[blockIdx.x] = t1[0];
+}
+
+// f'_k and the exit test.  first: global sorted index of the chunk's crossing 0; nord: length of the sorted list.
+__global__ void __launch_bounds__(kGcpTile) k_gcp_c3(GcpBufs b, int64_t count, int64_t first, int64_t nord,
+                                                     const double* __restrict__ offC, unsigned long long* __restrict__ exit_at)
+{
+    __shared__ double lds[4];
+    const int64_t k = int64_t(blockIdx.x) * kGcpTile + threadIdx.x;
+    double v[1], ex[1], tot[1];
+    v[0] = (k < count) ? b.dfp[k] : 0.0;
+    block_scan<1>(v, ex, tot, lds);
+    if (k >= count)
+        return;
+    const double fp = offC[blockIdx.x] + v[0];
+    b.fp[k] = fp;
+    const int64_t gk = first + k;
+    if (gk + 1 >= nord)
+        return;  // end of the list: the caller handles it (Cauchy.h:247-248)
+    const double dnext = b.brk[k + 1] - b.brk[k];
+    if (!(dnext > 0.0))
+        return;  // inside a group of ties
+    const double dtmin = -fp / b.fpp[k];
+    if (!(dtmin >= dnext))
+        atomicMin(exit_at, (unsigned long long) k);
+}
+
+// out = [p (NC), c (NC), f', f'', brk] after crossing e = exit (or count-1), out[2 NC + 3] = exit index in the
+// chunk or -1
+template <int NC>
+__global__ void k_gcp_extract(GcpBufs b, int64_t count, int ncorr, double theta,
+                              const unsigned long long* __restrict__ exit_at, double* __restrict__ out)
+{
+    const unsigned long long ex = *exit_at;
+    const bool found = ex < (unsigned long long) count;
+    const int64_t e = found ? int64_t(ex) : count - 1;
+    const int j = threadIdx.x;
+    if (j < NC)
+    {
+        double w = (j < 2 * ncorr) ? b.W[int64_t(j) * b.cap + e] : 0.0;
+        if (j >= ncorr)
+            w = w * theta;
+        out[j] = b.P[int64_t(j) * b.cap + e] + b.g[e] * w;
+        out[NC + j] = b.C[int64_t(j) * b.cap + e];
+    }
+    if (j == 0)
+    {
+        out[2 * NC] = b.fp[e];
+        out[2 * NC + 1] = b.fpp[e];
+        out[2 * NC + 2] = b.brk[e];
+        out[2 * NC + 3] = found ? double(e) : -1.0;
+    }
+}
+
+// gather for the device search: component-major W rows, brk (+1 look-ahead), g, z
+template <class T>
+__global__ void k_gcp_gather(BVecs<T> b, const T* __restrict__ keys, const int* __restrict__ vals, int64_t first,
+                             int64_t count, int64_t nord, const T* __restrict__ S, const T* __restrict__ Y, int64_t ld,
+                             const int* __restrict__ phys, int ncorr, double* __restrict__ o_brk, double* __restrict__ o_g,
+                             double* __restrict__ o_z, double* __restrict__ o_w, int64_t cap)
+{
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t k = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; k <= count; k += stride)
+    {
+        if (k == count)
+        {
+            if (first + k < nord)
+                o_brk[k] = double(keys[first + k]);
+            continue;
+        }
+        const int idx = vals[first + k];
+        o_brk[k] = double(keys[first + k]);
+        o_g[k] = double(b.g[idx]);
+        const T bound = (b.dvec[idx] > T(0)) ? b.ub[idx] : b.lb[idx];
+        o_z[k] = double(bound - b.x0[idx]);
+        for (int j = 0; j < ncorr; j++)
+        {
+            o_w[int64_t(j) * cap + k] = double(Y[int64_t(phys[j]) * ld + idx]);
+            o_w[int64_t(ncorr + j) * cap + k] = double(S[int64_t(phys[j]) * ld + idx]);
+        }
+    }
+}
+
+}  // namespace lbfgsx
+
+#endif

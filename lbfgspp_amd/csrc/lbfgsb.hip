@@ -9,6 +9,7 @@
 #include "ctx.hpp"
 #include "lbfgs_kernels.cuh"
 #include "lbfgsb_kernels.cuh"
+#include "gcp_scan.cuh"
 
 struct lbfgsb_state
 {
@@ -35,6 +36,12 @@ struct lbfgsb_state
     bool gram_mfma = false;  // opt-in (LBFGSX_GRAM=mfma): ~1 ulp per entry instead of the correctly rounded sums
     int gram_mode = 0;       // 2 (LBFGSX_GRAM=blocked): force the multi-launch blocked Gram + separate W'v
     int gram_dd_blocks = 512;
+    // device GCP search (gcp_scan.cuh): per-chunk work set, allocated on first use
+    double *s_brk = nullptr, *s_g = nullptr, *s_z = nullptr, *s_W = nullptr, *s_P = nullptr, *s_C = nullptr,
+           *s_fpp = nullptr, *s_dfp = nullptr, *s_fp = nullptr, *s_ts = nullptr, *s_off = nullptr, *s_small = nullptr;
+    unsigned long long* s_exit = nullptr;
+    int64_t s_cap = 0;
+    int s_nc = 0;
 };
 
 namespace lbfgsx {
@@ -181,7 +188,9 @@ void bounded_free(lbfgsx_ctx* c)
         return;
     void* ptrs[] = {b->brk, b->dvec, b->cF, b->y, b->yfb, b->lam, b->mu, b->rhs, b->keys_in, b->keys_out, b->st,
                     b->vals_in, b->vals_out, b->phys_dev, b->dout, b->coef_dev, b->mslot, b->sort_tmp, b->g_brk,
-                    b->g_g, b->g_z, b->g_w, b->g_idx, b->gram_partial, b->gram_partial2, b->gram_out};
+                    b->g_g, b->g_z, b->g_w, b->g_idx, b->gram_partial, b->gram_partial2, b->gram_out,
+                    b->s_brk, b->s_g, b->s_z, b->s_W, b->s_P, b->s_C, b->s_fpp, b->s_dfp, b->s_fp, b->s_ts, b->s_off,
+                    b->s_small, b->s_exit};
     for (void* p : ptrs)
         (void) hipFree(p);
     delete b;
@@ -524,6 +533,133 @@ int lbfgsx_b_cauchy_chunk(lbfgsx_ctx* c, int64_t first, int64_t count, double* b
     if (nc > 0 && wrows)
         LBFGSX_HIP(hipMemcpyAsync(wrows, b->g_w, sizeof(double) * size_t(count) * size_t(2 * nc), hipMemcpyDeviceToHost, c->stream));
     LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    return LBFGSX_OK;
+}
+
+// ---- device GCP search over sorted positions [first, first + count) (gcp_scan.cuh) ----------------------------
+}  // extern "C"
+template <int NC>
+static int gcp_scan_nc(lbfgsx_ctx* c, const GcpBufs& gb, int64_t first, int64_t count, int64_t nord, double theta,
+                       double t_prev)
+{
+    lbfgsb_state* b = c->bstate;
+    const int nc = c->ncorr;
+    const int ntiles = int((count + kGcpTile - 1) / kGcpTile);
+    // s_small: [0, NC*NC) M | init A (NC) | init B (NC+1) | init C (1) | fin (NC+1) | out (2NC+4)
+    double* M = b->s_small;
+    double* initA = M + NC * NC;
+    double* initB = initA + NC;
+    double* initC = initB + NC + 1;
+    double* fin = initC + 1;
+    double* out = fin + NC + 1;
+    hipStream_t st = c->stream;
+    hipLaunchKernelGGL((k_gcp_a1<NC>), dim3(ntiles), dim3(kGcpTile), 0, st, gb, count, nc, theta, b->s_ts);
+    hipLaunchKernelGGL(k_gcp_tiles, dim3(1), dim3(64), 0, st, b->s_ts, b->s_off, ntiles, NC, initA, fin);
+    hipLaunchKernelGGL((k_gcp_a3b1<NC>), dim3(ntiles), dim3(kGcpTile), 0, st, gb, count, nc, theta, t_prev, M, b->s_off, b->s_ts);
+    hipLaunchKernelGGL(k_gcp_tiles, dim3(1), dim3(64), 0, st, b->s_ts, b->s_off, ntiles, NC + 1, initB, fin);
+    hipLaunchKernelGGL((k_gcp_b3c1<NC>), dim3(ntiles), dim3(kGcpTile), 0, st, gb, count, nc, theta, t_prev, M, b->s_off, b->s_ts);
+    hipLaunchKernelGGL(k_gcp_tiles, dim3(1), dim3(64), 0, st, b->s_ts, b->s_off, ntiles, 1, initC, fin);
+    hipLaunchKernelGGL(k_gcp_c3, dim3(ntiles), dim3(kGcpTile), 0, st, gb, count, first, nord, b->s_off, b->s_exit);
+    hipLaunchKernelGGL((k_gcp_extract<NC>), dim3(1), dim3(64), 0, st, gb, count, nc, theta, b->s_exit, out);
+    LBFGSX_HIP(hipGetLastError());
+    return LBFGSX_OK;
+}
+extern "C" {
+
+int lbfgsx_b_cauchy_scan(lbfgsx_ctx* c, int64_t first, int64_t count, int64_t nord, const double* Mmat, double theta,
+                         double t_prev, const double* state_in, int64_t* exit_at, double* state_out)
+{
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    lbfgsb_state* b = c->bstate;
+    const int nc = c->ncorr, nc2 = 2 * nc;
+    if (c->dtype != LBFGSX_F64 || nc2 > 32 || count < 1 || first < 0 || first + count > nord)
+    {
+        set_error("lbfgsx_b_cauchy_scan: needs an f64 problem, 2*ncorr <= 32 and a non-empty range inside the sorted list");
+        return LBFGSX_E_INVALID;
+    }
+    const int NC = std::max(4, (nc2 + 3) / 4 * 4);
+    if (count > b->s_cap || NC > b->s_nc)
+    {
+        void* old[] = {b->s_brk, b->s_g, b->s_z, b->s_W, b->s_P, b->s_C, b->s_fpp, b->s_dfp, b->s_fp, b->s_ts, b->s_off};
+        for (void* p : old)
+            (void) hipFree(p);
+        const int64_t cap = std::max<int64_t>(count, b->s_cap);
+        const int ncap = std::max(NC, b->s_nc);
+        const size_t tiles = size_t((cap + kGcpTile - 1) / kGcpTile);
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_brk), sizeof(double) * size_t(cap + 1)));
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_g), sizeof(double) * size_t(cap)));
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_z), sizeof(double) * size_t(cap)));
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_W), sizeof(double) * size_t(cap) * size_t(ncap)));
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_P), sizeof(double) * size_t(cap) * size_t(ncap)));
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_C), sizeof(double) * size_t(cap) * size_t(ncap)));
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_fpp), sizeof(double) * size_t(cap)));
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_dfp), sizeof(double) * size_t(cap)));
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_fp), sizeof(double) * size_t(cap)));
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_ts), sizeof(double) * tiles * size_t(ncap + 1)));
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_off), sizeof(double) * tiles * size_t(ncap + 1)));
+        if (!b->s_small)
+        {
+            LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_small), sizeof(double) * (32 * 32 + 6 * 40)));
+            LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_exit), sizeof(unsigned long long)));
+        }
+        b->s_cap = cap;
+        b->s_nc = ncap;
+    }
+    rc = upload_phys(c);
+    if (rc)
+        return rc;
+    // small inputs in one staged copy: padded M (row-major NC x NC), the three scan seeds
+    double h[32 * 32 + 6 * 40];
+    std::memset(h, 0, sizeof(h));
+    for (int i = 0; i < nc2; i++)
+        for (int j = 0; j < nc2; j++)
+            h[i * NC + j] = Mmat[size_t(j) * size_t(nc2) + size_t(i)];
+    double* initA = h + NC * NC;
+    double* initB = initA + NC;
+    double* initC = initB + NC + 1;
+    for (int j = 0; j < nc2; j++)
+    {
+        initA[j] = state_in[j];        // p
+        initB[j] = state_in[nc2 + j];  // c
+    }
+    initB[NC] = state_in[2 * nc2 + 1];  // f''
+    initC[0] = state_in[2 * nc2];       // f'
+    const size_t nsmall = size_t(NC * NC + NC + NC + 1 + 1);
+    LBFGSX_HIP(hipMemcpyAsync(b->s_small, h, sizeof(double) * nsmall, hipMemcpyHostToDevice, c->stream));
+    LBFGSX_HIP(hipMemsetAsync(b->s_exit, 0xFF, sizeof(unsigned long long), c->stream));
+    const int grid = int(std::min<int64_t>((count + 256) / 256, 2048));
+    hipLaunchKernelGGL((k_gcp_gather<double>), dim3(grid), dim3(256), 0, c->stream, bvecs<double>(c), P<double>(b->keys_out),
+                       b->vals_out, first, count, nord, P<double>(c->S), P<double>(c->Y), c->ld, b->phys_dev, nc, b->s_brk,
+                       b->s_g, b->s_z, b->s_W, b->s_cap);
+    GcpBufs gb = {b->s_brk, b->s_g, b->s_z, b->s_W, b->s_P, b->s_C, b->s_fpp, b->s_dfp, b->s_fp, b->s_cap};
+    switch (NC)
+    {
+    case 4: rc = gcp_scan_nc<4>(c, gb, first, count, nord, theta, t_prev); break;
+    case 8: rc = gcp_scan_nc<8>(c, gb, first, count, nord, theta, t_prev); break;
+    case 12: rc = gcp_scan_nc<12>(c, gb, first, count, nord, theta, t_prev); break;
+    case 16: rc = gcp_scan_nc<16>(c, gb, first, count, nord, theta, t_prev); break;
+    case 20: rc = gcp_scan_nc<20>(c, gb, first, count, nord, theta, t_prev); break;
+    case 24: rc = gcp_scan_nc<24>(c, gb, first, count, nord, theta, t_prev); break;
+    case 28: rc = gcp_scan_nc<28>(c, gb, first, count, nord, theta, t_prev); break;
+    default: rc = gcp_scan_nc<32>(c, gb, first, count, nord, theta, t_prev); break;
+    }
+    if (rc)
+        return rc;
+    double o[2 * 32 + 4];
+    const double* dout = b->s_small + (NC * NC + NC + (NC + 1) + 1 + (NC + 1));
+    LBFGSX_HIP(hipMemcpyAsync(o, dout, sizeof(double) * size_t(2 * NC + 4), hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    for (int j = 0; j < nc2; j++)
+    {
+        state_out[j] = o[j];
+        state_out[nc2 + j] = o[NC + j];
+    }
+    state_out[2 * nc2] = o[2 * NC];          // f'
+    state_out[2 * nc2 + 1] = o[2 * NC + 1];  // f''
+    state_out[2 * nc2 + 2] = o[2 * NC + 2];  // break point of the last processed crossing
+    *exit_at = (o[2 * NC + 3] < 0.0) ? int64_t(-1) : first + int64_t(o[2 * NC + 3]);
     return LBFGSX_OK;
 }
 
