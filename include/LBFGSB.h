@@ -52,7 +52,8 @@ public:
         long long submin_calls = 0;
         long long submin_unconverged = 0;
         long long resets = 0;
-        double gcp_build_s = 0, gcp_fetch_s = 0, gcp_total_s = 0, submin_s = 0;
+        double gcp_build_s = 0, gcp_fetch_s = 0, gcp_total_s = 0, submin_s = 0, linesearch_s = 0, correction_s = 0;
+        long long gcp_dev_crossings = 0;
     };
 
 private:
@@ -87,6 +88,7 @@ private:
         typename Cauchy<Scalar>::Result gcp;
         Cauchy<Scalar>::get_cauchy_point(m_bfgs, gcp);                  // (:154)
         m_stats.gcp_crossings += gcp.crossings;
+        m_stats.gcp_dev_crossings += gcp.dev_crossings;
         m_stats.gcp_build_s += gcp.t_build;
         m_stats.gcp_fetch_s += gcp.t_fetch;
         m_stats.gcp_total_s += gcp.t_total;
@@ -112,6 +114,7 @@ private:
             step_max = std::min(m_param.max_step, step_max);            // (:200-202)
             Scalar step = Scalar(1);
             step = std::min(step, step_max);
+            const auto t_ls = std::chrono::steady_clock::now();
             try
             {
                 LineSearch<Scalar>::LineSearch(ev, m_param, step_max, step, fx, dg);
@@ -122,6 +125,7 @@ private:
                 throw;
             }
             m_nfev = ev.nfev();
+            m_stats.linesearch_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_ls).count();
 
             double pg = 0, x2 = 0, syd = 0, yyd = 0;
             detail::check(lbfgsx_b_post_linesearch(c, &pg, &x2, &syd, &yyd));   // (:206,235-237)
@@ -138,12 +142,15 @@ private:
             if (m_param.max_iterations != 0 && k >= m_param.max_iterations)
                 return k;
 
+            const auto t_corr = std::chrono::steady_clock::now();
             if (Scalar(syd) > eps * Scalar(yyd))                        // (:237-238)
                 m_bfgs.add_correction(Scalar(syd), Scalar(yyd));
+            m_stats.correction_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_corr).count();
 
             detail::check(lbfgsx_b_force_bounds(c));                    // (:240)
             Cauchy<Scalar>::get_cauchy_point(m_bfgs, gcp);              // (:241)
             m_stats.gcp_crossings += gcp.crossings;
+            m_stats.gcp_dev_crossings += gcp.dev_crossings;
             m_stats.gcp_build_s += gcp.t_build;
             m_stats.gcp_fetch_s += gcp.t_fetch;
             m_stats.gcp_total_s += gcp.t_total;
@@ -154,11 +161,17 @@ private:
             m_stats.submin_calls++;
             m_stats.submin_sweeps += st.sweeps;
             m_stats.submin_unconverged += st.converged ? 0 : 1;
+            if (m_trace_phases)
+                std::fprintf(stderr, "[lbfgsb] it %d: ls %.3f ms (cum) corr %.3f gcp %.3f (build %.3f fetch %.3f) submin %.3f | crossings %lld dev %lld sweeps %lld\n",
+                             k, m_stats.linesearch_s * 1e3, m_stats.correction_s * 1e3, m_stats.gcp_total_s * 1e3,
+                             m_stats.gcp_build_s * 1e3, m_stats.gcp_fetch_s * 1e3, m_stats.submin_s * 1e3,
+                             m_stats.gcp_crossings, m_stats.gcp_dev_crossings, m_stats.submin_sweeps);
             if (m_iter_hook)
                 m_iter_hook(k);
             k++;
         }
     }
+    const bool m_trace_phases = std::getenv("LBFGSX_TRACE_PHASES") != nullptr;  // debugging aid: cumulative phase times
 
 public:
     LBFGSBSolver(const LBFGSBParam<Scalar>& param) : m_param(param) { m_param.check_param(); }

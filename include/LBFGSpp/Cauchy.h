@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <limits>
 #include <vector>
@@ -262,6 +263,8 @@ public:
         }
         detail::check(lbfgsx_b_cauchy_finish(c, double(t_cross), double(tfinal), crossed_all ? 1 : 0, &out.nact, &out.nfree));
         out.t_fetch = ord.fetch_seconds;
+        if (std::getenv("LBFGSX_TRACE_PHASES"))
+            std::fprintf(stderr, "[gcp] ncorr %d nord %lld nfree %lld crossings %lld dev %lld crossed_all %d\n", ncorr, (long long) nord, (long long) nfree, (long long) out.crossings, (long long) out.dev_crossings, int(crossed_all));
         out.t_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     }
 };

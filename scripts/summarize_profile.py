@@ -14,6 +14,14 @@ rnd = sys.argv[1] if len(sys.argv) > 1 else "r1"
 src = os.path.join("gpurun_out", "prof_" + rnd)
 os.makedirs("profiles", exist_ok=True)
 shutil.copy(os.path.join(src, "trace", "bench_kernel_stats.csv"), os.path.join("profiles", rnd + "_kernel_stats.csv"))
+for name in ("northstar", "cfg3_m20", "cfg2_quad1e7", "cfg5_batched", "cfg4_lbfgsb", "cfg4_lbfgsb_mfma"):
+    f = os.path.join(src, "bench_%s.json" % name)
+    if os.path.exists(f):
+        shutil.copy(f, os.path.join("profiles", "%s_bench_%s.json" % (rnd, name)))
+for sub in ("lbfgsb", "lbfgsb_mfma", "batched"):
+    f = os.path.join(src, sub, "b_kernel_stats.csv")
+    if os.path.exists(f):
+        shutil.copy(f, os.path.join("profiles", "%s_%s_kernel_stats.csv" % (rnd, sub)))
 
 
 def short(name):
