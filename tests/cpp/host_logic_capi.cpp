@@ -1,0 +1,139 @@
+// tests/cpp/host_logic_capi.cpp -- TEST INFRASTRUCTURE: C wrappers around the pure-host pieces of the drop-in
+// headers (no device call is reachable from here, so the file links without liblbfgsx):
+//   BKLDLT<double>                       include/LBFGSpp/BKLDLT.h      (reference BKLDLT.h:390-520)
+//   LineSearchMoreThuente<>::Machine     include/LBFGSpp/LineSearchMoreThuente.h (reference MoreThuente.h:213-615)
+//   LBFGSParam / LBFGSBParam::check_param include/LBFGSpp/Param.h      (reference Param.h:193-217,352-376)
+// Built and driven by tests/test_host_logic_cpu.py (-m "not gpu").
+#include <cstring>
+#include <stdexcept>
+#include <vector>
+
+#include <LBFGSpp/BKLDLT.h>
+#include <LBFGSpp/LineSearchMoreThuente.h>
+#include <LBFGSpp/Param.h>
+
+using namespace LBFGSpp;
+
+extern "C" {
+
+// factor the symmetric n x n matrix (column major, lower triangle read) and solve A x = b; returns info()
+int hl_bkldlt_solve(int n, const double* A, const double* b, double* x)
+{
+    BKLDLT<double> f(A, n, n);
+    std::memcpy(x, b, sizeof(double) * size_t(n));
+    f.solve_inplace(x);
+    return f.info();
+}
+
+// solve before compute(): the reference throws std::logic_error (BKLDLT.h:446-447)
+int hl_bkldlt_uncomputed_throws(void)
+{
+    BKLDLT<double> f;
+    double x[2] = {1, 2};
+    try
+    {
+        f.solve_inplace(x);
+    }
+    catch (const std::logic_error&)
+    {
+        return 1;
+    }
+    return 0;
+}
+
+typedef double (*hl_phi)(double t, double* dphi, void* user);
+
+// More-Thuente search on phi(t) = f(xp + t d) from t = step.  returns 0 ok, 1 invalid_argument, 2 logic_error
+int hl_more_thuente(hl_phi phi, void* user, double ftol, double wolfe, double min_step, double max_step,
+                    int max_linesearch, double step, double step_max, double* step_out, double* f_out, double* dg_out,
+                    int* nfev, char* msg, int msglen)
+{
+    LBFGSParam<double> p;
+    p.ftol = ftol;
+    p.wolfe = wolfe;
+    p.min_step = min_step;
+    p.max_step = max_step;
+    p.max_linesearch = max_linesearch;
+    typedef LineSearchMoreThuente<double>::Machine Machine;
+    Machine m;
+    *nfev = 0;
+    try
+    {
+        double d0 = 0;
+        const double f0 = phi(0.0, &d0, user);
+        m.start(p, step_max, step, f0, d0);
+        double lo_t = 0, lo_f = f0, lo_d = d0;
+        for (;;)
+        {
+            double d = 0;
+            const double f = phi(double(m.step()), &d, user);
+            (*nfev)++;
+            bool keep = false;
+            const double t_eval = m.step();
+            const Machine::Action a = m.feed(f, d, keep);
+            if (keep)
+            {
+                lo_t = t_eval;
+                lo_f = f;
+                lo_d = d;
+            }
+            if (a == Machine::DONE_TRIAL)
+            {
+                *step_out = t_eval;
+                *f_out = f;
+                *dg_out = d;
+                return 0;
+            }
+            if (a == Machine::DONE_LO)
+            {
+                *step_out = lo_t;
+                *f_out = lo_f;
+                *dg_out = lo_d;
+                return 0;
+            }
+        }
+    }
+    catch (const std::invalid_argument& e)
+    {
+        std::strncpy(msg, e.what(), size_t(msglen - 1));
+        return 1;
+    }
+    catch (const std::logic_error& e)
+    {
+        std::strncpy(msg, e.what(), size_t(msglen - 1));
+        return 2;
+    }
+}
+
+// check_param(): returns 0 when accepted, 1 with the message otherwise.  which = 0: LBFGSParam, 1: LBFGSBParam
+int hl_check_param(int which, int m, double epsilon, double epsilon_rel, int past, double delta, int max_iterations,
+                   int linesearch, int max_linesearch, double min_step, double max_step, double ftol, double wolfe,
+                   int max_submin, char* msg, int msglen)
+{
+    try
+    {
+        if (which == 0)
+        {
+            LBFGSParam<double> p;
+            p.m = m; p.epsilon = epsilon; p.epsilon_rel = epsilon_rel; p.past = past; p.delta = delta;
+            p.max_iterations = max_iterations; p.linesearch = linesearch; p.max_linesearch = max_linesearch;
+            p.min_step = min_step; p.max_step = max_step; p.ftol = ftol; p.wolfe = wolfe;
+            p.check_param();
+        }
+        else
+        {
+            LBFGSBParam<double> p;
+            p.m = m; p.epsilon = epsilon; p.epsilon_rel = epsilon_rel; p.past = past; p.delta = delta;
+            p.max_iterations = max_iterations; p.max_submin = max_submin; p.max_linesearch = max_linesearch;
+            p.min_step = min_step; p.max_step = max_step; p.ftol = ftol; p.wolfe = wolfe;
+            p.check_param();
+        }
+    }
+    catch (const std::invalid_argument& e)
+    {
+        std::strncpy(msg, e.what(), size_t(msglen - 1));
+        return 1;
+    }
+    return 0;
+}
+}

@@ -1,0 +1,178 @@
+"""-m "not gpu": the pure-host pieces of the drop-in headers, compiled with g++ and driven through a small C
+wrapper (tests/cpp/host_logic_capi.cpp): Bunch-Kaufman LDL' (reference BKLDLT.h:390-520), the More-Thuente state
+machine (MoreThuente.h:213-615) and parameter validation (Param.h:193-217,352-376).  No GPU, no device library."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+@pytest.fixture(scope="module")
+def hl(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("hl") / "libhostlogic.so")
+    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"),
+           os.path.join(HERE, "cpp", "host_logic_capi.cpp"), "-o", out]
+    subprocess.check_call(cmd)
+    lib = C.CDLL(out)
+    lib.hl_bkldlt_solve.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    return lib
+
+
+def _sym(rng, n, kind):
+    A = rng.standard_normal((n, n))
+    A = A + A.T
+    if kind == "zero_diag":      # forces 2x2 pivots
+        np.fill_diagonal(A, 0.0)
+    elif kind == "permMinv":     # the L-BFGS-B structure: [[-D, L'], [L, theta S'S]] padded with identity rows
+        c = n // 2
+        S = rng.standard_normal((50, c))
+        Y = S * (1 + rng.random((50, c))) + 0.1 * rng.standard_normal((50, c))
+        SY = S.T @ Y
+        A = np.zeros((n, n))
+        A[:c, :c] = -np.diag(np.diag(SY))
+        A[c:2 * c, :c] = np.tril(SY, -1)
+        A[:c, c:2 * c] = np.tril(SY, -1).T
+        A[c:2 * c, c:2 * c] = 1.7 * (S.T @ S)
+        for i in range(2 * c, n):
+            A[i, i] = 1.0
+    elif kind == "spd":
+        A = A @ A.T + n * np.eye(n)
+    return A
+
+
+@pytest.mark.parametrize("kind", ["indefinite", "zero_diag", "permMinv", "spd"])
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 12, 20, 40])
+def test_bkldlt_solves_symmetric_systems(hl, n, kind):
+    if kind == "zero_diag" and n == 1:
+        pytest.skip("the 1 x 1 zero matrix is singular")
+    rng = np.random.default_rng(100 * n + len(kind))
+    A = _sym(rng, n, kind)
+    b = rng.standard_normal(n)
+    x = np.zeros(n)
+    Af = np.asfortranarray(np.tril(A) + np.triu(np.full((n, n), np.nan), 1))  # only the lower triangle may be read
+    info = hl.hl_bkldlt_solve(n, Af.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p))
+    # n = 1 never enters the elimination loop, so info() keeps its initial NOT_COMPUTED -- same as the reference
+    # (BKLDLT.h:407-436); the solve is valid all the same
+    assert info == (0 if n > 1 else 1)
+    ref = np.linalg.solve(A, b)
+    cond = np.linalg.cond(A)
+    assert np.abs(x - ref).max() <= 1e-13 * cond * max(1.0, np.abs(ref).max())
+    assert np.abs(A @ x - b).max() <= 1e-12 * max(1.0, np.abs(A).max() * np.abs(x).max())
+
+
+def test_bkldlt_requires_compute(hl):
+    assert hl.hl_bkldlt_uncomputed_throws() == 1
+
+
+PHI = C.CFUNCTYPE(C.c_double, C.c_double, C.POINTER(C.c_double), C.c_void_p)
+
+
+def _search(hl, fun, step=1.0, step_max=1e20, ftol=1e-4, wolfe=0.9, min_step=1e-20, max_step=1e20, max_ls=20):
+    calls = []
+
+    def phi(t, dphi, _):
+        f, d = fun(t)
+        dphi[0] = d
+        calls.append(t)
+        return f
+
+    cb = PHI(phi)
+    so, fo, do, nf = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+    msg = C.create_string_buffer(256)
+    hl.hl_more_thuente.argtypes = [PHI, C.c_void_p] + [C.c_double] * 4 + [C.c_int, C.c_double, C.c_double,
+                                                                           C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                                                           C.POINTER(C.c_double), C.POINTER(C.c_int),
+                                                                           C.c_char_p, C.c_int]
+    rc = hl.hl_more_thuente(cb, None, ftol, wolfe, min_step, max_step, max_ls, step, step_max, C.byref(so), C.byref(fo),
+                            C.byref(do), C.byref(nf), msg, 256)
+    return rc, so.value, fo.value, do.value, nf.value, msg.value.decode(), calls
+
+
+# the six test functions of More & Thuente (1994), table 5.1-5.6 shapes
+def _mt1(t, beta=2.0):
+    return -t / (t * t + beta), (t * t - beta) / (t * t + beta) ** 2
+
+
+def _mt2(t, beta=0.004):
+    return (t + beta) ** 5 - 2 * (t + beta) ** 4, 5 * (t + beta) ** 4 - 8 * (t + beta) ** 3
+
+
+def _quad(t):
+    return (t - 3.0) ** 2, 2 * (t - 3.0)
+
+
+@pytest.mark.parametrize("fun", [_mt1, _mt2, _quad], ids=["mt1", "mt2", "quad"])
+@pytest.mark.parametrize("step", [1e-3, 0.1, 1.0, 10.0])
+@pytest.mark.parametrize("wolfe", [0.9, 0.1])
+def test_more_thuente_returns_a_strong_wolfe_point(hl, fun, step, wolfe):
+    ftol = 1e-4
+    rc, t, f, d, nfev, msg, calls = _search(hl, fun, step=step, ftol=ftol, wolfe=wolfe, max_ls=40)
+    assert rc == 0, msg
+    f0, d0 = fun(0.0)
+    assert (f, d) == fun(t)                       # the reported values belong to the reported step
+    assert f <= f0 + ftol * t * d0 + 1e-15        # sufficient decrease
+    if nfev < 40:  # with the budget exhausted (1.1x extrapolation from a tiny first step) only decrease is promised
+        assert abs(d) <= wolfe * abs(d0) * (1 + 1e-12)  # curvature
+    assert 1 <= nfev <= 40 and calls[1] == step   # calls[0] is phi(0); the first trial is the given step
+
+
+def test_more_thuente_argument_errors(hl):
+    rc, *_, msg, _c = _search(hl, _quad, step=-1.0)
+    assert rc == 1 and msg == "'step' must be positive"
+    rc, *_, msg, _c = _search(hl, _quad, step=2.0, step_max=1.0)
+    assert rc == 1 and msg == "'step' exceeds 'step_max'"
+    rc, *_, msg, _c = _search(hl, lambda t: ((t + 3.0) ** 2, 2 * (t + 3.0)), step=1.0)
+    assert rc == 2 and msg == "the moving direction does not decrease the objective function value"
+
+
+def test_more_thuente_exhausted_budget_returns_best_point(hl):
+    """max_linesearch trials without a Wolfe point: the search hands back the saved best point, never throws
+    (reference MoreThuente.h:599-613)."""
+    rc, t, f, d, nfev, msg, calls = _search(hl, _mt2, step=1e-3, wolfe=1e-9, max_ls=3)
+    assert rc == 0 and nfev <= 4
+    assert (f, d) == _mt2(t) and f <= _mt2(0.0)[0]
+
+
+BAD = [dict(m=0), dict(epsilon=-1.0), dict(epsilon_rel=-1.0), dict(past=-1), dict(delta=-1.0), dict(max_iterations=-1),
+       dict(max_linesearch=0), dict(min_step=-1.0), dict(max_step=1e-30), dict(ftol=0.0), dict(ftol=0.6),
+       dict(wolfe=1e-5), dict(wolfe=1.0)]
+
+
+def _check(hl, which, **kw):
+    d = dict(m=6, epsilon=1e-5, epsilon_rel=1e-5, past=0, delta=0.0, max_iterations=0, linesearch=3, max_linesearch=20,
+             min_step=1e-20, max_step=1e20, ftol=1e-4, wolfe=0.9, max_submin=10)
+    d.update(kw)
+    msg = C.create_string_buffer(256)
+    hl.hl_check_param.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int,
+                                  C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_char_p, C.c_int]
+    rc = hl.hl_check_param(which, d["m"], d["epsilon"], d["epsilon_rel"], d["past"], d["delta"], d["max_iterations"],
+                           d["linesearch"], d["max_linesearch"], d["min_step"], d["max_step"], d["ftol"], d["wolfe"],
+                           d["max_submin"], msg, 256)
+    return rc, msg.value.decode()
+
+
+@pytest.mark.parametrize("bad", BAD, ids=[list(b)[0] + "=" + str(list(b.values())[0]) for b in BAD])
+def test_param_validation_messages_match_the_reference(hl, bad):
+    rc, msg = _check(hl, 0, **bad)
+    assert rc == 1 and msg
+    try:
+        ref = O.Oracle("ref", "dd")
+    except OSError:
+        pytest.skip("oracle/_ref not built here; message text is pinned where the reference build exists")
+    p = O.lbfgs_params(**bad)
+    _, r = ref.lbfgs(O.F64, O.LS_NW, O.OBJ_ROSEN, np.zeros(4), p)
+    assert r.status == 1 and r.msg.decode() == msg
+
+
+def test_param_validation_accepts_defaults_and_checks_lbfgsb_fields(hl):
+    assert _check(hl, 0)[0] == 0 and _check(hl, 1)[0] == 0
+    assert _check(hl, 0, linesearch=7)[0] == 1
+    rc, msg = _check(hl, 1, max_submin=-1)
+    assert rc == 1 and "max_submin" in msg
