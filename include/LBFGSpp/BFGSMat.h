@@ -142,18 +142,59 @@ public:
 
     // solve_PtBP (BFGSMat.h:529-565) on the coordinates selected by `mask`; v is a device-side selector.
     // Result goes to vecy on those coordinates.
-    void solve_PtBP(int mask, std::int64_t nP, int vsel) const
+    //
+    // `prologue` (LBFGSX_GP_RHS / LBFGSX_GP_LINEAR with coef1, coef2) is the combine statement that produces v --
+    // the two apply_PtBQv updates of rhs (SubspaceMin.h:236-241) or the linear term (:144-156).  It is evaluated
+    // inside the Gram pass when the one-pass kernel is available, by separate lbfgsx_b_wcombine launches otherwise.
+    // `Fy` (optional): on return W_F' y over `fy_mask` with the S half scaled as apply_WtPv does (`* theta`),
+    // produced by the same pass that writes y when the fused kernel applies (otherwise by a separate Wtv).
+    void solve_PtBP(int mask, std::int64_t nP, int vsel, int prologue = LBFGSX_GP_NONE, const double* coef1 = nullptr,
+                    const double* coef2 = nullptr, std::vector<Scalar>* Fy = nullptr, int fy_mask = 0) const
     {
+        auto finish = [&](const double* coef) {
+            double raw[80];
+            if (Fy && m_ncorr >= 1 &&
+                lbfgsx_b_solve_wty(m_c, mask, vsel, coef, double(m_theta), fy_mask, raw) == LBFGSX_OK)
+            {
+                Fy->assign(size_t(2 * m_ncorr), Scalar(0));
+                for (int j = 0; j < m_ncorr; j++)
+                {
+                    (*Fy)[size_t(j)] = Scalar(raw[j]);
+                    (*Fy)[size_t(m_ncorr + j)] = Scalar(raw[m_ncorr + j]) * m_theta;
+                }
+                return;
+            }
+            detail::check(lbfgsx_b_wcombine(m_c, LBFGSX_CB_SOLVE, mask, vsel, coef, double(m_theta)));
+            if (Fy)
+                Wtv(LBFGSX_VS_Y, fy_mask, false, *Fy);
+        };
+        auto prologue_unfused = [&]() {
+            if (prologue == LBFGSX_GP_RHS)
+            {
+                if (coef1)
+                    detail::check(lbfgsx_b_wcombine(m_c, LBFGSX_CB_RHS_ADD, mask, 0, coef1, double(m_theta)));
+                if (coef2)
+                    detail::check(lbfgsx_b_wcombine(m_c, LBFGSX_CB_RHS_ADD, mask, 0, coef2, double(m_theta)));
+            }
+            else if (prologue == LBFGSX_GP_LINEAR)
+                detail::check(lbfgsx_b_wcombine(m_c, LBFGSX_CB_LINEAR, mask, 0, coef1, double(m_theta)));
+        };
         if (m_ncorr < 1 || nP < 1)
         {
-            detail::check(lbfgsx_b_wcombine(m_c, LBFGSX_CB_SOLVE, mask, vsel, nullptr, double(m_theta)));
+            prologue_unfused();
+            finish(nullptr);
             return;
         }
         const int c = m_ncorr, t = 2 * c;
         std::vector<double> G(size_t(t) * size_t(t), 0.0);
         double raw[80];
-        // one pass on the matrix cores for W_P'W_P and W_P'v; the tiled VALU Gram is the fallback
-        const bool fused = (lbfgsx_b_gram_fused(m_c, mask, vsel, G.data(), raw) == LBFGSX_OK);
+        // one pass for W_P'W_P and W_P'v (and the prologue); the tiled VALU Gram is the fallback
+        bool fused = (lbfgsx_b_gram_fused_ex(m_c, mask, vsel, prologue, coef1, coef2, G.data(), raw) == LBFGSX_OK);
+        if (!fused && prologue != LBFGSX_GP_NONE)
+        {
+            prologue_unfused();
+            fused = (lbfgsx_b_gram_fused(m_c, mask, vsel, G.data(), raw) == LBFGSX_OK);  // e.g. the MFMA kernel
+        }
         if (!fused)
             detail::check(lbfgsx_b_gram(m_c, mask, G.data()));
         auto Gm = [&](int i, int j) { return Scalar(G[size_t(i) * size_t(t) + size_t(j)]); };
@@ -188,7 +229,7 @@ public:
             coef[size_t(j)] = double(WPv[size_t(j)]);
             coef[size_t(c + j)] = double(WPv[size_t(c + j)] * m_theta);              // (:563)
         }
-        detail::check(lbfgsx_b_wcombine(m_c, LBFGSX_CB_SOLVE, mask, vsel, coef.data(), double(m_theta)));
+        finish(coef.data());
     }
 
     lbfgsx_ctx* ctx() const { return m_c; }

@@ -25,16 +25,13 @@ namespace LBFGSpp {
 template <typename Scalar>
 class SubspaceMin
 {
-    // -F'W M (W'AA'd) then + g_F  -> vecc on the free set   (SubspaceMin.h:144-156, BFGSMat.h:486-522)
-    static void linear_term(const BFGSMatB<Scalar>& bfgs, const typename Cauchy<Scalar>::Result& gcp)
+    // coefficients of -F'W M (W'AA'd)  (SubspaceMin.h:144-156, BFGSMat.h:486-522); false when the term is absent
+    // (vecc = g_F).  The combine itself (cF = -W_F coef + g_F) runs as the prologue of the first solve.
+    static bool linear_coef(const BFGSMatB<Scalar>& bfgs, const typename Cauchy<Scalar>::Result& gcp, std::vector<double>& coef)
     {
-        lbfgsx_ctx* c = bfgs.ctx();
         const int nc = bfgs.num_corrections();
         if (nc < 1 || gcp.nact < 1 || gcp.nfree < 1)
-        {
-            detail::check(lbfgsx_b_wcombine(c, LBFGSX_CB_LINEAR, LBFGSX_ST_FREE, 0, nullptr, double(bfgs.theta())));
-            return;
-        }
+            return false;
         std::vector<Scalar> rhs;
         if (gcp.nact <= gcp.nfree)
             bfgs.Wtv(LBFGSX_VS_DRT, LBFGSX_ST_NEWACT, false, rhs);      // W_A'(A'd)            (:503-507)
@@ -44,24 +41,24 @@ class SubspaceMin
             for (int j = 0; j < 2 * nc; j++)
                 rhs[size_t(j)] = gcp.vecc[size_t(j)] - rhs[size_t(j)];
         }
-        std::vector<double> coef;
         bfgs.Mv_scaled(rhs, coef);
-        detail::check(lbfgsx_b_wcombine(c, LBFGSX_CB_LINEAR, LBFGSX_ST_FREE, 0, coef.data(), double(bfgs.theta())));
+        return true;
     }
 
-    // rhs += P'B Q v  for Q = L (v = vecl) or Q = U (v = vecu)   (SubspaceMin.h:236-241, BFGSMat.h:570-594)
-    static void add_PtBQv(const BFGSMatB<Scalar>& bfgs, int qmask, int vsel, std::int64_t nP, std::int64_t nQ)
+    // coefficients of P'B Q v  for Q = L (v = vecl) or Q = U (v = vecu)   (SubspaceMin.h:236-241, BFGSMat.h:570-594);
+    // false when the product is known to be zero.  rhs += -(W_P coef) runs as the prologue of the P solve.
+    static bool PtBQv_coef(const BFGSMatB<Scalar>& bfgs, int qmask, int vsel, std::int64_t nP, std::int64_t nQ,
+                           std::vector<double>& coef)
     {
         if (bfgs.num_corrections() < 1 || nP < 1 || nQ < 1)
-            return;
+            return false;
         std::vector<Scalar> WQtv;
         std::int64_t nnz = 0;
         bfgs.Wtv(vsel, qmask, false, WQtv, &nnz);
         if (nnz < 1)  // test_zero: every v entry is zero -> the product is known to be zero (:388-412)
-            return;
-        std::vector<double> coef;
+            return false;
         bfgs.Mv_scaled(WQtv, coef);
-        detail::check(lbfgsx_b_wcombine(bfgs.ctx(), LBFGSX_CB_RHS_ADD, LBFGSX_ST_P, 0, coef.data(), double(bfgs.theta())));
+        return true;
     }
 
 public:
@@ -83,8 +80,10 @@ public:
         if (nfree < 1)
             return;
 
-        linear_term(bfgs, gcp);                                         // vecc (:144-156)
-        bfgs.solve_PtBP(LBFGSX_ST_FREE, nfree, LBFGSX_VS_NEG_CF);       // vecy = -inv(B[F,F]) c (:159)
+        std::vector<double> lcoef;
+        const bool has_lin = linear_coef(bfgs, gcp, lcoef);             // vecc (:144-156) ...
+        bfgs.solve_PtBP(LBFGSX_ST_FREE, nfree, LBFGSX_VS_NEG_CF, LBFGSX_GP_LINEAR,   // ... fused with
+                        has_lin ? lcoef.data() : nullptr);              // vecy = -inv(B[F,F]) c (:159)
         std::int64_t cnt[4];
         detail::check(lbfgsx_b_sub_check(c, cnt));
         if (cnt[0] == 0)                                                // in_bounds (:162-166)
@@ -99,17 +98,25 @@ public:
         {
             std::int64_t nL = 0, nU = 0, nP = 0;
             detail::check(lbfgsx_b_sub_partition(c, &nL, &nU, &nP));    // (:194-219)
+            const bool need_mult = (nL > 0 || nU > 0);
+            std::vector<Scalar> Fy;
+            bool have_Fy = false;
             if (nP > 0)                                                 // (:229-245)
             {
                 detail::check(lbfgsx_b_sub_op(c, LBFGSX_SO_RHS_INIT));
-                add_PtBQv(bfgs, LBFGSX_ST_L, LBFGSX_VS_LBOUND, nP, nL);
-                add_PtBQv(bfgs, LBFGSX_ST_U, LBFGSX_VS_UBOUND, nP, nU);
-                bfgs.solve_PtBP(LBFGSX_ST_P, nP, LBFGSX_VS_NEG_RHS);
+                std::vector<double> cl, cu;
+                const bool hasL = PtBQv_coef(bfgs, LBFGSX_ST_L, LBFGSX_VS_LBOUND, nP, nL, cl);
+                const bool hasU = PtBQv_coef(bfgs, LBFGSX_ST_U, LBFGSX_VS_UBOUND, nP, nU, cu);
+                // the pass that writes y on P also delivers W_F'y for the multipliers below
+                bfgs.solve_PtBP(LBFGSX_ST_P, nP, LBFGSX_VS_NEG_RHS, (hasL || hasU) ? LBFGSX_GP_RHS : LBFGSX_GP_NONE,
+                                hasL ? cl.data() : nullptr, hasU ? cu.data() : nullptr, need_mult ? &Fy : nullptr,
+                                LBFGSX_ST_FREE);
+                have_Fy = need_mult;
             }
-            if (nL > 0 || nU > 0)                                       // multipliers (:247-268)
+            if (need_mult)                                              // multipliers (:247-268)
             {
-                std::vector<Scalar> Fy;
-                bfgs.Wtv(LBFGSX_VS_Y, LBFGSX_ST_FREE, false, Fy);
+                if (!have_Fy)
+                    bfgs.Wtv(LBFGSX_VS_Y, LBFGSX_ST_FREE, false, Fy);
                 std::vector<double> coef;
                 bfgs.Mv_scaled(Fy, coef);
                 const double* cf = (bfgs.num_corrections() < 1) ? nullptr : coef.data();

@@ -193,6 +193,19 @@ int lbfgsx_b_gram(lbfgsx_ctx* c, int mask, double* gram);
  * iterate-parity contract, so the path is opt-in: environment LBFGSX_GRAM=mfma at context creation.  Returns
  * LBFGSX_E_INVALID when not enabled or 2c+1 > 32 -- callers then use lbfgsx_b_gram + lbfgsx_b_wtv. */
 int lbfgsx_b_gram_fused(lbfgsx_ctx* c, int mask, int vsel, double* gram, double* wtv);
+/* The same with the combine statement that produces v fused in as a prologue (one pass instead of two or three):
+ *   LBFGSX_GP_RHS     rhs = (rhs + -(W_mask coef1)) + -(W_mask coef2), then v = -rhs   (two apply_PtBQv, BFGSMat.h:570-594;
+ *                     a NULL coefficient vector skips its term)
+ *   LBFGSX_GP_LINEAR  cF = -1 * (W_mask coef1) + g (coef1 NULL: cF = g), then v = -cF (compute_FtBAb, BFGSMat.h:486-522)
+ * coef*: 2c doubles, logical order [Y slots, S slots] as for lbfgsx_b_wcombine.  Default Gram kernel only. */
+enum { LBFGSX_GP_NONE = 0, LBFGSX_GP_RHS = 1, LBFGSX_GP_LINEAR = 2 };
+int lbfgsx_b_gram_fused_ex(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, const double* coef1, const double* coef2,
+                           double* gram, double* wtv);
+/* lbfgsx_b_wcombine(LBFGSX_CB_SOLVE, pmask, vsel, coef, theta) fused with the raw masked multi-dot
+ * wty = [Y_F' y, S_F' y] over `fmask` (pmask must be a subset of fmask): the solve result of solve_PtBP
+ * (BFGSMat.h:564) and the W_F' y the multipliers need (SubspaceMin.h:249-254, apply_WtPv BFGSMat.h:382-430) in one
+ * pass.  coef may be NULL (y = v/theta).  1 <= 2c <= 32, LBFGSX_E_INVALID otherwise. */
+int lbfgsx_b_solve_wty(lbfgsx_ctx* c, int pmask, int vsel, const double* coef, double theta, int fmask, double* wty);
 /* masked combine with element-wise epilogue, see LBFGSX_CB_*; coef = NULL means "W term absent" */
 int lbfgsx_b_wcombine(lbfgsx_ctx* c, int mode, int mask, int vsel, const double* coef, double theta);
 /* BOXCQP partition of the free set into L/U/P with the value/multiplier updates (SubspaceMin.h:194-219) */

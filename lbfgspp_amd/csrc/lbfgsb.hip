@@ -36,6 +36,7 @@ struct lbfgsb_state
     bool gram_mfma = false;  // opt-in (LBFGSX_GRAM=mfma): ~1 ulp per entry instead of the correctly rounded sums
     int gram_mode = 0;       // 2 (LBFGSX_GRAM=blocked): force the multi-launch blocked Gram + separate W'v
     int gram_dd_blocks = 512;
+    bool multidot_chunked = false;  // LBFGSX_MULTIDOT=chunked: 8 columns per launch (round-1a kernel)
     // device GCP search (gcp_scan.cuh): per-chunk work set, allocated on first use
     double *s_brk = nullptr, *s_g = nullptr, *s_z = nullptr, *s_W = nullptr, *s_P = nullptr, *s_C = nullptr,
            *s_fpp = nullptr, *s_dfp = nullptr, *s_fp = nullptr, *s_ts = nullptr, *s_off = nullptr, *s_small = nullptr;
@@ -171,6 +172,8 @@ int bounded_alloc(lbfgsx_ctx* c)
         b->gram_mfma = (std::strcmp(e, "mfma") == 0);
         b->gram_mode = (std::strcmp(e, "blocked") == 0) ? 2 : 0;
     }
+    if (const char* e = getenv("LBFGSX_MULTIDOT"))
+        b->multidot_chunked = (std::strcmp(e, "chunked") == 0);
     if (const char* e = getenv("LBFGSX_GRAM_BLOCKS"))
         b->gram_blocks = std::max(64, std::min(atoi(e), 4096));
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->gram_partial), sizeof(double) * size_t(b->gram_blocks) * 3 * 256 * 2));
@@ -218,6 +221,28 @@ static Cols<T, NC> col_list(lbfgsx_ctx* c, const int* which /* 0..2c-1: Y slots 
 }
 
 // raw masked W'v for all 2*ncorr columns: out[0..c) = Y_j . v, out[c..2c) = S_j . v ; nnz of v inside the mask
+template <class T, int NC>
+static int wtv_all(lbfgsx_ctx* c, int total, int vsel_id, const T* vcol, int mask, double* out, int64_t* nnz)
+{
+    int which[32];
+    for (int k = 0; k < total; k++)
+        which[k] = k;
+    Cols<T, 32> cl = col_list<T, 32>(c, which, total);
+    const int grid = c->grid_for(c->n);
+    hipLaunchKernelGGL((k_multidot_all<T, NC>), dim3(grid), dim3(kBlock), 0, c->stream, cl, total, bvecs<T>(c), vsel_id, vcol,
+                       mask, c->n, c->ws, c->bstate->dout);
+    LBFGSX_HIP(hipGetLastError());
+    double r[NC + 1];
+    int rc = fetch_doubles(c, NC + 1, r);
+    if (rc)
+        return rc;
+    for (int k = 0; k < total; k++)
+        out[k] = r[k];
+    if (nnz)
+        *nnz = int64_t(r[NC]);
+    return LBFGSX_OK;
+}
+
 template <class T>
 static int wtv_t(lbfgsx_ctx* c, int vsel_id, const T* vcol, int mask, double* out, int64_t* nnz)
 {
@@ -225,6 +250,13 @@ static int wtv_t(lbfgsx_ctx* c, int vsel_id, const T* vcol, int mask, double* ou
     const int total = 2 * c->ncorr;
     const int grid = c->grid_for(c->n);
     BVecs<T> b = bvecs<T>(c);
+    if (total > 8 && total <= 32 && !c->bstate->multidot_chunked)
+    {
+        // one launch for every column (all history columns are 16-byte aligned: ld is a multiple of 64 elements)
+        if (total <= 16) return wtv_all<T, 16>(c, total, vsel_id, vcol, mask, out, nnz);
+        if (total <= 24) return wtv_all<T, 24>(c, total, vsel_id, vcol, mask, out, nnz);
+        return wtv_all<T, 32>(c, total, vsel_id, vcol, mask, out, nnz);
+    }
     if (total == 0 && nnz)
     {
         // still count the non-zeros
@@ -271,16 +303,12 @@ static int wcombine_t(lbfgsx_ctx* c, int mode, int mask, int vsel_id, const doub
 {
     const int grid = c->grid_for(c->n);
     const int has_w = (coef != nullptr && c->ncorr > 0) ? 1 : 0;
-    T hc[80];
-    for (int k = 0; k < 2 * c->ncorr; k++)
-        hc[k] = has_w ? T(coef[k]) : T(0);
-    if (has_w)
-        LBFGSX_HIP(hipMemcpyAsync(c->bstate->coef_dev, hc, sizeof(T) * size_t(2 * c->ncorr), hipMemcpyHostToDevice, c->stream));
-    LBFGSX_HIP(hipStreamSynchronize(c->stream));  // hc lives on this stack frame
+    CoefArg<T> cf;
+    for (int k = 0; k < 80; k++)
+        cf.c[k] = (has_w && k < 2 * c->ncorr) ? T(coef[k]) : T(0);
     BVecs<T> bv = bvecs<T>(c);
     const T* S = P<T>(c->S);
     const T* Y = P<T>(c->Y);
-    const T* cf = P<T>(c->bstate->coef_dev);
     const int* ph = c->bstate->phys_dev;
     switch (mode)
     {
@@ -751,18 +779,24 @@ int lbfgsx_b_gram(lbfgsx_ctx* c, int mask, double* gram)
 // caller then falls back to lbfgsx_b_gram + lbfgsx_b_wtv.
 }  // extern "C"
 template <class T, int KP>
-static void launch_gram_dd(lbfgsx_ctx* c, int blocks, int tot, int vsel_id, int mask)
+static void launch_gram_dd(lbfgsx_ctx* c, int blocks, int tot, int vsel_id, int mask, const GramPrologue<T>& pro)
 {
     int which[32];
     for (int k = 0; k < tot; k++)
         which[k] = k;
     Cols<T, 32> cl = col_list<T, 32>(c, which, tot);
     hipLaunchKernelGGL((k_gram_dd<T, KP>), dim3(blocks), dim3(kBlock), 0, c->stream, cl, tot, bvecs<T>(c), vsel_id, mask,
-                       c->n, c->bstate->gram_partial);
+                       c->n, c->bstate->gram_partial, pro);
 }
 extern "C" {
 
 int lbfgsx_b_gram_fused(lbfgsx_ctx* c, int mask, int vsel_id, double* gram, double* wtv)
+{
+    return lbfgsx_b_gram_fused_ex(c, mask, vsel_id, LBFGSX_GP_NONE, nullptr, nullptr, gram, wtv);
+}
+
+int lbfgsx_b_gram_fused_ex(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, const double* coef1, const double* coef2,
+                           double* gram, double* wtv)
 {
     int rc = need_bounded(c);
     if (rc)
@@ -770,6 +804,11 @@ int lbfgsx_b_gram_fused(lbfgsx_ctx* c, int mask, int vsel_id, double* gram, doub
     lbfgsb_state* b = c->bstate;
     const int tot = 2 * c->ncorr;
     const int ntot = tot + (vsel_id >= 0 ? 1 : 0);
+    if (prologue != LBFGSX_GP_NONE && (b->gram_mfma || prologue < 0 || prologue > LBFGSX_GP_LINEAR))
+    {
+        set_error("lbfgsx_b_gram_fused_ex: the prologue needs the default one-pass Gram");
+        return LBFGSX_E_INVALID;
+    }
     if (tot < 1 || (b->gram_mfma ? tot + 1 > 32 : ntot > kGramDDCS) || b->gram_mode == 2)
     {
         set_error("lbfgsx_b_gram_fused: one-pass Gram not applicable");
@@ -819,12 +858,24 @@ int lbfgsx_b_gram_fused(lbfgsx_ctx* c, int mask, int vsel_id, double* gram, doub
     const int64_t nbatch = (c->n + kGramDDRows - 1) / kGramDDRows;
     // 2 blocks (64 KB of LDS each) are resident per CU: one persistent wave set per slot
     const int blocks = int(std::max<int64_t>(1, std::min<int64_t>(b->gram_dd_blocks, (nbatch + 3) / 4)));
+    rc = upload_phys(c);
+    if (rc)
+        return rc;
     DISPATCH_T(c, {
-        if (kp <= 1) launch_gram_dd<T, 1>(c, blocks, tot, vsel_id, mask);
-        else if (kp <= 2) launch_gram_dd<T, 2>(c, blocks, tot, vsel_id, mask);
-        else if (kp <= 4) launch_gram_dd<T, 4>(c, blocks, tot, vsel_id, mask);
-        else if (kp <= 6) launch_gram_dd<T, 6>(c, blocks, tot, vsel_id, mask);
-        else launch_gram_dd<T, 8>(c, blocks, tot, vsel_id, mask);
+        GramPrologue<T> pro;
+        pro.mode = prologue;
+        pro.use1 = coef1 ? 1 : 0;
+        pro.use2 = coef2 ? 1 : 0;
+        for (int k = 0; k < 64; k++)
+        {
+            pro.c1[k] = (coef1 && k < tot) ? T(coef1[k]) : T(0);
+            pro.c2[k] = (coef2 && k < tot) ? T(coef2[k]) : T(0);
+        }
+        if (kp <= 1) launch_gram_dd<T, 1>(c, blocks, tot, vsel_id, mask, pro);
+        else if (kp <= 2) launch_gram_dd<T, 2>(c, blocks, tot, vsel_id, mask, pro);
+        else if (kp <= 4) launch_gram_dd<T, 4>(c, blocks, tot, vsel_id, mask, pro);
+        else if (kp <= 6) launch_gram_dd<T, 6>(c, blocks, tot, vsel_id, mask, pro);
+        else launch_gram_dd<T, 8>(c, blocks, tot, vsel_id, mask, pro);
     });
     const int kpt = kp <= 1 ? 1 : kp <= 2 ? 2 : kp <= 4 ? 4 : kp <= 6 ? 6 : 8;
     const int ntile = (64 * kpt + 255) / 256;
@@ -861,6 +912,52 @@ int lbfgsx_b_wcombine(lbfgsx_ctx* c, int mode, int mask, int vsel_id, const doub
     if (rc)
         return rc;
     DISPATCH_T(c, { rc = wcombine_t<T>(c, mode, mask, vsel_id, coef, theta); });
+    return rc;
+}
+
+}  // extern "C"
+template <class T, int NC>
+static int solve_dots_t(lbfgsx_ctx* c, int pmask, int vsel_id, const double* coef, double theta, int fmask, double* wty)
+{
+    const int total = 2 * c->ncorr;
+    int which[32];
+    for (int k = 0; k < total; k++)
+        which[k] = k;
+    Cols<T, 32> cl = col_list<T, 32>(c, which, total);
+    CoefArg<T> cf;
+    for (int k = 0; k < 80; k++)
+        cf.c[k] = (coef && k < total) ? T(coef[k]) : T(0);
+    const int grid = c->grid_for(c->n);
+    hipLaunchKernelGGL((k_solve_dots<T, NC>), dim3(grid), dim3(kBlock), 0, c->stream, cl, total, bvecs<T>(c), vsel_id, cf,
+                       coef ? 1 : 0, pmask, fmask, T(theta), c->n, c->ws, c->bstate->dout);
+    LBFGSX_HIP(hipGetLastError());
+    double r[NC];
+    int rc = fetch_doubles(c, NC, r);
+    if (rc)
+        return rc;
+    for (int k = 0; k < total; k++)
+        wty[k] = r[k];
+    return LBFGSX_OK;
+}
+extern "C" {
+
+int lbfgsx_b_solve_wty(lbfgsx_ctx* c, int pmask, int vsel_id, const double* coef, double theta, int fmask, double* wty)
+{
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    const int total = 2 * c->ncorr;
+    if (total < 1 || total > 32 || c->bstate->multidot_chunked)
+    {
+        set_error("lbfgsx_b_solve_wty: needs 1 <= 2*ncorr <= 32");
+        return LBFGSX_E_INVALID;
+    }
+    DISPATCH_T(c, {
+        if (total <= 8) rc = solve_dots_t<T, 8>(c, pmask, vsel_id, coef, theta, fmask, wty);
+        else if (total <= 16) rc = solve_dots_t<T, 16>(c, pmask, vsel_id, coef, theta, fmask, wty);
+        else if (total <= 24) rc = solve_dots_t<T, 24>(c, pmask, vsel_id, coef, theta, fmask, wty);
+        else rc = solve_dots_t<T, 32>(c, pmask, vsel_id, coef, theta, fmask, wty);
+    });
     return rc;
 }
 

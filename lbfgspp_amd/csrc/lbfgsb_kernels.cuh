@@ -267,6 +267,73 @@ __global__ void __launch_bounds__(kBlock) k_multidot(Cols<T, NC> cols, int ncols
             out[k] = double(T(acc[k].value()));
 }
 
+// The same masked multi-dot for ALL 2c columns in one launch (K4): each thread takes one 16-byte vector of
+// consecutive rows per column, so 2c independent 16-byte loads are in flight per thread and v, the state byte and
+// the launch/reduction overhead are paid once instead of once per 8 columns.  out[0..ncols) dots, out[NC] nnz.
+template <class T, int NC>
+__global__ void __launch_bounds__(kBlock) k_multidot_all(Cols<T, 32> cols, int ncols, BVecs<T> b, int vsel_id,
+                                                         const T* __restrict__ vcol, int mask, int64_t n, RedWs ws,
+                                                         double* __restrict__ out)
+{
+    typedef typename AccOf<T>::type A;
+    constexpr int W = Vec16<T>::W;
+    A acc[NC + 1];
+    const int64_t nv = n / W;
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t vi = int64_t(blockIdx.x) * kBlock + threadIdx.x; vi < nv; vi += stride)
+    {
+        const int64_t r0 = vi * W;
+        bool in[W];
+        bool any = false;
+#pragma unroll
+        for (int e = 0; e < W; e++)
+        {
+            in[e] = !mask || (b.st[r0 + e] & mask);
+            any = any || in[e];
+        }
+        if (!any)
+            continue;
+        T v[W];
+#pragma unroll
+        for (int e = 0; e < W; e++)
+        {
+            v[e] = in[e] ? (vcol ? vcol[r0 + e] : vsel(b, vsel_id, r0 + e)) : T(0);
+            if (in[e] && v[e] != T(0))
+                acc[NC].add(T(1));
+        }
+        Pack<T> pc[NC];
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+            if (k < ncols)
+                pc[k] = ldv<T>(cols.p[k], vi);
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+            if (k < ncols)
+            {
+#pragma unroll
+                for (int e = 0; e < W; e++)
+                    if (in[e])
+                        acc[k].add_prod(pc[k].e[e], v[e]);
+            }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int64_t i = nv * W; i < n; i++)
+        {
+            if (mask && !(b.st[i] & mask))
+                continue;
+            const T v = vcol ? vcol[i] : vsel(b, vsel_id, i);
+            if (v != T(0))
+                acc[NC].add(T(1));
+#pragma unroll
+            for (int k = 0; k < NC; k++)
+                if (k < ncols)
+                    acc[k].add_prod(cols.p[k][i], v);
+        }
+    if (grid_reduce<NC + 1>(acc, ws) && threadIdx.x == 0)
+        for (int k = 0; k <= NC; k++)
+            out[k] = double(T(acc[k].value()));
+}
+
 // ---------------------------------------------------------------- masked Gram block: out[a*TB+c] = sum_{i in mask} I_a[i] * J_c[i]
 // (BFGSMat.h:543-556: WP'WP blocks of solve_PtBP)
 template <class T, int TB>
@@ -422,14 +489,38 @@ __global__ void __launch_bounds__(kBlock) k_gram_mfma(Cols<T, 32> cols, int ncol
 //     rows: two LDS reads (all lanes read the same row -> distinct banks or broadcast) and one compensated
 //     accumulate per pair per row.  The work is proportional to |P|, not n.
 // No __syncthreads in the main loop (tiles are wave private); per-block partials are summed by k_gram_finish.
+// Optional element-wise prologue of the one-pass Gram: the combine statement that produces the vector v the Gram's
+// last column is made of, evaluated on the row the lane has just loaded (so W_P * coef costs no second pass):
+//   GP_RHS     rhs_i = (rhs_i + -(W_P coef1)_i) + -(W_P coef2)_i ; v_i = -rhs_i    apply_PtBQv x2 (BFGSMat.h:570-594)
+//   GP_LINEAR  cF_i  = -1 * (W_F coef1)_i + g_i               ; v_i = -cF_i     compute_FtBAb (BFGSMat.h:486-522)
+// with the products accumulated exactly as k_wcombine does (Y columns then S columns, plain T).
+enum { GP_NONE = 0, GP_RHS = 1, GP_LINEAR = 2 };
+template <class T>
+struct GramPrologue
+{
+    int mode;
+    int use1, use2;  // which coefficient vectors are present
+    T c1[64], c2[64];
+};
+
 constexpr int kGramDDRows = 64;
 constexpr int kGramDDCS = 31;  // tile row stride (doubles): odd, >= ntot
 
 template <class T, int KP>
 __global__ void __launch_bounds__(kBlock) k_gram_dd(Cols<T, 32> cols, int ncols, BVecs<T> b, int vsel_id, int mask,
-                                                    int64_t n, double* __restrict__ partial)
+                                                    int64_t n, double* __restrict__ partial, GramPrologue<T> pro)
 {
     __shared__ double tile[(kBlock / 64) * kGramDDRows * kGramDDCS];
+    __shared__ T pc1[64], pc2[64];
+    if (pro.mode != GP_NONE)
+    {
+        if (threadIdx.x < 64)
+        {
+            pc1[threadIdx.x] = pro.c1[threadIdx.x];
+            pc2[threadIdx.x] = pro.c2[threadIdx.x];
+        }
+        __syncthreads();
+    }
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ntot = ncols + (vsel_id >= 0 ? 1 : 0);
     const int npairs = ntot * (ntot + 1) / 2;
@@ -473,6 +564,28 @@ __global__ void __launch_bounds__(kBlock) k_gram_dd(Cols<T, 32> cols, int ncols,
                 for (int u = 0; u < 8; u++)
                     if (c0 + u < ncols)
                         row[c0 + u] = v[u];
+            }
+            if (pro.mode != GP_NONE)
+            {
+                // (W * coef)(row): columns in order, plain accumulation -- the statement k_wcombine evaluates
+                T a1 = T(0), a2 = T(0);
+                if (pro.use1)
+                    for (int j = 0; j < ncols; j++)
+                        a1 = a1 + T(row[j]) * pc1[j];
+                if (pro.use2)
+                    for (int j = 0; j < ncols; j++)
+                        a2 = a2 + T(row[j]) * pc2[j];
+                if (pro.mode == GP_RHS)
+                {
+                    T rh = b.rhs[r];
+                    if (pro.use1)
+                        rh = rh + (-a1);
+                    if (pro.use2)
+                        rh = rh + (-a2);
+                    b.rhs[r] = rh;
+                }
+                else
+                    b.cF[r] = (pro.use1 ? (T(-1) * a1) : T(0)) + b.g[r];
             }
             if (vsel_id >= 0)
                 row[ncols] = double(vsel(b, vsel_id, r));
@@ -682,16 +795,22 @@ enum
     CB_MU = 4        // mu_i = -((-1*accp) + (cF_i + theta*y_i))    SubspaceMin.h:265-267
 };
 
+template <class T>
+struct CoefArg  // 2c coefficients passed by value in the kernel arguments (no staging copy, no host sync)
+{
+    T c[80];
+};
+
 template <class T, int MODE>
 __global__ void __launch_bounds__(kBlock) k_wcombine(BVecs<T> b, const T* __restrict__ S, const T* __restrict__ Y,
                                                      int64_t ld, const int* __restrict__ phys, int ncorr,
-                                                     const T* __restrict__ coef, int has_w, int mask, int vsel_id,
+                                                     CoefArg<T> coef, int has_w, int mask, int vsel_id,
                                                      T theta, int64_t n)
 {
     __shared__ T sc[80];
     __shared__ int sp[40];
     if (threadIdx.x < 2 * ncorr)
-        sc[threadIdx.x] = coef[threadIdx.x];
+        sc[threadIdx.x] = coef.c[threadIdx.x];
     if (threadIdx.x < ncorr)
         sp[threadIdx.x] = phys[threadIdx.x];
     __syncthreads();
@@ -737,6 +856,101 @@ __global__ void __launch_bounds__(kBlock) k_wcombine(BVecs<T> b, const T* __rest
                 b.mu[i] = -r;
         }
     }
+}
+
+// CB_SOLVE on the rows of `pmask` fused with the masked multi-dot W_F' y over `fmask` (pmask is a subset of fmask):
+//   y_i = v_i/theta + (W_P coef)_i/theta^2 on P      solve_PtBP result, BFGSMat.h:564   (k_wcombine<CB_SOLVE>)
+//   out[k] = sum_{i in F} col_k[i] * y_i              apply_WtPv for the multipliers, SubspaceMin.h:249-254
+// The row that was loaded for the combine is reused for the dots, so the multipliers' W'y costs no pass of its
+// own.  One 16-byte vector of consecutive rows per column and thread, as k_multidot_all.
+template <class T, int NC>
+__global__ void __launch_bounds__(kBlock) k_solve_dots(Cols<T, 32> cols, int ncols, BVecs<T> b, int vsel_id, CoefArg<T> coef,
+                                                       int has_w, int pmask, int fmask, T theta, int64_t n, RedWs ws,
+                                                       double* __restrict__ out)
+{
+    typedef typename AccOf<T>::type A;
+    constexpr int W = Vec16<T>::W;
+    __shared__ T sc[80];
+    if (threadIdx.x < 80)
+        sc[threadIdx.x] = coef.c[threadIdx.x];
+    __syncthreads();
+    const T theta2 = theta * theta;
+    A acc[NC];
+    const int64_t nv = n / W;
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t vi = int64_t(blockIdx.x) * kBlock + threadIdx.x; vi < nv; vi += stride)
+    {
+        const int64_t r0 = vi * W;
+        unsigned char st[W];
+        bool any = false;
+#pragma unroll
+        for (int e = 0; e < W; e++)
+        {
+            st[e] = b.st[r0 + e];
+            any = any || (st[e] & fmask);
+        }
+        if (!any)
+            continue;
+        Pack<T> pc[NC];
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+            if (k < ncols)
+                pc[k] = ldv<T>(cols.p[k], vi);
+#pragma unroll
+        for (int e = 0; e < W; e++)
+        {
+            if (!(st[e] & fmask))
+                continue;
+            T yi;
+            if (st[e] & pmask)
+            {
+                T a = T(0);
+                if (has_w)
+                {
+#pragma unroll
+                    for (int k = 0; k < NC; k++)
+                        if (k < ncols)
+                            a = a + pc[k].e[e] * sc[k];
+                }
+                const T v = vsel(b, vsel_id, r0 + e);
+                yi = has_w ? (v / theta + a / theta2) : (v / theta);
+                b.y[r0 + e] = yi;
+            }
+            else
+                yi = b.y[r0 + e];
+#pragma unroll
+            for (int k = 0; k < NC; k++)
+                if (k < ncols)
+                    acc[k].add_prod(pc[k].e[e], yi);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int64_t i = nv * W; i < n; i++)
+        {
+            const unsigned char s = b.st[i];
+            if (!(s & fmask))
+                continue;
+            T yi;
+            if (s & pmask)
+            {
+                T a = T(0);
+                if (has_w)
+                    for (int k = 0; k < ncols; k++)
+                        a = a + cols.p[k][i] * sc[k];
+                const T v = vsel(b, vsel_id, i);
+                yi = has_w ? (v / theta + a / theta2) : (v / theta);
+                b.y[i] = yi;
+            }
+            else
+                yi = b.y[i];
+#pragma unroll
+            for (int k = 0; k < NC; k++)
+                if (k < ncols)
+                    acc[k].add_prod(cols.p[k][i], yi);
+        }
+    if (grid_reduce<NC>(acc, ws) && threadIdx.x == 0)
+        for (int k = 0; k < NC; k++)
+            out[k] = double(T(acc[k].value()));
 }
 
 // BOXCQP partition (SubspaceMin.h:194-219); out = {#L, #U, #P}

@@ -19,7 +19,7 @@ namespace lbfgsx {
 
 constexpr int kBlock = 256;      // 4 waves of 64
 constexpr int kWaves = kBlock / 64;
-constexpr int kMaxRed = 16;      // max simultaneous reductions per kernel (4x4 Gram tile)
+constexpr int kMaxRed = 40;      // max simultaneous reductions per kernel (2c + 1 <= 33 masked dots in one pass)
 
 // ---------------------------------------------------------------- accumulators
 struct DD
