@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(kBlock) k_multidot(Cols<T, NC> cols, int ncols
 // consecutive rows per column, so 2c independent 16-byte loads are in flight per thread and v, the state byte and
 // the launch/reduction overhead are paid once instead of once per 8 columns.  out[0..ncols) dots, out[NC] nnz.
 template <class T, int NC>
-__global__ void __launch_bounds__(kBlock) k_multidot_all(Cols<T, 32> cols, int ncols, BVecs<T> b, int vsel_id,
+__global__ void __launch_bounds__(kBlock, 2) k_multidot_all(Cols<T, 32> cols, int ncols, BVecs<T> b, int vsel_id,
                                                          const T* __restrict__ vcol, int mask, int64_t n, RedWs ws,
                                                          double* __restrict__ out)
 {
@@ -862,92 +862,52 @@ __global__ void __launch_bounds__(kBlock) k_wcombine(BVecs<T> b, const T* __rest
 //   y_i = v_i/theta + (W_P coef)_i/theta^2 on P      solve_PtBP result, BFGSMat.h:564   (k_wcombine<CB_SOLVE>)
 //   out[k] = sum_{i in F} col_k[i] * y_i              apply_WtPv for the multipliers, SubspaceMin.h:249-254
 // The row that was loaded for the combine is reused for the dots, so the multipliers' W'y costs no pass of its
-// own.  One 16-byte vector of consecutive rows per column and thread, as k_multidot_all.
+// own.  One row per thread (as k_wcombine): the 2c loads of a row are independent and in flight together.
 template <class T, int NC>
 __global__ void __launch_bounds__(kBlock) k_solve_dots(Cols<T, 32> cols, int ncols, BVecs<T> b, int vsel_id, CoefArg<T> coef,
                                                        int has_w, int pmask, int fmask, T theta, int64_t n, RedWs ws,
                                                        double* __restrict__ out)
 {
     typedef typename AccOf<T>::type A;
-    constexpr int W = Vec16<T>::W;
     __shared__ T sc[80];
     if (threadIdx.x < 80)
         sc[threadIdx.x] = coef.c[threadIdx.x];
     __syncthreads();
     const T theta2 = theta * theta;
     A acc[NC];
-    const int64_t nv = n / W;
     const int64_t stride = int64_t(gridDim.x) * kBlock;
-    for (int64_t vi = int64_t(blockIdx.x) * kBlock + threadIdx.x; vi < nv; vi += stride)
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
     {
-        const int64_t r0 = vi * W;
-        unsigned char st[W];
-        bool any = false;
-#pragma unroll
-        for (int e = 0; e < W; e++)
-        {
-            st[e] = b.st[r0 + e];
-            any = any || (st[e] & fmask);
-        }
-        if (!any)
+        const unsigned char st = b.st[i];
+        if (!(st & fmask))
             continue;
-        Pack<T> pc[NC];
+        T w[NC];  // the row of W: loaded once, used by the combine and by the dots
 #pragma unroll
         for (int k = 0; k < NC; k++)
             if (k < ncols)
-                pc[k] = ldv<T>(cols.p[k], vi);
-#pragma unroll
-        for (int e = 0; e < W; e++)
+                w[k] = cols.p[k][i];
+        T yi;
+        if (st & pmask)
         {
-            if (!(st[e] & fmask))
-                continue;
-            T yi;
-            if (st[e] & pmask)
+            T a = T(0);
+            if (has_w)
             {
-                T a = T(0);
-                if (has_w)
-                {
 #pragma unroll
-                    for (int k = 0; k < NC; k++)
-                        if (k < ncols)
-                            a = a + pc[k].e[e] * sc[k];
-                }
-                const T v = vsel(b, vsel_id, r0 + e);
-                yi = has_w ? (v / theta + a / theta2) : (v / theta);
-                b.y[r0 + e] = yi;
+                for (int k = 0; k < NC; k++)
+                    if (k < ncols)
+                        a = a + w[k] * sc[k];
             }
-            else
-                yi = b.y[r0 + e];
-#pragma unroll
-            for (int k = 0; k < NC; k++)
-                if (k < ncols)
-                    acc[k].add_prod(pc[k].e[e], yi);
+            const T v = vsel(b, vsel_id, i);
+            yi = has_w ? (v / theta + a / theta2) : (v / theta);
+            b.y[i] = yi;
         }
+        else
+            yi = b.y[i];
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+            if (k < ncols)
+                acc[k].add_prod(w[k], yi);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        for (int64_t i = nv * W; i < n; i++)
-        {
-            const unsigned char s = b.st[i];
-            if (!(s & fmask))
-                continue;
-            T yi;
-            if (s & pmask)
-            {
-                T a = T(0);
-                if (has_w)
-                    for (int k = 0; k < ncols; k++)
-                        a = a + cols.p[k][i] * sc[k];
-                const T v = vsel(b, vsel_id, i);
-                yi = has_w ? (v / theta + a / theta2) : (v / theta);
-                b.y[i] = yi;
-            }
-            else
-                yi = b.y[i];
-#pragma unroll
-            for (int k = 0; k < NC; k++)
-                if (k < ncols)
-                    acc[k].add_prod(cols.p[k][i], yi);
-        }
     if (grid_reduce<NC>(acc, ws) && threadIdx.x == 0)
         for (int k = 0; k < NC; k++)
             out[k] = double(T(acc[k].value()));
