@@ -241,6 +241,15 @@ typedef struct
     double step;  /* trial step, or the scale a of the two-loop INIT */
 } lbfgsx_bat_desc;
 enum { LBFGSX_BAT_EVAL = 0, LBFGSX_BAT_TRIAL = 1, LBFGSX_BAT_POST = 2, LBFGSX_BAT_TWOLOOP = 3 };
+/* per-problem description of a whole apply_Hv (BFGSMat.h:276-302): d = -H grad(x_in), with the history columns
+ * pcol[0..ncorr) newest -> oldest (physical column ids) */
+typedef struct
+{
+    int active;
+    int x_in;   /* which of the 3 points holds the gradient */
+    int ncorr;
+    int pcol[32];
+} lbfgsx_bat_hvdesc;
 int lbfgsx_bat_create(lbfgsx_batch** out, int dtype, int64_t n, int m, int nproblems, int device);
 void lbfgsx_bat_destroy(lbfgsx_batch* c);
 /* index of a scalar inside a problem's table: kind 0 = ys[col], 1 = theta[col], 2 = two-loop dot k, 3 = output k */
@@ -249,6 +258,14 @@ int lbfgsx_bat_scalar_index(const lbfgsx_batch* c, int kind, int k);
 int lbfgsx_bat_gen_rosen_x0(lbfgsx_batch* c, uint64_t seed0);
 /* one launch for the whole batch; desc = P descriptors; then out[p*nout + k] = scalar (desc[p].i_out + k) */
 int lbfgsx_bat_launch(lbfgsx_batch* c, int kind, int objective, const lbfgsx_bat_desc* desc, int nout, double* out);
+/* The whole two-loop recursion of every active problem in ONE launch: one 256-thread block per problem keeps its q
+ * vector in registers across the 2c+1 steps (block-level reductions only, no grid synchronisation), so the history
+ * is read once and q never travels: (4c+2) n elements instead of (8c+1) n.  Same element-wise arithmetic and
+ * order-independent reductions as the step kernels, hence bit-identical results.  The final dot (grad . d) lands in
+ * scalar dot(2*ncorr) of each problem, as after the step-wise sequence.  Applicable when the vector fits the block's
+ * registers (n a multiple of the 16-byte vector width and n <= 256 * 98 * width: 100352 floats / 50176 doubles);
+ * LBFGSX_E_INVALID otherwise -- the caller then issues the LBFGSX_BAT_TWOLOOP steps. */
+int lbfgsx_bat_apply_Hv(lbfgsx_batch* c, const lbfgsx_bat_hvdesc* desc);
 /* out[p] = scalar idx[p] of problem p */
 int lbfgsx_bat_fetch(lbfgsx_batch* c, const int* idx, double* out);
 int lbfgsx_bat_download_x(lbfgsx_batch* c, int p, int point, void* host);

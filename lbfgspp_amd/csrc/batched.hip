@@ -352,6 +352,196 @@ __global__ void __launch_bounds__(kBlock) kb_twoloop(BatBufs<T> b, const BatDesc
         sc[de.i_out] = T(acc[0].value());
 }
 
+
+// ---------------------------------------------------------------- whole two-loop recursion, one block per problem
+// q (= the direction being built) stays on the CU for the whole recursion: 256 threads, one wavefront per SIMD so
+// that a lane owns the full 512-entry register file; the first 83 16-byte slots of a thread live in registers, the
+// overflow (<= 15 slots, 60 KB) in LDS.  Per step the block streams the two history columns involved, updates
+// its slice of q and reduces the next dot product inside the block (wave shuffles -> LDS -> thread 0).  Each step is
+// one straight-line block of code (mode hoisted, out-of-range slots clamped and zero-weighted instead of branched
+// around) so that the scheduler keeps as many loads in flight as registers allow.  The step sequence, the
+// coefficient formulas and the rounding points (every dot is rounded to T before use) are those of
+// kb_twoloop / apply_Hv_t, so the result is bit-identical to the step-wise launches.
+typedef lbfgsx_bat_hvdesc BatHvDesc;
+constexpr int kHvThreads = 256;
+constexpr int kHvRegSlots = 83;
+
+// One code path for the four step kinds, selected by wave-uniform values (a single instance of the slot code keeps
+// the register-resident q free of per-kind copies):
+//   init            q = -1 * v                         (BFGSMat.h:283, a = -1)
+//   otherwise       q = q + c * u                      c = -alpha (first loop, :289: q - alpha*y == q + (-alpha)*y
+//                                                      exactly) or alpha - beta (second loop, :299)
+//   always          q = q / theta afterwards           (:293; theta = 1 outside the division step)
+//   dot operand     w, or u itself when dot_u (the SUBDIV step reduces against the column it just subtracted)
+template <class T, int NR, int NL, class A>
+__device__ __forceinline__ void hv_step(Pack<T> (&rq)[NR], typename Vec16<T>::type* lq, const T* u, const T* w,
+                                        bool init, T c, T theta, int64_t nv, int tid, A (&acc)[4])
+{
+    constexpr int W = Vec16<T>::W;
+    constexpr int U = 6;  // slots per chunk: 2 U 16-byte loads in flight per thread, then the arithmetic
+#pragma unroll
+    for (int s0 = 0; s0 < NR + NL; s0 += U)
+    {
+        Pack<T> pu[U], pw[U];
+        bool ok[U];
+#pragma unroll
+        for (int k = 0; k < U; k++)
+            if (s0 + k < NR + NL)
+            {
+                const int64_t vi = int64_t(s0 + k) * kHvThreads + tid;
+                ok[k] = vi < nv;
+                const int64_t vc = ok[k] ? vi : int64_t(0);  // always a valid address; zero-weighted below
+                pu[k] = ldv<T, true>(u, vc);
+                pw[k] = ldv<T, true>(w, vc);
+            }
+#pragma unroll
+        for (int k = 0; k < U; k++)
+            if (s0 + k < NR + NL)
+            {
+                constexpr int dummy = 0;
+                const int s = s0 + k;
+                Pack<T> cur;
+                if (s < NR)
+                    cur = rq[s < NR ? s : dummy];
+                else
+                    cur.v = lq[(s < NR ? dummy : s - NR) * kHvThreads + tid];
+#pragma unroll
+                for (int e = 0; e < W; e++)
+                {
+                    const T upd = cur.e[e] + c * pu[k].e[e];
+                    const T ini = T(-1) * pu[k].e[e];
+                    cur.e[e] = init ? ini : upd;
+                }
+                // x / 1 == x exactly, so the division runs in every step with theta = 1 outside the division step:
+                // a per-slot branch here makes the register allocator keep two copies of q (measured: 8 instead of
+                // 4 registers per slot, i.e. spills at 98 slots); the extra VALU work hides behind the loads
+#pragma unroll
+                for (int e = 0; e < W; e++)
+                    cur.e[e] = cur.e[e] / theta;
+#pragma unroll
+                for (int e = 0; e < W; e++)
+                    acc[(k * W + e) & 3].add_prod(ok[k] ? pw[k].e[e] : T(0), ok[k] ? cur.e[e] : T(0));
+                if (s < NR)
+                    rq[s < NR ? s : dummy] = cur;
+                else
+                    lq[(s < NR ? dummy : s - NR) * kHvThreads + tid] = cur.v;
+            }
+        // keep the next chunk's loads from being hoisted over this one (compiler-level and scheduler-level fence)
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <class T, int NQ>
+__global__ void __launch_bounds__(kHvThreads) kb_twoloop_full(BatBufs<T> b, const BatHvDesc* __restrict__ desc, int64_t n,
+                                                              int m)
+{
+    const int p = blockIdx.x;
+    __shared__ BatHvDesc de;  // dynamic indexing of pcol[]: keep it out of scratch
+    if (threadIdx.x == 0)
+        de = desc[p];
+    __syncthreads();
+    if (!de.active)
+        return;
+    typedef typename AccOf<T>::type A;
+    constexpr int W = Vec16<T>::W;
+    constexpr int NR = NQ > kHvRegSlots ? kHvRegSlots : NQ;
+    constexpr int NL = NQ - NR;
+    __shared__ typename Vec16<T>::type lq[(NL > 0 ? NL : 1) * kHvThreads];
+    __shared__ double sh[2][kHvThreads / 64];
+    __shared__ T sdot[2 * 32 + 2];
+    T* sc = b.scal(p);
+    T* q = b.d(p);
+    const T* g = b.g(de.x_in, p);
+    const int cn = de.ncorr;
+    const int64_t nv = n / W;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    auto YS = [&](int col) { return sc[col]; };                // ScLayout::ys
+    auto TH = [&](int col) { return sc[(m + 1) + col]; };      // ScLayout::theta
+    const int DOT0 = 2 * (m + 1) + 1;                          // ScLayout::dot(0)
+
+    Pack<T> rq[NR];
+    for (int L = 0; L <= 2 * cn; L++)
+    {
+        A acc4[4];  // independent chains: the order-independent sums make any split legal
+        const T* u;
+        const T* w;
+        T c = T(0), theta = T(1);
+        if (L == 0)
+        {
+            u = g;
+            w = cn > 0 ? b.s(de.pcol[0], p) : g;
+        }
+        else if (L < cn)
+        {
+            u = b.y(de.pcol[L - 1], p);
+            w = b.s(de.pcol[L], p);
+            c = -(sdot[L - 1] / YS(de.pcol[L - 1]));
+        }
+        else if (L == cn)
+        {
+            u = b.y(de.pcol[cn - 1], p);
+            w = u;
+            c = -(sdot[cn - 1] / YS(de.pcol[cn - 1]));
+            theta = TH(de.pcol[0]);
+        }
+        else
+        {
+            const int t = L - cn - 1, i = cn - 1 - t;
+            u = b.s(de.pcol[i], p);
+            w = (t < cn - 1) ? b.y(de.pcol[i - 1], p) : g;
+            c = sdot[i] / YS(de.pcol[i]) - sdot[L - 1] / YS(de.pcol[i]);
+        }
+        // an opaque copy of the thread index per step: everything derived from it (slot addresses, range masks) is
+        // recomputed inside the step instead of being hoisted out of the L loop and kept in ~4 registers per slot
+        int tid_step = tid;
+        asm volatile("" : "+v"(tid_step));
+        hv_step<T, NR, NL>(rq, lq, u, w, L == 0, c, theta, nv, tid_step, acc4);
+        A acc = acc4[0];
+        for (int k = 1; k < 4; k++)
+            acc.merge(acc4[k].hi, acc_lo(acc4[k]));
+        // block reduction of the dot (order-independent accumulators)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+        {
+            const double ohi = __shfl_down(acc.hi, off, 64);
+            const double olo = __shfl_down(acc_lo(acc), off, 64);
+            acc.merge(ohi, olo);
+        }
+        if (lane == 0)
+        {
+            sh[0][wave] = acc.hi;
+            sh[1][wave] = acc_lo(acc);
+        }
+        __syncthreads();
+        if (tid == 0)
+        {
+            A t;
+            for (int wv = 0; wv < kHvThreads / 64; wv++)
+                t.merge(sh[0][wv], sh[1][wv]);
+            const T r = T(t.value());
+            sdot[L] = r;
+            sc[DOT0 + L] = r;
+        }
+        __syncthreads();
+    }
+    // the finished direction goes to memory once
+#pragma unroll
+    for (int s = 0; s < NQ; s++)
+    {
+        const int64_t vi = int64_t(s) * kHvThreads + tid;
+        if (vi < nv)
+        {
+            Pack<T> cur;
+            if (s < NR)
+                cur = rq[s < NR ? s : 0];
+            else
+                cur.v = lq[(s < NR ? 0 : s - NR) * kHvThreads + tid];
+            stv<T, false>(q, vi, cur);
+        }
+    }
+}
+
 }  // namespace lbfgsx
 
 using namespace lbfgsx;
@@ -371,6 +561,9 @@ struct lbfgsx_batch
     ScLayout sl;
     bool zigzag = true;
     unsigned tl_step = 0;
+    bool fused_hv = true;  // LBFGSX_BAT_FUSED_HV=0: always the step-wise two-loop launches
+    lbfgsx_bat_hvdesc* hvdesc_dev = nullptr;
+    lbfgsx_bat_hvdesc* hvdesc_host = nullptr;
 };
 
 #define BAT_DISPATCH(c, ...)          \
@@ -442,6 +635,8 @@ int lbfgsx_bat_create(lbfgsx_batch** out, int dtype, int64_t n, int m, int nprob
     int64_t gx = std::max<int64_t>(1, std::min<int64_t>(gx_n, 1024 / std::max(nproblems, 1)));
     if (const char* e = getenv("LBFGSX_ZIGZAG"))
         c->zigzag = atoi(e) != 0;
+    if (const char* e = getenv("LBFGSX_BAT_FUSED_HV"))
+        c->fused_hv = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_BAT_GX"))
         gx = std::max(1, std::min(atoi(e), 256));
     c->gx = int(gx);
@@ -470,7 +665,9 @@ void lbfgsx_bat_destroy(lbfgsx_batch* c)
         return;
     (void) hipSetDevice(c->device);
     (void) hipStreamSynchronize(c->stream);
-    void* ptrs[] = {c->X, c->G, c->D, c->S, c->Y, c->sc, c->ws.partials, c->ws.ticket, c->desc_dev};
+    void* ptrs[] = {c->X, c->G, c->D, c->S, c->Y, c->sc, c->ws.partials, c->ws.ticket, c->desc_dev, c->hvdesc_dev};
+    if (c->hvdesc_host)
+        (void) hipHostFree(c->hvdesc_host);
     for (void* p : ptrs)
         (void) hipFree(p);
     (void) hipHostFree(c->hout);
@@ -545,6 +742,39 @@ int lbfgsx_bat_launch(lbfgsx_batch* c, int kind, int objective, const lbfgsx_bat
                     out[size_t(p) * nout + k] = double(tab[size_t(p) * size_t(c->scn) + size_t(hd[p].i_out + k)]);
         });
     }
+    return LBFGSX_OK;
+}
+
+int lbfgsx_bat_apply_Hv(lbfgsx_batch* c, const lbfgsx_bat_hvdesc* desc)
+{
+    const int64_t w = (c->dtype == LBFGSX_F64) ? 2 : 4;
+    const int64_t nv = c->n / w;
+    if (!c->fused_hv || (c->n % w) != 0 || nv > int64_t(kHvThreads) * 98 || c->m > 32)
+    {
+        set_error("lbfgsx_bat_apply_Hv: vector does not fit one block's registers");
+        return LBFGSX_E_INVALID;
+    }
+    LBFGSX_HIP(hipStreamSynchronize(c->stream));  // the pinned staging may still be in flight
+    if (!c->hvdesc_dev)
+    {
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&c->hvdesc_dev), sizeof(BatHvDesc) * size_t(c->P)));
+        LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->hvdesc_host), sizeof(BatHvDesc) * size_t(c->P), hipHostMallocDefault));
+    }
+    std::memcpy(c->hvdesc_host, desc, sizeof(BatHvDesc) * size_t(c->P));
+    LBFGSX_HIP(hipMemcpyAsync(c->hvdesc_dev, c->hvdesc_host, sizeof(BatHvDesc) * size_t(c->P), hipMemcpyHostToDevice, c->stream));
+    const int slots = int((nv + kHvThreads - 1) / kHvThreads);
+    BAT_DISPATCH(c, {
+        BatBufs<T> b = bufs<T>(c);
+        if (slots <= 14)
+            hipLaunchKernelGGL((kb_twoloop_full<T, 14>), dim3(c->P), dim3(kHvThreads), 0, c->stream, b, c->hvdesc_dev, c->n, c->m);
+        else if (slots <= 28)
+            hipLaunchKernelGGL((kb_twoloop_full<T, 28>), dim3(c->P), dim3(kHvThreads), 0, c->stream, b, c->hvdesc_dev, c->n, c->m);
+        else if (slots <= 56)
+            hipLaunchKernelGGL((kb_twoloop_full<T, 56>), dim3(c->P), dim3(kHvThreads), 0, c->stream, b, c->hvdesc_dev, c->n, c->m);
+        else
+            hipLaunchKernelGGL((kb_twoloop_full<T, 98>), dim3(c->P), dim3(kHvThreads), 0, c->stream, b, c->hvdesc_dev, c->n, c->m);
+    });
+    LBFGSX_HIP(hipGetLastError());
     return LBFGSX_OK;
 }
 
