@@ -112,7 +112,47 @@ public:
         };
 
         // two-loop recursion for every active problem: drt = -H grad, dg = grad.drt   (LBFGS.h:106,123,165)
+        bool fused_hv = (m <= 32);  // one launch for the whole recursion while the device accepts it (fits in registers)
+        std::vector<lbfgsx_bat_hvdesc> hvdesc(static_cast<size_t>(P));
+        auto fetch_dg = [&]() {
+            std::vector<int> idx(static_cast<size_t>(P));
+            std::vector<double> dg(static_cast<size_t>(P));
+            for (int p = 0; p < P; p++)
+                idx[size_t(p)] = DOT(2 * pr[size_t(p)].ncorr);
+            detail::check(lbfgsx_bat_fetch(c, idx.data(), dg.data()));
+            for (int p = 0; p < P; p++)
+                pr[size_t(p)].dg = Scalar(dg[size_t(p)]);
+        };
         auto apply_Hv = [&]() {
+            if (fused_hv)
+            {
+                for (int p = 0; p < P; p++)
+                {
+                    Prob& q = pr[size_t(p)];
+                    lbfgsx_bat_hvdesc& d = hvdesc[size_t(p)];
+                    d = lbfgsx_bat_hvdesc();
+                    if (q.done)
+                        continue;
+                    d.active = 1;
+                    d.x_in = q.cur;
+                    d.ncorr = q.ncorr;
+                    int j = q.ptr % m;
+                    for (int i = 0; i < q.ncorr; i++)
+                    {
+                        j = (j + m - 1) % m;
+                        d.pcol[i] = q.phys[size_t(j)];
+                    }
+                }
+                const int rc = lbfgsx_bat_apply_Hv(c, hvdesc.data());
+                if (rc == LBFGSX_OK)
+                {
+                    fetch_dg();
+                    return;
+                }
+                if (rc != LBFGSX_E_INVALID)
+                    detail::check(rc);
+                fused_hv = false;  // not applicable for this n / m: step-wise launches from now on
+            }
             int lmax = 0;
             for (int p = 0; p < P; p++)
                 if (!pr[size_t(p)].done)
@@ -172,13 +212,7 @@ public:
                 }
                 detail::check(lbfgsx_bat_launch(c, LBFGSX_BAT_TWOLOOP, LBFGSX_OBJ_EXT_ROSENBROCK, desc.data(), 0, nullptr));
             }
-            std::vector<int> idx(static_cast<size_t>(P));
-            std::vector<double> dg(static_cast<size_t>(P));
-            for (int p = 0; p < P; p++)
-                idx[size_t(p)] = DOT(2 * pr[size_t(p)].ncorr);
-            detail::check(lbfgsx_bat_fetch(c, idx.data(), dg.data()));
-            for (int p = 0; p < P; p++)
-                pr[size_t(p)].dg = Scalar(dg[size_t(p)]);
+            fetch_dg();
         };
 
         // fx = f(x, grad); gnorm                                                   (LBFGS.h:91-103)

@@ -41,8 +41,11 @@ def test_batched_is_deterministic_across_thread_counts():
     assert np.array_equal(a, b)
 
 
+# n = 4098 (not a multiple of the vector width) takes the step-wise two-loop launches, the others the one-launch
+# register-resident recursion (lbfgsx_bat_apply_Hv) in its 14 / 56 / 98-slot variants (98: with the LDS overflow)
 @pytest.mark.parametrize("dtype,n,m,iters,count", [(np.float32, 4098, 10, 14, 9), (np.float64, 2048, 5, 20, 5),
-                                                   (np.float32, 1000, 3, 40, 17)])
+                                                   (np.float32, 1000, 3, 40, 17), (np.float32, 100000, 10, 7, 3),
+                                                   (np.float64, 50000, 7, 6, 2), (np.float32, 30000, 4, 8, 3)])
 def test_lockstep_batch_is_bit_identical_to_single_solves(dtype, n, m, iters, count):
     """every problem of the lock-step batch == LBFGSSolver<T, LineSearchMoreThuente> on the same start point,
     including problems that hit max_linesearch / converge at different iterations"""
@@ -73,3 +76,19 @@ def test_lockstep_equals_threaded_batch():
     a = B.solve_local(par, A.ExtendedRosenbrock.objective, 4096, 0, 24, dtype=np.float32, nthreads=4)
     b = B.solve_local_lockstep(par, 4096, 0, 24, dtype=np.float32)
     assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("dtype,n", [(np.float32, 100000), (np.float64, 20000), (np.float32, 4096)])
+def test_one_launch_two_loop_equals_step_wise_launches(monkeypatch, dtype, n):
+    """lbfgsx_bat_apply_Hv (q resident in registers / LDS for the whole recursion) against the LBFGSX_BAT_TWOLOOP
+    step launches: identical records and iterates"""
+    import lbfgspp_amd as A
+    from lbfgspp_amd import batched as B
+    par = A.LBFGSParam(m=8, epsilon=0.0, epsilon_rel=0.0, max_iterations=11)
+    monkeypatch.setenv("LBFGSX_BAT_FUSED_HV", "1")
+    a, xa = B.solve_local_lockstep(par, n, first=0, count=5, seed_base=77, dtype=dtype, return_x=True)
+    monkeypatch.setenv("LBFGSX_BAT_FUSED_HV", "0")
+    b, xb = B.solve_local_lockstep(par, n, first=0, count=5, seed_base=77, dtype=dtype, return_x=True)
+    assert np.array_equal(a, b)
+    for u, v in zip(xa, xb):
+        assert np.array_equal(u, v)
