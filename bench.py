@@ -131,6 +131,9 @@ def main_batched(args):
     if rank == 0:
         its, fev = int(full["niter"].sum()), int(full["nfev"].sum())
         bytes_ = (its * (8 * m + 12) + (fev - its) * 4) * n * 4.0
+        # HBM traffic model of the one-launch recursion (q resident on the CU): per apply_Hv 2m history reads twice
+        # (update + dot operand) less the shared column of the division step, + g twice, + one store of d
+        hbm_ = (its * (4 * m + 2 + 12) + (fev - its) * 4) * n * 4.0
         print(json.dumps({
             "metric": "batched L-BFGS problem-iterations/sec (cfg5: n=1e5, m=10, f32)", "value": its / elapsed,
             "unit": "problem-iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -141,7 +144,10 @@ def main_batched(args):
                        "problems_total": total, "fevals_total": fev, "failed": int((full["status"] != 0).sum())},
             "roofline": {"bound": "hbm", "achieved": bytes_ / elapsed / 1e9 / world, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": bytes_ / elapsed / 1e9 / world / HBM_PEAK_GBS, "traffic": None,
-                         "note": "whole-solve algorithmic bytes per GPU / wall time (includes host control flow)"}}))
+                         "hbm_model_GBs": hbm_ / elapsed / 1e9 / world, "hbm_model_frac": hbm_ / elapsed / 1e9 / world / HBM_PEAK_GBS,
+                         "note": "achieved = SURVEY 8(d) algorithmic bytes ((8m+12) n per iteration) per GPU / wall time, host "
+                                 "control flow included; the one-launch two-loop keeps q on the CU, so the HBM traffic model "
+                                 "is (4m+14) n per iteration (hbm_model_*): achieved may exceed the HBM peak"}}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
