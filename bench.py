@@ -161,7 +161,7 @@ def main():
     ap.add_argument("--n", type=float, default=1e8)
     ap.add_argument("--m", type=int, default=10)
     ap.add_argument("--objective", default="rosenbrock", choices=["rosenbrock", "quadratic"])
-    ap.add_argument("--cpu-n", type=float, default=4e6)
+    ap.add_argument("--cpu-n", type=float, default=2e7)
     ap.add_argument("--cpu-steps", type=int, default=12)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--workload", default="north-star", choices=["north-star", "cfg5-batched"],
