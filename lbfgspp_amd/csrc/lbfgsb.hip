@@ -36,6 +36,7 @@ struct lbfgsb_state
     bool gram_mfma = false;  // opt-in (LBFGSX_GRAM=mfma): ~1 ulp per entry instead of the correctly rounded sums
     int gram_mode = 0;       // 2 (LBFGSX_GRAM=blocked): force the multi-launch blocked Gram + separate W'v
     int gram_dd_blocks = 512;
+    int dots_grid = 512;            // LBFGSX_DOTS_GRID: blocks of the all-column multi-dot kernels
     bool multidot_chunked = false;  // LBFGSX_MULTIDOT=chunked: 8 columns per launch (round-1a kernel)
     // device GCP search (gcp_scan.cuh): per-chunk work set, allocated on first use
     double *s_brk = nullptr, *s_g = nullptr, *s_z = nullptr, *s_W = nullptr, *s_P = nullptr, *s_C = nullptr,
@@ -172,6 +173,8 @@ int bounded_alloc(lbfgsx_ctx* c)
         b->gram_mfma = (std::strcmp(e, "mfma") == 0);
         b->gram_mode = (std::strcmp(e, "blocked") == 0) ? 2 : 0;
     }
+    if (const char* e = getenv("LBFGSX_DOTS_GRID"))
+        b->dots_grid = std::max(64, std::min(atoi(e), 4096));
     if (const char* e = getenv("LBFGSX_MULTIDOT"))
         b->multidot_chunked = (std::strcmp(e, "chunked") == 0);
     if (const char* e = getenv("LBFGSX_GRAM_BLOCKS"))
@@ -228,7 +231,9 @@ static int wtv_all(lbfgsx_ctx* c, int total, int vsel_id, const T* vcol, int mas
     for (int k = 0; k < total; k++)
         which[k] = k;
     Cols<T, 32> cl = col_list<T, 32>(c, which, total);
-    const int grid = c->grid_for(c->n);
+    // 2c + 1 grid reductions per launch: fewer, fatter blocks keep the reduction tail short (each thread already has
+    // 2c 16-byte loads in flight)
+    const int grid = std::min(c->grid_for(c->n), c->bstate->dots_grid);
     hipLaunchKernelGGL((k_multidot_all<T, NC>), dim3(grid), dim3(kBlock), 0, c->stream, cl, total, bvecs<T>(c), vsel_id, vcol,
                        mask, c->n, c->ws, c->bstate->dout);
     LBFGSX_HIP(hipGetLastError());
@@ -927,7 +932,7 @@ static int solve_dots_t(lbfgsx_ctx* c, int pmask, int vsel_id, const double* coe
     CoefArg<T> cf;
     for (int k = 0; k < 80; k++)
         cf.c[k] = (coef && k < total) ? T(coef[k]) : T(0);
-    const int grid = c->grid_for(c->n);
+    const int grid = std::min(c->grid_for(c->n), c->bstate->dots_grid);
     hipLaunchKernelGGL((k_solve_dots<T, NC>), dim3(grid), dim3(kBlock), 0, c->stream, cl, total, bvecs<T>(c), vsel_id, cf,
                        coef ? 1 : 0, pmask, fmask, T(theta), c->n, c->ws, c->bstate->dout);
     LBFGSX_HIP(hipGetLastError());

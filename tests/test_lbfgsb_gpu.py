@@ -270,3 +270,25 @@ def test_mfma_gram_mode_solves_the_box_qp(A, monkeypatch):
     x = np.zeros(n)
     niter, fx = s.minimize(A.DiagQuadratic(a, b), x, lb, ub)
     assert niter < 400 and np.abs(x - np.clip(b / a, lb, ub)).max() < 1e-4
+
+
+def test_fused_subspace_passes_are_bit_identical_to_the_unfused_sequence(A, monkeypatch):
+    """Default path (one-pass Gram with the rhs / linear-term prologue, solve fused with W_F'y, one-launch
+    multi-dot) against the statement-by-statement sequence (LBFGSX_GRAM=blocked, LBFGSX_MULTIDOT=chunked): the fusions
+    only remove passes over S, Y, so every iterate must agree to the last bit."""
+    n, m, iters = 30000, 8, 18
+    a, b = O.quad_problem(n, 30.0, 3, O.F64)
+    res = {}
+    for label, env in (("fused", {}), ("unfused", {"LBFGSX_GRAM": "blocked", "LBFGSX_MULTIDOT": "chunked"})):
+        for k in ("LBFGSX_GRAM", "LBFGSX_MULTIDOT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        s = A.LBFGSBSolver(A.LBFGSBParam(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters))
+        tr = A.TraceBuffer(n, cap=256, stride=7)
+        x = np.zeros(n)
+        niter, fx = s.minimize(A.DiagQuadratic(a, b), x, -0.7 * np.ones(n), 0.9 * np.ones(n), trace=tr)
+        res[label] = (niter, s.last.nfev, fx, x.copy(), tr.xs[:tr.count].copy(), s.stats()["submin_sweeps"])
+    f, u = res["fused"], res["unfused"]
+    assert f[:3] == u[:3] and f[5] == u[5] and f[5] > 0
+    assert np.array_equal(f[3], u[3]) and np.array_equal(f[4], u[4])
