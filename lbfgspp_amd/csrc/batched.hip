@@ -363,74 +363,7 @@ __global__ void __launch_bounds__(kBlock) kb_twoloop(BatBufs<T> b, const BatDesc
 // coefficient formulas and the rounding points (every dot is rounded to T before use) are those of
 // kb_twoloop / apply_Hv_t, so the result is bit-identical to the step-wise launches.
 typedef lbfgsx_bat_hvdesc BatHvDesc;
-constexpr int kHvThreads = 256;
 constexpr int kHvRegSlots = 83;
-
-// One code path for the four step kinds, selected by wave-uniform values (a single instance of the slot code keeps
-// the register-resident q free of per-kind copies):
-//   init            q = -1 * v                         (BFGSMat.h:283, a = -1)
-//   otherwise       q = q + c * u                      c = -alpha (first loop, :289: q - alpha*y == q + (-alpha)*y
-//                                                      exactly) or alpha - beta (second loop, :299)
-//   always          q = q / theta afterwards           (:293; theta = 1 outside the division step)
-//   dot operand     w, or u itself when dot_u (the SUBDIV step reduces against the column it just subtracted)
-template <class T, int NR, int NL, class A>
-__device__ __forceinline__ void hv_step(Pack<T> (&rq)[NR], typename Vec16<T>::type* lq, const T* u, const T* w,
-                                        bool init, T c, T theta, int64_t nv, int tid, A (&acc)[4])
-{
-    constexpr int W = Vec16<T>::W;
-    constexpr int U = 6;  // slots per chunk: 2 U 16-byte loads in flight per thread, then the arithmetic
-#pragma unroll
-    for (int s0 = 0; s0 < NR + NL; s0 += U)
-    {
-        Pack<T> pu[U], pw[U];
-        bool ok[U];
-#pragma unroll
-        for (int k = 0; k < U; k++)
-            if (s0 + k < NR + NL)
-            {
-                const int64_t vi = int64_t(s0 + k) * kHvThreads + tid;
-                ok[k] = vi < nv;
-                const int64_t vc = ok[k] ? vi : int64_t(0);  // always a valid address; zero-weighted below
-                pu[k] = ldv<T, true>(u, vc);
-                pw[k] = ldv<T, true>(w, vc);
-            }
-#pragma unroll
-        for (int k = 0; k < U; k++)
-            if (s0 + k < NR + NL)
-            {
-                constexpr int dummy = 0;
-                const int s = s0 + k;
-                Pack<T> cur;
-                if (s < NR)
-                    cur = rq[s < NR ? s : dummy];
-                else
-                    cur.v = lq[(s < NR ? dummy : s - NR) * kHvThreads + tid];
-#pragma unroll
-                for (int e = 0; e < W; e++)
-                {
-                    const T upd = cur.e[e] + c * pu[k].e[e];
-                    const T ini = T(-1) * pu[k].e[e];
-                    cur.e[e] = init ? ini : upd;
-                }
-                // x / 1 == x exactly, so the division runs in every step with theta = 1 outside the division step:
-                // a per-slot branch here makes the register allocator keep two copies of q (measured: 8 instead of
-                // 4 registers per slot, i.e. spills at 98 slots); the extra VALU work hides behind the loads
-#pragma unroll
-                for (int e = 0; e < W; e++)
-                    cur.e[e] = cur.e[e] / theta;
-#pragma unroll
-                for (int e = 0; e < W; e++)
-                    acc[(k * W + e) & 3].add_prod(ok[k] ? pw[k].e[e] : T(0), ok[k] ? cur.e[e] : T(0));
-                if (s < NR)
-                    rq[s < NR ? s : dummy] = cur;
-                else
-                    lq[(s < NR ? dummy : s - NR) * kHvThreads + tid] = cur.v;
-            }
-        // keep the next chunk's loads from being hoisted over this one (compiler-level and scheduler-level fence)
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
 
 template <class T, int NQ>
 __global__ void __launch_bounds__(kHvThreads) kb_twoloop_full(BatBufs<T> b, const BatHvDesc* __restrict__ desc, int64_t n,
@@ -496,7 +429,7 @@ __global__ void __launch_bounds__(kHvThreads) kb_twoloop_full(BatBufs<T> b, cons
         // recomputed inside the step instead of being hoisted out of the L loop and kept in ~4 registers per slot
         int tid_step = tid;
         asm volatile("" : "+v"(tid_step));
-        hv_step<T, NR, NL>(rq, lq, u, w, L == 0, c, theta, nv, tid_step, acc4);
+        hv_step<T, NR, NL>(rq, lq, u, w, L == 0, T(-1), c, theta, nv, int64_t(tid_step), int64_t(kHvThreads), tid, acc4);
         A acc = acc4[0];
         for (int k = 1; k < 4; k++)
             acc.merge(acc4[k].hi, acc_lo(acc4[k]));

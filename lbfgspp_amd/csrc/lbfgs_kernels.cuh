@@ -444,4 +444,77 @@ __global__ void __launch_bounds__(kBlock) k_twoloop(T* __restrict__ q, const T* 
         sc[args.i_out] = T(acc[0].value());
 }
 
+// ---------------------------------------------------------------- q resident on the CU across the two-loop steps
+// Shared by the lock-step batch (one block = one problem, batched.hip) and by the persistent single-problem kernel:
+// a thread owns NR 16-byte slots of q in registers and NL more in LDS; slot s of the thread is the vector
+// s * vstride + vbase.
+constexpr int kHvThreads = 256;
+
+// One code path for the four step kinds, selected by wave-uniform values (a single instance of the slot code keeps
+// the register-resident q free of per-kind copies):
+//   init            q = a * v                          (BFGSMat.h:283; a = -1 in the solvers)
+//   otherwise       q = q + c * u                      c = -alpha (first loop, :289: q - alpha*y == q + (-alpha)*y
+//                                                      exactly) or alpha - beta (second loop, :299)
+//   always          q = q / theta afterwards           (:293; theta = 1 outside the division step)
+//   dot operand     w, or u itself when dot_u (the SUBDIV step reduces against the column it just subtracted)
+template <class T, int NR, int NL, class A>
+__device__ __forceinline__ void hv_step(Pack<T> (&rq)[NR], typename Vec16<T>::type* lq, const T* u, const T* w,
+                                        bool init, T a, T c, T theta, int64_t nv, int64_t vbase, int64_t vstride,
+                                        int ltid, A (&acc)[4])
+{
+    constexpr int W = Vec16<T>::W;
+    constexpr int U = 6;  // slots per chunk: 2 U 16-byte loads in flight per thread, then the arithmetic
+#pragma unroll
+    for (int s0 = 0; s0 < NR + NL; s0 += U)
+    {
+        Pack<T> pu[U], pw[U];
+        bool ok[U];
+#pragma unroll
+        for (int k = 0; k < U; k++)
+            if (s0 + k < NR + NL)
+            {
+                const int64_t vi = int64_t(s0 + k) * vstride + vbase;
+                ok[k] = vi < nv;
+                const int64_t vc = ok[k] ? vi : int64_t(0);  // always a valid address; zero-weighted below
+                pu[k] = ldv<T, true>(u, vc);
+                pw[k] = ldv<T, true>(w, vc);
+            }
+#pragma unroll
+        for (int k = 0; k < U; k++)
+            if (s0 + k < NR + NL)
+            {
+                constexpr int dummy = 0;
+                const int s = s0 + k;
+                Pack<T> cur;
+                if (s < NR)
+                    cur = rq[s < NR ? s : dummy];
+                else
+                    cur.v = lq[(s < NR ? dummy : s - NR) * kHvThreads + ltid];
+#pragma unroll
+                for (int e = 0; e < W; e++)
+                {
+                    const T upd = cur.e[e] + c * pu[k].e[e];
+                    const T ini = a * pu[k].e[e];
+                    cur.e[e] = init ? ini : upd;
+                }
+                // x / 1 == x exactly, so the division runs in every step with theta = 1 outside the division step:
+                // a per-slot branch here makes the register allocator keep two copies of q (measured: 8 instead of
+                // 4 registers per slot, i.e. spills at 98 slots); the extra VALU work hides behind the loads
+#pragma unroll
+                for (int e = 0; e < W; e++)
+                    cur.e[e] = cur.e[e] / theta;
+#pragma unroll
+                for (int e = 0; e < W; e++)
+                    acc[(k * W + e) & 3].add_prod(ok[k] ? pw[k].e[e] : T(0), ok[k] ? cur.e[e] : T(0));
+                if (s < NR)
+                    rq[s < NR ? s : dummy] = cur;
+                else
+                    lq[(s < NR ? dummy : s - NR) * kHvThreads + ltid] = cur.v;
+            }
+        // keep the next chunk's loads from being hoisted over this one (compiler-level and scheduler-level fence)
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 }  // namespace lbfgsx
