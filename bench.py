@@ -26,7 +26,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (about 6.3 TB/s achiev
 
 
 def pmc_traffic(n, m):
-    """HBM bytes per two-loop launch from the committed rocprofv3 PMC passes (profiles/*_pmc_summary.json,
+    """HBM bytes per two-loop step from the committed rocprofv3 PMC passes (profiles/*_pmc_summary.json,
     produced by scripts/profile.sh + scripts/summarize_profile.py on this same command); None if the
     committed profile is for another problem size."""
     import glob
@@ -37,7 +37,8 @@ def pmc_traffic(n, m):
             t = d.get("twoloop_avg_hbm_bytes_per_launch")
             # the profile was taken at n=1e8, m=10: (8m+2) n 8 bytes over 2m+1 launches
             expect = (8 * m + 2) * n * 8 / float(2 * m + 1)
-            if t and abs(t - expect) / expect < 0.05:
+            # the persistent kernel keeps part of q on the CUs, so its measured traffic sits below the algorithmic figure
+            if t and -0.25 < (t - expect) / expect < 0.05:
                 best = {"bytes_per_launch": t, "source": os.path.relpath(f, ROOT)}
         except Exception:
             pass

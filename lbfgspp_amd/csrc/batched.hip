@@ -588,6 +588,7 @@ int lbfgsx_bat_create(lbfgsx_batch** out, int dtype, int64_t n, int m, int nprob
     LBFGSX_HIP(hipMemset(c->ws.ticket, 0, sizeof(unsigned) * size_t(nproblems)));
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&c->desc_dev), sizeof(BatDesc) * size_t(nproblems)));
     LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->hdesc), sizeof(BatDesc) * size_t(nproblems), hipHostMallocDefault));
+    live_add(c->device, +1);
     *out = c;
     return LBFGSX_OK;
 }
@@ -598,6 +599,7 @@ void lbfgsx_bat_destroy(lbfgsx_batch* c)
         return;
     (void) hipSetDevice(c->device);
     (void) hipStreamSynchronize(c->stream);
+    live_add(c->device, -1);
     void* ptrs[] = {c->X, c->G, c->D, c->S, c->Y, c->sc, c->ws.partials, c->ws.ticket, c->desc_dev, c->hvdesc_dev};
     if (c->hvdesc_host)
         (void) hipHostFree(c->hvdesc_host);

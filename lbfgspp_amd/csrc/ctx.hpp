@@ -37,6 +37,11 @@ struct ScLayout
     int total() const { return out(16); }
 };
 
+// Live contexts / batches per device in this process.  The persistent two-loop kernel needs the whole GPU for itself
+// (every block resident, grid-wide meeting points); it is only used while its context is the single live one.
+void live_add(int device, int delta);   // lbfgsx.hip
+int live_count(int device);
+
 int bounded_alloc(lbfgsx_ctx* c);   // lbfgsb.hip
 void bounded_free(lbfgsx_ctx* c);
 
@@ -89,6 +94,14 @@ struct lbfgsx_ctx
                            // step re-reads, so it stays eligible for the memory-side cache by default
     bool zigzag = true;    // alternate the traversal direction of consecutive two-loop steps (MALL reuse of q's tail)
     unsigned tl_step = 0;  // launches issued so far (parity selects the direction)
+    // persistent one-launch apply_Hv (k_twoloop_persist)
+    bool persist = true;           // LBFGSX_PERSIST=0: always the 2c+1 step launches
+    int persist_grid = 0;          // co-resident blocks (occupancy * CUs), 0 = unavailable
+    unsigned* gen_dev = nullptr;   // generation word + error word
+    unsigned gen_count = 0;
+    int64_t persist_steps_timed = 0;
+    bool counted = false;          // registered in the live-context count
+    int64_t persist_launches = 0;  // instrumentation
 
     // L-BFGS-B work set (allocated with LBFGSX_FLAG_BOUNDED) lives in lbfgsb part
     void* lb = nullptr;

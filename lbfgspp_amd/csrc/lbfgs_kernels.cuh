@@ -517,4 +517,200 @@ __device__ __forceinline__ void hv_step(Pack<T> (&rq)[NR], typename Vec16<T>::ty
     }
 }
 
+// ---------------------------------------------------------------- K1p: the whole apply_Hv as ONE persistent launch
+// 2 blocks per CU stay resident for all 2c+1 steps.  Each thread keeps a fixed set of q vectors on the CU (NR slots
+// in registers + NL in LDS; slot s of thread g = s * gridDim.x * 256 + g): that part of q never travels.  The rest
+// of the vector is streamed exactly as k_twoloop does (grid-stride tiles of U 16-byte vectors per stream, the
+// direction alternating between steps).  Between steps the grid meets at a counter: the last block to arrive
+// reduces the per-block partials in index order, rounds the dot to T, stores it in sc[] and bumps a generation
+// word; the others poll that word from one lane (bounded, with s_sleep).  Element-wise arithmetic and reductions
+// are those of k_twoloop, so the result is bit-identical to the 2c+1 launches.
+//   n = 1e7 (cfg2): all of q fits (39 of the 45 slots): 2n elements per step instead of 4n.
+//   n = 1e8 (north-star): 12 % of q fits.
+struct PersistArgs
+{
+    int ncorr, m;
+    int pcol[32];          // physical columns newest -> oldest
+    unsigned gen_base;     // generation word value before this launch
+    int zigzag;
+    unsigned first_rev;    // direction parity of the first step
+    int64_t ld;            // column stride of S / Y (elements)
+};
+
+constexpr int kPersistNR = 30;
+constexpr int kPersistNL = 15;
+
+template <class T>
+__global__ void __launch_bounds__(kHvThreads, 2)
+    k_twoloop_persist(T* __restrict__ q, const T* __restrict__ vin, T a, const T* __restrict__ S, const T* __restrict__ Y,
+                      int64_t n, T* __restrict__ sc, PersistArgs pa, RedWs ws, unsigned* __restrict__ gen,
+                      int* __restrict__ err)
+{
+    typedef typename AccOf<T>::type A;
+    constexpr int W = Vec16<T>::W;
+    constexpr int NR = kPersistNR, NL = kPersistNL, U = 4;
+    __shared__ typename Vec16<T>::type lq[NL * kHvThreads];
+    __shared__ int s_pcol[32];  // dynamic indexing: keep the column list out of scratch
+    const int tid = threadIdx.x;
+    if (tid < 32)
+        s_pcol[tid] = pa.pcol[tid];
+    __syncthreads();
+    const int cn = pa.ncorr, m = pa.m;
+    const int64_t nv = n / W;
+    const int64_t gthreads = int64_t(gridDim.x) * kHvThreads;
+    const int64_t gtid = int64_t(blockIdx.x) * kHvThreads + tid;
+    // resident region: the first nres * gthreads vectors
+    int64_t nres = (nv + gthreads - 1) / gthreads;
+    if (nres > NR + NL)
+        nres = NR + NL;
+    const int64_t res_end = nres * gthreads < nv ? nres * gthreads : nv;  // vectors [0, res_end) are resident
+    const int DOT0 = 2 * (m + 1) + 1;  // ScLayout::dot(0); ys(col) = col; theta(col) = m + 1 + col
+    auto sload = [&](int idx) { return T(__hip_atomic_load(sc + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); };
+    auto col = [&](const T* base, int c) { return base + int64_t(c) * pa.ld; };
+
+    Pack<T> rq[NR];
+    const int64_t tile = int64_t(kHvThreads) * U;
+    for (int L = 0; L <= 2 * cn; L++)
+    {
+        const T* u;
+        const T* w;
+        T c = T(0), theta = T(1);
+        bool div = false;
+        if (L == 0)
+        {
+            u = vin;
+            w = cn > 0 ? col(S, s_pcol[0]) : vin;
+        }
+        else if (L < cn)
+        {
+            u = col(Y, s_pcol[L - 1]);
+            w = col(S, s_pcol[L]);
+            c = -(sload(DOT0 + L - 1) / sload(s_pcol[L - 1]));
+        }
+        else if (L == cn)
+        {
+            u = col(Y, s_pcol[cn - 1]);
+            w = u;
+            c = -(sload(DOT0 + cn - 1) / sload(s_pcol[cn - 1]));
+            theta = sload(m + 1 + s_pcol[0]);
+            div = true;
+        }
+        else
+        {
+            const int t = L - cn - 1, i = cn - 1 - t;
+            u = col(S, s_pcol[i]);
+            w = (t < cn - 1) ? col(Y, s_pcol[i - 1]) : vin;
+            c = sload(DOT0 + i) / sload(s_pcol[i]) - sload(DOT0 + L - 1) / sload(s_pcol[i]);
+        }
+        A acc4[4];
+        // resident slots (vectors beyond res_end are zero-weighted inside hv_step through nv = res_end)
+        {
+            int64_t gt = gtid;
+            asm volatile("" : "+v"(gt));  // see kb_twoloop_full: keeps per-slot address math inside the step
+            hv_step<T, NR, NL>(rq, lq, u, w, L == 0, a, c, theta, res_end, gt, gthreads, tid, acc4);
+        }
+        // streamed remainder [res_end, nv): tiles of U vectors per stream, q read and written in HBM
+        {
+            const bool rev = pa.zigzag && (((pa.first_rev + unsigned(L)) & 1u) != 0u);
+            const int64_t span = nv - res_end;
+            const int64_t ntile = (span + tile - 1) / tile;
+            for (int64_t t0 = blockIdx.x; t0 < ntile; t0 += gridDim.x)
+            {
+                const int64_t tt = rev ? ntile - 1 - t0 : t0;
+                const int64_t base = res_end + tt * tile + tid;
+                Pack<T> pq[U], pu[U], pw[U];
+#pragma unroll
+                for (int k = 0; k < U; k++)
+                {
+                    const int64_t vi = base + int64_t(k) * kHvThreads;
+                    if (vi < nv)
+                    {
+                        pu[k] = ldv<T, true>(u, vi);
+                        pw[k] = ldv<T, true>(w, vi);
+                        if (L != 0)
+                            pq[k] = ldv<T, false>(q, vi);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < U; k++)
+                {
+                    const int64_t vi = base + int64_t(k) * kHvThreads;
+                    if (vi < nv)
+                    {
+#pragma unroll
+                        for (int e = 0; e < W; e++)
+                        {
+                            T qv = (L == 0) ? a * pu[k].e[e] : pq[k].e[e] + c * pu[k].e[e];
+                            if (div)
+                                qv = qv / theta;
+                            pq[k].e[e] = qv;
+                            acc4[(k * W + e) & 3].add_prod(pw[k].e[e], qv);
+                        }
+                        stv<T, false>(q, vi, pq[k]);
+                    }
+                }
+            }
+            if (blockIdx.x == 0 && tid == 0)  // scalar tail (n not a multiple of the vector width)
+                for (int64_t i = nv * W; i < n; i++)
+                {
+                    T qv = (L == 0) ? a * u[i] : q[i] + c * u[i];
+                    if (div)
+                        qv = qv / theta;
+                    q[i] = qv;
+                    acc4[0].add_prod(w[i], qv);
+                }
+        }
+        A acc[1];
+        acc[0] = acc4[0];
+        for (int k = 1; k < 4; k++)
+            acc[0].merge(acc4[k].hi, acc_lo(acc4[k]));
+        const unsigned want = pa.gen_base + unsigned(L) + 1u;
+        if (grid_reduce<1>(acc, ws))
+        {
+            if (tid == 0)
+            {
+                __hip_atomic_store(sc + DOT0 + L, T(acc[0].value()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(gen, want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (L < 2 * cn)  // the last dot is only read by the host
+        {
+            if (tid == 0)
+            {
+                unsigned spins = 0;
+                while (int(__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0)
+                {
+                    __builtin_amdgcn_s_sleep(8);
+                    // never hang the device: after ~1 s of polling (or as soon as another block gave up) flag the
+                    // launch as failed and run to the end; the host reports LBFGSX_E_HIP
+                    if ((++spins & 1023u) == 0u &&
+                        (spins > (1u << 22) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
+                    {
+                        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+                __threadfence();
+            }
+            __syncthreads();
+        }
+    }
+    // the finished direction: the resident part goes to memory once
+#pragma unroll
+    for (int s = 0; s < NR + NL; s++)
+    {
+        const int64_t vi = int64_t(s) * gthreads + gtid;
+        if (vi < res_end)
+        {
+            Pack<T> cur;
+            if (s < NR)
+                cur = rq[s < NR ? s : 0];
+            else
+                cur.v = lq[(s < NR ? 0 : s - NR) * kHvThreads + tid];
+            stv<T, false>(q, vi, cur);
+        }
+    }
+}
+
 }  // namespace lbfgsx

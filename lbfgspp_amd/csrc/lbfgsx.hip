@@ -1,6 +1,7 @@
 // lbfgspp_amd/csrc/lbfgsx.hip -- C ABI (include/lbfgsx.h) over the CDNA4 kernels: context, history
 // bookkeeping, unconstrained L-BFGS statements.  Built with hipcc --offload-arch=gfx950 -ffp-contract=off.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -10,6 +11,15 @@
 #include "lbfgs_kernels.cuh"
 
 namespace lbfgsx {
+
+static std::atomic<int> g_live[64];
+void live_add(int device, int delta)
+{
+    if (device >= 0 && device < 64)
+        g_live[device].fetch_add(delta);
+}
+int live_count(int device) { return (device >= 0 && device < 64) ? g_live[device].load() : 2; }
+
 
 static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
@@ -205,6 +215,22 @@ int lbfgsx_create(lbfgsx_ctx** out, int dtype, int64_t n, int m, int device, int
         c->zigzag = atoi(e) != 0;
     LBFGSX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->own_stream = true;
+    if (const char* e = getenv("LBFGSX_PERSIST"))
+        c->persist = atoi(e) != 0;
+    {
+        // the persistent two-loop needs every block resident at once: occupancy * CUs
+        int occ = 0, coop = 0;
+        hipDeviceProp_t prop;
+        LBFGSX_HIP(hipGetDeviceProperties(&prop, device));
+        (void) hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, device);
+        if (dtype == LBFGSX_F64)
+            (void) hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_twoloop_persist<double>, kHvThreads, 0);
+        else
+            (void) hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_twoloop_persist<float>, kHvThreads, 0);
+        c->persist_grid = coop ? occ * prop.multiProcessorCount : 0;
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&c->gen_dev), 2 * sizeof(unsigned)));
+        LBFGSX_HIP(hipMemset(c->gen_dev, 0, 2 * sizeof(unsigned)));
+    }
     const size_t vbytes = size_t(c->ld) * c->esz;
     for (int k = 0; k < 3; k++)
     {
@@ -239,6 +265,8 @@ int lbfgsx_create(lbfgsx_ctx** out, int dtype, int64_t n, int m, int device, int
             return rc;
     }
     LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    live_add(c->device, +1);
+    c->counted = true;
     return LBFGSX_OK;
 }
 
@@ -248,6 +276,8 @@ void lbfgsx_destroy(lbfgsx_ctx* c)
         return;
     (void) hipSetDevice(c->device);
     (void) hipStreamSynchronize(c->stream);
+    if (c->counted)
+        live_add(c->device, -1);
     for (int k = 0; k < 3; k++)
     {
         (void) hipFree(c->xb[k]);
@@ -261,6 +291,7 @@ void lbfgsx_destroy(lbfgsx_ctx* c)
     (void) hipFree(c->sc);
     (void) hipHostFree(c->hout);
     (void) hipFree(c->ws.partials);
+    (void) hipFree(c->gen_dev);
     (void) hipFree(c->ws.ticket);
     (void) hipFree(c->lb);
     (void) hipFree(c->ub);
@@ -503,6 +534,65 @@ static int apply_Hv_t(lbfgsx_ctx* c, const T* v, T a, double* dg)
         LBFGSX_HIP(hipEventCreate(&hv.a));
         LBFGSX_HIP(hipEventCreate(&hv.b));
         LBFGSX_HIP(hipEventRecord(hv.a, c->stream));
+    }
+    if (c->persist && c->persist_grid > 0 && m <= 32 && live_count(c->device) == 1)
+    {
+        // ONE cooperative launch for the 2c+1 steps (k_twoloop_persist)
+        PersistArgs pa;
+        pa.ncorr = cn;
+        pa.m = m;
+        for (int i = 0; i < 32; i++)
+            pa.pcol[i] = i < cn ? pcol[i] : 0;
+        pa.gen_base = c->gen_count;
+        pa.zigzag = c->zigzag ? 1 : 0;
+        pa.first_rev = c->tl_step;
+        pa.ld = c->ld;
+        c->gen_count += unsigned(2 * cn + 1);
+        c->tl_step += unsigned(2 * cn + 1);
+        const T* Sb = P<T>(c->S);
+        const T* Yb = P<T>(c->Y);
+        int64_t nn = c->n;
+        RedWs ws = c->ws;
+        unsigned* gen = c->gen_dev;
+        int* err = reinterpret_cast<int*>(c->gen_dev + 1);
+        const T* vv = v;
+        T aa = a;
+        void* kargs[] = {&q, &vv, &aa, &Sb, &Yb, &nn, &sc, &pa, &ws, &gen, &err};
+        const hipError_t lerr = hipLaunchCooperativeKernel(reinterpret_cast<void*>(k_twoloop_persist<T>),
+                                                           dim3(c->persist_grid), dim3(kHvThreads), kargs, 0, c->stream);
+        if (lerr != hipSuccess)
+        {
+            // the runtime refused the cooperative launch (grid not co-resident on this device / partition): undo the
+            // bookkeeping and use the step launches from now on
+            (void) hipGetLastError();
+            c->gen_count -= unsigned(2 * cn + 1);
+            c->tl_step -= unsigned(2 * cn + 1);
+            c->persist = false;
+            if (c->timing)
+            {
+                (void) hipEventDestroy(hv.a);
+                (void) hipEventDestroy(hv.b);
+            }
+            return apply_Hv_t<T>(c, v, a, dg);
+        }
+        c->persist_launches++;
+        if (c->timing)
+        {
+            LBFGSX_HIP(hipEventRecord(hv.b, c->stream));
+            c->ev_hv.push_back(hv);
+            c->persist_steps_timed += 2 * cn + 1;
+        }
+        int herr = 0;
+        LBFGSX_HIP(hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        int rc2 = dg ? fetch_scalars<T>(c, sl.dot(2 * cn), 1, dg) : LBFGSX_OK;
+        if (!dg)
+            LBFGSX_HIP(hipStreamSynchronize(c->stream));
+        if (herr)
+        {
+            set_error("persistent two-loop: grid barrier timed out");
+            return LBFGSX_E_HIP;
+        }
+        return rc2;
     }
     auto launch = [&](int mode, const T* u, const T* w, TwoLoopArgs args) -> int {
         EventPair ev;
@@ -795,6 +885,7 @@ int lbfgsx_timing_enable(lbfgsx_ctx* c, int on)
     }
     c->ev_twoloop.clear();
     c->ev_hv.clear();
+    c->persist_steps_timed = 0;
     c->timing = (on != 0);
     return LBFGSX_OK;
 }
@@ -816,12 +907,24 @@ int lbfgsx_timing_read(lbfgsx_ctx* c, double* twoloop_ms_total, int64_t* twoloop
         LBFGSX_HIP(hipEventElapsedTime(&ms, e.a, e.b));
         t2 += ms;
     }
+    if (c->ev_twoloop.empty() && c->persist_steps_timed > 0)
+    {
+        // persistent mode: one launch per apply_Hv; report it as its 2c+1 steps so that per-step figures compare
+        t1 = t2;
+        if (twoloop_ms_total) *twoloop_ms_total = t1;
+        if (twoloop_launches) *twoloop_launches = c->persist_steps_timed;
+        if (applyhv_ms_total) *applyhv_ms_total = t2;
+        if (applyhv_calls) *applyhv_calls = int64_t(c->ev_hv.size());
+        return LBFGSX_OK;
+    }
     if (twoloop_ms_total) *twoloop_ms_total = t1;
     if (twoloop_launches) *twoloop_launches = int64_t(c->ev_twoloop.size());
     if (applyhv_ms_total) *applyhv_ms_total = t2;
     if (applyhv_calls) *applyhv_calls = int64_t(c->ev_hv.size());
     return LBFGSX_OK;
 }
+
+int64_t lbfgsx_persistent_launches(const lbfgsx_ctx* c) { return c ? c->persist_launches : 0; }
 
 int lbfgsx_stream_probe(lbfgsx_ctx* c, int reps, double* copy_gbs, double* triad_gbs)
 {

@@ -54,9 +54,21 @@ for k, c in sorted(agg.items()):
                          "hbm_bytes_per_launch": hbm,
                          "hbm_GBs": (hbm / (avg_ns * 1e-9) / 1e9) if avg_ns else None}
 # launch-weighted two-loop figures (what bench.py's roofline object quotes)
-tl = {k: v for k, v in out["kernels"].items() if k.startswith("k_twoloop")}
+tl = {k: v for k, v in out["kernels"].items() if k.startswith("k_twoloop") and "persist" not in k}
+ps = {k: v for k, v in out["kernels"].items() if k.startswith("k_twoloop_persist")}
 calls = sum(v["calls"] for v in tl.values())
-if calls:
+if ps:
+    # one persistent launch per apply_Hv = 2*ncorr+1 steps; the profiled command starts from an empty history with
+    # m = 10, so launch k (k = 0, 1, ...) runs 2*min(k, 10)+1 steps.  Per-step figures make it comparable with the
+    # step-wise kernels and with bench.py's algorithmic bytes per step.
+    v = list(ps.values())[0]
+    steps = sum(2 * min(k, 10) + 1 for k in range(v["calls"]))
+    out["twoloop_persistent"] = {"launches": v["calls"], "steps": steps,
+                                 "hbm_bytes_per_step": v["hbm_bytes_per_launch"] * v["calls"] / steps,
+                                 "ms_per_step": v["avg_ms"] * v["calls"] / steps}
+    out["twoloop_avg_hbm_bytes_per_launch"] = out["twoloop_persistent"]["hbm_bytes_per_step"]
+    out["twoloop_avg_ms"] = out["twoloop_persistent"]["ms_per_step"]
+elif calls:
     out["twoloop_avg_hbm_bytes_per_launch"] = sum(v["hbm_bytes_per_launch"] * v["calls"] for v in tl.values()) / calls
     out["twoloop_avg_ms"] = sum(v["avg_ms"] * v["calls"] for v in tl.values()) / calls
 with open(os.path.join("profiles", rnd + "_pmc_summary.json"), "w") as f:

@@ -257,3 +257,32 @@ def test_lbfgs_golden(A, case):
     assert np.abs(np.asarray(x[::case["stride"]], np.float64) - G.unhex(case["x_sample"])).max() <= tol
     # with order-independent reductions the HIP path is expected to reproduce the reference bit for bit
     assert fx == float.fromhex(case["fx"])
+
+
+@pytest.mark.parametrize("dtype,n,m", [(O.F64, 300002, 7), (O.F32, 100002, 5), (O.F64, 2048, 12)])
+def test_persistent_two_loop_is_bit_identical(A, oracle, monkeypatch, dtype, n, m):
+    """k_twoloop_persist (one cooperative launch per apply_Hv, part of q resident on the CUs) against the 2c+1 step
+    launches and against the oracle.  The persistent kernel only runs while its context is the single live one, so
+    stale solver objects are collected first and its use is asserted through lbfgsx_persistent_launches."""
+    import ctypes as C
+    import gc
+    core, _ = A.load()
+    core.lbfgsx_persistent_launches.restype = C.c_int64
+    core.lbfgsx_persistent_launches.argtypes = [C.c_void_p]
+    x0 = O.rosen_x0(n, 11, dtype)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LBFGSX_PERSIST", mode)
+        gc.collect()
+        s = A.LBFGSSolver(A.LBFGSParam(m=m, epsilon=0.0, epsilon_rel=0.0, max_iterations=2 * m + 5),
+                          linesearch=A.LS_MORE_THUENTE, dtype=O.NPDT[dtype])
+        x = x0.copy()
+        niter, fx = s.minimize(A.ExtendedRosenbrock(), x)
+        res[mode] = (niter, s.last.nfev, fx, x, int(core.lbfgsx_persistent_launches(s.ctx() if callable(s.ctx) else s.ctx)))
+        del s
+        gc.collect()
+    assert res["1"][4] > 0 and res["0"][4] == 0
+    assert res["1"][:3] == res["0"][:3] and np.array_equal(res["1"][3], res["0"][3])
+    x_ref, r = oracle.lbfgs(dtype, O.LS_MT, O.OBJ_ROSEN, x0, O.lbfgs_params(m=m, epsilon=0, epsilon_rel=0,
+                                                                            max_iterations=2 * m + 5))
+    assert (r.niter, r.nfev) == res["1"][:2] and np.array_equal(res["1"][3], x_ref)
