@@ -279,6 +279,10 @@ def main():
             except Exception as e:  # the baseline is reported, never required
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))
+    # release the device context before interpreter shutdown (profilers finalise in atexit handlers)
+    del solver
+    import gc
+    gc.collect()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -278,8 +278,8 @@ int lbfgsx_timing_enable(lbfgsx_ctx* c, int on);
 int lbfgsx_timing_read(lbfgsx_ctx* c, double* twoloop_ms_total, int64_t* twoloop_launches,
                        double* applyhv_ms_total, int64_t* applyhv_calls);
 /* number of apply_Hv calls of this context served by the persistent one-launch kernel (k_twoloop_persist: the
- * whole recursion in one cooperative launch with part of q resident on the CUs).  It is used when the device
- * supports cooperative launches, m <= 32, LBFGSX_PERSIST != 0 and this context is the only live one of the
+ * whole recursion in one launch of occupancy x CUs blocks with part of q resident on the CUs).  It is used when
+ * m <= 32, LBFGSX_PERSIST != 0 and this context is the only live one of the
  * process on its device; otherwise apply_Hv issues its 2c+1 step launches.  Results are bit-identical. */
 int64_t lbfgsx_persistent_launches(const lbfgsx_ctx* c);
 /* STREAM-style device bandwidth probe on this context's vectors: copy (XT = X) and triad, GB/s */

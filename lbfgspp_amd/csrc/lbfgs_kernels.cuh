@@ -518,6 +518,7 @@ __device__ __forceinline__ void hv_step(Pack<T> (&rq)[NR], typename Vec16<T>::ty
 }
 
 // ---------------------------------------------------------------- K1p: the whole apply_Hv as ONE persistent launch
+// (grid = occupancy x CUs blocks, launched while this context is the only live one: all blocks are resident)
 // 2 blocks per CU stay resident for all 2c+1 steps.  Each thread keeps a fixed set of q vectors on the CU (NR slots
 // in registers + NL in LDS; slot s of thread g = s * gridDim.x * 256 + g): that part of q never travels.  The rest
 // of the vector is streamed exactly as k_twoloop does (grid-stride tiles of U 16-byte vectors per stream, the

@@ -219,15 +219,14 @@ int lbfgsx_create(lbfgsx_ctx** out, int dtype, int64_t n, int m, int device, int
         c->persist = atoi(e) != 0;
     {
         // the persistent two-loop needs every block resident at once: occupancy * CUs
-        int occ = 0, coop = 0;
+        int occ = 0;
         hipDeviceProp_t prop;
         LBFGSX_HIP(hipGetDeviceProperties(&prop, device));
-        (void) hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, device);
         if (dtype == LBFGSX_F64)
             (void) hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_twoloop_persist<double>, kHvThreads, 0);
         else
             (void) hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_twoloop_persist<float>, kHvThreads, 0);
-        c->persist_grid = coop ? occ * prop.multiProcessorCount : 0;
+        c->persist_grid = occ * prop.multiProcessorCount;
         LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&c->gen_dev), 2 * sizeof(unsigned)));
         LBFGSX_HIP(hipMemset(c->gen_dev, 0, 2 * sizeof(unsigned)));
     }
@@ -537,7 +536,7 @@ static int apply_Hv_t(lbfgsx_ctx* c, const T* v, T a, double* dg)
     }
     if (c->persist && c->persist_grid > 0 && m <= 32 && live_count(c->device) == 1)
     {
-        // ONE cooperative launch for the 2c+1 steps (k_twoloop_persist)
+        // ONE launch for the 2c+1 steps (k_twoloop_persist)
         PersistArgs pa;
         pa.ncorr = cn;
         pa.m = m;
@@ -549,32 +548,14 @@ static int apply_Hv_t(lbfgsx_ctx* c, const T* v, T a, double* dg)
         pa.ld = c->ld;
         c->gen_count += unsigned(2 * cn + 1);
         c->tl_step += unsigned(2 * cn + 1);
-        const T* Sb = P<T>(c->S);
-        const T* Yb = P<T>(c->Y);
-        int64_t nn = c->n;
-        RedWs ws = c->ws;
-        unsigned* gen = c->gen_dev;
+        // A plain launch of exactly occupancy * CUs blocks: with this context the only live one and its stream in
+        // order, every block is resident when the kernel starts.  (hipLaunchCooperativeKernel would have the runtime
+        // check that, but rocprofv3 crashes at exit after cooperative launches on this stack; the kernel's meeting
+        // points are bounded polls, so a violated assumption ends in LBFGSX_E_HIP, never in a hang.)
+        hipLaunchKernelGGL((k_twoloop_persist<T>), dim3(c->persist_grid), dim3(kHvThreads), 0, c->stream, q, v, a,
+                           P<T>(c->S), P<T>(c->Y), c->n, sc, pa, c->ws, c->gen_dev, reinterpret_cast<int*>(c->gen_dev + 1));
+        LBFGSX_HIP(hipGetLastError());
         int* err = reinterpret_cast<int*>(c->gen_dev + 1);
-        const T* vv = v;
-        T aa = a;
-        void* kargs[] = {&q, &vv, &aa, &Sb, &Yb, &nn, &sc, &pa, &ws, &gen, &err};
-        const hipError_t lerr = hipLaunchCooperativeKernel(reinterpret_cast<void*>(k_twoloop_persist<T>),
-                                                           dim3(c->persist_grid), dim3(kHvThreads), kargs, 0, c->stream);
-        if (lerr != hipSuccess)
-        {
-            // the runtime refused the cooperative launch (grid not co-resident on this device / partition): undo the
-            // bookkeeping and use the step launches from now on
-            (void) hipGetLastError();
-            c->gen_count -= unsigned(2 * cn + 1);
-            c->tl_step -= unsigned(2 * cn + 1);
-            c->persist = false;
-            if (c->timing)
-            {
-                (void) hipEventDestroy(hv.a);
-                (void) hipEventDestroy(hv.b);
-            }
-            return apply_Hv_t<T>(c, v, a, dg);
-        }
         c->persist_launches++;
         if (c->timing)
         {
@@ -589,8 +570,21 @@ static int apply_Hv_t(lbfgsx_ctx* c, const T* v, T a, double* dg)
             LBFGSX_HIP(hipStreamSynchronize(c->stream));
         if (herr)
         {
-            set_error("persistent two-loop: grid barrier timed out");
-            return LBFGSX_E_HIP;
+            // a meeting point timed out (the blocks were not all resident: the device is shared after all).  Nothing
+            // was lost -- v and the history are untouched: reset the words the kernel uses and redo this product
+            // with the step launches, which this context keeps using from now on
+            LBFGSX_HIP(hipMemsetAsync(c->gen_dev, 0, 2 * sizeof(unsigned), c->stream));
+            LBFGSX_HIP(hipMemsetAsync(c->ws.ticket, 0, sizeof(unsigned), c->stream));
+            c->gen_count = 0;
+            c->persist = false;
+            if (c->timing && !c->ev_hv.empty())
+            {
+                (void) hipEventDestroy(c->ev_hv.back().a);
+                (void) hipEventDestroy(c->ev_hv.back().b);
+                c->ev_hv.pop_back();
+                c->persist_steps_timed -= 2 * cn + 1;
+            }
+            return apply_Hv_t<T>(c, v, a, dg);
         }
         return rc2;
     }
