@@ -234,6 +234,9 @@ def main():
 
     copy_gbs, triad_gbs = C.c_double(), C.c_double()
     L.check(core.lbfgsx_stream_probe(ctx, 10, C.byref(copy_gbs), C.byref(triad_gbs)))
+    core.lbfgsx_persistent_launches.restype = C.c_int64
+    core.lbfgsx_persistent_launches.argtypes = [C.c_void_p]
+    persist_launches = core.lbfgsx_persistent_launches(ctx)
 
     if rank == 0:
         tl_ms, tl_n, hv_ms, hv_n = marks["tl"]
@@ -262,7 +265,8 @@ def main():
                                    % (n, m) if args.objective == "rosenbrock" else
                                    "diag quadratic kappa=10 n=%d m=%d f64 LineSearchNocedalWright" % (n, m),
                        "n": n, "m": m, "problems_per_gpu": 1,
-                       "fevals_total": solver.last.nfev, "iterations_total": niter},
+                       "fevals_total": solver.last.nfev, "iterations_total": niter,
+                       "apply_Hv_persistent_launches": int(persist_launches)},
             "roofline": {"bound": "hbm", "kernel": "k_twoloop (two-loop recursion step: axpy + dot)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (pmc_traffic(n, m) or {}).get("bytes_per_launch"),
