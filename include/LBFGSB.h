@@ -53,7 +53,7 @@ public:
         long long submin_unconverged = 0;
         long long resets = 0;
         double gcp_build_s = 0, gcp_fetch_s = 0, gcp_total_s = 0, submin_s = 0, linesearch_s = 0, correction_s = 0;
-        long long gcp_dev_crossings = 0;
+        long long gcp_dev_crossings = 0, gcp_sort_fallbacks = 0, gcp_partial_sorts = 0;
     };
 
 private:
@@ -151,6 +151,8 @@ private:
             Cauchy<Scalar>::get_cauchy_point(m_bfgs, gcp);              // (:241)
             m_stats.gcp_crossings += gcp.crossings;
             m_stats.gcp_dev_crossings += gcp.dev_crossings;
+            m_stats.gcp_sort_fallbacks = gcp.sort_fallbacks;
+            m_stats.gcp_partial_sorts += (gcp.sorted < gcp.nord_total) ? 1 : 0;
             m_stats.gcp_build_s += gcp.t_build;
             m_stats.gcp_fetch_s += gcp.t_fetch;
             m_stats.gcp_total_s += gcp.t_total;

@@ -80,6 +80,14 @@ class Cauchy
         return e ? std::atoll(e) : std::int64_t(65536);
     }
 
+    // The next search sorts only the break points up to tau = factor * (this search's Cauchy time): in steady state
+    // a search crosses 10^2..10^3 of the ~n/2 candidates.  LBFGSX_GCP_TAU_FACTOR=0 always sorts everything.
+    static double tau_factor()
+    {
+        const char* e = std::getenv("LBFGSX_GCP_TAU_FACTOR");
+        return e ? std::atof(e) : 8.0;
+    }
+
 public:
     struct Result
     {
@@ -88,6 +96,10 @@ public:
         std::int64_t nfree = 0;        // |fv_set|
         std::int64_t crossings = 0;    // break points crossed (instrumentation)
         std::int64_t dev_crossings = 0;  // ... of which by the device search
+        double tau_hint = 0;           // in/out: sort only break points <= tau_hint next time (0: sort all)
+        std::int64_t sort_fallbacks = 0;  // partial sort turned out too short, full sort redone (cumulative)
+        std::int64_t sorted = 0;       // length of the sorted prefix of the last search
+        std::int64_t nord_total = 0;   // number of finite positive break points of the last search
         double t_build = 0, t_fetch = 0, t_total = 0;  // seconds (instrumentation)
     };
 
@@ -101,11 +113,13 @@ public:
         out.vecc.assign(size_t(2 * ncorr), Scalar(0));
         out.nact = out.nfree = out.crossings = out.dev_crossings = 0;
 
-        std::int64_t nfree = 0, nord = 0;
+        std::int64_t nfree = 0, nord = 0, lim = 0;
         double dd = 0;
         double wtd[80];
         const auto t_begin = std::chrono::steady_clock::now();
-        detail::check(lbfgsx_b_cauchy_build(c, &nfree, &nord, &dd, wtd));
+        const double factor = tau_factor();
+        double tau = (factor > 0.0) ? out.tau_hint : 0.0;
+        detail::check(lbfgsx_b_cauchy_build_partial(c, tau, &nfree, &nord, &lim, &dd, wtd));
         out.t_build = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
         if (nfree < 1 && nord < 1)
         {
@@ -113,6 +127,18 @@ public:
             detail::check(lbfgsx_b_cauchy_finish(c, 0.0, 0.0, 0, &out.nact, &out.nfree));
             return;
         }
+        // `lim` sorted entries are available; when lim < nord (partial sort) every break point <= tau is among
+        // them and the next one is known only to be > tau.  The search below is exact as long as it stops before
+        // that sentinel; if it cannot decide there, everything is sorted and the search restarts (second pass).
+        Scalar tfinal = Scalar(0), t_cross = Scalar(0);
+        bool crossed_all = false;
+        double fetch_seconds = 0.0;
+        for (int pass = 0; pass < 2; pass++)
+        {
+        const bool partial = lim < nord;
+        bool need_full = false;
+        out.vecc.assign(size_t(2 * ncorr), Scalar(0));
+        out.crossings = out.dev_crossings = 0;
 
         // p = W'd (:152), f' = -d'd (:154), f'' = -theta f' - p'Mp (:156-158)
         std::vector<Scalar> vecp(size_t(2 * ncorr)), cache, wact(size_t(2 * ncorr));
@@ -126,19 +152,25 @@ public:
         Scalar fpp = -theta * fp - detail::host_dot(vecp.data(), cache.data(), 2 * ncorr);
         Scalar deltatmin = -fp / fpp;
 
-        Stream ord(c, nord, ncorr);
+        Stream ord(c, lim, ncorr);
         Scalar il = Scalar(0);
         std::int64_t b = 0;
-        Scalar iu = (nord < 1) ? inf : ord.brk(0);
+        bool at_sentinel = (lim < 1) && partial;
+        Scalar iu = (lim < 1) ? (partial ? Scalar(tau) : inf) : ord.brk(0);
         Scalar deltat = iu - il;
-        bool crossed_all = false;
-        Scalar t_cross = Scalar(0);
+        crossed_all = false;
+        t_cross = Scalar(0);
 
         const std::int64_t dev_min = device_switch();
         bool dev_ok = sizeof(Scalar) == sizeof(double) && 2 * ncorr <= 32 && dev_min >= 0;
 
         while (deltatmin >= deltat)
         {
+            if (at_sentinel)  // would cross a break point the partial sort left out
+            {
+                need_full = true;
+                break;
+            }
             if (dev_ok && b >= dev_min)
             {
                 // hand the rest of the search to the device: state = (p, c, f', f''), the group starting at b is
@@ -165,9 +197,9 @@ public:
                 bool finished = false;
                 while (!finished)
                 {
-                    const std::int64_t cnt = std::min<std::int64_t>(chunk, nord - b);
+                    const std::int64_t cnt = std::min<std::int64_t>(chunk, lim - b);
                     std::int64_t ex = -1;
-                    const int rc = lbfgsx_b_cauchy_scan(c, b, cnt, nord, Mmat.data(), double(theta), double(il),
+                    const int rc = lbfgsx_b_cauchy_scan(c, b, cnt, lim, Mmat.data(), double(theta), double(il),
                                                         st_in.data(), &ex, st_out.data());
                     if (rc == LBFGSX_E_INVALID && out.dev_crossings == 0)
                     {
@@ -182,7 +214,7 @@ public:
                     t_cross = il;
                     b += done;
                     std::copy(st_out.begin(), st_out.begin() + (2 * t + 2), st_in.begin());
-                    finished = (ex >= 0) || b >= nord;
+                    finished = (ex >= 0) || b >= lim;
                     chunk = std::min<std::int64_t>(chunk * 4, std::int64_t(1) << 20);
                 }
                 if (!dev_ok)
@@ -195,7 +227,13 @@ public:
                 fp = Scalar(st_in[size_t(2 * t)]);
                 fpp = Scalar(st_in[size_t(2 * t + 1)]);
                 deltatmin = -fp / fpp;                                 // (:240)
-                if (nfree == 0 && b >= nord)                           // everything crossed (:198-213)
+                if (b >= lim && partial)
+                {
+                    // the sorted prefix is exhausted: the search may only stop here if it would stop before tau
+                    if (deltatmin >= Scalar(tau) - il)
+                        need_full = true;
+                }
+                else if (nfree == 0 && b >= nord)                      // everything crossed (:198-213)
                     crossed_all = true;
                 break;
             }
@@ -203,10 +241,10 @@ public:
                 out.vecc[size_t(j)] = out.vecc[size_t(j)] + deltat * vecp[size_t(j)];
             // tie group [b, e] of break points equal to iu (:193-194)
             std::int64_t e = b;
-            while (e < nord && !(ord.brk(e) > iu))
+            while (e < lim && !(ord.brk(e) > iu))
                 e++;
             e -= 1;
-            if (nfree == 0 && e == nord - 1)                          // everything crossed (:198-213)
+            if (!partial && nfree == 0 && e == nord - 1)              // everything crossed (:198-213)
             {
                 crossed_all = true;
                 t_cross = iu;
@@ -243,17 +281,31 @@ public:
             il = iu;
             t_cross = iu;
             b = e + 1;
-            if (b >= nord)
-                break;
-            iu = ord.brk(b);
+            if (b >= lim)
+            {
+                if (!partial)
+                    break;
+                iu = Scalar(tau);  // lower bound of the next (unsorted) break point
+                at_sentinel = true;
+            }
+            else
+                iu = ord.brk(b);
             deltat = iu - il;
+        }
+        fetch_seconds += ord.fetch_seconds;
+        if (need_full)
+        {
+            detail::check(lbfgsx_b_cauchy_sort_full(c));
+            lim = nord;
+            out.sort_fallbacks++;
+            continue;
         }
 
         const Scalar eps = std::numeric_limits<Scalar>::epsilon();
         if (fpp < eps)                                                 // (:260-262)
             deltatmin = -fp / eps;
 
-        Scalar tfinal = Scalar(0);
+        tfinal = Scalar(0);
         if (!crossed_all)                                              // (:265-282)
         {
             deltatmin = std::max(deltatmin, Scalar(0));
@@ -261,10 +313,20 @@ public:
                 out.vecc[size_t(j)] = out.vecc[size_t(j)] + deltatmin * vecp[size_t(j)];
             tfinal = il + deltatmin;
         }
+        break;
+        }  // pass
+        out.sorted = lim;
+        out.nord_total = nord;
+        // a short sorted prefix only pays off while few break points are crossed; otherwise sort everything next time
+        out.tau_hint = (factor > 0.0 && !crossed_all && double(tfinal) > 0.0 && out.crossings * 16 <= nord)
+                           ? factor * double(tfinal)
+                           : 0.0;
         detail::check(lbfgsx_b_cauchy_finish(c, double(t_cross), double(tfinal), crossed_all ? 1 : 0, &out.nact, &out.nfree));
-        out.t_fetch = ord.fetch_seconds;
+        out.t_fetch = fetch_seconds;
         if (std::getenv("LBFGSX_TRACE_PHASES"))
             std::fprintf(stderr, "[gcp] ncorr %d nord %lld nfree %lld crossings %lld dev %lld crossed_all %d\n", ncorr, (long long) nord, (long long) nfree, (long long) out.crossings, (long long) out.dev_crossings, int(crossed_all));
+        if (std::getenv("LBFGSX_TRACE_PHASES"))
+            std::fprintf(stderr, "[gcp] sorted %lld of %lld, tau_next %g, fallbacks %lld\n", (long long) lim, (long long) nord, out.tau_hint, (long long) out.sort_fallbacks);
         out.t_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     }
 };

@@ -169,6 +169,14 @@ int lbfgsx_b_cauchy_build(lbfgsx_ctx* c, int64_t* nfree, int64_t* nord, double* 
  * for the sequential piecewise-quadratic scan kept on the host (Cauchy.h:183-256) */
 int lbfgsx_b_cauchy_chunk(lbfgsx_ctx* c, int64_t first, int64_t count, double* brk, double* g, double* z, int* idx,
                           double* wrows);
+/* lbfgsx_b_cauchy_build with a PARTIAL sort: only the candidates whose break point is <= tau are compacted (in
+ * index order) and sorted -- in steady state a search crosses 10^2..10^3 of the ~n/2 candidates, so sorting all of
+ * them (8 radix passes over n pairs) is the largest item of the build.  *nsorted = length of the sorted prefix
+ * (== *nord when tau <= 0 or not finite: full sort).  Every break point <= tau is in the prefix, so the search is
+ * exact as long as it stops before tau; the caller falls back to lbfgsx_b_cauchy_sort_full otherwise. */
+int lbfgsx_b_cauchy_build_partial(lbfgsx_ctx* c, double tau, int64_t* nfree, int64_t* nord, int64_t* nsorted, double* dd,
+                                  double* wtd);
+int lbfgsx_b_cauchy_sort_full(lbfgsx_ctx* c);
 /* Device form of the break-point search (reference Cauchy.h:183-256) over sorted positions [first, first+count) of
  * the list produced by lbfgsx_b_cauchy_build: three dependent prefix sums (p; c and f''; f') and a min-index exit
  * test, see lbfgspp_amd/csrc/gcp_scan.cuh.  Mmat: explicit 2c x 2c matrix of apply_Mv (BFGSMat.h:361-376), column

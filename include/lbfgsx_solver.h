@@ -81,6 +81,9 @@ int lbfgsx_solver_hessians(lbfgsx_solver* s, double* B, double* H);
 /* L-BFGS-B instrumentation of the last minimize(): {GCP break points crossed, BOXCQP sweeps, subspace calls,
  * unconverged subspace calls, BFGS resets, 0, 0, 0} */
 int lbfgsx_solver_stats(lbfgsx_solver* s, long long out[8]);
+/* more of the same: {GCP crossings handled by the device search, partial sorts that had to be redone in full,
+ * searches served by a partial sort, subspace us, line-search us, add_correction us, 0, 0} */
+int lbfgsx_solver_stats2(lbfgsx_solver* s, long long out[8]);
 /* minimize(): objective = LBFGSX_OBJ_*; a/b host arrays or NULL (resident); x host in/out or NULL (resident:
  * start point in LBFGSX_VEC_X, result left there); lb/ub host arrays or NULL (resident), L-BFGS-B only */
 int lbfgsx_solver_minimize(lbfgsx_solver* s, int objective, int64_t n, const void* a, const void* b, void* x,

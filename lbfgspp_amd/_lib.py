@@ -119,6 +119,7 @@ def load():
         C.POINTER(BatchItem), vp, C.c_char_p, i32)
     sig(sol, "lbfgsx_solver_hessians", i32, vp, vp, vp)
     sig(sol, "lbfgsx_solver_stats", i32, vp, C.POINTER(C.c_longlong * 8))
+    sig(sol, "lbfgsx_solver_stats2", i32, vp, C.POINTER(C.c_longlong * 8))
     sig(sol, "lbfgsx_solver_minimize", i32, vp, i32, i64, vp, vp, vp, vp, vp, C.POINTER(Trace), C.POINTER(Result))
     _core, _solver = core, sol
     return core, sol

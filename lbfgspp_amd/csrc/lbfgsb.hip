@@ -44,6 +44,12 @@ struct lbfgsb_state
     unsigned long long* s_exit = nullptr;
     int64_t s_cap = 0;
     int s_nc = 0;
+    // partial sort of the break points (lbfgsx_b_cauchy_build_partial): compacted candidates, allocated on first use
+    void* pk = nullptr;
+    int* pv = nullptr;
+    unsigned* pcount = nullptr;
+    void* sel_tmp = nullptr;
+    size_t sel_tmp_bytes = 0;
 };
 
 namespace lbfgsx {
@@ -196,7 +202,7 @@ void bounded_free(lbfgsx_ctx* c)
                     b->vals_in, b->vals_out, b->phys_dev, b->dout, b->coef_dev, b->mslot, b->sort_tmp, b->g_brk,
                     b->g_g, b->g_z, b->g_w, b->g_idx, b->gram_partial, b->gram_partial2, b->gram_out,
                     b->s_brk, b->s_g, b->s_z, b->s_W, b->s_P, b->s_C, b->s_fpp, b->s_dfp, b->s_fp, b->s_ts, b->s_off,
-                    b->s_small, b->s_exit};
+                    b->s_small, b->s_exit, b->pk, b->pv, b->pcount, b->sel_tmp};
     for (void* p : ptrs)
         (void) hipFree(p);
     delete b;
@@ -521,6 +527,124 @@ int lbfgsx_b_cauchy_build(lbfgsx_ctx* c, int64_t* nfree, int64_t* nord, double* 
     if (dd) *dd = r[0];
     if (nfree) *nfree = int64_t(r[1]);
     if (nord) *nord = int64_t(r[2]);
+    return LBFGSX_OK;
+}
+
+}  // extern "C"
+namespace lbfgsx {
+template <class T>
+struct KeyLE
+{
+    T tau;
+    __device__ bool operator()(const T& k) const { return k <= tau; }
+};
+template <class T>
+__global__ void k_gather_keys(const T* __restrict__ keys, const int* __restrict__ idx, T* __restrict__ out, int64_t count)
+{
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t k = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; k < count; k += stride)
+        out[k] = keys[idx[k]];
+}
+}  // namespace lbfgsx
+template <class T>
+static int partial_sort_t(lbfgsx_ctx* c, double tau, int64_t* nsorted)
+{
+    lbfgsb_state* b = c->bstate;
+    const size_t n = size_t(c->n);
+    if (!b->pk)
+    {
+        LBFGSX_HIP(hipMalloc(&b->pk, sizeof(T) * n));
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->pv), sizeof(int) * n));
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->pcount), sizeof(unsigned)));
+    }
+    // ordered (deterministic) compaction of the indices whose break point is <= tau ...
+    rocprim::counting_iterator<int> ids(0);
+    rocprim::transform_iterator<const T*, KeyLE<T>, bool> flags(P<T>(b->keys_in), KeyLE<T>{T(tau)});
+    size_t bytes = 0;
+    LBFGSX_HIP(rocprim::select(nullptr, bytes, ids, flags, b->pv, b->pcount, n, c->stream));
+    if (bytes > b->sel_tmp_bytes)
+    {
+        (void) hipFree(b->sel_tmp);
+        LBFGSX_HIP(hipMalloc(&b->sel_tmp, bytes));
+        b->sel_tmp_bytes = bytes;
+    }
+    LBFGSX_HIP(rocprim::select(b->sel_tmp, bytes, ids, flags, b->pv, b->pcount, n, c->stream));
+    unsigned cnt = 0;
+    LBFGSX_HIP(hipMemcpyAsync(&cnt, b->pcount, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    *nsorted = int64_t(cnt);
+    if (cnt == 0)
+        return LBFGSX_OK;
+    // ... their keys, and a stable sort of that short list: the same order the full sort gives these entries
+    const int grid = int(std::min<int64_t>((int64_t(cnt) + 255) / 256, 1024));
+    hipLaunchKernelGGL((k_gather_keys<T>), dim3(grid), dim3(256), 0, c->stream, P<T>(b->keys_in), b->pv, P<T>(b->pk), int64_t(cnt));
+    size_t sbytes = b->sort_tmp_bytes;
+    LBFGSX_HIP(rocprim::radix_sort_pairs(b->sort_tmp, sbytes, P<T>(b->pk), P<T>(b->keys_out), b->pv, b->vals_out, size_t(cnt), 0,
+                                         int(sizeof(T) * 8), c->stream));
+    return LBFGSX_OK;
+}
+extern "C" {
+
+int lbfgsx_b_cauchy_build_partial(lbfgsx_ctx* c, double tau, int64_t* nfree, int64_t* nord, int64_t* nsorted, double* dd,
+                                  double* wtd)
+{
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    lbfgsb_state* b = c->bstate;
+    const int grid = c->grid_for(c->n);
+    double r[3];
+    int64_t ns = 0;
+    DISPATCH_T(c, {
+        BVecs<T> bv = bvecs<T>(c);
+        hipLaunchKernelGGL((k_cauchy_build<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, P<T>(b->keys_in), b->vals_in, c->n,
+                           c->ws, b->dout);
+        LBFGSX_HIP(hipGetLastError());
+        rc = fetch_doubles(c, 3, r);
+        if (rc)
+            return rc;
+        ns = int64_t(r[2]);
+        if (r[2] > 0)
+        {
+            if (tau > 0.0 && std::isfinite(tau))
+            {
+                rc = partial_sort_t<T>(c, tau, &ns);
+                if (rc)
+                    return rc;
+            }
+            else
+            {
+                size_t bytes = b->sort_tmp_bytes;
+                LBFGSX_HIP(rocprim::radix_sort_pairs(b->sort_tmp, bytes, P<T>(b->keys_in), P<T>(b->keys_out), b->vals_in,
+                                                     b->vals_out, size_t(c->n), 0, int(sizeof(T) * 8), c->stream));
+            }
+        }
+        if (wtd && c->ncorr > 0)  // p = W'd raw dots (Cauchy.h:152)
+        {
+            rc = wtv_t<T>(c, 0, static_cast<const T*>(b->dvec), 0, wtd, nullptr);
+            if (rc)
+                return rc;
+        }
+    });
+    if (dd) *dd = r[0];
+    if (nfree) *nfree = int64_t(r[1]);
+    if (nord) *nord = int64_t(r[2]);
+    if (nsorted) *nsorted = ns;
+    return LBFGSX_OK;
+}
+
+// full sort of the break points written by the last build (after a partial one turned out too short)
+int lbfgsx_b_cauchy_sort_full(lbfgsx_ctx* c)
+{
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    lbfgsb_state* b = c->bstate;
+    DISPATCH_T(c, {
+        size_t bytes = b->sort_tmp_bytes;
+        LBFGSX_HIP(rocprim::radix_sort_pairs(b->sort_tmp, bytes, P<T>(b->keys_in), P<T>(b->keys_out), b->vals_in, b->vals_out,
+                                             size_t(c->n), 0, int(sizeof(T) * 8), c->stream));
+    });
     return LBFGSX_OK;
 }
 

@@ -22,6 +22,7 @@ struct lbfgsx_solver
     virtual int hessians(double*, double*) { return LBFGSX_E_INVALID; }
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long stats_submin_us = 0;
+    long long stats2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     virtual void minimize(int objective, int64_t n, const void* a, const void* b, void* x, const void* lb,
                           const void* ub, lbfgsx_trace* tr, lbfgsx_result* out) = 0;
 };
@@ -201,6 +202,12 @@ struct LbfgsbImpl : lbfgsx_solver
         stats[6] = (long long) (st.gcp_fetch_s * 1e6);
         stats[7] = (long long) (st.gcp_total_s * 1e6);
         stats_submin_us = (long long) (st.submin_s * 1e6);
+        stats2[0] = st.gcp_dev_crossings;
+        stats2[1] = st.gcp_sort_fallbacks;
+        stats2[2] = st.gcp_partial_sorts;
+        stats2[3] = (long long) (st.submin_s * 1e6);
+        stats2[4] = (long long) (st.linesearch_s * 1e6);
+        stats2[5] = (long long) (st.correction_s * 1e6);
     }
 };
 
@@ -452,6 +459,13 @@ int lbfgsx_solver_stats(lbfgsx_solver* s, long long out[8])
 {
     for (int k = 0; k < 8; k++)
         out[k] = s->stats[k];
+    return LBFGSX_OK;
+}
+
+int lbfgsx_solver_stats2(lbfgsx_solver* s, long long out[8])
+{
+    for (int k = 0; k < 8; k++)
+        out[k] = s->stats2[k];
     return LBFGSX_OK;
 }
 

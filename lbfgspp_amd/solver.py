@@ -206,4 +206,9 @@ class LBFGSBSolver(_SolverBase):
         L.check(self._sol.lbfgsx_solver_stats(self._h, C.byref(arr)))
         keys = ("gcp_crossings", "submin_sweeps", "submin_calls", "submin_unconverged", "resets", "gcp_build_us",
                 "gcp_fetch_us", "gcp_total_us")
-        return dict(zip(keys, list(arr)))
+        d = dict(zip(keys, list(arr)))
+        arr2 = (C.c_longlong * 8)()
+        L.check(self._sol.lbfgsx_solver_stats2(self._h, C.byref(arr2)))
+        d.update(zip(("gcp_dev_crossings", "gcp_sort_fallbacks", "gcp_partial_sorts", "submin_us", "linesearch_us",
+                      "correction_us"), list(arr2)[:6]))
+        return d

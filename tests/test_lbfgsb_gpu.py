@@ -292,3 +292,25 @@ def test_fused_subspace_passes_are_bit_identical_to_the_unfused_sequence(A, monk
     f, u = res["fused"], res["unfused"]
     assert f[:3] == u[:3] and f[5] == u[5] and f[5] > 0
     assert np.array_equal(f[3], u[3]) and np.array_equal(f[4], u[4])
+
+
+def test_partial_break_point_sort_is_exact_and_falls_back(A, monkeypatch):
+    """lbfgsx_b_cauchy_build_partial: sorting only the break points below tau = factor * (previous Cauchy time) must
+    not change a single bit of the trajectory; with a factor < 1 the prefix is regularly too short, which exercises
+    the sentinel test and the full re-sort."""
+    n, m, iters = 40000, 6, 25
+    a, b = O.quad_problem(n, 20.0, 5, O.F64)
+    res = {}
+    for factor in ("0", "8", "0.4"):
+        monkeypatch.setenv("LBFGSX_GCP_TAU_FACTOR", factor)
+        s = A.LBFGSBSolver(A.LBFGSBParam(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters))
+        x = np.zeros(n)
+        niter, fx = s.minimize(A.DiagQuadratic(a, b), x, -0.5 * np.ones(n), 0.8 * np.ones(n))
+        st = s.stats()
+        res[factor] = (niter, s.last.nfev, fx, x.copy(), st["gcp_crossings"], st["gcp_partial_sorts"], st["gcp_sort_fallbacks"])
+    full, part, short = res["0"], res["8"], res["0.4"]
+    assert full[5] == 0 and full[6] == 0
+    assert part[5] > 0                      # partial sorts were used ...
+    assert short[6] > 0                     # ... and redone in full when tau was too small
+    for r in (part, short):
+        assert r[:3] == full[:3] and r[4] == full[4] and np.array_equal(r[3], full[3])
