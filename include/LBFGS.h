@@ -19,12 +19,15 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 #include <limits>
 #include <vector>
 
 #include "LBFGSpp/BKLDLT.h"
 #include "LBFGSpp/DenseHessian.h"
 #include "LBFGSpp/Device.h"
+#include "LBFGSpp/GramSpace.h"
 #include "LBFGSpp/LineSearchBacktracking.h"
 #include "LBFGSpp/LineSearchBracketing.h"
 #include "LBFGSpp/LineSearchMoreThuente.h"
@@ -43,6 +46,7 @@ class LBFGSSolver
     Scalar m_gnorm = Scalar(0);
     int m_device = 0;
     int m_nfev = 0;
+    int m_recursion = RECURSION_VECTOR;  // extension: see set_recursion()
     std::function<void(int, Scalar, DeviceState<Scalar>&)> m_trace;
     std::function<void(int)> m_iter_hook;
 
@@ -71,9 +75,28 @@ class LBFGSSolver
         if (m_gnorm <= m_param.epsilon || m_gnorm <= m_param.epsilon_rel * sqrt(xnorm2))
             return 1;
 
+        // Gram-space form of the recursion (opt-in, LBFGSpp/GramSpace.h): host Gram matrix + two device passes
+        const bool gram = (m_recursion == RECURSION_GRAM_SPACE);
+        GramSpaceHistory gsh;
+        std::vector<double> gs_coef, gs_sdots, gs_gdots;
+        double gs_coef_g = 0, gs_scal[7] = {0, 0, 0, 0, 0, 0, 0};
+        if (gram)
+        {
+            gsh.reset(m_param.m);
+            gsh.set_gradient_norm2(double(gnorm2));
+            gs_sdots.assign(size_t(2 * m_param.m), 0.0);
+            gs_gdots.assign(size_t(2 * m_param.m), 0.0);
+        }
+
         // drt = -grad (empty history => H = I); |drt| == |grad| exactly, so step = 1/|grad|
         double dgd = 0;
-        detail::check(lbfgsx_apply_Hv(c, LBFGSX_VEC_G, -1.0, &dgd));
+        if (gram)
+        {
+            gsh.direction(-1.0, gs_coef, gs_coef_g);
+            detail::check(lbfgsx_gs_direction(c, gs_coef.data(), gs_coef_g, &dgd));
+        }
+        else
+            detail::check(lbfgsx_apply_Hv(c, LBFGSX_VEC_G, -1.0, &dgd));
         Scalar dg = Scalar(dgd);
         Scalar step = Scalar(1) / m_gnorm;
         constexpr Scalar eps = std::numeric_limits<Scalar>::epsilon();
@@ -95,7 +118,17 @@ class LBFGSSolver
             m_nfev = ev.nfev();
 
             double g2 = 0, x2 = 0, syd = 0, yyd = 0;
-            detail::check(lbfgsx_post_linesearch(c, &g2, &x2, &syd, &yyd));
+            if (gram)
+            {
+                // the same statements plus the Gram rows of (s, y) and of the new gradient, in one pass
+                detail::check(lbfgsx_gs_post_linesearch(c, gs_scal, gs_sdots.data(), gs_gdots.data()));
+                g2 = gs_scal[0];
+                x2 = gs_scal[1];
+                syd = gs_scal[2];
+                yyd = gs_scal[3];
+            }
+            else
+                detail::check(lbfgsx_post_linesearch(c, &g2, &x2, &syd, &yyd));
             m_gnorm = sqrt(Scalar(g2));
             if (m_gnorm <= m_param.epsilon || m_gnorm <= m_param.epsilon_rel * sqrt(Scalar(x2)))
                 return k;
@@ -109,10 +142,18 @@ class LBFGSSolver
             if (m_param.max_iterations != 0 && k >= m_param.max_iterations)
                 return k;
 
-            if (Scalar(syd) > eps * Scalar(yyd))
+            const bool accept = Scalar(syd) > eps * Scalar(yyd);
+            if (accept)
                 detail::check(lbfgsx_commit_correction(c));
 
-            detail::check(lbfgsx_apply_Hv(c, LBFGSX_VEC_G, -1.0, &dgd));
+            if (gram)
+            {
+                gsh.update(gs_scal, gs_sdots.data(), gs_gdots.data(), accept);
+                gsh.direction(-1.0, gs_coef, gs_coef_g);
+                detail::check(lbfgsx_gs_direction(c, gs_coef.data(), gs_coef_g, &dgd));
+            }
+            else
+                detail::check(lbfgsx_apply_Hv(c, LBFGSX_VEC_G, -1.0, &dgd));
             dg = Scalar(dgd);
             step = Scalar(1);
             if (m_iter_hook)
@@ -122,7 +163,20 @@ class LBFGSSolver
     }
 
 public:
-    LBFGSSolver(const LBFGSParam<Scalar>& param) : m_param(param) { m_param.check_param(); }
+    LBFGSSolver(const LBFGSParam<Scalar>& param) : m_param(param)
+    {
+        m_param.check_param();
+        if (const char* e = std::getenv("LBFGSX_RECURSION"))
+            if (!std::strcmp(e, "gram") || !std::strcmp(e, "1"))
+                m_recursion = RECURSION_GRAM_SPACE;
+    }
+
+    // Extension (no reference counterpart): form of the two-loop recursion.  RECURSION_VECTOR (default) executes
+    // BFGSMat::apply_Hv statement by statement -- the bit-parity path.  RECURSION_GRAM_SPACE runs it on coefficients
+    // over [S, Y, g] (LBFGSpp/GramSpace.h): about half the HBM traffic per iteration, iterates equal to the vector
+    // form only up to rounding (m <= 24).  Environment LBFGSX_RECURSION=gram selects it at construction.
+    void set_recursion(int form) { m_recursion = form; }
+    int recursion() const { return m_recursion; }
 
     // choose the GPU of this solver (default 0); takes effect at the next minimize()
     void set_device(int device) { m_device = device; }

@@ -121,6 +121,18 @@ int lbfgsx_post_linesearch(lbfgsx_ctx* c, double* gnorm2, double* xnorm2, double
 /* BFGSMat::add_correction of the pair just formed (BFGSMat.h:81-97): index rotation only */
 int lbfgsx_commit_correction(lbfgsx_ctx* c);
 
+/* ---- Gram-space ("vector-free") form of the recursion: opt-in, outside the bit-parity contract ----
+ * BFGSMat::apply_Hv (BFGSMat.h:276-302) only combines the 2c+1 vectors [S, Y, g]; with their Gram matrix kept on the
+ * host (include/LBFGSpp/GramSpace.h) an iteration needs two passes over the history instead of 2c+1 dependent ones.
+ * Supported for m <= 24 (LBFGSX_E_INVALID otherwise). */
+/* lbfgsx_post_linesearch (LBFGS.h:130,137,159-161; s, y into the spare column) plus, in the same pass, the Gram rows
+ * of the new pair and of the new gradient.  scal = {g.g, x.x, s.y, y.y, s.s, g.s, g.y}; for the logical slots
+ * j < lbfgsx_bfgs_ncorr(): sdots[j] = S_j.s, sdots[m+j] = Y_j.s, gdots[j] = S_j.g, gdots[m+j] = Y_j.g (arrays of 2m).
+ * Sums accumulate in f64 (fixed reduction order). */
+int lbfgsx_gs_post_linesearch(lbfgsx_ctx* c, double scal[7], double* sdots, double* gdots);
+/* D = coef_g * G + sum_{j < ncorr} coef[j] * S_j + coef[m+j] * Y_j (logical slots); *dg = G . D  (LBFGS.h:123) */
+int lbfgsx_gs_direction(lbfgsx_ctx* c, const double* coef, double coef_g, double* dg);
+
 /* ---- L-BFGS-B device operators (contexts created with LBFGSX_FLAG_BOUNDED) ------------------------------
  * Index sets of the reference (fv_set, newact_set, BOXCQP's L/U/P: std::vector<int>) are a per-coordinate
  * state byte on the device; every operator streams the column-contiguous S/Y once and applies the mask. */

@@ -8,6 +8,7 @@ F64, F32 = 0, 1
 OBJ_DIAG_QUAD, OBJ_EXT_ROSENBROCK = 0, 1
 LS_NOCEDAL_WRIGHT, LS_MORE_THUENTE, LS_BACKTRACKING, LS_BRACKETING = 0, 1, 2, 3
 ALGO_LBFGS, ALGO_LBFGSB = 0, 1
+RECURSION_VECTOR, RECURSION_GRAM_SPACE = 0, 1
 FLAG_BOUNDED = 1
 (VEC_X, VEC_G, VEC_XP, VEC_GP, VEC_D, VEC_XT, VEC_GT, VEC_A, VEC_B, VEC_LB, VEC_UB, VEC_XCP) = range(12)
 E_INVALID, E_LOGIC, E_RUNTIME, E_HIP, E_NOGPU = -1, -2, -3, -4, -5
@@ -103,6 +104,8 @@ def load():
     sig(core, "lbfgsx_ls_end", i32, vp, i32)
     sig(core, "lbfgsx_post_linesearch", i32, vp, pd, pd, pd, pd)
     sig(core, "lbfgsx_commit_correction", i32, vp)
+    sig(core, "lbfgsx_gs_post_linesearch", i32, vp, pd, pd, pd)
+    sig(core, "lbfgsx_gs_direction", i32, vp, pd, dbl, pd)
     sig(core, "lbfgsx_timing_enable", i32, vp, i32)
     sig(core, "lbfgsx_timing_read", i32, vp, pd, C.POINTER(i64), pd, C.POINTER(i64))
     sig(core, "lbfgsx_stream_probe", i32, vp, i32, pd, pd)
@@ -112,6 +115,7 @@ def load():
     sig(sol, "lbfgsx_solver_destroy", None, vp)
     sig(sol, "lbfgsx_solver_prepare", i32, vp, i64)
     sig(sol, "lbfgsx_solver_ctx", vp, vp)
+    sig(sol, "lbfgsx_solver_set_recursion", i32, vp, i32)
     sig(sol, "lbfgsx_solver_set_iteration_hook", i32, vp, ITER_HOOK, vp)
     sig(sol, "lbfgsx_batch_minimize", i32, i32, i32, i32, C.POINTER(Params), i32, i64, i64, i64, C.c_uint64, i32, i32,
         C.POINTER(BatchItem))

@@ -44,6 +44,8 @@ int live_count(int device);
 
 int bounded_alloc(lbfgsx_ctx* c);   // lbfgsb.hip
 void bounded_free(lbfgsx_ctx* c);
+struct GsState;                     // gram_space.hip: scratch of the Gram-space recursion (allocated on first use)
+void gs_free(lbfgsx_ctx* c);
 
 struct EventPair
 {
@@ -108,6 +110,7 @@ struct lbfgsx_ctx
     void* ub = nullptr;
     void* xcp = nullptr;
     struct lbfgsb_state* bstate = nullptr;
+    lbfgsx::GsState* gs = nullptr;
 
     // instrumentation
     bool timing = false;

@@ -297,6 +297,7 @@ void lbfgsx_destroy(lbfgsx_ctx* c)
     (void) hipFree(c->xcp);
     (void) hipFree(c->gather_tmp);
     bounded_free(c);
+    gs_free(c);
     for (auto& e : c->ev_twoloop)
     {
         (void) hipEventDestroy(e.a);

@@ -20,6 +20,7 @@ struct lbfgsx_solver
     virtual lbfgsx_ctx* ctx() = 0;
     virtual void set_hook(void (*fn)(int, void*), void* user) = 0;
     virtual int hessians(double*, double*) { return LBFGSX_E_INVALID; }
+    virtual int set_recursion(int) { return LBFGSX_E_INVALID; }
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long stats_submin_us = 0;
     long long stats2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -99,6 +100,13 @@ struct LbfgsImpl : lbfgsx_solver
             solver->set_iteration_hook([fn, user](int k) { fn(k, user); });
         else
             solver->set_iteration_hook(nullptr);
+    }
+    int set_recursion(int form) override
+    {
+        if (form != RECURSION_VECTOR && form != RECURSION_GRAM_SPACE)
+            return LBFGSX_E_INVALID;
+        solver->set_recursion(form);
+        return LBFGSX_OK;
     }
     int hessians(double* B, double* H) override
     {
@@ -468,6 +476,8 @@ int lbfgsx_solver_stats2(lbfgsx_solver* s, long long out[8])
         out[k] = s->stats2[k];
     return LBFGSX_OK;
 }
+
+int lbfgsx_solver_set_recursion(lbfgsx_solver* s, int form) { return s->set_recursion(form); }
 
 int lbfgsx_solver_set_iteration_hook(lbfgsx_solver* s, void (*fn)(int, void*), void* user)
 {

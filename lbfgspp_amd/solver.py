@@ -124,6 +124,11 @@ class _SolverBase:
         self._hook = L.ITER_HOOK((lambda k, _u: fn(k)) if fn else 0)
         L.check(self._sol.lbfgsx_solver_set_iteration_hook(self._h, self._hook, None))
 
+    def set_recursion(self, form):
+        """Extension: L.RECURSION_VECTOR (bit-parity two-loop, default) or L.RECURSION_GRAM_SPACE (coefficient-space
+        recursion over [S, Y, g]: about half the HBM traffic, equal to the vector form only up to rounding)."""
+        L.check(self._sol.lbfgsx_solver_set_recursion(self._h, int(form)), "set_recursion: unknown form, or not an L-BFGS solver")
+
     @property
     def ctx(self):
         return C.c_void_p(self._sol.lbfgsx_solver_ctx(self._h))

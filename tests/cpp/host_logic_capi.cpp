@@ -2,6 +2,7 @@
 // headers (no device call is reachable from here, so the file links without liblbfgsx):
 //   BKLDLT<double>                       include/LBFGSpp/BKLDLT.h      (reference BKLDLT.h:390-520)
 //   LineSearchMoreThuente<>::Machine     include/LBFGSpp/LineSearchMoreThuente.h (reference MoreThuente.h:213-615)
+//   GramSpaceHistory                      include/LBFGSpp/GramSpace.h   (coefficient form of reference BFGSMat.h:81-97,276-302)
 //   LBFGSParam / LBFGSBParam::check_param include/LBFGSpp/Param.h      (reference Param.h:193-217,352-376)
 // Built and driven by tests/test_host_logic_cpu.py (-m "not gpu").
 #include <cstring>
@@ -9,6 +10,7 @@
 #include <vector>
 
 #include <LBFGSpp/BKLDLT.h>
+#include <LBFGSpp/GramSpace.h>
 #include <LBFGSpp/LineSearchMoreThuente.h>
 #include <LBFGSpp/Param.h>
 
@@ -136,4 +138,64 @@ int hl_check_param(int which, int m, double epsilon, double epsilon_rel, int pas
     }
     return 0;
 }
+}
+
+// GramSpaceHistory driven exactly as LBFGSSolver::run drives it, with the device's dot products computed here on the
+// host: gradients G[0..K] (row k = gradient after k steps), steps S[0..K-1]; y_k = G[k+1] - G[k]; accept[k] = curvature
+// test outcome.  Returns the coefficients of d = -H g_K over the slots and the slot bookkeeping.
+extern "C" int hl_gram_space(int n, int m, int K, const double* S, const double* G, const unsigned char* accept,
+                             double* coef, double* coef_g, int* slot_pair /* m: pair index held by slot j, -1 = empty */)
+{
+    using LBFGSpp::GramSpaceHistory;
+    auto dot = [n](const double* a, const double* b) {
+        double t = 0;
+        for (int i = 0; i < n; i++)
+            t += a[i] * b[i];
+        return t;
+    };
+    GramSpaceHistory h;
+    h.reset(m);
+    h.set_gradient_norm2(dot(G, G));
+    std::vector<std::vector<double> > Ys;
+    Ys.assign(size_t(K), std::vector<double>(size_t(n), 0.0));
+    std::vector<int> slot(size_t(m), -1);
+    int ptr = m, ncorr = 0;
+    std::vector<double> sd(size_t(2 * m)), gd(size_t(2 * m));
+    for (int k = 0; k < K; k++)
+    {
+        const double* s = S + size_t(k) * size_t(n);
+        const double* gn = G + size_t(k + 1) * size_t(n);
+        const double* go = G + size_t(k) * size_t(n);
+        std::vector<double>& y = Ys[size_t(k)];
+        for (int i = 0; i < n; i++)
+            y[size_t(i)] = gn[i] - go[i];
+        double scal[7] = {dot(gn, gn), 0.0, dot(s, y.data()), dot(y.data(), y.data()), dot(s, s), dot(gn, s), dot(gn, y.data())};
+        for (int j = 0; j < ncorr; j++)
+        {
+            const double* sj = S + size_t(slot[size_t(j)]) * size_t(n);
+            const double* yj = Ys[size_t(slot[size_t(j)])].data();
+            sd[size_t(j)] = dot(sj, s);
+            sd[size_t(m + j)] = dot(yj, s);
+            gd[size_t(j)] = dot(sj, gn);
+            gd[size_t(m + j)] = dot(yj, gn);
+        }
+        h.update(scal, sd.data(), gd.data(), accept[k] != 0);
+        if (accept[k])
+        {
+            const int loc = ptr % m;
+            slot[size_t(loc)] = k;
+            if (ncorr < m)
+                ncorr++;
+            ptr = loc + 1;
+        }
+        if (h.ncorr() != ncorr)
+            return -1;
+    }
+    std::vector<double> cf;
+    h.direction(-1.0, cf, *coef_g);
+    for (int k = 0; k < 2 * m; k++)
+        coef[k] = cf[size_t(k)];
+    for (int j = 0; j < m; j++)
+        slot_pair[j] = slot[size_t(j)];
+    return ptr;
 }

@@ -176,3 +176,52 @@ def test_param_validation_accepts_defaults_and_checks_lbfgsb_fields(hl):
     assert _check(hl, 0, linesearch=7)[0] == 1
     rc, msg = _check(hl, 1, max_submin=-1)
     assert rc == 1 and "max_submin" in msg
+
+
+# ---- Gram-space recursion (include/LBFGSpp/GramSpace.h): the coefficient form must reproduce BFGSMat::apply_Hv
+def _two_loop(S, Y, order, v, a):
+    """reference BFGSMat.h:276-302 on explicit vectors; order = pair indices newest -> oldest"""
+    q = a * v
+    alpha = {}
+    for k in order:
+        alpha[k] = (S[k] @ q) / (S[k] @ Y[k])
+        q = q - alpha[k] * Y[k]
+    if order:
+        k0 = order[0]
+        q = q / ((Y[k0] @ Y[k0]) / (S[k0] @ Y[k0]))
+    for k in reversed(order):
+        beta = (Y[k] @ q) / (S[k] @ Y[k])
+        q = q + (alpha[k] - beta) * S[k]
+    return q
+
+
+@pytest.mark.parametrize("n,m,K,reject", [(50, 6, 0, ()), (50, 6, 1, ()), (50, 6, 4, ()), (50, 6, 6, ()), (50, 6, 15, ()),
+                                          (64, 1, 5, ()), (40, 3, 11, (2, 7)), (200, 10, 27, (0, 13)), (30, 24, 30, ())])
+def test_gram_space_direction_equals_vector_two_loop(hl, n, m, K, reject):
+    rng = np.random.default_rng(7 * n + m + K)
+    # a smooth convex model so that s.y > 0: g(x) = A x with SPD diagonal-dominant A
+    A = np.diag(1.0 + 9.0 * rng.random(n)) + 0.05 * rng.standard_normal((n, n))
+    A = 0.5 * (A + A.T) + n * 0.05 * np.eye(n)
+    X = np.cumsum(0.3 * rng.standard_normal((K + 1, n)), axis=0)
+    G = X @ A
+    S = np.ascontiguousarray(X[1:] - X[:-1])
+    Y = G[1:] - G[:-1]
+    accept = np.ones(max(K, 1), dtype=np.uint8)
+    for k in reject:
+        accept[k] = 0
+    coef = np.zeros(2 * m)
+    cg = C.c_double()
+    slots = np.zeros(m, dtype=np.int32)
+    hl.hl_gram_space.restype = C.c_int
+    ptr = hl.hl_gram_space(n, m, K, S.ctypes.data_as(C.c_void_p), np.ascontiguousarray(G).ctypes.data_as(C.c_void_p),
+                           accept.ctypes.data_as(C.c_void_p), coef.ctypes.data_as(C.c_void_p), C.byref(cg),
+                           slots.ctypes.data_as(C.c_void_p))
+    assert ptr >= 0
+    kept = [k for k in range(K) if accept[k]][-m:]           # the pairs still in the history, oldest -> newest
+    assert sorted(int(v) for v in slots if v >= 0) == kept   # cyclic slot bookkeeping == BFGSMat::add_correction
+    d = cg.value * G[K]
+    for j in range(m):
+        if slots[j] >= 0:
+            d = d + coef[j] * S[slots[j]] + coef[m + j] * Y[slots[j]]
+    ref = _two_loop(S, Y, kept[::-1], G[K], -1.0)
+    assert np.linalg.norm(d - ref) <= 1e-9 * np.linalg.norm(ref)
