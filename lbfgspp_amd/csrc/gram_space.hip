@@ -248,7 +248,7 @@ struct GsState  // per-context scratch of this mode, allocated on first use
     double* out_dev = nullptr;   // [GS_NSCAL + 2 * kGsMaxCols]
     double* out_host = nullptr;  // pinned
     unsigned* ticket = nullptr;
-    int grid_post = 512, grid_combine = 1024;
+    int grid_post = 512, grid_combine = 1024;  // measured flat between 256 and 2048 blocks (profiles/r1g_gs_grid_sweep.txt)
 };
 
 static int gs_ensure(lbfgsx_ctx* c)
@@ -319,15 +319,16 @@ static int gs_post_t(lbfgsx_ctx* c, double* scal, double* sdots, double* gdots)
         LBFGSX_HIP(hipEventCreate(&ev.b));
         LBFGSX_HIP(hipEventRecord(ev.a, c->stream));
     }
-#define GS_POST(NC)                                                                                                            \
-    do                                                                                                                         \
-    {                                                                                                                          \
-        NCsel = NC;                                                                                                            \
-        hipLaunchKernelGGL((k_gs_post<T, NC>), dim3(grid), dim3(kBlock), 0, c->stream, static_cast<const T*>(c->xb[c->cur]),   \
-                           static_cast<const T*>(c->xb[c->xp]), static_cast<const T*>(c->gb[c->cur]),                          \
-                           static_cast<const T*>(c->gb[c->xp]), static_cast<T*>(c->col(c->S, c->spare)),                       \
-                           static_cast<T*>(c->col(c->Y, c->spare)), cols, nc, c->n, c->ws.partials, g->ticket, g->out_dev,     \
-                           sc + c->sl.out(0), sc + c->sl.ys(c->spare), sc + c->sl.theta(c->spare), rev);                       \
+#define GS_POST_ARGS                                                                                                           \
+    dim3(grid), dim3(kBlock), 0, c->stream, static_cast<const T*>(c->xb[c->cur]), static_cast<const T*>(c->xb[c->xp]),         \
+        static_cast<const T*>(c->gb[c->cur]), static_cast<const T*>(c->gb[c->xp]), static_cast<T*>(c->col(c->S, c->spare)),    \
+        static_cast<T*>(c->col(c->Y, c->spare)), cols, nc, c->n, c->ws.partials, g->ticket, g->out_dev, sc + c->sl.out(0),     \
+        sc + c->sl.ys(c->spare), sc + c->sl.theta(c->spare), rev
+#define GS_POST(NC)                                                   \
+    do                                                                \
+    {                                                                 \
+        NCsel = NC;                                                   \
+        hipLaunchKernelGGL((k_gs_post<T, NC>), GS_POST_ARGS);         \
     } while (0)
     if (nc == 0) GS_POST(1);
     else if (nc <= 8) GS_POST(8);
@@ -337,6 +338,7 @@ static int gs_post_t(lbfgsx_ctx* c, double* scal, double* sdots, double* gdots)
     else if (nc <= 40) GS_POST(40);
     else GS_POST(48);
 #undef GS_POST
+#undef GS_POST_ARGS
     LBFGSX_HIP(hipGetLastError());
     if (c->timing)
     {
@@ -387,10 +389,14 @@ static int gs_direction_t(lbfgsx_ctx* c, const double* coef, double coef_g, doub
         LBFGSX_HIP(hipEventCreate(&hv.b));
         LBFGSX_HIP(hipEventRecord(hv.a, c->stream));
     }
-#define GS_COMB(NC)                                                                                                     \
-    hipLaunchKernelGGL((k_gs_combine<T, NC>), dim3(grid), dim3(kBlock), 0, c->stream, static_cast<T*>(c->d),             \
-                       static_cast<const T*>(c->gb[c->cur]), T(coef_g), cols, cf, nc, c->n, c->ws.partials, g->ticket,   \
-                       g->out_dev, rev)
+#define GS_COMB_ARGS                                                                                                    \
+    dim3(grid), dim3(kBlock), 0, c->stream, static_cast<T*>(c->d), static_cast<const T*>(c->gb[c->cur]), T(coef_g), cols, cf,   \
+        nc, c->n, c->ws.partials, g->ticket, g->out_dev, rev
+#define GS_COMB(NC)                                                              \
+    do                                                                           \
+    {                                                                            \
+        hipLaunchKernelGGL((k_gs_combine<T, NC>), GS_COMB_ARGS);                 \
+    } while (0)
     if (nc == 0) GS_COMB(1);
     else if (nc <= 8) GS_COMB(8);
     else if (nc <= 16) GS_COMB(16);
@@ -399,6 +405,7 @@ static int gs_direction_t(lbfgsx_ctx* c, const double* coef, double coef_g, doub
     else if (nc <= 40) GS_COMB(40);
     else GS_COMB(48);
 #undef GS_COMB
+#undef GS_COMB_ARGS
     LBFGSX_HIP(hipGetLastError());
     if (c->timing)
     {
