@@ -8,6 +8,15 @@
 #define ORACLE_ACC 1
 #endif
 namespace oracle {
+// Replicated-problem mode (full-size parity tests, tests/test_full_size_gpu.py): an n-vector problem whose data repeats
+// with period p = n / R is the base problem of size p with every n-length sum multiplied by R.  For R a power of two
+// and correctly rounded sums, fl(R * s) == R * fl(s), so the base problem run with replication() = R reproduces the
+// big problem's scalars -- and therefore its iterates -- bit for bit.  1 = off.  L-BFGS path only.
+inline double& replication()
+{
+    static double r = 1.0;
+    return r;
+}
 template <class S>
 struct Acc
 {

@@ -37,12 +37,12 @@ T dot(const T* a, const T* b, long n)
     T r = ((acc[0] + acc[4]) + (acc[1] + acc[5])) + ((acc[2] + acc[6]) + (acc[3] + acc[7]));
     for (; i < n; i++)
         r += a[i] * b[i];
-    return r;
+    return r * T(oracle::replication());
 #else
     Acc<T> acc;
     for (long i = 0; i < n; i++)
         acc.add_prod(a[i], b[i]);
-    return acc.value();
+    return acc.value() * T(oracle::replication());
 #endif
 }
 
@@ -707,6 +707,16 @@ int oracle_port_apply_Hv(int dtype, long n, int m, int npairs, const void* S, co
             h.add_correction(static_cast<const float*>(S) + size_t(k) * size_t(n), static_cast<const float*>(Y) + size_t(k) * size_t(n));
         h.apply_Hv(static_cast<const float*>(v), float(alpha), static_cast<float*>(res));
     }
+    return 0;
+}
+
+/* replicated-problem mode of the L-BFGS restatement (oracle/acc.h): r must be a power of two; 1 switches it off */
+int oracle_port_set_replication(double r)
+{
+    int e = 0;
+    if (!(r >= 1.0) || std::frexp(r, &e) != 0.5)
+        return -1;
+    oracle::replication() = r;
     return 0;
 }
 

@@ -19,7 +19,7 @@ T eval_objective(int obj, long n, const T* a, const T* b, const T* x, T* g)
             g[i] = a[i] * r;
             acc.add(r * r);
         }
-        return T(0.5) * acc.value();
+        return T(0.5) * (acc.value() * T(replication()));
     }
     for (long i = 0; i + 1 < n; i += 2)
     {
@@ -29,7 +29,7 @@ T eval_objective(int obj, long n, const T* a, const T* b, const T* x, T* g)
         g[i] = T(-2) * (x[i] * g[i + 1] + t1);
         acc.add(t1 * t1 + t2 * t2);
     }
-    return acc.value();
+    return acc.value() * T(replication());
 }
 }  // namespace oracle
 #endif

@@ -76,6 +76,9 @@ typedef struct
 
 ORACLE_DECL(oracle_ref)
 ORACLE_DECL(oracle_port)
+/* restatement only: every n-length sum of the L-BFGS path is multiplied by r (a power of two), which makes the run
+ * the exact image of the r-fold replicated problem -- see oracle/acc.h; 1 = off */
+int oracle_port_set_replication(double r);
 
 #ifdef __cplusplus
 }

@@ -97,6 +97,17 @@ class Oracle:
         self._cs.argtypes = [C.c_int, C.c_long, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp,
                              C.POINTER(C.c_int), vp, C.POINTER(C.c_int), vp]
 
+    def set_replication(self, r):
+        """Restatement only (oracle/acc.h): every n-length sum of the L-BFGS path is multiplied by r (a power of two), so
+        a run on a base problem of size p is the exact image of the same problem tiled r times.  1 switches it off."""
+        if self.family != "port":
+            raise RuntimeError("replicated-problem mode exists in the restatement only")
+        f = self.lib.oracle_port_set_replication
+        f.argtypes = [C.c_double]
+        f.restype = C.c_int
+        if f(float(r)) != 0:
+            raise ValueError("replication factor must be a power of two >= 1")
+
     @property
     def supports_lbfgsb(self):
         """False for the restatement until its L-BFGS-B part is built (entry points answer -1000)."""

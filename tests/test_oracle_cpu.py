@@ -176,3 +176,33 @@ def test_hessian_fixture_is_consistent_and_reproducible():
                                     O.lbfgs_params(m=c["m"], max_iterations=c["max_iterations"], epsilon=1e-6))
     assert r.niter == c["niter"]
     assert [float(v).hex() for v in B.ravel(order="F")] == c["B"]
+
+
+@pytest.mark.parametrize("ls,obj", [(O.LS_MT, O.OBJ_ROSEN), (O.LS_NW, O.OBJ_QUAD), (O.LS_BT, O.OBJ_ROSEN)])
+@pytest.mark.parametrize("R", [2, 64])
+def test_replicated_problem_mode_is_the_exact_image_of_the_tiled_problem(ls, obj, R):
+    """The knob behind the full-size GPU parity tests (tests/test_full_size_gpu.py): the restatement on a base problem
+    of size p with every n-length sum multiplied by R == the R-fold tiled problem, bit for bit -- checked here against the
+    tiled problem solved by the UNMODIFIED reference headers (oracle/_ref) when present, else by the restatement."""
+    if not O.available("port", "dd"):
+        pytest.skip("restatement not built")
+    port = O.Oracle("port", "dd")
+    big_oracle = O.Oracle("ref", "dd") if O.available("ref", "dd") else port
+    p = 250
+    par = O.lbfgs_params(m=4, epsilon=0, epsilon_rel=0, max_iterations=14)
+    if obj == O.OBJ_ROSEN:
+        x0, a, b = O.rosen_x0(p), None, None
+    else:
+        a, b = O.quad_problem(p)
+        x0 = np.zeros(p)
+    tile = lambda v: None if v is None else np.tile(v, R)
+    trb, trs = O.TraceBuf(p * R, cap=64, with_x=False), O.TraceBuf(p, cap=64, with_x=False)
+    xb, rb = big_oracle.lbfgs(O.F64, ls, obj, tile(x0), par, a=tile(a), b=tile(b), trace=trb)
+    port.set_replication(R)
+    try:
+        xs, rs = port.lbfgs(O.F64, ls, obj, x0, par, a=a, b=b, trace=trs)
+    finally:
+        port.set_replication(1)
+    assert (rb.niter, rb.nfev, rb.fx, rb.gnorm) == (rs.niter, rs.nfev, rs.fx, rs.gnorm)
+    assert np.array_equal(trb.fx[:trb.count], trs.fx[:trs.count])
+    assert np.array_equal(xb.reshape(R, p), np.tile(xs, (R, 1)))
