@@ -14,7 +14,8 @@ rnd = sys.argv[1] if len(sys.argv) > 1 else "r1"
 src = os.path.join("gpurun_out", "prof_" + rnd)
 os.makedirs("profiles", exist_ok=True)
 shutil.copy(os.path.join(src, "trace", "bench_kernel_stats.csv"), os.path.join("profiles", rnd + "_kernel_stats.csv"))
-for name in ("northstar", "cfg3_m20", "cfg2_quad1e7", "cfg5_batched", "cfg4_lbfgsb", "cfg4_lbfgsb_mfma"):
+for name in ("northstar", "northstar_gram", "cfg3_m20", "cfg3_m20_gram", "cfg2_quad1e7", "cfg5_batched", "cfg4_lbfgsb",
+             "cfg4_lbfgsb_mfma"):
     f = os.path.join(src, "bench_%s.json" % name)
     if os.path.exists(f):
         shutil.copy(f, os.path.join("profiles", "%s_bench_%s.json" % (rnd, name)))
@@ -76,3 +77,36 @@ with open(os.path.join("profiles", rnd + "_pmc_summary.json"), "w") as f:
 print(json.dumps({k: v for k, v in out.items() if k != "kernels"}, indent=1))
 for k, v in out["kernels"].items():
     print("%-40s calls %4d avg %.4f ms  hbm %.4g B  %.0f GB/s" % (k[:40], v["calls"], v["avg_ms"], v["hbm_bytes_per_launch"], v["hbm_GBs"] or 0))
+
+
+# ---- the opt-in Gram-space recursion: same counters for its two kernels
+gsrc = os.path.join(src, "gram_trace", "bench_kernel_stats.csv")
+if os.path.exists(gsrc):
+    shutil.copy(gsrc, os.path.join("profiles", rnd + "_gram_kernel_stats.csv"))
+    gagg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for which in ("gram_pmc_fetch", "gram_pmc_write"):
+        fn = os.path.join(src, which, "bench_counter_collection.csv")
+        if os.path.exists(fn):
+            with open(fn) as f:
+                for r in csv.DictReader(f):
+                    gagg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    gstats = {}
+    with open(gsrc) as f:
+        for r in csv.DictReader(f):
+            gstats[short(r["Name"])] = (int(r["Calls"]), float(r["AverageNs"]))
+    gout = {"round": rnd, "command": out["command"].replace("bench.py", "bench.py --recursion gram"), "units": out["units"],
+            "note": "launches start from an empty history (m = 10): launch k reads 2*min(k,10) columns, so the per-launch "
+                    "averages below mix the warm-up launches with the full-history ones; max_* are the full-history launches",
+            "kernels": {}}
+    for k, c in sorted(gagg.items()):
+        if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c or not k.startswith("k_gs_"):
+            continue
+        hb = [(2.0 * fv + wv) * 1024.0 for fv, wv in zip(c["FETCH_SIZE"], c["WRITE_SIZE"])]
+        calls, avg_ns = gstats.get(k, (0, 0.0))
+        gout["kernels"][k] = {"calls": calls, "avg_ms": avg_ns * 1e-6, "hbm_bytes_per_launch_avg": sum(hb) / len(hb),
+                              "hbm_bytes_per_launch_max": max(hb)}
+    with open(os.path.join("profiles", rnd + "_gram_pmc_summary.json"), "w") as f:
+        json.dump(gout, f, indent=1)
+    for k, v in gout["kernels"].items():
+        print("%-40s calls %4d avg %.4f ms  hbm avg %.4g B max %.4g B" % (k[:40], v["calls"], v["avg_ms"],
+                                                                          v["hbm_bytes_per_launch_avg"], v["hbm_bytes_per_launch_max"]))
