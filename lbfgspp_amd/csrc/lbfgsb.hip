@@ -35,7 +35,8 @@ struct lbfgsb_state
     int gram_blocks = 1024;  // 4 resident blocks per CU (33 KB of LDS each)
     bool gram_mfma = false;  // opt-in (LBFGSX_GRAM=mfma): ~1 ulp per entry instead of the correctly rounded sums
     int gram_mode = 0;       // 2 (LBFGSX_GRAM=blocked): force the multi-launch blocked Gram + separate W'v
-    int gram_dd_blocks = 512;
+    int gram_dd_blocks = 0;          // LBFGSX_GRAM_DD_BLOCKS: 0 = occupancy x CUs
+    int num_cus = 256;
     int dots_grid = 512;            // LBFGSX_DOTS_GRID: blocks of the all-column multi-dot kernels
     bool multidot_chunked = false;  // LBFGSX_MULTIDOT=chunked: 8 columns per launch (round-1a kernel)
     // device GCP search (gcp_scan.cuh): per-chunk work set, allocated on first use
@@ -185,6 +186,13 @@ int bounded_alloc(lbfgsx_ctx* c)
         b->multidot_chunked = (std::strcmp(e, "chunked") == 0);
     if (const char* e = getenv("LBFGSX_GRAM_BLOCKS"))
         b->gram_blocks = std::max(64, std::min(atoi(e), 4096));
+    if (const char* e = getenv("LBFGSX_GRAM_DD_BLOCKS"))
+        b->gram_dd_blocks = std::max(0, atoi(e));
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0)
+            b->num_cus = prop.multiProcessorCount;
+    }
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->gram_partial), sizeof(double) * size_t(b->gram_blocks) * 3 * 256 * 2));
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->gram_partial2), sizeof(double) * 32 * 3 * 256 * 2));
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->gram_out), sizeof(double) * 3 * 256));
@@ -908,14 +916,25 @@ int lbfgsx_b_gram(lbfgsx_ctx* c, int mask, double* gram)
 // caller then falls back to lbfgsx_b_gram + lbfgsx_b_wtv.
 }  // extern "C"
 template <class T, int KP>
-static void launch_gram_dd(lbfgsx_ctx* c, int blocks, int tot, int vsel_id, int mask, const GramPrologue<T>& pro)
+static int launch_gram_dd(lbfgsx_ctx* c, int64_t nbatch, int tot, int vsel_id, int mask, const GramPrologue<T>& pro)
 {
+    lbfgsb_state* b = c->bstate;
+    const size_t lds = gram_dd_lds_bytes(gram_dd_cs(KP), KP);
+    // one persistent wave set per resident slot: occupancy x CUs blocks (3 per CU at m = 10)
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_gram_dd<T, KP>, kBlock, lds) != hipSuccess || occ < 1)
+        occ = 2;
+    int blocks = std::min(b->gram_blocks, occ * b->num_cus);
+    if (b->gram_dd_blocks > 0)
+        blocks = std::min(b->gram_blocks, b->gram_dd_blocks);
+    blocks = int(std::max<int64_t>(1, std::min<int64_t>(blocks, (nbatch + 3) / 4)));
     int which[32];
     for (int k = 0; k < tot; k++)
         which[k] = k;
     Cols<T, 32> cl = col_list<T, 32>(c, which, tot);
-    hipLaunchKernelGGL((k_gram_dd<T, KP>), dim3(blocks), dim3(kBlock), 0, c->stream, cl, tot, bvecs<T>(c), vsel_id, mask,
-                       c->n, c->bstate->gram_partial, pro);
+    hipLaunchKernelGGL((k_gram_dd<T, KP>), dim3(blocks), dim3(kBlock), lds, c->stream, cl, tot, bvecs<T>(c), vsel_id, mask,
+                       c->n, b->gram_partial, pro);
+    return blocks;
 }
 extern "C" {
 
@@ -985,8 +1004,7 @@ int lbfgsx_b_gram_fused_ex(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
     const int npairs = ntot * (ntot + 1) / 2;
     const int kp = (npairs + 63) / 64;  // pairs per lane: 1, 2, 4, 6 or 8 (ntot <= 31 -> 496 pairs)
     const int64_t nbatch = (c->n + kGramDDRows - 1) / kGramDDRows;
-    // 2 blocks (64 KB of LDS each) are resident per CU: one persistent wave set per slot
-    const int blocks = int(std::max<int64_t>(1, std::min<int64_t>(b->gram_dd_blocks, (nbatch + 3) / 4)));
+    int blocks = 1;
     rc = upload_phys(c);
     if (rc)
         return rc;
@@ -1000,11 +1018,11 @@ int lbfgsx_b_gram_fused_ex(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
             pro.c1[k] = (coef1 && k < tot) ? T(coef1[k]) : T(0);
             pro.c2[k] = (coef2 && k < tot) ? T(coef2[k]) : T(0);
         }
-        if (kp <= 1) launch_gram_dd<T, 1>(c, blocks, tot, vsel_id, mask, pro);
-        else if (kp <= 2) launch_gram_dd<T, 2>(c, blocks, tot, vsel_id, mask, pro);
-        else if (kp <= 4) launch_gram_dd<T, 4>(c, blocks, tot, vsel_id, mask, pro);
-        else if (kp <= 6) launch_gram_dd<T, 6>(c, blocks, tot, vsel_id, mask, pro);
-        else launch_gram_dd<T, 8>(c, blocks, tot, vsel_id, mask, pro);
+        if (kp <= 1) blocks = launch_gram_dd<T, 1>(c, nbatch, tot, vsel_id, mask, pro);
+        else if (kp <= 2) blocks = launch_gram_dd<T, 2>(c, nbatch, tot, vsel_id, mask, pro);
+        else if (kp <= 4) blocks = launch_gram_dd<T, 4>(c, nbatch, tot, vsel_id, mask, pro);
+        else if (kp <= 6) blocks = launch_gram_dd<T, 6>(c, nbatch, tot, vsel_id, mask, pro);
+        else blocks = launch_gram_dd<T, 8>(c, nbatch, tot, vsel_id, mask, pro);
     });
     const int kpt = kp <= 1 ? 1 : kp <= 2 ? 2 : kp <= 4 ? 4 : kp <= 6 ? 6 : 8;
     const int ntile = (64 * kpt + 255) / 256;

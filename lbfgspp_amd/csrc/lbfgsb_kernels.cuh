@@ -504,13 +504,27 @@ struct GramPrologue
 };
 
 constexpr int kGramDDRows = 64;
-constexpr int kGramDDCS = 31;  // tile row stride (doubles): odd, >= ntot
+constexpr int kGramDDCS = 31;  // largest tile row stride (doubles): ntot <= 31
+
+// LDS bytes of one block: the four wave-private tiles [64 rows][cs], re-used at the end as the block-reduction scratch
+// [wave][KP][64][2].  cs = the smallest odd value >= ntot: at m = 10 (ntot = 21) a block needs 43 KB instead of the
+// 63.5 KB of the fixed 31-double stride, so three blocks (3 waves per SIMD) are resident per CU instead of two.
+// The stride is a compile-time function of KP (pairs per lane): the largest ntot a KP serves, made odd -- so the row
+// offsets of the LDS reads are instruction immediates.  KP 1: ntot <= 10, 2: <= 15, 4: <= 22, 6: <= 27, 8: <= 31.
+constexpr int gram_dd_cs(int kp) { return kp <= 1 ? 11 : kp <= 2 ? 15 : kp <= 4 ? 23 : kp <= 6 ? 27 : 31; }
+inline size_t gram_dd_lds_bytes(int cs, int kp)
+{
+    const size_t tile = size_t(kBlock / 64) * kGramDDRows * size_t(cs) * sizeof(double);
+    const size_t scr = size_t(kBlock / 64) * size_t(kp) * 64 * 2 * sizeof(double);
+    return tile > scr ? tile : scr;
+}
 
 template <class T, int KP>
 __global__ void __launch_bounds__(kBlock) k_gram_dd(Cols<T, 32> cols, int ncols, BVecs<T> b, int vsel_id, int mask,
                                                     int64_t n, double* __restrict__ partial, GramPrologue<T> pro)
 {
-    __shared__ double tile[(kBlock / 64) * kGramDDRows * kGramDDCS];
+    constexpr int cs = gram_dd_cs(KP);
+    extern __shared__ double tile[];
     __shared__ T pc1[64], pc2[64];
     if (pro.mode != GP_NONE)
     {
@@ -524,7 +538,7 @@ __global__ void __launch_bounds__(kBlock) k_gram_dd(Cols<T, 32> cols, int ncols,
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ntot = ncols + (vsel_id >= 0 ? 1 : 0);
     const int npairs = ntot * (ntot + 1) / 2;
-    double* tl = tile + wv * (kGramDDRows * kGramDDCS);
+    double* tl = tile + wv * (kGramDDRows * cs);
     int pi[KP], pj[KP];
 #pragma unroll
     for (int k = 0; k < KP; k++)
@@ -552,7 +566,7 @@ __global__ void __launch_bounds__(kBlock) k_gram_dd(Cols<T, 32> cols, int ncols,
         const int pos = __popcll(bal & ((1ull << lane) - 1ull));
         if (keep)
         {
-            double* row = tl + pos * kGramDDCS;
+            double* row = tl + pos * cs;
             for (int c0 = 0; c0 < ncols; c0 += 8)
             {
                 // eight independent loads in flight per lane
@@ -595,20 +609,36 @@ __global__ void __launch_bounds__(kBlock) k_gram_dd(Cols<T, 32> cols, int ncols,
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         int rr = 0;
-        for (; rr + 1 < cnt; rr += 2)
         {
-            const double* ra = tl + rr * kGramDDCS;
-            const double* rb = ra + kGramDDCS;
-#pragma unroll
-            for (int k = 0; k < KP; k++)
+            // eight rows per trip: one address per operand and lane, the rows reached through instruction immediates
+            // (the per-entry order of the additions is unchanged: even rows into acc0, odd rows into acc1)
+            for (; rr + 7 < cnt; rr += 8)
             {
-                acc0[k].add_prod(ra[pi[k]], ra[pj[k]]);
-                acc1[k].add_prod(rb[pi[k]], rb[pj[k]]);
+                const double* r0 = tl + rr * cs;
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int k = 0; k < KP; k++)
+                    {
+                        acc0[k].add_prod(r0[pi[k] + (2 * q) * cs], r0[pj[k] + (2 * q) * cs]);
+                        acc1[k].add_prod(r0[pi[k] + (2 * q + 1) * cs], r0[pj[k] + (2 * q + 1) * cs]);
+                    }
+            }
+            for (; rr + 1 < cnt; rr += 2)
+            {
+                const double* ra = tl + rr * cs;
+                const double* rb = ra + cs;
+#pragma unroll
+                for (int k = 0; k < KP; k++)
+                {
+                    acc0[k].add_prod(ra[pi[k]], ra[pj[k]]);
+                    acc1[k].add_prod(rb[pi[k]], rb[pj[k]]);
+                }
             }
         }
         if (rr < cnt)
         {
-            const double* ra = tl + rr * kGramDDCS;
+            const double* ra = tl + rr * cs;
 #pragma unroll
             for (int k = 0; k < KP; k++)
                 acc0[k].add_prod(ra[pi[k]], ra[pj[k]]);
