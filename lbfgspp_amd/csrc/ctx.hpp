@@ -86,6 +86,11 @@ struct lbfgsx_ctx
     lbfgsx::ScLayout sl;
     void* sc = nullptr;      // device, T[sl.total()]
     void* hout = nullptr;    // pinned host staging
+    // Kernel outputs the host consumes right away (the `out(k)` slots) live in host-mapped pinned memory: the last block
+    // of a reduction stores them straight into it, so a fetch is a stream synchronisation instead of a copy kernel plus a
+    // synchronisation (an L-BFGS-B iteration makes ~50 such fetches).  Used by LBFGSX_FLAG_BOUNDED contexts (lbfgsx_create).
+    void* outmap_host = nullptr;
+    void* outmap_dev = nullptr;
     lbfgsx::RedWs ws;
     int grid_cap = 1024;     // blocks per launch of the streaming kernels (4 per CU; tuned on MI355X, see profiles/)
     int grid_cap_twoloop = 512;
@@ -118,6 +123,11 @@ struct lbfgsx_ctx
     void* gather_tmp = nullptr;
     int64_t gather_cap = 0;
 
+    template <class T>
+    T* out_slot() const  // where kernels put the scalars of sl.out(0..15)
+    {
+        return outmap_dev ? static_cast<T*>(outmap_dev) : static_cast<T*>(sc) + sl.out(0);
+    }
     void* col(void* base, int c) const { return static_cast<char*>(base) + size_t(c) * size_t(ld) * esz; }
     int grid_for(int64_t nelem, int unroll_ = 1) const
     {

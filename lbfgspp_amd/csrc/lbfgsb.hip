@@ -21,7 +21,9 @@ struct lbfgsb_state
     void* sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     int* phys_dev = nullptr;          // logical slot -> physical column, device copy
-    double* dout = nullptr;           // device staging for double outputs [64]
+    double* dout = nullptr;           // double outputs of the kernels [64]: device pointer of host-mapped memory, or
+    double* dout_host = nullptr;      //   (LBFGSX_MAPPED_OUT=0) plain device memory fetched by a copy
+    double* gram_out_host = nullptr;  // same for gram_out
     void* coef_dev = nullptr;         // T[80]
     unsigned long long* mslot = nullptr;  // max / min slots
     // chunk staging for the sequential GCP scan
@@ -114,6 +116,15 @@ static int upload_phys(lbfgsx_ctx* c)
 
 static int fetch_doubles(lbfgsx_ctx* c, int k, double* out)
 {
+    if (c->bstate->dout_host)
+    {
+        // dout is host-mapped: the kernel's stores are visible once the stream has drained (no copy kernel)
+        LBFGSX_HIP(hipStreamSynchronize(c->stream));
+        const volatile double* h = c->bstate->dout_host;
+        for (int i = 0; i < k; i++)
+            out[i] = h[i];
+        return LBFGSX_OK;
+    }
     LBFGSX_HIP(hipMemcpyAsync(c->hout, c->bstate->dout, sizeof(double) * size_t(k), hipMemcpyDeviceToHost, c->stream));
     LBFGSX_HIP(hipStreamSynchronize(c->stream));
     std::memcpy(out, c->hout, sizeof(double) * size_t(k));
@@ -123,6 +134,14 @@ static int fetch_doubles(lbfgsx_ctx* c, int k, double* out)
 template <class T>
 static int fetch_T(lbfgsx_ctx* c, int idx, int k, double* out)
 {
+    if (idx == c->sl.out(0) && c->outmap_dev)
+    {
+        LBFGSX_HIP(hipStreamSynchronize(c->stream));
+        const volatile T* h = static_cast<const volatile T*>(c->outmap_host);
+        for (int i = 0; i < k; i++)
+            out[i] = double(h[i]);
+        return LBFGSX_OK;
+    }
     LBFGSX_HIP(hipMemcpyAsync(c->hout, P<T>(c->sc) + idx, sizeof(T) * size_t(k), hipMemcpyDeviceToHost, c->stream));
     LBFGSX_HIP(hipStreamSynchronize(c->stream));
     const T* h = static_cast<const T*>(c->hout);
@@ -164,7 +183,14 @@ int bounded_alloc(lbfgsx_ctx* c)
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->vals_in), sizeof(int) * size_t(c->ld)));
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->vals_out), sizeof(int) * size_t(c->ld)));
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->phys_dev), sizeof(int) * size_t(c->m + 1)));
-    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->dout), sizeof(double) * 64));
+    if (c->outmap_dev)
+    {
+        LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->dout_host), sizeof(double) * 64, hipHostMallocMapped));
+        std::memset(b->dout_host, 0, sizeof(double) * 64);
+        LBFGSX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->dout), b->dout_host, 0));
+    }
+    else
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->dout), sizeof(double) * 64));
     LBFGSX_HIP(hipMalloc(&b->coef_dev, sizeof(double) * 80));
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->mslot), sizeof(unsigned long long) * 2));
     // radix sort temporary storage
@@ -195,7 +221,13 @@ int bounded_alloc(lbfgsx_ctx* c)
     }
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->gram_partial), sizeof(double) * size_t(b->gram_blocks) * 3 * 256 * 2));
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->gram_partial2), sizeof(double) * 32 * 3 * 256 * 2));
-    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->gram_out), sizeof(double) * 3 * 256));
+    if (c->outmap_dev)
+    {
+        LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->gram_out_host), sizeof(double) * 3 * 256, hipHostMallocMapped));
+        LBFGSX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->gram_out), b->gram_out_host, 0));
+    }
+    else
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->gram_out), sizeof(double) * 3 * 256));
     b->sort_tmp_bytes = bytes;
     LBFGSX_HIP(hipMalloc(&b->sort_tmp, bytes ? bytes : 16));
     return LBFGSX_OK;
@@ -212,7 +244,16 @@ void bounded_free(lbfgsx_ctx* c)
                     b->s_brk, b->s_g, b->s_z, b->s_W, b->s_P, b->s_C, b->s_fpp, b->s_dfp, b->s_fp, b->s_ts, b->s_off,
                     b->s_small, b->s_exit, b->pk, b->pv, b->pcount, b->sel_tmp};
     for (void* p : ptrs)
+    {
+        // dout / gram_out are device aliases of host-mapped memory when the mapped outputs are on
+        if ((p == b->dout && b->dout_host) || (p == b->gram_out && b->gram_out_host))
+            continue;
         (void) hipFree(p);
+    }
+    if (b->dout_host)
+        (void) hipHostFree(b->dout_host);
+    if (b->gram_out_host)
+        (void) hipHostFree(b->gram_out_host);
     delete b;
     c->bstate = nullptr;
 }
@@ -371,7 +412,7 @@ static int b_eval_t(lbfgsx_ctx* c, OBJ obj, double* r3)
     if (rc)
         return rc;
     hipLaunchKernelGGL((k_b_eval<T, OBJ>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]), P<T>(c->gb[c->cur]),
-                       P<T>(c->lb), P<T>(c->ub), c->n, obj, c->ws, P<T>(c->sc) + c->sl.out(0), c->bstate->mslot);
+                       P<T>(c->lb), P<T>(c->ub), c->n, obj, c->ws, c->out_slot<T>(), c->bstate->mslot);
     LBFGSX_HIP(hipGetLastError());
     rc = fetch_T<T>(c, c->sl.out(0), 2, r3);
     if (rc)
@@ -417,7 +458,7 @@ int lbfgsx_b_norms(lbfgsx_ctx* c, double* projgnorm, double* xnorm2)
     double r[1];
     DISPATCH_T(c, {
         hipLaunchKernelGGL((k_b_norms<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]), P<T>(c->gb[c->cur]),
-                           P<T>(c->lb), P<T>(c->ub), c->n, c->ws, P<T>(c->sc) + c->sl.out(0), c->bstate->mslot);
+                           P<T>(c->lb), P<T>(c->ub), c->n, c->ws, c->out_slot<T>(), c->bstate->mslot);
         LBFGSX_HIP(hipGetLastError());
         rc = fetch_T<T>(c, c->sl.out(0), 1, r);
     });
@@ -440,7 +481,7 @@ int lbfgsx_b_dg_maxstep(lbfgsx_ctx* c, double* dg, double* step_max)
     DISPATCH_T(c, {
         hipLaunchKernelGGL((k_b_dg_maxstep<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]),
                            P<T>(c->gb[c->cur]), P<T>(c->d), P<T>(c->lb), P<T>(c->ub), c->n, c->ws,
-                           P<T>(c->sc) + c->sl.out(0), c->bstate->mslot);
+                           c->out_slot<T>(), c->bstate->mslot);
         LBFGSX_HIP(hipGetLastError());
         rc = fetch_T<T>(c, c->sl.out(0), 1, r);
     });
@@ -463,7 +504,7 @@ int lbfgsx_b_post_linesearch(lbfgsx_ctx* c, double* projgnorm, double* xnorm2, d
     DISPATCH_T(c, {
         hipLaunchKernelGGL((k_b_post<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]), P<T>(c->xb[c->xp]),
                            P<T>(c->gb[c->cur]), P<T>(c->gb[c->xp]), P<T>(c->lb), P<T>(c->ub), P<T>(c->col(c->S, c->spare)),
-                           P<T>(c->col(c->Y, c->spare)), c->n, c->ws, P<T>(c->sc) + c->sl.out(0),
+                           P<T>(c->col(c->Y, c->spare)), c->n, c->ws, c->out_slot<T>(),
                            P<T>(c->sc) + c->sl.ys(c->spare), P<T>(c->sc) + c->sl.theta(c->spare), c->bstate->mslot);
         LBFGSX_HIP(hipGetLastError());
         rc = fetch_T<T>(c, c->sl.out(0), 3, r);
@@ -980,8 +1021,16 @@ int lbfgsx_b_gram_fused_ex(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
         hipLaunchKernelGGL(k_gram_finish, dim3(3, nch), dim3(kBlock), 0, c->stream, b->gram_partial, blocks, b->gram_partial2, 0);
         hipLaunchKernelGGL(k_gram_finish, dim3(3, 1), dim3(kBlock), 0, c->stream, b->gram_partial2, nch, b->gram_out, 1);
         LBFGSX_HIP(hipGetLastError());
-        LBFGSX_HIP(hipMemcpyAsync(h, b->gram_out, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-        LBFGSX_HIP(hipStreamSynchronize(c->stream));
+        if (b->gram_out_host)
+        {
+            LBFGSX_HIP(hipStreamSynchronize(c->stream));
+            std::memcpy(h, b->gram_out_host, sizeof(h));
+        }
+        else
+        {
+            LBFGSX_HIP(hipMemcpyAsync(h, b->gram_out, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+            LBFGSX_HIP(hipStreamSynchronize(c->stream));
+        }
         // entry (I, J), I >= J, of the padded 32 x 32 Gram
         auto G = [&](int I, int J) {
             const int tb = (I < 16) ? 0 : (J < 16 ? 1 : 2);
@@ -1030,8 +1079,16 @@ int lbfgsx_b_gram_fused_ex(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
     hipLaunchKernelGGL(k_gram_finish, dim3(ntile, nch), dim3(kBlock), 0, c->stream, b->gram_partial, blocks, b->gram_partial2, 0);
     hipLaunchKernelGGL(k_gram_finish, dim3(ntile, 1), dim3(kBlock), 0, c->stream, b->gram_partial2, nch, b->gram_out, 1);
     LBFGSX_HIP(hipGetLastError());
-    LBFGSX_HIP(hipMemcpyAsync(h, b->gram_out, sizeof(double) * size_t(ntile) * 256, hipMemcpyDeviceToHost, c->stream));
-    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    if (b->gram_out_host)
+    {
+        LBFGSX_HIP(hipStreamSynchronize(c->stream));
+        std::memcpy(h, b->gram_out_host, sizeof(double) * size_t(ntile) * 256);
+    }
+    else
+    {
+        LBFGSX_HIP(hipMemcpyAsync(h, b->gram_out, sizeof(double) * size_t(ntile) * 256, hipMemcpyDeviceToHost, c->stream));
+        LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    }
     for (int i = 0; i < tot; i++)
         for (int j = 0; j <= i; j++)
         {
@@ -1179,7 +1236,7 @@ int lbfgsx_b_dot_drt_g(lbfgsx_ctx* c, double* dg)
     double r[2];
     DISPATCH_T(c, {
         hipLaunchKernelGGL((k_dot<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->d), P<T>(c->gb[c->cur]),
-                           static_cast<const T*>(nullptr), c->n, c->ws, P<T>(c->sc) + c->sl.out(0));
+                           static_cast<const T*>(nullptr), c->n, c->ws, c->out_slot<T>());
         LBFGSX_HIP(hipGetLastError());
         int rc = fetch_T<T>(c, c->sl.out(0), 1, r);
         if (rc)
@@ -1198,7 +1255,7 @@ int lbfgsx_b_dir_from_xcp(lbfgsx_ctx* c, int normalize)
     double r[1];
     DISPATCH_T(c, {
         hipLaunchKernelGGL((k_b_dir_from_xcp<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xcp), P<T>(c->xb[c->cur]),
-                           P<T>(c->d), c->n, c->ws, P<T>(c->sc) + c->sl.out(0));
+                           P<T>(c->d), c->n, c->ws, c->out_slot<T>());
         LBFGSX_HIP(hipGetLastError());
         if (normalize)
         {
