@@ -301,7 +301,7 @@ def main():
                                            "avg_launch_ms": comb_s * 1e3,
                                            "achieved": comb_bytes / comb_s / 1e9 if comb_s > 0 else 0.0},
                                "stream_copy_GBs": copy_gbs.value, "stream_triad_GBs": triad_gbs.value}
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:  # the CPU baseline is timed on rank 0 of the single-GPU run only
             try:
                 out["cpu_baseline"] = cpu_baseline(args)
             except Exception as e:  # the baseline is reported, never required

@@ -32,13 +32,39 @@ def _glob(d, exts):
     return out
 
 
+def _compile_one(args):
+    src, obj, flags, verbose = args
+    cmd = [HIPCC] + flags + ["-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return obj
+
+
 def build(force=False, verbose=False):
     inc = os.path.join(os.path.dirname(HERE), "include")
     hip_src = sorted(f for f in _glob(CSRC, (".hip",)))
-    deps = _glob(CSRC, (".hip", ".cuh", ".hpp", ".cpp", ".map")) + _glob(inc, (".h",))
+    common = _glob(CSRC, (".cuh", ".hpp", ".map")) + _glob(inc, (".h",))
     lib = os.path.join(HERE, "liblbfgsx.so")
-    if force or _stale(lib, deps):
-        cmd = [HIPCC] + HIP_FLAGS + hip_src + ["-o", lib, "-Wl,--version-script=" + os.path.join(CSRC, "export.map")]
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    cflags = [f for f in HIP_FLAGS if f != "-shared"]
+    # one object per translation unit, stale ones compiled concurrently (hipcc handles a list of sources serially)
+    jobs = []
+    objs = []
+    for src in hip_src:
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + common):
+            jobs.append((src, obj, cflags, verbose))
+    if jobs:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+            list(ex.map(_compile_one, jobs))
+    deps = objs + _glob(CSRC, (".cpp",)) + common
+    if force or jobs or _stale(lib, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + \
+              ["-o", lib, "-Wl,--version-script=" + os.path.join(CSRC, "export.map")]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

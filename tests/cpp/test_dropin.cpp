@@ -213,6 +213,24 @@ int main()
             EXPECT(x[size_t(i)] == xb[size_t(i)]);
         lbfgsx_destroy(scratch);
     }
+    {  // extension: Gram-space form of the recursion with a HOST functor (reference signature) -- same answer as the
+       // vector form up to rounding, same 22-iteration neighbourhood on the README problem
+        LBFGSParam<double> param;
+        param.epsilon = 1e-6;
+        param.max_iterations = 100;
+        LBFGSSolver<double> solver(param);
+        solver.set_recursion(RECURSION_GRAM_SPACE);
+        EXPECT(solver.recursion() == RECURSION_GRAM_SPACE);
+        RosenbrockPairs f{10};
+        Vec x(10, 0.0);
+        double fx;
+        int niter = solver.minimize(f, x, fx);
+        std::printf("rosenbrock(host functor, Gram-space recursion): %d iterations, %d calls, f=%g\n", niter, f.calls, fx);
+        EXPECT(niter >= 18 && niter <= 26);
+        EXPECT(fx < 1e-10);
+        for (int i = 0; i < 10; i++)
+            EXPECT(std::fabs(x[i] - 1.0) < 1e-4);
+    }
     {  // constructor validation
         LBFGSParam<float> p;
         p.m = 0;
