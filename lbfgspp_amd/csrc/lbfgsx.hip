@@ -542,7 +542,7 @@ static int apply_Hv_t(lbfgsx_ctx* c, const T* v, T a, double* dg)
     const T* gcur = P<T>(c->gb[c->cur]);
     const ScLayout& sl = c->sl;
     // physical columns newest -> oldest (BFGSMat.h:284-287)
-    int pcol[64];
+    std::vector<int> pcol(size_t(cn > 0 ? cn : 1));  // any history length (the reference has no limit on m)
     {
         int j = c->ptr % m;
         for (int i = 0; i < cn; i++)
@@ -715,11 +715,6 @@ int lbfgsx_apply_Hv(lbfgsx_ctx* c, int v_which, double a, double* dg)
     if (!v || v == c->d)
     {
         set_error("lbfgsx_apply_Hv: invalid source vector");
-        return LBFGSX_E_INVALID;
-    }
-    if (c->m > 31)
-    {
-        set_error("lbfgsx_apply_Hv: m > 31 not supported");
         return LBFGSX_E_INVALID;
     }
     DISPATCH_T(c, { return apply_Hv_t<T>(c, P<T>(v), T(a), dg); });
