@@ -168,10 +168,11 @@ def main():
     ap.add_argument("--workload", default="north-star", choices=["north-star", "cfg5-batched"],
                     help="north-star (default, the BASELINE.json metric) or the batched cfg5 shard per GPU")
     ap.add_argument("--problems-per-gpu", type=int, default=1024)
-    ap.add_argument("--recursion", default="vector", choices=["vector", "gram"],
+    ap.add_argument("--recursion", default="vector", choices=["vector", "gram", "gram-f32h"],
                     help="vector (default): the reference's two-loop recursion statement by statement, the bit-parity "
                          "path the BASELINE metric is quoted on; gram: opt-in Gram-space form (SURVEY 8(f)-3), equal to "
-                         "the vector form only up to rounding -- reported under its own metric name")
+                         "the vector form only up to rounding; gram-f32h: the same with S, Y stored as float (SURVEY "
+                         "8(f)-4) -- both reported under their own metric names")
     args = ap.parse_args()
     if args.workload == "cfg5-batched":
         return main_batched(args)
@@ -191,9 +192,10 @@ def main():
     ls = A.LS_MORE_THUENTE if args.objective == "rosenbrock" else A.LS_NOCEDAL_WRIGHT
     par = A.LBFGSParam(m=m, epsilon=0.0, epsilon_rel=0.0, past=0, max_iterations=W + K + 1)
     solver = A.LBFGSSolver(par, linesearch=ls, dtype="float64", device=local)
-    gram = args.recursion == "gram"
+    gram = args.recursion != "vector"
+    f32h = args.recursion == "gram-f32h"
     if gram:
-        solver.set_recursion(L.RECURSION_GRAM_SPACE)
+        solver.set_recursion(L.RECURSION_GRAM_SPACE_F32H if f32h else L.RECURSION_GRAM_SPACE)
     ctx = solver.prepare(n)
     if args.objective == "rosenbrock":
         L.check(core.lbfgsx_gen_rosen_x0(ctx, 7 + rank))
@@ -255,12 +257,14 @@ def main():
         if gram:
             # tl_* = k_gs_post launches ((2m+6) n elements), hv_* = k_gs_combine launches ((2m+2) n elements)
             post_bytes, comb_bytes = (2 * m + 6) * n * esz, (2 * m + 2) * n * esz
+            if f32h:  # the 2m history columns (and the two written ones) are 4-byte elements
+                post_bytes, comb_bytes = (2 * m * 4 + 4 * esz + 2 * 4) * n, (2 * m * 4 + 2 * esz) * n
             post_s, comb_s = tl_ms / max(tl_n, 1) * 1e-3, hv_ms / max(hv_n, 1) * 1e-3
             achieved = post_bytes / post_s / 1e9 if post_s > 0 else 0.0
         out = {
             # BASELINE.json's metric string for the north-star configuration; other sizes say what they are
-            "metric": ("L-BFGS iterations/sec at n=%d, m=%d (%s), Gram-space recursion (opt-in, not the bit-parity path); "
-                       "achieved HBM GB/s vs peak" % (n, m, args.objective)) if gram else
+            "metric": ("L-BFGS iterations/sec at n=%d, m=%d (%s), Gram-space recursion%s (opt-in, not the bit-parity path); "
+                       "achieved HBM GB/s vs peak" % (n, m, args.objective, " with f32 history" if f32h else "")) if gram else
                       ("L-BFGS iterations/sec at n=10^8, m=10; achieved HBM GB/s vs peak"
                        if (n == 100000000 and m == 10 and args.objective == "rosenbrock") else
                        "L-BFGS iterations/sec at n=%d, m=%d (%s); achieved HBM GB/s vs peak" % (n, m, args.objective)),
@@ -292,12 +296,12 @@ def main():
                          "frac_of_stream_copy": achieved / copy_gbs.value if copy_gbs.value else None},
         }
         if gram:
-            out["config"]["recursion"] = "gram-space"
-            out["roofline"] = {"bound": "hbm", "kernel": "k_gs_post (s, y + Gram rows of the new pair and gradient, one pass)",
+            out["config"]["recursion"] = "gram-space, f32 history" if f32h else "gram-space"
+            out["roofline"] = {"bound": "hbm", "kernel": ("k_gs_post_mx" if f32h else "k_gs_post") + " (s, y + Gram rows of the new pair and gradient, one pass)",
                                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                "traffic": None, "algorithmic_bytes_per_launch": post_bytes, "avg_launch_ms": post_s * 1e3,
                                "launches_timed": tl_n,
-                               "combine": {"kernel": "k_gs_combine", "algorithmic_bytes_per_launch": comb_bytes,
+                               "combine": {"kernel": "k_gs_combine_mx" if f32h else "k_gs_combine", "algorithmic_bytes_per_launch": comb_bytes,
                                            "avg_launch_ms": comb_s * 1e3,
                                            "achieved": comb_bytes / comb_s / 1e9 if comb_s > 0 else 0.0},
                                "stream_copy_GBs": copy_gbs.value, "stream_triad_GBs": triad_gbs.value}

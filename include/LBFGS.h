@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <type_traits>
 #include <vector>
 
 #include "LBFGSpp/BKLDLT.h"
@@ -60,6 +61,8 @@ class LBFGSSolver
             ev.on_eval = [this](int k, Scalar v) { m_trace(k, v, m_dev); };
         lbfgsx_ctx* c = m_dev.ctx();
         detail::check(lbfgsx_bfgs_reset(c));
+        if (m_recursion == RECURSION_VECTOR)  // a previous minimize() of this solver may have run with an f32 history
+            detail::check(lbfgsx_gs_set_history_dtype(c, detail::dtype_of<Scalar>::value));
         ev.prepare();
 
         const int fpast = m_param.past;
@@ -76,9 +79,10 @@ class LBFGSSolver
             return 1;
 
         // Gram-space form of the recursion (opt-in, LBFGSpp/GramSpace.h): host Gram matrix + two device passes
-        const bool gram = (m_recursion == RECURSION_GRAM_SPACE);
+        const bool gram = (m_recursion != RECURSION_VECTOR);
+        const bool gram_f32h = (m_recursion == RECURSION_GRAM_SPACE_F32H) && std::is_same<Scalar, double>::value;
         GramSpaceHistory gsh;
-        std::vector<double> gs_coef, gs_sdots, gs_gdots;
+        std::vector<double> gs_coef, gs_sdots, gs_gdots, gs_ydots;
         double gs_coef_g = 0, gs_scal[7] = {0, 0, 0, 0, 0, 0, 0};
         if (gram)
         {
@@ -86,6 +90,8 @@ class LBFGSSolver
             gsh.set_gradient_norm2(double(gnorm2));
             gs_sdots.assign(size_t(2 * m_param.m), 0.0);
             gs_gdots.assign(size_t(2 * m_param.m), 0.0);
+            gs_ydots.assign(size_t(2 * m_param.m), 0.0);
+            detail::check(lbfgsx_gs_set_history_dtype(c, gram_f32h ? LBFGSX_F32 : detail::dtype_of<Scalar>::value));
         }
 
         // drt = -grad (empty history => H = I); |drt| == |grad| exactly, so step = 1/|grad|
@@ -121,7 +127,7 @@ class LBFGSSolver
             if (gram)
             {
                 // the same statements plus the Gram rows of (s, y) and of the new gradient, in one pass
-                detail::check(lbfgsx_gs_post_linesearch(c, gs_scal, gs_sdots.data(), gs_gdots.data()));
+                detail::check(lbfgsx_gs_post_linesearch(c, gs_scal, gs_sdots.data(), gs_gdots.data(), gs_ydots.data()));
                 g2 = gs_scal[0];
                 x2 = gs_scal[1];
                 syd = gs_scal[2];
@@ -148,7 +154,7 @@ class LBFGSSolver
 
             if (gram)
             {
-                gsh.update(gs_scal, gs_sdots.data(), gs_gdots.data(), accept);
+                gsh.update(gs_scal, gs_sdots.data(), gs_gdots.data(), accept, gram_f32h ? gs_ydots.data() : nullptr);
                 gsh.direction(-1.0, gs_coef, gs_coef_g);
                 detail::check(lbfgsx_gs_direction(c, gs_coef.data(), gs_coef_g, &dgd));
             }
@@ -167,14 +173,20 @@ public:
     {
         m_param.check_param();
         if (const char* e = std::getenv("LBFGSX_RECURSION"))
+        {
             if (!std::strcmp(e, "gram") || !std::strcmp(e, "1"))
                 m_recursion = RECURSION_GRAM_SPACE;
+            else if (!std::strcmp(e, "gram-f32h") || !std::strcmp(e, "2"))
+                m_recursion = RECURSION_GRAM_SPACE_F32H;
+        }
     }
 
     // Extension (no reference counterpart): form of the two-loop recursion.  RECURSION_VECTOR (default) executes
     // BFGSMat::apply_Hv statement by statement -- the bit-parity path.  RECURSION_GRAM_SPACE runs it on coefficients
     // over [S, Y, g] (LBFGSpp/GramSpace.h): about half the HBM traffic per iteration, iterates equal to the vector
-    // form only up to rounding (m <= 24).  Environment LBFGSX_RECURSION=gram selects it at construction.
+    // form only up to rounding (m <= 24).  RECURSION_GRAM_SPACE_F32H additionally stores S and Y as float on the device
+    // (f64 problems): half the history traffic again, the pairs perturbed at the 6e-8 level.  Environment
+    // LBFGSX_RECURSION=gram | gram-f32h selects either at construction.
     void set_recursion(int form) { m_recursion = form; }
     int recursion() const { return m_recursion; }
 

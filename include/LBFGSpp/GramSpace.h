@@ -22,7 +22,9 @@ namespace LBFGSpp {
 enum RECURSION_FORM
 {
     RECURSION_VECTOR = 0,     // the reference's two-loop recursion on n-vectors (bit-parity path, default)
-    RECURSION_GRAM_SPACE = 1  // the same recursion on coefficients over [S, Y, g]
+    RECURSION_GRAM_SPACE = 1,  // the same recursion on coefficients over [S, Y, g]
+    RECURSION_GRAM_SPACE_F32H = 2  // ... with S and Y stored as float on the device (f64 problems): half the
+                                   // history traffic and memory, a slightly perturbed quasi-Newton model
 };
 
 class GramSpaceHistory
@@ -62,7 +64,9 @@ public:
     // sdots[m+j] = Y_j.s, gdots[j] = S_j.g_new, gdots[m+j] = Y_j.g_new for the slots j < ncorr() stored BEFORE this
     // pair (lbfgsx_gs_post_linesearch).  accept = the curvature test s.y > eps * y.y of LBFGS.h:161: the pair enters
     // slot ptr % m exactly as in BFGSMat::add_correction (BFGSMat.h:81-97).
-    void update(const double* scal, const double* sdots, const double* gdots, bool accept)
+    // ydots (optional): S_j.y, Y_j.y computed directly by the device (mixed-precision history: the stored y is the
+    // rounded one); when null they are derived as differences of the gradient dots.
+    void update(const double* scal, const double* sdots, const double* gdots, bool accept, const double* ydots = nullptr)
     {
         const int m = m_m, ig = 2 * m, cn = m_ncorr;
         const double gg = scal[0], sy = scal[2], yy = scal[3], ss = scal[4], gs = scal[5], gy = scal[6];
@@ -74,7 +78,8 @@ public:
                 if (j == loc)
                     continue;  // the column being replaced
                 // y_new = g_new - g_old: its dots are differences of the direct gradient dots
-                const double yS = gdots[j] - G(ig, j), yY = gdots[m + j] - G(ig, m + j);
+                const double yS = ydots ? ydots[j] : gdots[j] - G(ig, j);
+                const double yY = ydots ? ydots[m + j] : gdots[m + j] - G(ig, m + j);
                 setsym(loc, j, sdots[j]);
                 setsym(loc, m + j, sdots[m + j]);
                 setsym(m + loc, j, yS);

@@ -128,8 +128,16 @@ int lbfgsx_commit_correction(lbfgsx_ctx* c);
 /* lbfgsx_post_linesearch (LBFGS.h:130,137,159-161; s, y into the spare column) plus, in the same pass, the Gram rows
  * of the new pair and of the new gradient.  scal = {g.g, x.x, s.y, y.y, s.s, g.s, g.y}; for the logical slots
  * j < lbfgsx_bfgs_ncorr(): sdots[j] = S_j.s, sdots[m+j] = Y_j.s, gdots[j] = S_j.g, gdots[m+j] = Y_j.g (arrays of 2m).
- * Sums accumulate in f64 (fixed reduction order). */
-int lbfgsx_gs_post_linesearch(lbfgsx_ctx* c, double scal[7], double* sdots, double* gdots);
+ * Sums accumulate in f64 (fixed reduction order).  ydots (2m doubles, may be NULL) receives S_j.y, Y_j.y when the
+ * history is kept in f32 (below) -- there the dots are taken from the rounded, stored y; with a native history the caller
+ * derives them as differences of the gradient dots and ydots is left untouched. */
+int lbfgsx_gs_post_linesearch(lbfgsx_ctx* c, double scal[7], double* sdots, double* gdots, double* ydots);
+/* Mixed-precision history: dtype = LBFGSX_F32 on an f64 context makes the Gram-space entry points keep
+ * S and Y as float (half the history traffic and memory; x, g, d and all sums stay f64).  Only with an empty history
+ * (after lbfgsx_bfgs_reset); dtype = the context's own type switches back.  While it is on, the vector-form entry points
+ * that touch the history (lbfgsx_apply_Hv with pairs stored, lbfgsx_post_linesearch, the history getters) return
+ * LBFGSX_E_LOGIC. */
+int lbfgsx_gs_set_history_dtype(lbfgsx_ctx* c, int dtype);
 /* D = coef_g * G + sum_{j < ncorr} coef[j] * S_j + coef[m+j] * Y_j (logical slots); *dg = G . D  (LBFGS.h:123) */
 int lbfgsx_gs_direction(lbfgsx_ctx* c, const double* coef, double coef_g, double* dg);
 

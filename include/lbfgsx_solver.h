@@ -71,7 +71,8 @@ lbfgsx_ctx* lbfgsx_solver_ctx(lbfgsx_solver* s);
 /* progress hook: fn(k, user) runs on the host after iteration k has produced the next search direction */
 int lbfgsx_solver_set_iteration_hook(lbfgsx_solver* s, void (*fn)(int, void*), void* user);
 /* LBFGSSolver::set_recursion (extension): 0 = vector two-loop (bit-parity path, default), 1 = Gram-space form
- * (include/LBFGSpp/GramSpace.h).  LBFGSX_E_INVALID for L-BFGS-B solvers. */
+ * (include/LBFGSpp/GramSpace.h), 2 = Gram-space form with an f32 history (f64 solvers only).  LBFGSX_E_INVALID for
+ * L-BFGS-B solvers. */
 int lbfgsx_solver_set_recursion(lbfgsx_solver* s, int form);
 /* test entry: Cauchy::get_cauchy_point + SubspaceMin::subspace_minimize of the drop-in headers on a history of
  * npairs host-provided corrections; counts = {|newact|, |free|, crossings, BOXCQP sweeps} */

@@ -8,7 +8,7 @@ F64, F32 = 0, 1
 OBJ_DIAG_QUAD, OBJ_EXT_ROSENBROCK = 0, 1
 LS_NOCEDAL_WRIGHT, LS_MORE_THUENTE, LS_BACKTRACKING, LS_BRACKETING = 0, 1, 2, 3
 ALGO_LBFGS, ALGO_LBFGSB = 0, 1
-RECURSION_VECTOR, RECURSION_GRAM_SPACE = 0, 1
+RECURSION_VECTOR, RECURSION_GRAM_SPACE, RECURSION_GRAM_SPACE_F32H = 0, 1, 2
 FLAG_BOUNDED = 1
 (VEC_X, VEC_G, VEC_XP, VEC_GP, VEC_D, VEC_XT, VEC_GT, VEC_A, VEC_B, VEC_LB, VEC_UB, VEC_XCP) = range(12)
 E_INVALID, E_LOGIC, E_RUNTIME, E_HIP, E_NOGPU = -1, -2, -3, -4, -5
@@ -104,7 +104,8 @@ def load():
     sig(core, "lbfgsx_ls_end", i32, vp, i32)
     sig(core, "lbfgsx_post_linesearch", i32, vp, pd, pd, pd, pd)
     sig(core, "lbfgsx_commit_correction", i32, vp)
-    sig(core, "lbfgsx_gs_post_linesearch", i32, vp, pd, pd, pd)
+    sig(core, "lbfgsx_gs_post_linesearch", i32, vp, pd, pd, pd, pd)
+    sig(core, "lbfgsx_gs_set_history_dtype", i32, vp, i32)
     sig(core, "lbfgsx_gs_direction", i32, vp, pd, dbl, pd)
     sig(core, "lbfgsx_timing_enable", i32, vp, i32)
     sig(core, "lbfgsx_timing_read", i32, vp, pd, C.POINTER(i64), pd, C.POINTER(i64))

@@ -116,6 +116,8 @@ struct lbfgsx_ctx
     void* xcp = nullptr;
     struct lbfgsb_state* bstate = nullptr;
     lbfgsx::GsState* gs = nullptr;
+    bool gs_f32h = false;  // the live history is the f32 copy kept by the Gram-space mode (gram_space.hip): the T-typed
+                           // S / Y columns are not maintained, so the vector-form entry points refuse to run
 
     // instrumentation
     bool timing = false;

@@ -243,11 +243,182 @@ __global__ void __launch_bounds__(kBlock) k_gs_combine(T* __restrict__ d, const 
     gs_grid_sum<1>(acc, partials, ticket, out);
 }
 
+// ---------------------------------------------------------------- f64 problem, f32 history
+// The same two passes with S and Y stored as float (lbfgsx_gs_set_history_dtype): the history is 2c of the 2c+6 / 2c+2
+// streams of these kernels, so the traffic per iteration drops from (4c+12) n 8 bytes to (16c + 72) n bytes at f64
+// (c = 10: 416 -> 232 bytes per coordinate) and the history needs half the HBM.  x, g, d and every sum stay f64.  The
+// Gram matrix describes the vectors AS STORED: s and y are rounded to float first and all their dots -- including
+// y.b_j, which the f64 form derives from gradient dots -- are taken from the rounded values, so the coefficient
+// recursion is exact for the stored basis; what changes is the quasi-Newton model itself (pairs perturbed by 6e-8
+// relative), i.e. this is a different, slightly noisier L-BFGS, further outside the parity contract than the f64 form.
+// One thread-iteration covers 4 coordinates: two 16-byte vectors of every f64 stream, one of every f32 column.
+template <int NC>
+__global__ void __launch_bounds__(kBlock) k_gs_post_mx(const double* __restrict__ x, const double* __restrict__ xp,
+                                                       const double* __restrict__ g, const double* __restrict__ gp,
+                                                       float* __restrict__ s, float* __restrict__ y, GsCols<float> cols,
+                                                       int ncols, int64_t n, double* __restrict__ partials,
+                                                       unsigned* __restrict__ ticket, double* __restrict__ out,
+                                                       double* __restrict__ out4, double* __restrict__ ys_slot,
+                                                       double* __restrict__ theta_slot, int rev)
+{
+    constexpr int NRED = GS_NSCAL + 3 * NC;  // s-dots, g-dots, y-dots
+    double acc[NRED];
+#pragma unroll
+    for (int r = 0; r < NRED; r++)
+        acc[r] = 0.0;
+    const int64_t nq = n / 4;
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t q0 = int64_t(blockIdx.x) * kBlock + threadIdx.x; q0 < nq; q0 += stride)
+    {
+        const int64_t qi = rev ? nq - 1 - q0 : q0;
+        Pack<double> px[2], pxp[2], pg[2], pgp[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+        {
+            px[h] = ldv<double, true>(x, 2 * qi + h);
+            pxp[h] = ldv<double, true>(xp, 2 * qi + h);
+            pg[h] = ldv<double, true>(g, 2 * qi + h);
+            pgp[h] = ldv<double, true>(gp, 2 * qi + h);
+        }
+        Pack<float> pc[NC];
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+            if (k < ncols)
+                pc[k] = ldv<float, true>(cols.p[k], qi);
+        Pack<float> ps, py;
+        double ds[4], dy[4], dgv[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+        {
+            const double xe = px[e >> 1].e[e & 1], ge = pg[e >> 1].e[e & 1];
+            ps.e[e] = float(xe - pxp[e >> 1].e[e & 1]);  // LBFGS.h:159, then rounded for storage
+            py.e[e] = float(ge - pgp[e >> 1].e[e & 1]);  // LBFGS.h:160
+            ds[e] = double(ps.e[e]);
+            dy[e] = double(py.e[e]);
+            dgv[e] = ge;
+            acc[GS_GG] = __builtin_fma(ge, ge, acc[GS_GG]);
+            acc[GS_XX] = __builtin_fma(xe, xe, acc[GS_XX]);
+            acc[GS_SY] = __builtin_fma(ds[e], dy[e], acc[GS_SY]);
+            acc[GS_YY] = __builtin_fma(dy[e], dy[e], acc[GS_YY]);
+            acc[GS_SS] = __builtin_fma(ds[e], ds[e], acc[GS_SS]);
+            acc[GS_GS] = __builtin_fma(ge, ds[e], acc[GS_GS]);
+            acc[GS_GY] = __builtin_fma(ge, dy[e], acc[GS_GY]);
+        }
+        stv(s, qi, ps);
+        stv(y, qi, py);
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+            if (k < ncols)
+            {
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                {
+                    const double cv = double(pc[k].e[e]);
+                    acc[GS_NSCAL + k] = __builtin_fma(cv, ds[e], acc[GS_NSCAL + k]);
+                    acc[GS_NSCAL + NC + k] = __builtin_fma(cv, dgv[e], acc[GS_NSCAL + NC + k]);
+                    acc[GS_NSCAL + 2 * NC + k] = __builtin_fma(cv, dy[e], acc[GS_NSCAL + 2 * NC + k]);
+                }
+            }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int64_t i = nq * 4; i < n; i++)  // scalar tail
+        {
+            const float sf = float(x[i] - xp[i]), yf = float(g[i] - gp[i]);
+            s[i] = sf;
+            y[i] = yf;
+            const double dsi = double(sf), dyi = double(yf), dgi = g[i], dxi = x[i];
+            acc[GS_GG] += dgi * dgi;
+            acc[GS_XX] += dxi * dxi;
+            acc[GS_SY] += dsi * dyi;
+            acc[GS_YY] += dyi * dyi;
+            acc[GS_SS] += dsi * dsi;
+            acc[GS_GS] += dgi * dsi;
+            acc[GS_GY] += dgi * dyi;
+#pragma unroll
+            for (int k = 0; k < NC; k++)
+                if (k < ncols)
+                {
+                    const double cv = double(cols.p[k][i]);
+                    acc[GS_NSCAL + k] += cv * dsi;
+                    acc[GS_NSCAL + NC + k] += cv * dgi;
+                    acc[GS_NSCAL + 2 * NC + k] += cv * dyi;
+                }
+        }
+    if (gs_grid_sum<NRED>(acc, partials, ticket, out) && threadIdx.x == 0)
+    {
+        const double sy = ld_agent(out + GS_SY), yy = ld_agent(out + GS_YY);
+        out4[0] = ld_agent(out + GS_GG);
+        out4[1] = ld_agent(out + GS_XX);
+        out4[2] = sy;
+        out4[3] = yy;
+        *ys_slot = sy;
+        *theta_slot = yy / sy;
+    }
+}
+
+template <int NC>
+__global__ void __launch_bounds__(kBlock) k_gs_combine_mx(double* __restrict__ d, const double* __restrict__ g, double cg,
+                                                          GsCols<float> cols, GsCoef<double> coef, int ncols, int64_t n,
+                                                          double* __restrict__ partials, unsigned* __restrict__ ticket,
+                                                          double* __restrict__ out, int rev)
+{
+    double acc[1] = {0.0};
+    const int64_t nq = n / 4;
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t q0 = int64_t(blockIdx.x) * kBlock + threadIdx.x; q0 < nq; q0 += stride)
+    {
+        const int64_t qi = rev ? nq - 1 - q0 : q0;
+        Pack<double> pg[2];
+        pg[0] = ldv<double, true>(g, 2 * qi);
+        pg[1] = ldv<double, true>(g, 2 * qi + 1);
+        Pack<float> pc[NC];
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+            if (k < ncols)
+                pc[k] = ldv<float, true>(cols.p[k], qi);
+        double dv[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            dv[e] = cg * pg[e >> 1].e[e & 1];
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+            if (k < ncols)
+            {
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    dv[e] = __builtin_fma(coef.c[k], double(pc[k].e[e]), dv[e]);
+            }
+        Pack<double> pd[2];
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+        {
+            pd[e >> 1].e[e & 1] = dv[e];
+            acc[0] = __builtin_fma(pg[e >> 1].e[e & 1], dv[e], acc[0]);
+        }
+        stv(d, 2 * qi, pd[0]);
+        stv(d, 2 * qi + 1, pd[1]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int64_t i = nq * 4; i < n; i++)
+        {
+            double di = cg * g[i];
+#pragma unroll
+            for (int k = 0; k < NC; k++)
+                if (k < ncols)
+                    di = __builtin_fma(coef.c[k], double(cols.p[k][i]), di);
+            d[i] = di;
+            acc[0] += g[i] * di;
+        }
+    gs_grid_sum<1>(acc, partials, ticket, out);
+}
+
 struct GsState  // per-context scratch of this mode, allocated on first use
 {
-    double* out_dev = nullptr;   // [GS_NSCAL + 2 * kGsMaxCols]
+    double* out_dev = nullptr;   // [GS_NSCAL + 3 * kGsMaxCols]
     double* out_host = nullptr;  // pinned
     unsigned* ticket = nullptr;
+    float* S32 = nullptr;        // f32 copy of the history of an f64 context (lbfgsx_gs_set_history_dtype), (m+1) columns
+    float* Y32 = nullptr;
     int grid_post = 512, grid_combine = 1024;  // measured flat (+-2 %) between 256 and 2048 blocks on the north-star size
 };
 
@@ -256,7 +427,7 @@ static int gs_ensure(lbfgsx_ctx* c)
     if (c->gs)
         return LBFGSX_OK;
     GsState* g = new GsState();
-    const size_t nout = GS_NSCAL + 2 * kGsMaxCols;
+    const size_t nout = GS_NSCAL + 3 * kGsMaxCols;
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&g->out_dev), sizeof(double) * nout));
     LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&g->out_host), sizeof(double) * nout, hipHostMallocDefault));
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&g->ticket), sizeof(unsigned)));
@@ -276,6 +447,8 @@ void gs_free(lbfgsx_ctx* c)
     (void) hipFree(c->gs->out_dev);
     (void) hipHostFree(c->gs->out_host);
     (void) hipFree(c->gs->ticket);
+    (void) hipFree(c->gs->S32);
+    (void) hipFree(c->gs->Y32);
     delete c->gs;
     c->gs = nullptr;
 }
@@ -419,13 +592,182 @@ static int gs_direction_t(lbfgsx_ctx* c, const double* coef, double coef_g, doub
     return LBFGSX_OK;
 }
 
+// ---- f32 history of an f64 context
+static void gs_fill_cols32(const lbfgsx_ctx* c, GsCols<float>& cols)
+{
+    const int cn = c->ncorr;
+    const GsState* g = c->gs;
+    for (int k = 0; k < kGsMaxCols; k++)
+        cols.p[k] = nullptr;
+    for (int j = 0; j < cn; j++)
+    {
+        cols.p[j] = g->S32 + size_t(c->phys[size_t(j)]) * size_t(c->ld);
+        cols.p[cn + j] = g->Y32 + size_t(c->phys[size_t(j)]) * size_t(c->ld);
+    }
+}
+
+static int gs_post_mx(lbfgsx_ctx* c, double* scal, double* sdots, double* gdots, double* ydots)
+{
+    GsState* g = c->gs;
+    const int cn = c->ncorr, nc = 2 * cn, m = c->m;
+    GsCols<float> cols;
+    gs_fill_cols32(c, cols);
+    const int64_t nq = c->n / 4;
+    const int grid = int(std::max<int64_t>(1, std::min<int64_t>((nq + kBlock - 1) / kBlock, g->grid_post)));
+    double* sc = static_cast<double*>(c->sc);
+    const int rev = (c->zigzag && (c->tl_step++ & 1u)) ? 1 : 0;
+    int NCsel = 0;
+    EventPair ev;
+    if (c->timing)
+    {
+        LBFGSX_HIP(hipEventCreate(&ev.a));
+        LBFGSX_HIP(hipEventCreate(&ev.b));
+        LBFGSX_HIP(hipEventRecord(ev.a, c->stream));
+    }
+#define GS_POSTMX(NC)                                                                                                       \
+    do                                                                                                                      \
+    {                                                                                                                       \
+        NCsel = NC;                                                                                                         \
+        hipLaunchKernelGGL((k_gs_post_mx<NC>), dim3(grid), dim3(kBlock), 0, c->stream,                                      \
+                           static_cast<const double*>(c->xb[c->cur]), static_cast<const double*>(c->xb[c->xp]),             \
+                           static_cast<const double*>(c->gb[c->cur]), static_cast<const double*>(c->gb[c->xp]),             \
+                           g->S32 + size_t(c->spare) * size_t(c->ld), g->Y32 + size_t(c->spare) * size_t(c->ld), cols, nc,  \
+                           c->n, c->ws.partials, g->ticket, g->out_dev, sc + c->sl.out(0), sc + c->sl.ys(c->spare),         \
+                           sc + c->sl.theta(c->spare), rev);                                                                \
+    } while (0)
+    if (nc == 0) GS_POSTMX(1);
+    else if (nc <= 8) GS_POSTMX(8);
+    else if (nc <= 16) GS_POSTMX(16);
+    else if (nc <= 24) GS_POSTMX(24);
+    else if (nc <= 32) GS_POSTMX(32);
+    else if (nc <= 40) GS_POSTMX(40);
+    else GS_POSTMX(48);
+#undef GS_POSTMX
+    LBFGSX_HIP(hipGetLastError());
+    if (c->timing)
+    {
+        LBFGSX_HIP(hipEventRecord(ev.b, c->stream));
+        c->ev_twoloop.push_back(ev);
+    }
+    const int nout = GS_NSCAL + 3 * NCsel;
+    LBFGSX_HIP(hipMemcpyAsync(g->out_host, g->out_dev, sizeof(double) * size_t(nout), hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    const double* h = g->out_host;
+    for (int k = 0; k < GS_NSCAL; k++)
+        scal[k] = h[k];
+    for (int j = 0; j < cn; j++)
+    {
+        sdots[j] = h[GS_NSCAL + j];
+        sdots[m + j] = h[GS_NSCAL + cn + j];
+        gdots[j] = h[GS_NSCAL + NCsel + j];
+        gdots[m + j] = h[GS_NSCAL + NCsel + cn + j];
+        if (ydots)
+        {
+            ydots[j] = h[GS_NSCAL + 2 * NCsel + j];
+            ydots[m + j] = h[GS_NSCAL + 2 * NCsel + cn + j];
+        }
+    }
+    c->pend_sy = h[GS_SY];
+    c->pend_yy = h[GS_YY];
+    c->pending = true;
+    return LBFGSX_OK;
+}
+
+static int gs_direction_mx(lbfgsx_ctx* c, const double* coef, double coef_g, double* dg)
+{
+    GsState* g = c->gs;
+    const int cn = c->ncorr, nc = 2 * cn, m = c->m;
+    GsCols<float> cols;
+    gs_fill_cols32(c, cols);
+    GsCoef<double> cf;
+    for (int k = 0; k < kGsMaxCols; k++)
+        cf.c[k] = 0.0;
+    for (int j = 0; j < cn; j++)
+    {
+        cf.c[j] = coef[j];
+        cf.c[cn + j] = coef[m + j];
+    }
+    const int64_t nq = c->n / 4;
+    const int grid = int(std::max<int64_t>(1, std::min<int64_t>((nq + kBlock - 1) / kBlock, g->grid_combine)));
+    const int rev = (c->zigzag && (c->tl_step++ & 1u)) ? 1 : 0;
+    EventPair hv;
+    if (c->timing)
+    {
+        LBFGSX_HIP(hipEventCreate(&hv.a));
+        LBFGSX_HIP(hipEventCreate(&hv.b));
+        LBFGSX_HIP(hipEventRecord(hv.a, c->stream));
+    }
+#define GS_COMBMX(NC)                                                                                                     \
+    hipLaunchKernelGGL((k_gs_combine_mx<NC>), dim3(grid), dim3(kBlock), 0, c->stream, static_cast<double*>(c->d),         \
+                       static_cast<const double*>(c->gb[c->cur]), coef_g, cols, cf, nc, c->n, c->ws.partials, g->ticket,  \
+                       g->out_dev, rev)
+    if (nc == 0) GS_COMBMX(1);
+    else if (nc <= 8) GS_COMBMX(8);
+    else if (nc <= 16) GS_COMBMX(16);
+    else if (nc <= 24) GS_COMBMX(24);
+    else if (nc <= 32) GS_COMBMX(32);
+    else if (nc <= 40) GS_COMBMX(40);
+    else GS_COMBMX(48);
+#undef GS_COMBMX
+    LBFGSX_HIP(hipGetLastError());
+    if (c->timing)
+    {
+        LBFGSX_HIP(hipEventRecord(hv.b, c->stream));
+        c->ev_hv.push_back(hv);
+    }
+    LBFGSX_HIP(hipMemcpyAsync(g->out_host, g->out_dev, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    if (dg)
+        *dg = g->out_host[0];
+    return LBFGSX_OK;
+}
+
 }  // namespace lbfgsx
 
 using namespace lbfgsx;
 
 extern "C" {
 
-int lbfgsx_gs_post_linesearch(lbfgsx_ctx* c, double scal[7], double* sdots, double* gdots)
+int lbfgsx_gs_set_history_dtype(lbfgsx_ctx* c, int dtype)
+{
+    if (!c || (dtype != LBFGSX_F64 && dtype != LBFGSX_F32))
+    {
+        set_error("lbfgsx_gs_set_history_dtype: invalid argument");
+        return LBFGSX_E_INVALID;
+    }
+    if (c->ncorr != 0 || c->pending)
+    {
+        set_error("lbfgsx_gs_set_history_dtype: the history must be empty (call lbfgsx_bfgs_reset first)");
+        return LBFGSX_E_LOGIC;
+    }
+    if (dtype == LBFGSX_F64 && c->dtype == LBFGSX_F32)
+    {
+        set_error("lbfgsx_gs_set_history_dtype: an f32 context cannot keep an f64 history");
+        return LBFGSX_E_INVALID;
+    }
+    const bool want32 = (dtype == LBFGSX_F32 && c->dtype == LBFGSX_F64);
+    if (want32)
+    {
+        if (2 * c->m > kGsMaxCols)
+        {
+            set_error("lbfgsx_gs_set_history_dtype: the Gram-space recursion supports m <= 24");
+            return LBFGSX_E_INVALID;
+        }
+        int rc = gs_ensure(c);
+        if (rc)
+            return rc;
+        if (!c->gs->S32)
+        {
+            const size_t bytes = sizeof(float) * size_t(c->ld) * size_t(c->m + 1);
+            LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&c->gs->S32), bytes));
+            LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&c->gs->Y32), bytes));
+        }
+    }
+    c->gs_f32h = want32;
+    return LBFGSX_OK;
+}
+
+int lbfgsx_gs_post_linesearch(lbfgsx_ctx* c, double scal[7], double* sdots, double* gdots, double* ydots)
 {
     if (!c || !scal || !sdots || !gdots)
     {
@@ -440,6 +782,8 @@ int lbfgsx_gs_post_linesearch(lbfgsx_ctx* c, double scal[7], double* sdots, doub
     int rc = gs_ensure(c);
     if (rc)
         return rc;
+    if (c->gs_f32h)
+        return gs_post_mx(c, scal, sdots, gdots, ydots);
     if (c->dtype == LBFGSX_F64)
         return gs_post_t<double>(c, scal, sdots, gdots);
     return gs_post_t<float>(c, scal, sdots, gdots);
@@ -460,6 +804,11 @@ int lbfgsx_gs_direction(lbfgsx_ctx* c, const double* coef, double coef_g, double
     int rc = gs_ensure(c);
     if (rc)
         return rc;
+    if (c->gs_f32h)
+    {
+        static const double zeros[2 * kGsMaxCols] = {0};
+        return gs_direction_mx(c, coef ? coef : zeros, coef_g, dg);
+    }
     if (c->dtype == LBFGSX_F64)
         return gs_direction_t<double>(c, coef, coef_g, dg);
     return gs_direction_t<float>(c, coef, coef_g, dg);

@@ -459,6 +459,11 @@ double lbfgsx_bfgs_theta(const lbfgsx_ctx* c) { return c->theta; }
 
 int lbfgsx_bfgs_download_history(lbfgsx_ctx* c, void* S_out, void* Y_out, int* ncorr, int* ptr, double* theta)
 {
+    if (c->gs_f32h)
+    {
+        set_error("lbfgsx_bfgs_download_history: this context keeps its history in f32 for the Gram-space recursion (lbfgsx_gs_set_history_dtype)");
+        return LBFGSX_E_LOGIC;
+    }
     for (int j = 0; j < c->ncorr; j++)
     {
         const size_t bytes = size_t(c->n) * c->esz;
@@ -498,6 +503,11 @@ int lbfgsx_commit_correction(lbfgsx_ctx* c)
 
 int lbfgsx_bfgs_stage_correction_host(lbfgsx_ctx* c, const void* s, const void* y, double* sy, double* yy)
 {
+    if (c->gs_f32h)
+    {
+        set_error("lbfgsx_bfgs_stage_correction_host: this context keeps its history in f32 for the Gram-space recursion (lbfgsx_gs_set_history_dtype)");
+        return LBFGSX_E_LOGIC;
+    }
     void* sp = c->col(c->S, c->spare);
     void* yp = c->col(c->Y, c->spare);
     LBFGSX_HIP(hipMemcpyAsync(sp, s, size_t(c->n) * c->esz, hipMemcpyHostToDevice, c->stream));
@@ -717,6 +727,11 @@ int lbfgsx_apply_Hv(lbfgsx_ctx* c, int v_which, double a, double* dg)
         set_error("lbfgsx_apply_Hv: invalid source vector");
         return LBFGSX_E_INVALID;
     }
+    if (c->gs_f32h && c->ncorr > 0)
+    {
+        set_error("lbfgsx_apply_Hv: this context keeps its history in f32 for the Gram-space recursion (lbfgsx_gs_set_history_dtype)");
+        return LBFGSX_E_LOGIC;
+    }
     DISPATCH_T(c, { return apply_Hv_t<T>(c, P<T>(v), T(a), dg); });
     return LBFGSX_OK;
 }
@@ -859,6 +874,11 @@ int lbfgsx_ls_end(lbfgsx_ctx* c, int use_lo)
 
 int lbfgsx_post_linesearch(lbfgsx_ctx* c, double* gnorm2, double* xnorm2, double* sy, double* yy)
 {
+    if (c->gs_f32h)
+    {
+        set_error("lbfgsx_post_linesearch: this context keeps its history in f32 for the Gram-space recursion (lbfgsx_gs_set_history_dtype)");
+        return LBFGSX_E_LOGIC;
+    }
     const int grid = c->grid_for(c->n);
     double r[4];
     DISPATCH_T(c, {

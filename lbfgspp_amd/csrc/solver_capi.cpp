@@ -103,7 +103,8 @@ struct LbfgsImpl : lbfgsx_solver
     }
     int set_recursion(int form) override
     {
-        if (form != RECURSION_VECTOR && form != RECURSION_GRAM_SPACE)
+        if (form != RECURSION_VECTOR && form != RECURSION_GRAM_SPACE &&
+            !(form == RECURSION_GRAM_SPACE_F32H && std::is_same<Scalar, double>::value))
             return LBFGSX_E_INVALID;
         solver->set_recursion(form);
         return LBFGSX_OK;

@@ -20,6 +20,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/batched -o b -- pytho
 python bench.py > $O/bench_northstar.json 2> /dev/null
 python bench.py --recursion gram --no-cpu > $O/bench_northstar_gram.json 2> /dev/null
 python bench.py --recursion gram --m 20 --steps 10 --warmup 22 --no-cpu > $O/bench_cfg3_m20_gram.json 2> /dev/null
+python bench.py --recursion gram-f32h --no-cpu > $O/bench_northstar_gram_f32h.json 2> /dev/null
 python bench.py --m 20 --steps 10 --warmup 22 --no-cpu > $O/bench_cfg3_m20.json 2> /dev/null
 python bench.py --objective quadratic --n 10000000 --no-cpu > $O/bench_cfg2_quad1e7.json 2> /dev/null
 python bench.py --workload cfg5-batched --steps 50 > $O/bench_cfg5_batched.json 2> /dev/null

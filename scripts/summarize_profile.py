@@ -14,7 +14,7 @@ rnd = sys.argv[1] if len(sys.argv) > 1 else "r1"
 src = os.path.join("gpurun_out", "prof_" + rnd)
 os.makedirs("profiles", exist_ok=True)
 shutil.copy(os.path.join(src, "trace", "bench_kernel_stats.csv"), os.path.join("profiles", rnd + "_kernel_stats.csv"))
-for name in ("northstar", "northstar_gram", "cfg3_m20", "cfg3_m20_gram", "cfg2_quad1e7", "cfg5_batched", "cfg4_lbfgsb",
+for name in ("northstar", "northstar_gram", "northstar_gram_f32h", "cfg3_m20", "cfg3_m20_gram", "cfg2_quad1e7", "cfg5_batched", "cfg4_lbfgsb",
              "cfg4_lbfgsb_mfma"):
     f = os.path.join(src, "bench_%s.json" % name)
     if os.path.exists(f):

@@ -59,7 +59,7 @@ def test_kernels_match_numpy(A, dtype, n, m, npairs):
         np.testing.assert_array_equal(x, xp + dt(step) * d)
 
         scal, sd, gd = np.zeros(7), np.zeros(2 * m), np.zeros(2 * m)
-        L.check(core.lbfgsx_gs_post_linesearch(h, _pd(scal), _pd(sd), _pd(gd)))
+        L.check(core.lbfgsx_gs_post_linesearch(h, _pd(scal), _pd(sd), _pd(gd), None))
         s, y = x - xp, gt - gp  # in T, as LBFGS.h:159-160
         f8 = lambda v: v.astype(np.float64)
         want = [f8(gt) @ f8(gt), f8(x) @ f8(x), f8(s) @ f8(y), f8(y) @ f8(y), f8(s) @ f8(s), f8(gt) @ f8(s), f8(gt) @ f8(y)]
@@ -187,3 +187,106 @@ def test_unsupported_configurations_fail_loudly(A):
     sb = A.LBFGSBSolver(A.LBFGSBParam(m=5))
     with pytest.raises(ValueError):
         sb.set_recursion(L.RECURSION_GRAM_SPACE)
+
+
+# ---------------------------------------------------------------- f32 history of an f64 problem
+@pytest.mark.parametrize("n,m,K", [(4099, 6, 9), (65536, 10, 12), (7, 3, 5), (1002, 24, 26)])
+def test_mixed_precision_history_kernels_match_numpy(A, n, m, K):
+    """Drive K line-search steps through lbfgsx_gs_post_linesearch with the history kept in f32: the stored columns are
+    the float-rounded s, y; every returned dot (s, g and y rows) and the combined direction must match numpy on them."""
+    from lbfgspp_amd import _lib as L
+    core, _ = A.load()
+    rng = np.random.default_rng(17 + n)
+    h = C.c_void_p()
+    L.check(core.lbfgsx_create(C.byref(h), O.F64, n, m, 0, 0))
+    try:
+        L.check(core.lbfgsx_gs_set_history_dtype(h, O.F32))
+        slots = {}  # slot -> (s_r, y_r) as float64 views of the stored floats
+        x = rng.standard_normal(n)
+        g = rng.standard_normal(n)
+        ptr = m
+        for k in range(K):
+            d = rng.standard_normal(n)
+            gt = g + 1.5 * 0.3 * d + 0.01 * rng.standard_normal(n)
+            L.check(core.lbfgsx_upload(h, L.VEC_X, _vp(x)))
+            L.check(core.lbfgsx_upload(h, L.VEC_G, _vp(g)))
+            L.check(core.lbfgsx_upload(h, L.VEC_D, _vp(d)))
+            L.check(core.lbfgsx_ls_begin(h))
+            L.check(core.lbfgsx_trial_point(h, 0.3))
+            L.check(core.lbfgsx_upload(h, L.VEC_GT, _vp(gt)))
+            L.check(core.lbfgsx_ls_end(h, 0))
+            xn = x + 0.3 * d
+            scal, sd, gd, yd = np.zeros(7), np.zeros(2 * m), np.zeros(2 * m), np.zeros(2 * m)
+            L.check(core.lbfgsx_gs_post_linesearch(h, _pd(scal), _pd(sd), _pd(gd), _pd(yd)))
+            s_r = (xn - x).astype(np.float32).astype(np.float64)
+            y_r = (gt - g).astype(np.float32).astype(np.float64)
+            want = [gt @ gt, xn @ xn, s_r @ y_r, y_r @ y_r, s_r @ s_r, gt @ s_r, gt @ y_r]
+            for got, w in zip(scal, want):
+                assert abs(got - w) <= 1e-11 * max(abs(w), 1.0) * np.sqrt(n)
+            for j, (sj, yj) in slots.items():
+                for got, u, v in ((sd[j], sj, s_r), (sd[m + j], yj, s_r), (gd[j], sj, gt), (gd[m + j], yj, gt),
+                                  (yd[j], sj, y_r), (yd[m + j], yj, y_r)):
+                    assert abs(got - u @ v) <= 1e-12 * (np.abs(u) @ np.abs(v))
+            L.check(core.lbfgsx_commit_correction(h))
+            loc = ptr % m
+            slots[loc] = (s_r, y_r)
+            ptr = loc + 1
+            x, g = xn, gt
+        assert core.lbfgsx_bfgs_ncorr(h) == min(K, m)
+        coef = rng.standard_normal(2 * m)
+        dg = C.c_double()
+        L.check(core.lbfgsx_gs_direction(h, _pd(coef), -0.7, C.byref(dg)))
+        dd = np.empty(n)
+        L.check(core.lbfgsx_download(h, L.VEC_D, _vp(dd)))
+        ref, mag = -0.7 * g, 0.7 * np.abs(g)
+        for j, (sj, yj) in slots.items():
+            ref = ref + coef[j] * sj + coef[m + j] * yj
+            mag = mag + abs(coef[j]) * np.abs(sj) + abs(coef[m + j]) * np.abs(yj)
+        assert np.all(np.abs(dd - ref) <= 4 * (2 * m + 1) * np.finfo(np.float64).eps * mag)
+        assert abs(dg.value - g @ dd) <= 1e-12 * (np.abs(g) @ np.abs(dd))
+        # the T-typed history is not maintained in this mode: the vector-form entry points refuse
+        with pytest.raises(ArithmeticError):
+            L.check(core.lbfgsx_apply_Hv(h, L.VEC_G, -1.0, C.byref(dg)))
+        with pytest.raises(ArithmeticError):
+            L.check(core.lbfgsx_post_linesearch(h, C.byref(dg), C.byref(dg), C.byref(dg), C.byref(dg)))
+        # and the mode cannot be changed with pairs stored
+        with pytest.raises(ArithmeticError):
+            L.check(core.lbfgsx_gs_set_history_dtype(h, O.F64))
+    finally:
+        core.lbfgsx_destroy(h)
+
+
+def test_mixed_precision_history_runs_converge_like_the_vector_form(A):
+    from lbfgspp_amd import _lib as L
+    n, m = 20000, 8
+    rng = np.random.default_rng(11)
+    a = 1.0 + 9.0 * np.arange(n) / (n - 1)
+    b = a * (4.0 * rng.random(n) - 2.0)
+    sols = {}
+    for form in (L.RECURSION_VECTOR, L.RECURSION_GRAM_SPACE_F32H):
+        sv = A.LBFGSSolver(A.LBFGSParam(m=m, epsilon=1e-7, epsilon_rel=0.0, max_iterations=300), linesearch=A.LS_NOCEDAL_WRIGHT)
+        sv.set_recursion(form)
+        x = np.zeros(n)
+        niter, fx = sv.minimize(A.DiagQuadratic(a, b), x)
+        sols[form] = (niter, fx, x)
+    v, w = sols[L.RECURSION_VECTOR], sols[L.RECURSION_GRAM_SPACE_F32H]
+    assert np.abs(w[2] - b / a).max() <= 1e-6 and np.abs(v[2] - w[2]).max() <= 1e-6
+    assert abs(w[0] - v[0]) <= max(6, v[0] // 3)
+
+    sv = A.LBFGSSolver(A.LBFGSParam(m=6, epsilon=1e-6, epsilon_rel=0.0, max_iterations=500), linesearch=A.LS_MORE_THUENTE)
+    sv.set_recursion(L.RECURSION_GRAM_SPACE_F32H)
+    x = O.rosen_x0(10000)
+    niter, fx = sv.minimize(A.ExtendedRosenbrock(), x)
+    assert fx < 1e-8 and np.abs(x - 1.0).max() < 1e-4 and niter < 400
+    # the same solver object goes back to the bit-parity form afterwards
+    sv.set_recursion(L.RECURSION_VECTOR)
+    x1 = O.rosen_x0(10000)
+    n1, f1 = sv.minimize(A.ExtendedRosenbrock(), x1)
+    fresh = A.LBFGSSolver(A.LBFGSParam(m=6, epsilon=1e-6, epsilon_rel=0.0, max_iterations=500), linesearch=A.LS_MORE_THUENTE)
+    x2 = O.rosen_x0(10000)
+    n2, f2 = fresh.minimize(A.ExtendedRosenbrock(), x2)
+    assert (n1, f1) == (n2, f2) and np.array_equal(x1, x2)
+    # f32 problems have nothing to halve
+    sf = A.LBFGSSolver(A.LBFGSParam(m=5), dtype=np.float32)
+    with pytest.raises(ValueError):
+        sf.set_recursion(L.RECURSION_GRAM_SPACE_F32H)
