@@ -39,15 +39,22 @@ class Cauchy
         int m_nc;
         std::vector<double> m_brk, m_g, m_z, m_w;
         std::int64_t m_next_chunk = 512;
+        std::int64_t m_soft_cap = -1;  // the host form hands over to the device here: do not fetch (much) further
 
     public:
         double fetch_seconds = 0.0;
         Stream(lbfgsx_ctx* c, std::int64_t nord, int ncorr) : m_c(c), m_nord(nord), m_nc(ncorr) {}
+        // The sequential form only ever reads up to `cap` entries (plus the look-ahead of a tie group): without this
+        // the geometric growth fetched 262144 rows (48 MB at m = 10) to serve a search that leaves at row 65536.
+        void set_soft_cap(std::int64_t cap) { m_soft_cap = cap; }
         void need(std::int64_t k)
         {
             while (k >= m_have && m_have < m_nord)
             {
-                const std::int64_t cnt = std::min<std::int64_t>(m_next_chunk, m_nord - m_have);
+                std::int64_t cnt = std::min<std::int64_t>(m_next_chunk, m_nord - m_have);
+                if (m_soft_cap >= 0 && m_have + cnt > m_soft_cap + 1024)
+                    cnt = std::max<std::int64_t>(std::min<std::int64_t>(cnt, m_soft_cap + 1024 - m_have), 1024);
+                cnt = std::min<std::int64_t>(cnt, m_nord - m_have);
                 const auto t0 = std::chrono::steady_clock::now();
                 m_brk.resize(size_t(m_have + cnt));
                 m_g.resize(size_t(m_have + cnt));
@@ -163,6 +170,8 @@ public:
 
         const std::int64_t dev_min = device_switch();
         bool dev_ok = sizeof(Scalar) == sizeof(double) && 2 * ncorr <= 32 && dev_min >= 0;
+        if (dev_ok)
+            ord.set_soft_cap(dev_min);
 
         while (deltatmin >= deltat)
         {
@@ -204,6 +213,7 @@ public:
                     if (rc == LBFGSX_E_INVALID && out.dev_crossings == 0)
                     {
                         dev_ok = false;  // not applicable: stay with the host form
+                        ord.set_soft_cap(-1);
                         break;
                     }
                     detail::check(rc);

@@ -15,7 +15,10 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # multiply/add expressions; FMAs are used only where written explicitly (error-free transformations).
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
              "-Wno-unused-result"]
-CXX_FLAGS = ["-std=c++17", "-O2", "-fPIC", "-shared", "-Wall"]
+# Host templates (line searches, BKLDLT, the sequential GCP form): x86-64-v3 so that std::fma -- the error-free product of
+# the double-double sums -- is the hardware instruction instead of a libm call; -ffp-contract=off keeps every other
+# expression un-fused, exactly as the oracle is built (oracle/Makefile).
+CXX_FLAGS = ["-std=c++17", "-O3", "-march=x86-64-v3", "-ffp-contract=off", "-fPIC", "-shared", "-Wall"]
 
 
 def _stale(target, sources):

@@ -18,12 +18,25 @@ def main():
     ap.add_argument("--m", type=int, default=10)
     ap.add_argument("--iters", type=int, default=40)
     ap.add_argument("--cpu-n", type=float, default=0)
+    ap.add_argument("--no-warmup", action="store_true",
+                    help="skip the untimed small solve that loads the code objects (first-launch cost of ~60 kernels)")
     args = ap.parse_args()
     import torch  # noqa: F401
     import lbfgspp_amd as A
     from lbfgspp_amd import _lib as L
     core, _ = A.load()
     n = int(args.n)
+    if not args.no_warmup:
+        # untimed warm-up on a small instance of the same problem: HIP loads a kernel's code object at its first launch
+        w = A.LBFGSBSolver(A.LBFGSBParam(m=args.m, epsilon=0, epsilon_rel=0, past=0, max_iterations=12))
+        wn = 1 << 18
+        wctx = w.prepare(wn)
+        L.check(core.lbfgsx_gen_diag_quad(wctx, 10.0, 1))
+        L.check(core.lbfgsx_fill(wctx, L.VEC_X, 0.0))
+        L.check(core.lbfgsx_fill(wctx, L.VEC_LB, -1.0))
+        L.check(core.lbfgsx_fill(wctx, L.VEC_UB, 1.0))
+        w.minimize_resident(A.DiagQuadratic(), wn)
+        w.close()
     s = A.LBFGSBSolver(A.LBFGSBParam(m=args.m, epsilon=0, epsilon_rel=0, past=0, max_iterations=args.iters))
     ctx = s.prepare(n)
     L.check(core.lbfgsx_gen_diag_quad(ctx, 10.0, 1))
@@ -37,7 +50,7 @@ def main():
     niter, fx = s.minimize_resident(A.DiagQuadratic(), n)
     t1 = time.perf_counter()
     per = np.diff(np.array([t0] + stamps))
-    out = dict(n=n, m=args.m, niter=niter, nfev=s.last.nfev, fx=fx, total_s=t1 - t0, it_per_s=niter / (t1 - t0),
+    out = dict(n=n, m=args.m, warmup=not args.no_warmup, niter=niter, nfev=s.last.nfev, fx=fx, total_s=t1 - t0, it_per_s=niter / (t1 - t0),
                steady_it_per_s=float(1.0 / np.median(per[len(per) // 2:])) if len(per) > 4 else None,
                per_iter_ms=[round(1e3 * v, 2) for v in per], stats=s.stats())
     if args.cpu_n:
