@@ -165,6 +165,8 @@ static int third_point(int p, int q)
 
 using namespace lbfgsx;
 
+static int create_fill(lbfgsx_ctx* c, int dtype, int64_t n, int m, int device, int flags);
+
 extern "C" {
 
 const char* lbfgsx_last_error(void) { return g_err.c_str(); }
@@ -198,6 +200,25 @@ int lbfgsx_create(lbfgsx_ctx** out, int dtype, int64_t n, int m, int device, int
     }
     LBFGSX_HIP(hipSetDevice(device));
     lbfgsx_ctx* c = new lbfgsx_ctx();
+    *out = nullptr;
+    const int rc = create_fill(c, dtype, n, m, device, flags);
+    if (rc != LBFGSX_OK)
+    {
+        // a failed allocation (e.g. n too large for the HBM that is free) must not leak what was already allocated;
+        // lbfgsx_destroy clobbers the thread's error text through the HIP calls it makes, so keep the original
+        const std::string msg = lbfgsx_last_error();
+        lbfgsx_destroy(c);
+        (void) hipGetLastError();  // the failed call's code must not surface at the next launch check of this thread
+        set_error(msg);
+        return rc;
+    }
+    *out = c;
+    return LBFGSX_OK;
+}
+
+}  // extern "C"
+static int create_fill(lbfgsx_ctx* c, int dtype, int64_t n, int m, int device, int flags)
+{
     c->dtype = dtype;
     c->esz = (dtype == LBFGSX_F64) ? 8 : 4;
     c->n = n;
@@ -271,7 +292,6 @@ int lbfgsx_create(lbfgsx_ctx** out, int dtype, int64_t n, int m, int device, int
     LBFGSX_HIP(hipMemset(c->ws.ticket, 0, sizeof(unsigned) * 4));
     c->phys.assign(size_t(m), 0);
     c->ys_host.assign(size_t(m), 0.0);
-    *out = c;
     int rc = lbfgsx_bfgs_reset(c);
     if (rc != LBFGSX_OK)
         return rc;
@@ -289,6 +309,7 @@ int lbfgsx_create(lbfgsx_ctx** out, int dtype, int64_t n, int m, int device, int
     c->counted = true;
     return LBFGSX_OK;
 }
+extern "C" {
 
 void lbfgsx_destroy(lbfgsx_ctx* c)
 {

@@ -170,3 +170,21 @@ def test_lbfgsb_unconstrained_limit_matches_free_solution(A):
     x = np.zeros(n)
     niter, fx = s.minimize(A.DiagQuadratic(a, b), x, -1e6 * np.ones(n), 1e6 * np.ones(n))
     assert niter < 300 and np.abs(x - b / a).max() < 1e-6
+
+
+def test_context_creation_failure_is_reported_and_leaves_the_device_usable(A):
+    """a dimension no HBM can hold: lbfgsx_create must answer LBFGSX_E_HIP (no crash, nothing leaked: a normal
+    context of the north-star's per-vector size can still be created right after)"""
+    import ctypes as C
+    from lbfgspp_amd import _lib as L
+    core, _ = A.load()
+    h = C.c_void_p()
+    rc = core.lbfgsx_create(C.byref(h), O.F64, 1 << 40, 10, 0, L.FLAG_BOUNDED)
+    assert rc == L.E_HIP and not h.value
+    assert b"hipMalloc" in core.lbfgsx_last_error()
+    for _ in range(3):  # repeated failures must not accumulate allocations
+        assert core.lbfgsx_create(C.byref(h), O.F64, 1 << 40, 4, 0, 0) == L.E_HIP
+    L.check(core.lbfgsx_create(C.byref(h), O.F64, 100_000_000, 2, 0, 0))
+    core.lbfgsx_destroy(h)
+    for bad in ((O.F64, 0, 5), (O.F64, 10, 0), (7, 10, 5)):
+        assert core.lbfgsx_create(C.byref(h), bad[0], bad[1], bad[2], 0, 0) == L.E_INVALID
