@@ -17,7 +17,7 @@ HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", 
              "-Wno-unused-result"]
 # Host templates (line searches, BKLDLT, the sequential GCP form): x86-64-v3 so that std::fma -- the error-free product of
 # the double-double sums -- is the hardware instruction instead of a libm call; -ffp-contract=off keeps every other
-# expression un-fused, exactly as the oracle is built (oracle/Makefile).
+# expression un-fused (the parity contract of DESIGN.md section 2: no contraction anywhere).
 CXX_FLAGS = ["-std=c++17", "-O3", "-march=x86-64-v3", "-ffp-contract=off", "-fPIC", "-shared", "-Wall"]
 
 
