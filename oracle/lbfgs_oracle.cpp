@@ -25,10 +25,52 @@ namespace {
 
 using oracle::Acc;
 
+// ORACLE_OMP (liboracle_native_omp.so only: the all-cores TIMING baseline of bench.py): the n-length
+// loops and copies run under OpenMP.  The sums then depend on the thread count, so this build is never a parity checker;
+// without the macro every statement below compiles exactly as before.
+#ifdef ORACLE_OMP
+#include <omp.h>
+#define ORACLE_PAR_FOR _Pragma("omp parallel for schedule(static)")
+#else
+#define ORACLE_PAR_FOR
+#endif
+template <class V>
+inline void pcopy(V& dst, const V& src)
+{
+#ifdef ORACLE_OMP
+    dst.resize(src.size());
+    const long n = long(src.size());
+    auto* d = dst.data();
+    const auto* q = src.data();
+    ORACLE_PAR_FOR
+    for (long i = 0; i < n; i++)
+        d[i] = q[i];
+#else
+    dst = src;
+#endif
+}
+template <class T>
+inline void pcopy_n(T* dst, const T* src, long n)
+{
+#ifdef ORACLE_OMP
+    ORACLE_PAR_FOR
+    for (long i = 0; i < n; i++)
+        dst[i] = src[i];
+#else
+    std::memcpy(dst, src, sizeof(T) * size_t(n));
+#endif
+}
+
 template <class T>
 T dot(const T* a, const T* b, long n)
 {
-#if ORACLE_ACC == 0
+#if defined(ORACLE_OMP)
+    T r = 0;
+#pragma omp parallel for reduction(+ : r) schedule(static)
+    for (long i = 0; i < n; i++)
+        r += a[i] * b[i];
+    return r * T(oracle::replication());
+#elif ORACLE_ACC == 0
     T acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long i = 0;
     for (; i + 8 <= n; i += 8)
@@ -75,8 +117,8 @@ struct History
     void add_correction(const T* sv, const T* yv)
     {
         const int loc = ptr % m;
-        std::memcpy(s(loc), sv, sizeof(T) * size_t(n));
-        std::memcpy(y(loc), yv, sizeof(T) * size_t(n));
+        pcopy_n(s(loc), sv, n);
+        pcopy_n(y(loc), yv, n);
         const T sy = dot(s(loc), y(loc), n);
         ys[size_t(loc)] = sy;
         theta = dot(y(loc), y(loc), n) / sy;
@@ -88,6 +130,7 @@ struct History
     // BFGSMat::apply_Hv, LBFGSpp/BFGSMat.h:276-302 (two-loop recursion)
     void apply_Hv(const T* v, T a, T* res)
     {
+        ORACLE_PAR_FOR
         for (long i = 0; i < n; i++)
             res[i] = a * v[i];
         int j = ptr % m;
@@ -97,9 +140,11 @@ struct History
             alpha[size_t(j)] = dot(s(j), res, n) / ys[size_t(j)];
             const T aj = alpha[size_t(j)];
             const T* yj = y(j);
+            ORACLE_PAR_FOR
             for (long k = 0; k < n; k++)
                 res[k] = res[k] - aj * yj[k];
         }
+        ORACLE_PAR_FOR
         for (long k = 0; k < n; k++)
             res[k] = res[k] / theta;
         for (int i = 0; i < ncorr; i++)
@@ -107,6 +152,7 @@ struct History
             const T beta = dot(y(j), res, n) / ys[size_t(j)];
             const T cf = alpha[size_t(j)] - beta;
             const T* sj = s(j);
+            ORACLE_PAR_FOR
             for (long k = 0; k < n; k++)
                 res[k] = res[k] + cf * sj[k];
             j = (j + 1) % m;
@@ -147,14 +193,24 @@ struct Search
     {
         xp = xp_;
         drt = drt_;
+#ifdef ORACLE_OMP
+        x_lo.resize(size_t(n));
+        grad_lo.resize(size_t(n));
+        pcopy_n(x_lo.data(), xp_, n);
+        pcopy_n(grad_lo.data(), g_, n);
+#else
         x_lo.assign(xp_, xp_ + n);       // Vector x_lo = xp, grad_lo = grad
         grad_lo.assign(g_, g_ + n);
+#endif
     }
     void trial(T step, T& fx, T& dg)
     {
         T* xv = x->data();
+        const T* xpv = xp;
+        const T* dv = drt;
+        ORACLE_PAR_FOR
         for (long i = 0; i < n; i++)
-            xv[i] = xp[i] + step * drt[i];
+            xv[i] = xpv[i] + step * dv[i];
         fx = f(*x, *grad);
         dg = dot(grad->data(), drt, n);
     }
@@ -596,6 +652,7 @@ int lbfgs_minimize(int ls, int obj, long n, const T* a, const T* b, T* xio, cons
     out->nfev = S.nfev;
     if (gnorm <= epsilon || gnorm <= epsilon_rel * std::sqrt(dot(x.data(), x.data(), n)))
         return finish(1);
+    ORACLE_PAR_FOR
     for (long i = 0; i < n; i++)
         drt[size_t(i)] = -grad[size_t(i)];
     T step = T(1) / std::sqrt(dot(drt.data(), drt.data(), n));
@@ -605,8 +662,8 @@ int lbfgs_minimize(int ls, int obj, long n, const T* a, const T* b, T* xio, cons
     {
         for (;;)
         {
-            xp = x;
-            gradp = grad;
+            pcopy(xp, x);
+            pcopy(gradp, grad);
             T dg = dot(grad.data(), drt.data(), n);
             const T step_max = T(p->max_step);
             S.begin(xp.data(), grad.data(), drt.data());
@@ -629,6 +686,7 @@ int lbfgs_minimize(int ls, int obj, long n, const T* a, const T* b, T* xio, cons
             }
             if (p->max_iterations != 0 && k >= p->max_iterations)
                 return finish(k);
+            ORACLE_PAR_FOR
             for (long i = 0; i < n; i++)
             {
                 vecs[size_t(i)] = x[size_t(i)] - xp[size_t(i)];
@@ -718,6 +776,19 @@ int oracle_port_set_replication(double r)
         return -1;
     oracle::replication() = r;
     return 0;
+}
+
+/* all-cores timing build only: number of OpenMP threads (0 elsewhere) */
+int oracle_port_set_threads(int nthreads)
+{
+#ifdef ORACLE_OMP
+    if (nthreads > 0)
+        omp_set_num_threads(nthreads);
+    return omp_get_max_threads();
+#else
+    (void) nthreads;
+    return 0;
+#endif
 }
 
 double oracle_port_eval(int dtype, int obj, long n, const void* a, const void* b, const void* x, void* grad)

@@ -10,6 +10,30 @@ namespace oracle {
 template <class T>
 T eval_objective(int obj, long n, const T* a, const T* b, const T* x, T* g)
 {
+#ifdef ORACLE_OMP  // all-cores timing build (see lbfgs_oracle.cpp): plain reductions under OpenMP
+    T sum = T(0);
+    if (obj == OBJ_DIAG_QUAD)
+    {
+#pragma omp parallel for reduction(+ : sum) schedule(static)
+        for (long i = 0; i < n; i++)
+        {
+            const T r = a[i] * x[i] - b[i];
+            g[i] = a[i] * r;
+            sum += r * r;
+        }
+        return T(0.5) * sum;
+    }
+#pragma omp parallel for reduction(+ : sum) schedule(static)
+    for (long i = 0; i < n - 1; i += 2)
+    {
+        const T t1 = T(1) - x[i];
+        const T t2 = T(10) * (x[i + 1] - x[i] * x[i]);
+        g[i + 1] = T(20) * t2;
+        g[i] = T(-2) * (x[i] * g[i + 1] + t1);
+        sum += t1 * t1 + t2 * t2;
+    }
+    return sum;
+#endif
     Acc<T> acc;
     if (obj == OBJ_DIAG_QUAD)
     {

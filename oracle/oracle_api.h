@@ -79,6 +79,8 @@ ORACLE_DECL(oracle_port)
 /* restatement only: every n-length sum of the L-BFGS path is multiplied by r (a power of two), which makes the run
  * the exact image of the r-fold replicated problem -- see oracle/acc.h; 1 = off */
 int oracle_port_set_replication(double r);
+/* liboracle_native_omp.so (bench.py's all-cores timing baseline): set / query the OpenMP thread count; 0 elsewhere */
+int oracle_port_set_threads(int nthreads);
 
 #ifdef __cplusplus
 }
