@@ -95,3 +95,19 @@ def test_product_never_imports_the_oracle():
                     txt = open(os.path.join(root, f)).read()
                     for b in banned:
                         assert b not in txt, "%s references %s" % (os.path.join(root, f), b)
+
+
+def test_bench_and_smoke_fail_loudly_without_a_gpu():
+    """bench.py / smoke() measure the HIP path only: on a box without a GPU they stop with a clear message instead of
+    timing some host path (run here on the CPU container; on the GPU box the condition is simply not met)."""
+    import subprocess
+    import sys
+    core, _ = __import__("lbfgspp_amd").load()
+    if core.lbfgsx_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode != 0 and "needs a GPU" in r.stdout and '"metric"' not in r.stdout
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode != 0 and "smoke() needs a GPU" in r.stdout
