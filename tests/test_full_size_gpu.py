@@ -141,3 +141,47 @@ def test_cfg5_full_per_gpu_batch_samples_match_single_solves_and_oracle(A, oracl
             assert np.abs(x.astype(np.float64) - xo.astype(np.float64)).max() <= 1e-4
     finally:
         sv.close()
+
+
+def test_more_than_2_31_coordinates_f32(A):
+    """64-bit indexing end to end: n = 2^31 + 2^20 floats (8.6 GB per vector, ~150 GB in all with m = 3).  The separable
+    quadratic has the closed-form minimiser b / a, checked on a strided sample that includes the coordinates past
+    2^31 and the very last one -- an index that wrapped at 32 bits would leave that region at x0 = 0."""
+    import ctypes as C
+    from lbfgspp_amd import _lib as L
+    core, _ = A.load()
+    n, m = (1 << 31) + (1 << 20), 3
+    sv = A.LBFGSSolver(A.LBFGSParam(m=m, epsilon=0.0, epsilon_rel=0.0, max_iterations=25), linesearch=A.LS_MORE_THUENTE,
+                       dtype=np.float32)
+    try:
+        ctx = sv.prepare(n)
+        L.check(core.lbfgsx_gen_diag_quad(ctx, 10.0, 1))
+        L.check(core.lbfgsx_fill(ctx, L.VEC_X, 0.0))
+        niter, fx = sv.minimize_resident(A.DiagQuadratic(), n)
+        assert niter == 25
+        stride = 1_048_573  # samples spread over the whole index range, the last ones beyond 2^31
+        idx = np.arange(0, n, stride, dtype=np.int64)
+        xs = np.zeros(len(idx))
+        L.check(core.lbfgsx_gather(ctx, L.VEC_X, stride, xs.ctypes.data_as(C.POINTER(C.c_double))))
+        assert idx[-1] > (1 << 31)
+        a = (1.0 + 9.0 * (idx.astype(np.float64) / float(n - 1))).astype(np.float32).astype(np.float64)
+        with np.errstate(over="ignore"):
+            h = O.splitmix64(idx.astype(np.uint64) + np.uint64((1 * 0x9E3779B97F4A7C15) & ((1 << 64) - 1)))
+        u = (h >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+        want = 4.0 * u - 2.0  # b / a with b = a (4 u - 2)
+        # 25 iterations with m = 3 leave the slowly converging coordinates (a near 1, low indices) ~10 % off; the stiff
+        # ones at the top of the index range -- the ones this test is about -- are already at the minimiser
+        assert np.all(np.abs(xs - want) <= 0.12 * np.abs(want) + 2e-2) and np.abs(xs).max() > 1.0
+        high = idx > (1 << 31)
+        assert high.sum() >= 1 and np.abs(xs[high] - want[high]).max() <= 2e-2
+        # and the tail of the vector proper: the last coordinate
+        last = np.zeros(1)
+        tail_stride = n - 1
+        two = np.zeros(2)
+        L.check(core.lbfgsx_gather(ctx, L.VEC_X, tail_stride, two.ctypes.data_as(C.POINTER(C.c_double))))
+        with np.errstate(over="ignore"):
+            hl = O.splitmix64(np.array([n - 1], dtype=np.uint64) + np.uint64((1 * 0x9E3779B97F4A7C15) & ((1 << 64) - 1)))
+        ul = float((hl >> np.uint64(11)).astype(np.float64)[0]) / 9007199254740992.0
+        assert abs(two[1] - (4.0 * ul - 2.0)) <= 2e-2
+    finally:
+        sv.close()
