@@ -210,8 +210,10 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=12)
     ap.add_argument("--cpu-n-all", type=float, default=2e7, help="problem size of the all-cores CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--workload", default="north-star", choices=["north-star", "cfg5-batched"],
-                    help="north-star (default, the BASELINE.json metric) or the batched cfg5 shard per GPU")
+    ap.add_argument("--workload", default="north-star", choices=["north-star", "cfg5-batched", "sharded"],
+                    help="north-star (default, the BASELINE.json metric: one problem per GPU), the batched cfg5 shard per "
+                         "GPU, or sharded: ONE problem of --n rows row-sharded over the ranks (strong scaling; opt-in "
+                         "Gram-space recursion, all-reduces of <= 6m+7 doubles over RCCL)")
     ap.add_argument("--problems-per-gpu", type=int, default=1024)
     ap.add_argument("--recursion", default="vector", choices=["vector", "gram", "gram-f32h"],
                     help="vector (default): the reference's two-loop recursion statement by statement, the bit-parity "
@@ -233,7 +235,16 @@ def main():
     if core.lbfgsx_device_count() < 1:
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
 
+    sharded = args.workload == "sharded"
+    if sharded and args.recursion == "vector":
+        args.recursion = "gram"  # the only form whose reductions can cross devices
     n, m, K, W = int(args.n), args.m, args.steps, max(args.warmup, 0)
+    n_global, shard_lo = n, 0
+    if sharded:
+        # contiguous row blocks, boundaries on multiples of 4 (whole Rosenbrock pairs, whole 16-byte vectors)
+        per = (n_global // world) // 4 * 4
+        shard_lo = rank * per
+        n = (n_global - shard_lo) if rank == world - 1 else per
     ls = A.LS_MORE_THUENTE if args.objective == "rosenbrock" else A.LS_NOCEDAL_WRIGHT
     par = A.LBFGSParam(m=m, epsilon=0.0, epsilon_rel=0.0, past=0, max_iterations=W + K + 1)
     solver = A.LBFGSSolver(par, linesearch=ls, dtype="float64", device=local)
@@ -242,11 +253,28 @@ def main():
     if gram:
         solver.set_recursion(L.RECURSION_GRAM_SPACE_F32H if f32h else L.RECURSION_GRAM_SPACE)
     ctx = solver.prepare(n)
+    if sharded:
+        L.check(core.lbfgsx_set_shard(ctx, shard_lo, n_global))
+        red_buf = torch.zeros(512, dtype=torch.float64, device=comm_dev)
+        n_reduces = [0]
+
+        def allreduce(v):
+            n_reduces[0] += 1
+            if world == 1:
+                return
+            k = v.shape[0]
+            if comm_dev.type == "cuda":   # RCCL: stage the few doubles through a device tensor
+                red_buf[:k].copy_(torch.from_numpy(v))
+                dist.all_reduce(red_buf[:k])
+                v[:] = red_buf[:k].cpu().numpy()
+            else:
+                dist.all_reduce(torch.from_numpy(v))  # in place on the callback's memory
+        solver.set_reducer(allreduce)
     if args.objective == "rosenbrock":
-        L.check(core.lbfgsx_gen_rosen_x0(ctx, 7 + rank))
+        L.check(core.lbfgsx_gen_rosen_x0(ctx, 7 + (0 if sharded else rank)))
         f = A.ExtendedRosenbrock()
     else:
-        L.check(core.lbfgsx_gen_diag_quad(ctx, 10.0, 1 + rank))
+        L.check(core.lbfgsx_gen_diag_quad(ctx, 10.0, 1 + (0 if sharded else rank)))
         L.check(core.lbfgsx_fill(ctx, L.VEC_X, 0.0))
         f = A.DiagQuadratic()
     L.check(core.lbfgsx_sync(ctx))
@@ -308,19 +336,22 @@ def main():
             achieved = post_bytes / post_s / 1e9 if post_s > 0 else 0.0
         out = {
             # BASELINE.json's metric string for the north-star configuration; other sizes say what they are
-            "metric": ("L-BFGS iterations/sec at n=%d, m=%d (%s), Gram-space recursion%s (opt-in, not the bit-parity path); "
+            "metric": ("L-BFGS iterations/sec of ONE problem n=%d row-sharded over %d GPU(s), m=%d (%s), Gram-space recursion%s "
+                       "(opt-in, not the bit-parity path); achieved HBM GB/s per GPU vs peak"
+                       % (n_global, world, m, args.objective, " with f32 history" if f32h else "")) if sharded else
+                      ("L-BFGS iterations/sec at n=%d, m=%d (%s), Gram-space recursion%s (opt-in, not the bit-parity path); "
                        "achieved HBM GB/s vs peak" % (n, m, args.objective, " with f32 history" if f32h else "")) if gram else
                       ("L-BFGS iterations/sec at n=10^8, m=10; achieved HBM GB/s vs peak"
                        if (n == 100000000 and m == 10 and args.objective == "rosenbrock") else
                        "L-BFGS iterations/sec at n=%d, m=%d (%s); achieved HBM GB/s vs peak" % (n, m, args.objective)),
-            "value": world * K / elapsed,
+            "value": (1 if sharded else world) * K / elapsed,
             "unit": "iterations/s",
             "n_gpus": world,
             "steps": K,
             "warmup": W,
             "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if sharded else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -342,6 +373,12 @@ def main():
         }
         if gram:
             out["config"]["recursion"] = "gram-space, f32 history" if f32h else "gram-space"
+            if sharded:
+                out["config"]["workload"] = ("one extended-Rosenbrock problem of n=%d rows, contiguous row blocks of %d over %d "
+                                             "rank(s); %d all-reduces of <= %d doubles in the run"
+                                             % (n_global, n, world, n_reduces[0], 6 * m + 7))
+                out["config"]["n"] = n_global
+                out["config"]["rows_per_gpu"] = n
             out["roofline"] = {"bound": "hbm", "kernel": ("k_gs_post_mx" if f32h else "k_gs_post") + " (s, y + Gram rows of the new pair and gradient, one pass)",
                                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                "traffic": None, "algorithmic_bytes_per_launch": post_bytes, "avg_launch_ms": post_s * 1e3,

@@ -50,6 +50,7 @@ class LBFGSSolver
     int m_recursion = RECURSION_VECTOR;  // extension: see set_recursion()
     std::function<void(int, Scalar, DeviceState<Scalar>&)> m_trace;
     std::function<void(int)> m_iter_hook;
+    std::function<void(double*, int)> m_reducer;  // extension: see set_reducer()
 
     template <typename Foo, typename HostVec>
     int run(Foo& f, Scalar& fx)
@@ -59,6 +60,13 @@ class LBFGSSolver
         detail::Evaluator<Scalar, Foo, HostVec> ev(f, m_dev);
         if (m_trace)
             ev.on_eval = [this](int k, Scalar v) { m_trace(k, v, m_dev); };
+        if (m_reducer)
+        {
+            if (m_recursion == RECURSION_VECTOR)
+                throw std::invalid_argument("a row-sharded run (set_reducer) needs the Gram-space recursion: the vector "
+                                            "two-loop reduces its dot products on the device, inside one launch");
+            ev.reduce = m_reducer;
+        }
         lbfgsx_ctx* c = m_dev.ctx();
         detail::check(lbfgsx_bfgs_reset(c));
         if (m_recursion == RECURSION_VECTOR)  // a previous minimize() of this solver may have run with an f32 history
@@ -100,6 +108,8 @@ class LBFGSSolver
         {
             gsh.direction(-1.0, gs_coef, gs_coef_g);
             detail::check(lbfgsx_gs_direction(c, gs_coef.data(), gs_coef_g, &dgd));
+            if (m_reducer)
+                m_reducer(&dgd, 1);
         }
         else
             detail::check(lbfgsx_apply_Hv(c, LBFGSX_VEC_G, -1.0, &dgd));
@@ -128,6 +138,21 @@ class LBFGSSolver
             {
                 // the same statements plus the Gram rows of (s, y) and of the new gradient, in one pass
                 detail::check(lbfgsx_gs_post_linesearch(c, gs_scal, gs_sdots.data(), gs_gdots.data(), gs_ydots.data()));
+                if (m_reducer)
+                {
+                    // one bundle per iteration: 7 scalars + the Gram rows (6m doubles)
+                    const size_t tm = size_t(2 * m_param.m);
+                    std::vector<double> bundle(7 + 3 * tm);
+                    std::copy(gs_scal, gs_scal + 7, bundle.begin());
+                    std::copy(gs_sdots.begin(), gs_sdots.end(), bundle.begin() + 7);
+                    std::copy(gs_gdots.begin(), gs_gdots.end(), bundle.begin() + 7 + tm);
+                    std::copy(gs_ydots.begin(), gs_ydots.end(), bundle.begin() + 7 + 2 * tm);
+                    m_reducer(bundle.data(), int(bundle.size()));
+                    std::copy(bundle.begin(), bundle.begin() + 7, gs_scal);
+                    std::copy(bundle.begin() + 7, bundle.begin() + 7 + tm, gs_sdots.begin());
+                    std::copy(bundle.begin() + 7 + tm, bundle.begin() + 7 + 2 * tm, gs_gdots.begin());
+                    std::copy(bundle.begin() + 7 + 2 * tm, bundle.end(), gs_ydots.begin());
+                }
                 g2 = gs_scal[0];
                 x2 = gs_scal[1];
                 syd = gs_scal[2];
@@ -157,6 +182,8 @@ class LBFGSSolver
                 gsh.update(gs_scal, gs_sdots.data(), gs_gdots.data(), accept, gram_f32h ? gs_ydots.data() : nullptr);
                 gsh.direction(-1.0, gs_coef, gs_coef_g);
                 detail::check(lbfgsx_gs_direction(c, gs_coef.data(), gs_coef_g, &dgd));
+                if (m_reducer)
+                    m_reducer(&dgd, 1);
             }
             else
                 detail::check(lbfgsx_apply_Hv(c, LBFGSX_VEC_G, -1.0, &dgd));
@@ -188,6 +215,13 @@ public:
     // (f64 problems): half the history traffic again, the pairs perturbed at the 6e-8 level.  Environment
     // LBFGSX_RECURSION=gram | gram-f32h selects either at construction.
     void set_recursion(int form) { m_recursion = form; }
+    // Extension: ROW-SHARDED run of one problem over several GPUs.  Each rank owns a contiguous
+    // block of rows in its own solver / context (DeviceState of the local length; lbfgsx_set_shard for the built-in
+    // data) and passes a function that sums a small array of doubles over all ranks in place (an all-reduce; RCCL
+    // over xGMI through torch.distributed in bench.py).  Every n-length sum -- f, g.d, the norms, the Gram rows -- goes
+    // through it before any scalar logic runs, so the ranks take identical decisions: 3-5 all-reduces of <= 6m+7
+    // doubles per iteration.  Needs the Gram-space recursion; nullptr switches back to a single-device run.
+    void set_reducer(std::function<void(double*, int)> allreduce_sum) { m_reducer = std::move(allreduce_sum); }
     int recursion() const { return m_recursion; }
 
     // choose the GPU of this solver (default 0); takes effect at the next minimize()

@@ -161,6 +161,9 @@ class Evaluator
 
 public:
     std::function<void(int, Scalar)> on_eval;  // (evaluation index, fx) -- parity tracing hook
+    // Row-sharded runs (LBFGSSolver::set_reducer): every bundle of n-length sums a statement returns is summed over
+    // the shards (an all-reduce) before any scalar logic sees it, so all ranks take identical decisions.
+    std::function<void(double*, int)> reduce;
 
     Evaluator(Foo& f, DeviceState<Scalar>& s) : m_f(f), m_s(s) {}
     int nfev() const { return m_nfev; }
@@ -185,6 +188,14 @@ public:
         {
             r0 = double(call_user(LBFGSX_VEC_X, LBFGSX_VEC_G));
             check(lbfgsx_norms(m_s.ctx(), &r1, &r2));
+        }
+        if (reduce)
+        {
+            double r[3] = {r0, r1, r2};
+            reduce(r, 3);
+            r0 = r[0];
+            r1 = r[1];
+            r2 = r[2];
         }
         fx = Scalar(r0);
         gnorm2 = Scalar(r1);
@@ -224,6 +235,13 @@ public:
             check(lbfgsx_trial_point(m_s.ctx(), double(step)));
             r0 = double(call_user(LBFGSX_VEC_XT, LBFGSX_VEC_GT));
             check(lbfgsx_trial_dg(m_s.ctx(), &r1));
+        }
+        if (reduce)
+        {
+            double r[2] = {r0, r1};
+            reduce(r, 2);
+            r0 = r[0];
+            r1 = r[1];
         }
         fx = Scalar(r0);
         dg = Scalar(r1);

@@ -75,6 +75,9 @@ int lbfgsx_download(lbfgsx_ctx* c, int which, void* host);       /* device -> ho
 int lbfgsx_gather(lbfgsx_ctx* c, int which, int64_t stride, double* host); /* host[k] = vec[k*stride] */
 
 /* ---- synthetic problems generated on the device from a counter hash */
+/* This context holds rows [offset, offset + n) of a problem of n_global rows (row-sharded runs, include/LBFGS.h
+ * set_reducer): the generators below then produce exactly that slice of the unsharded data.  Default: 0, n. */
+int lbfgsx_set_shard(lbfgsx_ctx* c, int64_t offset, int64_t n_global);
 int lbfgsx_gen_diag_quad(lbfgsx_ctx* c, double kappa, uint64_t seed); /* fills A, B */
 int lbfgsx_gen_rosen_x0(lbfgsx_ctx* c, uint64_t seed);                /* fills X    */
 int lbfgsx_fill(lbfgsx_ctx* c, int which, double value);

@@ -74,6 +74,9 @@ int lbfgsx_solver_set_iteration_hook(lbfgsx_solver* s, void (*fn)(int, void*), v
  * (include/LBFGSpp/GramSpace.h), 2 = Gram-space form with an f32 history (f64 solvers only).  LBFGSX_E_INVALID for
  * L-BFGS-B solvers. */
 int lbfgsx_solver_set_recursion(lbfgsx_solver* s, int form);
+/* LBFGSSolver::set_reducer (extension, row-sharded runs): fn(values, count, user) must sum `values` over all ranks in
+ * place (an all-reduce); NULL switches back.  L-BFGS solvers with the Gram-space recursion only. */
+int lbfgsx_solver_set_allreduce(lbfgsx_solver* s, void (*fn)(double*, int, void*), void* user);
 /* test entry: Cauchy::get_cauchy_point + SubspaceMin::subspace_minimize of the drop-in headers on a history of
  * npairs host-provided corrections; counts = {|newact|, |free|, crossings, BOXCQP sweeps} */
 int lbfgsx_test_cauchy_subspace(int dtype, int64_t n, int m, int npairs, const void* S, const void* Y, const void* x0,

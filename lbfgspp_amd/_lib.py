@@ -36,6 +36,7 @@ class Trace(C.Structure):
 
 
 ITER_HOOK = C.CFUNCTYPE(None, C.c_int, C.c_void_p)
+ALLREDUCE = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_int, C.c_void_p)
 
 _core = None
 _solver = None
@@ -117,6 +118,8 @@ def load():
     sig(sol, "lbfgsx_solver_prepare", i32, vp, i64)
     sig(sol, "lbfgsx_solver_ctx", vp, vp)
     sig(sol, "lbfgsx_solver_set_recursion", i32, vp, i32)
+    sig(sol, "lbfgsx_solver_set_allreduce", i32, vp, ALLREDUCE, vp)
+    sig(core, "lbfgsx_set_shard", i32, vp, i64, i64)
     sig(sol, "lbfgsx_solver_set_iteration_hook", i32, vp, ITER_HOOK, vp)
     sig(sol, "lbfgsx_batch_minimize", i32, i32, i32, i32, C.POINTER(Params), i32, i64, i64, i64, C.c_uint64, i32, i32,
         C.POINTER(BatchItem))

@@ -59,6 +59,7 @@ struct lbfgsx_ctx
     int dtype = LBFGSX_F64;
     size_t esz = 8;
     int64_t n = 0, ld = 0;
+    int64_t shard_off = 0, n_global = 0;  // row shard [shard_off, shard_off + n) of a problem of n_global rows (lbfgsx_set_shard)
     int m = 0, device = 0, flags = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;

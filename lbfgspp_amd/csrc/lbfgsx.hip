@@ -55,23 +55,29 @@ __device__ __forceinline__ double u01(uint64_t i, uint64_t seed)
     return double(splitmix64(i + seed * 0x9E3779B97F4A7C15ull) >> 11) * (1.0 / 9007199254740992.0);
 }
 
+// The generators work on global row indices: a context that holds the row shard [off, off + n) of a problem of ng rows
+// (lbfgsx_set_shard) produces exactly its slice of the unsharded data.
 template <class T>
-__global__ void k_gen_quad(T* a, T* b, int64_t n, double kappa, uint64_t seed)
+__global__ void k_gen_quad(T* a, T* b, int64_t n, double kappa, uint64_t seed, int64_t off, int64_t ng)
 {
     const int64_t stride = int64_t(gridDim.x) * blockDim.x;
     for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride)
     {
-        const double ai = (n > 1) ? 1.0 + (kappa - 1.0) * (double(i) / double(n - 1)) : 1.0;
+        const int64_t gi = i + off;
+        const double ai = (ng > 1) ? 1.0 + (kappa - 1.0) * (double(gi) / double(ng - 1)) : 1.0;
         a[i] = T(ai);
-        b[i] = T(ai * (4.0 * u01(uint64_t(i), seed) - 2.0));
+        b[i] = T(ai * (4.0 * u01(uint64_t(gi), seed) - 2.0));
     }
 }
 template <class T>
-__global__ void k_gen_rosen(T* x, int64_t n, uint64_t seed)
+__global__ void k_gen_rosen(T* x, int64_t n, uint64_t seed, int64_t off)
 {
     const int64_t stride = int64_t(gridDim.x) * blockDim.x;
     for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride)
-        x[i] = T(((i & 1) ? 1.0 : -1.2) + 0.4 * u01(uint64_t(i), seed));
+    {
+        const int64_t gi = i + off;
+        x[i] = T(((gi & 1) ? 1.0 : -1.2) + 0.4 * u01(uint64_t(gi), seed));
+    }
 }
 template <class T>
 __global__ void k_fill(T* x, int64_t n, T v)
@@ -222,6 +228,7 @@ static int create_fill(lbfgsx_ctx* c, int dtype, int64_t n, int m, int device, i
     c->dtype = dtype;
     c->esz = (dtype == LBFGSX_F64) ? 8 : 4;
     c->n = n;
+    c->n_global = n;
     c->ld = (n + 63) / 64 * 64;
     c->m = m;
     c->device = device;
@@ -426,10 +433,22 @@ int lbfgsx_gather(lbfgsx_ctx* c, int which, int64_t stride, double* host)
     return LBFGSX_OK;
 }
 
+int lbfgsx_set_shard(lbfgsx_ctx* c, int64_t offset, int64_t n_global)
+{
+    if (!c || offset < 0 || n_global < offset + c->n)
+    {
+        set_error("lbfgsx_set_shard: need 0 <= offset and offset + n <= n_global");
+        return LBFGSX_E_INVALID;
+    }
+    c->shard_off = offset;
+    c->n_global = n_global;
+    return LBFGSX_OK;
+}
+
 int lbfgsx_gen_diag_quad(lbfgsx_ctx* c, double kappa, uint64_t seed)
 {
     DISPATCH_T(c, { hipLaunchKernelGGL(k_gen_quad<T>, dim3(2048), dim3(256), 0, c->stream, P<T>(c->a), P<T>(c->b),
-                                       c->n, kappa, seed); });
+                                       c->n, kappa, seed, c->shard_off, c->n_global); });
     LBFGSX_HIP(hipGetLastError());
     return LBFGSX_OK;
 }
@@ -437,7 +456,7 @@ int lbfgsx_gen_diag_quad(lbfgsx_ctx* c, double kappa, uint64_t seed)
 int lbfgsx_gen_rosen_x0(lbfgsx_ctx* c, uint64_t seed)
 {
     DISPATCH_T(c, { hipLaunchKernelGGL(k_gen_rosen<T>, dim3(2048), dim3(256), 0, c->stream, P<T>(c->xb[c->cur]),
-                                       c->n, seed); });
+                                       c->n, seed, c->shard_off); });
     LBFGSX_HIP(hipGetLastError());
     return LBFGSX_OK;
 }

@@ -21,6 +21,7 @@ struct lbfgsx_solver
     virtual void set_hook(void (*fn)(int, void*), void* user) = 0;
     virtual int hessians(double*, double*) { return LBFGSX_E_INVALID; }
     virtual int set_recursion(int) { return LBFGSX_E_INVALID; }
+    virtual int set_allreduce(void (*)(double*, int, void*), void*) { return LBFGSX_E_INVALID; }
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long stats_submin_us = 0;
     long long stats2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -107,6 +108,14 @@ struct LbfgsImpl : lbfgsx_solver
             !(form == RECURSION_GRAM_SPACE_F32H && std::is_same<Scalar, double>::value))
             return LBFGSX_E_INVALID;
         solver->set_recursion(form);
+        return LBFGSX_OK;
+    }
+    int set_allreduce(void (*fn)(double*, int, void*), void* user) override
+    {
+        if (fn)
+            solver->set_reducer([fn, user](double* v, int k) { fn(v, k, user); });
+        else
+            solver->set_reducer(nullptr);
         return LBFGSX_OK;
     }
     int hessians(double* B, double* H) override
@@ -479,6 +488,10 @@ int lbfgsx_solver_stats2(lbfgsx_solver* s, long long out[8])
 }
 
 int lbfgsx_solver_set_recursion(lbfgsx_solver* s, int form) { return s->set_recursion(form); }
+int lbfgsx_solver_set_allreduce(lbfgsx_solver* s, void (*fn)(double*, int, void*), void* user)
+{
+    return s->set_allreduce(fn, user);
+}
 
 int lbfgsx_solver_set_iteration_hook(lbfgsx_solver* s, void (*fn)(int, void*), void* user)
 {

@@ -129,6 +129,17 @@ class _SolverBase:
         recursion over [S, Y, g]: about half the HBM traffic, equal to the vector form only up to rounding)."""
         L.check(self._sol.lbfgsx_solver_set_recursion(self._h, int(form)), "set_recursion: unknown form, or not an L-BFGS solver")
 
+    def set_reducer(self, fn):
+        """Extension, row-sharded runs: fn(values) receives a float64 numpy view of a small array and must replace it by
+        its sum over all ranks (an all-reduce).  None switches back.  Gram-space recursion only."""
+        if fn is None:
+            self._red = L.ALLREDUCE(0)
+        else:
+            def cb(ptr, count, _user):
+                fn(np.ctypeslib.as_array(ptr, shape=(count,)))
+            self._red = L.ALLREDUCE(cb)
+        L.check(self._sol.lbfgsx_solver_set_allreduce(self._h, self._red, None), "set_reducer: not an L-BFGS solver")
+
     @property
     def ctx(self):
         return C.c_void_p(self._sol.lbfgsx_solver_ctx(self._h))

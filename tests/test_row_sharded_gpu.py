@@ -1,0 +1,163 @@
+"""-m gpu: one problem row-sharded over several ranks (LBFGSSolver::set_reducer).  The ranks are
+emulated by threads of this process -- one solver / context / stream each on the same GPU -- and the all-reduce by a
+barrier: what is checked is the sharding logic itself (every n-length sum passes through the reducer before any scalar
+decision; the generators produce the right slice), independent of the transport bench.py uses (RCCL)."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def A():
+    import lbfgspp_amd as A
+    core, _ = A.load()
+    assert core.lbfgsx_device_count() >= 1, "no GPU visible: these tests must run on the MI355X box"
+    return A
+
+
+class ThreadAllReduce:
+    """sum over `world` threads, identical result (same order of additions) in every thread"""
+
+    def __init__(self, world):
+        self.world, self.slots, self.calls = world, [None] * world, [0] * world
+        self.barrier = threading.Barrier(world, timeout=60)
+
+    def reducer(self, rank):
+        def red(v):
+            self.calls[rank] += 1
+            self.slots[rank] = v.copy()
+            self.barrier.wait()
+            total = self.slots[0].copy()
+            for r in range(1, self.world):
+                total += self.slots[r]
+            self.barrier.wait()
+            v[:] = total
+        return red
+
+
+def _run_sharded(A, obj, n, bounds, m, iters, ls, form, dtype=np.float64):
+    from lbfgspp_amd import _lib as L
+    core, _ = A.load()
+    world = len(bounds) - 1
+    ar = ThreadAllReduce(world)
+    out = [None] * world
+    err = []
+
+    def worker(rank):
+        try:
+            lo, hi = bounds[rank], bounds[rank + 1]
+            sv = A.LBFGSSolver(A.LBFGSParam(m=m, epsilon=0.0, epsilon_rel=0.0, max_iterations=iters), linesearch=ls, dtype=dtype)
+            sv.set_recursion(form)
+            sv.set_reducer(ar.reducer(rank))
+            ctx = sv.prepare(hi - lo)
+            L.check(core.lbfgsx_set_shard(ctx, lo, n))
+            if obj == "rosen":
+                L.check(core.lbfgsx_gen_rosen_x0(ctx, 7))
+                f = A.ExtendedRosenbrock()
+            else:
+                L.check(core.lbfgsx_gen_diag_quad(ctx, 10.0, 1))
+                L.check(core.lbfgsx_fill(ctx, L.VEC_X, 0.0))
+                f = A.DiagQuadratic()
+            tr = A.TraceBuffer(hi - lo, cap=256, with_x=False)
+            niter, fx = sv.minimize_resident(f, hi - lo, trace=tr)
+            x = np.empty(hi - lo, dtype)
+            L.check(core.lbfgsx_download(sv.ctx, L.VEC_X, x.ctypes.data_as(C.c_void_p)))
+            out[rank] = (niter, fx, tr.fx[:tr.count].copy(), x, sv.last.nfev)
+            sv.close()
+        except BaseException as e:  # noqa: B902  (a failed rank must not leave the others at the barrier)
+            err.append(e)
+            ar.barrier.abort()
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(300)
+    assert not err, err
+    return out, ar
+
+
+def _run_single(A, obj, n, m, iters, ls, form, dtype=np.float64):
+    from lbfgspp_amd import _lib as L
+    core, _ = A.load()
+    sv = A.LBFGSSolver(A.LBFGSParam(m=m, epsilon=0.0, epsilon_rel=0.0, max_iterations=iters), linesearch=ls, dtype=dtype)
+    sv.set_recursion(form)
+    ctx = sv.prepare(n)
+    if obj == "rosen":
+        L.check(core.lbfgsx_gen_rosen_x0(ctx, 7))
+        f = A.ExtendedRosenbrock()
+    else:
+        L.check(core.lbfgsx_gen_diag_quad(ctx, 10.0, 1))
+        L.check(core.lbfgsx_fill(ctx, L.VEC_X, 0.0))
+        f = A.DiagQuadratic()
+    tr = A.TraceBuffer(n, cap=256, with_x=False)
+    niter, fx = sv.minimize_resident(f, n, trace=tr)
+    x = np.empty(n, dtype)
+    L.check(core.lbfgsx_download(sv.ctx, L.VEC_X, x.ctypes.data_as(C.c_void_p)))
+    r = (niter, fx, tr.fx[:tr.count].copy(), x, sv.last.nfev)
+    sv.close()
+    return r
+
+
+@pytest.mark.parametrize("obj,n,bounds,m,iters", [("rosen", 40000, (0, 20000, 40000), 6, 14),
+                                                  ("rosen", 30002, (0, 1000, 17002, 30002), 4, 11),
+                                                  ("quad", 50001, (0, 12345, 50001), 10, 25)])
+def test_row_sharded_run_equals_the_single_device_run(A, obj, n, bounds, m, iters):
+    from lbfgspp_amd import _lib as L
+    ls = A.LS_MORE_THUENTE if obj == "rosen" else A.LS_NOCEDAL_WRIGHT
+    single = _run_single(A, obj, n, m, iters, ls, L.RECURSION_GRAM_SPACE)
+    shards, ar = _run_sharded(A, obj, n, bounds, m, iters, ls, L.RECURSION_GRAM_SPACE)
+    world = len(bounds) - 1
+    # every rank took the same decisions and saw the same (global) objective values
+    for r in range(1, world):
+        assert shards[r][0] == shards[0][0] and shards[r][4] == shards[0][4]
+        assert np.array_equal(shards[r][2], shards[0][2])
+    assert len(set(ar.calls)) == 1  # the same number of all-reduces everywhere
+    # and they are the single-device run up to the rounding of a different split of the sums
+    assert shards[0][0] == single[0] and len(shards[0][2]) == len(single[2])
+    k = min(10, len(single[2]))
+    assert np.all(np.abs(shards[0][2][:k] - single[2][:k]) <= 1e-9 * np.abs(single[2][:k]))
+    x = np.concatenate([s[3] for s in shards])
+    tol = 1e-6 if obj == "rosen" else 1e-9
+    assert np.abs(x - single[3]).max() <= tol * max(1.0, np.abs(single[3]).max())
+
+
+def test_row_sharded_data_generators_produce_the_slices(A):
+    from lbfgspp_amd import _lib as L
+    core, _ = A.load()
+    n, lo, hi = 10001, 3000, 10001
+    full, part = C.c_void_p(), C.c_void_p()
+    L.check(core.lbfgsx_create(C.byref(full), O.F64, n, 2, 0, 0))
+    L.check(core.lbfgsx_create(C.byref(part), O.F64, hi - lo, 2, 0, 0))
+    try:
+        L.check(core.lbfgsx_set_shard(part, lo, n))
+        assert core.lbfgsx_set_shard(part, lo + 1, n) == L.E_INVALID  # would run past the end
+        for h in (full, part):
+            L.check(core.lbfgsx_gen_diag_quad(h, 10.0, 3))
+            L.check(core.lbfgsx_gen_rosen_x0(h, 11))
+        for which in (L.VEC_A, L.VEC_B, L.VEC_X):
+            a, b = np.empty(n), np.empty(hi - lo)
+            L.check(core.lbfgsx_download(full, which, a.ctypes.data_as(C.c_void_p)))
+            L.check(core.lbfgsx_download(part, which, b.ctypes.data_as(C.c_void_p)))
+            assert np.array_equal(a[lo:hi], b)
+    finally:
+        core.lbfgsx_destroy(full)
+        core.lbfgsx_destroy(part)
+
+
+def test_row_sharding_needs_the_gram_space_recursion(A):
+    sv = A.LBFGSSolver(A.LBFGSParam(m=5, max_iterations=3), linesearch=A.LS_MORE_THUENTE)
+    sv.set_reducer(lambda v: None)
+    with pytest.raises(ValueError, match="Gram-space"):
+        sv.minimize(A.ExtendedRosenbrock(), O.rosen_x0(100))
+    sv.set_reducer(None)
+    sv.minimize(A.ExtendedRosenbrock(), O.rosen_x0(100))
+    sb = A.LBFGSBSolver(A.LBFGSBParam(m=5))
+    with pytest.raises(ValueError):
+        sb.set_reducer(lambda v: None)
