@@ -14,7 +14,7 @@ rnd = sys.argv[1] if len(sys.argv) > 1 else "r1"
 src = os.path.join("gpurun_out", "prof_" + rnd)
 os.makedirs("profiles", exist_ok=True)
 shutil.copy(os.path.join(src, "trace", "bench_kernel_stats.csv"), os.path.join("profiles", rnd + "_kernel_stats.csv"))
-for name in ("northstar", "northstar_gram", "northstar_gram_f32h", "cfg3_m20", "cfg3_m20_gram", "cfg2_quad1e7", "cfg5_batched", "cfg4_lbfgsb",
+for name in ("northstar", "northstar_gram", "northstar_gram_f32h", "sharded_n1", "cfg3_m20", "cfg3_m20_gram", "cfg2_quad1e7", "cfg5_batched", "cfg4_lbfgsb",
              "cfg4_lbfgsb_mfma"):
     f = os.path.join(src, "bench_%s.json" % name)
     if os.path.exists(f):
@@ -79,12 +79,14 @@ for k, v in out["kernels"].items():
     print("%-40s calls %4d avg %.4f ms  hbm %.4g B  %.0f GB/s" % (k[:40], v["calls"], v["avg_ms"], v["hbm_bytes_per_launch"], v["hbm_GBs"] or 0))
 
 
-# ---- the opt-in Gram-space recursion: same counters for its two kernels
-gsrc = os.path.join(src, "gram_trace", "bench_kernel_stats.csv")
-if os.path.exists(gsrc):
-    shutil.copy(gsrc, os.path.join("profiles", rnd + "_gram_kernel_stats.csv"))
+# ---- the opt-in Gram-space recursion (f64 history and f32 history): same counters for its two kernels
+def gram_summary(prefix, tag, flag):
+    gsrc = os.path.join(src, prefix + "_trace", "bench_kernel_stats.csv")
+    if not os.path.exists(gsrc):
+        return
+    shutil.copy(gsrc, os.path.join("profiles", "%s_%s_kernel_stats.csv" % (rnd, tag)))
     gagg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for which in ("gram_pmc_fetch", "gram_pmc_write"):
+    for which in (prefix + "_pmc_fetch", prefix + "_pmc_write"):
         fn = os.path.join(src, which, "bench_counter_collection.csv")
         if os.path.exists(fn):
             with open(fn) as f:
@@ -94,7 +96,7 @@ if os.path.exists(gsrc):
     with open(gsrc) as f:
         for r in csv.DictReader(f):
             gstats[short(r["Name"])] = (int(r["Calls"]), float(r["AverageNs"]))
-    gout = {"round": rnd, "command": out["command"].replace("bench.py", "bench.py --recursion gram"), "units": out["units"],
+    gout = {"round": rnd, "command": out["command"].replace("bench.py", "bench.py --recursion " + flag), "units": out["units"],
             "note": "launches start from an empty history (m = 10): launch k reads 2*min(k,10) columns, so the per-launch "
                     "averages below mix the warm-up launches with the full-history ones; max_* are the full-history launches",
             "kernels": {}}
@@ -105,8 +107,12 @@ if os.path.exists(gsrc):
         calls, avg_ns = gstats.get(k, (0, 0.0))
         gout["kernels"][k] = {"calls": calls, "avg_ms": avg_ns * 1e-6, "hbm_bytes_per_launch_avg": sum(hb) / len(hb),
                               "hbm_bytes_per_launch_max": max(hb)}
-    with open(os.path.join("profiles", rnd + "_gram_pmc_summary.json"), "w") as f:
+    with open(os.path.join("profiles", "%s_%s_pmc_summary.json" % (rnd, tag)), "w") as f:
         json.dump(gout, f, indent=1)
     for k, v in gout["kernels"].items():
         print("%-40s calls %4d avg %.4f ms  hbm avg %.4g B max %.4g B" % (k[:40], v["calls"], v["avg_ms"],
                                                                           v["hbm_bytes_per_launch_avg"], v["hbm_bytes_per_launch_max"]))
+
+
+gram_summary("gram", "gram", "gram")
+gram_summary("f32h", "gram_f32h", "gram-f32h")
