@@ -141,6 +141,10 @@ class Evaluator
         }
         else if constexpr (is_device)
         {
+            // The point was produced by a kernel on the context's (non-blocking) stream: drain it, so the functor may
+            // use any stream of its own.  The functor returns f as a host scalar, i.e. its own work is complete when it
+            // returns and the solver's next kernel may read the gradient it wrote.
+            m_s.sync();
             DeviceVector<Scalar> x = m_s.vec(xwhich), g = m_s.vec(gwhich);
             const Scalar fx = m_f(static_cast<const DeviceVector<Scalar>&>(x), g);
             return fx;
