@@ -127,6 +127,31 @@ public:
         }
     }
 
+    // apply_Mv for B vectors at once: V, R are [2c][B] (row k of lane b at [k * B + b]); lane by lane bit-identical to
+    // apply_Mv (BKLDLT::solve_inplace_batch)
+    template <int B>
+    void apply_Mv_batch(const Scalar* V, Scalar* R) const
+    {
+        const int c = m_ncorr;
+        if (c < 1)
+            return;
+        std::vector<Scalar>& pad = m_pad;
+        pad.assign(size_t(2 * m_m) * size_t(B), Scalar(0));
+        for (int j = 0; j < c; j++)
+            for (int b = 0; b < B; b++)
+            {
+                pad[size_t(j * B + b)] = V[j * B + b];
+                pad[size_t((m_m + j) * B + b)] = V[(c + j) * B + b];
+            }
+        m_solver.template solve_inplace_batch<B>(pad.data());
+        for (int j = 0; j < c; j++)
+            for (int b = 0; b < B; b++)
+            {
+                R[j * B + b] = pad[size_t(j * B + b)];
+                R[(c + j) * B + b] = pad[size_t((m_m + j) * B + b)];
+            }
+    }
+
     // M*v with the theta scaling of the S half that precedes a W_P * (.) product (:446,475,591,612)
     void Mv_scaled(const std::vector<Scalar>& v, std::vector<double>& coef) const
     {

@@ -149,6 +149,9 @@ public:
 
         // p = W'd (:152), f' = -d'd (:154), f'' = -theta f' - p'Mp (:156-158)
         std::vector<Scalar> vecp(size_t(2 * ncorr)), cache, wact(size_t(2 * ncorr));
+        constexpr int kMwBatch = 4;  // break points whose M w is solved together (one AVX2 vector of doubles)
+        std::vector<Scalar> blk_w(size_t(2 * ncorr) * kMwBatch), blk_mw(size_t(2 * ncorr) * kMwBatch);
+        std::int64_t blk_first = -(std::int64_t(1) << 40);
         for (int j = 0; j < ncorr; j++)
         {
             vecp[size_t(j)] = Scalar(wtd[j]);
@@ -265,18 +268,35 @@ public:
             for (std::int64_t i = b; i <= e; i++)                      // (:219-235)
             {
                 const Scalar zact = ord.z(i), gact = ord.g(i), ggact = gact * gact;
-                const double* w = ord.w(i);
-                for (int j = 0; j < ncorr; j++)
-                {
-                    wact[size_t(j)] = Scalar(w[j]);
-                    wact[size_t(ncorr + j)] = Scalar(w[ncorr + j]) * theta;   // Wb(): tail *= theta (BFGSMat.h:333)
-                }
                 // with an empty history W has no columns: the three dot products are exact zeros, so the
                 // statements below reduce to the same arithmetic without the (no-op) M solve
                 Scalar d_c = Scalar(0), d_p = Scalar(0), d_w = Scalar(0);
                 if (ncorr > 0)
                 {
-                    bfgs.apply_Mv(wact, cache);
+                    // M w depends on w alone: the rows of kMwBatch consecutive break points are solved together, lane
+                    // by lane bit-identical to apply_Mv (whether or not the search goes on to cross all of them)
+                    if (i < blk_first || i >= blk_first + kMwBatch)
+                    {
+                        blk_first = i;
+                        for (int l = 0; l < kMwBatch; l++)
+                        {
+                            const bool have = (i + l < lim);
+                            const double* wl = have ? ord.w(i + l) : nullptr;
+                            for (int j = 0; j < ncorr; j++)
+                            {
+                                blk_w[size_t(j * kMwBatch + l)] = have ? Scalar(wl[j]) : Scalar(0);
+                                blk_w[size_t((ncorr + j) * kMwBatch + l)] =
+                                    have ? Scalar(wl[ncorr + j]) * theta : Scalar(0);   // Wb(): tail *= theta (BFGSMat.h:333)
+                            }
+                        }
+                        bfgs.template apply_Mv_batch<kMwBatch>(blk_w.data(), blk_mw.data());
+                    }
+                    const int l = int(i - blk_first);
+                    for (int j = 0; j < 2 * ncorr; j++)
+                    {
+                        wact[size_t(j)] = blk_w[size_t(j * kMwBatch + l)];
+                        cache[size_t(j)] = blk_mw[size_t(j * kMwBatch + l)];
+                    }
                     d_c = detail::host_dot(cache.data(), out.vecc.data(), 2 * ncorr);
                     d_p = detail::host_dot(cache.data(), vecp.data(), 2 * ncorr);
                     d_w = detail::host_dot(cache.data(), wact.data(), 2 * ncorr);

@@ -27,6 +27,21 @@ int hl_bkldlt_solve(int n, const double* A, const double* b, double* x)
     return f.info();
 }
 
+// the same factorisation applied to 4 right-hand sides at once (structure of arrays inside): x[k*n + i] = solution k
+int hl_bkldlt_solve_batch4(int n, const double* A, const double* b, double* x)
+{
+    BKLDLT<double> f(A, n, n);
+    std::vector<double> X(size_t(n) * 4);
+    for (int k = 0; k < 4; k++)
+        for (int i = 0; i < n; i++)
+            X[size_t(i) * 4 + size_t(k)] = b[size_t(k) * size_t(n) + size_t(i)];
+    f.solve_inplace_batch<4>(X.data());
+    for (int k = 0; k < 4; k++)
+        for (int i = 0; i < n; i++)
+            x[size_t(k) * size_t(n) + size_t(i)] = X[size_t(i) * 4 + size_t(k)];
+    return f.info();
+}
+
 // solve before compute(): the reference throws std::logic_error (BKLDLT.h:446-447)
 int hl_bkldlt_uncomputed_throws(void)
 {

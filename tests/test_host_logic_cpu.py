@@ -178,6 +178,26 @@ def test_param_validation_accepts_defaults_and_checks_lbfgsb_fields(hl):
     assert rc == 1 and "max_submin" in msg
 
 
+
+@pytest.mark.parametrize("kind", ["indefinite", "zero_diag", "permMinv", "spd"])
+@pytest.mark.parametrize("n", [2, 7, 20, 40])
+def test_bkldlt_batched_solve_is_bit_identical_lane_by_lane(hl, n, kind):
+    """solve_inplace_batch<4> (used by the sequential Cauchy search for the M w of four break points at once) must give,
+    in every lane, exactly the bits of solve_inplace"""
+    rng = np.random.default_rng(31 * n + len(kind))
+    A = _sym(rng, n, kind)
+    Af = np.asfortranarray(np.tril(A) + np.triu(np.full((n, n), np.nan), 1))
+    B = rng.standard_normal((4, n))
+    B[3] = 0.0  # a padding lane, as at the end of a break-point list
+    Xb = np.zeros((4, n))
+    hl.hl_bkldlt_solve_batch4.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    hl.hl_bkldlt_solve_batch4(n, Af.ctypes.data_as(C.c_void_p), B.ctypes.data_as(C.c_void_p), Xb.ctypes.data_as(C.c_void_p))
+    for k in range(4):
+        x = np.zeros(n)
+        hl.hl_bkldlt_solve(n, Af.ctypes.data_as(C.c_void_p), np.ascontiguousarray(B[k]).ctypes.data_as(C.c_void_p),
+                           x.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(x, Xb[k])
+
 # ---- Gram-space recursion (include/LBFGSpp/GramSpace.h): the coefficient form must reproduce BFGSMat::apply_Hv
 def _two_loop(S, Y, order, v, a):
     """reference BFGSMat.h:276-302 on explicit vectors; order = pair indices newest -> oldest"""
