@@ -188,3 +188,34 @@ def test_context_creation_failure_is_reported_and_leaves_the_device_usable(A):
     core.lbfgsx_destroy(h)
     for bad in ((O.F64, 0, 5), (O.F64, 10, 0), (7, 10, 5)):
         assert core.lbfgsx_create(C.byref(h), bad[0], bad[1], bad[2], 0, 0) == L.E_INVALID
+
+
+def test_no_device_memory_is_leaked_across_solver_lifetimes(A):
+    """every mode allocates its work sets lazily (L-BFGS-B sort / Cauchy scratch, Gram-space scratch, f32 history, batch
+    buffers): 20 create / solve / destroy cycles must hand all of it back"""
+    import torch
+    from lbfgspp_amd import _lib as L
+    from lbfgspp_amd import batched as B
+    n = 1 << 20
+
+    def cycle():
+        s = A.LBFGSSolver(A.LBFGSParam(m=5, epsilon=0.0, epsilon_rel=0.0, max_iterations=6), linesearch=A.LS_MORE_THUENTE)
+        for form in (L.RECURSION_VECTOR, L.RECURSION_GRAM_SPACE, L.RECURSION_GRAM_SPACE_F32H):
+            s.set_recursion(form)
+            s.minimize(A.ExtendedRosenbrock(), O.rosen_x0(n))
+        s.close()
+        a, b = O.quad_problem(n)
+        sb = A.LBFGSBSolver(A.LBFGSBParam(m=5, max_iterations=6))
+        sb.minimize(A.DiagQuadratic(a, b), np.zeros(n), -np.ones(n), np.ones(n))
+        sb.close()
+        B.solve_local_lockstep(A.LBFGSParam(m=4, epsilon=0.0, epsilon_rel=0.0, max_iterations=3), 4096, 0, 8,
+                               dtype=np.float32)
+
+    cycle()  # first use loads code objects and sizes the allocator's pools
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(20):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, "device memory shrank by %.1f MB over 20 cycles" % ((free0 - free1) / 2**20)
