@@ -17,11 +17,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* p, uint32_t b
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, int(bytes), 0x00020000);
 }
 
-template <int AUX_H, int AUX_Q, int AUX_S = -1>
+template <int AUX_H, int AUX_Q, int AUX_S = -1, int U = 4>
 __global__ void __launch_bounds__(256) k_step(double* q, const double* u, const double* w, int64_t nv, double c, int rev,
                                               double* out)
 {
-    constexpr int U = 4;
     const int64_t tile = 256 * U;
     const int64_t ntile = (nv + tile - 1) / tile;
     double acc = 0.0;
@@ -64,8 +63,8 @@ __global__ void __launch_bounds__(256) k_step(double* q, const double* u, const 
         out[0] = acc;
 }
 
-template <int AUX_H, int AUX_Q, int AUX_S = -1>
-static int run(const char* name, double* q, double* pool, int64_t n, int ncols, double* out)
+template <int AUX_H, int AUX_Q, int AUX_S = -1, int U = 4>
+static int run(const char* name, double* q, double* pool, int64_t n, int ncols, double* out, int grid = 512)
 {
     const int64_t nv = n / 2;
     hipEvent_t a, b;
@@ -81,7 +80,7 @@ static int run(const char* name, double* q, double* pool, int64_t n, int ncols, 
             {
                 const double* u = pool + int64_t((2 * L) % ncols) * n;
                 const double* w = pool + int64_t((2 * L + 1) % ncols) * n;
-                hipLaunchKernelGGL((k_step<AUX_H, AUX_Q, AUX_S>), dim3(512), dim3(256), 0, 0, q, u, w, nv, 1e-9, zig ? (L & 1) : 0, out);
+                hipLaunchKernelGGL((k_step<AUX_H, AUX_Q, AUX_S, U>), dim3(grid), dim3(256), 0, 0, q, u, w, nv, 1e-9, zig ? (L & 1) : 0, out);
             }
             CK(hipEventRecord(b));
             CK(hipEventSynchronize(b));
@@ -119,5 +118,14 @@ int main()
     if (run<2, 0, 16>("hist nt, q st sc1", q, pool, n, ncols, out)) return 1;
     if (run<2, 1, -1>("hist nt, q ld sc0", q, pool, n, ncols, out)) return 1;
     if (run<2, 16, -1>("hist nt, q ld sc1", q, pool, n, ncols, out)) return 1;
+    // geometry of the best policy
+    if (run<2, 0, -1, 2>("nt U=2 grid 512", q, pool, n, ncols, out, 512)) return 1;
+    if (run<2, 0, -1, 2>("nt U=2 grid 1024", q, pool, n, ncols, out, 1024)) return 1;
+    if (run<2, 0, -1, 4>("nt U=4 grid 256", q, pool, n, ncols, out, 256)) return 1;
+    if (run<2, 0, -1, 4>("nt U=4 grid 768", q, pool, n, ncols, out, 768)) return 1;
+    if (run<2, 0, -1, 4>("nt U=4 grid 1024", q, pool, n, ncols, out, 1024)) return 1;
+    if (run<2, 0, -1, 8>("nt U=8 grid 256", q, pool, n, ncols, out, 256)) return 1;
+    if (run<2, 0, -1, 8>("nt U=8 grid 512", q, pool, n, ncols, out, 512)) return 1;
+    if (run<2, 0, -1, 6>("nt U=6 grid 512", q, pool, n, ncols, out, 512)) return 1;
     return 0;
 }
