@@ -538,6 +538,7 @@ struct PersistArgs
     int64_t ld;            // column stride of S / Y (elements)
 };
 
+constexpr int kSc1 = 16;  // cache-policy bit of the buffer instructions: agent scope (loads bypass L1, stores write through)
 constexpr int kPersistNR = 30;
 constexpr int kPersistNL = 15;
 
@@ -619,6 +620,15 @@ __global__ void __launch_bounds__(kHvThreads, 2)
             {
                 const int64_t tt = rev ? ntile - 1 - t0 : t0;
                 const int64_t base = res_end + tt * tile + tid;
+                // q of this tile through a buffer descriptor: agent-scope (sc1) loads and write-through (sc1) stores.
+                // The tile order alternates between steps, so the block -- and the XCD -- that reads a tile in step
+                // L+1 is not the one that wrote it in step L, and the XCD L2s are not coherent with each other.
+                // MI355X_MICROARCH.md lists "16-byte sc1 stores AND sc1 loads" as a valid cross-XCD hand-off that
+                // needs no release / acquire fence; measured against the alternatives on one box: plain accesses +
+                // __threadfence() after the meeting point (not valid by that list, though never seen to fail) 85.7
+                // it/s, plain accesses + agent release before arrival + acquire after 84.2, this form 87.1.
+                const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<T*>(q) + W * (res_end + tt * tile), 0, int(tile * 16), 0x00020000);
                 Pack<T> pq[U], pu[U], pw[U];
 #pragma unroll
                 for (int k = 0; k < U; k++)
@@ -629,7 +639,8 @@ __global__ void __launch_bounds__(kHvThreads, 2)
                         pu[k] = ldv<T, true>(u, vi);
                         pw[k] = ldv<T, true>(w, vi);
                         if (L != 0)
-                            pq[k] = ldv<T, false>(q, vi);
+                            pq[k].v = __builtin_bit_cast(typename Vec16<T>::type,
+                                                         __builtin_amdgcn_raw_buffer_load_b128(rq, int((tid + k * kHvThreads) * 16), 0, kSc1));
                     }
                 }
 #pragma unroll
@@ -647,10 +658,14 @@ __global__ void __launch_bounds__(kHvThreads, 2)
                             pq[k].e[e] = qv;
                             acc4[(k * W + e) & 3].add_prod(pw[k].e[e], qv);
                         }
-                        stv<T, false>(q, vi, pq[k]);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4_t, pq[k].v), rq,
+                                                               int((tid + k * kHvThreads) * 16), 0, kSc1);
                     }
                 }
             }
+            // producer side of the hand-off: this wave's write-through stores have reached memory before the block
+            // arrives at the meeting point (grid_reduce synchronises the block before its lane 0 takes the ticket)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (blockIdx.x == 0 && tid == 0)  // scalar tail (n not a multiple of the vector width)
                 for (int64_t i = nv * W; i < n; i++)
                 {
@@ -692,7 +707,8 @@ __global__ void __launch_bounds__(kHvThreads, 2)
                         break;
                     }
                 }
-                __threadfence();
+                // consumer side: nothing to invalidate -- the only data that crosses blocks are q (sc1 loads, above) and
+                // the scalars (agent-scope atomic loads); the history and the gradient are read-only in this kernel
             }
             __syncthreads();
         }

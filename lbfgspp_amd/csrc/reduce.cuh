@@ -209,6 +209,7 @@ __device__ __forceinline__ bool grid_reduce(A (&acc)[NRED], const RedWs& ws)
 // ---------------------------------------------------------------- 16-byte vector access
 typedef double d2_t __attribute__((ext_vector_type(2)));
 typedef float f4_t __attribute__((ext_vector_type(4)));
+typedef int i4_t __attribute__((ext_vector_type(4)));
 template <class T> struct Vec16;
 template <> struct Vec16<double>
 {
