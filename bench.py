@@ -291,7 +291,7 @@ def main():
     def hook(k):
         if k == W:
             barrier()
-            L.check(core.lbfgsx_timing_enable(ctx, 1))
+            L.check(core.lbfgsx_timing_enable(ctx, 2 if os.environ.get("LBFGSX_PERSIST") == "0" else 1))
             marks["t0"] = time.perf_counter()
             marks["nfev0"] = None
         elif k == W + K:

@@ -304,7 +304,8 @@ int lbfgsx_bat_sync(lbfgsx_batch* c);
 
 /* ---- instrumentation ----------------------------------------------------------------------------------*/
 /* average duration (ms) of the two-loop step kernels since the last reset, measured with HIP events on
- * the context's stream; count = number of timed launches */
+ * the context's stream; count = number of timed launches.  on = 2: one event pair per apply_Hv only (the step launches
+ * then run back to back, without an event between them) and the per-step figures are that time / (2c+1) */
 int lbfgsx_timing_enable(lbfgsx_ctx* c, int on);
 int lbfgsx_timing_read(lbfgsx_ctx* c, double* twoloop_ms_total, int64_t* twoloop_launches,
                        double* applyhv_ms_total, int64_t* applyhv_calls);

@@ -108,6 +108,7 @@ struct lbfgsx_ctx
     unsigned* gen_dev = nullptr;   // generation word + error word
     unsigned gen_count = 0;
     int64_t persist_steps_timed = 0;
+    int64_t coarse_steps_timed = 0;
     bool counted = false;          // registered in the live-context count
     int64_t persist_launches = 0;  // instrumentation
 
@@ -122,6 +123,7 @@ struct lbfgsx_ctx
 
     // instrumentation
     bool timing = false;
+    bool timing_per_launch = true;  // false (lbfgsx_timing_enable(ctx, 2)): events around whole apply_Hv calls only
     std::vector<lbfgsx::EventPair> ev_twoloop, ev_hv;
     void* gather_tmp = nullptr;
     int64_t gather_cap = 0;

@@ -665,7 +665,7 @@ static int apply_Hv_t(lbfgsx_ctx* c, const T* v, T a, double* dg)
     auto launch = [&](int mode, const T* u, const T* w, TwoLoopArgs args) -> int {
         EventPair ev;
         args.rev = (c->zigzag && (c->tl_step++ & 1u)) ? 1 : 0;
-        if (c->timing)
+        if (c->timing && c->timing_per_launch)
         {
             LBFGSX_HIP(hipEventCreate(&ev.a));
             LBFGSX_HIP(hipEventCreate(&ev.b));
@@ -699,7 +699,7 @@ static int apply_Hv_t(lbfgsx_ctx* c, const T* v, T a, double* dg)
 #undef TL_VARIANT
 #undef TL_POLICY
 #undef TL_LAUNCH
-        if (c->timing)
+        if (c->timing && c->timing_per_launch)
         {
             LBFGSX_HIP(hipEventRecord(ev.b, c->stream));
             c->ev_twoloop.push_back(ev);
@@ -752,6 +752,8 @@ static int apply_Hv_t(lbfgsx_ctx* c, const T* v, T a, double* dg)
     {
         LBFGSX_HIP(hipEventRecord(hv.b, c->stream));
         c->ev_hv.push_back(hv);
+        if (!c->timing_per_launch)
+            c->coarse_steps_timed += 2 * cn + 1;
     }
     if (dg)
         return fetch_scalars<T>(c, sl.dot(2 * cn), 1, dg);
@@ -959,7 +961,9 @@ int lbfgsx_timing_enable(lbfgsx_ctx* c, int on)
     c->ev_twoloop.clear();
     c->ev_hv.clear();
     c->persist_steps_timed = 0;
+    c->coarse_steps_timed = 0;
     c->timing = (on != 0);
+    c->timing_per_launch = (on != 2);
     return LBFGSX_OK;
 }
 
@@ -979,6 +983,15 @@ int lbfgsx_timing_read(lbfgsx_ctx* c, double* twoloop_ms_total, int64_t* twoloop
         float ms = 0.f;
         LBFGSX_HIP(hipEventElapsedTime(&ms, e.a, e.b));
         t2 += ms;
+    }
+    if (c->ev_twoloop.empty() && c->persist_steps_timed == 0 && c->coarse_steps_timed > 0)
+    {
+        // coarse timing of the step launches: one event pair per apply_Hv, reported per step like the persistent form
+        if (twoloop_ms_total) *twoloop_ms_total = t2;
+        if (twoloop_launches) *twoloop_launches = c->coarse_steps_timed;
+        if (applyhv_ms_total) *applyhv_ms_total = t2;
+        if (applyhv_calls) *applyhv_calls = int64_t(c->ev_hv.size());
+        return LBFGSX_OK;
     }
     if (c->ev_twoloop.empty() && c->persist_steps_timed > 0)
     {
