@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(kBlock) k_eval(const T* __restrict__ x, T* __r
 
 // ---------------------------------------------------------------- K2: line-search trial
 // x = xp + step*d ; g = grad f(x) ; out[0] = f(x), out[1] = g.d
-template <class T, class OBJ>
+template <class T, class OBJ, int U = 4>
 __global__ void __launch_bounds__(kBlock) k_trial(const T* __restrict__ xp, const T* __restrict__ d, T step,
                                                   T* __restrict__ x, T* __restrict__ g, int64_t n, OBJ obj,
                                                   RedWs ws, T* __restrict__ out, int rev)
@@ -130,7 +130,6 @@ __global__ void __launch_bounds__(kBlock) k_trial(const T* __restrict__ xp, cons
     const int64_t nv = n / W;
     // tiles of U x kBlock vectors; both loads of every vector are issued before the first use.  The tile order
     // alternates between launches (TwoLoopArgs::rev)
-    constexpr int U = 2;
     const int64_t tile = int64_t(kBlock) * U;
     const int64_t top = ((nv + tile - 1) / tile - 1) * tile;
     for (int64_t t0 = int64_t(blockIdx.x) * tile; t0 < nv; t0 += int64_t(gridDim.x) * tile)
@@ -245,7 +244,7 @@ __global__ void __launch_bounds__(kBlock) k_dot(const T* __restrict__ u, const T
 // s = x - xp, y = g - gp (into the spare history column); out = {g.g, x.x, s.y, y.y}; additionally
 // ys_slot = s.y and theta_slot = y.y / s.y are stored for the column (BFGSMat.h:89-92), so a later
 // commit is a pure index rotation.
-template <class T>
+template <class T, int U = 4>
 __global__ void __launch_bounds__(kBlock) k_post(const T* __restrict__ x, const T* __restrict__ xp,
                                                  const T* __restrict__ g, const T* __restrict__ gp,
                                                  T* __restrict__ s, T* __restrict__ y, int64_t n, RedWs ws,
@@ -256,24 +255,44 @@ __global__ void __launch_bounds__(kBlock) k_post(const T* __restrict__ x, const 
     constexpr int W = Vec16<T>::W;
     A acc[4];
     const int64_t nv = n / W;
-    const int64_t stride = int64_t(gridDim.x) * kBlock;
-    for (int64_t v0 = int64_t(blockIdx.x) * kBlock + threadIdx.x; v0 < nv; v0 += stride)
+    // tiles of U x kBlock vectors, every load of a tile issued before the first use; the tile order alternates between
+    // launches (see k_trial)
+    const int64_t tile = int64_t(kBlock) * U;
+    const int64_t top = ((nv + tile - 1) / tile - 1) * tile;
+    for (int64_t t0 = int64_t(blockIdx.x) * tile; t0 < nv; t0 += int64_t(gridDim.x) * tile)
     {
-        const int64_t vi = rev ? nv - 1 - v0 : v0;
-        const Pack<T> px = ldv(x, vi), pxp = ldv(xp, vi), pg = ldv(g, vi), pgp = ldv(gp, vi);
-        Pack<T> ps, py;
+        const int64_t base = (rev ? top - t0 : t0) + threadIdx.x;
+        Pack<T> px[U], pxp[U], pg[U], pgp[U];
 #pragma unroll
-        for (int k = 0; k < W; k++)
+        for (int u = 0; u < U; u++)
+            if (base + u * kBlock < nv)
+            {
+                px[u] = ldv(x, base + u * kBlock);
+                pxp[u] = ldv(xp, base + u * kBlock);
+                pg[u] = ldv(g, base + u * kBlock);
+                pgp[u] = ldv(gp, base + u * kBlock);
+            }
+#pragma unroll
+        for (int u = 0; u < U; u++)
         {
-            ps.e[k] = px.e[k] - pxp.e[k];
-            py.e[k] = pg.e[k] - pgp.e[k];
-            acc[0].add_prod(pg.e[k], pg.e[k]);
-            acc[1].add_prod(px.e[k], px.e[k]);
-            acc[2].add_prod(ps.e[k], py.e[k]);
-            acc[3].add_prod(py.e[k], py.e[k]);
+            const int64_t vi = base + u * kBlock;
+            if (vi < nv)
+            {
+                Pack<T> ps, py;
+#pragma unroll
+                for (int k = 0; k < W; k++)
+                {
+                    ps.e[k] = px[u].e[k] - pxp[u].e[k];
+                    py.e[k] = pg[u].e[k] - pgp[u].e[k];
+                    acc[0].add_prod(pg[u].e[k], pg[u].e[k]);
+                    acc[1].add_prod(px[u].e[k], px[u].e[k]);
+                    acc[2].add_prod(ps.e[k], py.e[k]);
+                    acc[3].add_prod(py.e[k], py.e[k]);
+                }
+                stv(s, vi, ps);
+                stv(y, vi, py);
+            }
         }
-        stv(s, vi, ps);
-        stv(y, vi, py);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0)
         for (int64_t i = nv * W; i < n; i++)

@@ -846,9 +846,10 @@ template <class T, class OBJ>
 static int trial_t(lbfgsx_ctx* c, OBJ obj, T step, double* out2)
 {
     const int grid = c->grid_for(c->n);
-    hipLaunchKernelGGL((k_trial<T, OBJ>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->xp]), P<T>(c->d), step,
-                       P<T>(c->xb[c->trial]), P<T>(c->gb[c->trial]), c->n, obj, c->ws, c->out_slot<T>(),
-                       (c->zigzag && (c->tl_step++ & 1u)) ? 1 : 0);
+    const int rev = (c->zigzag && (c->tl_step++ & 1u)) ? 1 : 0;
+    // 4 vectors per stream and thread in flight (measured +1 % on the north-star against 2; profiles/r1_mall_policy_ab.txt)
+    hipLaunchKernelGGL((k_trial<T, OBJ, 4>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->xp]), P<T>(c->d), step,
+                       P<T>(c->xb[c->trial]), P<T>(c->gb[c->trial]), c->n, obj, c->ws, c->out_slot<T>(), rev);
     LBFGSX_HIP(hipGetLastError());
     return fetch_scalars<T>(c, c->sl.out(0), 2, out2);
 }
@@ -924,11 +925,11 @@ int lbfgsx_post_linesearch(lbfgsx_ctx* c, double* gnorm2, double* xnorm2, double
     const int grid = c->grid_for(c->n);
     double r[4];
     DISPATCH_T(c, {
-        hipLaunchKernelGGL((k_post<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]), P<T>(c->xb[c->xp]),
+        const int rev = (c->zigzag && (c->tl_step++ & 1u)) ? 1 : 0;
+        hipLaunchKernelGGL((k_post<T, 4>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]), P<T>(c->xb[c->xp]),
                            P<T>(c->gb[c->cur]), P<T>(c->gb[c->xp]), P<T>(c->col(c->S, c->spare)),
-                           P<T>(c->col(c->Y, c->spare)), c->n, c->ws, c->out_slot<T>(),
-                           P<T>(c->sc) + c->sl.ys(c->spare), P<T>(c->sc) + c->sl.theta(c->spare),
-                           (c->zigzag && (c->tl_step++ & 1u)) ? 1 : 0);
+                           P<T>(c->col(c->Y, c->spare)), c->n, c->ws, c->out_slot<T>(), P<T>(c->sc) + c->sl.ys(c->spare),
+                           P<T>(c->sc) + c->sl.theta(c->spare), rev);
         LBFGSX_HIP(hipGetLastError());
         int rc = fetch_scalars<T>(c, c->sl.out(0), 4, r);
         if (rc)
