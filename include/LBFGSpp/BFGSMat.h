@@ -10,6 +10,7 @@
 #ifndef LBFGSX_DROPIN_BFGSMAT_H
 #define LBFGSX_DROPIN_BFGSMAT_H
 
+#include <cstdlib>
 #include <vector>
 
 #include "BKLDLT.h"
@@ -26,6 +27,24 @@ class BFGSMatB
     BKLDLT<Scalar> m_solver;
     lbfgsx_ctx* m_c = nullptr;
     mutable std::vector<Scalar> m_pad;  // scratch of apply_Mv
+    // Un-rounded (double-double) W_F'W_F of the subspace problem in progress, kept by the first solve_PtBP of
+    // subspace_minimize: a BOXCQP sweep then gets W_P'W_P = W_F'W_F - W_{L u U}'W_{L u U} from a Gram over the few
+    // rows of L u U instead of the ~n/2 rows of P (both sums carry ~100 bits, the difference rounds like the direct sum)
+    mutable std::vector<double> m_GF_dd;
+    mutable bool m_GF_valid = false;
+
+    static double dd_sub_round(double ah, double al, double bh, double bl)
+    {
+        const double s = ah - bh;  // TwoSum(ah, -bh)
+        const double bb = s - ah;
+        const double e = (ah - (s - bb)) + (-bh - bb);
+        return s + (e + (al - bl));
+    }
+    static bool complement_enabled()
+    {
+        const char* e = std::getenv("LBFGSX_GRAM_COMPLEMENT");
+        return !(e && std::atoi(e) == 0);
+    }
 
     Scalar& Minv(int i, int j) { return m_permMinv[size_t(j) * size_t(2 * m_m) + size_t(i)]; }
     const Scalar& Minv(int i, int j) const { return m_permMinv[size_t(j) * size_t(2 * m_m) + size_t(i)]; }
@@ -173,8 +192,13 @@ public:
     // inside the Gram pass when the one-pass kernel is available, by separate lbfgsx_b_wcombine launches otherwise.
     // `Fy` (optional): on return W_F' y over `fy_mask` with the S half scaled as apply_WtPv does (`* theta`),
     // produced by the same pass that writes y when the fused kernel applies (otherwise by a separate Wtv).
+    //
+    // `keep_as_F`: this is the solve over the whole free set; its un-rounded Gram is kept.  `comp_mask` / `ncomp`: the
+    // sets that make up F \ mask and their size; when they are small the Gram comes from the complement identity above.
+    void gram_cache_reset() const { m_GF_valid = false; }
     void solve_PtBP(int mask, std::int64_t nP, int vsel, int prologue = LBFGSX_GP_NONE, const double* coef1 = nullptr,
-                    const double* coef2 = nullptr, std::vector<Scalar>* Fy = nullptr, int fy_mask = 0) const
+                    const double* coef2 = nullptr, std::vector<Scalar>* Fy = nullptr, int fy_mask = 0,
+                    bool keep_as_F = false, int comp_mask = 0, std::int64_t ncomp = -1) const
     {
         auto finish = [&](const double* coef) {
             double raw[80];
@@ -213,8 +237,37 @@ public:
         const int c = m_ncorr, t = 2 * c;
         std::vector<double> G(size_t(t) * size_t(t), 0.0);
         double raw[80];
+        bool fused = false;
+        if (comp_mask && ncomp >= 0 && ncomp * 8 < nP && m_GF_valid && m_GF_dd.size() == size_t(t) * size_t(t + 1) &&
+            complement_enabled())
+        {
+            // complement identity: Gram over the rows of F \ mask first (it has no side effects), then the v row with
+            // the prologue
+            std::vector<double> cdd(size_t(t) * size_t(t + 1), 0.0);
+            const bool ok = (ncomp == 0) || lbfgsx_b_gram_fused_dd(m_c, comp_mask, -1, LBFGSX_GP_NONE, nullptr, nullptr,
+                                                                    nullptr, nullptr, cdd.data()) == LBFGSX_OK;
+            if (ok && lbfgsx_b_wtv_prologue(m_c, mask, vsel, prologue, coef1, coef2, raw) == LBFGSX_OK)
+            {
+                for (int i = 0; i < t; i++)
+                    for (int j = 0; j <= i; j++)
+                    {
+                        const size_t e = size_t(i) * size_t(i + 1) / 2 + size_t(j);
+                        const double v = dd_sub_round(m_GF_dd[2 * e], m_GF_dd[2 * e + 1], cdd[2 * e], cdd[2 * e + 1]);
+                        G[size_t(i) * size_t(t) + size_t(j)] = v;
+                        G[size_t(j) * size_t(t) + size_t(i)] = v;
+                    }
+                fused = true;
+            }
+        }
         // one pass for W_P'W_P and W_P'v (and the prologue); the tiled VALU Gram is the fallback
-        bool fused = (lbfgsx_b_gram_fused_ex(m_c, mask, vsel, prologue, coef1, coef2, G.data(), raw) == LBFGSX_OK);
+        if (!fused && keep_as_F)
+        {
+            m_GF_dd.assign(size_t(t) * size_t(t + 1), 0.0);
+            fused = (lbfgsx_b_gram_fused_dd(m_c, mask, vsel, prologue, coef1, coef2, G.data(), raw, m_GF_dd.data()) == LBFGSX_OK);
+            m_GF_valid = fused;
+        }
+        if (!fused)
+            fused = (lbfgsx_b_gram_fused_ex(m_c, mask, vsel, prologue, coef1, coef2, G.data(), raw) == LBFGSX_OK);
         if (!fused && prologue != LBFGSX_GP_NONE)
         {
             prologue_unfused();

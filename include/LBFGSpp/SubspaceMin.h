@@ -82,8 +82,10 @@ public:
 
         std::vector<double> lcoef;
         const bool has_lin = linear_coef(bfgs, gcp, lcoef);             // vecc (:144-156) ...
+        bfgs.gram_cache_reset();
         bfgs.solve_PtBP(LBFGSX_ST_FREE, nfree, LBFGSX_VS_NEG_CF, LBFGSX_GP_LINEAR,   // ... fused with
-                        has_lin ? lcoef.data() : nullptr);              // vecy = -inv(B[F,F]) c (:159)
+                        has_lin ? lcoef.data() : nullptr, nullptr, nullptr, 0,      // vecy = -inv(B[F,F]) c (:159)
+                        /*keep_as_F=*/true);
         std::int64_t cnt[4];
         detail::check(lbfgsx_b_sub_check(c, cnt));
         if (cnt[0] == 0)                                                // in_bounds (:162-166)
@@ -110,7 +112,7 @@ public:
                 // the pass that writes y on P also delivers W_F'y for the multipliers below
                 bfgs.solve_PtBP(LBFGSX_ST_P, nP, LBFGSX_VS_NEG_RHS, (hasL || hasU) ? LBFGSX_GP_RHS : LBFGSX_GP_NONE,
                                 hasL ? cl.data() : nullptr, hasU ? cu.data() : nullptr, need_mult ? &Fy : nullptr,
-                                LBFGSX_ST_FREE);
+                                LBFGSX_ST_FREE, false, LBFGSX_ST_L | LBFGSX_ST_U, nL + nU);
                 have_Fy = need_mult;
             }
             if (need_mult)                                              // multipliers (:247-268)

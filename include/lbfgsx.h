@@ -232,6 +232,17 @@ int lbfgsx_b_gram_fused(lbfgsx_ctx* c, int mask, int vsel, double* gram, double*
 enum { LBFGSX_GP_NONE = 0, LBFGSX_GP_RHS = 1, LBFGSX_GP_LINEAR = 2 };
 int lbfgsx_b_gram_fused_ex(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, const double* coef1, const double* coef2,
                            double* gram, double* wtv);
+/* The same pass that additionally returns the UN-ROUNDED double-double sums of the 2c x 2c block: gram_dd[2 e],
+ * gram_dd[2 e + 1] = (hi, lo) of entry e = i (i + 1) / 2 + j (i >= j), 2c (2c + 1) doubles.  They let the caller form
+ * the Gram of a subset through the complement identity  W_P'W_P = W_F'W_F - W_{F\P}'W_{F\P}: both sums are accurate to
+ * ~2^-100, so their difference rounds to the same double as the direct sum -- and in a BOXCQP sweep the complement
+ * L u U holds 10^1..10^3 rows against |P| ~ n/2.  gram and wtv may be NULL.  Default Gram kernel only. */
+int lbfgsx_b_gram_fused_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, const double* coef1, const double* coef2,
+                           double* gram, double* wtv, double* gram_dd);
+/* The v row of lbfgsx_b_gram_fused_ex alone: the prologue statement on the rows of `mask`, then the raw masked
+ * multi-dot wtv = [Y_mask'v, S_mask'v] -- the Gram kernel with one pair per lane instead of all of them. 1 <= 2c <= 30. */
+int lbfgsx_b_wtv_prologue(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, const double* coef1, const double* coef2,
+                          double* wtv);
 /* lbfgsx_b_wcombine(LBFGSX_CB_SOLVE, pmask, vsel, coef, theta) fused with the raw masked multi-dot
  * wty = [Y_F' y, S_F' y] over `fmask` (pmask must be a subset of fmask): the solve result of solve_PtBP
  * (BFGSMat.h:564) and the W_F' y the multipliers need (SubspaceMin.h:249-254, apply_WtPv BFGSMat.h:382-430) in one

@@ -24,6 +24,7 @@ struct lbfgsb_state
     double* dout = nullptr;           // double outputs of the kernels [64]: device pointer of host-mapped memory, or
     double* dout_host = nullptr;      //   (LBFGSX_MAPPED_OUT=0) plain device memory fetched by a copy
     double* gram_out_host = nullptr;  // same for gram_out
+    double* gram_dd = nullptr;        // [3][256][2] un-rounded (hi, lo) sums of the last one-pass Gram (device)
     void* coef_dev = nullptr;         // T[80]
     unsigned long long* mslot = nullptr;  // max / min slots
     // chunk staging for the sequential GCP scan
@@ -221,6 +222,7 @@ int bounded_alloc(lbfgsx_ctx* c)
     }
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->gram_partial), sizeof(double) * size_t(b->gram_blocks) * 3 * 256 * 2));
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->gram_partial2), sizeof(double) * 32 * 3 * 256 * 2));
+    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->gram_dd), sizeof(double) * 3 * 256 * 2));
     if (c->outmap_dev)
     {
         LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->gram_out_host), sizeof(double) * 3 * 256, hipHostMallocMapped));
@@ -240,7 +242,7 @@ void bounded_free(lbfgsx_ctx* c)
         return;
     void* ptrs[] = {b->brk, b->dvec, b->cF, b->y, b->yfb, b->lam, b->mu, b->rhs, b->keys_in, b->keys_out, b->st,
                     b->vals_in, b->vals_out, b->phys_dev, b->dout, b->coef_dev, b->mslot, b->sort_tmp, b->g_brk,
-                    b->g_g, b->g_z, b->g_w, b->g_idx, b->gram_partial, b->gram_partial2, b->gram_out,
+                    b->g_g, b->g_z, b->g_w, b->g_idx, b->gram_partial, b->gram_partial2, b->gram_out, b->gram_dd,
                     b->s_brk, b->s_g, b->s_z, b->s_W, b->s_P, b->s_C, b->s_fpp, b->s_dfp, b->s_fp, b->s_ts, b->s_off,
                     b->s_small, b->s_exit, b->pk, b->pv, b->pcount, b->sel_tmp};
     for (void* p : ptrs)
@@ -977,7 +979,81 @@ static int launch_gram_dd(lbfgsx_ctx* c, int64_t nbatch, int tot, int vsel_id, i
                        c->n, b->gram_partial, pro);
     return blocks;
 }
+template <class T, int CS>
+static int launch_gram_vonly(lbfgsx_ctx* c, int64_t nbatch, int tot, int vsel_id, int mask, const GramPrologue<T>& pro)
+{
+    lbfgsb_state* b = c->bstate;
+    const size_t lds = gram_dd_lds_bytes(CS, 1);
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_gram_dd<T, 1, CS, true>, kBlock, lds) != hipSuccess || occ < 1)
+        occ = 2;
+    int blocks = std::min(b->gram_blocks, occ * b->num_cus);
+    blocks = int(std::max<int64_t>(1, std::min<int64_t>(blocks, (nbatch + 3) / 4)));
+    int which[32];
+    for (int k = 0; k < tot; k++)
+        which[k] = k;
+    Cols<T, 32> cl = col_list<T, 32>(c, which, tot);
+    hipLaunchKernelGGL((k_gram_dd<T, 1, CS, true>), dim3(blocks), dim3(kBlock), lds, c->stream, cl, tot, bvecs<T>(c), vsel_id,
+                       mask, c->n, b->gram_partial, pro);
+    return blocks;
+}
 extern "C" {
+
+int lbfgsx_b_wtv_prologue(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, const double* coef1, const double* coef2,
+                          double* wtv)
+{
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    lbfgsb_state* b = c->bstate;
+    const int tot = 2 * c->ncorr, ntot = tot + 1;
+    if (tot < 1 || ntot > kGramDDCS || vsel_id < 0 || !wtv || b->gram_mfma || b->gram_mode == 2 ||
+        prologue < LBFGSX_GP_NONE || prologue > LBFGSX_GP_LINEAR)
+    {
+        set_error("lbfgsx_b_wtv_prologue: needs the default one-pass Gram, 1 <= 2c <= 30, a vector selector and a known prologue");
+        return LBFGSX_E_INVALID;
+    }
+    const int64_t nbatch = (c->n + kGramDDRows - 1) / kGramDDRows;
+    rc = upload_phys(c);
+    if (rc)
+        return rc;
+    int blocks = 1;
+    DISPATCH_T(c, {
+        GramPrologue<T> pro;
+        pro.mode = prologue;
+        pro.use1 = coef1 ? 1 : 0;
+        pro.use2 = coef2 ? 1 : 0;
+        for (int k = 0; k < 64; k++)
+        {
+            pro.c1[k] = (coef1 && k < tot) ? T(coef1[k]) : T(0);
+            pro.c2[k] = (coef2 && k < tot) ? T(coef2[k]) : T(0);
+        }
+        // the tile row stride must hold ntot columns: the strides of the full kernel's KP classes
+        if (ntot <= 11) blocks = launch_gram_vonly<T, 11>(c, nbatch, tot, vsel_id, mask, pro);
+        else if (ntot <= 15) blocks = launch_gram_vonly<T, 15>(c, nbatch, tot, vsel_id, mask, pro);
+        else if (ntot <= 23) blocks = launch_gram_vonly<T, 23>(c, nbatch, tot, vsel_id, mask, pro);
+        else if (ntot <= 27) blocks = launch_gram_vonly<T, 27>(c, nbatch, tot, vsel_id, mask, pro);
+        else blocks = launch_gram_vonly<T, 31>(c, nbatch, tot, vsel_id, mask, pro);
+    });
+    const int nch = std::min(blocks, 32);
+    hipLaunchKernelGGL(k_gram_finish, dim3(1, nch), dim3(kBlock), 0, c->stream, b->gram_partial, blocks, b->gram_partial2, 0);
+    hipLaunchKernelGGL(k_gram_finish, dim3(1, 1), dim3(kBlock), 0, c->stream, b->gram_partial2, nch, b->gram_out, 1);
+    LBFGSX_HIP(hipGetLastError());
+    double h[64];
+    if (b->gram_out_host)
+    {
+        LBFGSX_HIP(hipStreamSynchronize(c->stream));
+        std::memcpy(h, b->gram_out_host, sizeof(h));
+    }
+    else
+    {
+        LBFGSX_HIP(hipMemcpyAsync(h, b->gram_out, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    }
+    for (int j = 0; j < tot; j++)
+        wtv[j] = h[j];
+    return LBFGSX_OK;
+}
 
 int lbfgsx_b_gram_fused(lbfgsx_ctx* c, int mask, int vsel_id, double* gram, double* wtv)
 {
@@ -986,6 +1062,12 @@ int lbfgsx_b_gram_fused(lbfgsx_ctx* c, int mask, int vsel_id, double* gram, doub
 
 int lbfgsx_b_gram_fused_ex(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, const double* coef1, const double* coef2,
                            double* gram, double* wtv)
+{
+    return lbfgsx_b_gram_fused_dd(c, mask, vsel_id, prologue, coef1, coef2, gram, wtv, nullptr);
+}
+
+int lbfgsx_b_gram_fused_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, const double* coef1, const double* coef2,
+                           double* gram, double* wtv, double* gram_dd)
 {
     int rc = need_bounded(c);
     if (rc)
@@ -996,6 +1078,11 @@ int lbfgsx_b_gram_fused_ex(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
     if (prologue != LBFGSX_GP_NONE && (b->gram_mfma || prologue < 0 || prologue > LBFGSX_GP_LINEAR))
     {
         set_error("lbfgsx_b_gram_fused_ex: the prologue needs the default one-pass Gram");
+        return LBFGSX_E_INVALID;
+    }
+    if (gram_dd && b->gram_mfma)
+    {
+        set_error("lbfgsx_b_gram_fused_dd: the un-rounded sums exist for the default one-pass Gram only");
         return LBFGSX_E_INVALID;
     }
     if (tot < 1 || (b->gram_mfma ? tot + 1 > 32 : ntot > kGramDDCS) || b->gram_mode == 2)
@@ -1077,8 +1164,15 @@ int lbfgsx_b_gram_fused_ex(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
     const int ntile = (64 * kpt + 255) / 256;
     const int nch = std::min(blocks, 32);
     hipLaunchKernelGGL(k_gram_finish, dim3(ntile, nch), dim3(kBlock), 0, c->stream, b->gram_partial, blocks, b->gram_partial2, 0);
-    hipLaunchKernelGGL(k_gram_finish, dim3(ntile, 1), dim3(kBlock), 0, c->stream, b->gram_partial2, nch, b->gram_out, 1);
+    hipLaunchKernelGGL(k_gram_finish, dim3(ntile, 1), dim3(kBlock), 0, c->stream, b->gram_partial2, nch, b->gram_out, 1,
+                       gram_dd ? b->gram_dd : static_cast<double*>(nullptr));
     LBFGSX_HIP(hipGetLastError());
+    std::vector<double> hdd;
+    if (gram_dd)
+    {
+        hdd.resize(size_t(ntile) * 256 * 2);
+        LBFGSX_HIP(hipMemcpyAsync(hdd.data(), b->gram_dd, sizeof(double) * hdd.size(), hipMemcpyDeviceToHost, c->stream));
+    }
     if (b->gram_out_host)
     {
         LBFGSX_HIP(hipStreamSynchronize(c->stream));
@@ -1089,16 +1183,19 @@ int lbfgsx_b_gram_fused_ex(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
         LBFGSX_HIP(hipMemcpyAsync(h, b->gram_out, sizeof(double) * size_t(ntile) * 256, hipMemcpyDeviceToHost, c->stream));
         LBFGSX_HIP(hipStreamSynchronize(c->stream));
     }
-    for (int i = 0; i < tot; i++)
-        for (int j = 0; j <= i; j++)
-        {
-            const double v = h[i * (i + 1) / 2 + j];
-            gram[i * tot + j] = v;
-            gram[j * tot + i] = v;
-        }
+    if (gram)
+        for (int i = 0; i < tot; i++)
+            for (int j = 0; j <= i; j++)
+            {
+                const double v = h[i * (i + 1) / 2 + j];
+                gram[i * tot + j] = v;
+                gram[j * tot + i] = v;
+            }
     if (wtv && vsel_id >= 0)
         for (int j = 0; j < tot; j++)
             wtv[j] = h[tot * (tot + 1) / 2 + j];
+    if (gram_dd)  // packed lower triangle of the 2c x 2c block, e = i (i + 1) / 2 + j: (hi, lo)
+        std::memcpy(gram_dd, hdd.data(), sizeof(double) * size_t(tot) * size_t(tot + 1));
     return LBFGSX_OK;
 }
 

@@ -519,11 +519,14 @@ inline size_t gram_dd_lds_bytes(int cs, int kp)
     return tile > scr ? tile : scr;
 }
 
-template <class T, int KP>
+// VONLY: only the v row of the matrix -- the pairs (v, column j) and (v, v), one per lane (KP = 1, ntot <= 64 lanes) --
+// with the same staging and prologue as the full pass: a BOXCQP sweep whose 2c x 2c block comes from the complement
+// identity (lbfgsx_b_gram_fused_dd) then pays 1 instead of KP double-double accumulations per row and wavefront.
+template <class T, int KP, int CS = gram_dd_cs(KP), bool VONLY = false>
 __global__ void __launch_bounds__(kBlock) k_gram_dd(Cols<T, 32> cols, int ncols, BVecs<T> b, int vsel_id, int mask,
                                                     int64_t n, double* __restrict__ partial, GramPrologue<T> pro)
 {
-    constexpr int cs = gram_dd_cs(KP);
+    constexpr int cs = CS;
     extern __shared__ double tile[];
     __shared__ T pc1[64], pc2[64];
     if (pro.mode != GP_NONE)
@@ -544,6 +547,13 @@ __global__ void __launch_bounds__(kBlock) k_gram_dd(Cols<T, 32> cols, int ncols,
     for (int k = 0; k < KP; k++)
     {
         int e = lane * KP + k;
+        if (VONLY)
+        {
+            // entry e = (v, column e) for e < ncols, (v, v) for e == ncols; v is column `ncols` of the tile
+            pi[k] = ncols;
+            pj[k] = (e <= ncols) ? e : 0;
+            continue;
+        }
         if (e >= npairs)
             e = 0;  // idle slot: accumulates G(0,0) again, never read back
         int I = 0;
@@ -555,10 +565,25 @@ __global__ void __launch_bounds__(kBlock) k_gram_dd(Cols<T, 32> cols, int ncols,
     DD acc0[KP], acc1[KP];
     const int64_t nbatch = (n + kGramDDRows - 1) / kGramDDRows;
     const int64_t nwaves = int64_t(gridDim.x) * (kBlock / 64);
-    for (int64_t bt = int64_t(blockIdx.x) * (kBlock / 64) + wv; bt < nbatch; bt += nwaves)
+    // the state bytes of four batches are loaded together: with a sparse mask (the complement sets of
+    // lbfgsx_b_gram_fused_dd keep 10^1..10^3 of 10^7 rows) a wavefront otherwise pays one load latency per empty batch
+    for (int64_t bt0 = int64_t(blockIdx.x) * (kBlock / 64) + wv; bt0 < nbatch; bt0 += 4 * nwaves)
     {
+    unsigned char st4[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+    {
+        const int64_t ru = (bt0 + u * nwaves) * kGramDDRows + lane;
+        st4[u] = (mask && ru < n) ? b.st[ru] : (unsigned char) 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+    {
+        const int64_t bt = bt0 + u * nwaves;
+        if (bt >= nbatch)
+            break;
         const int64_t r = bt * kGramDDRows + lane;
-        const bool keep = r < n && (!mask || (b.st[r] & mask));
+        const bool keep = r < n && (!mask || (st4[u] & mask));
         const unsigned long long bal = __ballot(keep);
         const int cnt = __popcll(bal);
         if (cnt == 0)
@@ -646,6 +671,7 @@ __global__ void __launch_bounds__(kBlock) k_gram_dd(Cols<T, 32> cols, int ncols,
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+    }
     // block reduction: the 4 waves hold partial sums of the same pairs
     __syncthreads();
     double* scr = tile;  // [wave][KP][64][2]
@@ -676,9 +702,10 @@ __global__ void __launch_bounds__(kBlock) k_gram_dd(Cols<T, 32> cols, int ncols,
 // Sum per-block partial tiles.  grid = (3 tiles, nchunks): block (tb, ch) adds the partials of input blocks
 // ch, ch + nchunks, ... for its 256 entries.  final = 0: writes a double-double partial per chunk (second level
 // input); final = 1 (nchunks == 1): writes the rounded entries out[tb*256 + e], e = reg*64 + lane  <->  Gram row
-// (lane>>4) + 4*reg, column lane&15.
+// (lane>>4) + 4*reg, column lane&15; with out_dd also the un-rounded double-double sums (hi, lo) per entry, for the
+// complement identity of lbfgsx_b_gram_fused_dd.
 __global__ void __launch_bounds__(kBlock) k_gram_finish(const double* __restrict__ partial, int nblocks,
-                                                        double* __restrict__ out, int final)
+                                                        double* __restrict__ out, int final, double* __restrict__ out_dd = nullptr)
 {
     const int tb = blockIdx.x, ch = blockIdx.y, nch = gridDim.y, e = threadIdx.x;
     DD t;
@@ -688,7 +715,14 @@ __global__ void __launch_bounds__(kBlock) k_gram_finish(const double* __restrict
         t.merge(p[0], p[1]);
     }
     if (final)
+    {
         out[tb * 256 + e] = t.value();
+        if (out_dd)
+        {
+            out_dd[(tb * 256 + e) * 2 + 0] = t.hi;
+            out_dd[(tb * 256 + e) * 2 + 1] = t.lo;
+        }
+    }
     else
     {
         double* q = out + (size_t(ch) * 3 * 256 + size_t(tb) * 256 + e) * 2;
