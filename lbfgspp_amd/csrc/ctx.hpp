@@ -76,6 +76,7 @@ struct lbfgsx_ctx
     void* S = nullptr;
     void* Y = nullptr;
     std::vector<int> phys;  // logical slot (reference storage order, BFGSMat.h:83) -> physical column
+    unsigned phys_version = 1;  // bumped whenever phys changes (device copies are refreshed lazily)
     int spare = 0;
     int ncorr = 0, ptr = 0;
     bool pending = false;     // spare column holds an uncommitted (s, y) pair

@@ -21,6 +21,7 @@ struct lbfgsb_state
     void* sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     int* phys_dev = nullptr;          // logical slot -> physical column, device copy
+    unsigned phys_seen = 0;           //   ctx::phys_version that copy holds
     double* dout = nullptr;           // double outputs of the kernels [64]: device pointer of host-mapped memory, or
     double* dout_host = nullptr;      //   (LBFGSX_MAPPED_OUT=0) plain device memory fetched by a copy
     double* gram_out_host = nullptr;  // same for gram_out
@@ -111,6 +112,9 @@ static int need_bounded(lbfgsx_ctx* c)
 
 static int upload_phys(lbfgsx_ctx* c)
 {
+    if (c->bstate->phys_seen == c->phys_version)  // the map changes once per accepted correction, the operators
+        return LBFGSX_OK;                         // that read it run a dozen times per iteration
+    c->bstate->phys_seen = c->phys_version;
     LBFGSX_HIP(hipMemcpyAsync(c->bstate->phys_dev, c->phys.data(), sizeof(int) * size_t(c->m), hipMemcpyHostToDevice, c->stream));
     return LBFGSX_OK;
 }

@@ -484,6 +484,7 @@ int lbfgsx_bfgs_reset(lbfgsx_ctx* c)
     c->pending = false;
     for (int j = 0; j < c->m; j++)
         c->phys[size_t(j)] = j;
+    c->phys_version++;
     c->spare = c->m;
     // sc[one] = 1
     DISPATCH_T(c, {
@@ -531,6 +532,7 @@ int lbfgsx_commit_correction(lbfgsx_ctx* c)
     const int loc = c->ptr % c->m;
     const int old = c->phys[size_t(loc)];
     c->phys[size_t(loc)] = c->spare;
+    c->phys_version++;
     c->spare = old;
     c->ys_host[size_t(loc)] = c->pend_sy;
     DISPATCH_T(c, { c->theta = double(T(T(c->pend_yy) / T(c->pend_sy))); });
