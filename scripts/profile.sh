@@ -20,7 +20,10 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/f32h_pmc_write -o bench -- 
 # secondary workloads: kernel-trace stats only
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/lbfgsb -o b -- python scripts/bench_lbfgsb.py --n 1e7 --iters 40 > $O/lbfgsb.log 2>&1
 LBFGSX_GRAM=mfma rocprofv3 --kernel-trace --stats --output-format csv -d $O/lbfgsb_mfma -o b -- python scripts/bench_lbfgsb.py --n 1e7 --iters 40 > $O/lbfgsb_mfma.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/batched -o b -- python bench.py --workload cfg5-batched --steps 50 > $O/batched.log 2>&1
+BCMD="python bench.py --workload cfg5-batched --steps 50 --no-cpu"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/batched_trace -o bench -- $BCMD > $O/batched_trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/batched_pmc_fetch -o bench -- $BCMD > $O/batched_pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/batched_pmc_write -o bench -- $BCMD > $O/batched_pmc_write.log 2>&1
 # plain (un-profiled) numbers
 python bench.py > $O/bench_northstar.json 2> /dev/null
 python bench.py --recursion gram --no-cpu > $O/bench_northstar_gram.json 2> /dev/null

@@ -19,7 +19,7 @@ for name in ("northstar", "northstar_gram", "northstar_gram_f32h", "sharded_n1",
     f = os.path.join(src, "bench_%s.json" % name)
     if os.path.exists(f):
         shutil.copy(f, os.path.join("profiles", "%s_bench_%s.json" % (rnd, name)))
-for sub in ("lbfgsb", "lbfgsb_mfma", "batched"):
+for sub in ("lbfgsb", "lbfgsb_mfma"):
     f = os.path.join(src, sub, "b_kernel_stats.csv")
     if os.path.exists(f):
         shutil.copy(f, os.path.join("profiles", "%s_%s_kernel_stats.csv" % (rnd, sub)))
@@ -80,7 +80,7 @@ for k, v in out["kernels"].items():
 
 
 # ---- the opt-in Gram-space recursion (f64 history and f32 history): same counters for its two kernels
-def gram_summary(prefix, tag, flag):
+def gram_summary(prefix, tag, flag, kprefix="k_gs_", note=None):
     gsrc = os.path.join(src, prefix + "_trace", "bench_kernel_stats.csv")
     if not os.path.exists(gsrc):
         return
@@ -96,12 +96,12 @@ def gram_summary(prefix, tag, flag):
     with open(gsrc) as f:
         for r in csv.DictReader(f):
             gstats[short(r["Name"])] = (int(r["Calls"]), float(r["AverageNs"]))
-    gout = {"round": rnd, "command": out["command"].replace("bench.py", "bench.py --recursion " + flag), "units": out["units"],
-            "note": "launches start from an empty history (m = 10): launch k reads 2*min(k,10) columns, so the per-launch "
+    gout = {"round": rnd, "command": out["command"].replace("bench.py", "bench.py " + flag), "units": out["units"],
+            "note": note or "launches start from an empty history (m = 10): launch k reads 2*min(k,10) columns, so the per-launch "
                     "averages below mix the warm-up launches with the full-history ones; max_* are the full-history launches",
             "kernels": {}}
     for k, c in sorted(gagg.items()):
-        if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c or not k.startswith("k_gs_"):
+        if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c or not k.startswith(kprefix):
             continue
         hb = [(2.0 * fv + wv) * 1024.0 for fv, wv in zip(c["FETCH_SIZE"], c["WRITE_SIZE"])]
         calls, avg_ns = gstats.get(k, (0, 0.0))
@@ -114,5 +114,10 @@ def gram_summary(prefix, tag, flag):
                                                                           v["hbm_bytes_per_launch_avg"], v["hbm_bytes_per_launch_max"]))
 
 
-gram_summary("gram", "gram", "gram")
-gram_summary("f32h", "gram_f32h", "gram-f32h")
+gram_summary("gram", "gram", "--recursion gram")
+gram_summary("f32h", "gram_f32h", "--recursion gram-f32h")
+# cfg5: 1024 lock-step f32 problems of n = 1e5 (bench.py --workload cfg5-batched --steps 50)
+gram_summary("batched", "batched", "--workload cfg5-batched --steps 50 --no-cpu", kprefix="kb_",
+             note="one launch covers the 1024 problems of the batch; launches start from an empty history (m = 10), "
+                  "max_* are the full-history launches: kb_twoloop_full reads 4m columns-worth of f32 per problem "
+                  "(the direction vector stays on the CU), i.e. 1024 * (40 + 2) * 1e5 * 4 B = 17.2 GB algorithmic")
