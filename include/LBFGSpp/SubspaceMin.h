@@ -14,6 +14,7 @@
 #define LBFGSX_DROPIN_SUBSPACE_MIN_H
 
 #include <cstdint>
+#include <cstdlib>
 #include <limits>
 #include <vector>
 
@@ -93,19 +94,31 @@ public:
             detail::check(lbfgsx_b_sub_op(c, LBFGSX_SO_ASSIGN_Y));
             return;
         }
-        detail::check(lbfgsx_b_sub_op(c, LBFGSX_SO_SAVE_FALLBACK));     // yfallback, lambda = mu = 0 (:170-172)
+        // The element-wise statements between two solves -- yfallback / lambda = mu = 0 (:170-172) before the first
+        // sweep, the convergence counts (:271) before the others, then the partition (:194-219) and rhs = c_P (:232) --
+        // are one pass (lbfgsx_b_sub_sweep_begin); LBFGSX_SUB_FUSE=0 runs them as the reference's separate statements.
+        const char* fuse_env = std::getenv("LBFGSX_SUB_FUSE");
+        const bool fuse = !(fuse_env && fuse_env[0] == '0');
+        std::int64_t nL = 0, nU = 0, nP = 0;
+        if (fuse)
+            detail::check(lbfgsx_b_sub_sweep_begin(c, 1, &nL, &nU, &nP, cnt));
+        else
+            detail::check(lbfgsx_b_sub_op(c, LBFGSX_SO_SAVE_FALLBACK)); // yfallback, lambda = mu = 0 (:170-172)
 
         int k;
         for (k = 0; k < maxit; k++)
         {
-            std::int64_t nL = 0, nU = 0, nP = 0;
-            detail::check(lbfgsx_b_sub_partition(c, &nL, &nU, &nP));    // (:194-219)
+            if (!fuse)
+            {
+                detail::check(lbfgsx_b_sub_partition(c, &nL, &nU, &nP)); // (:194-219)
+                if (nP > 0)
+                    detail::check(lbfgsx_b_sub_op(c, LBFGSX_SO_RHS_INIT));
+            }
             const bool need_mult = (nL > 0 || nU > 0);
             std::vector<Scalar> Fy;
             bool have_Fy = false;
             if (nP > 0)                                                 // (:229-245)
             {
-                detail::check(lbfgsx_b_sub_op(c, LBFGSX_SO_RHS_INIT));
                 std::vector<double> cl, cu;
                 const bool hasL = PtBQv_coef(bfgs, LBFGSX_ST_L, LBFGSX_VS_LBOUND, nP, nL, cl);
                 const bool hasU = PtBQv_coef(bfgs, LBFGSX_ST_U, LBFGSX_VS_UBOUND, nP, nU, cu);
@@ -127,7 +140,11 @@ public:
                 if (nU > 0)
                     detail::check(lbfgsx_b_wcombine(c, LBFGSX_CB_MU, LBFGSX_ST_U, 0, cf, double(theta)));
             }
-            detail::check(lbfgsx_b_sub_check(c, cnt));                  // (:271)
+            // convergence (:271); with another sweep allowed the same pass already prepares it
+            if (fuse && k + 1 < maxit)
+                detail::check(lbfgsx_b_sub_sweep_begin(c, 0, &nL, &nU, &nP, cnt));
+            else
+                detail::check(lbfgsx_b_sub_check(c, cnt));
             if (cnt[1] == 0 && cnt[2] == 0 && cnt[3] == 0)
                 break;
         }

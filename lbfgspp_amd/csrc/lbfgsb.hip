@@ -1307,6 +1307,30 @@ int lbfgsx_b_sub_check(lbfgsx_ctx* c, int64_t counts[4])
     return LBFGSX_OK;
 }
 
+int lbfgsx_b_sub_sweep_begin(lbfgsx_ctx* c, int first, int64_t* nL, int64_t* nU, int64_t* nP, int64_t counts[4])
+{
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    const int grid = c->grid_for(c->n);
+    double r[7];
+    DISPATCH_T(c, {
+        BVecs<T> bv = bvecs<T>(c);
+        hipLaunchKernelGGL((k_sub_sweep_begin<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, first ? 1 : 0, c->n, c->ws,
+                           c->bstate->dout);
+    });
+    LBFGSX_HIP(hipGetLastError());
+    rc = fetch_doubles(c, 7, r);
+    if (rc)
+        return rc;
+    *nL = int64_t(r[0]);
+    *nU = int64_t(r[1]);
+    *nP = int64_t(r[2]);
+    for (int k = 0; k < 4; k++)
+        counts[k] = int64_t(r[3 + k]);
+    return LBFGSX_OK;
+}
+
 int lbfgsx_b_sub_op(lbfgsx_ctx* c, int op)
 {
     int rc = need_bounded(c);

@@ -1052,6 +1052,76 @@ __global__ void __launch_bounds__(kBlock) k_sub_check(BVecs<T> b, int64_t n, Red
             out[k] = acc[k].value();
 }
 
+// One pass for the element-wise statements between two BOXCQP solves (SubspaceMin.h:170-172 | :271, then :194-219,
+// :232): first sweep   yfallback = y, lambda = mu = 0            (SO_SAVE_FALLBACK)
+//         later sweeps the convergence counts of k_sub_check on the values the last solve left,
+// then the partition of k_sub_partition and rhs = c on the new P (SO_RHS_INIT).  Statement for statement the three
+// kernels it replaces, so every value is the same bit pattern; when the counts are all zero the partition moves no
+// y (a converged sweep has every y inside its box and every multiplier non-negative), so running it is harmless.
+// out = {#L, #U, #P, 0, #P outside, #L with lambda < 0, #U with mu < 0}
+template <class T>
+__global__ void __launch_bounds__(kBlock) k_sub_sweep_begin(BVecs<T> b, int first, int64_t n, RedWs ws, double* __restrict__ out)
+{
+    typedef typename AccOf<T>::type A;
+    A acc[7];
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
+    {
+        unsigned char s = b.st[i];
+        if (!(s & ST_FREE))
+            continue;
+        const T li = b.lb[i] - b.x0[i], ui = b.ub[i] - b.x0[i];
+        const T yi = b.y[i];
+        T lam, mu;
+        if (first)
+        {
+            b.yfb[i] = yi;
+            lam = T(0);
+            mu = T(0);
+        }
+        else
+        {
+            lam = b.lam[i];
+            mu = b.mu[i];
+            if ((s & ST_P) && (yi < li || yi > ui))
+                acc[4].add(T(1));
+            if ((s & ST_L) && lam < T(0))
+                acc[5].add(T(1));
+            if ((s & ST_U) && mu < T(0))
+                acc[6].add(T(1));
+        }
+        s &= (unsigned char) ~(ST_L | ST_U | ST_P);
+        if ((yi < li) || (yi == li && lam >= T(0)))
+        {
+            s |= ST_L;
+            b.y[i] = li;
+            mu = T(0);
+            acc[0].add(T(1));
+        }
+        else if ((yi > ui) || (yi == ui && mu >= T(0)))
+        {
+            s |= ST_U;
+            b.y[i] = ui;
+            lam = T(0);
+            acc[1].add(T(1));
+        }
+        else
+        {
+            s |= ST_P;
+            lam = T(0);
+            mu = T(0);
+            b.rhs[i] = b.cF[i];
+            acc[2].add(T(1));
+        }
+        b.lam[i] = lam;
+        b.mu[i] = mu;
+        b.st[i] = s;
+    }
+    if (grid_reduce<7>(acc, ws) && threadIdx.x == 0)
+        for (int k = 0; k < 7; k++)
+            out[k] = acc[k].value();
+}
+
 // misc element-wise statements of SubspaceMin.h, selected by `op`
 enum
 {

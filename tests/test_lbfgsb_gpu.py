@@ -272,26 +272,33 @@ def test_mfma_gram_mode_solves_the_box_qp(A, monkeypatch):
     assert niter < 400 and np.abs(x - np.clip(b / a, lb, ub)).max() < 1e-4
 
 
-def test_fused_subspace_passes_are_bit_identical_to_the_unfused_sequence(A, monkeypatch):
+@pytest.mark.parametrize("max_submin", [10, 2, 1])
+def test_fused_subspace_passes_are_bit_identical_to_the_unfused_sequence(A, monkeypatch, max_submin):
     """Default path (one-pass Gram with the rhs / linear-term prologue, solve fused with W_F'y, one-launch
-    multi-dot) against the statement-by-statement sequence (LBFGSX_GRAM=blocked, LBFGSX_MULTIDOT=chunked): the fusions
-    only remove passes over S, Y, so every iterate must agree to the last bit."""
+    multi-dot, one element-wise pass between two BOXCQP solves) against the statement-by-statement sequence
+    (LBFGSX_GRAM=blocked, LBFGSX_MULTIDOT=chunked, LBFGSX_SUB_FUSE=0): the fusions only remove passes, so every iterate
+    must agree to the last bit -- also when the sweeps run out (max_submin = 2, 1: the fallback ladder of
+    SubspaceMin.h:276-296)."""
     n, m, iters = 30000, 8, 18
     a, b = O.quad_problem(n, 30.0, 3, O.F64)
     res = {}
-    for label, env in (("fused", {}), ("unfused", {"LBFGSX_GRAM": "blocked", "LBFGSX_MULTIDOT": "chunked"})):
-        for k in ("LBFGSX_GRAM", "LBFGSX_MULTIDOT"):
+    for label, env in (("fused", {}), ("unfused", {"LBFGSX_GRAM": "blocked", "LBFGSX_MULTIDOT": "chunked",
+                                                     "LBFGSX_SUB_FUSE": "0"})):
+        for k in ("LBFGSX_GRAM", "LBFGSX_MULTIDOT", "LBFGSX_SUB_FUSE"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        s = A.LBFGSBSolver(A.LBFGSBParam(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters))
+        s = A.LBFGSBSolver(A.LBFGSBParam(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters,
+                                          max_submin=max_submin))
         tr = A.TraceBuffer(n, cap=256, stride=7)
         x = np.zeros(n)
         niter, fx = s.minimize(A.DiagQuadratic(a, b), x, -0.7 * np.ones(n), 0.9 * np.ones(n), trace=tr)
-        res[label] = (niter, s.last.nfev, fx, x.copy(), tr.xs[:tr.count].copy(), s.stats()["submin_sweeps"])
+        res[label] = (niter, s.last.nfev, fx, x.copy(), tr.xs[:tr.count].copy(), s.stats()["submin_sweeps"],
+                      s.stats()["submin_unconverged"])
     f, u = res["fused"], res["unfused"]
     assert f[:3] == u[:3] and f[5] == u[5] and f[5] > 0
     assert np.array_equal(f[3], u[3]) and np.array_equal(f[4], u[4])
+    assert f[6] == u[6] and (max_submin >= 10 or f[6] > 0)
 
 
 def test_partial_break_point_sort_is_exact_and_falls_back(A, monkeypatch):
