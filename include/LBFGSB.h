@@ -144,7 +144,7 @@ private:
 
             const auto t_corr = std::chrono::steady_clock::now();
             if (Scalar(syd) > eps * Scalar(yyd))                        // (:237-238)
-                m_bfgs.add_correction(Scalar(syd), Scalar(yyd));
+                m_bfgs.add_correction_begin(Scalar(syd), Scalar(yyd), m_defer_dots);  // finished inside get_cauchy_point
             m_stats.correction_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_corr).count();
 
             detail::check(lbfgsx_b_force_bounds(c));                    // (:240)
@@ -173,6 +173,11 @@ private:
             k++;
         }
     }
+    // LBFGSX_CORR_DEFER=0: the dots of add_correction's tail in a pass of their own, as the reference has them
+    const bool m_defer_dots = [] {
+        const char* e = std::getenv("LBFGSX_CORR_DEFER");
+        return !(e && e[0] == '0');
+    }();
     const bool m_trace_phases = std::getenv("LBFGSX_TRACE_PHASES") != nullptr;  // debugging aid: cumulative phase times
 
 public:

@@ -25,6 +25,9 @@ class BFGSMatB
     Scalar m_theta = Scalar(1);
     std::vector<Scalar> m_permMinv;  // column-major 2m x 2m
     BKLDLT<Scalar> m_solver;
+    bool m_pending = false;          // add_correction_begin done, finish_correction outstanding
+    int m_pend_loc = 0;
+    Scalar m_pend_sy = Scalar(0);
     lbfgsx_ctx* m_c = nullptr;
     mutable std::vector<Scalar> m_pad;  // scratch of apply_Mv
     // Un-rounded (double-double) W_F'W_F of the subspace problem in progress, kept by the first solve_PtBP of
@@ -58,6 +61,7 @@ public:
         m_theta = Scalar(1);
         m_ncorr = 0;
         m_ptr = m;
+        m_pending = false;
         m_permMinv.assign(size_t(4) * size_t(m) * size_t(m), Scalar(0));
         for (int i = 0; i < 2 * m; i++)
             Minv(i, i) = Scalar(1);
@@ -73,13 +77,36 @@ public:
     // index rotation.  The LBFGSB tail needs S's_new and the s_new.y_j row: one masked multi-dot pass.
     void add_correction(Scalar sy, Scalar yy)
     {
+        add_correction_begin(sy, yy, false);
+        finish_correction();
+    }
+
+    // The two halves of add_correction.  With defer = true the device part of the tail (the dots of s_new against
+    // the history) rides on the W'd pass of the Cauchy search that follows (lbfgsx_b_correction_dots_defer) and
+    // finish_correction() -- called by Cauchy::get_cauchy_point right after its build, before M is first used --
+    // completes Minv and its factorisation.
+    void add_correction_begin(Scalar sy, Scalar yy, bool defer)
+    {
         const int loc = m_ptr % m_m;
         detail::check(lbfgsx_commit_correction(m_c));
         m_theta = yy / sy;
         if (m_ncorr < m_m)
             m_ncorr++;
         m_ptr = loc + 1;
-
+        m_pend_loc = loc;
+        m_pend_sy = sy;
+        m_pending = true;
+        if (defer)
+            detail::check(lbfgsx_b_correction_dots_defer(m_c));
+    }
+    bool correction_pending() const { return m_pending; }
+    void finish_correction()
+    {
+        if (!m_pending)
+            return;
+        m_pending = false;
+        const int loc = m_pend_loc;
+        const Scalar sy = m_pend_sy;
         double sd[64], yd[64];
         detail::check(lbfgsx_b_correction_dots(m_c, sd, yd));
 

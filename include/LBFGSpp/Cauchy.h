@@ -111,7 +111,7 @@ public:
     };
 
     // xcp and the state byte are left on the device; vecc and the set sizes are returned
-    static void get_cauchy_point(const BFGSMatB<Scalar>& bfgs, Result& out)
+    static void get_cauchy_point(BFGSMatB<Scalar>& bfgs, Result& out)
     {
         lbfgsx_ctx* c = bfgs.ctx();
         const int ncorr = bfgs.num_corrections();
@@ -127,6 +127,7 @@ public:
         const double factor = tau_factor();
         double tau = (factor > 0.0) ? out.tau_hint : 0.0;
         detail::check(lbfgsx_b_cauchy_build_partial(c, tau, &nfree, &nord, &lim, &dd, wtd));
+        bfgs.finish_correction();  // a deferred add_correction tail: its dots came with the W'd pass of the build
         out.t_build = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
         if (nfree < 1 && nord < 1)
         {

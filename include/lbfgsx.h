@@ -185,6 +185,10 @@ int lbfgsx_b_dg_maxstep(lbfgsx_ctx* c, double* dg, double* step_max);
 int lbfgsx_b_post_linesearch(lbfgsx_ctx* c, double* projgnorm, double* xnorm2, double* sy, double* yy);
 /* add_correction tail: sdots[j] = S_j.s_new, ydots[j] = Y_j.s_new for slots j < ncorr  (BFGSMat.h:111,138) */
 int lbfgsx_b_correction_dots(lbfgsx_ctx* c, double* sdots, double* ydots);
+/* ask the next lbfgsx_b_cauchy_build* to take those dots in the pass that computes W'd (Cauchy.h:152) -- the same 2c
+ * columns, one read instead of two; lbfgsx_b_correction_dots then returns them without a launch.  Same sums, same
+ * bits.  Without a following build (or with 4c > 40 reductions) lbfgsx_b_correction_dots computes them as before. */
+int lbfgsx_b_correction_dots_defer(lbfgsx_ctx* c);
 /* GCP build: break points, vecd, xcp = x0, radix sort of the finite positive break points; returns the counts
  * of free (brk = inf) and ordered coordinates, d.d, and the raw W'd dots [Y'd, S'd]  (Cauchy.h:93-133,152-154) */
 int lbfgsx_b_cauchy_build(lbfgsx_ctx* c, int64_t* nfree, int64_t* nord, double* dd, double* wtd);

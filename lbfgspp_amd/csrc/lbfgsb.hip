@@ -22,6 +22,9 @@ struct lbfgsb_state
     size_t sort_tmp_bytes = 0;
     int* phys_dev = nullptr;          // logical slot -> physical column, device copy
     unsigned phys_seen = 0;           //   ctx::phys_version that copy holds
+    // lbfgsx_b_correction_dots_defer: the dots of the newest s against the history ride on the next W'd pass
+    bool corr_defer = false, corr_stash_valid = false;
+    double corr_raw[80];              //   raw dots (Y slots then S slots) kept for lbfgsx_b_correction_dots
     double* dout = nullptr;           // double outputs of the kernels [64]: device pointer of host-mapped memory, or
     double* dout_host = nullptr;      //   (LBFGSX_MAPPED_OUT=0) plain device memory fetched by a copy
     double* gram_out_host = nullptr;  // same for gram_out
@@ -359,6 +362,49 @@ static int wtv_t(lbfgsx_ctx* c, int vsel_id, const T* vcol, int mask, double* ou
     return LBFGSX_OK;
 }
 
+// p = W'd of the Cauchy search; when the dots of the last commit were deferred (lbfgsx_b_correction_dots_defer) and
+// 4c reductions fit one launch, the same pass also delivers them (k_multidot2_all)
+template <class T, int NC>
+static int wtd2_all(lbfgsx_ctx* c, int total, const T* snew, const T* dvec, double* wtd)
+{
+    int which[32];
+    for (int k = 0; k < total; k++)
+        which[k] = k;
+    Cols<T, 32> cl = col_list<T, 32>(c, which, total);
+    const int grid = std::min(c->grid_for(c->n), c->bstate->dots_grid);
+    hipLaunchKernelGGL((k_multidot2_all<T, NC>), dim3(grid), dim3(kBlock), 0, c->stream, cl, total, snew, dvec, c->n, c->ws,
+                       c->bstate->dout);
+    LBFGSX_HIP(hipGetLastError());
+    double r[2 * NC];
+    int rc = fetch_doubles(c, 2 * NC, r);
+    if (rc)
+        return rc;
+    for (int k = 0; k < total; k++)
+    {
+        c->bstate->corr_raw[k] = r[k];
+        wtd[k] = r[NC + k];
+    }
+    c->bstate->corr_stash_valid = true;
+    return LBFGSX_OK;
+}
+template <class T>
+static int cauchy_wtd(lbfgsx_ctx* c, double* wtd)
+{
+    lbfgsb_state* b = c->bstate;
+    const int total = 2 * c->ncorr;
+    const bool defer = b->corr_defer;
+    b->corr_defer = false;
+    if (defer && total > 8 && total <= 20 && !b->multidot_chunked)
+    {
+        const int newest = (c->ptr + c->m - 1) % c->m;
+        const T* snew = static_cast<const T*>(c->col(c->S, c->phys[size_t(newest)]));
+        if (total <= 16)
+            return wtd2_all<T, 16>(c, total, snew, static_cast<const T*>(b->dvec), wtd);
+        return wtd2_all<T, 20>(c, total, snew, static_cast<const T*>(b->dvec), wtd);
+    }
+    return wtv_t<T>(c, 0, static_cast<const T*>(b->dvec), 0, wtd, nullptr);
+}
+
 }  // namespace lbfgsx
 
 namespace lbfgsx {
@@ -526,6 +572,16 @@ int lbfgsx_b_post_linesearch(lbfgsx_ctx* c, double* projgnorm, double* xnorm2, d
     return read_slot(c, projgnorm);
 }
 
+int lbfgsx_b_correction_dots_defer(lbfgsx_ctx* c)
+{
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    c->bstate->corr_defer = c->ncorr > 0;
+    c->bstate->corr_stash_valid = false;
+    return LBFGSX_OK;
+}
+
 int lbfgsx_b_correction_dots(lbfgsx_ctx* c, double* sdots, double* ydots)
 {
     int rc = need_bounded(c);
@@ -535,6 +591,17 @@ int lbfgsx_b_correction_dots(lbfgsx_ctx* c, double* sdots, double* ydots)
         return LBFGSX_OK;
     const int newest = (c->ptr + c->m - 1) % c->m;  // slot written by the last commit (BFGSMat.h:83,97)
     double raw[80];
+    c->bstate->corr_defer = false;
+    if (c->bstate->corr_stash_valid)  // delivered by the W'd pass of lbfgsx_b_cauchy_build* (k_multidot2_all)
+    {
+        c->bstate->corr_stash_valid = false;
+        for (int j = 0; j < c->ncorr; j++)
+        {
+            ydots[j] = c->bstate->corr_raw[j];
+            sdots[j] = c->bstate->corr_raw[c->ncorr + j];
+        }
+        return LBFGSX_OK;
+    }
     DISPATCH_T(c, {
         const T* snew = static_cast<const T*>(c->col(c->S, c->phys[size_t(newest)]));
         rc = wtv_t<T>(c, 0, snew, 0, raw, nullptr);
@@ -574,7 +641,7 @@ int lbfgsx_b_cauchy_build(lbfgsx_ctx* c, int64_t* nfree, int64_t* nord, double* 
         // p = W'd raw dots (Cauchy.h:152)
         if (wtd && c->ncorr > 0)
         {
-            rc = wtv_t<T>(c, 0, static_cast<const T*>(b->dvec), 0, wtd, nullptr);
+            rc = cauchy_wtd<T>(c, wtd);
             if (rc)
                 return rc;
         }
@@ -676,7 +743,7 @@ int lbfgsx_b_cauchy_build_partial(lbfgsx_ctx* c, double tau, int64_t* nfree, int
         }
         if (wtd && c->ncorr > 0)  // p = W'd raw dots (Cauchy.h:152)
         {
-            rc = wtv_t<T>(c, 0, static_cast<const T*>(b->dvec), 0, wtd, nullptr);
+            rc = cauchy_wtd<T>(c, wtd);
             if (rc)
                 return rc;
         }

@@ -334,6 +334,56 @@ __global__ void __launch_bounds__(kBlock, 2) k_multidot_all(Cols<T, 32> cols, in
             out[k] = double(T(acc[k].value()));
 }
 
+// Two unmasked multi-dots in ONE pass over the 2c columns: out[k] = col_k . v1, out[NC + k] = col_k . v2.
+// The tail of add_correction (S's_new and the s_new.y_j row, BFGSMat.h:111,138) and p = W'd of the Cauchy search that
+// follows it (Cauchy.h:152) read the same 2c columns with nothing but element-wise work on other vectors in between;
+// every dot is the same correctly rounded sum as in k_multidot_all, so taking them together changes no bit.
+template <class T, int NC>
+__global__ void __launch_bounds__(kBlock, 1) k_multidot2_all(Cols<T, 32> cols, int ncols, const T* __restrict__ v1,
+                                                          const T* __restrict__ v2, int64_t n, RedWs ws,
+                                                          double* __restrict__ out)
+{
+    typedef typename AccOf<T>::type A;
+    constexpr int W = Vec16<T>::W;
+    A acc[2 * NC];
+    const int64_t nv = n / W;
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t vi = int64_t(blockIdx.x) * kBlock + threadIdx.x; vi < nv; vi += stride)
+    {
+        const Pack<T> a = ldv<T>(v1, vi), d = ldv<T>(v2, vi);
+        Pack<T> pc[NC];
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+            if (k < ncols)
+                pc[k] = ldv<T>(cols.p[k], vi);
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+            if (k < ncols)
+            {
+#pragma unroll
+                for (int e = 0; e < W; e++)
+                {
+                    acc[k].add_prod(pc[k].e[e], a.e[e]);
+                    acc[NC + k].add_prod(pc[k].e[e], d.e[e]);
+                }
+            }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int64_t i = nv * W; i < n; i++)
+        {
+#pragma unroll
+            for (int k = 0; k < NC; k++)
+                if (k < ncols)
+                {
+                    acc[k].add_prod(cols.p[k][i], v1[i]);
+                    acc[NC + k].add_prod(cols.p[k][i], v2[i]);
+                }
+        }
+    if (grid_reduce<2 * NC>(acc, ws) && threadIdx.x == 0)
+        for (int k = 0; k < 2 * NC; k++)
+            out[k] = double(T(acc[k].value()));
+}
+
 // ---------------------------------------------------------------- masked Gram block: out[a*TB+c] = sum_{i in mask} I_a[i] * J_c[i]
 // (BFGSMat.h:543-556: WP'WP blocks of solve_PtBP)
 template <class T, int TB>

@@ -275,16 +275,16 @@ def test_mfma_gram_mode_solves_the_box_qp(A, monkeypatch):
 @pytest.mark.parametrize("max_submin", [10, 2, 1])
 def test_fused_subspace_passes_are_bit_identical_to_the_unfused_sequence(A, monkeypatch, max_submin):
     """Default path (one-pass Gram with the rhs / linear-term prologue, solve fused with W_F'y, one-launch
-    multi-dot, one element-wise pass between two BOXCQP solves) against the statement-by-statement sequence
-    (LBFGSX_GRAM=blocked, LBFGSX_MULTIDOT=chunked, LBFGSX_SUB_FUSE=0): the fusions only remove passes, so every iterate
+    multi-dot, one element-wise pass between two BOXCQP solves, add_correction's dots taken by the W'd pass) against the statement-by-statement sequence
+    (LBFGSX_GRAM=blocked, LBFGSX_MULTIDOT=chunked, LBFGSX_SUB_FUSE=0, LBFGSX_CORR_DEFER=0): the fusions only remove passes, so every iterate
     must agree to the last bit -- also when the sweeps run out (max_submin = 2, 1: the fallback ladder of
     SubspaceMin.h:276-296)."""
     n, m, iters = 30000, 8, 18
     a, b = O.quad_problem(n, 30.0, 3, O.F64)
     res = {}
     for label, env in (("fused", {}), ("unfused", {"LBFGSX_GRAM": "blocked", "LBFGSX_MULTIDOT": "chunked",
-                                                     "LBFGSX_SUB_FUSE": "0"})):
-        for k in ("LBFGSX_GRAM", "LBFGSX_MULTIDOT", "LBFGSX_SUB_FUSE"):
+                                                     "LBFGSX_SUB_FUSE": "0", "LBFGSX_CORR_DEFER": "0"})):
+        for k in ("LBFGSX_GRAM", "LBFGSX_MULTIDOT", "LBFGSX_SUB_FUSE", "LBFGSX_CORR_DEFER"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -299,6 +299,27 @@ def test_fused_subspace_passes_are_bit_identical_to_the_unfused_sequence(A, monk
     assert f[:3] == u[:3] and f[5] == u[5] and f[5] > 0
     assert np.array_equal(f[3], u[3]) and np.array_equal(f[4], u[4])
     assert f[6] == u[6] and (max_submin >= 10 or f[6] > 0)
+
+
+@pytest.mark.parametrize("m", [3, 5, 8, 10, 12])
+def test_deferred_correction_dots_change_no_bit(A, monkeypatch, m):
+    """add_correction's S's_new / s_new.y_j dots taken by the W'd pass of the following Cauchy search
+    (lbfgsx_b_correction_dots_defer, k_multidot2_all for 8 < 2c <= 20) against the pass of their own
+    (LBFGSX_CORR_DEFER=0): the same correctly rounded sums, so the same trajectory bit for bit; 2c <= 8 and
+    2c > 20 take the separate pass either way."""
+    n, iters = 50001, 2 * m + 6  # odd n: the scalar tail of the vectorised pass
+    a, b = O.quad_problem(n, 25.0, 7, O.F64)
+    res = {}
+    for defer in ("1", "0"):
+        monkeypatch.setenv("LBFGSX_CORR_DEFER", defer)
+        s = A.LBFGSBSolver(A.LBFGSBParam(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters))
+        tr = A.TraceBuffer(n, cap=256, stride=11)
+        x = np.zeros(n)
+        niter, fx = s.minimize(A.DiagQuadratic(a, b), x, -0.6 * np.ones(n), 0.8 * np.ones(n), trace=tr)
+        res[defer] = (niter, s.last.nfev, fx, x.copy(), tr.xs[:tr.count].copy())
+    f, u = res["1"], res["0"]
+    assert f[:3] == u[:3] and f[0] == iters
+    assert np.array_equal(f[3], u[3]) and np.array_equal(f[4], u[4])
 
 
 def test_partial_break_point_sort_is_exact_and_falls_back(A, monkeypatch):
