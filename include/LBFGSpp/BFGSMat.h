@@ -26,6 +26,7 @@ class BFGSMatB
     std::vector<Scalar> m_permMinv;  // column-major 2m x 2m
     BKLDLT<Scalar> m_solver;
     bool m_pending = false;          // add_correction_begin done, finish_correction outstanding
+    mutable bool m_sweeps_expected = false;
     int m_pend_loc = 0;
     Scalar m_pend_sy = Scalar(0);
     lbfgsx_ctx* m_c = nullptr;
@@ -62,6 +63,7 @@ public:
         m_ncorr = 0;
         m_ptr = m;
         m_pending = false;
+        m_sweeps_expected = false;
         m_permMinv.assign(size_t(4) * size_t(m) * size_t(m), Scalar(0));
         for (int i = 0; i < 2 * m; i++)
             Minv(i, i) = Scalar(1);
@@ -100,6 +102,9 @@ public:
             detail::check(lbfgsx_b_correction_dots_defer(m_c));
     }
     bool correction_pending() const { return m_pending; }
+    // hint for SubspaceMin: did the last subspace minimisation need BOXCQP sweeps?
+    bool sweeps_expected() const { return m_sweeps_expected; }
+    void expect_sweeps(bool v) const { m_sweeps_expected = v; }
     void finish_correction()
     {
         if (!m_pending)

@@ -87,21 +87,32 @@ public:
         bfgs.solve_PtBP(LBFGSX_ST_FREE, nfree, LBFGSX_VS_NEG_CF, LBFGSX_GP_LINEAR,   // ... fused with
                         has_lin ? lcoef.data() : nullptr, nullptr, nullptr, 0,      // vecy = -inv(B[F,F]) c (:159)
                         /*keep_as_F=*/true);
-        std::int64_t cnt[4];
-        detail::check(lbfgsx_b_sub_check(c, cnt));
-        if (cnt[0] == 0)                                                // in_bounds (:162-166)
-        {
-            detail::check(lbfgsx_b_sub_op(c, LBFGSX_SO_ASSIGN_Y));
-            return;
-        }
         // The element-wise statements between two solves -- yfallback / lambda = mu = 0 (:170-172) before the first
         // sweep, the convergence counts (:271) before the others, then the partition (:194-219) and rhs = c_P (:232) --
         // are one pass (lbfgsx_b_sub_sweep_begin); LBFGSX_SUB_FUSE=0 runs them as the reference's separate statements.
+        // When the previous call needed sweeps, the in_bounds test (:162-166) rides on that pass as well (the pass
+        // moves no y when everything is in bounds, so taking it early is harmless).
         const char* fuse_env = std::getenv("LBFGSX_SUB_FUSE");
         const bool fuse = !(fuse_env && fuse_env[0] == '0');
+        const bool early = fuse && bfgs.sweeps_expected();
+        std::int64_t cnt[4];
         std::int64_t nL = 0, nU = 0, nP = 0;
-        if (fuse)
+        if (early)
             detail::check(lbfgsx_b_sub_sweep_begin(c, 1, &nL, &nU, &nP, cnt));
+        else
+            detail::check(lbfgsx_b_sub_check(c, cnt));
+        if (cnt[0] == 0)                                                // in_bounds (:162-166)
+        {
+            bfgs.expect_sweeps(false);
+            detail::check(lbfgsx_b_sub_op(c, LBFGSX_SO_ASSIGN_Y));
+            return;
+        }
+        bfgs.expect_sweeps(true);
+        if (fuse)
+        {
+            if (!early)
+                detail::check(lbfgsx_b_sub_sweep_begin(c, 1, &nL, &nU, &nP, cnt));
+        }
         else
             detail::check(lbfgsx_b_sub_op(c, LBFGSX_SO_SAVE_FALLBACK)); // yfallback, lambda = mu = 0 (:170-172)
 

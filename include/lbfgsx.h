@@ -259,9 +259,9 @@ int lbfgsx_b_sub_partition(lbfgsx_ctx* c, int64_t* nL, int64_t* nU, int64_t* nP)
 /* counts = {#F outside [l,u], #P outside [l,u], #L with lambda<0, #U with mu<0}  (SubspaceMin.h:60-108) */
 int lbfgsx_b_sub_check(lbfgsx_ctx* c, int64_t counts[4]);
 /* the element-wise statements between two BOXCQP solves in ONE pass: first != 0: LBFGSX_SO_SAVE_FALLBACK
- * (SubspaceMin.h:170-172), else the counts of lbfgsx_b_sub_check on the current values (counts[0] = 0: the in_bounds
- * test belongs to the first solve); then lbfgsx_b_sub_partition (:194-219) and LBFGSX_SO_RHS_INIT (:232).  Bit for
- * bit the three calls it replaces. */
+ * (SubspaceMin.h:170-172) with counts[0] = #F outside [l,u] (the in_bounds test of the first solve, :162; when it is 0
+ * the pass has moved no value of y), else the counts[1..3] of lbfgsx_b_sub_check on the current values; then
+ * lbfgsx_b_sub_partition (:194-219) and LBFGSX_SO_RHS_INIT (:232).  Bit for bit the calls it replaces. */
 int lbfgsx_b_sub_sweep_begin(lbfgsx_ctx* c, int first, int64_t* nL, int64_t* nU, int64_t* nP, int64_t counts[4]);
 /* element-wise statements of SubspaceMin.h selected by LBFGSX_SO_* */
 int lbfgsx_b_sub_op(lbfgsx_ctx* c, int op);

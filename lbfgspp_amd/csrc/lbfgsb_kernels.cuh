@@ -1108,7 +1108,8 @@ __global__ void __launch_bounds__(kBlock) k_sub_check(BVecs<T> b, int64_t n, Red
 // then the partition of k_sub_partition and rhs = c on the new P (SO_RHS_INIT).  Statement for statement the three
 // kernels it replaces, so every value is the same bit pattern; when the counts are all zero the partition moves no
 // y (a converged sweep has every y inside its box and every multiplier non-negative), so running it is harmless.
-// out = {#L, #U, #P, 0, #P outside, #L with lambda < 0, #U with mu < 0}
+// out = {#L, #U, #P, first ? #F outside (the in_bounds test of the first solve, :162) : 0, #P outside, #L with lambda < 0,
+//        #U with mu < 0}
 template <class T>
 __global__ void __launch_bounds__(kBlock) k_sub_sweep_begin(BVecs<T> b, int first, int64_t n, RedWs ws, double* __restrict__ out)
 {
@@ -1125,6 +1126,8 @@ __global__ void __launch_bounds__(kBlock) k_sub_sweep_begin(BVecs<T> b, int firs
         T lam, mu;
         if (first)
         {
+            if (yi < li || yi > ui)
+                acc[3].add(T(1));
             b.yfb[i] = yi;
             lam = T(0);
             mu = T(0);
