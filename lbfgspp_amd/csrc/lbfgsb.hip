@@ -864,8 +864,11 @@ int lbfgsx_b_cauchy_scan(lbfgsx_ctx* c, int64_t first, int64_t count, int64_t no
         void* old[] = {b->s_brk, b->s_g, b->s_z, b->s_W, b->s_P, b->s_C, b->s_fpp, b->s_dfp, b->s_fp, b->s_ts, b->s_off};
         for (void* p : old)
             (void) hipFree(p);
-        const int64_t cap = std::max<int64_t>(count, b->s_cap);
-        const int ncap = std::max(NC, b->s_nc);
+        // sized once for the largest chunk the search asks for (2^20 crossings, or all n coordinates) and the full
+        // history: the chunk grows 2^16 -> 2^20 within a search and 2c grows over the first m iterations, and every
+        // regrowth would free and allocate eleven buffers in the middle of the iteration
+        const int64_t cap = std::max<int64_t>(std::max<int64_t>(count, b->s_cap), std::min<int64_t>(int64_t(1) << 20, c->n));
+        const int ncap = std::max(std::max(NC, b->s_nc), std::min(32, (2 * c->m + 3) / 4 * 4));
         const size_t tiles = size_t((cap + kGcpTile - 1) / kGcpTile);
         LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_brk), sizeof(double) * size_t(cap + 1)));
         LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_g), sizeof(double) * size_t(cap)));
