@@ -13,7 +13,7 @@
 // The recurrences are three dependent prefix sums:  A: p  ->  B: c and f''  ->  C: f'.  Each is a deterministic
 // reduce-then-scan over tiles of 256 crossings (fixed association order: the result does not depend on timing):
 //     k_gcp_a1          tile totals of g w
-//     k_gcp_tiles       exclusive scan of the tile totals (one block)
+//     k_gcp_tiles       exclusive scan of the tile totals (one wavefront per component, additions left to right)
 //     k_gcp_a3b1        p_{k-1} (stored), tile totals of [dt p_{k-1}, f'' increments]
 //     k_gcp_tiles
 //     k_gcp_b3c1        c_k and f''_k (stored), f' increments (stored), their tile totals
@@ -129,29 +129,49 @@ __global__ void __launch_bounds__(kGcpTile) k_gcp_a1(GcpBufs b, int64_t count, i
 }
 
 // off[t][j] = init[j] + sum_{t' < t} ts[t'][j]  (left to right);  fin[j] = the grand total including init
-__global__ void k_gcp_tiles(const double* __restrict__ ts, double* __restrict__ off, int ntiles, int ncomp,
-                            const double* __restrict__ init, double* __restrict__ fin)
+// One wavefront per component (grid = ncomp blocks of 64 lanes).  The additions stay strictly left to right -- that
+// chain is the only serial part -- while the loads and stores of 64 tiles are one coalesced access per lane: lane u's
+// value reaches the running sum through v_readlane, and the lane keeps the sum it met as its exclusive prefix.
+__global__ void __launch_bounds__(64)
+    k_gcp_tiles(const double* __restrict__ ts, double* __restrict__ off, int ntiles, int ncomp,
+                const double* __restrict__ init, double* __restrict__ fin)
 {
-    const int j = threadIdx.x;
-    if (j >= ncomp)
-        return;
-    double run = init[j];
-    constexpr int B = 16;  // independent loads in flight; the additions stay strictly left to right
-    for (int t0 = 0; t0 < ntiles; t0 += B)
+    const int j = blockIdx.x, lane = threadIdx.x;
+    double run = init[j];  // wave-uniform
+    auto bcast = [](double v, int src) {
+        const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+        const unsigned lo = unsigned(__builtin_amdgcn_readlane(int(unsigned(b)), src));
+        const unsigned hi = unsigned(__builtin_amdgcn_readlane(int(unsigned(b >> 32)), src));
+        return __builtin_bit_cast(double, (static_cast<unsigned long long>(hi) << 32) | lo);
+    };
+    for (int t0 = 0; t0 < ntiles; t0 += 64)
     {
-        double v[B];
+        const int t = t0 + lane;
+        const double v = (t < ntiles) ? ts[int64_t(t) * ncomp + j] : 0.0;
+        double ex = 0.0;
+        if (t0 + 64 <= ntiles)
+        {
 #pragma unroll
-        for (int u = 0; u < B; u++)
-            v[u] = (t0 + u < ntiles) ? ts[int64_t(t0 + u) * ncomp + j] : 0.0;
-#pragma unroll
-        for (int u = 0; u < B; u++)
-            if (t0 + u < ntiles)
+            for (int u = 0; u < 64; u++)
             {
-                off[int64_t(t0 + u) * ncomp + j] = run;
-                run = run + v[u];
+                ex = (lane == u) ? run : ex;
+                run = run + bcast(v, u);
             }
+        }
+        else
+        {
+            const int cnt = ntiles - t0;  // wave-uniform
+            for (int u = 0; u < cnt; u++)
+            {
+                ex = (lane == u) ? run : ex;
+                run = run + bcast(v, u);
+            }
+        }
+        if (t < ntiles)
+            off[int64_t(t) * ncomp + j] = ex;
     }
-    fin[j] = run;
+    if (lane == 0)
+        fin[j] = run;
 }
 
 // the f'' increment and dt p_{k-1} of one crossing (shared by a3b1 and b3c1 so that both evaluate the same

@@ -833,9 +833,9 @@ static int gcp_scan_nc(lbfgsx_ctx* c, const GcpBufs& gb, int64_t first, int64_t 
     double* out = fin + NC + 1;
     hipStream_t st = c->stream;
     hipLaunchKernelGGL((k_gcp_a1<NC>), dim3(ntiles), dim3(kGcpTile), 0, st, gb, count, nc, theta, b->s_ts);
-    hipLaunchKernelGGL(k_gcp_tiles, dim3(1), dim3(64), 0, st, b->s_ts, b->s_off, ntiles, NC, initA, fin);
+    hipLaunchKernelGGL(k_gcp_tiles, dim3(NC), dim3(64), 0, st, b->s_ts, b->s_off, ntiles, NC, initA, fin);
     hipLaunchKernelGGL((k_gcp_a3b1<NC>), dim3(ntiles), dim3(kGcpTile), 0, st, gb, count, nc, theta, t_prev, M, b->s_off, b->s_ts);
-    hipLaunchKernelGGL(k_gcp_tiles, dim3(1), dim3(64), 0, st, b->s_ts, b->s_off, ntiles, NC + 1, initB, fin);
+    hipLaunchKernelGGL(k_gcp_tiles, dim3(NC + 1), dim3(64), 0, st, b->s_ts, b->s_off, ntiles, NC + 1, initB, fin);
     hipLaunchKernelGGL((k_gcp_b3c1<NC>), dim3(ntiles), dim3(kGcpTile), 0, st, gb, count, nc, theta, t_prev, M, b->s_off, b->s_ts);
     hipLaunchKernelGGL(k_gcp_tiles, dim3(1), dim3(64), 0, st, b->s_ts, b->s_off, ntiles, 1, initC, fin);
     hipLaunchKernelGGL(k_gcp_c3, dim3(ntiles), dim3(kGcpTile), 0, st, gb, count, first, nord, b->s_off, b->s_exit);
