@@ -35,4 +35,5 @@ python bench.py --objective quadratic --n 10000000 --no-cpu > $O/bench_cfg2_quad
 python bench.py --workload cfg5-batched --steps 50 > $O/bench_cfg5_batched.json 2> /dev/null
 python scripts/bench_lbfgsb.py --n 1e7 --iters 40 --cpu-n 2e5 > $O/bench_cfg4_lbfgsb.json 2> /dev/null
 LBFGSX_GRAM=mfma python scripts/bench_lbfgsb.py --n 1e7 --iters 40 > $O/bench_cfg4_lbfgsb_mfma.json 2> /dev/null
+LBFGSX_GCP_DEVICE_MIN=4096 python scripts/bench_lbfgsb.py --n 1e7 --iters 40 > $O/bench_cfg4_lbfgsb_devmin4096.json 2> /dev/null
 find $O -type f | wc -l
