@@ -214,3 +214,77 @@ extern "C" int hl_gram_space(int n, int m, int K, const double* S, const double*
         slot_pair[j] = slot[size_t(j)];
     return ptr;
 }
+
+// The same drive with the rows split over ranks: n is this rank's block of rows, and every sum over rows passes
+// through `reduce` (an all-reduce) as ONE bundle per iteration -- the row-sharded mode of LBFGSSolver (set_reducer).
+extern "C" int hl_gram_space_sharded(int n, int m, int K, const double* S, const double* G, const unsigned char* accept,
+                                     double* coef, double* coef_g, int* slot_pair, void (*reduce)(double*, int))
+{
+    using LBFGSpp::GramSpaceHistory;
+    auto dot = [n](const double* a, const double* b) {
+        double t = 0;
+        for (int i = 0; i < n; i++)
+            t += a[i] * b[i];
+        return t;
+    };
+    GramSpaceHistory h;
+    h.reset(m);
+    {
+        double g2 = dot(G, G);
+        reduce(&g2, 1);
+        h.set_gradient_norm2(g2);
+    }
+    std::vector<std::vector<double> > Ys;
+    Ys.assign(size_t(K), std::vector<double>(size_t(n), 0.0));
+    std::vector<int> slot(size_t(m), -1);
+    int ptr = m, ncorr = 0;
+    std::vector<double> sd(size_t(2 * m)), gd(size_t(2 * m));
+    for (int k = 0; k < K; k++)
+    {
+        const double* s = S + size_t(k) * size_t(n);
+        const double* gn = G + size_t(k + 1) * size_t(n);
+        const double* go = G + size_t(k) * size_t(n);
+        std::vector<double>& y = Ys[size_t(k)];
+        for (int i = 0; i < n; i++)
+            y[size_t(i)] = gn[i] - go[i];
+        double scal[7] = {dot(gn, gn), 0.0, dot(s, y.data()), dot(y.data(), y.data()), dot(s, s), dot(gn, s), dot(gn, y.data())};
+        for (int j = 0; j < ncorr; j++)
+        {
+            const double* sj = S + size_t(slot[size_t(j)]) * size_t(n);
+            const double* yj = Ys[size_t(slot[size_t(j)])].data();
+            sd[size_t(j)] = dot(sj, s);
+            sd[size_t(m + j)] = dot(yj, s);
+            gd[size_t(j)] = dot(sj, gn);
+            gd[size_t(m + j)] = dot(yj, gn);
+        }
+        {
+            // the bundle LBFGSSolver::run hands to its reducer: 7 scalars, then the two rows of dots (include/LBFGS.h)
+            std::vector<double> bundle(size_t(7 + 4 * m));
+            std::copy(scal, scal + 7, bundle.begin());
+            std::copy(sd.begin(), sd.end(), bundle.begin() + 7);
+            std::copy(gd.begin(), gd.end(), bundle.begin() + 7 + 2 * m);
+            reduce(bundle.data(), int(bundle.size()));
+            std::copy(bundle.begin(), bundle.begin() + 7, scal);
+            std::copy(bundle.begin() + 7, bundle.begin() + 7 + 2 * m, sd.begin());
+            std::copy(bundle.begin() + 7 + 2 * m, bundle.end(), gd.begin());
+        }
+        h.update(scal, sd.data(), gd.data(), accept[k] != 0);
+        if (accept[k])
+        {
+            const int loc = ptr % m;
+            slot[size_t(loc)] = k;
+            if (ncorr < m)
+                ncorr++;
+            ptr = loc + 1;
+        }
+        if (h.ncorr() != ncorr)
+            return -1;
+    }
+    std::vector<double> cf;
+    h.direction(-1.0, cf, *coef_g);
+    for (int k = 0; k < 2 * m; k++)
+        coef[k] = cf[size_t(k)];
+    for (int j = 0; j < m; j++)
+        slot_pair[j] = slot[size_t(j)];
+    return ptr;
+}

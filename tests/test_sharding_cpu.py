@@ -1,4 +1,5 @@
-"""CPU suite, part 3: the N > 1 path (problem sharding + result gather) with world_size 2 over gloo."""
+"""CPU suite, part 3: the N > 1 paths with world_size 2 over gloo: problem sharding + result gather (batched mode) and
+the all-reduced bundle of the row-sharded Gram-space recursion."""
 import os
 import socket
 import subprocess
@@ -61,6 +62,79 @@ def test_shard_range_partitions_exactly():
 def test_two_rank_gather_over_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER % {"root": ROOT})
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   LOCAL_RANK=str(rank))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for rank, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert "RANK%d OK" % rank in o, o
+
+
+ROW_WORKER = r'''
+import ctypes as C, os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+hl = C.CDLL(%(lib)r)
+n, m, K = 602, 5, 9
+rng = np.random.default_rng(11)                       # every rank builds the same full problem ...
+a = 1.0 + 9.0 * rng.random(n)
+G = np.zeros((K + 1, n)); S = np.zeros((K, n))
+x = rng.standard_normal(n); G[0] = a * x
+for k in range(K):
+    S[k] = -0.3 * G[k] / a * (1 + 0.2 * rng.random(n)); x = x + S[k]; G[k + 1] = a * x
+accept = np.ones(K, dtype=np.uint8); accept[4] = 0
+per = (n // world) // 4 * 4                           # ... and keeps the row block bench.py --workload sharded gives it
+lo = rank * per; hi = n if rank == world - 1 else lo + per
+nred = [0]
+
+@C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_int)
+def reduce(ptr, k):
+    v = np.ctypeslib.as_array(ptr, shape=(k,))
+    dist.all_reduce(torch.from_numpy(v))              # in place on the callback's memory, as bench.py does over gloo
+    nred[0] += 1
+
+def run(fn, Sx, Gx, *extra):
+    coef = np.zeros(2 * m); cg = C.c_double(); slots = np.zeros(m, dtype=np.int32)
+    Sx = np.ascontiguousarray(Sx); Gx = np.ascontiguousarray(Gx)
+    fn.restype = C.c_int
+    ptr = fn(Sx.shape[1], m, K, Sx.ctypes.data_as(C.c_void_p), Gx.ctypes.data_as(C.c_void_p),
+             accept.ctypes.data_as(C.c_void_p), coef.ctypes.data_as(C.c_void_p), C.byref(cg),
+             slots.ctypes.data_as(C.c_void_p), *extra)
+    assert ptr >= 0
+    return np.concatenate([coef, [cg.value]]), slots
+
+full, slots_full = run(hl.hl_gram_space, S, G)
+mine, slots_mine = run(hl.hl_gram_space_sharded, S[:, lo:hi], G[:, lo:hi], reduce)
+ok = nred[0] == K + 1                                  # one bundle per iteration (+ the initial g.g)
+ok = ok and np.array_equal(slots_full, slots_mine)
+ok = ok and np.allclose(mine, full, rtol=1e-9, atol=1e-12)   # the sums only differ in their association
+both = [torch.zeros(2 * m + 1, dtype=torch.float64) for _ in range(world)]
+dist.all_gather(both, torch.from_numpy(mine))
+ok = ok and all(torch.equal(both[0], b) for b in both)       # every rank computes the same coefficients, bit for bit
+print("RANK%%d %%s" %% (rank, "OK" if ok else "BAD %%r %%r" %% (mine, full)))
+dist.destroy_process_group()
+'''
+
+
+def test_row_sharded_bundle_over_gloo(tmp_path):
+    """Row-sharded Gram-space recursion (SURVEY 8(f) rank 4): GramSpaceHistory driven as LBFGSSolver::run drives it,
+    each rank holding a block of rows and every sum over rows all-reduced as one bundle per iteration.  The
+    coefficients of the direction must equal the single-process ones to rounding and be identical on all ranks."""
+    lib = str(tmp_path / "libhostlogic.so")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-I",
+                           os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "host_logic_capi.cpp"),
+                           "-o", lib])
+    script = tmp_path / "row_worker.py"
+    script.write_text(ROW_WORKER % {"lib": lib})
     port = _free_port()
     procs = []
     for rank in range(2):
