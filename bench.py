@@ -361,7 +361,10 @@ def main():
                        "n": n, "m": m, "problems_per_gpu": 1,
                        "fevals_total": solver.last.nfev, "iterations_total": niter,
                        "apply_Hv_persistent_launches": int(persist_launches)},
-            "roofline": {"bound": "hbm", "kernel": "k_twoloop (two-loop recursion step: axpy + dot)",
+            "roofline": {"bound": "hbm",
+                         "kernel": ("k_twoloop_persist (one launch per apply_Hv = 2c+1 two-loop steps, axpy + dot each; "
+                                    "the figures below are per step = launch / (2c+1))") if persist_launches > 0 else
+                                   "k_twoloop (two-loop recursion step: axpy + dot)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (pmc_traffic(n, m) or {}).get("bytes_per_launch"),
                          "traffic_source": (pmc_traffic(n, m) or {}).get("source"),
