@@ -304,6 +304,13 @@ static int create_fill(lbfgsx_ctx* c, int dtype, int64_t n, int m, int device, i
         return rc;
     if (flags & LBFGSX_FLAG_BOUNDED)
     {
+        if (m > 40)
+        {
+            // the masked operators pass the 2c coefficients of a W product in the kernel arguments (80 slots) and the
+            // host side keeps 2c-vectors in fixed arrays of that size
+            set_error("lbfgsx_create: an L-BFGS-B context supports m <= 40 history pairs");
+            return LBFGSX_E_INVALID;
+        }
         LBFGSX_HIP(hipMalloc(&c->lb, vbytes));
         LBFGSX_HIP(hipMalloc(&c->ub, vbytes));
         LBFGSX_HIP(hipMalloc(&c->xcp, vbytes));

@@ -156,6 +156,28 @@ def test_lbfgsb_argument_errors(A):
         s.minimize(A.DiagQuadratic(np.ones(4), np.ones(4)), np.zeros(4), -np.ones(3), np.ones(4))
     with pytest.raises(ValueError, match="'max_submin' must be non-negative"):
         A.LBFGSBSolver(A.LBFGSBParam(max_submin=-1))
+    # the reference has no limit on m; this implementation's masked operators stop at 2m = 80 and say so
+    s = A.LBFGSBSolver(A.LBFGSBParam(m=41))
+    with pytest.raises(ValueError, match="m <= 40"):
+        s.minimize(A.DiagQuadratic(np.ones(8), np.ones(8)), np.zeros(8), -np.ones(8), np.ones(8))
+    s = A.LBFGSBSolver(A.LBFGSBParam(m=40, max_iterations=3))
+    s.minimize(A.DiagQuadratic(np.ones(8), np.ones(8)), np.zeros(8), -np.ones(8), np.ones(8))
+
+
+@pytest.mark.parametrize("m,iters", [(20, 30), (36, 45), (40, 50)])
+def test_lbfgsb_long_histories_match_oracle(A, boracle, m, iters):
+    """2c beyond the single-launch widths (multi-dot chunks of 8 columns, blocked Gram, host Cauchy search) up to the
+    limit 2m = 80 of the masked operators: same iteration / evaluation counts and iterates as the reference."""
+    n = 3000
+    a, b = O.quad_problem(n, 200.0, 3, O.F64)
+    lb, ub = -0.4 * np.ones(n), 0.6 * np.ones(n)
+    p = O.lbfgsb_params(m=m, max_iterations=iters, epsilon=0, epsilon_rel=0, past=0)
+    x_ref, r_ref = boracle.lbfgsb(O.F64, O.OBJ_QUAD, np.zeros(n), lb, ub, p, a=a, b=b)
+    s = A.LBFGSBSolver(A.LBFGSBParam(m=m, max_iterations=iters, epsilon=0, epsilon_rel=0, past=0))
+    x = np.zeros(n)
+    niter, fx = s.minimize(A.DiagQuadratic(a, b), x, lb, ub)
+    assert niter == r_ref.niter == iters and s.last.nfev == r_ref.nfev
+    assert np.abs(x - x_ref).max() <= 1e-10
 
 
 def test_lbfgsb_start_outside_bounds_is_projected(A, boracle):
