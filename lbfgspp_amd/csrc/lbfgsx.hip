@@ -311,6 +311,12 @@ static int create_fill(lbfgsx_ctx* c, int dtype, int64_t n, int m, int device, i
             set_error("lbfgsx_create: an L-BFGS-B context supports m <= 40 history pairs");
             return LBFGSX_E_INVALID;
         }
+        if (n > int64_t(2147483647))
+        {
+            // the sorted break-point list carries 32-bit coordinate indices (Cauchy.h keeps std::vector<int> as well)
+            set_error("lbfgsx_create: an L-BFGS-B context supports n < 2^31 coordinates");
+            return LBFGSX_E_INVALID;
+        }
         LBFGSX_HIP(hipMalloc(&c->lb, vbytes));
         LBFGSX_HIP(hipMalloc(&c->ub, vbytes));
         LBFGSX_HIP(hipMalloc(&c->xcp, vbytes));

@@ -162,6 +162,10 @@ def test_lbfgsb_argument_errors(A):
         s.minimize(A.DiagQuadratic(np.ones(8), np.ones(8)), np.zeros(8), -np.ones(8), np.ones(8))
     s = A.LBFGSBSolver(A.LBFGSBParam(m=40, max_iterations=3))
     s.minimize(A.DiagQuadratic(np.ones(8), np.ones(8)), np.zeros(8), -np.ones(8), np.ones(8))
+    # ... and the break-point list carries 32-bit indices, as the reference's index sets do
+    s = A.LBFGSBSolver(A.LBFGSBParam(m=2), dtype=np.float32)
+    with pytest.raises(ValueError, match="n < 2\\^31"):
+        s.prepare(2 ** 31)
 
 
 @pytest.mark.parametrize("m,iters", [(20, 30), (36, 45), (40, 50)])
