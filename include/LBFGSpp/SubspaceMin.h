@@ -9,6 +9,8 @@
 //   W_set' v      -> lbfgsx_b_wtv      (2c order-independent dot products)
 //   W_P' W_P      -> lbfgsx_b_gram     (masked Gram, 4x4 register tiles)
 //   W_set * coef  -> lbfgsx_b_wcombine (row-wise, with the reference's element-wise epilogue fused in)
+//   the element-wise statements between two BOXCQP solves (:170-172 | :271, :194-219, :232)
+//                 -> lbfgsx_b_sub_sweep_begin (one pass; lbfgsx_b_sub_partition / _sub_check / _sub_op one by one)
 // The 2c x 2c algebra (M, mid, their LDL' solves) is host scalar work in BFGSMatB.
 #ifndef LBFGSX_DROPIN_SUBSPACE_MIN_H
 #define LBFGSX_DROPIN_SUBSPACE_MIN_H
