@@ -8,7 +8,11 @@ pass, history commit and the 2m+1-launch two-loop recursion) on the north-star w
 Rosenbrock, n = 1e8, m = 10, f64, LineSearchMoreThuente, inputs generated in HBM from a counter hash
 (no host copy of any n-vector).  For N > 1 every rank solves its own independent problem of that size on
 its own GPU (the path shards by independent minimisations; no data-path collective) and the aggregate
-iterations/s is reported ("scaling": "weak"); RCCL is used only for the barriers / final gather.
+iterations/s is reported ("scaling": "weak"); RCCL is used only for the barriers / final gather.  Launched under
+torchrun the ranks come from the environment; launched plainly with --gpus N > 1 the script starts its N ranks itself
+(one process per GPU) and fails if the box has fewer than N devices -- it never reports fewer GPUs than it was asked for.
+The timed window always starts with the history full (c = m), whatever --warmup says.  The default workload's line also
+carries the batched mode of BASELINE.json's cfg5 (the mode that shards problem ids over the GPUs) as "cfg5_batched".
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -26,19 +30,16 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (about 6.3 TB/s achiev
 
 
 def pmc_traffic(n, m):
-    """HBM bytes per two-loop step from the committed rocprofv3 PMC passes (profiles/*_pmc_summary.json,
-    produced by scripts/profile.sh + scripts/summarize_profile.py on this same command); None if the
-    committed profile is for another problem size."""
+    """HBM bytes per two-loop step from a committed rocprofv3 PMC summary (profiles/*_pmc_summary.json, produced by
+    scripts/profile.sh + scripts/summarize_profile.py on this same command) -- used only when that profile was taken
+    at exactly this (n, m); PMC counters cannot be collected from inside the timed process."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
         try:
             d = json.load(open(f))
             t = d.get("twoloop_avg_hbm_bytes_per_launch")
-            # the profile was taken at n=1e8, m=10: (8m+2) n 8 bytes over 2m+1 launches
-            expect = (8 * m + 2) * n * 8 / float(2 * m + 1)
-            # the persistent kernel keeps part of q on the CUs, so its measured traffic sits below the algorithmic figure
-            if t and -0.25 < (t - expect) / expect < 0.05:
+            if t and int(d.get("n", 0)) == int(n) and int(d.get("m", 0)) == int(m):
                 best = {"bytes_per_launch": t, "source": os.path.relpath(f, ROOT)}
         except Exception:
             pass
@@ -69,6 +70,7 @@ def cpu_baseline(args):
     its = (r2.niter - r1.niter) / dt
     scale = n / float(args.n)
     return {"value": its * scale, "unit": "iterations/s", "cores": 1, "kind": kind,
+            "extrapolated": True, "measured_value": its, "measured_n": n,
             "sample": "same workload at n=%d (%.3g of n), %d timed iterations after %d warm-up, %.1f s of CPU; "
                       "measured %.4g it/s scaled linearly by n ratio; host has %d cores"
                       % (n, scale, r2.niter - r1.niter, r1.niter, t2 - t0, its, os.cpu_count())}
@@ -113,21 +115,56 @@ def cpu_baseline_all_cores(args):
     its = (r2.niter - r1.niter) / dt
     scale = n / float(args.n)
     return {"value": its * scale, "unit": "iterations/s", "cores": cores, "kind": "port",
+            "extrapolated": True, "measured_value": its, "measured_n": n,
             "sample": "restatement under OpenMP (every core of the CPU quota, native accumulators) at n=%d "
                       "(%.3g of n), %d timed iterations after %d warm-up, %.1f s of CPU wall; measured %.4g it/s scaled "
                       "linearly by n ratio" % (n, scale, r2.niter - r1.niter, r1.niter, t2 - t0, its)}
 
 
-def init_dist():
-    """One process per GPU (torchrun env).  Backend nccl (= RCCL over xGMI); LBFGSX_BENCH_BACKEND=gloo and
-    LBFGSX_BENCH_FORCE_DEVICE=k exist only to exercise the N > 1 code path on a single-GPU box."""
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one process per GPU, with the
+    environment torchrun would give them.  Rank 0's stdout is the parent's (the one JSON line)."""
+    import socket
+    import subprocess
+    import lbfgspp_amd as A
+    core, _ = A.load()
+    ndev = core.lbfgsx_device_count()
+    forced = os.environ.get("LBFGSX_BENCH_FORCE_DEVICE")
+    if ndev < args.gpus and forced is None:
+        raise SystemExit("bench.py --gpus %d: this box has %d GPU(s); refusing to report fewer GPUs than asked for "
+                         "(LBFGSX_BENCH_FORCE_DEVICE=k shares device k between the ranks, protocol test only)"
+                         % (args.gpus, ndev))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if forced is not None:
+            env.setdefault("LBFGSX_PERSIST", "0")  # ranks sharing one device cannot each own all of its CUs
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    raise SystemExit(rc)
+
+
+def init_dist(args):
+    """One process per GPU (torchrun env, or spawn_ranks).  Backend nccl (= RCCL over xGMI); LBFGSX_BENCH_FORCE_DEVICE=k
+    (with gloo) exists only to exercise the N > 1 code path on a single-GPU box."""
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dev = int(os.environ.get("LBFGSX_BENCH_FORCE_DEVICE", local))
-    backend = os.environ.get("LBFGSX_BENCH_BACKEND", "nccl")
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    forced = os.environ.get("LBFGSX_BENCH_FORCE_DEVICE")
+    dev = int(forced) if forced is not None else local
+    backend = os.environ.get("LBFGSX_BENCH_BACKEND", "gloo" if forced is not None else "nccl")
     comm_dev = torch.device("cpu")
     if world > 1:
         if backend == "nccl":
@@ -139,33 +176,32 @@ def init_dist():
     return rank, world, dev, comm_dev, dist
 
 
-def main_batched(args):
+def run_batched(args, rank, world, local, comm_dev, dist, steps):
     """BASELINE.json cfg5: independent extended-Rosenbrock problems n=1e5, m=10, f32, LineSearchMoreThuente, fixed
     budget of `steps` iterations per problem; every rank solves its own contiguous shard of problem ids in the
-    lock-step batch (no data-path collective) and the per-problem records are all-gathered at the end."""
+    lock-step batch (no data-path collective) and the per-problem records are all-gathered at the end.
+    Returns the result object on rank 0 (None elsewhere)."""
     import numpy as np
     import torch
-    import torch.distributed as dist
 
     import lbfgspp_amd as A
     from lbfgspp_amd import batched as B
-    rank, world, local, comm_dev, dist = init_dist()
     n, m, P = 100000, 10, args.problems_per_gpu
     total = P * world
     first, count = B.shard_range(total, rank, world)
-    par = A.LBFGSParam(m=m, epsilon=0.0, epsilon_rel=0.0, max_iterations=args.steps)
+    par = A.LBFGSParam(m=m, epsilon=0.0, epsilon_rel=0.0, max_iterations=steps)
     for _ in range(max(1, min(args.warmup, 2))):  # warm-up: allocator, code objects
         B.solve_local_lockstep(par, n, first, min(count, 64), dtype=np.float32, device=local)
-    if world > 1:
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+    barrier()
     t0 = time.perf_counter()
     recs = B.solve_local_lockstep(par, n, first, count, seed_base=1000, dtype=np.float32, device=local)
-    if world > 1:
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
+    barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
@@ -173,64 +209,39 @@ def main_batched(args):
         elapsed = float(t.item())
     full = B.gather_records(recs, total, rank, world, dist=dist if world > 1 else None,
                             device=comm_dev if world > 1 else None)
-    if rank == 0:
-        its, fev = int(full["niter"].sum()), int(full["nfev"].sum())
-        bytes_ = (its * (8 * m + 12) + (fev - its) * 4) * n * 4.0
-        # HBM traffic model of the one-launch recursion (q resident on the CU): per apply_Hv 2m history reads twice
-        # (update + dot operand) less the shared column of the division step, + g twice, + one store of d
-        hbm_ = (its * (4 * m + 2 + 12) + (fev - its) * 4) * n * 4.0
-        print(json.dumps({
-            "metric": "batched L-BFGS problem-iterations/sec (cfg5: n=1e5, m=10, f32)", "value": its / elapsed,
-            "unit": "problem-iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "cfg5: %d independent extended-Rosenbrock problems per GPU, n=1e5, m=10, f32, "
-                                   "LineSearchMoreThuente, %d iterations each, lock-step batch" % (P, args.steps),
-                       "problems_total": total, "fevals_total": fev, "failed": int((full["status"] != 0).sum())},
-            "roofline": {"bound": "hbm", "achieved": bytes_ / elapsed / 1e9 / world, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": bytes_ / elapsed / 1e9 / world / HBM_PEAK_GBS, "traffic": None,
-                         "hbm_model_GBs": hbm_ / elapsed / 1e9 / world, "hbm_model_frac": hbm_ / elapsed / 1e9 / world / HBM_PEAK_GBS,
-                         "note": "achieved = SURVEY 8(d) algorithmic bytes ((8m+12) n per iteration) per GPU / wall time, host "
-                                 "control flow included; the one-launch two-loop keeps q on the CU, so the HBM traffic model "
-                                 "is (4m+14) n per iteration (hbm_model_*): achieved may exceed the HBM peak"}}))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    if rank != 0:
+        return None
+    its, fev = int(full["niter"].sum()), int(full["nfev"].sum())
+    # SURVEY 8(d) algorithmic bytes: (8m+12) n per iteration + 4n per extra trial
+    alg_ = (its * (8 * m + 12) + (fev - its) * 4) * n * 4.0
+    # HBM traffic model of the one-launch recursion (q resident on the CU): per apply_Hv 2m history reads twice
+    # (update + dot operand) less the shared column of the division step, + g twice, + one store of d
+    hbm_ = (its * (4 * m + 2 + 12) + (fev - its) * 4) * n * 4.0
+    model_gbs = hbm_ / elapsed / 1e9 / world
+    return {
+        "metric": "batched L-BFGS problem-iterations/sec (cfg5: n=1e5, m=10, f32)", "value": its / elapsed,
+        "unit": "problem-iterations/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / max(steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "cfg5: %d independent extended-Rosenbrock problems per GPU, n=1e5, m=10, f32, "
+                               "LineSearchMoreThuente, %d iterations each, lock-step batch; contiguous problem-id blocks "
+                               "per rank, no data-path collective, one all-gather of the result records" % (P, steps),
+                   "problems_total": total, "fevals_total": fev, "failed": int((full["status"] != 0).sum())},
+        "roofline": {"bound": "hbm", "achieved": model_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": model_gbs / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_GBs": alg_ / elapsed / 1e9 / world,
+                     "note": "end to end per GPU, host control flow included. achieved = HBM traffic model of the "
+                             "one-launch two-loop ((4m+14) n elements per iteration: q stays on the CU) / wall time; "
+                             "algorithmic_GBs = SURVEY 8(d)'s (8m+12) n per iteration / wall time, which counts the q "
+                             "traffic that never reaches HBM and may therefore exceed the peak"}}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=12)
-    ap.add_argument("--n", type=float, default=1e8)
-    ap.add_argument("--m", type=int, default=10)
-    ap.add_argument("--objective", default="rosenbrock", choices=["rosenbrock", "quadratic"])
-    ap.add_argument("--cpu-n", type=float, default=2e7)
-    ap.add_argument("--cpu-steps", type=int, default=12)
-    ap.add_argument("--cpu-n-all", type=float, default=2e7, help="problem size of the all-cores CPU baseline")
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--workload", default="north-star", choices=["north-star", "cfg5-batched", "sharded"],
-                    help="north-star (default, the BASELINE.json metric: one problem per GPU), the batched cfg5 shard per "
-                         "GPU, or sharded: ONE problem of --n rows row-sharded over the ranks (strong scaling; opt-in "
-                         "Gram-space recursion, all-reduces of <= 6m+7 doubles over RCCL)")
-    ap.add_argument("--problems-per-gpu", type=int, default=1024)
-    ap.add_argument("--recursion", default="vector", choices=["vector", "gram", "gram-f32h"],
-                    help="vector (default): the reference's two-loop recursion statement by statement, the bit-parity "
-                         "path the BASELINE metric is quoted on; gram: opt-in Gram-space form (SURVEY 8(f)-3), equal to "
-                         "the vector form only up to rounding; gram-f32h: the same with S, Y stored as float (SURVEY "
-                         "8(f)-4) -- both reported under their own metric names")
-    args = ap.parse_args()
-    if args.workload == "cfg5-batched":
-        return main_batched(args)
-
+def run_north_star(args, rank, world, local, comm_dev, dist):
     import torch  # noqa: F401  (first: its bundled HIP runtime must be the process-wide one)
-    import torch.distributed as dist
 
     import lbfgspp_amd as A
     from lbfgspp_amd import _lib as L
 
-    rank, world, local, comm_dev, dist = init_dist()
     core, _ = A.load()
     if core.lbfgsx_device_count() < 1:
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
@@ -238,7 +249,11 @@ def main():
     sharded = args.workload == "sharded"
     if sharded and args.recursion == "vector":
         args.recursion = "gram"  # the only form whose reductions can cross devices
-    n, m, K, W = int(args.n), args.m, args.steps, max(args.warmup, 0)
+    n, m, K = int(args.n), args.m, args.steps
+    # the timed window starts with the history full (c = m).  Iteration k's apply_Hv sees min(k, m) pairs,
+    # so at least m untimed iterations come first whatever --warmup says; "warmup" in the line is what was asked for,
+    # "warmup_run" what ran.
+    W = max(args.warmup, m)
     n_global, shard_lo = n, 0
     if sharded:
         # contiguous row blocks, boundaries on multiples of 4 (whole Rosenbrock pairs, whole 16-byte vectors)
@@ -290,10 +305,10 @@ def main():
 
     def hook(k):
         if k == W:
+            marks["ncorr0"] = core.lbfgsx_bfgs_ncorr(ctx)
             barrier()
             L.check(core.lbfgsx_timing_enable(ctx, 2 if os.environ.get("LBFGSX_PERSIST") == "0" else 1))
             marks["t0"] = time.perf_counter()
-            marks["nfev0"] = None
         elif k == W + K:
             barrier()
             marks["t1"] = time.perf_counter()
@@ -302,8 +317,6 @@ def main():
             marks["tl"] = (tl_ms.value, tl_n.value, hv_ms.value, hv_n.value)
             L.check(core.lbfgsx_timing_enable(ctx, 0))
 
-    if W == 0:
-        hook(0)
     solver.set_iteration_hook(hook)
     niter, fx = solver.minimize_resident(f, n)
     if "t1" not in marks:
@@ -319,78 +332,153 @@ def main():
     core.lbfgsx_persistent_launches.restype = C.c_int64
     core.lbfgsx_persistent_launches.argtypes = [C.c_void_p]
     persist_launches = core.lbfgsx_persistent_launches(ctx)
+    core.lbfgsx_persistent_resident_elems.restype = C.c_int64
+    core.lbfgsx_persistent_resident_elems.argtypes = [C.c_void_p]
+    resident = core.lbfgsx_persistent_resident_elems(ctx) if persist_launches > 0 else 0
+    nfev, last_niter = solver.last.nfev, niter
+    del solver  # release the device context (the batched leg and the profilers' atexit handlers come next)
+    import gc
+    gc.collect()
+    if rank != 0:
+        return None
 
-    if rank == 0:
-        tl_ms, tl_n, hv_ms, hv_n = marks["tl"]
-        esz = 8
-        hv_bytes = (8 * m + 1) * n * esz  # algorithmic bytes per apply_Hv call, history full
-        per_launch_bytes = hv_bytes / float(2 * m + 1)
-        avg_launch_s = (tl_ms / max(tl_n, 1)) * 1e-3
-        achieved = per_launch_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        if gram:
-            # tl_* = k_gs_post launches ((2m+6) n elements), hv_* = k_gs_combine launches ((2m+2) n elements)
-            post_bytes, comb_bytes = (2 * m + 6) * n * esz, (2 * m + 2) * n * esz
-            if f32h:  # the 2m history columns (and the two written ones) are 4-byte elements
-                post_bytes, comb_bytes = (2 * m * 4 + 4 * esz + 2 * 4) * n, (2 * m * 4 + 2 * esz) * n
-            post_s, comb_s = tl_ms / max(tl_n, 1) * 1e-3, hv_ms / max(hv_n, 1) * 1e-3
-            achieved = post_bytes / post_s / 1e9 if post_s > 0 else 0.0
-        out = {
-            # BASELINE.json's metric string for the north-star configuration; other sizes say what they are
-            "metric": ("L-BFGS iterations/sec of ONE problem n=%d row-sharded over %d GPU(s), m=%d (%s), Gram-space recursion%s "
-                       "(opt-in, not the bit-parity path); achieved HBM GB/s per GPU vs peak"
-                       % (n_global, world, m, args.objective, " with f32 history" if f32h else "")) if sharded else
-                      ("L-BFGS iterations/sec at n=%d, m=%d (%s), Gram-space recursion%s (opt-in, not the bit-parity path); "
-                       "achieved HBM GB/s vs peak" % (n, m, args.objective, " with f32 history" if f32h else "")) if gram else
-                      ("L-BFGS iterations/sec at n=10^8, m=10; achieved HBM GB/s vs peak"
-                       if (n == 100000000 and m == 10 and args.objective == "rosenbrock") else
-                       "L-BFGS iterations/sec at n=%d, m=%d (%s); achieved HBM GB/s vs peak" % (n, m, args.objective)),
-            "value": (1 if sharded else world) * K / elapsed,
-            "unit": "iterations/s",
-            "n_gpus": world,
-            "steps": K,
-            "warmup": W,
-            "ms_per_step": elapsed / K * 1e3,
-            "higher_is_better": True,
-            "scaling": "strong" if sharded else "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": "north-star: extended Rosenbrock n=%d m=%d f64 LineSearchMoreThuente, x0 from counter hash"
-                                   % (n, m) if args.objective == "rosenbrock" else
-                                   "diag quadratic kappa=10 n=%d m=%d f64 LineSearchNocedalWright" % (n, m),
-                       "n": n, "m": m, "problems_per_gpu": 1,
-                       "fevals_total": solver.last.nfev, "iterations_total": niter,
-                       "apply_Hv_persistent_launches": int(persist_launches)},
-            "roofline": {"bound": "hbm",
-                         "kernel": ("k_twoloop_persist (one launch per apply_Hv = 2c+1 two-loop steps, axpy + dot each; "
-                                    "the figures below are per step = launch / (2c+1))") if persist_launches > 0 else
-                                   "k_twoloop (two-loop recursion step: axpy + dot)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (pmc_traffic(n, m) or {}).get("bytes_per_launch"),
-                         "traffic_source": (pmc_traffic(n, m) or {}).get("source"),
-                         "algorithmic_bytes_per_launch": per_launch_bytes,
-                         "avg_launch_ms": avg_launch_s * 1e3, "launches_timed": tl_n,
-                         "apply_Hv_ms": hv_ms / max(hv_n, 1), "apply_Hv_GBs": hv_bytes / (hv_ms / max(hv_n, 1) * 1e-3) / 1e9,
-                         "stream_copy_GBs": copy_gbs.value, "stream_triad_GBs": triad_gbs.value,
-                         "frac_of_stream_copy": achieved / copy_gbs.value if copy_gbs.value else None},
-        }
-        if gram:
-            out["config"]["recursion"] = "gram-space, f32 history" if f32h else "gram-space"
-            if sharded:
-                out["config"]["workload"] = ("one extended-Rosenbrock problem of n=%d rows, contiguous row blocks of %d over %d "
-                                             "rank(s); %d all-reduces of <= %d doubles in the run"
-                                             % (n_global, n, world, n_reduces[0], 6 * m + 7))
-                out["config"]["n"] = n_global
-                out["config"]["rows_per_gpu"] = n
-            out["roofline"] = {"bound": "hbm", "kernel": ("k_gs_post_mx" if f32h else "k_gs_post") + " (s, y + Gram rows of the new pair and gradient, one pass)",
-                               "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                               "traffic": None, "algorithmic_bytes_per_launch": post_bytes, "avg_launch_ms": post_s * 1e3,
-                               "launches_timed": tl_n,
-                               "combine": {"kernel": "k_gs_combine_mx" if f32h else "k_gs_combine", "algorithmic_bytes_per_launch": comb_bytes,
-                                           "avg_launch_ms": comb_s * 1e3,
-                                           "achieved": comb_bytes / comb_s / 1e9 if comb_s > 0 else 0.0},
-                               "stream_copy_GBs": copy_gbs.value, "stream_triad_GBs": triad_gbs.value}
-        if not args.no_cpu and world == 1:  # the CPU baseline is timed on rank 0 of the single-GPU run only
+    tl_ms, tl_n, hv_ms, hv_n = marks["tl"]
+    esz = 8
+    hv_bytes = (8 * m + 1) * n * esz  # algorithmic bytes per apply_Hv call, history full
+    per_launch_bytes = hv_bytes / float(2 * m + 1)
+    avg_launch_s = (tl_ms / max(tl_n, 1)) * 1e-3
+    alg_gbs = per_launch_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+    history_full = (marks["ncorr0"] == m) and (gram or tl_n == K * (2 * m + 1))
+    # HBM-traffic model of the step: the persistent launch keeps `resident` elements of q on the CUs, and that share
+    # of q's 4m reads / writes per apply_Hv never reaches HBM.  For n <= resident (cfg2) the algorithmic figure would
+    # exceed the HBM peak, so `achieved` / `frac` quote the model and the algorithmic figure rides along.
+    model_bytes = per_launch_bytes - (4 * m) * min(resident, n) * esz / float(2 * m + 1)
+    model_gbs = model_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+    use_model = alg_gbs > HBM_PEAK_GBS
+    achieved = model_gbs if use_model else alg_gbs
+    if gram:
+        # tl_* = k_gs_post launches ((2m+6) n elements), hv_* = k_gs_combine launches ((2m+2) n elements)
+        post_bytes, comb_bytes = (2 * m + 6) * n * esz, (2 * m + 2) * n * esz
+        if f32h:  # the 2m history columns (and the two written ones) are 4-byte elements
+            post_bytes, comb_bytes = (2 * m * 4 + 4 * esz + 2 * 4) * n, (2 * m * 4 + 2 * esz) * n
+        post_s, comb_s = tl_ms / max(tl_n, 1) * 1e-3, hv_ms / max(hv_n, 1) * 1e-3
+        achieved = post_bytes / post_s / 1e9 if post_s > 0 else 0.0
+    pmc = pmc_traffic(n, m) if persist_launches > 0 and not gram else None
+    out = {
+        # BASELINE.json's metric string for the north-star configuration; other sizes say what they are
+        "metric": ("L-BFGS iterations/sec of ONE problem n=%d row-sharded over %d GPU(s), m=%d (%s), Gram-space recursion%s "
+                   "(opt-in, not the bit-parity path); achieved HBM GB/s per GPU vs peak"
+                   % (n_global, world, m, args.objective, " with f32 history" if f32h else "")) if sharded else
+                  ("L-BFGS iterations/sec at n=%d, m=%d (%s), Gram-space recursion%s (opt-in, not the bit-parity path); "
+                   "achieved HBM GB/s vs peak" % (n, m, args.objective, " with f32 history" if f32h else "")) if gram else
+                  ("L-BFGS iterations/sec at n=10^8, m=10; achieved HBM GB/s vs peak"
+                   if (n == 100000000 and m == 10 and args.objective == "rosenbrock") else
+                   "L-BFGS iterations/sec at n=%d, m=%d (%s); achieved HBM GB/s vs peak" % (n, m, args.objective)),
+        "value": (1 if sharded else world) * K / elapsed,
+        "unit": "iterations/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / K * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong" if sharded else "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "north-star: extended Rosenbrock n=%d m=%d f64 LineSearchMoreThuente, x0 from counter hash"
+                               % (n, m) if args.objective == "rosenbrock" else
+                               "diag quadratic kappa=10 n=%d m=%d f64 LineSearchNocedalWright" % (n, m),
+                   "n": n, "m": m, "problems_per_gpu": 1, "warmup_run": W, "history_full": bool(history_full),
+                   "fevals_total": nfev, "iterations_total": last_niter,
+                   "apply_Hv_persistent_launches": int(persist_launches)},
+        "roofline": {"bound": "hbm",
+                     "kernel": ("k_twoloop_persist (one launch per apply_Hv = 2c+1 two-loop steps, axpy + dot each; "
+                                "the figures below are per step = launch / (2c+1))") if persist_launches > 0 else
+                               "k_twoloop (two-loop recursion step: axpy + dot)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "achieved_is": ("hbm traffic model (q resident on the CUs is not counted); the algorithmic figure "
+                                     "exceeds the HBM peak at this size" if use_model else "algorithmic bytes / time"),
+                     "algorithmic_GBs": alg_gbs, "hbm_model_GBs": model_gbs,
+                     "traffic": pmc["bytes_per_launch"] if pmc else None,
+                     "traffic_static": True if pmc else None,
+                     "traffic_source": (pmc["source"] + " (rocprofv3 PMC passes of this command at this n, m, taken "
+                                                        "separately: counters cannot be read inside the timed run)") if pmc else None,
+                     "algorithmic_bytes_per_launch": per_launch_bytes, "hbm_model_bytes_per_launch": model_bytes,
+                     "q_resident_elems": int(min(resident, n)),
+                     "avg_launch_ms": avg_launch_s * 1e3, "launches_timed": tl_n,
+                     "apply_Hv_ms": hv_ms / max(hv_n, 1),
+                     # bytes of the steps that actually ran in the window / their time
+                     "apply_Hv_GBs": (per_launch_bytes * tl_n / (hv_ms * 1e-3) / 1e9) if hv_ms > 0 else None,
+                     "stream_copy_GBs": copy_gbs.value, "stream_triad_GBs": triad_gbs.value,
+                     "frac_of_stream_copy": achieved / copy_gbs.value if copy_gbs.value else None},
+    }
+    if gram:
+        out["config"]["recursion"] = "gram-space, f32 history" if f32h else "gram-space"
+        if sharded:
+            out["config"]["workload"] = ("one extended-Rosenbrock problem of n=%d rows, contiguous row blocks of %d over %d "
+                                         "rank(s); %d all-reduces of <= %d doubles in the run"
+                                         % (n_global, n, world, n_reduces[0], 6 * m + 7))
+            out["config"]["n"] = n_global
+            out["config"]["rows_per_gpu"] = n
+        out["roofline"] = {"bound": "hbm", "kernel": ("k_gs_post_mx" if f32h else "k_gs_post") + " (s, y + Gram rows of the new pair and gradient, one pass)",
+                           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                           "traffic": None, "algorithmic_bytes_per_launch": post_bytes, "avg_launch_ms": post_s * 1e3,
+                           "launches_timed": tl_n,
+                           "combine": {"kernel": "k_gs_combine_mx" if f32h else "k_gs_combine", "algorithmic_bytes_per_launch": comb_bytes,
+                                       "avg_launch_ms": comb_s * 1e3,
+                                       "achieved": comb_bytes / comb_s / 1e9 if comb_s > 0 else 0.0},
+                           "stream_copy_GBs": copy_gbs.value, "stream_triad_GBs": triad_gbs.value}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="GPUs of this node (default: the launcher's WORLD_SIZE, else 1); N > 1 without a launcher starts N ranks")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=12)
+    ap.add_argument("--n", type=float, default=1e8)
+    ap.add_argument("--m", type=int, default=10)
+    ap.add_argument("--objective", default="rosenbrock", choices=["rosenbrock", "quadratic"])
+    ap.add_argument("--cpu-n", type=float, default=2e7)
+    ap.add_argument("--cpu-steps", type=int, default=12)
+    ap.add_argument("--cpu-n-all", type=float, default=2e7, help="problem size of the all-cores CPU baseline")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--workload", default="north-star", choices=["north-star", "cfg5-batched", "sharded"],
+                    help="north-star (default, the BASELINE.json metric: one problem per GPU; its line also carries the "
+                         "cfg5 batch as `cfg5_batched`), the batched cfg5 shard per GPU alone, or sharded: ONE problem of "
+                         "--n rows row-sharded over the ranks (strong scaling; opt-in Gram-space recursion, all-reduces "
+                         "of <= 6m+7 doubles over RCCL)")
+    ap.add_argument("--problems-per-gpu", type=int, default=1024)
+    ap.add_argument("--batched-steps", type=int, default=50, help="iterations per problem of the cfg5 leg of the default line")
+    ap.add_argument("--no-batched", action="store_true", help="skip the cfg5 leg of the default line")
+    ap.add_argument("--recursion", default="vector", choices=["vector", "gram", "gram-f32h"],
+                    help="vector (default): the reference's two-loop recursion statement by statement, the bit-parity "
+                         "path the BASELINE metric is quoted on; gram: opt-in Gram-space form (SURVEY 8(f)-3), equal to "
+                         "the vector form only up to rounding; gram-f32h: the same with S, Y stored as float (SURVEY "
+                         "8(f)-4) -- both reported under their own metric names")
+    args = ap.parse_args()
+    launched = "WORLD_SIZE" in os.environ
+    if args.gpus is None:
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and not launched:
+        spawn_ranks(args)  # does not return
+
+    import torch  # noqa: F401  (first: its bundled HIP runtime must be the process-wide one)
+    rank, world, local, comm_dev, dist = init_dist(args)
+    if args.workload == "cfg5-batched":
+        out = run_batched(args, rank, world, local, comm_dev, dist, args.steps)
+    else:
+        out = run_north_star(args, rank, world, local, comm_dev, dist)
+        if args.workload == "north-star" and args.recursion == "vector" and not args.no_batched:
+            # the mode that shards naturally: same ranks, same barriers, reported inside the one line
+            b = run_batched(args, rank, world, local, comm_dev, dist, args.batched_steps)
+            if rank == 0:
+                out["cfg5_batched"] = {k: b[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step",
+                                                          "scaling", "dtype", "config", "roofline")}
+        if rank == 0 and not args.no_cpu and world == 1:  # the CPU baseline is timed on rank 0 of the single-GPU run only
             try:
                 out["cpu_baseline"] = cpu_baseline(args)
             except Exception as e:  # the baseline is reported, never required
@@ -399,11 +487,8 @@ def main():
                 out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args)
             except Exception as e:
                 out["cpu_baseline_all_cores"] = {"error": repr(e)}
-        print(json.dumps(out))
-    # release the device context before interpreter shutdown (profilers finalise in atexit handlers)
-    del solver
-    import gc
-    gc.collect()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -334,6 +334,9 @@ int lbfgsx_timing_read(lbfgsx_ctx* c, double* twoloop_ms_total, int64_t* twoloop
  * m <= 32, LBFGSX_PERSIST != 0 and this context is the only live one of the
  * process on its device; otherwise apply_Hv issues its 2c+1 step launches.  Results are bit-identical. */
 int64_t lbfgsx_persistent_launches(const lbfgsx_ctx* c);
+/* elements of q (= the direction vector, BFGSMat.h:283-301 `res`) that a persistent launch of this context keeps in the
+ * registers / LDS of the CUs for the whole recursion: that share of q's traffic never reaches HBM (0: not available) */
+int64_t lbfgsx_persistent_resident_elems(const lbfgsx_ctx* c);
 /* STREAM-style device bandwidth probe on this context's vectors: copy (XT = X) and triad, GB/s */
 int lbfgsx_stream_probe(lbfgsx_ctx* c, int reps, double* copy_gbs, double* triad_gbs);
 

@@ -587,7 +587,7 @@ int lbfgsx_bat_create(lbfgsx_batch** out, int dtype, int64_t n, int m, int nprob
         set_error("lbfgsx_bat_create: no HIP device available (this library has no CPU fallback)");
         return LBFGSX_E_NOGPU;
     }
-    LBFGSX_HIP(hipSetDevice(device));
+    lbfgsx::DeviceGuard dev_guard_(device);
     lbfgsx_batch* c = new lbfgsx_batch();
     c->dtype = dtype;
     c->esz = (dtype == LBFGSX_F64) ? 8 : 4;
@@ -637,7 +637,7 @@ void lbfgsx_bat_destroy(lbfgsx_batch* c)
 {
     if (!c)
         return;
-    (void) hipSetDevice(c->device);
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     (void) hipStreamSynchronize(c->stream);
     live_add(c->device, -1);
     void* ptrs[] = {c->X, c->G, c->D, c->S, c->Y, c->sc, c->ws.partials, c->ws.ticket, c->desc_dev, c->hvdesc_dev};
@@ -664,6 +664,7 @@ int lbfgsx_bat_scalar_index(const lbfgsx_batch* c, int kind, int k)
 
 int lbfgsx_bat_gen_rosen_x0(lbfgsx_batch* c, uint64_t seed0)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     const dim3 grid(unsigned(std::max(c->gx, 8)), unsigned(c->P));
     BAT_DISPATCH(c, { hipLaunchKernelGGL((kb_gen_rosen<T>), grid, dim3(kBlock), 0, c->stream, bufs<T>(c), c->n, seed0); });
     LBFGSX_HIP(hipGetLastError());
@@ -674,6 +675,7 @@ int lbfgsx_bat_gen_rosen_x0(lbfgsx_batch* c, uint64_t seed0)
 // After the launch `nout` scalars starting at each problem's desc.i_out are copied back into out[p*nout + k].
 int lbfgsx_bat_launch(lbfgsx_batch* c, int kind, int objective, const lbfgsx_bat_desc* desc, int nout, double* out)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     LBFGSX_HIP(hipStreamSynchronize(c->stream));  // the pinned descriptor staging may still be in flight
     std::memcpy(c->hdesc, desc, sizeof(BatDesc) * size_t(c->P));
     LBFGSX_HIP(hipMemcpyAsync(c->desc_dev, c->hdesc, sizeof(BatDesc) * size_t(c->P), hipMemcpyHostToDevice, c->stream));
@@ -722,6 +724,7 @@ int lbfgsx_bat_launch(lbfgsx_batch* c, int kind, int objective, const lbfgsx_bat
 
 int lbfgsx_bat_apply_Hv(lbfgsx_batch* c, const lbfgsx_bat_hvdesc* desc)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     const int64_t w = (c->dtype == LBFGSX_F64) ? 2 : 4;
     const int64_t nv = c->n / w;
     if (!c->fused_hv || (c->n % w) != 0 || nv > int64_t(kHvThreads) * 98 || c->m > 32)
@@ -755,6 +758,7 @@ int lbfgsx_bat_apply_Hv(lbfgsx_batch* c, const lbfgsx_bat_hvdesc* desc)
 
 int lbfgsx_bat_fetch(lbfgsx_batch* c, const int* idx, double* out)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     BAT_DISPATCH(c, {
         const size_t tot = size_t(c->P) * size_t(c->scn);
         if (c->hout_cap < tot * sizeof(T))
@@ -776,6 +780,7 @@ int lbfgsx_bat_fetch(lbfgsx_batch* c, const int* idx, double* out)
 // copy the current iterate of problem p (point index pt) to the host (n elements)
 int lbfgsx_bat_download_x(lbfgsx_batch* c, int p, int pt, void* host)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     const char* base = static_cast<const char*>(c->X) + (size_t(pt) * c->P + size_t(p)) * size_t(c->ld) * c->esz;
     LBFGSX_HIP(hipMemcpyAsync(host, base, size_t(c->n) * c->esz, hipMemcpyDeviceToHost, c->stream));
     LBFGSX_HIP(hipStreamSynchronize(c->stream));
@@ -784,6 +789,7 @@ int lbfgsx_bat_download_x(lbfgsx_batch* c, int p, int pt, void* host)
 
 int lbfgsx_bat_sync(lbfgsx_batch* c)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     LBFGSX_HIP(hipStreamSynchronize(c->stream));
     return LBFGSX_OK;
 }

@@ -25,6 +25,27 @@ void set_error(const std::string& msg);
         }                                                                                     \
     } while (0)
 
+// Every ABI entry that allocates, launches or records runs with the context's device current and restores the caller's
+// on return: a thread that drives two contexts on two GPUs (or a context created in another thread) must not get its
+// lazily allocated buffers and events on whatever device happened to be current.  hipGetDevice is a thread-local read.
+struct DeviceGuard
+{
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess || prev != dev)
+            switched = (hipSetDevice(dev) == hipSuccess) && prev >= 0;
+    }
+    ~DeviceGuard()
+    {
+        if (switched)
+            (void) hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 // indices into the device scalar array (element type T)
 struct ScLayout
 {

@@ -730,6 +730,7 @@ extern "C" {
 
 int lbfgsx_gs_set_history_dtype(lbfgsx_ctx* c, int dtype)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     if (!c || (dtype != LBFGSX_F64 && dtype != LBFGSX_F32))
     {
         set_error("lbfgsx_gs_set_history_dtype: invalid argument");
@@ -769,6 +770,7 @@ int lbfgsx_gs_set_history_dtype(lbfgsx_ctx* c, int dtype)
 
 int lbfgsx_gs_post_linesearch(lbfgsx_ctx* c, double scal[7], double* sdots, double* gdots, double* ydots)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     if (!c || !scal || !sdots || !gdots)
     {
         set_error("lbfgsx_gs_post_linesearch: null argument");
@@ -791,6 +793,7 @@ int lbfgsx_gs_post_linesearch(lbfgsx_ctx* c, double scal[7], double* sdots, doub
 
 int lbfgsx_gs_direction(lbfgsx_ctx* c, const double* coef, double coef_g, double* dg)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     if (!c || (!coef && c->ncorr > 0))
     {
         set_error("lbfgsx_gs_direction: null argument");

@@ -442,6 +442,7 @@ extern "C" {
 
 int lbfgsx_b_force_bounds(lbfgsx_ctx* c)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     int rc = need_bounded(c);
     if (rc)
         return rc;
@@ -477,6 +478,7 @@ extern "C" {
 
 int lbfgsx_b_eval(lbfgsx_ctx* c, int objective, double* fx, double* projgnorm, double* xnorm2)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     int rc = need_bounded(c);
     if (rc)
         return rc;
@@ -500,6 +502,7 @@ int lbfgsx_b_eval(lbfgsx_ctx* c, int objective, double* fx, double* projgnorm, d
 
 int lbfgsx_b_norms(lbfgsx_ctx* c, double* projgnorm, double* xnorm2)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     int rc = need_bounded(c);
     if (rc)
         return rc;
@@ -522,6 +525,7 @@ int lbfgsx_b_norms(lbfgsx_ctx* c, double* projgnorm, double* xnorm2)
 
 int lbfgsx_b_dg_maxstep(lbfgsx_ctx* c, double* dg, double* step_max)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     int rc = need_bounded(c);
     if (rc)
         return rc;
@@ -545,6 +549,7 @@ int lbfgsx_b_dg_maxstep(lbfgsx_ctx* c, double* dg, double* step_max)
 
 int lbfgsx_b_post_linesearch(lbfgsx_ctx* c, double* projgnorm, double* xnorm2, double* sy, double* yy)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     int rc = need_bounded(c);
     if (rc)
         return rc;
@@ -584,6 +589,7 @@ int lbfgsx_b_correction_dots_defer(lbfgsx_ctx* c)
 
 int lbfgsx_b_correction_dots(lbfgsx_ctx* c, double* sdots, double* ydots)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     int rc = need_bounded(c);
     if (rc)
         return rc;
@@ -618,6 +624,7 @@ int lbfgsx_b_correction_dots(lbfgsx_ctx* c, double* sdots, double* ydots)
 
 int lbfgsx_b_cauchy_build(lbfgsx_ctx* c, int64_t* nfree, int64_t* nord, double* dd, double* wtd)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     int rc = need_bounded(c);
     if (rc)
         return rc;
@@ -710,6 +717,7 @@ extern "C" {
 int lbfgsx_b_cauchy_build_partial(lbfgsx_ctx* c, double tau, int64_t* nfree, int64_t* nord, int64_t* nsorted, double* dd,
                                   double* wtd)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     int rc = need_bounded(c);
     if (rc)
         return rc;
@@ -758,6 +766,7 @@ int lbfgsx_b_cauchy_build_partial(lbfgsx_ctx* c, double tau, int64_t* nfree, int
 // full sort of the break points written by the last build (after a partial one turned out too short)
 int lbfgsx_b_cauchy_sort_full(lbfgsx_ctx* c)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     int rc = need_bounded(c);
     if (rc)
         return rc;
@@ -773,6 +782,7 @@ int lbfgsx_b_cauchy_sort_full(lbfgsx_ctx* c)
 int lbfgsx_b_cauchy_chunk(lbfgsx_ctx* c, int64_t first, int64_t count, double* brk, double* g, double* z, int* idx,
                           double* wrows)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     int rc = need_bounded(c);
     if (rc)
         return rc;
@@ -848,6 +858,7 @@ extern "C" {
 int lbfgsx_b_cauchy_scan(lbfgsx_ctx* c, int64_t first, int64_t count, int64_t nord, const double* Mmat, double theta,
                          double t_prev, const double* state_in, int64_t* exit_at, double* state_out)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     int rc = need_bounded(c);
     if (rc)
         return rc;
@@ -947,6 +958,7 @@ int lbfgsx_b_cauchy_scan(lbfgsx_ctx* c, int64_t first, int64_t count, int64_t no
 
 int lbfgsx_b_cauchy_finish(lbfgsx_ctx* c, double t_cross, double tfinal, int crossed_all, int64_t* nact, int64_t* nfree)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     int rc = need_bounded(c);
     if (rc)
         return rc;
@@ -968,6 +980,7 @@ int lbfgsx_b_cauchy_finish(lbfgsx_ctx* c, double t_cross, double tfinal, int cro
 
 int lbfgsx_b_sub_begin(lbfgsx_ctx* c)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     int rc = need_bounded(c);
     if (rc)
         return rc;
@@ -982,6 +995,7 @@ int lbfgsx_b_sub_begin(lbfgsx_ctx* c)
 
 int lbfgsx_b_wtv(lbfgsx_ctx* c, int vsel_id, int mask, double* out, int64_t* nnz)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     int rc = need_bounded(c);
     if (rc)
         return rc;
@@ -991,6 +1005,7 @@ int lbfgsx_b_wtv(lbfgsx_ctx* c, int vsel_id, int mask, double* out, int64_t* nnz
 
 int lbfgsx_b_gram(lbfgsx_ctx* c, int mask, double* gram)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     // lower triangle (and everything else, by symmetry) of the 2c x 2c Gram of [Y_P, S_P] in logical slot order
     int rc = need_bounded(c);
     if (rc)
@@ -1076,6 +1091,7 @@ extern "C" {
 int lbfgsx_b_wtv_prologue(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, const double* coef1, const double* coef2,
                           double* wtv)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     int rc = need_bounded(c);
     if (rc)
         return rc;
@@ -1131,18 +1147,21 @@ int lbfgsx_b_wtv_prologue(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, co
 
 int lbfgsx_b_gram_fused(lbfgsx_ctx* c, int mask, int vsel_id, double* gram, double* wtv)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     return lbfgsx_b_gram_fused_ex(c, mask, vsel_id, LBFGSX_GP_NONE, nullptr, nullptr, gram, wtv);
 }
 
 int lbfgsx_b_gram_fused_ex(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, const double* coef1, const double* coef2,
                            double* gram, double* wtv)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     return lbfgsx_b_gram_fused_dd(c, mask, vsel_id, prologue, coef1, coef2, gram, wtv, nullptr);
 }
 
 int lbfgsx_b_gram_fused_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, const double* coef1, const double* coef2,
                            double* gram, double* wtv, double* gram_dd)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     int rc = need_bounded(c);
     if (rc)
         return rc;
@@ -1275,6 +1294,7 @@ int lbfgsx_b_gram_fused_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
 
 int lbfgsx_b_wcombine(lbfgsx_ctx* c, int mode, int mask, int vsel_id, const double* coef, double theta)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     int rc = need_bounded(c);
     if (rc)
         return rc;
@@ -1318,6 +1338,7 @@ extern "C" {
 
 int lbfgsx_b_solve_wty(lbfgsx_ctx* c, int pmask, int vsel_id, const double* coef, double theta, int fmask, double* wty)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     int rc = need_bounded(c);
     if (rc)
         return rc;
@@ -1338,6 +1359,7 @@ int lbfgsx_b_solve_wty(lbfgsx_ctx* c, int pmask, int vsel_id, const double* coef
 
 int lbfgsx_b_sub_partition(lbfgsx_ctx* c, int64_t* nL, int64_t* nU, int64_t* nP)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     int rc = need_bounded(c);
     if (rc)
         return rc;
@@ -1359,6 +1381,7 @@ int lbfgsx_b_sub_partition(lbfgsx_ctx* c, int64_t* nL, int64_t* nU, int64_t* nP)
 
 int lbfgsx_b_sub_check(lbfgsx_ctx* c, int64_t counts[4])
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     int rc = need_bounded(c);
     if (rc)
         return rc;
@@ -1379,6 +1402,7 @@ int lbfgsx_b_sub_check(lbfgsx_ctx* c, int64_t counts[4])
 
 int lbfgsx_b_sub_sweep_begin(lbfgsx_ctx* c, int first, int64_t* nL, int64_t* nU, int64_t* nP, int64_t counts[4])
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     int rc = need_bounded(c);
     if (rc)
         return rc;
@@ -1403,6 +1427,7 @@ int lbfgsx_b_sub_sweep_begin(lbfgsx_ctx* c, int first, int64_t* nL, int64_t* nU,
 
 int lbfgsx_b_sub_op(lbfgsx_ctx* c, int op)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     int rc = need_bounded(c);
     if (rc)
         return rc;
@@ -1417,6 +1442,7 @@ int lbfgsx_b_sub_op(lbfgsx_ctx* c, int op)
 
 int lbfgsx_b_download_state(lbfgsx_ctx* c, unsigned char* host)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     int rc = need_bounded(c);
     if (rc)
         return rc;
@@ -1427,6 +1453,7 @@ int lbfgsx_b_download_state(lbfgsx_ctx* c, unsigned char* host)
 
 int lbfgsx_b_dot_drt_g(lbfgsx_ctx* c, double* dg)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     const int grid = c->grid_for(c->n);
     double r[2];
     DISPATCH_T(c, {
@@ -1443,6 +1470,7 @@ int lbfgsx_b_dot_drt_g(lbfgsx_ctx* c, double* dg)
 
 int lbfgsx_b_dir_from_xcp(lbfgsx_ctx* c, int normalize)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     int rc = need_bounded(c);
     if (rc)
         return rc;

@@ -204,7 +204,7 @@ int lbfgsx_create(lbfgsx_ctx** out, int dtype, int64_t n, int m, int device, int
         set_error("lbfgsx_create: device index out of range");
         return LBFGSX_E_INVALID;
     }
-    LBFGSX_HIP(hipSetDevice(device));
+    lbfgsx::DeviceGuard dev_guard_(device);
     lbfgsx_ctx* c = new lbfgsx_ctx();
     *out = nullptr;
     const int rc = create_fill(c, dtype, n, m, device, flags);
@@ -335,7 +335,7 @@ void lbfgsx_destroy(lbfgsx_ctx* c)
 {
     if (!c)
         return;
-    (void) hipSetDevice(c->device);
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     (void) hipStreamSynchronize(c->stream);
     if (c->counted)
         live_add(c->device, -1);
@@ -379,6 +379,7 @@ void lbfgsx_destroy(lbfgsx_ctx* c)
 
 int lbfgsx_set_stream(lbfgsx_ctx* c, void* hip_stream)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     LBFGSX_HIP(hipStreamSynchronize(c->stream));
     if (c->own_stream)
         LBFGSX_HIP(hipStreamDestroy(c->stream));
@@ -389,6 +390,7 @@ int lbfgsx_set_stream(lbfgsx_ctx* c, void* hip_stream)
 
 int lbfgsx_sync(lbfgsx_ctx* c)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     LBFGSX_HIP(hipStreamSynchronize(c->stream));
     return LBFGSX_OK;
 }
@@ -398,6 +400,7 @@ void* lbfgsx_vec(lbfgsx_ctx* c, int which) { return vec_ptr(c, which); }
 
 int lbfgsx_upload(lbfgsx_ctx* c, int which, const void* host)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     void* p = vec_ptr(c, which);
     if (!p || !host)
     {
@@ -411,6 +414,7 @@ int lbfgsx_upload(lbfgsx_ctx* c, int which, const void* host)
 
 int lbfgsx_download(lbfgsx_ctx* c, int which, void* host)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     void* p = vec_ptr(c, which);
     if (!p || !host)
     {
@@ -424,6 +428,7 @@ int lbfgsx_download(lbfgsx_ctx* c, int which, void* host)
 
 int lbfgsx_gather(lbfgsx_ctx* c, int which, int64_t stride, double* host)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     void* p = vec_ptr(c, which);
     if (!p || !host || stride < 1)
     {
@@ -460,6 +465,7 @@ int lbfgsx_set_shard(lbfgsx_ctx* c, int64_t offset, int64_t n_global)
 
 int lbfgsx_gen_diag_quad(lbfgsx_ctx* c, double kappa, uint64_t seed)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     DISPATCH_T(c, { hipLaunchKernelGGL(k_gen_quad<T>, dim3(2048), dim3(256), 0, c->stream, P<T>(c->a), P<T>(c->b),
                                        c->n, kappa, seed, c->shard_off, c->n_global); });
     LBFGSX_HIP(hipGetLastError());
@@ -468,6 +474,7 @@ int lbfgsx_gen_diag_quad(lbfgsx_ctx* c, double kappa, uint64_t seed)
 
 int lbfgsx_gen_rosen_x0(lbfgsx_ctx* c, uint64_t seed)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     DISPATCH_T(c, { hipLaunchKernelGGL(k_gen_rosen<T>, dim3(2048), dim3(256), 0, c->stream, P<T>(c->xb[c->cur]),
                                        c->n, seed, c->shard_off); });
     LBFGSX_HIP(hipGetLastError());
@@ -476,6 +483,7 @@ int lbfgsx_gen_rosen_x0(lbfgsx_ctx* c, uint64_t seed)
 
 int lbfgsx_fill(lbfgsx_ctx* c, int which, double value)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     void* p = vec_ptr(c, which);
     if (!p)
     {
@@ -490,11 +498,13 @@ int lbfgsx_fill(lbfgsx_ctx* c, int which, double value)
 // ---- BFGSMat ---------------------------------------------------------------------------------------
 int lbfgsx_bfgs_reset(lbfgsx_ctx* c)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     // BFGSMat.h:61-78
     c->theta = 1.0;
     c->ncorr = 0;
     c->ptr = c->m;
     c->pending = false;
+    c->tl_step = 0;  // the traversal direction of every launch of a run is a function of the run alone
     for (int j = 0; j < c->m; j++)
         c->phys[size_t(j)] = j;
     c->phys_version++;
@@ -513,6 +523,7 @@ double lbfgsx_bfgs_theta(const lbfgsx_ctx* c) { return c->theta; }
 
 int lbfgsx_bfgs_download_history(lbfgsx_ctx* c, void* S_out, void* Y_out, int* ncorr, int* ptr, double* theta)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     if (c->gs_f32h)
     {
         set_error("lbfgsx_bfgs_download_history: this context keeps its history in f32 for the Gram-space recursion (lbfgsx_gs_set_history_dtype)");
@@ -535,6 +546,7 @@ int lbfgsx_bfgs_download_history(lbfgsx_ctx* c, void* S_out, void* Y_out, int* n
 
 int lbfgsx_commit_correction(lbfgsx_ctx* c)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     if (!c->pending)
     {
         set_error("lbfgsx_commit_correction: no pending (s, y) pair");
@@ -558,6 +570,7 @@ int lbfgsx_commit_correction(lbfgsx_ctx* c)
 
 int lbfgsx_bfgs_stage_correction_host(lbfgsx_ctx* c, const void* s, const void* y, double* sy, double* yy)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     if (c->gs_f32h)
     {
         set_error("lbfgsx_bfgs_stage_correction_host: this context keeps its history in f32 for the Gram-space recursion (lbfgsx_gs_set_history_dtype)");
@@ -590,6 +603,7 @@ int lbfgsx_bfgs_stage_correction_host(lbfgsx_ctx* c, const void* s, const void* 
 
 int lbfgsx_bfgs_add_correction_host(lbfgsx_ctx* c, const void* s, const void* y)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     int rc = lbfgsx_bfgs_stage_correction_host(c, s, y, nullptr, nullptr);
     if (rc)
         return rc;
@@ -778,6 +792,7 @@ extern "C" {
 
 int lbfgsx_apply_Hv(lbfgsx_ctx* c, int v_which, double a, double* dg)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     void* v = vec_ptr(c, v_which);
     if (!v || v == c->d)
     {
@@ -808,6 +823,7 @@ extern "C" {
 
 int lbfgsx_eval(lbfgsx_ctx* c, int objective, double* fx, double* gnorm2, double* xnorm2)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     double r[3];
     int rc = LBFGSX_E_INVALID;
     if (objective == LBFGSX_OBJ_EXT_ROSENBROCK && (c->n & 1))
@@ -833,6 +849,7 @@ int lbfgsx_eval(lbfgsx_ctx* c, int objective, double* fx, double* gnorm2, double
 
 int lbfgsx_norms(lbfgsx_ctx* c, double* gnorm2, double* xnorm2)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     const int grid = c->grid_for(c->n);
     double r[2];
     DISPATCH_T(c, {
@@ -872,6 +889,7 @@ extern "C" {
 
 int lbfgsx_trial(lbfgsx_ctx* c, int objective, double step, double* fx, double* dg)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     double r[2];
     int rc = LBFGSX_E_INVALID;
     DISPATCH_T(c, {
@@ -891,6 +909,7 @@ int lbfgsx_trial(lbfgsx_ctx* c, int objective, double step, double* fx, double* 
 
 int lbfgsx_trial_point(lbfgsx_ctx* c, double step)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     const int grid = c->grid_for(c->n);
     DISPATCH_T(c, {
         hipLaunchKernelGGL((k_axpy_point<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->xp]), P<T>(c->d),
@@ -902,6 +921,7 @@ int lbfgsx_trial_point(lbfgsx_ctx* c, double step)
 
 int lbfgsx_trial_dg(lbfgsx_ctx* c, double* dg)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     const int grid = c->grid_for(c->n);
     DISPATCH_T(c, {
         hipLaunchKernelGGL((k_dot<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->gb[c->trial]), P<T>(c->d),
@@ -932,6 +952,7 @@ int lbfgsx_ls_end(lbfgsx_ctx* c, int use_lo)
 
 int lbfgsx_post_linesearch(lbfgsx_ctx* c, double* gnorm2, double* xnorm2, double* sy, double* yy)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     if (c->gs_f32h)
     {
         set_error("lbfgsx_post_linesearch: this context keeps its history in f32 for the Gram-space recursion (lbfgsx_gs_set_history_dtype)");
@@ -963,6 +984,7 @@ int lbfgsx_post_linesearch(lbfgsx_ctx* c, double* gnorm2, double* xnorm2, double
 // ---- instrumentation ----------------------------------------------------------------------------------
 int lbfgsx_timing_enable(lbfgsx_ctx* c, int on)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     LBFGSX_HIP(hipStreamSynchronize(c->stream));
     for (auto& e : c->ev_twoloop)
     {
@@ -986,6 +1008,7 @@ int lbfgsx_timing_enable(lbfgsx_ctx* c, int on)
 int lbfgsx_timing_read(lbfgsx_ctx* c, double* twoloop_ms_total, int64_t* twoloop_launches, double* applyhv_ms_total,
                        int64_t* applyhv_calls)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     LBFGSX_HIP(hipStreamSynchronize(c->stream));
     double t1 = 0.0, t2 = 0.0;
     for (auto& e : c->ev_twoloop)
@@ -1028,8 +1051,19 @@ int lbfgsx_timing_read(lbfgsx_ctx* c, double* twoloop_ms_total, int64_t* twoloop
 
 int64_t lbfgsx_persistent_launches(const lbfgsx_ctx* c) { return c ? c->persist_launches : 0; }
 
+int64_t lbfgsx_persistent_resident_elems(const lbfgsx_ctx* c)
+{
+    if (!c || c->persist_grid <= 0)
+        return 0;
+    // k_twoloop_persist: slot s of global thread g holds vector s * gthreads + g, NR + NL slots per thread
+    const int64_t w = (c->dtype == LBFGSX_F64) ? 2 : 4;
+    const int64_t cap = int64_t(kPersistNR + kPersistNL) * int64_t(c->persist_grid) * kHvThreads * w;
+    return std::min<int64_t>(cap, c->n / w * w);
+}
+
 int lbfgsx_stream_probe(lbfgsx_ctx* c, int reps, double* copy_gbs, double* triad_gbs)
 {
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     if (reps < 1)
         reps = 1;
     const int grid = c->grid_for(c->n);

@@ -40,7 +40,8 @@ with open(os.path.join(src, "trace", "bench_kernel_stats.csv")) as f:
     for r in csv.DictReader(f):
         stats[short(r["Name"])] = (int(r["Calls"]), float(r["AverageNs"]))
 
-out = {"round": rnd, "command": "rocprofv3 {--kernel-trace --stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE} "
+out = {"round": rnd, "n": 100000000, "m": 10,  # bench.py's defaults: the profiled command passes no --n / --m
+       "command": "rocprofv3 {--kernel-trace --stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE} "
                                 "--output-format csv -- python bench.py --no-cpu --steps 10 --warmup 11",
        "units": "FETCH_SIZE/WRITE_SIZE in KiB; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 correction)",
        "kernels": {}}
@@ -96,7 +97,8 @@ def gram_summary(prefix, tag, flag, kprefix="k_gs_", note=None):
     with open(gsrc) as f:
         for r in csv.DictReader(f):
             gstats[short(r["Name"])] = (int(r["Calls"]), float(r["AverageNs"]))
-    gout = {"round": rnd, "command": out["command"].replace("bench.py", "bench.py " + flag), "units": out["units"],
+    gout = {"round": rnd, "n": 100000000, "m": 10,  # bench.py's defaults: the profiled command passes no --n / --m
+       "command": out["command"].replace("bench.py", "bench.py " + flag), "units": out["units"],
             "note": note or "launches start from an empty history (m = 10): launch k reads 2*min(k,10) columns, so the per-launch "
                     "averages below mix the warm-up launches with the full-history ones; max_* are the full-history launches",
             "kernels": {}}

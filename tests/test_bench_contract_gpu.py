@@ -10,9 +10,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(*extra):
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "12"] + list(extra)
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT)
+def _run(*extra, gpus=1, warmup=12, env=None):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup", str(warmup)] + list(extra)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT,
+                       env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, "bench.py must print exactly ONE line on stdout: %r" % lines
@@ -30,9 +31,16 @@ def test_default_line_has_the_contract_keys():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.3 < r["frac"] < 1.0
     assert r["traffic"] is None or 0.7 * r["algorithmic_bytes_per_launch"] < r["traffic"] < 1.1 * r["algorithmic_bytes_per_launch"]
+    assert (r["traffic"] is None) == (r["traffic_source"] is None)
     assert d["config"]["apply_Hv_persistent_launches"] > 0
+    # the timed window holds full-history products only: 3 iterations x (2m+1) steps
+    assert d["config"]["history_full"] is True and r["launches_timed"] == 3 * 21
+    b = d["cfg5_batched"]   # the batched mode of BASELINE.json's cfg5 rides in the same line
+    assert b["unit"] == "problem-iterations/s" and b["n_gpus"] == 1 and b["value"] > 1e4 and b["config"]["failed"] == 0
+    assert 0.1 < b["roofline"]["frac"] < 1.0
     c = d["cpu_baseline"]
     assert c["unit"] == "iterations/s" and c["cores"] == 1 and c["kind"] in ("reference", "port") and c["value"] > 0 and c["sample"]
+    assert c["extrapolated"] is True and c["measured_n"] == 2000000
     a = d["cpu_baseline_all_cores"]
     assert a is None or (a["cores"] >= 1 and a["value"] > 0)
 
@@ -44,3 +52,40 @@ def test_opt_in_modes_are_labelled_as_such():
         assert d["config"]["recursion"].startswith("gram-space") and d["roofline"]["kernel"].startswith("k_gs_post")
     d = _run("--workload", "sharded", "--no-cpu")
     assert d["scaling"] == "strong" and "row-sharded" in d["metric"] and d["config"]["rows_per_gpu"] == 100000000
+
+
+def test_history_is_full_whatever_the_warmup():
+    """timed iterations run with c = m.  --warmup 0 and --warmup 12 time the same work."""
+    a = _run("--no-cpu", "--no-batched", warmup=0)
+    b = _run("--no-cpu", "--no-batched", warmup=12)
+    for d in (a, b):
+        assert d["config"]["history_full"] is True and d["roofline"]["launches_timed"] == 3 * 21
+    assert a["config"]["warmup_run"] == 10 and b["config"]["warmup_run"] == 12 and a["warmup"] == 0
+    assert abs(a["value"] / b["value"] - 1.0) < 0.1
+    assert abs(a["roofline"]["apply_Hv_GBs"] / a["roofline"]["algorithmic_GBs"] - 1.0) < 0.02
+
+
+def test_small_problem_reports_the_hbm_model_fraction():
+    """cfg2 size: q lives on the CUs, the algorithmic figure exceeds the HBM peak; `frac` stays a roofline fraction."""
+    d = _run("--objective", "quadratic", "--n", "10000000", "--no-cpu", "--no-batched")
+    r = d["roofline"]
+    assert r["frac"] < 1.0 and r["q_resident_elems"] == 10000000 and r["hbm_model_GBs"] < r["algorithmic_GBs"]
+    assert r["traffic"] is None   # no committed PMC profile at this (n, m)
+
+
+def test_gpus_2_starts_two_ranks_or_refuses():
+    """`python bench.py --gpus 2` without a launcher starts its own two ranks.  On a one-GPU box they share device 0 over
+    gloo (protocol test); without that override the script must refuse rather than report one GPU."""
+    import ctypes as C
+    sys.path.insert(0, ROOT)
+    import lbfgspp_amd as A
+    ndev = A.load()[0].lbfgsx_device_count()
+    env = {} if ndev >= 2 else {"LBFGSX_BENCH_FORCE_DEVICE": "0"}
+    d = _run("--no-cpu", "--n", "20000000", "--problems-per-gpu", "256", gpus=2, env=env)
+    assert d["n_gpus"] == 2 and d["cfg5_batched"]["n_gpus"] == 2 and d["cfg5_batched"]["config"]["problems_total"] == 512
+    assert d["config"]["history_full"] is True
+    if ndev < 2:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--no-cpu"]
+        env0 = {k: v for k, v in os.environ.items() if k not in ("LBFGSX_BENCH_FORCE_DEVICE", "WORLD_SIZE", "RANK")}
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, cwd=ROOT, env=env0)
+        assert r.returncode != 0 and not r.stdout.strip()

@@ -146,3 +146,22 @@ def test_row_sharded_bundle_over_gloo(tmp_path):
     for rank, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert "RANK%d OK" % rank in o, o
+
+
+def test_bench_refuses_to_report_fewer_gpus_than_asked_for():
+    """`python bench.py --gpus 2` on a box with fewer devices exits non-zero and prints no result line (it used to parse
+    --gpus and ignore it); under a launcher whose world size differs from --gpus it refuses as well."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LBFGSX_BENCH_FORCE_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    if r.returncode == 0:   # a box with >= 2 GPUs: then the line must say so
+        import json
+        assert json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 2
+    else:
+        assert not r.stdout.strip() and "refusing" in r.stderr
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=dict(env, WORLD_SIZE="2", RANK="0"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode != 0 and not r.stdout.strip() and "launcher started 2" in r.stderr
