@@ -466,6 +466,12 @@ def main():
     if args.gpus > 1 and not launched:
         spawn_ranks(args)  # does not return
 
+    # Exactly ONE line on stdout: libraries that print there (gloo's connection notice, HIP runtime notes) are sent to
+    # stderr for the whole run; the result line goes to the saved descriptor at the end.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch  # noqa: F401  (first: its bundled HIP runtime must be the process-wide one)
     rank, world, local, comm_dev, dist = init_dist(args)
     if args.workload == "cfg5-batched":
@@ -488,7 +494,8 @@ def main():
             except Exception as e:
                 out["cpu_baseline_all_cores"] = {"error": repr(e)}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
