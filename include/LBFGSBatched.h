@@ -10,8 +10,10 @@
 #include <cmath>
 #include <cstdint>
 #include <limits>
+#include <exception>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "LBFGSpp/Device.h"
@@ -383,6 +385,62 @@ public:
             out[size_t(p)].gnorm = pr[size_t(p)].gnorm;
             if (x_out)
                 detail::check(lbfgsx_bat_download_x(c, p, pr[size_t(p)].cur, x_out + std::int64_t(p) * n));
+        }
+    }
+
+    // contiguous, balanced block of `count` problems for shard r of w (remainder to the low shards) -- the partition
+    // bench.py / lbfgspp_amd/batched.py:shard_range give one-process-per-GPU ranks
+    static void shard_range(std::int64_t count, int r, int w, std::int64_t& first, std::int64_t& len)
+    {
+        const std::int64_t base = count / w, rem = count % w;
+        len = base + (r < rem ? 1 : 0);
+        first = std::int64_t(r) * base + std::min<std::int64_t>(r, rem);
+    }
+
+    // The batched mode over several GPUs of one node from ONE process (independent units, no data-path
+    // collective): devices[r] solves the r-th contiguous block of problem ids in its own lock-step batch, driven by its
+    // own host thread; the per-problem records (and, when asked for, the iterates) are gathered in host memory in
+    // problem-id order.  A device may appear more than once (its blocks then share it).  Per problem the arithmetic
+    // is the single-device one, so the records are bit-identical whatever the device list.  The first exception a
+    // shard would have thrown is rethrown after all shards have finished.
+    void minimize(std::int64_t n, std::uint64_t seed_base, std::int64_t first, int count, const std::vector<int>& devices,
+                  std::vector<Item>& out, Scalar* x_out = nullptr)
+    {
+        if (devices.empty())
+            throw std::invalid_argument("LBFGSBatchedSolver::minimize: empty device list");
+        out.assign(size_t(count > 0 ? count : 0), Item());
+        if (count <= 0)
+            return;
+        const int w = int(devices.size());
+        std::vector<std::vector<Item>> part(static_cast<size_t>(w));
+        std::vector<std::exception_ptr> err(static_cast<size_t>(w));
+        std::vector<std::thread> pool;
+        for (int r = 0; r < w; r++)
+            pool.emplace_back([&, r]() {
+                std::int64_t lo = 0, len = 0;
+                shard_range(count, r, w, lo, len);
+                try
+                {
+                    if (len > 0)
+                        minimize(n, seed_base, first + lo, int(len), devices[size_t(r)], part[size_t(r)],
+                                 x_out ? x_out + lo * n : nullptr);
+                }
+                catch (...)
+                {
+                    err[size_t(r)] = std::current_exception();
+                }
+            });
+        for (auto& th : pool)
+            th.join();
+        for (int r = 0; r < w; r++)
+            if (err[size_t(r)])
+                std::rethrow_exception(err[size_t(r)]);
+        for (int r = 0; r < w; r++)
+        {
+            std::int64_t lo = 0, len = 0;
+            shard_range(count, r, w, lo, len);
+            for (std::int64_t k = 0; k < len; k++)
+                out[size_t(lo + k)] = part[size_t(r)][size_t(k)];
         }
     }
 };

@@ -116,6 +116,13 @@ int lbfgsx_batch_minimize(int algo, int dtype, int linesearch, const lbfgsx_para
 int lbfgsx_batch_minimize_lockstep(int dtype, const lbfgsx_params* p, int64_t n, int64_t first, int count,
                                    uint64_t seed_base, int device, lbfgsx_batch_item* out, void* x_out, char* errbuf,
                                    int errlen);
+/* The same over several GPUs of one node from one process (BASELINE.json cfg5 "sharded over 8 x MI355X"):
+ * devices[r] (r < ndev) solves the r-th contiguous, balanced block of the `count` problem ids in its own lock-step
+ * batch on its own host thread; no data crosses between devices, the records (and x_out) are gathered in host memory in
+ * problem-id order.  A device id may repeat.  Records are bit-identical to the single-device call. */
+int lbfgsx_batch_minimize_lockstep_multi(int dtype, const lbfgsx_params* p, int64_t n, int64_t first, int count,
+                                         uint64_t seed_base, const int* devices, int ndev, lbfgsx_batch_item* out,
+                                         void* x_out, char* errbuf, int errlen);
 
 #ifdef __cplusplus
 }

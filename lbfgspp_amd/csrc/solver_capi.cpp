@@ -432,12 +432,15 @@ int lbfgsx_batch_minimize(int algo, int dtype, int linesearch, const lbfgsx_para
 }
 
 // lock-step batch (include/LBFGSBatched.h): L-BFGS + More-Thuente + extended Rosenbrock
-int lbfgsx_batch_minimize_lockstep(int dtype, const lbfgsx_params* p, int64_t n, int64_t first, int count,
-                                   uint64_t seed_base, int device, lbfgsx_batch_item* out, void* x_out, char* errbuf,
-                                   int errlen)
+int lbfgsx_batch_minimize_lockstep_multi(int dtype, const lbfgsx_params* p, int64_t n, int64_t first, int count,
+                                         uint64_t seed_base, const int* devices, int ndev, lbfgsx_batch_item* out,
+                                         void* x_out, char* errbuf, int errlen)
 {
     lbfgsx_result r;
     int rc = guarded(&r, [&]() {
+        if (!devices || ndev < 1)
+            throw std::invalid_argument("lbfgsx_batch_minimize_lockstep_multi: empty device list");
+        const std::vector<int> devs(devices, devices + ndev);
         auto body = [&](auto tag) {
             typedef decltype(tag) T;
             LBFGSParam<T> param;
@@ -445,7 +448,10 @@ int lbfgsx_batch_minimize_lockstep(int dtype, const lbfgsx_params* p, int64_t n,
             param.linesearch = p->linesearch;
             LBFGSBatchedSolver<T> solver(param);
             std::vector<typename LBFGSBatchedSolver<T>::Item> items;
-            solver.minimize(n, seed_base, first, count, device, items, static_cast<T*>(x_out));
+            if (ndev == 1)
+                solver.minimize(n, seed_base, first, count, devs[0], items, static_cast<T*>(x_out));
+            else
+                solver.minimize(n, seed_base, first, count, devs, items, static_cast<T*>(x_out));
             for (int k = 0; k < count; k++)
             {
                 out[k].niter = items[size_t(k)].niter;
@@ -463,6 +469,13 @@ int lbfgsx_batch_minimize_lockstep(int dtype, const lbfgsx_params* p, int64_t n,
     if (errbuf && errlen > 0)
         std::snprintf(errbuf, size_t(errlen), "%s", r.msg);
     return rc;
+}
+
+int lbfgsx_batch_minimize_lockstep(int dtype, const lbfgsx_params* p, int64_t n, int64_t first, int count,
+                                   uint64_t seed_base, int device, lbfgsx_batch_item* out, void* x_out, char* errbuf,
+                                   int errlen)
+{
+    return lbfgsx_batch_minimize_lockstep_multi(dtype, p, n, first, count, seed_base, &device, 1, out, x_out, errbuf, errlen);
 }
 
 int lbfgsx_solver_hessians(lbfgsx_solver* s, double* B, double* H)

@@ -92,3 +92,34 @@ def test_one_launch_two_loop_equals_step_wise_launches(monkeypatch, dtype, n):
     assert np.array_equal(a, b)
     for u, v in zip(xa, xb):
         assert np.array_equal(u, v)
+
+
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0], None])
+def test_multi_device_batch_equals_the_single_device_batch(devices):
+    """SURVEY 8(e) behind the C ABI: lbfgsx_batch_minimize_lockstep_multi gives every listed device a contiguous block of
+    problem ids on its own host thread.  On the one-GPU test box the list repeats device 0 (None: every device of the box);
+    records and iterates are bit-identical to the single-device call, uneven blocks included."""
+    import lbfgspp_amd as A
+    from lbfgspp_amd import batched as B
+    if devices is None:
+        devices = list(range(A.load()[0].lbfgsx_device_count()))
+    n, m, iters, count = 30000, 6, 9, 11
+    par = A.LBFGSParam(m=m, epsilon=1e-3, epsilon_rel=0.0, max_iterations=iters, max_linesearch=6)
+    r1, x1 = B.solve_local_lockstep(par, n, first=2, count=count, seed_base=1000, dtype=np.float32, return_x=True)
+    r2, x2 = B.solve_local_lockstep(par, n, first=2, count=count, seed_base=1000, dtype=np.float32, return_x=True,
+                                    devices=devices)
+    assert np.array_equal(r1, r2) and np.array_equal(x1, x2)
+    # blocks follow shard_range: the records of block r start at its first id
+    f, c = B.shard_range(count, len(devices) - 1, len(devices))
+    r3 = B.solve_local_lockstep(par, n, first=2 + f, count=c, seed_base=1000, dtype=np.float32)
+    assert np.array_equal(r3, r1[f:f + c])
+
+
+def test_multi_device_batch_reports_bad_device_lists():
+    import lbfgspp_amd as A
+    from lbfgspp_amd import batched as B
+    par = A.LBFGSParam(m=4, epsilon=0.0, epsilon_rel=0.0, max_iterations=3)
+    with pytest.raises(ValueError):
+        B.solve_local_lockstep(par, 1024, 0, 4, devices=[])
+    with pytest.raises((ValueError, RuntimeError)):
+        B.solve_local_lockstep(par, 1024, 0, 4, devices=[0, 99])
