@@ -7,9 +7,10 @@
 //                                    in the reference's sequential form, fed by chunks of the sorted list gathered
 //                                    on the device (brk, g, z, W row) -- typically a few hundred crossings per
 //                                    call after the first iterations
-//   device  (lbfgsx_b_cauchy_scan)   the same search as prefix sums (csrc/gcp_scan.cuh) once more than
-//                                    device_switch() break points have been crossed (f64, 2c <= 32): the early
-//                                    iterations of a large problem cross 10^5..10^6 of them
+//   device  (lbfgsx_b_cauchy_scan)   the same search once more than device_switch() break points have been crossed
+//                                    (f64, 2c <= 32; the early iterations of a large problem cross 10^5..10^7 of
+//                                    them): p and c as prefix sums (csrc/gcp_scan.cuh), the f' / f'' chains and the
+//                                    exit test in the reference's order over the per-crossing terms
 //   device  (lbfgsx_b_cauchy_finish) xcp on crossed / free coordinates and the free / newly-active state byte
 //                                    from the crossing threshold (:201-206,219-233,265-282)
 // Scalars keep the reference's evaluation order; short dot products use the order-independent host accumulator.
@@ -74,17 +75,20 @@ class Cauchy
         const double* w(std::int64_t k) { if (k >= m_have) need(k); return m_w.data() + size_t(k) * size_t(2 * m_nc); }
     };
 
-    // Crossings handled in the reference's sequential form before the search moves to the device
-    // (LBFGSX_GCP_DEVICE_MIN; negative: never).  f' is a long cancelling sum (it starts at -d'd and ends near the
-    // root), so its low bits depend on the summation order: a tree-order sum agrees with the left-to-right one to
-    // ~1e-13 relative on the step, which an L-BFGS-B trajectory then amplifies (measured 1.6e-10 after 20 iterations
-    // at n = 6000).  The sequential form therefore stays in charge of every search the 1e-10 parity contract is
-    // checked on; the device takes over only past 65536 crossings, where the sequential order's own rounding noise
-    // (~N eps) is already of that size and the host loop would cost milliseconds per search.
+    // Crossings handled in the reference's sequential form on the host before the search moves to the device
+    // (LBFGSX_GCP_DEVICE_MIN; negative: never).  The device form keeps the two order-sensitive recurrences -- f' starts
+    // at -d'd and climbs to its root, f'' shrinks monotonically, so every addition rounds at the scale of the start
+    // value -- in the reference's left-to-right order (the per-crossing terms come from the device, the two scalar
+    // chains run on the host, lbfgsx_b_cauchy_scan); only p and c, whose terms change sign and whose rounding does not
+    // accumulate, are prefix sums.  Measured at cfg4's size (n = 1e7, 9.5e6 crossings in the first search): the
+    // iterates are the same, evaluation by evaluation, as with the host form alone (profiles/r2_drift_cfg4_*.json),
+    // so the hand-over point is chosen for speed: a device chunk costs ~0.5 ms, a host crossing ~0.1 us.
+    // LBFGSX_GCP_CHAIN=scan restores the round-1 form (f' and f'' as tree-order prefix sums on the device, 1e-8 on
+    // whole trajectories).
     static std::int64_t device_switch()
     {
         const char* e = std::getenv("LBFGSX_GCP_DEVICE_MIN");
-        return e ? std::atoll(e) : std::int64_t(65536);
+        return e ? std::atoll(e) : std::int64_t(4096);
     }
 
     // The next search sorts only the break points up to tau = factor * (this search's Cauchy time): in steady state

@@ -248,10 +248,18 @@ __global__ void __launch_bounds__(kGcpTile) k_gcp_a3b1(GcpBufs b, int64_t count,
     }
 }
 
-template <int NC>
+// CHAIN: the exact-order mode (lbfgsx_b_cauchy_scan, default).  The two scalar recurrences f' and f'' are long sums
+// whose low bits depend on the order of the additions -- f' starts at -d'd and climbs to its root, so every addition
+// rounds at the scale of the start value -- and the reference performs them strictly left to right (Cauchy.h:218,
+// 227-228).  In this mode the kernel only emits, per crossing, the three quantities that enter those statements,
+//     dfp[k] = g^2 + theta g z - g (M w).c_k         (:227, without the dt f'' term of :218)
+//     fpp[k] = theta g^2 + 2 g (M w).p_{k-1} + g^2 w.(M w)      (:228, the amount subtracted from f'')
+//     fp[k]  = dt_k  (fp[count] = distance to the next break point after the chunk, or -1 at the end of the list)
+// and the host runs the two chains in the reference's order (gcp_chain_host in lbfgsb.hip).
+template <int NC, bool CHAIN = false>
 __global__ void __launch_bounds__(kGcpTile) k_gcp_b3c1(GcpBufs b, int64_t count, int ncorr, double theta, double t_prev,
                                                        const double* __restrict__ Mg, const double* __restrict__ offB,
-                                                       double* __restrict__ tsC)
+                                                       double* __restrict__ tsC, int64_t first = 0, int64_t nord = 0)
 {
     __shared__ double lds[(NC + 1) * 4];
     __shared__ double M[NC * NC];
@@ -292,6 +300,30 @@ __global__ void __launch_bounds__(kGcpTile) k_gcp_b3c1(GcpBufs b, int64_t count,
         for (int j = 0; j < NC; j++)
             u = u + M[i * NC + j] * w[j];
         d_c = d_c + u * inc[i];
+    }
+    if (CHAIN)
+    {
+        if (k < count)
+        {
+            const double gg = g * g;
+            double d_p = 0.0, d_w = 0.0;
+#pragma unroll
+            for (int i = 0; i < NC; i++)
+            {
+                double u = 0.0;
+#pragma unroll
+                for (int j = 0; j < NC; j++)
+                    u = u + M[i * NC + j] * w[j];
+                d_p = d_p + u * pprev[i];
+                d_w = d_w + u * w[i];
+            }
+            b.dfp[k] = g * g + theta * g * b.z[k] - g * d_c;
+            b.fpp[k] = theta * gg + 2 * g * d_p + gg * d_w;
+            b.fp[k] = dt;
+            if (k == count - 1)
+                b.fp[count] = (first + count < nord) ? b.brk[count] - b.brk[count - 1] : -1.0;
+        }
+        return;
     }
     const double fpp_k = offB[int64_t(blockIdx.x) * (NC + 1) + NC] + inc[NC];
     const double fpp_prev = offB[int64_t(blockIdx.x) * (NC + 1) + NC] + ex[NC];

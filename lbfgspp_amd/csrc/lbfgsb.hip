@@ -50,6 +50,8 @@ struct lbfgsb_state
     double *s_brk = nullptr, *s_g = nullptr, *s_z = nullptr, *s_W = nullptr, *s_P = nullptr, *s_C = nullptr,
            *s_fpp = nullptr, *s_dfp = nullptr, *s_fp = nullptr, *s_ts = nullptr, *s_off = nullptr, *s_small = nullptr;
     unsigned long long* s_exit = nullptr;
+    double* h_chain = nullptr;   // pinned: [3][s_cap + 1] per-crossing terms of the f' / f'' chains (exact-order mode)
+    bool chain_host = true;      // LBFGSX_GCP_CHAIN=scan: tree-order f' / f'' on the device instead
     int64_t s_cap = 0;
     int s_nc = 0;
     // partial sort of the break points (lbfgsx_b_cauchy_build_partial): compacted candidates, allocated on first use
@@ -214,6 +216,8 @@ int bounded_alloc(lbfgsx_ctx* c)
         b->gram_mfma = (std::strcmp(e, "mfma") == 0);
         b->gram_mode = (std::strcmp(e, "blocked") == 0) ? 2 : 0;
     }
+    if (const char* e = getenv("LBFGSX_GCP_CHAIN"))
+        b->chain_host = std::strcmp(e, "scan") != 0;
     if (const char* e = getenv("LBFGSX_DOTS_GRID"))
         b->dots_grid = std::max(64, std::min(atoi(e), 4096));
     if (const char* e = getenv("LBFGSX_MULTIDOT"))
@@ -252,6 +256,8 @@ void bounded_free(lbfgsx_ctx* c)
                     b->g_g, b->g_z, b->g_w, b->g_idx, b->gram_partial, b->gram_partial2, b->gram_out, b->gram_dd,
                     b->s_brk, b->s_g, b->s_z, b->s_W, b->s_P, b->s_C, b->s_fpp, b->s_dfp, b->s_fp, b->s_ts, b->s_off,
                     b->s_small, b->s_exit, b->pk, b->pv, b->pcount, b->sel_tmp};
+    if (b->h_chain)
+        (void) hipHostFree(b->h_chain);
     for (void* p : ptrs)
     {
         // dout / gram_out are device aliases of host-mapped memory when the mapped outputs are on
@@ -846,12 +852,54 @@ static int gcp_scan_nc(lbfgsx_ctx* c, const GcpBufs& gb, int64_t first, int64_t 
     hipLaunchKernelGGL(k_gcp_tiles, dim3(NC), dim3(64), 0, st, b->s_ts, b->s_off, ntiles, NC, initA, fin);
     hipLaunchKernelGGL((k_gcp_a3b1<NC>), dim3(ntiles), dim3(kGcpTile), 0, st, gb, count, nc, theta, t_prev, M, b->s_off, b->s_ts);
     hipLaunchKernelGGL(k_gcp_tiles, dim3(NC + 1), dim3(64), 0, st, b->s_ts, b->s_off, ntiles, NC + 1, initB, fin);
-    hipLaunchKernelGGL((k_gcp_b3c1<NC>), dim3(ntiles), dim3(kGcpTile), 0, st, gb, count, nc, theta, t_prev, M, b->s_off, b->s_ts);
+    if (b->chain_host)
+    {
+        // exact-order mode: per-crossing terms only; the chains and the exit test run on the host (gcp_chain_host)
+        hipLaunchKernelGGL((k_gcp_b3c1<NC, true>), dim3(ntiles), dim3(kGcpTile), 0, st, gb, count, nc, theta, t_prev, M,
+                           b->s_off, b->s_ts, first, nord);
+        LBFGSX_HIP(hipGetLastError());
+        return LBFGSX_OK;
+    }
+    hipLaunchKernelGGL((k_gcp_b3c1<NC, false>), dim3(ntiles), dim3(kGcpTile), 0, st, gb, count, nc, theta, t_prev, M, b->s_off, b->s_ts, first, nord);
     hipLaunchKernelGGL(k_gcp_tiles, dim3(1), dim3(64), 0, st, b->s_ts, b->s_off, ntiles, 1, initC, fin);
     hipLaunchKernelGGL(k_gcp_c3, dim3(ntiles), dim3(kGcpTile), 0, st, gb, count, first, nord, b->s_off, b->s_exit);
     hipLaunchKernelGGL((k_gcp_extract<NC>), dim3(1), dim3(64), 0, st, gb, count, nc, theta, b->s_exit, out);
     LBFGSX_HIP(hipGetLastError());
     return LBFGSX_OK;
+}
+template <int NC>
+static void gcp_extract_nc(lbfgsx_ctx* c, const GcpBufs& gb, int64_t count, double theta)
+{
+    lbfgsb_state* b = c->bstate;
+    double* out = b->s_small + (NC * NC + NC + (NC + 1) + 1 + (NC + 1));
+    hipLaunchKernelGGL((k_gcp_extract<NC>), dim3(1), dim3(64), 0, c->stream, gb, count, c->ncorr, theta, b->s_exit, out);
+}
+
+// The f' / f'' recurrences of the break-point search in the reference's own order (Cauchy.h:218,227-228,240-256) over
+// the per-crossing terms a chunk of the device search produced: dt[k] (0 inside a group of ties, where the statements
+// the reference executes once per group are exact no-ops), A[k] (added to f'), B[k] (subtracted from f'').
+// dt[count] = distance to the break point after the chunk, -1 at the end of the sorted list.  Returns the index of the
+// group end at which the search stops, or -1.  Plain IEEE operations, no contraction (the TU is built with
+// -ffp-contract=off): bit for bit the scalar statements of the sequential form.
+static int64_t gcp_chain_host(const double* dt, const double* A, const double* B, int64_t count, double& fp, double& fpp)
+{
+    double f1 = fp, f2 = fpp;
+    for (int64_t k = 0; k < count; k++)
+    {
+        f1 = f1 + dt[k] * f2;   // fp += deltat * fpp                                   (:218)
+        f1 = f1 + A[k];         // fp += ggact + theta*gact*zact - gact*cache.dot(vecc)  (:227)
+        f2 = f2 - B[k];         // fpp -= (...)                                          (:228)
+        const double dn = dt[k + 1];
+        if (dn > 0.0 && !(-f1 / f2 >= dn))   // group end: deltatmin = -fp/fpp (:240) against the next deltat (:183)
+        {
+            fp = f1;
+            fpp = f2;
+            return k;
+        }
+    }
+    fp = f1;
+    fpp = f2;
+    return -1;
 }
 extern "C" {
 
@@ -889,7 +937,11 @@ int lbfgsx_b_cauchy_scan(lbfgsx_ctx* c, int64_t first, int64_t count, int64_t no
         LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_C), sizeof(double) * size_t(cap) * size_t(ncap)));
         LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_fpp), sizeof(double) * size_t(cap)));
         LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_dfp), sizeof(double) * size_t(cap)));
-        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_fp), sizeof(double) * size_t(cap)));
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_fp), sizeof(double) * size_t(cap + 1)));
+        if (b->h_chain)
+            (void) hipHostFree(b->h_chain);
+        b->h_chain = nullptr;
+        LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->h_chain), sizeof(double) * 3 * size_t(cap + 1), hipHostMallocDefault));
         LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_ts), sizeof(double) * tiles * size_t(ncap + 1)));
         LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_off), sizeof(double) * tiles * size_t(ncap + 1)));
         if (!b->s_small)
@@ -940,6 +992,32 @@ int lbfgsx_b_cauchy_scan(lbfgsx_ctx* c, int64_t first, int64_t count, int64_t no
     }
     if (rc)
         return rc;
+    double fp_h = state_in[2 * nc2], fpp_h = state_in[2 * nc2 + 1];
+    if (b->chain_host)
+    {
+        double* hdt = b->h_chain;
+        double* hA = hdt + (b->s_cap + 1);
+        double* hB = hA + (b->s_cap + 1);
+        LBFGSX_HIP(hipMemcpyAsync(hdt, b->s_fp, sizeof(double) * size_t(count + 1), hipMemcpyDeviceToHost, c->stream));
+        LBFGSX_HIP(hipMemcpyAsync(hA, b->s_dfp, sizeof(double) * size_t(count), hipMemcpyDeviceToHost, c->stream));
+        LBFGSX_HIP(hipMemcpyAsync(hB, b->s_fpp, sizeof(double) * size_t(count), hipMemcpyDeviceToHost, c->stream));
+        LBFGSX_HIP(hipStreamSynchronize(c->stream));
+        const int64_t e = gcp_chain_host(hdt, hA, hB, count, fp_h, fpp_h);
+        const unsigned long long ex = (e >= 0) ? (unsigned long long) e : ~0ull;
+        LBFGSX_HIP(hipMemcpyAsync(b->s_exit, &ex, sizeof(ex), hipMemcpyHostToDevice, c->stream));
+        switch (NC)
+        {
+        case 4: gcp_extract_nc<4>(c, gb, count, theta); break;
+        case 8: gcp_extract_nc<8>(c, gb, count, theta); break;
+        case 12: gcp_extract_nc<12>(c, gb, count, theta); break;
+        case 16: gcp_extract_nc<16>(c, gb, count, theta); break;
+        case 20: gcp_extract_nc<20>(c, gb, count, theta); break;
+        case 24: gcp_extract_nc<24>(c, gb, count, theta); break;
+        case 28: gcp_extract_nc<28>(c, gb, count, theta); break;
+        default: gcp_extract_nc<32>(c, gb, count, theta); break;
+        }
+        LBFGSX_HIP(hipGetLastError());
+    }
     double o[2 * 32 + 4];
     const double* dout = b->s_small + (NC * NC + NC + (NC + 1) + 1 + (NC + 1));
     LBFGSX_HIP(hipMemcpyAsync(o, dout, sizeof(double) * size_t(2 * NC + 4), hipMemcpyDeviceToHost, c->stream));
@@ -949,8 +1027,8 @@ int lbfgsx_b_cauchy_scan(lbfgsx_ctx* c, int64_t first, int64_t count, int64_t no
         state_out[j] = o[j];
         state_out[nc2 + j] = o[NC + j];
     }
-    state_out[2 * nc2] = o[2 * NC];          // f'
-    state_out[2 * nc2 + 1] = o[2 * NC + 1];  // f''
+    state_out[2 * nc2] = b->chain_host ? fp_h : o[2 * NC];           // f'
+    state_out[2 * nc2 + 1] = b->chain_host ? fpp_h : o[2 * NC + 1];  // f''
     state_out[2 * nc2 + 2] = o[2 * NC + 2];  // break point of the last processed crossing
     *exit_at = (o[2 * NC + 3] < 0.0) ? int64_t(-1) : first + int64_t(o[2 * NC + 3]);
     return LBFGSX_OK;
