@@ -78,7 +78,7 @@ def test_cfg4_parity_at_size(A, boracle, monkeypatch, n, iters, devmin):
     assert per_eval.max() <= 1e-10, "iterates deviate by %.3g" % per_eval.max()
     assert np.abs(x - x_ref).max() <= 1e-10
     assert np.array_equal(np.abs(x) == 1.0, np.abs(x_ref) == 1.0)
-    assert abs(fx - r_ref.fx) <= 1e-13 * abs(r_ref.fx)
+    assert abs(fx - r_ref.fx) <= 1e-11 * abs(r_ref.fx)
 
 
 @pytest.mark.parametrize("n,m,npairs,mode", [(50000, 6, 6, "hard"), (200000, 10, 10, "edge"), (4096, 8, 0, "hard")])
