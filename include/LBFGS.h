@@ -28,6 +28,7 @@
 #include "LBFGSpp/BKLDLT.h"
 #include "LBFGSpp/DenseHessian.h"
 #include "LBFGSpp/Device.h"
+#include "LBFGSpp/Interop.h"
 #include "LBFGSpp/GramSpace.h"
 #include "LBFGSpp/LineSearchBacktracking.h"
 #include "LBFGSpp/LineSearchBracketing.h"
@@ -43,7 +44,7 @@ class LBFGSSolver
     const LBFGSParam<Scalar>& m_param;  // non-owning, like the reference (LBFGS.h:29)
     DeviceState<Scalar> m_dev;
     std::vector<Scalar> m_fx;           // ring of past objective values
-    std::vector<Scalar> m_grad_host;    // filled lazily by final_grad()
+    mutable detail::ResultVector<Scalar> m_grad_host;  // filled lazily by final_grad()
     Scalar m_gnorm = Scalar(0);
     int m_device = 0;
     int m_nfev = 0;
@@ -124,7 +125,9 @@ class LBFGSSolver
             const Scalar step_max = m_param.max_step;
             try
             {
-                LineSearch<Scalar>::LineSearch(ev, m_param, step_max, step, fx, dg);
+                // the device form of the built-in policies, or the reference's ten-argument form of a user policy
+                // staged through host vectors (LBFGSpp/Interop.h)
+                detail::run_line_search<Scalar, LineSearch<Scalar>, HostVec>(ev, m_param, step_max, step, fx, dg);
             }
             catch (...)
             {
@@ -240,7 +243,18 @@ public:
         const std::int64_t n = std::int64_t(x.size());
         m_dev.ensure(n, m_param.m, 0, m_device);
         m_dev.upload(LBFGSX_VEC_X, x.data());
-        const int k = run<Foo, Vec>(f, fx);
+        int k = 0;
+        try
+        {
+            k = run<Foo, Vec>(f, fx);
+        }
+        catch (...)
+        {
+            // a line search that throws leaves its last trial point in the caller's x (the reference's policies write
+            // the trial into x itself, LineSearchNocedalWright.h:146, LineSearchMoreThuente.h:412)
+            (void) lbfgsx_download(m_dev.ctx(), LBFGSX_VEC_XT, x.data());
+            throw;
+        }
         m_dev.download(LBFGSX_VEC_X, x.data());
         return k;
     }
@@ -255,10 +269,12 @@ public:
     }
     void prepare_resident(std::int64_t n) { m_dev.ensure(n, m_param.m, 0, m_device); }
 
-    // final_grad(): copied back on demand (the reference returns its host member, LBFGS.h:182)
-    const std::vector<Scalar>& final_grad()
+    // final_grad(): copied back on demand (the reference returns its host member, LBFGS.h:182).  Eigen's vector type
+    // when Eigen is on the include path (so .norm(), .transpose() and streaming work as in the reference's examples),
+    // std::vector otherwise (LBFGSpp/Interop.h).
+    const detail::ResultVector<Scalar>& final_grad() const
     {
-        m_grad_host.resize(size_t(m_dev.size()));
+        m_grad_host.resize(m_dev.size());
         m_dev.download(LBFGSX_VEC_G, m_grad_host.data());
         return m_grad_host;
     }
@@ -266,13 +282,13 @@ public:
 
     // final_approx_hessian() / final_approx_inverse_hessian() (LBFGS.h:192-197): explicit n x n matrices built on
     // the host from a copy of the history -- a debugging aid for small n, exactly as in the reference
-    DenseMatrix<Scalar> final_approx_hessian()
+    detail::ResultMatrix<Scalar> final_approx_hessian() const
     {
-        return detail::dense_B(detail::fetch_history<Scalar>(m_dev.ctx(), int(m_dev.size()), m_param.m));
+        return detail::to_result_matrix(detail::dense_B(detail::fetch_history<Scalar>(m_dev.ctx(), int(m_dev.size()), m_param.m)));
     }
-    DenseMatrix<Scalar> final_approx_inverse_hessian()
+    detail::ResultMatrix<Scalar> final_approx_inverse_hessian() const
     {
-        return detail::dense_H(detail::fetch_history<Scalar>(m_dev.ctx(), int(m_dev.size()), m_param.m));
+        return detail::to_result_matrix(detail::dense_H(detail::fetch_history<Scalar>(m_dev.ctx(), int(m_dev.size()), m_param.m)));
     }
 };
 

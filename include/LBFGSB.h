@@ -24,6 +24,7 @@
 #include "LBFGSpp/BFGSMat.h"
 #include "LBFGSpp/Cauchy.h"
 #include "LBFGSpp/Device.h"
+#include "LBFGSpp/Interop.h"
 #include "LBFGSpp/LineSearchMoreThuente.h"
 #include "LBFGSpp/Param.h"
 #include "LBFGSpp/SubspaceMin.h"
@@ -37,7 +38,7 @@ class LBFGSBSolver
     DeviceState<Scalar> m_dev;
     BFGSMatB<Scalar> m_bfgs;
     std::vector<Scalar> m_fx;
-    std::vector<Scalar> m_grad_host;
+    mutable detail::ResultVector<Scalar> m_grad_host;
     Scalar m_projgnorm = Scalar(0);
     int m_device = 0;
     int m_nfev = 0;
@@ -117,7 +118,9 @@ private:
             const auto t_ls = std::chrono::steady_clock::now();
             try
             {
-                LineSearch<Scalar>::LineSearch(ev, m_param, step_max, step, fx, dg);
+                // the device form of the built-in policies, or the reference's ten-argument form of a user policy
+                // staged through host vectors (LBFGSpp/Interop.h)
+                detail::run_line_search<Scalar, LineSearch<Scalar>, HostVec>(ev, m_param, step_max, step, fx, dg);
             }
             catch (...)
             {
@@ -201,7 +204,17 @@ public:
         m_dev.upload(LBFGSX_VEC_X, x.data());
         m_dev.upload(LBFGSX_VEC_LB, lb.data());
         m_dev.upload(LBFGSX_VEC_UB, ub.data());
-        const int k = run<Foo, Vec>(f, fx);
+        int k = 0;
+        try
+        {
+            k = run<Foo, Vec>(f, fx);
+        }
+        catch (...)
+        {
+            // as in the reference, a line search that throws leaves its last trial point in x (LineSearchMoreThuente.h:412)
+            (void) lbfgsx_download(m_dev.ctx(), LBFGSX_VEC_XT, x.data());
+            throw;
+        }
         m_dev.download(LBFGSX_VEC_X, x.data());
         return k;
     }
@@ -215,9 +228,10 @@ public:
     }
     void prepare_resident(std::int64_t n) { m_dev.ensure(n, m_param.m, LBFGSX_FLAG_BOUNDED, m_device); }
 
-    const std::vector<Scalar>& final_grad()
+    // Eigen's vector type when Eigen is on the include path, std::vector otherwise (LBFGSpp/Interop.h; LBFGSB.h:271)
+    const detail::ResultVector<Scalar>& final_grad() const
     {
-        m_grad_host.resize(size_t(m_dev.size()));
+        m_grad_host.resize(m_dev.size());
         m_dev.download(LBFGSX_VEC_G, m_grad_host.data());
         return m_grad_host;
     }

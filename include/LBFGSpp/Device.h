@@ -129,8 +129,12 @@ class Evaluator
     int m_nfev = 0;
 
     static constexpr bool is_builtin = std::is_same<typename std::decay<Foo>::type, BuiltinObjective<Scalar> >::value;
+    // A functor that accepts the caller's host vectors is a host functor even if it would also accept device vectors
+    // (a generic `template <class V> operator()(const V&, V&)` or `[](const auto& x, auto& g)` satisfies both traits;
+    // handing it raw HBM pointers to dereference on the host would crash).  Device functors name DeviceVector.
+    static constexpr bool is_host = !is_builtin && std::is_invocable<Foo&, const HostVec&, HostVec&>::value;
     static constexpr bool is_device =
-        std::is_invocable<Foo&, const DeviceVector<Scalar>&, DeviceVector<Scalar>&>::value;
+        !is_host && std::is_invocable<Foo&, const DeviceVector<Scalar>&, DeviceVector<Scalar>&>::value;
 
     // evaluate the user functor at (xwhich) writing (gwhich); returns fx
     Scalar call_user(int xwhich, int gwhich)
@@ -251,6 +255,42 @@ public:
         dg = Scalar(r1);
         if (on_eval) on_eval(m_nfev, fx);
         m_nfev++;
+    }
+    // ---- compatibility path of detail::run_line_search (LBFGSpp/Interop.h): a line-search policy with the reference's
+    // signature drives the search on host vectors.  fx = f(x, grad) at a host point, whatever kind of objective Foo is.
+    template <typename Vec>
+    Scalar eval_host_point(const Vec& x, Vec& grad)
+    {
+        Scalar fx;
+        if constexpr (is_builtin)
+        {
+            // the point goes into the trial buffer, which becomes the current one for the evaluation kernel
+            m_s.upload(LBFGSX_VEC_XT, x.data());
+            check(lbfgsx_ls_end(m_s.ctx(), 0));
+            double r0 = 0;
+            check(lbfgsx_eval(m_s.ctx(), m_f.id, &r0, nullptr, nullptr));
+            m_s.download(LBFGSX_VEC_G, grad.data());
+            fx = Scalar(r0);
+        }
+        else if constexpr (is_device)
+        {
+            m_s.upload(LBFGSX_VEC_XT, x.data());
+            fx = call_user(LBFGSX_VEC_XT, LBFGSX_VEC_GT);
+            m_s.download(LBFGSX_VEC_GT, grad.data());
+        }
+        else
+            fx = m_f(x, grad);
+        if (on_eval) on_eval(m_nfev, fx);
+        m_nfev++;
+        return fx;
+    }
+    // the point the policy settled on becomes the accepted one (x, grad of LBFGS.h:127 after the search)
+    template <typename Vec>
+    void finish_host_point(const Vec& x, const Vec& grad)
+    {
+        m_s.upload(LBFGSX_VEC_XT, x.data());
+        m_s.upload(LBFGSX_VEC_GT, grad.data());
+        check(lbfgsx_ls_end(m_s.ctx(), 0));
     }
     // x_lo.swap(x); grad_lo.swap(grad)
     void keep_trial_as_lo() { check(lbfgsx_ls_keep_trial_as_lo(m_s.ctx())); }

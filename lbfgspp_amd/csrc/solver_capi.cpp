@@ -120,7 +120,8 @@ struct LbfgsImpl : lbfgsx_solver
     }
     int hessians(double* B, double* H) override
     {
-        const DenseMatrix<Scalar> mb = solver->final_approx_hessian(), mh = solver->final_approx_inverse_hessian();
+        const auto mb = solver->final_approx_hessian();
+        const auto mh = solver->final_approx_inverse_hessian();
         const int n = mb.rows();
         for (int j = 0; j < n; j++)
             for (int i = 0; i < n; i++)

@@ -111,3 +111,39 @@ def test_bench_and_smoke_fail_loudly_without_a_gpu():
     r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=ROOT,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode != 0 and "smoke() needs a GPU" in r.stdout
+
+
+REF_EXAMPLES = "/root/reference/examples"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_EXAMPLES), reason="the reference checkout only exists in the build container")
+@pytest.mark.parametrize("example", ["example-quadratic.cpp", "example-rosenbrock.cpp", "example-rosenbrock-box.cpp",
+                                     "example-rosenbrock-bracketing.cpp", "example-rosenbrock-comparison.cpp"])
+def test_reference_examples_build_verbatim_against_the_dropin_headers(tmp_path, example):
+    """The reference's example programs, UNMODIFIED and read where they lie, compile and link against include/ +
+    liblbfgsx.so with a plain g++ (oracle/eigen_shim stands in for Eigen, which is not installed): Eigen vector types
+    through minimize(), final_grad().transpose(), streaming final_approx_hessian(), every line-search policy as the
+    template argument, LBFGSBSolver with Eigen bounds.  They run on the GPU box as tests/cpp/test_dropin.cpp (re-typed)
+    and tests/cpp/test_reference_policy.cpp (Eigen-typed); here the point is that nothing had to be edited."""
+    import subprocess
+    lib = os.path.join(ROOT, "lbfgspp_amd")
+    if not os.path.exists(os.path.join(lib, "liblbfgsx.so")):
+        pytest.skip("liblbfgsx.so not built")
+    cmd = ["g++", "-std=c++17", "-O0", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "oracle", "eigen_shim"),
+           os.path.join(REF_EXAMPLES, example), "-o", str(tmp_path / "a.out"), "-L" + lib, "-llbfgsx", "-L/opt/rocm/lib",
+           "-lamdhip64", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:]
+
+
+def test_user_policy_program_compiles_without_a_gpu(tmp_path):
+    import subprocess
+    cmd = ["g++", "-std=c++17", "-O0", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
+           "-I", os.path.join(ROOT, "oracle", "eigen_shim"), os.path.join(ROOT, "tests", "cpp", "test_reference_policy.cpp")]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:]
+    # and the std::vector flavour still builds with Eigen hidden
+    cmd = ["g++", "-std=c++17", "-O0", "-fsyntax-only", "-DLBFGSX_NO_EIGEN", "-I", os.path.join(ROOT, "include"),
+           "-I", os.path.join(ROOT, "oracle", "eigen_shim"), os.path.join(ROOT, "tests", "cpp", "test_dropin.cpp")]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:]

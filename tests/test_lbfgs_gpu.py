@@ -286,3 +286,36 @@ def test_persistent_two_loop_is_bit_identical(A, oracle, monkeypatch, dtype, n, 
     x_ref, r = oracle.lbfgs(dtype, O.LS_MT, O.OBJ_ROSEN, x0, O.lbfgs_params(m=m, epsilon=0, epsilon_rel=0,
                                                                             max_iterations=2 * m + 5))
     assert (r.niter, r.nfev) == res["1"][:2] and np.array_equal(res["1"][3], x_ref)
+
+
+@pytest.mark.parametrize("obj,ls,window,tol", [(O.OBJ_ROSEN, O.LS_MT, 40, 1e-10), (O.OBJ_QUAD, O.LS_NW, 50, 1e-12)])
+def test_drift_against_the_native_accumulator_reference(A, obj, ls, window, tol):
+    """north_star: "match the Eigen reference iterate-for-iterate within 1e-10".  Every other trajectory test compares
+    with the reference built on extended-precision sums (bit-identical); this one compares with the SAME reference
+    headers built with native accumulators (plain f64 sums in index order: Eigen's reductions up to their packet order,
+    oracle/_ref/libref_native.so).  A different summation order alone separates two correct runs chaotically (SURVEY
+    7(1e)), so the bound holds over a window: 1e-10 through the first 40 objective evaluations (about 30 iterations)
+    of the extended Rosenbrock run -- the full curve, which leaves the band at evaluation ~50, is committed as
+    profiles/r2_drift_native_accumulators.json (scripts/drift_curves.py native) -- and 1e-12 over all 40 iterations of
+    the convex quadratic.  Reference: BFGSMat.h:276-302, LBFGS.h:78-173."""
+    if not O.available("ref", "native"):
+        pytest.skip("oracle/_ref/libref_native.so not built")
+    nat = O.Oracle("ref", "native")
+    n, m, iters = 200000, 10, 40
+    p = O.lbfgs_params(m=m, epsilon=0, epsilon_rel=0, max_iterations=iters)
+    if obj == O.OBJ_ROSEN:
+        x0, a, b, f = O.rosen_x0(n), None, None, A.ExtendedRosenbrock()
+    else:
+        a, b = O.quad_problem(n, 10.0, 1, O.F64)
+        x0, f = np.zeros(n), A.DiagQuadratic(a, b)
+    tn, tg = O.TraceBuf(n, cap=512, stride=7), A.TraceBuffer(n, cap=512, stride=7)
+    xn, rn = nat.lbfgs(O.F64, ls, obj, x0, p, a=a, b=b, trace=tn)
+    s = A.LBFGSSolver(A.LBFGSParam(m=m, epsilon=0, epsilon_rel=0, max_iterations=iters),
+                      linesearch=A.LS_MORE_THUENTE if ls == O.LS_MT else A.LS_NOCEDAL_WRIGHT)
+    x = x0.copy()
+    niter, fx = s.minimize(f, x, trace=tg)
+    assert (niter, s.last.nfev) == (rn.niter, rn.nfev)    # same decisions all the way
+    k = min(window, tg.count)
+    err = np.abs(tg.xs[:k] - tn.xs[:k]).max(axis=1)
+    assert err.max() <= tol, "evaluation %d deviates by %.3g" % (int(err.argmax()), err.max())
+    assert err[:8].max() <= 1e-13                          # SURVEY probe: 1.7e-13 at K = 10
