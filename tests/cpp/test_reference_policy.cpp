@@ -162,7 +162,6 @@ int main()
     {
         LBFGSParam<Scalar> p2;
         p2.max_linesearch = 1;
-        p2.ftol = 0.9;
         p2.linesearch = LBFGS_LINESEARCH_BACKTRACKING_ARMIJO;
         RosenbrockPairs f{n};
         LBFGSSolver<Scalar, LineSearchBacktracking> s(p2);
