@@ -331,8 +331,9 @@ int lbfgsx_timing_read(lbfgsx_ctx* c, double* twoloop_ms_total, int64_t* twoloop
                        double* applyhv_ms_total, int64_t* applyhv_calls);
 /* number of apply_Hv calls of this context served by the persistent one-launch kernel (k_twoloop_persist: the
  * whole recursion in one launch of occupancy x CUs blocks with part of q resident on the CUs).  It is used when
- * m <= 32, LBFGSX_PERSIST != 0 and this context is the only live one of the
- * process on its device; otherwise apply_Hv issues its 2c+1 step launches.  Results are bit-identical. */
+ * m <= 128 and LBFGSX_PERSIST != 0, one such kernel per device at a time within the process (a per-device lock taken
+ * for the launch; a context that finds it taken issues its 2c+1 step launches for that call, as does one whose launch
+ * timed out because another process shares the GPU).  Results are bit-identical either way. */
 int64_t lbfgsx_persistent_launches(const lbfgsx_ctx* c);
 /* elements of q (= the direction vector, BFGSMat.h:283-301 `res`) that a persistent launch of this context keeps in the
  * registers / LDS of the CUs for the whole recursion: that share of q's traffic never reaches HBM (0: not available) */

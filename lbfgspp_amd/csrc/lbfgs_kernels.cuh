@@ -547,10 +547,11 @@ __device__ __forceinline__ void hv_step(Pack<T> (&rq)[NR], typename Vec16<T>::ty
 // are those of k_twoloop, so the result is bit-identical to the 2c+1 launches.
 //   n = 1e7 (cfg2): all of q fits (39 of the 45 slots): 2n elements per step instead of 4n.
 //   n = 1e8 (north-star): 12 % of q fits.
+constexpr int kPersistMaxM = 128;  // history pairs a persistent launch can describe (the column list rides in the arguments)
 struct PersistArgs
 {
     int ncorr, m;
-    int pcol[32];          // physical columns newest -> oldest
+    int pcol[kPersistMaxM];  // physical columns newest -> oldest
     unsigned gen_base;     // generation word value before this launch
     int zigzag;
     unsigned first_rev;    // direction parity of the first step
@@ -571,9 +572,9 @@ __global__ void __launch_bounds__(kHvThreads, 2)
     constexpr int W = Vec16<T>::W;
     constexpr int NR = kPersistNR, NL = kPersistNL, U = 4;
     __shared__ typename Vec16<T>::type lq[NL * kHvThreads];
-    __shared__ int s_pcol[32];  // dynamic indexing: keep the column list out of scratch
+    __shared__ int s_pcol[kPersistMaxM];  // dynamic indexing: keep the column list out of scratch
     const int tid = threadIdx.x;
-    if (tid < 32)
+    if (tid < kPersistMaxM)
         s_pcol[tid] = pa.pcol[tid];
     __syncthreads();
     const int cn = pa.ncorr, m = pa.m;
@@ -714,13 +715,17 @@ __global__ void __launch_bounds__(kHvThreads, 2)
             if (tid == 0)
             {
                 unsigned spins = 0;
+                const unsigned long long t_begin = wall_clock64();  // constant 100 MHz counter (s_memrealtime)
                 while (int(__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0)
                 {
                     __builtin_amdgcn_s_sleep(8);
-                    // never hang the device: after ~1 s of polling (or as soon as another block gave up) flag the
-                    // launch as failed and run to the end; the host reports LBFGSX_E_HIP
-                    if ((++spins & 1023u) == 0u &&
-                        (spins > (1u << 22) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
+                    // never hang the device: a step of the largest problem takes well under 1 ms, so after 100 ms of
+                    // wall-clock waiting (or as soon as another block gave up) the blocks are not all resident -- some
+                    // other process holds CUs.  Flag the launch as failed and run to the end; the host redoes the
+                    // product with the step launches.
+                    if ((++spins & 255u) == 0u &&
+                        (wall_clock64() - t_begin > 10000000ull ||
+                         __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
                     {
                         __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         break;

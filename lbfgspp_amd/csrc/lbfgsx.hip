@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "ctx.hpp"
 #include "lbfgs_kernels.cuh"
@@ -20,6 +21,12 @@ void live_add(int device, int delta)
 }
 int live_count(int device) { return (device >= 0 && device < 64) ? g_live[device].load() : 2; }
 
+
+// One persistent two-loop kernel per device at a time (within this process): its blocks wait for each other at grid-wide
+// meeting points, so two of them, each partly resident, could wait forever.  Ordinary kernels of other contexts only
+// delay residency -- they always finish.  apply_Hv takes the device's lock for the launch and the synchronisation that
+// ends it; a context that finds the lock taken (worker threads of a pool) issues the step launches for that call.
+static std::mutex g_persist_mu[64];
 
 static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
@@ -637,13 +644,16 @@ static int apply_Hv_t(lbfgsx_ctx* c, const T* v, T a, double* dg)
         LBFGSX_HIP(hipEventCreate(&hv.b));
         LBFGSX_HIP(hipEventRecord(hv.a, c->stream));
     }
-    if (c->persist && c->persist_grid > 0 && m <= 32 && live_count(c->device) == 1)
+    std::unique_lock<std::mutex> persist_lock;
+    if (c->persist && c->persist_grid > 0 && m <= kPersistMaxM && c->device >= 0 && c->device < 64)
+        persist_lock = std::unique_lock<std::mutex>(g_persist_mu[c->device], std::try_to_lock);
+    if (persist_lock.owns_lock())
     {
         // ONE launch for the 2c+1 steps (k_twoloop_persist)
         PersistArgs pa;
         pa.ncorr = cn;
         pa.m = m;
-        for (int i = 0; i < 32; i++)
+        for (int i = 0; i < kPersistMaxM; i++)
             pa.pcol[i] = i < cn ? pcol[i] : 0;
         pa.gen_base = c->gen_count;
         pa.zigzag = c->zigzag ? 1 : 0;
@@ -651,10 +661,12 @@ static int apply_Hv_t(lbfgsx_ctx* c, const T* v, T a, double* dg)
         pa.ld = c->ld;
         c->gen_count += unsigned(2 * cn + 1);
         c->tl_step += unsigned(2 * cn + 1);
-        // A plain launch of exactly occupancy * CUs blocks: with this context the only live one and its stream in
-        // order, every block is resident when the kernel starts.  (hipLaunchCooperativeKernel would have the runtime
-        // check that, but rocprofv3 crashes at exit after cooperative launches on this stack; the kernel's meeting
-        // points are bounded polls, so a violated assumption ends in LBFGSX_E_HIP, never in a hang.)
+        // A plain launch of exactly occupancy * CUs blocks.  No other persistent kernel of this process is in flight on
+        // the device (the lock above, held until the synchronisation below), so every block becomes resident as soon
+        // as the ordinary kernels ahead of it retire.  hipLaunchCooperativeKernel adds nothing to that inside one
+        // process and rocprofv3 crashes at exit after cooperative launches on this stack; a device shared with another
+        // PROCESS is caught by the wall-clock bound of the kernel's meeting points (the product is then redone with
+        // the step launches), never by a hang.
         hipLaunchKernelGGL((k_twoloop_persist<T>), dim3(c->persist_grid), dim3(kHvThreads), 0, c->stream, q, v, a,
                            P<T>(c->S), P<T>(c->Y), c->n, sc, pa, c->ws, c->gen_dev, reinterpret_cast<int*>(c->gen_dev + 1));
         LBFGSX_HIP(hipGetLastError());
@@ -680,6 +692,7 @@ static int apply_Hv_t(lbfgsx_ctx* c, const T* v, T a, double* dg)
             LBFGSX_HIP(hipMemsetAsync(c->ws.ticket, 0, sizeof(unsigned), c->stream));
             c->gen_count = 0;
             c->persist = false;
+            persist_lock.unlock();
             if (c->timing && !c->ev_hv.empty())
             {
                 (void) hipEventDestroy(c->ev_hv.back().a);

@@ -261,9 +261,8 @@ def test_lbfgs_golden(A, case):
 
 @pytest.mark.parametrize("dtype,n,m", [(O.F64, 300002, 7), (O.F32, 100002, 5), (O.F64, 2048, 12)])
 def test_persistent_two_loop_is_bit_identical(A, oracle, monkeypatch, dtype, n, m):
-    """k_twoloop_persist (one cooperative launch per apply_Hv, part of q resident on the CUs) against the 2c+1 step
-    launches and against the oracle.  The persistent kernel only runs while its context is the single live one, so
-    stale solver objects are collected first and its use is asserted through lbfgsx_persistent_launches."""
+    """k_twoloop_persist (one launch per apply_Hv, part of q resident on the CUs) against the 2c+1 step launches and
+    against the oracle; its use is asserted through lbfgsx_persistent_launches."""
     import ctypes as C
     import gc
     core, _ = A.load()
@@ -286,6 +285,32 @@ def test_persistent_two_loop_is_bit_identical(A, oracle, monkeypatch, dtype, n, 
     x_ref, r = oracle.lbfgs(dtype, O.LS_MT, O.OBJ_ROSEN, x0, O.lbfgs_params(m=m, epsilon=0, epsilon_rel=0,
                                                                             max_iterations=2 * m + 5))
     assert (r.niter, r.nfev) == res["1"][:2] and np.array_equal(res["1"][3], x_ref)
+
+
+def test_two_live_solvers_on_one_device_both_use_the_persistent_kernel(A, oracle):
+    """Round 1 used the one-launch recursion only while its context was the single live one of the process.  The
+    requirement is narrower -- at most one PERSISTENT kernel in flight per device -- and is kept by a per-device lock held
+    for the launch: two live solvers driven alternately both get it, m > 32 included, and nothing changes in the bits."""
+    import ctypes as C
+    core, _ = A.load()
+    core.lbfgsx_persistent_launches.restype = C.c_int64
+    core.lbfgsx_persistent_launches.argtypes = [C.c_void_p]
+    n = 120002
+    x0 = O.rosen_x0(n, 5, O.F64)
+    pars = [dict(m=6, it=16), dict(m=40, it=44)]
+    solvers = [A.LBFGSSolver(A.LBFGSParam(m=p["m"], epsilon=0.0, epsilon_rel=0.0, max_iterations=p["it"]),
+                             linesearch=A.LS_MORE_THUENTE) for p in pars]
+    xs = [x0.copy(), x0.copy()]
+    out = [None, None]
+    for rnd in range(2):           # both contexts stay alive across both rounds
+        for k, s in enumerate(solvers):
+            xs[k] = x0.copy()
+            out[k] = s.minimize(A.ExtendedRosenbrock(), xs[k])
+    for k, s in enumerate(solvers):
+        assert int(core.lbfgsx_persistent_launches(s.ctx)) > 0, "solver %d fell back to the step launches" % k
+        x_ref, r = oracle.lbfgs(O.F64, O.LS_MT, O.OBJ_ROSEN, x0, O.lbfgs_params(m=pars[k]["m"], epsilon=0, epsilon_rel=0,
+                                                                                max_iterations=pars[k]["it"]))
+        assert (r.niter, r.nfev) == (out[k][0], s.last.nfev) and np.array_equal(xs[k], x_ref)
 
 
 @pytest.mark.parametrize("obj,ls,window,tol", [(O.OBJ_ROSEN, O.LS_MT, 40, 1e-10), (O.OBJ_QUAD, O.LS_NW, 50, 1e-12)])
