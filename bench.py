@@ -29,7 +29,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (about 6.3 TB/s achievable)
 
 
-def pmc_traffic(n, m):
+def pmc_traffic(n, m, fused=False):
     """HBM bytes per two-loop step from a committed rocprofv3 PMC summary (profiles/*_pmc_summary.json, produced by
     scripts/profile.sh + scripts/summarize_profile.py on this same command) -- used only when that profile was taken
     at exactly this (n, m); PMC counters cannot be collected from inside the timed process."""
@@ -39,7 +39,7 @@ def pmc_traffic(n, m):
         try:
             d = json.load(open(f))
             t = d.get("twoloop_avg_hbm_bytes_per_launch")
-            if t and int(d.get("n", 0)) == int(n) and int(d.get("m", 0)) == int(m):
+            if t and int(d.get("n", 0)) == int(n) and int(d.get("m", 0)) == int(m) and bool(d.get("fused_post", False)) == fused:
                 best = {"bytes_per_launch": t, "source": os.path.relpath(f, ROOT)}
         except Exception:
             pass
@@ -315,6 +315,9 @@ def run_north_star(args, rank, world, local, comm_dev, dist):
             tl_ms, tl_n, hv_ms, hv_n = C.c_double(), C.c_int64(), C.c_double(), C.c_int64()
             L.check(core.lbfgsx_timing_read(ctx, C.byref(tl_ms), C.byref(tl_n), C.byref(hv_ms), C.byref(hv_n)))
             marks["tl"] = (tl_ms.value, tl_n.value, hv_ms.value, hv_n.value)
+            core.lbfgsx_timing_fused_launches.restype = C.c_int64
+            core.lbfgsx_timing_fused_launches.argtypes = [C.c_void_p]
+            marks["fused"] = core.lbfgsx_timing_fused_launches(ctx)
             L.check(core.lbfgsx_timing_enable(ctx, 0))
 
     solver.set_iteration_hook(hook)
@@ -335,6 +338,9 @@ def run_north_star(args, rank, world, local, comm_dev, dist):
     core.lbfgsx_persistent_resident_elems.restype = C.c_int64
     core.lbfgsx_persistent_resident_elems.argtypes = [C.c_void_p]
     resident = core.lbfgsx_persistent_resident_elems(ctx) if persist_launches > 0 else 0
+    core.lbfgsx_timing_fused_launches.restype = C.c_int64
+    core.lbfgsx_timing_fused_launches.argtypes = [C.c_void_p]
+    fused = int(marks.get("fused", 0))
     nfev, last_niter = solver.last.nfev, niter
     del solver  # release the device context (the batched leg and the profilers' atexit handlers come next)
     import gc
@@ -345,6 +351,11 @@ def run_north_star(args, rank, world, local, comm_dev, dist):
     tl_ms, tl_n, hv_ms, hv_n = marks["tl"]
     esz = 8
     hv_bytes = (8 * m + 1) * n * esz  # algorithmic bytes per apply_Hv call, history full
+    # launches that carry K3 as their step 0 (lbfgsx_post_linesearch_spec): K3's 6n elements ride along and the first
+    # step's reads of grad and the new s (2n) are gone: (8m+5) n per launch.  The per-step figure stays launch / (2m+1).
+    fused_all = fused > 0 and fused == hv_n
+    if fused_all:
+        hv_bytes = (8 * m + 5) * n * esz
     per_launch_bytes = hv_bytes / float(2 * m + 1)
     avg_launch_s = (tl_ms / max(tl_n, 1)) * 1e-3
     alg_gbs = per_launch_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
@@ -363,7 +374,7 @@ def run_north_star(args, rank, world, local, comm_dev, dist):
             post_bytes, comb_bytes = (2 * m * 4 + 4 * esz + 2 * 4) * n, (2 * m * 4 + 2 * esz) * n
         post_s, comb_s = tl_ms / max(tl_n, 1) * 1e-3, hv_ms / max(hv_n, 1) * 1e-3
         achieved = post_bytes / post_s / 1e9 if post_s > 0 else 0.0
-    pmc = pmc_traffic(n, m) if persist_launches > 0 and not gram else None
+    pmc = pmc_traffic(n, m, fused_all) if persist_launches > 0 and not gram else None
     out = {
         # BASELINE.json's metric string for the north-star configuration; other sizes say what they are
         "metric": ("L-BFGS iterations/sec of ONE problem n=%d row-sharded over %d GPU(s), m=%d (%s), Gram-space recursion%s "
@@ -390,9 +401,11 @@ def run_north_star(args, rank, world, local, comm_dev, dist):
                                "diag quadratic kappa=10 n=%d m=%d f64 LineSearchNocedalWright" % (n, m),
                    "n": n, "m": m, "problems_per_gpu": 1, "warmup_run": W, "history_full": bool(history_full),
                    "fevals_total": nfev, "iterations_total": last_niter,
-                   "apply_Hv_persistent_launches": int(persist_launches)},
+                   "apply_Hv_persistent_launches": int(persist_launches), "fused_post_launches_timed": fused},
         "roofline": {"bound": "hbm",
-                     "kernel": ("k_twoloop_persist (one launch per apply_Hv = 2c+1 two-loop steps, axpy + dot each; "
+                     "kernel": ("k_twoloop_persist<fused post> (one launch = K3's statements as step 0 + the 2c+1 two-loop "
+                                "steps, (8m+5) n elements; the figures below are per step = launch / (2c+1))") if fused_all else
+                               ("k_twoloop_persist (one launch per apply_Hv = 2c+1 two-loop steps, axpy + dot each; "
                                 "the figures below are per step = launch / (2c+1))") if persist_launches > 0 else
                                "k_twoloop (two-loop recursion step: axpy + dot)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -8,9 +8,9 @@
 //     :106-108 drt = -grad, 1/drt.norm()            -> lbfgsx_apply_Hv with an empty history
 //     :121-123 xp = x, gradp = grad, grad.dot(drt)  -> lbfgsx_ls_begin (rotation) + dot fused into K1
 //     :127    line search                           -> LineSearch policies over lbfgsx_trial (K2)
-//     :130,137,159-161 norms, s, y, s.y, y.y        -> lbfgsx_post_linesearch (K3)
+//     :130,137,159-161 norms, s, y, s.y, y.y        -> lbfgsx_post_linesearch_spec (K3 as step 0 of the recursion's launch)
 //     :162    add_correction                        -> lbfgsx_commit_correction (index rotation)
-//     :165    apply_Hv                              -> lbfgsx_apply_Hv          (2c+1 launches of K1)
+//     :165    apply_Hv                              -> lbfgsx_apply_Hv          (one persistent launch, or 2c+1 of K1)
 // `Foo` may be a BuiltinObjective (fused kernels), a device functor
 // `Scalar(const DeviceVector<Scalar>&, DeviceVector<Scalar>&)`, or a host functor on `Vec` (compatibility
 // path, stages x/grad through host memory at every evaluation).
@@ -161,8 +161,8 @@ class LBFGSSolver
                 syd = gs_scal[2];
                 yyd = gs_scal[3];
             }
-            else
-                detail::check(lbfgsx_post_linesearch(c, &g2, &x2, &syd, &yyd));
+            else  // K3, with the recursion of :165 speculated on top of it in the same launch (lbfgsx.h)
+                detail::check(lbfgsx_post_linesearch_spec(c, -1.0, &g2, &x2, &syd, &yyd));
             m_gnorm = sqrt(Scalar(g2));
             if (m_gnorm <= m_param.epsilon || m_gnorm <= m_param.epsilon_rel * sqrt(Scalar(x2)))
                 return k;

@@ -123,6 +123,19 @@ int lbfgsx_ls_end(lbfgsx_ctx* c, int use_lo);
 int lbfgsx_post_linesearch(lbfgsx_ctx* c, double* gnorm2, double* xnorm2, double* sy, double* yy);
 /* BFGSMat::add_correction of the pair just formed (BFGSMat.h:81-97): index rotation only */
 int lbfgsx_commit_correction(lbfgsx_ctx* c);
+/* lbfgsx_post_linesearch with the next statement of the driver folded in when the pair turns out usable:
+ *     s, y, the four sums (LBFGS.h:130,137,159-161)   and, speculatively,   drt = a * H * grad  (LBFGS.h:165)
+ * for the history "stored pairs + the pair just formed" -- as step 0 and steps 1..2c of ONE persistent launch: the first
+ * step of the recursion needs exactly grad and the new s, which the post pass holds in registers (2n elements fewer per
+ * iteration, one launch less).  The kernel applies the driver's test s.y > eps y.y (LBFGS.h:161) itself and stops after
+ * the post statements when it fails.  The caller proceeds exactly as after lbfgsx_post_linesearch: convergence tests,
+ * lbfgsx_commit_correction if the pair is accepted, lbfgsx_apply_Hv(LBFGSX_VEC_G, a) -- which returns the direction
+ * already computed when the speculation applies (same history, same gradient, same a) and computes it otherwise.
+ * Falls back to lbfgsx_post_linesearch when the persistent kernel is unavailable (LBFGSX_PERSIST=0, LBFGSX_FUSE_POST=0,
+ * m > 128, another persistent launch in flight on the device).  Bit-identical results either way. */
+int lbfgsx_post_linesearch_spec(lbfgsx_ctx* c, double a, double* gnorm2, double* xnorm2, double* sy, double* yy);
+/* instrumentation: {fused launches, directions taken over by lbfgsx_apply_Hv, pairs rejected by the kernel} */
+int lbfgsx_spec_counts(const lbfgsx_ctx* c, int64_t out[3]);
 
 /* ---- Gram-space ("vector-free") form of the recursion: opt-in, outside the bit-parity contract ----
  * BFGSMat::apply_Hv (BFGSMat.h:276-302) only combines the 2c+1 vectors [S, Y, g]; with their Gram matrix kept on the
@@ -335,6 +348,9 @@ int lbfgsx_timing_read(lbfgsx_ctx* c, double* twoloop_ms_total, int64_t* twoloop
  * for the launch; a context that finds it taken issues its 2c+1 step launches for that call, as does one whose launch
  * timed out because another process shares the GPU).  Results are bit-identical either way. */
 int64_t lbfgsx_persistent_launches(const lbfgsx_ctx* c);
+/* of the apply_Hv calls timed since lbfgsx_timing_enable, how many were persistent launches that also carried the post
+ * statements (lbfgsx_post_linesearch_spec): their algorithmic bytes are (8c+1) n for the product plus 6n - 2n for K3 */
+int64_t lbfgsx_timing_fused_launches(const lbfgsx_ctx* c);
 /* elements of q (= the direction vector, BFGSMat.h:283-301 `res`) that a persistent launch of this context keeps in the
  * registers / LDS of the CUs for the whole recursion: that share of q's traffic never reaches HBM (0: not available) */
 int64_t lbfgsx_persistent_resident_elems(const lbfgsx_ctx* c);

@@ -131,8 +131,17 @@ struct lbfgsx_ctx
     unsigned gen_count = 0;
     int64_t persist_steps_timed = 0;
     int64_t coarse_steps_timed = 0;
+    int64_t fused_timed = 0;       // timed persistent launches that carried the post statements as step 0
     bool counted = false;          // registered in the live-context count
     int64_t persist_launches = 0;  // instrumentation
+    // lbfgsx_post_linesearch_spec: the post statements ran as step 0 of a persistent launch that went on to compute the
+    // direction for "history + the pending pair"; lbfgsx_apply_Hv returns that result when the pair was committed
+    bool fuse_post = true;         // LBFGSX_FUSE_POST=0: never speculate
+    bool spec_valid = false;
+    unsigned spec_version = 0;     // phys_version the speculation is valid for (= after the commit)
+    int spec_cur = 0;              // point whose gradient it used
+    double spec_a = 0.0, spec_dg = 0.0;
+    int64_t spec_launches = 0, spec_used = 0, spec_rejected = 0;  // instrumentation
 
     // L-BFGS-B work set (allocated with LBFGSX_FLAG_BOUNDED) lives in lbfgsb part
     void* lb = nullptr;

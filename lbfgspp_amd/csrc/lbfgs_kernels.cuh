@@ -559,20 +559,117 @@ struct PersistArgs
 };
 
 constexpr int kSc1 = 16;  // cache-policy bit of the buffer instructions: agent scope (loads bypass L1, stores write through)
+
+// K3 as step 0 of the persistent launch (k_twoloop_persist<T, true>).  After a line search the driver runs
+//     s = x - xp; y = grad - gradp; grad.norm(); x.norm(); s.y; y.y        (LBFGS.h:130,137,159-161, BFGSMat.h:85-92)
+// and, unless it stops or rejects the pair, the recursion on the new gradient -- whose first step needs exactly the two
+// streams the first statement has in registers: q = -grad and its dot with the newest s.  Speculating that the pair is
+// accepted (it is, except when s.y <= eps y.y), the post pass becomes step 0: 2n elements fewer per iteration, one launch
+// less.  The kernel decides the acceptance itself (same test, same rounded scalars) and stops after step 0 when the pair
+// is rejected; the host then runs the recursion on the old history as before.  Same statements, same order-independent
+// sums: bit-identical to k_post followed by the un-fused recursion.
+template <class T>
+struct PostFuse
+{
+    const T* x;       // accepted point
+    const T* xp;      // start point of the line search
+    const T* gp;      // gradient at xp (the gradient at x is the kernel's `vin`)
+    T* s;             // spare history columns that receive s and y
+    T* y;
+    T* out;           // {g.g, x.x, s.y, y.y}
+    T* ys_slot;       // sc[] slots of the spare column: s.y and theta = y.y / s.y
+    T* theta_slot;
+    T eps;            // machine epsilon of T: the pair is usable iff s.y > eps * y.y (LBFGS.h:161)
+    int* verdict;     // 1: pair accepted, recursion completed; 2: rejected, only the post statements ran
+};
+
+// the post statements + q = a * g for the resident slots of a thread (slot s = vector s * vstride + vbase)
+// (vbase = bbase + ltid; bbase is the block's first vector, wave-uniform: it forms the buffer descriptors of the stores)
+template <class T, int NR, int NL, class A>
+__device__ __forceinline__ void hv_post_step(Pack<T> (&rq)[NR], typename Vec16<T>::type* lq, const PostFuse<T>& pf,
+                                             const T* g, T a, int64_t nv, int64_t bbase, int64_t vstride, int ltid,
+                                             A (&acc)[5])
+{
+    const int64_t vbase = bbase + ltid;
+    constexpr int W = Vec16<T>::W;
+    constexpr int U = 2;  // slots per chunk: 4 U 16-byte loads in flight per thread
+    // one descriptor per column for all slots of the block (slot offsets < (NR + NL) * vstride * 16 bytes < 2^31 ride
+    // in the scalar offset): write-through (sc1) stores -- later steps read these columns from other XCDs
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pf.s + W * bbase, 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(pf.y + W * bbase, 0, 0x7FFFFFFF, 0x00020000);
+#pragma unroll
+    for (int s0 = 0; s0 < NR + NL; s0 += U)
+    {
+        Pack<T> px[U], pxp[U], pg[U], pgp[U];
+        bool ok[U];
+#pragma unroll
+        for (int k = 0; k < U; k++)
+            if (s0 + k < NR + NL)
+            {
+                const int64_t vi = int64_t(s0 + k) * vstride + vbase;
+                ok[k] = vi < nv;
+                const int64_t vc = ok[k] ? vi : int64_t(0);
+                px[k] = ldv<T, true>(pf.x, vc);
+                pxp[k] = ldv<T, true>(pf.xp, vc);
+                pg[k] = ldv<T, true>(g, vc);
+                pgp[k] = ldv<T, true>(pf.gp, vc);
+            }
+#pragma unroll
+        for (int k = 0; k < U; k++)
+            if (s0 + k < NR + NL)
+            {
+                constexpr int dummy = 0;
+                const int s = s0 + k;
+                Pack<T> ps, py, cur;
+#pragma unroll
+                for (int e = 0; e < W; e++)
+                {
+                    ps.e[e] = px[k].e[e] - pxp[k].e[e];
+                    py.e[e] = pg[k].e[e] - pgp[k].e[e];
+                    cur.e[e] = a * pg[k].e[e];
+                }
+                // no per-slot branch (it makes the register allocator keep two copies of q, see hv_step): slots beyond the
+                // resident region are zero-weighted in the sums and their stores carry an offset outside the descriptor's
+                // range, which the hardware drops
+                const int soff = int(int64_t(s) * vstride * 16);  // wave-uniform
+                const int voff = ok[k] ? ltid * 16 : 0x7FFFFFF0;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4_t, ps.v), rs, voff, soff, kSc1);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4_t, py.v), ry, voff, soff, kSc1);
+#pragma unroll
+                for (int e = 0; e < W; e++)
+                {
+                    const T zg = ok[k] ? pg[k].e[e] : T(0), zx = ok[k] ? px[k].e[e] : T(0);
+                    const T zs = ok[k] ? ps.e[e] : T(0), zy = ok[k] ? py.e[e] : T(0);
+                    acc[0].add_prod(zg, zg);
+                    acc[1].add_prod(zx, zx);
+                    acc[2].add_prod(zs, zy);
+                    acc[3].add_prod(zy, zy);
+                    acc[4].add_prod(zs, cur.e[e]);
+                }
+                if (s < NR)
+                    rq[s < NR ? s : dummy] = cur;
+                else
+                    lq[(s < NR ? dummy : s - NR) * kHvThreads + ltid] = cur.v;
+            }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
 constexpr int kPersistNR = 30;
 constexpr int kPersistNL = 15;
 
-template <class T>
+template <class T, bool FUSE = false>
 __global__ void __launch_bounds__(kHvThreads, 2)
     k_twoloop_persist(T* __restrict__ q, const T* __restrict__ vin, T a, const T* __restrict__ S, const T* __restrict__ Y,
                       int64_t n, T* __restrict__ sc, PersistArgs pa, RedWs ws, unsigned* __restrict__ gen,
-                      int* __restrict__ err)
+                      int* __restrict__ err, PostFuse<T> pf)
 {
     typedef typename AccOf<T>::type A;
     constexpr int W = Vec16<T>::W;
     constexpr int NR = kPersistNR, NL = kPersistNL, U = 4;
     __shared__ typename Vec16<T>::type lq[NL * kHvThreads];
     __shared__ int s_pcol[kPersistMaxM];  // dynamic indexing: keep the column list out of scratch
+    __shared__ int s_verdict;
     const int tid = threadIdx.x;
     if (tid < kPersistMaxM)
         s_pcol[tid] = pa.pcol[tid];
@@ -592,7 +689,119 @@ __global__ void __launch_bounds__(kHvThreads, 2)
 
     Pack<T> rq[NR];
     const int64_t tile = int64_t(kHvThreads) * U;
-    for (int L = 0; L <= 2 * cn; L++)
+    // step 0 with the post statements is peeled out of the step loop: a branch between two producers of q inside the
+    // loop body makes the register allocator keep two copies of the resident slots
+    if (FUSE)
+    {
+        // ---- step 0 with the post-line-search statements fused in (PostFuse): s, y into the spare column = pcol[0]
+        A accp[5];
+        hv_post_step<T, NR, NL>(rq, lq, pf, vin, a, res_end, int64_t(blockIdx.x) * kHvThreads, gthreads, tid, accp);
+        {
+            const bool rev = pa.zigzag && ((pa.first_rev & 1u) != 0u);
+            const int64_t span = nv - res_end;
+            const int64_t ntile = (span + tile - 1) / tile;
+            for (int64_t t0 = blockIdx.x; t0 < ntile; t0 += gridDim.x)
+            {
+                const int64_t tt = rev ? ntile - 1 - t0 : t0;
+                const int64_t base = res_end + tt * tile + tid;
+                const int64_t eoff = W * (res_end + tt * tile);
+                const __amdgpu_buffer_rsrc_t rq_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(q) + eoff, 0, int(tile * 16), 0x00020000);
+                const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(pf.s + eoff, 0, int(tile * 16), 0x00020000);
+                const __amdgpu_buffer_rsrc_t ry_ = __builtin_amdgcn_make_buffer_rsrc(pf.y + eoff, 0, int(tile * 16), 0x00020000);
+                Pack<T> px[U], pxp[U], pg[U], pgp[U];
+#pragma unroll
+                for (int k = 0; k < U; k++)
+                {
+                    const int64_t vi = base + int64_t(k) * kHvThreads;
+                    if (vi < nv)
+                    {
+                        px[k] = ldv<T, true>(pf.x, vi);
+                        pxp[k] = ldv<T, true>(pf.xp, vi);
+                        pg[k] = ldv<T, true>(vin, vi);
+                        pgp[k] = ldv<T, true>(pf.gp, vi);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < U; k++)
+                {
+                    const int64_t vi = base + int64_t(k) * kHvThreads;
+                    if (vi < nv)
+                    {
+                        Pack<T> ps, py, cur;
+#pragma unroll
+                        for (int e = 0; e < W; e++)
+                        {
+                            ps.e[e] = px[k].e[e] - pxp[k].e[e];
+                            py.e[e] = pg[k].e[e] - pgp[k].e[e];
+                            cur.e[e] = a * pg[k].e[e];
+                            accp[0].add_prod(pg[k].e[e], pg[k].e[e]);
+                            accp[1].add_prod(px[k].e[e], px[k].e[e]);
+                            accp[2].add_prod(ps.e[e], py.e[e]);
+                            accp[3].add_prod(py.e[e], py.e[e]);
+                            accp[4].add_prod(ps.e[e], cur.e[e]);
+                        }
+                        const int boff = int((tid + k * kHvThreads) * 16);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4_t, ps.v), rs_, boff, 0, kSc1);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4_t, py.v), ry_, boff, 0, kSc1);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4_t, cur.v), rq_, boff, 0, kSc1);
+                    }
+                }
+            }
+            if (blockIdx.x == 0 && tid == 0)  // scalar tail
+                for (int64_t i = nv * W; i < n; i++)
+                {
+                    const T si = pf.x[i] - pf.xp[i], yi = vin[i] - pf.gp[i], qi = a * vin[i];
+                    __hip_atomic_store(pf.s + i, si, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(pf.y + i, yi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    q[i] = qi;
+                    accp[0].add_prod(vin[i], vin[i]);
+                    accp[1].add_prod(pf.x[i], pf.x[i]);
+                    accp[2].add_prod(si, yi);
+                    accp[3].add_prod(yi, yi);
+                    accp[4].add_prod(si, qi);
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const unsigned want0 = pa.gen_base + 1u;
+        if (grid_reduce<5>(accp, ws))
+        {
+            if (tid == 0)
+            {
+                const T sy = T(accp[2].value()), yy = T(accp[3].value());
+                pf.out[0] = T(accp[0].value());
+                pf.out[1] = T(accp[1].value());
+                pf.out[2] = sy;
+                pf.out[3] = yy;
+                __hip_atomic_store(pf.ys_slot, sy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(pf.theta_slot, yy / sy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(sc + DOT0, T(accp[4].value()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(pf.verdict, (sy > pf.eps * yy) ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(gen, want0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (tid == 0)
+        {
+            unsigned spins = 0;
+            const unsigned long long t_begin = wall_clock64();
+            while (int(__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want0) < 0)
+            {
+                __builtin_amdgcn_s_sleep(8);
+                if ((++spins & 255u) == 0u &&
+                    (wall_clock64() - t_begin > 10000000ull ||
+                     __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
+                {
+                    __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+            s_verdict = __hip_atomic_load(pf.verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (s_verdict != 1)
+            return;  // pair rejected (or the launch timed out): q is not needed, the host takes over
+    }
+    for (int L = FUSE ? 1 : 0; L <= 2 * cn; L++)
     {
         const T* u;
         const T* w;

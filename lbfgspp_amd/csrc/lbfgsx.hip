@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <mutex>
 
 #include "ctx.hpp"
@@ -261,18 +262,20 @@ static int create_fill(lbfgsx_ctx* c, int dtype, int64_t n, int m, int device, i
     c->own_stream = true;
     if (const char* e = getenv("LBFGSX_PERSIST"))
         c->persist = atoi(e) != 0;
+    if (const char* e = getenv("LBFGSX_FUSE_POST"))
+        c->fuse_post = atoi(e) != 0;
     {
         // the persistent two-loop needs every block resident at once: occupancy * CUs
         int occ = 0;
         hipDeviceProp_t prop;
         LBFGSX_HIP(hipGetDeviceProperties(&prop, device));
         if (dtype == LBFGSX_F64)
-            (void) hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_twoloop_persist<double>, kHvThreads, 0);
+            (void) hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_twoloop_persist<double, true>, kHvThreads, 0);
         else
-            (void) hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_twoloop_persist<float>, kHvThreads, 0);
+            (void) hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_twoloop_persist<float, true>, kHvThreads, 0);
         c->persist_grid = occ * prop.multiProcessorCount;
-        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&c->gen_dev), 2 * sizeof(unsigned)));
-        LBFGSX_HIP(hipMemset(c->gen_dev, 0, 2 * sizeof(unsigned)));
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&c->gen_dev), 4 * sizeof(unsigned)));  // generation, time-out flag, verdict
+        LBFGSX_HIP(hipMemset(c->gen_dev, 0, 4 * sizeof(unsigned)));
     }
     const size_t vbytes = size_t(c->ld) * c->esz;
     for (int k = 0; k < 3; k++)
@@ -511,6 +514,7 @@ int lbfgsx_bfgs_reset(lbfgsx_ctx* c)
     c->ncorr = 0;
     c->ptr = c->m;
     c->pending = false;
+    c->spec_valid = false;
     c->tl_step = 0;  // the traversal direction of every launch of a run is a function of the run alone
     for (int j = 0; j < c->m; j++)
         c->phys[size_t(j)] = j;
@@ -667,8 +671,9 @@ static int apply_Hv_t(lbfgsx_ctx* c, const T* v, T a, double* dg)
         // process and rocprofv3 crashes at exit after cooperative launches on this stack; a device shared with another
         // PROCESS is caught by the wall-clock bound of the kernel's meeting points (the product is then redone with
         // the step launches), never by a hang.
-        hipLaunchKernelGGL((k_twoloop_persist<T>), dim3(c->persist_grid), dim3(kHvThreads), 0, c->stream, q, v, a,
-                           P<T>(c->S), P<T>(c->Y), c->n, sc, pa, c->ws, c->gen_dev, reinterpret_cast<int*>(c->gen_dev + 1));
+        hipLaunchKernelGGL((k_twoloop_persist<T, false>), dim3(c->persist_grid), dim3(kHvThreads), 0, c->stream, q, v, a,
+                           P<T>(c->S), P<T>(c->Y), c->n, sc, pa, c->ws, c->gen_dev, reinterpret_cast<int*>(c->gen_dev + 1),
+                           PostFuse<T>());
         LBFGSX_HIP(hipGetLastError());
         int* err = reinterpret_cast<int*>(c->gen_dev + 1);
         c->persist_launches++;
@@ -816,6 +821,20 @@ int lbfgsx_apply_Hv(lbfgsx_ctx* c, int v_which, double a, double* dg)
     {
         set_error("lbfgsx_apply_Hv: this context keeps its history in f32 for the Gram-space recursion (lbfgsx_gs_set_history_dtype)");
         return LBFGSX_E_LOGIC;
+    }
+    if (c->spec_valid)
+    {
+        // the direction for exactly this request is already in D (lbfgsx_post_linesearch_spec): same history (the
+        // pending pair has been committed since, nothing else changed), same source vector, same scale
+        const bool hit = c->spec_version == c->phys_version && !c->pending && v == c->gb[c->spec_cur] &&
+                         c->spec_cur == c->cur && a == c->spec_a;
+        c->spec_valid = false;
+        if (hit)
+        {
+            c->spec_used++;
+            if (dg) *dg = c->spec_dg;
+            return LBFGSX_OK;
+        }
     }
     DISPATCH_T(c, { return apply_Hv_t<T>(c, P<T>(v), T(a), dg); });
     return LBFGSX_OK;
@@ -994,6 +1013,155 @@ int lbfgsx_post_linesearch(lbfgsx_ctx* c, double* gnorm2, double* xnorm2, double
     return LBFGSX_OK;
 }
 
+}  // extern "C"
+// post statements + speculative recursion in one persistent launch; returns 1 when not applicable (caller runs k_post)
+template <class T>
+static int post_spec_t(lbfgsx_ctx* c, T a, double* r4)
+{
+    const int m = c->m;
+    if (!(c->fuse_post && c->persist && c->persist_grid > 0 && m <= kPersistMaxM && !c->gs_f32h && c->device >= 0 &&
+          c->device < 64))
+        return 1;
+    std::unique_lock<std::mutex> lock(g_persist_mu[c->device], std::try_to_lock);
+    if (!lock.owns_lock())
+        return 1;
+    // history as it will be once the pending pair is committed (lbfgsx_commit_correction): slot loc takes the spare column
+    const int loc = c->ptr % m;
+    const int cn = std::min(c->ncorr + 1, m);
+    PersistArgs pa;
+    pa.ncorr = cn;
+    pa.m = m;
+    for (int i = 0; i < kPersistMaxM; i++)
+        pa.pcol[i] = 0;
+    {
+        int j = loc;  // newest logical slot after the commit
+        for (int i = 0; i < cn; i++)
+        {
+            pa.pcol[i] = (j == loc) ? c->spare : c->phys[size_t(j)];
+            j = (j + m - 1) % m;
+        }
+    }
+    pa.gen_base = c->gen_count;
+    pa.zigzag = c->zigzag ? 1 : 0;
+    pa.first_rev = c->tl_step;
+    pa.ld = c->ld;
+    c->gen_count += unsigned(2 * cn + 1);
+    c->tl_step += unsigned(2 * cn + 1);
+    T* sc = P<T>(c->sc);
+    PostFuse<T> pf;
+    pf.x = P<T>(c->xb[c->cur]);
+    pf.xp = P<T>(c->xb[c->xp]);
+    pf.gp = P<T>(c->gb[c->xp]);
+    pf.s = P<T>(c->col(c->S, c->spare));
+    pf.y = P<T>(c->col(c->Y, c->spare));
+    pf.out = c->out_slot<T>();
+    pf.ys_slot = sc + c->sl.ys(c->spare);
+    pf.theta_slot = sc + c->sl.theta(c->spare);
+    pf.eps = std::numeric_limits<T>::epsilon();
+    pf.verdict = reinterpret_cast<int*>(c->gen_dev + 2);
+    EventPair hv;
+    if (c->timing)
+    {
+        LBFGSX_HIP(hipEventCreate(&hv.a));
+        LBFGSX_HIP(hipEventCreate(&hv.b));
+        LBFGSX_HIP(hipEventRecord(hv.a, c->stream));
+    }
+    hipLaunchKernelGGL((k_twoloop_persist<T, true>), dim3(c->persist_grid), dim3(kHvThreads), 0, c->stream, P<T>(c->d),
+                       P<T>(c->gb[c->cur]), a, P<T>(c->S), P<T>(c->Y), c->n, sc, pa, c->ws, c->gen_dev,
+                       reinterpret_cast<int*>(c->gen_dev + 1), pf);
+    LBFGSX_HIP(hipGetLastError());
+    if (c->timing)
+    {
+        LBFGSX_HIP(hipEventRecord(hv.b, c->stream));
+        c->ev_hv.push_back(hv);
+        c->persist_steps_timed += 2 * cn + 1;
+        c->fused_timed++;
+    }
+    int hflags[2] = {0, 0};  // time-out flag, verdict
+    LBFGSX_HIP(hipMemcpyAsync(hflags, c->gen_dev + 1, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    // the five scalars the host needs, one synchronisation: dg = grad . d, then {g.g, x.x, s.y, y.y}
+    T* h = static_cast<T*>(c->hout);
+    LBFGSX_HIP(hipMemcpyAsync(h, sc + c->sl.dot(2 * cn), sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    if (!c->outmap_dev)
+        LBFGSX_HIP(hipMemcpyAsync(h + 8, sc + c->sl.out(0), 4 * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    const double dgv = double(h[0]);
+    for (int i = 0; i < 4; i++)
+        r4[i] = c->outmap_dev ? double(static_cast<const volatile T*>(c->outmap_host)[i]) : double(h[8 + i]);
+    if (hflags[0])
+    {
+        // a meeting point timed out (device shared with another process): reset, never speculate again, redo with k_post
+        LBFGSX_HIP(hipMemsetAsync(c->gen_dev, 0, 4 * sizeof(unsigned), c->stream));
+        LBFGSX_HIP(hipMemsetAsync(c->ws.ticket, 0, sizeof(unsigned), c->stream));
+        c->gen_count = 0;
+        c->persist = false;
+        if (c->timing && !c->ev_hv.empty())
+        {
+            (void) hipEventDestroy(c->ev_hv.back().a);
+            (void) hipEventDestroy(c->ev_hv.back().b);
+            c->ev_hv.pop_back();
+            c->persist_steps_timed -= 2 * cn + 1;
+            c->fused_timed--;
+        }
+        return 1;
+    }
+    c->persist_launches++;
+    c->spec_launches++;
+    if (hflags[1] == 1)
+    {
+        c->spec_valid = true;
+        c->spec_version = c->phys_version + 1;  // lbfgsx_commit_correction bumps it once
+        c->spec_cur = c->cur;
+        c->spec_a = double(a);
+        c->spec_dg = dgv;
+    }
+    else
+    {
+        c->spec_rejected++;
+        if (c->timing && !c->ev_hv.empty())  // only step 0 ran: not an apply_Hv to be averaged
+        {
+            (void) hipEventDestroy(c->ev_hv.back().a);
+            (void) hipEventDestroy(c->ev_hv.back().b);
+            c->ev_hv.pop_back();
+            c->persist_steps_timed -= 2 * cn + 1;
+            c->fused_timed--;
+        }
+    }
+    return LBFGSX_OK;
+}
+extern "C" {
+
+int lbfgsx_post_linesearch_spec(lbfgsx_ctx* c, double a, double* gnorm2, double* xnorm2, double* sy, double* yy)
+{
+    lbfgsx::DeviceGuard dev_guard_(c->device);
+    if (c->gs_f32h)
+        return lbfgsx_post_linesearch(c, gnorm2, xnorm2, sy, yy);  // reports the mode error
+    double r[4];
+    int rc = 1;
+    c->spec_valid = false;
+    DISPATCH_T(c, { rc = post_spec_t<T>(c, T(a), r); });
+    if (rc == 1)
+        return lbfgsx_post_linesearch(c, gnorm2, xnorm2, sy, yy);
+    if (rc)
+        return rc;
+    c->pend_sy = r[2];
+    c->pend_yy = r[3];
+    c->pending = true;
+    if (gnorm2) *gnorm2 = r[0];
+    if (xnorm2) *xnorm2 = r[1];
+    if (sy) *sy = r[2];
+    if (yy) *yy = r[3];
+    return LBFGSX_OK;
+}
+
+int lbfgsx_spec_counts(const lbfgsx_ctx* c, int64_t out[3])
+{
+    out[0] = c->spec_launches;
+    out[1] = c->spec_used;
+    out[2] = c->spec_rejected;
+    return LBFGSX_OK;
+}
+
 // ---- instrumentation ----------------------------------------------------------------------------------
 int lbfgsx_timing_enable(lbfgsx_ctx* c, int on)
 {
@@ -1013,6 +1181,7 @@ int lbfgsx_timing_enable(lbfgsx_ctx* c, int on)
     c->ev_hv.clear();
     c->persist_steps_timed = 0;
     c->coarse_steps_timed = 0;
+    c->fused_timed = 0;
     c->timing = (on != 0);
     c->timing_per_launch = (on != 2);
     return LBFGSX_OK;
@@ -1063,6 +1232,7 @@ int lbfgsx_timing_read(lbfgsx_ctx* c, double* twoloop_ms_total, int64_t* twoloop
 }
 
 int64_t lbfgsx_persistent_launches(const lbfgsx_ctx* c) { return c ? c->persist_launches : 0; }
+int64_t lbfgsx_timing_fused_launches(const lbfgsx_ctx* c) { return c ? c->fused_timed : 0; }
 
 int64_t lbfgsx_persistent_resident_elems(const lbfgsx_ctx* c)
 {

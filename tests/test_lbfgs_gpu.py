@@ -287,6 +287,66 @@ def test_persistent_two_loop_is_bit_identical(A, oracle, monkeypatch, dtype, n, 
     assert (r.niter, r.nfev) == res["1"][:2] and np.array_equal(res["1"][3], x_ref)
 
 
+def _spec_counts(A, s):
+    import ctypes as C
+    core, _ = A.load()
+    out = (C.c_int64 * 3)()
+    core.lbfgsx_spec_counts(s.ctx, C.byref(out))
+    return tuple(int(v) for v in out)
+
+
+@pytest.mark.parametrize("dtype,n,m,ls", [(O.F64, 300002, 7, O.LS_MT), (O.F32, 100002, 5, O.LS_MT), (O.F64, 2051, 12, O.LS_NW),
+                                          (O.F64, 20_000_002, 4, O.LS_MT)])
+def test_post_statements_fused_into_the_recursion_launch_change_no_bit(A, oracle, monkeypatch, dtype, n, m, ls):
+    """lbfgsx_post_linesearch_spec: K3 (s, y, the four sums) as step 0 of the persistent launch that speculatively
+    computes the next direction.  Same trajectory, evaluation for evaluation, as the separate launches
+    (LBFGSX_FUSE_POST=0) and as the oracle; n = 2051 has a scalar tail, n = 2e7 a streamed (non-resident) part."""
+    x0 = O.rosen_x0(n, 3, dtype)
+    iters = 2 * m + 6 if n < 10_000_000 else 8
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LBFGSX_FUSE_POST", mode)
+        s = A.LBFGSSolver(A.LBFGSParam(m=m, epsilon=0.0, epsilon_rel=0.0, max_iterations=iters),
+                          linesearch=A.LS_MORE_THUENTE if ls == O.LS_MT else A.LS_NOCEDAL_WRIGHT, dtype=O.NPDT[dtype])
+        x = x0.copy()
+        tr = A.TraceBuffer(n, cap=256, with_x=False)
+        niter, fx = s.minimize(A.ExtendedRosenbrock(), x, trace=tr)
+        res[mode] = (niter, s.last.nfev, fx, x, tr.fx[:tr.count].copy(), _spec_counts(A, s))
+        s.close()
+    fused, used, rejected = res["1"][5]
+    assert fused == iters and used == iters - 1 and rejected == 0   # the last iteration stops before using its direction
+    assert res["0"][5] == (0, 0, 0)
+    assert res["1"][:3] == res["0"][:3] and np.array_equal(res["1"][3], res["0"][3]) and np.array_equal(res["1"][4], res["0"][4])
+    if n < 10_000_000:
+        x_ref, r = oracle.lbfgs(dtype, ls, O.OBJ_ROSEN, x0, O.lbfgs_params(m=m, epsilon=0, epsilon_rel=0, max_iterations=iters))
+        assert (r.niter, r.nfev) == res["1"][:2] and np.array_equal(res["1"][3], x_ref)
+
+
+def test_rejected_pair_stops_the_fused_launch_after_the_post_statements(A, oracle, monkeypatch):
+    """Armijo backtracking has no curvature condition: from a start in the non-convex region of the Rosenbrock pairs
+    (x_even = 0, x_odd = 1) some steps give s.y <= eps y.y, the driver drops the pair (LBFGS.h:161) and the recursion
+    runs on the OLD history.  The fused launch sees the same test fail, stops after step 0, and lbfgsx_apply_Hv takes
+    the ordinary path: same bits as the un-fused run and the oracle."""
+    n, m, iters = 40000, 6, 30
+    x0 = np.zeros(n)
+    x0[1::2] = 1.0
+    x0 += 0.01 * (O.rosen_x0(n, 9, O.F64) - 1.0)
+    par = dict(m=m, epsilon=0.0, epsilon_rel=0.0, max_iterations=iters, linesearch=1, max_linesearch=40)  # ARMIJO
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LBFGSX_FUSE_POST", mode)
+        s = A.LBFGSSolver(A.LBFGSParam(**par), linesearch=A.LS_BACKTRACKING)
+        x = x0.copy()
+        niter, fx = s.minimize(A.ExtendedRosenbrock(), x)
+        res[mode] = (niter, s.last.nfev, fx, x, _spec_counts(A, s))
+        s.close()
+    fused, used, rejected = res["1"][4]
+    assert rejected > 0 and fused == niter and used == niter - 1 - rejected, res["1"][4]
+    assert res["1"][:3] == res["0"][:3] and np.array_equal(res["1"][3], res["0"][3])
+    x_ref, r = oracle.lbfgs(O.F64, O.LS_BT, O.OBJ_ROSEN, x0, O.lbfgs_params(**par))
+    assert (r.niter, r.nfev) == res["1"][:2] and np.array_equal(res["1"][3], x_ref)
+
+
 def test_two_live_solvers_on_one_device_both_use_the_persistent_kernel(A, oracle):
     """Round 1 used the one-launch recursion only while its context was the single live one of the process.  The
     requirement is narrower -- at most one PERSISTENT kernel in flight per device -- and is kept by a per-device lock held
