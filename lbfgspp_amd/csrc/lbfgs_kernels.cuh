@@ -593,10 +593,10 @@ __device__ __forceinline__ void hv_post_step(Pack<T> (&rq)[NR], typename Vec16<T
     const int64_t vbase = bbase + ltid;
     constexpr int W = Vec16<T>::W;
     constexpr int U = 2;  // slots per chunk: 4 U 16-byte loads in flight per thread
-    // one descriptor per column for all slots of the block (slot offsets < (NR + NL) * vstride * 16 bytes < 2^31 ride
-    // in the scalar offset): write-through (sc1) stores -- later steps read these columns from other XCDs
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pf.s + W * bbase, 0, 0x7FFFFFFF, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(pf.y + W * bbase, 0, 0x7FFFFFFF, 0x00020000);
+    // one descriptor per column for all slots of the block (slot offsets < (NR + NL) * vstride * 16 bytes < 2^30 ride
+    // in the scalar offset; the range is 2^30 bytes so that the "dropped" offset 0x7FFFFFF0 below lies well outside it): write-through (sc1) stores -- later steps read these columns from other XCDs
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pf.s + W * bbase, 0, 0x40000000, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(pf.y + W * bbase, 0, 0x40000000, 0x00020000);
 #pragma unroll
     for (int s0 = 0; s0 < NR + NL; s0 += U)
     {
