@@ -301,7 +301,10 @@ def test_post_statements_fused_into_the_recursion_launch_change_no_bit(A, oracle
     """lbfgsx_post_linesearch_spec: K3 (s, y, the four sums) as step 0 of the persistent launch that speculatively
     computes the next direction.  Same trajectory, evaluation for evaluation, as the separate launches
     (LBFGSX_FUSE_POST=0) and as the oracle; n = 2051 has a scalar tail, n = 2e7 a streamed (non-resident) part."""
-    x0 = O.rosen_x0(n, 3, dtype)
+    odd = (n % 2) == 1     # an odd dimension (scalar tail in f64) needs the quadratic: the Rosenbrock pairs want n even
+    a, b = O.quad_problem(n, 10.0, 1, dtype) if odd else (None, None)
+    x0 = np.zeros(n, O.NPDT[dtype]) if odd else O.rosen_x0(n, 3, dtype)
+    obj = O.OBJ_QUAD if odd else O.OBJ_ROSEN
     iters = 2 * m + 6 if n < 10_000_000 else 8
     res = {}
     for mode in ("1", "0"):
@@ -310,7 +313,7 @@ def test_post_statements_fused_into_the_recursion_launch_change_no_bit(A, oracle
                           linesearch=A.LS_MORE_THUENTE if ls == O.LS_MT else A.LS_NOCEDAL_WRIGHT, dtype=O.NPDT[dtype])
         x = x0.copy()
         tr = A.TraceBuffer(n, cap=256, with_x=False)
-        niter, fx = s.minimize(A.ExtendedRosenbrock(), x, trace=tr)
+        niter, fx = s.minimize(A.DiagQuadratic(a, b) if odd else A.ExtendedRosenbrock(), x, trace=tr)
         res[mode] = (niter, s.last.nfev, fx, x, tr.fx[:tr.count].copy(), _spec_counts(A, s))
         s.close()
     fused, used, rejected = res["1"][5]
@@ -318,7 +321,7 @@ def test_post_statements_fused_into_the_recursion_launch_change_no_bit(A, oracle
     assert res["0"][5] == (0, 0, 0)
     assert res["1"][:3] == res["0"][:3] and np.array_equal(res["1"][3], res["0"][3]) and np.array_equal(res["1"][4], res["0"][4])
     if n < 10_000_000:
-        x_ref, r = oracle.lbfgs(dtype, ls, O.OBJ_ROSEN, x0, O.lbfgs_params(m=m, epsilon=0, epsilon_rel=0, max_iterations=iters))
+        x_ref, r = oracle.lbfgs(dtype, ls, obj, x0, O.lbfgs_params(m=m, epsilon=0, epsilon_rel=0, max_iterations=iters), a=a, b=b)
         assert (r.niter, r.nfev) == res["1"][:2] and np.array_equal(res["1"][3], x_ref)
 
 
