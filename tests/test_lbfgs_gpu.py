@@ -325,29 +325,63 @@ def test_post_statements_fused_into_the_recursion_launch_change_no_bit(A, oracle
         assert (r.niter, r.nfev) == res["1"][:2] and np.array_equal(res["1"][3], x_ref)
 
 
-def test_rejected_pair_stops_the_fused_launch_after_the_post_statements(A, oracle, monkeypatch):
-    """Armijo backtracking has no curvature condition: from a start in the non-convex region of the Rosenbrock pairs
-    (x_even = 0, x_odd = 1) some steps give s.y <= eps y.y, the driver drops the pair (LBFGS.h:161) and the recursion
-    runs on the OLD history.  The fused launch sees the same test fail, stops after step 0, and lbfgsx_apply_Hv takes
-    the ordinary path: same bits as the un-fused run and the oracle."""
-    n, m, iters = 40000, 6, 30
-    x0 = np.zeros(n)
-    x0[1::2] = 1.0
-    x0 += 0.01 * (O.rosen_x0(n, 9, O.F64) - 1.0)
-    par = dict(m=m, epsilon=0.0, epsilon_rel=0.0, max_iterations=iters, linesearch=1, max_linesearch=40)  # ARMIJO
-    res = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("LBFGSX_FUSE_POST", mode)
-        s = A.LBFGSSolver(A.LBFGSParam(**par), linesearch=A.LS_BACKTRACKING)
-        x = x0.copy()
-        niter, fx = s.minimize(A.ExtendedRosenbrock(), x)
-        res[mode] = (niter, s.last.nfev, fx, x, _spec_counts(A, s))
-        s.close()
-    fused, used, rejected = res["1"][4]
-    assert rejected > 0 and fused == niter and used == niter - 1 - rejected, res["1"][4]
-    assert res["1"][:3] == res["0"][:3] and np.array_equal(res["1"][3], res["0"][3])
-    x_ref, r = oracle.lbfgs(O.F64, O.LS_BT, O.OBJ_ROSEN, x0, O.lbfgs_params(**par))
-    assert (r.niter, r.nfev) == res["1"][:2] and np.array_equal(res["1"][3], x_ref)
+@pytest.mark.parametrize("dtype", [O.F64, O.F32])
+@pytest.mark.parametrize("n,m,npairs,accept", [(70002, 6, 4, False), (70002, 6, 4, True), (4100, 5, 9, False), (1000, 4, 0, False),
+                                              (1000, 4, 0, True), (300002, 5, 5, True)])
+def test_fused_post_launch_statement_level(A, oracle, dtype, n, m, npairs, accept):
+    """lbfgsx_post_linesearch_spec on hand-made points.  A pair with s.y <= eps y.y is rejected by the driver
+    (LBFGS.h:161) and the recursion runs on the OLD history: the fused launch sees the same test fail, stops after the
+    post statements, and lbfgsx_apply_Hv computes the direction the ordinary way.  An accepted pair: the direction of
+    the fused launch is the one lbfgsx_apply_Hv hands out after the commit, equal to the oracle's product on the
+    history that includes the new pair.  The four sums and the stored s, y are k_post's in both cases."""
+    rng = np.random.default_rng(99 + n + npairs)
+    dt = O.NPDT[dtype]
+    S = rng.standard_normal((max(npairs, 1), n)).astype(dt)
+    Y = (S * (1.0 + rng.random((max(npairs, 1), n))) + 0.05 * rng.standard_normal((max(npairs, 1), n))).astype(dt)
+    S, Y = S[:npairs], Y[:npairs]
+    xp, gp = rng.standard_normal(n).astype(dt), rng.standard_normal(n).astype(dt)
+    s_new = rng.standard_normal(n).astype(dt)
+    y_new = ((1.5 if accept else -1.5) * s_new + 0.05 * rng.standard_normal(n)).astype(dt)
+    x, g = (xp + s_new).astype(dt), (gp + y_new).astype(dt)
+    s_new, y_new = x - xp, g - gp      # what the statements will form
+    c = Ctx(A, dtype, n, m)
+    L = c.L
+    for k in range(npairs):
+        L.check(c.core.lbfgsx_bfgs_add_correction_host(c.h, S[k].ctypes.data_as(C.c_void_p), Y[k].ctypes.data_as(C.c_void_p)))
+    c.up(L.VEC_X, xp)
+    c.up(L.VEC_G, gp)
+    L.check(c.core.lbfgsx_ls_begin(c.h))
+    c.up(L.VEC_XT, x)
+    c.up(L.VEC_GT, g)
+    L.check(c.core.lbfgsx_ls_end(c.h, 0))
+    r = [C.c_double() for _ in range(4)]
+    L.check(c.core.lbfgsx_post_linesearch_spec(c.h, -1.0, *[C.byref(v) for v in r]))
+    g2, x2, sy, yy = [v.value for v in r]
+    f64 = np.float64
+    for got, want in ((g2, np.dot(g.astype(f64), g.astype(f64))), (x2, np.dot(x.astype(f64), x.astype(f64))),
+                      (sy, np.dot(s_new.astype(f64), y_new.astype(f64))), (yy, np.dot(y_new.astype(f64), y_new.astype(f64)))):
+        assert abs(got - want) <= (1e-12 if dtype == O.F64 else 2e-6) * abs(want)
+    assert (sy > np.finfo(dt).eps * yy) == accept
+    counts = (C.c_int64 * 3)()
+    c.core.lbfgsx_spec_counts(c.h, C.byref(counts))
+    assert tuple(counts) == (1, 0, 0 if accept else 1)
+    if accept:
+        L.check(c.core.lbfgsx_commit_correction(c.h))
+        hist_S, hist_Y = np.vstack([S.reshape(npairs, n), s_new[None]]), np.vstack([Y.reshape(npairs, n), y_new[None]])
+    else:
+        hist_S, hist_Y = S.reshape(npairs, n), Y.reshape(npairs, n)
+    dg = C.c_double()
+    L.check(c.core.lbfgsx_apply_Hv(c.h, L.VEC_G, -1.0, C.byref(dg)))
+    got = c.down(L.VEC_D)
+    c.core.lbfgsx_spec_counts(c.h, C.byref(counts))
+    assert tuple(counts) == (1, 1 if accept else 0, 0 if accept else 1)
+    assert c.core.lbfgsx_bfgs_ncorr(c.h) == min(npairs + (1 if accept else 0), m)
+    c.close()
+    ref = oracle.apply_Hv(dtype, m, hist_S, hist_Y, g, -1.0)
+    scale = np.abs(ref).max() + 1e-300
+    assert np.abs(got - ref).max() <= 4 * np.finfo(dt).eps * scale and np.mean(got == ref) > 0.99
+    want = float(np.dot(g.astype(f64), got.astype(f64)))
+    assert abs(dg.value - want) <= (1e-12 if dtype == O.F64 else 1e-5) * abs(want)
 
 
 def test_two_live_solvers_on_one_device_both_use_the_persistent_kernel(A, oracle):
