@@ -122,6 +122,7 @@ struct lbfgsx_ctx
     bool chunked = false;  // contiguous slab per block instead of grid-stride tiles
     int q_policy = 0;      // non-temporal hint on q itself (bit 0 loads, bit 1 stores).  q is the vector every two-loop
                            // step re-reads, so it stays eligible for the memory-side cache by default
+    int trial_policy = 0;  // LBFGSX_TRIAL_POLICY: bit 0 NT loads, bit 1 NT stores, 4: 8 vectors in flight (k_trial A/B)
     bool zigzag = true;    // alternate the traversal direction of consecutive two-loop steps (MALL reuse of q's tail)
     unsigned tl_step = 0;  // launches issued so far (parity selects the direction)
     // persistent one-launch apply_Hv (k_twoloop_persist)

@@ -119,7 +119,8 @@ __global__ void __launch_bounds__(kBlock) k_eval(const T* __restrict__ x, T* __r
 
 // ---------------------------------------------------------------- K2: line-search trial
 // x = xp + step*d ; g = grad f(x) ; out[0] = f(x), out[1] = g.d
-template <class T, class OBJ, int U = 4>
+// NTL / NTS: non-temporal hint on the loads of xp and d / on the stores of x and g (measured, profiles/r2_trial_policy_ab.txt)
+template <class T, class OBJ, int U = 4, bool NTL = false, bool NTS = false>
 __global__ void __launch_bounds__(kBlock) k_trial(const T* __restrict__ xp, const T* __restrict__ d, T step,
                                                   T* __restrict__ x, T* __restrict__ g, int64_t n, OBJ obj,
                                                   RedWs ws, T* __restrict__ out, int rev)
@@ -140,8 +141,8 @@ __global__ void __launch_bounds__(kBlock) k_trial(const T* __restrict__ xp, cons
         for (int u = 0; u < U; u++)
             if (base + u * kBlock < nv)
             {
-                pxp[u] = ldv(xp, base + u * kBlock);
-                pd[u] = ldv(d, base + u * kBlock);
+                pxp[u] = ldv<T, NTL>(xp, base + u * kBlock);
+                pd[u] = ldv<T, NTL>(d, base + u * kBlock);
             }
 #pragma unroll
         for (int u = 0; u < U; u++)
@@ -154,8 +155,8 @@ __global__ void __launch_bounds__(kBlock) k_trial(const T* __restrict__ xp, cons
                 for (int k = 0; k < W; k++)
                     px.e[k] = pxp[u].e[k] + step * pd[u].e[k];
                 obj.pack(vi, px, pg, acc[0]);
-                stv(x, vi, px);
-                stv(g, vi, pg);
+                stv<T, NTS>(x, vi, px);
+                stv<T, NTS>(g, vi, pg);
 #pragma unroll
                 for (int k = 0; k < W; k++)
                     acc[1].add_prod(pg.e[k], pd[u].e[k]);

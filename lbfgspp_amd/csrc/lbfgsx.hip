@@ -262,6 +262,8 @@ static int create_fill(lbfgsx_ctx* c, int dtype, int64_t n, int m, int device, i
     c->own_stream = true;
     if (const char* e = getenv("LBFGSX_PERSIST"))
         c->persist = atoi(e) != 0;
+    if (const char* e = getenv("LBFGSX_TRIAL_POLICY"))
+        c->trial_policy = atoi(e);
     if (const char* e = getenv("LBFGSX_FUSE_POST"))
         c->fuse_post = atoi(e) != 0;
     {
@@ -912,8 +914,19 @@ static int trial_t(lbfgsx_ctx* c, OBJ obj, T step, double* out2)
     const int grid = c->grid_for(c->n);
     const int rev = (c->zigzag && (c->tl_step++ & 1u)) ? 1 : 0;
     // 4 vectors per stream and thread in flight (measured +1 % on the north-star against 2; profiles/r1_mall_policy_ab.txt)
-    hipLaunchKernelGGL((k_trial<T, OBJ, 4>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->xp]), P<T>(c->d), step,
-                       P<T>(c->xb[c->trial]), P<T>(c->gb[c->trial]), c->n, obj, c->ws, c->out_slot<T>(), rev);
+#define TRIAL_LAUNCH(UU, NTL, NTS)                                                                                            \
+    hipLaunchKernelGGL((k_trial<T, OBJ, UU, NTL, NTS>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->xp]), P<T>(c->d), \
+                       step, P<T>(c->xb[c->trial]), P<T>(c->gb[c->trial]), c->n, obj, c->ws, c->out_slot<T>(), rev)
+    switch (c->trial_policy)
+    {
+    case 1: TRIAL_LAUNCH(4, true, false); break;
+    case 2: TRIAL_LAUNCH(4, false, true); break;
+    case 3: TRIAL_LAUNCH(4, true, true); break;
+    case 4: TRIAL_LAUNCH(8, false, false); break;
+    case 7: TRIAL_LAUNCH(8, true, true); break;
+    default: TRIAL_LAUNCH(4, false, false); break;
+    }
+#undef TRIAL_LAUNCH
     LBFGSX_HIP(hipGetLastError());
     return fetch_scalars<T>(c, c->sl.out(0), 2, out2);
 }

@@ -14,7 +14,7 @@ rnd = sys.argv[1] if len(sys.argv) > 1 else "r1"
 src = os.path.join("gpurun_out", "prof_" + rnd)
 os.makedirs("profiles", exist_ok=True)
 shutil.copy(os.path.join(src, "trace", "bench_kernel_stats.csv"), os.path.join("profiles", rnd + "_kernel_stats.csv"))
-for name in ("northstar", "northstar_gram", "northstar_gram_f32h", "sharded_n1", "cfg3_m20", "cfg3_m20_gram", "cfg2_quad1e7", "cfg5_batched", "cfg4_lbfgsb",
+for name in ("northstar", "northstar_unfused", "northstar_gram", "northstar_gram_f32h", "sharded_n1", "cfg3_m20", "cfg3_m20_gram", "cfg2_quad1e7", "cfg5_batched", "cfg4_lbfgsb",
              "cfg4_lbfgsb_mfma", "cfg4_lbfgsb_devmin4096"):
     f = os.path.join(src, "bench_%s.json" % name)
     if os.path.exists(f):
@@ -59,7 +59,20 @@ for k, c in sorted(agg.items()):
 tl = {k: v for k, v in out["kernels"].items() if k.startswith("k_twoloop") and "persist" not in k}
 ps = {k: v for k, v in out["kernels"].items() if k.startswith("k_twoloop_persist")}
 calls = sum(v["calls"] for v in tl.values())
-if ps:
+fused = {k: v for k, v in ps.items() if "true" in k}
+if fused:
+    # round 2: every apply_Hv after the first rides in the launch that also carries K3 (k_twoloop_persist<T, true>,
+    # lbfgsx_post_linesearch_spec).  Launch k (k = 1, 2, ...) runs 2*min(k, 10)+1 steps, step 0 being the post statements.
+    v = list(fused.values())[0]
+    steps = sum(2 * min(k, 10) + 1 for k in range(1, v["calls"] + 1))
+    out["fused_post"] = True
+    out["twoloop_persistent"] = {"kernel": list(fused.keys())[0], "launches": v["calls"], "steps": steps,
+                                 "hbm_bytes_per_step": v["hbm_bytes_per_launch"] * v["calls"] / steps,
+                                 "ms_per_step": v["avg_ms"] * v["calls"] / steps,
+                                 "algorithmic_bytes_per_step_full_history": (8 * 10 + 5) * 1e8 * 8 / 21.0}
+    out["twoloop_avg_hbm_bytes_per_launch"] = out["twoloop_persistent"]["hbm_bytes_per_step"]
+    out["twoloop_avg_ms"] = out["twoloop_persistent"]["ms_per_step"]
+elif ps:
     # one persistent launch per apply_Hv = 2*ncorr+1 steps; the profiled command starts from an empty history with
     # m = 10, so launch k (k = 0, 1, ...) runs 2*min(k, 10)+1 steps.  Per-step figures make it comparable with the
     # step-wise kernels and with bench.py's algorithmic bytes per step.
@@ -123,3 +136,40 @@ gram_summary("batched", "batched", "--workload cfg5-batched --steps 50 --no-cpu"
              note="one launch covers the 1024 problems of the batch; launches start from an empty history (m = 10), "
                   "max_* are the full-history launches: kb_twoloop_full reads 4m columns-worth of f32 per problem "
                   "(the direction vector stays on the CU), i.e. 1024 * (40 + 2) * 1e5 * 4 B = 17.2 GB algorithmic")
+
+
+# ---- cfg4 (L-BFGS-B): per-kernel HBM traffic of scripts/bench_lbfgsb.py --n 1e7 --iters 40
+def lbfgsb_pmc():
+    tr = os.path.join(src, "lbfgsb", "b_kernel_stats.csv")
+    ff = os.path.join(src, "lbfgsb_pmc_fetch", "b_counter_collection.csv")
+    fw = os.path.join(src, "lbfgsb_pmc_write", "b_counter_collection.csv")
+    if not (os.path.exists(tr) and os.path.exists(ff) and os.path.exists(fw)):
+        return
+    a = collections.defaultdict(lambda: collections.defaultdict(list))
+    for fn in (ff, fw):
+        with open(fn) as f:
+            for r in csv.DictReader(f):
+                a[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    st = {}
+    with open(tr) as f:
+        for r in csv.DictReader(f):
+            st[short(r["Name"])] = (int(r["Calls"]), float(r["AverageNs"]), float(r["TotalDurationNs"]))
+    tot = sum(v[2] for v in st.values())
+    o = {"round": rnd, "command": "rocprofv3 {--kernel-trace --stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE} --output-format csv -- "
+                                  "python scripts/bench_lbfgsb.py --n 1e7 --iters 40  (cfg4; includes its untimed warm-up solve at n = 2^18)",
+         "units": out["units"], "total_kernel_ms": tot * 1e-6, "kernels": {}}
+    for k, c in a.items():
+        if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c or k not in st:
+            continue
+        calls, avg_ns, total_ns = st[k]
+        hb = (2.0 * sum(c["FETCH_SIZE"]) + sum(c["WRITE_SIZE"])) * 1024.0   # all launches of the kernel
+        o["kernels"][k] = {"calls": calls, "avg_ms": avg_ns * 1e-6, "share_of_kernel_time": total_ns / tot,
+                           "hbm_bytes_total": hb, "hbm_GBs": hb / (total_ns * 1e-9) / 1e9 if total_ns else None}
+    o["kernels"] = dict(sorted(o["kernels"].items(), key=lambda kv: -kv[1]["share_of_kernel_time"]))
+    with open(os.path.join("profiles", rnd + "_lbfgsb_pmc_summary.json"), "w") as f:
+        json.dump(o, f, indent=1)
+    for k, v in list(o["kernels"].items())[:14]:
+        print("%-44s calls %4d avg %.4f ms  %5.1f %%  %.0f GB/s" % (k[:44], v["calls"], v["avg_ms"], 100 * v["share_of_kernel_time"], v["hbm_GBs"] or 0))
+
+
+lbfgsb_pmc()
