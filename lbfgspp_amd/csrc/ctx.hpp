@@ -65,6 +65,7 @@ int live_count(int device);
 
 int bounded_alloc(lbfgsx_ctx* c);   // lbfgsb.hip
 void bounded_free(lbfgsx_ctx* c);
+int bounded_note_column(lbfgsx_ctx* c, int col);  // a history column pair was written outside k_b_post: refresh its max |.|
 struct GsState;                     // gram_space.hip: scratch of the Gram-space recursion (allocated on first use)
 void gs_free(lbfgsx_ctx* c);
 

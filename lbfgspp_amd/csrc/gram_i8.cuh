@@ -1,0 +1,372 @@
+// lbfgspp_amd/csrc/gram_i8.cuh -- K6 on the matrix cores, exactly: the masked Gram of solve_PtBP
+// (/root/reference/include/LBFGSpp/BFGSMat.h:543-556,  W_P'W_P  column by column) as an error-free integer contraction.
+//
+// Why integers.  The parity contract wants every Gram entry to be the correctly rounded value of the exact sum (the
+// oracle accumulates in extended precision), and ill-conditioned `mid` systems amplify even 1 ulp beyond 1e-10.  A
+// floating-point MFMA rounds after every accumulate; v_mfma_i32_32x32x32_i8 does not round at all.  So each column is put
+// on a fixed-point grid of its own (86 bits below a power of two that bounds the column, taken from the exact max |.| kept
+// per history column) and cut into D = 11 signed radix-256 digits:
+//     x  ~  2^(E - 86) * sum_k d_k 256^k ,   d_k in [-128, 127],  k = 0..10                (truncation < 2^(E - 86))
+// A product of two elements is the sum of 121 digit products d_k d'_l 256^(k+l); the 66 with k + l >= 10 are kept (the
+// rest is below 2^-82 of the two column scales), grouped by u = k + l - 10 into 11 int32 accumulator tiles: one
+// v_mfma_i32_32x32x32_i8 per digit pair adds the contributions of 32 rows to all 32 x 32 column pairs at once.  Sums of
+// integers are exact and order independent, so the result does not depend on the grid or on timing: per-wave int64
+// partials, an integer tree, and ONE rounding at the very end (k_gram_i8_final: double-double assembly of
+// sum_u V_u 256^(10+u), scaled by 2^(E_i + E_j - 172)).  Error against the exact sum: < 2^-80 of sum |x_i||x_j| for
+// entries whose columns are used to within 2^-3 of their max -- far inside the half-ulp, like the double-double kernel
+// (k_gram_dd) whose results it reproduces bit for bit in the tests.
+//
+// Layout.  Rows are loaded as in k_gram_dd: a wavefront takes 64 consecutive rows (lane = row, coalesced 512-byte column
+// segments), drops the rows outside the mask by ballot compaction and stages the survivors in a wave-private LDS tile
+// [row][col]; the prologue statement and the v row (W_P'v and v'v: 2c+1 double-double sums per lane, v is produced on
+// the fly and has no known scale) are evaluated right there, lane = row.  For the matrix cores the tile is re-read in
+// operand layout: lane l holds column l & 31 and the 16 rows of half l >> 5, cuts its 16 elements into digits and
+// byte-transposes them into eleven 16-byte operands (one per digit); A and B operands of G = W'W are the same registers.
+// MFMA: 66 instructions per 32 staged rows; VALU (digits): ~36 integer instructions per element.
+#pragma once
+#include "lbfgsb_kernels.cuh"
+
+namespace lbfgsx {
+
+constexpr int kI8Digits = 11;
+constexpr int kI8Acc = 11;         // u = k + l - 10 = 0..10
+constexpr int kI8FlushGroups = 256;  // 32-row groups between flushes: 256 * 32 * 11 * 2^14 < 2^31
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+struct GramI8Args
+{
+    const unsigned long long* colmax;  // bit patterns of max |column| per physical column: [0, m] Y, [m+1, 2m+1] S
+    int cidx[32];                      // logical column -> index into colmax
+};
+
+// 11 signed digits of trunc(x * 2^(86 - E)), E = emax - 1022 (emax: biased exponent of the column's max): bytes 0..7 in
+// lo, 8..10 in hi
+__device__ __forceinline__ void gram_i8_digits(double x, int emax, unsigned long long& lo, unsigned long long& hi)
+{
+    const unsigned long long bits = (unsigned long long) __double_as_longlong(x);
+    const int e = int((bits >> 52) & 0x7FFull);
+    unsigned long long M = (bits & 0x000FFFFFFFFFFFFFull) | 0x0010000000000000ull;
+    M = (e == 0) ? 0ull : M;  // zeros; denormals lie > 2^-900 below any column scale
+    const int sh = e - emax + 33;  // <= 33: |t| < 2^86
+    unsigned long long l, h;
+    if (sh >= 0)
+    {
+        l = M << sh;
+        h = (sh > 11) ? (M >> (64 - sh)) : 0ull;  // M < 2^53: nothing leaves the low word for sh <= 11
+    }
+    else
+    {
+        const int r = -sh;
+        l = (r < 64) ? (M >> r) : 0ull;
+        h = 0ull;
+    }
+    // two's complement of (h:l) for negative x
+    const unsigned long long sm = (unsigned long long) (((long long) bits) >> 63);
+    l ^= sm;
+    h ^= sm;
+    const unsigned long long l1 = l - sm;  // + 1 when negative
+    h += (sm != 0ull && l1 == 0ull) ? 1ull : 0ull;
+    // bias 0x80 into bytes 0..9 (all but the leading digit) and flip it back: unsigned bytes -> signed digits
+    const unsigned long long bl = 0x8080808080808080ull, bh = 0x0000000000008080ull;
+    const unsigned long long l2 = l1 + bl;
+    h = h + bh + ((l2 < bl) ? 1ull : 0ull);
+    lo = l2 ^ bl;
+    hi = h ^ bh;
+}
+
+// 4 x 4 byte transpose: word w of four elements -> four words, byte j of output k = byte k of input j
+__device__ __forceinline__ void gram_i8_tr4(unsigned a, unsigned b, unsigned c, unsigned d, unsigned (&o)[4])
+{
+    const unsigned t0 = __builtin_amdgcn_perm(b, a, 0x05010400u);  // a0 b0 a1 b1
+    const unsigned t1 = __builtin_amdgcn_perm(b, a, 0x07030602u);  // a2 b2 a3 b3
+    const unsigned t2 = __builtin_amdgcn_perm(d, c, 0x05010400u);  // c0 d0 c1 d1
+    const unsigned t3 = __builtin_amdgcn_perm(d, c, 0x07030602u);  // c2 d2 c3 d3
+    o[0] = __builtin_amdgcn_perm(t2, t0, 0x05040100u);             // a0 b0 c0 d0
+    o[1] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);             // a1 b1 c1 d1
+    o[2] = __builtin_amdgcn_perm(t3, t1, 0x05040100u);             // a2 b2 c2 d2
+    o[3] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);             // a3 b3 c3 d3
+}
+
+// entry (i, j), i >= j, of the packed lower triangle
+__device__ __forceinline__ int gram_tri(int i, int j) { return i * (i + 1) / 2 + j; }
+
+// part_i: [waves][kI8Acc][ne_pad] int64 (ne_pad = padded number of lower-triangle entries of the ncols x ncols block)
+// part_v: [waves][32][2] double-double sums of the v row: entry j < ncols = v . col_j, entry ncols = v . v
+template <int CS>
+__global__ void __launch_bounds__(kBlock, 1)
+    k_gram_i8(Cols<double, 32> cols, int ncols, BVecs<double> b, int vsel_id, int mask, int64_t n,
+              long long* __restrict__ part_i, int ne_pad, double* __restrict__ part_v, GramPrologue<double> pro, GramI8Args ga)
+{
+    constexpr int cs = CS;
+    extern __shared__ double tile[];
+    __shared__ double pc1[64], pc2[64];
+    __shared__ int s_emax[32];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < 64)
+    {
+        pc1[tid] = pro.c1[tid];
+        pc2[tid] = pro.c2[tid];
+    }
+    if (tid < 32)
+        s_emax[tid] = (tid < ncols) ? int((ga.colmax[ga.cidx[tid]] >> 52) & 0x7FFull) : 0;
+    __syncthreads();
+    double* tl = tile + wv * (kGramDDRows * cs);
+    const int mc = lane & 31, mh = lane >> 5;  // operand layout: column, row half
+    const int my_emax = s_emax[mc];
+    const bool col_ok = mc < ncols;
+    const int64_t gwave = int64_t(blockIdx.x) * (kBlock / 64) + wv;
+    const int64_t nwaves = int64_t(gridDim.x) * (kBlock / 64);
+    long long* mypart = part_i + gwave * int64_t(kI8Acc) * ne_pad;
+
+    i32x16 acc[kI8Acc];
+#pragma unroll
+    for (int u = 0; u < kI8Acc; u++)
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            acc[u][r] = 0;
+    int groups = 0;
+    bool flushed_once = false;
+    // v row: lane l accumulates entry l % (ncols + 1) -- v . col_j for j < ncols, v . v for j = ncols -- over the staged
+    // rows l / (ncols + 1), + nvg, ... (nvg = 64 / (ncols + 1) rows per trip use all lanes); v sits in tile column ncols
+    DD accv;
+    const int nv1 = ncols + 1, nvg = 64 / nv1;
+    const int vj = lane % nv1, vg = lane / nv1;
+
+    auto flush = [&]() {
+        // C/D layout of the 32x32 tile: column j = lane & 31, row i = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+        for (int u = 0; u < kI8Acc; u++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+            {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * mh, j = mc;
+                if (i < ncols && j <= i)
+                {
+                    long long* p = mypart + int64_t(u) * ne_pad + gram_tri(i, j);
+                    const long long old = flushed_once ? *p : 0ll;
+                    *p = old + (long long) acc[u][r];
+                }
+                acc[u][r] = 0;
+            }
+        flushed_once = true;
+        groups = 0;
+    };
+
+    const int64_t nbatch = (n + kGramDDRows - 1) / kGramDDRows;
+    for (int64_t bt = gwave; bt < nbatch; bt += nwaves)
+    {
+        const int64_t r = bt * kGramDDRows + lane;
+        const unsigned char st = (mask && r < n) ? b.st[r] : (unsigned char) 0;
+        const bool keep = r < n && (!mask || (st & mask));
+        const unsigned long long bal = __ballot(keep);
+        const int cnt = __popcll(bal);
+        if (cnt == 0)
+            continue;
+        const int pos = __popcll(bal & ((1ull << lane) - 1ull));
+        if (keep)
+        {
+            double* row = tl + pos * cs;
+            for (int c0 = 0; c0 < ncols; c0 += 8)
+            {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    v[u] = (c0 + u < ncols) ? cols.p[c0 + u][r] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (c0 + u < ncols)
+                        row[c0 + u] = v[u];
+            }
+            if (pro.mode != GP_NONE)
+            {
+                // (W * coef)(row): columns in order, plain accumulation -- the statement k_wcombine evaluates
+                double a1 = 0.0, a2 = 0.0;
+                if (pro.use1)
+                    for (int j = 0; j < ncols; j++)
+                        a1 = a1 + row[j] * pc1[j];
+                if (pro.use2)
+                    for (int j = 0; j < ncols; j++)
+                        a2 = a2 + row[j] * pc2[j];
+                if (pro.mode == GP_RHS)
+                {
+                    double rh = b.rhs[r];
+                    if (pro.use1)
+                        rh = rh + (-a1);
+                    if (pro.use2)
+                        rh = rh + (-a2);
+                    b.rhs[r] = rh;
+                }
+                else
+                    b.cF[r] = (pro.use1 ? (-1.0 * a1) : 0.0) + b.g[r];
+            }
+            if (vsel_id >= 0)
+                row[ncols] = vsel(b, vsel_id, r);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (vsel_id >= 0 && vg < nvg)
+            for (int rr = vg; rr < cnt; rr += nvg)
+                accv.add_prod(tl[rr * cs + ncols], tl[rr * cs + vj]);
+        for (int g0 = 0; g0 < cnt; g0 += 32)
+        {
+            // ---- digits of this lane's 16 elements (rows g0 + 16 mh + t of column mc), byte-transposed into operands
+            i32x4 dig[kI8Digits];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+            {
+                unsigned w0[4], w1[4], w2[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                {
+                    const int rr = g0 + 16 * mh + 4 * q + t;
+                    const double x = (col_ok && rr < cnt) ? tl[rr * cs + mc] : 0.0;
+                    unsigned long long lo, hi;
+                    gram_i8_digits(x, my_emax, lo, hi);
+                    w0[t] = unsigned(lo);
+                    w1[t] = unsigned(lo >> 32);
+                    w2[t] = unsigned(hi);
+                }
+                unsigned o[4];
+                gram_i8_tr4(w0[0], w0[1], w0[2], w0[3], o);
+                dig[0][q] = int(o[0]);
+                dig[1][q] = int(o[1]);
+                dig[2][q] = int(o[2]);
+                dig[3][q] = int(o[3]);
+                gram_i8_tr4(w1[0], w1[1], w1[2], w1[3], o);
+                dig[4][q] = int(o[0]);
+                dig[5][q] = int(o[1]);
+                dig[6][q] = int(o[2]);
+                dig[7][q] = int(o[3]);
+                gram_i8_tr4(w2[0], w2[1], w2[2], w2[3], o);
+                dig[8][q] = int(o[0]);
+                dig[9][q] = int(o[1]);
+                dig[10][q] = int(o[2]);
+                // one quartet of elements at a time: left alone, the scheduler starts all 16 extractions at once and the
+                // 64-bit temporaries of the digit arithmetic spill
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- 66 digit pairs: accumulator u collects k + l = 10 + u
+#pragma unroll
+            for (int u = 0; u < kI8Acc; u++)
+#pragma unroll
+                for (int k = 0; k < kI8Digits; k++)
+                {
+                    const int l = 10 + u - k;
+                    if (l >= 0 && l < kI8Digits)
+                        acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(dig[k], dig[l], acc[u], 0, 0, 0);
+                }
+            if (++groups >= kI8FlushGroups)
+                flush();
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    flush();
+    // v row: the lanes that hold the same entry are nv1 apart
+    if (vsel_id >= 0)
+    {
+        __builtin_amdgcn_wave_barrier();
+        double* scr = tl;  // the tile is free now: [64][2]
+        scr[lane * 2 + 0] = accv.hi;
+        scr[lane * 2 + 1] = accv.lo;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < nv1)
+        {
+            DD t;
+            for (int g = 0; g < nvg; g++)
+                t.merge(scr[(g * nv1 + lane) * 2 + 0], scr[(g * nv1 + lane) * 2 + 1]);
+            part_v[(gwave * 32 + lane) * 2 + 0] = t.hi;
+            part_v[(gwave * 32 + lane) * 2 + 1] = t.lo;
+        }
+    }
+}
+
+// integer tree, level 1: sum the per-wave partials.  grid = (kI8Acc, chunks); vsum[u][e] (int64) via atomics on the few
+// chunk results (integer addition: exact, order independent)
+__global__ void __launch_bounds__(kBlock) k_gram_i8_sum(const long long* __restrict__ part_i, int nwaves, int ne, int ne_pad,
+                                                        unsigned long long* __restrict__ vsum)
+{
+    const int u = blockIdx.x, ch = blockIdx.y, nch = gridDim.y;
+    for (int e = threadIdx.x; e < ne; e += kBlock)
+    {
+        long long t = 0;
+        for (int w = ch; w < nwaves; w += nch)
+            t += part_i[(int64_t(w) * kI8Acc + u) * ne_pad + e];
+        atomicAdd(vsum + u * ne_pad + e, (unsigned long long) t);
+    }
+}
+
+// the one rounding: entry e = (i, j) of the ncols x ncols block from its 11 integer sums; the v row from the per-wave
+// double-double partials.  out / out_dd in the packed lower-triangle format of k_gram_finish's callers:
+// e = i (i + 1) / 2 + j over ntot = ncols (+ 1 with v) rows.
+__global__ void __launch_bounds__(kBlock) k_gram_i8_final(const unsigned long long* __restrict__ vsum, int ncols, int ne_pad,
+                                                          const double* __restrict__ part_v, int nwaves, int with_v,
+                                                          GramI8Args ga, double* __restrict__ out, double* __restrict__ out_dd)
+{
+    const int ne = ncols * (ncols + 1) / 2;
+    for (int e = threadIdx.x; e < ne; e += kBlock)
+    {
+        int i = 0;
+        while ((i + 1) * (i + 2) / 2 <= e)
+            i++;
+        const int j = e - i * (i + 1) / 2;
+        const int ei = int((ga.colmax[ga.cidx[i]] >> 52) & 0x7FFull) - 1022;
+        const int ej = int((ga.colmax[ga.cidx[j]] >> 52) & 0x7FFull) - 1022;
+        DD t;
+        for (int u = kI8Acc - 1; u >= 0; u--)
+        {
+            const long long v = (long long) vsum[u * ne_pad + e];
+            const double hi = double(v);                       // |v| < 2^56: the difference below is exact
+            const double lo = double(v - (long long) hi);
+            const int sc = ei + ej - 172 + 8 * (10 + u);
+            t.add(ldexp(hi, sc));
+            t.add(ldexp(lo, sc));
+        }
+        const double s = t.hi + t.lo;  // renormalise
+        t.lo = t.lo - (s - t.hi);
+        t.hi = s;
+        out[e] = t.value();
+        if (out_dd)
+        {
+            out_dd[e * 2 + 0] = t.hi;
+            out_dd[e * 2 + 1] = t.lo;
+        }
+    }
+    if (with_v)
+        for (int j = threadIdx.x; j <= ncols; j += kBlock)
+        {
+            DD t;
+            for (int w = 0; w < nwaves; w++)
+                t.merge(part_v[(int64_t(w) * 32 + j) * 2 + 0], part_v[(int64_t(w) * 32 + j) * 2 + 1]);
+            out[ne + j] = t.value();
+            if (out_dd)
+            {
+                out_dd[(ne + j) * 2 + 0] = t.hi;
+                out_dd[(ne + j) * 2 + 1] = t.lo;
+            }
+        }
+}
+
+// exact max |col| of one column into its slot (columns that did not come through k_b_post)
+template <class T>
+__global__ void __launch_bounds__(kBlock) k_colmax2(const T* __restrict__ s, const T* __restrict__ y, int64_t n,
+                                                    unsigned long long* slot_s, unsigned long long* slot_y)
+{
+    double ms = 0.0, my = 0.0;
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
+    {
+        ms = fmax(ms, fabs(double(s[i])));
+        my = fmax(my, fabs(double(y[i])));
+    }
+    block_atomic_max(slot_s, ms);
+    block_atomic_max(slot_y, my);
+}
+
+}  // namespace lbfgsx

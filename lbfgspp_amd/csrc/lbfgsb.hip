@@ -10,6 +10,7 @@
 #include "lbfgs_kernels.cuh"
 #include "lbfgsb_kernels.cuh"
 #include "gcp_scan.cuh"
+#include "gram_i8.cuh"
 
 struct lbfgsb_state
 {
@@ -41,6 +42,14 @@ struct lbfgsb_state
     double* gram_out = nullptr;       // [3][256]
     int gram_blocks = 1024;  // 4 resident blocks per CU (33 KB of LDS each)
     bool gram_mfma = false;  // opt-in (LBFGSX_GRAM=mfma): ~1 ulp per entry instead of the correctly rounded sums
+    // exact Gram on the matrix cores (gram_i8.cuh): radix-256 digits, v_mfma_i32_32x32x32_i8, integer sums
+    bool gram_i8 = false;                    // LBFGSX_GRAM=i8
+    unsigned long long* colmax = nullptr;    // [m + 1][2]: bit patterns of max |Y col|, max |S col| per physical column
+    std::vector<unsigned char> colmax_ok;    // per physical column: the slots above describe the column's current content
+    long long* i8_part = nullptr;            // [waves][11][ne_pad]
+    double* i8_partv = nullptr;              // [waves][32][2]
+    unsigned long long* i8_vsum = nullptr;   // [11][ne_pad]
+    int i8_waves = 0, i8_nepad = 0;
     int gram_mode = 0;       // 2 (LBFGSX_GRAM=blocked): force the multi-launch blocked Gram + separate W'v
     int gram_dd_blocks = 0;          // LBFGSX_GRAM_DD_BLOCKS: 0 = occupancy x CUs
     int num_cus = 256;
@@ -203,6 +212,9 @@ int bounded_alloc(lbfgsx_ctx* c)
         LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->dout), sizeof(double) * 64));
     LBFGSX_HIP(hipMalloc(&b->coef_dev, sizeof(double) * 80));
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->mslot), sizeof(unsigned long long) * 2));
+    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->colmax), sizeof(unsigned long long) * 2 * size_t(c->m + 1)));
+    LBFGSX_HIP(hipMemset(b->colmax, 0, sizeof(unsigned long long) * 2 * size_t(c->m + 1)));
+    b->colmax_ok.assign(size_t(c->m + 1), 0);
     // radix sort temporary storage
     size_t bytes = 0;
     if (c->dtype == LBFGSX_F64)
@@ -214,6 +226,7 @@ int bounded_alloc(lbfgsx_ctx* c)
     if (const char* e = getenv("LBFGSX_GRAM"))
     {
         b->gram_mfma = (std::strcmp(e, "mfma") == 0);
+        b->gram_i8 = (std::strcmp(e, "i8") == 0);
         b->gram_mode = (std::strcmp(e, "blocked") == 0) ? 2 : 0;
     }
     if (const char* e = getenv("LBFGSX_GCP_CHAIN"))
@@ -258,6 +271,10 @@ void bounded_free(lbfgsx_ctx* c)
                     b->s_small, b->s_exit, b->pk, b->pv, b->pcount, b->sel_tmp};
     if (b->h_chain)
         (void) hipHostFree(b->h_chain);
+    (void) hipFree(b->colmax);
+    (void) hipFree(b->i8_part);
+    (void) hipFree(b->i8_partv);
+    (void) hipFree(b->i8_vsum);
     for (void* p : ptrs)
     {
         // dout / gram_out are device aliases of host-mapped memory when the mapped outputs are on
@@ -564,11 +581,15 @@ int lbfgsx_b_post_linesearch(lbfgsx_ctx* c, double* projgnorm, double* xnorm2, d
     if (rc)
         return rc;
     double r[3];
+    // exact max |s|, max |y| of the new column pair ride along (the fixed-point scale of the integer Gram, gram_i8.cuh)
+    unsigned long long* cmx = c->bstate->colmax + 2 * size_t(c->spare);
+    LBFGSX_HIP(hipMemsetAsync(cmx, 0, 2 * sizeof(unsigned long long), c->stream));
+    c->bstate->colmax_ok[size_t(c->spare)] = 1;
     DISPATCH_T(c, {
         hipLaunchKernelGGL((k_b_post<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]), P<T>(c->xb[c->xp]),
                            P<T>(c->gb[c->cur]), P<T>(c->gb[c->xp]), P<T>(c->lb), P<T>(c->ub), P<T>(c->col(c->S, c->spare)),
                            P<T>(c->col(c->Y, c->spare)), c->n, c->ws, c->out_slot<T>(),
-                           P<T>(c->sc) + c->sl.ys(c->spare), P<T>(c->sc) + c->sl.theta(c->spare), c->bstate->mslot);
+                           P<T>(c->sc) + c->sl.ys(c->spare), P<T>(c->sc) + c->sl.theta(c->spare), c->bstate->mslot, cmx);
         LBFGSX_HIP(hipGetLastError());
         rc = fetch_T<T>(c, c->sl.out(0), 3, r);
     });
@@ -1125,6 +1146,91 @@ int lbfgsx_b_gram(lbfgsx_ctx* c, int mask, double* gram)
 // kernel (~1 ulp per entry, 2c+1 <= 32).  Returns LBFGSX_E_INVALID (outputs untouched) when neither applies; the
 // caller then falls back to lbfgsx_b_gram + lbfgsx_b_wtv.
 }  // extern "C"
+namespace lbfgsx {
+int bounded_note_column(lbfgsx_ctx* c, int col)
+{
+    lbfgsb_state* b = c->bstate;
+    if (!b || col < 0 || col > c->m)
+        return LBFGSX_OK;
+    unsigned long long* cmx = b->colmax + 2 * size_t(col);
+    LBFGSX_HIP(hipMemsetAsync(cmx, 0, 2 * sizeof(unsigned long long), c->stream));
+    const int grid = c->grid_for(c->n);
+    DISPATCH_T(c, {
+        hipLaunchKernelGGL((k_colmax2<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->col(c->S, col)), P<T>(c->col(c->Y, col)),
+                           c->n, cmx + 1, cmx + 0);
+    });
+    LBFGSX_HIP(hipGetLastError());
+    b->colmax_ok[size_t(col)] = 1;
+    return LBFGSX_OK;
+}
+}  // namespace lbfgsx
+
+// exact integer Gram on the matrix cores (gram_i8.cuh): returns the number of per-wave partials, or -1 when not applicable
+template <int CS>
+static int launch_gram_i8_cs(lbfgsx_ctx* c, int tot, int vsel_id, int mask, const GramPrologue<double>& pro, const GramI8Args& ga,
+                             int blocks, int ne_pad)
+{
+    lbfgsb_state* b = c->bstate;
+    int which[32];
+    for (int k = 0; k < tot; k++)
+        which[k] = k;
+    Cols<double, 32> cl = col_list<double, 32>(c, which, tot);
+    const size_t lds = size_t(kBlock / 64) * kGramDDRows * size_t(CS) * sizeof(double);
+    hipLaunchKernelGGL((k_gram_i8<CS>), dim3(blocks), dim3(kBlock), lds, c->stream, cl, tot, bvecs<double>(c), vsel_id, mask, c->n,
+                       b->i8_part, ne_pad, b->i8_partv, pro, ga);
+    return blocks * (kBlock / 64);
+}
+static int gram_i8_run(lbfgsx_ctx* c, int tot, int vsel_id, int mask, const GramPrologue<double>& pro, bool want_dd)
+{
+    lbfgsb_state* b = c->bstate;
+    GramI8Args ga;
+    ga.colmax = b->colmax;
+    for (int k = 0; k < 32; k++)
+        ga.cidx[k] = 0;
+    for (int k = 0; k < tot; k++)
+    {
+        const int slot = (k < c->ncorr) ? k : k - c->ncorr;
+        const int col = c->phys[size_t(slot)];
+        if (!b->colmax_ok[size_t(col)])
+            return -1;
+        ga.cidx[k] = 2 * col + ((k < c->ncorr) ? 0 : 1);  // Y columns first, then S columns (col_list's order)
+    }
+    const int ne = tot * (tot + 1) / 2;
+    const int ne_pad = (ne + 63) / 64 * 64;
+    const int64_t nbatch = (c->n + kGramDDRows - 1) / kGramDDRows;
+    const int blocks = int(std::max<int64_t>(1, std::min<int64_t>(b->num_cus, (nbatch + 3) / 4)));
+    const int waves = blocks * (kBlock / 64);
+    if (waves > b->i8_waves || ne_pad > b->i8_nepad)
+    {
+        (void) hipFree(b->i8_part);
+        (void) hipFree(b->i8_partv);
+        (void) hipFree(b->i8_vsum);
+        b->i8_part = nullptr;
+        b->i8_partv = nullptr;
+        b->i8_vsum = nullptr;
+        const int wcap = std::max(waves, b->num_cus * (kBlock / 64));
+        const int ecap = std::max(ne_pad, 512);  // 2c <= 30 -> 465 entries
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->i8_part), sizeof(long long) * size_t(wcap) * kI8Acc * size_t(ecap)));
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->i8_partv), sizeof(double) * size_t(wcap) * 32 * 2));
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->i8_vsum), sizeof(unsigned long long) * kI8Acc * size_t(ecap)));
+        b->i8_waves = wcap;
+        b->i8_nepad = ecap;
+    }
+    LBFGSX_HIP(hipMemsetAsync(b->i8_vsum, 0, sizeof(unsigned long long) * kI8Acc * size_t(ne_pad), c->stream));
+    if (vsel_id >= 0)
+        LBFGSX_HIP(hipMemsetAsync(b->i8_partv, 0, sizeof(double) * size_t(waves) * 32 * 2, c->stream));
+    if (tot <= 23)
+        launch_gram_i8_cs<23>(c, tot, vsel_id, mask, pro, ga, blocks, ne_pad);
+    else
+        launch_gram_i8_cs<31>(c, tot, vsel_id, mask, pro, ga, blocks, ne_pad);
+    const int nch = std::min(waves, 16);
+    hipLaunchKernelGGL(k_gram_i8_sum, dim3(kI8Acc, nch), dim3(kBlock), 0, c->stream, b->i8_part, waves, ne, ne_pad, b->i8_vsum);
+    hipLaunchKernelGGL(k_gram_i8_final, dim3(1), dim3(kBlock), 0, c->stream, b->i8_vsum, tot, ne_pad, b->i8_partv, waves,
+                       vsel_id >= 0 ? 1 : 0, ga, b->gram_out, want_dd ? b->gram_dd : static_cast<double*>(nullptr));
+    LBFGSX_HIP(hipGetLastError());
+    return waves;
+}
+
 template <class T, int KP>
 static int launch_gram_dd(lbfgsx_ctx* c, int64_t nbatch, int tot, int vsel_id, int mask, const GramPrologue<T>& pro)
 {
@@ -1315,6 +1421,27 @@ int lbfgsx_b_gram_fused_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
     rc = upload_phys(c);
     if (rc)
         return rc;
+    bool done_i8 = false;
+    if (b->gram_i8 && c->dtype == LBFGSX_F64 && tot <= 30)
+    {
+        GramPrologue<double> pro;
+        pro.mode = prologue;
+        pro.use1 = coef1 ? 1 : 0;
+        pro.use2 = coef2 ? 1 : 0;
+        for (int k = 0; k < 64; k++)
+        {
+            pro.c1[k] = (coef1 && k < tot) ? coef1[k] : 0.0;
+            pro.c2[k] = (coef2 && k < tot) ? coef2[k] : 0.0;
+        }
+        const int w = gram_i8_run(c, tot, vsel_id, mask, pro, gram_dd != nullptr);
+        if (w < -1)
+            return w;
+        done_i8 = (w > 0);
+    }
+    const int kpt_ = kp <= 1 ? 1 : kp <= 2 ? 2 : kp <= 4 ? 4 : kp <= 6 ? 6 : 8;
+    const int ntile_ = (64 * kpt_ + 255) / 256;
+    if (!done_i8)
+    {
     DISPATCH_T(c, {
         GramPrologue<T> pro;
         pro.mode = prologue;
@@ -1331,13 +1458,13 @@ int lbfgsx_b_gram_fused_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
         else if (kp <= 6) blocks = launch_gram_dd<T, 6>(c, nbatch, tot, vsel_id, mask, pro);
         else blocks = launch_gram_dd<T, 8>(c, nbatch, tot, vsel_id, mask, pro);
     });
-    const int kpt = kp <= 1 ? 1 : kp <= 2 ? 2 : kp <= 4 ? 4 : kp <= 6 ? 6 : 8;
-    const int ntile = (64 * kpt + 255) / 256;
     const int nch = std::min(blocks, 32);
-    hipLaunchKernelGGL(k_gram_finish, dim3(ntile, nch), dim3(kBlock), 0, c->stream, b->gram_partial, blocks, b->gram_partial2, 0);
-    hipLaunchKernelGGL(k_gram_finish, dim3(ntile, 1), dim3(kBlock), 0, c->stream, b->gram_partial2, nch, b->gram_out, 1,
+    hipLaunchKernelGGL(k_gram_finish, dim3(ntile_, nch), dim3(kBlock), 0, c->stream, b->gram_partial, blocks, b->gram_partial2, 0);
+    hipLaunchKernelGGL(k_gram_finish, dim3(ntile_, 1), dim3(kBlock), 0, c->stream, b->gram_partial2, nch, b->gram_out, 1,
                        gram_dd ? b->gram_dd : static_cast<double*>(nullptr));
     LBFGSX_HIP(hipGetLastError());
+    }
+    const int ntile = ntile_;
     std::vector<double> hdd;
     if (gram_dd)
     {

@@ -210,11 +210,12 @@ __global__ void __launch_bounds__(kBlock) k_b_post(const T* __restrict__ x, cons
                                                    const T* __restrict__ lb, const T* __restrict__ ub,
                                                    T* __restrict__ s, T* __restrict__ y, int64_t n, RedWs ws,
                                                    T* __restrict__ out, T* __restrict__ ys_slot,
-                                                   T* __restrict__ theta_slot, unsigned long long* maxslot)
+                                                   T* __restrict__ theta_slot, unsigned long long* maxslot,
+                                                   unsigned long long* colmax /* [0] max |y|, [1] max |s| of the new pair */)
 {
     typedef typename AccOf<T>::type A;
     A acc[3];
-    double pg = 0.0;
+    double pg = 0.0, ms = 0.0, my = 0.0;
     const int64_t stride = int64_t(gridDim.x) * kBlock;
     for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
     {
@@ -226,8 +227,12 @@ __global__ void __launch_bounds__(kBlock) k_b_post(const T* __restrict__ x, cons
         acc[1].add_prod(si, yi);
         acc[2].add_prod(yi, yi);
         pg = fmax(pg, double(projg_term(xi, gi, lb[i], ub[i])));
+        ms = fmax(ms, fabs(double(si)));
+        my = fmax(my, fabs(double(yi)));
     }
     block_atomic_max(maxslot, pg);
+    block_atomic_max(colmax + 0, my);
+    block_atomic_max(colmax + 1, ms);
     if (grid_reduce<3>(acc, ws) && threadIdx.x == 0)
     {
         const T sy = T(acc[1].value()), yy = T(acc[2].value());

@@ -593,6 +593,12 @@ int lbfgsx_bfgs_stage_correction_host(lbfgsx_ctx* c, const void* s, const void* 
     void* yp = c->col(c->Y, c->spare);
     LBFGSX_HIP(hipMemcpyAsync(sp, s, size_t(c->n) * c->esz, hipMemcpyHostToDevice, c->stream));
     LBFGSX_HIP(hipMemcpyAsync(yp, y, size_t(c->n) * c->esz, hipMemcpyHostToDevice, c->stream));
+    if (c->bstate)
+    {
+        const int rcn = bounded_note_column(c, c->spare);
+        if (rcn)
+            return rcn;
+    }
     const int grid = c->grid_for(c->n);
     double r[2];
     DISPATCH_T(c, {

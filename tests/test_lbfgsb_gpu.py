@@ -368,3 +368,66 @@ def test_partial_break_point_sort_is_exact_and_falls_back(A, monkeypatch):
     assert short[6] > 0                     # ... and redone in full when tau was too small
     for r in (part, short):
         assert r[:3] == full[:3] and r[4] == full[4] and np.array_equal(r[3], full[3])
+
+
+@pytest.mark.parametrize("n,m,npairs,spread", [(5000, 10, 10, 0), (300001, 6, 4, 6), (1 << 20, 15, 15, 3), (70, 3, 2, 0),
+                                               (200003, 10, 7, 12)])
+def test_integer_mfma_gram_is_bit_identical_to_the_double_double_gram(A, monkeypatch, n, m, npairs, spread):
+    """LBFGSX_GRAM=i8 (csrc/gram_i8.cuh): W_P'W_P on v_mfma_i32_32x32x32_i8 from radix-256 digits of a per-column
+    fixed-point grid -- integer sums, one rounding at the end.  Every rounded entry must equal the double-double kernel's
+    (both are the correctly rounded exact sum), the un-rounded (hi, lo) pairs must agree to ~2^-95, and the v row (kept
+    in double-double) is identical.  `spread`: rows scaled by 10^U(-spread, spread) so that most elements sit far below
+    their column's maximum (the digits of small elements start many bytes down)."""
+    from lbfgspp_amd import _lib as L
+    core, _ = A.load()
+    vp = C.c_void_p
+    f = core.lbfgsx_b_gram_fused_dd
+    f.restype, f.argtypes = C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+    out = {}
+    for mode in ("i8", "dd"):
+        monkeypatch.setenv("LBFGSX_GRAM", mode)
+        h = C.c_void_p()
+        L.check(core.lbfgsx_create(C.byref(h), 0, n, m, 0, 1))
+        rng = np.random.default_rng(n + 17)
+        scale = 10.0 ** rng.uniform(-spread, spread, n) if spread else np.ones(n)
+        for k in range(npairs):
+            s_ = rng.standard_normal(n) * scale
+            y_ = s_ * (1 + rng.random(n))
+            L.check(core.lbfgsx_bfgs_add_correction_host(h, s_.ctypes.data_as(vp), y_.ctypes.data_as(vp)))
+        d = rng.standard_normal(n) * scale
+        L.check(core.lbfgsx_upload(h, L.VEC_D, d.ctypes.data_as(vp)))
+        t = 2 * min(npairs, m)
+        g, w, gd = np.zeros((t, t)), np.zeros(t), np.zeros(t * (t + 1))
+        L.check(f(h, 0, 0, 0, None, None, g.ctypes.data_as(vp), w.ctypes.data_as(vp), gd.ctypes.data_as(vp)))
+        core.lbfgsx_destroy(h)
+        out[mode] = (g, w, gd.reshape(-1, 2))
+    assert np.array_equal(out["i8"][0], out["dd"][0]), "rounded Gram entries differ: max rel %.3g" % (
+        np.abs(out["i8"][0] - out["dd"][0]) / np.abs(out["dd"][0])).max()
+    assert np.array_equal(out["i8"][1], out["dd"][1])
+    hi8, hdd = out["i8"][2], out["dd"][2]
+    tot8, totd = hi8[:, 0] + hi8[:, 1], hdd[:, 0] + hdd[:, 1]
+    assert np.array_equal(tot8, totd)
+    resid = np.abs((hi8[:, 0] - hdd[:, 0]) + (hi8[:, 1] - hdd[:, 1]))
+    diag = np.sqrt(np.abs(np.outer(np.diag(out["dd"][0]), np.diag(out["dd"][0]))))
+    idx = [(i, j) for i in range(diag.shape[0]) for j in range(i + 1)]
+    bound = np.array([diag[i, j] for i, j in idx]) * 2.0 ** -90
+    assert (resid <= bound).all(), "un-rounded sums differ by up to 2^%.1f of the column scales" % np.log2((resid / bound).max() * 2.0 ** -90)
+
+
+@pytest.mark.parametrize("n,m,iters,kappa", [(30000, 8, 18, 30.0), (400000, 10, 12, 10.0)])
+def test_integer_mfma_gram_trajectories_change_no_bit(A, monkeypatch, n, m, iters, kappa):
+    """whole L-BFGS-B runs (masks, prologues, the complement identity of the BOXCQP sweeps on the un-rounded sums) with
+    the integer Gram against the double-double Gram: identical iterates"""
+    a, b = O.quad_problem(n, kappa, 3, O.F64)
+    lb, ub = -np.ones(n), np.ones(n)
+    res = {}
+    for mode in ("i8", "dd"):
+        monkeypatch.setenv("LBFGSX_GRAM", mode)
+        s = A.LBFGSBSolver(A.LBFGSBParam(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters))
+        x = np.zeros(n)
+        tr = A.TraceBuffer(n, cap=512, stride=max(1, n // 5000))
+        niter, fx = s.minimize(A.DiagQuadratic(a, b), x, lb, ub, trace=tr)
+        res[mode] = (niter, s.last.nfev, fx, x, tr.xs[:tr.count].copy())
+        s.close()
+    assert res["i8"][:3] == res["dd"][:3]
+    assert np.array_equal(res["i8"][3], res["dd"][3]) and np.array_equal(res["i8"][4], res["dd"][4])
