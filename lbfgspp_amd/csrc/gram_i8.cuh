@@ -30,6 +30,7 @@ namespace lbfgsx {
 
 constexpr int kI8Digits = 11;
 constexpr int kI8Acc = 11;         // u = k + l - 10 = 0..10
+constexpr int kI8Ring = 128;       // rows of the wave-private staging ring (31 left over + 64 new < 128)
 constexpr int kI8FlushGroups = 256;  // 32-row groups between flushes: 256 * 32 * 11 * 2^14 < 2^31
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -112,7 +113,7 @@ __global__ void __launch_bounds__(kBlock, 1)
     if (tid < 32)
         s_emax[tid] = (tid < ncols) ? int((ga.colmax[ga.cidx[tid]] >> 52) & 0x7FFull) : 0;
     __syncthreads();
-    double* tl = tile + wv * (kGramDDRows * cs);
+    double* tl = tile + wv * (kI8Ring * cs);
     const int mc = lane & 31, mh = lane >> 5;  // operand layout: column, row half
     const int my_emax = s_emax[mc];
     const bool col_ok = mc < ncols;
@@ -154,41 +155,121 @@ __global__ void __launch_bounds__(kBlock, 1)
         groups = 0;
     };
 
+    int head = 0, fill = 0;  // ring rows [head, head + fill) are staged and not yet contracted
+    // ---- one group of (up to) 32 staged rows, ring positions head .. head + nrows - 1, onto the matrix cores
+    auto contract = [&](int nrows) {
+        // digits of this lane's 16 elements (rows 16 mh + t of the group, column mc), byte-transposed into operands
+        i32x4 dig[kI8Digits];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            unsigned w0[4], w1[4], w2[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+            {
+                const int rr = 16 * mh + 4 * q + t;
+                const double x = (col_ok && rr < nrows) ? tl[((head + rr) & (kI8Ring - 1)) * cs + mc] : 0.0;
+                unsigned long long lo, hi;
+                gram_i8_digits(x, my_emax, lo, hi);
+                w0[t] = unsigned(lo);
+                w1[t] = unsigned(lo >> 32);
+                w2[t] = unsigned(hi);
+            }
+            unsigned o[4];
+            gram_i8_tr4(w0[0], w0[1], w0[2], w0[3], o);
+            dig[0][q] = int(o[0]);
+            dig[1][q] = int(o[1]);
+            dig[2][q] = int(o[2]);
+            dig[3][q] = int(o[3]);
+            gram_i8_tr4(w1[0], w1[1], w1[2], w1[3], o);
+            dig[4][q] = int(o[0]);
+            dig[5][q] = int(o[1]);
+            dig[6][q] = int(o[2]);
+            dig[7][q] = int(o[3]);
+            gram_i8_tr4(w2[0], w2[1], w2[2], w2[3], o);
+            dig[8][q] = int(o[0]);
+            dig[9][q] = int(o[1]);
+            dig[10][q] = int(o[2]);
+        }
+        // 66 digit pairs: accumulator u collects k + l = 10 + u
+#pragma unroll
+        for (int u = 0; u < kI8Acc; u++)
+#pragma unroll
+            for (int k = 0; k < kI8Digits; k++)
+            {
+                const int l = 10 + u - k;
+                if (l >= 0 && l < kI8Digits)
+                    acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(dig[k], dig[l], acc[u], 0, 0, 0);
+            }
+        if (++groups >= kI8FlushGroups)
+            flush();
+    };
+
+    // ---- batches of 64 rows, software-pipelined: the state bytes run two batches ahead and the column values one batch
+    // ahead of the batch being staged (one wavefront per SIMD: nothing else hides the HBM latency)
     const int64_t nbatch = (n + kGramDDRows - 1) / kGramDDRows;
-    for (int64_t bt = gwave; bt < nbatch; bt += nwaves)
+    auto load_st = [&](int64_t bq) -> unsigned char {
+        const int64_t rq = bq * kGramDDRows + lane;
+        return (mask && bq < nbatch && rq < n) ? b.st[rq] : (unsigned char) 0;
+    };
+    auto keep_of = [&](int64_t bq, unsigned char stq) -> bool {
+        const int64_t rq = bq * kGramDDRows + lane;
+        return bq < nbatch && rq < n && (!mask || (stq & mask));
+    };
+    int64_t bt = gwave;
+    unsigned char st_a = load_st(bt), st_b = load_st(bt + nwaves);
+    bool keep_n = keep_of(bt, st_a);
+    double vn[CS];
+#pragma unroll
+    for (int j = 0; j < CS; j++)
+        vn[j] = (keep_n && j < ncols) ? cols.p[j][bt * kGramDDRows + lane] : 0.0;
+    for (; bt < nbatch; bt += nwaves)
     {
         const int64_t r = bt * kGramDDRows + lane;
-        const unsigned char st = (mask && r < n) ? b.st[r] : (unsigned char) 0;
-        const bool keep = r < n && (!mask || (st & mask));
+        const bool keep = keep_n;
+        double vc[CS];
+#pragma unroll
+        for (int j = 0; j < CS; j++)
+            vc[j] = vn[j];
+        // advance the prefetch
+        const int64_t bn = bt + nwaves;
+        st_a = st_b;
+        st_b = load_st(bn + nwaves);
+        keep_n = keep_of(bn, st_a);
+#pragma unroll
+        for (int j = 0; j < CS; j++)
+            vn[j] = (keep_n && j < ncols) ? cols.p[j][bn * kGramDDRows + lane] : 0.0;
         const unsigned long long bal = __ballot(keep);
         const int cnt = __popcll(bal);
         if (cnt == 0)
             continue;
         const int pos = __popcll(bal & ((1ull << lane) - 1ull));
+        const int base = head + fill;
         if (keep)
         {
-            double* row = tl + pos * cs;
-            for (int c0 = 0; c0 < ncols; c0 += 8)
-            {
-                double v[8];
+            double* row = tl + ((base + pos) & (kI8Ring - 1)) * cs;
 #pragma unroll
-                for (int u = 0; u < 8; u++)
-                    v[u] = (c0 + u < ncols) ? cols.p[c0 + u][r] : 0.0;
-#pragma unroll
-                for (int u = 0; u < 8; u++)
-                    if (c0 + u < ncols)
-                        row[c0 + u] = v[u];
-            }
+            for (int j = 0; j < CS; j++)
+                if (j < ncols)
+                    row[j] = vc[j];
             if (pro.mode != GP_NONE)
             {
                 // (W * coef)(row): columns in order, plain accumulation -- the statement k_wcombine evaluates
                 double a1 = 0.0, a2 = 0.0;
                 if (pro.use1)
-                    for (int j = 0; j < ncols; j++)
-                        a1 = a1 + row[j] * pc1[j];
+                {
+#pragma unroll
+                    for (int j = 0; j < CS; j++)
+                        if (j < ncols)
+                            a1 = a1 + vc[j] * pc1[j];
+                }
                 if (pro.use2)
-                    for (int j = 0; j < ncols; j++)
-                        a2 = a2 + row[j] * pc2[j];
+                {
+#pragma unroll
+                    for (int j = 0; j < CS; j++)
+                        if (j < ncols)
+                            a2 = a2 + vc[j] * pc2[j];
+                }
                 if (pro.mode == GP_RHS)
                 {
                     double rh = b.rhs[r];
@@ -209,62 +290,22 @@ __global__ void __launch_bounds__(kBlock, 1)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (vsel_id >= 0 && vg < nvg)
             for (int rr = vg; rr < cnt; rr += nvg)
-                accv.add_prod(tl[rr * cs + ncols], tl[rr * cs + vj]);
-        for (int g0 = 0; g0 < cnt; g0 += 32)
-        {
-            // ---- digits of this lane's 16 elements (rows g0 + 16 mh + t of column mc), byte-transposed into operands
-            i32x4 dig[kI8Digits];
-#pragma unroll
-            for (int q = 0; q < 4; q++)
             {
-                unsigned w0[4], w1[4], w2[4];
-#pragma unroll
-                for (int t = 0; t < 4; t++)
-                {
-                    const int rr = g0 + 16 * mh + 4 * q + t;
-                    const double x = (col_ok && rr < cnt) ? tl[rr * cs + mc] : 0.0;
-                    unsigned long long lo, hi;
-                    gram_i8_digits(x, my_emax, lo, hi);
-                    w0[t] = unsigned(lo);
-                    w1[t] = unsigned(lo >> 32);
-                    w2[t] = unsigned(hi);
-                }
-                unsigned o[4];
-                gram_i8_tr4(w0[0], w0[1], w0[2], w0[3], o);
-                dig[0][q] = int(o[0]);
-                dig[1][q] = int(o[1]);
-                dig[2][q] = int(o[2]);
-                dig[3][q] = int(o[3]);
-                gram_i8_tr4(w1[0], w1[1], w1[2], w1[3], o);
-                dig[4][q] = int(o[0]);
-                dig[5][q] = int(o[1]);
-                dig[6][q] = int(o[2]);
-                dig[7][q] = int(o[3]);
-                gram_i8_tr4(w2[0], w2[1], w2[2], w2[3], o);
-                dig[8][q] = int(o[0]);
-                dig[9][q] = int(o[1]);
-                dig[10][q] = int(o[2]);
-                // one quartet of elements at a time: left alone, the scheduler starts all 16 extractions at once and the
-                // 64-bit temporaries of the digit arithmetic spill
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
+                const double* rw = tl + ((base + rr) & (kI8Ring - 1)) * cs;
+                accv.add_prod(rw[ncols], rw[vj]);
             }
-            // ---- 66 digit pairs: accumulator u collects k + l = 10 + u
-#pragma unroll
-            for (int u = 0; u < kI8Acc; u++)
-#pragma unroll
-                for (int k = 0; k < kI8Digits; k++)
-                {
-                    const int l = 10 + u - k;
-                    if (l >= 0 && l < kI8Digits)
-                        acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(dig[k], dig[l], acc[u], 0, 0, 0);
-                }
-            if (++groups >= kI8FlushGroups)
-                flush();
+        fill += cnt;
+        while (fill >= 32)
+        {
+            contract(32);
+            head = (head + 32) & (kI8Ring - 1);
+            fill -= 32;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+    if (fill > 0)
+        contract(fill);
     flush();
     // v row: the lanes that hold the same entry are nv1 apart
     if (vsel_id >= 0)

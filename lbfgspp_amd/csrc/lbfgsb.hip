@@ -1175,7 +1175,7 @@ static int launch_gram_i8_cs(lbfgsx_ctx* c, int tot, int vsel_id, int mask, cons
     for (int k = 0; k < tot; k++)
         which[k] = k;
     Cols<double, 32> cl = col_list<double, 32>(c, which, tot);
-    const size_t lds = size_t(kBlock / 64) * kGramDDRows * size_t(CS) * sizeof(double);
+    const size_t lds = size_t(kBlock / 64) * kI8Ring * size_t(CS) * sizeof(double);
     hipLaunchKernelGGL((k_gram_i8<CS>), dim3(blocks), dim3(kBlock), lds, c->stream, cl, tot, bvecs<double>(c), vsel_id, mask, c->n,
                        b->i8_part, ne_pad, b->i8_partv, pro, ga);
     return blocks * (kBlock / 64);
