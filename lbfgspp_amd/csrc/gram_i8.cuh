@@ -156,57 +156,10 @@ __global__ void __launch_bounds__(kBlock, 1)
     };
 
     int head = 0, fill = 0;  // ring rows [head, head + fill) are staged and not yet contracted
-    // ---- one group of (up to) 32 staged rows, ring positions head .. head + nrows - 1, onto the matrix cores
-    auto contract = [&](int nrows) {
-        // digits of this lane's 16 elements (rows 16 mh + t of the group, column mc), byte-transposed into operands
-        i32x4 dig[kI8Digits];
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-        {
-            unsigned w0[4], w1[4], w2[4];
-#pragma unroll
-            for (int t = 0; t < 4; t++)
-            {
-                const int rr = 16 * mh + 4 * q + t;
-                const double x = (col_ok && rr < nrows) ? tl[((head + rr) & (kI8Ring - 1)) * cs + mc] : 0.0;
-                unsigned long long lo, hi;
-                gram_i8_digits(x, my_emax, lo, hi);
-                w0[t] = unsigned(lo);
-                w1[t] = unsigned(lo >> 32);
-                w2[t] = unsigned(hi);
-            }
-            unsigned o[4];
-            gram_i8_tr4(w0[0], w0[1], w0[2], w0[3], o);
-            dig[0][q] = int(o[0]);
-            dig[1][q] = int(o[1]);
-            dig[2][q] = int(o[2]);
-            dig[3][q] = int(o[3]);
-            gram_i8_tr4(w1[0], w1[1], w1[2], w1[3], o);
-            dig[4][q] = int(o[0]);
-            dig[5][q] = int(o[1]);
-            dig[6][q] = int(o[2]);
-            dig[7][q] = int(o[3]);
-            gram_i8_tr4(w2[0], w2[1], w2[2], w2[3], o);
-            dig[8][q] = int(o[0]);
-            dig[9][q] = int(o[1]);
-            dig[10][q] = int(o[2]);
-        }
-        // 66 digit pairs: accumulator u collects k + l = 10 + u
-#pragma unroll
-        for (int u = 0; u < kI8Acc; u++)
-#pragma unroll
-            for (int k = 0; k < kI8Digits; k++)
-            {
-                const int l = 10 + u - k;
-                if (l >= 0 && l < kI8Digits)
-                    acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(dig[k], dig[l], acc[u], 0, 0, 0);
-            }
-        if (++groups >= kI8FlushGroups)
-            flush();
-    };
 
-    // ---- batches of 64 rows, software-pipelined: the state bytes run two batches ahead and the column values one batch
-    // ahead of the batch being staged (one wavefront per SIMD: nothing else hides the HBM latency)
+    // ---- batches of 64 rows, software-pipelined: the state bytes run two batches ahead, the column values and the few
+    // per-row inputs of the prologue / of v one batch ahead of the batch being staged (one wavefront per SIMD: nothing
+    // else hides the HBM latency).  Every load of an iteration is issued before the first use of any of them.
     const int64_t nbatch = (n + kGramDDRows - 1) / kGramDDRows;
     auto load_st = [&](int64_t bq) -> unsigned char {
         const int64_t rq = bq * kGramDDRows + lane;
@@ -216,96 +169,193 @@ __global__ void __launch_bounds__(kBlock, 1)
         const int64_t rq = bq * kGramDDRows + lane;
         return bq < nbatch && rq < n && (!mask || (stq & mask));
     };
+    const bool need_rhs = pro.mode == GP_RHS || vsel_id == VS_NEG_RHS;
+    const bool need_g = pro.mode == GP_LINEAR;
+    // the per-row inputs: pa = rhs (or g for the linear prologue), pb / pc = what v is formed from
+    auto load_aux = [&](int64_t rq, bool kq, double& pa, double& pb, double& pc) {
+        pa = pb = pc = 0.0;
+        if (!kq)
+            return;
+        if (need_rhs)
+            pa = b.rhs[rq];
+        else if (need_g)
+            pa = b.g[rq];
+        switch (vsel_id)
+        {
+        case VS_DRT: pb = b.drt[rq]; break;
+        case VS_NEG_CF: if (!need_g) pb = b.cF[rq]; break;
+        case VS_LBOUND: pb = b.lb[rq]; pc = b.x0[rq]; break;
+        case VS_UBOUND: pb = b.ub[rq]; pc = b.x0[rq]; break;
+        case VS_Y: pb = b.y[rq]; break;
+        default: break;
+        }
+    };
     int64_t bt = gwave;
     unsigned char st_a = load_st(bt), st_b = load_st(bt + nwaves);
     bool keep_n = keep_of(bt, st_a);
-    double vn[CS];
+    double vn[CS], an0, an1, an2;
 #pragma unroll
     for (int j = 0; j < CS; j++)
         vn[j] = (keep_n && j < ncols) ? cols.p[j][bt * kGramDDRows + lane] : 0.0;
-    for (; bt < nbatch; bt += nwaves)
+    load_aux(bt * kGramDDRows + lane, keep_n, an0, an1, an2);
+    bool last = false;
+    for (;;)
     {
-        const int64_t r = bt * kGramDDRows + lane;
-        const bool keep = keep_n;
-        double vc[CS];
-#pragma unroll
-        for (int j = 0; j < CS; j++)
-            vc[j] = vn[j];
-        // advance the prefetch
-        const int64_t bn = bt + nwaves;
-        st_a = st_b;
-        st_b = load_st(bn + nwaves);
-        keep_n = keep_of(bn, st_a);
-#pragma unroll
-        for (int j = 0; j < CS; j++)
-            vn[j] = (keep_n && j < ncols) ? cols.p[j][bn * kGramDDRows + lane] : 0.0;
-        const unsigned long long bal = __ballot(keep);
-        const int cnt = __popcll(bal);
-        if (cnt == 0)
-            continue;
-        const int pos = __popcll(bal & ((1ull << lane) - 1ull));
-        const int base = head + fill;
-        if (keep)
+        if (bt < nbatch)
         {
-            double* row = tl + ((base + pos) & (kI8Ring - 1)) * cs;
+            const int64_t r = bt * kGramDDRows + lane;
+            const bool keep = keep_n;
+            double vc[CS];
 #pragma unroll
             for (int j = 0; j < CS; j++)
-                if (j < ncols)
-                    row[j] = vc[j];
-            if (pro.mode != GP_NONE)
+                vc[j] = vn[j];
+            const double pa = an0, pb = an1, pc = an2;
+            // advance the prefetch
+            const int64_t bn = bt + nwaves;
+            st_a = st_b;
+            st_b = load_st(bn + nwaves);
+            keep_n = keep_of(bn, st_a);
+#pragma unroll
+            for (int j = 0; j < CS; j++)
+                vn[j] = (keep_n && j < ncols) ? cols.p[j][bn * kGramDDRows + lane] : 0.0;
+            load_aux(bn * kGramDDRows + lane, keep_n, an0, an1, an2);
+            bt = bn;
+            const unsigned long long bal = __ballot(keep);
+            const int cnt = __popcll(bal);
+            if (cnt > 0)
             {
-                // (W * coef)(row): columns in order, plain accumulation -- the statement k_wcombine evaluates
-                double a1 = 0.0, a2 = 0.0;
-                if (pro.use1)
+                const int pos = __popcll(bal & ((1ull << lane) - 1ull));
+                const int base = head + fill;
+                if (keep)
                 {
+                    double* row = tl + ((base + pos) & (kI8Ring - 1)) * cs;
 #pragma unroll
                     for (int j = 0; j < CS; j++)
                         if (j < ncols)
-                            a1 = a1 + vc[j] * pc1[j];
-                }
-                if (pro.use2)
-                {
+                            row[j] = vc[j];
+                    double rhs_new = pa, cF_new = pb;
+                    if (pro.mode != GP_NONE)
+                    {
+                        // (W * coef)(row): columns in order, plain accumulation -- the statement k_wcombine evaluates
+                        double a1 = 0.0, a2 = 0.0;
+                        if (pro.use1)
+                        {
 #pragma unroll
-                    for (int j = 0; j < CS; j++)
-                        if (j < ncols)
-                            a2 = a2 + vc[j] * pc2[j];
+                            for (int j = 0; j < CS; j++)
+                                if (j < ncols)
+                                    a1 = a1 + vc[j] * pc1[j];
+                        }
+                        if (pro.use2)
+                        {
+#pragma unroll
+                            for (int j = 0; j < CS; j++)
+                                if (j < ncols)
+                                    a2 = a2 + vc[j] * pc2[j];
+                        }
+                        if (pro.mode == GP_RHS)
+                        {
+                            double rh = pa;
+                            if (pro.use1)
+                                rh = rh + (-a1);
+                            if (pro.use2)
+                                rh = rh + (-a2);
+                            b.rhs[r] = rh;
+                            rhs_new = rh;
+                        }
+                        else
+                        {
+                            cF_new = (pro.use1 ? (-1.0 * a1) : 0.0) + pa;
+                            b.cF[r] = cF_new;
+                        }
+                    }
+                    if (vsel_id >= 0)
+                    {
+                        double vr;  // vsel() of lbfgsb_kernels.cuh on the values already in registers
+                        switch (vsel_id)
+                        {
+                        case VS_DRT: vr = pb; break;
+                        case VS_NEG_CF: vr = -cF_new; break;
+                        case VS_NEG_RHS: vr = -rhs_new; break;
+                        case VS_LBOUND: vr = pb - pc; break;
+                        case VS_UBOUND: vr = pb - pc; break;
+                        default: vr = pb; break;
+                        }
+                        row[ncols] = vr;
+                    }
                 }
-                if (pro.mode == GP_RHS)
-                {
-                    double rh = b.rhs[r];
-                    if (pro.use1)
-                        rh = rh + (-a1);
-                    if (pro.use2)
-                        rh = rh + (-a2);
-                    b.rhs[r] = rh;
-                }
-                else
-                    b.cF[r] = (pro.use1 ? (-1.0 * a1) : 0.0) + b.g[r];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (vsel_id >= 0 && vg < nvg)
+                    for (int rr = vg; rr < cnt; rr += nvg)
+                    {
+                        const double* rw = tl + ((base + rr) & (kI8Ring - 1)) * cs;
+                        accv.add_prod(rw[ncols], rw[vj]);
+                    }
+                fill += cnt;
             }
-            if (vsel_id >= 0)
-                row[ncols] = vsel(b, vsel_id, r);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (vsel_id >= 0 && vg < nvg)
-            for (int rr = vg; rr < cnt; rr += nvg)
-            {
-                const double* rw = tl + ((base + rr) & (kI8Ring - 1)) * cs;
-                accv.add_prod(rw[ncols], rw[vj]);
-            }
-        fill += cnt;
-        while (fill >= 32)
+        else
+            last = true;
+        // ---- groups of 32 staged rows (the last one zero-padded) onto the matrix cores.  ONE copy of this code: the
+        // accumulator tiles must stay in registers (a second inlined copy sent them to scratch memory)
+        while (fill >= 32 || (last && fill > 0))
         {
-            contract(32);
-            head = (head + 32) & (kI8Ring - 1);
-            fill -= 32;
+            const int nrows = fill < 32 ? fill : 32;
+            // digits of this lane's 16 elements (rows 16 mh + t of the group, column mc), byte-transposed into operands
+            i32x4 dig[kI8Digits];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+            {
+                unsigned w0[4], w1[4], w2[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                {
+                    const int rr = 16 * mh + 4 * q + t;
+                    const double x = (col_ok && rr < nrows) ? tl[((head + rr) & (kI8Ring - 1)) * cs + mc] : 0.0;
+                    unsigned long long lo, hi;
+                    gram_i8_digits(x, my_emax, lo, hi);
+                    w0[t] = unsigned(lo);
+                    w1[t] = unsigned(lo >> 32);
+                    w2[t] = unsigned(hi);
+                }
+                unsigned o[4];
+                gram_i8_tr4(w0[0], w0[1], w0[2], w0[3], o);
+                dig[0][q] = int(o[0]);
+                dig[1][q] = int(o[1]);
+                dig[2][q] = int(o[2]);
+                dig[3][q] = int(o[3]);
+                gram_i8_tr4(w1[0], w1[1], w1[2], w1[3], o);
+                dig[4][q] = int(o[0]);
+                dig[5][q] = int(o[1]);
+                dig[6][q] = int(o[2]);
+                dig[7][q] = int(o[3]);
+                gram_i8_tr4(w2[0], w2[1], w2[2], w2[3], o);
+                dig[8][q] = int(o[0]);
+                dig[9][q] = int(o[1]);
+                dig[10][q] = int(o[2]);
+            }
+            // 66 digit pairs, accumulator u collects k + l = 10 + u; issued round-robin over the accumulators so that
+            // consecutive instructions are independent
+#pragma unroll
+            for (int k = 0; k < kI8Digits; k++)
+#pragma unroll
+                for (int u = 0; u < kI8Acc; u++)
+                {
+                    const int l = 10 + u - k;
+                    if (l >= 0 && l < kI8Digits)
+                        acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(dig[k], dig[l], acc[u], 0, 0, 0);
+                }
+            head = (head + nrows) & (kI8Ring - 1);
+            fill -= nrows;
+            if (++groups >= kI8FlushGroups)
+                flush();
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if (last)
+            break;
     }
-    if (fill > 0)
-        contract(fill);
     flush();
     // v row: the lanes that hold the same entry are nv1 apart
     if (vsel_id >= 0)

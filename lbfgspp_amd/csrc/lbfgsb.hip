@@ -1422,7 +1422,9 @@ int lbfgsx_b_gram_fused_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
     if (rc)
         return rc;
     bool done_i8 = false;
-    if (b->gram_i8 && c->dtype == LBFGSX_F64 && tot <= 30)
+    // the integer kernel pays a fixed cost per launch (per-wave partials, the integer tree): row sets that are not the
+    // free set -- the sparse L u U complements of the BOXCQP sweeps -- stay on the double-double kernel
+    if (b->gram_i8 && c->dtype == LBFGSX_F64 && tot <= 30 && (mask == 0 || (mask & ST_FREE)))
     {
         GramPrologue<double> pro;
         pro.mode = prologue;
