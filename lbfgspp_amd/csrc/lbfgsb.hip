@@ -582,9 +582,13 @@ int lbfgsx_b_post_linesearch(lbfgsx_ctx* c, double* projgnorm, double* xnorm2, d
         return rc;
     double r[3];
     // exact max |s|, max |y| of the new column pair ride along (the fixed-point scale of the integer Gram, gram_i8.cuh)
-    unsigned long long* cmx = c->bstate->colmax + 2 * size_t(c->spare);
-    LBFGSX_HIP(hipMemsetAsync(cmx, 0, 2 * sizeof(unsigned long long), c->stream));
-    c->bstate->colmax_ok[size_t(c->spare)] = 1;
+    unsigned long long* cmx = nullptr;
+    if (c->bstate->gram_i8)
+    {
+        cmx = c->bstate->colmax + 2 * size_t(c->spare);
+        LBFGSX_HIP(hipMemsetAsync(cmx, 0, 2 * sizeof(unsigned long long), c->stream));
+        c->bstate->colmax_ok[size_t(c->spare)] = 1;
+    }
     DISPATCH_T(c, {
         hipLaunchKernelGGL((k_b_post<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]), P<T>(c->xb[c->xp]),
                            P<T>(c->gb[c->cur]), P<T>(c->gb[c->xp]), P<T>(c->lb), P<T>(c->ub), P<T>(c->col(c->S, c->spare)),
@@ -1150,7 +1154,7 @@ namespace lbfgsx {
 int bounded_note_column(lbfgsx_ctx* c, int col)
 {
     lbfgsb_state* b = c->bstate;
-    if (!b || col < 0 || col > c->m)
+    if (!b || !b->gram_i8 || col < 0 || col > c->m)
         return LBFGSX_OK;
     unsigned long long* cmx = b->colmax + 2 * size_t(col);
     LBFGSX_HIP(hipMemsetAsync(cmx, 0, 2 * sizeof(unsigned long long), c->stream));

@@ -231,8 +231,11 @@ __global__ void __launch_bounds__(kBlock) k_b_post(const T* __restrict__ x, cons
         my = fmax(my, fabs(double(yi)));
     }
     block_atomic_max(maxslot, pg);
-    block_atomic_max(colmax + 0, my);
-    block_atomic_max(colmax + 1, ms);
+    if (colmax)  // only contexts that run the integer Gram (LBFGSX_GRAM=i8) keep the column maxima
+    {
+        block_atomic_max(colmax + 0, my);
+        block_atomic_max(colmax + 1, ms);
+    }
     if (grid_reduce<3>(acc, ws) && threadIdx.x == 0)
     {
         const T sy = T(acc[1].value()), yy = T(acc[2].value());
