@@ -177,7 +177,7 @@ public:
         t_cross = Scalar(0);
 
         const std::int64_t dev_min = device_switch();
-        bool dev_ok = sizeof(Scalar) == sizeof(double) && 2 * ncorr <= 32 && dev_min >= 0;
+        bool dev_ok = 2 * ncorr <= 80 && dev_min >= 0;  // f32 problems: the device form computes in double (lbfgsx.h)
         if (dev_ok)
             ord.set_soft_cap(dev_min);
 

@@ -223,7 +223,9 @@ int lbfgsx_b_cauchy_sort_full(lbfgsx_ctx* c);
  * major; state_in = [p (2c), c (2c), f', f'']; t_prev = break point of the last crossing already processed (0 at
  * the start).  On return *exit_at = sorted index of the group end at which the search stops (-1: not inside this
  * range) and state_out = [p, c, f', f'', brk] after that crossing (after the last crossing of the range when -1).
- * f64 problems with 2c <= 32 only (LBFGSX_E_INVALID otherwise: the caller keeps the host form). */
+ * 2c <= 80 (every m an L-BFGS-B context accepts); f32 problems are gathered into doubles and searched in double.
+ * The order-sensitive scalar recurrences f', f'' and the exit test run in the reference's left-to-right order on the
+ * host over per-crossing terms produced by the device (LBFGSX_GCP_CHAIN=scan: as tree-order prefix sums on the device). */
 int lbfgsx_b_cauchy_scan(lbfgsx_ctx* ctx, int64_t first, int64_t count, int64_t nord, const double* Mmat, double theta,
                          double t_prev, const double* state_in, int64_t* exit_at, double* state_out);
 /* xcp and the free / newly-active sets from the crossing threshold (Cauchy.h:201-206,219-233,265-282) */

@@ -374,8 +374,7 @@ __global__ void k_gcp_extract(GcpBufs b, int64_t count, int ncorr, double theta,
     const unsigned long long ex = *exit_at;
     const bool found = ex < (unsigned long long) count;
     const int64_t e = found ? int64_t(ex) : count - 1;
-    const int j = threadIdx.x;
-    if (j < NC)
+    for (int j = threadIdx.x; j < NC; j += blockDim.x)
     {
         double w = (j < 2 * ncorr) ? b.W[int64_t(j) * b.cap + e] : 0.0;
         if (j >= ncorr)
@@ -383,7 +382,7 @@ __global__ void k_gcp_extract(GcpBufs b, int64_t count, int ncorr, double theta,
         out[j] = b.P[int64_t(j) * b.cap + e] + b.g[e] * w;
         out[NC + j] = b.C[int64_t(j) * b.cap + e];
     }
-    if (j == 0)
+    if (threadIdx.x == 0)
     {
         out[2 * NC] = b.fp[e];
         out[2 * NC + 1] = b.fpp[e];

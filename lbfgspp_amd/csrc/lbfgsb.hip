@@ -937,12 +937,13 @@ int lbfgsx_b_cauchy_scan(lbfgsx_ctx* c, int64_t first, int64_t count, int64_t no
         return rc;
     lbfgsb_state* b = c->bstate;
     const int nc = c->ncorr, nc2 = 2 * nc;
-    if (c->dtype != LBFGSX_F64 || nc2 > 32 || count < 1 || first < 0 || first + count > nord)
+    if (nc2 > 80 || count < 1 || first < 0 || first + count > nord)
     {
-        set_error("lbfgsx_b_cauchy_scan: needs an f64 problem, 2*ncorr <= 32 and a non-empty range inside the sorted list");
+        set_error("lbfgsx_b_cauchy_scan: needs 2*ncorr <= 80 and a non-empty range inside the sorted list");
         return LBFGSX_E_INVALID;
     }
-    const int NC = std::max(4, (nc2 + 3) / 4 * 4);
+    // component counts the kernels are built for: multiples of 4 up to 32, then 40, 48, 64, 80 (m = 20, 24, 32, 40)
+    const int NC = nc2 <= 32 ? std::max(4, (nc2 + 3) / 4 * 4) : nc2 <= 40 ? 40 : nc2 <= 48 ? 48 : nc2 <= 64 ? 64 : 80;
     if (count > b->s_cap || NC > b->s_nc)
     {
         void* old[] = {b->s_brk, b->s_g, b->s_z, b->s_W, b->s_P, b->s_C, b->s_fpp, b->s_dfp, b->s_fp, b->s_ts, b->s_off};
@@ -952,7 +953,8 @@ int lbfgsx_b_cauchy_scan(lbfgsx_ctx* c, int64_t first, int64_t count, int64_t no
         // history: the chunk grows 2^16 -> 2^20 within a search and 2c grows over the first m iterations, and every
         // regrowth would free and allocate eleven buffers in the middle of the iteration
         const int64_t cap = std::max<int64_t>(std::max<int64_t>(count, b->s_cap), std::min<int64_t>(int64_t(1) << 20, c->n));
-        const int ncap = std::max(std::max(NC, b->s_nc), std::min(32, (2 * c->m + 3) / 4 * 4));
+        const int mcap = 2 * c->m <= 32 ? (2 * c->m + 3) / 4 * 4 : 2 * c->m <= 40 ? 40 : 2 * c->m <= 48 ? 48 : 2 * c->m <= 64 ? 64 : 80;
+        const int ncap = std::max(std::max(NC, b->s_nc), mcap);
         const size_t tiles = size_t((cap + kGcpTile - 1) / kGcpTile);
         LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_brk), sizeof(double) * size_t(cap + 1)));
         LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_g), sizeof(double) * size_t(cap)));
@@ -971,7 +973,7 @@ int lbfgsx_b_cauchy_scan(lbfgsx_ctx* c, int64_t first, int64_t count, int64_t no
         LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_off), sizeof(double) * tiles * size_t(ncap + 1)));
         if (!b->s_small)
         {
-            LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_small), sizeof(double) * (32 * 32 + 6 * 40)));
+            LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_small), sizeof(double) * (80 * 80 + 6 * 88)));
             LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_exit), sizeof(unsigned long long)));
         }
         b->s_cap = cap;
@@ -981,8 +983,8 @@ int lbfgsx_b_cauchy_scan(lbfgsx_ctx* c, int64_t first, int64_t count, int64_t no
     if (rc)
         return rc;
     // small inputs in one staged copy: padded M (row-major NC x NC), the three scan seeds
-    double h[32 * 32 + 6 * 40];
-    std::memset(h, 0, sizeof(h));
+    std::vector<double> hbuf(size_t(80 * 80 + 6 * 88), 0.0);
+    double* h = hbuf.data();
     for (int i = 0; i < nc2; i++)
         for (int j = 0; j < nc2; j++)
             h[i * NC + j] = Mmat[size_t(j) * size_t(nc2) + size_t(i)];
@@ -1000,9 +1002,13 @@ int lbfgsx_b_cauchy_scan(lbfgsx_ctx* c, int64_t first, int64_t count, int64_t no
     LBFGSX_HIP(hipMemcpyAsync(b->s_small, h, sizeof(double) * nsmall, hipMemcpyHostToDevice, c->stream));
     LBFGSX_HIP(hipMemsetAsync(b->s_exit, 0xFF, sizeof(unsigned long long), c->stream));
     const int grid = int(std::min<int64_t>((count + 256) / 256, 2048));
-    hipLaunchKernelGGL((k_gcp_gather<double>), dim3(grid), dim3(256), 0, c->stream, bvecs<double>(c), P<double>(b->keys_out),
-                       b->vals_out, first, count, nord, P<double>(c->S), P<double>(c->Y), c->ld, b->phys_dev, nc, b->s_brk,
-                       b->s_g, b->s_z, b->s_W, b->s_cap);
+    // f32 problems: the sorted list is gathered into doubles and the search runs in double (the reference would run it in
+    // float; the north_star tolerance for f32 is 1e-4, the difference is at the 1e-7 level)
+    DISPATCH_T(c, {
+        hipLaunchKernelGGL((k_gcp_gather<T>), dim3(grid), dim3(256), 0, c->stream, bvecs<T>(c), P<T>(b->keys_out), b->vals_out,
+                           first, count, nord, P<T>(c->S), P<T>(c->Y), c->ld, b->phys_dev, nc, b->s_brk, b->s_g, b->s_z, b->s_W,
+                           b->s_cap);
+    });
     GcpBufs gb = {b->s_brk, b->s_g, b->s_z, b->s_W, b->s_P, b->s_C, b->s_fpp, b->s_dfp, b->s_fp, b->s_cap};
     switch (NC)
     {
@@ -1013,7 +1019,11 @@ int lbfgsx_b_cauchy_scan(lbfgsx_ctx* c, int64_t first, int64_t count, int64_t no
     case 20: rc = gcp_scan_nc<20>(c, gb, first, count, nord, theta, t_prev); break;
     case 24: rc = gcp_scan_nc<24>(c, gb, first, count, nord, theta, t_prev); break;
     case 28: rc = gcp_scan_nc<28>(c, gb, first, count, nord, theta, t_prev); break;
-    default: rc = gcp_scan_nc<32>(c, gb, first, count, nord, theta, t_prev); break;
+    case 32: rc = gcp_scan_nc<32>(c, gb, first, count, nord, theta, t_prev); break;
+    case 40: rc = gcp_scan_nc<40>(c, gb, first, count, nord, theta, t_prev); break;
+    case 48: rc = gcp_scan_nc<48>(c, gb, first, count, nord, theta, t_prev); break;
+    case 64: rc = gcp_scan_nc<64>(c, gb, first, count, nord, theta, t_prev); break;
+    default: rc = gcp_scan_nc<80>(c, gb, first, count, nord, theta, t_prev); break;
     }
     if (rc)
         return rc;
@@ -1039,11 +1049,15 @@ int lbfgsx_b_cauchy_scan(lbfgsx_ctx* c, int64_t first, int64_t count, int64_t no
         case 20: gcp_extract_nc<20>(c, gb, count, theta); break;
         case 24: gcp_extract_nc<24>(c, gb, count, theta); break;
         case 28: gcp_extract_nc<28>(c, gb, count, theta); break;
-        default: gcp_extract_nc<32>(c, gb, count, theta); break;
+        case 32: gcp_extract_nc<32>(c, gb, count, theta); break;
+        case 40: gcp_extract_nc<40>(c, gb, count, theta); break;
+        case 48: gcp_extract_nc<48>(c, gb, count, theta); break;
+        case 64: gcp_extract_nc<64>(c, gb, count, theta); break;
+        default: gcp_extract_nc<80>(c, gb, count, theta); break;
         }
         LBFGSX_HIP(hipGetLastError());
     }
-    double o[2 * 32 + 4];
+    double o[2 * 80 + 4];
     const double* dout = b->s_small + (NC * NC + NC + (NC + 1) + 1 + (NC + 1));
     LBFGSX_HIP(hipMemcpyAsync(o, dout, sizeof(double) * size_t(2 * NC + 4), hipMemcpyDeviceToHost, c->stream));
     LBFGSX_HIP(hipStreamSynchronize(c->stream));

@@ -111,3 +111,39 @@ def test_switch_mid_search(A, monkeypatch):
     assert mix["crossings"] == host["crossings"]
     assert np.array_equal(mix["state"], host["state"])
     assert np.abs(mix["xcp"] - host["xcp"]).max() <= 1e-10 * max(1.0, np.abs(host["xcp"]).max())
+
+
+@pytest.mark.parametrize("n,m,npairs,mode", [(20000, 20, 20, "hard"), (8000, 40, 40, "edge"), (30000, 24, 30, "hard"),
+                                             (6000, 32, 32, "gentle")])
+def test_device_search_with_long_histories(A, boracle, device_search, n, m, npairs, mode):
+    """2c = 40 .. 80 components (m = 20 .. 40, every m an L-BFGS-B context accepts): the device form of the search used to
+    stop at 2c = 32 and leave such problems to the host loop (Cauchy.h:183-256 is generic in m)."""
+    T.test_cauchy_and_subspace_match_oracle(A, boracle, O.F64, n, m, npairs, mode)
+
+
+@pytest.mark.parametrize("n,m,iters", [(12000, 20, 24)])
+def test_device_search_trajectory_with_a_long_history(A, boracle, device_search, n, m, iters):
+    T.test_trajectory_box_quadratic_f64(A, boracle, n, m, iters, tol=1e-10)
+
+
+@pytest.mark.parametrize("n,m,iters,devmin", [(200000, 6, 10, "0"), (200000, 10, 8, None), (4000, 6, 8, "0")])
+def test_device_search_f32(A, boracle, monkeypatch, n, m, iters, devmin):
+    """f32 problems: the device form gathers the sorted list into doubles and searches in double (the reference would
+    search in float); north_star's f32 tolerance is 1e-4 on the iterates.  200000 coordinates: ~1e5 crossings in the
+    first search, which the host loop used to walk alone."""
+    if devmin is not None:
+        monkeypatch.setenv("LBFGSX_GCP_DEVICE_MIN", devmin)
+    a, b = O.quad_problem(n, 10.0, 1, O.F32)
+    lb, ub = -np.ones(n, np.float32), np.ones(n, np.float32)
+    p = O.lbfgsb_params(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters)
+    x_ref, r = boracle.lbfgsb(O.F32, O.OBJ_QUAD, np.zeros(n, np.float32), lb, ub, p, a=a, b=b)
+    s = A.LBFGSBSolver(A.LBFGSBParam(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters), dtype=np.float32)
+    x = np.zeros(n, np.float32)
+    niter, fx = s.minimize(A.DiagQuadratic(a, b), x, lb, ub)
+    st = s.stats()
+    s.close()
+    assert niter == r.niter
+    if n >= 100000:
+        assert st["gcp_dev_crossings"] > 0.5 * st["gcp_crossings"] > 1000
+    assert np.abs(x.astype(np.float64) - x_ref.astype(np.float64)).max() <= 1e-4
+    assert abs(fx - r.fx) <= 1e-4 * abs(r.fx)
