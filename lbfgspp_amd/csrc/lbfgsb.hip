@@ -906,24 +906,28 @@ static void gcp_extract_nc(lbfgsx_ctx* c, const GcpBufs& gb, int64_t count, doub
 // dt[count] = distance to the break point after the chunk, -1 at the end of the sorted list.  Returns the index of the
 // group end at which the search stops, or -1.  Plain IEEE operations, no contraction (the TU is built with
 // -ffp-contract=off): bit for bit the scalar statements of the sequential form.
+// CT: the scalar type of the problem.  An f32 reference runs these chains in float, and over 10^5 crossings the float
+// rounding of f' (partial sums of the size of d'd) moves the Cauchy point far more than the f32 tolerance: the chain is
+// part of what has to be reproduced, so f32 problems run it in float over the (double-computed, then rounded) terms.
+template <class CT>
 static int64_t gcp_chain_host(const double* dt, const double* A, const double* B, int64_t count, double& fp, double& fpp)
 {
-    double f1 = fp, f2 = fpp;
+    CT f1 = CT(fp), f2 = CT(fpp);
     for (int64_t k = 0; k < count; k++)
     {
-        f1 = f1 + dt[k] * f2;   // fp += deltat * fpp                                   (:218)
-        f1 = f1 + A[k];         // fp += ggact + theta*gact*zact - gact*cache.dot(vecc)  (:227)
-        f2 = f2 - B[k];         // fpp -= (...)                                          (:228)
-        const double dn = dt[k + 1];
-        if (dn > 0.0 && !(-f1 / f2 >= dn))   // group end: deltatmin = -fp/fpp (:240) against the next deltat (:183)
+        f1 = f1 + CT(dt[k]) * f2;   // fp += deltat * fpp                                   (:218)
+        f1 = f1 + CT(A[k]);         // fp += ggact + theta*gact*zact - gact*cache.dot(vecc)  (:227)
+        f2 = f2 - CT(B[k]);         // fpp -= (...)                                          (:228)
+        const CT dn = CT(dt[k + 1]);
+        if (dn > CT(0) && !(-f1 / f2 >= dn))   // group end: deltatmin = -fp/fpp (:240) against the next deltat (:183)
         {
-            fp = f1;
-            fpp = f2;
+            fp = double(f1);
+            fpp = double(f2);
             return k;
         }
     }
-    fp = f1;
-    fpp = f2;
+    fp = double(f1);
+    fpp = double(f2);
     return -1;
 }
 extern "C" {
@@ -1037,7 +1041,8 @@ int lbfgsx_b_cauchy_scan(lbfgsx_ctx* c, int64_t first, int64_t count, int64_t no
         LBFGSX_HIP(hipMemcpyAsync(hA, b->s_dfp, sizeof(double) * size_t(count), hipMemcpyDeviceToHost, c->stream));
         LBFGSX_HIP(hipMemcpyAsync(hB, b->s_fpp, sizeof(double) * size_t(count), hipMemcpyDeviceToHost, c->stream));
         LBFGSX_HIP(hipStreamSynchronize(c->stream));
-        const int64_t e = gcp_chain_host(hdt, hA, hB, count, fp_h, fpp_h);
+        const int64_t e = (c->dtype == LBFGSX_F32) ? gcp_chain_host<float>(hdt, hA, hB, count, fp_h, fpp_h)
+                                                   : gcp_chain_host<double>(hdt, hA, hB, count, fp_h, fpp_h);
         const unsigned long long ex = (e >= 0) ? (unsigned long long) e : ~0ull;
         LBFGSX_HIP(hipMemcpyAsync(b->s_exit, &ex, sizeof(ex), hipMemcpyHostToDevice, c->stream));
         switch (NC)
