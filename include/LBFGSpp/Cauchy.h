@@ -85,10 +85,15 @@ class Cauchy
     // so the hand-over point is chosen for speed: a device chunk costs ~0.5 ms, a host crossing ~0.1 us.
     // LBFGSX_GCP_CHAIN=scan restores the round-1 form (f' and f'' as tree-order prefix sums on the device, 1e-8 on
     // whole trajectories).
+    // f32 problems: the device form computes p, c and the per-crossing terms in double where the reference computes in
+    // float, and an f32 L-BFGS-B trajectory amplifies even that 1e-7 difference past the 1e-4 tolerance within ~10
+    // iterations (native f32 sums lose 1e-4 after ~8); the host form -- the reference's own float
+    // arithmetic -- therefore keeps every search up to 65536 crossings, and the device only takes the searches the host
+    // loop would spend seconds on.
     static std::int64_t device_switch()
     {
         const char* e = std::getenv("LBFGSX_GCP_DEVICE_MIN");
-        return e ? std::atoll(e) : std::int64_t(4096);
+        return e ? std::atoll(e) : (sizeof(Scalar) == sizeof(double) ? std::int64_t(4096) : std::int64_t(65536));
     }
 
     // The next search sorts only the break points up to tau = factor * (this search's Cauchy time): in steady state
