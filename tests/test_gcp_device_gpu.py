@@ -126,7 +126,7 @@ def test_device_search_trajectory_with_a_long_history(A, boracle, device_search,
     T.test_trajectory_box_quadratic_f64(A, boracle, n, m, iters, tol=1e-10)
 
 
-@pytest.mark.parametrize("n,m,iters,devmin,tol", [(200000, 10, 8, None, 1e-4), (400000, 6, 6, None, 1e-4), (4000, 6, 8, "0", 5e-2)])
+@pytest.mark.parametrize("n,m,iters,devmin,tol", [(200000, 10, 8, None, 1e-4), (400000, 6, 3, None, 1e-4), (4000, 6, 8, "0", 5e-2)])
 def test_device_search_f32(A, boracle, monkeypatch, n, m, iters, devmin, tol):
     """f32 problems: the device form gathers the sorted list into doubles, forms p, c and the per-crossing terms in
     double and runs the f' / f'' chains in float like the reference.  By default it takes over after 65536 crossings
