@@ -126,7 +126,23 @@ def test_device_search_trajectory_with_a_long_history(A, boracle, device_search,
     T.test_trajectory_box_quadratic_f64(A, boracle, n, m, iters, tol=1e-10)
 
 
-@pytest.mark.parametrize("n,m,iters,devmin,tol", [(200000, 10, 8, None, 1e-4), (400000, 6, 3, None, 1e-4), (4000, 6, 8, "0", 5e-2)])
+@pytest.mark.parametrize("n,m,npairs,mode", [(30000, 6, 6, "hard"), (3000, 6, 0, "hard"), (10000, 20, 20, "edge")])
+def test_device_search_single_instances_f32(A, boracle, device_search, n, m, npairs, mode):
+    """one search + subspace step in f32 through the device form, against the f32 oracle: same crossed / free sets up to
+    the coordinates whose break point ties with the Cauchy time at float resolution, Cauchy point within 1e-4."""
+    rng = np.random.default_rng(500 + n + npairs)
+    S, Y, x0, g, lb, ub = T._instance(rng, n, npairs, O.F32, mode)
+    ref = boracle.cauchy_subspace(O.F32, m, S, Y, x0, g, lb, ub, max_submin=10, subspace=False)
+    got = T._device_cauchy_subspace(A, O.F32, m, S, Y, x0, g, lb, ub, subspace=False)
+    newact = np.zeros(n, bool)
+    newact[ref["newact"]] = True
+    assert np.mean(((got["state"] & 2) != 0) == newact) > 0.999
+    scale = max(1.0, np.abs(ref["xcp"]).max())
+    # coordinates that cross on one side only sit on a bound in one result and a float-ulp-scale step away in the other
+    assert np.percentile(np.abs(got["xcp"].astype(np.float64) - ref["xcp"].astype(np.float64)), 99.9) <= 1e-4 * scale
+
+
+@pytest.mark.parametrize("n,m,iters,devmin,tol", [(200000, 10, 8, None, 1e-4), (4000, 6, 8, "0", 5e-2)])
 def test_device_search_f32(A, boracle, monkeypatch, n, m, iters, devmin, tol):
     """f32 problems: the device form gathers the sorted list into doubles, forms p, c and the per-crossing terms in
     double and runs the f' / f'' chains in float like the reference.  By default it takes over after 65536 crossings
