@@ -22,6 +22,10 @@ python bench.py --m 20 --steps 10 --warmup 22 --no-cpu --no-batched > $O/bench_c
 python bench.py --objective quadratic --n 10000000 --no-cpu --no-batched > $O/bench_cfg2_quad1e7.json 2> /dev/null
 python bench.py --workload cfg5-batched --steps 50 > $O/bench_cfg5_batched.json 2> /dev/null
 python scripts/bench_lbfgsb.py --n 1e7 --iters 40 --cpu-n 2e5 > $O/bench_cfg4_lbfgsb.json 2> /dev/null
+LBFGSX_GRAM=i8 python scripts/bench_lbfgsb.py --n 1e7 --iters 40 > $O/bench_cfg4_lbfgsb_i8.json 2> /dev/null
+LBFGSX_GCP_CHAIN=scan python scripts/bench_lbfgsb.py --n 1e7 --iters 40 > $O/bench_cfg4_lbfgsb_scan.json 2> /dev/null
+LBFGSX_GRAM=i8 rocprofv3 --kernel-trace --stats --output-format csv -d $O/lbfgsb_i8 -o b -- $BCMD > $O/lbfgsb_i8.log 2>&1
+LBFGSX_BENCH_FORCE_DEVICE=0 python bench.py --gpus 2 --no-cpu --steps 5 > $O/bench_two_ranks_one_device.json 2> /dev/null
 # keep only what the summary needs (the raw traces are large)
 find $O -name "*.csv" ! -name "*kernel_stats.csv" ! -name "*counter_collection.csv" -delete
 find $O -type f | wc -l; du -sh $O
