@@ -31,7 +31,7 @@ namespace lbfgsx {
 constexpr int kI8Digits = 11;
 constexpr int kI8Acc = 11;         // u = k + l - 10 = 0..10
 constexpr int kI8Ring = 128;       // rows of the wave-private staging ring (31 left over + 64 new < 128)
-constexpr int kI8FlushGroups = 256;  // 32-row groups between flushes: 256 * 32 * 11 * 2^14 < 2^31
+constexpr int kI8FlushBatches = 120;  // 64-row batches between flushes: <= 241 groups, 241 * 32 * 11 * 2^14 < 2^31
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
@@ -42,39 +42,30 @@ struct GramI8Args
     int cidx[32];                      // logical column -> index into colmax
 };
 
-// 11 signed digits of trunc(x * 2^(86 - E)), E = emax - 1022 (emax: biased exponent of the column's max): bytes 0..7 in
-// lo, 8..10 in hi
-__device__ __forceinline__ void gram_i8_digits(double x, int emax, unsigned long long& lo, unsigned long long& hi)
+// 11 signed digits of t = trunc(x * 2^(86 - E)), E = emax - 1022 (emax: biased exponent of the column's max), as three
+// words: bytes 0..3, 4..7, 8..10.  The 86-bit magnitude is peeled off in f64, 22 + 32 + 32 bits (every step exact: a
+// truncation, the subtraction of an integer part, a multiplication by 2^32), which costs 11 full-rate instructions where
+// shifting the 53-bit mantissa into a 96-bit field costs a dozen quarter-rate 64-bit shifts; the sign (two's complement)
+// and the digit bias then take 10 integer instructions on the three words.
+__device__ __forceinline__ void gram_i8_digits(double x, int lsh /* 1044 - emax */, unsigned& w0, unsigned& w1, unsigned& w2)
 {
-    const unsigned long long bits = (unsigned long long) __double_as_longlong(x);
-    const int e = int((bits >> 52) & 0x7FFull);
-    unsigned long long M = (bits & 0x000FFFFFFFFFFFFFull) | 0x0010000000000000ull;
-    M = (e == 0) ? 0ull : M;  // zeros; denormals lie > 2^-900 below any column scale
-    const int sh = e - emax + 33;  // <= 33: |t| < 2^86
-    unsigned long long l, h;
-    if (sh >= 0)
-    {
-        l = M << sh;
-        h = (sh > 11) ? (M >> (64 - sh)) : 0ull;  // M < 2^53: nothing leaves the low word for sh <= 11
-    }
-    else
-    {
-        const int r = -sh;
-        l = (r < 64) ? (M >> r) : 0ull;
-        h = 0ull;
-    }
-    // two's complement of (h:l) for negative x
-    const unsigned long long sm = (unsigned long long) (((long long) bits) >> 63);
-    l ^= sm;
-    h ^= sm;
-    const unsigned long long l1 = l - sm;  // + 1 when negative
-    h += (sm != 0ull && l1 == 0ull) ? 1ull : 0ull;
-    // bias 0x80 into bytes 0..9 (all but the leading digit) and flip it back: unsigned bytes -> signed digits
-    const unsigned long long bl = 0x8080808080808080ull, bh = 0x0000000000008080ull;
-    const unsigned long long l2 = l1 + bl;
-    h = h + bh + ((l2 < bl) ? 1ull : 0ull);
-    lo = l2 ^ bl;
-    hi = h ^ bh;
+    const double a = __builtin_ldexp(__builtin_fabs(x), lsh);  // |t| / 2^64 < 2^22
+    const double p2 = __builtin_trunc(a);
+    const double bq = __builtin_ldexp(a - p2, 32);
+    const double p1 = __builtin_trunc(bq);
+    const double cq = __builtin_ldexp(bq - p1, 32);
+    unsigned u2 = (unsigned) p2, u1 = (unsigned) p1, u0 = (unsigned) __builtin_trunc(cq);
+    // two's complement for negative x, then + 0x80 in bytes 0..9 (all digits but the leading one): one carry chain
+    const unsigned sm = unsigned(int(__double2hiint(x)) >> 31);  // all ones when negative
+    u0 ^= sm;
+    u1 ^= sm;
+    u2 ^= sm;
+    const unsigned long long s0 = (unsigned long long) u0 + (0x80808080u - sm);  // - sm = + 1 when negative
+    const unsigned long long s1 = (unsigned long long) u1 + 0x80808080u + (s0 >> 32);
+    u2 = u2 + 0x00008080u + unsigned(s1 >> 32);
+    w0 = unsigned(s0) ^ 0x80808080u;
+    w1 = unsigned(s1) ^ 0x80808080u;
+    w2 = u2 ^ 0x00008080u;
 }
 
 // 4 x 4 byte transpose: word w of four elements -> four words, byte j of output k = byte k of input j
@@ -93,7 +84,8 @@ __device__ __forceinline__ void gram_i8_tr4(unsigned a, unsigned b, unsigned c, 
 // entry (i, j), i >= j, of the packed lower triangle
 __device__ __forceinline__ int gram_tri(int i, int j) { return i * (i + 1) / 2 + j; }
 
-// part_i: [waves][kI8Acc][ne_pad] int64 (ne_pad = padded number of lower-triangle entries of the ncols x ncols block)
+// part_i: [blocks][kI8Acc][ne_pad] int64, zeroed by the host (ne_pad = padded number of lower-triangle entries of the
+// ncols x ncols block)
 // part_v: [waves][32][2] double-double sums of the v row: entry j < ncols = v . col_j, entry ncols = v . v
 template <int CS>
 __global__ void __launch_bounds__(kBlock, 1)
@@ -115,11 +107,11 @@ __global__ void __launch_bounds__(kBlock, 1)
     __syncthreads();
     double* tl = tile + wv * (kI8Ring * cs);
     const int mc = lane & 31, mh = lane >> 5;  // operand layout: column, row half
-    const int my_emax = s_emax[mc];
+    const int my_lsh = 1044 - s_emax[mc];
     const bool col_ok = mc < ncols;
     const int64_t gwave = int64_t(blockIdx.x) * (kBlock / 64) + wv;
     const int64_t nwaves = int64_t(gridDim.x) * (kBlock / 64);
-    long long* mypart = part_i + gwave * int64_t(kI8Acc) * ne_pad;
+    long long* mypart = part_i + int64_t(blockIdx.x) * int64_t(kI8Acc) * ne_pad;
 
     i32x16 acc[kI8Acc];
 #pragma unroll
@@ -127,39 +119,12 @@ __global__ void __launch_bounds__(kBlock, 1)
 #pragma unroll
         for (int r = 0; r < 16; r++)
             acc[u][r] = 0;
-    int groups = 0;
-    bool flushed_once = false;
     // v row: lane l accumulates entry l % (ncols + 1) -- v . col_j for j < ncols, v . v for j = ncols -- over the staged
     // rows l / (ncols + 1), + nvg, ... (nvg = 64 / (ncols + 1) rows per trip use all lanes); v sits in tile column ncols
     DD accv;
     const int nv1 = ncols + 1, nvg = 64 / nv1;
     const int vj = lane % nv1, vg = lane / nv1;
 
-    auto flush = [&]() {
-        // C/D layout of the 32x32 tile: column j = lane & 31, row i = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-#pragma unroll
-        for (int u = 0; u < kI8Acc; u++)
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-            {
-                const int i = (r & 3) + 8 * (r >> 2) + 4 * mh, j = mc;
-                if (i < ncols && j <= i)
-                {
-                    long long* p = mypart + int64_t(u) * ne_pad + gram_tri(i, j);
-                    const long long old = flushed_once ? *p : 0ll;
-                    *p = old + (long long) acc[u][r];
-                }
-                acc[u][r] = 0;
-            }
-        flushed_once = true;
-        groups = 0;
-    };
-
-    int head = 0, fill = 0;  // ring rows [head, head + fill) are staged and not yet contracted
-
-    // ---- batches of 64 rows, software-pipelined: the state bytes run two batches ahead, the column values and the few
-    // per-row inputs of the prologue / of v one batch ahead of the batch being staged (one wavefront per SIMD: nothing
-    // else hides the HBM latency).  Every load of an iteration is issued before the first use of any of them.
     const int64_t nbatch = (n + kGramDDRows - 1) / kGramDDRows;
     auto load_st = [&](int64_t bq) -> unsigned char {
         const int64_t rq = bq * kGramDDRows + lane;
@@ -171,59 +136,47 @@ __global__ void __launch_bounds__(kBlock, 1)
     };
     const bool need_rhs = pro.mode == GP_RHS || vsel_id == VS_NEG_RHS;
     const bool need_g = pro.mode == GP_LINEAR;
-    // the per-row inputs: pa = rhs (or g for the linear prologue), pb / pc = what v is formed from
-    auto load_aux = [&](int64_t rq, bool kq, double& pa, double& pb, double& pc) {
-        pa = pb = pc = 0.0;
-        if (!kq)
-            return;
-        if (need_rhs)
-            pa = b.rhs[rq];
-        else if (need_g)
-            pa = b.g[rq];
-        switch (vsel_id)
-        {
-        case VS_DRT: pb = b.drt[rq]; break;
-        case VS_NEG_CF: if (!need_g) pb = b.cF[rq]; break;
-        case VS_LBOUND: pb = b.lb[rq]; pc = b.x0[rq]; break;
-        case VS_UBOUND: pb = b.ub[rq]; pc = b.x0[rq]; break;
-        case VS_Y: pb = b.y[rq]; break;
-        default: break;
-        }
-    };
+
+    // ---- software pipeline.  State bytes run two batches ahead; the column values (vn) and the per-row inputs of the
+    // prologue / of v (an*) one batch ahead: they are requested right after the previous batch has been staged, so the
+    // contraction of that batch -- the long part -- covers their latency (one wavefront per SIMD: nothing else would).
     int64_t bt = gwave;
     unsigned char st_a = load_st(bt), st_b = load_st(bt + nwaves);
     bool keep_n = keep_of(bt, st_a);
-    double vn[CS], an0, an1, an2;
+    double vn[CS], an0 = 0.0, an1 = 0.0, an2 = 0.0;
+    auto issue_loads = [&](int64_t bq, bool kq) {
+        const int64_t rq = kq ? bq * kGramDDRows + lane : int64_t(0);  // masked-out lanes re-read row 0 (no branch)
 #pragma unroll
-    for (int j = 0; j < CS; j++)
-        vn[j] = (keep_n && j < ncols) ? cols.p[j][bt * kGramDDRows + lane] : 0.0;
-    load_aux(bt * kGramDDRows + lane, keep_n, an0, an1, an2);
+        for (int j = 0; j < CS; j++)
+            vn[j] = cols.p[j < ncols ? j : ncols - 1][rq];              // columns beyond ncols repeat the last one
+        an0 = need_rhs ? b.rhs[rq] : (need_g ? b.g[rq] : 0.0);
+        an1 = an2 = 0.0;
+        switch (vsel_id)
+        {
+        case VS_DRT: an1 = b.drt[rq]; break;
+        case VS_NEG_CF: if (!need_g) an1 = b.cF[rq]; break;
+        case VS_LBOUND: an1 = b.lb[rq]; an2 = b.x0[rq]; break;
+        case VS_UBOUND: an1 = b.ub[rq]; an2 = b.x0[rq]; break;
+        case VS_Y: an1 = b.y[rq]; break;
+        default: break;
+        }
+    };
+    issue_loads(bt, keep_n);
+
+    int head = 0, fill = 0;  // ring rows [head, head + fill) are staged and not yet contracted
     bool last = false;
     for (;;)
     {
-        if (bt < nbatch)
+        // ---- flush interval: at most kI8FlushBatches batches (2 groups each at most) between two flushes
+        for (int it = 0; it < kI8FlushBatches && !last; it++)
         {
-            const int64_t r = bt * kGramDDRows + lane;
-            const bool keep = keep_n;
-            double vc[CS];
-#pragma unroll
-            for (int j = 0; j < CS; j++)
-                vc[j] = vn[j];
-            const double pa = an0, pb = an1, pc = an2;
-            // advance the prefetch
-            const int64_t bn = bt + nwaves;
-            st_a = st_b;
-            st_b = load_st(bn + nwaves);
-            keep_n = keep_of(bn, st_a);
-#pragma unroll
-            for (int j = 0; j < CS; j++)
-                vn[j] = (keep_n && j < ncols) ? cols.p[j][bn * kGramDDRows + lane] : 0.0;
-            load_aux(bn * kGramDDRows + lane, keep_n, an0, an1, an2);
-            bt = bn;
-            const unsigned long long bal = __ballot(keep);
-            const int cnt = __popcll(bal);
-            if (cnt > 0)
+            if (bt < nbatch)
             {
+                // -- stage the batch whose values have arrived
+                const int64_t r = bt * kGramDDRows + lane;
+                const bool keep = keep_n;
+                const unsigned long long bal = __ballot(keep);
+                const int cnt = __popcll(bal);
                 const int pos = __popcll(bal & ((1ull << lane) - 1ull));
                 const int base = head + fill;
                 if (keep)
@@ -231,9 +184,8 @@ __global__ void __launch_bounds__(kBlock, 1)
                     double* row = tl + ((base + pos) & (kI8Ring - 1)) * cs;
 #pragma unroll
                     for (int j = 0; j < CS; j++)
-                        if (j < ncols)
-                            row[j] = vc[j];
-                    double rhs_new = pa, cF_new = pb;
+                        row[j] = vn[j];
+                    double rhs_new = an0, cF_new = an1;
                     if (pro.mode != GP_NONE)
                     {
                         // (W * coef)(row): columns in order, plain accumulation -- the statement k_wcombine evaluates
@@ -243,18 +195,18 @@ __global__ void __launch_bounds__(kBlock, 1)
 #pragma unroll
                             for (int j = 0; j < CS; j++)
                                 if (j < ncols)
-                                    a1 = a1 + vc[j] * pc1[j];
+                                    a1 = a1 + vn[j] * pc1[j];
                         }
                         if (pro.use2)
                         {
 #pragma unroll
                             for (int j = 0; j < CS; j++)
                                 if (j < ncols)
-                                    a2 = a2 + vc[j] * pc2[j];
+                                    a2 = a2 + vn[j] * pc2[j];
                         }
                         if (pro.mode == GP_RHS)
                         {
-                            double rh = pa;
+                            double rh = an0;
                             if (pro.use1)
                                 rh = rh + (-a1);
                             if (pro.use2)
@@ -264,7 +216,7 @@ __global__ void __launch_bounds__(kBlock, 1)
                         }
                         else
                         {
-                            cF_new = (pro.use1 ? (-1.0 * a1) : 0.0) + pa;
+                            cF_new = (pro.use1 ? (-1.0 * a1) : 0.0) + an0;
                             b.cF[r] = cF_new;
                         }
                     }
@@ -273,16 +225,22 @@ __global__ void __launch_bounds__(kBlock, 1)
                         double vr;  // vsel() of lbfgsb_kernels.cuh on the values already in registers
                         switch (vsel_id)
                         {
-                        case VS_DRT: vr = pb; break;
                         case VS_NEG_CF: vr = -cF_new; break;
                         case VS_NEG_RHS: vr = -rhs_new; break;
-                        case VS_LBOUND: vr = pb - pc; break;
-                        case VS_UBOUND: vr = pb - pc; break;
-                        default: vr = pb; break;
+                        case VS_LBOUND: vr = an1 - an2; break;
+                        case VS_UBOUND: vr = an1 - an2; break;
+                        default: vr = an1; break;  // VS_DRT, VS_Y
                         }
-                        row[ncols] = vr;
+                        row[ncols] = vr;  // after the columns: column ncols of the tile is v
                     }
                 }
+                // -- request the next batch
+                const int64_t bn = bt + nwaves;
+                st_a = st_b;
+                st_b = load_st(bn + nwaves);
+                keep_n = keep_of(bn, st_a);
+                issue_loads(bn, keep_n);
+                bt = bn;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -294,69 +252,77 @@ __global__ void __launch_bounds__(kBlock, 1)
                     }
                 fill += cnt;
             }
-        }
-        else
-            last = true;
-        // ---- groups of 32 staged rows (the last one zero-padded) onto the matrix cores.  ONE copy of this code: the
-        // accumulator tiles must stay in registers (a second inlined copy sent them to scratch memory)
-        while (fill >= 32 || (last && fill > 0))
-        {
-            const int nrows = fill < 32 ? fill : 32;
-            // digits of this lane's 16 elements (rows 16 mh + t of the group, column mc), byte-transposed into operands
-            i32x4 dig[kI8Digits];
-#pragma unroll
-            for (int q = 0; q < 4; q++)
+            else
+                last = true;
+            // ---- groups of 32 staged rows (the last one zero-padded) onto the matrix cores: the digits of the group at
+            // the head of the ring are cut (VALU), then its 66 MFMAs are issued.  ONE copy of this code: with a second
+            // inlined copy the accumulator tiles went to scratch memory.
+            while (fill >= 32 || (last && fill > 0))
             {
-                unsigned w0[4], w1[4], w2[4];
+                const int nrows = fill < 32 ? fill : 32;
+                i32x4 dcur[kI8Digits];
 #pragma unroll
-                for (int t = 0; t < 4; t++)
+                for (int q = 0; q < 4; q++)
                 {
-                    const int rr = 16 * mh + 4 * q + t;
-                    const double x = (col_ok && rr < nrows) ? tl[((head + rr) & (kI8Ring - 1)) * cs + mc] : 0.0;
-                    unsigned long long lo, hi;
-                    gram_i8_digits(x, my_emax, lo, hi);
-                    w0[t] = unsigned(lo);
-                    w1[t] = unsigned(lo >> 32);
-                    w2[t] = unsigned(hi);
+                    unsigned w0[4], w1[4], w2[4];
+#pragma unroll
+                    for (int t = 0; t < 4; t++)
+                    {
+                        const int rr = 16 * mh + 4 * q + t;
+                        const double x = (col_ok && rr < nrows) ? tl[((head + rr) & (kI8Ring - 1)) * cs + mc] : 0.0;
+                        gram_i8_digits(x, my_lsh, w0[t], w1[t], w2[t]);
+                    }
+                    unsigned o[4];
+                    gram_i8_tr4(w0[0], w0[1], w0[2], w0[3], o);
+                    dcur[0][q] = int(o[0]);
+                    dcur[1][q] = int(o[1]);
+                    dcur[2][q] = int(o[2]);
+                    dcur[3][q] = int(o[3]);
+                    gram_i8_tr4(w1[0], w1[1], w1[2], w1[3], o);
+                    dcur[4][q] = int(o[0]);
+                    dcur[5][q] = int(o[1]);
+                    dcur[6][q] = int(o[2]);
+                    dcur[7][q] = int(o[3]);
+                    gram_i8_tr4(w2[0], w2[1], w2[2], w2[3], o);
+                    dcur[8][q] = int(o[0]);
+                    dcur[9][q] = int(o[1]);
+                    dcur[10][q] = int(o[2]);
                 }
-                unsigned o[4];
-                gram_i8_tr4(w0[0], w0[1], w0[2], w0[3], o);
-                dig[0][q] = int(o[0]);
-                dig[1][q] = int(o[1]);
-                dig[2][q] = int(o[2]);
-                dig[3][q] = int(o[3]);
-                gram_i8_tr4(w1[0], w1[1], w1[2], w1[3], o);
-                dig[4][q] = int(o[0]);
-                dig[5][q] = int(o[1]);
-                dig[6][q] = int(o[2]);
-                dig[7][q] = int(o[3]);
-                gram_i8_tr4(w2[0], w2[1], w2[2], w2[3], o);
-                dig[8][q] = int(o[0]);
-                dig[9][q] = int(o[1]);
-                dig[10][q] = int(o[2]);
+                // 66 digit pairs, accumulator u collects k + l = 10 + u; round-robin over the
+                // accumulators so that consecutive MFMAs are independent
+#pragma unroll
+                for (int k = 0; k < kI8Digits; k++)
+#pragma unroll
+                    for (int u = 0; u < kI8Acc; u++)
+                    {
+                        const int l = 10 + u - k;
+                        if (l >= 0 && l < kI8Digits)
+                            acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(dcur[k], dcur[l], acc[u], 0, 0, 0);
+                    }
+                head = (head + nrows) & (kI8Ring - 1);
+                fill -= nrows;
             }
-            // 66 digit pairs, accumulator u collects k + l = 10 + u; issued round-robin over the accumulators so that
-            // consecutive instructions are independent
-#pragma unroll
-            for (int k = 0; k < kI8Digits; k++)
-#pragma unroll
-                for (int u = 0; u < kI8Acc; u++)
-                {
-                    const int l = 10 + u - k;
-                    if (l >= 0 && l < kI8Digits)
-                        acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(dig[k], dig[l], acc[u], 0, 0, 0);
-                }
-            head = (head + nrows) & (kI8Ring - 1);
-            fill -= nrows;
-            if (++groups >= kI8FlushGroups)
-                flush();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        // ---- flush the int32 tiles into the block's int64 partials (zeroed by the host): integer atomics -- exact, order
+        // independent, and no read-modify-write through registers (176 of those at once were what spilled).  C/D layout
+        // of the 32x32 tile: column j = lane & 31, row i = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+        for (int u = 0; u < kI8Acc; u++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+            {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * mh, j = mc;
+                if (i < ncols && j <= i && acc[u][r] != 0)
+                    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(mypart + int64_t(u) * ne_pad + gram_tri(i, j)),
+                                           (unsigned long long) (long long) acc[u][r], __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                acc[u][r] = 0;
+            }
         if (last)
             break;
     }
-    flush();
     // v row: the lanes that hold the same entry are nv1 apart
     if (vsel_id >= 0)
     {

@@ -1240,14 +1240,15 @@ static int gram_i8_run(lbfgsx_ctx* c, int tot, int vsel_id, int mask, const Gram
         b->i8_nepad = ecap;
     }
     LBFGSX_HIP(hipMemsetAsync(b->i8_vsum, 0, sizeof(unsigned long long) * kI8Acc * size_t(ne_pad), c->stream));
+    LBFGSX_HIP(hipMemsetAsync(b->i8_part, 0, sizeof(long long) * size_t(blocks) * kI8Acc * size_t(ne_pad), c->stream));
     if (vsel_id >= 0)
         LBFGSX_HIP(hipMemsetAsync(b->i8_partv, 0, sizeof(double) * size_t(waves) * 32 * 2, c->stream));
     if (tot <= 23)
         launch_gram_i8_cs<23>(c, tot, vsel_id, mask, pro, ga, blocks, ne_pad);
     else
         launch_gram_i8_cs<31>(c, tot, vsel_id, mask, pro, ga, blocks, ne_pad);
-    const int nch = std::min(waves, 16);
-    hipLaunchKernelGGL(k_gram_i8_sum, dim3(kI8Acc, nch), dim3(kBlock), 0, c->stream, b->i8_part, waves, ne, ne_pad, b->i8_vsum);
+    hipLaunchKernelGGL(k_gram_i8_sum, dim3(kI8Acc, std::min(blocks, 16)), dim3(kBlock), 0, c->stream, b->i8_part, blocks, ne, ne_pad,
+                       b->i8_vsum);
     hipLaunchKernelGGL(k_gram_i8_final, dim3(1), dim3(kBlock), 0, c->stream, b->i8_vsum, tot, ne_pad, b->i8_partv, waves,
                        vsel_id >= 0 ? 1 : 0, ga, b->gram_out, want_dd ? b->gram_dd : static_cast<double*>(nullptr));
     LBFGSX_HIP(hipGetLastError());
