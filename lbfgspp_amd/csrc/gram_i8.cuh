@@ -396,18 +396,29 @@ __global__ void __launch_bounds__(kBlock) k_gram_i8_final(const unsigned long lo
         }
     }
     if (with_v)
-        for (int j = threadIdx.x; j <= ncols; j += kBlock)
+    {
+        // v row: 32 entries x 8 slices of the per-wave partials per thread, then the 8 slices of an entry in order
+        __shared__ double sv[8][32][2];
+        const int j = threadIdx.x & 31, sl = threadIdx.x >> 5;
+        DD t;
+        for (int w = sl; w < nwaves; w += 8)
+            t.merge(part_v[(int64_t(w) * 32 + j) * 2 + 0], part_v[(int64_t(w) * 32 + j) * 2 + 1]);
+        sv[sl][j][0] = t.hi;
+        sv[sl][j][1] = t.lo;
+        __syncthreads();
+        if (threadIdx.x <= ncols)
         {
-            DD t;
-            for (int w = 0; w < nwaves; w++)
-                t.merge(part_v[(int64_t(w) * 32 + j) * 2 + 0], part_v[(int64_t(w) * 32 + j) * 2 + 1]);
-            out[ne + j] = t.value();
+            DD r;
+            for (int q = 0; q < 8; q++)
+                r.merge(sv[q][threadIdx.x][0], sv[q][threadIdx.x][1]);
+            out[ne + threadIdx.x] = r.value();
             if (out_dd)
             {
-                out_dd[(ne + j) * 2 + 0] = t.hi;
-                out_dd[(ne + j) * 2 + 1] = t.lo;
+                out_dd[(ne + threadIdx.x) * 2 + 0] = r.hi;
+                out_dd[(ne + threadIdx.x) * 2 + 1] = r.lo;
             }
         }
+    }
 }
 
 // exact max |col| of one column into its slot (columns that did not come through k_b_post)
