@@ -137,33 +137,31 @@ __global__ void __launch_bounds__(kBlock, 1)
     const bool need_rhs = pro.mode == GP_RHS || vsel_id == VS_NEG_RHS;
     const bool need_g = pro.mode == GP_LINEAR;
 
-    // ---- software pipeline.  State bytes run three batches ahead; the column values and the per-row inputs of the
-    // prologue / of v two batches ahead (vn: the batch to stage next; vm: the one after it, in flight): a request has two
-    // contractions to arrive in (one wavefront per SIMD: nothing else hides the HBM latency).
+    // ---- software pipeline.  State bytes run two batches ahead; the column values (vn) and the per-row inputs of the
+    // prologue / of v (an*) one batch ahead: they are requested right after the previous batch has been staged, so the
+    // contraction of that batch -- the long part -- covers their latency (one wavefront per SIMD: nothing else would).
     int64_t bt = gwave;
-    unsigned char st_b = load_st(bt + nwaves), st_c = load_st(bt + 2 * nwaves);
-    bool keep_n = keep_of(bt, load_st(bt)), keep_m = keep_of(bt + nwaves, st_b);
-    double vn[CS], an0 = 0.0, an1 = 0.0, an2 = 0.0;  // batch bt: arrived when staged
-    double vm[CS], am0 = 0.0, am1 = 0.0, am2 = 0.0;  // batch bt + nwaves: in flight
-    auto issue_loads = [&](int64_t bq, bool kq, double (&vv)[CS], double& a0, double& a1, double& a2) {
+    unsigned char st_a = load_st(bt), st_b = load_st(bt + nwaves);
+    bool keep_n = keep_of(bt, st_a);
+    double vn[CS], an0 = 0.0, an1 = 0.0, an2 = 0.0;
+    auto issue_loads = [&](int64_t bq, bool kq) {
         const int64_t rq = kq ? bq * kGramDDRows + lane : int64_t(0);  // masked-out lanes re-read row 0 (no branch)
 #pragma unroll
         for (int j = 0; j < CS; j++)
-            vv[j] = cols.p[j < ncols ? j : ncols - 1][rq];              // columns beyond ncols repeat the last one
-        a0 = need_rhs ? b.rhs[rq] : (need_g ? b.g[rq] : 0.0);
-        a1 = a2 = 0.0;
+            vn[j] = cols.p[j < ncols ? j : ncols - 1][rq];              // columns beyond ncols repeat the last one
+        an0 = need_rhs ? b.rhs[rq] : (need_g ? b.g[rq] : 0.0);
+        an1 = an2 = 0.0;
         switch (vsel_id)
         {
-        case VS_DRT: a1 = b.drt[rq]; break;
-        case VS_NEG_CF: if (!need_g) a1 = b.cF[rq]; break;
-        case VS_LBOUND: a1 = b.lb[rq]; a2 = b.x0[rq]; break;
-        case VS_UBOUND: a1 = b.ub[rq]; a2 = b.x0[rq]; break;
-        case VS_Y: a1 = b.y[rq]; break;
+        case VS_DRT: an1 = b.drt[rq]; break;
+        case VS_NEG_CF: if (!need_g) an1 = b.cF[rq]; break;
+        case VS_LBOUND: an1 = b.lb[rq]; an2 = b.x0[rq]; break;
+        case VS_UBOUND: an1 = b.ub[rq]; an2 = b.x0[rq]; break;
+        case VS_Y: an1 = b.y[rq]; break;
         default: break;
         }
     };
-    issue_loads(bt, keep_n, vn, an0, an1, an2);
-    issue_loads(bt + nwaves, keep_m, vm, am0, am1, am2);
+    issue_loads(bt, keep_n);
 
     int head = 0, fill = 0;  // ring rows [head, head + fill) are staged and not yet contracted
     bool last = false;
@@ -236,18 +234,12 @@ __global__ void __launch_bounds__(kBlock, 1)
                         row[ncols] = vr;  // after the columns: column ncols of the tile is v
                     }
                 }
-                // -- the batch in flight becomes the next one to stage; request the one after it
+                // -- request the next batch
                 const int64_t bn = bt + nwaves;
-#pragma unroll
-                for (int j = 0; j < CS; j++)
-                    vn[j] = vm[j];
-                an0 = am0;
-                an1 = am1;
-                an2 = am2;
-                keep_n = keep_m;
-                keep_m = keep_of(bn + nwaves, st_c);
-                st_c = load_st(bn + 2 * nwaves);
-                issue_loads(bn + nwaves, keep_m, vm, am0, am1, am2);
+                st_a = st_b;
+                st_b = load_st(bn + nwaves);
+                keep_n = keep_of(bn, st_a);
+                issue_loads(bn, keep_n);
                 bt = bn;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
