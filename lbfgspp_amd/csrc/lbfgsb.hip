@@ -31,7 +31,9 @@ struct lbfgsb_state
     double* gram_out_host = nullptr;  // same for gram_out
     double* gram_dd = nullptr;        // [3][256][2] un-rounded (hi, lo) sums of the last one-pass Gram (device)
     void* coef_dev = nullptr;         // T[80]
-    unsigned long long* mslot = nullptr;  // max / min slots
+    unsigned long long* mslot = nullptr;  // (unused since the extrema ride in the grid reductions)
+    double* g_host = nullptr;             // pinned landing zone of lbfgsx_b_cauchy_chunk
+    size_t g_host_cap = 0;
     // chunk staging for the sequential GCP scan
     double *g_brk = nullptr, *g_g = nullptr, *g_z = nullptr, *g_w = nullptr;
     int* g_idx = nullptr;
@@ -169,26 +171,6 @@ static int fetch_T(lbfgsx_ctx* c, int idx, int k, double* out)
     return LBFGSX_OK;
 }
 
-static int read_slot(lbfgsx_ctx* c, double* v)
-{
-    unsigned long long bits = 0;
-    LBFGSX_HIP(hipMemcpyAsync(&bits, c->bstate->mslot, sizeof(bits), hipMemcpyDeviceToHost, c->stream));
-    LBFGSX_HIP(hipStreamSynchronize(c->stream));
-    std::memcpy(v, &bits, sizeof(double));
-    return LBFGSX_OK;
-}
-static int arm_slot(lbfgsx_ctx* c, bool for_min)
-{
-    // max slots start at +0.0, min slots at +inf (bit patterns of non-negative doubles are order preserving)
-    LBFGSX_HIP(hipMemsetAsync(c->bstate->mslot, 0, sizeof(unsigned long long), c->stream));
-    if (for_min)
-    {
-        static const unsigned long long inf_bits = 0x7FF0000000000000ull;
-        LBFGSX_HIP(hipMemcpyAsync(c->bstate->mslot, &inf_bits, sizeof(inf_bits), hipMemcpyHostToDevice, c->stream));
-    }
-    return LBFGSX_OK;
-}
-
 int bounded_alloc(lbfgsx_ctx* c)
 {
     lbfgsb_state* b = new lbfgsb_state();
@@ -271,6 +253,8 @@ void bounded_free(lbfgsx_ctx* c)
                     b->s_small, b->s_exit, b->pk, b->pv, b->pcount, b->sel_tmp};
     if (b->h_chain)
         (void) hipHostFree(b->h_chain);
+    if (b->g_host)
+        (void) hipHostFree(b->g_host);
     (void) hipFree(b->colmax);
     (void) hipFree(b->i8_part);
     (void) hipFree(b->i8_partv);
@@ -484,16 +468,10 @@ template <class T, class OBJ>
 static int b_eval_t(lbfgsx_ctx* c, OBJ obj, double* r3)
 {
     const int grid = c->grid_for(c->n);
-    int rc = arm_slot(c, false);
-    if (rc)
-        return rc;
     hipLaunchKernelGGL((k_b_eval<T, OBJ>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]), P<T>(c->gb[c->cur]),
-                       P<T>(c->lb), P<T>(c->ub), c->n, obj, c->ws, c->out_slot<T>(), c->bstate->mslot);
+                       P<T>(c->lb), P<T>(c->ub), c->n, obj, c->ws, c->out_slot<T>());
     LBFGSX_HIP(hipGetLastError());
-    rc = fetch_T<T>(c, c->sl.out(0), 2, r3);
-    if (rc)
-        return rc;
-    return read_slot(c, &r3[2]);
+    return fetch_T<T>(c, c->sl.out(0), 3, r3);
 }
 }  // namespace lbfgsx
 
@@ -530,20 +508,18 @@ int lbfgsx_b_norms(lbfgsx_ctx* c, double* projgnorm, double* xnorm2)
     if (rc)
         return rc;
     const int grid = c->grid_for(c->n);
-    rc = arm_slot(c, false);
-    if (rc)
-        return rc;
-    double r[1];
+    double r[2];
     DISPATCH_T(c, {
         hipLaunchKernelGGL((k_b_norms<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]), P<T>(c->gb[c->cur]),
-                           P<T>(c->lb), P<T>(c->ub), c->n, c->ws, c->out_slot<T>(), c->bstate->mslot);
+                           P<T>(c->lb), P<T>(c->ub), c->n, c->ws, c->out_slot<T>());
         LBFGSX_HIP(hipGetLastError());
-        rc = fetch_T<T>(c, c->sl.out(0), 1, r);
+        rc = fetch_T<T>(c, c->sl.out(0), 2, r);
     });
     if (rc)
         return rc;
     if (xnorm2) *xnorm2 = r[0];
-    return read_slot(c, projgnorm);
+    if (projgnorm) *projgnorm = r[1];
+    return LBFGSX_OK;
 }
 
 int lbfgsx_b_dg_maxstep(lbfgsx_ctx* c, double* dg, double* step_max)
@@ -553,21 +529,18 @@ int lbfgsx_b_dg_maxstep(lbfgsx_ctx* c, double* dg, double* step_max)
     if (rc)
         return rc;
     const int grid = c->grid_for(c->n);
-    rc = arm_slot(c, true);
-    if (rc)
-        return rc;
-    double r[1];
+    double r[2];
     DISPATCH_T(c, {
         hipLaunchKernelGGL((k_b_dg_maxstep<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]),
-                           P<T>(c->gb[c->cur]), P<T>(c->d), P<T>(c->lb), P<T>(c->ub), c->n, c->ws,
-                           c->out_slot<T>(), c->bstate->mslot);
+                           P<T>(c->gb[c->cur]), P<T>(c->d), P<T>(c->lb), P<T>(c->ub), c->n, c->ws, c->out_slot<T>());
         LBFGSX_HIP(hipGetLastError());
-        rc = fetch_T<T>(c, c->sl.out(0), 1, r);
+        rc = fetch_T<T>(c, c->sl.out(0), 2, r);
     });
     if (rc)
         return rc;
     if (dg) *dg = r[0];
-    return read_slot(c, step_max);
+    if (step_max) *step_max = r[1];
+    return LBFGSX_OK;
 }
 
 int lbfgsx_b_post_linesearch(lbfgsx_ctx* c, double* projgnorm, double* xnorm2, double* sy, double* yy)
@@ -577,10 +550,7 @@ int lbfgsx_b_post_linesearch(lbfgsx_ctx* c, double* projgnorm, double* xnorm2, d
     if (rc)
         return rc;
     const int grid = c->grid_for(c->n);
-    rc = arm_slot(c, false);
-    if (rc)
-        return rc;
-    double r[3];
+    double r[4];
     // exact max |s|, max |y| of the new column pair ride along (the fixed-point scale of the integer Gram, gram_i8.cuh)
     unsigned long long* cmx = nullptr;
     if (c->bstate->gram_i8)
@@ -593,9 +563,9 @@ int lbfgsx_b_post_linesearch(lbfgsx_ctx* c, double* projgnorm, double* xnorm2, d
         hipLaunchKernelGGL((k_b_post<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]), P<T>(c->xb[c->xp]),
                            P<T>(c->gb[c->cur]), P<T>(c->gb[c->xp]), P<T>(c->lb), P<T>(c->ub), P<T>(c->col(c->S, c->spare)),
                            P<T>(c->col(c->Y, c->spare)), c->n, c->ws, c->out_slot<T>(),
-                           P<T>(c->sc) + c->sl.ys(c->spare), P<T>(c->sc) + c->sl.theta(c->spare), c->bstate->mslot, cmx);
+                           P<T>(c->sc) + c->sl.ys(c->spare), P<T>(c->sc) + c->sl.theta(c->spare), cmx);
         LBFGSX_HIP(hipGetLastError());
-        rc = fetch_T<T>(c, c->sl.out(0), 3, r);
+        rc = fetch_T<T>(c, c->sl.out(0), 4, r);
     });
     if (rc)
         return rc;
@@ -605,7 +575,8 @@ int lbfgsx_b_post_linesearch(lbfgsx_ctx* c, double* projgnorm, double* xnorm2, d
     if (xnorm2) *xnorm2 = r[0];
     if (sy) *sy = r[1];
     if (yy) *yy = r[2];
-    return read_slot(c, projgnorm);
+    if (projgnorm) *projgnorm = r[3];
+    return LBFGSX_OK;
 }
 
 int lbfgsx_b_correction_dots_defer(lbfgsx_ctx* c)
@@ -821,20 +792,26 @@ int lbfgsx_b_cauchy_chunk(lbfgsx_ctx* c, int64_t first, int64_t count, double* b
     if (count <= 0)
         return LBFGSX_OK;
     const int nc = c->ncorr;
+    // one packed device buffer [brk | g | z | W rows] of (3 + 2c) * count doubles and ONE copy back (four separate copies
+    // were four blit kernels per chunk); the pinned landing zone serves the chunks the host form actually asks for
+    const size_t per = size_t(3 + 2 * nc);
     if (count > b->g_cap || nc != b->g_ncorr)
     {
-        void* old[] = {b->g_brk, b->g_g, b->g_z, b->g_w, b->g_idx};
+        void* old[] = {b->g_brk, b->g_idx};
         for (void* p : old)
             (void) hipFree(p);
+        b->g_brk = nullptr;
+        b->g_idx = nullptr;
         const int64_t cap = std::max<int64_t>(count, b->g_cap);
-        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->g_brk), sizeof(double) * size_t(cap)));
-        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->g_g), sizeof(double) * size_t(cap)));
-        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->g_z), sizeof(double) * size_t(cap)));
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->g_brk), sizeof(double) * size_t(cap) * per));
         LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->g_idx), sizeof(int) * size_t(cap)));
-        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->g_w), sizeof(double) * size_t(cap) * size_t(std::max(2 * nc, 1))));
         b->g_cap = cap;
         b->g_ncorr = nc;
     }
+    double* d_brk = b->g_brk;
+    double* d_g = d_brk + count;
+    double* d_z = d_g + count;
+    double* d_w = d_z + count;
     rc = upload_phys(c);
     if (rc)
         return rc;
@@ -842,17 +819,39 @@ int lbfgsx_b_cauchy_chunk(lbfgsx_ctx* c, int64_t first, int64_t count, double* b
     DISPATCH_T(c, {
         BVecs<T> bv = bvecs<T>(c);
         hipLaunchKernelGGL((k_cauchy_gather<T>), dim3(grid), dim3(256), 0, c->stream, bv, P<T>(b->keys_out), b->vals_out, first,
-                           count, P<T>(c->S), P<T>(c->Y), c->ld, b->phys_dev, nc, b->g_brk, b->g_g, b->g_z, b->g_idx, b->g_w);
+                           count, P<T>(c->S), P<T>(c->Y), c->ld, b->phys_dev, nc, d_brk, d_g, d_z, b->g_idx, d_w);
     });
     LBFGSX_HIP(hipGetLastError());
-    LBFGSX_HIP(hipMemcpyAsync(brk, b->g_brk, sizeof(double) * size_t(count), hipMemcpyDeviceToHost, c->stream));
-    LBFGSX_HIP(hipMemcpyAsync(g, b->g_g, sizeof(double) * size_t(count), hipMemcpyDeviceToHost, c->stream));
-    LBFGSX_HIP(hipMemcpyAsync(z, b->g_z, sizeof(double) * size_t(count), hipMemcpyDeviceToHost, c->stream));
+    const size_t ndbl = size_t(count) * ((nc > 0 && wrows) ? per : size_t(3));
+    if (ndbl > b->g_host_cap)
+    {
+        if (b->g_host)
+            (void) hipHostFree(b->g_host);
+        b->g_host = nullptr;
+        b->g_host_cap = 0;
+        const size_t want = std::max<size_t>(ndbl, size_t(1) << 16);
+        if (want <= (size_t(1) << 25))  // up to 256 MB pinned; larger chunks land in a pageable buffer
+        {
+            LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->g_host), sizeof(double) * want, hipHostMallocDefault));
+            b->g_host_cap = want;
+        }
+    }
+    std::vector<double> pageable;
+    double* land = b->g_host;
+    if (ndbl > b->g_host_cap)
+    {
+        pageable.resize(ndbl);
+        land = pageable.data();
+    }
+    LBFGSX_HIP(hipMemcpyAsync(land, d_brk, sizeof(double) * ndbl, hipMemcpyDeviceToHost, c->stream));
     if (idx)
         LBFGSX_HIP(hipMemcpyAsync(idx, b->g_idx, sizeof(int) * size_t(count), hipMemcpyDeviceToHost, c->stream));
-    if (nc > 0 && wrows)
-        LBFGSX_HIP(hipMemcpyAsync(wrows, b->g_w, sizeof(double) * size_t(count) * size_t(2 * nc), hipMemcpyDeviceToHost, c->stream));
     LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    std::memcpy(brk, land, sizeof(double) * size_t(count));
+    std::memcpy(g, land + count, sizeof(double) * size_t(count));
+    std::memcpy(z, land + 2 * count, sizeof(double) * size_t(count));
+    if (nc > 0 && wrows)
+        std::memcpy(wrows, land + 3 * count, sizeof(double) * size_t(count) * size_t(2 * nc));
     return LBFGSX_OK;
 }
 

@@ -117,12 +117,11 @@ __device__ __forceinline__ T projg_term(T x, T g, T lb, T ub)
 }
 
 // ---------------------------------------------------------------- evaluation with the projected-gradient norm
-// out[0] = f(x), out[1] = x.x ; *maxslot = ||P(x-g)-x||_inf  (LBFGSB.h:137-138,146)
+// out[0] = f(x), out[1] = x.x, out[2] = ||P(x-g)-x||_inf  (LBFGSB.h:137-138,146)
 template <class T, class OBJ>
 __global__ void __launch_bounds__(kBlock) k_b_eval(const T* __restrict__ x, T* __restrict__ g,
                                                    const T* __restrict__ lb, const T* __restrict__ ub, int64_t n,
-                                                   OBJ obj, RedWs ws, T* __restrict__ out,
-                                                   unsigned long long* maxslot)
+                                                   OBJ obj, RedWs ws, T* __restrict__ out)
 {
     typedef typename AccOf<T>::type A;
     constexpr int W = Vec16<T>::W;
@@ -150,11 +149,16 @@ __global__ void __launch_bounds__(kBlock) k_b_eval(const T* __restrict__ x, T* _
             acc[1].add_prod(x[i], x[i]);
             pg = fmax(pg, double(projg_term(x[i], g[i], lb[i], ub[i])));
         }
-    block_atomic_max(maxslot, pg);
-    if (grid_reduce<2>(acc, ws) && threadIdx.x == 0)
+    ext_publish<false>(pg, ws, 4);
+    if (grid_reduce<2>(acc, ws))
     {
-        out[0] = obj.finish(T(acc[0].value()));
-        out[1] = T(acc[1].value());
+        const double pgmax = ext_collect<false>(ws, 4);
+        if (threadIdx.x == 0)
+        {
+            out[0] = obj.finish(T(acc[0].value()));
+            out[1] = T(acc[1].value());
+            out[2] = T(pgmax);
+        }
     }
 }
 
@@ -162,7 +166,7 @@ __global__ void __launch_bounds__(kBlock) k_b_eval(const T* __restrict__ x, T* _
 template <class T>
 __global__ void __launch_bounds__(kBlock) k_b_norms(const T* __restrict__ x, const T* __restrict__ g,
                                                     const T* __restrict__ lb, const T* __restrict__ ub, int64_t n,
-                                                    RedWs ws, T* __restrict__ out, unsigned long long* maxslot)
+                                                    RedWs ws, T* __restrict__ out)
 {
     typedef typename AccOf<T>::type A;
     A acc[1];
@@ -173,9 +177,16 @@ __global__ void __launch_bounds__(kBlock) k_b_norms(const T* __restrict__ x, con
         acc[0].add_prod(x[i], x[i]);
         pg = fmax(pg, double(projg_term(x[i], g[i], lb[i], ub[i])));
     }
-    block_atomic_max(maxslot, pg);
-    if (grid_reduce<1>(acc, ws) && threadIdx.x == 0)
-        out[0] = T(acc[0].value());
+    ext_publish<false>(pg, ws, 2);
+    if (grid_reduce<1>(acc, ws))
+    {
+        const double pgmax = ext_collect<false>(ws, 2);
+        if (threadIdx.x == 0)
+        {
+            out[0] = T(acc[0].value());
+            out[1] = T(pgmax);
+        }
+    }
 }
 
 // dg = g.d ; step_max = max feasible step (LBFGSB.h:68-86,176-179)
@@ -183,7 +194,7 @@ template <class T>
 __global__ void __launch_bounds__(kBlock) k_b_dg_maxstep(const T* __restrict__ x, const T* __restrict__ g,
                                                          const T* __restrict__ d, const T* __restrict__ lb,
                                                          const T* __restrict__ ub, int64_t n, RedWs ws,
-                                                         T* __restrict__ out, unsigned long long* minslot)
+                                                         T* __restrict__ out)
 {
     typedef typename AccOf<T>::type A;
     A acc[1];
@@ -198,9 +209,16 @@ __global__ void __launch_bounds__(kBlock) k_b_dg_maxstep(const T* __restrict__ x
         else if (di < T(0))
             smin = fmin(smin, double((lb[i] - x[i]) / di) + 0.0);
     }
-    block_atomic_min(minslot, smin);
-    if (grid_reduce<1>(acc, ws) && threadIdx.x == 0)
-        out[0] = T(acc[0].value());
+    ext_publish<true>(smin, ws, 2);
+    if (grid_reduce<1>(acc, ws))
+    {
+        const double smin_all = ext_collect<true>(ws, 2);
+        if (threadIdx.x == 0)
+        {
+            out[0] = T(acc[0].value());
+            out[1] = T(smin_all);
+        }
+    }
 }
 
 // after the line search (LBFGSB.h:206,213,235-237): projected-gradient norm, x.x, s, y, s.y, y.y
@@ -210,7 +228,7 @@ __global__ void __launch_bounds__(kBlock) k_b_post(const T* __restrict__ x, cons
                                                    const T* __restrict__ lb, const T* __restrict__ ub,
                                                    T* __restrict__ s, T* __restrict__ y, int64_t n, RedWs ws,
                                                    T* __restrict__ out, T* __restrict__ ys_slot,
-                                                   T* __restrict__ theta_slot, unsigned long long* maxslot,
+                                                   T* __restrict__ theta_slot,
                                                    unsigned long long* colmax /* [0] max |y|, [1] max |s| of the new pair */)
 {
     typedef typename AccOf<T>::type A;
@@ -230,20 +248,25 @@ __global__ void __launch_bounds__(kBlock) k_b_post(const T* __restrict__ x, cons
         ms = fmax(ms, fabs(double(si)));
         my = fmax(my, fabs(double(yi)));
     }
-    block_atomic_max(maxslot, pg);
     if (colmax)  // only contexts that run the integer Gram (LBFGSX_GRAM=i8) keep the column maxima
     {
         block_atomic_max(colmax + 0, my);
         block_atomic_max(colmax + 1, ms);
     }
-    if (grid_reduce<3>(acc, ws) && threadIdx.x == 0)
+    ext_publish<false>(pg, ws, 6);
+    if (grid_reduce<3>(acc, ws))
     {
-        const T sy = T(acc[1].value()), yy = T(acc[2].value());
-        out[0] = T(acc[0].value());
-        out[1] = sy;
-        out[2] = yy;
-        *ys_slot = sy;
-        *theta_slot = yy / sy;
+        const double pgmax = ext_collect<false>(ws, 6);
+        if (threadIdx.x == 0)
+        {
+            const T sy = T(acc[1].value()), yy = T(acc[2].value());
+            out[0] = T(acc[0].value());
+            out[1] = sy;
+            out[2] = yy;
+            out[3] = T(pgmax);
+            *ys_slot = sy;
+            *theta_slot = yy / sy;
+        }
     }
 }
 

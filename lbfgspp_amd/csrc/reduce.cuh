@@ -206,6 +206,51 @@ __device__ __forceinline__ bool grid_reduce(A (&acc)[NRED], const RedWs& ws)
     return true;
 }
 
+// One extremum (max or min) of non-negative values next to the sums of a grid_reduce -- the infinity norm of the
+// projected gradient (LBFGSB.h:62-65), the largest feasible step (LBFGSB.h:68-86).  Order independent by nature.  The
+// per-block value rides in a row of the partials the sums do not use: ext_publish BEFORE grid_reduce (every thread; the
+// store of thread 0 is drained with the block's other partials before the ticket), ext_collect AFTER it in the last
+// block (every thread; the result is valid in thread 0).  Replaces an atomic slot that had to be armed by a fill and
+// fetched by a copy: two blit kernels and a synchronisation per use.
+template <bool MIN>
+__device__ __forceinline__ double ext_op(double a, double b) { return MIN ? fmin(a, b) : fmax(a, b); }
+template <bool MIN>
+__device__ __forceinline__ void ext_publish(double v, const RedWs& ws, int row)
+{
+    __shared__ double sx[kWaves];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v = ext_op<MIN>(v, __shfl_down(v, off, 64));
+    if ((threadIdx.x & 63) == 0)
+        sx[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        double t = sx[0];
+        for (int w = 1; w < kWaves; w++)
+            t = ext_op<MIN>(t, sx[w]);
+        st_agent(ws.partials + size_t(row) * ws.maxGrid + blockIdx.x, t);
+    }
+}
+template <bool MIN>
+__device__ __forceinline__ double ext_collect(const RedWs& ws, int row)
+{
+    __shared__ double sy[kWaves];
+    double v = MIN ? __longlong_as_double(0x7FF0000000000000ll) : 0.0;
+    for (int b = threadIdx.x; b < int(gridDim.x); b += kBlock)
+        v = ext_op<MIN>(v, ld_agent(ws.partials + size_t(row) * ws.maxGrid + b));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v = ext_op<MIN>(v, __shfl_down(v, off, 64));
+    if ((threadIdx.x & 63) == 0)
+        sy[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = sy[0];
+    for (int w = 1; w < kWaves; w++)
+        t = ext_op<MIN>(t, sy[w]);
+    return t;
+}
+
 // ---------------------------------------------------------------- 16-byte vector access
 typedef double d2_t __attribute__((ext_vector_type(2)));
 typedef float f4_t __attribute__((ext_vector_type(4)));
