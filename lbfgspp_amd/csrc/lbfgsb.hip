@@ -32,6 +32,14 @@ struct lbfgsb_state
     double* gram_dd = nullptr;        // [3][256][2] un-rounded (hi, lo) sums of the last one-pass Gram (device)
     void* coef_dev = nullptr;         // T[80]
     unsigned long long* mslot = nullptr;  // (unused since the extrema ride in the grid reductions)
+    // index list of the rows the last BOXCQP partition put into L or U (k_sub_sweep_begin); lu_valid: it describes the
+    // current state bytes (any other writer of ST_L / ST_U clears it)
+    int* lu_list = nullptr;
+    unsigned* lu_cnt = nullptr;
+    unsigned lu_cap = 0;
+    int lu_n = 0;
+    bool lu_valid = false;
+    bool lu_use = true;                   // LBFGSX_LU_LIST=0: always scan
     double* g_host = nullptr;             // pinned landing zone of lbfgsx_b_cauchy_chunk
     size_t g_host_cap = 0;
     // chunk staging for the sequential GCP scan
@@ -194,6 +202,12 @@ int bounded_alloc(lbfgsx_ctx* c)
         LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->dout), sizeof(double) * 64));
     LBFGSX_HIP(hipMalloc(&b->coef_dev, sizeof(double) * 80));
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->mslot), sizeof(unsigned long long) * 2));
+    b->lu_cap = unsigned(std::min<int64_t>(c->n, int64_t(1) << 20));
+    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->lu_list), sizeof(int) * size_t(b->lu_cap)));
+    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->lu_cnt), sizeof(unsigned)));
+    LBFGSX_HIP(hipMemset(b->lu_cnt, 0, sizeof(unsigned)));
+    if (const char* e = getenv("LBFGSX_LU_LIST"))
+        b->lu_use = atoi(e) != 0;
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->colmax), sizeof(unsigned long long) * 2 * size_t(c->m + 1)));
     LBFGSX_HIP(hipMemset(b->colmax, 0, sizeof(unsigned long long) * 2 * size_t(c->m + 1)));
     b->colmax_ok.assign(size_t(c->m + 1), 0);
@@ -255,6 +269,8 @@ void bounded_free(lbfgsx_ctx* c)
         (void) hipHostFree(b->h_chain);
     if (b->g_host)
         (void) hipHostFree(b->g_host);
+    (void) hipFree(b->lu_list);
+    (void) hipFree(b->lu_cnt);
     (void) hipFree(b->colmax);
     (void) hipFree(b->i8_part);
     (void) hipFree(b->i8_partv);
@@ -326,6 +342,39 @@ static int wtv_t(lbfgsx_ctx* c, int vsel_id, const T* vcol, int mask, double* ou
     const int total = 2 * c->ncorr;
     const int grid = c->grid_for(c->n);
     BVecs<T> b = bvecs<T>(c);
+    if (!vcol && c->bstate->lu_valid && mask != 0 && (mask & ~(ST_L | ST_U)) == 0 && total <= 32)
+    {
+        // rows inside L u U: the index list of the last partition (k_sub_sweep_begin)
+        const int nl = c->bstate->lu_n;
+        const int lgrid = std::max(1, std::min(32, (nl + kBlock - 1) / kBlock));
+        int which[32];
+        for (int k = 0; k < total; k++)
+            which[k] = k;
+        Cols<T, 32> cl = col_list<T, 32>(c, which, total);
+        double r[33];
+        int nc_used;
+#define ML_LAUNCH(N)                                                                                                        \
+    do                                                                                                                      \
+    {                                                                                                                       \
+        hipLaunchKernelGGL((k_multidot_list<T, N>), dim3(lgrid), dim3(kBlock), 0, c->stream, cl, total, b, vsel_id, mask,   \
+                           c->bstate->lu_list, nl, c->ws, c->bstate->dout);                                                 \
+        nc_used = N;                                                                                                        \
+    } while (0)
+        if (total <= 8) ML_LAUNCH(8);
+        else if (total <= 16) ML_LAUNCH(16);
+        else if (total <= 24) ML_LAUNCH(24);
+        else ML_LAUNCH(32);
+#undef ML_LAUNCH
+        LBFGSX_HIP(hipGetLastError());
+        int rc = fetch_doubles(c, nc_used + 1, r);
+        if (rc)
+            return rc;
+        for (int k = 0; k < total; k++)
+            out[k] = r[k];
+        if (nnz)
+            *nnz = int64_t(r[nc_used]);
+        return LBFGSX_OK;
+    }
     if (total > 8 && total <= 32 && !c->bstate->multidot_chunked)
     {
         // one launch for every column (all history columns are 16-byte aligned: ld is a multiple of 64 elements)
@@ -416,11 +465,17 @@ static int cauchy_wtd(lbfgsx_ctx* c, double* wtd)
 
 namespace lbfgsx {
 #define CB_LAUNCH(M) \
-    hipLaunchKernelGGL((k_wcombine<T, M>), dim3(grid), dim3(kBlock), 0, c->stream, bv, S, Y, c->ld, ph, c->ncorr, cf, has_w, mask, vsel_id, T(theta), c->n)
+    hipLaunchKernelGGL((k_wcombine<T, M>), dim3(grid), dim3(kBlock), 0, c->stream, bv, S, Y, c->ld, ph, c->ncorr, cf, has_w, mask, vsel_id, T(theta), c->n, lst, nlst)
 template <class T>
 static int wcombine_t(lbfgsx_ctx* c, int mode, int mask, int vsel_id, const double* coef, double theta)
 {
-    const int grid = c->grid_for(c->n);
+    // masks inside L u U: walk the index list of the last partition instead of all n rows
+    const bool sparse = c->bstate->lu_valid && mask != 0 && (mask & ~(ST_L | ST_U)) == 0;
+    const int* lst = sparse ? c->bstate->lu_list : nullptr;
+    const int nlst = sparse ? c->bstate->lu_n : 0;
+    if (sparse && nlst == 0)
+        return LBFGSX_OK;
+    const int grid = sparse ? std::max(1, std::min(64, (nlst + kBlock - 1) / kBlock)) : c->grid_for(c->n);
     const int has_w = (coef != nullptr && c->ncorr > 0) ? 1 : 0;
     CoefArg<T> cf;
     for (int k = 0; k < 80; k++)
@@ -1087,6 +1142,7 @@ int lbfgsx_b_cauchy_finish(lbfgsx_ctx* c, double t_cross, double tfinal, int cro
     double r[2];
     DISPATCH_T(c, {
         BVecs<T> bv = bvecs<T>(c);
+        c->bstate->lu_valid = false;  // the state bytes are rewritten
         hipLaunchKernelGGL((k_cauchy_finish<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, T(t_cross), T(tfinal), crossed_all,
                            c->n, c->ws, c->bstate->dout);
     });
@@ -1597,6 +1653,7 @@ int lbfgsx_b_sub_partition(lbfgsx_ctx* c, int64_t* nL, int64_t* nU, int64_t* nP)
     double r[3];
     DISPATCH_T(c, {
         BVecs<T> bv = bvecs<T>(c);
+        c->bstate->lu_valid = false;  // this partition keeps no index list
         hipLaunchKernelGGL((k_sub_partition<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, c->n, c->ws, c->bstate->dout);
     });
     LBFGSX_HIP(hipGetLastError());
@@ -1641,15 +1698,21 @@ int lbfgsx_b_sub_sweep_begin(lbfgsx_ctx* c, int first, int64_t* nL, int64_t* nU,
     DISPATCH_T(c, {
         BVecs<T> bv = bvecs<T>(c);
         hipLaunchKernelGGL((k_sub_sweep_begin<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, first ? 1 : 0, c->n, c->ws,
-                           c->bstate->dout);
+                           c->bstate->dout, c->bstate->lu_list, c->bstate->lu_cnt, c->bstate->lu_cap);
     });
     LBFGSX_HIP(hipGetLastError());
+    c->bstate->lu_valid = false;
     rc = fetch_doubles(c, 7, r);
     if (rc)
         return rc;
     *nL = int64_t(r[0]);
     *nU = int64_t(r[1]);
     *nP = int64_t(r[2]);
+    if (c->bstate->lu_use && *nL + *nU <= int64_t(c->bstate->lu_cap))
+    {
+        c->bstate->lu_n = int(*nL + *nU);
+        c->bstate->lu_valid = true;
+    }
     for (int k = 0; k < 4; k++)
         counts[k] = int64_t(r[3 + k]);
     return LBFGSX_OK;

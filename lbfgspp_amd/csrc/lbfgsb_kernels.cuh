@@ -298,6 +298,34 @@ __global__ void __launch_bounds__(kBlock) k_multidot(Cols<T, NC> cols, int ncols
             out[k] = double(T(acc[k].value()));
 }
 
+// The masked multi-dot over the rows of an index list (the L u U rows of the last BOXCQP partition): out[k], k < ncols,
+// and out[NC] = nnz as above.  10^1..10^3 rows: a handful of blocks instead of a scan of n state bytes.
+template <class T, int NC>
+__global__ void __launch_bounds__(kBlock) k_multidot_list(Cols<T, 32> cols, int ncols, BVecs<T> b, int vsel_id, int mask,
+                                                          const int* __restrict__ list, int nlist, RedWs ws,
+                                                          double* __restrict__ out)
+{
+    typedef typename AccOf<T>::type A;
+    A acc[NC + 1];
+    const int stride = int(gridDim.x) * kBlock;
+    for (int t = int(blockIdx.x) * kBlock + threadIdx.x; t < nlist; t += stride)
+    {
+        const int64_t i = list[t];
+        if (!(b.st[i] & mask))
+            continue;
+        const T v = vsel(b, vsel_id, i);
+        if (v != T(0))
+            acc[NC].add(T(1));
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+            if (k < ncols)
+                acc[k].add_prod(cols.p[k][i], v);
+    }
+    if (grid_reduce<NC + 1>(acc, ws) && threadIdx.x == 0)
+        for (int k = 0; k <= NC; k++)
+            out[k] = double(T(acc[k].value()));
+}
+
 // The same masked multi-dot for ALL 2c columns in one launch (K4): each thread takes one 16-byte vector of
 // consecutive rows per column, so 2c independent 16-byte loads are in flight per thread and v, the state byte and
 // the launch/reduction overhead are paid once instead of once per 8 columns.  out[0..ncols) dots, out[NC] nnz.
@@ -950,7 +978,7 @@ template <class T, int MODE>
 __global__ void __launch_bounds__(kBlock) k_wcombine(BVecs<T> b, const T* __restrict__ S, const T* __restrict__ Y,
                                                      int64_t ld, const int* __restrict__ phys, int ncorr,
                                                      CoefArg<T> coef, int has_w, int mask, int vsel_id,
-                                                     T theta, int64_t n)
+                                                     T theta, int64_t n, const int* __restrict__ list = nullptr, int nlist = 0)
 {
     __shared__ T sc[80];
     __shared__ int sp[40];
@@ -961,8 +989,11 @@ __global__ void __launch_bounds__(kBlock) k_wcombine(BVecs<T> b, const T* __rest
     __syncthreads();
     const T theta2 = theta * theta;
     const int64_t stride = int64_t(gridDim.x) * kBlock;
-    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
+    // list != nullptr: only the rows of the list (a superset of the rows of `mask`: the L u U rows of the last partition)
+    const int64_t cnt = list ? int64_t(nlist) : n;
+    for (int64_t t = int64_t(blockIdx.x) * kBlock + threadIdx.x; t < cnt; t += stride)
     {
+        const int64_t i = list ? int64_t(list[t]) : t;
         if (!(b.st[i] & mask))
             continue;
         T acc = T(0);
@@ -1142,8 +1173,12 @@ __global__ void __launch_bounds__(kBlock) k_sub_check(BVecs<T> b, int64_t n, Red
 // out = {#L, #U, #P, first ? #F outside (the in_bounds test of the first solve, :162) : 0, #P outside, #L with lambda < 0,
 //        #U with mu < 0}
 template <class T>
-__global__ void __launch_bounds__(kBlock) k_sub_sweep_begin(BVecs<T> b, int first, int64_t n, RedWs ws, double* __restrict__ out)
+__global__ void __launch_bounds__(kBlock) k_sub_sweep_begin(BVecs<T> b, int first, int64_t n, RedWs ws, double* __restrict__ out,
+                                                            int* __restrict__ lu_list, unsigned* __restrict__ lu_cnt, unsigned lu_cap)
 {
+    // lu_list: the rows this pass puts into L or U, in arrival order (the sets hold 10^1..10^3 of ~n/2 free rows in steady
+    // state; the operators that act on them -- apply_PtBQv's W_L'l / W_U'u, the multipliers -- then walk this list
+    // instead of scanning n state bytes).  The count is nL + nU, known to the host from the sums below.
     typedef typename AccOf<T>::type A;
     A acc[7];
     const int64_t stride = int64_t(gridDim.x) * kBlock;
@@ -1181,6 +1216,9 @@ __global__ void __launch_bounds__(kBlock) k_sub_sweep_begin(BVecs<T> b, int firs
             b.y[i] = li;
             mu = T(0);
             acc[0].add(T(1));
+            const unsigned pos = atomicAdd(lu_cnt, 1u);
+            if (pos < lu_cap)
+                lu_list[pos] = int(i);
         }
         else if ((yi > ui) || (yi == ui && mu >= T(0)))
         {
@@ -1188,6 +1226,9 @@ __global__ void __launch_bounds__(kBlock) k_sub_sweep_begin(BVecs<T> b, int firs
             b.y[i] = ui;
             lam = T(0);
             acc[1].add(T(1));
+            const unsigned pos = atomicAdd(lu_cnt, 1u);
+            if (pos < lu_cap)
+                lu_list[pos] = int(i);
         }
         else
         {
@@ -1202,8 +1243,12 @@ __global__ void __launch_bounds__(kBlock) k_sub_sweep_begin(BVecs<T> b, int firs
         b.st[i] = s;
     }
     if (grid_reduce<7>(acc, ws) && threadIdx.x == 0)
+    {
         for (int k = 0; k < 7; k++)
             out[k] = acc[k].value();
+        // every append has returned its position before its block took the ticket: re-arm the counter for the next pass
+        __hip_atomic_store(lu_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // misc element-wise statements of SubspaceMin.h, selected by `op`
