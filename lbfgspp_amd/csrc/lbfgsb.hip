@@ -38,6 +38,7 @@ struct lbfgsb_state
     unsigned* lu_cnt = nullptr;
     unsigned lu_cap = 0;
     int lu_n = 0;
+    int64_t lu_pred = int64_t(1) << 40;  // |L u U| of the previous partition: the list is only kept while the sets are small
     bool lu_valid = false;
     bool lu_use = true;                   // LBFGSX_LU_LIST=0: always scan
     double* g_host = nullptr;             // pinned landing zone of lbfgsx_b_cauchy_chunk
@@ -1695,10 +1696,13 @@ int lbfgsx_b_sub_sweep_begin(lbfgsx_ctx* c, int first, int64_t* nL, int64_t* nU,
         return rc;
     const int grid = c->grid_for(c->n);
     double r[7];
+    // the list pays while L u U is a few thousand rows (steady state: 10^1..10^3); in the early iterations the sets hold
+    // 10^5..10^6 rows and the dense scans are the better form -- decided from the size the previous partition found
+    const unsigned lu_cap_now = (c->bstate->lu_use && c->bstate->lu_pred <= 16384) ? c->bstate->lu_cap : 0u;
     DISPATCH_T(c, {
         BVecs<T> bv = bvecs<T>(c);
         hipLaunchKernelGGL((k_sub_sweep_begin<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, first ? 1 : 0, c->n, c->ws,
-                           c->bstate->dout, c->bstate->lu_list, c->bstate->lu_cnt, c->bstate->lu_cap);
+                           c->bstate->dout, c->bstate->lu_list, c->bstate->lu_cnt, lu_cap_now);
     });
     LBFGSX_HIP(hipGetLastError());
     c->bstate->lu_valid = false;
@@ -1708,7 +1712,8 @@ int lbfgsx_b_sub_sweep_begin(lbfgsx_ctx* c, int first, int64_t* nL, int64_t* nU,
     *nL = int64_t(r[0]);
     *nU = int64_t(r[1]);
     *nP = int64_t(r[2]);
-    if (c->bstate->lu_use && *nL + *nU <= int64_t(c->bstate->lu_cap))
+    c->bstate->lu_pred = *nL + *nU;
+    if (lu_cap_now && *nL + *nU <= int64_t(lu_cap_now))
     {
         c->bstate->lu_n = int(*nL + *nU);
         c->bstate->lu_valid = true;

@@ -1216,9 +1216,6 @@ __global__ void __launch_bounds__(kBlock) k_sub_sweep_begin(BVecs<T> b, int firs
             b.y[i] = li;
             mu = T(0);
             acc[0].add(T(1));
-            const unsigned pos = atomicAdd(lu_cnt, 1u);
-            if (pos < lu_cap)
-                lu_list[pos] = int(i);
         }
         else if ((yi > ui) || (yi == ui && mu >= T(0)))
         {
@@ -1226,9 +1223,6 @@ __global__ void __launch_bounds__(kBlock) k_sub_sweep_begin(BVecs<T> b, int firs
             b.y[i] = ui;
             lam = T(0);
             acc[1].add(T(1));
-            const unsigned pos = atomicAdd(lu_cnt, 1u);
-            if (pos < lu_cap)
-                lu_list[pos] = int(i);
         }
         else
         {
@@ -1241,6 +1235,23 @@ __global__ void __launch_bounds__(kBlock) k_sub_sweep_begin(BVecs<T> b, int firs
         b.lam[i] = lam;
         b.mu[i] = mu;
         b.st[i] = s;
+        if (lu_cap)
+        {
+            // one counter update per wavefront: the lanes that append are ranked by ballot
+            const bool app = (s & (ST_L | ST_U)) != 0;
+            const unsigned long long am = __ballot(app);
+            if (am)
+            {
+                const int leader = __ffsll((long long) am) - 1;
+                unsigned basep = 0;
+                if (int(threadIdx.x & 63) == leader)
+                    basep = atomicAdd(lu_cnt, unsigned(__popcll(am)));
+                basep = unsigned(__shfl(int(basep), leader, 64));
+                const unsigned pos = basep + unsigned(__popcll(am & ((1ull << (threadIdx.x & 63)) - 1ull)));
+                if (app && pos < lu_cap)
+                    lu_list[pos] = int(i);
+            }
+        }
     }
     if (grid_reduce<7>(acc, ws) && threadIdx.x == 0)
     {
