@@ -337,6 +337,18 @@ int lbfgsx_bat_fetch(lbfgsx_batch* c, const int* idx, double* out);
 int lbfgsx_bat_download_x(lbfgsx_batch* c, int p, int point, void* host);
 int lbfgsx_bat_sync(lbfgsx_batch* c);
 
+/* ---- the exchange step of the batched mode over RCCL --------------------------------------
+ * After a batch has been sharded over the GPUs of a node (lbfgsx_batch_minimize_lockstep_multi in lbfgsx_solver.h, or one
+ * process per GPU) the only data that crosses devices are the per-problem result records.  This call leaves ALL `count`
+ * records (rec_bytes each, in problem-id order, given in host memory as the solver returned them) on EVERY listed device:
+ * device r contributes its contiguous block, one grouped ncclAllGather over xGMI moves the blocks, dev_out[r] receives a
+ * device buffer on devices[r] (release it with lbfgsx_device_free).  One rank per GPU: a device listed twice is refused.
+ * RCCL is loaded with dlopen on first use.  No reference counterpart (the reference solves one problem per call). */
+int lbfgsx_rccl_allgather_records(const int* devices, int ndev, const void* records, int64_t count, int64_t rec_bytes,
+                                  void** dev_out);
+int lbfgsx_device_download(int device, const void* dev_ptr, int64_t bytes, void* host);
+void lbfgsx_device_free(int device, void* dev_ptr);
+
 /* ---- instrumentation ----------------------------------------------------------------------------------*/
 /* average duration (ms) of the two-loop step kernels since the last reset, measured with HIP events on
  * the context's stream; count = number of timed launches.  on = 2: one event pair per apply_Hv only (the step launches

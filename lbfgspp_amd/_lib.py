@@ -112,6 +112,9 @@ def load():
     sig(core, "lbfgsx_timing_read", i32, vp, pd, C.POINTER(i64), pd, C.POINTER(i64))
     sig(core, "lbfgsx_stream_probe", i32, vp, i32, pd, pd)
     sig(core, "lbfgsx_post_linesearch_spec", i32, vp, dbl, pd, pd, pd, pd)
+    sig(core, "lbfgsx_rccl_allgather_records", i32, C.POINTER(i32), i32, vp, i64, i64, C.POINTER(vp))
+    sig(core, "lbfgsx_device_download", i32, i32, vp, i64, vp)
+    sig(core, "lbfgsx_device_free", None, i32, vp)
     sig(core, "lbfgsx_spec_counts", i32, vp, C.POINTER(i64 * 3))
 
     sig(sol, "lbfgsx_solver_create", i32, C.POINTER(vp), i32, i32, i32, C.POINTER(Params), i32)

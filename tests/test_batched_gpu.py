@@ -123,3 +123,31 @@ def test_multi_device_batch_reports_bad_device_lists():
         B.solve_local_lockstep(par, 1024, 0, 4, devices=[])
     with pytest.raises((ValueError, RuntimeError)):
         B.solve_local_lockstep(par, 1024, 0, 4, devices=[0, 99])
+
+
+def test_rccl_allgather_of_the_result_records():
+    """lbfgsx_rccl_allgather_records: the one exchange step of the sharded batch natively over RCCL (ncclCommInitAll +
+    a grouped ncclAllGather, loaded with dlopen).  On the one-GPU box the communicator has a single rank: the records of
+    a real batch come back from the device unchanged and in problem-id order; on a box with more GPUs every device must
+    hold the same full array.  A device listed twice is refused (one rank per GPU)."""
+    import ctypes as C
+    import lbfgspp_amd as A
+    from lbfgspp_amd import batched as B
+    from lbfgspp_amd import _lib as L
+    core, _ = A.load()
+    par = A.LBFGSParam(m=4, epsilon=0.0, epsilon_rel=0.0, max_iterations=5)
+    recs = B.solve_local_lockstep(par, 2048, first=0, count=37, dtype=np.float32)
+    raw = np.ascontiguousarray(recs).view(np.uint8).reshape(37, -1)
+    ndev = core.lbfgsx_device_count()
+    devs = (C.c_int * ndev)(*range(ndev))
+    outp = (C.c_void_p * ndev)()
+    L.check(core.lbfgsx_rccl_allgather_records(devs, ndev, raw.ctypes.data_as(C.c_void_p), 37, raw.shape[1], outp))
+    for r in range(ndev):
+        back = np.zeros_like(raw)
+        L.check(core.lbfgsx_device_download(r, outp[r], raw.size, back.ctypes.data_as(C.c_void_p)))
+        core.lbfgsx_device_free(r, outp[r])
+        assert np.array_equal(back, raw)
+    dup = (C.c_int * 2)(0, 0)
+    out2 = (C.c_void_p * 2)()
+    with pytest.raises(ValueError, match="listed twice"):
+        L.check(core.lbfgsx_rccl_allgather_records(dup, 2, raw.ctypes.data_as(C.c_void_p), 37, raw.shape[1], out2))
