@@ -55,6 +55,7 @@ public:
         long long resets = 0;
         double gcp_build_s = 0, gcp_fetch_s = 0, gcp_total_s = 0, submin_s = 0, linesearch_s = 0, correction_s = 0;
         long long gcp_dev_crossings = 0, gcp_sort_fallbacks = 0, gcp_partial_sorts = 0;
+        long long submin_fused_sweeps = 0;
     };
 
 private:
@@ -166,6 +167,7 @@ private:
             m_stats.submin_calls++;
             m_stats.submin_sweeps += st.sweeps;
             m_stats.submin_unconverged += st.converged ? 0 : 1;
+            m_stats.submin_fused_sweeps += st.fused_sweeps;
             if (m_trace_phases)
                 std::fprintf(stderr, "[lbfgsb] it %d: ls %.3f ms (cum) corr %.3f gcp %.3f (build %.3f fetch %.3f) submin %.3f | crossings %lld dev %lld sweeps %lld\n",
                              k, m_stats.linesearch_s * 1e3, m_stats.correction_s * 1e3, m_stats.gcp_total_s * 1e3,

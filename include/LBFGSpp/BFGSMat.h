@@ -230,10 +230,29 @@ public:
     void gram_cache_reset() const { m_GF_valid = false; }
     void solve_PtBP(int mask, std::int64_t nP, int vsel, int prologue = LBFGSX_GP_NONE, const double* coef1 = nullptr,
                     const double* coef2 = nullptr, std::vector<Scalar>* Fy = nullptr, int fy_mask = 0,
-                    bool keep_as_F = false, int comp_mask = 0, std::int64_t ncomp = -1) const
+                    bool keep_as_F = false, int comp_mask = 0, std::int64_t ncomp = -1, std::int64_t* sweep = nullptr,
+                    bool sweep_first = false, bool* swept = nullptr) const
     {
+        // `sweep` (optional, 7 sums): let the pass that writes y also run the statements of the sweep that follows on the
+        // rows it writes (lbfgsx_b_solve_sweep); *swept tells whether it did
         auto finish = [&](const double* coef) {
             double raw[80];
+            if (sweep && swept && m_ncorr >= 1 &&
+                (sweep_first ? (mask == LBFGSX_ST_FREE && !Fy) : (mask == LBFGSX_ST_P && Fy && fy_mask == LBFGSX_ST_FREE)) &&
+                lbfgsx_b_solve_sweep(m_c, sweep_first ? 1 : 0, vsel, coef, double(m_theta), raw, sweep) == LBFGSX_OK)
+            {
+                *swept = true;
+                if (Fy)
+                {
+                    Fy->assign(size_t(2 * m_ncorr), Scalar(0));
+                    for (int j = 0; j < m_ncorr; j++)
+                    {
+                        (*Fy)[size_t(j)] = Scalar(raw[j]);
+                        (*Fy)[size_t(m_ncorr + j)] = Scalar(raw[m_ncorr + j]) * m_theta;
+                    }
+                }
+                return;
+            }
             if (Fy && m_ncorr >= 1 &&
                 lbfgsx_b_solve_wty(m_c, mask, vsel, coef, double(m_theta), fy_mask, raw) == LBFGSX_OK)
             {

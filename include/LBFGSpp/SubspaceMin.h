@@ -69,6 +69,7 @@ public:
     {
         int sweeps = 0;
         bool converged = true;
+        int fused_sweeps = 0;  // sweeps whose element-wise statements rode on the solve before them
     };
 
     // On entry xcp / state byte / vecc describe the generalized Cauchy point; on exit the device's drt holds
@@ -86,20 +87,35 @@ public:
         std::vector<double> lcoef;
         const bool has_lin = linear_coef(bfgs, gcp, lcoef);             // vecc (:144-156) ...
         bfgs.gram_cache_reset();
+        const char* fuse_env = std::getenv("LBFGSX_SUB_FUSE");
+        const bool fuse = !(fuse_env && fuse_env[0] == '0');
+        const bool early = fuse && bfgs.sweeps_expected();
+        std::int64_t s7[7] = {0, 0, 0, 0, 0, 0, 0};
+        bool swept = false;
         bfgs.solve_PtBP(LBFGSX_ST_FREE, nfree, LBFGSX_VS_NEG_CF, LBFGSX_GP_LINEAR,   // ... fused with
                         has_lin ? lcoef.data() : nullptr, nullptr, nullptr, 0,      // vecy = -inv(B[F,F]) c (:159)
-                        /*keep_as_F=*/true);
+                        /*keep_as_F=*/true, 0, -1, early ? s7 : nullptr, true, &swept);
         // The element-wise statements between two solves -- yfallback / lambda = mu = 0 (:170-172) before the first
         // sweep, the convergence counts (:271) before the others, then the partition (:194-219) and rhs = c_P (:232) --
         // are one pass (lbfgsx_b_sub_sweep_begin); LBFGSX_SUB_FUSE=0 runs them as the reference's separate statements.
         // When the previous call needed sweeps, the in_bounds test (:162-166) rides on that pass as well (the pass
         // moves no y when everything is in bounds, so taking it early is harmless).
-        const char* fuse_env = std::getenv("LBFGSX_SUB_FUSE");
-        const bool fuse = !(fuse_env && fuse_env[0] == '0');
-        const bool early = fuse && bfgs.sweeps_expected();
+        // With a sweep expected the pass even rides on the solve before it: the solve's kernel has the row's y in a
+        // register (lbfgsx_b_solve_sweep); the rows of L and U, which wait for their multipliers, follow through the index
+        // list of the last partition (lbfgsx_b_lu_sweep).
         std::int64_t cnt[4];
         std::int64_t nL = 0, nU = 0, nP = 0;
-        if (early)
+        auto take = [&](const std::int64_t* a, const std::int64_t* b2) {
+            nL = a[0] + (b2 ? b2[0] : 0);
+            nU = a[1] + (b2 ? b2[1] : 0);
+            nP = a[2] + (b2 ? b2[2] : 0);
+            for (int q = 0; q < 4; q++)
+                cnt[q] = a[3 + q] + (b2 ? b2[3 + q] : 0);
+        };
+        int nfused = swept ? 1 : 0;
+        if (swept)
+            take(s7, nullptr);
+        else if (early)
             detail::check(lbfgsx_b_sub_sweep_begin(c, 1, &nL, &nU, &nP, cnt));
         else
             detail::check(lbfgsx_b_sub_check(c, cnt));
@@ -121,6 +137,7 @@ public:
         int k;
         for (k = 0; k < maxit; k++)
         {
+            swept = false;
             if (!fuse)
             {
                 detail::check(lbfgsx_b_sub_partition(c, &nL, &nU, &nP)); // (:194-219)
@@ -138,7 +155,8 @@ public:
                 // the pass that writes y on P also delivers W_F'y for the multipliers below
                 bfgs.solve_PtBP(LBFGSX_ST_P, nP, LBFGSX_VS_NEG_RHS, (hasL || hasU) ? LBFGSX_GP_RHS : LBFGSX_GP_NONE,
                                 hasL ? cl.data() : nullptr, hasU ? cu.data() : nullptr, need_mult ? &Fy : nullptr,
-                                LBFGSX_ST_FREE, false, LBFGSX_ST_L | LBFGSX_ST_U, nL + nU);
+                                LBFGSX_ST_FREE, false, LBFGSX_ST_L | LBFGSX_ST_U, nL + nU,
+                                (fuse && need_mult && k + 1 < maxit) ? s7 : nullptr, false, &swept);
                 have_Fy = need_mult;
             }
             if (need_mult)                                              // multipliers (:247-268)
@@ -148,13 +166,25 @@ public:
                 std::vector<double> coef;
                 bfgs.Mv_scaled(Fy, coef);
                 const double* cf = (bfgs.num_corrections() < 1) ? nullptr : coef.data();
-                if (nL > 0)
-                    detail::check(lbfgsx_b_wcombine(c, LBFGSX_CB_LAMBDA, LBFGSX_ST_L, 0, cf, double(theta)));
-                if (nU > 0)
-                    detail::check(lbfgsx_b_wcombine(c, LBFGSX_CB_MU, LBFGSX_ST_U, 0, cf, double(theta)));
+                if (swept)
+                {
+                    std::int64_t t7[7];
+                    detail::check(lbfgsx_b_lu_sweep(c, cf, double(theta), t7));
+                    take(s7, t7);
+                    nfused++;
+                }
+                else
+                {
+                    if (nL > 0)
+                        detail::check(lbfgsx_b_wcombine(c, LBFGSX_CB_LAMBDA, LBFGSX_ST_L, 0, cf, double(theta)));
+                    if (nU > 0)
+                        detail::check(lbfgsx_b_wcombine(c, LBFGSX_CB_MU, LBFGSX_ST_U, 0, cf, double(theta)));
+                }
             }
             // convergence (:271); with another sweep allowed the same pass already prepares it
-            if (fuse && k + 1 < maxit)
+            if (swept)
+                ;
+            else if (fuse && k + 1 < maxit)
                 detail::check(lbfgsx_b_sub_sweep_begin(c, 0, &nL, &nU, &nP, cnt));
             else
                 detail::check(lbfgsx_b_sub_check(c, cnt));
@@ -165,6 +195,7 @@ public:
         {
             stats->sweeps = (k < maxit) ? k + 1 : maxit;
             stats->converged = (k < maxit);
+            stats->fused_sweeps = nfused;
         }
 
         if (k >= maxit)                                                 // fallback ladder (:276-296)

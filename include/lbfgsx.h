@@ -278,6 +278,23 @@ int lbfgsx_b_sub_check(lbfgsx_ctx* c, int64_t counts[4]);
  * the pass has moved no value of y), else the counts[1..3] of lbfgsx_b_sub_check on the current values; then
  * lbfgsx_b_sub_partition (:194-219) and LBFGSX_SO_RHS_INIT (:232).  Bit for bit the calls it replaces. */
 int lbfgsx_b_sub_sweep_begin(lbfgsx_ctx* c, int first, int64_t* nL, int64_t* nU, int64_t* nP, int64_t counts[4]);
+/* A BOXCQP solve and the statements of lbfgsx_b_sub_sweep_begin on the rows it writes, in ONE pass (the solve's row of W is
+ * in registers; the sweep's pass over n rows disappears).  Bit for bit lbfgsx_b_wcombine(LBFGSX_CB_SOLVE) /
+ * lbfgsx_b_solve_wty followed by lbfgsx_b_sub_sweep_begin.
+ *   first != 0: y = v/theta + (W coef)/theta^2 on every free row (SubspaceMin.h:159), then the first sweep's statements;
+ *               sums = {#L, #U, #P, #F outside, 0, 0, 0}; wty is not written.
+ *   first == 0: y on the rows of P (:243) and wty = W_F'y as lbfgsx_b_solve_wty, then the next sweep's statements on the
+ *               rows of P (their multipliers are zero); sums = {#L, #U, #P, 0, #P outside, 0, 0} over those rows.  The
+ *               rows of the old L and U follow in lbfgsx_b_lu_sweep, which needs the multipliers' coefficients the caller
+ *               derives from wty; the totals are the sums of the two calls.  Needs the index list of L u U that the
+ *               previous sweep kept (small sets).
+ * LBFGSX_E_INVALID when the fused form does not apply here (2c > 32, no list, LBFGSX_SWEEP_SOLVE_FUSE=0): nothing has
+ * been changed, run the separate calls. */
+int lbfgsx_b_solve_sweep(lbfgsx_ctx* c, int first, int vsel, const double* coef, double theta, double* wty, int64_t sums[7]);
+/* completes lbfgsx_b_solve_sweep(first == 0): lambda on the rows of L, mu on the rows of U (SubspaceMin.h:256-267, the two
+ * lbfgsx_b_wcombine calls) and the sweep's statements on those rows, walking the index list;
+ * sums = {#L, #U, #P, 0, 0, #L with lambda < 0, #U with mu < 0} over those rows */
+int lbfgsx_b_lu_sweep(lbfgsx_ctx* c, const double* coef, double theta, int64_t sums[7]);
 /* element-wise statements of SubspaceMin.h selected by LBFGSX_SO_* */
 int lbfgsx_b_sub_op(lbfgsx_ctx* c, int op);
 /* copy the per-coordinate state byte (LBFGSX_ST_* bits) to the host: n bytes */

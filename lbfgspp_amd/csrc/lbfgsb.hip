@@ -34,13 +34,19 @@ struct lbfgsb_state
     unsigned long long* mslot = nullptr;  // (unused since the extrema ride in the grid reductions)
     // index list of the rows the last BOXCQP partition put into L or U (k_sub_sweep_begin); lu_valid: it describes the
     // current state bytes (any other writer of ST_L / ST_U clears it)
-    int* lu_list = nullptr;
+    int* lu_list = nullptr;               // two buffers of lu_cap entries: the current list and the one a fused sweep builds
+    int lu_cur = 0;
+    int* lu_ptr() const { return lu_list + size_t(lu_cur) * size_t(lu_cap); }
+    int* lu_other() const { return lu_list + size_t(1 - lu_cur) * size_t(lu_cap); }
+    bool lu_pending = false;              // lbfgsx_b_solve_sweep(first = 0) ran; lbfgsx_b_lu_sweep completes the sweep
+    int64_t lu_pending_n = 0;             //   rows that pass appended
     unsigned* lu_cnt = nullptr;
     unsigned lu_cap = 0;
     int lu_n = 0;
     int64_t lu_pred = int64_t(1) << 40;  // |L u U| of the previous partition: the list is only kept while the sets are small
     bool lu_valid = false;
     bool lu_use = true;                   // LBFGSX_LU_LIST=0: always scan
+    bool sweep_fuse = true;               // LBFGSX_SWEEP_SOLVE_FUSE=0: the solve and the sweep's statements stay separate passes
     double* g_host = nullptr;             // pinned landing zone of lbfgsx_b_cauchy_chunk
     size_t g_host_cap = 0;
     // chunk staging for the sequential GCP scan
@@ -204,11 +210,13 @@ int bounded_alloc(lbfgsx_ctx* c)
     LBFGSX_HIP(hipMalloc(&b->coef_dev, sizeof(double) * 80));
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->mslot), sizeof(unsigned long long) * 2));
     b->lu_cap = unsigned(std::min<int64_t>(c->n, int64_t(1) << 20));
-    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->lu_list), sizeof(int) * size_t(b->lu_cap)));
+    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->lu_list), sizeof(int) * 2 * size_t(b->lu_cap)));
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->lu_cnt), sizeof(unsigned)));
     LBFGSX_HIP(hipMemset(b->lu_cnt, 0, sizeof(unsigned)));
     if (const char* e = getenv("LBFGSX_LU_LIST"))
         b->lu_use = atoi(e) != 0;
+    if (const char* e = getenv("LBFGSX_SWEEP_SOLVE_FUSE"))
+        b->sweep_fuse = atoi(e) != 0;
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->colmax), sizeof(unsigned long long) * 2 * size_t(c->m + 1)));
     LBFGSX_HIP(hipMemset(b->colmax, 0, sizeof(unsigned long long) * 2 * size_t(c->m + 1)));
     b->colmax_ok.assign(size_t(c->m + 1), 0);
@@ -358,7 +366,7 @@ static int wtv_t(lbfgsx_ctx* c, int vsel_id, const T* vcol, int mask, double* ou
     do                                                                                                                      \
     {                                                                                                                       \
         hipLaunchKernelGGL((k_multidot_list<T, N>), dim3(lgrid), dim3(kBlock), 0, c->stream, cl, total, b, vsel_id, mask,   \
-                           c->bstate->lu_list, nl, c->ws, c->bstate->dout);                                                 \
+                           c->bstate->lu_ptr(), nl, c->ws, c->bstate->dout);                                                \
         nc_used = N;                                                                                                        \
     } while (0)
         if (total <= 8) ML_LAUNCH(8);
@@ -472,7 +480,7 @@ static int wcombine_t(lbfgsx_ctx* c, int mode, int mask, int vsel_id, const doub
 {
     // masks inside L u U: walk the index list of the last partition instead of all n rows
     const bool sparse = c->bstate->lu_valid && mask != 0 && (mask & ~(ST_L | ST_U)) == 0;
-    const int* lst = sparse ? c->bstate->lu_list : nullptr;
+    const int* lst = sparse ? c->bstate->lu_ptr() : nullptr;
     const int nlst = sparse ? c->bstate->lu_n : 0;
     if (sparse && nlst == 0)
         return LBFGSX_OK;
@@ -1702,7 +1710,7 @@ int lbfgsx_b_sub_sweep_begin(lbfgsx_ctx* c, int first, int64_t* nL, int64_t* nU,
     DISPATCH_T(c, {
         BVecs<T> bv = bvecs<T>(c);
         hipLaunchKernelGGL((k_sub_sweep_begin<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, first ? 1 : 0, c->n, c->ws,
-                           c->bstate->dout, c->bstate->lu_list, c->bstate->lu_cnt, lu_cap_now);
+                           c->bstate->dout, c->bstate->lu_ptr(), c->bstate->lu_cnt, lu_cap_now);
     });
     LBFGSX_HIP(hipGetLastError());
     c->bstate->lu_valid = false;
@@ -1720,6 +1728,150 @@ int lbfgsx_b_sub_sweep_begin(lbfgsx_ctx* c, int first, int64_t* nL, int64_t* nU,
     }
     for (int k = 0; k < 4; k++)
         counts[k] = int64_t(r[3 + k]);
+    return LBFGSX_OK;
+}
+
+}  // extern "C"
+template <class T, int NC>
+static int solve_sweep_t(lbfgsx_ctx* c, int first, int vsel_id, const double* coef, double theta, double* wty, double* sums,
+                         unsigned lu_cap_now, int* lu_dst)
+{
+    const int total = 2 * c->ncorr;
+    int which[32];
+    for (int k = 0; k < total; k++)
+        which[k] = k;
+    Cols<T, 32> cl = col_list<T, 32>(c, which, total);
+    CoefArg<T> cf;
+    for (int k = 0; k < 80; k++)
+        cf.c[k] = (coef && k < total) ? T(coef[k]) : T(0);
+    const int grid = std::min(c->grid_for(c->n), c->bstate->dots_grid);
+    if (first)
+        hipLaunchKernelGGL((k_solve_sweep<T, NC, 1>), dim3(grid), dim3(kBlock), 0, c->stream, cl, total, bvecs<T>(c), vsel_id, cf,
+                           coef ? 1 : 0, T(theta), c->n, c->ws, c->bstate->dout, lu_dst, c->bstate->lu_cnt, lu_cap_now);
+    else
+        hipLaunchKernelGGL((k_solve_sweep<T, NC, 0>), dim3(grid), dim3(kBlock), 0, c->stream, cl, total, bvecs<T>(c), vsel_id, cf,
+                           coef ? 1 : 0, T(theta), c->n, c->ws, c->bstate->dout, lu_dst, c->bstate->lu_cnt, lu_cap_now);
+    LBFGSX_HIP(hipGetLastError());
+    const int nd = first ? 0 : NC;
+    double r[NC + 7];
+    int rc = fetch_doubles(c, nd + 7, r);
+    if (rc)
+        return rc;
+    if (!first)
+        for (int k = 0; k < total; k++)
+            wty[k] = r[k];
+    for (int k = 0; k < 7; k++)
+        sums[k] = r[nd + k];
+    return LBFGSX_OK;
+}
+extern "C" {
+
+int lbfgsx_b_solve_sweep(lbfgsx_ctx* c, int first, int vsel_id, const double* coef, double theta, double* wty, int64_t sums[7])
+{
+    lbfgsx::DeviceGuard dev_guard_(c->device);
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    lbfgsb_state* b = c->bstate;
+    const int total = 2 * c->ncorr;
+    if (total < 1 || total > 32 || b->multidot_chunked || !b->sweep_fuse)
+    {
+        set_error("lbfgsx_b_solve_sweep: not available here (needs 1 <= 2*ncorr <= 32); run the separate passes");
+        return LBFGSX_E_INVALID;
+    }
+    unsigned cap;
+    int* dst;
+    if (first)
+    {
+        cap = (b->lu_use && b->lu_pred <= 16384) ? b->lu_cap : 0u;
+        dst = b->lu_ptr();
+    }
+    else
+    {
+        // the rows of the old L and U are reached through the list of the partition that made them
+        if (!b->lu_valid || b->lu_n < 1)
+        {
+            set_error("lbfgsx_b_solve_sweep: no index list of L u U; run the separate passes");
+            return LBFGSX_E_INVALID;
+        }
+        cap = b->lu_cap;
+        dst = b->lu_other();
+    }
+    double r[7];
+    DISPATCH_T(c, {
+        if (total <= 8) rc = solve_sweep_t<T, 8>(c, first, vsel_id, coef, theta, wty, r, cap, dst);
+        else if (total <= 16) rc = solve_sweep_t<T, 16>(c, first, vsel_id, coef, theta, wty, r, cap, dst);
+        else if (total <= 24) rc = solve_sweep_t<T, 24>(c, first, vsel_id, coef, theta, wty, r, cap, dst);
+        else rc = solve_sweep_t<T, 32>(c, first, vsel_id, coef, theta, wty, r, cap, dst);
+    });
+    if (rc)
+    {
+        b->lu_valid = false;
+        return rc;
+    }
+    for (int k = 0; k < 7; k++)
+        sums[k] = int64_t(r[k]);
+    if (first)
+    {
+        b->lu_valid = false;
+        b->lu_pred = sums[0] + sums[1];
+        if (cap && sums[0] + sums[1] <= int64_t(cap))
+        {
+            b->lu_n = int(sums[0] + sums[1]);
+            b->lu_valid = true;
+        }
+    }
+    else
+    {
+        b->lu_pending = true;
+        b->lu_pending_n = sums[0] + sums[1];
+    }
+    return LBFGSX_OK;
+}
+
+int lbfgsx_b_lu_sweep(lbfgsx_ctx* c, const double* coef, double theta, int64_t sums[7])
+{
+    lbfgsx::DeviceGuard dev_guard_(c->device);
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    lbfgsb_state* b = c->bstate;
+    if (!b->lu_pending || !b->lu_valid)
+    {
+        set_error("lbfgsx_b_lu_sweep: completes lbfgsx_b_solve_sweep(first = 0)");
+        return LBFGSX_E_INVALID;
+    }
+    b->lu_pending = false;
+    rc = upload_phys(c);
+    if (rc)
+        return rc;
+    const int nl = b->lu_n;
+    const int grid = std::max(1, std::min(64, (nl + kBlock - 1) / kBlock));
+    const int has_w = (coef != nullptr && c->ncorr > 0) ? 1 : 0;
+    double r[7];
+    DISPATCH_T(c, {
+        CoefArg<T> cf;
+        for (int k = 0; k < 80; k++)
+            cf.c[k] = (has_w && k < 2 * c->ncorr) ? T(coef[k]) : T(0);
+        hipLaunchKernelGGL((k_lu_sweep<T>), dim3(grid), dim3(kBlock), 0, c->stream, bvecs<T>(c), P<T>(c->S), P<T>(c->Y), c->ld,
+                           b->phys_dev, c->ncorr, cf, has_w, T(theta), b->lu_ptr(), nl, c->ws, b->dout, b->lu_other(), b->lu_cnt,
+                           b->lu_cap);
+    });
+    LBFGSX_HIP(hipGetLastError());
+    b->lu_valid = false;
+    rc = fetch_doubles(c, 7, r);
+    if (rc)
+        return rc;
+    for (int k = 0; k < 7; k++)
+        sums[k] = int64_t(r[k]);
+    const int64_t total = b->lu_pending_n + sums[0] + sums[1];
+    b->lu_pred = total;
+    b->lu_cur = 1 - b->lu_cur;
+    if (total <= int64_t(b->lu_cap))
+    {
+        b->lu_n = int(total);
+        b->lu_valid = true;
+    }
     return LBFGSX_OK;
 }
 

@@ -1172,6 +1172,86 @@ __global__ void __launch_bounds__(kBlock) k_sub_check(BVecs<T> b, int64_t n, Red
 // y (a converged sweep has every y inside its box and every multiplier non-negative), so running it is harmless.
 // out = {#L, #U, #P, first ? #F outside (the in_bounds test of the first solve, :162) : 0, #P outside, #L with lambda < 0,
 //        #U with mu < 0}
+// The statements of one free row in the pass above, shared by the three kernels that run them: `lam`, `mu` are the
+// row's multipliers as the reference holds them at this point.  Returns the new state byte; the 7 counts are per-thread
+// integers (a thread sees n / threads rows), turned into the kernel's sums by sweep_counts() after the loop.
+template <class T>
+__device__ inline unsigned char sweep_row(const BVecs<T>& b, int64_t i, unsigned char s, T yi, T lam, T mu, bool first,
+                                          bool store_mult, unsigned* cnt)
+{
+    const T li = b.lb[i] - b.x0[i], ui = b.ub[i] - b.x0[i];
+    if (first)
+    {
+        cnt[3] += (yi < li || yi > ui) ? 1u : 0u;
+        b.yfb[i] = yi;
+    }
+    else
+    {
+        cnt[4] += ((s & ST_P) && (yi < li || yi > ui)) ? 1u : 0u;
+        cnt[5] += ((s & ST_L) && lam < T(0)) ? 1u : 0u;
+        cnt[6] += ((s & ST_U) && mu < T(0)) ? 1u : 0u;
+    }
+    s &= (unsigned char) ~(ST_L | ST_U | ST_P);
+    if ((yi < li) || (yi == li && lam >= T(0)))
+    {
+        s |= ST_L;
+        b.y[i] = li;
+        mu = T(0);
+        cnt[0]++;
+    }
+    else if ((yi > ui) || (yi == ui && mu >= T(0)))
+    {
+        s |= ST_U;
+        b.y[i] = ui;
+        lam = T(0);
+        cnt[1]++;
+    }
+    else
+    {
+        s |= ST_P;
+        lam = T(0);
+        mu = T(0);
+        b.rhs[i] = b.cF[i];
+        cnt[2]++;
+    }
+    if (store_mult)
+    {
+        b.lam[i] = lam;
+        b.mu[i] = mu;
+    }
+    b.st[i] = s;
+    return s;
+}
+template <class T, class A>
+__device__ inline void sweep_counts(const unsigned* cnt, A* acc)
+{
+#pragma unroll
+    for (int k = 0; k < 7; k++)
+        for (unsigned c = cnt[k]; c;)  // exact in T whatever the thread's share of the rows
+        {
+            const unsigned q = c < (1u << 20) ? c : (1u << 20);
+            acc[k].add(T(q));
+            c -= q;
+        }
+}
+
+// append row i to the index list when `app`; one counter update per wavefront, the lanes that append ranked by ballot
+__device__ inline void lu_append(bool app, int64_t i, int* __restrict__ lu_list, unsigned* __restrict__ lu_cnt, unsigned lu_cap)
+{
+    const unsigned long long am = __ballot(app);
+    if (am)
+    {
+        const int leader = __ffsll((long long) am) - 1;
+        unsigned basep = 0;
+        if (int(threadIdx.x & 63) == leader)
+            basep = atomicAdd(lu_cnt, unsigned(__popcll(am)));
+        basep = unsigned(__shfl(int(basep), leader, 64));
+        const unsigned pos = basep + unsigned(__popcll(am & ((1ull << (threadIdx.x & 63)) - 1ull)));
+        if (app && pos < lu_cap)
+            lu_list[pos] = int(i);
+    }
+}
+
 template <class T>
 __global__ void __launch_bounds__(kBlock) k_sub_sweep_begin(BVecs<T> b, int first, int64_t n, RedWs ws, double* __restrict__ out,
                                                             int* __restrict__ lu_list, unsigned* __restrict__ lu_cnt, unsigned lu_cap)
@@ -1180,84 +1260,160 @@ __global__ void __launch_bounds__(kBlock) k_sub_sweep_begin(BVecs<T> b, int firs
     // state; the operators that act on them -- apply_PtBQv's W_L'l / W_U'u, the multipliers -- then walk this list
     // instead of scanning n state bytes).  The count is nL + nU, known to the host from the sums below.
     typedef typename AccOf<T>::type A;
-    A acc[7];
+    unsigned cnt[7] = {0, 0, 0, 0, 0, 0, 0};
     const int64_t stride = int64_t(gridDim.x) * kBlock;
     for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
     {
         unsigned char s = b.st[i];
         if (!(s & ST_FREE))
             continue;
-        const T li = b.lb[i] - b.x0[i], ui = b.ub[i] - b.x0[i];
         const T yi = b.y[i];
-        T lam, mu;
-        if (first)
-        {
-            if (yi < li || yi > ui)
-                acc[3].add(T(1));
-            b.yfb[i] = yi;
-            lam = T(0);
-            mu = T(0);
-        }
-        else
-        {
-            lam = b.lam[i];
-            mu = b.mu[i];
-            if ((s & ST_P) && (yi < li || yi > ui))
-                acc[4].add(T(1));
-            if ((s & ST_L) && lam < T(0))
-                acc[5].add(T(1));
-            if ((s & ST_U) && mu < T(0))
-                acc[6].add(T(1));
-        }
-        s &= (unsigned char) ~(ST_L | ST_U | ST_P);
-        if ((yi < li) || (yi == li && lam >= T(0)))
-        {
-            s |= ST_L;
-            b.y[i] = li;
-            mu = T(0);
-            acc[0].add(T(1));
-        }
-        else if ((yi > ui) || (yi == ui && mu >= T(0)))
-        {
-            s |= ST_U;
-            b.y[i] = ui;
-            lam = T(0);
-            acc[1].add(T(1));
-        }
-        else
-        {
-            s |= ST_P;
-            lam = T(0);
-            mu = T(0);
-            b.rhs[i] = b.cF[i];
-            acc[2].add(T(1));
-        }
-        b.lam[i] = lam;
-        b.mu[i] = mu;
-        b.st[i] = s;
+        const T lam = first ? T(0) : b.lam[i], mu = first ? T(0) : b.mu[i];
+        s = sweep_row<T>(b, i, s, yi, lam, mu, first != 0, true, cnt);
         if (lu_cap)
-        {
-            // one counter update per wavefront: the lanes that append are ranked by ballot
-            const bool app = (s & (ST_L | ST_U)) != 0;
-            const unsigned long long am = __ballot(app);
-            if (am)
-            {
-                const int leader = __ffsll((long long) am) - 1;
-                unsigned basep = 0;
-                if (int(threadIdx.x & 63) == leader)
-                    basep = atomicAdd(lu_cnt, unsigned(__popcll(am)));
-                basep = unsigned(__shfl(int(basep), leader, 64));
-                const unsigned pos = basep + unsigned(__popcll(am & ((1ull << (threadIdx.x & 63)) - 1ull)));
-                if (app && pos < lu_cap)
-                    lu_list[pos] = int(i);
-            }
-        }
+            lu_append((s & (ST_L | ST_U)) != 0, i, lu_list, lu_cnt, lu_cap);
     }
+    A acc[7];
+    sweep_counts<T, A>(cnt, acc);
     if (grid_reduce<7>(acc, ws) && threadIdx.x == 0)
     {
         for (int k = 0; k < 7; k++)
             out[k] = acc[k].value();
         // every append has returned its position before its block took the ticket: re-arm the counter for the next pass
+        __hip_atomic_store(lu_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// The solve that precedes a sweep and the sweep's statements on the rows that solve writes, in one pass
+// (k_solve_dots / k_wcombine<CB_SOLVE> followed by k_sub_sweep_begin):
+//   FIRST = 1: y = -inv(B[F,F]) c on every free row (SubspaceMin.h:159), then the first sweep's statements on it; no dots.
+//   FIRST = 0: y on the P rows (:243), the dots W_F'y over all free rows with the y the reference has at that point (the
+//              un-clamped y of the P rows), then the next sweep's statements on the P rows, whose multipliers are zero.
+//              The rows of the old L and U need the multipliers this pass's dots lead to: k_lu_sweep, over the index
+//              list, right after.
+// out = {dots[ND], the 7 sums of k_sub_sweep_begin over the rows handled here}
+template <class T, int NC, int FIRST>
+__global__ void __launch_bounds__(kBlock, NC <= 24 ? 2 : 1) k_solve_sweep(Cols<T, 32> cols, int ncols, BVecs<T> b, int vsel_id, CoefArg<T> coef,
+                                                        int has_w, T theta, int64_t n, RedWs ws, double* __restrict__ out,
+                                                        int* __restrict__ lu_list, unsigned* __restrict__ lu_cnt, unsigned lu_cap)
+{
+    typedef typename AccOf<T>::type A;
+    constexpr int ND = FIRST ? 0 : NC;
+    __shared__ T sc[80];
+    if (threadIdx.x < 80)
+        sc[threadIdx.x] = coef.c[threadIdx.x];
+    __syncthreads();
+    const T theta2 = theta * theta;
+    A dots[ND ? ND : 1];
+    unsigned cnt[7] = {0, 0, 0, 0, 0, 0, 0};
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
+    {
+        unsigned char st = b.st[i];
+        if (!(st & ST_FREE))
+            continue;
+        T w[NC];
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+            if (k < ncols)
+                w[k] = cols.p[k][i];
+        const bool solve = FIRST || (st & ST_P);
+        T yi;
+        if (solve)
+        {
+            T a = T(0);
+            if (has_w)
+            {
+#pragma unroll
+                for (int k = 0; k < NC; k++)
+                    if (k < ncols)
+                        a = a + w[k] * sc[k];
+            }
+            const T v = vsel(b, vsel_id, i);
+            yi = has_w ? (v / theta + a / theta2) : (v / theta);
+            b.y[i] = yi;
+        }
+        else
+            yi = b.y[i];
+        if (!FIRST)
+        {
+#pragma unroll
+            for (int k = 0; k < NC; k++)
+                if (k < ncols)
+                    dots[k].add_prod(w[k], yi);
+        }
+        bool app = false;
+        if (solve)
+        {
+            // a P row's multipliers are zero (the sweep that made it P stored them); the first sweep sets them
+            st = sweep_row<T>(b, i, st, yi, T(0), T(0), FIRST != 0, FIRST != 0, cnt);
+            app = (st & (ST_L | ST_U)) != 0;
+        }
+        if (lu_cap)
+            lu_append(app, i, lu_list, lu_cnt, lu_cap);
+    }
+    A acc[ND + 7];
+#pragma unroll
+    for (int k = 0; k < ND; k++)
+        acc[k] = dots[k];
+    sweep_counts<T, A>(cnt, acc + ND);
+    if (grid_reduce<ND + 7>(acc, ws) && threadIdx.x == 0)
+    {
+        for (int k = 0; k < ND; k++)
+            out[k] = double(T(acc[k].value()));
+        for (int k = 0; k < 7; k++)
+            out[ND + k] = acc[ND + k].value();
+        if (FIRST)
+            __hip_atomic_store(lu_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// The multipliers of the rows of L and U (k_wcombine<CB_LAMBDA>, <CB_MU>) and the next sweep's statements on those rows,
+// over the index list of the partition that made them L or U.  Completes k_solve_sweep<FIRST = 0>; appends to the same
+// new list and re-arms its counter.
+template <class T>
+__global__ void __launch_bounds__(kBlock) k_lu_sweep(BVecs<T> b, const T* __restrict__ S, const T* __restrict__ Y, int64_t ld,
+                                                     const int* __restrict__ phys, int ncorr, CoefArg<T> coef, int has_w, T theta,
+                                                     const int* __restrict__ list, int nlist, RedWs ws, double* __restrict__ out,
+                                                     int* __restrict__ lu_list, unsigned* __restrict__ lu_cnt, unsigned lu_cap)
+{
+    typedef typename AccOf<T>::type A;
+    __shared__ T sc[80];
+    __shared__ int sp[40];
+    if (threadIdx.x < 2 * ncorr)
+        sc[threadIdx.x] = coef.c[threadIdx.x];
+    if (threadIdx.x < ncorr)
+        sp[threadIdx.x] = phys[threadIdx.x];
+    __syncthreads();
+    unsigned cnt[7] = {0, 0, 0, 0, 0, 0, 0};
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t t = int64_t(blockIdx.x) * kBlock + threadIdx.x; t < int64_t(nlist); t += stride)
+    {
+        const int64_t i = int64_t(list[t]);
+        unsigned char s = b.st[i];
+        if (!(s & (ST_L | ST_U)))
+            continue;
+        T a = T(0);
+        if (has_w)
+            for (int j = 0; j < ncorr; j++)
+                a = a + (sc[j] * Y[int64_t(sp[j]) * ld + i] + sc[ncorr + j] * S[int64_t(sp[j]) * ld + i]);
+        const T yi = b.y[i];
+        const T r = (T(-1) * a) + (b.cF[i] + theta * yi);
+        T lam = b.lam[i], mu = b.mu[i];
+        if (s & ST_L)
+            lam = r;
+        if (s & ST_U)
+            mu = -r;
+        s = sweep_row<T>(b, i, s, yi, lam, mu, false, true, cnt);
+        if (lu_cap)
+            lu_append((s & (ST_L | ST_U)) != 0, i, lu_list, lu_cnt, lu_cap);
+    }
+    A acc[7];
+    sweep_counts<T, A>(cnt, acc);
+    if (grid_reduce<7>(acc, ws) && threadIdx.x == 0)
+    {
+        for (int k = 0; k < 7; k++)
+            out[k] = acc[k].value();
         __hip_atomic_store(lu_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }

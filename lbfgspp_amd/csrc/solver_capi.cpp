@@ -227,6 +227,7 @@ struct LbfgsbImpl : lbfgsx_solver
         stats2[3] = (long long) (st.submin_s * 1e6);
         stats2[4] = (long long) (st.linesearch_s * 1e6);
         stats2[5] = (long long) (st.correction_s * 1e6);
+        stats2[6] = st.submin_fused_sweeps;
     }
 };
 

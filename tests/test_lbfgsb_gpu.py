@@ -327,6 +327,37 @@ def test_fused_subspace_passes_are_bit_identical_to_the_unfused_sequence(A, monk
     assert f[6] == u[6] and (max_submin >= 10 or f[6] > 0)
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("m,max_submin", [(8, 10), (10, 3), (3, 10), (14, 10)])
+def test_sweep_statements_riding_on_the_solve_change_no_bit(A, monkeypatch, m, max_submin, dtype):
+    """lbfgsx_b_solve_sweep / lbfgsx_b_lu_sweep (the sweep's element-wise statements inside the solve's pass, the rows of
+    L and U through the index list) against the separate passes (LBFGSX_SWEEP_SOLVE_FUSE=0): same statements on the same
+    values, so the same trajectory bit for bit and the same sweep counts; the fused form must actually have run."""
+    n, iters = 40003, 20
+    dt = O.F64 if dtype == "f64" else O.F32
+    npdt = O.NPDT[dt]
+    a, b = O.quad_problem(n, 30.0, 5, dt)
+    res = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("LBFGSX_SWEEP_SOLVE_FUSE", fuse)
+        s = A.LBFGSBSolver(A.LBFGSBParam(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters, max_submin=max_submin),
+                           dtype=npdt)
+        tr = A.TraceBuffer(n, cap=256, stride=13)
+        x = np.zeros(n, dtype=npdt)
+        try:
+            niter, fx = s.minimize(A.DiagQuadratic(a, b), x, (-0.7 * np.ones(n)).astype(npdt), (0.9 * np.ones(n)).astype(npdt),
+                                   trace=tr)
+        except RuntimeError:  # f32 may stop on a line-search failure: both forms must then stop at the same place
+            niter, fx = -1, float("nan")
+        st = s.stats()
+        res[fuse] = (niter, s.last.nfev, x.copy(), tr.xs[:tr.count].copy(), st["submin_sweeps"], st["submin_unconverged"],
+                     st["submin_fused_sweeps"])
+    f, u = res["1"], res["0"]
+    assert f[:2] == u[:2] and f[4:6] == u[4:6] and f[4] > 0
+    assert np.array_equal(f[2], u[2]) and np.array_equal(f[3], u[3])
+    assert u[6] == 0 and f[6] > 0
+
+
 @pytest.mark.parametrize("m", [3, 5, 8, 10, 12])
 def test_deferred_correction_dots_change_no_bit(A, monkeypatch, m):
     """add_correction's S's_new / s_new.y_j dots taken by the W'd pass of the following Cauchy search
