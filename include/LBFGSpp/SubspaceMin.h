@@ -92,6 +92,8 @@ public:
         const bool early = fuse && bfgs.sweeps_expected();
         std::int64_t s7[7] = {0, 0, 0, 0, 0, 0, 0};
         bool swept = false;
+        if (early)  // sweeps ahead: the first solve's Gram pass leaves a compact copy of the free rows for their passes
+            detail::check(lbfgsx_b_set_compaction(c, 1));
         bfgs.solve_PtBP(LBFGSX_ST_FREE, nfree, LBFGSX_VS_NEG_CF, LBFGSX_GP_LINEAR,   // ... fused with
                         has_lin ? lcoef.data() : nullptr, nullptr, nullptr, 0,      // vecy = -inv(B[F,F]) c (:159)
                         /*keep_as_F=*/true, 0, -1, early ? s7 : nullptr, true, &swept);

@@ -278,6 +278,13 @@ int lbfgsx_b_sub_check(lbfgsx_ctx* c, int64_t counts[4]);
  * the pass has moved no value of y), else the counts[1..3] of lbfgsx_b_sub_check on the current values; then
  * lbfgsx_b_sub_partition (:194-219) and LBFGSX_SO_RHS_INIT (:232).  Bit for bit the calls it replaces. */
 int lbfgsx_b_sub_sweep_begin(lbfgsx_ctx* c, int first, int64_t* nL, int64_t* nU, int64_t* nP, int64_t counts[4]);
+/* Hint for the subspace minimisation that lbfgsx_b_sub_begin has just opened (which clears it): BOXCQP sweeps are expected,
+ * so the full Gram pass of the first solve (lbfgsx_b_gram_fused_dd over LBFGSX_ST_FREE) may also write a compact copy of the
+ * free rows of [Y S], and the passes of the sweeps (lbfgsx_b_wtv_prologue, lbfgsx_b_solve_sweep, the complement Grams) then
+ * read that copy instead of fetching all n rows through the state-byte mask.  Same sums (double-double), same bits; only
+ * taken when the free set leaves out at least an eighth of the rows.  LBFGSX_COMPACT_FREE=0 disables it.  The copy is
+ * valid until the next lbfgsx_b_sub_begin / lbfgsx_b_cauchy_finish; the history must not change in between. */
+int lbfgsx_b_set_compaction(lbfgsx_ctx* c, int enable);
 /* A BOXCQP solve and the statements of lbfgsx_b_sub_sweep_begin on the rows it writes, in ONE pass (the solve's row of W is
  * in registers; the sweep's pass over n rows disappears).  Bit for bit lbfgsx_b_wcombine(LBFGSX_CB_SOLVE) /
  * lbfgsx_b_solve_wty followed by lbfgsx_b_sub_sweep_begin.

@@ -47,6 +47,20 @@ struct lbfgsb_state
     bool lu_valid = false;
     bool lu_use = true;                   // LBFGSX_LU_LIST=0: always scan
     bool sweep_fuse = true;               // LBFGSX_SWEEP_SOLVE_FUSE=0: the solve and the sweep's statements stay separate passes
+    // compact copy of the free rows of [Y S] (GramRows, lbfgsb_kernels.cuh): written by the full Gram pass of the first
+    // BOXCQP solve when the caller expects sweeps (lbfgsx_b_set_compaction), read by the passes of the sweeps
+    void* wf = nullptr;                   // T[32][wf_ld]
+    int64_t wf_ld = 0;
+    int* wf_idx = nullptr;                // [n]
+    int* wf_cnt = nullptr;                // [n / 64 + 2] free rows per batch, then their exclusive prefix
+    int* wf_base = nullptr;
+    void* wf_tmp = nullptr;
+    size_t wf_tmp_bytes = 0;
+    bool wf_use = true;                   // LBFGSX_COMPACT_FREE=0: never
+    bool wf_on = false;                   // the caller's hint for the current subspace minimisation
+    bool wf_valid = false;
+    int64_t wf_n = 0;                     // rows in the copy
+    int64_t nfree_last = 0;               // |F| of the last lbfgsx_b_cauchy_finish
     double* g_host = nullptr;             // pinned landing zone of lbfgsx_b_cauchy_chunk
     size_t g_host_cap = 0;
     // chunk staging for the sequential GCP scan
@@ -217,6 +231,8 @@ int bounded_alloc(lbfgsx_ctx* c)
         b->lu_use = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_SWEEP_SOLVE_FUSE"))
         b->sweep_fuse = atoi(e) != 0;
+    if (const char* e = getenv("LBFGSX_COMPACT_FREE"))
+        b->wf_use = atoi(e) != 0;
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->colmax), sizeof(unsigned long long) * 2 * size_t(c->m + 1)));
     LBFGSX_HIP(hipMemset(b->colmax, 0, sizeof(unsigned long long) * 2 * size_t(c->m + 1)));
     b->colmax_ok.assign(size_t(c->m + 1), 0);
@@ -279,6 +295,11 @@ void bounded_free(lbfgsx_ctx* c)
     if (b->g_host)
         (void) hipHostFree(b->g_host);
     (void) hipFree(b->lu_list);
+    (void) hipFree(b->wf);
+    (void) hipFree(b->wf_idx);
+    (void) hipFree(b->wf_cnt);
+    (void) hipFree(b->wf_base);
+    (void) hipFree(b->wf_tmp);
     (void) hipFree(b->lu_cnt);
     (void) hipFree(b->colmax);
     (void) hipFree(b->i8_part);
@@ -317,6 +338,64 @@ static Cols<T, NC> col_list(lbfgsx_ctx* c, const int* which /* 0..2c-1: Y slots 
             cl.p[k] = nullptr;
     }
     return cl;
+}
+
+// columns of the compact copy of the free rows, logical order (Y slots then S slots)
+template <class T>
+static Cols<T, 32> wf_cols(lbfgsx_ctx* c, int count)
+{
+    Cols<T, 32> cl;
+    for (int k = 0; k < 32; k++)
+        cl.p[k] = (k < count) ? static_cast<const T*>(c->bstate->wf) + int64_t(k) * c->bstate->wf_ld : nullptr;
+    return cl;
+}
+// a mask inside the free set can be served from the compact copy
+static inline bool wf_serves(const lbfgsx_ctx* c, int mask)
+{
+    return c->bstate->wf_valid && mask != 0 && (mask & ~(ST_FREE | ST_L | ST_U | ST_P)) == 0;
+}
+// buffers of the compact copy and the positions of the 64-row batches for the current free set; false: do without
+static bool wf_prepare(lbfgsx_ctx* c)
+{
+    lbfgsb_state* b = c->bstate;
+    const int64_t nbatch = (c->n + 63) / 64;
+    if (!b->wf)
+    {
+        const size_t esz = (c->dtype == LBFGSX_F64) ? 8 : 4;
+        b->wf_ld = c->ld;
+        size_t bytes = 0;
+        bool ok = hipMalloc(&b->wf, esz * size_t(b->wf_ld) * 32) == hipSuccess &&
+                  hipMalloc(reinterpret_cast<void**>(&b->wf_idx), sizeof(int) * size_t(c->n)) == hipSuccess &&
+                  hipMalloc(reinterpret_cast<void**>(&b->wf_cnt), sizeof(int) * size_t(nbatch + 2)) == hipSuccess &&
+                  hipMalloc(reinterpret_cast<void**>(&b->wf_base), sizeof(int) * size_t(nbatch + 2)) == hipSuccess &&
+                  rocprim::exclusive_scan(nullptr, bytes, b->wf_cnt, b->wf_base, 0, size_t(nbatch + 1), rocprim::plus<int>(),
+                                          c->stream) == hipSuccess &&
+                  hipMalloc(&b->wf_tmp, std::max<size_t>(bytes, 16)) == hipSuccess;
+        b->wf_tmp_bytes = bytes;
+        if (!ok)
+        {
+            (void) hipGetLastError();
+            (void) hipFree(b->wf);
+            (void) hipFree(b->wf_idx);
+            (void) hipFree(b->wf_cnt);
+            (void) hipFree(b->wf_base);
+            (void) hipFree(b->wf_tmp);
+            b->wf = b->wf_tmp = nullptr;
+            b->wf_idx = b->wf_cnt = b->wf_base = nullptr;
+            b->wf_use = false;  // no room for the copy: the masked passes do the work
+            return false;
+        }
+    }
+    const int grid = int(std::min<int64_t>(c->grid_for(c->n), (nbatch + 4) / 4));
+    hipLaunchKernelGGL(k_free_counts, dim3(std::max(1, grid)), dim3(kBlock), 0, c->stream, c->bstate->st, c->n, nbatch, b->wf_cnt);
+    size_t bytes = b->wf_tmp_bytes;
+    if (rocprim::exclusive_scan(b->wf_tmp, bytes, b->wf_cnt, b->wf_base, 0, size_t(nbatch + 1), rocprim::plus<int>(), c->stream) !=
+        hipSuccess)
+    {
+        (void) hipGetLastError();
+        return false;
+    }
+    return true;
 }
 
 // raw masked W'v for all 2*ncorr columns: out[0..c) = Y_j . v, out[c..2c) = S_j . v ; nnz of v inside the mask
@@ -1152,6 +1231,7 @@ int lbfgsx_b_cauchy_finish(lbfgsx_ctx* c, double t_cross, double tfinal, int cro
     DISPATCH_T(c, {
         BVecs<T> bv = bvecs<T>(c);
         c->bstate->lu_valid = false;  // the state bytes are rewritten
+        c->bstate->wf_valid = false;
         hipLaunchKernelGGL((k_cauchy_finish<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, T(t_cross), T(tfinal), crossed_all,
                            c->n, c->ws, c->bstate->dout);
     });
@@ -1161,6 +1241,7 @@ int lbfgsx_b_cauchy_finish(lbfgsx_ctx* c, double t_cross, double tfinal, int cro
         return rc;
     if (nact) *nact = int64_t(r[0]);
     if (nfree) *nfree = int64_t(r[1]);
+    c->bstate->nfree_last = int64_t(r[1]);
     return LBFGSX_OK;
 }
 
@@ -1171,11 +1252,24 @@ int lbfgsx_b_sub_begin(lbfgsx_ctx* c)
     if (rc)
         return rc;
     const int grid = c->grid_for(c->n);
+    c->bstate->wf_valid = false;  // a compact copy of the free rows belongs to one subspace minimisation
+    c->bstate->wf_on = false;
     DISPATCH_T(c, {
         BVecs<T> bv = bvecs<T>(c);
         hipLaunchKernelGGL((k_sub_begin<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, c->n);
     });
     LBFGSX_HIP(hipGetLastError());
+    return LBFGSX_OK;
+}
+
+int lbfgsx_b_set_compaction(lbfgsx_ctx* c, int enable)
+{
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    c->bstate->wf_on = enable != 0;
+    if (!enable)
+        c->bstate->wf_valid = false;
     return LBFGSX_OK;
 }
 
@@ -1320,7 +1414,8 @@ static int gram_i8_run(lbfgsx_ctx* c, int tot, int vsel_id, int mask, const Gram
 }
 
 template <class T, int KP>
-static int launch_gram_dd(lbfgsx_ctx* c, int64_t nbatch, int tot, int vsel_id, int mask, const GramPrologue<T>& pro)
+static int launch_gram_dd(lbfgsx_ctx* c, int64_t nbatch, int tot, int vsel_id, int mask, const GramPrologue<T>& pro,
+                          const GramRows<T>& gr, int64_t nrows)
 {
     lbfgsb_state* b = c->bstate;
     const size_t lds = gram_dd_lds_bytes(gram_dd_cs(KP), KP);
@@ -1335,13 +1430,14 @@ static int launch_gram_dd(lbfgsx_ctx* c, int64_t nbatch, int tot, int vsel_id, i
     int which[32];
     for (int k = 0; k < tot; k++)
         which[k] = k;
-    Cols<T, 32> cl = col_list<T, 32>(c, which, tot);
+    Cols<T, 32> cl = gr.in_idx ? wf_cols<T>(c, tot) : col_list<T, 32>(c, which, tot);
     hipLaunchKernelGGL((k_gram_dd<T, KP>), dim3(blocks), dim3(kBlock), lds, c->stream, cl, tot, bvecs<T>(c), vsel_id, mask,
-                       c->n, b->gram_partial, pro);
+                       nrows, b->gram_partial, pro, gr);
     return blocks;
 }
 template <class T, int CS>
-static int launch_gram_vonly(lbfgsx_ctx* c, int64_t nbatch, int tot, int vsel_id, int mask, const GramPrologue<T>& pro)
+static int launch_gram_vonly(lbfgsx_ctx* c, int64_t nbatch, int tot, int vsel_id, int mask, const GramPrologue<T>& pro,
+                             const GramRows<T>& gr, int64_t nrows)
 {
     lbfgsb_state* b = c->bstate;
     const size_t lds = gram_dd_lds_bytes(CS, 1);
@@ -1353,9 +1449,9 @@ static int launch_gram_vonly(lbfgsx_ctx* c, int64_t nbatch, int tot, int vsel_id
     int which[32];
     for (int k = 0; k < tot; k++)
         which[k] = k;
-    Cols<T, 32> cl = col_list<T, 32>(c, which, tot);
+    Cols<T, 32> cl = gr.in_idx ? wf_cols<T>(c, tot) : col_list<T, 32>(c, which, tot);
     hipLaunchKernelGGL((k_gram_dd<T, 1, CS, true>), dim3(blocks), dim3(kBlock), lds, c->stream, cl, tot, bvecs<T>(c), vsel_id,
-                       mask, c->n, b->gram_partial, pro);
+                       mask, nrows, b->gram_partial, pro, gr);
     return blocks;
 }
 extern "C" {
@@ -1375,7 +1471,9 @@ int lbfgsx_b_wtv_prologue(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, co
         set_error("lbfgsx_b_wtv_prologue: needs the default one-pass Gram, 1 <= 2c <= 30, a vector selector and a known prologue");
         return LBFGSX_E_INVALID;
     }
-    const int64_t nbatch = (c->n + kGramDDRows - 1) / kGramDDRows;
+    const bool compact = wf_serves(c, mask);
+    const int64_t nrows = compact ? b->wf_n : c->n;
+    const int64_t nbatch = (nrows + kGramDDRows - 1) / kGramDDRows;
     rc = upload_phys(c);
     if (rc)
         return rc;
@@ -1390,12 +1488,13 @@ int lbfgsx_b_wtv_prologue(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, co
             pro.c1[k] = (coef1 && k < tot) ? T(coef1[k]) : T(0);
             pro.c2[k] = (coef2 && k < tot) ? T(coef2[k]) : T(0);
         }
+        GramRows<T> gr{compact ? b->wf_idx : nullptr, nullptr, 0, nullptr, nullptr};
         // the tile row stride must hold ntot columns: the strides of the full kernel's KP classes
-        if (ntot <= 11) blocks = launch_gram_vonly<T, 11>(c, nbatch, tot, vsel_id, mask, pro);
-        else if (ntot <= 15) blocks = launch_gram_vonly<T, 15>(c, nbatch, tot, vsel_id, mask, pro);
-        else if (ntot <= 23) blocks = launch_gram_vonly<T, 23>(c, nbatch, tot, vsel_id, mask, pro);
-        else if (ntot <= 27) blocks = launch_gram_vonly<T, 27>(c, nbatch, tot, vsel_id, mask, pro);
-        else blocks = launch_gram_vonly<T, 31>(c, nbatch, tot, vsel_id, mask, pro);
+        if (ntot <= 11) blocks = launch_gram_vonly<T, 11>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
+        else if (ntot <= 15) blocks = launch_gram_vonly<T, 15>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
+        else if (ntot <= 23) blocks = launch_gram_vonly<T, 23>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
+        else if (ntot <= 27) blocks = launch_gram_vonly<T, 27>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
+        else blocks = launch_gram_vonly<T, 31>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
     });
     const int nch = std::min(blocks, 32);
     hipLaunchKernelGGL(k_gram_finish, dim3(1, nch), dim3(kBlock), 0, c->stream, b->gram_partial, blocks, b->gram_partial2, 0);
@@ -1504,11 +1603,20 @@ int lbfgsx_b_gram_fused_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
     }
     const int npairs = ntot * (ntot + 1) / 2;
     const int kp = (npairs + 63) / 64;  // pairs per lane: 1, 2, 4, 6 or 8 (ntot <= 31 -> 496 pairs)
-    const int64_t nbatch = (c->n + kGramDDRows - 1) / kGramDDRows;
     int blocks = 1;
     rc = upload_phys(c);
     if (rc)
         return rc;
+    // the pass over the whole free set that keeps its un-rounded sums is the first solve of a subspace minimisation: with
+    // sweeps expected it also leaves the compact copy of the free rows (worth it when F leaves out a good part of the rows)
+    const bool compact_in = wf_serves(c, mask);
+    bool compact_out = !compact_in && b->wf_use && b->wf_on && gram_dd != nullptr && mask == ST_FREE && vsel_id >= 0 &&
+                       !(b->gram_i8 && c->dtype == LBFGSX_F64) && c->n < (int64_t(1) << 31) && b->nfree_last >= 4096 &&
+                       b->nfree_last * 8 <= c->n * 7;
+    if (compact_out)
+        compact_out = wf_prepare(c);
+    const int64_t nrows = compact_in ? b->wf_n : c->n;
+    const int64_t nbatch = (nrows + kGramDDRows - 1) / kGramDDRows;
     bool done_i8 = false;
     // the integer kernel pays a fixed cost per launch (per-wave partials, the integer tree): row sets that are not the
     // free set -- the sparse L u U complements of the BOXCQP sweeps -- stay on the double-double kernel
@@ -1542,12 +1650,19 @@ int lbfgsx_b_gram_fused_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
             pro.c1[k] = (coef1 && k < tot) ? T(coef1[k]) : T(0);
             pro.c2[k] = (coef2 && k < tot) ? T(coef2[k]) : T(0);
         }
-        if (kp <= 1) blocks = launch_gram_dd<T, 1>(c, nbatch, tot, vsel_id, mask, pro);
-        else if (kp <= 2) blocks = launch_gram_dd<T, 2>(c, nbatch, tot, vsel_id, mask, pro);
-        else if (kp <= 4) blocks = launch_gram_dd<T, 4>(c, nbatch, tot, vsel_id, mask, pro);
-        else if (kp <= 6) blocks = launch_gram_dd<T, 6>(c, nbatch, tot, vsel_id, mask, pro);
-        else blocks = launch_gram_dd<T, 8>(c, nbatch, tot, vsel_id, mask, pro);
+        GramRows<T> gr{compact_in ? b->wf_idx : nullptr, compact_out ? static_cast<T*>(b->wf) : nullptr, b->wf_ld,
+                       compact_out ? b->wf_idx : nullptr, compact_out ? b->wf_base : nullptr};
+        if (kp <= 1) blocks = launch_gram_dd<T, 1>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
+        else if (kp <= 2) blocks = launch_gram_dd<T, 2>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
+        else if (kp <= 4) blocks = launch_gram_dd<T, 4>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
+        else if (kp <= 6) blocks = launch_gram_dd<T, 6>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
+        else blocks = launch_gram_dd<T, 8>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
     });
+    if (compact_out)
+    {
+        b->wf_valid = true;
+        b->wf_n = b->nfree_last;
+    }
     const int nch = std::min(blocks, 32);
     hipLaunchKernelGGL(k_gram_finish, dim3(ntile_, nch), dim3(kBlock), 0, c->stream, b->gram_partial, blocks, b->gram_partial2, 0);
     hipLaunchKernelGGL(k_gram_finish, dim3(ntile_, 1), dim3(kBlock), 0, c->stream, b->gram_partial2, nch, b->gram_out, 1,
@@ -1740,17 +1855,21 @@ static int solve_sweep_t(lbfgsx_ctx* c, int first, int vsel_id, const double* co
     int which[32];
     for (int k = 0; k < total; k++)
         which[k] = k;
-    Cols<T, 32> cl = col_list<T, 32>(c, which, total);
+    // the rows this pass acts on are the free rows: from their compact copy when the Gram pass before it left one
+    const bool compact = wf_serves(c, ST_FREE);
+    const int64_t nrows = compact ? c->bstate->wf_n : c->n;
+    const int* ridx = compact ? c->bstate->wf_idx : nullptr;
+    Cols<T, 32> cl = compact ? wf_cols<T>(c, total) : col_list<T, 32>(c, which, total);
     CoefArg<T> cf;
     for (int k = 0; k < 80; k++)
         cf.c[k] = (coef && k < total) ? T(coef[k]) : T(0);
-    const int grid = std::min(c->grid_for(c->n), c->bstate->dots_grid);
+    const int grid = std::min(c->grid_for(nrows), c->bstate->dots_grid);
     if (first)
         hipLaunchKernelGGL((k_solve_sweep<T, NC, 1>), dim3(grid), dim3(kBlock), 0, c->stream, cl, total, bvecs<T>(c), vsel_id, cf,
-                           coef ? 1 : 0, T(theta), c->n, c->ws, c->bstate->dout, lu_dst, c->bstate->lu_cnt, lu_cap_now);
+                           coef ? 1 : 0, T(theta), nrows, c->ws, c->bstate->dout, lu_dst, c->bstate->lu_cnt, lu_cap_now, ridx);
     else
         hipLaunchKernelGGL((k_solve_sweep<T, NC, 0>), dim3(grid), dim3(kBlock), 0, c->stream, cl, total, bvecs<T>(c), vsel_id, cf,
-                           coef ? 1 : 0, T(theta), c->n, c->ws, c->bstate->dout, lu_dst, c->bstate->lu_cnt, lu_cap_now);
+                           coef ? 1 : 0, T(theta), nrows, c->ws, c->bstate->dout, lu_dst, c->bstate->lu_cnt, lu_cap_now, ridx);
     LBFGSX_HIP(hipGetLastError());
     const int nd = first ? 0 : NC;
     double r[NC + 7];

@@ -628,13 +628,46 @@ inline size_t gram_dd_lds_bytes(int cs, int kp)
     return tile > scr ? tile : scr;
 }
 
+// Compact copy of the free rows.  Every pass of the subspace minimisation acts on rows of the free set F (about half of
+// the rows in a box-constrained steady state); read through the state-byte mask each of them fetches all n rows of the 2c
+// columns.  The first pass over F (the full Gram of the first solve) therefore also writes the rows it keeps to a dense
+// copy WF[k][t] with the row numbers idx[t] (t ascending with the row: positions from a prefix sum over the 64-row
+// batches, so the copy is the same on every run), and the passes after it read WF at t and the other vectors at idx[t].
+template <class T>
+struct GramRows
+{
+    const int* in_idx;    // input is the compact copy: row t of the columns is row in_idx[t] of the vectors (null: identity)
+    T* out_w;             // write the kept rows to out_w[k * out_ld + out_base[batch] + position in the batch]
+    int64_t out_ld;
+    int* out_idx;
+    const int* out_base;
+};
+
+// free rows per 64-row batch (the exclusive prefix sum over it places the batch in the compact copy)
+__global__ void __launch_bounds__(kBlock) k_free_counts(const unsigned char* __restrict__ st, int64_t n, int64_t nbatch,
+                                                        int* __restrict__ counts)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t nwaves = int64_t(gridDim.x) * (kBlock / 64);
+    for (int64_t bt = int64_t(blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6); bt <= nbatch; bt += nwaves)
+    {
+        const int64_t r = bt * 64 + lane;
+        const bool keep = bt < nbatch && r < n && (st[r] & ST_FREE);
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0)
+            counts[bt] = __popcll(bal);  // counts[nbatch] = 0: the scan leaves the total there
+    }
+}
+
 // VONLY: only the v row of the matrix -- the pairs (v, column j) and (v, v), one per lane (KP = 1, ntot <= 64 lanes) --
 // with the same staging and prologue as the full pass: a BOXCQP sweep whose 2c x 2c block comes from the complement
 // identity (lbfgsx_b_gram_fused_dd) then pays 1 instead of KP double-double accumulations per row and wavefront.
 template <class T, int KP, int CS = gram_dd_cs(KP), bool VONLY = false>
 __global__ void __launch_bounds__(kBlock) k_gram_dd(Cols<T, 32> cols, int ncols, BVecs<T> b, int vsel_id, int mask,
-                                                    int64_t n, double* __restrict__ partial, GramPrologue<T> pro)
+                                                    int64_t n, double* __restrict__ partial, GramPrologue<T> pro,
+                                                    GramRows<T> gr)
 {
+    // n: rows of the columns this pass walks (the compact count with gr.in_idx)
     constexpr int cs = CS;
     extern __shared__ double tile[];
     __shared__ T pc1[64], pc2[64];
@@ -683,7 +716,7 @@ __global__ void __launch_bounds__(kBlock) k_gram_dd(Cols<T, 32> cols, int ncols,
     for (int u = 0; u < 4; u++)
     {
         const int64_t ru = (bt0 + u * nwaves) * kGramDDRows + lane;
-        st4[u] = (mask && ru < n) ? b.st[ru] : (unsigned char) 0;
+        st4[u] = (mask && ru < n) ? b.st[gr.in_idx ? int64_t(gr.in_idx[ru]) : ru] : (unsigned char) 0;
     }
 #pragma unroll
     for (int u = 0; u < 4; u++)
@@ -691,8 +724,8 @@ __global__ void __launch_bounds__(kBlock) k_gram_dd(Cols<T, 32> cols, int ncols,
         const int64_t bt = bt0 + u * nwaves;
         if (bt >= nbatch)
             break;
-        const int64_t r = bt * kGramDDRows + lane;
-        const bool keep = r < n && (!mask || (st4[u] & mask));
+        const int64_t rt = bt * kGramDDRows + lane;  // row of the columns
+        const bool keep = rt < n && (!mask || (st4[u] & mask));
         const unsigned long long bal = __ballot(keep);
         const int cnt = __popcll(bal);
         if (cnt == 0)
@@ -700,18 +733,26 @@ __global__ void __launch_bounds__(kBlock) k_gram_dd(Cols<T, 32> cols, int ncols,
         const int pos = __popcll(bal & ((1ull << lane) - 1ull));
         if (keep)
         {
+            const int64_t r = gr.in_idx ? int64_t(gr.in_idx[rt]) : rt;  // row of the vectors
             double* row = tl + pos * cs;
+            const int64_t ot = gr.out_w ? int64_t(gr.out_base[bt]) + pos : 0;
+            if (gr.out_w)
+                gr.out_idx[ot] = int(r);
             for (int c0 = 0; c0 < ncols; c0 += 8)
             {
                 // eight independent loads in flight per lane
                 double v[8];
 #pragma unroll
                 for (int u = 0; u < 8; u++)
-                    v[u] = (c0 + u < ncols) ? double(cols.p[c0 + u][r]) : 0.0;
+                    v[u] = (c0 + u < ncols) ? double(cols.p[c0 + u][rt]) : 0.0;
 #pragma unroll
                 for (int u = 0; u < 8; u++)
                     if (c0 + u < ncols)
+                    {
                         row[c0 + u] = v[u];
+                        if (gr.out_w)
+                            gr.out_w[int64_t(c0 + u) * gr.out_ld + ot] = T(v[u]);
+                    }
             }
             if (pro.mode != GP_NONE)
             {
@@ -1295,8 +1336,10 @@ __global__ void __launch_bounds__(kBlock) k_sub_sweep_begin(BVecs<T> b, int firs
 template <class T, int NC, int FIRST>
 __global__ void __launch_bounds__(kBlock, NC <= 24 ? 2 : 1) k_solve_sweep(Cols<T, 32> cols, int ncols, BVecs<T> b, int vsel_id, CoefArg<T> coef,
                                                         int has_w, T theta, int64_t n, RedWs ws, double* __restrict__ out,
-                                                        int* __restrict__ lu_list, unsigned* __restrict__ lu_cnt, unsigned lu_cap)
+                                                        int* __restrict__ lu_list, unsigned* __restrict__ lu_cnt, unsigned lu_cap,
+                                                        const int* __restrict__ ridx)
 {
+    // ridx: `cols` is the compact copy of the free rows (GramRows): n of them, row t of the columns = row ridx[t] of the vectors
     typedef typename AccOf<T>::type A;
     constexpr int ND = FIRST ? 0 : NC;
     __shared__ T sc[80];
@@ -1307,8 +1350,9 @@ __global__ void __launch_bounds__(kBlock, NC <= 24 ? 2 : 1) k_solve_sweep(Cols<T
     A dots[ND ? ND : 1];
     unsigned cnt[7] = {0, 0, 0, 0, 0, 0, 0};
     const int64_t stride = int64_t(gridDim.x) * kBlock;
-    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
+    for (int64_t t = int64_t(blockIdx.x) * kBlock + threadIdx.x; t < n; t += stride)
     {
+        const int64_t i = ridx ? int64_t(ridx[t]) : t;
         unsigned char st = b.st[i];
         if (!(st & ST_FREE))
             continue;
@@ -1316,7 +1360,7 @@ __global__ void __launch_bounds__(kBlock, NC <= 24 ? 2 : 1) k_solve_sweep(Cols<T
 #pragma unroll
         for (int k = 0; k < NC; k++)
             if (k < ncols)
-                w[k] = cols.p[k][i];
+                w[k] = cols.p[k][t];
         const bool solve = FIRST || (st & ST_P);
         T yi;
         if (solve)

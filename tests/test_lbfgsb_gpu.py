@@ -358,6 +358,35 @@ def test_sweep_statements_riding_on_the_solve_change_no_bit(A, monkeypatch, m, m
     assert u[6] == 0 and f[6] > 0
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("n,m,max_submin", [(70001, 8, 10), (70001, 10, 2), (65536, 3, 10), (90000, 14, 10)])
+def test_compact_copy_of_the_free_rows_changes_no_bit(A, monkeypatch, n, m, max_submin, dtype):
+    """The passes of the BOXCQP sweeps reading the compact copy of the free rows that the first solve's Gram pass leaves
+    (lbfgsx_b_set_compaction) against the same passes reading all n rows through the state-byte mask
+    (LBFGSX_COMPACT_FREE=0): the same rows in the same order, so the same trajectory bit for bit."""
+    iters = 20
+    dt = O.F64 if dtype == "f64" else O.F32
+    npdt = O.NPDT[dt]
+    a, b = O.quad_problem(n, 30.0, 9, dt)
+    res = {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("LBFGSX_COMPACT_FREE", on)
+        s = A.LBFGSBSolver(A.LBFGSBParam(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters, max_submin=max_submin),
+                           dtype=npdt)
+        tr = A.TraceBuffer(n, cap=256, stride=17)
+        x = np.zeros(n, dtype=npdt)
+        try:
+            niter, fx = s.minimize(A.DiagQuadratic(a, b), x, (-0.7 * np.ones(n)).astype(npdt), (0.9 * np.ones(n)).astype(npdt),
+                                   trace=tr)
+        except RuntimeError:
+            niter, fx = -1, float("nan")
+        st = s.stats()
+        res[on] = (niter, s.last.nfev, x.copy(), tr.xs[:tr.count].copy(), st["submin_sweeps"], st["submin_unconverged"])
+    f, u = res["1"], res["0"]
+    assert f[:2] == u[:2] and f[4:] == u[4:] and f[4] > 0
+    assert np.array_equal(f[2], u[2]) and np.array_equal(f[3], u[3])
+
+
 @pytest.mark.parametrize("m", [3, 5, 8, 10, 12])
 def test_deferred_correction_dots_change_no_bit(A, monkeypatch, m):
     """add_correction's S's_new / s_new.y_j dots taken by the W'd pass of the following Cauchy search
