@@ -57,6 +57,7 @@ struct lbfgsb_state
     void* wf_tmp = nullptr;
     size_t wf_tmp_bytes = 0;
     bool wf_use = true;                   // LBFGSX_COMPACT_FREE=0: never
+    int vonly_groups = 0;                 // LBFGSX_VONLY_GROUPS=1: the v-row Gram walks one row per step (A/B of the lane groups)
     bool wf_on = false;                   // the caller's hint for the current subspace minimisation
     bool wf_valid = false;
     int64_t wf_n = 0;                     // rows in the copy
@@ -233,6 +234,8 @@ int bounded_alloc(lbfgsx_ctx* c)
         b->sweep_fuse = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_COMPACT_FREE"))
         b->wf_use = atoi(e) != 0;
+    if (const char* e = getenv("LBFGSX_VONLY_GROUPS"))
+        b->vonly_groups = atoi(e);
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->colmax), sizeof(unsigned long long) * 2 * size_t(c->m + 1)));
     LBFGSX_HIP(hipMemset(b->colmax, 0, sizeof(unsigned long long) * 2 * size_t(c->m + 1)));
     b->colmax_ok.assign(size_t(c->m + 1), 0);
@@ -1488,7 +1491,7 @@ int lbfgsx_b_wtv_prologue(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, co
             pro.c1[k] = (coef1 && k < tot) ? T(coef1[k]) : T(0);
             pro.c2[k] = (coef2 && k < tot) ? T(coef2[k]) : T(0);
         }
-        GramRows<T> gr{compact ? b->wf_idx : nullptr, nullptr, 0, nullptr, nullptr};
+        GramRows<T> gr{compact ? b->wf_idx : nullptr, nullptr, 0, nullptr, nullptr, b->vonly_groups};
         // the tile row stride must hold ntot columns: the strides of the full kernel's KP classes
         if (ntot <= 11) blocks = launch_gram_vonly<T, 11>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
         else if (ntot <= 15) blocks = launch_gram_vonly<T, 15>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
@@ -1651,7 +1654,7 @@ int lbfgsx_b_gram_fused_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
             pro.c2[k] = (coef2 && k < tot) ? T(coef2[k]) : T(0);
         }
         GramRows<T> gr{compact_in ? b->wf_idx : nullptr, compact_out ? static_cast<T*>(b->wf) : nullptr, b->wf_ld,
-                       compact_out ? b->wf_idx : nullptr, compact_out ? b->wf_base : nullptr};
+                       compact_out ? b->wf_idx : nullptr, compact_out ? b->wf_base : nullptr, 0};
         if (kp <= 1) blocks = launch_gram_dd<T, 1>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
         else if (kp <= 2) blocks = launch_gram_dd<T, 2>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
         else if (kp <= 4) blocks = launch_gram_dd<T, 4>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
@@ -1728,13 +1731,16 @@ static int solve_dots_t(lbfgsx_ctx* c, int pmask, int vsel_id, const double* coe
     int which[32];
     for (int k = 0; k < total; k++)
         which[k] = k;
-    Cols<T, 32> cl = col_list<T, 32>(c, which, total);
+    const bool compact = wf_serves(c, fmask) && wf_serves(c, pmask);
+    const int64_t nrows = compact ? c->bstate->wf_n : c->n;
+    Cols<T, 32> cl = compact ? wf_cols<T>(c, total) : col_list<T, 32>(c, which, total);
     CoefArg<T> cf;
     for (int k = 0; k < 80; k++)
         cf.c[k] = (coef && k < total) ? T(coef[k]) : T(0);
-    const int grid = std::min(c->grid_for(c->n), c->bstate->dots_grid);
+    const int grid = std::min(c->grid_for(nrows), c->bstate->dots_grid);
     hipLaunchKernelGGL((k_solve_dots<T, NC>), dim3(grid), dim3(kBlock), 0, c->stream, cl, total, bvecs<T>(c), vsel_id, cf,
-                       coef ? 1 : 0, pmask, fmask, T(theta), c->n, c->ws, c->bstate->dout);
+                       coef ? 1 : 0, pmask, fmask, T(theta), nrows, c->ws, c->bstate->dout,
+                       compact ? c->bstate->wf_idx : static_cast<const int*>(nullptr));
     LBFGSX_HIP(hipGetLastError());
     double r[NC];
     int rc = fetch_doubles(c, NC, r);

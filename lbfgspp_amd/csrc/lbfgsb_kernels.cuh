@@ -641,6 +641,7 @@ struct GramRows
     int64_t out_ld;
     int* out_idx;
     const int* out_base;
+    int vgroups;          // VONLY: 1 = one row per step for all lanes (the single-group form), 0 = as many groups as fit
 };
 
 // free rows per 64-row batch (the exclusive prefix sum over it places the batch in the compact copy)
@@ -685,6 +686,10 @@ __global__ void __launch_bounds__(kBlock) k_gram_dd(Cols<T, 32> cols, int ncols,
     const int npairs = ntot * (ntot + 1) / 2;
     double* tl = tile + wv * (kGramDDRows * cs);
     int pi[KP], pj[KP];
+    // VONLY: the ntot entries of the v row fill ntot of the 64 lanes, so the lanes form vg = 64 / ntot groups that take
+    // every vg-th row of the tile each (3 groups at m = 10); the groups' sums of an entry are merged after the loop
+    const int vg = (VONLY && gr.vgroups != 1 && 64 / ntot > 0) ? 64 / ntot : 1;
+    const int grp = VONLY ? lane / ntot : 0;
 #pragma unroll
     for (int k = 0; k < KP; k++)
     {
@@ -693,7 +698,7 @@ __global__ void __launch_bounds__(kBlock) k_gram_dd(Cols<T, 32> cols, int ncols,
         {
             // entry e = (v, column e) for e < ncols, (v, v) for e == ncols; v is column `ncols` of the tile
             pi[k] = ncols;
-            pj[k] = (e <= ncols) ? e : 0;
+            pj[k] = lane - grp * ntot;
             continue;
         }
         if (e >= npairs)
@@ -784,6 +789,25 @@ __global__ void __launch_bounds__(kBlock) k_gram_dd(Cols<T, 32> cols, int ncols,
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         int rr = 0;
+        if (VONLY)
+        {
+            if (grp < vg)
+            {
+                const double* rp = tl + grp * cs;
+                const int step = vg * cs;
+                int j = grp;
+                for (; j + vg < cnt; j += 2 * vg)
+                {
+                    acc0[0].add_prod(rp[pi[0]], rp[pj[0]]);
+                    acc1[0].add_prod(rp[step + pi[0]], rp[step + pj[0]]);
+                    rp += 2 * step;
+                }
+                if (j < cnt)
+                    acc0[0].add_prod(rp[pi[0]], rp[pj[0]]);
+            }
+            rr = cnt;
+        }
+        else
         {
             // eight rows per trip: one address per operand and lane, the rows reached through instruction immediates
             // (the per-entry order of the additions is unchanged: even rows into acc0, odd rows into acc1)
@@ -829,6 +853,17 @@ __global__ void __launch_bounds__(kBlock) k_gram_dd(Cols<T, 32> cols, int ncols,
     for (int k = 0; k < KP; k++)
     {
         acc0[k].merge(acc1[k].hi, acc1[k].lo);
+        if (VONLY)
+        {
+            for (int g = 1; g < vg; g++)
+            {
+                const double ohi = __shfl(acc0[k].hi, lane + g * ntot, 64), olo = __shfl(acc0[k].lo, lane + g * ntot, 64);
+                if (lane < ntot)
+                    acc0[k].merge(ohi, olo);
+            }
+            if (lane >= ntot)
+                acc0[k] = DD();
+        }
         scr[((wv * KP + k) * 64 + lane) * 2 + 0] = acc0[k].hi;
         scr[((wv * KP + k) * 64 + lane) * 2 + 1] = acc0[k].lo;
     }
@@ -1083,8 +1118,9 @@ __global__ void __launch_bounds__(kBlock) k_wcombine(BVecs<T> b, const T* __rest
 template <class T, int NC>
 __global__ void __launch_bounds__(kBlock) k_solve_dots(Cols<T, 32> cols, int ncols, BVecs<T> b, int vsel_id, CoefArg<T> coef,
                                                        int has_w, int pmask, int fmask, T theta, int64_t n, RedWs ws,
-                                                       double* __restrict__ out)
+                                                       double* __restrict__ out, const int* __restrict__ ridx)
 {
+    // ridx: `cols` is the compact copy of the free rows (GramRows): n of them, row t of the columns = row ridx[t] of the vectors
     typedef typename AccOf<T>::type A;
     __shared__ T sc[80];
     if (threadIdx.x < 80)
@@ -1093,8 +1129,9 @@ __global__ void __launch_bounds__(kBlock) k_solve_dots(Cols<T, 32> cols, int nco
     const T theta2 = theta * theta;
     A acc[NC];
     const int64_t stride = int64_t(gridDim.x) * kBlock;
-    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
+    for (int64_t t = int64_t(blockIdx.x) * kBlock + threadIdx.x; t < n; t += stride)
     {
+        const int64_t i = ridx ? int64_t(ridx[t]) : t;
         const unsigned char st = b.st[i];
         if (!(st & fmask))
             continue;
@@ -1102,7 +1139,7 @@ __global__ void __launch_bounds__(kBlock) k_solve_dots(Cols<T, 32> cols, int nco
 #pragma unroll
         for (int k = 0; k < NC; k++)
             if (k < ncols)
-                w[k] = cols.p[k][i];
+                w[k] = cols.p[k][t];
         T yi;
         if (st & pmask)
         {
