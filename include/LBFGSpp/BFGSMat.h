@@ -178,6 +178,24 @@ public:
         }
     }
 
+    // W_L' l and W_U' u of a BOXCQP sweep in one launch (lbfgsx_b_wtv_lu); false: not available here, use Wtv per set
+    bool Wtv_lu(std::vector<Scalar>& res_l, std::int64_t& nnz_l, std::vector<Scalar>& res_u, std::int64_t& nnz_u) const
+    {
+        double rl[80], ru[80];
+        if (m_ncorr < 1 || lbfgsx_b_wtv_lu(m_c, rl, &nnz_l, ru, &nnz_u) != LBFGSX_OK)
+            return false;
+        res_l.assign(size_t(2 * m_ncorr), Scalar(0));
+        res_u.assign(size_t(2 * m_ncorr), Scalar(0));
+        for (int j = 0; j < m_ncorr; j++)
+        {
+            res_l[size_t(j)] = Scalar(rl[j]);
+            res_l[size_t(m_ncorr + j)] = Scalar(rl[m_ncorr + j]) * m_theta;
+            res_u[size_t(j)] = Scalar(ru[j]);
+            res_u[size_t(m_ncorr + j)] = Scalar(ru[m_ncorr + j]) * m_theta;
+        }
+        return true;
+    }
+
     // apply_Mv for B vectors at once: V, R are [2c][B] (row k of lane b at [k * B + b]); lane by lane bit-identical to
     // apply_Mv (BKLDLT::solve_inplace_batch)
     template <int B>

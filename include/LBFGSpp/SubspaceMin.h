@@ -152,8 +152,23 @@ public:
             if (nP > 0)                                                 // (:229-245)
             {
                 std::vector<double> cl, cu;
-                const bool hasL = PtBQv_coef(bfgs, LBFGSX_ST_L, LBFGSX_VS_LBOUND, nP, nL, cl);
-                const bool hasU = PtBQv_coef(bfgs, LBFGSX_ST_U, LBFGSX_VS_UBOUND, nP, nU, cu);
+                bool hasL, hasU;
+                std::vector<Scalar> wl, wu;
+                std::int64_t zl = 0, zu = 0;
+                if (nL > 0 && nU > 0 && bfgs.Wtv_lu(wl, zl, wu, zu))    // both inner products from one launch
+                {
+                    hasL = zl >= 1;                                     // test_zero (BFGSMat.h:388-412), as PtBQv_coef
+                    hasU = zu >= 1;
+                    if (hasL)
+                        bfgs.Mv_scaled(wl, cl);
+                    if (hasU)
+                        bfgs.Mv_scaled(wu, cu);
+                }
+                else
+                {
+                    hasL = PtBQv_coef(bfgs, LBFGSX_ST_L, LBFGSX_VS_LBOUND, nP, nL, cl);
+                    hasU = PtBQv_coef(bfgs, LBFGSX_ST_U, LBFGSX_VS_UBOUND, nP, nU, cu);
+                }
                 // the pass that writes y on P also delivers W_F'y for the multipliers below
                 bfgs.solve_PtBP(LBFGSX_ST_P, nP, LBFGSX_VS_NEG_RHS, (hasL || hasU) ? LBFGSX_GP_RHS : LBFGSX_GP_NONE,
                                 hasL ? cl.data() : nullptr, hasU ? cu.data() : nullptr, need_mult ? &Fy : nullptr,

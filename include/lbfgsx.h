@@ -278,6 +278,10 @@ int lbfgsx_b_sub_check(lbfgsx_ctx* c, int64_t counts[4]);
  * the pass has moved no value of y), else the counts[1..3] of lbfgsx_b_sub_check on the current values; then
  * lbfgsx_b_sub_partition (:194-219) and LBFGSX_SO_RHS_INIT (:232).  Bit for bit the calls it replaces. */
 int lbfgsx_b_sub_sweep_begin(lbfgsx_ctx* c, int first, int64_t* nL, int64_t* nU, int64_t* nP, int64_t counts[4]);
+/* lbfgsx_b_wtv(LBFGSX_VS_LBOUND, LBFGSX_ST_L) and lbfgsx_b_wtv(LBFGSX_VS_UBOUND, LBFGSX_ST_U) -- the inner products of the two
+ * apply_PtBQv statements of a BOXCQP sweep (SubspaceMin.h:236-241, BFGSMat.h:570-594) -- in one launch over the index list of
+ * L u U.  LBFGSX_E_INVALID when there is no list or 2c > 24: call lbfgsx_b_wtv per set. */
+int lbfgsx_b_wtv_lu(lbfgsx_ctx* c, double* out_l, int64_t* nnz_l, double* out_u, int64_t* nnz_u);
 /* Hint for the subspace minimisation that lbfgsx_b_sub_begin has just opened (which clears it): BOXCQP sweeps are expected,
  * so the full Gram pass of the first solve (lbfgsx_b_gram_fused_dd over LBFGSX_ST_FREE) may also write a compact copy of the
  * free rows of [Y S], and the passes of the sweeps (lbfgsx_b_wtv_prologue, lbfgsx_b_solve_sweep, the complement Grams) then

@@ -1286,6 +1286,59 @@ int lbfgsx_b_wtv(lbfgsx_ctx* c, int vsel_id, int mask, double* out, int64_t* nnz
     return rc;
 }
 
+int lbfgsx_b_wtv_lu(lbfgsx_ctx* c, double* out_l, int64_t* nnz_l, double* out_u, int64_t* nnz_u)
+{
+    lbfgsx::DeviceGuard dev_guard_(c->device);
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    lbfgsb_state* b = c->bstate;
+    const int total = 2 * c->ncorr;
+    if (!b->lu_valid || total < 1 || total > 24 || b->multidot_chunked)
+    {
+        set_error("lbfgsx_b_wtv_lu: needs the index list of L u U and 1 <= 2c <= 24; use lbfgsx_b_wtv per set");
+        return LBFGSX_E_INVALID;
+    }
+    const int nl = b->lu_n;
+    const int lgrid = std::max(1, std::min(32, (nl + kBlock - 1) / kBlock));
+    int which[32];
+    for (int k = 0; k < total; k++)
+        which[k] = k;
+    double r[50];
+    int nc = 24;
+    DISPATCH_T(c, {
+        Cols<T, 32> cl = col_list<T, 32>(c, which, total);
+        BVecs<T> bv = bvecs<T>(c);
+        if (total <= 8)
+        {
+            nc = 8;
+            hipLaunchKernelGGL((k_multidot_list2<T, 8>), dim3(lgrid), dim3(kBlock), 0, c->stream, cl, total, bv, b->lu_ptr(), nl, c->ws,
+                               b->dout);
+        }
+        else if (total <= 16)
+        {
+            nc = 16;
+            hipLaunchKernelGGL((k_multidot_list2<T, 16>), dim3(lgrid), dim3(kBlock), 0, c->stream, cl, total, bv, b->lu_ptr(), nl,
+                               c->ws, b->dout);
+        }
+        else
+            hipLaunchKernelGGL((k_multidot_list2<T, 24>), dim3(lgrid), dim3(kBlock), 0, c->stream, cl, total, bv, b->lu_ptr(), nl,
+                               c->ws, b->dout);
+    });
+    LBFGSX_HIP(hipGetLastError());
+    rc = fetch_doubles(c, 2 * (nc + 1), r);
+    if (rc)
+        return rc;
+    for (int k = 0; k < total; k++)
+    {
+        out_l[k] = r[k];
+        out_u[k] = r[nc + 1 + k];
+    }
+    *nnz_l = int64_t(r[nc]);
+    *nnz_u = int64_t(r[2 * nc + 1]);
+    return LBFGSX_OK;
+}
+
 int lbfgsx_b_gram(lbfgsx_ctx* c, int mask, double* gram)
 {
     lbfgsx::DeviceGuard dev_guard_(c->device);

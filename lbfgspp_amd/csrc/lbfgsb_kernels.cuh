@@ -326,6 +326,53 @@ __global__ void __launch_bounds__(kBlock) k_multidot_list(Cols<T, 32> cols, int 
             out[k] = double(T(acc[k].value()));
 }
 
+// Both products a BOXCQP sweep needs before its solve in one launch over the index list: W_L' l (rows of L, v = the lower
+// bounds) and W_U' u (rows of U, the upper bounds) -- apply_PtBQv's inner products (BFGSMat.h:570-594) for the two
+// statements SubspaceMin.h:236-241.  out = {L dots [NC], nnz_L, U dots [NC], nnz_U}.
+template <class T, int NC>
+__global__ void __launch_bounds__(kBlock) k_multidot_list2(Cols<T, 32> cols, int ncols, BVecs<T> b, const int* __restrict__ list,
+                                                           int nlist, RedWs ws, double* __restrict__ out)
+{
+    typedef typename AccOf<T>::type A;
+    A acc[2 * (NC + 1)];
+    const int stride = int(gridDim.x) * kBlock;
+    for (int t = int(blockIdx.x) * kBlock + threadIdx.x; t < nlist; t += stride)
+    {
+        const int64_t i = list[t];
+        const unsigned char st = b.st[i];
+        if (!(st & (ST_L | ST_U)))
+            continue;
+        const bool isl = (st & ST_L) != 0;
+        const T v = vsel(b, isl ? VS_LBOUND : VS_UBOUND, i);
+        T w[NC];
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+            if (k < ncols)
+                w[k] = cols.p[k][i];
+        if (isl)
+        {
+            if (v != T(0))
+                acc[NC].add(T(1));
+#pragma unroll
+            for (int k = 0; k < NC; k++)
+                if (k < ncols)
+                    acc[k].add_prod(w[k], v);
+        }
+        else
+        {
+            if (v != T(0))
+                acc[2 * NC + 1].add(T(1));
+#pragma unroll
+            for (int k = 0; k < NC; k++)
+                if (k < ncols)
+                    acc[NC + 1 + k].add_prod(w[k], v);
+        }
+    }
+    if (grid_reduce<2 * (NC + 1)>(acc, ws) && threadIdx.x == 0)
+        for (int k = 0; k < 2 * (NC + 1); k++)
+            out[k] = double(T(acc[k].value()));
+}
+
 // The same masked multi-dot for ALL 2c columns in one launch (K4): each thread takes one 16-byte vector of
 // consecutive rows per column, so 2c independent 16-byte loads are in flight per thread and v, the state byte and
 // the launch/reduction overhead are paid once instead of once per 8 columns.  out[0..ncols) dots, out[NC] nnz.

@@ -19,7 +19,7 @@ namespace lbfgsx {
 
 constexpr int kBlock = 256;      // 4 waves of 64
 constexpr int kWaves = kBlock / 64;
-constexpr int kMaxRed = 40;      // max simultaneous reductions per kernel (2c + 1 <= 33 masked dots in one pass)
+constexpr int kMaxRed = 56;      // max simultaneous reductions per kernel (2c + 1 <= 33 masked dots in one pass; 2 (24 + 1) for the L and U dots of a sweep)
 
 // ---------------------------------------------------------------- accumulators
 struct DD
@@ -113,95 +113,174 @@ __device__ __forceinline__ double ld_agent(const double* p)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Sum NRED per-thread accumulators over the block; the total of sum r is returned in thread r (r < NRED).
+//
+// Wave level by recursive halving: at the step with lane distance `off` the lanes with that bit clear keep the lower half
+// of the sums they still hold and hand the upper half to their partner, the others the other way round, so a lane merges
+// NRED/2 + NRED/4 + ... ~ NRED partner values in all instead of 6 NRED for a butterfly per sum (each merge is a chain of
+// ~11 dependent f64 operations behind two cross-lane moves: with 20..50 sums the butterflies were 40..70 us at the tail
+// of every launch).  After the six steps each sum lives in exactly one lane.  Then one LDS slot per (sum, wave) and thread
+// r adds the waves' values of sum r.  The order of the additions differs from a butterfly's; the sums are double-double
+// (or compensated), the rounded totals are the same.
+// one halving step over the CUR sums a lane still holds, then the next (compile-time recursion: every index is static)
+template <int NRED, int CUR, int OFF, class A>
+struct HalveStep
+{
+    static __device__ __forceinline__ void run(A (&v)[NRED], int lane)
+    {
+        constexpr int H = (CUR + 1) / 2;
+        const bool up = (lane & OFF) != 0;
+#pragma unroll
+        for (int j = 0; j < H; j++)
+        {
+            // the values first, as registers the compiler cannot see through: written as a select between array elements
+            // it becomes a select between their addresses, and the whole array moves to scratch memory
+            double ahi = v[j].hi, alo = acc_lo(v[j]);
+            double bhi = (j + H < CUR) ? v[(j + H < CUR) ? j + H : j].hi : 0.0;       // odd count: the upper half is one short
+            double blo = (j + H < CUR) ? acc_lo(v[(j + H < CUR) ? j + H : j]) : 0.0;
+            asm volatile("" : "+v"(ahi), "+v"(alo), "+v"(bhi), "+v"(blo));
+            const double khi = up ? bhi : ahi, klo = up ? blo : alo;
+            const double shi = up ? ahi : bhi, slo = up ? alo : blo;
+            const double rhi = __shfl_xor(shi, OFF, 64), rlo = __shfl_xor(slo, OFF, 64);
+            A t;
+            t.hi = khi;
+            t.lo = klo;
+            t.merge(rhi, rlo);
+            v[j] = t;
+        }
+        HalveStep<NRED, H, OFF / 2, A>::run(v, lane);
+    }
+};
+template <int NRED, int CUR, class A>
+struct HalveStep<NRED, CUR, 0, A>
+{
+    static __device__ __forceinline__ void run(A (&)[NRED], int) {}
+};
+
+template <int NRED, class A>
+__device__ __forceinline__ A block_reduce_all(A (&v)[NRED], double (*sh)[2][kWaves])
+{
+    static_assert(NRED >= 1 && NRED <= 64, "one lane per sum after the halving steps");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    HalveStep<NRED, NRED, 32, A>::run(v, lane);
+    // which sum this lane ended up with: walking the steps backwards, r = index inside the array of that step
+    int hs[6], cs[6];
+    {
+        int c = NRED;
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+        {
+            cs[k] = c;
+            hs[k] = (c + 1) / 2;
+            c = hs[k];
+        }
+    }
+    int r = 0;
+    bool valid = true;
+#pragma unroll
+    for (int k = 5; k >= 0; k--)
+    {
+        if (lane & (32 >> k))
+            r += hs[k];
+        valid = valid && (r < cs[k]);
+    }
+    if (valid)
+    {
+        sh[r][0][wave] = v[0].hi;
+        sh[r][1][wave] = acc_lo(v[0]);
+    }
+    __syncthreads();
+    A t;
+    if (threadIdx.x < NRED)
+        for (int w = 0; w < kWaves; w++)
+            t.merge(sh[threadIdx.x][0][w], sh[threadIdx.x][1][w]);
+    return t;
+}
+
 // Reduce NRED accumulators over the whole grid.  Returns true in every thread of the LAST block,
 // with the grand totals in acc[] (valid in thread 0 only).
 template <int NRED, class A>
 __device__ __forceinline__ bool grid_reduce(A (&acc)[NRED], const RedWs& ws)
 {
     __shared__ double sh[NRED][2][kWaves];
+    __shared__ double sfin[NRED][2];
     __shared__ int s_last;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int G = gridDim.x;
+    const int tid = threadIdx.x;
 
-#pragma unroll
-    for (int r = 0; r < NRED; r++)
+    A mine = block_reduce_all<NRED, A>(acc, sh);
+    if (G > 1)
     {
+        if (tid < NRED)
+        {
+            st_agent(ws.partials + (size_t(tid) * 2 + 0) * ws.maxGrid + blockIdx.x, mine.hi);
+            st_agent(ws.partials + (size_t(tid) * 2 + 1) * ws.maxGrid + blockIdx.x, acc_lo(mine));
+            // release: the partials were stored write-through at agent scope (sc1), so draining the storing waves'
+            // stores orders them before the ticket; a full release fence would write back the whole XCD L2 --
+            // all the streaming data this launch just produced -- once per block (MI355X_MICROARCH.md, R1 form)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (tid == 0)
+        {
+            const unsigned old = __hip_atomic_fetch_add(ws.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (old == unsigned(G - 1));
+            if (last)
+                __threadfence();  // acquire side for this CU
+            s_last = last;
+        }
+        __syncthreads();
+        if (!s_last)
+            return false;
+
+        // last block: every thread gathers a strided share of the G partials of every sum (the loads of RB sums issued
+        // together: one sum at a time every sum pays a memory round trip of its own), then the block sum as above
+        constexpr int RB = 8;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1)
+        for (int r0 = 0; r0 < NRED; r0 += RB)
         {
-            const double ohi = __shfl_down(acc[r].hi, off, 64);
-            const double olo = __shfl_down(acc_lo(acc[r]), off, 64);
-            acc[r].merge(ohi, olo);
+            A t[RB];
+            for (int b = tid; b < G; b += kBlock)
+            {
+                double h[RB], l[RB];
+#pragma unroll
+                for (int j = 0; j < RB; j++)
+                    if (r0 + j < NRED)
+                    {
+                        h[j] = ld_agent(ws.partials + (size_t(r0 + j) * 2 + 0) * ws.maxGrid + b);
+                        l[j] = ld_agent(ws.partials + (size_t(r0 + j) * 2 + 1) * ws.maxGrid + b);
+                    }
+#pragma unroll
+                for (int j = 0; j < RB; j++)
+                    if (r0 + j < NRED)
+                        t[j].merge(h[j], l[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < RB; j++)
+                if (r0 + j < NRED)
+                    acc[r0 + j] = t[j];
         }
-        if (lane == 0)
-        {
-            sh[r][0][wave] = acc[r].hi;
-            sh[r][1][wave] = acc_lo(acc[r]);
-        }
+        __syncthreads();  // sh[] reuse
+        mine = block_reduce_all<NRED, A>(acc, sh);
+    }
+    if (tid < NRED)
+    {
+        sfin[tid][0] = mine.hi;
+        sfin[tid][1] = acc_lo(mine);
     }
     __syncthreads();
-    if (threadIdx.x == 0)
+    if (tid == 0)
     {
 #pragma unroll
         for (int r = 0; r < NRED; r++)
         {
             A t;
-            for (int w = 0; w < kWaves; w++)
-                t.merge(sh[r][0][w], sh[r][1][w]);
-            st_agent(ws.partials + (size_t(r) * 2 + 0) * ws.maxGrid + blockIdx.x, t.hi);
-            st_agent(ws.partials + (size_t(r) * 2 + 1) * ws.maxGrid + blockIdx.x, acc_lo(t));
-        }
-        // release: the partials were stored write-through at agent scope (sc1), so draining this wave's
-        // stores orders them before the ticket; a full release fence would write back the whole XCD L2 --
-        // all the streaming data this launch just produced -- once per block (MI355X_MICROARCH.md, R1 form)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned old = __hip_atomic_fetch_add(ws.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = (old == unsigned(G - 1));
-        if (last)
-            __threadfence();  // acquire side for this CU
-        s_last = last;
-    }
-    __syncthreads();
-    if (!s_last)
-        return false;
-
-    // last block: fixed-order re-reduction of the G partials
-#pragma unroll
-    for (int r = 0; r < NRED; r++)
-    {
-        A t;
-        for (int b = threadIdx.x; b < G; b += kBlock)
-            t.merge(ld_agent(ws.partials + (size_t(r) * 2 + 0) * ws.maxGrid + b),
-                    ld_agent(ws.partials + (size_t(r) * 2 + 1) * ws.maxGrid + b));
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1)
-        {
-            const double ohi = __shfl_down(t.hi, off, 64);
-            const double olo = __shfl_down(acc_lo(t), off, 64);
-            t.merge(ohi, olo);
-        }
-        acc[r] = t;
-    }
-    __syncthreads();  // sh[] reuse
-#pragma unroll
-    for (int r = 0; r < NRED; r++)
-        if (lane == 0)
-        {
-            sh[r][0][wave] = acc[r].hi;
-            sh[r][1][wave] = acc_lo(acc[r]);
-        }
-    __syncthreads();
-    if (threadIdx.x == 0)
-    {
-#pragma unroll
-        for (int r = 0; r < NRED; r++)
-        {
-            A t;
-            for (int w = 0; w < kWaves; w++)
-                t.merge(sh[r][0][w], sh[r][1][w]);
+            t.hi = sfin[r][0];
+            t.lo = sfin[r][1];
             acc[r] = t;
         }
-        __hip_atomic_store(ws.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+        if (G > 1)
+            __hip_atomic_store(ws.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
     }
     return true;
 }
