@@ -1,16 +1,20 @@
 // lbfgspp_amd/csrc/reduce.cuh -- device-side reduction machinery for gfx950 (wave64).
 //
 // Every O(n) kernel of the hot path ends in one or more grid-wide sums (dot products, norms, the
-// objective value).  Parity with the reference requires those sums to be independent of the
-// summation order (hard part 1), so f64 data is accumulated in double-double
-// (TwoProd via FMA + Knuth TwoSum, ~2^-104 relative error) and f32 data in f64; the result is
-// rounded to T exactly once.  The kernels are HBM-bound, the extra ~10 flop/element are free.
+// objective value).  Parity with the reference requires those sums not to depend on the summation
+// order (hard part 1), so f64 data is accumulated in double-double (TwoProd via
+// FMA + Knuth TwoSum, error ~2^-104 of the sum of the terms' magnitudes) and f32 data in f64; the
+// result is rounded to T exactly once.  That makes the rounded value independent of the order in
+// practice, not by theorem: two orders can round differently when the exact sum lies within that error
+// of a rounding boundary (or cancels by ~50 bits).  The kernels are HBM-bound, the extra ~10
+// flop/element are free.
 //
 // Grid-wide protocol (no float atomics, bit-reproducible for a fixed grid):
-//   per-thread accumulators -> wave64 __shfl_down tree -> LDS across the block's waves ->
-//   one partial per block stored with agent-scope (write-through) stores -> release fence +
-//   ticket atomic -> the last block to arrive acquires, re-reduces the partials in index order
-//   and publishes the rounded scalars.  (MI355X_MICROARCH.md "inter-workgroup visibility".)
+//   per-thread accumulators -> recursive halving across the 64 lanes (block_reduce_all) -> LDS
+//   across the block's waves -> thread r stores the block's partial of sum r with agent-scope
+//   (write-through) stores -> drain + ticket atomic -> the last block to arrive acquires, re-reduces
+//   the partials the same way and publishes the rounded scalars.
+//   (MI355X_MICROARCH.md "inter-workgroup visibility".)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
