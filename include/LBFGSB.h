@@ -56,10 +56,12 @@ public:
         double gcp_build_s = 0, gcp_fetch_s = 0, gcp_total_s = 0, submin_s = 0, linesearch_s = 0, correction_s = 0;
         long long gcp_dev_crossings = 0, gcp_sort_fallbacks = 0, gcp_partial_sorts = 0;
         long long submin_fused_sweeps = 0;
+        long long gram_carried = 0;  // first solves whose W_F'W_F came from the carried sums
     };
 
 private:
     Stats m_stats;
+    long long m_carried0 = 0;
 
     template <typename Foo, typename HostVec>
     int run(Foo& f, Scalar& fx)
@@ -71,6 +73,7 @@ private:
             ev.on_eval = [this](int k, Scalar v) { m_trace(k, v, m_dev); };
         lbfgsx_ctx* c = m_dev.ctx();
         m_stats = Stats();
+        m_carried0 = m_bfgs.carried_grams();
 
         detail::check(lbfgsx_b_force_bounds(c));                        // (:128)
         m_bfgs.reset(c, m_param.m);                                     // (:131)
@@ -168,6 +171,7 @@ private:
             m_stats.submin_sweeps += st.sweeps;
             m_stats.submin_unconverged += st.converged ? 0 : 1;
             m_stats.submin_fused_sweeps += st.fused_sweeps;
+            m_stats.gram_carried = m_bfgs.carried_grams() - m_carried0;
             if (m_trace_phases)
                 std::fprintf(stderr, "[lbfgsb] it %d: ls %.3f ms (cum) corr %.3f gcp %.3f (build %.3f fetch %.3f) submin %.3f | crossings %lld dev %lld sweeps %lld\n",
                              k, m_stats.linesearch_s * 1e3, m_stats.correction_s * 1e3, m_stats.gcp_total_s * 1e3,

@@ -10,6 +10,7 @@
 #ifndef LBFGSX_DROPIN_BFGSMAT_H
 #define LBFGSX_DROPIN_BFGSMAT_H
 
+#include <algorithm>
 #include <cstdlib>
 #include <vector>
 
@@ -36,6 +37,162 @@ class BFGSMatB
     // rows of L u U instead of the ~n/2 rows of P (both sums carry ~100 bits, the difference rounds like the direct sum)
     mutable std::vector<double> m_GF_dd;
     mutable bool m_GF_valid = false;
+    // The same sums carried from one iteration to the next.  Between two subspace minimisations add_correction replaces
+    // one storage slot (its Y and its S column) and a few rows enter or leave F, so of the 2c (2c + 1) / 2 entries only
+    // those of the two new columns need a pass over F -- together with the v row they are 6c <= 64 entries, one per lane,
+    // the cost of a v-row pass instead of the full Gram's -- and the others change by the outer products of the rows that
+    // moved (lbfgsx_b_free_delta, lbfgsx_b_gram_list_dd).  Everything stays un-rounded double-double, so the rounded
+    // entries are those of the direct sums (error ~2^-104 per update; a full pass every kCarryMaxAge iterations bounds
+    // what can build up).  Indexed by u = family * m + slot (family 0: Y, 1: S), lower triangle u >= v.
+    static constexpr int kCarryMaxAge = 32;
+    mutable std::vector<double> m_carry;      // [2m (2m + 1) / 2][2]
+    mutable std::vector<char> m_carry_col;    // [2m]: the column's entries describe its current content
+    mutable bool m_carry_valid = false;
+    mutable int m_carry_age = 0;
+    mutable long long m_carried = 0;
+
+    static bool carry_enabled()
+    {
+        const char* e = std::getenv("LBFGSX_GRAM_CARRY");
+        return !(e && std::atoi(e) == 0);
+    }
+    static size_t tri(int u, int v) { return u >= v ? size_t(u) * size_t(u + 1) / 2 + size_t(v) : size_t(v) * size_t(v + 1) / 2 + size_t(u); }
+    static void two_sum(double a, double b, double& s, double& e)
+    {
+        s = a + b;
+        const double bb = s - a;
+        e = (a - (s - bb)) + (b - bb);
+    }
+    // (h, l) += sign * (bh, bl), both double-doubles
+    static void dd_acc(double& h, double& l, double bh, double bl, double sign)
+    {
+        double s, e1, t, e2;
+        two_sum(h, sign * bh, s, e1);
+        two_sum(l, sign * bl, t, e2);
+        e1 += t;
+        double s2 = s + e1;
+        e1 = e1 - (s2 - s);
+        e1 += e2;
+        h = s2 + e1;
+        l = e1 - (h - s2);
+    }
+    int carry_index(int i) const { const int c = m_ncorr; return (i < c) ? i : m_m + (i - c); }  // logical column -> u
+    void carry_store(const std::vector<double>& packed_dd) const
+    {
+        const int t = 2 * m_ncorr;
+        m_carry.resize(size_t(2 * m_m) * size_t(2 * m_m + 1), 0.0);
+        m_carry_col.resize(size_t(2 * m_m), 0);
+        for (int i = 0; i < t; i++)
+            for (int j = 0; j <= i; j++)
+            {
+                const size_t e = size_t(i) * size_t(i + 1) / 2 + size_t(j), q = tri(carry_index(i), carry_index(j));
+                m_carry[2 * q] = packed_dd[2 * e];
+                m_carry[2 * q + 1] = packed_dd[2 * e + 1];
+            }
+        for (int i = 0; i < t; i++)
+            m_carry_col[size_t(carry_index(i))] = 1;
+    }
+    // W_F'W_F and W_F'v of the first solve from the carried sums; false: not possible now, take the full pass
+    bool carried_gram(int mask, std::int64_t nF, int vsel, int prologue, const double* coef1, const double* coef2,
+                      std::vector<double>& G, double* raw) const
+    {
+        const int c = m_ncorr, t = 2 * c;
+        std::int64_t ne = 0, nl = 0;
+        if (6 * c > 64)                                         // more entries than lanes: the full pass every time
+            return false;
+        if (lbfgsx_b_free_delta(m_c, &ne, &nl) != LBFGSX_OK)   // always: the remembered set must follow F
+            return false;
+        if (!m_carry_valid || m_carry_age >= kCarryMaxAge || m_carry_col.size() != size_t(2 * m_m) ||
+            (ne + nl) * 16 > nF || ne > (std::int64_t(1) << 14) || nl > (std::int64_t(1) << 14))
+            return false;
+        int ndirty = 0, ds = -1;
+        for (int j = 0; j < c; j++)
+            if (!m_carry_col[size_t(j)] || !m_carry_col[size_t(m_m + j)])
+            {
+                ndirty++;
+                ds = j;
+            }
+        if (ndirty > 1)
+            return false;
+        // entries that need the pass over F: rows of the two new columns (if any), then the v row
+        int pi[64], pj[64], np = 0;
+        if (ndirty == 1)
+        {
+            for (int J = 0; J < t; J++)
+            {
+                pi[np] = std::max(ds, J);
+                pj[np++] = std::min(ds, J);
+            }
+            for (int J = 0; J < t; J++)
+                if (J != ds)
+                {
+                    pi[np] = std::max(c + ds, J);
+                    pj[np++] = std::min(c + ds, J);
+                }
+        }
+        const int vrow = np;
+        for (int J = 0; J <= t; J++)
+        {
+            pi[np] = t;
+            pj[np++] = J;
+        }
+        std::vector<double> pd(size_t(2 * np), 0.0), edd, ldd;
+        if (lbfgsx_b_gram_pairs_dd(m_c, mask, vsel, prologue, coef1, coef2, np, pi, pj, pd.data()) != LBFGSX_OK)
+            return false;
+        if (ne > 0)
+        {
+            edd.assign(size_t(t) * size_t(t + 1), 0.0);
+            detail::check(lbfgsx_b_gram_list_dd(m_c, 0, edd.data()));
+        }
+        if (nl > 0)
+        {
+            ldd.assign(size_t(t) * size_t(t + 1), 0.0);
+            detail::check(lbfgsx_b_gram_list_dd(m_c, 1, ldd.data()));
+        }
+        m_GF_dd.assign(size_t(t) * size_t(t + 1), 0.0);
+        for (int i = 0; i < t; i++)
+            for (int j = 0; j <= i; j++)
+            {
+                const size_t e = size_t(i) * size_t(i + 1) / 2 + size_t(j), q = tri(carry_index(i), carry_index(j));
+                double h, l;
+                const bool fresh = ndirty == 1 && (i == ds || i == c + ds || j == ds || j == c + ds);
+                if (fresh)
+                {
+                    int k = -1;
+                    for (int z = 0; z < vrow; z++)
+                        if (pi[z] == i && pj[z] == j)
+                        {
+                            k = z;
+                            break;
+                        }
+                    h = pd[size_t(2 * k)];
+                    l = pd[size_t(2 * k + 1)];
+                }
+                else
+                {
+                    h = m_carry[2 * q];
+                    l = m_carry[2 * q + 1];
+                    if (ne > 0)
+                        dd_acc(h, l, edd[2 * e], edd[2 * e + 1], 1.0);
+                    if (nl > 0)
+                        dd_acc(h, l, ldd[2 * e], ldd[2 * e + 1], -1.0);
+                }
+                m_GF_dd[2 * e] = h;
+                m_GF_dd[2 * e + 1] = l;
+                m_carry[2 * q] = h;
+                m_carry[2 * q + 1] = l;
+                const double v = h + l;
+                G[size_t(i) * size_t(t) + size_t(j)] = v;
+                G[size_t(j) * size_t(t) + size_t(i)] = v;
+            }
+        for (int i = 0; i < t; i++)
+            m_carry_col[size_t(carry_index(i))] = 1;
+        for (int J = 0; J < t; J++)
+            raw[J] = pd[size_t(2 * (vrow + J))] + pd[size_t(2 * (vrow + J) + 1)];
+        m_carry_age++;
+        m_carried++;
+        return true;
+    }
 
     static double dd_sub_round(double ah, double al, double bh, double bl)
     {
@@ -64,6 +221,8 @@ public:
         m_ptr = m;
         m_pending = false;
         m_sweeps_expected = false;
+        m_carry_valid = false;
+        m_carry_col.assign(size_t(2 * m), 0);
         m_permMinv.assign(size_t(4) * size_t(m) * size_t(m), Scalar(0));
         for (int i = 0; i < 2 * m; i++)
             Minv(i, i) = Scalar(1);
@@ -91,6 +250,8 @@ public:
     {
         const int loc = m_ptr % m_m;
         detail::check(lbfgsx_commit_correction(m_c));
+        if (m_carry_col.size() == size_t(2 * m_m))   // the slot's two columns have new content
+            m_carry_col[size_t(loc)] = m_carry_col[size_t(m_m + loc)] = 0;
         m_theta = yy / sy;
         if (m_ncorr < m_m)
             m_ncorr++;
@@ -246,6 +407,7 @@ public:
     // `keep_as_F`: this is the solve over the whole free set; its un-rounded Gram is kept.  `comp_mask` / `ncomp`: the
     // sets that make up F \ mask and their size; when they are small the Gram comes from the complement identity above.
     void gram_cache_reset() const { m_GF_valid = false; }
+    long long carried_grams() const { return m_carried; }
     void solve_PtBP(int mask, std::int64_t nP, int vsel, int prologue = LBFGSX_GP_NONE, const double* coef1 = nullptr,
                     const double* coef2 = nullptr, std::vector<Scalar>* Fy = nullptr, int fy_mask = 0,
                     bool keep_as_F = false, int comp_mask = 0, std::int64_t ncomp = -1, std::int64_t* sweep = nullptr,
@@ -331,9 +493,22 @@ public:
         // one pass for W_P'W_P and W_P'v (and the prologue); the tiled VALU Gram is the fallback
         if (!fused && keep_as_F)
         {
-            m_GF_dd.assign(size_t(t) * size_t(t + 1), 0.0);
-            fused = (lbfgsx_b_gram_fused_dd(m_c, mask, vsel, prologue, coef1, coef2, G.data(), raw, m_GF_dd.data()) == LBFGSX_OK);
-            m_GF_valid = fused;
+            const bool carry = carry_enabled() && vsel >= 0;
+            if (carry && carried_gram(mask, nP, vsel, prologue, coef1, coef2, G, raw))
+                fused = m_GF_valid = true;
+            else
+            {
+                m_GF_dd.assign(size_t(t) * size_t(t + 1), 0.0);
+                fused = (lbfgsx_b_gram_fused_dd(m_c, mask, vsel, prologue, coef1, coef2, G.data(), raw, m_GF_dd.data()) == LBFGSX_OK);
+                m_GF_valid = fused;
+                m_carry_valid = false;
+                if (fused && carry && 6 * c <= 64)   // the remembered free set (lbfgsx_b_free_delta above) is the F of these sums
+                {
+                    carry_store(m_GF_dd);
+                    m_carry_valid = true;
+                    m_carry_age = 0;
+                }
+            }
         }
         if (!fused)
             fused = (lbfgsx_b_gram_fused_ex(m_c, mask, vsel, prologue, coef1, coef2, G.data(), raw) == LBFGSX_OK);

@@ -282,6 +282,23 @@ int lbfgsx_b_sub_sweep_begin(lbfgsx_ctx* c, int first, int64_t* nL, int64_t* nU,
  * apply_PtBQv statements of a BOXCQP sweep (SubspaceMin.h:236-241, BFGSMat.h:570-594) -- in one launch over the index list of
  * L u U.  LBFGSX_E_INVALID when there is no list or 2c > 24: call lbfgsx_b_wtv per set. */
 int lbfgsx_b_wtv_lu(lbfgsx_ctx* c, double* out_l, int64_t* nnz_l, double* out_u, int64_t* nnz_u);
+/* ---- pieces of the carried Gram of the free set (BFGSMatB::solve_PtBP): W_F'W_F of one iteration from that of the one
+ * before -- the entries of the columns add_correction replaced computed afresh, the others corrected by the outer products
+ * of the rows that entered or left F.  All sums un-rounded double-doubles (hi, lo).
+ *
+ * lbfgsx_b_free_delta: the rows whose membership of F (LBFGSX_ST_FREE) differs from what it was at the previous call (the
+ * first call: from the empty set) are put on two lists, their sizes returned (a size above 2^14 means: more than that, the
+ * list is not usable); the remembered set becomes the current one. */
+int lbfgsx_b_free_delta(lbfgsx_ctx* c, int64_t* n_enter, int64_t* n_leave);
+/* the 2c x 2c Gram of [Y S] over the rows of one of those lists (0: entered, 1: left), packed lower triangle
+ * e = i (i + 1) / 2 + j as lbfgsx_b_gram_fused_dd returns it; LBFGSX_E_INVALID for an empty or overflowed (> 2^14 rows) list */
+int lbfgsx_b_gram_list_dd(lbfgsx_ctx* c, int which, double* gram_dd);
+/* selected entries of [Y_P S_P v]'[Y_P S_P v] in one pass with the prologue of lbfgsx_b_gram_fused_ex: entry e is the
+ * product of the columns pair_i[e], pair_j[e] (0..2c-1: Y slots then S slots; 2c: v), at most 64 of them (one per lane:
+ * the cost of lbfgsx_b_wtv_prologue); out_dd[2 e], out_dd[2 e + 1] = (hi, lo).  Writes the compact copy of the free rows
+ * under the conditions of lbfgsx_b_set_compaction. */
+int lbfgsx_b_gram_pairs_dd(lbfgsx_ctx* c, int mask, int vsel, int prologue, const double* coef1, const double* coef2,
+                           int npairs, const int* pair_i, const int* pair_j, double* out_dd);
 /* Hint for the subspace minimisation that lbfgsx_b_sub_begin has just opened (which clears it): BOXCQP sweeps are expected,
  * so the full Gram pass of the first solve (lbfgsx_b_gram_fused_dd over LBFGSX_ST_FREE) may also write a compact copy of the
  * free rows of [Y S], and the passes of the sweeps (lbfgsx_b_wtv_prologue, lbfgsx_b_solve_sweep, the complement Grams) then

@@ -62,6 +62,13 @@ struct lbfgsb_state
     bool wf_valid = false;
     int64_t wf_n = 0;                     // rows in the copy
     int64_t nfree_last = 0;               // |F| of the last lbfgsx_b_cauchy_finish
+    // rows that entered / left the free set since the last lbfgsx_b_free_delta (the carried Gram of BFGSMatB::solve_PtBP)
+    unsigned char* fprev = nullptr;       // [n] free bit at that call
+    int* dl_enter = nullptr;              // [dl_cap]
+    int* dl_leave = nullptr;
+    unsigned* dl_cnt = nullptr;           // [2]
+    unsigned dl_cap = 0;
+    int64_t dl_n[2] = {0, 0};             // rows in the two lists, -1: the list overflowed
     double* g_host = nullptr;             // pinned landing zone of lbfgsx_b_cauchy_chunk
     size_t g_host_cap = 0;
     // chunk staging for the sequential GCP scan
@@ -298,6 +305,10 @@ void bounded_free(lbfgsx_ctx* c)
     if (b->g_host)
         (void) hipHostFree(b->g_host);
     (void) hipFree(b->lu_list);
+    (void) hipFree(b->fprev);
+    (void) hipFree(b->dl_enter);
+    (void) hipFree(b->dl_leave);
+    (void) hipFree(b->dl_cnt);
     (void) hipFree(b->wf);
     (void) hipFree(b->wf_idx);
     (void) hipFree(b->wf_cnt);
@@ -1486,7 +1497,7 @@ static int launch_gram_dd(lbfgsx_ctx* c, int64_t nbatch, int tot, int vsel_id, i
     int which[32];
     for (int k = 0; k < tot; k++)
         which[k] = k;
-    Cols<T, 32> cl = gr.in_idx ? wf_cols<T>(c, tot) : col_list<T, 32>(c, which, tot);
+    Cols<T, 32> cl = (gr.in_idx && !gr.w_by_row) ? wf_cols<T>(c, tot) : col_list<T, 32>(c, which, tot);
     hipLaunchKernelGGL((k_gram_dd<T, KP>), dim3(blocks), dim3(kBlock), lds, c->stream, cl, tot, bvecs<T>(c), vsel_id, mask,
                        nrows, b->gram_partial, pro, gr);
     return blocks;
@@ -1505,7 +1516,7 @@ static int launch_gram_vonly(lbfgsx_ctx* c, int64_t nbatch, int tot, int vsel_id
     int which[32];
     for (int k = 0; k < tot; k++)
         which[k] = k;
-    Cols<T, 32> cl = gr.in_idx ? wf_cols<T>(c, tot) : col_list<T, 32>(c, which, tot);
+    Cols<T, 32> cl = (gr.in_idx && !gr.w_by_row) ? wf_cols<T>(c, tot) : col_list<T, 32>(c, which, tot);
     hipLaunchKernelGGL((k_gram_dd<T, 1, CS, true>), dim3(blocks), dim3(kBlock), lds, c->stream, cl, tot, bvecs<T>(c), vsel_id,
                        mask, nrows, b->gram_partial, pro, gr);
     return blocks;
@@ -1544,7 +1555,7 @@ int lbfgsx_b_wtv_prologue(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, co
             pro.c1[k] = (coef1 && k < tot) ? T(coef1[k]) : T(0);
             pro.c2[k] = (coef2 && k < tot) ? T(coef2[k]) : T(0);
         }
-        GramRows<T> gr{compact ? b->wf_idx : nullptr, nullptr, 0, nullptr, nullptr, b->vonly_groups};
+        GramRows<T> gr{compact ? b->wf_idx : nullptr, nullptr, 0, nullptr, nullptr, b->vonly_groups, 0, 0, {0}, {0}};
         // the tile row stride must hold ntot columns: the strides of the full kernel's KP classes
         if (ntot <= 11) blocks = launch_gram_vonly<T, 11>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
         else if (ntot <= 15) blocks = launch_gram_vonly<T, 15>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
@@ -1572,6 +1583,125 @@ int lbfgsx_b_wtv_prologue(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, co
     return LBFGSX_OK;
 }
 
+static int gram_dd_core(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, const double* coef1, const double* coef2,
+                        double* gram, double* wtv, double* gram_dd, const int* list, int64_t nlist);
+int lbfgsx_b_free_delta(lbfgsx_ctx* c, int64_t* n_enter, int64_t* n_leave)
+{
+    lbfgsx::DeviceGuard dev_guard_(c->device);
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    lbfgsb_state* b = c->bstate;
+    if (!b->fprev)
+    {
+        b->dl_cap = unsigned(std::min<int64_t>(c->n, int64_t(1) << 14));
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->fprev), size_t(c->ld)));   // padded like the state bytes
+        LBFGSX_HIP(hipMemsetAsync(b->fprev, 0, size_t(c->ld), c->stream));
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->dl_enter), sizeof(int) * size_t(b->dl_cap)));
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->dl_leave), sizeof(int) * size_t(b->dl_cap)));
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->dl_cnt), sizeof(unsigned) * 2));
+    }
+    LBFGSX_HIP(hipMemsetAsync(b->dl_cnt, 0, sizeof(unsigned) * 2, c->stream));
+    const int64_t n8 = (c->n + 7) / 8;
+    const int grid = c->grid_for(n8);
+    hipLaunchKernelGGL(k_free_delta, dim3(grid), dim3(kBlock), 0, c->stream, b->st, b->fprev, n8, c->n, b->dl_enter, b->dl_leave,
+                       b->dl_cnt, b->dl_cap);
+    LBFGSX_HIP(hipGetLastError());
+    unsigned* h = static_cast<unsigned*>(c->hout);
+    LBFGSX_HIP(hipMemcpyAsync(h, b->dl_cnt, sizeof(unsigned) * 2, hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    for (int d = 0; d < 2; d++)
+        b->dl_n[d] = (h[d] <= b->dl_cap) ? int64_t(h[d]) : -1;
+    *n_enter = int64_t(h[0]);
+    *n_leave = int64_t(h[1]);
+    return LBFGSX_OK;
+}
+
+int lbfgsx_b_gram_list_dd(lbfgsx_ctx* c, int which, double* gram_dd)
+{
+    lbfgsx::DeviceGuard dev_guard_(c->device);
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    lbfgsb_state* b = c->bstate;
+    if (which < 0 || which > 1 || !b->fprev || b->dl_n[which] < 1 || !gram_dd)
+    {
+        set_error("lbfgsx_b_gram_list_dd: no such list (lbfgsx_b_free_delta first; an overflowed or empty list has no Gram)");
+        return LBFGSX_E_INVALID;
+    }
+    return gram_dd_core(c, 0, -1, LBFGSX_GP_NONE, nullptr, nullptr, nullptr, nullptr, gram_dd, which == 0 ? b->dl_enter : b->dl_leave,
+                        b->dl_n[which]);
+}
+
+int lbfgsx_b_gram_pairs_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, const double* coef1, const double* coef2,
+                           int npairs, const int* pair_i, const int* pair_j, double* out_dd)
+{
+    lbfgsx::DeviceGuard dev_guard_(c->device);
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    lbfgsb_state* b = c->bstate;
+    const int tot = 2 * c->ncorr, ntot = tot + 1;
+    if (tot < 1 || ntot > kGramDDCS || vsel_id < 0 || !out_dd || b->gram_mfma || b->gram_mode == 2 || npairs < 1 || npairs > 64 ||
+        prologue < LBFGSX_GP_NONE || prologue > LBFGSX_GP_LINEAR)
+    {
+        set_error("lbfgsx_b_gram_pairs_dd: needs the default one-pass Gram, 1 <= 2c <= 30, a vector selector and 1..64 entries");
+        return LBFGSX_E_INVALID;
+    }
+    for (int e = 0; e < npairs; e++)
+        if (pair_i[e] < 0 || pair_i[e] > tot || pair_j[e] < 0 || pair_j[e] > tot)
+        {
+            set_error("lbfgsx_b_gram_pairs_dd: entry outside the [Y S v] columns");
+            return LBFGSX_E_INVALID;
+        }
+    const bool compact_in = wf_serves(c, mask);
+    bool compact_out = !compact_in && b->wf_use && b->wf_on && mask == ST_FREE && !(b->gram_i8 && c->dtype == LBFGSX_F64) &&
+                       c->n < (int64_t(1) << 31) && b->nfree_last >= 4096 && b->nfree_last * 8 <= c->n * 7;
+    rc = upload_phys(c);
+    if (rc)
+        return rc;
+    if (compact_out)
+        compact_out = wf_prepare(c);
+    const int64_t nrows = compact_in ? b->wf_n : c->n;
+    const int64_t nbatch = (nrows + kGramDDRows - 1) / kGramDDRows;
+    int blocks = 1;
+    DISPATCH_T(c, {
+        GramPrologue<T> pro;
+        pro.mode = prologue;
+        pro.use1 = coef1 ? 1 : 0;
+        pro.use2 = coef2 ? 1 : 0;
+        for (int k = 0; k < 64; k++)
+        {
+            pro.c1[k] = (coef1 && k < tot) ? T(coef1[k]) : T(0);
+            pro.c2[k] = (coef2 && k < tot) ? T(coef2[k]) : T(0);
+        }
+        GramRows<T> gr{compact_in ? b->wf_idx : nullptr, compact_out ? static_cast<T*>(b->wf) : nullptr, b->wf_ld,
+                       compact_out ? b->wf_idx : nullptr, compact_out ? b->wf_base : nullptr, 1, 0, 1, {0}, {0}};
+        for (int e = 0; e < 64; e++)
+        {
+            gr.ti[e] = (unsigned char) (e < npairs ? pair_i[e] : 0);
+            gr.tj[e] = (unsigned char) (e < npairs ? pair_j[e] : 0);
+        }
+        if (ntot <= 11) blocks = launch_gram_vonly<T, 11>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
+        else if (ntot <= 15) blocks = launch_gram_vonly<T, 15>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
+        else if (ntot <= 23) blocks = launch_gram_vonly<T, 23>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
+        else if (ntot <= 27) blocks = launch_gram_vonly<T, 27>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
+        else blocks = launch_gram_vonly<T, 31>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
+    });
+    if (compact_out)
+    {
+        b->wf_valid = true;
+        b->wf_n = b->nfree_last;
+    }
+    const int nch = std::min(blocks, 32);
+    hipLaunchKernelGGL(k_gram_finish, dim3(1, nch), dim3(kBlock), 0, c->stream, b->gram_partial, blocks, b->gram_partial2, 0);
+    hipLaunchKernelGGL(k_gram_finish, dim3(1, 1), dim3(kBlock), 0, c->stream, b->gram_partial2, nch, b->gram_out, 1, b->gram_dd);
+    LBFGSX_HIP(hipGetLastError());
+    LBFGSX_HIP(hipMemcpyAsync(out_dd, b->gram_dd, sizeof(double) * 2 * size_t(npairs), hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    return LBFGSX_OK;
+}
+
 int lbfgsx_b_gram_fused(lbfgsx_ctx* c, int mask, int vsel_id, double* gram, double* wtv)
 {
     lbfgsx::DeviceGuard dev_guard_(c->device);
@@ -1589,6 +1719,13 @@ int lbfgsx_b_gram_fused_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
                            double* gram, double* wtv, double* gram_dd)
 {
     lbfgsx::DeviceGuard dev_guard_(c->device);
+    return gram_dd_core(c, mask, vsel_id, prologue, coef1, coef2, gram, wtv, gram_dd, nullptr, 0);
+}
+
+// list != nullptr: the Gram over the nlist rows of an index list (mask ignored, full-length columns read at those rows)
+static int gram_dd_core(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, const double* coef1, const double* coef2,
+                        double* gram, double* wtv, double* gram_dd, const int* list, int64_t nlist)
+{
     int rc = need_bounded(c);
     if (rc)
         return rc;
@@ -1665,18 +1802,20 @@ int lbfgsx_b_gram_fused_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
         return rc;
     // the pass over the whole free set that keeps its un-rounded sums is the first solve of a subspace minimisation: with
     // sweeps expected it also leaves the compact copy of the free rows (worth it when F leaves out a good part of the rows)
-    const bool compact_in = wf_serves(c, mask);
-    bool compact_out = !compact_in && b->wf_use && b->wf_on && gram_dd != nullptr && mask == ST_FREE && vsel_id >= 0 &&
+    if (list)
+        mask = 0;
+    const bool compact_in = !list && wf_serves(c, mask);
+    bool compact_out = !list && !compact_in && b->wf_use && b->wf_on && gram_dd != nullptr && mask == ST_FREE && vsel_id >= 0 &&
                        !(b->gram_i8 && c->dtype == LBFGSX_F64) && c->n < (int64_t(1) << 31) && b->nfree_last >= 4096 &&
                        b->nfree_last * 8 <= c->n * 7;
     if (compact_out)
         compact_out = wf_prepare(c);
-    const int64_t nrows = compact_in ? b->wf_n : c->n;
+    const int64_t nrows = list ? nlist : compact_in ? b->wf_n : c->n;
     const int64_t nbatch = (nrows + kGramDDRows - 1) / kGramDDRows;
     bool done_i8 = false;
     // the integer kernel pays a fixed cost per launch (per-wave partials, the integer tree): row sets that are not the
     // free set -- the sparse L u U complements of the BOXCQP sweeps -- stay on the double-double kernel
-    if (b->gram_i8 && c->dtype == LBFGSX_F64 && tot <= 30 && (mask == 0 || (mask & ST_FREE)))
+    if (!list && b->gram_i8 && c->dtype == LBFGSX_F64 && tot <= 30 && (mask == 0 || (mask & ST_FREE)))
     {
         GramPrologue<double> pro;
         pro.mode = prologue;
@@ -1706,8 +1845,8 @@ int lbfgsx_b_gram_fused_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
             pro.c1[k] = (coef1 && k < tot) ? T(coef1[k]) : T(0);
             pro.c2[k] = (coef2 && k < tot) ? T(coef2[k]) : T(0);
         }
-        GramRows<T> gr{compact_in ? b->wf_idx : nullptr, compact_out ? static_cast<T*>(b->wf) : nullptr, b->wf_ld,
-                       compact_out ? b->wf_idx : nullptr, compact_out ? b->wf_base : nullptr, 0};
+        GramRows<T> gr{list ? list : compact_in ? b->wf_idx : nullptr, compact_out ? static_cast<T*>(b->wf) : nullptr, b->wf_ld,
+                       compact_out ? b->wf_idx : nullptr, compact_out ? b->wf_base : nullptr, 0, list ? 1 : 0, 0, {0}, {0}};
         if (kp <= 1) blocks = launch_gram_dd<T, 1>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
         else if (kp <= 2) blocks = launch_gram_dd<T, 2>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
         else if (kp <= 4) blocks = launch_gram_dd<T, 4>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);

@@ -689,7 +689,79 @@ struct GramRows
     int* out_idx;
     const int* out_base;
     int vgroups;          // VONLY: 1 = one row per step for all lanes (the single-group form), 0 = as many groups as fit
+    int w_by_row;         // with in_idx: the columns are the full-length ones, read at row in_idx[t] (an index list of rows)
+    int use_table;        // VONLY: lane e accumulates the entry (ti[e], tj[e]) of the tile's columns instead of the v row
+    unsigned char ti[64], tj[64];
 };
+
+// rows whose membership of the free set changed since the last call (prev[] holds that call's free bits): appended to
+// the lists `enter` / `leave` in arrival order, counts in cnt[0..1]; prev := current.  Feeds the carried Gram of the free
+// set (BFGSMatB::solve_PtBP): W_F'W_F changes by the outer products of exactly these rows.
+__global__ void __launch_bounds__(kBlock) k_free_delta(const unsigned char* __restrict__ st, unsigned char* __restrict__ prev,
+                                                       int64_t n8 /* 8-row groups: ceil(n / 8), the arrays are padded */, int64_t n,
+                                                       int* __restrict__ enter, int* __restrict__ leave,
+                                                       unsigned* __restrict__ cnt, unsigned cap)
+{
+    // eight rows per lane (one 8-byte load of each array); a wavefront without a change -- nearly all of them in steady
+    // state -- is done after one ballot
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long* s8 = reinterpret_cast<const unsigned long long*>(st);
+    unsigned long long* p8 = reinterpret_cast<unsigned long long*>(prev);
+    for (int64_t v0 = (int64_t(blockIdx.x) * kBlock + threadIdx.x - lane); v0 < n8; v0 += stride)
+    {
+        const int64_t v = v0 + lane;
+        unsigned long long now = 0, was = 0;
+        if (v < n8)
+        {
+            now = s8[v] & 0x0101010101010101ull;  // ST_FREE = 1: the low bit of every state byte
+            was = p8[v];
+            const int64_t left = n - v * 8;       // rows of this group that exist
+            if (left < 8)
+                now &= (1ull << (8 * left)) - 1ull;
+        }
+        const unsigned long long diff = now ^ was;
+        if (__ballot(diff != 0ull) == 0ull)
+            continue;
+        if (diff)
+            p8[v] = now;
+        // one counter update per direction and wavefront: the lanes' counts are ranked by a prefix sum over the lanes
+#pragma unroll
+        for (int dir = 0; dir < 2; dir++)
+        {
+            const unsigned long long bits = (dir == 0) ? (now & ~was) : (was & ~now);  // one set bit per changed row (bit 8k)
+            const int mine = __popcll(bits);
+            int incl = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1)
+            {
+                const int o = __shfl_up(incl, off, 64);
+                if (lane >= off)
+                    incl += o;
+            }
+            const int total = __shfl(incl, 63, 64);
+            if (total == 0)
+                continue;
+            // a list that has overflowed is of no use: stop counting (millions of rows change in the first iterations)
+            if (__hip_atomic_load(cnt + dir, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > cap)
+                continue;
+            unsigned basep = 0;
+            if (lane == 63)
+                basep = atomicAdd(cnt + dir, unsigned(total));
+            basep = unsigned(__shfl(int(basep), 63, 64));
+            unsigned pos = basep + unsigned(incl - mine);
+            int* dst = (dir == 0) ? enter : leave;
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if ((bits >> (8 * k)) & 1ull)
+                {
+                    if (pos < cap)
+                        dst[pos] = int(v * 8 + k);
+                    pos++;
+                }
+        }
+    }
+}
 
 // free rows per 64-row batch (the exclusive prefix sum over it places the batch in the compact copy)
 __global__ void __launch_bounds__(kBlock) k_free_counts(const unsigned char* __restrict__ st, int64_t n, int64_t nbatch,
@@ -735,8 +807,8 @@ __global__ void __launch_bounds__(kBlock) k_gram_dd(Cols<T, 32> cols, int ncols,
     int pi[KP], pj[KP];
     // VONLY: the ntot entries of the v row fill ntot of the 64 lanes, so the lanes form vg = 64 / ntot groups that take
     // every vg-th row of the tile each (3 groups at m = 10); the groups' sums of an entry are merged after the loop
-    const int vg = (VONLY && gr.vgroups != 1 && 64 / ntot > 0) ? 64 / ntot : 1;
-    const int grp = VONLY ? lane / ntot : 0;
+    const int vg = (VONLY && gr.vgroups != 1 && !gr.use_table && 64 / ntot > 0) ? 64 / ntot : 1;
+    const int grp = (VONLY && !gr.use_table) ? lane / ntot : 0;
 #pragma unroll
     for (int k = 0; k < KP; k++)
     {
@@ -744,8 +816,8 @@ __global__ void __launch_bounds__(kBlock) k_gram_dd(Cols<T, 32> cols, int ncols,
         if (VONLY)
         {
             // entry e = (v, column e) for e < ncols, (v, v) for e == ncols; v is column `ncols` of the tile
-            pi[k] = ncols;
-            pj[k] = lane - grp * ntot;
+            pi[k] = gr.use_table ? int(gr.ti[lane]) : ncols;
+            pj[k] = gr.use_table ? int(gr.tj[lane]) : lane - grp * ntot;
             continue;
         }
         if (e >= npairs)
@@ -786,6 +858,7 @@ __global__ void __launch_bounds__(kBlock) k_gram_dd(Cols<T, 32> cols, int ncols,
         if (keep)
         {
             const int64_t r = gr.in_idx ? int64_t(gr.in_idx[rt]) : rt;  // row of the vectors
+            const int64_t wr = gr.w_by_row ? r : rt;                    // row of the columns
             double* row = tl + pos * cs;
             const int64_t ot = gr.out_w ? int64_t(gr.out_base[bt]) + pos : 0;
             if (gr.out_w)
@@ -796,7 +869,7 @@ __global__ void __launch_bounds__(kBlock) k_gram_dd(Cols<T, 32> cols, int ncols,
                 double v[8];
 #pragma unroll
                 for (int u = 0; u < 8; u++)
-                    v[u] = (c0 + u < ncols) ? double(cols.p[c0 + u][rt]) : 0.0;
+                    v[u] = (c0 + u < ncols) ? double(cols.p[c0 + u][wr]) : 0.0;
 #pragma unroll
                 for (int u = 0; u < 8; u++)
                     if (c0 + u < ncols)
@@ -900,7 +973,7 @@ __global__ void __launch_bounds__(kBlock) k_gram_dd(Cols<T, 32> cols, int ncols,
     for (int k = 0; k < KP; k++)
     {
         acc0[k].merge(acc1[k].hi, acc1[k].lo);
-        if (VONLY)
+        if (VONLY && !gr.use_table)
         {
             for (int g = 1; g < vg; g++)
             {

@@ -228,6 +228,7 @@ struct LbfgsbImpl : lbfgsx_solver
         stats2[4] = (long long) (st.linesearch_s * 1e6);
         stats2[5] = (long long) (st.correction_s * 1e6);
         stats2[6] = st.submin_fused_sweeps;
+        stats2[7] = st.gram_carried;
     }
 };
 

@@ -226,5 +226,5 @@ class LBFGSBSolver(_SolverBase):
         arr2 = (C.c_longlong * 8)()
         L.check(self._sol.lbfgsx_solver_stats2(self._h, C.byref(arr2)))
         d.update(zip(("gcp_dev_crossings", "gcp_sort_fallbacks", "gcp_partial_sorts", "submin_us", "linesearch_us",
-                      "correction_us", "submin_fused_sweeps"), list(arr2)[:7]))
+                      "correction_us", "submin_fused_sweeps", "gram_carried"), list(arr2)[:8]))
         return d

@@ -387,6 +387,39 @@ def test_compact_copy_of_the_free_rows_changes_no_bit(A, monkeypatch, n, m, max_
     assert np.array_equal(f[2], u[2]) and np.array_equal(f[3], u[3])
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("n,m,iters", [(70001, 8, 60), (70001, 10, 45), (65536, 3, 40), (90000, 12, 20), (200000, 10, 80)])
+def test_carried_gram_of_the_free_set_changes_no_bit(A, monkeypatch, n, m, iters, dtype):
+    """W_F'W_F of the first BOXCQP solve from the sums of the previous iteration -- the rows of the two replaced columns
+    computed afresh, the other entries corrected by the outer products of the rows that entered or left the free set, all
+    in double-double (BFGSMatB::carried_gram) -- against the full Gram pass every iteration (LBFGSX_GRAM_CARRY=0): the
+    rounded entries are the same, so the trajectory is bit for bit the same; for m <= 10 the carried form must have run
+    (m = 12 has more entries than lanes and always takes the full pass), across its periodic refresh (every 32
+    iterations) and the growth of the history."""
+    dt = O.F64 if dtype == "f64" else O.F32
+    npdt = O.NPDT[dt]
+    a, b = O.quad_problem(n, 30.0, 11, dt)
+    res = {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("LBFGSX_GRAM_CARRY", on)
+        s = A.LBFGSBSolver(A.LBFGSBParam(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters), dtype=npdt)
+        tr = A.TraceBuffer(n, cap=512, stride=29)
+        x = np.zeros(n, dtype=npdt)
+        try:
+            niter, fx = s.minimize(A.DiagQuadratic(a, b), x, (-0.7 * np.ones(n)).astype(npdt), (0.9 * np.ones(n)).astype(npdt),
+                                   trace=tr)
+        except RuntimeError:
+            niter, fx = -1, float("nan")
+        st = s.stats()
+        res[on] = (niter, s.last.nfev, x.copy(), tr.xs[:tr.count].copy(), st["submin_sweeps"], st["gram_carried"], st["submin_calls"])
+    f, u = res["1"], res["0"]
+    assert f[:2] == u[:2] and f[4] == u[4]
+    assert np.array_equal(f[2], u[2]) and np.array_equal(f[3], u[3])
+    assert u[5] == 0
+    if m <= 10 and dtype == "f64":
+        assert f[5] >= f[6] // 3, "the carried form ran in %d of %d subspace minimisations" % (f[5], f[6])
+
+
 @pytest.mark.parametrize("m", [3, 5, 8, 10, 12])
 def test_deferred_correction_dots_change_no_bit(A, monkeypatch, m):
     """add_correction's S's_new / s_new.y_j dots taken by the W'd pass of the following Cauchy search
