@@ -56,6 +56,11 @@ class BFGSMatB
         const char* e = std::getenv("LBFGSX_GRAM_CARRY");
         return !(e && std::atoi(e) == 0);
     }
+    static bool keep_copy_enabled()
+    {
+        const char* e = std::getenv("LBFGSX_COMPACT_KEEP");
+        return !(e && std::atoi(e) == 0);
+    }
     static size_t tri(int u, int v) { return u >= v ? size_t(u) * size_t(u + 1) / 2 + size_t(v) : size_t(v) * size_t(v + 1) / 2 + size_t(u); }
     static void two_sum(double a, double b, double& s, double& e)
     {
@@ -137,7 +142,8 @@ class BFGSMatB
             pj[np++] = J;
         }
         std::vector<double> pd(size_t(2 * np), 0.0), edd, ldd;
-        if (lbfgsx_b_gram_pairs_dd(m_c, mask, vsel, prologue, coef1, coef2, np, pi, pj, pd.data()) != LBFGSX_OK)
+        if (lbfgsx_b_gram_pairs_dd(m_c, mask, vsel, prologue, coef1, coef2, np, pi, pj, keep_copy_enabled() ? (ndirty == 1 ? ds : -1) : -2,
+                                   pd.data()) != LBFGSX_OK)
             return false;
         if (ne > 0)
         {

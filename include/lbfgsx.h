@@ -298,7 +298,12 @@ int lbfgsx_b_gram_list_dd(lbfgsx_ctx* c, int which, double* gram_dd);
  * the cost of lbfgsx_b_wtv_prologue); out_dd[2 e], out_dd[2 e + 1] = (hi, lo).  Writes the compact copy of the free rows
  * under the conditions of lbfgsx_b_set_compaction. */
 int lbfgsx_b_gram_pairs_dd(lbfgsx_ctx* c, int mask, int vsel, int prologue, const double* coef1, const double* coef2,
-                           int npairs, const int* pair_i, const int* pair_j, double* out_dd);
+                           int npairs, const int* pair_i, const int* pair_j, int refresh_slot, double* out_dd);
+/* refresh_slot >= -1: the caller vouches that since the previous subspace minimisation the history changed in at most the
+ * storage slot `refresh_slot` (-1: not at all) and that lbfgsx_b_free_delta has been called for the current free set.  The
+ * pass may then read the compact copy of the free rows it KEPT from that minimisation (rows that entered F were appended by
+ * lbfgsx_b_free_delta, rows that left are skipped through their state byte) and only rewrites the two columns of that slot
+ * in it, instead of reading every row of the 2c columns through the mask and writing the copy afresh.  -2: never. */
 /* Hint for the subspace minimisation that lbfgsx_b_sub_begin has just opened (which clears it): BOXCQP sweeps are expected,
  * so the full Gram pass of the first solve (lbfgsx_b_gram_fused_dd over LBFGSX_ST_FREE) may also write a compact copy of the
  * free rows of [Y S], and the passes of the sweeps (lbfgsx_b_wtv_prologue, lbfgsx_b_solve_sweep, the complement Grams) then

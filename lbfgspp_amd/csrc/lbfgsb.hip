@@ -69,6 +69,11 @@ struct lbfgsb_state
     unsigned* dl_cnt = nullptr;           // [2]
     unsigned dl_cap = 0;
     int64_t dl_n[2] = {0, 0};             // rows in the two lists, -1: the list overflowed
+    // the compact copy kept across iterations (the carried first solve): a superset of the free rows, every column current
+    // except those the caller names when it uses it
+    bool wf_live = false;
+    int wf_ncorr = 0;                     // history size the copy's column order belongs to (Y slots, then S slots)
+    int* wf_pos = nullptr;                // [n] row -> position, -1: none
     double* g_host = nullptr;             // pinned landing zone of lbfgsx_b_cauchy_chunk
     size_t g_host_cap = 0;
     // chunk staging for the sequential GCP scan
@@ -305,6 +310,7 @@ void bounded_free(lbfgsx_ctx* c)
     if (b->g_host)
         (void) hipHostFree(b->g_host);
     (void) hipFree(b->lu_list);
+    (void) hipFree(b->wf_pos);
     (void) hipFree(b->fprev);
     (void) hipFree(b->dl_enter);
     (void) hipFree(b->dl_leave);
@@ -380,6 +386,7 @@ static bool wf_prepare(lbfgsx_ctx* c)
         size_t bytes = 0;
         bool ok = hipMalloc(&b->wf, esz * size_t(b->wf_ld) * 32) == hipSuccess &&
                   hipMalloc(reinterpret_cast<void**>(&b->wf_idx), sizeof(int) * size_t(c->n)) == hipSuccess &&
+                  hipMalloc(reinterpret_cast<void**>(&b->wf_pos), sizeof(int) * size_t(c->n)) == hipSuccess &&
                   hipMalloc(reinterpret_cast<void**>(&b->wf_cnt), sizeof(int) * size_t(nbatch + 2)) == hipSuccess &&
                   hipMalloc(reinterpret_cast<void**>(&b->wf_base), sizeof(int) * size_t(nbatch + 2)) == hipSuccess &&
                   rocprim::exclusive_scan(nullptr, bytes, b->wf_cnt, b->wf_base, 0, size_t(nbatch + 1), rocprim::plus<int>(),
@@ -394,11 +401,18 @@ static bool wf_prepare(lbfgsx_ctx* c)
             (void) hipFree(b->wf_cnt);
             (void) hipFree(b->wf_base);
             (void) hipFree(b->wf_tmp);
+            (void) hipFree(b->wf_pos);
             b->wf = b->wf_tmp = nullptr;
-            b->wf_idx = b->wf_cnt = b->wf_base = nullptr;
+            b->wf_idx = b->wf_cnt = b->wf_base = b->wf_pos = nullptr;
             b->wf_use = false;  // no room for the copy: the masked passes do the work
             return false;
         }
+    }
+    b->wf_live = false;
+    if (hipMemsetAsync(b->wf_pos, 0xFF, sizeof(int) * size_t(c->n), c->stream) != hipSuccess)  // every position -1
+    {
+        (void) hipGetLastError();
+        return false;
     }
     const int grid = int(std::min<int64_t>(c->grid_for(c->n), (nbatch + 4) / 4));
     hipLaunchKernelGGL(k_free_counts, dim3(std::max(1, grid)), dim3(kBlock), 0, c->stream, c->bstate->st, c->n, nbatch, b->wf_cnt);
@@ -410,6 +424,16 @@ static bool wf_prepare(lbfgsx_ctx* c)
         return false;
     }
     return true;
+}
+
+// after a pass has written the compact copy afresh: usable now, and kept for the next iteration's carried first solve
+static void wf_rebuilt(lbfgsx_ctx* c)
+{
+    lbfgsb_state* b = c->bstate;
+    b->wf_valid = true;
+    b->wf_n = b->nfree_last;
+    b->wf_live = true;
+    b->wf_ncorr = c->ncorr;
 }
 
 // raw masked W'v for all 2*ncorr columns: out[0..c) = Y_j . v, out[c..2c) = S_j . v ; nnz of v inside the mask
@@ -1555,7 +1579,9 @@ int lbfgsx_b_wtv_prologue(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, co
             pro.c1[k] = (coef1 && k < tot) ? T(coef1[k]) : T(0);
             pro.c2[k] = (coef2 && k < tot) ? T(coef2[k]) : T(0);
         }
-        GramRows<T> gr{compact ? b->wf_idx : nullptr, nullptr, 0, nullptr, nullptr, b->vonly_groups, 0, 0, {0}, {0}};
+        GramRows<T> gr{};
+        gr.in_idx = compact ? b->wf_idx : nullptr;
+        gr.vgroups = b->vonly_groups;
         // the tile row stride must hold ntot columns: the strides of the full kernel's KP classes
         if (ntot <= 11) blocks = launch_gram_vonly<T, 11>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
         else if (ntot <= 15) blocks = launch_gram_vonly<T, 15>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
@@ -1599,19 +1625,47 @@ int lbfgsx_b_free_delta(lbfgsx_ctx* c, int64_t* n_enter, int64_t* n_leave)
         LBFGSX_HIP(hipMemsetAsync(b->fprev, 0, size_t(c->ld), c->stream));
         LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->dl_enter), sizeof(int) * size_t(b->dl_cap)));
         LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->dl_leave), sizeof(int) * size_t(b->dl_cap)));
-        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->dl_cnt), sizeof(unsigned) * 2));
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->dl_cnt), sizeof(unsigned) * 4));
     }
-    LBFGSX_HIP(hipMemsetAsync(b->dl_cnt, 0, sizeof(unsigned) * 2, c->stream));
+    if (b->wf_live && b->wf_ncorr != c->ncorr)
+        b->wf_live = false;  // the history has grown: another column order
+    // {rows entered, rows left, rows in the kept compact copy, 1: the copy cannot be kept}
+    const unsigned init[4] = {0u, 0u, unsigned(b->wf_live ? b->wf_n : 0), 0u};
+    LBFGSX_HIP(hipMemcpyAsync(b->dl_cnt, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
     const int64_t n8 = (c->n + 7) / 8;
     const int grid = c->grid_for(n8);
     hipLaunchKernelGGL(k_free_delta, dim3(grid), dim3(kBlock), 0, c->stream, b->st, b->fprev, n8, c->n, b->dl_enter, b->dl_leave,
                        b->dl_cnt, b->dl_cap);
     LBFGSX_HIP(hipGetLastError());
+    if (b->wf_live)
+    {
+        // rows new to the free set join the kept compact copy
+        rc = upload_phys(c);
+        if (rc)
+            return rc;
+        const int total = 2 * c->ncorr;
+        int which[32];
+        for (int k = 0; k < total; k++)
+            which[k] = k;
+        DISPATCH_T(c, {
+            Cols<T, 32> cl = col_list<T, 32>(c, which, total);
+            hipLaunchKernelGGL((k_wf_append<T>), dim3(16), dim3(kBlock), 0, c->stream, cl, total, static_cast<T*>(b->wf), b->wf_ld,
+                               b->wf_idx, b->wf_pos, b->dl_enter, b->dl_cnt, b->dl_cap, unsigned(std::min<int64_t>(c->n, b->wf_ld)));
+        });
+        LBFGSX_HIP(hipGetLastError());
+    }
     unsigned* h = static_cast<unsigned*>(c->hout);
-    LBFGSX_HIP(hipMemcpyAsync(h, b->dl_cnt, sizeof(unsigned) * 2, hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(hipMemcpyAsync(h, b->dl_cnt, sizeof(unsigned) * 4, hipMemcpyDeviceToHost, c->stream));
     LBFGSX_HIP(hipStreamSynchronize(c->stream));
     for (int d = 0; d < 2; d++)
         b->dl_n[d] = (h[d] <= b->dl_cap) ? int64_t(h[d]) : -1;
+    if (b->wf_live)
+    {
+        if (h[3])
+            b->wf_live = false;
+        else
+            b->wf_n = int64_t(h[2]);
+    }
     *n_enter = int64_t(h[0]);
     *n_leave = int64_t(h[1]);
     return LBFGSX_OK;
@@ -1634,7 +1688,7 @@ int lbfgsx_b_gram_list_dd(lbfgsx_ctx* c, int which, double* gram_dd)
 }
 
 int lbfgsx_b_gram_pairs_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, const double* coef1, const double* coef2,
-                           int npairs, const int* pair_i, const int* pair_j, double* out_dd)
+                           int npairs, const int* pair_i, const int* pair_j, int refresh_slot, double* out_dd)
 {
     lbfgsx::DeviceGuard dev_guard_(c->device);
     int rc = need_bounded(c);
@@ -1654,7 +1708,18 @@ int lbfgsx_b_gram_pairs_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
             set_error("lbfgsx_b_gram_pairs_dd: entry outside the [Y S v] columns");
             return LBFGSX_E_INVALID;
         }
-    const bool compact_in = wf_serves(c, mask);
+    if (refresh_slot < -2 || refresh_slot >= c->ncorr)
+    {
+        set_error("lbfgsx_b_gram_pairs_dd: refresh_slot is a storage slot, -1 (nothing replaced) or -2 (no kept copy)");
+        return LBFGSX_E_INVALID;
+    }
+    // the copy kept from the previous iteration serves when the caller vouches for the history (refresh_slot >= -1), the
+    // mask is the free set and the copy is not overgrown with rows that have left it
+    const bool kept = refresh_slot >= -1 && b->wf_live && b->wf_use && mask == ST_FREE && b->wf_n * 8 <= b->nfree_last * 9 &&
+                      b->wf_n >= b->nfree_last;
+    if (!kept)
+        b->wf_live = false;
+    const bool compact_in = kept || wf_serves(c, mask);
     bool compact_out = !compact_in && b->wf_use && b->wf_on && mask == ST_FREE && !(b->gram_i8 && c->dtype == LBFGSX_F64) &&
                        c->n < (int64_t(1) << 31) && b->nfree_last >= 4096 && b->nfree_last * 8 <= c->n * 7;
     rc = upload_phys(c);
@@ -1675,8 +1740,27 @@ int lbfgsx_b_gram_pairs_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
             pro.c1[k] = (coef1 && k < tot) ? T(coef1[k]) : T(0);
             pro.c2[k] = (coef2 && k < tot) ? T(coef2[k]) : T(0);
         }
-        GramRows<T> gr{compact_in ? b->wf_idx : nullptr, compact_out ? static_cast<T*>(b->wf) : nullptr, b->wf_ld,
-                       compact_out ? b->wf_idx : nullptr, compact_out ? b->wf_base : nullptr, 1, 0, 1, {0}, {0}};
+        GramRows<T> gr{};
+        gr.in_idx = compact_in ? b->wf_idx : nullptr;
+        gr.vgroups = 1;
+        gr.use_table = 1;
+        if (compact_out)
+        {
+            gr.out_w = static_cast<T*>(b->wf);
+            gr.out_ld = b->wf_ld;
+            gr.out_idx = b->wf_idx;
+            gr.out_base = b->wf_base;
+            gr.out_pos = b->wf_pos;
+        }
+        if (kept && refresh_slot >= 0)
+        {
+            gr.fresh_a = refresh_slot;
+            gr.fresh_b = c->ncorr + refresh_slot;
+            gr.src_a = static_cast<const T*>(c->col(c->Y, c->phys[size_t(refresh_slot)]));
+            gr.src_b = static_cast<const T*>(c->col(c->S, c->phys[size_t(refresh_slot)]));
+            gr.dst_a = static_cast<T*>(b->wf) + int64_t(gr.fresh_a) * b->wf_ld;
+            gr.dst_b = static_cast<T*>(b->wf) + int64_t(gr.fresh_b) * b->wf_ld;
+        }
         for (int e = 0; e < 64; e++)
         {
             gr.ti[e] = (unsigned char) (e < npairs ? pair_i[e] : 0);
@@ -1689,10 +1773,9 @@ int lbfgsx_b_gram_pairs_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
         else blocks = launch_gram_vonly<T, 31>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
     });
     if (compact_out)
-    {
-        b->wf_valid = true;
-        b->wf_n = b->nfree_last;
-    }
+        wf_rebuilt(c);
+    if (kept)
+        b->wf_valid = true;  // usable by the passes of this subspace minimisation
     const int nch = std::min(blocks, 32);
     hipLaunchKernelGGL(k_gram_finish, dim3(1, nch), dim3(kBlock), 0, c->stream, b->gram_partial, blocks, b->gram_partial2, 0);
     hipLaunchKernelGGL(k_gram_finish, dim3(1, 1), dim3(kBlock), 0, c->stream, b->gram_partial2, nch, b->gram_out, 1, b->gram_dd);
@@ -1845,8 +1928,17 @@ static int gram_dd_core(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, cons
             pro.c1[k] = (coef1 && k < tot) ? T(coef1[k]) : T(0);
             pro.c2[k] = (coef2 && k < tot) ? T(coef2[k]) : T(0);
         }
-        GramRows<T> gr{list ? list : compact_in ? b->wf_idx : nullptr, compact_out ? static_cast<T*>(b->wf) : nullptr, b->wf_ld,
-                       compact_out ? b->wf_idx : nullptr, compact_out ? b->wf_base : nullptr, 0, list ? 1 : 0, 0, {0}, {0}};
+        GramRows<T> gr{};
+        gr.in_idx = list ? list : compact_in ? b->wf_idx : nullptr;
+        gr.w_by_row = list ? 1 : 0;
+        if (compact_out)
+        {
+            gr.out_w = static_cast<T*>(b->wf);
+            gr.out_ld = b->wf_ld;
+            gr.out_idx = b->wf_idx;
+            gr.out_base = b->wf_base;
+            gr.out_pos = b->wf_pos;
+        }
         if (kp <= 1) blocks = launch_gram_dd<T, 1>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
         else if (kp <= 2) blocks = launch_gram_dd<T, 2>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
         else if (kp <= 4) blocks = launch_gram_dd<T, 4>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
@@ -1854,10 +1946,7 @@ static int gram_dd_core(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, cons
         else blocks = launch_gram_dd<T, 8>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
     });
     if (compact_out)
-    {
-        b->wf_valid = true;
-        b->wf_n = b->nfree_last;
-    }
+        wf_rebuilt(c);
     const int nch = std::min(blocks, 32);
     hipLaunchKernelGGL(k_gram_finish, dim3(ntile_, nch), dim3(kBlock), 0, c->stream, b->gram_partial, blocks, b->gram_partial2, 0);
     hipLaunchKernelGGL(k_gram_finish, dim3(ntile_, 1), dim3(kBlock), 0, c->stream, b->gram_partial2, nch, b->gram_out, 1,

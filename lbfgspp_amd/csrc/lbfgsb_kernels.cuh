@@ -692,7 +692,48 @@ struct GramRows
     int w_by_row;         // with in_idx: the columns are the full-length ones, read at row in_idx[t] (an index list of rows)
     int use_table;        // VONLY: lane e accumulates the entry (ti[e], tj[e]) of the tile's columns instead of the v row
     unsigned char ti[64], tj[64];
+    int* out_pos;         // with out_w: row -> position in the copy
+    // with in_idx (the copy kept from the previous iteration): the two columns of the storage slot add_correction has
+    // replaced since are read from the full-length columns and written to the copy on every row it holds
+    int fresh_a, fresh_b;         // their tile columns
+    const T *src_a, *src_b;
+    T *dst_a, *dst_b;
 };
+
+// Rows that entered the free set and have no position in the kept compact copy yet (GramRows) are appended to it: all 2c
+// columns gathered from the full-length ones.  A row that was in the copy before (it left F and came back) still has its
+// position -- the passes skip positions whose row is not free, and every replaced column is rewritten on all positions --
+// so it needs nothing.  cnt[0] = entries of `enter`, cnt[2] = rows in the copy (updated), cnt[3] = 1: the copy cannot
+// be kept (list overflow, no room).
+template <class T>
+__global__ void __launch_bounds__(kBlock) k_wf_append(Cols<T, 32> orig, int ncols, T* __restrict__ wf, int64_t wf_ld,
+                                                      int* __restrict__ wf_idx, int* __restrict__ pos, const int* __restrict__ enter,
+                                                      unsigned* __restrict__ cnt, unsigned cap, unsigned wf_cap)
+{
+    const unsigned ne = __hip_atomic_load(cnt + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ne > cap)
+    {
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            cnt[3] = 1u;
+        return;
+    }
+    for (unsigned e = blockIdx.x * kBlock + threadIdx.x; e < ne; e += gridDim.x * kBlock)
+    {
+        const int row = enter[e];
+        if (pos[row] >= 0)
+            continue;
+        const unsigned slot = atomicAdd(cnt + 2, 1u);
+        if (slot >= wf_cap)
+        {
+            cnt[3] = 1u;
+            continue;
+        }
+        wf_idx[slot] = row;
+        pos[row] = int(slot);
+        for (int k = 0; k < ncols; k++)
+            wf[int64_t(k) * wf_ld + slot] = orig.p[k][row];
+    }
+}
 
 // rows whose membership of the free set changed since the last call (prev[] holds that call's free bits): appended to
 // the lists `enter` / `leave` in arrival order, counts in cnt[0..1]; prev := current.  Feeds the carried Gram of the free
@@ -850,6 +891,15 @@ __global__ void __launch_bounds__(kBlock) k_gram_dd(Cols<T, 32> cols, int ncols,
             break;
         const int64_t rt = bt * kGramDDRows + lane;  // row of the columns
         const bool keep = rt < n && (!mask || (st4[u] & mask));
+        T fa = T(0), fb = T(0);
+        if (gr.dst_a && rt < n)
+        {
+            const int64_t rr = int64_t(gr.in_idx[rt]);
+            fa = gr.src_a[rr];
+            fb = gr.src_b[rr];
+            gr.dst_a[rt] = fa;
+            gr.dst_b[rt] = fb;
+        }
         const unsigned long long bal = __ballot(keep);
         const int cnt = __popcll(bal);
         if (cnt == 0)
@@ -862,7 +912,11 @@ __global__ void __launch_bounds__(kBlock) k_gram_dd(Cols<T, 32> cols, int ncols,
             double* row = tl + pos * cs;
             const int64_t ot = gr.out_w ? int64_t(gr.out_base[bt]) + pos : 0;
             if (gr.out_w)
+            {
                 gr.out_idx[ot] = int(r);
+                if (gr.out_pos)
+                    gr.out_pos[r] = int(ot);
+            }
             for (int c0 = 0; c0 < ncols; c0 += 8)
             {
                 // eight independent loads in flight per lane
@@ -878,6 +932,11 @@ __global__ void __launch_bounds__(kBlock) k_gram_dd(Cols<T, 32> cols, int ncols,
                         if (gr.out_w)
                             gr.out_w[int64_t(c0 + u) * gr.out_ld + ot] = T(v[u]);
                     }
+            }
+            if (gr.dst_a)
+            {
+                row[gr.fresh_a] = double(fa);
+                row[gr.fresh_b] = double(fb);
             }
             if (pro.mode != GP_NONE)
             {

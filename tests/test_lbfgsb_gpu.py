@@ -400,8 +400,11 @@ def test_carried_gram_of_the_free_set_changes_no_bit(A, monkeypatch, n, m, iters
     npdt = O.NPDT[dt]
     a, b = O.quad_problem(n, 30.0, 11, dt)
     res = {}
-    for on in ("1", "0"):
-        monkeypatch.setenv("LBFGSX_GRAM_CARRY", on)
+    for on in ("1", "0", "nokeep"):
+        # "nokeep": carried sums, but the compact copy of the free rows is written afresh every iteration instead of being
+        # kept and patched (the rows that entered F appended, the replaced slot's two columns rewritten)
+        monkeypatch.setenv("LBFGSX_GRAM_CARRY", "0" if on == "0" else "1")
+        monkeypatch.setenv("LBFGSX_COMPACT_KEEP", "0" if on == "nokeep" else "1")
         s = A.LBFGSBSolver(A.LBFGSBParam(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters), dtype=npdt)
         tr = A.TraceBuffer(n, cap=512, stride=29)
         x = np.zeros(n, dtype=npdt)
@@ -412,10 +415,11 @@ def test_carried_gram_of_the_free_set_changes_no_bit(A, monkeypatch, n, m, iters
             niter, fx = -1, float("nan")
         st = s.stats()
         res[on] = (niter, s.last.nfev, x.copy(), tr.xs[:tr.count].copy(), st["submin_sweeps"], st["gram_carried"], st["submin_calls"])
-    f, u = res["1"], res["0"]
+    f, u, k = res["1"], res["0"], res["nokeep"]
     assert f[:2] == u[:2] and f[4] == u[4]
     assert np.array_equal(f[2], u[2]) and np.array_equal(f[3], u[3])
-    assert u[5] == 0
+    assert k[:2] == u[:2] and k[4] == u[4] and np.array_equal(k[2], u[2]) and np.array_equal(k[3], u[3])
+    assert u[5] == 0 and k[5] == f[5]
     if m <= 10 and dtype == "f64":
         assert f[5] >= f[6] // 3, "the carried form ran in %d of %d subspace minimisations" % (f[5], f[6])
 
