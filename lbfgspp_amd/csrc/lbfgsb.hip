@@ -1887,6 +1887,22 @@ static int gram_dd_core(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, cons
     // sweeps expected it also leaves the compact copy of the free rows (worth it when F leaves out a good part of the rows)
     if (list)
         mask = 0;
+    else if (b->lu_valid && b->lu_use && vsel_id < 0 && prologue == LBFGSX_GP_NONE && mask != 0 && (mask & ~(ST_L | ST_U)) == 0 &&
+             !b->gram_mfma)
+    {
+        // the complement Gram of a BOXCQP sweep (rows of L u U): walk the index list of the partition instead of the state
+        // bytes of every (free) row; the mask stays, the list may hold rows of the other set
+        if (b->lu_n < 1)
+        {
+            if (gram)
+                std::fill(gram, gram + size_t(tot) * size_t(tot), 0.0);
+            if (gram_dd)
+                std::fill(gram_dd, gram_dd + size_t(tot) * size_t(tot + 1), 0.0);
+            return LBFGSX_OK;
+        }
+        list = b->lu_ptr();
+        nlist = b->lu_n;
+    }
     const bool compact_in = !list && wf_serves(c, mask);
     bool compact_out = !list && !compact_in && b->wf_use && b->wf_on && gram_dd != nullptr && mask == ST_FREE && vsel_id >= 0 &&
                        !(b->gram_i8 && c->dtype == LBFGSX_F64) && c->n < (int64_t(1) << 31) && b->nfree_last >= 4096 &&
