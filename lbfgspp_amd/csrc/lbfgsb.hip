@@ -62,6 +62,8 @@ struct lbfgsb_state
     bool wf_valid = false;
     int64_t wf_n = 0;                     // rows in the copy
     int64_t nfree_last = 0;               // |F| of the last lbfgsx_b_cauchy_finish
+    hipEvent_t chain_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // pieces of a Cauchy chunk
+    int chain_pieces = 8;                 // LBFGSX_GCP_PIECES=1: a chunk's terms arrive in one piece
     // rows that entered / left the free set since the last lbfgsx_b_free_delta (the carried Gram of BFGSMatB::solve_PtBP)
     unsigned char* fprev = nullptr;       // [n] free bit at that call
     int* dl_enter = nullptr;              // [dl_cap]
@@ -248,6 +250,8 @@ int bounded_alloc(lbfgsx_ctx* c)
         b->wf_use = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_VONLY_GROUPS"))
         b->vonly_groups = atoi(e);
+    if (const char* e = getenv("LBFGSX_GCP_PIECES"))
+        b->chain_pieces = std::max(1, std::min(8, atoi(e)));
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->colmax), sizeof(unsigned long long) * 2 * size_t(c->m + 1)));
     LBFGSX_HIP(hipMemset(b->colmax, 0, sizeof(unsigned long long) * 2 * size_t(c->m + 1)));
     b->colmax_ok.assign(size_t(c->m + 1), 0);
@@ -311,6 +315,9 @@ void bounded_free(lbfgsx_ctx* c)
         (void) hipHostFree(b->g_host);
     (void) hipFree(b->lu_list);
     (void) hipFree(b->wf_pos);
+    for (hipEvent_t ev : b->chain_ev)
+        if (ev)
+            (void) hipEventDestroy(ev);
     (void) hipFree(b->fprev);
     (void) hipFree(b->dl_enter);
     (void) hipFree(b->dl_leave);
@@ -1090,10 +1097,12 @@ static void gcp_extract_nc(lbfgsx_ctx* c, const GcpBufs& gb, int64_t count, doub
 // rounding of f' (partial sums of the size of d'd) moves the Cauchy point far more than the f32 tolerance: the chain is
 // part of what has to be reproduced, so f32 problems run it in float over the (double-computed, then rounded) terms.
 template <class CT>
-static int64_t gcp_chain_host(const double* dt, const double* A, const double* B, int64_t count, double& fp, double& fpp)
+static int64_t gcp_chain_host(const double* dt, const double* A, const double* B, int64_t k0, int64_t k1, double& fp, double& fpp)
 {
+    // crossings [k0, k1) of the chunk; f' and f'' go in and out through fp, fpp (exact for CT = float too: a float
+    // widened to double and back is the same float), so a chunk can be walked in pieces as its terms arrive
     CT f1 = CT(fp), f2 = CT(fpp);
-    for (int64_t k = 0; k < count; k++)
+    for (int64_t k = k0; k < k1; k++)
     {
         f1 = f1 + CT(dt[k]) * f2;   // fp += deltat * fpp                                   (:218)
         f1 = f1 + CT(A[k]);         // fp += ggact + theta*gact*zact - gact*cache.dot(vecc)  (:227)
@@ -1217,12 +1226,33 @@ int lbfgsx_b_cauchy_scan(lbfgsx_ctx* c, int64_t first, int64_t count, int64_t no
         double* hdt = b->h_chain;
         double* hA = hdt + (b->s_cap + 1);
         double* hB = hA + (b->s_cap + 1);
-        LBFGSX_HIP(hipMemcpyAsync(hdt, b->s_fp, sizeof(double) * size_t(count + 1), hipMemcpyDeviceToHost, c->stream));
-        LBFGSX_HIP(hipMemcpyAsync(hA, b->s_dfp, sizeof(double) * size_t(count), hipMemcpyDeviceToHost, c->stream));
-        LBFGSX_HIP(hipMemcpyAsync(hB, b->s_fpp, sizeof(double) * size_t(count), hipMemcpyDeviceToHost, c->stream));
-        LBFGSX_HIP(hipStreamSynchronize(c->stream));
-        const int64_t e = (c->dtype == LBFGSX_F32) ? gcp_chain_host<float>(hdt, hA, hB, count, fp_h, fpp_h)
-                                                   : gcp_chain_host<double>(hdt, hA, hB, count, fp_h, fpp_h);
+        // 24 bytes per crossing over PCIe and ~1.4 ns of host arithmetic per crossing are about the same time: the chunk
+        // travels in pieces and the host walks a piece while the next ones are still on the way
+        const int nsub = (count >= (int64_t(1) << 17) && b->chain_pieces > 1) ? b->chain_pieces : 1;
+        if (nsub > 1 && !b->chain_ev[0])
+            for (int q = 0; q < 8; q++)
+                LBFGSX_HIP(hipEventCreateWithFlags(&b->chain_ev[q], hipEventDisableTiming));
+        for (int q = 0; q < nsub; q++)
+        {
+            const int64_t lo = count * q / nsub, hi = count * (q + 1) / nsub;
+            const int64_t dlo = q ? lo + 1 : lo;  // dt[k + 1] closes crossing k: the piece ends with dt[hi]
+            LBFGSX_HIP(hipMemcpyAsync(hdt + dlo, b->s_fp + dlo, sizeof(double) * size_t(hi + 1 - dlo), hipMemcpyDeviceToHost, c->stream));
+            LBFGSX_HIP(hipMemcpyAsync(hA + lo, b->s_dfp + lo, sizeof(double) * size_t(hi - lo), hipMemcpyDeviceToHost, c->stream));
+            LBFGSX_HIP(hipMemcpyAsync(hB + lo, b->s_fpp + lo, sizeof(double) * size_t(hi - lo), hipMemcpyDeviceToHost, c->stream));
+            if (nsub > 1)
+                LBFGSX_HIP(hipEventRecord(b->chain_ev[q], c->stream));
+        }
+        int64_t e = -1;
+        for (int q = 0; q < nsub && e < 0; q++)
+        {
+            const int64_t lo = count * q / nsub, hi = count * (q + 1) / nsub;
+            if (nsub > 1)
+                LBFGSX_HIP(hipEventSynchronize(b->chain_ev[q]));
+            else
+                LBFGSX_HIP(hipStreamSynchronize(c->stream));
+            e = (c->dtype == LBFGSX_F32) ? gcp_chain_host<float>(hdt, hA, hB, lo, hi, fp_h, fpp_h)
+                                         : gcp_chain_host<double>(hdt, hA, hB, lo, hi, fp_h, fpp_h);
+        }
         const unsigned long long ex = (e >= 0) ? (unsigned long long) e : ~0ull;
         LBFGSX_HIP(hipMemcpyAsync(b->s_exit, &ex, sizeof(ex), hipMemcpyHostToDevice, c->stream));
         switch (NC)
