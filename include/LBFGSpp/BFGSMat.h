@@ -42,9 +42,14 @@ class BFGSMatB
     // those of the two new columns need a pass over F -- together with the v row they are 6c <= 64 entries, one per lane,
     // the cost of a v-row pass instead of the full Gram's -- and the others change by the outer products of the rows that
     // moved (lbfgsx_b_free_delta, lbfgsx_b_gram_list_dd).  Everything stays un-rounded double-double, so the rounded
-    // entries are those of the direct sums (error ~2^-104 per update; a full pass every kCarryMaxAge iterations bounds
+    // entries are those of the direct sums (error ~2^-104 per update; a full pass every carry_max_age() = 32 iterations bounds
     // what can build up).  Indexed by u = family * m + slot (family 0: Y, 1: S), lower triangle u >= v.
-    static constexpr int kCarryMaxAge = 32;
+    static int carry_max_age()   // iterations between two full passes; LBFGSX_GRAM_CARRY_AGE for the tests
+    {
+        const char* e = std::getenv("LBFGSX_GRAM_CARRY_AGE");
+        const int v = e ? std::atoi(e) : 32;
+        return v < 1 ? 1 : v;
+    }
     mutable std::vector<double> m_carry;      // [2m (2m + 1) / 2][2]
     mutable std::vector<char> m_carry_col;    // [2m]: the column's entries describe its current content
     mutable bool m_carry_valid = false;
@@ -107,7 +112,7 @@ class BFGSMatB
             return false;
         if (lbfgsx_b_free_delta(m_c, &ne, &nl) != LBFGSX_OK)   // always: the remembered set must follow F
             return false;
-        if (!m_carry_valid || m_carry_age >= kCarryMaxAge || m_carry_col.size() != size_t(2 * m_m) ||
+        if (!m_carry_valid || m_carry_age >= carry_max_age() || m_carry_col.size() != size_t(2 * m_m) ||
             (ne + nl) * 16 > nF || ne > (std::int64_t(1) << 14) || nl > (std::int64_t(1) << 14))
             return false;
         int ndirty = 0, ds = -1;

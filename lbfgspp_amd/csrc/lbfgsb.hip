@@ -75,6 +75,10 @@ struct lbfgsb_state
     // except those the caller names when it uses it
     bool wf_live = false;
     int wf_ncorr = 0;                     // history size the copy's column order belongs to (Y slots, then S slots)
+    // the kept copy is current only if the subspace minimisation right before this one wrote or patched it: one that did
+    // neither (no sweeps expected, a fallback Gram, an early return) leaves a copy that misses that iteration's new columns
+    long long sub_epoch = 0;              // subspace minimisations opened (lbfgsx_b_sub_begin)
+    long long wf_epoch = -2;              // the one that last wrote or patched the copy
     int* wf_pos = nullptr;                // [n] row -> position, -1: none
     double* g_host = nullptr;             // pinned landing zone of lbfgsx_b_cauchy_chunk
     size_t g_host_cap = 0;
@@ -441,6 +445,7 @@ static void wf_rebuilt(lbfgsx_ctx* c)
     b->wf_n = b->nfree_last;
     b->wf_live = true;
     b->wf_ncorr = c->ncorr;
+    b->wf_epoch = b->sub_epoch;
 }
 
 // raw masked W'v for all 2*ncorr columns: out[0..c) = Y_j . v, out[c..2c) = S_j . v ; nnz of v inside the mask
@@ -1320,6 +1325,7 @@ int lbfgsx_b_sub_begin(lbfgsx_ctx* c)
     if (rc)
         return rc;
     const int grid = c->grid_for(c->n);
+    c->bstate->sub_epoch++;
     c->bstate->wf_valid = false;  // a compact copy of the free rows belongs to one subspace minimisation
     c->bstate->wf_on = false;
     DISPATCH_T(c, {
@@ -1657,8 +1663,8 @@ int lbfgsx_b_free_delta(lbfgsx_ctx* c, int64_t* n_enter, int64_t* n_leave)
         LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->dl_leave), sizeof(int) * size_t(b->dl_cap)));
         LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->dl_cnt), sizeof(unsigned) * 4));
     }
-    if (b->wf_live && b->wf_ncorr != c->ncorr)
-        b->wf_live = false;  // the history has grown: another column order
+    if (b->wf_live && (b->wf_ncorr != c->ncorr || b->wf_epoch + 1 != b->sub_epoch))
+        b->wf_live = false;  // the history has grown (another column order), or the copy missed an iteration
     // {rows entered, rows left, rows in the kept compact copy, 1: the copy cannot be kept}
     const unsigned init[4] = {0u, 0u, unsigned(b->wf_live ? b->wf_n : 0), 0u};
     LBFGSX_HIP(hipMemcpyAsync(b->dl_cnt, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
@@ -1746,7 +1752,7 @@ int lbfgsx_b_gram_pairs_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
     // the copy kept from the previous iteration serves when the caller vouches for the history (refresh_slot >= -1), the
     // mask is the free set and the copy is not overgrown with rows that have left it
     const bool kept = refresh_slot >= -1 && b->wf_live && b->wf_use && mask == ST_FREE && b->wf_n * 8 <= b->nfree_last * 9 &&
-                      b->wf_n >= b->nfree_last;
+                      b->wf_n >= b->nfree_last && b->wf_ncorr == c->ncorr && b->wf_epoch + 1 == b->sub_epoch;
     if (!kept)
         b->wf_live = false;
     const bool compact_in = kept || wf_serves(c, mask);
@@ -1805,7 +1811,10 @@ int lbfgsx_b_gram_pairs_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
     if (compact_out)
         wf_rebuilt(c);
     if (kept)
+    {
         b->wf_valid = true;  // usable by the passes of this subspace minimisation
+        b->wf_epoch = b->sub_epoch;
+    }
     const int nch = std::min(blocks, 32);
     hipLaunchKernelGGL(k_gram_finish, dim3(1, nch), dim3(kBlock), 0, c->stream, b->gram_partial, blocks, b->gram_partial2, 0);
     hipLaunchKernelGGL(k_gram_finish, dim3(1, 1), dim3(kBlock), 0, c->stream, b->gram_partial2, nch, b->gram_out, 1, b->gram_dd);

@@ -53,6 +53,18 @@ def main():
     out = dict(n=n, m=args.m, warmup=not args.no_warmup, niter=niter, nfev=s.last.nfev, fx=fx, total_s=t1 - t0, it_per_s=niter / (t1 - t0),
                steady_it_per_s=float(1.0 / np.median(per[len(per) // 2:])) if len(per) > 4 else None,
                per_iter_ms=[round(1e3 * v, 2) for v in per], stats=s.stats())
+    # algorithmic bytes of an L-BFGS-B iteration with q BOXCQP sweeps and one objective evaluation,
+    # [(4m + 19) + (q + 1)(4m + 1)] n elements (history full); the roofline view of the steady state against 8 TB/s
+    st = out["stats"]
+    q = st["submin_sweeps"] / max(1, st["submin_calls"])
+    bytes_it = ((4 * args.m + 19) + (q + 1.0) * (4 * args.m + 1)) * n * 8
+    out["q_sweeps_per_iteration"] = q
+    out["gcp_crossings_per_iteration"] = st["gcp_crossings"] / max(1, niter)
+    out["algorithmic_bytes_per_iteration"] = bytes_it
+    if out["steady_it_per_s"]:
+        ach = bytes_it * out["steady_it_per_s"] / 1e9
+        out["roofline"] = dict(bound="hbm", achieved=ach, peak=8000.0, unit="GB/s", frac=ach / 8000.0,
+                               note="steady state (median of the second half of the iterations), algorithmic bytes / time")
     if args.cpu_n:
         import oracle_lib as O
         orc = O.Oracle("ref", "native")

@@ -388,8 +388,9 @@ def test_compact_copy_of_the_free_rows_changes_no_bit(A, monkeypatch, n, m, max_
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
-@pytest.mark.parametrize("n,m,iters", [(70001, 8, 60), (70001, 10, 45), (65536, 3, 40), (90000, 12, 20), (200000, 10, 80)])
-def test_carried_gram_of_the_free_set_changes_no_bit(A, monkeypatch, n, m, iters, dtype):
+@pytest.mark.parametrize("n,m,iters,age", [(70001, 8, 60, 32), (70001, 10, 45, 32), (65536, 3, 40, 32), (90000, 12, 20, 32),
+                                           (200000, 10, 80, 32), (70001, 8, 40, 2), (120000, 10, 40, 5), (65536, 5, 40, 3)])
+def test_carried_gram_of_the_free_set_changes_no_bit(A, monkeypatch, n, m, iters, age, dtype):
     """W_F'W_F of the first BOXCQP solve from the sums of the previous iteration -- the rows of the two replaced columns
     computed afresh, the other entries corrected by the outer products of the rows that entered or left the free set, all
     in double-double (BFGSMatB::carried_gram) -- against the full Gram pass every iteration (LBFGSX_GRAM_CARRY=0): the
@@ -399,6 +400,7 @@ def test_carried_gram_of_the_free_set_changes_no_bit(A, monkeypatch, n, m, iters
     dt = O.F64 if dtype == "f64" else O.F32
     npdt = O.NPDT[dt]
     a, b = O.quad_problem(n, 30.0, 11, dt)
+    monkeypatch.setenv("LBFGSX_GRAM_CARRY_AGE", str(age))  # a short period interleaves full and carried passes differently
     res = {}
     for on in ("1", "0", "nokeep"):
         # "nokeep": carried sums, but the compact copy of the free rows is written afresh every iteration instead of being
