@@ -31,7 +31,6 @@ struct lbfgsb_state
     double* gram_out_host = nullptr;  // same for gram_out
     double* gram_dd = nullptr;        // [3][256][2] un-rounded (hi, lo) sums of the last one-pass Gram (device)
     void* coef_dev = nullptr;         // T[80]
-    unsigned long long* mslot = nullptr;  // (unused since the extrema ride in the grid reductions)
     // index list of the rows the last BOXCQP partition put into L or U (k_sub_sweep_begin); lu_valid: it describes the
     // current state bytes (any other writer of ST_L / ST_U clears it)
     int* lu_list = nullptr;               // two buffers of lu_cap entries: the current list and the one a fused sweep builds
@@ -241,7 +240,6 @@ int bounded_alloc(lbfgsx_ctx* c)
     else
         LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->dout), sizeof(double) * 64));
     LBFGSX_HIP(hipMalloc(&b->coef_dev, sizeof(double) * 80));
-    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->mslot), sizeof(unsigned long long) * 2));
     b->lu_cap = unsigned(std::min<int64_t>(c->n, int64_t(1) << 20));
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->lu_list), sizeof(int) * 2 * size_t(b->lu_cap)));
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->lu_cnt), sizeof(unsigned)));
@@ -309,7 +307,7 @@ void bounded_free(lbfgsx_ctx* c)
     if (!b)
         return;
     void* ptrs[] = {b->brk, b->dvec, b->cF, b->y, b->yfb, b->lam, b->mu, b->rhs, b->keys_in, b->keys_out, b->st,
-                    b->vals_in, b->vals_out, b->phys_dev, b->dout, b->coef_dev, b->mslot, b->sort_tmp, b->g_brk,
+                    b->vals_in, b->vals_out, b->phys_dev, b->dout, b->coef_dev, b->sort_tmp, b->g_brk,
                     b->g_g, b->g_z, b->g_w, b->g_idx, b->gram_partial, b->gram_partial2, b->gram_out, b->gram_dd,
                     b->s_brk, b->s_g, b->s_z, b->s_W, b->s_P, b->s_C, b->s_fpp, b->s_dfp, b->s_fp, b->s_ts, b->s_off,
                     b->s_small, b->s_exit, b->pk, b->pv, b->pcount, b->sel_tmp};
