@@ -418,6 +418,11 @@ int64_t lbfgsx_timing_fused_launches(const lbfgsx_ctx* c);
 /* elements of q (= the direction vector, BFGSMat.h:283-301 `res`) that a persistent launch of this context keeps in the
  * registers / LDS of the CUs for the whole recursion: that share of q's traffic never reaches HBM (0: not available) */
 int64_t lbfgsx_persistent_resident_elems(const lbfgsx_ctx* c);
+/* Diagnostic: runs the grid-wide reduction every kernel of the path ends in (csrc/reduce.cuh) on `nred` sums of known small
+ * integers over `grid` blocks of 256 threads; out[r] = the total of sum r, which the caller checks against the closed
+ * form: sum over g < 256 grid of (r + 1)(1 + g mod 7) + (block(g) mod 3) + (1000003 r mod 17).  nred in {1 2 3 5 7 8 9 25 31
+ * 33 40 50 56}; f32_accumulators != 0 uses the accumulator type of f32 contexts. */
+int lbfgsx_selftest_reduce(lbfgsx_ctx* c, int nred, int grid, int f32_accumulators, double* out);
 /* STREAM-style device bandwidth probe on this context's vectors: copy (XT = X) and triad, GB/s */
 int lbfgsx_stream_probe(lbfgsx_ctx* c, int reps, double* copy_gbs, double* triad_gbs);
 

@@ -111,6 +111,7 @@ def load():
     sig(core, "lbfgsx_timing_enable", i32, vp, i32)
     sig(core, "lbfgsx_timing_read", i32, vp, pd, C.POINTER(i64), pd, C.POINTER(i64))
     sig(core, "lbfgsx_stream_probe", i32, vp, i32, pd, pd)
+    sig(core, "lbfgsx_selftest_reduce", i32, vp, i32, i32, i32, pd)
     sig(core, "lbfgsx_post_linesearch_spec", i32, vp, dbl, pd, pd, pd, pd)
     sig(core, "lbfgsx_rccl_allgather_records", i32, C.POINTER(i32), i32, vp, i64, i64, C.POINTER(vp))
     sig(core, "lbfgsx_device_download", i32, i32, vp, i64, vp)

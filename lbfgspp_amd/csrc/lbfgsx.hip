@@ -1263,6 +1263,68 @@ int64_t lbfgsx_persistent_resident_elems(const lbfgsx_ctx* c)
     return std::min<int64_t>(cap, c->n / w * w);
 }
 
+}  // extern "C"
+namespace lbfgsx {
+// Self-test of the grid reduction (reduce.cuh): NRED sums of small integers whose value depends on the sum's index, the
+// thread and the block, so a partial that reaches the wrong sum, lane or block shows in the totals (all exact in double)
+template <class A, int NRED>
+__global__ void __launch_bounds__(kBlock) k_selftest_reduce(RedWs ws, double* __restrict__ out)
+{
+    A acc[NRED];
+    const int g = int(blockIdx.x) * kBlock + int(threadIdx.x);
+#pragma unroll
+    for (int r = 0; r < NRED; r++)
+    {
+        acc[r].add(double((r + 1) * (1 + g % 7) + (blockIdx.x % 3)));
+        acc[r].add(double(r * 1000003 % 17));
+    }
+    if (grid_reduce<NRED>(acc, ws) && threadIdx.x == 0)
+        for (int r = 0; r < NRED; r++)
+            out[r] = acc[r].value();
+}
+template <class A, int NRED>
+static void selftest_launch(lbfgsx_ctx* c, int grid, double* out)
+{
+    hipLaunchKernelGGL((k_selftest_reduce<A, NRED>), dim3(grid), dim3(kBlock), 0, c->stream, c->ws, out);
+}
+}  // namespace lbfgsx
+extern "C" {
+
+int lbfgsx_selftest_reduce(lbfgsx_ctx* c, int nred, int grid, int f32_accumulators, double* out)
+{
+    lbfgsx::DeviceGuard dev_guard_(c->device);
+    if (grid < 1 || grid > c->ws.maxGrid || !out)
+    {
+        set_error("lbfgsx_selftest_reduce: 1 <= grid <= the context's reduction workspace");
+        return LBFGSX_E_INVALID;
+    }
+    double* tmp = nullptr;
+    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&tmp), sizeof(double) * 64));
+#define ST_CASE(N)                                                                 \
+    case N:                                                                        \
+        if (f32_accumulators) selftest_launch<D1, N>(c, grid, tmp);                \
+        else selftest_launch<DD, N>(c, grid, tmp);                                 \
+        break
+    switch (nred)
+    {
+        ST_CASE(1); ST_CASE(2); ST_CASE(3); ST_CASE(5); ST_CASE(7); ST_CASE(8); ST_CASE(9); ST_CASE(25); ST_CASE(31); ST_CASE(33);
+        ST_CASE(40); ST_CASE(50); ST_CASE(56);
+    default:
+        (void) hipFree(tmp);
+        set_error("lbfgsx_selftest_reduce: nred must be one of 1 2 3 5 7 8 9 25 31 33 40 50 56");
+        return LBFGSX_E_INVALID;
+    }
+#undef ST_CASE
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(out, tmp, sizeof(double) * size_t(nred), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(c->stream);
+    (void) hipFree(tmp);
+    LBFGSX_HIP(e);
+    return LBFGSX_OK;
+}
+
 int lbfgsx_stream_probe(lbfgsx_ctx* c, int reps, double* copy_gbs, double* triad_gbs)
 {
     lbfgsx::DeviceGuard dev_guard_(c->device);

@@ -219,3 +219,32 @@ def test_no_device_memory_is_leaked_across_solver_lifetimes(A):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 64 << 20, "device memory shrank by %.1f MB over 20 cycles" % ((free0 - free1) / 2**20)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("f32acc", [0, 1])
+@pytest.mark.parametrize("grid", [1, 2, 3, 5, 64, 257, 1000])
+def test_grid_reduction_routes_every_partial_to_its_sum(grid, f32acc):
+    """csrc/reduce.cuh directly: `nred` sums over `grid` blocks whose terms depend on the sum's index, the thread and the
+    block (lbfgsx_selftest_reduce) against the closed form -- the recursive halving across the lanes, the per-sum threads,
+    the batched partial loads of the last block and the one-block shortcut, for every count of sums the kernels use and
+    the odd ones in between."""
+    import ctypes as C
+
+    import lbfgspp_amd as A
+    from lbfgspp_amd import _lib as L
+    core, _ = A.load()
+    ctx = C.c_void_p()
+    L.check(core.lbfgsx_create(C.byref(ctx), L.F64, 4096, 3, 0, 0))
+    try:
+        g = np.arange(256 * grid, dtype=np.int64)
+        for nred in (1, 2, 3, 5, 7, 8, 9, 25, 31, 33, 40, 50, 56):
+            out = (C.c_double * 64)()
+            L.check(core.lbfgsx_selftest_reduce(ctx, nred, grid, f32acc, out))
+            for r in range(nred):
+                want = int(((r + 1) * (1 + g % 7) + ((g // 256) % 3) + (r * 1000003 % 17)).sum())
+                assert out[r] == float(want), "nred %d grid %d sum %d: %r != %d" % (nred, grid, r, out[r], want)
+        bad = (C.c_double * 64)()
+        assert core.lbfgsx_selftest_reduce(ctx, 4, grid, 0, bad) == L.E_INVALID
+    finally:
+        core.lbfgsx_destroy(ctx)
