@@ -113,7 +113,7 @@ class BFGSMatB
         if (lbfgsx_b_free_delta(m_c, &ne, &nl) != LBFGSX_OK)   // always: the remembered set must follow F
             return false;
         if (!m_carry_valid || m_carry_age >= carry_max_age() || m_carry_col.size() != size_t(2 * m_m) ||
-            (ne + nl) * 16 > nF || ne > (std::int64_t(1) << 14) || nl > (std::int64_t(1) << 14))
+            ne < 0 || nl < 0 || (ne + nl) * 16 > nF)
             return false;
         int ndirty = 0, ds = -1;
         for (int j = 0; j < c; j++)

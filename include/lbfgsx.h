@@ -287,11 +287,11 @@ int lbfgsx_b_wtv_lu(lbfgsx_ctx* c, double* out_l, int64_t* nnz_l, double* out_u,
  * of the rows that entered or left F.  All sums un-rounded double-doubles (hi, lo).
  *
  * lbfgsx_b_free_delta: the rows whose membership of F (LBFGSX_ST_FREE) differs from what it was at the previous call (the
- * first call: from the empty set) are put on two lists, their sizes returned (a size above 2^14 means: more than that, the
- * list is not usable); the remembered set becomes the current one. */
+ * first call: from the empty set) are put on two lists, their sizes returned (-1: more rows than the list
+ * holds -- n / 64 of them, at least 2^14 and at most 2^20 -- so it is not usable); the remembered set becomes the current one. */
 int lbfgsx_b_free_delta(lbfgsx_ctx* c, int64_t* n_enter, int64_t* n_leave);
 /* the 2c x 2c Gram of [Y S] over the rows of one of those lists (0: entered, 1: left), packed lower triangle
- * e = i (i + 1) / 2 + j as lbfgsx_b_gram_fused_dd returns it; LBFGSX_E_INVALID for an empty or overflowed (> 2^14 rows) list */
+ * e = i (i + 1) / 2 + j as lbfgsx_b_gram_fused_dd returns it; LBFGSX_E_INVALID for an empty or overflowed list */
 int lbfgsx_b_gram_list_dd(lbfgsx_ctx* c, int which, double* gram_dd);
 /* selected entries of [Y_P S_P v]'[Y_P S_P v] in one pass with the prologue of lbfgsx_b_gram_fused_ex: entry e is the
  * product of the columns pair_i[e], pair_j[e] (0..2c-1: Y slots then S slots; 2c: v), at most 64 of them (one per lane:

@@ -1654,7 +1654,10 @@ int lbfgsx_b_free_delta(lbfgsx_ctx* c, int64_t* n_enter, int64_t* n_leave)
     lbfgsb_state* b = c->bstate;
     if (!b->fprev)
     {
-        b->dl_cap = unsigned(std::min<int64_t>(c->n, int64_t(1) << 14));
+        // room for n / 64 changed rows (what is worth patching instead of recomputing grows with n), 2^14 .. 2^20
+        b->dl_cap = unsigned(std::min<int64_t>(c->n, std::max<int64_t>(int64_t(1) << 14, std::min<int64_t>(int64_t(1) << 20, c->n / 64))));
+        if (const char* e = getenv("LBFGSX_DELTA_CAP"))  // tuning aid
+            b->dl_cap = unsigned(std::min<int64_t>(c->n, std::max<int64_t>(64, atoll(e))));
         LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->fprev), size_t(c->ld)));   // padded like the state bytes
         LBFGSX_HIP(hipMemsetAsync(b->fprev, 0, size_t(c->ld), c->stream));
         LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->dl_enter), sizeof(int) * size_t(b->dl_cap)));
@@ -1700,8 +1703,8 @@ int lbfgsx_b_free_delta(lbfgsx_ctx* c, int64_t* n_enter, int64_t* n_leave)
         else
             b->wf_n = int64_t(h[2]);
     }
-    *n_enter = int64_t(h[0]);
-    *n_leave = int64_t(h[1]);
+    *n_enter = b->dl_n[0];
+    *n_leave = b->dl_n[1];
     return LBFGSX_OK;
 }
 
