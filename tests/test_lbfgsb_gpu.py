@@ -530,3 +530,110 @@ def test_integer_mfma_gram_trajectories_change_no_bit(A, monkeypatch, n, m, iter
         s.close()
     assert res["i8"][:3] == res["dd"][:3]
     assert np.array_equal(res["i8"][3], res["dd"][3]) and np.array_equal(res["i8"][4], res["dd"][4])
+
+
+@pytest.mark.parametrize("n,m,npairs", [(50000, 10, 10), (300001, 6, 4), (65536, 10, 7)])
+def test_selected_entries_and_list_grams_equal_the_full_pass(A, n, m, npairs):
+    """The pieces of the carried first solve against the full one-pass Gram on the same data: the entries
+    lbfgsx_b_gram_pairs_dd returns (one per lane) round to the full pass's entries; with the free set changed by some
+    rows, the old un-rounded sums plus the list Gram of the rows that entered / minus that of the rows that left
+    (lbfgsx_b_free_delta, lbfgsx_b_gram_list_dd) round to the new full pass's entries.  Misuse is refused."""
+    import math
+
+    from lbfgspp_amd import _lib as L
+    core, _ = A.load()
+    vp, i32, i64, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_double
+    ST_FREE, VS_DRT = 1, 0   # LBFGSX_ST_FREE, LBFGSX_VS_DRT (include/lbfgsx.h)
+    fdd = core.lbfgsx_b_gram_fused_dd
+    fdd.restype, fdd.argtypes = i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp]
+    fpairs = core.lbfgsx_b_gram_pairs_dd
+    fpairs.restype, fpairs.argtypes = i32, [vp, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp]
+    fdelta = core.lbfgsx_b_free_delta
+    fdelta.restype, fdelta.argtypes = i32, [vp, C.POINTER(i64), C.POINTER(i64)]
+    flist = core.lbfgsx_b_gram_list_dd
+    flist.restype, flist.argtypes = i32, [vp, i32, vp]
+    fbuild = core.lbfgsx_b_cauchy_build
+    fbuild.restype, fbuild.argtypes = i32, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(f64), vp]
+    ffin = core.lbfgsx_b_cauchy_finish
+    ffin.restype, ffin.argtypes = i32, [vp, f64, f64, i32, C.POINTER(i64), C.POINTER(i64)]
+    h = C.c_void_p()
+    L.check(core.lbfgsx_create(C.byref(h), 0, n, m, 0, 1))
+    try:
+        rng = np.random.default_rng(n + 3)
+        for k in range(npairs):
+            s_ = rng.standard_normal(n)
+            y_ = s_ * (1 + rng.random(n))
+            L.check(core.lbfgsx_bfgs_add_correction_host(h, s_.ctypes.data_as(vp), y_.ctypes.data_as(vp)))
+        c = min(npairs, m)
+        t = 2 * c
+        # break points 1 / |g_i| (x0 = 0 in [-1, 1]): lbfgsx_b_cauchy_finish(tc) frees the rows whose break point lies beyond tc
+        x0, g = np.zeros(n), rng.standard_normal(n)
+        for which, v in ((L.VEC_X, x0), (L.VEC_G, g), (L.VEC_LB, -np.ones(n)), (L.VEC_UB, np.ones(n))):
+            L.check(core.lbfgsx_upload(h, which, v.ctypes.data_as(vp)))
+        nf, no, dd = i64(), i64(), f64()
+        wtd = np.zeros(2 * m)
+        L.check(fbuild(h, C.byref(nf), C.byref(no), C.byref(dd), wtd.ctypes.data_as(vp)))
+
+        def free_set(tc):
+            na, nfree = i64(), i64()
+            L.check(ffin(h, tc, tc, 0, C.byref(na), C.byref(nfree)))
+            assert nfree.value == int((1.0 / np.abs(g) > tc).sum())
+            L.check(core.lbfgsx_b_sub_begin(h))            # drt = xcp - x0: the vector the v row is taken with
+            return nfree.value
+
+        def full():
+            G, w, gd = np.zeros((t, t)), np.zeros(t), np.zeros(t * (t + 1))
+            L.check(fdd(h, ST_FREE, VS_DRT, 0, None, None, G.ctypes.data_as(vp), w.ctypes.data_as(vp), gd.ctypes.data_as(vp)))
+            return G, w, gd.reshape(-1, 2)
+
+        n1 = free_set(0.8)
+        ne, nl = i64(), i64()
+        L.check(fdelta(h, C.byref(ne), C.byref(nl)))         # first call: everything "entered"
+        assert nl.value == 0 and ne.value in (n1, -1)
+        G1, w1, gd1 = full()
+        # the rows of one slot's two columns and the v row, one entry per lane, as carried_gram asks for them
+        ds = c // 2
+        pi, pj = [], []
+        for J in range(t):
+            pi.append(max(ds, J)); pj.append(min(ds, J))
+        for J in range(t):
+            if J != ds:
+                pi.append(max(c + ds, J)); pj.append(min(c + ds, J))
+        vrow = len(pi)
+        for J in range(t + 1):
+            pi.append(t); pj.append(J)
+        if len(pi) <= 64:
+            api, apj = (i32 * 64)(*pi), (i32 * 64)(*pj)
+            pd = np.zeros(2 * len(pi))
+            L.check(fpairs(h, ST_FREE, VS_DRT, 0, None, None, len(pi), api, apj, -2, pd.ctypes.data_as(vp)))
+            got = pd[0::2] + pd[1::2]
+            for e in range(vrow):
+                assert got[e] == G1[pi[e], pj[e]], (e, pi[e], pj[e])
+            assert np.array_equal(got[vrow:vrow + t], w1)
+            assert fpairs(h, ST_FREE, VS_DRT, 0, None, None, 0, api, apj, -2, pd.ctypes.data_as(vp)) == L.E_INVALID
+            assert fpairs(h, ST_FREE, VS_DRT, 0, None, None, 3, api, apj, 99, pd.ctypes.data_as(vp)) == L.E_INVALID
+        tri = [(i, j) for i in range(t) for j in range(i + 1)]
+        for tc, grows in ((0.79, True), (0.805, False)):     # a few more rows free, then fewer (the lists hold max(2^14, n/64) rows)
+            nprev = free_set(tc)
+            L.check(fdelta(h, C.byref(ne), C.byref(nl)))
+            assert (ne.value > 0 and nl.value == 0) if grows else (ne.value == 0 and nl.value > 0)
+            ldd = np.zeros(t * (t + 1))
+            L.check(flist(h, 0 if grows else 1, ldd.ctypes.data_as(vp)))
+            assert flist(h, 1 if grows else 0, ldd.ctypes.data_as(vp)) == L.E_INVALID   # the other list is empty
+            ldd = ldd.reshape(-1, 2)
+            G2, w2, gd2 = full()
+            sign = 1.0 if grows else -1.0
+            for e, (i, j) in enumerate(tri):
+                want = math.fsum([gd1[e, 0], gd1[e, 1], sign * ldd[e, 0], sign * ldd[e, 1]])
+                assert want == G2[i, j], "entry (%d, %d): %.17g != %.17g" % (i, j, want, G2[i, j])
+            gd1 = gd2
+        assert flist(h, 2, ldd.ctypes.data_as(vp)) == L.E_INVALID
+        flu = core.lbfgsx_b_lu_sweep
+        flu.restype, flu.argtypes = i32, [vp, vp, f64, vp]
+        s7 = (i64 * 7)()
+        assert flu(h, None, 1.0, C.cast(s7, vp)) == L.E_INVALID          # nothing to complete
+        fss = core.lbfgsx_b_solve_sweep
+        fss.restype, fss.argtypes = i32, [vp, i32, i32, vp, f64, vp, vp]
+        assert fss(h, 0, VS_DRT, None, 1.0, wtd.ctypes.data_as(vp), C.cast(s7, vp)) == L.E_INVALID   # no index list yet
+    finally:
+        core.lbfgsx_destroy(h)
