@@ -76,6 +76,58 @@ def cpu_baseline(args):
                       % (n, scale, r2.niter - r1.niter, r1.niter, t2 - t0, its, os.cpu_count())}
 
 
+def cpu_baseline_full(args):
+    """the 1-core reference at the metric's OWN size (n = 1e8, m = 10), un-extrapolated: m+2 warm-up iterations
+    (history full) + a few timed ones in ONE run.  The oracle stamps every functor call (oracle_*_set_eval_clock); the gap
+    between two calls that holds a two-loop recursion (~(8m+1) n elements) is an order of magnitude longer than the gap
+    between two trials of one line search, which marks the iteration boundaries; the count of boundaries is checked against
+    the iterations the run reports.  Skipped (None) when the host cannot hold the ~(2m+12) n doubles."""
+    import numpy as np
+
+    import oracle_lib as O
+    fam, kind = ("ref", "reference") if O.available("ref", "native") else ("port", "port")
+    if not O.available(fam, "native"):
+        return None
+    n, m = int(args.n), args.m
+    need = (2 * m + 14) * n * 8
+    try:
+        avail = [int(ln.split()[1]) * 1024 for ln in open("/proc/meminfo") if ln.startswith("MemAvailable:")][0]
+    except Exception:
+        avail = 0
+    if avail < 1.25 * need or (args.cpu_full == "auto" and avail < 48e9):
+        return {"skipped": "host memory: %.0f GB available, %.0f GB needed" % (avail / 1e9, 1.25 * need / 1e9)}
+    orc = O.Oracle(fam, "native")
+    setc = getattr(orc.lib, ("oracle_ref" if fam == "ref" else "oracle_port") + "_set_eval_clock")
+    setc.argtypes = [C.POINTER(C.c_double), C.c_int]
+    warm, timed = m + 2, args.cpu_full_steps
+    stamps = np.zeros(4096)
+    x0 = O.rosen_x0(n)
+    setc(stamps.ctypes.data_as(C.POINTER(C.c_double)), stamps.size)
+    t0 = time.perf_counter()
+    try:
+        _, r = orc.lbfgs(O.F64, O.LS_MT, O.OBJ_ROSEN, x0, O.lbfgs_params(m=m, epsilon=0, epsilon_rel=0, max_iterations=warm + timed))
+    finally:
+        setc(None, 0)
+    t1 = time.perf_counter()
+    ts = stamps[:min(r.nfev, stamps.size)]
+    gaps = np.diff(ts)
+    thr = float(np.sqrt(gaps.min() * gaps.max()))  # geometric middle of "next trial" and "next iteration" gaps
+    # last functor call of every iteration; the gap after call 0 (f at x0; first-touch page faults of the history) is no
+    # boundary: the first line search starts from it directly (LBFGS.h:91-108)
+    ends = [i for i, g in enumerate(gaps) if g > thr and i > 0] + [len(ts) - 1]
+    ok = len(ends) == r.niter and r.niter == warm + timed and gaps.max() > 3 * gaps.min()
+    if ok:
+        dt = float(ts[ends[-1]] - ts[ends[-1 - timed]])
+        its, how = timed / dt, ("iterations %d..%d of one run, boundaries from the functor-call clock (%d boundaries = %d "
+                                "iterations)" % (warm + 1, warm + timed, len(ends), r.niter))
+    else:  # could not separate the iterations: whole-run average, first (short-history) iterations included
+        its, how = r.niter / (t1 - t0), "whole run of %d iterations (boundaries not separable: %d found)" % (r.niter, len(ends))
+    return {"value": its, "unit": "iterations/s", "cores": 1, "kind": kind, "extrapolated": False, "measured_n": n,
+            "timed_iterations": timed if ok else r.niter, "nfev": r.nfev,
+            "sample": "the metric's own size n=%d, m=%d: %s; %.1f s of CPU in all; host has %d cores"
+                      % (n, m, how, t1 - t0, os.cpu_count())}
+
+
 def cpu_baseline_all_cores(args):
     """SURVEY.md 8(d)'s stronger CPU point: the restatement with its n-length loops under OpenMP (native accumulators,
     oracle/liboracle_native_omp.so) on every host core.  Reported next to `cpu_baseline`, never instead of it."""
@@ -176,6 +228,29 @@ def init_dist(args):
     return rank, world, dev, comm_dev, dist
 
 
+def gather_objects(obj, rank, world, dist):
+    """Every rank's small record, in rank order, on every rank (the list is only reported by rank 0)."""
+    if world == 1:
+        return [obj]
+    out = [None] * world
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def collective_info(dist, world):
+    """Which collective library carried the barriers / reductions / gathers of an N > 1 run."""
+    import torch
+    info = {"backend": dist.get_backend(), "world_size": world, "rccl_version": None,
+            "data_path_collectives": 0,
+            "used_for": "timing barriers, max-over-ranks of the elapsed time, gather of the per-rank / per-problem records"}
+    try:
+        if info["backend"] == "nccl":
+            info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        pass
+    return info
+
+
 def run_batched(args, rank, world, local, comm_dev, dist, steps):
     """BASELINE.json cfg5: independent extended-Rosenbrock problems n=1e5, m=10, f32, LineSearchMoreThuente, fixed
     budget of `steps` iterations per problem; every rank solves its own contiguous shard of problem ids in the
@@ -202,13 +277,15 @@ def run_batched(args, rank, world, local, comm_dev, dist, steps):
     t0 = time.perf_counter()
     recs = B.solve_local_lockstep(par, n, first, count, seed_base=1000, dtype=np.float32, device=local)
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = local_elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     full = B.gather_records(recs, total, rank, world, dist=dist if world > 1 else None,
                             device=comm_dev if world > 1 else None)
+    per_rank = gather_objects({"rank": rank, "device": local, "first_problem": int(first), "problems": int(count),
+                               "seconds": local_elapsed, "value": float(recs["niter"].sum()) / local_elapsed}, rank, world, dist)
     if rank != 0:
         return None
     its, fev = int(full["niter"].sum()), int(full["nfev"].sum())
@@ -226,7 +303,8 @@ def run_batched(args, rank, world, local, comm_dev, dist, steps):
         "config": {"workload": "cfg5: %d independent extended-Rosenbrock problems per GPU, n=1e5, m=10, f32, "
                                "LineSearchMoreThuente, %d iterations each, lock-step batch; contiguous problem-id blocks "
                                "per rank, no data-path collective, one all-gather of the result records" % (P, steps),
-                   "problems_total": total, "fevals_total": fev, "failed": int((full["status"] != 0).sum())},
+                   "problems_total": total, "fevals_total": fev, "failed": int((full["status"] != 0).sum()),
+                   "per_rank": per_rank if world > 1 else None},
         "roofline": {"bound": "hbm", "achieved": model_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": model_gbs / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_GBs": alg_ / elapsed / 1e9 / world,
@@ -234,6 +312,112 @@ def run_batched(args, rank, world, local, comm_dev, dist, steps):
                              "one-launch two-loop ((4m+14) n elements per iteration: q stays on the CU) / wall time; "
                              "algorithmic_GBs = SURVEY 8(d)'s (8m+12) n per iteration / wall time, which counts the q "
                              "traffic that never reaches HBM and may therefore exceed the peak"}}
+
+
+def run_cfg4(args, rank, world, local, comm_dev, dist, iters=40):
+    """BASELINE.json cfg4: L-BFGS-B (generalized Cauchy point + BOXCQP subspace minimisation) on the box-constrained diag
+    quadratic, n=1e7, m=10, lb=-1, ub=1, x0=0, f64 -- `iters` iterations from x0 on every rank (independent problems,
+    seed 1+rank).  Reports the rate from x0 (Cauchy searches with millions of crossings included) and the steady rate
+    (median of the second half), with SURVEY 8(d)'s q / n_ord / crossings and the launches / host synchronisations / copies
+    per iteration counted by the library.  Returns the object on rank 0."""
+    import numpy as np
+    import torch  # noqa: F401
+
+    import lbfgspp_amd as A
+    from lbfgspp_amd import _lib as L
+    core, _ = A.load()
+    n, m = int(args.cfg4_n), 10
+
+    def setup(solver, nn, seed):
+        ctx = solver.prepare(nn)
+        L.check(core.lbfgsx_gen_diag_quad(ctx, 10.0, seed))
+        L.check(core.lbfgsx_fill(ctx, L.VEC_X, 0.0))
+        L.check(core.lbfgsx_fill(ctx, L.VEC_LB, -1.0))
+        L.check(core.lbfgsx_fill(ctx, L.VEC_UB, 1.0))
+        L.check(core.lbfgsx_sync(ctx))
+        return ctx
+    # untimed small solve of the same problem: HIP loads a kernel's code object at its first launch (~60 kernels)
+    w = A.LBFGSBSolver(A.LBFGSBParam(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=12), device=local)
+    setup(w, 1 << 18, 1)
+    w.minimize_resident(A.DiagQuadratic(), 1 << 18)
+    w.close()
+    s = A.LBFGSBSolver(A.LBFGSBParam(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters), device=local)
+    setup(s, n, 1 + rank)
+
+    def barrier():
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+    stamps = []
+    s.set_iteration_hook(lambda k: stamps.append(time.perf_counter()))
+    cnt = (C.c_int64 * 3)()
+    barrier()
+    core.lbfgsx_counters(None, 1)
+    t0 = time.perf_counter()
+    niter, fx = s.minimize_resident(A.DiagQuadratic(), n)
+    t1 = time.perf_counter()
+    core.lbfgsx_counters(C.byref(cnt), 0)
+    barrier()
+    st = s.stats()
+    s.close()
+    per = np.diff(np.array([t0] + stamps))
+    total, steady_ms = t1 - t0, float(np.median(per[len(per) // 2:])) * 1e3
+    first_ms = float(per[0]) * 1e3
+    if world > 1:
+        t = torch.tensor([total, steady_ms], dtype=torch.float64, device=comm_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        total, steady_ms = float(t[0].item()), float(t[1].item())
+    if rank != 0:
+        return None
+    # SURVEY.md 8(d): algorithmic bytes of an L-BFGS-B iteration with q BOXCQP sweeps and one objective evaluation,
+    # [(4m + 19) + (q + 1)(4m + 1)] n elements (history full); radix-sort traffic (~96 B per sorted break point) on top
+    q = st["submin_sweeps"] / max(1, st["submin_calls"])
+    searches = max(1, st["gcp_searches"])
+    n_ord, n_sorted = st["gcp_nord"] / searches, st["gcp_sorted"] / searches
+    bytes_it = ((4 * m + 19) + (q + 1.0) * (4 * m + 1)) * n * 8 + 96.0 * n_sorted
+    steady = 1e3 / steady_ms
+    ach_steady, ach_x0 = bytes_it * steady / 1e9, bytes_it * (niter / total) / 1e9
+    return {
+        "metric": "L-BFGS-B iterations/sec at n=%d, m=%d (box-constrained diag quadratic); steady state" % (n, m),
+        "value": world * steady, "unit": "iterations/s", "n_gpus": world, "steps": iters,
+        "ms_per_step": steady_ms, "scaling": "weak", "dtype": "f64",
+        "from_x0": {"value": world * niter / total, "unit": "iterations/s", "iterations": niter, "seconds": total,
+                    "first_iteration_ms": first_ms,
+                    "note": "all %d iterations from x0 = 0, the first Cauchy searches (millions of crossings) included" % niter},
+        "config": {"workload": "cfg4: L-BFGS-B, f = 0.5 ||diag(a) x - b||^2, kappa=10, lb=-1, ub=1, x0=0, n=%d, m=%d, f64, "
+                               "LineSearchMoreThuente, %d iterations from x0 (epsilon=epsilon_rel=0, past=0); value = steady "
+                               "state = 1 / median of the second half of the per-iteration wall times" % (n, m, iters),
+                   "n": n, "m": m, "iterations": niter, "fevals_total": s.last.nfev, "fx": fx,
+                   "q": q, "n_ord": n_ord, "n_sorted": n_sorted, "gcp_crossings": st["gcp_crossings"] / max(1, niter),
+                   "gcp_crossings_total": st["gcp_crossings"], "gcp_dev_crossings_total": st["gcp_dev_crossings"],
+                   "submin_calls": st["submin_calls"], "submin_sweeps": st["submin_sweeps"], "gram_carried": st["gram_carried"],
+                   "launches_per_iteration": cnt[0] / max(1, niter), "host_syncs_per_iteration": cnt[1] / max(1, niter),
+                   "copies_per_iteration": cnt[2] / max(1, niter),
+                   "phase_ms_per_iteration": {"cauchy": st["gcp_total_us"] / 1e3 / niter, "subspace": st["submin_us"] / 1e3 / niter,
+                                              "linesearch": st["linesearch_us"] / 1e3 / niter}},
+        "roofline": {"bound": "hbm", "kernel": "whole L-BFGS-B iteration (masked W'v / Gram / solve-sweep passes over the compact "
+                                               "copy of the free rows dominate; no single kernel holds more than a fifth of the time)",
+                     "achieved": ach_steady, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_steady / HBM_PEAK_GBS,
+                     "achieved_from_x0": ach_x0, "frac_from_x0": ach_x0 / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes": bytes_it,
+                     "note": "SURVEY 8(d): [(4m+19) + (q+1)(4m+1)] n sizeof(T) + 96 B per sorted break point, per iteration, "
+                             "divided by the wall time of an iteration (host control flow included)"}}
+
+
+def lbfgs_leg(args, rank, world, local, comm_dev, dist, **over):
+    """One more L-BFGS configuration of BASELINE.json through the same code as the headline (run_north_star), reduced to
+    the keys the line carries per leg."""
+    import copy
+    a = copy.copy(args)
+    for k, v in over.items():
+        setattr(a, k, v)
+    a.workload, a.recursion = "north-star", "vector"
+    out = run_north_star(a, rank, world, local, comm_dev, dist)
+    if rank != 0:
+        return None
+    return {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "dtype",
+                                "config", "roofline")}
 
 
 def run_north_star(args, rank, world, local, comm_dev, dist):
@@ -324,7 +508,7 @@ def run_north_star(args, rank, world, local, comm_dev, dist):
     niter, fx = solver.minimize_resident(f, n)
     if "t1" not in marks:
         raise SystemExit("solver stopped after %d iterations, before the timed window ended" % niter)
-    elapsed = marks["t1"] - marks["t0"]
+    elapsed = local_elapsed = marks["t1"] - marks["t0"]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -345,6 +529,9 @@ def run_north_star(args, rank, world, local, comm_dev, dist):
     del solver  # release the device context (the batched leg and the profilers' atexit handlers come next)
     import gc
     gc.collect()
+    # N > 1: what every rank saw, so that the aggregate explains itself (which device, its own rate, its copy probe)
+    per_rank = gather_objects({"rank": rank, "device": local, "value": K / local_elapsed, "ms_per_step": local_elapsed / K * 1e3,
+                               "stream_copy_GBs": copy_gbs.value, "rows": n}, rank, world, dist)
     if rank != 0:
         return None
 
@@ -425,6 +612,9 @@ def run_north_star(args, rank, world, local, comm_dev, dist):
                      "stream_copy_GBs": copy_gbs.value, "stream_triad_GBs": triad_gbs.value,
                      "frac_of_stream_copy": achieved / copy_gbs.value if copy_gbs.value else None},
     }
+    if world > 1:
+        out["per_rank"] = per_rank
+        out["collective"] = collective_info(dist, world)
     if gram:
         out["config"]["recursion"] = "gram-space, f32 history" if f32h else "gram-space"
         if sharded:
@@ -444,6 +634,181 @@ def run_north_star(args, rank, world, local, comm_dev, dist):
     return out
 
 
+class ThreadDist:
+    """The few torch.distributed calls of this script over the threads of ONE process (--single-process: one host thread
+    per GPU instead of one process per GPU)."""
+
+    class ReduceOp:
+        MAX, SUM = "max", "sum"
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self._bar = threading.Barrier(world)
+        self._slots = [None] * world
+        self._tls = threading.local()
+
+    def bind(self, rank):
+        self._tls.rank = rank
+
+    def barrier(self):
+        self._bar.wait()
+
+    def all_gather_object(self, out, obj):
+        self._slots[self._tls.rank] = obj
+        self._bar.wait()
+        out[:] = list(self._slots)
+        self._bar.wait()
+
+    def all_reduce(self, t, op="sum"):
+        parts = [None] * self.world
+        self.all_gather_object(parts, t.clone())
+        acc = parts[0].clone()
+        for p_ in parts[1:]:
+            acc = (acc + p_) if op == "sum" else acc.max(p_)  # rank order: identical on every thread
+        t.copy_(acc)
+
+    def get_backend(self):
+        return "threads"
+
+
+def run_single_process(args, ndev_asked):
+    """--single-process --gpus N: ONE process drives all N GPUs -- one host thread and one solver context per device for the
+    single-problem legs, lbfgsx_batch_minimize_lockstep_multi for the batch, and the batch's one exchange step natively over
+    RCCL (lbfgsx_rccl_allgather_records: ncclCommInitAll + a grouped ncclAllGather).  LBFGSX_BENCH_DEVICES=0,0 lists the
+    devices explicitly (a device twice: protocol test on a one-GPU box)."""
+    import threading
+
+    import numpy as np
+    import torch
+
+    import lbfgspp_amd as A
+    from lbfgspp_amd import batched as B
+    from lbfgspp_amd import _lib as L
+    core, _ = A.load()
+    ndev = core.lbfgsx_device_count()
+    env = os.environ.get("LBFGSX_BENCH_DEVICES")
+    devices = [int(v) for v in env.split(",")] if env else list(range(ndev_asked))
+    if len(devices) != ndev_asked or any(d < 0 or d >= ndev for d in devices):
+        raise SystemExit("bench.py --single-process --gpus %d: devices %r on a box with %d GPU(s); refusing to report fewer "
+                         "GPUs than asked for" % (ndev_asked, devices, ndev))
+    world = ndev_asked
+    td = ThreadDist(world)
+    results, errors = [None] * world, []
+    cpu = torch.device("cpu")
+
+    def worker(r):
+        td.bind(r)
+        try:
+            results[r] = run_all(args, r, world, devices[r], cpu, td, batched=False)
+        except BaseException as e:  # noqa: BLE001  (a dead thread must not leave the others at a barrier)
+            errors.append(e)
+            td._bar.abort()
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if errors:
+        raise SystemExit("bench.py --single-process: %r" % (errors[0],))
+    out = results[0]
+    out["config"]["process_model"] = "one process, one host thread + one solver context per GPU (devices %r)" % devices
+    out["collective"] = {"backend": "threads for the barriers; RCCL (dlopen, ncclCommInitAll) for the batch's record gather",
+                         "world_size": world, "data_path_collectives": 0}
+    if args.workload == "north-star" and args.recursion == "vector" and not args.no_batched:
+        n, m, P, steps = 100000, 10, args.problems_per_gpu, args.batched_steps
+        total = P * world
+        par = A.LBFGSParam(m=m, epsilon=0.0, epsilon_rel=0.0, max_iterations=steps)
+        B.solve_local_lockstep(par, n, 0, min(total, 64 * world), dtype=np.float32, devices=devices)  # warm-up
+        t0 = time.perf_counter()
+        recs = B.solve_local_lockstep(par, n, 0, total, seed_base=1000, dtype=np.float32, devices=devices)
+        t1 = time.perf_counter()
+        # the exchange step: every device ends up with all records (one rank per distinct device)
+        uniq = sorted(set(devices))
+        raw = np.ascontiguousarray(recs).view(np.uint8).reshape(total, -1)
+        dv = (C.c_int * len(uniq))(*uniq)
+        outp = (C.c_void_p * len(uniq))()
+        L.check(core.lbfgsx_rccl_allgather_records(dv, len(uniq), raw.ctypes.data_as(C.c_void_p), total, raw.shape[1], outp))
+        back = np.zeros_like(raw)
+        L.check(core.lbfgsx_device_download(uniq[-1], outp[len(uniq) - 1], raw.size, back.ctypes.data_as(C.c_void_p)))
+        for k, d in enumerate(uniq):
+            core.lbfgsx_device_free(d, outp[k])
+        t2 = time.perf_counter()
+        if not np.array_equal(back, raw):
+            raise SystemExit("bench.py --single-process: the gathered records differ from the solver's")
+        its, fev = int(recs["niter"].sum()), int(recs["nfev"].sum())
+        elapsed = t2 - t0
+        hbm_ = (its * (4 * m + 2 + 12) + (fev - its) * 4) * n * 4.0
+        model_gbs = hbm_ / elapsed / 1e9 / world
+        out["cfg5_batched"] = {
+            "metric": "batched L-BFGS problem-iterations/sec (cfg5: n=1e5, m=10, f32)", "value": its / elapsed,
+            "unit": "problem-iterations/s", "n_gpus": world, "steps": steps, "ms_per_step": elapsed / max(steps, 1) * 1e3,
+            "scaling": "weak", "dtype": "f32",
+            "config": {"workload": "cfg5: %d independent extended-Rosenbrock problems per GPU, n=1e5, m=10, f32, "
+                                   "LineSearchMoreThuente, %d iterations each; ONE process: lbfgsx_batch_minimize_lockstep_multi "
+                                   "(contiguous problem-id blocks, one host thread + one lock-step batch per device) and the "
+                                   "records all-gathered natively over RCCL" % (P, steps),
+                       "problems_total": total, "fevals_total": fev, "failed": int((recs["status"] != 0).sum()),
+                       "devices": devices, "solve_seconds": t1 - t0, "rccl_allgather_seconds": t2 - t1,
+                       "rccl_ranks": len(uniq)},
+            "roofline": {"bound": "hbm", "achieved": model_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": model_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "note": "end to end per GPU, HBM traffic model of the one-launch two-loop ((4m+14) n elements per "
+                                 "iteration) / wall time, the RCCL gather included"}}
+    return out
+
+
+def run_all(args, rank, world, local, comm_dev, dist, batched=True):
+    """Everything one rank does for the chosen workload; the result object on rank 0 (None elsewhere)."""
+    if args.workload == "cfg5-batched":
+        out = run_batched(args, rank, world, local, comm_dev, dist, args.steps)
+    else:
+        out = run_north_star(args, rank, world, local, comm_dev, dist)
+        if args.workload == "north-star" and args.recursion == "vector" and not args.no_batched and batched:
+            # the mode that shards naturally (SURVEY 8(e)): same ranks, same barriers, reported inside the one line
+            b = run_batched(args, rank, world, local, comm_dev, dist, args.batched_steps)
+            if rank == 0:
+                out["cfg5_batched"] = {k: b[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step",
+                                                          "scaling", "dtype", "config", "roofline")}
+        headline = int(args.n) == 100000000 and args.m == 10 and args.objective == "rosenbrock"
+        if args.workload == "north-star" and args.recursion == "vector" and headline and not args.no_legs:
+            # the other single-GPU configurations of BASELINE.json, each through the product path with its own roofline
+            # (SURVEY 8(d)); every rank runs its own instance, like the headline
+            leg = lbfgs_leg(args, rank, world, local, comm_dev, dist, objective="quadratic", n=1e7, m=10,
+                            steps=max(args.steps, 20), warmup=12)
+            if rank == 0:
+                out["cfg2"] = leg
+            leg = lbfgs_leg(args, rank, world, local, comm_dev, dist, objective="rosenbrock", n=1e8, m=20,
+                            steps=min(args.steps, 10), warmup=22)
+            if rank == 0:
+                out["cfg3"] = leg
+            leg = run_cfg4(args, rank, world, local, comm_dev, dist, iters=args.cfg4_iters)
+            if rank == 0:
+                out["cfg4_lbfgsb"] = leg
+        if rank == 0 and not args.no_cpu and world == 1:  # the CPU baseline is timed on rank 0 of the single-GPU run only
+            try:
+                out["cpu_baseline"] = cpu_baseline(args)
+            except Exception as e:  # the baseline is reported, never required
+                out["cpu_baseline"] = {"error": repr(e)}
+            if args.cpu_full != "off" and args.workload == "north-star":
+                # the same reference at the metric's own size, measured: when it ran, IT is `cpu_baseline` and the scaled
+                # small-n sample rides along as `cpu_baseline_sample`
+                try:
+                    full = cpu_baseline_full(args)
+                except Exception as e:
+                    full = {"error": repr(e)}
+                if full and "value" in full:
+                    out["cpu_baseline_sample"] = out["cpu_baseline"]
+                    out["cpu_baseline"] = full
+                else:
+                    out["cpu_baseline_full"] = full
+            try:
+                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args)
+            except Exception as e:
+                out["cpu_baseline_all_cores"] = {"error": repr(e)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None,
@@ -454,9 +819,13 @@ def main():
     ap.add_argument("--m", type=int, default=10)
     ap.add_argument("--objective", default="rosenbrock", choices=["rosenbrock", "quadratic"])
     ap.add_argument("--cpu-n", type=float, default=2e7)
-    ap.add_argument("--cpu-steps", type=int, default=12)
+    ap.add_argument("--cpu-steps", type=int, default=6)
     ap.add_argument("--cpu-n-all", type=float, default=2e7, help="problem size of the all-cores CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-full", default="auto", choices=["auto", "on", "off"],
+                    help="1-core reference at the metric's own n (m+2 warm-up + --cpu-full-steps timed iterations of one run, "
+                         "un-extrapolated); auto: when the host has >= 48 GB available")
+    ap.add_argument("--cpu-full-steps", type=int, default=3)
     ap.add_argument("--workload", default="north-star", choices=["north-star", "cfg5-batched", "sharded"],
                     help="north-star (default, the BASELINE.json metric: one problem per GPU; its line also carries the "
                          "cfg5 batch as `cfg5_batched`), the batched cfg5 shard per GPU alone, or sharded: ONE problem of "
@@ -465,6 +834,12 @@ def main():
     ap.add_argument("--problems-per-gpu", type=int, default=1024)
     ap.add_argument("--batched-steps", type=int, default=50, help="iterations per problem of the cfg5 leg of the default line")
     ap.add_argument("--no-batched", action="store_true", help="skip the cfg5 leg of the default line")
+    ap.add_argument("--single-process", action="store_true",
+                    help="--gpus N from ONE process: one host thread + one context per GPU, the batch through "
+                         "lbfgsx_batch_minimize_lockstep_multi and its record gather natively over RCCL")
+    ap.add_argument("--no-legs", action="store_true", help="skip the cfg2 / cfg3 / cfg4 legs of the default line")
+    ap.add_argument("--cfg4-n", type=float, default=1e7, help="problem size of the L-BFGS-B leg (cfg4)")
+    ap.add_argument("--cfg4-iters", type=int, default=40, help="iterations from x0 of the L-BFGS-B leg (cfg4)")
     ap.add_argument("--recursion", default="vector", choices=["vector", "gram", "gram-f32h"],
                     help="vector (default): the reference's two-loop recursion statement by statement, the bit-parity "
                          "path the BASELINE metric is quoted on; gram: opt-in Gram-space form (SURVEY 8(f)-3), equal to "
@@ -476,8 +851,11 @@ def main():
         args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
-    if args.gpus > 1 and not launched:
+    if args.single_process and launched and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        raise SystemExit("bench.py: --single-process runs without a launcher (one process drives all GPUs)")
+    if args.gpus > 1 and not launched and not args.single_process:
         spawn_ranks(args)  # does not return
+    world_arg = args.gpus
 
     # Exactly ONE line on stdout: libraries that print there (gloo's connection notice, HIP runtime notes) are sent to
     # stderr for the whole run; the result line goes to the saved descriptor at the end.
@@ -486,26 +864,14 @@ def main():
     os.dup2(2, 1)
 
     import torch  # noqa: F401  (first: its bundled HIP runtime must be the process-wide one)
-    rank, world, local, comm_dev, dist = init_dist(args)
-    if args.workload == "cfg5-batched":
-        out = run_batched(args, rank, world, local, comm_dev, dist, args.steps)
+    if args.single_process and world_arg > 1:
+        rank, world = 0, 1
     else:
-        out = run_north_star(args, rank, world, local, comm_dev, dist)
-        if args.workload == "north-star" and args.recursion == "vector" and not args.no_batched:
-            # the mode that shards naturally: same ranks, same barriers, reported inside the one line
-            b = run_batched(args, rank, world, local, comm_dev, dist, args.batched_steps)
-            if rank == 0:
-                out["cfg5_batched"] = {k: b[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step",
-                                                          "scaling", "dtype", "config", "roofline")}
-        if rank == 0 and not args.no_cpu and world == 1:  # the CPU baseline is timed on rank 0 of the single-GPU run only
-            try:
-                out["cpu_baseline"] = cpu_baseline(args)
-            except Exception as e:  # the baseline is reported, never required
-                out["cpu_baseline"] = {"error": repr(e)}
-            try:
-                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args)
-            except Exception as e:
-                out["cpu_baseline_all_cores"] = {"error": repr(e)}
+        rank, world, local, comm_dev, dist = init_dist(args)
+    if args.single_process and world_arg > 1:
+        out = run_single_process(args, world_arg)
+    else:
+        out = run_all(args, rank, world, local, comm_dev, dist)
     if rank == 0:
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())

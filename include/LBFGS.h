@@ -48,6 +48,7 @@ class LBFGSSolver
     Scalar m_gnorm = Scalar(0);
     int m_device = 0;
     int m_nfev = 0;
+    int m_x_at_throw = LBFGSX_VEC_X;  // which device vector is "x" for a caller that catches an exception of minimize()
     int m_recursion = RECURSION_VECTOR;  // extension: see set_recursion()
     std::function<void(int, Scalar, DeviceState<Scalar>&)> m_trace;
     std::function<void(int)> m_iter_hook;
@@ -123,6 +124,7 @@ class LBFGSSolver
         {
             detail::check(lbfgsx_ls_begin(c));
             const Scalar step_max = m_param.max_step;
+            ev.trial_written = false;
             try
             {
                 // the device form of the built-in policies, or the reference's ten-argument form of a user policy
@@ -132,6 +134,8 @@ class LBFGSSolver
             catch (...)
             {
                 m_nfev = ev.nfev();  // keep the evaluation count truthful when the search throws
+                if (ev.trial_written)
+                    m_x_at_throw = LBFGSX_VEC_XT;  // the reference's policies wrote their trial into x before throwing
                 throw;
             }
             m_nfev = ev.nfev();
@@ -244,15 +248,18 @@ public:
         m_dev.ensure(n, m_param.m, 0, m_device);
         m_dev.upload(LBFGSX_VEC_X, x.data());
         int k = 0;
+        m_x_at_throw = LBFGSX_VEC_X;
         try
         {
             k = run<Foo, Vec>(f, fx);
         }
         catch (...)
         {
-            // a line search that throws leaves its last trial point in the caller's x (the reference's policies write
-            // the trial into x itself, LineSearchNocedalWright.h:146, LineSearchMoreThuente.h:412)
-            (void) lbfgsx_download(m_dev.ctx(), LBFGSX_VEC_XT, x.data());
+            // A line search that throws after a trial leaves that trial point in the caller's x (the reference's policies
+            // write the trial into x itself, LineSearchNocedalWright.h:146, LineSearchMoreThuente.h:412).  Anything thrown
+            // before a trial was written -- the functor at x0, a policy's entry checks ("the moving direction increases
+            // the objective function value"), a device error -- leaves the current iterate there, as in the reference.
+            (void) lbfgsx_download(m_dev.ctx(), m_x_at_throw, x.data());
             throw;
         }
         m_dev.download(LBFGSX_VEC_X, x.data());

@@ -42,6 +42,7 @@ class LBFGSBSolver
     Scalar m_projgnorm = Scalar(0);
     int m_device = 0;
     int m_nfev = 0;
+    int m_x_at_throw = LBFGSX_VEC_X;  // which device vector is "x" for a caller that catches an exception of minimize()
     std::function<void(int, Scalar, DeviceState<Scalar>&)> m_trace;
     std::function<void(int)> m_iter_hook;
 
@@ -57,6 +58,9 @@ public:
         long long gcp_dev_crossings = 0, gcp_sort_fallbacks = 0, gcp_partial_sorts = 0;
         long long submin_fused_sweeps = 0;
         long long gram_carried = 0;  // first solves whose W_F'W_F came from the carried sums
+        long long gcp_searches = 0;  // generalized-Cauchy-point searches
+        long long gcp_nord = 0;      // sum over the searches of the finite positive break points (the reference's |ord|)
+        long long gcp_sorted = 0;    // ... of which were actually sorted (partial sort)
     };
 
 private:
@@ -94,6 +98,9 @@ private:
         Cauchy<Scalar>::get_cauchy_point(m_bfgs, gcp);                  // (:154)
         m_stats.gcp_crossings += gcp.crossings;
         m_stats.gcp_dev_crossings += gcp.dev_crossings;
+        m_stats.gcp_searches++;
+        m_stats.gcp_nord += gcp.nord_total;
+        m_stats.gcp_sorted += gcp.sorted;
         m_stats.gcp_build_s += gcp.t_build;
         m_stats.gcp_fetch_s += gcp.t_fetch;
         m_stats.gcp_total_s += gcp.t_total;
@@ -120,6 +127,7 @@ private:
             Scalar step = Scalar(1);
             step = std::min(step, step_max);
             const auto t_ls = std::chrono::steady_clock::now();
+            ev.trial_written = false;
             try
             {
                 // the device form of the built-in policies, or the reference's ten-argument form of a user policy
@@ -129,6 +137,8 @@ private:
             catch (...)
             {
                 m_nfev = ev.nfev();  // keep the evaluation count truthful when the search throws
+                if (ev.trial_written)
+                    m_x_at_throw = LBFGSX_VEC_XT;  // the reference's policies wrote their trial into x before throwing
                 throw;
             }
             m_nfev = ev.nfev();
@@ -160,6 +170,9 @@ private:
             m_stats.gcp_dev_crossings += gcp.dev_crossings;
             m_stats.gcp_sort_fallbacks = gcp.sort_fallbacks;
             m_stats.gcp_partial_sorts += (gcp.sorted < gcp.nord_total) ? 1 : 0;
+            m_stats.gcp_searches++;
+            m_stats.gcp_nord += gcp.nord_total;
+            m_stats.gcp_sorted += gcp.sorted;
             m_stats.gcp_build_s += gcp.t_build;
             m_stats.gcp_fetch_s += gcp.t_fetch;
             m_stats.gcp_total_s += gcp.t_total;
@@ -211,14 +224,16 @@ public:
         m_dev.upload(LBFGSX_VEC_LB, lb.data());
         m_dev.upload(LBFGSX_VEC_UB, ub.data());
         int k = 0;
+        m_x_at_throw = LBFGSX_VEC_X;
         try
         {
             k = run<Foo, Vec>(f, fx);
         }
         catch (...)
         {
-            // as in the reference, a line search that throws leaves its last trial point in x (LineSearchMoreThuente.h:412)
-            (void) lbfgsx_download(m_dev.ctx(), LBFGSX_VEC_XT, x.data());
+            // as in the reference, a line search that throws after a trial leaves that trial point in x
+            // (LineSearchMoreThuente.h:412); anything thrown before a trial was written leaves the current iterate
+            (void) lbfgsx_download(m_dev.ctx(), m_x_at_throw, x.data());
             throw;
         }
         m_dev.download(LBFGSX_VEC_X, x.data());

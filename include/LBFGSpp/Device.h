@@ -150,6 +150,14 @@ class Evaluator
             // returns and the solver's next kernel may read the gradient it wrote.
             m_s.sync();
             DeviceVector<Scalar> x = m_s.vec(xwhich), g = m_s.vec(gwhich);
+            // the functor launches its own kernels on x and g: they live on the context's device, which need not be the
+            // calling thread's current one (set_device(k), several solvers per thread) -- make it current for the call
+            struct Current
+            {
+                int prev = -1;
+                explicit Current(lbfgsx_ctx* c) { check(lbfgsx_device_push(c, &prev)); }
+                ~Current() { (void) lbfgsx_device_pop(prev); }
+            } current(m_s.ctx());
             const Scalar fx = m_f(static_cast<const DeviceVector<Scalar>&>(x), g);
             return fx;
         }
@@ -172,6 +180,10 @@ public:
     // Row-sharded runs (LBFGSSolver::set_reducer): every bundle of n-length sums a statement returns is summed over
     // the shards (an all-reduce) before any scalar logic sees it, so all ranks take identical decisions.
     std::function<void(double*, int)> reduce;
+    // has the line search in progress written a trial point (x = xp + step * drt) yet?  A search that throws afterwards
+    // leaves that point in the caller's x, as the reference's policies do; one that throws at its entry checks, or an
+    // exception from anywhere else, leaves the current iterate there.  The solver clears it before every search.
+    bool trial_written = false;
 
     Evaluator(Foo& f, DeviceState<Scalar>& s) : m_f(f), m_s(s) {}
     int nfev() const { return m_nfev; }
@@ -237,10 +249,12 @@ public:
         if constexpr (is_builtin)
         {
             check(lbfgsx_trial(m_s.ctx(), m_f.id, double(step), &r0, &r1));
+            trial_written = true;
         }
         else
         {
             check(lbfgsx_trial_point(m_s.ctx(), double(step)));
+            trial_written = true;
             r0 = double(call_user(LBFGSX_VEC_XT, LBFGSX_VEC_GT));
             check(lbfgsx_trial_dg(m_s.ctx(), &r1));
         }

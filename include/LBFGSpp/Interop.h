@@ -93,7 +93,17 @@ inline void run_line_search(Ev& ev, const Param& param, const Scalar& step_max, 
         for (std::int64_t i = 0; i < n; i++)
             x[i] = xp[i];
         HostObjective<Scalar, Ev, HostVec> f{ev};
-        Policy::LineSearch(f, param, xp, drt, step_max, step, fx, grad, dg, x);
+        try
+        {
+            Policy::LineSearch(f, param, xp, drt, step_max, step, fx, grad, dg, x);
+        }
+        catch (...)
+        {
+            // the policy's x is what the reference would leave in the caller's vector: park it where minimize() looks
+            ev.state().upload(LBFGSX_VEC_XT, x.data());
+            ev.trial_written = true;
+            throw;
+        }
         ev.finish_host_point(x, grad);
     }
 }

@@ -136,6 +136,25 @@ int lbfgsx_commit_correction(lbfgsx_ctx* c);
 int lbfgsx_post_linesearch_spec(lbfgsx_ctx* c, double a, double* gnorm2, double* xnorm2, double* sy, double* yy);
 /* instrumentation: {fused launches, directions taken over by lbfgsx_apply_Hv, pairs rejected by the kernel} */
 int lbfgsx_spec_counts(const lbfgsx_ctx* c, int64_t out[3]);
+/* Every entry point of this ABI makes the context's device current for its own duration and restores the caller's
+ * afterwards.  Code that launches its OWN kernels on the context's vectors (a device functor, lbfgsx_vec) must run with
+ * that device current too: lbfgsx_device tells which one it is, lbfgsx_device_push makes it current for the calling
+ * thread (returning the previous one in *prev), lbfgsx_device_pop restores.  The drop-in solvers bracket every call of a
+ * device functor with the pair (LBFGSpp/Device.h, Evaluator::call_user). */
+int lbfgsx_device(const lbfgsx_ctx* c);
+int lbfgsx_device_push(const lbfgsx_ctx* c, int* prev);
+int lbfgsx_device_pop(int prev);
+/* The persistent launch survives a device it does not own: a meeting point that waits longer than 100 ms flags the launch,
+ * the product is redone with the 2c+1 step launches (bit-identical), which the context keeps for 8 products before it tries
+ * the persistent form again; every further time-out quadruples that pause, a clean persistent launch resets it.
+ * out = {persistent launches, time-outs, products left of the current pause, products computed with step launches}. */
+int lbfgsx_persist_counts(const lbfgsx_ctx* c, int64_t out[4]);
+/* test hook: sets the failure word the next persistent launch of this context will find (as if a meeting point had timed
+ * out); that launch does nothing and the host takes the recovery path above */
+int lbfgsx_debug_persist_fault(lbfgsx_ctx* c);
+/* instrumentation, process-wide: {kernel launches, stream synchronisations, asynchronous copies} issued by the library
+ * since load (or the last call with reset != 0).  bench.py divides them by the iterations of its L-BFGS-B leg. */
+int lbfgsx_counters(int64_t out[3], int reset);
 
 /* ---- Gram-space ("vector-free") form of the recursion: opt-in, outside the bit-parity contract ----
  * BFGSMat::apply_Hv (BFGSMat.h:276-302) only combines the 2c+1 vectors [S, Y, g]; with their Gram matrix kept on the

@@ -91,6 +91,9 @@ int lbfgsx_solver_stats(lbfgsx_solver* s, long long out[8]);
 /* more of the same: {GCP crossings handled by the device search, partial sorts that had to be redone in full,
  * searches served by a partial sort, subspace us, line-search us, add_correction us, 0, 0} */
 int lbfgsx_solver_stats2(lbfgsx_solver* s, long long out[8]);
+/* and: {GCP searches, sum of their finite positive break points (the reference's |ord|, Cauchy.h:132-133), sum of the
+ * break points actually sorted, 0, 0, 0, 0, 0} */
+int lbfgsx_solver_stats3(lbfgsx_solver* s, long long out[8]);
 /* minimize(): objective = LBFGSX_OBJ_*; a/b host arrays or NULL (resident); x host in/out or NULL (resident:
  * start point in LBFGSX_VEC_X, result left there); lb/ub host arrays or NULL (resident), L-BFGS-B only */
 int lbfgsx_solver_minimize(lbfgsx_solver* s, int objective, int64_t n, const void* a, const void* b, void* x,

@@ -117,6 +117,10 @@ def load():
     sig(core, "lbfgsx_device_download", i32, i32, vp, i64, vp)
     sig(core, "lbfgsx_device_free", None, i32, vp)
     sig(core, "lbfgsx_spec_counts", i32, vp, C.POINTER(i64 * 3))
+    sig(core, "lbfgsx_counters", i32, C.POINTER(i64 * 3), i32)
+    sig(core, "lbfgsx_device", i32, vp)
+    sig(core, "lbfgsx_persist_counts", i32, vp, C.POINTER(i64 * 4))
+    sig(core, "lbfgsx_debug_persist_fault", i32, vp)
 
     sig(sol, "lbfgsx_solver_create", i32, C.POINTER(vp), i32, i32, i32, C.POINTER(Params), i32)
     sig(sol, "lbfgsx_solver_create_error", C.c_char_p)
@@ -136,6 +140,7 @@ def load():
     sig(sol, "lbfgsx_solver_hessians", i32, vp, vp, vp)
     sig(sol, "lbfgsx_solver_stats", i32, vp, C.POINTER(C.c_longlong * 8))
     sig(sol, "lbfgsx_solver_stats2", i32, vp, C.POINTER(C.c_longlong * 8))
+    sig(sol, "lbfgsx_solver_stats3", i32, vp, C.POINTER(C.c_longlong * 8))
     sig(sol, "lbfgsx_solver_minimize", i32, vp, i32, i64, vp, vp, vp, vp, vp, C.POINTER(Trace), C.POINTER(Result))
     _core, _solver = core, sol
     return core, sol

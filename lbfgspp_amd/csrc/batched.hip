@@ -638,7 +638,7 @@ void lbfgsx_bat_destroy(lbfgsx_batch* c)
     if (!c)
         return;
     lbfgsx::DeviceGuard dev_guard_(c->device);
-    (void) hipStreamSynchronize(c->stream);
+    (void) lbfgsx::stream_sync(c->stream);
     live_add(c->device, -1);
     void* ptrs[] = {c->X, c->G, c->D, c->S, c->Y, c->sc, c->ws.partials, c->ws.ticket, c->desc_dev, c->hvdesc_dev};
     if (c->hvdesc_host)
@@ -666,7 +666,7 @@ int lbfgsx_bat_gen_rosen_x0(lbfgsx_batch* c, uint64_t seed0)
 {
     lbfgsx::DeviceGuard dev_guard_(c->device);
     const dim3 grid(unsigned(std::max(c->gx, 8)), unsigned(c->P));
-    BAT_DISPATCH(c, { hipLaunchKernelGGL((kb_gen_rosen<T>), grid, dim3(kBlock), 0, c->stream, bufs<T>(c), c->n, seed0); });
+    BAT_DISPATCH(c, { LBFGSX_LAUNCH((kb_gen_rosen<T>), grid, dim3(kBlock), 0, c->stream, bufs<T>(c), c->n, seed0); });
     LBFGSX_HIP(hipGetLastError());
     return LBFGSX_OK;
 }
@@ -676,9 +676,9 @@ int lbfgsx_bat_gen_rosen_x0(lbfgsx_batch* c, uint64_t seed0)
 int lbfgsx_bat_launch(lbfgsx_batch* c, int kind, int objective, const lbfgsx_bat_desc* desc, int nout, double* out)
 {
     lbfgsx::DeviceGuard dev_guard_(c->device);
-    LBFGSX_HIP(hipStreamSynchronize(c->stream));  // the pinned descriptor staging may still be in flight
+    LBFGSX_HIP(lbfgsx::stream_sync(c->stream));  // the pinned descriptor staging may still be in flight
     std::memcpy(c->hdesc, desc, sizeof(BatDesc) * size_t(c->P));
-    LBFGSX_HIP(hipMemcpyAsync(c->desc_dev, c->hdesc, sizeof(BatDesc) * size_t(c->P), hipMemcpyHostToDevice, c->stream));
+    LBFGSX_HIP(lbfgsx::copy_async(c->desc_dev, c->hdesc, sizeof(BatDesc) * size_t(c->P), hipMemcpyHostToDevice, c->stream));
     const dim3 grid(unsigned(c->gx), unsigned(c->P));
     if (kind != 3 && kind != 2 && objective != LBFGSX_OBJ_EXT_ROSENBROCK)
     {
@@ -689,10 +689,10 @@ int lbfgsx_bat_launch(lbfgsx_batch* c, int kind, int objective, const lbfgsx_bat
         BatBufs<T> b = bufs<T>(c);
         switch (kind)
         {
-        case 0: hipLaunchKernelGGL((kb_eval<T, ObjRosen<T> >), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n, ObjRosen<T>{}, c->ws); break;
-        case 1: hipLaunchKernelGGL((kb_trial<T, ObjRosen<T> >), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n, ObjRosen<T>{}, c->ws); break;
-        case 2: hipLaunchKernelGGL((kb_post<T>), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n, c->ws); break;
-        default: hipLaunchKernelGGL((kb_twoloop<T>), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n, c->ws,
+        case 0: LBFGSX_LAUNCH((kb_eval<T, ObjRosen<T> >), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n, ObjRosen<T>{}, c->ws); break;
+        case 1: LBFGSX_LAUNCH((kb_trial<T, ObjRosen<T> >), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n, ObjRosen<T>{}, c->ws); break;
+        case 2: LBFGSX_LAUNCH((kb_post<T>), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n, c->ws); break;
+        default: LBFGSX_LAUNCH((kb_twoloop<T>), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n, c->ws,
                                     (c->zigzag && (c->tl_step++ & 1u)) ? 1 : 0); break;
         }
     });
@@ -711,8 +711,8 @@ int lbfgsx_bat_launch(lbfgsx_batch* c, int kind, int objective, const lbfgsx_bat
                 LBFGSX_HIP(hipHostMalloc(&c->hout, tot * sizeof(T), hipHostMallocDefault));
                 c->hout_cap = tot * sizeof(T);
             }
-            LBFGSX_HIP(hipMemcpyAsync(c->hout, c->sc, tot * sizeof(T), hipMemcpyDeviceToHost, c->stream));
-            LBFGSX_HIP(hipStreamSynchronize(c->stream));
+            LBFGSX_HIP(lbfgsx::copy_async(c->hout, c->sc, tot * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+            LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
             const T* tab = static_cast<const T*>(c->hout);
             for (int p = 0; p < c->P; p++)
                 for (int k = 0; k < nout; k++)
@@ -732,25 +732,25 @@ int lbfgsx_bat_apply_Hv(lbfgsx_batch* c, const lbfgsx_bat_hvdesc* desc)
         set_error("lbfgsx_bat_apply_Hv: vector does not fit one block's registers");
         return LBFGSX_E_INVALID;
     }
-    LBFGSX_HIP(hipStreamSynchronize(c->stream));  // the pinned staging may still be in flight
+    LBFGSX_HIP(lbfgsx::stream_sync(c->stream));  // the pinned staging may still be in flight
     if (!c->hvdesc_dev)
     {
         LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&c->hvdesc_dev), sizeof(BatHvDesc) * size_t(c->P)));
         LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->hvdesc_host), sizeof(BatHvDesc) * size_t(c->P), hipHostMallocDefault));
     }
     std::memcpy(c->hvdesc_host, desc, sizeof(BatHvDesc) * size_t(c->P));
-    LBFGSX_HIP(hipMemcpyAsync(c->hvdesc_dev, c->hvdesc_host, sizeof(BatHvDesc) * size_t(c->P), hipMemcpyHostToDevice, c->stream));
+    LBFGSX_HIP(lbfgsx::copy_async(c->hvdesc_dev, c->hvdesc_host, sizeof(BatHvDesc) * size_t(c->P), hipMemcpyHostToDevice, c->stream));
     const int slots = int((nv + kHvThreads - 1) / kHvThreads);
     BAT_DISPATCH(c, {
         BatBufs<T> b = bufs<T>(c);
         if (slots <= 14)
-            hipLaunchKernelGGL((kb_twoloop_full<T, 14>), dim3(c->P), dim3(kHvThreads), 0, c->stream, b, c->hvdesc_dev, c->n, c->m);
+            LBFGSX_LAUNCH((kb_twoloop_full<T, 14>), dim3(c->P), dim3(kHvThreads), 0, c->stream, b, c->hvdesc_dev, c->n, c->m);
         else if (slots <= 28)
-            hipLaunchKernelGGL((kb_twoloop_full<T, 28>), dim3(c->P), dim3(kHvThreads), 0, c->stream, b, c->hvdesc_dev, c->n, c->m);
+            LBFGSX_LAUNCH((kb_twoloop_full<T, 28>), dim3(c->P), dim3(kHvThreads), 0, c->stream, b, c->hvdesc_dev, c->n, c->m);
         else if (slots <= 56)
-            hipLaunchKernelGGL((kb_twoloop_full<T, 56>), dim3(c->P), dim3(kHvThreads), 0, c->stream, b, c->hvdesc_dev, c->n, c->m);
+            LBFGSX_LAUNCH((kb_twoloop_full<T, 56>), dim3(c->P), dim3(kHvThreads), 0, c->stream, b, c->hvdesc_dev, c->n, c->m);
         else
-            hipLaunchKernelGGL((kb_twoloop_full<T, 98>), dim3(c->P), dim3(kHvThreads), 0, c->stream, b, c->hvdesc_dev, c->n, c->m);
+            LBFGSX_LAUNCH((kb_twoloop_full<T, 98>), dim3(c->P), dim3(kHvThreads), 0, c->stream, b, c->hvdesc_dev, c->n, c->m);
     });
     LBFGSX_HIP(hipGetLastError());
     return LBFGSX_OK;
@@ -768,8 +768,8 @@ int lbfgsx_bat_fetch(lbfgsx_batch* c, const int* idx, double* out)
             LBFGSX_HIP(hipHostMalloc(&c->hout, tot * sizeof(T), hipHostMallocDefault));
             c->hout_cap = tot * sizeof(T);
         }
-        LBFGSX_HIP(hipMemcpyAsync(c->hout, c->sc, tot * sizeof(T), hipMemcpyDeviceToHost, c->stream));
-        LBFGSX_HIP(hipStreamSynchronize(c->stream));
+        LBFGSX_HIP(lbfgsx::copy_async(c->hout, c->sc, tot * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+        LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
         const T* tab = static_cast<const T*>(c->hout);
         for (int p = 0; p < c->P; p++)
             out[p] = double(tab[size_t(p) * size_t(c->scn) + size_t(idx[p])]);
@@ -782,15 +782,15 @@ int lbfgsx_bat_download_x(lbfgsx_batch* c, int p, int pt, void* host)
 {
     lbfgsx::DeviceGuard dev_guard_(c->device);
     const char* base = static_cast<const char*>(c->X) + (size_t(pt) * c->P + size_t(p)) * size_t(c->ld) * c->esz;
-    LBFGSX_HIP(hipMemcpyAsync(host, base, size_t(c->n) * c->esz, hipMemcpyDeviceToHost, c->stream));
-    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    LBFGSX_HIP(lbfgsx::copy_async(host, base, size_t(c->n) * c->esz, hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
     return LBFGSX_OK;
 }
 
 int lbfgsx_bat_sync(lbfgsx_batch* c)
 {
     lbfgsx::DeviceGuard dev_guard_(c->device);
-    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
     return LBFGSX_OK;
 }
 }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -23,6 +24,30 @@ void set_error(const std::string& msg);
             lbfgsx::set_error(std::string(#expr) + ": " + hipGetErrorString(e_) + " [" + __FILE__ + ":" + std::to_string(__LINE__) + "]");            \
             return LBFGSX_E_HIP;                                                              \
         }                                                                                     \
+    } while (0)
+
+// Process-wide instrumentation (lbfgsx_counters): kernel launches, stream synchronisations and asynchronous copies issued
+// by the library.  bench.py reports them per L-BFGS-B iteration; relaxed atomics, nothing is ordered by them.
+struct Counters
+{
+    std::atomic<int64_t> launches{0}, syncs{0}, copies{0};
+};
+Counters& counters();  // lbfgsx.hip
+inline hipError_t stream_sync(hipStream_t s)
+{
+    counters().syncs.fetch_add(1, std::memory_order_relaxed);
+    return hipStreamSynchronize(s);
+}
+inline hipError_t copy_async(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s)
+{
+    counters().copies.fetch_add(1, std::memory_order_relaxed);
+    return hipMemcpyAsync(dst, src, bytes, kind, s);
+}
+#define LBFGSX_LAUNCH(...)                                                        \
+    do                                                                            \
+    {                                                                             \
+        lbfgsx::counters().launches.fetch_add(1, std::memory_order_relaxed);      \
+        hipLaunchKernelGGL(__VA_ARGS__);                                          \
     } while (0)
 
 // Every ABI entry that allocates, launches or records runs with the context's device current and restores the caller's
@@ -128,6 +153,13 @@ struct lbfgsx_ctx
     unsigned tl_step = 0;  // launches issued so far (parity selects the direction)
     // persistent one-launch apply_Hv (k_twoloop_persist)
     bool persist = true;           // LBFGSX_PERSIST=0: always the 2c+1 step launches
+    // A persistent launch whose meeting points timed out (CUs held by another process) is redone with the step launches,
+    // which the context then keeps for `persist_cooldown` products before it tries the persistent form again; every
+    // further time-out quadruples the pause (8, 32, ... 8192 products), a clean persistent product resets it.
+    int persist_cooldown = 0;
+    int persist_backoff = 8;
+    int64_t persist_timeouts = 0;  // instrumentation (lbfgsx_persist_counts)
+    int64_t step_products = 0;     // products computed with the 2c+1 step launches
     int persist_grid = 0;          // co-resident blocks (occupancy * CUs), 0 = unavailable
     unsigned* gen_dev = nullptr;   // generation word + error word
     unsigned gen_count = 0;

@@ -501,7 +501,7 @@ static int gs_post_t(lbfgsx_ctx* c, double* scal, double* sdots, double* gdots)
     do                                                                \
     {                                                                 \
         NCsel = NC;                                                   \
-        hipLaunchKernelGGL((k_gs_post<T, NC>), GS_POST_ARGS);         \
+        LBFGSX_LAUNCH((k_gs_post<T, NC>), GS_POST_ARGS);         \
     } while (0)
     if (nc == 0) GS_POST(1);
     else if (nc <= 8) GS_POST(8);
@@ -519,8 +519,8 @@ static int gs_post_t(lbfgsx_ctx* c, double* scal, double* sdots, double* gdots)
         c->ev_twoloop.push_back(ev);  // reported as the "step" figures of lbfgsx_timing_read in this mode
     }
     const int nout = GS_NSCAL + 2 * NCsel;
-    LBFGSX_HIP(hipMemcpyAsync(g->out_host, g->out_dev, sizeof(double) * size_t(nout), hipMemcpyDeviceToHost, c->stream));
-    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    LBFGSX_HIP(lbfgsx::copy_async(g->out_host, g->out_dev, sizeof(double) * size_t(nout), hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
     const double* h = g->out_host;
     for (int k = 0; k < GS_NSCAL; k++)
         scal[k] = h[k];
@@ -568,7 +568,7 @@ static int gs_direction_t(lbfgsx_ctx* c, const double* coef, double coef_g, doub
 #define GS_COMB(NC)                                                              \
     do                                                                           \
     {                                                                            \
-        hipLaunchKernelGGL((k_gs_combine<T, NC>), GS_COMB_ARGS);                 \
+        LBFGSX_LAUNCH((k_gs_combine<T, NC>), GS_COMB_ARGS);                 \
     } while (0)
     if (nc == 0) GS_COMB(1);
     else if (nc <= 8) GS_COMB(8);
@@ -585,8 +585,8 @@ static int gs_direction_t(lbfgsx_ctx* c, const double* coef, double coef_g, doub
         LBFGSX_HIP(hipEventRecord(hv.b, c->stream));
         c->ev_hv.push_back(hv);
     }
-    LBFGSX_HIP(hipMemcpyAsync(g->out_host, g->out_dev, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    LBFGSX_HIP(lbfgsx::copy_async(g->out_host, g->out_dev, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
     if (dg)
         *dg = double(T(g->out_host[0]));
     return LBFGSX_OK;
@@ -628,7 +628,7 @@ static int gs_post_mx(lbfgsx_ctx* c, double* scal, double* sdots, double* gdots,
     do                                                                                                                      \
     {                                                                                                                       \
         NCsel = NC;                                                                                                         \
-        hipLaunchKernelGGL((k_gs_post_mx<NC>), dim3(grid), dim3(kBlock), 0, c->stream,                                      \
+        LBFGSX_LAUNCH((k_gs_post_mx<NC>), dim3(grid), dim3(kBlock), 0, c->stream,                                      \
                            static_cast<const double*>(c->xb[c->cur]), static_cast<const double*>(c->xb[c->xp]),             \
                            static_cast<const double*>(c->gb[c->cur]), static_cast<const double*>(c->gb[c->xp]),             \
                            g->S32 + size_t(c->spare) * size_t(c->ld), g->Y32 + size_t(c->spare) * size_t(c->ld), cols, nc,  \
@@ -650,8 +650,8 @@ static int gs_post_mx(lbfgsx_ctx* c, double* scal, double* sdots, double* gdots,
         c->ev_twoloop.push_back(ev);
     }
     const int nout = GS_NSCAL + 3 * NCsel;
-    LBFGSX_HIP(hipMemcpyAsync(g->out_host, g->out_dev, sizeof(double) * size_t(nout), hipMemcpyDeviceToHost, c->stream));
-    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    LBFGSX_HIP(lbfgsx::copy_async(g->out_host, g->out_dev, sizeof(double) * size_t(nout), hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
     const double* h = g->out_host;
     for (int k = 0; k < GS_NSCAL; k++)
         scal[k] = h[k];
@@ -698,7 +698,7 @@ static int gs_direction_mx(lbfgsx_ctx* c, const double* coef, double coef_g, dou
         LBFGSX_HIP(hipEventRecord(hv.a, c->stream));
     }
 #define GS_COMBMX(NC)                                                                                                     \
-    hipLaunchKernelGGL((k_gs_combine_mx<NC>), dim3(grid), dim3(kBlock), 0, c->stream, static_cast<double*>(c->d),         \
+    LBFGSX_LAUNCH((k_gs_combine_mx<NC>), dim3(grid), dim3(kBlock), 0, c->stream, static_cast<double*>(c->d),         \
                        static_cast<const double*>(c->gb[c->cur]), coef_g, cols, cf, nc, c->n, c->ws.partials, g->ticket,  \
                        g->out_dev, rev)
     if (nc == 0) GS_COMBMX(1);
@@ -715,8 +715,8 @@ static int gs_direction_mx(lbfgsx_ctx* c, const double* coef, double coef_g, dou
         LBFGSX_HIP(hipEventRecord(hv.b, c->stream));
         c->ev_hv.push_back(hv);
     }
-    LBFGSX_HIP(hipMemcpyAsync(g->out_host, g->out_dev, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    LBFGSX_HIP(lbfgsx::copy_async(g->out_host, g->out_dev, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
     if (dg)
         *dg = g->out_host[0];
     return LBFGSX_OK;
@@ -730,12 +730,12 @@ extern "C" {
 
 int lbfgsx_gs_set_history_dtype(lbfgsx_ctx* c, int dtype)
 {
-    lbfgsx::DeviceGuard dev_guard_(c->device);
     if (!c || (dtype != LBFGSX_F64 && dtype != LBFGSX_F32))
     {
         set_error("lbfgsx_gs_set_history_dtype: invalid argument");
         return LBFGSX_E_INVALID;
     }
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     if (c->ncorr != 0 || c->pending)
     {
         set_error("lbfgsx_gs_set_history_dtype: the history must be empty (call lbfgsx_bfgs_reset first)");
@@ -770,12 +770,13 @@ int lbfgsx_gs_set_history_dtype(lbfgsx_ctx* c, int dtype)
 
 int lbfgsx_gs_post_linesearch(lbfgsx_ctx* c, double scal[7], double* sdots, double* gdots, double* ydots)
 {
-    lbfgsx::DeviceGuard dev_guard_(c->device);
     if (!c || !scal || !sdots || !gdots)
     {
         set_error("lbfgsx_gs_post_linesearch: null argument");
         return LBFGSX_E_INVALID;
     }
+    c->spec_valid = false;  // the spare column is rewritten
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     if (2 * c->m > kGsMaxCols)
     {
         set_error("lbfgsx_gs_post_linesearch: the Gram-space recursion supports m <= 24");
@@ -793,12 +794,13 @@ int lbfgsx_gs_post_linesearch(lbfgsx_ctx* c, double scal[7], double* sdots, doub
 
 int lbfgsx_gs_direction(lbfgsx_ctx* c, const double* coef, double coef_g, double* dg)
 {
-    lbfgsx::DeviceGuard dev_guard_(c->device);
     if (!c || (!coef && c->ncorr > 0))
     {
         set_error("lbfgsx_gs_direction: null argument");
         return LBFGSX_E_INVALID;
     }
+    c->spec_valid = false;  // the direction buffer is rewritten
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     if (2 * c->m > kGsMaxCols)
     {
         set_error("lbfgsx_gs_direction: the Gram-space recursion supports m <= 24");

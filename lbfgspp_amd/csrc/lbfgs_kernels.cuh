@@ -674,6 +674,14 @@ __global__ void __launch_bounds__(kHvThreads, 2)
     const int tid = threadIdx.x;
     if (tid < kPersistMaxM)
         s_pcol[tid] = pa.pcol[tid];
+    // A launch that finds the failure word already set does nothing at all: every block sees the same word, so the grid
+    // leaves uniformly and the host redoes the product with the step launches (also the hook of the fault-injection test,
+    // lbfgsx_debug_persist_fault).  s_verdict doubles as the flag; FUSE rewrites it at the first meeting point.
+    if (tid == 0)
+        s_verdict = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_verdict != 0)
+        return;
     __syncthreads();
     const int cn = pa.ncorr, m = pa.m;
     const int64_t nv = n / W;
@@ -784,6 +792,7 @@ __global__ void __launch_bounds__(kHvThreads, 2)
         if (tid == 0)
         {
             unsigned spins = 0;
+            bool gave_up = false;
             const unsigned long long t_begin = wall_clock64();
             while (int(__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want0) < 0)
             {
@@ -793,10 +802,12 @@ __global__ void __launch_bounds__(kHvThreads, 2)
                      __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
                 {
                     __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    gave_up = true;
                     break;
                 }
             }
-            s_verdict = __hip_atomic_load(pf.verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // a block that gave up must not act on the verdict word: it may still hold the previous launch's value
+            s_verdict = gave_up ? 2 : __hip_atomic_load(pf.verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         if (s_verdict != 1)

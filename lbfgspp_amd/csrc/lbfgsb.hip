@@ -178,7 +178,7 @@ static int upload_phys(lbfgsx_ctx* c)
     if (c->bstate->phys_seen == c->phys_version)  // the map changes once per accepted correction, the operators
         return LBFGSX_OK;                         // that read it run a dozen times per iteration
     c->bstate->phys_seen = c->phys_version;
-    LBFGSX_HIP(hipMemcpyAsync(c->bstate->phys_dev, c->phys.data(), sizeof(int) * size_t(c->m), hipMemcpyHostToDevice, c->stream));
+    LBFGSX_HIP(lbfgsx::copy_async(c->bstate->phys_dev, c->phys.data(), sizeof(int) * size_t(c->m), hipMemcpyHostToDevice, c->stream));
     return LBFGSX_OK;
 }
 
@@ -187,14 +187,14 @@ static int fetch_doubles(lbfgsx_ctx* c, int k, double* out)
     if (c->bstate->dout_host)
     {
         // dout is host-mapped: the kernel's stores are visible once the stream has drained (no copy kernel)
-        LBFGSX_HIP(hipStreamSynchronize(c->stream));
+        LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
         const volatile double* h = c->bstate->dout_host;
         for (int i = 0; i < k; i++)
             out[i] = h[i];
         return LBFGSX_OK;
     }
-    LBFGSX_HIP(hipMemcpyAsync(c->hout, c->bstate->dout, sizeof(double) * size_t(k), hipMemcpyDeviceToHost, c->stream));
-    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    LBFGSX_HIP(lbfgsx::copy_async(c->hout, c->bstate->dout, sizeof(double) * size_t(k), hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
     std::memcpy(out, c->hout, sizeof(double) * size_t(k));
     return LBFGSX_OK;
 }
@@ -204,14 +204,14 @@ static int fetch_T(lbfgsx_ctx* c, int idx, int k, double* out)
 {
     if (idx == c->sl.out(0) && c->outmap_dev)
     {
-        LBFGSX_HIP(hipStreamSynchronize(c->stream));
+        LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
         const volatile T* h = static_cast<const volatile T*>(c->outmap_host);
         for (int i = 0; i < k; i++)
             out[i] = double(h[i]);
         return LBFGSX_OK;
     }
-    LBFGSX_HIP(hipMemcpyAsync(c->hout, P<T>(c->sc) + idx, sizeof(T) * size_t(k), hipMemcpyDeviceToHost, c->stream));
-    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    LBFGSX_HIP(lbfgsx::copy_async(c->hout, P<T>(c->sc) + idx, sizeof(T) * size_t(k), hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
     const T* h = static_cast<const T*>(c->hout);
     for (int i = 0; i < k; i++)
         out[i] = double(h[i]);
@@ -424,7 +424,7 @@ static bool wf_prepare(lbfgsx_ctx* c)
         return false;
     }
     const int grid = int(std::min<int64_t>(c->grid_for(c->n), (nbatch + 4) / 4));
-    hipLaunchKernelGGL(k_free_counts, dim3(std::max(1, grid)), dim3(kBlock), 0, c->stream, c->bstate->st, c->n, nbatch, b->wf_cnt);
+    LBFGSX_LAUNCH(k_free_counts, dim3(std::max(1, grid)), dim3(kBlock), 0, c->stream, c->bstate->st, c->n, nbatch, b->wf_cnt);
     size_t bytes = b->wf_tmp_bytes;
     if (rocprim::exclusive_scan(b->wf_tmp, bytes, b->wf_cnt, b->wf_base, 0, size_t(nbatch + 1), rocprim::plus<int>(), c->stream) !=
         hipSuccess)
@@ -457,7 +457,7 @@ static int wtv_all(lbfgsx_ctx* c, int total, int vsel_id, const T* vcol, int mas
     // 2c + 1 grid reductions per launch: fewer, fatter blocks keep the reduction tail short (each thread already has
     // 2c 16-byte loads in flight)
     const int grid = std::min(c->grid_for(c->n), c->bstate->dots_grid);
-    hipLaunchKernelGGL((k_multidot_all<T, NC>), dim3(grid), dim3(kBlock), 0, c->stream, cl, total, bvecs<T>(c), vsel_id, vcol,
+    LBFGSX_LAUNCH((k_multidot_all<T, NC>), dim3(grid), dim3(kBlock), 0, c->stream, cl, total, bvecs<T>(c), vsel_id, vcol,
                        mask, c->n, c->ws, c->bstate->dout);
     LBFGSX_HIP(hipGetLastError());
     double r[NC + 1];
@@ -492,7 +492,7 @@ static int wtv_t(lbfgsx_ctx* c, int vsel_id, const T* vcol, int mask, double* ou
 #define ML_LAUNCH(N)                                                                                                        \
     do                                                                                                                      \
     {                                                                                                                       \
-        hipLaunchKernelGGL((k_multidot_list<T, N>), dim3(lgrid), dim3(kBlock), 0, c->stream, cl, total, b, vsel_id, mask,   \
+        LBFGSX_LAUNCH((k_multidot_list<T, N>), dim3(lgrid), dim3(kBlock), 0, c->stream, cl, total, b, vsel_id, mask,   \
                            c->bstate->lu_ptr(), nl, c->ws, c->bstate->dout);                                                \
         nc_used = N;                                                                                                        \
     } while (0)
@@ -523,7 +523,7 @@ static int wtv_t(lbfgsx_ctx* c, int vsel_id, const T* vcol, int mask, double* ou
         // still count the non-zeros
         int dummy = 0;
         Cols<T, NC> cl = col_list<T, NC>(c, &dummy, 0);
-        hipLaunchKernelGGL((k_multidot<T, NC>), dim3(grid), dim3(kBlock), 0, c->stream, cl, 0, b, vsel_id, vcol, mask, c->n,
+        LBFGSX_LAUNCH((k_multidot<T, NC>), dim3(grid), dim3(kBlock), 0, c->stream, cl, 0, b, vsel_id, vcol, mask, c->n,
                            c->ws, c->bstate->dout);
         double r[NC + 1];
         int rc = fetch_doubles(c, NC + 1, r);
@@ -539,7 +539,7 @@ static int wtv_t(lbfgsx_ctx* c, int vsel_id, const T* vcol, int mask, double* ou
         for (int k = 0; k < cnt; k++)
             which[k] = first + k;
         Cols<T, NC> cl = col_list<T, NC>(c, which, cnt);
-        hipLaunchKernelGGL((k_multidot<T, NC>), dim3(grid), dim3(kBlock), 0, c->stream, cl, cnt, b, vsel_id, vcol, mask, c->n,
+        LBFGSX_LAUNCH((k_multidot<T, NC>), dim3(grid), dim3(kBlock), 0, c->stream, cl, cnt, b, vsel_id, vcol, mask, c->n,
                            c->ws, c->bstate->dout);
         LBFGSX_HIP(hipGetLastError());
         double r[NC + 1];
@@ -564,7 +564,7 @@ static int wtd2_all(lbfgsx_ctx* c, int total, const T* snew, const T* dvec, doub
         which[k] = k;
     Cols<T, 32> cl = col_list<T, 32>(c, which, total);
     const int grid = std::min(c->grid_for(c->n), c->bstate->dots_grid);
-    hipLaunchKernelGGL((k_multidot2_all<T, NC>), dim3(grid), dim3(kBlock), 0, c->stream, cl, total, snew, dvec, c->n, c->ws,
+    LBFGSX_LAUNCH((k_multidot2_all<T, NC>), dim3(grid), dim3(kBlock), 0, c->stream, cl, total, snew, dvec, c->n, c->ws,
                        c->bstate->dout);
     LBFGSX_HIP(hipGetLastError());
     double r[2 * NC];
@@ -601,7 +601,7 @@ static int cauchy_wtd(lbfgsx_ctx* c, double* wtd)
 
 namespace lbfgsx {
 #define CB_LAUNCH(M) \
-    hipLaunchKernelGGL((k_wcombine<T, M>), dim3(grid), dim3(kBlock), 0, c->stream, bv, S, Y, c->ld, ph, c->ncorr, cf, has_w, mask, vsel_id, T(theta), c->n, lst, nlst)
+    LBFGSX_LAUNCH((k_wcombine<T, M>), dim3(grid), dim3(kBlock), 0, c->stream, bv, S, Y, c->ld, ph, c->ncorr, cf, has_w, mask, vsel_id, T(theta), c->n, lst, nlst)
 template <class T>
 static int wcombine_t(lbfgsx_ctx* c, int mode, int mask, int vsel_id, const double* coef, double theta)
 {
@@ -646,7 +646,7 @@ int lbfgsx_b_force_bounds(lbfgsx_ctx* c)
         return rc;
     const int grid = c->grid_for(c->n);
     DISPATCH_T(c, {
-        hipLaunchKernelGGL((k_force_bounds<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]), P<T>(c->lb),
+        LBFGSX_LAUNCH((k_force_bounds<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]), P<T>(c->lb),
                            P<T>(c->ub), c->n);
     });
     LBFGSX_HIP(hipGetLastError());
@@ -659,7 +659,7 @@ template <class T, class OBJ>
 static int b_eval_t(lbfgsx_ctx* c, OBJ obj, double* r3)
 {
     const int grid = c->grid_for(c->n);
-    hipLaunchKernelGGL((k_b_eval<T, OBJ>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]), P<T>(c->gb[c->cur]),
+    LBFGSX_LAUNCH((k_b_eval<T, OBJ>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]), P<T>(c->gb[c->cur]),
                        P<T>(c->lb), P<T>(c->ub), c->n, obj, c->ws, c->out_slot<T>());
     LBFGSX_HIP(hipGetLastError());
     return fetch_T<T>(c, c->sl.out(0), 3, r3);
@@ -701,7 +701,7 @@ int lbfgsx_b_norms(lbfgsx_ctx* c, double* projgnorm, double* xnorm2)
     const int grid = c->grid_for(c->n);
     double r[2];
     DISPATCH_T(c, {
-        hipLaunchKernelGGL((k_b_norms<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]), P<T>(c->gb[c->cur]),
+        LBFGSX_LAUNCH((k_b_norms<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]), P<T>(c->gb[c->cur]),
                            P<T>(c->lb), P<T>(c->ub), c->n, c->ws, c->out_slot<T>());
         LBFGSX_HIP(hipGetLastError());
         rc = fetch_T<T>(c, c->sl.out(0), 2, r);
@@ -722,7 +722,7 @@ int lbfgsx_b_dg_maxstep(lbfgsx_ctx* c, double* dg, double* step_max)
     const int grid = c->grid_for(c->n);
     double r[2];
     DISPATCH_T(c, {
-        hipLaunchKernelGGL((k_b_dg_maxstep<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]),
+        LBFGSX_LAUNCH((k_b_dg_maxstep<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]),
                            P<T>(c->gb[c->cur]), P<T>(c->d), P<T>(c->lb), P<T>(c->ub), c->n, c->ws, c->out_slot<T>());
         LBFGSX_HIP(hipGetLastError());
         rc = fetch_T<T>(c, c->sl.out(0), 2, r);
@@ -751,7 +751,7 @@ int lbfgsx_b_post_linesearch(lbfgsx_ctx* c, double* projgnorm, double* xnorm2, d
         c->bstate->colmax_ok[size_t(c->spare)] = 1;
     }
     DISPATCH_T(c, {
-        hipLaunchKernelGGL((k_b_post<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]), P<T>(c->xb[c->xp]),
+        LBFGSX_LAUNCH((k_b_post<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]), P<T>(c->xb[c->xp]),
                            P<T>(c->gb[c->cur]), P<T>(c->gb[c->xp]), P<T>(c->lb), P<T>(c->ub), P<T>(c->col(c->S, c->spare)),
                            P<T>(c->col(c->Y, c->spare)), c->n, c->ws, c->out_slot<T>(),
                            P<T>(c->sc) + c->sl.ys(c->spare), P<T>(c->sc) + c->sl.theta(c->spare), cmx);
@@ -826,7 +826,7 @@ int lbfgsx_b_cauchy_build(lbfgsx_ctx* c, int64_t* nfree, int64_t* nord, double* 
     double r[3];
     DISPATCH_T(c, {
         BVecs<T> bv = bvecs<T>(c);
-        hipLaunchKernelGGL((k_cauchy_build<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, P<T>(b->keys_in), b->vals_in, c->n,
+        LBFGSX_LAUNCH((k_cauchy_build<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, P<T>(b->keys_in), b->vals_in, c->n,
                            c->ws, b->dout);
         LBFGSX_HIP(hipGetLastError());
         rc = fetch_doubles(c, 3, r);
@@ -892,14 +892,14 @@ static int partial_sort_t(lbfgsx_ctx* c, double tau, int64_t* nsorted)
     }
     LBFGSX_HIP(rocprim::select(b->sel_tmp, bytes, ids, flags, b->pv, b->pcount, n, c->stream));
     unsigned cnt = 0;
-    LBFGSX_HIP(hipMemcpyAsync(&cnt, b->pcount, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    LBFGSX_HIP(lbfgsx::copy_async(&cnt, b->pcount, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
     *nsorted = int64_t(cnt);
     if (cnt == 0)
         return LBFGSX_OK;
     // ... their keys, and a stable sort of that short list: the same order the full sort gives these entries
     const int grid = int(std::min<int64_t>((int64_t(cnt) + 255) / 256, 1024));
-    hipLaunchKernelGGL((k_gather_keys<T>), dim3(grid), dim3(256), 0, c->stream, P<T>(b->keys_in), b->pv, P<T>(b->pk), int64_t(cnt));
+    LBFGSX_LAUNCH((k_gather_keys<T>), dim3(grid), dim3(256), 0, c->stream, P<T>(b->keys_in), b->pv, P<T>(b->pk), int64_t(cnt));
     size_t sbytes = b->sort_tmp_bytes;
     LBFGSX_HIP(rocprim::radix_sort_pairs(b->sort_tmp, sbytes, P<T>(b->pk), P<T>(b->keys_out), b->pv, b->vals_out, size_t(cnt), 0,
                                          int(sizeof(T) * 8), c->stream));
@@ -920,7 +920,7 @@ int lbfgsx_b_cauchy_build_partial(lbfgsx_ctx* c, double tau, int64_t* nfree, int
     int64_t ns = 0;
     DISPATCH_T(c, {
         BVecs<T> bv = bvecs<T>(c);
-        hipLaunchKernelGGL((k_cauchy_build<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, P<T>(b->keys_in), b->vals_in, c->n,
+        LBFGSX_LAUNCH((k_cauchy_build<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, P<T>(b->keys_in), b->vals_in, c->n,
                            c->ws, b->dout);
         LBFGSX_HIP(hipGetLastError());
         rc = fetch_doubles(c, 3, r);
@@ -1009,7 +1009,7 @@ int lbfgsx_b_cauchy_chunk(lbfgsx_ctx* c, int64_t first, int64_t count, double* b
     const int grid = int(std::min<int64_t>((count + 255) / 256, 2048));
     DISPATCH_T(c, {
         BVecs<T> bv = bvecs<T>(c);
-        hipLaunchKernelGGL((k_cauchy_gather<T>), dim3(grid), dim3(256), 0, c->stream, bv, P<T>(b->keys_out), b->vals_out, first,
+        LBFGSX_LAUNCH((k_cauchy_gather<T>), dim3(grid), dim3(256), 0, c->stream, bv, P<T>(b->keys_out), b->vals_out, first,
                            count, P<T>(c->S), P<T>(c->Y), c->ld, b->phys_dev, nc, d_brk, d_g, d_z, b->g_idx, d_w);
     });
     LBFGSX_HIP(hipGetLastError());
@@ -1034,10 +1034,10 @@ int lbfgsx_b_cauchy_chunk(lbfgsx_ctx* c, int64_t first, int64_t count, double* b
         pageable.resize(ndbl);
         land = pageable.data();
     }
-    LBFGSX_HIP(hipMemcpyAsync(land, d_brk, sizeof(double) * ndbl, hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(lbfgsx::copy_async(land, d_brk, sizeof(double) * ndbl, hipMemcpyDeviceToHost, c->stream));
     if (idx)
-        LBFGSX_HIP(hipMemcpyAsync(idx, b->g_idx, sizeof(int) * size_t(count), hipMemcpyDeviceToHost, c->stream));
-    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+        LBFGSX_HIP(lbfgsx::copy_async(idx, b->g_idx, sizeof(int) * size_t(count), hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
     std::memcpy(brk, land, sizeof(double) * size_t(count));
     std::memcpy(g, land + count, sizeof(double) * size_t(count));
     std::memcpy(z, land + 2 * count, sizeof(double) * size_t(count));
@@ -1063,22 +1063,22 @@ static int gcp_scan_nc(lbfgsx_ctx* c, const GcpBufs& gb, int64_t first, int64_t 
     double* fin = initC + 1;
     double* out = fin + NC + 1;
     hipStream_t st = c->stream;
-    hipLaunchKernelGGL((k_gcp_a1<NC>), dim3(ntiles), dim3(kGcpTile), 0, st, gb, count, nc, theta, b->s_ts);
-    hipLaunchKernelGGL(k_gcp_tiles, dim3(NC), dim3(64), 0, st, b->s_ts, b->s_off, ntiles, NC, initA, fin);
-    hipLaunchKernelGGL((k_gcp_a3b1<NC>), dim3(ntiles), dim3(kGcpTile), 0, st, gb, count, nc, theta, t_prev, M, b->s_off, b->s_ts);
-    hipLaunchKernelGGL(k_gcp_tiles, dim3(NC + 1), dim3(64), 0, st, b->s_ts, b->s_off, ntiles, NC + 1, initB, fin);
+    LBFGSX_LAUNCH((k_gcp_a1<NC>), dim3(ntiles), dim3(kGcpTile), 0, st, gb, count, nc, theta, b->s_ts);
+    LBFGSX_LAUNCH(k_gcp_tiles, dim3(NC), dim3(64), 0, st, b->s_ts, b->s_off, ntiles, NC, initA, fin);
+    LBFGSX_LAUNCH((k_gcp_a3b1<NC>), dim3(ntiles), dim3(kGcpTile), 0, st, gb, count, nc, theta, t_prev, M, b->s_off, b->s_ts);
+    LBFGSX_LAUNCH(k_gcp_tiles, dim3(NC + 1), dim3(64), 0, st, b->s_ts, b->s_off, ntiles, NC + 1, initB, fin);
     if (b->chain_host)
     {
         // exact-order mode: per-crossing terms only; the chains and the exit test run on the host (gcp_chain_host)
-        hipLaunchKernelGGL((k_gcp_b3c1<NC, true>), dim3(ntiles), dim3(kGcpTile), 0, st, gb, count, nc, theta, t_prev, M,
+        LBFGSX_LAUNCH((k_gcp_b3c1<NC, true>), dim3(ntiles), dim3(kGcpTile), 0, st, gb, count, nc, theta, t_prev, M,
                            b->s_off, b->s_ts, first, nord);
         LBFGSX_HIP(hipGetLastError());
         return LBFGSX_OK;
     }
-    hipLaunchKernelGGL((k_gcp_b3c1<NC, false>), dim3(ntiles), dim3(kGcpTile), 0, st, gb, count, nc, theta, t_prev, M, b->s_off, b->s_ts, first, nord);
-    hipLaunchKernelGGL(k_gcp_tiles, dim3(1), dim3(64), 0, st, b->s_ts, b->s_off, ntiles, 1, initC, fin);
-    hipLaunchKernelGGL(k_gcp_c3, dim3(ntiles), dim3(kGcpTile), 0, st, gb, count, first, nord, b->s_off, b->s_exit);
-    hipLaunchKernelGGL((k_gcp_extract<NC>), dim3(1), dim3(64), 0, st, gb, count, nc, theta, b->s_exit, out);
+    LBFGSX_LAUNCH((k_gcp_b3c1<NC, false>), dim3(ntiles), dim3(kGcpTile), 0, st, gb, count, nc, theta, t_prev, M, b->s_off, b->s_ts, first, nord);
+    LBFGSX_LAUNCH(k_gcp_tiles, dim3(1), dim3(64), 0, st, b->s_ts, b->s_off, ntiles, 1, initC, fin);
+    LBFGSX_LAUNCH(k_gcp_c3, dim3(ntiles), dim3(kGcpTile), 0, st, gb, count, first, nord, b->s_off, b->s_exit);
+    LBFGSX_LAUNCH((k_gcp_extract<NC>), dim3(1), dim3(64), 0, st, gb, count, nc, theta, b->s_exit, out);
     LBFGSX_HIP(hipGetLastError());
     return LBFGSX_OK;
 }
@@ -1087,7 +1087,7 @@ static void gcp_extract_nc(lbfgsx_ctx* c, const GcpBufs& gb, int64_t count, doub
 {
     lbfgsb_state* b = c->bstate;
     double* out = b->s_small + (NC * NC + NC + (NC + 1) + 1 + (NC + 1));
-    hipLaunchKernelGGL((k_gcp_extract<NC>), dim3(1), dim3(64), 0, c->stream, gb, count, c->ncorr, theta, b->s_exit, out);
+    LBFGSX_LAUNCH((k_gcp_extract<NC>), dim3(1), dim3(64), 0, c->stream, gb, count, c->ncorr, theta, b->s_exit, out);
 }
 
 // The f' / f'' recurrences of the break-point search in the reference's own order (Cauchy.h:218,227-228,240-256) over
@@ -1195,13 +1195,13 @@ int lbfgsx_b_cauchy_scan(lbfgsx_ctx* c, int64_t first, int64_t count, int64_t no
     initB[NC] = state_in[2 * nc2 + 1];  // f''
     initC[0] = state_in[2 * nc2];       // f'
     const size_t nsmall = size_t(NC * NC + NC + NC + 1 + 1);
-    LBFGSX_HIP(hipMemcpyAsync(b->s_small, h, sizeof(double) * nsmall, hipMemcpyHostToDevice, c->stream));
+    LBFGSX_HIP(lbfgsx::copy_async(b->s_small, h, sizeof(double) * nsmall, hipMemcpyHostToDevice, c->stream));
     LBFGSX_HIP(hipMemsetAsync(b->s_exit, 0xFF, sizeof(unsigned long long), c->stream));
     const int grid = int(std::min<int64_t>((count + 256) / 256, 2048));
     // f32 problems: the sorted list is gathered into doubles and the search runs in double (the reference would run it in
     // float; the north_star tolerance for f32 is 1e-4, the difference is at the 1e-7 level)
     DISPATCH_T(c, {
-        hipLaunchKernelGGL((k_gcp_gather<T>), dim3(grid), dim3(256), 0, c->stream, bvecs<T>(c), P<T>(b->keys_out), b->vals_out,
+        LBFGSX_LAUNCH((k_gcp_gather<T>), dim3(grid), dim3(256), 0, c->stream, bvecs<T>(c), P<T>(b->keys_out), b->vals_out,
                            first, count, nord, P<T>(c->S), P<T>(c->Y), c->ld, b->phys_dev, nc, b->s_brk, b->s_g, b->s_z, b->s_W,
                            b->s_cap);
     });
@@ -1239,9 +1239,9 @@ int lbfgsx_b_cauchy_scan(lbfgsx_ctx* c, int64_t first, int64_t count, int64_t no
         {
             const int64_t lo = count * q / nsub, hi = count * (q + 1) / nsub;
             const int64_t dlo = q ? lo + 1 : lo;  // dt[k + 1] closes crossing k: the piece ends with dt[hi]
-            LBFGSX_HIP(hipMemcpyAsync(hdt + dlo, b->s_fp + dlo, sizeof(double) * size_t(hi + 1 - dlo), hipMemcpyDeviceToHost, c->stream));
-            LBFGSX_HIP(hipMemcpyAsync(hA + lo, b->s_dfp + lo, sizeof(double) * size_t(hi - lo), hipMemcpyDeviceToHost, c->stream));
-            LBFGSX_HIP(hipMemcpyAsync(hB + lo, b->s_fpp + lo, sizeof(double) * size_t(hi - lo), hipMemcpyDeviceToHost, c->stream));
+            LBFGSX_HIP(lbfgsx::copy_async(hdt + dlo, b->s_fp + dlo, sizeof(double) * size_t(hi + 1 - dlo), hipMemcpyDeviceToHost, c->stream));
+            LBFGSX_HIP(lbfgsx::copy_async(hA + lo, b->s_dfp + lo, sizeof(double) * size_t(hi - lo), hipMemcpyDeviceToHost, c->stream));
+            LBFGSX_HIP(lbfgsx::copy_async(hB + lo, b->s_fpp + lo, sizeof(double) * size_t(hi - lo), hipMemcpyDeviceToHost, c->stream));
             if (nsub > 1)
                 LBFGSX_HIP(hipEventRecord(b->chain_ev[q], c->stream));
         }
@@ -1252,12 +1252,12 @@ int lbfgsx_b_cauchy_scan(lbfgsx_ctx* c, int64_t first, int64_t count, int64_t no
             if (nsub > 1)
                 LBFGSX_HIP(hipEventSynchronize(b->chain_ev[q]));
             else
-                LBFGSX_HIP(hipStreamSynchronize(c->stream));
+                LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
             e = (c->dtype == LBFGSX_F32) ? gcp_chain_host<float>(hdt, hA, hB, lo, hi, fp_h, fpp_h)
                                          : gcp_chain_host<double>(hdt, hA, hB, lo, hi, fp_h, fpp_h);
         }
         const unsigned long long ex = (e >= 0) ? (unsigned long long) e : ~0ull;
-        LBFGSX_HIP(hipMemcpyAsync(b->s_exit, &ex, sizeof(ex), hipMemcpyHostToDevice, c->stream));
+        LBFGSX_HIP(lbfgsx::copy_async(b->s_exit, &ex, sizeof(ex), hipMemcpyHostToDevice, c->stream));
         switch (NC)
         {
         case 4: gcp_extract_nc<4>(c, gb, count, theta); break;
@@ -1277,8 +1277,8 @@ int lbfgsx_b_cauchy_scan(lbfgsx_ctx* c, int64_t first, int64_t count, int64_t no
     }
     double o[2 * 80 + 4];
     const double* dout = b->s_small + (NC * NC + NC + (NC + 1) + 1 + (NC + 1));
-    LBFGSX_HIP(hipMemcpyAsync(o, dout, sizeof(double) * size_t(2 * NC + 4), hipMemcpyDeviceToHost, c->stream));
-    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    LBFGSX_HIP(lbfgsx::copy_async(o, dout, sizeof(double) * size_t(2 * NC + 4), hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
     for (int j = 0; j < nc2; j++)
     {
         state_out[j] = o[j];
@@ -1303,7 +1303,7 @@ int lbfgsx_b_cauchy_finish(lbfgsx_ctx* c, double t_cross, double tfinal, int cro
         BVecs<T> bv = bvecs<T>(c);
         c->bstate->lu_valid = false;  // the state bytes are rewritten
         c->bstate->wf_valid = false;
-        hipLaunchKernelGGL((k_cauchy_finish<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, T(t_cross), T(tfinal), crossed_all,
+        LBFGSX_LAUNCH((k_cauchy_finish<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, T(t_cross), T(tfinal), crossed_all,
                            c->n, c->ws, c->bstate->dout);
     });
     LBFGSX_HIP(hipGetLastError());
@@ -1328,7 +1328,7 @@ int lbfgsx_b_sub_begin(lbfgsx_ctx* c)
     c->bstate->wf_on = false;
     DISPATCH_T(c, {
         BVecs<T> bv = bvecs<T>(c);
-        hipLaunchKernelGGL((k_sub_begin<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, c->n);
+        LBFGSX_LAUNCH((k_sub_begin<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, c->n);
     });
     LBFGSX_HIP(hipGetLastError());
     return LBFGSX_OK;
@@ -1381,17 +1381,17 @@ int lbfgsx_b_wtv_lu(lbfgsx_ctx* c, double* out_l, int64_t* nnz_l, double* out_u,
         if (total <= 8)
         {
             nc = 8;
-            hipLaunchKernelGGL((k_multidot_list2<T, 8>), dim3(lgrid), dim3(kBlock), 0, c->stream, cl, total, bv, b->lu_ptr(), nl, c->ws,
+            LBFGSX_LAUNCH((k_multidot_list2<T, 8>), dim3(lgrid), dim3(kBlock), 0, c->stream, cl, total, bv, b->lu_ptr(), nl, c->ws,
                                b->dout);
         }
         else if (total <= 16)
         {
             nc = 16;
-            hipLaunchKernelGGL((k_multidot_list2<T, 16>), dim3(lgrid), dim3(kBlock), 0, c->stream, cl, total, bv, b->lu_ptr(), nl,
+            LBFGSX_LAUNCH((k_multidot_list2<T, 16>), dim3(lgrid), dim3(kBlock), 0, c->stream, cl, total, bv, b->lu_ptr(), nl,
                                c->ws, b->dout);
         }
         else
-            hipLaunchKernelGGL((k_multidot_list2<T, 24>), dim3(lgrid), dim3(kBlock), 0, c->stream, cl, total, bv, b->lu_ptr(), nl,
+            LBFGSX_LAUNCH((k_multidot_list2<T, 24>), dim3(lgrid), dim3(kBlock), 0, c->stream, cl, total, bv, b->lu_ptr(), nl,
                                c->ws, b->dout);
     });
     LBFGSX_HIP(hipGetLastError());
@@ -1430,7 +1430,7 @@ int lbfgsx_b_gram(lbfgsx_ctx* c, int mask, double* gram)
             double r[TB * TB];
             DISPATCH_T(c, {
                 Cols<T, TB> ci = col_list<T, TB>(c, wi, ni), cj = col_list<T, TB>(c, wj, nj);
-                hipLaunchKernelGGL((k_gram<T, TB>), dim3(grid), dim3(kBlock), 0, c->stream, ci, ni, cj, nj, c->bstate->st, mask,
+                LBFGSX_LAUNCH((k_gram<T, TB>), dim3(grid), dim3(kBlock), 0, c->stream, ci, ni, cj, nj, c->bstate->st, mask,
                                    c->n, c->ws, c->bstate->dout);
             });
             LBFGSX_HIP(hipGetLastError());
@@ -1462,7 +1462,7 @@ int bounded_note_column(lbfgsx_ctx* c, int col)
     LBFGSX_HIP(hipMemsetAsync(cmx, 0, 2 * sizeof(unsigned long long), c->stream));
     const int grid = c->grid_for(c->n);
     DISPATCH_T(c, {
-        hipLaunchKernelGGL((k_colmax2<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->col(c->S, col)), P<T>(c->col(c->Y, col)),
+        LBFGSX_LAUNCH((k_colmax2<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->col(c->S, col)), P<T>(c->col(c->Y, col)),
                            c->n, cmx + 1, cmx + 0);
     });
     LBFGSX_HIP(hipGetLastError());
@@ -1482,7 +1482,7 @@ static int launch_gram_i8_cs(lbfgsx_ctx* c, int tot, int vsel_id, int mask, cons
         which[k] = k;
     Cols<double, 32> cl = col_list<double, 32>(c, which, tot);
     const size_t lds = size_t(kBlock / 64) * kI8Ring * size_t(CS) * sizeof(double);
-    hipLaunchKernelGGL((k_gram_i8<CS>), dim3(blocks), dim3(kBlock), lds, c->stream, cl, tot, bvecs<double>(c), vsel_id, mask, c->n,
+    LBFGSX_LAUNCH((k_gram_i8<CS>), dim3(blocks), dim3(kBlock), lds, c->stream, cl, tot, bvecs<double>(c), vsel_id, mask, c->n,
                        b->i8_part, ne_pad, b->i8_partv, pro, ga);
     return blocks * (kBlock / 64);
 }
@@ -1530,9 +1530,9 @@ static int gram_i8_run(lbfgsx_ctx* c, int tot, int vsel_id, int mask, const Gram
         launch_gram_i8_cs<23>(c, tot, vsel_id, mask, pro, ga, blocks, ne_pad);
     else
         launch_gram_i8_cs<31>(c, tot, vsel_id, mask, pro, ga, blocks, ne_pad);
-    hipLaunchKernelGGL(k_gram_i8_sum, dim3(kI8Acc, std::min(blocks, 16)), dim3(kBlock), 0, c->stream, b->i8_part, blocks, ne, ne_pad,
+    LBFGSX_LAUNCH(k_gram_i8_sum, dim3(kI8Acc, std::min(blocks, 16)), dim3(kBlock), 0, c->stream, b->i8_part, blocks, ne, ne_pad,
                        b->i8_vsum);
-    hipLaunchKernelGGL(k_gram_i8_final, dim3(1), dim3(kBlock), 0, c->stream, b->i8_vsum, tot, ne_pad, b->i8_partv, waves,
+    LBFGSX_LAUNCH(k_gram_i8_final, dim3(1), dim3(kBlock), 0, c->stream, b->i8_vsum, tot, ne_pad, b->i8_partv, waves,
                        vsel_id >= 0 ? 1 : 0, ga, b->gram_out, want_dd ? b->gram_dd : static_cast<double*>(nullptr));
     LBFGSX_HIP(hipGetLastError());
     return waves;
@@ -1556,7 +1556,7 @@ static int launch_gram_dd(lbfgsx_ctx* c, int64_t nbatch, int tot, int vsel_id, i
     for (int k = 0; k < tot; k++)
         which[k] = k;
     Cols<T, 32> cl = (gr.in_idx && !gr.w_by_row) ? wf_cols<T>(c, tot) : col_list<T, 32>(c, which, tot);
-    hipLaunchKernelGGL((k_gram_dd<T, KP>), dim3(blocks), dim3(kBlock), lds, c->stream, cl, tot, bvecs<T>(c), vsel_id, mask,
+    LBFGSX_LAUNCH((k_gram_dd<T, KP>), dim3(blocks), dim3(kBlock), lds, c->stream, cl, tot, bvecs<T>(c), vsel_id, mask,
                        nrows, b->gram_partial, pro, gr);
     return blocks;
 }
@@ -1575,7 +1575,7 @@ static int launch_gram_vonly(lbfgsx_ctx* c, int64_t nbatch, int tot, int vsel_id
     for (int k = 0; k < tot; k++)
         which[k] = k;
     Cols<T, 32> cl = (gr.in_idx && !gr.w_by_row) ? wf_cols<T>(c, tot) : col_list<T, 32>(c, which, tot);
-    hipLaunchKernelGGL((k_gram_dd<T, 1, CS, true>), dim3(blocks), dim3(kBlock), lds, c->stream, cl, tot, bvecs<T>(c), vsel_id,
+    LBFGSX_LAUNCH((k_gram_dd<T, 1, CS, true>), dim3(blocks), dim3(kBlock), lds, c->stream, cl, tot, bvecs<T>(c), vsel_id,
                        mask, nrows, b->gram_partial, pro, gr);
     return blocks;
 }
@@ -1624,19 +1624,19 @@ int lbfgsx_b_wtv_prologue(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, co
         else blocks = launch_gram_vonly<T, 31>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
     });
     const int nch = std::min(blocks, 32);
-    hipLaunchKernelGGL(k_gram_finish, dim3(1, nch), dim3(kBlock), 0, c->stream, b->gram_partial, blocks, b->gram_partial2, 0);
-    hipLaunchKernelGGL(k_gram_finish, dim3(1, 1), dim3(kBlock), 0, c->stream, b->gram_partial2, nch, b->gram_out, 1);
+    LBFGSX_LAUNCH(k_gram_finish, dim3(1, nch), dim3(kBlock), 0, c->stream, b->gram_partial, blocks, b->gram_partial2, 0);
+    LBFGSX_LAUNCH(k_gram_finish, dim3(1, 1), dim3(kBlock), 0, c->stream, b->gram_partial2, nch, b->gram_out, 1);
     LBFGSX_HIP(hipGetLastError());
     double h[64];
     if (b->gram_out_host)
     {
-        LBFGSX_HIP(hipStreamSynchronize(c->stream));
+        LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
         std::memcpy(h, b->gram_out_host, sizeof(h));
     }
     else
     {
-        LBFGSX_HIP(hipMemcpyAsync(h, b->gram_out, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-        LBFGSX_HIP(hipStreamSynchronize(c->stream));
+        LBFGSX_HIP(lbfgsx::copy_async(h, b->gram_out, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
     }
     for (int j = 0; j < tot; j++)
         wtv[j] = h[j];
@@ -1668,10 +1668,10 @@ int lbfgsx_b_free_delta(lbfgsx_ctx* c, int64_t* n_enter, int64_t* n_leave)
         b->wf_live = false;  // the history has grown (another column order), or the copy missed an iteration
     // {rows entered, rows left, rows in the kept compact copy, 1: the copy cannot be kept}
     const unsigned init[4] = {0u, 0u, unsigned(b->wf_live ? b->wf_n : 0), 0u};
-    LBFGSX_HIP(hipMemcpyAsync(b->dl_cnt, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    LBFGSX_HIP(lbfgsx::copy_async(b->dl_cnt, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
     const int64_t n8 = (c->n + 7) / 8;
     const int grid = c->grid_for(n8);
-    hipLaunchKernelGGL(k_free_delta, dim3(grid), dim3(kBlock), 0, c->stream, b->st, b->fprev, n8, c->n, b->dl_enter, b->dl_leave,
+    LBFGSX_LAUNCH(k_free_delta, dim3(grid), dim3(kBlock), 0, c->stream, b->st, b->fprev, n8, c->n, b->dl_enter, b->dl_leave,
                        b->dl_cnt, b->dl_cap);
     LBFGSX_HIP(hipGetLastError());
     if (b->wf_live)
@@ -1686,14 +1686,14 @@ int lbfgsx_b_free_delta(lbfgsx_ctx* c, int64_t* n_enter, int64_t* n_leave)
             which[k] = k;
         DISPATCH_T(c, {
             Cols<T, 32> cl = col_list<T, 32>(c, which, total);
-            hipLaunchKernelGGL((k_wf_append<T>), dim3(16), dim3(kBlock), 0, c->stream, cl, total, static_cast<T*>(b->wf), b->wf_ld,
+            LBFGSX_LAUNCH((k_wf_append<T>), dim3(16), dim3(kBlock), 0, c->stream, cl, total, static_cast<T*>(b->wf), b->wf_ld,
                                b->wf_idx, b->wf_pos, b->dl_enter, b->dl_cnt, b->dl_cap, unsigned(std::min<int64_t>(c->n, b->wf_ld)));
         });
         LBFGSX_HIP(hipGetLastError());
     }
     unsigned* h = static_cast<unsigned*>(c->hout);
-    LBFGSX_HIP(hipMemcpyAsync(h, b->dl_cnt, sizeof(unsigned) * 4, hipMemcpyDeviceToHost, c->stream));
-    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    LBFGSX_HIP(lbfgsx::copy_async(h, b->dl_cnt, sizeof(unsigned) * 4, hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
     for (int d = 0; d < 2; d++)
         b->dl_n[d] = (h[d] <= b->dl_cap) ? int64_t(h[d]) : -1;
     if (b->wf_live)
@@ -1817,11 +1817,11 @@ int lbfgsx_b_gram_pairs_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
         b->wf_epoch = b->sub_epoch;
     }
     const int nch = std::min(blocks, 32);
-    hipLaunchKernelGGL(k_gram_finish, dim3(1, nch), dim3(kBlock), 0, c->stream, b->gram_partial, blocks, b->gram_partial2, 0);
-    hipLaunchKernelGGL(k_gram_finish, dim3(1, 1), dim3(kBlock), 0, c->stream, b->gram_partial2, nch, b->gram_out, 1, b->gram_dd);
+    LBFGSX_LAUNCH(k_gram_finish, dim3(1, nch), dim3(kBlock), 0, c->stream, b->gram_partial, blocks, b->gram_partial2, 0);
+    LBFGSX_LAUNCH(k_gram_finish, dim3(1, 1), dim3(kBlock), 0, c->stream, b->gram_partial2, nch, b->gram_out, 1, b->gram_dd);
     LBFGSX_HIP(hipGetLastError());
-    LBFGSX_HIP(hipMemcpyAsync(out_dd, b->gram_dd, sizeof(double) * 2 * size_t(npairs), hipMemcpyDeviceToHost, c->stream));
-    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    LBFGSX_HIP(lbfgsx::copy_async(out_dd, b->gram_dd, sizeof(double) * 2 * size_t(npairs), hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
     return LBFGSX_OK;
 }
 
@@ -1880,23 +1880,23 @@ static int gram_dd_core(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, cons
             for (int k = 0; k < tot; k++)
                 which[k] = k;
             Cols<T, 32> cl = col_list<T, 32>(c, which, tot);
-            hipLaunchKernelGGL((k_gram_mfma<T>), dim3(blocks), dim3(kBlock), 0, c->stream, cl, tot, bvecs<T>(c), vsel_id, mask,
+            LBFGSX_LAUNCH((k_gram_mfma<T>), dim3(blocks), dim3(kBlock), 0, c->stream, cl, tot, bvecs<T>(c), vsel_id, mask,
                                c->n, b->gram_partial);
         });
         // two-level sum of the per-block partials: 32 chunks in parallel, then the final rounding
         const int nch = std::min(blocks, 32);
-        hipLaunchKernelGGL(k_gram_finish, dim3(3, nch), dim3(kBlock), 0, c->stream, b->gram_partial, blocks, b->gram_partial2, 0);
-        hipLaunchKernelGGL(k_gram_finish, dim3(3, 1), dim3(kBlock), 0, c->stream, b->gram_partial2, nch, b->gram_out, 1);
+        LBFGSX_LAUNCH(k_gram_finish, dim3(3, nch), dim3(kBlock), 0, c->stream, b->gram_partial, blocks, b->gram_partial2, 0);
+        LBFGSX_LAUNCH(k_gram_finish, dim3(3, 1), dim3(kBlock), 0, c->stream, b->gram_partial2, nch, b->gram_out, 1);
         LBFGSX_HIP(hipGetLastError());
         if (b->gram_out_host)
         {
-            LBFGSX_HIP(hipStreamSynchronize(c->stream));
+            LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
             std::memcpy(h, b->gram_out_host, sizeof(h));
         }
         else
         {
-            LBFGSX_HIP(hipMemcpyAsync(h, b->gram_out, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-            LBFGSX_HIP(hipStreamSynchronize(c->stream));
+            LBFGSX_HIP(lbfgsx::copy_async(h, b->gram_out, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+            LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
         }
         // entry (I, J), I >= J, of the padded 32 x 32 Gram
         auto G = [&](int I, int J) {
@@ -2004,8 +2004,8 @@ static int gram_dd_core(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, cons
     if (compact_out)
         wf_rebuilt(c);
     const int nch = std::min(blocks, 32);
-    hipLaunchKernelGGL(k_gram_finish, dim3(ntile_, nch), dim3(kBlock), 0, c->stream, b->gram_partial, blocks, b->gram_partial2, 0);
-    hipLaunchKernelGGL(k_gram_finish, dim3(ntile_, 1), dim3(kBlock), 0, c->stream, b->gram_partial2, nch, b->gram_out, 1,
+    LBFGSX_LAUNCH(k_gram_finish, dim3(ntile_, nch), dim3(kBlock), 0, c->stream, b->gram_partial, blocks, b->gram_partial2, 0);
+    LBFGSX_LAUNCH(k_gram_finish, dim3(ntile_, 1), dim3(kBlock), 0, c->stream, b->gram_partial2, nch, b->gram_out, 1,
                        gram_dd ? b->gram_dd : static_cast<double*>(nullptr));
     LBFGSX_HIP(hipGetLastError());
     }
@@ -2014,17 +2014,17 @@ static int gram_dd_core(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, cons
     if (gram_dd)
     {
         hdd.resize(size_t(ntile) * 256 * 2);
-        LBFGSX_HIP(hipMemcpyAsync(hdd.data(), b->gram_dd, sizeof(double) * hdd.size(), hipMemcpyDeviceToHost, c->stream));
+        LBFGSX_HIP(lbfgsx::copy_async(hdd.data(), b->gram_dd, sizeof(double) * hdd.size(), hipMemcpyDeviceToHost, c->stream));
     }
     if (b->gram_out_host)
     {
-        LBFGSX_HIP(hipStreamSynchronize(c->stream));
+        LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
         std::memcpy(h, b->gram_out_host, sizeof(double) * size_t(ntile) * 256);
     }
     else
     {
-        LBFGSX_HIP(hipMemcpyAsync(h, b->gram_out, sizeof(double) * size_t(ntile) * 256, hipMemcpyDeviceToHost, c->stream));
-        LBFGSX_HIP(hipStreamSynchronize(c->stream));
+        LBFGSX_HIP(lbfgsx::copy_async(h, b->gram_out, sizeof(double) * size_t(ntile) * 256, hipMemcpyDeviceToHost, c->stream));
+        LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
     }
     if (gram)
         for (int i = 0; i < tot; i++)
@@ -2075,7 +2075,7 @@ static int solve_dots_t(lbfgsx_ctx* c, int pmask, int vsel_id, const double* coe
     for (int k = 0; k < 80; k++)
         cf.c[k] = (coef && k < total) ? T(coef[k]) : T(0);
     const int grid = std::min(c->grid_for(nrows), c->bstate->dots_grid);
-    hipLaunchKernelGGL((k_solve_dots<T, NC>), dim3(grid), dim3(kBlock), 0, c->stream, cl, total, bvecs<T>(c), vsel_id, cf,
+    LBFGSX_LAUNCH((k_solve_dots<T, NC>), dim3(grid), dim3(kBlock), 0, c->stream, cl, total, bvecs<T>(c), vsel_id, cf,
                        coef ? 1 : 0, pmask, fmask, T(theta), nrows, c->ws, c->bstate->dout,
                        compact ? c->bstate->wf_idx : static_cast<const int*>(nullptr));
     LBFGSX_HIP(hipGetLastError());
@@ -2121,7 +2121,7 @@ int lbfgsx_b_sub_partition(lbfgsx_ctx* c, int64_t* nL, int64_t* nU, int64_t* nP)
     DISPATCH_T(c, {
         BVecs<T> bv = bvecs<T>(c);
         c->bstate->lu_valid = false;  // this partition keeps no index list
-        hipLaunchKernelGGL((k_sub_partition<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, c->n, c->ws, c->bstate->dout);
+        LBFGSX_LAUNCH((k_sub_partition<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, c->n, c->ws, c->bstate->dout);
     });
     LBFGSX_HIP(hipGetLastError());
     rc = fetch_doubles(c, 3, r);
@@ -2143,7 +2143,7 @@ int lbfgsx_b_sub_check(lbfgsx_ctx* c, int64_t counts[4])
     double r[4];
     DISPATCH_T(c, {
         BVecs<T> bv = bvecs<T>(c);
-        hipLaunchKernelGGL((k_sub_check<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, c->n, c->ws, c->bstate->dout);
+        LBFGSX_LAUNCH((k_sub_check<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, c->n, c->ws, c->bstate->dout);
     });
     LBFGSX_HIP(hipGetLastError());
     rc = fetch_doubles(c, 4, r);
@@ -2167,7 +2167,7 @@ int lbfgsx_b_sub_sweep_begin(lbfgsx_ctx* c, int first, int64_t* nL, int64_t* nU,
     const unsigned lu_cap_now = (c->bstate->lu_use && c->bstate->lu_pred <= 16384) ? c->bstate->lu_cap : 0u;
     DISPATCH_T(c, {
         BVecs<T> bv = bvecs<T>(c);
-        hipLaunchKernelGGL((k_sub_sweep_begin<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, first ? 1 : 0, c->n, c->ws,
+        LBFGSX_LAUNCH((k_sub_sweep_begin<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, first ? 1 : 0, c->n, c->ws,
                            c->bstate->dout, c->bstate->lu_ptr(), c->bstate->lu_cnt, lu_cap_now);
     });
     LBFGSX_HIP(hipGetLastError());
@@ -2208,10 +2208,10 @@ static int solve_sweep_t(lbfgsx_ctx* c, int first, int vsel_id, const double* co
         cf.c[k] = (coef && k < total) ? T(coef[k]) : T(0);
     const int grid = std::min(c->grid_for(nrows), c->bstate->dots_grid);
     if (first)
-        hipLaunchKernelGGL((k_solve_sweep<T, NC, 1>), dim3(grid), dim3(kBlock), 0, c->stream, cl, total, bvecs<T>(c), vsel_id, cf,
+        LBFGSX_LAUNCH((k_solve_sweep<T, NC, 1>), dim3(grid), dim3(kBlock), 0, c->stream, cl, total, bvecs<T>(c), vsel_id, cf,
                            coef ? 1 : 0, T(theta), nrows, c->ws, c->bstate->dout, lu_dst, c->bstate->lu_cnt, lu_cap_now, ridx);
     else
-        hipLaunchKernelGGL((k_solve_sweep<T, NC, 0>), dim3(grid), dim3(kBlock), 0, c->stream, cl, total, bvecs<T>(c), vsel_id, cf,
+        LBFGSX_LAUNCH((k_solve_sweep<T, NC, 0>), dim3(grid), dim3(kBlock), 0, c->stream, cl, total, bvecs<T>(c), vsel_id, cf,
                            coef ? 1 : 0, T(theta), nrows, c->ws, c->bstate->dout, lu_dst, c->bstate->lu_cnt, lu_cap_now, ridx);
     LBFGSX_HIP(hipGetLastError());
     const int nd = first ? 0 : NC;
@@ -2315,7 +2315,7 @@ int lbfgsx_b_lu_sweep(lbfgsx_ctx* c, const double* coef, double theta, int64_t s
         CoefArg<T> cf;
         for (int k = 0; k < 80; k++)
             cf.c[k] = (has_w && k < 2 * c->ncorr) ? T(coef[k]) : T(0);
-        hipLaunchKernelGGL((k_lu_sweep<T>), dim3(grid), dim3(kBlock), 0, c->stream, bvecs<T>(c), P<T>(c->S), P<T>(c->Y), c->ld,
+        LBFGSX_LAUNCH((k_lu_sweep<T>), dim3(grid), dim3(kBlock), 0, c->stream, bvecs<T>(c), P<T>(c->S), P<T>(c->Y), c->ld,
                            b->phys_dev, c->ncorr, cf, has_w, T(theta), b->lu_ptr(), nl, c->ws, b->dout, b->lu_other(), b->lu_cnt,
                            b->lu_cap);
     });
@@ -2346,7 +2346,7 @@ int lbfgsx_b_sub_op(lbfgsx_ctx* c, int op)
     const int grid = c->grid_for(c->n);
     DISPATCH_T(c, {
         BVecs<T> bv = bvecs<T>(c);
-        hipLaunchKernelGGL((k_sub_op<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, op, c->n);
+        LBFGSX_LAUNCH((k_sub_op<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, op, c->n);
     });
     LBFGSX_HIP(hipGetLastError());
     return LBFGSX_OK;
@@ -2358,8 +2358,8 @@ int lbfgsx_b_download_state(lbfgsx_ctx* c, unsigned char* host)
     int rc = need_bounded(c);
     if (rc)
         return rc;
-    LBFGSX_HIP(hipMemcpyAsync(host, c->bstate->st, size_t(c->n), hipMemcpyDeviceToHost, c->stream));
-    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    LBFGSX_HIP(lbfgsx::copy_async(host, c->bstate->st, size_t(c->n), hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
     return LBFGSX_OK;
 }
 
@@ -2369,7 +2369,7 @@ int lbfgsx_b_dot_drt_g(lbfgsx_ctx* c, double* dg)
     const int grid = c->grid_for(c->n);
     double r[2];
     DISPATCH_T(c, {
-        hipLaunchKernelGGL((k_dot<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->d), P<T>(c->gb[c->cur]),
+        LBFGSX_LAUNCH((k_dot<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->d), P<T>(c->gb[c->cur]),
                            static_cast<const T*>(nullptr), c->n, c->ws, c->out_slot<T>());
         LBFGSX_HIP(hipGetLastError());
         int rc = fetch_T<T>(c, c->sl.out(0), 1, r);
@@ -2389,7 +2389,7 @@ int lbfgsx_b_dir_from_xcp(lbfgsx_ctx* c, int normalize)
     const int grid = c->grid_for(c->n);
     double r[1];
     DISPATCH_T(c, {
-        hipLaunchKernelGGL((k_b_dir_from_xcp<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xcp), P<T>(c->xb[c->cur]),
+        LBFGSX_LAUNCH((k_b_dir_from_xcp<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xcp), P<T>(c->xb[c->cur]),
                            P<T>(c->d), c->n, c->ws, c->out_slot<T>());
         LBFGSX_HIP(hipGetLastError());
         if (normalize)
@@ -2399,7 +2399,7 @@ int lbfgsx_b_dir_from_xcp(lbfgsx_ctx* c, int normalize)
                 return rc;
             const T z = T(r[0]);
             if (z > T(0))  // Eigen normalize(): divide only when the squared norm is positive
-                hipLaunchKernelGGL((k_b_scale_div<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->d), T(std::sqrt(z)), c->n);
+                LBFGSX_LAUNCH((k_b_scale_div<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->d), T(std::sqrt(z)), c->n);
         }
     });
     LBFGSX_HIP(hipGetLastError());

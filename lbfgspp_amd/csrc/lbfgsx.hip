@@ -15,6 +15,12 @@
 namespace lbfgsx {
 
 static std::atomic<int> g_live[64];
+Counters& counters()
+{
+    static Counters g;
+    return g;
+}
+
 void live_add(int device, int delta)
 {
     if (device >= 0 && device < 64)
@@ -28,6 +34,13 @@ int live_count(int device) { return (device >= 0 && device < 64) ? g_live[device
 // delay residency -- they always finish.  apply_Hv takes the device's lock for the launch and the synchronisation that
 // ends it; a context that finds the lock taken (worker threads of a pool) issues the step launches for that call.
 static std::mutex g_persist_mu[64];
+// a meeting point of the persistent launch timed out: step launches for the next `persist_backoff` products, then retry
+static void persist_timed_out(lbfgsx_ctx* c)
+{
+    c->persist_timeouts++;
+    c->persist_cooldown = c->persist_backoff;
+    c->persist_backoff = std::min(c->persist_backoff * 4, 8192);
+}
 
 static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
@@ -133,14 +146,14 @@ static int fetch_scalars(lbfgsx_ctx* c, int idx, int k, double* out)
     if (idx == c->sl.out(0) && c->outmap_dev)
     {
         // the kernel stored these into host-mapped memory (ctx.hpp): visible once the stream has drained
-        LBFGSX_HIP(hipStreamSynchronize(c->stream));
+        LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
         const volatile T* h = static_cast<const volatile T*>(c->outmap_host);
         for (int i = 0; i < k; i++)
             out[i] = double(h[i]);
         return LBFGSX_OK;
     }
-    LBFGSX_HIP(hipMemcpyAsync(c->hout, P<T>(c->sc) + idx, sizeof(T) * size_t(k), hipMemcpyDeviceToHost, c->stream));
-    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    LBFGSX_HIP(lbfgsx::copy_async(c->hout, P<T>(c->sc) + idx, sizeof(T) * size_t(k), hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
     const T* h = static_cast<const T*>(c->hout);
     for (int i = 0; i < k; i++)
         out[i] = double(h[i]);
@@ -336,7 +349,7 @@ static int create_fill(lbfgsx_ctx* c, int dtype, int64_t n, int m, int device, i
         if (rc != LBFGSX_OK)
             return rc;
     }
-    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
     live_add(c->device, +1);
     c->counted = true;
     return LBFGSX_OK;
@@ -348,7 +361,7 @@ void lbfgsx_destroy(lbfgsx_ctx* c)
     if (!c)
         return;
     lbfgsx::DeviceGuard dev_guard_(c->device);
-    (void) hipStreamSynchronize(c->stream);
+    (void) lbfgsx::stream_sync(c->stream);
     if (c->counted)
         live_add(c->device, -1);
     for (int k = 0; k < 3; k++)
@@ -392,7 +405,7 @@ void lbfgsx_destroy(lbfgsx_ctx* c)
 int lbfgsx_set_stream(lbfgsx_ctx* c, void* hip_stream)
 {
     lbfgsx::DeviceGuard dev_guard_(c->device);
-    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
     if (c->own_stream)
         LBFGSX_HIP(hipStreamDestroy(c->stream));
     c->stream = static_cast<hipStream_t>(hip_stream);
@@ -403,7 +416,7 @@ int lbfgsx_set_stream(lbfgsx_ctx* c, void* hip_stream)
 int lbfgsx_sync(lbfgsx_ctx* c)
 {
     lbfgsx::DeviceGuard dev_guard_(c->device);
-    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
     return LBFGSX_OK;
 }
 
@@ -413,14 +426,15 @@ void* lbfgsx_vec(lbfgsx_ctx* c, int which) { return vec_ptr(c, which); }
 int lbfgsx_upload(lbfgsx_ctx* c, int which, const void* host)
 {
     lbfgsx::DeviceGuard dev_guard_(c->device);
+    c->spec_valid = false;  // a buffer the stored speculative direction was computed from may change (lbfgsx_apply_Hv)
     void* p = vec_ptr(c, which);
     if (!p || !host)
     {
         set_error("lbfgsx_upload: unknown vector or null host pointer");
         return LBFGSX_E_INVALID;
     }
-    LBFGSX_HIP(hipMemcpyAsync(p, host, size_t(c->n) * c->esz, hipMemcpyHostToDevice, c->stream));
-    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    LBFGSX_HIP(lbfgsx::copy_async(p, host, size_t(c->n) * c->esz, hipMemcpyHostToDevice, c->stream));
+    LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
     return LBFGSX_OK;
 }
 
@@ -433,8 +447,8 @@ int lbfgsx_download(lbfgsx_ctx* c, int which, void* host)
         set_error("lbfgsx_download: unknown vector or null host pointer");
         return LBFGSX_E_INVALID;
     }
-    LBFGSX_HIP(hipMemcpyAsync(host, p, size_t(c->n) * c->esz, hipMemcpyDeviceToHost, c->stream));
-    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    LBFGSX_HIP(lbfgsx::copy_async(host, p, size_t(c->n) * c->esz, hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
     return LBFGSX_OK;
 }
 
@@ -456,10 +470,10 @@ int lbfgsx_gather(lbfgsx_ctx* c, int which, int64_t stride, double* host)
         c->gather_cap = nsamp;
     }
     const int grid = int(std::min<int64_t>((nsamp + 255) / 256, 1024));
-    DISPATCH_T(c, { hipLaunchKernelGGL(k_gather<T>, dim3(grid), dim3(256), 0, c->stream, P<T>(p), nsamp, stride,
+    DISPATCH_T(c, { LBFGSX_LAUNCH(k_gather<T>, dim3(grid), dim3(256), 0, c->stream, P<T>(p), nsamp, stride,
                                        static_cast<double*>(c->gather_tmp)); });
-    LBFGSX_HIP(hipMemcpyAsync(host, c->gather_tmp, sizeof(double) * size_t(nsamp), hipMemcpyDeviceToHost, c->stream));
-    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    LBFGSX_HIP(lbfgsx::copy_async(host, c->gather_tmp, sizeof(double) * size_t(nsamp), hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
     return LBFGSX_OK;
 }
 
@@ -478,7 +492,8 @@ int lbfgsx_set_shard(lbfgsx_ctx* c, int64_t offset, int64_t n_global)
 int lbfgsx_gen_diag_quad(lbfgsx_ctx* c, double kappa, uint64_t seed)
 {
     lbfgsx::DeviceGuard dev_guard_(c->device);
-    DISPATCH_T(c, { hipLaunchKernelGGL(k_gen_quad<T>, dim3(2048), dim3(256), 0, c->stream, P<T>(c->a), P<T>(c->b),
+    c->spec_valid = false;  // a buffer the stored speculative direction was computed from may change (lbfgsx_apply_Hv)
+    DISPATCH_T(c, { LBFGSX_LAUNCH(k_gen_quad<T>, dim3(2048), dim3(256), 0, c->stream, P<T>(c->a), P<T>(c->b),
                                        c->n, kappa, seed, c->shard_off, c->n_global); });
     LBFGSX_HIP(hipGetLastError());
     return LBFGSX_OK;
@@ -487,7 +502,8 @@ int lbfgsx_gen_diag_quad(lbfgsx_ctx* c, double kappa, uint64_t seed)
 int lbfgsx_gen_rosen_x0(lbfgsx_ctx* c, uint64_t seed)
 {
     lbfgsx::DeviceGuard dev_guard_(c->device);
-    DISPATCH_T(c, { hipLaunchKernelGGL(k_gen_rosen<T>, dim3(2048), dim3(256), 0, c->stream, P<T>(c->xb[c->cur]),
+    c->spec_valid = false;  // a buffer the stored speculative direction was computed from may change (lbfgsx_apply_Hv)
+    DISPATCH_T(c, { LBFGSX_LAUNCH(k_gen_rosen<T>, dim3(2048), dim3(256), 0, c->stream, P<T>(c->xb[c->cur]),
                                        c->n, seed, c->shard_off); });
     LBFGSX_HIP(hipGetLastError());
     return LBFGSX_OK;
@@ -496,13 +512,14 @@ int lbfgsx_gen_rosen_x0(lbfgsx_ctx* c, uint64_t seed)
 int lbfgsx_fill(lbfgsx_ctx* c, int which, double value)
 {
     lbfgsx::DeviceGuard dev_guard_(c->device);
+    c->spec_valid = false;  // a buffer the stored speculative direction was computed from may change (lbfgsx_apply_Hv)
     void* p = vec_ptr(c, which);
     if (!p)
     {
         set_error("lbfgsx_fill: unknown vector");
         return LBFGSX_E_INVALID;
     }
-    DISPATCH_T(c, { hipLaunchKernelGGL(k_fill<T>, dim3(2048), dim3(256), 0, c->stream, P<T>(p), c->n, T(value)); });
+    DISPATCH_T(c, { LBFGSX_LAUNCH(k_fill<T>, dim3(2048), dim3(256), 0, c->stream, P<T>(p), c->n, T(value)); });
     LBFGSX_HIP(hipGetLastError());
     return LBFGSX_OK;
 }
@@ -525,8 +542,8 @@ int lbfgsx_bfgs_reset(lbfgsx_ctx* c)
     // sc[one] = 1
     DISPATCH_T(c, {
         T one = T(1);
-        LBFGSX_HIP(hipMemcpyAsync(P<T>(c->sc) + c->sl.one(), &one, sizeof(T), hipMemcpyHostToDevice, c->stream));
-        LBFGSX_HIP(hipStreamSynchronize(c->stream));
+        LBFGSX_HIP(lbfgsx::copy_async(P<T>(c->sc) + c->sl.one(), &one, sizeof(T), hipMemcpyHostToDevice, c->stream));
+        LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
     });
     return LBFGSX_OK;
 }
@@ -545,12 +562,12 @@ int lbfgsx_bfgs_download_history(lbfgsx_ctx* c, void* S_out, void* Y_out, int* n
     for (int j = 0; j < c->ncorr; j++)
     {
         const size_t bytes = size_t(c->n) * c->esz;
-        LBFGSX_HIP(hipMemcpyAsync(static_cast<char*>(S_out) + size_t(j) * bytes, c->col(c->S, c->phys[size_t(j)]), bytes,
+        LBFGSX_HIP(lbfgsx::copy_async(static_cast<char*>(S_out) + size_t(j) * bytes, c->col(c->S, c->phys[size_t(j)]), bytes,
                                   hipMemcpyDeviceToHost, c->stream));
-        LBFGSX_HIP(hipMemcpyAsync(static_cast<char*>(Y_out) + size_t(j) * bytes, c->col(c->Y, c->phys[size_t(j)]), bytes,
+        LBFGSX_HIP(lbfgsx::copy_async(static_cast<char*>(Y_out) + size_t(j) * bytes, c->col(c->Y, c->phys[size_t(j)]), bytes,
                                   hipMemcpyDeviceToHost, c->stream));
     }
-    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
     if (ncorr) *ncorr = c->ncorr;
     if (ptr) *ptr = c->ptr;
     if (theta) *theta = c->theta;
@@ -584,6 +601,7 @@ int lbfgsx_commit_correction(lbfgsx_ctx* c)
 int lbfgsx_bfgs_stage_correction_host(lbfgsx_ctx* c, const void* s, const void* y, double* sy, double* yy)
 {
     lbfgsx::DeviceGuard dev_guard_(c->device);
+    c->spec_valid = false;  // a buffer the stored speculative direction was computed from may change (lbfgsx_apply_Hv)
     if (c->gs_f32h)
     {
         set_error("lbfgsx_bfgs_stage_correction_host: this context keeps its history in f32 for the Gram-space recursion (lbfgsx_gs_set_history_dtype)");
@@ -591,8 +609,8 @@ int lbfgsx_bfgs_stage_correction_host(lbfgsx_ctx* c, const void* s, const void* 
     }
     void* sp = c->col(c->S, c->spare);
     void* yp = c->col(c->Y, c->spare);
-    LBFGSX_HIP(hipMemcpyAsync(sp, s, size_t(c->n) * c->esz, hipMemcpyHostToDevice, c->stream));
-    LBFGSX_HIP(hipMemcpyAsync(yp, y, size_t(c->n) * c->esz, hipMemcpyHostToDevice, c->stream));
+    LBFGSX_HIP(lbfgsx::copy_async(sp, s, size_t(c->n) * c->esz, hipMemcpyHostToDevice, c->stream));
+    LBFGSX_HIP(lbfgsx::copy_async(yp, y, size_t(c->n) * c->esz, hipMemcpyHostToDevice, c->stream));
     if (c->bstate)
     {
         const int rcn = bounded_note_column(c, c->spare);
@@ -602,15 +620,15 @@ int lbfgsx_bfgs_stage_correction_host(lbfgsx_ctx* c, const void* s, const void* 
     const int grid = c->grid_for(c->n);
     double r[2];
     DISPATCH_T(c, {
-        hipLaunchKernelGGL((k_dot<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(sp), P<T>(yp), P<T>(yp), c->n,
+        LBFGSX_LAUNCH((k_dot<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(sp), P<T>(yp), P<T>(yp), c->n,
                            c->ws, c->out_slot<T>());
         int rc = fetch_scalars<T>(c, c->sl.out(0), 2, r);
         if (rc)
             return rc;
         T vals[2] = {T(r[0]), T(T(r[1]) / T(r[0]))};
-        LBFGSX_HIP(hipMemcpyAsync(P<T>(c->sc) + c->sl.ys(c->spare), &vals[0], sizeof(T), hipMemcpyHostToDevice, c->stream));
-        LBFGSX_HIP(hipMemcpyAsync(P<T>(c->sc) + c->sl.theta(c->spare), &vals[1], sizeof(T), hipMemcpyHostToDevice, c->stream));
-        LBFGSX_HIP(hipStreamSynchronize(c->stream));
+        LBFGSX_HIP(lbfgsx::copy_async(P<T>(c->sc) + c->sl.ys(c->spare), &vals[0], sizeof(T), hipMemcpyHostToDevice, c->stream));
+        LBFGSX_HIP(lbfgsx::copy_async(P<T>(c->sc) + c->sl.theta(c->spare), &vals[1], sizeof(T), hipMemcpyHostToDevice, c->stream));
+        LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
     });
     c->pend_sy = r[0];
     c->pend_yy = r[1];
@@ -657,7 +675,7 @@ static int apply_Hv_t(lbfgsx_ctx* c, const T* v, T a, double* dg)
         LBFGSX_HIP(hipEventRecord(hv.a, c->stream));
     }
     std::unique_lock<std::mutex> persist_lock;
-    if (c->persist && c->persist_grid > 0 && m <= kPersistMaxM && c->device >= 0 && c->device < 64)
+    if (c->persist && c->persist_cooldown == 0 && c->persist_grid > 0 && m <= kPersistMaxM && c->device >= 0 && c->device < 64)
         persist_lock = std::unique_lock<std::mutex>(g_persist_mu[c->device], std::try_to_lock);
     if (persist_lock.owns_lock())
     {
@@ -679,7 +697,7 @@ static int apply_Hv_t(lbfgsx_ctx* c, const T* v, T a, double* dg)
         // process and rocprofv3 crashes at exit after cooperative launches on this stack; a device shared with another
         // PROCESS is caught by the wall-clock bound of the kernel's meeting points (the product is then redone with
         // the step launches), never by a hang.
-        hipLaunchKernelGGL((k_twoloop_persist<T, false>), dim3(c->persist_grid), dim3(kHvThreads), 0, c->stream, q, v, a,
+        LBFGSX_LAUNCH((k_twoloop_persist<T, false>), dim3(c->persist_grid), dim3(kHvThreads), 0, c->stream, q, v, a,
                            P<T>(c->S), P<T>(c->Y), c->n, sc, pa, c->ws, c->gen_dev, reinterpret_cast<int*>(c->gen_dev + 1),
                            PostFuse<T>());
         LBFGSX_HIP(hipGetLastError());
@@ -692,19 +710,19 @@ static int apply_Hv_t(lbfgsx_ctx* c, const T* v, T a, double* dg)
             c->persist_steps_timed += 2 * cn + 1;
         }
         int herr = 0;
-        LBFGSX_HIP(hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        LBFGSX_HIP(lbfgsx::copy_async(&herr, err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         int rc2 = dg ? fetch_scalars<T>(c, sl.dot(2 * cn), 1, dg) : LBFGSX_OK;
         if (!dg)
-            LBFGSX_HIP(hipStreamSynchronize(c->stream));
+            LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
         if (herr)
         {
             // a meeting point timed out (the blocks were not all resident: the device is shared after all).  Nothing
             // was lost -- v and the history are untouched: reset the words the kernel uses and redo this product
-            // with the step launches, which this context keeps using from now on
-            LBFGSX_HIP(hipMemsetAsync(c->gen_dev, 0, 2 * sizeof(unsigned), c->stream));
+            // with the step launches, which this context keeps using for a while (persist_cooldown, ctx.hpp)
+            LBFGSX_HIP(hipMemsetAsync(c->gen_dev, 0, 4 * sizeof(unsigned), c->stream));
             LBFGSX_HIP(hipMemsetAsync(c->ws.ticket, 0, sizeof(unsigned), c->stream));
             c->gen_count = 0;
-            c->persist = false;
+            persist_timed_out(c);
             persist_lock.unlock();
             if (c->timing && !c->ev_hv.empty())
             {
@@ -715,8 +733,12 @@ static int apply_Hv_t(lbfgsx_ctx* c, const T* v, T a, double* dg)
             }
             return apply_Hv_t<T>(c, v, a, dg);
         }
+        c->persist_backoff = 8;  // a clean persistent product
         return rc2;
     }
+    c->step_products++;
+    if (c->persist_cooldown > 0)
+        c->persist_cooldown--;
     auto launch = [&](int mode, const T* u, const T* w, TwoLoopArgs args) -> int {
         EventPair ev;
         args.rev = (c->zigzag && (c->tl_step++ & 1u)) ? 1 : 0;
@@ -727,7 +749,7 @@ static int apply_Hv_t(lbfgsx_ctx* c, const T* v, T a, double* dg)
             LBFGSX_HIP(hipEventRecord(ev.a, c->stream));
         }
 #define TL_LAUNCH(MODE, U, NT, QPOL)                                                                                  \
-    hipLaunchKernelGGL((k_twoloop<T, MODE, U, NT, QPOL>), dim3(grid), dim3(kBlock), 0, c->stream, q, v, a, u, w, c->n, \
+    LBFGSX_LAUNCH((k_twoloop<T, MODE, U, NT, QPOL>), dim3(grid), dim3(kBlock), 0, c->stream, q, v, a, u, w, c->n, \
                        sc, args, c->ws)
 #define TL_POLICY(MODE, U)                                        \
     do                                                            \
@@ -854,7 +876,7 @@ template <class T, class OBJ>
 static int eval_t(lbfgsx_ctx* c, OBJ obj, double* out3)
 {
     const int grid = c->grid_for(c->n);
-    hipLaunchKernelGGL((k_eval<T, OBJ>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]),
+    LBFGSX_LAUNCH((k_eval<T, OBJ>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]),
                        P<T>(c->gb[c->cur]), c->n, obj, c->ws, c->out_slot<T>());
     LBFGSX_HIP(hipGetLastError());
     return fetch_scalars<T>(c, c->sl.out(0), 3, out3);
@@ -864,6 +886,7 @@ extern "C" {
 int lbfgsx_eval(lbfgsx_ctx* c, int objective, double* fx, double* gnorm2, double* xnorm2)
 {
     lbfgsx::DeviceGuard dev_guard_(c->device);
+    c->spec_valid = false;  // a buffer the stored speculative direction was computed from may change (lbfgsx_apply_Hv)
     double r[3];
     int rc = LBFGSX_E_INVALID;
     if (objective == LBFGSX_OBJ_EXT_ROSENBROCK && (c->n & 1))
@@ -894,7 +917,7 @@ int lbfgsx_norms(lbfgsx_ctx* c, double* gnorm2, double* xnorm2)
     double r[2];
     DISPATCH_T(c, {
         const T* g = P<T>(c->gb[c->cur]);
-        hipLaunchKernelGGL((k_dot<T>), dim3(grid), dim3(kBlock), 0, c->stream, g, g, P<T>(c->xb[c->cur]), c->n, c->ws,
+        LBFGSX_LAUNCH((k_dot<T>), dim3(grid), dim3(kBlock), 0, c->stream, g, g, P<T>(c->xb[c->cur]), c->n, c->ws,
                            c->out_slot<T>());
         int rc = fetch_scalars<T>(c, c->sl.out(0), 2, r);
         if (rc)
@@ -921,7 +944,7 @@ static int trial_t(lbfgsx_ctx* c, OBJ obj, T step, double* out2)
     const int rev = (c->zigzag && (c->tl_step++ & 1u)) ? 1 : 0;
     // 4 vectors per stream and thread in flight (measured +1 % on the north-star against 2; profiles/r1_mall_policy_ab.txt)
 #define TRIAL_LAUNCH(UU, NTL, NTS)                                                                                            \
-    hipLaunchKernelGGL((k_trial<T, OBJ, UU, NTL, NTS>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->xp]), P<T>(c->d), \
+    LBFGSX_LAUNCH((k_trial<T, OBJ, UU, NTL, NTS>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->xp]), P<T>(c->d), \
                        step, P<T>(c->xb[c->trial]), P<T>(c->gb[c->trial]), c->n, obj, c->ws, c->out_slot<T>(), rev)
     switch (c->trial_policy)
     {
@@ -941,6 +964,7 @@ extern "C" {
 int lbfgsx_trial(lbfgsx_ctx* c, int objective, double step, double* fx, double* dg)
 {
     lbfgsx::DeviceGuard dev_guard_(c->device);
+    c->spec_valid = false;  // a buffer the stored speculative direction was computed from may change (lbfgsx_apply_Hv)
     double r[2];
     int rc = LBFGSX_E_INVALID;
     DISPATCH_T(c, {
@@ -961,9 +985,10 @@ int lbfgsx_trial(lbfgsx_ctx* c, int objective, double step, double* fx, double* 
 int lbfgsx_trial_point(lbfgsx_ctx* c, double step)
 {
     lbfgsx::DeviceGuard dev_guard_(c->device);
+    c->spec_valid = false;  // a buffer the stored speculative direction was computed from may change (lbfgsx_apply_Hv)
     const int grid = c->grid_for(c->n);
     DISPATCH_T(c, {
-        hipLaunchKernelGGL((k_axpy_point<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->xp]), P<T>(c->d),
+        LBFGSX_LAUNCH((k_axpy_point<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->xp]), P<T>(c->d),
                            T(step), P<T>(c->xb[c->trial]), c->n);
     });
     LBFGSX_HIP(hipGetLastError());
@@ -975,7 +1000,7 @@ int lbfgsx_trial_dg(lbfgsx_ctx* c, double* dg)
     lbfgsx::DeviceGuard dev_guard_(c->device);
     const int grid = c->grid_for(c->n);
     DISPATCH_T(c, {
-        hipLaunchKernelGGL((k_dot<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->gb[c->trial]), P<T>(c->d),
+        LBFGSX_LAUNCH((k_dot<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->gb[c->trial]), P<T>(c->d),
                            static_cast<const T*>(nullptr), c->n, c->ws, c->out_slot<T>());
         LBFGSX_HIP(hipGetLastError());
         return fetch_scalars<T>(c, c->sl.out(0), 1, dg);
@@ -1004,6 +1029,7 @@ int lbfgsx_ls_end(lbfgsx_ctx* c, int use_lo)
 int lbfgsx_post_linesearch(lbfgsx_ctx* c, double* gnorm2, double* xnorm2, double* sy, double* yy)
 {
     lbfgsx::DeviceGuard dev_guard_(c->device);
+    c->spec_valid = false;  // a buffer the stored speculative direction was computed from may change (lbfgsx_apply_Hv)
     if (c->gs_f32h)
     {
         set_error("lbfgsx_post_linesearch: this context keeps its history in f32 for the Gram-space recursion (lbfgsx_gs_set_history_dtype)");
@@ -1013,7 +1039,7 @@ int lbfgsx_post_linesearch(lbfgsx_ctx* c, double* gnorm2, double* xnorm2, double
     double r[4];
     DISPATCH_T(c, {
         const int rev = (c->zigzag && (c->tl_step++ & 1u)) ? 1 : 0;
-        hipLaunchKernelGGL((k_post<T, 4>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]), P<T>(c->xb[c->xp]),
+        LBFGSX_LAUNCH((k_post<T, 4>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]), P<T>(c->xb[c->xp]),
                            P<T>(c->gb[c->cur]), P<T>(c->gb[c->xp]), P<T>(c->col(c->S, c->spare)),
                            P<T>(c->col(c->Y, c->spare)), c->n, c->ws, c->out_slot<T>(), P<T>(c->sc) + c->sl.ys(c->spare),
                            P<T>(c->sc) + c->sl.theta(c->spare), rev);
@@ -1038,7 +1064,7 @@ template <class T>
 static int post_spec_t(lbfgsx_ctx* c, T a, double* r4)
 {
     const int m = c->m;
-    if (!(c->fuse_post && c->persist && c->persist_grid > 0 && m <= kPersistMaxM && !c->gs_f32h && c->device >= 0 &&
+    if (!(c->fuse_post && c->persist && c->persist_cooldown == 0 && c->persist_grid > 0 && m <= kPersistMaxM && !c->gs_f32h && c->device >= 0 &&
           c->device < 64))
         return 1;
     std::unique_lock<std::mutex> lock(g_persist_mu[c->device], std::try_to_lock);
@@ -1085,7 +1111,7 @@ static int post_spec_t(lbfgsx_ctx* c, T a, double* r4)
         LBFGSX_HIP(hipEventCreate(&hv.b));
         LBFGSX_HIP(hipEventRecord(hv.a, c->stream));
     }
-    hipLaunchKernelGGL((k_twoloop_persist<T, true>), dim3(c->persist_grid), dim3(kHvThreads), 0, c->stream, P<T>(c->d),
+    LBFGSX_LAUNCH((k_twoloop_persist<T, true>), dim3(c->persist_grid), dim3(kHvThreads), 0, c->stream, P<T>(c->d),
                        P<T>(c->gb[c->cur]), a, P<T>(c->S), P<T>(c->Y), c->n, sc, pa, c->ws, c->gen_dev,
                        reinterpret_cast<int*>(c->gen_dev + 1), pf);
     LBFGSX_HIP(hipGetLastError());
@@ -1097,13 +1123,13 @@ static int post_spec_t(lbfgsx_ctx* c, T a, double* r4)
         c->fused_timed++;
     }
     int hflags[2] = {0, 0};  // time-out flag, verdict
-    LBFGSX_HIP(hipMemcpyAsync(hflags, c->gen_dev + 1, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(lbfgsx::copy_async(hflags, c->gen_dev + 1, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     // the five scalars the host needs, one synchronisation: dg = grad . d, then {g.g, x.x, s.y, y.y}
     T* h = static_cast<T*>(c->hout);
-    LBFGSX_HIP(hipMemcpyAsync(h, sc + c->sl.dot(2 * cn), sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(lbfgsx::copy_async(h, sc + c->sl.dot(2 * cn), sizeof(T), hipMemcpyDeviceToHost, c->stream));
     if (!c->outmap_dev)
-        LBFGSX_HIP(hipMemcpyAsync(h + 8, sc + c->sl.out(0), 4 * sizeof(T), hipMemcpyDeviceToHost, c->stream));
-    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+        LBFGSX_HIP(lbfgsx::copy_async(h + 8, sc + c->sl.out(0), 4 * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
     const double dgv = double(h[0]);
     for (int i = 0; i < 4; i++)
         r4[i] = c->outmap_dev ? double(static_cast<const volatile T*>(c->outmap_host)[i]) : double(h[8 + i]);
@@ -1113,7 +1139,7 @@ static int post_spec_t(lbfgsx_ctx* c, T a, double* r4)
         LBFGSX_HIP(hipMemsetAsync(c->gen_dev, 0, 4 * sizeof(unsigned), c->stream));
         LBFGSX_HIP(hipMemsetAsync(c->ws.ticket, 0, sizeof(unsigned), c->stream));
         c->gen_count = 0;
-        c->persist = false;
+        persist_timed_out(c);
         if (c->timing && !c->ev_hv.empty())
         {
             (void) hipEventDestroy(c->ev_hv.back().a);
@@ -1126,6 +1152,7 @@ static int post_spec_t(lbfgsx_ctx* c, T a, double* r4)
     }
     c->persist_launches++;
     c->spec_launches++;
+    c->persist_backoff = 8;  // a clean persistent launch
     if (hflags[1] == 1)
     {
         c->spec_valid = true;
@@ -1182,10 +1209,77 @@ int lbfgsx_spec_counts(const lbfgsx_ctx* c, int64_t out[3])
 }
 
 // ---- instrumentation ----------------------------------------------------------------------------------
+int lbfgsx_device(const lbfgsx_ctx* c) { return c ? c->device : -1; }
+
+int lbfgsx_device_push(const lbfgsx_ctx* c, int* prev)
+{
+    int cur = -1;
+    if (!c || !prev)
+    {
+        set_error("lbfgsx_device_push: null argument");
+        return LBFGSX_E_INVALID;
+    }
+    LBFGSX_HIP(hipGetDevice(&cur));
+    *prev = cur;
+    if (cur != c->device)
+        LBFGSX_HIP(hipSetDevice(c->device));
+    return LBFGSX_OK;
+}
+
+int lbfgsx_device_pop(int prev)
+{
+    int cur = -1;
+    if (prev < 0)
+        return LBFGSX_OK;
+    LBFGSX_HIP(hipGetDevice(&cur));
+    if (cur != prev)
+        LBFGSX_HIP(hipSetDevice(prev));
+    return LBFGSX_OK;
+}
+
+int lbfgsx_persist_counts(const lbfgsx_ctx* c, int64_t out[4])
+{
+    out[0] = c->persist_launches;
+    out[1] = c->persist_timeouts;
+    out[2] = c->persist_cooldown;
+    out[3] = c->step_products;
+    return LBFGSX_OK;
+}
+
+int lbfgsx_debug_persist_fault(lbfgsx_ctx* c)
+{
+    lbfgsx::DeviceGuard dev_guard_(c->device);
+    if (!c->gen_dev)
+    {
+        set_error("lbfgsx_debug_persist_fault: this context has no persistent launch");
+        return LBFGSX_E_INVALID;
+    }
+    LBFGSX_HIP(hipMemsetAsync(c->gen_dev + 1, 1, 1, c->stream));  // failure word = 1 (low byte)
+    return LBFGSX_OK;
+}
+
+int lbfgsx_counters(int64_t out[3], int reset)
+{
+    auto& g = lbfgsx::counters();
+    if (out)
+    {
+        out[0] = g.launches.load(std::memory_order_relaxed);
+        out[1] = g.syncs.load(std::memory_order_relaxed);
+        out[2] = g.copies.load(std::memory_order_relaxed);
+    }
+    if (reset)
+    {
+        g.launches = 0;
+        g.syncs = 0;
+        g.copies = 0;
+    }
+    return LBFGSX_OK;
+}
+
 int lbfgsx_timing_enable(lbfgsx_ctx* c, int on)
 {
     lbfgsx::DeviceGuard dev_guard_(c->device);
-    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
     for (auto& e : c->ev_twoloop)
     {
         (void) hipEventDestroy(e.a);
@@ -1210,7 +1304,7 @@ int lbfgsx_timing_read(lbfgsx_ctx* c, double* twoloop_ms_total, int64_t* twoloop
                        int64_t* applyhv_calls)
 {
     lbfgsx::DeviceGuard dev_guard_(c->device);
-    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
     double t1 = 0.0, t2 = 0.0;
     for (auto& e : c->ev_twoloop)
     {
@@ -1285,7 +1379,7 @@ __global__ void __launch_bounds__(kBlock) k_selftest_reduce(RedWs ws, double* __
 template <class A, int NRED>
 static void selftest_launch(lbfgsx_ctx* c, int grid, double* out)
 {
-    hipLaunchKernelGGL((k_selftest_reduce<A, NRED>), dim3(grid), dim3(kBlock), 0, c->stream, c->ws, out);
+    LBFGSX_LAUNCH((k_selftest_reduce<A, NRED>), dim3(grid), dim3(kBlock), 0, c->stream, c->ws, out);
 }
 }  // namespace lbfgsx
 extern "C" {
@@ -1317,9 +1411,9 @@ int lbfgsx_selftest_reduce(lbfgsx_ctx* c, int nred, int grid, int f32_accumulato
 #undef ST_CASE
     hipError_t e = hipGetLastError();
     if (e == hipSuccess)
-        e = hipMemcpyAsync(out, tmp, sizeof(double) * size_t(nred), hipMemcpyDeviceToHost, c->stream);
+        e = lbfgsx::copy_async(out, tmp, sizeof(double) * size_t(nred), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess)
-        e = hipStreamSynchronize(c->stream);
+        e = lbfgsx::stream_sync(c->stream);
     (void) hipFree(tmp);
     LBFGSX_HIP(e);
     return LBFGSX_OK;
@@ -1340,16 +1434,16 @@ int lbfgsx_stream_probe(lbfgsx_ctx* c, int reps, double* copy_gbs, double* triad
     void* dst = c->col(c->Y, c->spare);
     void* z = c->xb[(c->cur + 1) % 3];
     DISPATCH_T(c, {
-        hipLaunchKernelGGL((k_copy<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(src), P<T>(dst), c->n);  // warm-up
+        LBFGSX_LAUNCH((k_copy<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(src), P<T>(dst), c->n);  // warm-up
         LBFGSX_HIP(hipEventRecord(e0, c->stream));
         for (int r = 0; r < reps; r++)
-            hipLaunchKernelGGL((k_copy<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(src), P<T>(dst), c->n);
+            LBFGSX_LAUNCH((k_copy<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(src), P<T>(dst), c->n);
         LBFGSX_HIP(hipEventRecord(e1, c->stream));
         for (int r = 0; r < reps; r++)
-            hipLaunchKernelGGL((k_triad<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(src), P<T>(z), T(0.5), P<T>(dst), c->n);
+            LBFGSX_LAUNCH((k_triad<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(src), P<T>(z), T(0.5), P<T>(dst), c->n);
         LBFGSX_HIP(hipEventRecord(e2, c->stream));
     });
-    LBFGSX_HIP(hipStreamSynchronize(c->stream));
+    LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
     float ms_c = 0.f, ms_t = 0.f;
     LBFGSX_HIP(hipEventElapsedTime(&ms_c, e0, e1));
     LBFGSX_HIP(hipEventElapsedTime(&ms_t, e1, e2));

@@ -130,7 +130,7 @@ int lbfgsx_rccl_allgather_records(const int* devices, int ndev, const void* reco
         HIP_CALL(hipMalloc(&recv[size_t(r)], blk * size_t(ndev)));
         HIP_CALL(hipMalloc(&dev_out[r], size_t(count) * size_t(rec_bytes)));
         HIP_CALL(hipMemsetAsync(send[size_t(r)], 0, blk, streams[size_t(r)]));
-        HIP_CALL(hipMemcpyAsync(send[size_t(r)], static_cast<const char*>(records) + size_t(lo) * size_t(rec_bytes),
+        HIP_CALL(lbfgsx::copy_async(send[size_t(r)], static_cast<const char*>(records) + size_t(lo) * size_t(rec_bytes),
                                 size_t(len) * size_t(rec_bytes), hipMemcpyHostToDevice, streams[size_t(r)]));
     }
     RCCL_CALL(R.CommInitAll(comms.data(), ndev, devices));
@@ -147,18 +147,18 @@ int lbfgsx_rccl_allgather_records(const int* devices, int ndev, const void* reco
             int64_t lo = 0, len = 0;
             shard_range(count, q, ndev, lo, len);
             if (len > 0)
-                HIP_CALL(hipMemcpyAsync(static_cast<char*>(dev_out[r]) + size_t(lo) * size_t(rec_bytes),
+                HIP_CALL(lbfgsx::copy_async(static_cast<char*>(dev_out[r]) + size_t(lo) * size_t(rec_bytes),
                                         static_cast<const char*>(recv[size_t(r)]) + size_t(q) * blk,
                                         size_t(len) * size_t(rec_bytes), hipMemcpyDeviceToDevice, streams[size_t(r)]));
         }
-        HIP_CALL(hipStreamSynchronize(streams[size_t(r)]));
+        HIP_CALL(lbfgsx::stream_sync(streams[size_t(r)]));
     }
 done:
     for (int r = 0; r < ndev; r++)
     {
         (void) hipSetDevice(devices[r]);
         if (streams[size_t(r)])
-            (void) hipStreamSynchronize(streams[size_t(r)]);
+            (void) lbfgsx::stream_sync(streams[size_t(r)]);
         if (comms_up && comms[size_t(r)])
             (void) R.CommDestroy(comms[size_t(r)]);
         (void) hipFree(send[size_t(r)]);

@@ -25,6 +25,7 @@ struct lbfgsx_solver
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long stats_submin_us = 0;
     long long stats2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long stats3[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     virtual void minimize(int objective, int64_t n, const void* a, const void* b, void* x, const void* lb,
                           const void* ub, lbfgsx_trace* tr, lbfgsx_result* out) = 0;
 };
@@ -229,6 +230,9 @@ struct LbfgsbImpl : lbfgsx_solver
         stats2[5] = (long long) (st.correction_s * 1e6);
         stats2[6] = st.submin_fused_sweeps;
         stats2[7] = st.gram_carried;
+        stats3[0] = st.gcp_searches;
+        stats3[1] = st.gcp_nord;
+        stats3[2] = st.gcp_sorted;
     }
 };
 
@@ -500,6 +504,13 @@ int lbfgsx_solver_stats2(lbfgsx_solver* s, long long out[8])
 {
     for (int k = 0; k < 8; k++)
         out[k] = s->stats2[k];
+    return LBFGSX_OK;
+}
+
+int lbfgsx_solver_stats3(lbfgsx_solver* s, long long out[8])
+{
+    for (int k = 0; k < 8; k++)
+        out[k] = s->stats3[k];
     return LBFGSX_OK;
 }
 

@@ -227,4 +227,7 @@ class LBFGSBSolver(_SolverBase):
         L.check(self._sol.lbfgsx_solver_stats2(self._h, C.byref(arr2)))
         d.update(zip(("gcp_dev_crossings", "gcp_sort_fallbacks", "gcp_partial_sorts", "submin_us", "linesearch_us",
                       "correction_us", "submin_fused_sweeps", "gram_carried"), list(arr2)[:8]))
+        arr3 = (C.c_longlong * 8)()
+        L.check(self._sol.lbfgsx_solver_stats3(self._h, C.byref(arr3)))
+        d.update(zip(("gcp_searches", "gcp_nord", "gcp_sorted"), list(arr3)[:3]))
         return d

@@ -186,6 +186,7 @@ struct Search
                     tr->xs[long(nfev) * tr->nsamp + s] = double(xv[size_t(s * tr->stride)]);
             tr->count = nfev + 1;
         }
+        oracle::stamp_eval(nfev);
         nfev++;
         return fx;
     }
@@ -775,6 +776,13 @@ int oracle_port_set_replication(double r)
     if (!(r >= 1.0) || std::frexp(r, &e) != 0.5)
         return -1;
     oracle::replication() = r;
+    return 0;
+}
+
+int oracle_port_set_eval_clock(double* stamps, int cap)
+{
+    oracle::eval_clock().stamps = stamps;
+    oracle::eval_clock().cap = stamps ? cap : 0;
     return 0;
 }
 

@@ -4,9 +4,29 @@
 // Element-wise arithmetic in T without contraction; the fx sum uses the oracle accumulator.
 #ifndef LBFGSX_ORACLE_OBJECTIVES_H
 #define LBFGSX_ORACLE_OBJECTIVES_H
+#include <chrono>
+
 #include "acc.h"
 #include "problems.h"
 namespace oracle {
+// bench.py's CPU baseline at the metric's own size: wall-clock stamp of every functor call (oracle_*_set_eval_clock), so
+// that ONE run yields the duration of its last iterations without a second, shorter run to subtract
+struct EvalClock
+{
+    double* stamps = nullptr;
+    int cap = 0;
+};
+inline EvalClock& eval_clock()
+{
+    static EvalClock c;
+    return c;
+}
+inline void stamp_eval(int k)
+{
+    EvalClock& c = eval_clock();
+    if (c.stamps && k < c.cap)
+        c.stamps[k] = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 template <class T>
 T eval_objective(int obj, long n, const T* a, const T* b, const T* x, T* g)
 {

@@ -72,6 +72,9 @@ typedef struct
        B and H column-major n x n doubles; -1000 when the implementation has no dense getters */                    \
     int prefix##_lbfgs_hessians(int dtype, int ls, int obj, long n, const void* a, const void* b, void* x,        \
                                 const oracle_params* p, double* B, double* H, oracle_result* out);                \
+    /* timing aid of bench.py's CPU baseline: stamps[k] = steady-clock seconds right after the k-th functor call of the   \
+       following solves (k < cap); NULL switches it off */                                                             \
+    int prefix##_set_eval_clock(double* stamps, int cap);                                                         \
     const char* prefix##_describe(void);
 
 ORACLE_DECL(oracle_ref)

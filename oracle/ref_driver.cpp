@@ -43,6 +43,7 @@ struct Functor
                     tr->xs[long(nfev) * tr->nsamp + s] = double(x[s * tr->stride]);
             tr->count = nfev + 1;
         }
+        oracle::stamp_eval(nfev);
         nfev++;
         return fx;
     }
@@ -326,6 +327,13 @@ int oracle_ref_cauchy_subspace(int dtype, long n, int m, int npairs, const void*
     else
         cauchy_subspace_t<float>(n, m, npairs, S, Y, x0, g, lb, ub, max_submin, xcp, vecc, newact, n_newact, fv,
                                  n_fv, drt);
+    return 0;
+}
+
+int oracle_ref_set_eval_clock(double* stamps, int cap)
+{
+    oracle::eval_clock().stamps = stamps;
+    oracle::eval_clock().cap = stamps ? cap : 0;
     return 0;
 }
 

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 R=${1:-r2}
 O=gpurun_out/prof_$R; mkdir -p $O
-CMD="python bench.py --no-cpu --no-batched --steps 10 --warmup 11"
+CMD="python bench.py --no-cpu --no-batched --no-legs --steps 10 --warmup 11"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- $CMD > $O/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o bench -- $CMD > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o bench -- $CMD > $O/pmc_write.log 2>&1
@@ -17,9 +17,9 @@ KCMD="python bench.py --workload cfg5-batched --steps 50 --no-cpu"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/batched_trace -o bench -- $KCMD > $O/batched_trace.log 2>&1
 # plain (un-profiled) numbers, same box
 python bench.py > $O/bench_northstar.json 2> /dev/null
-LBFGSX_FUSE_POST=0 python bench.py --no-cpu --no-batched > $O/bench_northstar_unfused.json 2> /dev/null
-python bench.py --m 20 --steps 10 --warmup 22 --no-cpu --no-batched > $O/bench_cfg3_m20.json 2> /dev/null
-python bench.py --objective quadratic --n 10000000 --no-cpu --no-batched > $O/bench_cfg2_quad1e7.json 2> /dev/null
+LBFGSX_FUSE_POST=0 python bench.py --no-cpu --no-batched --no-legs > $O/bench_northstar_unfused.json 2> /dev/null
+python bench.py --m 20 --steps 10 --warmup 22 --no-cpu --no-batched --no-legs > $O/bench_cfg3_m20.json 2> /dev/null
+python bench.py --objective quadratic --n 10000000 --no-cpu --no-batched --no-legs > $O/bench_cfg2_quad1e7.json 2> /dev/null
 python bench.py --workload cfg5-batched --steps 50 > $O/bench_cfg5_batched.json 2> /dev/null
 python scripts/bench_lbfgsb.py --n 1e7 --iters 40 --cpu-n 2e5 > $O/bench_cfg4_lbfgsb.json 2> /dev/null
 LBFGSX_GRAM=i8 python scripts/bench_lbfgsb.py --n 1e7 --iters 40 > $O/bench_cfg4_lbfgsb_i8.json 2> /dev/null

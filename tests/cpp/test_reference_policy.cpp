@@ -178,6 +178,59 @@ int main()
         }
         EXPECT(threw && x.norm() > 0);
     }
+    // ---- ... but what is thrown BEFORE a trial point exists leaves the current iterate (here x0) in x, as the reference
+    //      does: a policy's entry checks, and the functor itself throwing at x0
+    {
+        LBFGSParam<Scalar> p3;
+        p3.linesearch = LBFGS_LINESEARCH_BACKTRACKING_ARMIJO;  // refused by LineSearchNocedalWright at entry (:95-96)
+        RosenbrockPairs f{n};
+        LBFGSSolver<Scalar, LineSearchNocedalWright> s(p3);
+        Vector x = Vector::Constant(n, 0.25);
+        Scalar fx;
+        bool threw = false;
+        try
+        {
+            s.minimize(f, x, fx);
+        }
+        catch (const std::invalid_argument&)
+        {
+            threw = true;
+        }
+        EXPECT(threw && (x - Vector::Constant(n, 0.25)).norm() == 0);
+
+        LBFGSParam<Scalar> p4;
+        p4.max_step = 1e-12;  // the first step 1/|g| exceeds it: LineSearchMoreThuente refuses at entry (:231-232)
+        LBFGSSolver<Scalar, LineSearchMoreThuente> s4(p4);
+        BuiltinObjective<Scalar> rosen = ExtendedRosenbrock<Scalar>();
+        Vector x4 = Vector::Constant(n, -0.5);
+        threw = false;
+        try
+        {
+            s4.minimize(rosen, x4, fx);
+        }
+        catch (const std::invalid_argument&)
+        {
+            threw = true;
+        }
+        EXPECT(threw && (x4 - Vector::Constant(n, -0.5)).norm() == 0);
+
+        struct ThrowsAtOnce
+        {
+            Scalar operator()(const Vector&, Vector&) { throw std::domain_error("objective undefined here"); }
+        } bad;
+        LBFGSSolver<Scalar> s5(LBFGSParam<Scalar>{});
+        Vector x5 = Vector::Constant(n, 0.75);
+        threw = false;
+        try
+        {
+            s5.minimize(bad, x5, fx);
+        }
+        catch (const std::domain_error&)
+        {
+            threw = true;
+        }
+        EXPECT(threw && (x5 - Vector::Constant(n, 0.75)).norm() == 0);
+    }
     // ---- generic functor -> host path (no device pointers dereferenced on the host)
     {
         GenericQuadratic q;

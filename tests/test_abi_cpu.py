@@ -44,6 +44,19 @@ def test_version_and_device_count(libs):
     assert core.lbfgsx_device_count() >= 0
 
 
+def test_null_context_is_an_invalid_argument_not_a_crash(libs):
+    """the Gram-space entries check their context before anything dereferences it."""
+    from lbfgspp_amd import _lib as L
+    core, _ = libs
+    scal = (C.c_double * 7)()
+    assert core.lbfgsx_gs_set_history_dtype(None, L.F64) == L.E_INVALID
+    assert core.lbfgsx_gs_post_linesearch(None, scal, scal, scal, scal) == L.E_INVALID
+    assert core.lbfgsx_gs_direction(None, None, 0.0, None) == L.E_INVALID
+    assert core.lbfgsx_device(None) == -1
+    out = (C.c_int64 * 3)()
+    assert core.lbfgsx_counters(C.byref(out), 0) == 0 and all(v >= 0 for v in out)   # process-wide, needs no context
+
+
 def test_param_validation_matches_reference_messages():
     """reference Param.h:191-218 / 350-376: same exception type (invalid_argument -> ValueError) and text."""
     import lbfgspp_amd as A

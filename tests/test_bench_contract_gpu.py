@@ -21,7 +21,7 @@ def _run(*extra, gpus=1, warmup=12, env=None):
 
 
 def test_default_line_has_the_contract_keys():
-    d = _run("--cpu-n", "2000000", "--cpu-steps", "4", "--cpu-n-all", "2000000")
+    d = _run("--cpu-n", "2000000", "--cpu-steps", "4", "--cpu-n-all", "2000000", "--cpu-full", "off")
     assert d["metric"] == "L-BFGS iterations/sec at n=10^8, m=10; achieved HBM GB/s vs peak"   # BASELINE.json's metric
     assert d["unit"] == "iterations/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 12
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
@@ -43,6 +43,40 @@ def test_default_line_has_the_contract_keys():
     assert c["extrapolated"] is True and c["measured_n"] == 2000000
     a = d["cpu_baseline_all_cores"]
     assert a is None or (a["cores"] >= 1 and a["value"] > 0)
+    # every other single-GPU configuration of BASELINE.json rides in the same line, each with its own roofline object
+    for key, n, m in (("cfg2", 10000000, 10), ("cfg3", 100000000, 20)):
+        g = d[key]
+        assert g["unit"] == "iterations/s" and g["value"] > 10 and g["config"]["n"] == n and g["config"]["m"] == m
+        assert g["config"]["history_full"] is True and "workload" in g["config"]
+        assert abs(g["ms_per_step"] * g["value"] - 1e3) < 1e-3
+        gr = g["roofline"]
+        assert gr["bound"] == "hbm" and 0.2 < gr["frac"] < 1.0 and gr["kernel"] and gr["algorithmic_bytes_per_launch"] > 0
+        assert gr["launches_timed"] == g["steps"] * (2 * m + 1)
+    assert d["cfg2"]["roofline"]["q_resident_elems"] == 10000000      # cfg2: q never leaves the CUs
+    c4 = d["cfg4_lbfgsb"]
+    assert c4["unit"] == "iterations/s" and c4["value"] > 50 and c4["from_x0"]["value"] > 30 and c4["steps"] == 40
+    assert c4["from_x0"]["value"] < c4["value"] and c4["from_x0"]["first_iteration_ms"] > c4["ms_per_step"]
+    cc = c4["config"]
+    assert cc["n"] == 10000000 and cc["m"] == 10 and cc["iterations"] == 40 and "workload" in cc
+    assert 1.0 <= cc["q"] <= 10.0 and cc["n_ord"] > 1e5 and cc["n_sorted"] <= cc["n_ord"] and cc["gcp_crossings"] > 0
+    assert 10 < cc["launches_per_iteration"] < 500 and 1 < cc["host_syncs_per_iteration"] < 200 and cc["copies_per_iteration"] >= 0
+    r4 = c4["roofline"]
+    assert r4["bound"] == "hbm" and r4["kernel"] and abs(r4["frac"] - r4["achieved"] / 8000.0) < 1e-12 and 0.1 < r4["frac"] < 1.0
+    assert abs(r4["achieved"] - r4["algorithmic_bytes"] * c4["value"] / 1e9) < 1e-6 * r4["achieved"]
+    assert r4["frac_from_x0"] < r4["frac"]
+
+
+def test_cpu_baseline_at_the_metric_size_is_measured_not_scaled():
+    """--cpu-full on (at a size this test can afford): `cpu_baseline` is the un-extrapolated figure of ONE run whose
+    iteration boundaries come from the functor-call clock; the scaled small-n sample rides along."""
+    d = _run("--n", "4000000", "--cpu-full", "on", "--cpu-n", "1000000", "--cpu-steps", "3", "--cpu-n-all", "1000000",
+             "--no-batched", "--no-legs")
+    c = d["cpu_baseline"]
+    assert c["extrapolated"] is False and c["measured_n"] == 4000000 and c["cores"] == 1 and c["timed_iterations"] == 3
+    assert "boundaries from the functor-call clock" in c["sample"] and c["value"] > 0
+    s = d["cpu_baseline_sample"]
+    assert s["extrapolated"] is True and s["measured_n"] == 1000000
+    assert 0.3 < c["value"] / s["value"] < 3.0   # the scaled sample and the measured point agree in magnitude
 
 
 def test_opt_in_modes_are_labelled_as_such():
@@ -56,8 +90,8 @@ def test_opt_in_modes_are_labelled_as_such():
 
 def test_history_is_full_whatever_the_warmup():
     """timed iterations run with c = m.  --warmup 0 and --warmup 12 time the same work."""
-    a = _run("--no-cpu", "--no-batched", warmup=0)
-    b = _run("--no-cpu", "--no-batched", warmup=12)
+    a = _run("--no-cpu", "--no-batched", "--no-legs", warmup=0)
+    b = _run("--no-cpu", "--no-batched", "--no-legs", warmup=12)
     for d in (a, b):
         assert d["config"]["history_full"] is True and d["roofline"]["launches_timed"] == 3 * 21
     assert a["config"]["warmup_run"] == 10 and b["config"]["warmup_run"] == 12 and a["warmup"] == 0
@@ -67,7 +101,7 @@ def test_history_is_full_whatever_the_warmup():
 
 def test_small_problem_reports_the_hbm_model_fraction():
     """cfg2 size: q lives on the CUs, the algorithmic figure exceeds the HBM peak; `frac` stays a roofline fraction."""
-    d = _run("--objective", "quadratic", "--n", "10000000", "--no-cpu", "--no-batched")
+    d = _run("--objective", "quadratic", "--n", "10000000", "--no-cpu", "--no-batched", "--no-legs")
     r = d["roofline"]
     assert r["frac"] < 1.0 and r["q_resident_elems"] == 10000000 and r["hbm_model_GBs"] < r["algorithmic_GBs"]
     assert r["traffic"] is None   # no committed PMC profile at this (n, m)
@@ -84,8 +118,37 @@ def test_gpus_2_starts_two_ranks_or_refuses():
     d = _run("--no-cpu", "--n", "20000000", "--problems-per-gpu", "256", gpus=2, env=env)
     assert d["n_gpus"] == 2 and d["cfg5_batched"]["n_gpus"] == 2 and d["cfg5_batched"]["config"]["problems_total"] == 512
     assert d["config"]["history_full"] is True
+    # the N > 1 line explains itself: what every rank saw, which collective library carried the (non data-path) exchanges
+    assert [p["rank"] for p in d["per_rank"]] == [0, 1] and all(p["value"] > 0 and p["stream_copy_GBs"] > 0 for p in d["per_rank"])
+    assert d["collective"]["world_size"] == 2 and d["collective"]["backend"] in ("nccl", "gloo")
+    assert d["collective"]["data_path_collectives"] == 0
+    pr = d["cfg5_batched"]["config"]["per_rank"]
+    assert [(p["first_problem"], p["problems"]) for p in pr] == [(0, 256), (256, 256)]
     if ndev < 2:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--no-cpu"]
         env0 = {k: v for k, v in os.environ.items() if k not in ("LBFGSX_BENCH_FORCE_DEVICE", "WORLD_SIZE", "RANK")}
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, cwd=ROOT, env=env0)
+        assert r.returncode != 0 and not r.stdout.strip()
+
+
+def test_single_process_drives_every_listed_device():
+    """--single-process --gpus 2: ONE process, one host thread + context per listed device, the batch through
+    lbfgsx_batch_minimize_lockstep_multi and its records gathered natively over RCCL.  On the one-GPU box the device list
+    is {0, 0} (LBFGSX_BENCH_DEVICES)."""
+    sys.path.insert(0, ROOT)
+    import lbfgspp_amd as A
+    ndev = A.load()[0].lbfgsx_device_count()
+    env = {} if ndev >= 2 else {"LBFGSX_BENCH_DEVICES": "0,0"}
+    d = _run("--single-process", "--no-cpu", "--n", "20000000", "--problems-per-gpu", "128", gpus=2, env=env)
+    assert d["n_gpus"] == 2 and len(d["per_rank"]) == 2 and [p["rank"] for p in d["per_rank"]] == [0, 1]
+    assert all(p["value"] > 0 and p["stream_copy_GBs"] > 0 for p in d["per_rank"])
+    assert abs(d["value"] - 2 * d["steps"] / (d["ms_per_step"] * d["steps"] * 1e-3)) < 1e-6 * d["value"]
+    assert "one process" in d["config"]["process_model"]
+    b = d["cfg5_batched"]
+    assert b["n_gpus"] == 2 and b["config"]["problems_total"] == 256 and b["config"]["failed"] == 0
+    assert b["config"]["rccl_ranks"] == min(2, ndev) and b["config"]["rccl_allgather_seconds"] > 0
+    if ndev < 2:   # asking for two devices on a one-GPU box without the override is refused
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--single-process", "--steps", "2", "--no-cpu"]
+        env0 = {k: v for k, v in os.environ.items() if k not in ("LBFGSX_BENCH_DEVICES", "WORLD_SIZE", "RANK")}
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, cwd=ROOT, env=env0)
         assert r.returncode != 0 and not r.stdout.strip()

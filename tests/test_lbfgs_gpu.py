@@ -384,6 +384,96 @@ def test_fused_post_launch_statement_level(A, oracle, dtype, n, m, npairs, accep
     assert abs(dg.value - want) <= (1e-12 if dtype == O.F64 else 1e-5) * abs(want)
 
 
+def test_stored_speculative_direction_is_dropped_when_its_inputs_change(A, oracle):
+    """lbfgsx_apply_Hv hands out the direction the fused launch computed only if nothing it was computed from
+    has changed.  post_linesearch_spec -> stage_correction_host (the spare column now holds ANOTHER pair) -> commit ->
+    apply_Hv must recompute: the product on the history with the staged pair, not the speculated one.  Likewise an upload
+    into the gradient after the speculation."""
+    dtype, n, m, npairs = O.F64, 6000, 5, 3
+    rng = np.random.default_rng(5)
+    S = rng.standard_normal((npairs, n))
+    Y = S * (1.0 + rng.random((npairs, n))) + 0.05 * rng.standard_normal((npairs, n))
+    xp, gp = rng.standard_normal(n), rng.standard_normal(n)
+    s_new = rng.standard_normal(n)
+    x, g = xp + s_new, gp + 1.5 * s_new + 0.05 * rng.standard_normal(n)
+    s2 = rng.standard_normal(n)
+    y2 = 2.0 * s2 + 0.05 * rng.standard_normal(n)
+    g_other = rng.standard_normal(n)
+    for variant in ("restage", "upload"):
+        c = Ctx(A, dtype, n, m)
+        L = c.L
+        for k in range(npairs):
+            L.check(c.core.lbfgsx_bfgs_add_correction_host(c.h, S[k].ctypes.data_as(C.c_void_p), Y[k].ctypes.data_as(C.c_void_p)))
+        c.up(L.VEC_X, xp)
+        c.up(L.VEC_G, gp)
+        L.check(c.core.lbfgsx_ls_begin(c.h))
+        c.up(L.VEC_XT, x)
+        c.up(L.VEC_GT, g)
+        L.check(c.core.lbfgsx_ls_end(c.h, 0))
+        r = [C.c_double() for _ in range(4)]
+        L.check(c.core.lbfgsx_post_linesearch_spec(c.h, -1.0, *[C.byref(v) for v in r]))
+        counts = (C.c_int64 * 3)()
+        c.core.lbfgsx_spec_counts(c.h, C.byref(counts))
+        assert tuple(counts) == (1, 0, 0)       # the speculation ran and its pair was accepted
+        if variant == "restage":
+            sy, yy = C.c_double(), C.c_double()
+            c.core.lbfgsx_bfgs_stage_correction_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double),
+                                                                 C.POINTER(C.c_double)]
+            L.check(c.core.lbfgsx_bfgs_stage_correction_host(c.h, s2.ctypes.data_as(C.c_void_p), y2.ctypes.data_as(C.c_void_p),
+                                                             C.byref(sy), C.byref(yy)))
+            L.check(c.core.lbfgsx_commit_correction(c.h))
+            hist_S, hist_Y, v = np.vstack([S, s2[None]]), np.vstack([Y, y2[None]]), g
+        else:
+            L.check(c.core.lbfgsx_commit_correction(c.h))
+            c.up(L.VEC_G, g_other)
+            hist_S, hist_Y, v = np.vstack([S, (x - xp)[None]]), np.vstack([Y, (g - gp)[None]]), g_other
+        dg = C.c_double()
+        L.check(c.core.lbfgsx_apply_Hv(c.h, L.VEC_G, -1.0, C.byref(dg)))
+        got = c.down(L.VEC_D)
+        c.core.lbfgsx_spec_counts(c.h, C.byref(counts))
+        assert counts[1] == 0, "the stale speculative direction was handed out (%s)" % variant
+        c.close()
+        ref = oracle.apply_Hv(dtype, m, hist_S, hist_Y, v, -1.0)
+        assert np.abs(got - ref).max() <= 4 * np.finfo(np.float64).eps * np.abs(ref).max()
+
+
+def test_persistent_launch_recovers_from_a_timed_out_meeting_point(A, monkeypatch):
+    """VERDICT r2 / ADVICE r2: one time-out used to switch the persistent launch off for the life of the context.  The
+    failure word is pre-set twice during a solve (lbfgsx_debug_persist_fault: the next persistent launch finds it, does
+    nothing, the host redoes the product with the step launches): the trajectory is bit-identical to an undisturbed run,
+    the context pauses for 8 products each time and then goes back to the persistent form."""
+    import gc
+    core, _ = A.load()
+    n, m, iters = 200002, 6, 44
+    x0 = O.rosen_x0(n, 21, O.F64)
+    res = {}
+    for mode in ("faulted", "clean"):
+        gc.collect()
+        s = A.LBFGSSolver(A.LBFGSParam(m=m, epsilon=0.0, epsilon_rel=0.0, max_iterations=iters), linesearch=A.LS_MORE_THUENTE)
+        seen = []
+
+        def hook(k, s=s, mode=mode, seen=seen):
+            pc = (C.c_int64 * 4)()
+            core.lbfgsx_persist_counts(s.ctx, C.byref(pc))
+            seen.append(tuple(int(v) for v in pc))
+            if mode == "faulted" and k in (4, 24):
+                assert core.lbfgsx_debug_persist_fault(s.ctx) == 0
+        s.set_iteration_hook(hook)
+        x = x0.copy()
+        niter, fx = s.minimize(A.ExtendedRosenbrock(), x)
+        pc = (C.c_int64 * 4)()
+        core.lbfgsx_persist_counts(s.ctx, C.byref(pc))
+        res[mode] = (niter, s.last.nfev, fx, x, tuple(int(v) for v in pc), seen)
+        del s
+    assert res["faulted"][:3] == res["clean"][:3] and np.array_equal(res["faulted"][3], res["clean"][3])
+    launches, timeouts, pause, steps = res["faulted"][4]
+    assert timeouts == 2 and pause == 0 and 16 <= steps <= 20, res["faulted"][4]
+    assert launches >= iters - 20                      # it went back to the persistent form both times
+    assert res["clean"][4][1] == 0 and res["clean"][4][3] == 0
+    pauses = [t[2] for t in res["faulted"][5]]
+    assert max(pauses) <= 8 and pauses.count(0) >= iters - 22   # never more than the 8-product pause: no escalation after a clean launch
+
+
 def test_two_live_solvers_on_one_device_both_use_the_persistent_kernel(A, oracle):
     """Round 1 used the one-launch recursion only while its context was the single live one of the process.  The
     requirement is narrower -- at most one PERSISTENT kernel in flight per device -- and is kept by a per-device lock held
