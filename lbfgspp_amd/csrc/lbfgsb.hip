@@ -57,6 +57,8 @@ struct lbfgsb_state
     size_t wf_tmp_bytes = 0;
     bool wf_use = true;                   // LBFGSX_COMPACT_FREE=0: never
     int vonly_groups = 0;                 // LBFGSX_VONLY_GROUPS=1: the v-row Gram walks one row per step (A/B of the lane groups)
+    bool vrows = true;                    // LBFGSX_VROWS=0: the v-row / selected-entries passes through the LDS tile kernel (k_gram_dd<.., VONLY>)
+                                          // instead of the register kernel k_vrows (A/B; same sums)
     bool wf_on = false;                   // the caller's hint for the current subspace minimisation
     bool wf_valid = false;
     int64_t wf_n = 0;                     // rows in the copy
@@ -252,6 +254,8 @@ int bounded_alloc(lbfgsx_ctx* c)
         b->wf_use = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_VONLY_GROUPS"))
         b->vonly_groups = atoi(e);
+    if (const char* e = getenv("LBFGSX_VROWS"))
+        b->vrows = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_GCP_PIECES"))
         b->chain_pieces = std::max(1, std::min(8, atoi(e)));
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->colmax), sizeof(unsigned long long) * 2 * size_t(c->m + 1)));
@@ -364,7 +368,7 @@ static Cols<T, NC> col_list(lbfgsx_ctx* c, const int* which /* 0..2c-1: Y slots 
             cl.p[k] = static_cast<const T*>(c->col(base, c->phys[size_t(slot)]));
         }
         else
-            cl.p[k] = nullptr;
+            cl.p[k] = cl.p[0];  // padding: valid memory, so that a kernel may load all NC columns without a branch per column
     }
     return cl;
 }
@@ -375,7 +379,7 @@ static Cols<T, 32> wf_cols(lbfgsx_ctx* c, int count)
 {
     Cols<T, 32> cl;
     for (int k = 0; k < 32; k++)
-        cl.p[k] = (k < count) ? static_cast<const T*>(c->bstate->wf) + int64_t(k) * c->bstate->wf_ld : nullptr;
+        cl.p[k] = static_cast<const T*>(c->bstate->wf) + int64_t(k < count ? k : 0) * c->bstate->wf_ld;  // padded with column 0
     return cl;
 }
 // a mask inside the free set can be served from the compact copy
@@ -1579,6 +1583,94 @@ static int launch_gram_vonly(lbfgsx_ctx* c, int64_t nbatch, int tot, int vsel_id
                        mask, nrows, b->gram_partial, pro, gr);
     return blocks;
 }
+// k_vrows: the v row (NA = 1) or the v row and the rows of two columns (NA = 3) of the masked Gram, rounded values in
+// gram_out[r * (NC + 1) + j] and (hi, lo) pairs from gram_out + 256 on (host-mapped when the mapped outputs are on)
+template <class T, int NC, int NA>
+static int launch_vrows(lbfgsx_ctx* c, int tot, int vsel_id, int mask, const GramPrologue<T>& pro, const GramRows<T>& gr,
+                        int64_t nrows, int col_a, int col_b)
+{
+    lbfgsb_state* b = c->bstate;
+    int which[32];
+    for (int k = 0; k < tot; k++)
+        which[k] = k;
+    Cols<T, 32> cl = gr.in_idx ? wf_cols<T>(c, tot) : col_list<T, 32>(c, which, tot);
+    // resident wave sets: two blocks per CU while the accumulators leave room for two waves per SIMD, else one
+    const int per_cu = (NA == 1 && NC <= 20) ? 2 : 1;
+    const int grid = std::max(1, std::min(std::min(c->grid_for(nrows), b->num_cus * per_cu), c->ws.maxGrid));
+    LBFGSX_LAUNCH((k_vrows<T, NC, NA>), dim3(grid), dim3(kBlock), 0, c->stream, cl, tot, bvecs<T>(c), vsel_id, mask, nrows,
+                  c->ws, b->gram_out, b->gram_out + 256, pro, gr, col_a, col_b);
+    LBFGSX_HIP(hipGetLastError());
+    return LBFGSX_OK;
+}
+template <class T>
+static int launch_vrows_v(lbfgsx_ctx* c, int tot, int vsel_id, int mask, const GramPrologue<T>& pro, const GramRows<T>& gr,
+                          int64_t nrows)
+{
+    if (tot <= 8) return launch_vrows<T, 8, 1>(c, tot, vsel_id, mask, pro, gr, nrows, 0, 0);
+    if (tot <= 16) return launch_vrows<T, 16, 1>(c, tot, vsel_id, mask, pro, gr, nrows, 0, 0);
+    if (tot <= 20) return launch_vrows<T, 20, 1>(c, tot, vsel_id, mask, pro, gr, nrows, 0, 0);
+    if (tot <= 24) return launch_vrows<T, 24, 1>(c, tot, vsel_id, mask, pro, gr, nrows, 0, 0);
+    return launch_vrows<T, 32, 1>(c, tot, vsel_id, mask, pro, gr, nrows, 0, 0);
+}
+// the (hi, lo) outputs of k_vrows (and its rounded values) on the host: `count` doubles from gram_out + first
+static int fetch_gram_out(lbfgsx_ctx* c, int first, int count, double* h)
+{
+    lbfgsb_state* b = c->bstate;
+    if (b->gram_out_host)
+    {
+        LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
+        const volatile double* src = b->gram_out_host + first;
+        for (int i = 0; i < count; i++)
+            h[i] = src[i];
+        return LBFGSX_OK;
+    }
+    LBFGSX_HIP(lbfgsx::copy_async(h, b->gram_out + first, sizeof(double) * size_t(count), hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
+    return LBFGSX_OK;
+}
+// Can the requested entries be served by k_vrows?  Every entry must lie in the v row (I = tot) or contain one of at most
+// two other columns (the two columns add_correction replaced, in the carried first solve).  slot[z] = index of entry z
+// in the kernel's output, rows of NP entries: 0 = v row, 1 = column a, 2 = column b.
+static bool vrows_plan(int npairs, const int* pi, const int* pj, int tot, int NP, int& col_a, int& col_b, int* slot)
+{
+    int freq[33];
+    for (int k = 0; k <= 32; k++)
+        freq[k] = 0;
+    bool other = false;
+    for (int z = 0; z < npairs; z++)
+        if (pi[z] != tot && pj[z] != tot)
+        {
+            other = true;
+            freq[pi[z]]++;
+            if (pj[z] != pi[z])
+                freq[pj[z]]++;
+        }
+    col_a = col_b = -1;
+    if (other)
+    {
+        for (int k = 0; k < tot; k++)
+            if (col_a < 0 || freq[k] > freq[col_a])
+                col_a = k;
+        for (int k = 0; k < tot; k++)
+            if (k != col_a && freq[k] > 0 && (col_b < 0 || freq[k] > freq[col_b]))
+                col_b = k;
+        if (col_b < 0)
+            col_b = col_a;
+    }
+    for (int z = 0; z < npairs; z++)
+    {
+        const int I = pi[z], J = pj[z];
+        if (I == tot || J == tot)
+            slot[z] = (I == tot) ? J : I;                       // v row: entry = the other index (tot for v.v)
+        else if (I == col_a || J == col_a)
+            slot[z] = NP + (I == col_a ? J : I);
+        else if (I == col_b || J == col_b)
+            slot[z] = 2 * NP + (I == col_b ? J : I);
+        else
+            return false;
+    }
+    return true;
+}
 extern "C" {
 
 int lbfgsx_b_wtv_prologue(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, const double* coef1, const double* coef2,
@@ -1616,18 +1708,34 @@ int lbfgsx_b_wtv_prologue(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, co
         GramRows<T> gr{};
         gr.in_idx = compact ? b->wf_idx : nullptr;
         gr.vgroups = b->vonly_groups;
+        if (b->vrows)
+        {
+            rc = launch_vrows_v<T>(c, tot, vsel_id, mask, pro, gr, nrows);
+            blocks = 0;
+        }
         // the tile row stride must hold ntot columns: the strides of the full kernel's KP classes
-        if (ntot <= 11) blocks = launch_gram_vonly<T, 11>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
+        else if (ntot <= 11) blocks = launch_gram_vonly<T, 11>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
         else if (ntot <= 15) blocks = launch_gram_vonly<T, 15>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
         else if (ntot <= 23) blocks = launch_gram_vonly<T, 23>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
         else if (ntot <= 27) blocks = launch_gram_vonly<T, 27>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
         else blocks = launch_gram_vonly<T, 31>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
     });
+    if (rc)
+        return rc;
+    double h[64];
+    if (blocks == 0)  // k_vrows: the last block has published the rounded sums
+    {
+        rc = fetch_gram_out(c, 0, tot, h);
+        if (rc)
+            return rc;
+        for (int j = 0; j < tot; j++)
+            wtv[j] = h[j];
+        return LBFGSX_OK;
+    }
     const int nch = std::min(blocks, 32);
     LBFGSX_LAUNCH(k_gram_finish, dim3(1, nch), dim3(kBlock), 0, c->stream, b->gram_partial, blocks, b->gram_partial2, 0);
     LBFGSX_LAUNCH(k_gram_finish, dim3(1, 1), dim3(kBlock), 0, c->stream, b->gram_partial2, nch, b->gram_out, 1);
     LBFGSX_HIP(hipGetLastError());
-    double h[64];
     if (b->gram_out_host)
     {
         LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
@@ -1767,6 +1875,17 @@ int lbfgsx_b_gram_pairs_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
     const int64_t nrows = compact_in ? b->wf_n : c->n;
     const int64_t nbatch = (nrows + kGramDDRows - 1) / kGramDDRows;
     int blocks = 1;
+    // the register kernel serves the pass that writes no new copy when the entries are the v row plus the rows of at most
+    // two columns (3 (2c + 1) <= 64 sums: one lane per sum in the block reduction)
+    int col_a = -1, col_b = -1, slot[64];
+    bool use_vrows = b->vrows && !compact_out && vrows_plan(npairs, pair_i, pair_j, tot, (tot <= 20 ? 20 : 32) + 1, col_a, col_b, slot);
+    if (use_vrows && col_a >= 0 && (tot > 20 || !compact_in))  // the three-row form walks the compact copy's row list
+        use_vrows = false;
+    if (use_vrows && col_a < 0)  // v row only: the row length of the class launch_vrows_v picks
+    {
+        const int np = (tot <= 8 ? 8 : tot <= 16 ? 16 : tot <= 20 ? 20 : tot <= 24 ? 24 : 32) + 1;
+        (void) vrows_plan(npairs, pair_i, pair_j, tot, np, col_a, col_b, slot);
+    }
     DISPATCH_T(c, {
         GramPrologue<T> pro;
         pro.mode = prologue;
@@ -1803,7 +1922,15 @@ int lbfgsx_b_gram_pairs_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
             gr.ti[e] = (unsigned char) (e < npairs ? pair_i[e] : 0);
             gr.tj[e] = (unsigned char) (e < npairs ? pair_j[e] : 0);
         }
-        if (ntot <= 11) blocks = launch_gram_vonly<T, 11>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
+        if (use_vrows)
+        {
+            blocks = 0;
+            if (col_a < 0)
+                rc = launch_vrows_v<T>(c, tot, vsel_id, mask, pro, gr, nrows);
+            else
+                rc = launch_vrows<T, 20, 3>(c, tot, vsel_id, mask, pro, gr, nrows, col_a, col_b);
+        }
+        else if (ntot <= 11) blocks = launch_gram_vonly<T, 11>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
         else if (ntot <= 15) blocks = launch_gram_vonly<T, 15>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
         else if (ntot <= 23) blocks = launch_gram_vonly<T, 23>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
         else if (ntot <= 27) blocks = launch_gram_vonly<T, 27>(c, nbatch, tot, vsel_id, mask, pro, gr, nrows);
@@ -1815,6 +1942,21 @@ int lbfgsx_b_gram_pairs_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
     {
         b->wf_valid = true;  // usable by the passes of this subspace minimisation
         b->wf_epoch = b->sub_epoch;
+    }
+    if (rc)
+        return rc;
+    if (blocks == 0)  // k_vrows: (hi, lo) of row r, entry j at gram_out[256 + 2 (r NP + j)]
+    {
+        double h[2 * 64];
+        rc = fetch_gram_out(c, 256, 2 * 64, h);
+        if (rc)
+            return rc;
+        for (int z = 0; z < npairs; z++)
+        {
+            out_dd[2 * z] = h[2 * slot[z]];
+            out_dd[2 * z + 1] = h[2 * slot[z] + 1];
+        }
+        return LBFGSX_OK;
     }
     const int nch = std::min(blocks, 32);
     LBFGSX_LAUNCH(k_gram_finish, dim3(1, nch), dim3(kBlock), 0, c->stream, b->gram_partial, blocks, b->gram_partial2, 0);
@@ -2263,6 +2405,7 @@ int lbfgsx_b_solve_sweep(lbfgsx_ctx* c, int first, int vsel_id, const double* co
     DISPATCH_T(c, {
         if (total <= 8) rc = solve_sweep_t<T, 8>(c, first, vsel_id, coef, theta, wty, r, cap, dst);
         else if (total <= 16) rc = solve_sweep_t<T, 16>(c, first, vsel_id, coef, theta, wty, r, cap, dst);
+        else if (total <= 20) rc = solve_sweep_t<T, 20>(c, first, vsel_id, coef, theta, wty, r, cap, dst);  // m = 10: no idle registers
         else if (total <= 24) rc = solve_sweep_t<T, 24>(c, first, vsel_id, coef, theta, wty, r, cap, dst);
         else rc = solve_sweep_t<T, 32>(c, first, vsel_id, coef, theta, wty, r, cap, dst);
     });

@@ -454,25 +454,48 @@ __global__ void __launch_bounds__(kBlock, 1) k_multidot2_all(Cols<T, 32> cols, i
     A acc[2 * NC];
     const int64_t nv = n / W;
     const int64_t stride = int64_t(gridDim.x) * kBlock;
-    for (int64_t vi = int64_t(blockIdx.x) * kBlock + threadIdx.x; vi < nv; vi += stride)
-    {
-        const Pack<T> a = ldv<T>(v1, vi), d = ldv<T>(v2, vi);
-        Pack<T> pc[NC];
+    // One wavefront per SIMD (the 4 NC accumulator registers leave no room for a second): nothing else hides the memory
+    // latency, so the loads of the next tile are issued before the ~12 NC W dependent f64 operations of the current one
+    // (two register sets, ping-pong; the order of the additions is unchanged).
+    // All NC columns are loaded and accumulated, no test per column (the pointers beyond ncols repeat column 0, their sums
+    // are never read): a branch between two loads makes the compiler wait for EVERY outstanding load at the join,
+    // which would serialise the two register sets again.
+    auto load = [&](int64_t vi, Pack<T>& a, Pack<T>& d, Pack<T>(&pc)[NC]) __attribute__((always_inline)) {
+        a = ldv<T>(v1, vi);
+        d = ldv<T>(v2, vi);
 #pragma unroll
         for (int k = 0; k < NC; k++)
-            if (k < ncols)
-                pc[k] = ldv<T>(cols.p[k], vi);
+            pc[k] = ldv<T>(cols.p[k], vi);
+    };
+    auto work = [&](const Pack<T>& a, const Pack<T>& d, const Pack<T>(&pc)[NC]) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < NC; k++)
-            if (k < ncols)
+        {
+#pragma unroll
+            for (int e = 0; e < W; e++)
             {
-#pragma unroll
-                for (int e = 0; e < W; e++)
-                {
-                    acc[k].add_prod(pc[k].e[e], a.e[e]);
-                    acc[NC + k].add_prod(pc[k].e[e], d.e[e]);
-                }
+                acc[k].add_prod(pc[k].e[e], a.e[e]);
+                acc[NC + k].add_prod(pc[k].e[e], d.e[e]);
             }
+        }
+    };
+    if (nv > 0)
+    {
+        // the loads are unconditional (a tile index beyond the end is clamped to the last tile and its values dropped):
+        // a load inside an `if` leaves the compiler unable to count the outstanding loads at the join
+        Pack<T> a0, d0, p0[NC], a1, d1, p1[NC];
+        const int64_t last = nv - 1;
+        int64_t vi = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+        load(vi < nv ? vi : last, a0, d0, p0);
+        for (; vi < nv; vi += 2 * stride)
+        {
+            const int64_t vb = vi + stride, vc = vb + stride;
+            load(vb < nv ? vb : last, a1, d1, p1);
+            work(a0, d0, p0);
+            load(vc < nv ? vc : last, a0, d0, p0);
+            if (vb < nv)
+                work(a1, d1, p1);
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0)
         for (int64_t i = nv * W; i < n; i++)
@@ -1095,6 +1118,211 @@ __global__ void __launch_bounds__(kBlock) k_gram_finish(const double* __restrict
     }
 }
 
+// ---------------------------------------------------------------- the v row (and up to two more rows) of the masked Gram, in registers
+// What k_gram_dd<.., VONLY> computes, for the passes that walk rows in order (the compact copy of the free rows, or the
+// full-length columns under a mask) and write no new copy.  One row per lane, its 2c column values in registers: the
+// prologue statements (GP_RHS / GP_LINEAR), the patch of the two columns add_correction replaced and the products all read
+// them there; no LDS tile, no second trip.  The sums
+//     V[j] = sum_rows v * col_j (j < 2c),  V[2c] = sum v * v
+//     NA = 3:  A[j] = sum col_a * col_j,  B[j] = sum col_b * col_j   (the two fresh columns: the selected entries the
+//              carried first solve needs, lbfgsx_b_gram_pairs_dd)
+// end in grid_reduce: the last block publishes the rounded values and the un-rounded (hi, lo) pairs, no k_gram_finish
+// launches.  Same correctly rounded sums as the tile kernel (the order of the additions differs).
+//
+// What makes it fast (scripts/experiments/streams.hip: a bare pass over 20 column streams with gathers runs at 5.2 TB/s,
+// the tile kernel at 4.1): EVERY load of a row is issued unconditionally and up front -- all NC columns (the pointers
+// beyond ncols repeat column 0, their sums are never read), the state byte, the vectors of the prologue and of v through
+// pointers chosen once per launch (a vector a mode does not use is read from a valid stand-in and ignored).  A load under
+// an `if`, even a uniform one, makes the compiler wait for every outstanding load at the join.
+// out[r * (NC + 1) + j], r = 0 (V), 1 (A), 2 (B); out_dd the same entries as (hi, lo).
+template <class T>
+struct VrowIn  // what a row needs besides its column values
+{
+    T pre, va, vb, fa, fb;
+    unsigned char st;
+};
+template <class T, int NC, int NA>
+__global__ void __launch_bounds__(kBlock, (NA == 1 && NC <= 20) ? 2 : 1)
+    k_vrows(Cols<T, 32> cols, int ncols, BVecs<T> b, int vsel_id, int mask, int64_t n, RedWs ws, double* __restrict__ out,
+            double* __restrict__ out_dd, GramPrologue<T> pro, GramRows<T> gr, int col_a, int col_b)
+{
+    typedef typename AccOf<T>::type A;
+    constexpr int NP = NC + 1;
+    __shared__ T pc1[64], pc2[64];
+    if (threadIdx.x < 64)
+    {
+        pc1[threadIdx.x] = pro.c1[threadIdx.x];
+        pc2[threadIdx.x] = pro.c2[threadIdx.x];
+    }
+    __syncthreads();
+    Accs<A, NA * NP> accs;
+    A(&acc)[NA * NP] = accs.v;
+    A vv;  // sum v * v
+    // the vectors a row reads, as pointers fixed for the launch
+    const T* pre_p = pro.mode == GP_LINEAR ? b.g : b.rhs;
+    const T* va_p;
+    const T* vb_p;
+    int vkind;  // 0: v = a, 1: v = -a, 2: v = a - b
+    switch (vsel_id)
+    {
+    case VS_DRT: va_p = b.drt; vb_p = b.drt; vkind = 0; break;
+    case VS_NEG_CF: va_p = b.cF; vb_p = b.cF; vkind = 1; break;
+    case VS_NEG_RHS: va_p = b.rhs; vb_p = b.rhs; vkind = 1; break;
+    case VS_LBOUND: va_p = b.lb; vb_p = b.x0; vkind = 2; break;
+    case VS_UBOUND: va_p = b.ub; vb_p = b.x0; vkind = 2; break;
+    default: va_p = b.y; vb_p = b.y; vkind = 0; break;
+    }
+    const bool patch = gr.dst_a != nullptr;
+    const T* fa_p = patch ? gr.src_a : b.rhs;
+    const T* fb_p = patch ? gr.src_b : b.rhs;
+    auto fetch = [&](int64_t r, VrowIn<T>& x, T(&w)[NC], int64_t t) __attribute__((always_inline)) {
+        x.st = b.st[r];
+        x.pre = pre_p[r];
+        x.va = va_p[r];
+        x.vb = vb_p[r];
+        x.fa = fa_p[r];
+        x.fb = fb_p[r];
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+            w[k] = cols.p[k][t];
+    };
+    // the statements of one row whose column values sit in row[0..NC)
+    auto one_row = [&](T(&row)[NC], int64_t rt, int64_t r, const VrowIn<T>& x) __attribute__((always_inline)) {
+        if (patch)  // every position of the kept copy gets the two replaced columns, kept or not
+        {
+            gr.dst_a[rt] = x.fa;
+            gr.dst_b[rt] = x.fb;
+#pragma unroll
+            for (int k = 0; k < NC; k++)
+                row[k] = (k == gr.fresh_a) ? x.fa : (k == gr.fresh_b) ? x.fb : row[k];
+        }
+        if (mask && !(x.st & mask))
+            return;
+        T v = vkind == 0 ? x.va : vkind == 1 ? -x.va : x.va - x.vb;
+        if (pro.mode != GP_NONE)
+        {
+            // (W * coef)(row): columns in order, plain accumulation -- the statement k_wcombine evaluates
+            T a1 = T(0), a2 = T(0);
+            if (pro.use1)
+            {
+#pragma unroll
+                for (int j = 0; j < NC; j++)
+                    if (j < ncols)
+                        a1 = a1 + row[j] * pc1[j];
+            }
+            if (pro.use2)
+            {
+#pragma unroll
+                for (int j = 0; j < NC; j++)
+                    if (j < ncols)
+                        a2 = a2 + row[j] * pc2[j];
+            }
+            if (pro.mode == GP_RHS)
+            {
+                T rh = x.pre;
+                if (pro.use1)
+                    rh = rh + (-a1);
+                if (pro.use2)
+                    rh = rh + (-a2);
+                b.rhs[r] = rh;
+                if (vsel_id == VS_NEG_RHS)  // v is read from the vector just written
+                    v = -rh;
+            }
+            else
+            {
+                const T cf = (pro.use1 ? (T(-1) * a1) : T(0)) + x.pre;
+                b.cF[r] = cf;
+                if (vsel_id == VS_NEG_CF)
+                    v = -cf;
+            }
+        }
+        T xa = T(0), xb = T(0);
+        if (NA > 1)
+        {
+#pragma unroll
+            for (int k = 0; k < NC; k++)
+            {
+                xa = (k == col_a) ? row[k] : xa;
+                xb = (k == col_b) ? row[k] : xb;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NC; j++)
+        {
+            acc[j].add_prod(v, row[j]);
+            if (NA > 1)
+            {
+                acc[NP + j].add_prod(xa, row[j]);
+                acc[2 * NP + j].add_prod(xb, row[j]);
+            }
+        }
+        // the (v, v) entry sits right behind the columns (entry `ncols`, as in the tile kernel); with ncols < NC the
+        // padding entries acc[ncols..NC) hold sums nobody reads and (v, v) lands on top of one of them: cleared first
+#pragma unroll
+        for (int j = 0; j < NP; j++)
+            if (j == ncols)
+                vv.add_prod(v, v);
+    };
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    if (NA == 1)
+    {
+        for (int64_t t = int64_t(blockIdx.x) * kBlock + threadIdx.x; t < n; t += stride)
+        {
+            // a row number comes from the compact copy's list or is the position itself; the one load under a (uniform)
+            // test -- nothing else is outstanding at that point
+            int64_t r = t;
+            if (gr.in_idx)
+                r = gr.in_idx[t];
+            VrowIn<T> x;
+            T w[NC];
+            fetch(r, x, w, t);
+            one_row(w, t, r, x);
+        }
+    }
+    else if (n > 0)
+    {
+        // One wavefront per SIMD (3 (2c + 1) accumulators): two register sets, the loads of the next row issued before
+        // the ~36 (2c + 1) dependent f64 operations of the current one; the row numbers run one step further ahead.
+        // Indices beyond the end are clamped to the last row (loaded again, dropped).  Needs gr.in_idx.
+        const int64_t last = n - 1;
+        int64_t t = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+        auto cl = [&](int64_t q) __attribute__((always_inline)) { return q < n ? q : last; };
+        int64_t r0 = gr.in_idx[cl(t)], r1 = gr.in_idx[cl(t + stride)];
+        VrowIn<T> x0, x1;
+        T w0[NC], w1[NC];
+        fetch(r0, x0, w0, cl(t));
+        for (; t < n; t += 2 * stride)
+        {
+            const int64_t tb = t + stride, tc = tb + stride, td = tc + stride;
+            const int64_t r2 = gr.in_idx[cl(tc)];
+            fetch(r1, x1, w1, cl(tb));
+            one_row(w0, t, r0, x0);
+            r0 = r2;
+            const int64_t r3 = gr.in_idx[cl(td)];
+            fetch(r0, x0, w0, cl(tc));
+            if (tb < n)
+                one_row(w1, tb, r1, x1);
+            r1 = r3;
+        }
+    }
+    // (v, v) goes where the tile kernel has it
+#pragma unroll
+    for (int j = 0; j < NP; j++)
+        if (j == ncols)
+            acc[j] = vv;
+    if (grid_reduce<NA * NP>(acc, ws) && threadIdx.x == 0)
+#pragma unroll
+        for (int k = 0; k < NA * NP; k++)
+        {
+            out[k] = acc[k].value();
+            if (out_dd)
+            {
+                out_dd[2 * k] = acc[k].hi;
+                out_dd[2 * k + 1] = acc_lo(acc[k]);
+            }
+        }
+}
+
 // ---------------------------------------------------------------- Cauchy build (Cauchy.h:111-129,154)
 // brk, vecd, sort keys/values; out[0] = d.d, out[1] = #free (brk = inf), out[2] = #ord (0 < brk < inf)
 template <class T>
@@ -1549,6 +1777,57 @@ __global__ void __launch_bounds__(kBlock) k_sub_sweep_begin(BVecs<T> b, int firs
 //              The rows of the old L and U need the multipliers this pass's dots lead to: k_lu_sweep, over the index
 //              list, right after.
 // out = {dots[ND], the 7 sums of k_sub_sweep_begin over the rows handled here}
+// Every load of a row is issued unconditionally and up front (the NC columns -- pointers beyond ncols repeat column 0 --,
+// the state byte, v, y, the bounds, x0, cF): the statements that follow only select among values that are already on
+// their way, so one memory round trip serves the row (see k_vrows).  The statements themselves are those of the separate
+// kernels, in their order.
+template <class T>
+__device__ __forceinline__ unsigned char sweep_row_v(const BVecs<T>& b, int64_t i, unsigned char s, T yi, T lam, T mu, bool first,
+                                                     bool store_mult, unsigned* cnt, T li, T ui, T cfi)
+{
+    // sweep_row with lb - x0, ub - x0 and cF of the row passed in
+    if (first)
+    {
+        cnt[3] += (yi < li || yi > ui) ? 1u : 0u;
+        b.yfb[i] = yi;
+    }
+    else
+    {
+        cnt[4] += ((s & ST_P) && (yi < li || yi > ui)) ? 1u : 0u;
+        cnt[5] += ((s & ST_L) && lam < T(0)) ? 1u : 0u;
+        cnt[6] += ((s & ST_U) && mu < T(0)) ? 1u : 0u;
+    }
+    s &= (unsigned char) ~(ST_L | ST_U | ST_P);
+    if ((yi < li) || (yi == li && lam >= T(0)))
+    {
+        s |= ST_L;
+        b.y[i] = li;
+        mu = T(0);
+        cnt[0]++;
+    }
+    else if ((yi > ui) || (yi == ui && mu >= T(0)))
+    {
+        s |= ST_U;
+        b.y[i] = ui;
+        lam = T(0);
+        cnt[1]++;
+    }
+    else
+    {
+        s |= ST_P;
+        lam = T(0);
+        mu = T(0);
+        b.rhs[i] = cfi;
+        cnt[2]++;
+    }
+    if (store_mult)
+    {
+        b.lam[i] = lam;
+        b.mu[i] = mu;
+    }
+    b.st[i] = s;
+    return s;
+}
 template <class T, int NC, int FIRST>
 __global__ void __launch_bounds__(kBlock, NC <= 24 ? 2 : 1) k_solve_sweep(Cols<T, 32> cols, int ncols, BVecs<T> b, int vsel_id, CoefArg<T> coef,
                                                         int has_w, T theta, int64_t n, RedWs ws, double* __restrict__ out,
@@ -1563,22 +1842,37 @@ __global__ void __launch_bounds__(kBlock, NC <= 24 ? 2 : 1) k_solve_sweep(Cols<T
         sc[threadIdx.x] = coef.c[threadIdx.x];
     __syncthreads();
     const T theta2 = theta * theta;
+    const T* va_p;
+    const T* vb_p;
+    int vkind;  // 0: v = a, 1: v = -a, 2: v = a - b
+    switch (vsel_id)
+    {
+    case VS_DRT: va_p = b.drt; vb_p = b.drt; vkind = 0; break;
+    case VS_NEG_CF: va_p = b.cF; vb_p = b.cF; vkind = 1; break;
+    case VS_NEG_RHS: va_p = b.rhs; vb_p = b.rhs; vkind = 1; break;
+    case VS_LBOUND: va_p = b.lb; vb_p = b.x0; vkind = 2; break;
+    case VS_UBOUND: va_p = b.ub; vb_p = b.x0; vkind = 2; break;
+    default: va_p = b.y; vb_p = b.y; vkind = 0; break;
+    }
     A dots[ND ? ND : 1];
     unsigned cnt[7] = {0, 0, 0, 0, 0, 0, 0};
     const int64_t stride = int64_t(gridDim.x) * kBlock;
     for (int64_t t = int64_t(blockIdx.x) * kBlock + threadIdx.x; t < n; t += stride)
     {
-        const int64_t i = ridx ? int64_t(ridx[t]) : t;
-        unsigned char st = b.st[i];
-        if (!(st & ST_FREE))
-            continue;
+        int64_t i = t;
+        if (ridx)
+            i = ridx[t];
+        const unsigned char st0 = b.st[i];
         T w[NC];
 #pragma unroll
         for (int k = 0; k < NC; k++)
-            if (k < ncols)
-                w[k] = cols.p[k][t];
-        const bool solve = FIRST || (st & ST_P);
-        T yi;
+            w[k] = cols.p[k][t];
+        const T xa = va_p[i], xb = vb_p[i];
+        const T yold = b.y[i], lbi = b.lb[i], ubi = b.ub[i], x0i = b.x0[i], cfi = b.cF[i];
+        if (!(st0 & ST_FREE))
+            continue;
+        const bool solve = FIRST || (st0 & ST_P);
+        T yi = yold;
         if (solve)
         {
             T a = T(0);
@@ -1589,25 +1883,22 @@ __global__ void __launch_bounds__(kBlock, NC <= 24 ? 2 : 1) k_solve_sweep(Cols<T
                     if (k < ncols)
                         a = a + w[k] * sc[k];
             }
-            const T v = vsel(b, vsel_id, i);
+            const T v = vkind == 0 ? xa : vkind == 1 ? -xa : xa - xb;
             yi = has_w ? (v / theta + a / theta2) : (v / theta);
             b.y[i] = yi;
         }
-        else
-            yi = b.y[i];
         if (!FIRST)
         {
 #pragma unroll
             for (int k = 0; k < NC; k++)
-                if (k < ncols)
-                    dots[k].add_prod(w[k], yi);
+                dots[k].add_prod(w[k], yi);
         }
         bool app = false;
         if (solve)
         {
             // a P row's multipliers are zero (the sweep that made it P stored them); the first sweep sets them
-            st = sweep_row<T>(b, i, st, yi, T(0), T(0), FIRST != 0, FIRST != 0, cnt);
-            app = (st & (ST_L | ST_U)) != 0;
+            const unsigned char s2 = sweep_row_v<T>(b, i, st0, yi, T(0), T(0), FIRST != 0, FIRST != 0, cnt, lbi - x0i, ubi - x0i, cfi);
+            app = (s2 & (ST_L | ST_U)) != 0;
         }
         if (lu_cap)
             lu_append(app, i, lu_list, lu_cnt, lu_cap);

@@ -23,7 +23,8 @@ namespace lbfgsx {
 
 constexpr int kBlock = 256;      // 4 waves of 64
 constexpr int kWaves = kBlock / 64;
-constexpr int kMaxRed = 56;      // max simultaneous reductions per kernel (2c + 1 <= 33 masked dots in one pass; 2 (24 + 1) for the L and U dots of a sweep)
+constexpr int kMaxRed = 64;      // max simultaneous reductions per kernel (2c + 1 <= 33 masked dots in one pass; 2 (24 + 1) for the L and U dots of
+                                 // a sweep; 3 (20 + 1) for the three Gram rows of k_vrows) -- one lane per sum after the halving steps
 
 // ---------------------------------------------------------------- accumulators
 struct DD
@@ -86,6 +87,26 @@ struct D1  // accumulator for f32 data: products of floats are exact in double, 
         hi = t;
     }
     __device__ __forceinline__ double value() const { return hi + lo; }
+};
+
+// N accumulators cleared by an unrolled loop.  A plain `A acc[N]` runs A's constructor from a loop that the optimiser only
+// unrolls for N up to ~50; beyond that the array is indexed by a loop variable and therefore lives in scratch memory.
+template <class A, int N>
+struct Accs
+{
+    union
+    {
+        A v[N];
+    };
+    __device__ __forceinline__ Accs()
+    {
+#pragma unroll
+        for (int k = 0; k < N; k++)
+        {
+            v[k].hi = 0.0;
+            v[k].lo = 0.0;
+        }
+    }
 };
 
 template <class T> struct AccOf;

@@ -1,0 +1,59 @@
+#!/usr/bin/env python
+"""Timeline of a steady cfg4 (L-BFGS-B) iteration from a rocprofv3 kernel trace: per kernel and per gap.
+
+    rocprofv3 --kernel-trace --output-format csv -d DIR -o b -- python scripts/bench_lbfgsb.py --n 1e7 --iters 40
+    python scripts/trace_cfg4.py DIR > summary.txt
+
+Iterations are delimited by k_b_post launches (one per iteration); the last `tail` iterations are averaged.
+"""
+import collections
+import csv
+import glob
+import os
+import re
+import sys
+
+d = sys.argv[1]
+tail = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+f = sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True))[-1]
+rows = []
+with open(f) as fh:
+    for r in csv.DictReader(fh):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+rows.sort()
+
+
+def short(n):
+    n = n.replace("void ", "").replace("lbfgsx::", "")
+    n = re.sub(r"rocprim::ROCPRIM_\d+_NS::detail::", "rocprim::", n)
+    n = n.split("(")[0]
+    return n[:70]
+
+
+posts = [i for i, r in enumerate(rows) if "k_b_post" in r[2]]
+# the warm-up solve comes first: keep the posts of the big run = the last 40
+posts = posts[-40:]
+lo, hi = posts[-tail - 1], posts[-1]
+seg = rows[lo:hi]
+wall = (rows[hi][0] - rows[lo][0]) / tail
+busy = sum(e - s for s, e, _ in seg) / tail
+agg = collections.OrderedDict()
+for s, e, n in seg:
+    k = short(n)
+    a = agg.setdefault(k, [0, 0])
+    a[0] += 1
+    a[1] += e - s
+print("steady iteration (last %d): wall %.3f ms, kernels %.3f ms, idle %.3f ms, launches %.1f"
+      % (tail, wall / 1e6, busy / 1e6, (wall - busy) / 1e6, len(seg) / tail))
+for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    print("%7.3f ms/it  %5.2f calls/it  %8.1f us avg  %s" % (t / tail / 1e6, c / tail, t / c / 1e3, k))
+# one iteration in order, with the idle gap before each kernel
+print("\n--- the last iteration, in order (gap before the kernel, duration) ---")
+s0 = posts[-2]
+prev_end = rows[s0][0]
+for s, e, n in rows[s0:posts[-1]]:
+    print("%8.1f us gap %8.1f us  %s" % ((s - prev_end) / 1e3, (e - s) / 1e3, short(n)))
+    prev_end = e
+# the first iterations: where the from-x0 time goes
+print("\n--- per-iteration wall (ms), all 40 ---")
+print(" ".join("%.2f" % ((rows[posts[i + 1]][0] - rows[posts[i]][0]) / 1e6) for i in range(len(posts) - 1)))
