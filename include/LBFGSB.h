@@ -164,7 +164,7 @@ private:
                 m_bfgs.add_correction_begin(Scalar(syd), Scalar(yyd), m_defer_dots);  // finished inside get_cauchy_point
             m_stats.correction_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_corr).count();
 
-            detail::check(lbfgsx_b_force_bounds(c));                    // (:240)
+            detail::check(lbfgsx_b_force_bounds_deferred(c));           // (:240), evaluated inside the build's pass
             Cauchy<Scalar>::get_cauchy_point(m_bfgs, gcp);              // (:241)
             m_stats.gcp_crossings += gcp.crossings;
             m_stats.gcp_dev_crossings += gcp.dev_crossings;

@@ -207,6 +207,10 @@ enum /* lbfgsx_b_sub_op */
 };
 /* force_bounds: x = x.cwiseMax(lb).cwiseMin(ub)  (LBFGSB.h:55-58,128,240) */
 int lbfgsx_b_force_bounds(lbfgsx_ctx* c);
+/* the same statement where the generalized-Cauchy-point build follows at once (LBFGSB.h:240-241): nothing is launched,
+ * the build's own pass -- which reads x, lb and ub anyway -- clamps on the way (a coordinate already inside its bounds
+ * costs no store).  Any other entry of the bounded path called in between runs the statement first.  Same x, same bits. */
+int lbfgsx_b_force_bounds_deferred(lbfgsx_ctx* c);
 /* fx = f(x,grad); ||P(x-g,l,u)-x||_inf; x.x   (LBFGSB.h:137-138,146) */
 int lbfgsx_b_eval(lbfgsx_ctx* c, int objective, double* fx, double* projgnorm, double* xnorm2);
 /* the two reductions alone, for objectives evaluated by the caller (device / host functors) */

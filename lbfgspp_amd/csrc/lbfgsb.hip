@@ -56,6 +56,7 @@ struct lbfgsb_state
     void* wf_tmp = nullptr;
     size_t wf_tmp_bytes = 0;
     bool wf_use = true;                   // LBFGSX_COMPACT_FREE=0: never
+    bool force_pending = false;           // lbfgsx_b_force_bounds_deferred: x = clamp(x) rides on the next Cauchy build
     int vonly_groups = 0;                 // LBFGSX_VONLY_GROUPS=1: the v-row Gram walks one row per step (A/B of the lane groups)
     bool vrows = true;                    // LBFGSX_VROWS=0: the v-row / selected-entries passes through the LDS tile kernel (k_gram_dd<.., VONLY>)
                                           // instead of the register kernel k_vrows (A/B; same sums)
@@ -165,12 +166,20 @@ static BVecs<T> bvecs(lbfgsx_ctx* c)
     return v;
 }
 
-static int need_bounded(lbfgsx_ctx* c)
+static int run_force_bounds(lbfgsx_ctx* c);
+// keep_force: the caller is the Cauchy build, which evaluates a deferred x = clamp(x) itself (lbfgsx_b_force_bounds_deferred);
+// every other entry of the bounded path runs it first
+static int need_bounded(lbfgsx_ctx* c, bool keep_force = false)
 {
     if (!c->bstate)
     {
         set_error("this context was not created with LBFGSX_FLAG_BOUNDED");
         return LBFGSX_E_LOGIC;
+    }
+    if (c->bstate->force_pending && !keep_force)
+    {
+        c->bstate->force_pending = false;
+        return run_force_bounds(c);
     }
     return LBFGSX_OK;
 }
@@ -648,6 +657,26 @@ int lbfgsx_b_force_bounds(lbfgsx_ctx* c)
     int rc = need_bounded(c);
     if (rc)
         return rc;
+    return run_force_bounds(c);
+}
+
+int lbfgsx_b_force_bounds_deferred(lbfgsx_ctx* c)
+{
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    const char* e = getenv("LBFGSX_FORCE_FUSE");  // =0: A/B, run the statement as its own pass
+    if (e && e[0] == '0')
+        return lbfgsx_b_force_bounds(c);
+    c->bstate->force_pending = true;
+    return LBFGSX_OK;
+}
+}
+
+namespace lbfgsx {
+static int run_force_bounds(lbfgsx_ctx* c)
+{
+    lbfgsx::DeviceGuard dev_guard_(c->device);
     const int grid = c->grid_for(c->n);
     DISPATCH_T(c, {
         LBFGSX_LAUNCH((k_force_bounds<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]), P<T>(c->lb),
@@ -822,16 +851,18 @@ int lbfgsx_b_correction_dots(lbfgsx_ctx* c, double* sdots, double* ydots)
 int lbfgsx_b_cauchy_build(lbfgsx_ctx* c, int64_t* nfree, int64_t* nord, double* dd, double* wtd)
 {
     lbfgsx::DeviceGuard dev_guard_(c->device);
-    int rc = need_bounded(c);
+    int rc = need_bounded(c, true);
     if (rc)
         return rc;
     lbfgsb_state* b = c->bstate;
+    const bool force = b->force_pending;  // a deferred x = clamp(x): evaluated by the build's own pass
+    b->force_pending = false;
     const int grid = c->grid_for(c->n);
     double r[3];
     DISPATCH_T(c, {
         BVecs<T> bv = bvecs<T>(c);
         LBFGSX_LAUNCH((k_cauchy_build<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, P<T>(b->keys_in), b->vals_in, c->n,
-                           c->ws, b->dout);
+                           c->ws, b->dout, force ? P<T>(c->xb[c->cur]) : static_cast<T*>(nullptr));
         LBFGSX_HIP(hipGetLastError());
         rc = fetch_doubles(c, 3, r);
         if (rc)
@@ -915,17 +946,19 @@ int lbfgsx_b_cauchy_build_partial(lbfgsx_ctx* c, double tau, int64_t* nfree, int
                                   double* wtd)
 {
     lbfgsx::DeviceGuard dev_guard_(c->device);
-    int rc = need_bounded(c);
+    int rc = need_bounded(c, true);
     if (rc)
         return rc;
     lbfgsb_state* b = c->bstate;
+    const bool force = b->force_pending;  // a deferred x = clamp(x): evaluated by the build's own pass
+    b->force_pending = false;
     const int grid = c->grid_for(c->n);
     double r[3];
     int64_t ns = 0;
     DISPATCH_T(c, {
         BVecs<T> bv = bvecs<T>(c);
         LBFGSX_LAUNCH((k_cauchy_build<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, P<T>(b->keys_in), b->vals_in, c->n,
-                           c->ws, b->dout);
+                           c->ws, b->dout, force ? P<T>(c->xb[c->cur]) : static_cast<T*>(nullptr));
         LBFGSX_HIP(hipGetLastError());
         rc = fetch_doubles(c, 3, r);
         if (rc)

@@ -1325,9 +1325,11 @@ __global__ void __launch_bounds__(kBlock, (NA == 1 && NC <= 20) ? 2 : 1)
 
 // ---------------------------------------------------------------- Cauchy build (Cauchy.h:111-129,154)
 // brk, vecd, sort keys/values; out[0] = d.d, out[1] = #free (brk = inf), out[2] = #ord (0 < brk < inf)
+// xforce != null: x = x.cwiseMax(lb).cwiseMin(ub) (LBFGSB.h:240, k_force_bounds) evaluated on the way -- this pass reads
+// x, lb and ub anyway; a coordinate inside its bounds (all of them once the iterates are feasible) costs no store.
 template <class T>
 __global__ void __launch_bounds__(kBlock) k_cauchy_build(BVecs<T> b, T* __restrict__ keys, int* __restrict__ vals,
-                                                         int64_t n, RedWs ws, double* __restrict__ out)
+                                                         int64_t n, RedWs ws, double* __restrict__ out, T* __restrict__ xforce)
 {
     typedef typename AccOf<T>::type A;
     A acc[3];
@@ -1335,7 +1337,17 @@ __global__ void __launch_bounds__(kBlock) k_cauchy_build(BVecs<T> b, T* __restri
     const int64_t stride = int64_t(gridDim.x) * kBlock;
     for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
     {
-        const T gi = b.g[i], xi = b.x0[i], lo = b.lb[i], up = b.ub[i];
+        const T gi = b.g[i], lo = b.lb[i], up = b.ub[i];
+        T xi = b.x0[i];
+        if (xforce)
+        {
+            T v = xi;
+            v = (v < lo) ? lo : v;
+            v = (up < v) ? up : v;
+            if (!(v == xi))  // also rewrites a NaN, as the unconditional assignment would
+                xforce[i] = v;
+            xi = v;
+        }
         T t;
         if (lo == up)
             t = T(0);
@@ -1868,7 +1880,8 @@ __global__ void __launch_bounds__(kBlock, NC <= 24 ? 2 : 1) k_solve_sweep(Cols<T
         for (int k = 0; k < NC; k++)
             w[k] = cols.p[k][t];
         const T xa = va_p[i], xb = vb_p[i];
-        const T yold = b.y[i], lbi = b.lb[i], ubi = b.ub[i], x0i = b.x0[i], cfi = b.cF[i];
+        const T yold = FIRST ? T(0) : b.y[i];  // the first solve writes every free row: nothing to keep
+        const T lbi = b.lb[i], ubi = b.ub[i], x0i = b.x0[i], cfi = b.cF[i];
         if (!(st0 & ST_FREE))
             continue;
         const bool solve = FIRST || (st0 & ST_P);
