@@ -454,21 +454,43 @@ def run_north_star(args, rank, world, local, comm_dev, dist):
     ctx = solver.prepare(n)
     if sharded:
         L.check(core.lbfgsx_set_shard(ctx, shard_lo, n_global))
-        red_buf = torch.zeros(512, dtype=torch.float64, device=comm_dev)
+        # The driver's sums cross the shards through the LIBRARY's all-reduce (lbfgsx_comm_*, csrc/rccl_allreduce.hip: one
+        # ncclAllReduce over xGMI per bundle), called from C without a Python frame in between.  The launcher's collective
+        # library only distributes the communicator's id.  (Ranks that share one device -- the protocol test on a
+        # one-GPU box, LBFGSX_BENCH_FORCE_DEVICE -- cannot be RCCL ranks; they fall back to the launcher's all-reduce.)
         n_reduces = [0]
-
-        def allreduce(v):
-            n_reduces[0] += 1
-            if world == 1:
-                return
-            k = v.shape[0]
-            if comm_dev.type == "cuda":   # RCCL: stage the few doubles through a device tensor
-                red_buf[:k].copy_(torch.from_numpy(v))
-                dist.all_reduce(red_buf[:k])
-                v[:] = red_buf[:k].cpu().numpy()
-            else:
+        comm = C.c_void_p()
+        comm_owner = True
+        threads = isinstance(dist, ThreadDist)
+        shared_device = os.environ.get("LBFGSX_BENCH_FORCE_DEVICE") is not None and world > 1
+        if shared_device:
+            def allreduce(v):
+                n_reduces[0] += 1
                 dist.all_reduce(torch.from_numpy(v))  # in place on the callback's memory
-        solver.set_reducer(allreduce)
+            solver.set_reducer(allreduce)
+            comm = None
+        elif threads:
+            # one process drives every device: rank 0 forms the communicator over the device list, the others take it
+            devs = gather_objects(local, rank, world, dist)
+            handle = [None]
+            if rank == 0:
+                arr = (C.c_int * world)(*devs)
+                L.check(core.lbfgsx_comm_create_local(C.byref(comm), arr, world))
+                handle[0] = comm.value
+            handle = gather_objects(handle[0], rank, world, dist)
+            comm = C.c_void_p(handle[0])
+            comm_owner = rank == 0
+            solver.set_native_reducer(comm, rank)
+        else:
+            ident = [None]
+            if rank == 0:
+                buf = C.create_string_buffer(128)
+                L.check(core.lbfgsx_comm_unique_id(buf))
+                ident[0] = buf.raw
+            if world > 1:
+                dist.broadcast_object_list(ident, src=0)
+            L.check(core.lbfgsx_comm_create_rank(C.byref(comm), local, rank, world, ident[0]))
+            solver.set_native_reducer(comm, 0)
     if args.objective == "rosenbrock":
         L.check(core.lbfgsx_gen_rosen_x0(ctx, 7 + (0 if sharded else rank)))
         f = A.ExtendedRosenbrock()
@@ -526,6 +548,17 @@ def run_north_star(args, rank, world, local, comm_dev, dist):
     core.lbfgsx_timing_fused_launches.argtypes = [C.c_void_p]
     fused = int(marks.get("fused", 0))
     nfev, last_niter = solver.last.nfev, niter
+    comm_info = None
+    if sharded and comm is not None:
+        info = (C.c_int * 4)()
+        core.lbfgsx_comm_info(comm, C.byref(info))
+        n_reduces[0] = int(core.lbfgsx_comm_calls(comm, rank if isinstance(dist, ThreadDist) else 0))
+        comm_info = {"transport": "RCCL (ncclAllReduce, f64 sum) inside liblbfgsx.so" if info[2] else "host memory (ranks share a device)",
+                     "ranks": int(info[0]), "rccl_version_code": int(info[3])}
+        if world > 1:
+            dist.barrier()   # every rank is done with the communicator
+        if comm_owner:
+            core.lbfgsx_comm_destroy(comm)
     del solver  # release the device context (the batched leg and the profilers' atexit handlers come next)
     import gc
     gc.collect()
@@ -623,6 +656,7 @@ def run_north_star(args, rank, world, local, comm_dev, dist):
                                          % (n_global, n, world, n_reduces[0], 6 * m + 7))
             out["config"]["n"] = n_global
             out["config"]["rows_per_gpu"] = n
+            out["config"]["allreduce"] = comm_info or {"transport": "the launcher's all-reduce (ranks share one device)"}
         out["roofline"] = {"bound": "hbm", "kernel": ("k_gs_post_mx" if f32h else "k_gs_post") + " (s, y + Gram rows of the new pair and gradient, one pass)",
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                            "traffic": None, "algorithmic_bytes_per_launch": post_bytes, "avg_launch_ms": post_s * 1e3,

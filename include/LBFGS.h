@@ -21,7 +21,11 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <limits>
+#include <stdexcept>
+#include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -53,6 +57,8 @@ class LBFGSSolver
     std::function<void(int, Scalar, DeviceState<Scalar>&)> m_trace;
     std::function<void(int)> m_iter_hook;
     std::function<void(double*, int)> m_reducer;  // extension: see set_reducer()
+    std::vector<int> m_devices;                   // extension: see set_devices()
+    mutable bool m_grad_gathered = false;         // final_grad() already holds the gradient of a row-sharded run
 
     template <typename Foo, typename HostVec>
     int run(Foo& f, Scalar& fx)
@@ -233,6 +239,16 @@ public:
 
     // choose the GPU of this solver (default 0); takes effect at the next minimize()
     void set_device(int device) { m_device = device; }
+    // Extension: ONE problem row-sharded over the listed GPUs of this node, driven from THIS process.
+    // minimize(f, x, fx) with a built-in objective then gives every device a contiguous block of rows (boundaries on
+    // multiples of 4: whole Rosenbrock pairs, whole 16-byte vectors) and its own solver + host thread; the n-length sums
+    // of the driver (the reference's LBFGS.h:92,123,130,161 and the Gram rows of the recursion) cross the devices as
+    // small bundles through lbfgsx_comm_allreduce_sum -- one ncclAllReduce over xGMI each, RCCL loaded on first use --
+    // so every shard takes the same decisions.  Needs the Gram-space recursion (selected if the vector form is set: its
+    // dots are reduced on the device inside one launch and cannot cross devices).  An empty list switches back.
+    // A device may be listed twice (tests on a one-GPU box): the sums are then formed in host memory.
+    void set_devices(std::vector<int> devices) { m_devices = std::move(devices); }
+    const std::vector<int>& devices() const { return m_devices; }
     // parity tracing: called after every objective evaluation with (index, fx, device state)
     void set_trace(std::function<void(int, Scalar, DeviceState<Scalar>&)> cb) { m_trace = std::move(cb); }
     // progress/timing hook: called with k after iteration k has produced the next search direction
@@ -245,6 +261,14 @@ public:
     inline int minimize(Foo& f, Vec& x, Scalar& fx)
     {
         const std::int64_t n = std::int64_t(x.size());
+        m_grad_gathered = false;
+        if constexpr (std::is_same<typename std::decay<Foo>::type, BuiltinObjective<Scalar> >::value)
+        {
+            if (!m_devices.empty())
+                return minimize_sharded(f, x, fx);
+        }
+        else if (!m_devices.empty())
+            throw std::invalid_argument("set_devices: a row-sharded run needs a built-in objective (each shard evaluates its own rows)");
         m_dev.ensure(n, m_param.m, 0, m_device);
         m_dev.upload(LBFGSX_VEC_X, x.data());
         int k = 0;
@@ -266,6 +290,68 @@ public:
         return k;
     }
 
+private:
+    // set_devices(): one solver + host thread per listed device over contiguous row blocks, sums through the communicator
+    template <typename Vec>
+    int minimize_sharded(BuiltinObjective<Scalar>& f, Vec& x, Scalar& fx)
+    {
+        const int G = int(m_devices.size());
+        const std::int64_t n = std::int64_t(x.size());
+        const std::int64_t per = (n / G) / 4 * 4;
+        if (per < 4)
+            throw std::invalid_argument("set_devices: fewer than 4 rows per device");
+        lbfgsx_comm* comm = nullptr;
+        detail::check(lbfgsx_comm_create_local(&comm, m_devices.data(), G));
+        const size_t ng = size_t(G);
+        std::vector<int> niter(ng, 0), nfev(ng, 0);
+        std::vector<Scalar> fxs(ng, Scalar(0)), gns(ng, Scalar(0));
+        std::vector<std::exception_ptr> err(ng);
+        m_grad_host.resize(n);
+        std::vector<std::thread> th;
+        for (int g = 0; g < G; g++)
+            th.emplace_back([&, g]() {
+                try
+                {
+                    const std::int64_t lo = std::int64_t(g) * per, len = (g == G - 1) ? n - lo : per;
+                    LBFGSSolver<Scalar, LineSearch> s(m_param);
+                    s.set_device(m_devices[size_t(g)]);
+                    s.set_recursion(m_recursion == RECURSION_VECTOR ? RECURSION_GRAM_SPACE : m_recursion);
+                    s.set_reducer([comm, g](double* v, int k) {
+                        if (lbfgsx_comm_allreduce_sum(comm, g, v, k) != LBFGSX_OK)
+                            throw std::runtime_error(lbfgsx_last_error());
+                    });
+                    if (m_iter_hook && g == 0)
+                        s.set_iteration_hook(m_iter_hook);
+                    s.prepare_resident(len);
+                    detail::check(lbfgsx_set_shard(s.device_state().ctx(), lo, n));
+                    s.device_state().upload(LBFGSX_VEC_X, x.data() + lo);
+                    BuiltinObjective<Scalar> fl(f.id, f.a ? f.a + lo : nullptr, f.b ? f.b + lo : nullptr);
+                    niter[size_t(g)] = s.template minimize_resident_as<Vec>(fl, len, fxs[size_t(g)]);
+                    nfev[size_t(g)] = s.num_evaluations();
+                    gns[size_t(g)] = s.final_grad_norm();
+                    s.device_state().download(LBFGSX_VEC_X, x.data() + lo);
+                    s.device_state().download(LBFGSX_VEC_G, m_grad_host.data() + lo);
+                }
+                catch (...)
+                {
+                    err[size_t(g)] = std::current_exception();
+                    (void) lbfgsx_comm_abort(comm);  // the other shards must not wait for this one
+                }
+            });
+        for (auto& t : th)
+            t.join();
+        lbfgsx_comm_destroy(comm);
+        for (int g = 0; g < G; g++)
+            if (err[size_t(g)])
+                std::rethrow_exception(err[size_t(g)]);
+        fx = fxs[0];  // every shard holds the reduced value
+        m_gnorm = gns[0];
+        m_nfev = nfev[0];
+        m_grad_gathered = true;
+        return niter[0];
+    }
+
+public:
     // Device-resident variant: x0 already sits in LBFGSX_VEC_X of device_state() (e.g. generated there);
     // the minimiser is left in LBFGSX_VEC_X.  No host copy of any n-vector is made.
     template <typename Foo>
@@ -275,12 +361,21 @@ public:
         return run<Foo, std::vector<Scalar> >(f, fx);
     }
     void prepare_resident(std::int64_t n) { m_dev.ensure(n, m_param.m, 0, m_device); }
+    // the same with the host vector type a user line-search policy of the reference's signature is handed (Interop.h)
+    template <typename HostVec, typename Foo>
+    inline int minimize_resident_as(Foo& f, std::int64_t n, Scalar& fx)
+    {
+        m_dev.ensure(n, m_param.m, 0, m_device);
+        return run<Foo, HostVec>(f, fx);
+    }
 
     // final_grad(): copied back on demand (the reference returns its host member, LBFGS.h:182).  Eigen's vector type
     // when Eigen is on the include path (so .norm(), .transpose() and streaming work as in the reference's examples),
     // std::vector otherwise (LBFGSpp/Interop.h).
     const detail::ResultVector<Scalar>& final_grad() const
     {
+        if (m_grad_gathered)  // a row-sharded run left the shards' gradients here
+            return m_grad_host;
         m_grad_host.resize(m_dev.size());
         m_dev.download(LBFGSX_VEC_G, m_grad_host.data());
         return m_grad_host;

@@ -419,6 +419,33 @@ int lbfgsx_bat_sync(lbfgsx_batch* c);
  * RCCL is loaded with dlopen on first use.  No reference counterpart (the reference solves one problem per call). */
 int lbfgsx_rccl_allgather_records(const int* devices, int ndev, const void* records, int64_t count, int64_t rec_bytes,
                                   void** dev_out);
+/* ---- the sum over the row shards of ONE problem, natively over RCCL --------------------------------
+ * A problem whose rows are spread over several GPUs (lbfgsx_set_shard) needs every n-length sum of the driver -- the
+ * reference's fx, grad.dot(drt), grad.norm(), x.norm(), s.y, y.y (LBFGS.h:92,123,130,161) and the 6m + 7 sums of the
+ * Gram-space pass -- added over the shards before any scalar logic runs.  lbfgsx_comm_allreduce_sum does that for one
+ * rank's small bundle of doubles (<= 512): device buffer, ONE ncclAllReduce(sum, f64) over xGMI on the rank's stream,
+ * result back in `buf`; every rank gets the same bits.  Communicators:
+ *   lbfgsx_comm_create_local  all ranks in THIS process, one host thread per device (ncclCommInitAll).  A device listed
+ *                             twice cannot be two RCCL ranks: the sums are then formed in host memory, in rank order,
+ *                             behind a barrier (the emulation a one-GPU box runs; lbfgsx_comm_info tells which);
+ *   lbfgsx_comm_create_rank   one rank of a multi-process communicator (ncclCommInitRank; the id comes from
+ *                             lbfgsx_comm_unique_id on one rank and travels through the caller's launcher).
+ * Every rank must make the same sequence of calls (as with any collective).  lbfgsx_comm_abort releases ranks that wait
+ * for one that failed.  RCCL is loaded with dlopen on first use.  No reference counterpart. */
+typedef struct lbfgsx_comm lbfgsx_comm;
+int lbfgsx_comm_unique_id(unsigned char id[128]);
+int lbfgsx_comm_create_rank(lbfgsx_comm** out, int device, int rank, int nranks, const unsigned char id[128]);
+int lbfgsx_comm_create_local(lbfgsx_comm** out, const int* devices, int ndev);
+int lbfgsx_comm_allreduce_sum(lbfgsx_comm* comm, int local_rank, double* buf, int count);
+int lbfgsx_comm_abort(lbfgsx_comm* comm);
+/* info = {ranks, ranks driven by this process, 1 when RCCL carries the sums (0: host emulation), RCCL version code} */
+int lbfgsx_comm_info(const lbfgsx_comm* comm, int info[4]);
+int64_t lbfgsx_comm_calls(const lbfgsx_comm* comm, int local_rank);
+/* the all-reduce as the callback LBFGSSolver::set_reducer / lbfgsx_solver_set_allreduce take: pass
+ * lbfgsx_comm_allreduce_hook with user = lbfgsx_comm_hook_arg(comm, local_rank) (owned by the communicator) */
+void* lbfgsx_comm_hook_arg(lbfgsx_comm* comm, int local_rank);
+void lbfgsx_comm_allreduce_hook(double* buf, int count, void* hook_arg);
+void lbfgsx_comm_destroy(lbfgsx_comm* comm);
 int lbfgsx_device_download(int device, const void* dev_ptr, int64_t bytes, void* host);
 void lbfgsx_device_free(int device, void* dev_ptr);
 

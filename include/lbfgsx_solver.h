@@ -77,6 +77,10 @@ int lbfgsx_solver_set_recursion(lbfgsx_solver* s, int form);
 /* LBFGSSolver::set_reducer (extension, row-sharded runs): fn(values, count, user) must sum `values` over all ranks in
  * place (an all-reduce); NULL switches back.  L-BFGS solvers with the Gram-space recursion only. */
 int lbfgsx_solver_set_allreduce(lbfgsx_solver* s, void (*fn)(double*, int, void*), void* user);
+/* LBFGSSolver::set_devices (extension): the next lbfgsx_solver_minimize with a host x row-shards the ONE problem over the
+ * listed GPUs of this node -- one host thread + context per device, the driver's sums through lbfgsx_comm_allreduce_sum
+ * (RCCL; include/lbfgsx.h).  ndev = 0 switches back.  L-BFGS solvers only. */
+int lbfgsx_solver_set_devices(lbfgsx_solver* s, const int* devices, int ndev);
 /* test entry: Cauchy::get_cauchy_point + SubspaceMin::subspace_minimize of the drop-in headers on a history of
  * npairs host-provided corrections; counts = {|newact|, |free|, crossings, BOXCQP sweeps} */
 int lbfgsx_test_cauchy_subspace(int dtype, int64_t n, int m, int npairs, const void* S, const void* Y, const void* x0,

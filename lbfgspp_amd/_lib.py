@@ -129,6 +129,16 @@ def load():
     sig(sol, "lbfgsx_solver_ctx", vp, vp)
     sig(sol, "lbfgsx_solver_set_recursion", i32, vp, i32)
     sig(sol, "lbfgsx_solver_set_allreduce", i32, vp, ALLREDUCE, vp)
+    sig(sol, "lbfgsx_solver_set_devices", i32, vp, C.POINTER(i32), i32)
+    sig(core, "lbfgsx_comm_unique_id", i32, C.c_char_p)
+    sig(core, "lbfgsx_comm_create_rank", i32, C.POINTER(vp), i32, i32, i32, C.c_char_p)
+    sig(core, "lbfgsx_comm_create_local", i32, C.POINTER(vp), C.POINTER(i32), i32)
+    sig(core, "lbfgsx_comm_allreduce_sum", i32, vp, i32, pd, i32)
+    sig(core, "lbfgsx_comm_abort", i32, vp)
+    sig(core, "lbfgsx_comm_info", i32, vp, C.POINTER(i32 * 4))
+    sig(core, "lbfgsx_comm_calls", i64, vp, i32)
+    sig(core, "lbfgsx_comm_hook_arg", vp, vp, i32)
+    sig(core, "lbfgsx_comm_destroy", None, vp)
     sig(core, "lbfgsx_set_shard", i32, vp, i64, i64)
     sig(sol, "lbfgsx_solver_set_iteration_hook", i32, vp, ITER_HOOK, vp)
     sig(sol, "lbfgsx_batch_minimize", i32, i32, i32, i32, C.POINTER(Params), i32, i64, i64, i64, C.c_uint64, i32, i32,

@@ -22,6 +22,7 @@ struct lbfgsx_solver
     virtual int hessians(double*, double*) { return LBFGSX_E_INVALID; }
     virtual int set_recursion(int) { return LBFGSX_E_INVALID; }
     virtual int set_allreduce(void (*)(double*, int, void*), void*) { return LBFGSX_E_INVALID; }
+    virtual int set_devices(const int*, int) { return LBFGSX_E_INVALID; }
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long stats_submin_us = 0;
     long long stats2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -117,6 +118,11 @@ struct LbfgsImpl : lbfgsx_solver
             solver->set_reducer([fn, user](double* v, int k) { fn(v, k, user); });
         else
             solver->set_reducer(nullptr);
+        return LBFGSX_OK;
+    }
+    int set_devices(const int* devs, int ndev) override
+    {
+        solver->set_devices(devs && ndev > 0 ? std::vector<int>(devs, devs + ndev) : std::vector<int>());
         return LBFGSX_OK;
     }
     int hessians(double* B, double* H) override
@@ -519,6 +525,8 @@ int lbfgsx_solver_set_allreduce(lbfgsx_solver* s, void (*fn)(double*, int, void*
 {
     return s->set_allreduce(fn, user);
 }
+
+int lbfgsx_solver_set_devices(lbfgsx_solver* s, const int* devices, int ndev) { return s->set_devices(devices, ndev); }
 
 int lbfgsx_solver_set_iteration_hook(lbfgsx_solver* s, void (*fn)(int, void*), void* user)
 {

@@ -140,6 +140,22 @@ class _SolverBase:
             self._red = L.ALLREDUCE(cb)
         L.check(self._sol.lbfgsx_solver_set_allreduce(self._h, self._red, None), "set_reducer: not an L-BFGS solver")
 
+    def set_devices(self, devices):
+        """Extension: minimize(f, x) row-shards the ONE problem over these GPUs of the node from this process (one host
+        thread + context per device; the driver's sums cross the devices through the library's RCCL all-reduce).
+        [] switches back."""
+        devs = [int(d) for d in (devices or [])]
+        arr = (C.c_int * max(len(devs), 1))(*devs)
+        L.check(self._sol.lbfgsx_solver_set_devices(self._h, arr, len(devs)), "set_devices: not an L-BFGS solver")
+
+    def set_native_reducer(self, comm, local_rank=0):
+        """Extension, row-sharded runs: the reducer is the library's own all-reduce over `comm` (lbfgsx_comm_create_*),
+        called from C without passing through Python."""
+        core, _ = L.load()
+        hook = C.cast(core.lbfgsx_comm_allreduce_hook, L.ALLREDUCE)
+        L.check(self._sol.lbfgsx_solver_set_allreduce(self._h, hook, C.c_void_p(core.lbfgsx_comm_hook_arg(comm, local_rank))),
+                "set_reducer: not an L-BFGS solver")
+
     @property
     def ctx(self):
         return C.c_void_p(self._sol.lbfgsx_solver_ctx(self._h))

@@ -86,6 +86,25 @@ def test_opt_in_modes_are_labelled_as_such():
         assert d["config"]["recursion"].startswith("gram-space") and d["roofline"]["kernel"].startswith("k_gs_post")
     d = _run("--workload", "sharded", "--no-cpu")
     assert d["scaling"] == "strong" and "row-sharded" in d["metric"] and d["config"]["rows_per_gpu"] == 100000000
+    # the sums cross the shards through the library's own RCCL all-reduce (here a communicator of one rank)
+    ar = d["config"]["allreduce"]
+    assert ar["transport"].startswith("RCCL") and ar["ranks"] == 1 and ar["rccl_version_code"] > 20000
+    assert "all-reduces of <=" in d["config"]["workload"] and " 0 all-reduces" not in d["config"]["workload"]
+
+
+def test_sharded_workload_from_one_process_over_a_device_list():
+    """--workload sharded --single-process --gpus 2: ONE problem, two row blocks, two host threads of one process, the
+    sums through lbfgsx_comm_allreduce_sum.  With two GPUs the transport is RCCL; the one-GPU box lists device 0 twice and
+    the communicator adds the bundles in host memory."""
+    sys.path.insert(0, ROOT)
+    import lbfgspp_amd as A
+    ndev = A.load()[0].lbfgsx_device_count()
+    env = {} if ndev >= 2 else {"LBFGSX_BENCH_DEVICES": "0,0"}
+    d = _run("--workload", "sharded", "--single-process", "--no-cpu", "--n", "40000000", gpus=2, env=env)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["n"] == 40000000
+    assert d["config"]["rows_per_gpu"] == 20000000 and d["config"]["allreduce"]["ranks"] == 2
+    assert d["config"]["allreduce"]["transport"].startswith("RCCL" if ndev >= 2 else "host memory")
+    assert [p["rows"] for p in d["per_rank"]] == [20000000, 20000000]
 
 
 def test_history_is_full_whatever_the_warmup():

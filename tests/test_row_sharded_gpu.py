@@ -161,3 +161,122 @@ def test_row_sharding_needs_the_gram_space_recursion(A):
     sb = A.LBFGSBSolver(A.LBFGSBParam(m=5))
     with pytest.raises(ValueError):
         sb.set_reducer(lambda v: None)
+
+
+# ---- the product's own all-reduce (lbfgsx_comm_*, csrc/rccl_allreduce.hip) and LBFGSSolver::set_devices ----------------
+def _comm_local(A, devices):
+    from lbfgspp_amd import _lib as L
+    core, _ = A.load()
+    h = C.c_void_p()
+    arr = (C.c_int * len(devices))(*devices)
+    L.check(core.lbfgsx_comm_create_local(C.byref(h), arr, len(devices)))
+    info = (C.c_int * 4)()
+    L.check(core.lbfgsx_comm_info(h, C.byref(info)))
+    return h, tuple(info)
+
+
+def test_native_allreduce_single_rank_goes_through_rccl(A):
+    """One rank per distinct device: the communicator is RCCL's (ncclCommInitAll), and lbfgsx_comm_allreduce_sum is a real
+    ncclAllReduce even with a single rank -- the bundle comes back unchanged, bit for bit."""
+    from lbfgspp_amd import _lib as L
+    core, _ = A.load()
+    ndev = core.lbfgsx_device_count()
+    comm, info = _comm_local(A, list(range(ndev)))
+    assert info[0] == ndev and info[1] == ndev and info[2] == 1 and info[3] > 20000   # RCCL version code, e.g. 22xxx
+    rng = np.random.default_rng(3)
+    bufs = [rng.standard_normal(67) for _ in range(ndev)]
+    want = np.sum(bufs, axis=0) if ndev > 1 else bufs[0].copy()
+    outs = [b.copy() for b in bufs]
+    th = [threading.Thread(target=lambda r=r: L.check(core.lbfgsx_comm_allreduce_sum(
+        comm, r, outs[r].ctypes.data_as(C.POINTER(C.c_double)), 67))) for r in range(ndev)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for r in range(ndev):
+        assert np.array_equal(outs[r], outs[0])
+        assert np.allclose(outs[r], want, rtol=1e-15, atol=0) if ndev > 1 else np.array_equal(outs[r], want)
+    assert core.lbfgsx_comm_calls(comm, 0) == 1
+    big = np.zeros(513)
+    assert core.lbfgsx_comm_allreduce_sum(comm, 0, big.ctypes.data_as(C.POINTER(C.c_double)), 513) == L.E_INVALID
+    core.lbfgsx_comm_destroy(comm)
+
+
+def test_native_allreduce_thread_emulated_ranks(A):
+    """A device listed three times cannot be three RCCL ranks: the communicator adds the bundles in rank order in host
+    memory behind a barrier; every rank gets the same bits, call after call; an abort releases the waiting ranks."""
+    from lbfgspp_amd import _lib as L
+    core, _ = A.load()
+    comm, info = _comm_local(A, [0, 0, 0])
+    assert info[:3] == (3, 3, 0)
+    rng = np.random.default_rng(4)
+    rounds = [[rng.standard_normal(31) for _ in range(3)] for _ in range(50)]
+    got = [[None] * 50 for _ in range(3)]
+
+    def worker(r):
+        for k in range(50):
+            v = rounds[k][r].copy()
+            L.check(core.lbfgsx_comm_allreduce_sum(comm, r, v.ctypes.data_as(C.POINTER(C.c_double)), 31))
+            got[r][k] = v
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(3)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for k in range(50):
+        want = (rounds[k][0] + rounds[k][1]) + rounds[k][2]       # rank order
+        for r in range(3):
+            assert np.array_equal(got[r][k], want)
+    # a rank that waits alone is released by an abort from outside
+    res = []
+    v = np.zeros(4)
+    t = threading.Thread(target=lambda: res.append(core.lbfgsx_comm_allreduce_sum(comm, 1, v.ctypes.data_as(C.POINTER(C.c_double)), 4)))
+    t.start()
+    import time
+    time.sleep(0.2)
+    core.lbfgsx_comm_abort(comm)
+    t.join(timeout=10)
+    assert not t.is_alive() and res == [L.E_RUNTIME]
+    core.lbfgsx_comm_destroy(comm)
+
+
+@pytest.mark.parametrize("obj,n,devices,m,iters", [("rosen", 40000, [0, 0], 6, 25), ("quad", 30004, [0, 0, 0], 5, 20),
+                                                   ("rosen", 200000, [0], 10, 15)])
+def test_set_devices_row_shards_one_problem_from_one_process(A, oracle, obj, n, devices, m, iters):
+    """LBFGSSolver::set_devices: minimize(f, x) on a host x gives every listed device a row block, its own host thread and
+    solver, and sums the driver's dots through lbfgsx_comm_allreduce_sum.  Compared with
+      * the ORACLE's vector two-loop on the same problem: same iteration and evaluation counts, every iterate within 1e-8
+        over these short runs (the Gram-space recursion equals the vector form only up to rounding, which the trajectory
+        then amplifies: this is the stated window of the opt-in mode, not the 1e-10 of the parity path);
+      * the un-sharded Gram-space run on one device: 1e-9 (a different split of the same sums)."""
+    from lbfgspp_amd import _lib as L
+    ls = O.LS_MT if obj == "rosen" else O.LS_NW
+    a, b = O.quad_problem(n) if obj == "quad" else (None, None)
+    x0 = O.rosen_x0(n, 9) if obj == "rosen" else np.zeros(n)
+    f = A.ExtendedRosenbrock() if obj == "rosen" else A.DiagQuadratic(a, b)
+    par = A.LBFGSParam(m=m, epsilon=0.0, epsilon_rel=0.0, max_iterations=iters)
+    s = A.LBFGSSolver(par, linesearch=ls)
+    s.set_devices(devices)
+    x = x0.copy()
+    niter, fx = s.minimize(f, x)
+    nfev = s.last.nfev
+    s.set_devices([])
+    s.set_recursion(L.RECURSION_GRAM_SPACE)
+    x1 = x0.copy()
+    niter1, fx1 = s.minimize(f, x1)
+    assert (niter, nfev) == (niter1, s.last.nfev)
+    assert np.abs(x - x1).max() <= 1e-9 and abs(fx - fx1) <= 1e-9 * max(1.0, abs(fx1))
+    x_ref, r = oracle.lbfgs(O.F64, ls, O.OBJ_ROSEN if obj == "rosen" else O.OBJ_QUAD, x0,
+                            O.lbfgs_params(m=m, epsilon=0, epsilon_rel=0, max_iterations=iters), a=a, b=b)
+    assert (niter, nfev) == (r.niter, r.nfev)
+    assert np.abs(x - x_ref).max() <= 1e-8 and abs(fx - r.fx) <= 1e-8 * max(1.0, abs(r.fx))
+
+
+def test_set_devices_refuses_what_it_cannot_shard(A):
+    par = A.LBFGSParam(m=4, epsilon=0.0, epsilon_rel=0.0, max_iterations=3)
+    s = A.LBFGSSolver(par, linesearch=O.LS_MT)
+    s.set_devices([0, 0, 0, 0])
+    with pytest.raises(ValueError, match="fewer than 4 rows"):
+        s.minimize(A.ExtendedRosenbrock(), np.zeros(8))
+    s.set_devices([0, 7])
+    with pytest.raises((ValueError, RuntimeError)):
+        s.minimize(A.ExtendedRosenbrock(), np.zeros(64))
+    sb = A.LBFGSBSolver(A.LBFGSBParam(m=4))
+    with pytest.raises(ValueError):
+        sb.set_devices([0, 0])
