@@ -1,14 +1,19 @@
 // include/LBFGSBatched.h -- lock-step batched L-BFGS: P independent problems, one kernel launch per statement
 // for the whole batch (BASELINE.json cfg5).  Host control flow per problem is that of LBFGSSolver::minimize
-// (/root/reference/include/LBFGS.h:78-173) with LineSearchMoreThuente; problems that converge, fail or finish a
-// line search early simply sit out of the following launches.  Per problem the arithmetic is identical to the
-// single-problem path, so results are bit-identical to LBFGSSolver<Scalar, LineSearchMoreThuente>.
+// (/root/reference/include/LBFGS.h:78-173); the line search is the template parameter the reference's solver has
+// (LBFGS.h:20-21) for the two policies that exist as state machines -- LineSearchMoreThuente (default) and
+// LineSearchNocedalWright -- one machine per problem, advanced one trial per launch; problems that converge, fail or
+// finish a line search early simply sit out of the following launches.  The objective is a built-in one evaluated
+// inside the fused kernels (extended Rosenbrock, diagonal quadratic; BatchObjective) or a device functor evaluated by
+// the caller over the whole batch between two library launches (BatchFunctor).  Per problem the arithmetic is identical
+// to the single-problem path, so results are bit-identical to LBFGSSolver<Scalar, LineSearch> on the same problem.
 #ifndef LBFGSX_DROPIN_LBFGS_BATCHED_H
 #define LBFGSX_DROPIN_LBFGS_BATCHED_H
 
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <functional>
 #include <limits>
 #include <exception>
 #include <stdexcept>
@@ -18,11 +23,35 @@
 
 #include "LBFGSpp/Device.h"
 #include "LBFGSpp/LineSearchMoreThuente.h"
+#include "LBFGSpp/LineSearchNocedalWright.h"
 #include "LBFGSpp/Param.h"
 
 namespace LBFGSpp {
 
+// a built-in objective with its data generated on the device, problem id -> seed seed_base + id:
+//   LBFGSX_OBJ_EXT_ROSENBROCK  start points of lbfgsx_gen_rosen_x0
+//   LBFGSX_OBJ_DIAG_QUAD       a, b of lbfgsx_gen_diag_quad(kappa, seed), x0 = 0
+struct BatchObjective
+{
+    int id = LBFGSX_OBJ_EXT_ROSENBROCK;
+    double kappa = 10.0;
+};
+
+// A user objective on device memory, evaluated for the whole batch at once.
+//   start(batch)             writes the start point of every problem p into lbfgsx_bat_vec(batch, 0, 0, p)
+//   eval(batch, point, fx)   for every problem p with point[p] >= 0: reads x = lbfgsx_bat_vec(batch, 0, point[p], p), writes
+//                            grad f(x) to lbfgsx_bat_vec(batch, 1, point[p], p) and f(x) to fx[p] (host); its kernels run
+//                            on lbfgsx_bat_stream(batch) or are complete when it returns
+// The library's launches around it are the statements the single-problem solver runs around a device functor
+// (x = xp + step * drt before, grad . drt after), so a batch member follows the trajectory of a stand-alone solve.
 template <typename Scalar>
+struct BatchFunctor
+{
+    std::function<void(lbfgsx_batch*)> start;
+    std::function<void(lbfgsx_batch*, const int*, Scalar*)> eval;
+};
+
+template <typename Scalar, template <class> class LineSearch = LineSearchMoreThuente>
 class LBFGSBatchedSolver
 {
 public:
@@ -34,7 +63,7 @@ public:
     };
 
 private:
-    typedef typename LineSearchMoreThuente<Scalar>::Machine Machine;
+    typedef typename LineSearch<Scalar>::Machine Machine;
     const LBFGSParam<Scalar>& m_param;
 
     struct Prob
@@ -71,6 +100,27 @@ public:
     // optional x_out: count*n scalars, the final iterates
     void minimize(std::int64_t n, std::uint64_t seed_base, std::int64_t first, int count, int device, std::vector<Item>& out,
                   Scalar* x_out = nullptr)
+    {
+        run(n, seed_base, first, count, device, out, x_out, BatchObjective(), nullptr);
+    }
+    // the same for a built-in objective chosen by the caller
+    void minimize(const BatchObjective& obj, std::int64_t n, std::uint64_t seed_base, std::int64_t first, int count, int device,
+                  std::vector<Item>& out, Scalar* x_out = nullptr)
+    {
+        run(n, seed_base, first, count, device, out, x_out, obj, nullptr);
+    }
+    // ... and for a device functor evaluated by the caller over the whole batch (BatchFunctor)
+    void minimize(const BatchFunctor<Scalar>& f, std::int64_t n, int count, int device, std::vector<Item>& out,
+                  Scalar* x_out = nullptr)
+    {
+        if (!f.start || !f.eval)
+            throw std::invalid_argument("LBFGSBatchedSolver::minimize: the functor needs both start and eval");
+        run(n, 0, 0, count, device, out, x_out, BatchObjective(), &f);
+    }
+
+private:
+    void run(std::int64_t n, std::uint64_t seed_base, std::int64_t first, int count, int device, std::vector<Item>& out,
+             Scalar* x_out, const BatchObjective& bobj, const BatchFunctor<Scalar>* fun)
     {
         using std::abs;
         using std::sqrt;
@@ -212,17 +262,67 @@ public:
                         d.i_den = YS(pc[size_t(i)]);
                     }
                 }
-                detail::check(lbfgsx_bat_launch(c, LBFGSX_BAT_TWOLOOP, LBFGSX_OBJ_EXT_ROSENBROCK, desc.data(), 0, nullptr));
+                detail::check(lbfgsx_bat_launch(c, LBFGSX_BAT_TWOLOOP, bobj.id, desc.data(), 0, nullptr));
             }
             fetch_dg();
         };
 
+        // a user objective: the caller evaluates f and grad of the active problems, the library the sums around it
+        std::vector<int> fpoint(static_cast<size_t>(P));
+        std::vector<Scalar> ffx(static_cast<size_t>(P));
+        std::vector<double> res1(static_cast<size_t>(P) * 2);
+        auto user_eval = [&](bool at_out) {
+            for (int p = 0; p < P; p++)
+                fpoint[size_t(p)] = desc[size_t(p)].active ? (at_out ? desc[size_t(p)].x_out : desc[size_t(p)].x_in) : -1;
+            detail::check(lbfgsx_bat_sync(c));  // the points are written: the functor may use any stream
+            fun->eval(c, fpoint.data(), ffx.data());
+        };
+        // {f, grad.grad, x.x} at x_in of every active problem
+        auto launch_eval = [&]() {
+            if (!fun)
+            {
+                detail::check(lbfgsx_bat_launch(c, LBFGSX_BAT_EVAL, bobj.id, desc.data(), 3, res.data()));
+                return;
+            }
+            user_eval(false);
+            detail::check(lbfgsx_bat_launch(c, LBFGSX_BAT_NORMS, bobj.id, desc.data(), 2, res1.data()));
+            for (int p = 0; p < P; p++)
+            {
+                res[size_t(p) * 3 + 0] = double(ffx[size_t(p)]);
+                res[size_t(p) * 3 + 1] = res1[size_t(p) * 2 + 0];
+                res[size_t(p) * 3 + 2] = res1[size_t(p) * 2 + 1];
+            }
+        };
+        // x_out = x_in + step * drt; {f, grad.drt} there
+        auto launch_trial = [&]() {
+            if (!fun)
+            {
+                detail::check(lbfgsx_bat_launch(c, LBFGSX_BAT_TRIAL, bobj.id, desc.data(), 2, res.data()));
+                return;
+            }
+            detail::check(lbfgsx_bat_launch(c, LBFGSX_BAT_POINT, bobj.id, desc.data(), 0, nullptr));
+            user_eval(true);
+            detail::check(lbfgsx_bat_launch(c, LBFGSX_BAT_GDOT, bobj.id, desc.data(), 1, res1.data()));
+            for (int p = 0; p < P; p++)
+            {
+                res[size_t(p) * 2 + 0] = double(ffx[size_t(p)]);
+                res[size_t(p) * 2 + 1] = res1[size_t(p)];
+            }
+        };
+
         // fx = f(x, grad); gnorm                                                   (LBFGS.h:91-103)
-        detail::check(lbfgsx_bat_gen_rosen_x0(c, seed_base + std::uint64_t(first)));
+        if (fun)
+            fun->start(c);
+        else if (bobj.id == LBFGSX_OBJ_DIAG_QUAD)
+            detail::check(lbfgsx_bat_gen_diag_quad(c, bobj.kappa, seed_base + std::uint64_t(first)));
+        else if (bobj.id == LBFGSX_OBJ_EXT_ROSENBROCK)
+            detail::check(lbfgsx_bat_gen_rosen_x0(c, seed_base + std::uint64_t(first)));
+        else
+            throw std::invalid_argument("LBFGSBatchedSolver::minimize: unknown built-in objective");
         clear_desc();
         for (auto& d : desc)
             d.active = 1;
-        detail::check(lbfgsx_bat_launch(c, LBFGSX_BAT_EVAL, LBFGSX_OBJ_EXT_ROSENBROCK, desc.data(), 3, res.data()));
+        launch_eval();
         int remaining = 0;
         for (int p = 0; p < P; p++)
         {
@@ -281,7 +381,7 @@ public:
                     d.x_out = q.trial;
                     d.step = double(q.mt.step());
                 }
-                detail::check(lbfgsx_bat_launch(c, LBFGSX_BAT_TRIAL, LBFGSX_OBJ_EXT_ROSENBROCK, desc.data(), 2, res.data()));
+                launch_trial();
                 for (int p = 0; p < P; p++)
                 {
                     Prob& q = pr[size_t(p)];
@@ -290,7 +390,19 @@ public:
                     out[size_t(p)].nfev++;
                     const Scalar fx = Scalar(res[size_t(p) * 2 + 0]), dg = Scalar(res[size_t(p) * 2 + 1]);
                     bool keep = false;
-                    const typename Machine::Action a = q.mt.feed(fx, dg, keep);
+                    typename Machine::Action a;
+                    try
+                    {
+                        a = q.mt.feed(fx, dg, keep);
+                    }
+                    catch (const std::runtime_error& e)  // what the single solve's search would throw (Nocedal-Wright)
+                    {
+                        fail(q, out[size_t(p)], LBFGSX_E_RUNTIME, e.what(), k);
+                        q.fx = fx;
+                        searching--;
+                        remaining--;
+                        continue;
+                    }
                     if (keep)
                     {
                         if (q.lo == q.xp)
@@ -337,7 +449,7 @@ public:
                 d.i_den = YS(q.spare);
                 d.i_theta = TH(q.spare);
             }
-            detail::check(lbfgsx_bat_launch(c, LBFGSX_BAT_POST, LBFGSX_OBJ_EXT_ROSENBROCK, desc.data(), 4, res.data()));
+            detail::check(lbfgsx_bat_launch(c, LBFGSX_BAT_POST, bobj.id, desc.data(), 4, res.data()));
             for (int p = 0; p < P; p++)
             {
                 Prob& q = pr[size_t(p)];
@@ -388,6 +500,8 @@ public:
         }
     }
 
+public:
+
     // contiguous, balanced block of `count` problems for shard r of w (remainder to the low shards) -- the partition
     // bench.py / lbfgspp_amd/batched.py:shard_range give one-process-per-GPU ranks
     static void shard_range(std::int64_t count, int r, int w, std::int64_t& first, std::int64_t& len)
@@ -406,6 +520,11 @@ public:
     void minimize(std::int64_t n, std::uint64_t seed_base, std::int64_t first, int count, const std::vector<int>& devices,
                   std::vector<Item>& out, Scalar* x_out = nullptr)
     {
+        minimize(BatchObjective(), n, seed_base, first, count, devices, out, x_out);
+    }
+    void minimize(const BatchObjective& obj, std::int64_t n, std::uint64_t seed_base, std::int64_t first, int count,
+                  const std::vector<int>& devices, std::vector<Item>& out, Scalar* x_out = nullptr)
+    {
         if (devices.empty())
             throw std::invalid_argument("LBFGSBatchedSolver::minimize: empty device list");
         out.assign(size_t(count > 0 ? count : 0), Item());
@@ -422,7 +541,7 @@ public:
                 try
                 {
                     if (len > 0)
-                        minimize(n, seed_base, first + lo, int(len), devices[size_t(r)], part[size_t(r)],
+                        minimize(obj, n, seed_base, first + lo, int(len), devices[size_t(r)], part[size_t(r)],
                                  x_out ? x_out + lo * n : nullptr);
                 }
                 catch (...)

@@ -33,99 +33,161 @@ class LineSearchNocedalWright
     }
 
 public:
-    // ev: detail::Evaluator bound to the device state (xp, drt, grad, x are device-resident).
-    // step/fx/dg are in-out exactly as in the reference signature; step_max is ignored (reference :72-73).
-    template <typename Eval>
-    static void LineSearch(Eval& ev, const LBFGSParam<Scalar>& param, const Scalar& /*step_max*/, Scalar& step,
-                           Scalar& fx, Scalar& dg)
+    // The search as a state machine: one feed() per evaluated trial, no vectors inside.  LineSearch() below drives it for
+    // one problem; LBFGSBatchedSolver advances one machine per problem in lock-step, one trial kernel per round for the
+    // whole batch (same decisions, hence bit-identical iterates).
+    class Machine
     {
-        using std::abs;
-        if (step <= Scalar(0))
-            throw std::invalid_argument("'step' must be positive");
-        if (param.linesearch != LBFGS_LINESEARCH_BACKTRACKING_STRONG_WOLFE)
-            throw std::invalid_argument("'param.linesearch' must be 'LBFGS_LINESEARCH_BACKTRACKING_STRONG_WOLFE' for LineSearchNocedalWright");
-
-        const Scalar f0 = fx, g0 = dg;
-        if (g0 > Scalar(0))
-            throw std::logic_error("the moving direction increases the objective function value");
-        const Scalar armijo = param.ftol * g0, curvature = -param.wolfe * g0;
-
-        Scalar s_lo = Scalar(0), f_lo = f0, g_lo = g0, s_hi = Scalar(0), f_hi = Scalar(0);
-        int trials = 0;
-        const char* const precision_msg = "the line search routine failed, possibly due to insufficient numeric precision";
-
-        // phase 1: expand until the step is bracketed
-        for (;;)
+    public:
+        enum Action
         {
-            ev.trial(step, fx, dg);
-            if (fx - f0 > step * armijo || (Scalar(0) < s_lo && fx >= f_lo))
-            {
-                s_hi = step;
-                f_hi = fx;
-                break;
-            }
-            if (abs(dg) <= curvature)
-            {
-                ev.finish(false);
-                return;
-            }
-            s_hi = s_lo;
-            f_hi = f_lo;
-            s_lo = step;
-            f_lo = fx;
-            g_lo = dg;
-            ev.keep_trial_as_lo();
-            if (dg >= Scalar(0))
-                break;
-            if (++trials >= param.max_linesearch)
-            {
-                ev.finish(true);  // best point so far is the one just saved
-                return;
-            }
-            step *= Scalar(2);
+            TRIAL,       // evaluate step() next
+            DONE_TRIAL,  // finished: the accepted point is the last trial
+            DONE_LO      // finished (trials exhausted): the accepted point is the saved _lo point
+        };
+
+    private:
+        Scalar m_step = 0, m_f0 = 0, m_armijo = 0, m_curvature = 0;
+        Scalar m_slo = 0, m_flo = 0, m_glo = 0, m_shi = 0, m_fhi = 0;
+        Scalar m_fx = 0, m_dg = 0;
+        int m_trials = 0, m_max = 0;
+        bool m_zoom = false;
+        static const char* precision_msg() { return "the line search routine failed, possibly due to insufficient numeric precision"; }
+
+    public:
+        Scalar step() const { return m_step; }
+        Scalar fx() const { return m_fx; }
+        Scalar dg() const { return m_dg; }
+
+        template <typename SolverParam>
+        void start(const SolverParam& param, Scalar /*step_max: ignored, reference :72-73*/, Scalar step, Scalar fx, Scalar dg)
+        {
+            if (step <= Scalar(0))
+                throw std::invalid_argument("'step' must be positive");
+            if (param.linesearch != LBFGS_LINESEARCH_BACKTRACKING_STRONG_WOLFE)
+                throw std::invalid_argument("'param.linesearch' must be 'LBFGS_LINESEARCH_BACKTRACKING_STRONG_WOLFE' for LineSearchNocedalWright");
+            if (dg > Scalar(0))
+                throw std::logic_error("the moving direction increases the objective function value");
+            m_step = step;
+            m_f0 = fx;
+            m_armijo = param.ftol * dg;
+            m_curvature = -param.wolfe * dg;
+            m_slo = Scalar(0);
+            m_flo = fx;
+            m_glo = dg;
+            m_shi = m_fhi = Scalar(0);
+            m_trials = 0;
+            m_max = param.max_linesearch;
+            m_zoom = false;
         }
 
-        // phase 2: zoom
-        for (;;)
+        // fx, dg: objective and directional derivative at step().  keep_lo is set when the point just evaluated must be
+        // saved as the new _lo point (x_lo.swap(x); grad_lo.swap(grad), reference :172-173, :254-255).  Throws what the
+        // reference's search throws (:227, :247, :267).
+        Action feed(Scalar fx, Scalar dg, bool& keep_lo)
         {
-            step = interpolate(s_lo, s_hi, f_lo, f_hi, g_lo);
-            ev.trial(step, fx, dg);
-            if (fx - f0 > step * armijo || fx >= f_lo)
+            using std::abs;
+            keep_lo = false;
+            m_fx = fx;
+            m_dg = dg;
+            if (!m_zoom)
             {
-                if (step == s_hi)
-                    throw std::runtime_error(precision_msg);
-                s_hi = step;
-                f_hi = fx;
+                // phase 1: expand until the step is bracketed
+                if (fx - m_f0 > m_step * m_armijo || (Scalar(0) < m_slo && fx >= m_flo))
+                {
+                    m_shi = m_step;
+                    m_fhi = fx;
+                    m_zoom = true;
+                }
+                else
+                {
+                    if (abs(dg) <= m_curvature)
+                        return DONE_TRIAL;
+                    m_shi = m_slo;
+                    m_fhi = m_flo;
+                    m_slo = m_step;
+                    m_flo = fx;
+                    m_glo = dg;
+                    keep_lo = true;
+                    if (dg >= Scalar(0))
+                        m_zoom = true;
+                    else
+                    {
+                        if (++m_trials >= m_max)
+                            return DONE_LO;  // best point so far is the one just saved
+                        m_step *= Scalar(2);
+                        return TRIAL;
+                    }
+                }
+                m_step = interpolate(m_slo, m_shi, m_flo, m_fhi, m_glo);
+                return TRIAL;
+            }
+            // phase 2: zoom
+            if (fx - m_f0 > m_step * m_armijo || fx >= m_flo)
+            {
+                if (m_step == m_shi)
+                    throw std::runtime_error(precision_msg());
+                m_shi = m_step;
+                m_fhi = fx;
             }
             else
             {
-                if (abs(dg) <= curvature)
+                if (abs(dg) <= m_curvature)
+                    return DONE_TRIAL;
+                if (dg * (m_shi - m_slo) >= Scalar(0))
                 {
-                    ev.finish(false);
-                    return;
+                    m_shi = m_slo;
+                    m_fhi = m_flo;
                 }
-                if (dg * (s_hi - s_lo) >= Scalar(0))
-                {
-                    s_hi = s_lo;
-                    f_hi = f_lo;
-                }
-                if (step == s_lo)
-                    throw std::runtime_error(precision_msg);
-                s_lo = step;
-                f_lo = fx;
-                g_lo = dg;
-                ev.keep_trial_as_lo();
+                if (m_step == m_slo)
+                    throw std::runtime_error(precision_msg());
+                m_slo = m_step;
+                m_flo = fx;
+                m_glo = dg;
+                keep_lo = true;
             }
-            if (++trials >= param.max_linesearch)
+            if (++m_trials >= m_max)
             {
-                if (s_lo <= Scalar(0))
+                if (m_slo <= Scalar(0))
                     throw std::runtime_error("the line search routine failed, unable to sufficiently decrease the function value");
-                step = s_lo;
-                fx = f_lo;
-                dg = g_lo;
-                ev.finish(true);
-                return;
+                m_step = m_slo;
+                m_fx = m_flo;
+                m_dg = m_glo;
+                return DONE_LO;
             }
+            m_step = interpolate(m_slo, m_shi, m_flo, m_fhi, m_glo);
+            return TRIAL;
+        }
+    };
+
+    // ev: detail::Evaluator bound to the device state (xp, drt, grad, x are device-resident).
+    // step/fx/dg are in-out exactly as in the reference signature; step_max is ignored (reference :72-73).
+    template <typename Eval>
+    static void LineSearch(Eval& ev, const LBFGSParam<Scalar>& param, const Scalar& step_max, Scalar& step,
+                           Scalar& fx, Scalar& dg)
+    {
+        Machine mc;
+        mc.start(param, step_max, step, fx, dg);
+        for (;;)
+        {
+            step = mc.step();
+            ev.trial(step, fx, dg);
+            bool keep = false;
+            const typename Machine::Action a = mc.feed(fx, dg, keep);
+            if (keep)
+                ev.keep_trial_as_lo();
+            if (a == Machine::TRIAL)
+                continue;
+            if (a == Machine::DONE_TRIAL)
+                ev.finish(false);
+            else
+            {
+                step = mc.step();
+                fx = mc.fx();
+                dg = mc.dg();
+                ev.finish(true);
+            }
+            return;
         }
     }
 };

@@ -379,7 +379,14 @@ typedef struct
     float pad;
     double step;  /* trial step, or the scale a of the two-loop INIT */
 } lbfgsx_bat_desc;
-enum { LBFGSX_BAT_EVAL = 0, LBFGSX_BAT_TRIAL = 1, LBFGSX_BAT_POST = 2, LBFGSX_BAT_TWOLOOP = 3 };
+enum
+{
+    LBFGSX_BAT_EVAL = 0, LBFGSX_BAT_TRIAL = 1, LBFGSX_BAT_POST = 2, LBFGSX_BAT_TWOLOOP = 3,
+    /* a user objective evaluated by the caller over the whole batch: the trial point alone (x_out = x_in + step * drt),
+     * then -- after the caller's kernels have written f and grad of every active problem -- grad(x_out) . drt, or, after
+     * the first evaluation, grad . grad and x . x at x_in */
+    LBFGSX_BAT_POINT = 4, LBFGSX_BAT_GDOT = 5, LBFGSX_BAT_NORMS = 6
+};
 /* per-problem description of a whole apply_Hv (BFGSMat.h:276-302): d = -H grad(x_in), with the history columns
  * pcol[0..ncorr) newest -> oldest (physical column ids) */
 typedef struct
@@ -395,6 +402,14 @@ void lbfgsx_bat_destroy(lbfgsx_batch* c);
 int lbfgsx_bat_scalar_index(const lbfgsx_batch* c, int kind, int k);
 /* x0 of problem p (point 0) = extended-Rosenbrock start for seed seed0 + p */
 int lbfgsx_bat_gen_rosen_x0(lbfgsx_batch* c, uint64_t seed0);
+/* the diagonal quadratics of seeds seed0 + p (a, b as lbfgsx_gen_diag_quad makes them for one problem) and x0 = 0 */
+int lbfgsx_bat_gen_diag_quad(lbfgsx_batch* c, double kappa, uint64_t seed0);
+/* device pointers into the batch for code that evaluates its own objective: kind 0 = x, 1 = grad of `point` (0..2) of
+ * `problem`, 2 = its search direction; consecutive problems of one point lie lbfgsx_bat_ld() elements apart.  The
+ * caller's kernels must be ordered after the library's on lbfgsx_bat_stream() (launch there, or synchronise). */
+void* lbfgsx_bat_vec(lbfgsx_batch* c, int kind, int point, int problem);
+int64_t lbfgsx_bat_ld(const lbfgsx_batch* c);
+void* lbfgsx_bat_stream(lbfgsx_batch* c);
 /* one launch for the whole batch; desc = P descriptors; then out[p*nout + k] = scalar (desc[p].i_out + k) */
 int lbfgsx_bat_launch(lbfgsx_batch* c, int kind, int objective, const lbfgsx_bat_desc* desc, int nout, double* out);
 /* The whole two-loop recursion of every active problem in ONE launch: one 256-thread block per problem keeps its q

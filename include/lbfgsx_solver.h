@@ -118,7 +118,8 @@ int lbfgsx_batch_minimize(int algo, int dtype, int linesearch, const lbfgsx_para
                           int64_t first, int64_t count, uint64_t seed_base, int device, int nthreads,
                           lbfgsx_batch_item* out);
 /* lock-step variant (include/LBFGSBatched.h): all `count` problems resident at once and advanced together, one
- * kernel launch per statement for the whole batch; L-BFGS + LineSearchMoreThuente + extended Rosenbrock.
+ * kernel launch per statement for the whole batch; L-BFGS + LineSearchMoreThuente + extended Rosenbrock (the general
+ * form below takes the line search and the objective).
  * x_out (optional): count*n scalars receiving the final iterates. */
 int lbfgsx_batch_minimize_lockstep(int dtype, const lbfgsx_params* p, int64_t n, int64_t first, int count,
                                    uint64_t seed_base, int device, lbfgsx_batch_item* out, void* x_out, char* errbuf,
@@ -130,6 +131,15 @@ int lbfgsx_batch_minimize_lockstep(int dtype, const lbfgsx_params* p, int64_t n,
 int lbfgsx_batch_minimize_lockstep_multi(int dtype, const lbfgsx_params* p, int64_t n, int64_t first, int count,
                                          uint64_t seed_base, const int* devices, int ndev, lbfgsx_batch_item* out,
                                          void* x_out, char* errbuf, int errlen);
+/* The general form: the line search the reference's solver takes as its template parameter (LBFGS.h:20-21) -- the two
+ * policies that exist as state machines, LBFGSX_LS_MORE_THUENTE and LBFGSX_LS_NOCEDAL_WRIGHT -- and the built-in
+ * objective: LBFGSX_OBJ_EXT_ROSENBROCK (start points of seed seed_base + id) or LBFGSX_OBJ_DIAG_QUAD (a, b of
+ * lbfgsx_gen_diag_quad(kappa, seed_base + id), x0 = 0).  Every problem follows the trajectory of the single-problem solver
+ * with that policy, bit for bit.  (A user objective on device memory: LBFGSBatchedSolver::minimize(BatchFunctor, ...) in
+ * include/LBFGSBatched.h, over lbfgsx_bat_launch(LBFGSX_BAT_POINT / _GDOT / _NORMS).) */
+int lbfgsx_batch_minimize_lockstep_ex(int dtype, int linesearch, int objective, double kappa, const lbfgsx_params* p, int64_t n,
+                                      int64_t first, int count, uint64_t seed_base, const int* devices, int ndev,
+                                      lbfgsx_batch_item* out, void* x_out, char* errbuf, int errlen);
 
 #ifdef __cplusplus
 }

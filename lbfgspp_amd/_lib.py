@@ -147,6 +147,8 @@ def load():
         C.POINTER(BatchItem), vp, C.c_char_p, i32)
     sig(sol, "lbfgsx_batch_minimize_lockstep_multi", i32, i32, C.POINTER(Params), i64, i64, i32, C.c_uint64,
         C.POINTER(i32), i32, C.POINTER(BatchItem), vp, C.c_char_p, i32)
+    sig(sol, "lbfgsx_batch_minimize_lockstep_ex", i32, i32, i32, i32, dbl, C.POINTER(Params), i64, i64, i32, C.c_uint64,
+        C.POINTER(i32), i32, C.POINTER(BatchItem), vp, C.c_char_p, i32)
     sig(sol, "lbfgsx_solver_hessians", i32, vp, vp, vp)
     sig(sol, "lbfgsx_solver_stats", i32, vp, C.POINTER(C.c_longlong * 8))
     sig(sol, "lbfgsx_solver_stats2", i32, vp, C.POINTER(C.c_longlong * 8))

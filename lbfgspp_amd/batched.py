@@ -41,24 +41,25 @@ def solve_local(param, objective, n, first, count, seed_base=1000, algo=L.ALGO_L
     return out
 
 
-def solve_local_lockstep(param, n, first, count, seed_base=1000, dtype=np.float32, device=0, return_x=False, devices=None):
-    """Lock-step batch on one GPU: all `count` problems resident, one launch per statement for the whole batch
-    (L-BFGS, LineSearchMoreThuente, extended Rosenbrock).  Returns RECORD array [, final iterates (count, n)].
-    devices = [d0, d1, ...]: the single-process multi-GPU form (lbfgsx_batch_minimize_lockstep_multi): contiguous blocks
-    of problem ids, one per listed device, each driven by its own host thread."""
+def solve_local_lockstep(param, n, first, count, seed_base=1000, dtype=np.float32, device=0, return_x=False, devices=None,
+                         linesearch=L.LS_MORE_THUENTE, objective=L.OBJ_EXT_ROSENBROCK, kappa=10.0):
+    """Lock-step batch on one GPU: all `count` problems resident, one launch per statement for the whole batch.
+    L-BFGS with LineSearchMoreThuente (default) or LineSearchNocedalWright; built-in objective: extended Rosenbrock
+    (default) or the diagonal quadratic of condition number `kappa`, problem id -> data of seed seed_base + id.
+    Returns RECORD array [, final iterates (count, n)].
+    devices = [d0, d1, ...]: the single-process multi-GPU form: contiguous blocks of problem ids, one per listed device,
+    each driven by its own host thread."""
     _, sol = L.load()
     items = (L.BatchItem * max(count, 1))()
     cp = param._c()
     dt = L.F64 if np.dtype(dtype) == np.float64 else L.F32
     xs = np.empty((count, n), dtype=dtype) if return_x else None
     err = C.create_string_buffer(256)
-    if devices is not None:
-        dv = (C.c_int * len(devices))(*[int(d) for d in devices])
-        rc = sol.lbfgsx_batch_minimize_lockstep_multi(dt, C.byref(cp), n, first, count, seed_base, dv, len(devices), items,
-                                                      xs.ctypes.data_as(C.c_void_p) if return_x else None, err, 256)
-    else:
-        rc = sol.lbfgsx_batch_minimize_lockstep(dt, C.byref(cp), n, first, count, seed_base, device, items,
-                                                xs.ctypes.data_as(C.c_void_p) if return_x else None, err, 256)
+    devs = [int(d) for d in devices] if devices is not None else [int(device)]
+    dv = (C.c_int * max(len(devs), 1))(*devs)
+    rc = sol.lbfgsx_batch_minimize_lockstep_ex(dt, int(linesearch), int(objective), float(kappa), C.byref(cp), n, first, count,
+                                               seed_base, dv, len(devs), items,
+                                               xs.ctypes.data_as(C.c_void_p) if return_x else None, err, 256)
     L.check(rc, err.value.decode())
     out = np.zeros(count, dtype=RECORD)
     for k in range(count):

@@ -156,9 +156,98 @@ __global__ void __launch_bounds__(kBlock) kb_gen_rosen(BatBufs<T> b, int64_t n, 
     }
 }
 
+// The objective of problem p.  The extended Rosenbrock function has no data; the diagonal quadratic reads the rows of
+// problem p of the batch's a, b arrays ([P][ld], lbfgsx_bat_gen_diag_quad).  Per problem these are the single-problem
+// objects of lbfgs_kernels.cuh: the arithmetic of a batch member IS that of a stand-alone solve.
+template <class T>
+struct BatRosen
+{
+    __device__ __forceinline__ ObjRosen<T> bind(int) const { return ObjRosen<T>{}; }
+};
+template <class T>
+struct BatQuad
+{
+    const T* A;
+    const T* B;
+    int64_t ld;
+    __device__ __forceinline__ ObjQuad<T> bind(int p) const { return ObjQuad<T>{A + int64_t(p) * ld, B + int64_t(p) * ld}; }
+};
+
+// a, b of problem p = the diagonal quadratic of seed (seed0 + p) (lbfgsx_gen_diag_quad); x0 = 0
+template <class T>
+__global__ void __launch_bounds__(kBlock) kb_gen_quad(BatBufs<T> b, T* __restrict__ A, T* __restrict__ B, int64_t n, double kappa,
+                                                      uint64_t seed0)
+{
+    const int p = blockIdx.y;
+    T* a = A + int64_t(p) * b.ld;
+    T* bb = B + int64_t(p) * b.ld;
+    T* x = b.x(0, p);
+    const uint64_t seed = seed0 + uint64_t(p);
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
+    {
+        const double ai = (n > 1) ? 1.0 + (kappa - 1.0) * (double(i) / double(n - 1)) : 1.0;
+        const double u = double(b_splitmix64(uint64_t(i) + seed * 0x9E3779B97F4A7C15ull) >> 11) * (1.0 / 9007199254740992.0);
+        a[i] = T(ai);
+        bb[i] = T(ai * (4.0 * u - 2.0));
+        x[i] = T(0);
+    }
+}
+
+// ---- a user objective evaluated by the CALLER over the whole batch (LBFGSBatchedSolver::minimize with a functor) ----
+// The fused kernels above evaluate a built-in objective inside the pass; with a device functor the three statements of
+// a trial are separate: kb_point (x = xp + step * drt), the caller's kernels (f and grad of every active problem at that
+// point), kb_gdot (grad . drt; with norms: grad . grad and x . x instead, the statements after the first evaluation).
+template <class T>
+__global__ void __launch_bounds__(kBlock) kb_point(BatBufs<T> b, const BatDesc* __restrict__ desc, int64_t n)
+{
+    const int p = blockIdx.y;
+    const BatDesc de = desc[p];
+    if (!de.active)
+        return;
+    const T* xp = b.x(de.x_in, p);
+    const T* d = b.d(p);
+    T* x = b.x(de.x_out, p);
+    const T step = T(de.step);
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
+        x[i] = xp[i] + step * d[i];
+}
+// out (per problem, at sc[i_out..]): NORMS = 0: g(x_out) . d ; NORMS = 1: g.g, x.x at x_in
+template <class T, int NORMS>
+__global__ void __launch_bounds__(kBlock) kb_gdot(BatBufs<T> b, const BatDesc* __restrict__ desc, int64_t n, BatWs ws)
+{
+    const int p = blockIdx.y;
+    const BatDesc de = desc[p];
+    if (!de.active)
+        return;
+    typedef typename AccOf<T>::type A;
+    const T* g = b.g(NORMS ? de.x_in : de.x_out, p);
+    const T* w = NORMS ? b.x(de.x_in, p) : b.d(p);
+    A acc[2];
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
+    {
+        if (NORMS)
+        {
+            acc[0].add_prod(g[i], g[i]);
+            acc[1].add_prod(w[i], w[i]);
+        }
+        else
+            acc[0].add_prod(g[i], w[i]);
+    }
+    if (bat_reduce<2>(acc, ws) && threadIdx.x == 0)
+    {
+        T* o = b.scal(p) + de.i_out;
+        o[0] = T(acc[0].value());
+        if (NORMS)
+            o[1] = T(acc[1].value());
+    }
+}
+
 // out (per problem, at sc[i_out..]): f(x), g.g, x.x at point x_in
 template <class T, class OBJ>
-__global__ void __launch_bounds__(kBlock) kb_eval(BatBufs<T> b, const BatDesc* __restrict__ desc, int64_t n, OBJ obj, BatWs ws)
+__global__ void __launch_bounds__(kBlock) kb_eval(BatBufs<T> b, const BatDesc* __restrict__ desc, int64_t n, OBJ objs, BatWs ws)
 {
     const int p = blockIdx.y;
     const BatDesc de = desc[p];
@@ -168,6 +257,7 @@ __global__ void __launch_bounds__(kBlock) kb_eval(BatBufs<T> b, const BatDesc* _
     constexpr int W = Vec16<T>::W;
     const T* x = b.x(de.x_in, p);
     T* g = b.g(de.x_in, p);
+    const auto obj = objs.bind(p);
     A acc[3];
     const int64_t nv = n / W, stride = int64_t(gridDim.x) * kBlock;
     for (int64_t vi = int64_t(blockIdx.x) * kBlock + threadIdx.x; vi < nv; vi += stride)
@@ -201,7 +291,7 @@ __global__ void __launch_bounds__(kBlock) kb_eval(BatBufs<T> b, const BatDesc* _
 
 // x_out = x_in + step*d ; g_out = grad f ; out = {f, g.d}
 template <class T, class OBJ>
-__global__ void __launch_bounds__(kBlock) kb_trial(BatBufs<T> b, const BatDesc* __restrict__ desc, int64_t n, OBJ obj, BatWs ws)
+__global__ void __launch_bounds__(kBlock) kb_trial(BatBufs<T> b, const BatDesc* __restrict__ desc, int64_t n, OBJ objs, BatWs ws)
 {
     const int p = blockIdx.y;
     const BatDesc de = desc[p];
@@ -214,6 +304,7 @@ __global__ void __launch_bounds__(kBlock) kb_trial(BatBufs<T> b, const BatDesc* 
     T* x = b.x(de.x_out, p);
     T* g = b.g(de.x_out, p);
     const T step = T(de.step);
+    const auto obj = objs.bind(p);
     A acc[2];
     const int64_t nv = n / W;
     // tiles of U x kBlock vectors: with one block per problem a thread walks ~100 vectors, so the loads of U of them
@@ -526,6 +617,7 @@ struct lbfgsx_batch
     int64_t n = 0, ld = 0;
     hipStream_t stream = nullptr;
     void *X = nullptr, *G = nullptr, *D = nullptr, *S = nullptr, *Y = nullptr, *sc = nullptr;
+    void *QA = nullptr, *QB = nullptr;  // a, b of the diagonal quadratics, [P][ld] each (lbfgsx_bat_gen_diag_quad)
     BatWs ws;
     BatDesc* desc_dev = nullptr;
     void* hout = nullptr;  // pinned staging for the scalar table
@@ -640,7 +732,7 @@ void lbfgsx_bat_destroy(lbfgsx_batch* c)
     lbfgsx::DeviceGuard dev_guard_(c->device);
     (void) lbfgsx::stream_sync(c->stream);
     live_add(c->device, -1);
-    void* ptrs[] = {c->X, c->G, c->D, c->S, c->Y, c->sc, c->ws.partials, c->ws.ticket, c->desc_dev, c->hvdesc_dev};
+    void* ptrs[] = {c->X, c->G, c->D, c->S, c->Y, c->sc, c->QA, c->QB, c->ws.partials, c->ws.ticket, c->desc_dev, c->hvdesc_dev};
     if (c->hvdesc_host)
         (void) hipHostFree(c->hvdesc_host);
     for (void* p : ptrs)
@@ -671,7 +763,38 @@ int lbfgsx_bat_gen_rosen_x0(lbfgsx_batch* c, uint64_t seed0)
     return LBFGSX_OK;
 }
 
-// kind: 0 eval, 1 trial, 2 post, 3 two-loop step.  `desc` = host array of P descriptors (uploaded here).
+int lbfgsx_bat_gen_diag_quad(lbfgsx_batch* c, double kappa, uint64_t seed0)
+{
+    lbfgsx::DeviceGuard dev_guard_(c->device);
+    const size_t vb = size_t(c->ld) * c->esz * size_t(c->P);
+    if (!c->QA)
+    {
+        LBFGSX_HIP(hipMalloc(&c->QA, vb));
+        LBFGSX_HIP(hipMalloc(&c->QB, vb));
+    }
+    const dim3 grid(unsigned(std::max(c->gx, 8)), unsigned(c->P));
+    BAT_DISPATCH(c, {
+        LBFGSX_LAUNCH((kb_gen_quad<T>), grid, dim3(kBlock), 0, c->stream, bufs<T>(c), static_cast<T*>(c->QA), static_cast<T*>(c->QB),
+                      c->n, kappa, seed0);
+    });
+    LBFGSX_HIP(hipGetLastError());
+    return LBFGSX_OK;
+}
+
+void* lbfgsx_bat_vec(lbfgsx_batch* c, int kind, int point, int problem)
+{
+    if (!c || problem < 0 || problem >= c->P || point < 0 || point > 2)
+        return nullptr;
+    char* base = static_cast<char*>(kind == 0 ? c->X : kind == 1 ? c->G : c->D);
+    const int64_t row = (kind == 2) ? int64_t(problem) : int64_t(point) * c->P + problem;
+    return base + size_t(row) * size_t(c->ld) * c->esz;
+}
+
+int64_t lbfgsx_bat_ld(const lbfgsx_batch* c) { return c ? c->ld : 0; }
+void* lbfgsx_bat_stream(lbfgsx_batch* c) { return c ? static_cast<void*>(c->stream) : nullptr; }
+
+// kind: 0 eval, 1 trial, 2 post, 3 two-loop step, 4 trial point only, 5 grad . drt, 6 grad . grad and x . x.
+// `desc` = host array of P descriptors (uploaded here).
 // After the launch `nout` scalars starting at each problem's desc.i_out are copied back into out[p*nout + k].
 int lbfgsx_bat_launch(lbfgsx_batch* c, int kind, int objective, const lbfgsx_bat_desc* desc, int nout, double* out)
 {
@@ -680,17 +803,40 @@ int lbfgsx_bat_launch(lbfgsx_batch* c, int kind, int objective, const lbfgsx_bat
     std::memcpy(c->hdesc, desc, sizeof(BatDesc) * size_t(c->P));
     LBFGSX_HIP(lbfgsx::copy_async(c->desc_dev, c->hdesc, sizeof(BatDesc) * size_t(c->P), hipMemcpyHostToDevice, c->stream));
     const dim3 grid(unsigned(c->gx), unsigned(c->P));
-    if (kind != 3 && kind != 2 && objective != LBFGSX_OBJ_EXT_ROSENBROCK)
+    const bool fused_obj = (kind == 0 || kind == 1);
+    if (fused_obj && objective != LBFGSX_OBJ_EXT_ROSENBROCK && objective != LBFGSX_OBJ_DIAG_QUAD)
     {
-        set_error("lbfgsx_bat_launch: the lock-step batch supports the extended Rosenbrock objective");
+        set_error("lbfgsx_bat_launch: the fused launches evaluate the extended Rosenbrock function or the diagonal quadratic; "
+                  "any other objective is evaluated by the caller between LBFGSX_BAT_POINT and LBFGSX_BAT_GDOT");
+        return LBFGSX_E_INVALID;
+    }
+    if (fused_obj && objective == LBFGSX_OBJ_DIAG_QUAD && !c->QA)
+    {
+        set_error("lbfgsx_bat_launch: the diagonal quadratic needs its data (lbfgsx_bat_gen_diag_quad)");
+        return LBFGSX_E_LOGIC;
+    }
+    if (kind < 0 || kind > 6)
+    {
+        set_error("lbfgsx_bat_launch: unknown kind");
         return LBFGSX_E_INVALID;
     }
     BAT_DISPATCH(c, {
         BatBufs<T> b = bufs<T>(c);
+        const BatQuad<T> quad = {static_cast<const T*>(c->QA), static_cast<const T*>(c->QB), c->ld};
+        const bool q = objective == LBFGSX_OBJ_DIAG_QUAD;
         switch (kind)
         {
-        case 0: LBFGSX_LAUNCH((kb_eval<T, ObjRosen<T> >), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n, ObjRosen<T>{}, c->ws); break;
-        case 1: LBFGSX_LAUNCH((kb_trial<T, ObjRosen<T> >), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n, ObjRosen<T>{}, c->ws); break;
+        case 0:
+            if (q) LBFGSX_LAUNCH((kb_eval<T, BatQuad<T> >), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n, quad, c->ws);
+            else LBFGSX_LAUNCH((kb_eval<T, BatRosen<T> >), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n, BatRosen<T>{}, c->ws);
+            break;
+        case 1:
+            if (q) LBFGSX_LAUNCH((kb_trial<T, BatQuad<T> >), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n, quad, c->ws);
+            else LBFGSX_LAUNCH((kb_trial<T, BatRosen<T> >), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n, BatRosen<T>{}, c->ws);
+            break;
+        case 4: LBFGSX_LAUNCH((kb_point<T>), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n); break;
+        case 5: LBFGSX_LAUNCH((kb_gdot<T, 0>), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n, c->ws); break;
+        case 6: LBFGSX_LAUNCH((kb_gdot<T, 1>), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n, c->ws); break;
         case 2: LBFGSX_LAUNCH((kb_post<T>), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n, c->ws); break;
         default: LBFGSX_LAUNCH((kb_twoloop<T>), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n, c->ws,
                                     (c->zigzag && (c->tl_step++ & 1u)) ? 1 : 0); break;

@@ -444,44 +444,73 @@ int lbfgsx_batch_minimize(int algo, int dtype, int linesearch, const lbfgsx_para
     return fatal.load();
 }
 
-// lock-step batch (include/LBFGSBatched.h): L-BFGS + More-Thuente + extended Rosenbrock
-int lbfgsx_batch_minimize_lockstep_multi(int dtype, const lbfgsx_params* p, int64_t n, int64_t first, int count,
-                                         uint64_t seed_base, const int* devices, int ndev, lbfgsx_batch_item* out,
-                                         void* x_out, char* errbuf, int errlen)
+}  // extern "C"
+// lock-step batch (include/LBFGSBatched.h): L-BFGS, LineSearchMoreThuente or LineSearchNocedalWright, a built-in objective
+template <class T, template <class> class LS>
+static void lockstep_body(const lbfgsx_params* p, int objective, double kappa, int64_t n, int64_t first, int count,
+                          uint64_t seed_base, const std::vector<int>& devs, lbfgsx_batch_item* out, void* x_out)
+{
+    LBFGSParam<T> param;
+    fill_common<T>(param, p);
+    param.linesearch = p->linesearch;
+    LBFGSBatchedSolver<T, LS> solver(param);
+    std::vector<typename LBFGSBatchedSolver<T, LS>::Item> items;
+    BatchObjective obj;
+    obj.id = objective;
+    obj.kappa = kappa;
+    if (devs.size() == 1)
+        solver.minimize(obj, n, seed_base, first, count, devs[0], items, static_cast<T*>(x_out));
+    else
+        solver.minimize(obj, n, seed_base, first, count, devs, items, static_cast<T*>(x_out));
+    for (int k = 0; k < count; k++)
+    {
+        out[k].niter = items[size_t(k)].niter;
+        out[k].nfev = items[size_t(k)].nfev;
+        out[k].status = items[size_t(k)].status;
+        out[k].fx = double(items[size_t(k)].fx);
+        out[k].gnorm = double(items[size_t(k)].gnorm);
+    }
+}
+
+extern "C" {
+
+int lbfgsx_batch_minimize_lockstep_ex(int dtype, int linesearch, int objective, double kappa, const lbfgsx_params* p, int64_t n,
+                                      int64_t first, int count, uint64_t seed_base, const int* devices, int ndev,
+                                      lbfgsx_batch_item* out, void* x_out, char* errbuf, int errlen)
 {
     lbfgsx_result r;
     int rc = guarded(&r, [&]() {
         if (!devices || ndev < 1)
-            throw std::invalid_argument("lbfgsx_batch_minimize_lockstep_multi: empty device list");
+            throw std::invalid_argument("lbfgsx_batch_minimize_lockstep: empty device list");
+        if (linesearch != LBFGSX_LS_MORE_THUENTE && linesearch != LBFGSX_LS_NOCEDAL_WRIGHT)
+            throw std::invalid_argument("lbfgsx_batch_minimize_lockstep: the lock-step batch runs LineSearchMoreThuente or "
+                                        "LineSearchNocedalWright (the policies that exist as state machines)");
+        if (objective != LBFGSX_OBJ_EXT_ROSENBROCK && objective != LBFGSX_OBJ_DIAG_QUAD)
+            throw std::invalid_argument("lbfgsx_batch_minimize_lockstep: unknown built-in objective");
         const std::vector<int> devs(devices, devices + ndev);
-        auto body = [&](auto tag) {
-            typedef decltype(tag) T;
-            LBFGSParam<T> param;
-            fill_common<T>(param, p);
-            param.linesearch = p->linesearch;
-            LBFGSBatchedSolver<T> solver(param);
-            std::vector<typename LBFGSBatchedSolver<T>::Item> items;
-            if (ndev == 1)
-                solver.minimize(n, seed_base, first, count, devs[0], items, static_cast<T*>(x_out));
-            else
-                solver.minimize(n, seed_base, first, count, devs, items, static_cast<T*>(x_out));
-            for (int k = 0; k < count; k++)
-            {
-                out[k].niter = items[size_t(k)].niter;
-                out[k].nfev = items[size_t(k)].nfev;
-                out[k].status = items[size_t(k)].status;
-                out[k].fx = double(items[size_t(k)].fx);
-                out[k].gnorm = double(items[size_t(k)].gnorm);
-            }
-        };
+        const bool nw = linesearch == LBFGSX_LS_NOCEDAL_WRIGHT;
         if (dtype == LBFGSX_F64)
-            body(double());
+        {
+            if (nw) lockstep_body<double, LineSearchNocedalWright>(p, objective, kappa, n, first, count, seed_base, devs, out, x_out);
+            else lockstep_body<double, LineSearchMoreThuente>(p, objective, kappa, n, first, count, seed_base, devs, out, x_out);
+        }
         else
-            body(float());
+        {
+            if (nw) lockstep_body<float, LineSearchNocedalWright>(p, objective, kappa, n, first, count, seed_base, devs, out, x_out);
+            else lockstep_body<float, LineSearchMoreThuente>(p, objective, kappa, n, first, count, seed_base, devs, out, x_out);
+        }
     });
     if (errbuf && errlen > 0)
         std::snprintf(errbuf, size_t(errlen), "%s", r.msg);
     return rc;
+}
+
+int lbfgsx_batch_minimize_lockstep_multi(int dtype, const lbfgsx_params* p, int64_t n, int64_t first, int count,
+                                         uint64_t seed_base, const int* devices, int ndev, lbfgsx_batch_item* out,
+                                         void* x_out, char* errbuf, int errlen)
+{
+    return lbfgsx_batch_minimize_lockstep_ex(dtype, LBFGSX_LS_MORE_THUENTE, LBFGSX_OBJ_EXT_ROSENBROCK, 10.0, p, n, first, count,
+                                             seed_base, devices, ndev, out, x_out, errbuf, errlen);
 }
 
 int lbfgsx_batch_minimize_lockstep(int dtype, const lbfgsx_params* p, int64_t n, int64_t first, int count,

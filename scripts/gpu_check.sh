@@ -2,7 +2,7 @@
 # one gpurun call: the GPU suite, then the default bench line (what the driver runs), both logged under gpurun_out/
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/check; mkdir -p $O
-timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log
+timeout 1500 python -m pytest tests -m gpu -x -q --durations=25 > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log
 tail -5 $O/pytest.log
 ( time timeout 600 python bench.py > $O/bench.json 2> $O/bench.err ) 2>&1 | tail -3
 python - <<'P'

@@ -57,3 +57,15 @@ for s, e, n in rows[s0:posts[-1]]:
 # the first iterations: where the from-x0 time goes
 print("\n--- per-iteration wall (ms), all 40 ---")
 print(" ".join("%.2f" % ((rows[posts[i + 1]][0] - rows[posts[i]][0]) / 1e6) for i in range(len(posts) - 1)))
+
+# the first iterations one by one: wall, kernel time, launches, the three largest kernels
+print("\n--- the first 20 iterations: wall ms | kernels ms | launches | largest kernels (ms) ---")
+for i in range(min(20, len(posts) - 1)):
+    seg_i = rows[posts[i]:posts[i + 1]]
+    w = (rows[posts[i + 1]][0] - rows[posts[i]][0]) / 1e6
+    busy_i = sum(e - s for s, e, _ in seg_i) / 1e6
+    ag = collections.Counter()
+    for s_, e_, n_ in seg_i:
+        ag[short(n_)[:34]] += (e_ - s_) / 1e6
+    top = ", ".join("%s %.2f" % (k, v) for k, v in ag.most_common(4))
+    print("%2d  %6.2f | %6.2f | %4d | %s" % (i + 1, w, busy_i, len(seg_i), top))

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include <LBFGS.h>
+#include <LBFGSBatched.h>
 #include <LBFGSB.h>
 
 using namespace LBFGSpp;
@@ -244,6 +245,69 @@ int main()
             thrown = true;
         }
         EXPECT(thrown);
+    }
+    // ---- lock-step batch with a USER objective on device memory (BatchFunctor): the caller evaluates f and grad of the
+    //      active problems between two library launches.  Here the "user kernel" is the built-in Rosenbrock evaluated in a
+    //      scratch context, so the batch must follow the built-in batch bit for bit -- with either line search.
+    {
+        const std::int64_t nb = 4096;
+        const int P = 6;
+        lbfgsx_ctx* scratch = nullptr;
+        EXPECT(lbfgsx_create(&scratch, LBFGSX_F64, nb, 3, 0, 0) == 0);
+        const size_t nbs = size_t(nb);
+        std::vector<double> hx(nbs), hg(nbs);
+        BatchFunctor<double> fun;
+        fun.start = [&](lbfgsx_batch* bc) {
+            for (int p = 0; p < P; p++)
+            {
+                lbfgsx_gen_rosen_x0(scratch, 500 + std::uint64_t(p));
+                lbfgsx_download(scratch, LBFGSX_VEC_X, hx.data());
+                hipMemcpy(lbfgsx_bat_vec(bc, 0, 0, p), hx.data(), size_t(nb) * sizeof(double), 1);
+            }
+        };
+        int calls = 0;
+        fun.eval = [&](lbfgsx_batch* bc, const int* point, double* fx) {
+            for (int p = 0; p < P; p++)
+            {
+                if (point[p] < 0)
+                    continue;
+                calls++;
+                hipMemcpy(hx.data(), lbfgsx_bat_vec(bc, 0, point[p], p), size_t(nb) * sizeof(double), 2);
+                lbfgsx_upload(scratch, LBFGSX_VEC_X, hx.data());
+                double g2 = 0, x2 = 0;
+                lbfgsx_eval(scratch, LBFGSX_OBJ_EXT_ROSENBROCK, &fx[p], &g2, &x2);
+                lbfgsx_download(scratch, LBFGSX_VEC_G, hg.data());
+                hipMemcpy(lbfgsx_bat_vec(bc, 1, point[p], p), hg.data(), size_t(nb) * sizeof(double), 1);
+            }
+        };
+        LBFGSParam<double> pb;
+        pb.m = 5;
+        pb.epsilon = 0;
+        pb.epsilon_rel = 0;
+        pb.max_iterations = 12;
+        auto compare = [&](auto& solver) {
+            typedef typename std::remove_reference<decltype(solver)>::type S;
+            std::vector<typename S::Item> a, b2;
+            const size_t tot = size_t(P) * nbs;
+            std::vector<double> xa(tot), xb(tot);
+            calls = 0;
+            solver.minimize(fun, nb, P, 0, a, xa.data());
+            solver.minimize(BatchObjective(), nb, 500, 0, P, 0, b2, xb.data());
+            int evals = 0;
+            for (int p = 0; p < P; p++)
+            {
+                EXPECT(a[size_t(p)].niter == b2[size_t(p)].niter && a[size_t(p)].nfev == b2[size_t(p)].nfev && a[size_t(p)].status == 0);
+                EXPECT(a[size_t(p)].fx == b2[size_t(p)].fx && a[size_t(p)].gnorm == b2[size_t(p)].gnorm);
+                evals += a[size_t(p)].nfev;
+            }
+            EXPECT(calls == evals);
+            EXPECT(xa == xb);
+        };
+        LBFGSBatchedSolver<double> mt(pb);
+        LBFGSBatchedSolver<double, LineSearchNocedalWright> nw(pb);
+        compare(mt);
+        compare(nw);
+        lbfgsx_destroy(scratch);
     }
     std::printf(failures ? "DROPIN FAILED (%d)\n" : "DROPIN OK\n", failures);
     return failures ? 1 : 0;

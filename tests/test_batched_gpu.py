@@ -1,4 +1,5 @@
 """-m gpu: batched mode (cfg5 shape, scaled down) -- every problem of a batch equals its stand-alone solve."""
+import ctypes as C
 import numpy as np
 import pytest
 
@@ -151,3 +152,57 @@ def test_rccl_allgather_of_the_result_records():
     out2 = (C.c_void_p * 2)()
     with pytest.raises(ValueError, match="listed twice"):
         L.check(core.lbfgsx_rccl_allgather_records(dup, 2, raw.ctypes.data_as(C.c_void_p), 37, raw.shape[1], out2))
+
+
+@pytest.mark.parametrize("ls,obj,dtype,n,m,iters", [("nw", "rosen", np.float64, 20000, 6, 25), ("mt", "quad", np.float64, 30001, 5, 20),
+                                                    ("nw", "quad", np.float32, 10000, 4, 15), ("nw", "rosen", np.float32, 4096, 5, 20)])
+def test_lockstep_batch_with_another_line_search_or_objective_equals_single_solves(A, ls, obj, dtype, n, m, iters):
+    """the lock-step batch was L-BFGS + More-Thuente + extended Rosenbrock only.  The line search is now the
+    template parameter the reference's solver has (LBFGS.h:20-21) for the two policies that exist as state machines, and
+    the built-in objective is selectable.  Every batch member must be the single-problem solver's run on the same data,
+    bit for bit -- also when a member's search fails (Nocedal-Wright in f32 runs out of precision: same status, same
+    message class, same evaluation count as the stand-alone solve that throws)."""
+    from lbfgspp_amd import batched as B
+    from lbfgspp_amd import _lib as L
+    core, _ = A.load()
+    LS = L.LS_NOCEDAL_WRIGHT if ls == "nw" else L.LS_MORE_THUENTE
+    OBJ = L.OBJ_DIAG_QUAD if obj == "quad" else L.OBJ_EXT_ROSENBROCK
+    par = A.LBFGSParam(m=m, epsilon=0.0, epsilon_rel=0.0, max_iterations=iters)
+    P, seed = 7, 300
+    recs, xs = B.solve_local_lockstep(par, n, 0, P, seed_base=seed, dtype=dtype, return_x=True, linesearch=LS, objective=OBJ, kappa=10.0)
+    failed = 0
+    for p in range(P):
+        s = A.LBFGSSolver(par, linesearch=LS, dtype=dtype)
+        ctx = s.prepare(n)
+        if obj == "quad":
+            L.check(core.lbfgsx_gen_diag_quad(ctx, 10.0, seed + p))
+            L.check(core.lbfgsx_fill(ctx, L.VEC_X, 0.0))
+            f = A.DiagQuadratic()
+        else:
+            L.check(core.lbfgsx_gen_rosen_x0(ctx, seed + p))
+            f = A.ExtendedRosenbrock()
+        status = 0
+        try:
+            niter, fx = s.minimize_resident(f, n)
+        except RuntimeError:
+            status = L.E_RUNTIME
+            failed += 1
+        x = np.empty(n, dtype)
+        assert recs["status"][p] == status
+        assert recs["nfev"][p] == s.last.nfev
+        if status == 0:
+            L.check(core.lbfgsx_download(ctx, L.VEC_X, x.ctypes.data_as(C.c_void_p)))
+            assert (recs["niter"][p], recs["fx"][p]) == (niter, fx) and recs["gnorm"][p] == s.last.gnorm
+            assert np.array_equal(xs[p], x)
+        s.close()
+    assert failed < P   # the comparison above is not vacuous
+
+
+def test_lockstep_batch_refuses_policies_without_a_state_machine(A):
+    from lbfgspp_amd import batched as B
+    from lbfgspp_amd import _lib as L
+    par = A.LBFGSParam(m=4, epsilon=0.0, epsilon_rel=0.0, max_iterations=3)
+    with pytest.raises(ValueError, match="state machines"):
+        B.solve_local_lockstep(par, 1024, 0, 4, linesearch=L.LS_BACKTRACKING)
+    with pytest.raises(ValueError, match="objective"):
+        B.solve_local_lockstep(par, 1024, 0, 4, objective=7)
