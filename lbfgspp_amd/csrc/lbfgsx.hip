@@ -273,8 +273,19 @@ static int create_fill(lbfgsx_ctx* c, int dtype, int64_t n, int m, int device, i
         c->zigzag = atoi(e) != 0;
     LBFGSX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->own_stream = true;
+    {
+        // A vector of a few thousand elements is one tile of one block: the persistent launch would bring up the whole
+        // chip (occupancy x CUs blocks, 2c+1 grid-wide meeting points) for it and takes ~200 us where the 2c+1 step
+        // launches take ~50 (measured with the reference's example programs, n <= 24: 4x slower end to end).  Below
+        // LBFGSX_PERSIST_MIN_N elements (default 4096) the step launches are the default; same bits either way.
+        int64_t min_n = 4096;
+        if (const char* e = getenv("LBFGSX_PERSIST_MIN_N"))
+            min_n = atoll(e);
+        if (n < min_n)
+            c->persist = false;
+    }
     if (const char* e = getenv("LBFGSX_PERSIST"))
-        c->persist = atoi(e) != 0;
+        c->persist = atoi(e) != 0 && c->persist;
     if (const char* e = getenv("LBFGSX_TRIAL_POLICY"))
         c->trial_policy = atoi(e);
     if (const char* e = getenv("LBFGSX_FUSE_POST"))

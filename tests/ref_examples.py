@@ -53,6 +53,14 @@ def build_all(force=False):
                                   "-Wl,-rpath,$ORIGIN/../../../lbfgspp_amd", "-Wl,-rpath,/opt/rocm/lib"])
         if force or _stale(ref, deps + [src]):
             jobs.append(COMMON + ["-I", os.path.join(REF, "include"), src, "-o", ref])
+    # the solve-by-solve probe of the comparison loop (our own source, tests/cpp/cmp_probe.cpp), same two flavours
+    psrc = os.path.join(ROOT, "tests", "cpp", "cmp_probe.cpp")
+    pgpu, pref = paths("cmp_probe")
+    if force or _stale(pgpu, deps + [psrc]):
+        jobs.append(COMMON + ["-I", inc, psrc, "-o", pgpu, "-L" + lib, "-llbfgsx", "-L/opt/rocm/lib", "-lamdhip64",
+                              "-Wl,-rpath,$ORIGIN/../../../lbfgspp_amd", "-Wl,-rpath,/opt/rocm/lib"])
+    if force or _stale(pref, deps + [psrc]):
+        jobs.append(COMMON + ["-I", os.path.join(REF, "include"), psrc, "-o", pref])
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=min(max(len(jobs), 1), os.cpu_count() or 1)) as ex:
         list(ex.map(subprocess.check_call, jobs))

@@ -8,6 +8,14 @@ import oracle_lib as O
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(scope="module")
+def A():
+    import lbfgspp_amd as A
+    core, _ = A.load()
+    assert core.lbfgsx_device_count() >= 1, "no GPU visible: these tests must run on the MI355X box"
+    return A
+
+
 def test_batched_equals_single_solves_and_oracle(oracle):
     import lbfgspp_amd as A
     from lbfgspp_amd import batched as B

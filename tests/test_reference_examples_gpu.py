@@ -20,9 +20,11 @@ def _have(name):
     return os.path.exists(gpu) and os.path.exists(ref)
 
 
-def _run(path, timeout=600):
+def _run(path, timeout=600, args=()):
+    env = {k: v for k, v in os.environ.items() if k != "LBFGSX_PERSIST_MIN_N"}   # the product's defaults (conftest.py)
     try:
-        r = subprocess.run([path], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout)
+        r = subprocess.run([path] + [str(a) for a in args], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                           timeout=timeout, env=env)
         return r.returncode, r.stdout, False
     except subprocess.TimeoutExpired as e:
         out = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
@@ -126,3 +128,22 @@ def test_comparison_example_counts_match_the_reference():
     assert len(got) >= (12 if slow else 1), "only %d dimensions completed: %r" % (len(got), sorted(got))
     for n, rows in got.items():
         assert rows == want[n], "n = %d: %r vs the reference's %r" % (n, rows, want[n])
+
+
+@pytest.mark.parametrize("policy", [0, 1, 2, 3])
+def test_comparison_loop_solve_by_solve(policy):
+    """tests/cpp/cmp_probe.cpp: the loop of the comparison example for n = 2 and one line-search policy (0 backtracking,
+    1 bracketing, 2 Nocedal-Wright, 3 More-Thuente), printing every one of the 1024 solves -- start point, iteration
+    count, call count, f and x with 17 digits.  The build against the drop-in headers (on the GPU, host-functor path)
+    must print what the build against the reference's headers prints, character for character.  (Both draw their start
+    points from the Eigen stand-in's own generator: std::rand() is shared with the GPU runtime's threads.)"""
+    gpu, ref = RX.paths("cmp_probe")
+    if not (os.path.exists(gpu) and os.path.exists(ref)):
+        pytest.skip("tests/cpp/bin/cmp_probe.* not built")
+    rc_g, out_g, _ = _run(gpu, timeout=300, args=(2, policy, 1024))
+    rc_r, out_r, _ = _run(ref, args=(2, policy, 1024))
+    assert rc_g == 0 and rc_r == 0, out_g[-2000:]
+    lg, lr = out_g.strip().split("\n"), out_r.strip().split("\n")
+    assert len(lr) == 1024 and len(lg) == 1024
+    bad = [k for k in range(1024) if lg[k] != lr[k]]
+    assert not bad, "%d solves differ, first: %s | %s" % (len(bad), lg[bad[0]], lr[bad[0]])
