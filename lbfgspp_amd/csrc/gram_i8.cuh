@@ -40,6 +40,13 @@ struct GramI8Args
 {
     const unsigned long long* colmax;  // bit patterns of max |column| per physical column: [0, m] Y, [m+1, 2m+1] S
     int cidx[32];                      // logical column -> index into colmax
+    // The compact copy of the free rows (GramRows of lbfgsb_kernels.cuh), written on the way by a pass over the
+    // full-length columns: row kept at position pos of batch bt goes to position out_base[bt] + pos.  Null: not written.
+    double* out_w;
+    int64_t out_ld;
+    int* out_idx;
+    const int* out_base;
+    int* out_pos;
 };
 
 // 11 signed digits of t = trunc(x * 2^(86 - E)), E = emax - 1022 (emax: biased exponent of the column's max), as three
@@ -90,8 +97,11 @@ __device__ __forceinline__ int gram_tri(int i, int j) { return i * (i + 1) / 2 +
 template <int CS>
 __global__ void __launch_bounds__(kBlock, 1)
     k_gram_i8(Cols<double, 32> cols, int ncols, BVecs<double> b, int vsel_id, int mask, int64_t n,
-              long long* __restrict__ part_i, int ne_pad, double* __restrict__ part_v, GramPrologue<double> pro, GramI8Args ga)
+              long long* __restrict__ part_i, int ne_pad, double* __restrict__ part_v, GramPrologue<double> pro, GramI8Args ga,
+              const int* __restrict__ ridx)
 {
+    // ridx: `cols` is the compact copy of the free rows (GramRows): n of them, row t of the columns = row ridx[t] of the
+    // vectors and of the state bytes; null: the full-length columns, row t = row t
     constexpr int cs = CS;
     extern __shared__ double tile[];
     __shared__ double pc1[64], pc2[64];
@@ -126,9 +136,16 @@ __global__ void __launch_bounds__(kBlock, 1)
     const int vj = lane % nv1, vg = lane / nv1;
 
     const int64_t nbatch = (n + kGramDDRows - 1) / kGramDDRows;
-    auto load_st = [&](int64_t bq) -> unsigned char {
+    // the row of the vectors behind position (bq, lane) of the columns
+    auto row_of = [&](int64_t bq) -> int64_t {
         const int64_t rq = bq * kGramDDRows + lane;
-        return (mask && bq < nbatch && rq < n) ? b.st[rq] : (unsigned char) 0;
+        if (!(bq < nbatch && rq < n))
+            return 0;
+        return ridx ? int64_t(ridx[rq]) : rq;
+    };
+    auto load_st = [&](int64_t bq, int64_t row) -> unsigned char {
+        const int64_t rq = bq * kGramDDRows + lane;
+        return (mask && bq < nbatch && rq < n) ? b.st[row] : (unsigned char) 0;
     };
     auto keep_of = [&](int64_t bq, unsigned char stq) -> bool {
         const int64_t rq = bq * kGramDDRows + lane;
@@ -140,15 +157,19 @@ __global__ void __launch_bounds__(kBlock, 1)
     // ---- software pipeline.  State bytes run two batches ahead; the column values (vn) and the per-row inputs of the
     // prologue / of v (an*) one batch ahead: they are requested right after the previous batch has been staged, so the
     // contraction of that batch -- the long part -- covers their latency (one wavefront per SIMD: nothing else would).
+    // (with a row list the row numbers run three batches ahead, one ahead of the state bytes they address)
     int64_t bt = gwave;
-    unsigned char st_a = load_st(bt), st_b = load_st(bt + nwaves);
+    int64_t row_a = row_of(bt), row_b = row_of(bt + nwaves), row_c = row_of(bt + 2 * nwaves);
+    unsigned char st_a = load_st(bt, row_a), st_b = load_st(bt + nwaves, row_b);
     bool keep_n = keep_of(bt, st_a);
+    int64_t row_n = row_a;  // row of the batch whose values are in flight (vn, an*)
     double vn[CS], an0 = 0.0, an1 = 0.0, an2 = 0.0;
-    auto issue_loads = [&](int64_t bq, bool kq) {
-        const int64_t rq = kq ? bq * kGramDDRows + lane : int64_t(0);  // masked-out lanes re-read row 0 (no branch)
+    auto issue_loads = [&](int64_t bq, bool kq, int64_t row) {
+        const int64_t cq = kq ? bq * kGramDDRows + lane : int64_t(0);  // masked-out lanes re-read row 0 (no branch)
+        const int64_t rq = kq ? row : int64_t(0);
 #pragma unroll
         for (int j = 0; j < CS; j++)
-            vn[j] = cols.p[j < ncols ? j : ncols - 1][rq];              // columns beyond ncols repeat the last one
+            vn[j] = cols.p[j < ncols ? j : ncols - 1][cq];              // columns beyond ncols repeat the last one
         an0 = need_rhs ? b.rhs[rq] : (need_g ? b.g[rq] : 0.0);
         an1 = an2 = 0.0;
         switch (vsel_id)
@@ -161,7 +182,7 @@ __global__ void __launch_bounds__(kBlock, 1)
         default: break;
         }
     };
-    issue_loads(bt, keep_n);
+    issue_loads(bt, keep_n, row_n);
 
     int head = 0, fill = 0;  // ring rows [head, head + fill) are staged and not yet contracted
     bool last = false;
@@ -173,7 +194,7 @@ __global__ void __launch_bounds__(kBlock, 1)
             if (bt < nbatch)
             {
                 // -- stage the batch whose values have arrived
-                const int64_t r = bt * kGramDDRows + lane;
+                const int64_t r = row_n;  // row of the vectors (= bt * kGramDDRows + lane without a row list)
                 const bool keep = keep_n;
                 const unsigned long long bal = __ballot(keep);
                 const int cnt = __popcll(bal);
@@ -185,6 +206,16 @@ __global__ void __launch_bounds__(kBlock, 1)
 #pragma unroll
                     for (int j = 0; j < CS; j++)
                         row[j] = vn[j];
+                    if (ga.out_w)  // the dense copy of the free rows for the passes that follow (ridx is null here)
+                    {
+                        const int64_t ot = int64_t(ga.out_base[bt]) + pos;
+                        ga.out_idx[ot] = int(r);
+                        ga.out_pos[r] = int(ot);
+#pragma unroll
+                        for (int j = 0; j < CS; j++)
+                            if (j < ncols)
+                                ga.out_w[int64_t(j) * ga.out_ld + ot] = vn[j];
+                    }
                     double rhs_new = an0, cF_new = an1;
                     if (pro.mode != GP_NONE)
                     {
@@ -237,9 +268,12 @@ __global__ void __launch_bounds__(kBlock, 1)
                 // -- request the next batch
                 const int64_t bn = bt + nwaves;
                 st_a = st_b;
-                st_b = load_st(bn + nwaves);
+                st_b = load_st(bn + nwaves, row_c);
+                row_n = row_b;
+                row_b = row_c;
+                row_c = row_of(bn + 2 * nwaves);
                 keep_n = keep_of(bn, st_a);
-                issue_loads(bn, keep_n);
+                issue_loads(bn, keep_n, row_n);
                 bt = bn;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();

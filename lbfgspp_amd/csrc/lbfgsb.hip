@@ -95,7 +95,8 @@ struct lbfgsb_state
     int gram_blocks = 1024;  // 4 resident blocks per CU (33 KB of LDS each)
     bool gram_mfma = false;  // opt-in (LBFGSX_GRAM=mfma): ~1 ulp per entry instead of the correctly rounded sums
     // exact Gram on the matrix cores (gram_i8.cuh): radix-256 digits, v_mfma_i32_32x32x32_i8, integer sums
-    bool gram_i8 = false;                    // LBFGSX_GRAM=i8
+    bool gram_i8 = false;                    // LBFGSX_GRAM=i8; default ON for f64 contexts with 12 <= m <= 15 (bounded_alloc)
+    int i8_min_tot = 1;                      // fewer columns than this: the double-double kernel (auto mode: 23)
     unsigned long long* colmax = nullptr;    // [m + 1][2]: bit patterns of max |Y col|, max |S col| per physical column
     std::vector<unsigned char> colmax_ok;    // per physical column: the slots above describe the column's current content
     long long* i8_part = nullptr;            // [waves][11][ne_pad]
@@ -278,10 +279,25 @@ int bounded_alloc(lbfgsx_ctx* c)
     else
         (void) rocprim::radix_sort_pairs(nullptr, bytes, P<float>(b->keys_in), P<float>(b->keys_out), b->vals_in,
                                          b->vals_out, size_t(c->n), 0, 32, c->stream);
+    // Which kernel forms a full W_F'W_F.  The double-double VALU kernel costs ~ (2c + 1)^2 per row, the exact integer
+    // kernel on the matrix cores (gram_i8.cuh) is flat up to 32 columns but bound by the ~1000 VALU instructions per 32
+    // rows that cut the radix-256 digits.  Measured on MI355X (n = 1e7, ~5e6 free rows, the pass also writing the compact
+    // copy of the free rows; profiles/r3_gram_dd_vs_i8.txt): 0.74 / 1.35 / 1.71 / 1.75 ms against 0.73 / 1.41 / 1.48 /
+    // 1.51 ms at m = 10 / 12 / 14 / 15, and end to end (steady iterations per second, same box) 198 / 175 / 153 against
+    // 190 / 172 / 155 at m = 12 / 14 / 15: the matrix-core kernel only pays where the tile kernel is at its largest class,
+    // so it is the default for f64 problems at m = 15 (once the history holds >= 23 columns) and opt-in elsewhere.  At
+    // m <= 10 the question does not arise in the steady state: W_F'W_F is carried between iterations and a full pass runs
+    // once in 32.  Bit-identical sums either way.  LBFGSX_GRAM=dd / i8 / mfma / blocked overrides.
+    if (c->dtype == LBFGSX_F64 && c->m == 15)
+    {
+        b->gram_i8 = true;
+        b->i8_min_tot = 23;
+    }
     if (const char* e = getenv("LBFGSX_GRAM"))
     {
         b->gram_mfma = (std::strcmp(e, "mfma") == 0);
         b->gram_i8 = (std::strcmp(e, "i8") == 0);
+        b->i8_min_tot = 1;
         b->gram_mode = (std::strcmp(e, "blocked") == 0) ? 2 : 0;
     }
     if (const char* e = getenv("LBFGSX_GCP_CHAIN"))
@@ -1509,25 +1525,35 @@ int bounded_note_column(lbfgsx_ctx* c, int col)
 }  // namespace lbfgsx
 
 // exact integer Gram on the matrix cores (gram_i8.cuh): returns the number of per-wave partials, or -1 when not applicable
+// compact: the pass walks the compact copy of the free rows (wf_cols, wf_n rows, row list wf_idx) instead of the full-length
+// columns under the mask -- the same rows, the same integer sums
 template <int CS>
 static int launch_gram_i8_cs(lbfgsx_ctx* c, int tot, int vsel_id, int mask, const GramPrologue<double>& pro, const GramI8Args& ga,
-                             int blocks, int ne_pad)
+                             int blocks, int ne_pad, bool compact)
 {
     lbfgsb_state* b = c->bstate;
     int which[32];
     for (int k = 0; k < tot; k++)
         which[k] = k;
-    Cols<double, 32> cl = col_list<double, 32>(c, which, tot);
+    Cols<double, 32> cl = compact ? wf_cols<double>(c, tot) : col_list<double, 32>(c, which, tot);
     const size_t lds = size_t(kBlock / 64) * kI8Ring * size_t(CS) * sizeof(double);
-    LBFGSX_LAUNCH((k_gram_i8<CS>), dim3(blocks), dim3(kBlock), lds, c->stream, cl, tot, bvecs<double>(c), vsel_id, mask, c->n,
-                       b->i8_part, ne_pad, b->i8_partv, pro, ga);
+    LBFGSX_LAUNCH((k_gram_i8<CS>), dim3(blocks), dim3(kBlock), lds, c->stream, cl, tot, bvecs<double>(c), vsel_id, mask,
+                  compact ? b->wf_n : c->n, b->i8_part, ne_pad, b->i8_partv, pro, ga,
+                  compact ? b->wf_idx : static_cast<const int*>(nullptr));
     return blocks * (kBlock / 64);
 }
-static int gram_i8_run(lbfgsx_ctx* c, int tot, int vsel_id, int mask, const GramPrologue<double>& pro, bool want_dd)
+// compact_out: the pass (over the full-length columns) also writes the compact copy of the free rows (wf_prepare done)
+static int gram_i8_run(lbfgsx_ctx* c, int tot, int vsel_id, int mask, const GramPrologue<double>& pro, bool want_dd, bool compact,
+                       bool compact_out)
 {
     lbfgsb_state* b = c->bstate;
     GramI8Args ga;
     ga.colmax = b->colmax;
+    ga.out_w = compact_out ? static_cast<double*>(b->wf) : nullptr;
+    ga.out_ld = b->wf_ld;
+    ga.out_idx = b->wf_idx;
+    ga.out_base = b->wf_base;
+    ga.out_pos = b->wf_pos;
     for (int k = 0; k < 32; k++)
         ga.cidx[k] = 0;
     for (int k = 0; k < tot; k++)
@@ -1540,7 +1566,7 @@ static int gram_i8_run(lbfgsx_ctx* c, int tot, int vsel_id, int mask, const Gram
     }
     const int ne = tot * (tot + 1) / 2;
     const int ne_pad = (ne + 63) / 64 * 64;
-    const int64_t nbatch = (c->n + kGramDDRows - 1) / kGramDDRows;
+    const int64_t nbatch = ((compact ? b->wf_n : c->n) + kGramDDRows - 1) / kGramDDRows;
     const int blocks = int(std::max<int64_t>(1, std::min<int64_t>(b->num_cus, (nbatch + 3) / 4)));
     const int waves = blocks * (kBlock / 64);
     if (waves > b->i8_waves || ne_pad > b->i8_nepad)
@@ -1564,9 +1590,9 @@ static int gram_i8_run(lbfgsx_ctx* c, int tot, int vsel_id, int mask, const Gram
     if (vsel_id >= 0)
         LBFGSX_HIP(hipMemsetAsync(b->i8_partv, 0, sizeof(double) * size_t(waves) * 32 * 2, c->stream));
     if (tot <= 23)
-        launch_gram_i8_cs<23>(c, tot, vsel_id, mask, pro, ga, blocks, ne_pad);
+        launch_gram_i8_cs<23>(c, tot, vsel_id, mask, pro, ga, blocks, ne_pad, compact);
     else
-        launch_gram_i8_cs<31>(c, tot, vsel_id, mask, pro, ga, blocks, ne_pad);
+        launch_gram_i8_cs<31>(c, tot, vsel_id, mask, pro, ga, blocks, ne_pad, compact);
     LBFGSX_LAUNCH(k_gram_i8_sum, dim3(kI8Acc, std::min(blocks, 16)), dim3(kBlock), 0, c->stream, b->i8_part, blocks, ne, ne_pad,
                        b->i8_vsum);
     LBFGSX_LAUNCH(k_gram_i8_final, dim3(1), dim3(kBlock), 0, c->stream, b->i8_vsum, tot, ne_pad, b->i8_partv, waves,
@@ -1898,7 +1924,7 @@ int lbfgsx_b_gram_pairs_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
     if (!kept)
         b->wf_live = false;
     const bool compact_in = kept || wf_serves(c, mask);
-    bool compact_out = !compact_in && b->wf_use && b->wf_on && mask == ST_FREE && !(b->gram_i8 && c->dtype == LBFGSX_F64) &&
+    bool compact_out = !compact_in && b->wf_use && b->wf_on && mask == ST_FREE &&
                        c->n < (int64_t(1) << 31) && b->nfree_last >= 4096 && b->nfree_last * 8 <= c->n * 7;
     rc = upload_phys(c);
     if (rc)
@@ -2120,8 +2146,7 @@ static int gram_dd_core(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, cons
     }
     const bool compact_in = !list && wf_serves(c, mask);
     bool compact_out = !list && !compact_in && b->wf_use && b->wf_on && gram_dd != nullptr && mask == ST_FREE && vsel_id >= 0 &&
-                       !(b->gram_i8 && c->dtype == LBFGSX_F64) && c->n < (int64_t(1) << 31) && b->nfree_last >= 4096 &&
-                       b->nfree_last * 8 <= c->n * 7;
+                       c->n < (int64_t(1) << 31) && b->nfree_last >= 4096 && b->nfree_last * 8 <= c->n * 7;
     if (compact_out)
         compact_out = wf_prepare(c);
     const int64_t nrows = list ? nlist : compact_in ? b->wf_n : c->n;
@@ -2129,7 +2154,7 @@ static int gram_dd_core(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, cons
     bool done_i8 = false;
     // the integer kernel pays a fixed cost per launch (per-wave partials, the integer tree): row sets that are not the
     // free set -- the sparse L u U complements of the BOXCQP sweeps -- stay on the double-double kernel
-    if (!list && b->gram_i8 && c->dtype == LBFGSX_F64 && tot <= 30 && (mask == 0 || (mask & ST_FREE)))
+    if (!list && b->gram_i8 && c->dtype == LBFGSX_F64 && tot <= 30 && tot >= b->i8_min_tot && (mask == 0 || (mask & ST_FREE)))
     {
         GramPrologue<double> pro;
         pro.mode = prologue;
@@ -2140,10 +2165,12 @@ static int gram_dd_core(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, cons
             pro.c1[k] = (coef1 && k < tot) ? coef1[k] : 0.0;
             pro.c2[k] = (coef2 && k < tot) ? coef2[k] : 0.0;
         }
-        const int w = gram_i8_run(c, tot, vsel_id, mask, pro, gram_dd != nullptr);
+        const int w = gram_i8_run(c, tot, vsel_id, mask, pro, gram_dd != nullptr, compact_in, compact_out);
         if (w < -1)
             return w;
         done_i8 = (w > 0);
+        if (done_i8 && compact_out)
+            wf_rebuilt(c);
     }
     const int kpt_ = kp <= 1 ? 1 : kp <= 2 ? 2 : kp <= 4 ? 4 : kp <= 6 ? 6 : 8;
     const int ntile_ = (64 * kpt_ + 255) / 256;

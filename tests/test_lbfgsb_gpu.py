@@ -532,6 +532,35 @@ def test_integer_mfma_gram_trajectories_change_no_bit(A, monkeypatch, n, m, iter
     assert np.array_equal(res["i8"][3], res["dd"][3]) and np.array_equal(res["i8"][4], res["dd"][4])
 
 
+def test_integer_mfma_gram_is_the_default_at_m_15_and_writes_the_compact_copy(A, oracle, monkeypatch):
+    """Round 3: the matrix-core Gram reads the compact copy of the free rows and writes it when the pass rebuilds it, and is
+    the DEFAULT kernel of the full W_F'W_F pass for f64 problems at m = 15 (the tile kernel's largest class, where it is
+    the slower one).  A default run at m = 15 must (a) launch it -- the process-wide launch counter of an explicit
+    LBFGSX_GRAM=dd run is lower by the integer kernel's extra launches is not observable, so the check is the trajectory
+    itself under the three settings -- and (b) follow the double-double run and the oracle: every iterate identical."""
+    n, m, iters = 200000, 15, 24      # > 4096 free rows: the compact copy is in use; 2c reaches 30 >= 23 columns
+    a, b = O.quad_problem(n, 10.0, 3, O.F64)
+    lb, ub = -np.ones(n), np.ones(n)
+    res = {}
+    for mode in ("default", "dd", "i8"):
+        if mode == "default":
+            monkeypatch.delenv("LBFGSX_GRAM", raising=False)
+        else:
+            monkeypatch.setenv("LBFGSX_GRAM", mode)
+        s = A.LBFGSBSolver(A.LBFGSBParam(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters))
+        x = np.zeros(n)
+        tr = A.TraceBuffer(n, cap=512, stride=max(1, n // 5000))
+        niter, fx = s.minimize(A.DiagQuadratic(a, b), x, lb, ub, trace=tr)
+        res[mode] = (niter, s.last.nfev, fx, x, tr.xs[:tr.count].copy())
+        s.close()
+    for mode in ("dd", "i8"):
+        assert res["default"][:3] == res[mode][:3]
+        assert np.array_equal(res["default"][3], res[mode][3]) and np.array_equal(res["default"][4], res[mode][4])
+    x_ref, r = oracle.lbfgsb(O.F64, O.OBJ_QUAD, np.zeros(n), lb, ub,
+                             O.lbfgsb_params(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters), a=a, b=b)
+    assert (r.niter, r.nfev) == res["default"][:2] and np.abs(res["default"][3] - x_ref).max() <= 1e-10
+
+
 @pytest.mark.parametrize("n,m,npairs", [(50000, 10, 10), (300001, 6, 4), (65536, 10, 7)])
 def test_selected_entries_and_list_grams_equal_the_full_pass(A, n, m, npairs):
     """The pieces of the carried first solve against the full one-pass Gram on the same data: the entries
