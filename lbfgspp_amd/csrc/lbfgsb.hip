@@ -43,6 +43,8 @@ struct lbfgsb_state
     unsigned lu_cap = 0;
     int lu_n = 0;
     int64_t lu_pred = int64_t(1) << 40;  // |L u U| of the previous partition: the list is only kept while the sets are small
+    int64_t lu_max = 262144;             // ... i.e. up to this many rows (LBFGSX_LU_MAX; 16384 until round 3: with 65536 .. 2^20
+                                         // the iterations whose sets hold 10^4..10^5 rows keep the fused sweeps, +2 % from x0)
     bool lu_valid = false;
     bool lu_use = true;                   // LBFGSX_LU_LIST=0: always scan
     bool sweep_fuse = true;               // LBFGSX_SWEEP_SOLVE_FUSE=0: the solve and the sweep's statements stay separate passes
@@ -266,6 +268,8 @@ int bounded_alloc(lbfgsx_ctx* c)
         b->vonly_groups = atoi(e);
     if (const char* e = getenv("LBFGSX_VROWS"))
         b->vrows = atoi(e) != 0;
+    if (const char* e = getenv("LBFGSX_LU_MAX"))
+        b->lu_max = std::max<int64_t>(0, atoll(e));
     if (const char* e = getenv("LBFGSX_GCP_PIECES"))
         b->chain_pieces = std::max(1, std::min(8, atoi(e)));
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->colmax), sizeof(unsigned long long) * 2 * size_t(c->m + 1)));
@@ -2366,7 +2370,7 @@ int lbfgsx_b_sub_sweep_begin(lbfgsx_ctx* c, int first, int64_t* nL, int64_t* nU,
     double r[7];
     // the list pays while L u U is a few thousand rows (steady state: 10^1..10^3); in the early iterations the sets hold
     // 10^5..10^6 rows and the dense scans are the better form -- decided from the size the previous partition found
-    const unsigned lu_cap_now = (c->bstate->lu_use && c->bstate->lu_pred <= 16384) ? c->bstate->lu_cap : 0u;
+    const unsigned lu_cap_now = (c->bstate->lu_use && c->bstate->lu_pred <= c->bstate->lu_max) ? c->bstate->lu_cap : 0u;
     DISPATCH_T(c, {
         BVecs<T> bv = bvecs<T>(c);
         LBFGSX_LAUNCH((k_sub_sweep_begin<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, first ? 1 : 0, c->n, c->ws,
@@ -2447,7 +2451,7 @@ int lbfgsx_b_solve_sweep(lbfgsx_ctx* c, int first, int vsel_id, const double* co
     int* dst;
     if (first)
     {
-        cap = (b->lu_use && b->lu_pred <= 16384) ? b->lu_cap : 0u;
+        cap = (b->lu_use && b->lu_pred <= b->lu_max) ? b->lu_cap : 0u;
         dst = b->lu_ptr();
     }
     else
