@@ -97,8 +97,8 @@ struct lbfgsb_state
     int gram_blocks = 1024;  // 4 resident blocks per CU (33 KB of LDS each)
     bool gram_mfma = false;  // opt-in (LBFGSX_GRAM=mfma): ~1 ulp per entry instead of the correctly rounded sums
     // exact Gram on the matrix cores (gram_i8.cuh): radix-256 digits, v_mfma_i32_32x32x32_i8, integer sums
-    bool gram_i8 = false;                    // LBFGSX_GRAM=i8; default ON for f64 contexts with 12 <= m <= 15 (bounded_alloc)
-    int i8_min_tot = 1;                      // fewer columns than this: the double-double kernel (auto mode: 23)
+    bool gram_i8 = false;                    // LBFGSX_GRAM=i8
+    int i8_min_tot = 1;                      // fewer columns than this: the double-double kernel (LBFGSX_GRAM_I8_MIN)
     unsigned long long* colmax = nullptr;    // [m + 1][2]: bit patterns of max |Y col|, max |S col| per physical column
     std::vector<unsigned char> colmax_ok;    // per physical column: the slots above describe the column's current content
     long long* i8_part = nullptr;            // [waves][11][ne_pad]
@@ -283,25 +283,21 @@ int bounded_alloc(lbfgsx_ctx* c)
     else
         (void) rocprim::radix_sort_pairs(nullptr, bytes, P<float>(b->keys_in), P<float>(b->keys_out), b->vals_in,
                                          b->vals_out, size_t(c->n), 0, 32, c->stream);
-    // Which kernel forms a full W_F'W_F.  The double-double VALU kernel costs ~ (2c + 1)^2 per row, the exact integer
-    // kernel on the matrix cores (gram_i8.cuh) is flat up to 32 columns but bound by the ~1000 VALU instructions per 32
-    // rows that cut the radix-256 digits.  Measured on MI355X (n = 1e7, ~5e6 free rows, the pass also writing the compact
-    // copy of the free rows; profiles/r3_gram_dd_vs_i8.txt): 0.74 / 1.35 / 1.71 / 1.75 ms against 0.73 / 1.41 / 1.48 /
-    // 1.51 ms at m = 10 / 12 / 14 / 15, and end to end (steady iterations per second, same box) 198 / 175 / 153 against
-    // 190 / 172 / 155 at m = 12 / 14 / 15: the matrix-core kernel only pays where the tile kernel is at its largest class,
-    // so it is the default for f64 problems at m = 15 (once the history holds >= 23 columns) and opt-in elsewhere.  At
-    // m <= 10 the question does not arise in the steady state: W_F'W_F is carried between iterations and a full pass runs
-    // once in 32.  Bit-identical sums either way.  LBFGSX_GRAM=dd / i8 / mfma / blocked overrides.
-    if (c->dtype == LBFGSX_F64 && c->m == 15)
-    {
-        b->gram_i8 = true;
-        b->i8_min_tot = 23;
-    }
+    // Which kernel forms a full W_F'W_F.  The double-double VALU kernel costs ~ (2c + 1)^2 per row; the exact integer
+    // kernel on the matrix cores (gram_i8.cuh, LBFGSX_GRAM=i8) is flat up to 32 columns but bound by the ~1000 VALU
+    // instructions per 32 rows that cut the radix-256 digits.  Measured on MI355X (n = 1e7, ~5e6 free rows, the pass also
+    // writing the compact copy of the free rows; profiles/r3_gram_dd_vs_i8.txt): 0.74 / 1.35 / 1.71 / 1.75 ms against
+    // 0.73 / 1.41 / 1.48 / 1.51 ms at m = 10 / 12 / 14 / 15 -- the matrix-core kernel is the faster one from m = 14 on,
+    // by 14 % of a pass that is a quarter of an iteration there.  End to end that is +1 % steady and -4 % from x0 at
+    // m = 15 (its per-column maxima cost a little in every iteration, k_b_post), and a loss below; at m <= 10 the question
+    // does not arise in the steady state, W_F'W_F being carried between iterations (one full pass in 32).  So the
+    // double-double kernel stays the default at every m and the matrix-core kernel an option that changes no bit.
     if (const char* e = getenv("LBFGSX_GRAM"))
     {
         b->gram_mfma = (std::strcmp(e, "mfma") == 0);
         b->gram_i8 = (std::strcmp(e, "i8") == 0);
-        b->i8_min_tot = 1;
+        if (const char* e2 = getenv("LBFGSX_GRAM_I8_MIN"))
+            b->i8_min_tot = std::max(1, atoi(e2));
         b->gram_mode = (std::strcmp(e, "blocked") == 0) ? 2 : 0;
     }
     if (const char* e = getenv("LBFGSX_GCP_CHAIN"))

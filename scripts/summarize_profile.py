@@ -14,12 +14,16 @@ rnd = sys.argv[1] if len(sys.argv) > 1 else "r1"
 src = os.path.join("gpurun_out", "prof_" + rnd)
 os.makedirs("profiles", exist_ok=True)
 shutil.copy(os.path.join(src, "trace", "bench_kernel_stats.csv"), os.path.join("profiles", rnd + "_kernel_stats.csv"))
-for name in ("northstar", "northstar_unfused", "northstar_gram", "northstar_gram_f32h", "sharded_n1", "cfg3_m20", "cfg3_m20_gram", "cfg2_quad1e7", "cfg5_batched", "cfg4_lbfgsb",
+for name in ("default", "cfg4_m15", "cfg4_m15_dd", "sharded_one_process_2x", "single_process_2x", "northstar", "northstar_unfused", "northstar_gram", "northstar_gram_f32h", "sharded_n1", "cfg3_m20", "cfg3_m20_gram", "cfg2_quad1e7", "cfg5_batched", "cfg4_lbfgsb",
              "cfg4_lbfgsb_mfma", "cfg4_lbfgsb_devmin4096", "cfg4_lbfgsb_i8", "cfg4_lbfgsb_scan", "two_ranks_one_device"):
     f = os.path.join(src, "bench_%s.json" % name)
     if os.path.exists(f):
         shutil.copy(f, os.path.join("profiles", "%s_bench_%s.json" % (rnd, name)))
-for sub in ("lbfgsb", "lbfgsb_mfma", "lbfgsb_i8"):
+for extra in ("cfg4_timeline.txt",):
+    f = os.path.join(src, extra)
+    if os.path.exists(f):
+        shutil.copy(f, os.path.join("profiles", "%s_%s" % (rnd, extra)))
+for sub in ("lbfgsb", "lbfgsb_mfma", "lbfgsb_i8", "lbfgsb_m15"):
     f = os.path.join(src, sub, "b_kernel_stats.csv")
     if os.path.exists(f):
         shutil.copy(f, os.path.join("profiles", "%s_%s_kernel_stats.csv" % (rnd, sub)))

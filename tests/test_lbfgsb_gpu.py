@@ -532,28 +532,29 @@ def test_integer_mfma_gram_trajectories_change_no_bit(A, monkeypatch, n, m, iter
     assert np.array_equal(res["i8"][3], res["dd"][3]) and np.array_equal(res["i8"][4], res["dd"][4])
 
 
-def test_integer_mfma_gram_is_the_default_at_m_15_and_writes_the_compact_copy(A, oracle, monkeypatch):
-    """Round 3: the matrix-core Gram reads the compact copy of the free rows and writes it when the pass rebuilds it, and is
-    the DEFAULT kernel of the full W_F'W_F pass for f64 problems at m = 15 (the tile kernel's largest class, where it is
-    the slower one).  A default run at m = 15 must (a) launch it -- the process-wide launch counter of an explicit
-    LBFGSX_GRAM=dd run is lower by the integer kernel's extra launches is not observable, so the check is the trajectory
-    itself under the three settings -- and (b) follow the double-double run and the oracle: every iterate identical."""
-    n, m, iters = 200000, 15, 24      # > 4096 free rows: the compact copy is in use; 2c reaches 30 >= 23 columns
+def test_integer_mfma_gram_reads_and_writes_the_compact_copy(A, oracle, monkeypatch):
+    """Round 3: the matrix-core Gram (LBFGSX_GRAM=i8) reads the compact copy of the free rows and writes it when its pass
+    rebuilds it (it used to leave the sweeps on the masked full-length columns).  At m = 15 -- where the carried first
+    solve does not apply and EVERY iteration runs a full pass, the tile kernel in its largest class -- a run with it, one
+    with it from 23 columns on only, and the double-double default must be the same run, and the oracle's to 1e-10."""
+    n, m, iters = 200000, 15, 24      # > 4096 free rows: the compact copy is in use; 2c reaches 30 columns
     a, b = O.quad_problem(n, 10.0, 3, O.F64)
     lb, ub = -np.ones(n), np.ones(n)
     res = {}
-    for mode in ("default", "dd", "i8"):
-        if mode == "default":
-            monkeypatch.delenv("LBFGSX_GRAM", raising=False)
-        else:
-            monkeypatch.setenv("LBFGSX_GRAM", mode)
+    for mode in ("default", "i8", "i8-from-23"):
+        monkeypatch.delenv("LBFGSX_GRAM", raising=False)
+        monkeypatch.delenv("LBFGSX_GRAM_I8_MIN", raising=False)
+        if mode != "default":
+            monkeypatch.setenv("LBFGSX_GRAM", "i8")
+        if mode == "i8-from-23":
+            monkeypatch.setenv("LBFGSX_GRAM_I8_MIN", "23")
         s = A.LBFGSBSolver(A.LBFGSBParam(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters))
         x = np.zeros(n)
         tr = A.TraceBuffer(n, cap=512, stride=max(1, n // 5000))
         niter, fx = s.minimize(A.DiagQuadratic(a, b), x, lb, ub, trace=tr)
         res[mode] = (niter, s.last.nfev, fx, x, tr.xs[:tr.count].copy())
         s.close()
-    for mode in ("dd", "i8"):
+    for mode in ("i8", "i8-from-23"):
         assert res["default"][:3] == res[mode][:3]
         assert np.array_equal(res["default"][3], res[mode][3]) and np.array_equal(res["default"][4], res[mode][4])
     x_ref, r = oracle.lbfgsb(O.F64, O.OBJ_QUAD, np.zeros(n), lb, ub,
