@@ -65,6 +65,16 @@ int main()
         t1 = now();
         printf("spin=%4d  launch + poll host-mapped flag      : %6.2f us per round trip\n", spin, (t1 - t0) / reps * 1e6);
         CK(hipStreamSynchronize(st));
+        // spin on hipStreamQuery instead of blocking in hipStreamSynchronize
+        t0 = now();
+        for (int i = 0; i < reps; i++)
+        {
+            hipLaunchKernelGGL(k_small, dim3(64), dim3(256), 0, st, out_d, (volatile unsigned*) nullptr, 0u, spin);
+            while (hipStreamQuery(st) == hipErrorNotReady)
+                ;
+        }
+        t1 = now();
+        printf("spin=%4d  launch + spin on hipStreamQuery         : %6.2f us per round trip\n", spin, (t1 - t0) / reps * 1e6);
         // the kernel knows nothing of the flag: a stream write-value operation behind it, the host polls
         seq = *flag_h;
         t0 = now();
