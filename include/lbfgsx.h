@@ -334,6 +334,14 @@ int lbfgsx_b_gram_pairs_dd(lbfgsx_ctx* c, int mask, int vsel, int prologue, cons
  * taken when the free set leaves out at least an eighth of the rows.  LBFGSX_COMPACT_FREE=0 disables it.  The copy is
  * valid until the next lbfgsx_b_sub_begin / lbfgsx_b_cauchy_finish; the history must not change in between. */
 int lbfgsx_b_set_compaction(lbfgsx_ctx* c, int enable);
+/* Compact vectors (round 3).  While lbfgsx_b_solve_sweep / _lu_sweep / _wtv_lu / _wtv_prologue and the L u U complement of
+ * lbfgsx_b_gram_fused_dd sweep over the compact copy, vecy, yfallback, lambda, mu, rhs, c_F, l - x0, u - x0 and the
+ * partition bits of the free rows (SubspaceMin.h:159-268) sit at the rows' POSITIONS in the copy (contiguous) instead of at
+ * the rows; lbfgsx_b_sub_op(LBFGSX_SO_ASSIGN_Y) assigns the result from there, any other entry of the bounded path first
+ * puts them back at their rows.  Same statements on the same values: no bit changes.  LBFGSX_COMPACT_VEC=0 keeps the
+ * vectors at their rows.  Instrumentation, process-wide: out = {minimisations that ran on compact vectors, times they were
+ * put back before the result was assigned}. */
+int lbfgsx_b_compact_vec_counts(int64_t out[2], int reset);
 /* A BOXCQP solve and the statements of lbfgsx_b_sub_sweep_begin on the rows it writes, in ONE pass (the solve's row of W is
  * in registers; the sweep's pass over n rows disappears).  Bit for bit lbfgsx_b_wcombine(LBFGSX_CB_SOLVE) /
  * lbfgsx_b_solve_wty followed by lbfgsx_b_sub_sweep_begin.

@@ -1,5 +1,6 @@
 // lbfgspp_amd/csrc/lbfgsb.hip -- C ABI of the L-BFGS-B device operators (include/lbfgsx.h, "L-BFGS-B" block).
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -59,6 +60,14 @@ struct lbfgsb_state
     size_t wf_tmp_bytes = 0;
     bool wf_use = true;                   // LBFGSX_COMPACT_FREE=0: never
     bool force_pending = false;           // lbfgsx_b_force_bounds_deferred: x = clamp(x) rides on the next Cauchy build
+    // compact vectors of a subspace minimisation (lbfgsb_kernels.cuh "cv"): y, yfallback, lambda, mu, rhs, cF, lb - x0,
+    // ub - x0 and the state byte of the free rows at their POSITION in the compact copy, from the first solve-sweep until
+    // the result is assigned (or a pass outside the fused path needs them by row again: cv_back)
+    bool cv_use = true;                   // LBFGSX_COMPACT_VEC=0: the vectors stay at their rows
+    bool cv_live = false;
+    void* cv_buf = nullptr;               // 8 vectors of cv_cap elements + cv_cap state bytes
+    int64_t cv_cap = 0;
+    int64_t cv_backs = 0, cv_starts = 0;  // instrumentation: passes that put them back early / minimisations that used them
     int vonly_groups = 0;                 // LBFGSX_VONLY_GROUPS=1: the v-row Gram walks one row per step (A/B of the lane groups)
     bool vrows = true;                    // LBFGSX_VROWS=0: the v-row / selected-entries passes through the LDS tile kernel (k_gram_dd<.., VONLY>)
                                           // instead of the register kernel k_vrows (A/B; same sums)
@@ -169,15 +178,87 @@ static BVecs<T> bvecs(lbfgsx_ctx* c)
     return v;
 }
 
+// instrumentation, process-wide: {subspace minimisations that ran on compact vectors, times they went back to their rows
+// before the minimisation assigned its result}
+static std::atomic<int64_t> g_cv_starts{0}, g_cv_backs{0};
+// the vectors of the free rows by POSITION (cv_buf): what the fused sweep kernels are handed while cv_live
+template <class T>
+static BVecs<T> bvecs_cv(lbfgsx_ctx* c, T** cli = nullptr, T** cui = nullptr)
+{
+    lbfgsb_state* b = c->bstate;
+    BVecs<T> v = bvecs<T>(c);
+    T* base = static_cast<T*>(b->cv_buf);
+    const int64_t cap = b->cv_cap;
+    v.y = base;
+    v.yfb = base + cap;
+    v.lam = base + 2 * cap;
+    v.mu = base + 3 * cap;
+    v.rhs = base + 4 * cap;
+    v.cF = base + 5 * cap;
+    if (cli) *cli = base + 6 * cap;
+    if (cui) *cui = base + 7 * cap;
+    v.st = reinterpret_cast<unsigned char*>(base + 8 * cap);
+    return v;
+}
+static int cv_alloc(lbfgsx_ctx* c)
+{
+    lbfgsb_state* b = c->bstate;
+    if (b->cv_buf && b->cv_cap >= c->ld)
+        return LBFGSX_OK;
+    if (b->cv_buf)
+        (void) hipFree(b->cv_buf);
+    b->cv_buf = nullptr;
+    b->cv_cap = c->ld;
+    if (hipMalloc(&b->cv_buf, size_t(b->cv_cap) * (8 * c->esz + 1) + 64) != hipSuccess)
+    {
+        (void) hipGetLastError();
+        b->cv_buf = nullptr;
+        b->cv_cap = 0;
+        return LBFGSX_E_HIP;  // the caller simply keeps the vectors at their rows
+    }
+    return LBFGSX_OK;
+}
+// put the compact vectors back at their rows; assign: only what subvec_assign(drt, fv_set, vecy) needs (+ the state bytes)
+static int cv_back(lbfgsx_ctx* c, bool assign)
+{
+    lbfgsb_state* b = c->bstate;
+    if (!b->cv_live)
+        return LBFGSX_OK;
+    b->cv_live = false;
+    if (!assign)
+    {
+        b->cv_backs++;
+        g_cv_backs.fetch_add(1, std::memory_order_relaxed);
+    }
+    const int64_t npos = b->wf_n;
+    const int grid = std::max(1, std::min(c->grid_for(2 * npos), 1024));
+    DISPATCH_T(c, {
+        if (assign)
+            LBFGSX_LAUNCH((k_cv_back<T, 1>), dim3(grid), dim3(kBlock), 0, c->stream, bvecs<T>(c), bvecs_cv<T>(c), b->wf_idx, npos);
+        else
+            LBFGSX_LAUNCH((k_cv_back<T, 0>), dim3(grid), dim3(kBlock), 0, c->stream, bvecs<T>(c), bvecs_cv<T>(c), b->wf_idx, npos);
+    });
+    LBFGSX_HIP(hipGetLastError());
+    return LBFGSX_OK;
+}
 static int run_force_bounds(lbfgsx_ctx* c);
 // keep_force: the caller is the Cauchy build, which evaluates a deferred x = clamp(x) itself (lbfgsx_b_force_bounds_deferred);
 // every other entry of the bounded path runs it first
-static int need_bounded(lbfgsx_ctx* c, bool keep_force = false)
+// keep_cv: the caller is one of the fused sweep entries, which work on the compact vectors of the free rows; every other
+// entry gets them back at their rows first
+static int need_bounded(lbfgsx_ctx* c, bool keep_force = false, bool keep_cv = false)
 {
     if (!c->bstate)
     {
         set_error("this context was not created with LBFGSX_FLAG_BOUNDED");
         return LBFGSX_E_LOGIC;
+    }
+    if (c->bstate->cv_live && !keep_cv)
+    {
+        lbfgsx::DeviceGuard dev_guard_(c->device);
+        const int rc = cv_back(c, false);
+        if (rc)
+            return rc;
     }
     if (c->bstate->force_pending && !keep_force)
     {
@@ -268,6 +349,8 @@ int bounded_alloc(lbfgsx_ctx* c)
         b->vonly_groups = atoi(e);
     if (const char* e = getenv("LBFGSX_VROWS"))
         b->vrows = atoi(e) != 0;
+    if (const char* e = getenv("LBFGSX_COMPACT_VEC"))
+        b->cv_use = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_LU_MAX"))
         b->lu_max = std::max<int64_t>(0, atoll(e));
     if (const char* e = getenv("LBFGSX_GCP_PIECES"))
@@ -374,6 +457,7 @@ void bounded_free(lbfgsx_ctx* c)
         (void) hipHostFree(b->dout_host);
     if (b->gram_out_host)
         (void) hipHostFree(b->gram_out_host);
+    (void) hipFree(b->cv_buf);
     delete b;
     c->bstate = nullptr;
 }
@@ -1387,6 +1471,21 @@ int lbfgsx_b_sub_begin(lbfgsx_ctx* c)
     return LBFGSX_OK;
 }
 
+int lbfgsx_b_compact_vec_counts(int64_t out[2], int reset)
+{
+    if (out)
+    {
+        out[0] = g_cv_starts.load(std::memory_order_relaxed);
+        out[1] = g_cv_backs.load(std::memory_order_relaxed);
+    }
+    if (reset)
+    {
+        g_cv_starts = 0;
+        g_cv_backs = 0;
+    }
+    return LBFGSX_OK;
+}
+
 int lbfgsx_b_set_compaction(lbfgsx_ctx* c, int enable)
 {
     int rc = need_bounded(c);
@@ -1411,7 +1510,7 @@ int lbfgsx_b_wtv(lbfgsx_ctx* c, int vsel_id, int mask, double* out, int64_t* nnz
 int lbfgsx_b_wtv_lu(lbfgsx_ctx* c, double* out_l, int64_t* nnz_l, double* out_u, int64_t* nnz_u)
 {
     lbfgsx::DeviceGuard dev_guard_(c->device);
-    int rc = need_bounded(c);
+    int rc = need_bounded(c, false, /*keep_cv=*/true);
     if (rc)
         return rc;
     lbfgsb_state* b = c->bstate;
@@ -1431,21 +1530,24 @@ int lbfgsx_b_wtv_lu(lbfgsx_ctx* c, double* out_l, int64_t* nnz_l, double* out_u,
     DISPATCH_T(c, {
         Cols<T, 32> cl = col_list<T, 32>(c, which, total);
         BVecs<T> bv = bvecs<T>(c);
+        // the partition bits of the rows: at their positions while the compact vectors are live
+        const unsigned char* stc = b->cv_live ? bvecs_cv<T>(c).st : static_cast<const unsigned char*>(nullptr);
+        const int* stpos = b->cv_live ? b->wf_pos : static_cast<const int*>(nullptr);
         if (total <= 8)
         {
             nc = 8;
             LBFGSX_LAUNCH((k_multidot_list2<T, 8>), dim3(lgrid), dim3(kBlock), 0, c->stream, cl, total, bv, b->lu_ptr(), nl, c->ws,
-                               b->dout);
+                               b->dout, stc, stpos);
         }
         else if (total <= 16)
         {
             nc = 16;
             LBFGSX_LAUNCH((k_multidot_list2<T, 16>), dim3(lgrid), dim3(kBlock), 0, c->stream, cl, total, bv, b->lu_ptr(), nl,
-                               c->ws, b->dout);
+                               c->ws, b->dout, stc, stpos);
         }
         else
             LBFGSX_LAUNCH((k_multidot_list2<T, 24>), dim3(lgrid), dim3(kBlock), 0, c->stream, cl, total, bv, b->lu_ptr(), nl,
-                               c->ws, b->dout);
+                               c->ws, b->dout, stc, stpos);
     });
     LBFGSX_HIP(hipGetLastError());
     rc = fetch_doubles(c, 2 * (nc + 1), r);
@@ -1646,30 +1748,31 @@ static int launch_gram_vonly(lbfgsx_ctx* c, int64_t nbatch, int tot, int vsel_id
 // gram_out[r * (NC + 1) + j] and (hi, lo) pairs from gram_out + 256 on (host-mapped when the mapped outputs are on)
 template <class T, int NC, int NA>
 static int launch_vrows(lbfgsx_ctx* c, int tot, int vsel_id, int mask, const GramPrologue<T>& pro, const GramRows<T>& gr,
-                        int64_t nrows, int col_a, int col_b)
+                        int64_t nrows, int col_a, int col_b, const BVecs<T>* by_pos = nullptr)
 {
+    // by_pos: the compact vectors are live -- the rows of the compact copy in order, their vectors at the same positions
     lbfgsb_state* b = c->bstate;
     int which[32];
     for (int k = 0; k < tot; k++)
         which[k] = k;
-    Cols<T, 32> cl = gr.in_idx ? wf_cols<T>(c, tot) : col_list<T, 32>(c, which, tot);
+    Cols<T, 32> cl = (gr.in_idx || by_pos) ? wf_cols<T>(c, tot) : col_list<T, 32>(c, which, tot);
     // resident wave sets: two blocks per CU while the accumulators leave room for two waves per SIMD, else one
     const int per_cu = (NA == 1 && NC <= 20) ? 2 : 1;
     const int grid = std::max(1, std::min(std::min(c->grid_for(nrows), b->num_cus * per_cu), c->ws.maxGrid));
-    LBFGSX_LAUNCH((k_vrows<T, NC, NA>), dim3(grid), dim3(kBlock), 0, c->stream, cl, tot, bvecs<T>(c), vsel_id, mask, nrows,
-                  c->ws, b->gram_out, b->gram_out + 256, pro, gr, col_a, col_b);
+    LBFGSX_LAUNCH((k_vrows<T, NC, NA>), dim3(grid), dim3(kBlock), 0, c->stream, cl, tot, by_pos ? *by_pos : bvecs<T>(c), vsel_id,
+                  mask, nrows, c->ws, b->gram_out, b->gram_out + 256, pro, gr, col_a, col_b);
     LBFGSX_HIP(hipGetLastError());
     return LBFGSX_OK;
 }
 template <class T>
 static int launch_vrows_v(lbfgsx_ctx* c, int tot, int vsel_id, int mask, const GramPrologue<T>& pro, const GramRows<T>& gr,
-                          int64_t nrows)
+                          int64_t nrows, const BVecs<T>* by_pos = nullptr)
 {
-    if (tot <= 8) return launch_vrows<T, 8, 1>(c, tot, vsel_id, mask, pro, gr, nrows, 0, 0);
-    if (tot <= 16) return launch_vrows<T, 16, 1>(c, tot, vsel_id, mask, pro, gr, nrows, 0, 0);
-    if (tot <= 20) return launch_vrows<T, 20, 1>(c, tot, vsel_id, mask, pro, gr, nrows, 0, 0);
-    if (tot <= 24) return launch_vrows<T, 24, 1>(c, tot, vsel_id, mask, pro, gr, nrows, 0, 0);
-    return launch_vrows<T, 32, 1>(c, tot, vsel_id, mask, pro, gr, nrows, 0, 0);
+    if (tot <= 8) return launch_vrows<T, 8, 1>(c, tot, vsel_id, mask, pro, gr, nrows, 0, 0, by_pos);
+    if (tot <= 16) return launch_vrows<T, 16, 1>(c, tot, vsel_id, mask, pro, gr, nrows, 0, 0, by_pos);
+    if (tot <= 20) return launch_vrows<T, 20, 1>(c, tot, vsel_id, mask, pro, gr, nrows, 0, 0, by_pos);
+    if (tot <= 24) return launch_vrows<T, 24, 1>(c, tot, vsel_id, mask, pro, gr, nrows, 0, 0, by_pos);
+    return launch_vrows<T, 32, 1>(c, tot, vsel_id, mask, pro, gr, nrows, 0, 0, by_pos);
 }
 // the (hi, lo) outputs of k_vrows (and its rounded values) on the host: `count` doubles from gram_out + first
 static int fetch_gram_out(lbfgsx_ctx* c, int first, int count, double* h)
@@ -1736,7 +1839,7 @@ int lbfgsx_b_wtv_prologue(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, co
                           double* wtv)
 {
     lbfgsx::DeviceGuard dev_guard_(c->device);
-    int rc = need_bounded(c);
+    int rc = need_bounded(c, false, /*keep_cv=*/true);
     if (rc)
         return rc;
     lbfgsb_state* b = c->bstate;
@@ -1746,6 +1849,15 @@ int lbfgsx_b_wtv_prologue(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, co
     {
         set_error("lbfgsx_b_wtv_prologue: needs the default one-pass Gram, 1 <= 2c <= 30, a vector selector and a known prologue");
         return LBFGSX_E_INVALID;
+    }
+    // the compact vectors serve the pass between two sweeps: rhs += ..., v = -rhs on the P rows of the compact copy
+    const bool by_pos = b->cv_live && b->vrows && wf_serves(c, mask) && prologue != LBFGSX_GP_LINEAR &&
+                        (vsel_id == VS_NEG_RHS || vsel_id == VS_NEG_CF || vsel_id == VS_Y);
+    if (b->cv_live && !by_pos)
+    {
+        rc = cv_back(c, false);
+        if (rc)
+            return rc;
     }
     const bool compact = wf_serves(c, mask);
     const int64_t nrows = compact ? b->wf_n : c->n;
@@ -1765,11 +1877,12 @@ int lbfgsx_b_wtv_prologue(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, co
             pro.c2[k] = (coef2 && k < tot) ? T(coef2[k]) : T(0);
         }
         GramRows<T> gr{};
-        gr.in_idx = compact ? b->wf_idx : nullptr;
+        gr.in_idx = (compact && !by_pos) ? b->wf_idx : nullptr;
         gr.vgroups = b->vonly_groups;
         if (b->vrows)
         {
-            rc = launch_vrows_v<T>(c, tot, vsel_id, mask, pro, gr, nrows);
+            const BVecs<T> cvb = bvecs_cv<T>(c);
+            rc = launch_vrows_v<T>(c, tot, vsel_id, mask, pro, gr, nrows, by_pos ? &cvb : nullptr);
             blocks = 0;
         }
         // the tile row stride must hold ntot columns: the strides of the full kernel's KP classes
@@ -2050,12 +2163,20 @@ int lbfgsx_b_gram_fused_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
 static int gram_dd_core(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, const double* coef1, const double* coef2,
                         double* gram, double* wtv, double* gram_dd, const int* list, int64_t nlist)
 {
-    int rc = need_bounded(c);
+    int rc = need_bounded(c, false, /*keep_cv=*/true);  // the walk over the L u U list reads the partition bits where they are
     if (rc)
         return rc;
     lbfgsb_state* b = c->bstate;
     const int tot = 2 * c->ncorr;
     const int ntot = tot + (vsel_id >= 0 ? 1 : 0);
+    const bool lu_walk = !list && b->lu_valid && b->lu_use && vsel_id < 0 && prologue == LBFGSX_GP_NONE && mask != 0 &&
+                         (mask & ~(ST_L | ST_U)) == 0 && !b->gram_mfma;
+    if (b->cv_live && !lu_walk)
+    {
+        rc = cv_back(c, false);
+        if (rc)
+            return rc;
+    }
     if (prologue != LBFGSX_GP_NONE && (b->gram_mfma || prologue < 0 || prologue > LBFGSX_GP_LINEAR))
     {
         set_error("lbfgsx_b_gram_fused_ex: the prologue needs the default one-pass Gram");
@@ -2128,8 +2249,7 @@ static int gram_dd_core(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, cons
     // sweeps expected it also leaves the compact copy of the free rows (worth it when F leaves out a good part of the rows)
     if (list)
         mask = 0;
-    else if (b->lu_valid && b->lu_use && vsel_id < 0 && prologue == LBFGSX_GP_NONE && mask != 0 && (mask & ~(ST_L | ST_U)) == 0 &&
-             !b->gram_mfma)
+    else if (lu_walk)
     {
         // the complement Gram of a BOXCQP sweep (rows of L u U): walk the index list of the partition instead of the state
         // bytes of every (free) row; the mask stays, the list may hold rows of the other set
@@ -2189,6 +2309,11 @@ static int gram_dd_core(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, cons
         GramRows<T> gr{};
         gr.in_idx = list ? list : compact_in ? b->wf_idx : nullptr;
         gr.w_by_row = list ? 1 : 0;
+        if (b->cv_live)  // lu_walk
+        {
+            gr.st_alt = bvecs_cv<T>(c).st;
+            gr.st_pos = b->wf_pos;
+        }
         if (compact_out)
         {
             gr.out_w = static_cast<T*>(b->wf);
@@ -2401,20 +2526,52 @@ static int solve_sweep_t(lbfgsx_ctx* c, int first, int vsel_id, const double* co
     for (int k = 0; k < total; k++)
         which[k] = k;
     // the rows this pass acts on are the free rows: from their compact copy when the Gram pass before it left one
+    lbfgsb_state* b = c->bstate;
     const bool compact = wf_serves(c, ST_FREE);
-    const int64_t nrows = compact ? c->bstate->wf_n : c->n;
-    const int* ridx = compact ? c->bstate->wf_idx : nullptr;
+    const int64_t nrows = compact ? b->wf_n : c->n;
+    const int* ridx = compact ? b->wf_idx : nullptr;
     Cols<T, 32> cl = compact ? wf_cols<T>(c, total) : col_list<T, 32>(c, which, total);
     CoefArg<T> cf;
     for (int k = 0; k < 80; k++)
         cf.c[k] = (coef && k < total) ? T(coef[k]) : T(0);
-    const int grid = std::min(c->grid_for(nrows), c->bstate->dots_grid);
+    const int grid = std::min(c->grid_for(nrows), b->dots_grid);
+    // compact vectors: the first solve over the compact copy starts them (when an index list of L u U will let the sweeps
+    // that follow stay on the fused path), the later solves use them
+    int cv = 0;
     if (first)
-        LBFGSX_LAUNCH((k_solve_sweep<T, NC, 1>), dim3(grid), dim3(kBlock), 0, c->stream, cl, total, bvecs<T>(c), vsel_id, cf,
-                           coef ? 1 : 0, T(theta), nrows, c->ws, c->bstate->dout, lu_dst, c->bstate->lu_cnt, lu_cap_now, ridx);
+    {
+        b->cv_live = false;
+        if (compact && b->cv_use && lu_cap_now > 0 && (vsel_id == VS_NEG_CF || vsel_id == VS_NEG_RHS || vsel_id == VS_Y) &&
+            cv_alloc(c) == LBFGSX_OK)
+            cv = 1;
+    }
+    else if (b->cv_live)
+    {
+        if (compact && (vsel_id == VS_NEG_CF || vsel_id == VS_NEG_RHS || vsel_id == VS_Y))
+            cv = 2;
+        else
+        {
+            const int rcb = cv_back(c, false);
+            if (rcb)
+                return rcb;
+        }
+    }
+    T* cli = nullptr;
+    T* cui = nullptr;
+    const BVecs<T> full = bvecs<T>(c);
+    const BVecs<T> cvb = cv ? bvecs_cv<T>(c, &cli, &cui) : full;
+    if (first)
+        LBFGSX_LAUNCH((k_solve_sweep<T, NC, 1>), dim3(grid), dim3(kBlock), 0, c->stream, cl, total, full, cvb, vsel_id, cf,
+                      coef ? 1 : 0, T(theta), nrows, c->ws, b->dout, lu_dst, b->lu_cnt, lu_cap_now, ridx, cli, cui, cv);
     else
-        LBFGSX_LAUNCH((k_solve_sweep<T, NC, 0>), dim3(grid), dim3(kBlock), 0, c->stream, cl, total, bvecs<T>(c), vsel_id, cf,
-                           coef ? 1 : 0, T(theta), nrows, c->ws, c->bstate->dout, lu_dst, c->bstate->lu_cnt, lu_cap_now, ridx);
+        LBFGSX_LAUNCH((k_solve_sweep<T, NC, 0>), dim3(grid), dim3(kBlock), 0, c->stream, cl, total, cv ? cvb : full, cvb, vsel_id, cf,
+                      coef ? 1 : 0, T(theta), nrows, c->ws, b->dout, lu_dst, b->lu_cnt, lu_cap_now, ridx, cli, cui, cv);
+    if (cv == 1)
+    {
+        b->cv_live = true;
+        b->cv_starts++;
+        g_cv_starts.fetch_add(1, std::memory_order_relaxed);
+    }
     LBFGSX_HIP(hipGetLastError());
     const int nd = first ? 0 : NC;
     double r[NC + 7];
@@ -2433,7 +2590,7 @@ extern "C" {
 int lbfgsx_b_solve_sweep(lbfgsx_ctx* c, int first, int vsel_id, const double* coef, double theta, double* wty, int64_t sums[7])
 {
     lbfgsx::DeviceGuard dev_guard_(c->device);
-    int rc = need_bounded(c);
+    int rc = need_bounded(c, false, /*keep_cv=*/first == 0);
     if (rc)
         return rc;
     lbfgsb_state* b = c->bstate;
@@ -2497,7 +2654,7 @@ int lbfgsx_b_solve_sweep(lbfgsx_ctx* c, int first, int vsel_id, const double* co
 int lbfgsx_b_lu_sweep(lbfgsx_ctx* c, const double* coef, double theta, int64_t sums[7])
 {
     lbfgsx::DeviceGuard dev_guard_(c->device);
-    int rc = need_bounded(c);
+    int rc = need_bounded(c, false, /*keep_cv=*/true);
     if (rc)
         return rc;
     lbfgsb_state* b = c->bstate;
@@ -2518,9 +2675,12 @@ int lbfgsx_b_lu_sweep(lbfgsx_ctx* c, const double* coef, double theta, int64_t s
         CoefArg<T> cf;
         for (int k = 0; k < 80; k++)
             cf.c[k] = (has_w && k < 2 * c->ncorr) ? T(coef[k]) : T(0);
-        LBFGSX_LAUNCH((k_lu_sweep<T>), dim3(grid), dim3(kBlock), 0, c->stream, bvecs<T>(c), P<T>(c->S), P<T>(c->Y), c->ld,
+        T* cli = nullptr;
+        T* cui = nullptr;
+        const BVecs<T> bv = b->cv_live ? bvecs_cv<T>(c, &cli, &cui) : bvecs<T>(c);
+        LBFGSX_LAUNCH((k_lu_sweep<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, P<T>(c->S), P<T>(c->Y), c->ld,
                            b->phys_dev, c->ncorr, cf, has_w, T(theta), b->lu_ptr(), nl, c->ws, b->dout, b->lu_other(), b->lu_cnt,
-                           b->lu_cap);
+                           b->lu_cap, b->cv_live ? b->wf_pos : static_cast<const int*>(nullptr), cli, cui);
     });
     LBFGSX_HIP(hipGetLastError());
     b->lu_valid = false;
@@ -2543,9 +2703,11 @@ int lbfgsx_b_lu_sweep(lbfgsx_ctx* c, const double* coef, double theta, int64_t s
 int lbfgsx_b_sub_op(lbfgsx_ctx* c, int op)
 {
     lbfgsx::DeviceGuard dev_guard_(c->device);
-    int rc = need_bounded(c);
+    int rc = need_bounded(c, false, /*keep_cv=*/op == SO_ASSIGN_Y);
     if (rc)
         return rc;
+    if (c->bstate->cv_live)  // op == SO_ASSIGN_Y: drt = vecy on the free rows, straight from the compact y
+        return cv_back(c, true);
     const int grid = c->grid_for(c->n);
     DISPATCH_T(c, {
         BVecs<T> bv = bvecs<T>(c);

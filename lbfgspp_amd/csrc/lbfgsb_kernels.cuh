@@ -331,15 +331,17 @@ __global__ void __launch_bounds__(kBlock) k_multidot_list(Cols<T, 32> cols, int 
 // statements SubspaceMin.h:236-241.  out = {L dots [NC], nnz_L, U dots [NC], nnz_U}.
 template <class T, int NC>
 __global__ void __launch_bounds__(kBlock) k_multidot_list2(Cols<T, 32> cols, int ncols, BVecs<T> b, const int* __restrict__ list,
-                                                           int nlist, RedWs ws, double* __restrict__ out)
+                                                           int nlist, RedWs ws, double* __restrict__ out,
+                                                           const unsigned char* __restrict__ stc, const int* __restrict__ pos)
 {
+    // stc, pos: the partition bits live with the compact vectors (k_solve_sweep): row i -> stc[pos[i]]
     typedef typename AccOf<T>::type A;
     A acc[2 * (NC + 1)];
     const int stride = int(gridDim.x) * kBlock;
     for (int t = int(blockIdx.x) * kBlock + threadIdx.x; t < nlist; t += stride)
     {
         const int64_t i = list[t];
-        const unsigned char st = b.st[i];
+        const unsigned char st = stc ? stc[pos[i]] : b.st[i];
         if (!(st & (ST_L | ST_U)))
             continue;
         const bool isl = (st & ST_L) != 0;
@@ -721,6 +723,9 @@ struct GramRows
     int fresh_a, fresh_b;         // their tile columns
     const T *src_a, *src_b;
     T *dst_a, *dst_b;
+    // the partition bits live with the compact vectors (k_solve_sweep): state byte of row r = st_alt[st_pos[r]]
+    const unsigned char* st_alt;
+    const int* st_pos;
 };
 
 // Rows that entered the free set and have no position in the kept compact copy yet (GramRows) are appended to it: all 2c
@@ -904,7 +909,13 @@ __global__ void __launch_bounds__(kBlock) k_gram_dd(Cols<T, 32> cols, int ncols,
     for (int u = 0; u < 4; u++)
     {
         const int64_t ru = (bt0 + u * nwaves) * kGramDDRows + lane;
-        st4[u] = (mask && ru < n) ? b.st[gr.in_idx ? int64_t(gr.in_idx[ru]) : ru] : (unsigned char) 0;
+        if (mask && ru < n)
+        {
+            const int64_t rw = gr.in_idx ? int64_t(gr.in_idx[ru]) : ru;
+            st4[u] = gr.st_alt ? gr.st_alt[gr.st_pos[rw]] : b.st[rw];
+        }
+        else
+            st4[u] = (unsigned char) 0;
     }
 #pragma unroll
     for (int u = 0; u < 4; u++)
@@ -1840,11 +1851,19 @@ __device__ __forceinline__ unsigned char sweep_row_v(const BVecs<T>& b, int64_t 
     b.st[i] = s;
     return s;
 }
+// Compact vectors (cv, round 3).  While a subspace minimisation sweeps, the free set F is fixed and every pass walks the
+// compact copy of its rows -- but y, rhs, the multipliers, the partition bits, cF and the bounds of a row sat at the row's
+// own index: gathered with half of every cache line used, written back as partial lines.  From the first solve on they
+// live at the row's POSITION t instead (lbfgsb_state::cv_*, contiguous), until the minimisation assigns its result
+// (k_cv_assign) or leaves the fused path (k_cv_scatter puts them back).  cv = 0: vectors by row, as before (b = bw);
+// cv = 1 (FIRST only): this pass starts it -- reads by row through b, writes by position through bw, cF, lb - x0, ub - x0
+// and the state byte of every position included; cv = 2: reads and writes by position (b = bw = the compact set),
+// lb - x0 / ub - x0 from cli / cui, the row number only fetched for a row that enters the L u U list.
 template <class T, int NC, int FIRST>
-__global__ void __launch_bounds__(kBlock, NC <= 24 ? 2 : 1) k_solve_sweep(Cols<T, 32> cols, int ncols, BVecs<T> b, int vsel_id, CoefArg<T> coef,
-                                                        int has_w, T theta, int64_t n, RedWs ws, double* __restrict__ out,
+__global__ void __launch_bounds__(kBlock, NC <= 24 ? 2 : 1) k_solve_sweep(Cols<T, 32> cols, int ncols, BVecs<T> b, BVecs<T> bw, int vsel_id,
+                                                        CoefArg<T> coef, int has_w, T theta, int64_t n, RedWs ws, double* __restrict__ out,
                                                         int* __restrict__ lu_list, unsigned* __restrict__ lu_cnt, unsigned lu_cap,
-                                                        const int* __restrict__ ridx)
+                                                        const int* __restrict__ ridx, T* __restrict__ cli, T* __restrict__ cui, int cv)
 {
     // ridx: `cols` is the compact copy of the free rows (GramRows): n of them, row t of the columns = row ridx[t] of the vectors
     typedef typename AccOf<T>::type A;
@@ -1866,22 +1885,37 @@ __global__ void __launch_bounds__(kBlock, NC <= 24 ? 2 : 1) k_solve_sweep(Cols<T
     case VS_UBOUND: va_p = b.ub; vb_p = b.x0; vkind = 2; break;
     default: va_p = b.y; vb_p = b.y; vkind = 0; break;
     }
+    const bool cvt = cv == 2;
+    // lb - x0, ub - x0: two values by position, or three by row (one pointer set per launch: every load unconditional)
+    const T* la_p = cvt ? cli : b.lb;
+    const T* ua_p = cvt ? cui : b.ub;
     A dots[ND ? ND : 1];
     unsigned cnt[7] = {0, 0, 0, 0, 0, 0, 0};
     const int64_t stride = int64_t(gridDim.x) * kBlock;
     for (int64_t t = int64_t(blockIdx.x) * kBlock + threadIdx.x; t < n; t += stride)
     {
         int64_t i = t;
-        if (ridx)
+        if (ridx && !cvt)
             i = ridx[t];
-        const unsigned char st0 = b.st[i];
+        const int64_t ir = cvt ? t : i;  // where this pass reads the vectors of the row
+        const int64_t iw = cv ? t : i;   // ... and writes them
+        const unsigned char st0 = b.st[ir];
         T w[NC];
 #pragma unroll
         for (int k = 0; k < NC; k++)
             w[k] = cols.p[k][t];
-        const T xa = va_p[i], xb = vb_p[i];
-        const T yold = FIRST ? T(0) : b.y[i];  // the first solve writes every free row: nothing to keep
-        const T lbi = b.lb[i], ubi = b.ub[i], x0i = b.x0[i], cfi = b.cF[i];
+        const T xa = va_p[ir], xb = vb_p[ir];
+        const T yold = FIRST ? T(0) : b.y[ir];  // the first solve writes every free row: nothing to keep
+        const T la = la_p[ir], ua = ua_p[ir], x0i = b.x0[i], cfi = b.cF[ir];
+        const T li = cvt ? la : la - x0i, ui = cvt ? ua : ua - x0i;
+        if (cv == 1)  // every position gets its constants, free or not
+        {
+            cli[t] = li;
+            cui[t] = ui;
+            bw.cF[t] = cfi;
+            if (!(st0 & ST_FREE))
+                bw.st[t] = st0;
+        }
         if (!(st0 & ST_FREE))
             continue;
         const bool solve = FIRST || (st0 & ST_P);
@@ -1898,7 +1932,7 @@ __global__ void __launch_bounds__(kBlock, NC <= 24 ? 2 : 1) k_solve_sweep(Cols<T
             }
             const T v = vkind == 0 ? xa : vkind == 1 ? -xa : xa - xb;
             yi = has_w ? (v / theta + a / theta2) : (v / theta);
-            b.y[i] = yi;
+            bw.y[iw] = yi;
         }
         if (!FIRST)
         {
@@ -1910,11 +1944,16 @@ __global__ void __launch_bounds__(kBlock, NC <= 24 ? 2 : 1) k_solve_sweep(Cols<T
         if (solve)
         {
             // a P row's multipliers are zero (the sweep that made it P stored them); the first sweep sets them
-            const unsigned char s2 = sweep_row_v<T>(b, i, st0, yi, T(0), T(0), FIRST != 0, FIRST != 0, cnt, lbi - x0i, ubi - x0i, cfi);
+            const unsigned char s2 = sweep_row_v<T>(bw, iw, st0, yi, T(0), T(0), FIRST != 0, FIRST != 0, cnt, li, ui, cfi);
             app = (s2 & (ST_L | ST_U)) != 0;
         }
         if (lu_cap)
-            lu_append(app, i, lu_list, lu_cnt, lu_cap);
+        {
+            int64_t irow = i;
+            if (cvt && app)
+                irow = ridx[t];  // the list holds rows
+            lu_append(app, irow, lu_list, lu_cnt, lu_cap);
+        }
     }
     A acc[ND + 7];
 #pragma unroll
@@ -1939,8 +1978,10 @@ template <class T>
 __global__ void __launch_bounds__(kBlock) k_lu_sweep(BVecs<T> b, const T* __restrict__ S, const T* __restrict__ Y, int64_t ld,
                                                      const int* __restrict__ phys, int ncorr, CoefArg<T> coef, int has_w, T theta,
                                                      const int* __restrict__ list, int nlist, RedWs ws, double* __restrict__ out,
-                                                     int* __restrict__ lu_list, unsigned* __restrict__ lu_cnt, unsigned lu_cap)
+                                                     int* __restrict__ lu_list, unsigned* __restrict__ lu_cnt, unsigned lu_cap,
+                                                     const int* __restrict__ pos, const T* __restrict__ cli, const T* __restrict__ cui)
 {
+    // pos: the compact vectors are live (k_solve_sweep): b holds them, row i of the list sits at position pos[i]
     typedef typename AccOf<T>::type A;
     __shared__ T sc[80];
     __shared__ int sp[40];
@@ -1954,21 +1995,24 @@ __global__ void __launch_bounds__(kBlock) k_lu_sweep(BVecs<T> b, const T* __rest
     for (int64_t t = int64_t(blockIdx.x) * kBlock + threadIdx.x; t < int64_t(nlist); t += stride)
     {
         const int64_t i = int64_t(list[t]);
-        unsigned char s = b.st[i];
+        const int64_t iv = pos ? int64_t(pos[i]) : i;
+        unsigned char s = b.st[iv];
         if (!(s & (ST_L | ST_U)))
             continue;
         T a = T(0);
         if (has_w)
             for (int j = 0; j < ncorr; j++)
                 a = a + (sc[j] * Y[int64_t(sp[j]) * ld + i] + sc[ncorr + j] * S[int64_t(sp[j]) * ld + i]);
-        const T yi = b.y[i];
-        const T r = (T(-1) * a) + (b.cF[i] + theta * yi);
-        T lam = b.lam[i], mu = b.mu[i];
+        const T yi = b.y[iv];
+        const T cfi = b.cF[iv];
+        const T r = (T(-1) * a) + (cfi + theta * yi);
+        T lam = b.lam[iv], mu = b.mu[iv];
         if (s & ST_L)
             lam = r;
         if (s & ST_U)
             mu = -r;
-        s = sweep_row<T>(b, i, s, yi, lam, mu, false, true, cnt);
+        const T li = pos ? cli[iv] : b.lb[i] - b.x0[i], ui = pos ? cui[iv] : b.ub[i] - b.x0[i];
+        s = sweep_row_v<T>(b, iv, s, yi, lam, mu, false, true, cnt, li, ui, cfi);
         if (lu_cap)
             lu_append((s & (ST_L | ST_U)) != 0, i, lu_list, lu_cnt, lu_cap);
     }
@@ -2024,6 +2068,33 @@ __global__ void __launch_bounds__(kBlock) k_sub_op(BVecs<T> b, int op, int64_t n
             break;
         }
         default: b.drt[i] = b.yfb[i]; break;
+        }
+    }
+}
+
+// The compact vectors go back to where the rest of the path expects them.  ASSIGN: subvec_assign(drt, fv_set, vecy)
+// (SubspaceMin.h:164, :279, :301) straight from the compact y; the state bytes follow.  Otherwise (the minimisation leaves
+// the fused path: a fallback pass, the ladder of :276-296): y, yfallback, the multipliers, rhs and the state bytes.
+template <class T, int ASSIGN>
+__global__ void __launch_bounds__(kBlock) k_cv_back(BVecs<T> full, BVecs<T> cvb, const int* __restrict__ idx, int64_t npos)
+{
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t t = int64_t(blockIdx.x) * kBlock + threadIdx.x; t < npos; t += stride)
+    {
+        const unsigned char s = cvb.st[t];
+        if (!(s & ST_FREE))
+            continue;
+        const int64_t r = idx[t];
+        full.st[r] = s;
+        if (ASSIGN)
+            full.drt[r] = cvb.y[t];
+        else
+        {
+            full.y[r] = cvb.y[t];
+            full.yfb[r] = cvb.yfb[t];
+            full.lam[r] = cvb.lam[t];
+            full.mu[r] = cvb.mu[t];
+            full.rhs[r] = cvb.rhs[t];
         }
     }
 }

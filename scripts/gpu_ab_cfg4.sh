@@ -6,8 +6,8 @@ run() { env "$@" python scripts/bench_lbfgsb.py --n 1e7 --iters 40 2>/dev/null |
 import json,sys
 d=json.loads(sys.stdin.read()); print('$*: from x0 %.1f steady %.1f sweeps %d fx %.17g' % (d['it_per_s'], d['steady_it_per_s'], d['stats']['submin_sweeps'], d.get('fx', 0)))"; }
 for rep in 1 2; do
-run LBFGSX_FORCE_FUSE=0
-run LBFGSX_FORCE_FUSE=1
+run LBFGSX_COMPACT_VEC=0
+run LBFGSX_COMPACT_VEC=1
 done
 timeout 900 python -m pytest tests/test_lbfgsb_gpu.py tests/test_gcp_device_gpu.py -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.log
 rocprofv3 --kernel-trace --output-format csv -d $O/t -o b -- python scripts/bench_lbfgsb.py --n 1e7 --iters 40 > $O/run.json 2> $O/run.err

@@ -388,6 +388,53 @@ def test_compact_copy_of_the_free_rows_changes_no_bit(A, monkeypatch, n, m, max_
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("n,m,max_submin,leave", [(70001, 8, 10, False), (70001, 10, 2, False), (65536, 3, 10, False),
+                                                 (90000, 14, 10, False), (120000, 10, 10, True)])
+def test_compact_vectors_of_the_free_rows_change_no_bit(A, monkeypatch, n, m, max_submin, leave, dtype):
+    """While the BOXCQP sweeps walk the compact copy, vecy / yfallback / lambda / mu / rhs / c_F / l - x0 / u - x0 and the
+    partition bits of the free rows sit at the rows' positions (lbfgsx_b_compact_vec_counts) instead of at the rows
+    (LBFGSX_COMPACT_VEC=0): the same statements on the same values, so the same trajectory bit for bit and the same sweep
+    counts; the compact form must have run.  Without the complement identity (LBFGSX_GRAM_COMPLEMENT=0) the second solve
+    of a minimisation is a masked Gram pass over the rows: the vectors go back to their rows in the middle of the
+    minimisation -- also without a changed bit."""
+    import ctypes as C
+    from lbfgspp_amd import _lib
+    core, _ = _lib.load()
+    iters = 25
+    dt = O.F64 if dtype == "f64" else O.F32
+    npdt = O.NPDT[dt]
+    a, b = O.quad_problem(n, 30.0, 9, dt)
+    if leave:
+        monkeypatch.setenv("LBFGSX_GRAM_COMPLEMENT", "0")
+    res = {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("LBFGSX_COMPACT_VEC", on)
+        core.lbfgsx_b_compact_vec_counts(None, 1)
+        s = A.LBFGSBSolver(A.LBFGSBParam(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters, max_submin=max_submin),
+                           dtype=npdt)
+        tr = A.TraceBuffer(n, cap=256, stride=17)
+        x = np.zeros(n, dtype=npdt)
+        try:
+            niter, fx = s.minimize(A.DiagQuadratic(a, b), x, (-0.7 * np.ones(n)).astype(npdt), (0.9 * np.ones(n)).astype(npdt),
+                                   trace=tr)
+        except RuntimeError:
+            niter, fx = -1, float("nan")
+        st = s.stats()
+        cnt = (C.c_int64 * 2)()
+        core.lbfgsx_b_compact_vec_counts(C.byref(cnt), 0)
+        res[on] = (niter, s.last.nfev, x.copy(), tr.xs[:tr.count].copy(), st["submin_sweeps"], st["submin_unconverged"],
+                   st["submin_fused_sweeps"], (cnt[0], cnt[1]))
+    f, u = res["1"], res["0"]
+    assert f[:2] == u[:2] and f[4:7] == u[4:7] and f[4] > 0
+    assert np.array_equal(f[2], u[2]) and np.array_equal(f[3], u[3])
+    assert u[7] == (0, 0) and f[7][0] > 0
+    if leave:
+        assert f[7][1] > 0
+    else:
+        assert f[7][1] <= f[7][0]
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("n,m,iters,age", [(70001, 8, 60, 32), (70001, 10, 45, 32), (65536, 3, 40, 32), (90000, 12, 20, 32),
                                            (200000, 10, 80, 32), (70001, 8, 40, 2), (120000, 10, 40, 5), (65536, 5, 40, 3)])
 def test_carried_gram_of_the_free_set_changes_no_bit(A, monkeypatch, n, m, iters, age, dtype):
