@@ -339,9 +339,13 @@ int lbfgsx_b_set_compaction(lbfgsx_ctx* c, int enable);
  * partition bits of the free rows (SubspaceMin.h:159-268) sit at the rows' POSITIONS in the copy (contiguous) instead of at
  * the rows; lbfgsx_b_sub_op(LBFGSX_SO_ASSIGN_Y) assigns the result from there, any other entry of the bounded path first
  * puts them back at their rows.  Same statements on the same values: no bit changes.  LBFGSX_COMPACT_VEC=0 keeps the
- * vectors at their rows.  Instrumentation, process-wide: out = {minimisations that ran on compact vectors, times they were
- * put back before the result was assigned}. */
-int lbfgsx_b_compact_vec_counts(int64_t out[2], int reset);
+ * vectors at their rows.
+ * The kept copy also serves the Cauchy search (round 3): p = W'd (Cauchy.h:152) and the deferred dots of add_correction
+ * (BFGSMat.h:111,138) are sums over the rows where d or s_new is not zero -- the positions of the copy plus a short list of
+ * other rows that lbfgsx_b_cauchy_build* writes on its way -- instead of over all n rows (LBFGSX_WTD_COMPACT=0: all rows).
+ * Instrumentation, process-wide: out = {minimisations that ran on compact vectors, times they were put back before the
+ * result was assigned, Cauchy searches whose W'd came from the copy}. */
+int lbfgsx_b_compact_vec_counts(int64_t out[3], int reset);
 /* A BOXCQP solve and the statements of lbfgsx_b_sub_sweep_begin on the rows it writes, in ONE pass (the solve's row of W is
  * in registers; the sweep's pass over n rows disappears).  Bit for bit lbfgsx_b_wcombine(LBFGSX_CB_SOLVE) /
  * lbfgsx_b_solve_wty followed by lbfgsx_b_sub_sweep_begin.

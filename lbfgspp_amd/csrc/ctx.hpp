@@ -33,20 +33,38 @@ struct Counters
     std::atomic<int64_t> launches{0}, syncs{0}, copies{0};
 };
 Counters& counters();  // lbfgsx.hip
+// Host-side timeline (LBFGSX_HOST_TRACE=<file>): one line "<ns> <tag>" per launch (tag = the kernel expression), copy
+// and synchronisation (">sync" when the wait starts, "<sync" when it returns), written when the process ends.  What
+// scripts/host_trace.py turns into "host time between a wait and the next launch".  Off: one relaxed load per event.
+bool host_trace_on();                // lbfgsx.hip
+void host_trace(const char* tag);    // lbfgsx.hip
 inline hipError_t stream_sync(hipStream_t s)
 {
     counters().syncs.fetch_add(1, std::memory_order_relaxed);
+    if (host_trace_on())
+    {
+        host_trace(">sync");
+        const hipError_t e = hipStreamSynchronize(s);
+        host_trace("<sync");
+        return e;
+    }
     return hipStreamSynchronize(s);
 }
 inline hipError_t copy_async(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s)
 {
     counters().copies.fetch_add(1, std::memory_order_relaxed);
+    if (host_trace_on())
+        host_trace(kind == hipMemcpyDeviceToHost ? "copy_d2h" : kind == hipMemcpyHostToDevice ? "copy_h2d" : "copy");
     return hipMemcpyAsync(dst, src, bytes, kind, s);
 }
+#define LBFGSX_FIRST_STR_(first, ...) #first
+#define LBFGSX_FIRST_STR(...) LBFGSX_FIRST_STR_(__VA_ARGS__, 0)
 #define LBFGSX_LAUNCH(...)                                                        \
     do                                                                            \
     {                                                                             \
         lbfgsx::counters().launches.fetch_add(1, std::memory_order_relaxed);      \
+        if (lbfgsx::host_trace_on())                                              \
+            lbfgsx::host_trace(LBFGSX_FIRST_STR(__VA_ARGS__));                    \
         hipLaunchKernelGGL(__VA_ARGS__);                                          \
     } while (0)
 

@@ -31,6 +31,7 @@ struct lbfgsb_state
     double* dout_host = nullptr;      //   (LBFGSX_MAPPED_OUT=0) plain device memory fetched by a copy
     double* gram_out_host = nullptr;  // same for gram_out
     double* gram_dd = nullptr;        // [3][256][2] un-rounded (hi, lo) sums of the last one-pass Gram (device)
+    double* gram_dd_host = nullptr;   // ... host-mapped when the mapped outputs are on (gram_dd is then its device alias)
     void* coef_dev = nullptr;         // T[80]
     // index list of the rows the last BOXCQP partition put into L or U (k_sub_sweep_begin); lu_valid: it describes the
     // current state bytes (any other writer of ST_L / ST_U clears it)
@@ -63,6 +64,13 @@ struct lbfgsb_state
     // compact vectors of a subspace minimisation (lbfgsb_kernels.cuh "cv"): y, yfallback, lambda, mu, rhs, cF, lb - x0,
     // ub - x0 and the state byte of the free rows at their POSITION in the compact copy, from the first solve-sweep until
     // the result is assigned (or a pass outside the fused path needs them by row again: cv_back)
+    // W'd of the Cauchy search (and the deferred dots of add_correction) from the kept compact copy (k_multidot2_wf)
+    bool wtdc_use = true;                 // LBFGSX_WTD_COMPACT=0: always the pass over the full-length columns
+    int* wtdc_list = nullptr;             // rows outside the copy with d != 0 or s_new != 0 (k_cauchy_build)
+    unsigned* wtdc_cnt = nullptr;
+    unsigned wtdc_cap = 1u << 16;
+    int64_t wtdc_n = -1;                  // entries of the list of this iteration's build; -1: none
+    int64_t wtdc_runs = 0;
     bool cv_use = true;                   // LBFGSX_COMPACT_VEC=0: the vectors stay at their rows
     bool cv_live = false;
     void* cv_buf = nullptr;               // 8 vectors of cv_cap elements + cv_cap state bytes
@@ -180,7 +188,7 @@ static BVecs<T> bvecs(lbfgsx_ctx* c)
 
 // instrumentation, process-wide: {subspace minimisations that ran on compact vectors, times they went back to their rows
 // before the minimisation assigned its result}
-static std::atomic<int64_t> g_cv_starts{0}, g_cv_backs{0};
+static std::atomic<int64_t> g_cv_starts{0}, g_cv_backs{0}, g_wtdc_runs{0};
 // the vectors of the free rows by POSITION (cv_buf): what the fused sweep kernels are handed while cv_live
 template <class T>
 static BVecs<T> bvecs_cv(lbfgsx_ctx* c, T** cli = nullptr, T** cui = nullptr)
@@ -351,6 +359,10 @@ int bounded_alloc(lbfgsx_ctx* c)
         b->vrows = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_COMPACT_VEC"))
         b->cv_use = atoi(e) != 0;
+    if (const char* e = getenv("LBFGSX_WTD_COMPACT"))
+        b->wtdc_use = atoi(e) != 0;
+    if (const char* e = getenv("LBFGSX_WTD_LIST_CAP"))  // test aid: a short list overflows
+        b->wtdc_cap = unsigned(std::max(1, std::min(1 << 20, atoi(e))));
     if (const char* e = getenv("LBFGSX_LU_MAX"))
         b->lu_max = std::max<int64_t>(0, atoll(e));
     if (const char* e = getenv("LBFGSX_GCP_PIECES"))
@@ -400,14 +412,19 @@ int bounded_alloc(lbfgsx_ctx* c)
     }
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->gram_partial), sizeof(double) * size_t(b->gram_blocks) * 3 * 256 * 2));
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->gram_partial2), sizeof(double) * 32 * 3 * 256 * 2));
-    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->gram_dd), sizeof(double) * 3 * 256 * 2));
     if (c->outmap_dev)
     {
+        // the (hi, lo) sums land where the host reads them: a copy into pageable memory is staged and costs ~20 us a fetch
+        LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->gram_dd_host), sizeof(double) * 3 * 256 * 2, hipHostMallocMapped));
+        LBFGSX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->gram_dd), b->gram_dd_host, 0));
         LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->gram_out_host), sizeof(double) * 3 * 256, hipHostMallocMapped));
         LBFGSX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->gram_out), b->gram_out_host, 0));
     }
     else
+    {
         LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->gram_out), sizeof(double) * 3 * 256));
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->gram_dd), sizeof(double) * 3 * 256 * 2));
+    }
     b->sort_tmp_bytes = bytes;
     LBFGSX_HIP(hipMalloc(&b->sort_tmp, bytes ? bytes : 16));
     return LBFGSX_OK;
@@ -429,6 +446,8 @@ void bounded_free(lbfgsx_ctx* c)
         (void) hipHostFree(b->g_host);
     (void) hipFree(b->lu_list);
     (void) hipFree(b->wf_pos);
+    (void) hipFree(b->wtdc_list);
+    (void) hipFree(b->wtdc_cnt);
     for (hipEvent_t ev : b->chain_ev)
         if (ev)
             (void) hipEventDestroy(ev);
@@ -449,7 +468,7 @@ void bounded_free(lbfgsx_ctx* c)
     for (void* p : ptrs)
     {
         // dout / gram_out are device aliases of host-mapped memory when the mapped outputs are on
-        if ((p == b->dout && b->dout_host) || (p == b->gram_out && b->gram_out_host))
+        if ((p == b->dout && b->dout_host) || (p == b->gram_out && b->gram_out_host) || (p == b->gram_dd && b->gram_dd_host))
             continue;
         (void) hipFree(p);
     }
@@ -457,6 +476,8 @@ void bounded_free(lbfgsx_ctx* c)
         (void) hipHostFree(b->dout_host);
     if (b->gram_out_host)
         (void) hipHostFree(b->gram_out_host);
+    if (b->gram_dd_host)
+        (void) hipHostFree(b->gram_dd_host);
     (void) hipFree(b->cv_buf);
     delete b;
     c->bstate = nullptr;
@@ -692,11 +713,91 @@ static int wtd2_all(lbfgsx_ctx* c, int total, const T* snew, const T* dvec, doub
     c->bstate->corr_stash_valid = true;
     return LBFGSX_OK;
 }
+// the same from the kept compact copy: its positions, then the short list of rows outside it (k_multidot2_wf)
+template <class T, int NC>
+static int wtd2_wf(lbfgsx_ctx* c, int total, int newest, double* wtd)
+{
+    lbfgsb_state* b = c->bstate;
+    int rc = upload_phys(c);
+    if (rc)
+        return rc;
+    int which[32];
+    for (int k = 0; k < total; k++)
+        which[k] = k;
+    Cols<T, 32> full = col_list<T, 32>(c, which, total);
+    Cols<T, 32> wfc = wf_cols<T>(c, total);
+    const int fresh_a = newest, fresh_b = c->ncorr + newest;
+    const int stand_in = (newest == 0) ? 1 : 0;  // another Y column of the copy: read anyway, so the stale pair costs nothing
+    wfc.p[fresh_a] = wfc.p[stand_in];
+    wfc.p[fresh_b] = wfc.p[stand_in];
+    const T* snew = static_cast<const T*>(c->col(c->S, c->phys[size_t(newest)]));
+    const T* ynew = static_cast<const T*>(c->col(c->Y, c->phys[size_t(newest)]));
+    const int grid = std::max(1, std::min(std::min(c->grid_for(b->wf_n), b->num_cus), c->ws.maxGrid));
+    LBFGSX_LAUNCH((k_multidot2_wf<T, NC>), dim3(grid), dim3(kBlock), 0, c->stream, wfc, fresh_a, fresh_b, snew, ynew,
+                  static_cast<const T*>(b->dvec), b->wf_idx, b->wf_n, full, b->wtdc_list, int(b->wtdc_n), c->ws, b->dout);
+    LBFGSX_HIP(hipGetLastError());
+    double r[2 * NC];
+    rc = fetch_doubles(c, 2 * NC, r);
+    if (rc)
+        return rc;
+    for (int k = 0; k < total; k++)
+    {
+        b->corr_raw[k] = r[k];
+        wtd[k] = r[NC + k];
+    }
+    b->corr_stash_valid = true;
+    b->wtdc_runs++;
+    g_wtdc_runs.fetch_add(1, std::memory_order_relaxed);
+    return LBFGSX_OK;
+}
+// can this iteration's W'd come from the kept compact copy?  Asked before the build (which then writes the list of the
+// rows outside the copy) and again by cauchy_wtd
+static bool wtdc_ready(lbfgsx_ctx* c)
+{
+    lbfgsb_state* b = c->bstate;
+    const int total = 2 * c->ncorr;
+    // the copy of the previous minimisation, same history length (the commit replaced a slot), not overgrown: the pass must
+    // read clearly less than the full-length one
+    return b->wtdc_use && b->corr_defer && total > 8 && total <= 20 && !b->multidot_chunked && b->wf_use && b->wf_live &&
+           b->wf_ncorr == c->ncorr && b->wf_epoch == b->sub_epoch && c->ncorr == c->m && c->n < (int64_t(1) << 31) &&
+           b->wf_n >= 4096 && b->wf_n * 4 <= c->n * 3;
+}
+static bool wtdc_prepare(lbfgsx_ctx* c)
+{
+    lbfgsb_state* b = c->bstate;
+    b->wtdc_n = -1;
+    if (!wtdc_ready(c))
+        return false;
+    if (!b->wtdc_list)
+    {
+        if (hipMalloc(reinterpret_cast<void**>(&b->wtdc_list), sizeof(int) * size_t(b->wtdc_cap)) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&b->wtdc_cnt), sizeof(unsigned)) != hipSuccess ||
+            hipMemsetAsync(b->wtdc_cnt, 0, sizeof(unsigned), c->stream) != hipSuccess)
+        {
+            (void) hipGetLastError();
+            (void) hipFree(b->wtdc_list);
+            (void) hipFree(b->wtdc_cnt);
+            b->wtdc_list = nullptr;
+            b->wtdc_cnt = nullptr;
+            b->wtdc_use = false;
+            return false;
+        }
+    }
+    return true;
+}
 template <class T>
 static int cauchy_wtd(lbfgsx_ctx* c, double* wtd)
 {
     lbfgsb_state* b = c->bstate;
     const int total = 2 * c->ncorr;
+    if (b->wtdc_n >= 0 && b->wtdc_n <= int64_t(b->wtdc_cap) && wtdc_ready(c))
+    {
+        b->corr_defer = false;
+        const int newest = (c->ptr + c->m - 1) % c->m;
+        if (total <= 16)
+            return wtd2_wf<T, 16>(c, total, newest, wtd);
+        return wtd2_wf<T, 20>(c, total, newest, wtd);
+    }
     const bool defer = b->corr_defer;
     b->corr_defer = false;
     if (defer && total > 8 && total <= 20 && !b->multidot_chunked)
@@ -958,15 +1059,20 @@ int lbfgsx_b_cauchy_build(lbfgsx_ctx* c, int64_t* nfree, int64_t* nord, double* 
     const bool force = b->force_pending;  // a deferred x = clamp(x): evaluated by the build's own pass
     b->force_pending = false;
     const int grid = c->grid_for(c->n);
-    double r[3];
+    double r[4] = {0, 0, 0, -1};
     DISPATCH_T(c, {
         BVecs<T> bv = bvecs<T>(c);
+        const bool wc = wtdc_prepare(c);
+        const int newest = (c->ptr + c->m - 1) % c->m;
         LBFGSX_LAUNCH((k_cauchy_build<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, P<T>(b->keys_in), b->vals_in, c->n,
-                           c->ws, b->dout, force ? P<T>(c->xb[c->cur]) : static_cast<T*>(nullptr));
+                           c->ws, b->dout, force ? P<T>(c->xb[c->cur]) : static_cast<T*>(nullptr),
+                           wc ? static_cast<const T*>(c->col(c->S, c->phys[size_t(newest)])) : static_cast<const T*>(nullptr),
+                           wc ? b->wf_pos : static_cast<const int*>(nullptr), b->wtdc_list, b->wtdc_cnt, b->wtdc_cap);
         LBFGSX_HIP(hipGetLastError());
-        rc = fetch_doubles(c, 3, r);
+        rc = fetch_doubles(c, wc ? 4 : 3, r);
         if (rc)
             return rc;
+        b->wtdc_n = wc ? int64_t(r[3]) : -1;
         if (r[2] > 0)
         {
             size_t bytes = b->sort_tmp_bytes;
@@ -1053,16 +1159,21 @@ int lbfgsx_b_cauchy_build_partial(lbfgsx_ctx* c, double tau, int64_t* nfree, int
     const bool force = b->force_pending;  // a deferred x = clamp(x): evaluated by the build's own pass
     b->force_pending = false;
     const int grid = c->grid_for(c->n);
-    double r[3];
+    double r[4] = {0, 0, 0, -1};
     int64_t ns = 0;
     DISPATCH_T(c, {
         BVecs<T> bv = bvecs<T>(c);
+        const bool wc = wtdc_prepare(c);
+        const int newest = (c->ptr + c->m - 1) % c->m;
         LBFGSX_LAUNCH((k_cauchy_build<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, P<T>(b->keys_in), b->vals_in, c->n,
-                           c->ws, b->dout, force ? P<T>(c->xb[c->cur]) : static_cast<T*>(nullptr));
+                           c->ws, b->dout, force ? P<T>(c->xb[c->cur]) : static_cast<T*>(nullptr),
+                           wc ? static_cast<const T*>(c->col(c->S, c->phys[size_t(newest)])) : static_cast<const T*>(nullptr),
+                           wc ? b->wf_pos : static_cast<const int*>(nullptr), b->wtdc_list, b->wtdc_cnt, b->wtdc_cap);
         LBFGSX_HIP(hipGetLastError());
-        rc = fetch_doubles(c, 3, r);
+        rc = fetch_doubles(c, wc ? 4 : 3, r);
         if (rc)
             return rc;
+        b->wtdc_n = wc ? int64_t(r[3]) : -1;
         ns = int64_t(r[2]);
         if (r[2] > 0)
         {
@@ -1123,7 +1234,10 @@ int lbfgsx_b_cauchy_chunk(lbfgsx_ctx* c, int64_t first, int64_t count, double* b
     // one packed device buffer [brk | g | z | W rows] of (3 + 2c) * count doubles and ONE copy back (four separate copies
     // were four blit kernels per chunk); the pinned landing zone serves the chunks the host form actually asks for
     const size_t per = size_t(3 + 2 * nc);
-    if (count > b->g_cap || nc != b->g_ncorr)
+    // sized for the full history: 2c grows over the first m iterations, and a free + two allocations in the middle of each
+    // of them cost 0.3-0.4 ms apiece
+    const size_t per_cap = size_t(3 + 2 * c->m);
+    if (count > b->g_cap || c->m != b->g_ncorr)
     {
         void* old[] = {b->g_brk, b->g_idx};
         for (void* p : old)
@@ -1131,10 +1245,10 @@ int lbfgsx_b_cauchy_chunk(lbfgsx_ctx* c, int64_t first, int64_t count, double* b
         b->g_brk = nullptr;
         b->g_idx = nullptr;
         const int64_t cap = std::max<int64_t>(count, b->g_cap);
-        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->g_brk), sizeof(double) * size_t(cap) * per));
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->g_brk), sizeof(double) * size_t(cap) * per_cap));
         LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->g_idx), sizeof(int) * size_t(cap)));
         b->g_cap = cap;
-        b->g_ncorr = nc;
+        b->g_ncorr = c->m;
     }
     double* d_brk = b->g_brk;
     double* d_g = d_brk + count;
@@ -1471,17 +1585,19 @@ int lbfgsx_b_sub_begin(lbfgsx_ctx* c)
     return LBFGSX_OK;
 }
 
-int lbfgsx_b_compact_vec_counts(int64_t out[2], int reset)
+int lbfgsx_b_compact_vec_counts(int64_t out[3], int reset)
 {
     if (out)
     {
         out[0] = g_cv_starts.load(std::memory_order_relaxed);
         out[1] = g_cv_backs.load(std::memory_order_relaxed);
+        out[2] = g_wtdc_runs.load(std::memory_order_relaxed);
     }
     if (reset)
     {
         g_cv_starts = 0;
         g_cv_backs = 0;
+        g_wtdc_runs = 0;
     }
     return LBFGSX_OK;
 }
@@ -2134,6 +2250,12 @@ int lbfgsx_b_gram_pairs_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
     LBFGSX_LAUNCH(k_gram_finish, dim3(1, nch), dim3(kBlock), 0, c->stream, b->gram_partial, blocks, b->gram_partial2, 0);
     LBFGSX_LAUNCH(k_gram_finish, dim3(1, 1), dim3(kBlock), 0, c->stream, b->gram_partial2, nch, b->gram_out, 1, b->gram_dd);
     LBFGSX_HIP(hipGetLastError());
+    if (b->gram_dd_host)
+    {
+        LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
+        std::memcpy(out_dd, b->gram_dd_host, sizeof(double) * 2 * size_t(npairs));
+        return LBFGSX_OK;
+    }
     LBFGSX_HIP(lbfgsx::copy_async(out_dd, b->gram_dd, sizeof(double) * 2 * size_t(npairs), hipMemcpyDeviceToHost, c->stream));
     LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
     return LBFGSX_OK;
@@ -2338,7 +2460,7 @@ static int gram_dd_core(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, cons
     }
     const int ntile = ntile_;
     std::vector<double> hdd;
-    if (gram_dd)
+    if (gram_dd && !b->gram_dd_host)
     {
         hdd.resize(size_t(ntile) * 256 * 2);
         LBFGSX_HIP(lbfgsx::copy_async(hdd.data(), b->gram_dd, sizeof(double) * hdd.size(), hipMemcpyDeviceToHost, c->stream));
@@ -2365,7 +2487,7 @@ static int gram_dd_core(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, cons
         for (int j = 0; j < tot; j++)
             wtv[j] = h[tot * (tot + 1) / 2 + j];
     if (gram_dd)  // packed lower triangle of the 2c x 2c block, e = i (i + 1) / 2 + j: (hi, lo)
-        std::memcpy(gram_dd, hdd.data(), sizeof(double) * size_t(tot) * size_t(tot + 1));
+        std::memcpy(gram_dd, b->gram_dd_host ? b->gram_dd_host : hdd.data(), sizeof(double) * size_t(tot) * size_t(tot + 1));
     return LBFGSX_OK;
 }
 

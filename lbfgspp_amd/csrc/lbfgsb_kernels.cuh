@@ -515,6 +515,89 @@ __global__ void __launch_bounds__(kBlock, 1) k_multidot2_all(Cols<T, 32> cols, i
             out[k] = double(T(acc[k].value()));
 }
 
+// The same two multi-dots from the compact copy of the free rows kept from the previous iteration (GramRows).  Both
+// vectors are sparse in a box-constrained steady state: s_new = x_{k+1} - x_k is zero on the rows that stayed at a bound,
+// d (Cauchy.h:111-129) on the rows that sit at a bound with the gradient pointing outward -- about half of the rows in
+// cfg4 -- and a row where both are zero adds exact zeros to every sum.  The rows where one of them is not zero are the
+// rows of the copy (the free set of the last subspace minimisation and what it has accumulated) and a short list of
+// others, which k_cauchy_build writes on its way (rows without a position in the copy; `list`, read through the
+// full-length columns).  So: positions t < npos of the compact columns with the vectors gathered at idx[t], then the
+// list.  Columns fresh_a / fresh_b of the copy (the slot add_correction has just replaced: the copy still holds the old
+// pair) are taken from the full-length y_new / s_new at the row instead; the kernel is handed a stand-in pointer for
+// them, so the stale values cost no memory traffic.  Every sum has the same non-zero terms as k_multidot2_all, in
+// another order, and is correctly rounded like there.
+// One wavefront per SIMD, two register sets, the row numbers one trip further ahead (see k_vrows<NA = 3>).
+template <class T, int NC>
+__global__ void __launch_bounds__(kBlock, 1) k_multidot2_wf(Cols<T, 32> wfc, int fresh_a, int fresh_b, const T* __restrict__ snew,
+                                                         const T* __restrict__ ynew, const T* __restrict__ dvec,
+                                                         const int* __restrict__ idx, int64_t npos, Cols<T, 32> full,
+                                                         const int* __restrict__ list, int nlist, RedWs ws,
+                                                         double* __restrict__ out)
+{
+    typedef typename AccOf<T>::type A;
+    Accs<A, 2 * NC> accs;
+    A(&acc)[2 * NC] = accs.v;
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    auto fetch = [&](int64_t r, int64_t t, T& a, T& y, T& d, T(&w)[NC]) __attribute__((always_inline)) {
+        a = snew[r];
+        y = ynew[r];
+        d = dvec[r];
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+            w[k] = wfc.p[k][t];
+    };
+    auto work = [&](T a, T y, T d, T(&w)[NC]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+        {
+            const T wk = (k == fresh_a) ? y : (k == fresh_b) ? a : w[k];
+            acc[k].add_prod(wk, a);
+            acc[NC + k].add_prod(wk, d);
+        }
+    };
+    if (npos > 0)
+    {
+        const int64_t last = npos - 1;
+        int64_t t = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+        auto cl = [&](int64_t q) __attribute__((always_inline)) { return q < npos ? q : last; };
+        int64_t r0 = idx[cl(t)], r1 = idx[cl(t + stride)];
+        T a0, y0, d0, w0[NC], a1, y1, d1, w1[NC];
+        fetch(r0, cl(t), a0, y0, d0, w0);
+        for (; t < npos; t += 2 * stride)
+        {
+            const int64_t tb = t + stride, tc = tb + stride, td = tc + stride;
+            const int64_t r2 = idx[cl(tc)];
+            fetch(r1, cl(tb), a1, y1, d1, w1);
+            work(a0, y0, d0, w0);
+            r0 = r2;
+            const int64_t r3 = idx[cl(td)];
+            fetch(r0, cl(tc), a0, y0, d0, w0);
+            if (tb < npos)
+                work(a1, y1, d1, w1);
+            r1 = r3;
+        }
+    }
+    // the rows outside the copy: all columns at the row, from the full-length arrays (which hold the new pair)
+    for (int64_t e = int64_t(blockIdx.x) * kBlock + threadIdx.x; e < int64_t(nlist); e += stride)
+    {
+        const int64_t r = list[e];
+        const T a = snew[r], d = dvec[r];
+        T w[NC];
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+            w[k] = full.p[k][r];
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+        {
+            acc[k].add_prod(w[k], a);
+            acc[NC + k].add_prod(w[k], d);
+        }
+    }
+    if (grid_reduce<2 * NC>(acc, ws) && threadIdx.x == 0)
+        for (int k = 0; k < 2 * NC; k++)
+            out[k] = double(T(acc[k].value()));
+}
+
 // ---------------------------------------------------------------- masked Gram block: out[a*TB+c] = sum_{i in mask} I_a[i] * J_c[i]
 // (BFGSMat.h:543-556: WP'WP blocks of solve_PtBP)
 template <class T, int TB>
@@ -1334,14 +1417,35 @@ __global__ void __launch_bounds__(kBlock, (NA == 1 && NC <= 20) ? 2 : 1)
         }
 }
 
+// append row i to the index list when `app`; one counter update per wavefront, the lanes that append ranked by ballot
+__device__ inline void lu_append(bool app, int64_t i, int* __restrict__ lu_list, unsigned* __restrict__ lu_cnt, unsigned lu_cap)
+{
+    const unsigned long long am = __ballot(app);
+    if (am)
+    {
+        const int leader = __ffsll((long long) am) - 1;
+        unsigned basep = 0;
+        if (int(threadIdx.x & 63) == leader)
+            basep = atomicAdd(lu_cnt, unsigned(__popcll(am)));
+        basep = unsigned(__shfl(int(basep), leader, 64));
+        const unsigned pos = basep + unsigned(__popcll(am & ((1ull << (threadIdx.x & 63)) - 1ull)));
+        if (app && pos < lu_cap)
+            lu_list[pos] = int(i);
+    }
+}
+
 // ---------------------------------------------------------------- Cauchy build (Cauchy.h:111-129,154)
 // brk, vecd, sort keys/values; out[0] = d.d, out[1] = #free (brk = inf), out[2] = #ord (0 < brk < inf)
 // xforce != null: x = x.cwiseMax(lb).cwiseMin(ub) (LBFGSB.h:240, k_force_bounds) evaluated on the way -- this pass reads
 // x, lb and ub anyway; a coordinate inside its bounds (all of them once the iterates are feasible) costs no store.
 template <class T>
 __global__ void __launch_bounds__(kBlock) k_cauchy_build(BVecs<T> b, T* __restrict__ keys, int* __restrict__ vals,
-                                                         int64_t n, RedWs ws, double* __restrict__ out, T* __restrict__ xforce)
+                                                         int64_t n, RedWs ws, double* __restrict__ out, T* __restrict__ xforce,
+                                                         const T* __restrict__ snew, const int* __restrict__ pos,
+                                                         int* __restrict__ olist, unsigned* __restrict__ ocnt, unsigned ocap)
 {
+    // pos != null (k_multidot2_wf follows): the rows without a position in the kept compact copy on which d or s_new is
+    // not zero go to olist; out[3] = their number (beyond ocap: the list is incomplete, the full-length pass runs)
     typedef typename AccOf<T>::type A;
     A acc[3];
     const T inf = T(__longlong_as_double(0x7FF0000000000000ll));
@@ -1382,12 +1486,23 @@ __global__ void __launch_bounds__(kBlock) k_cauchy_build(BVecs<T> b, T* __restri
             acc[2].add(T(1));
         keys[i] = isord ? t : inf;  // non-candidates sort to the end
         vals[i] = int(i);
+        if (pos)
+        {
+            const bool outside = pos[i] < 0 && (di != T(0) || snew[i] != T(0));
+            lu_append(outside, i, olist, ocnt, ocap);
+        }
     }
     if (grid_reduce<3>(acc, ws) && threadIdx.x == 0)
     {
         out[0] = double(T(acc[0].value()));
         out[1] = acc[1].value();
         out[2] = acc[2].value();
+        if (pos)
+        {
+            // every append has returned its position before its block took the ticket
+            out[3] = double(__hip_atomic_load(ocnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            __hip_atomic_store(ocnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -1743,23 +1858,6 @@ __device__ inline void sweep_counts(const unsigned* cnt, A* acc)
         }
 }
 
-// append row i to the index list when `app`; one counter update per wavefront, the lanes that append ranked by ballot
-__device__ inline void lu_append(bool app, int64_t i, int* __restrict__ lu_list, unsigned* __restrict__ lu_cnt, unsigned lu_cap)
-{
-    const unsigned long long am = __ballot(app);
-    if (am)
-    {
-        const int leader = __ffsll((long long) am) - 1;
-        unsigned basep = 0;
-        if (int(threadIdx.x & 63) == leader)
-            basep = atomicAdd(lu_cnt, unsigned(__popcll(am)));
-        basep = unsigned(__shfl(int(basep), leader, 64));
-        const unsigned pos = basep + unsigned(__popcll(am & ((1ull << (threadIdx.x & 63)) - 1ull)));
-        if (app && pos < lu_cap)
-            lu_list[pos] = int(i);
-    }
-}
-
 template <class T>
 __global__ void __launch_bounds__(kBlock) k_sub_sweep_begin(BVecs<T> b, int first, int64_t n, RedWs ws, double* __restrict__ out,
                                                             int* __restrict__ lu_list, unsigned* __restrict__ lu_cnt, unsigned lu_cap)
@@ -1889,6 +1987,7 @@ __global__ void __launch_bounds__(kBlock, NC <= 24 ? 2 : 1) k_solve_sweep(Cols<T
     // lb - x0, ub - x0: two values by position, or three by row (one pointer set per launch: every load unconditional)
     const T* la_p = cvt ? cli : b.lb;
     const T* ua_p = cvt ? cui : b.ub;
+    const T* x0_p = cvt ? cli : b.x0;  // by position nothing is subtracted: a stand-in that is loaded anyway
     A dots[ND ? ND : 1];
     unsigned cnt[7] = {0, 0, 0, 0, 0, 0, 0};
     const int64_t stride = int64_t(gridDim.x) * kBlock;
@@ -1906,7 +2005,7 @@ __global__ void __launch_bounds__(kBlock, NC <= 24 ? 2 : 1) k_solve_sweep(Cols<T
             w[k] = cols.p[k][t];
         const T xa = va_p[ir], xb = vb_p[ir];
         const T yold = FIRST ? T(0) : b.y[ir];  // the first solve writes every free row: nothing to keep
-        const T la = la_p[ir], ua = ua_p[ir], x0i = b.x0[i], cfi = b.cF[ir];
+        const T la = la_p[ir], ua = ua_p[ir], x0i = x0_p[ir], cfi = b.cF[ir];
         const T li = cvt ? la : la - x0i, ui = cvt ? ua : ua - x0i;
         if (cv == 1)  // every position gets its constants, free or not
         {

@@ -3,6 +3,10 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <chrono>
+#include <string>
+#include <vector>
+#include <utility>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -19,6 +23,51 @@ Counters& counters()
 {
     static Counters g;
     return g;
+}
+
+// host-side timeline (ctx.hpp): events kept in memory, written by the destructor of the function-local static
+namespace {
+struct HostTrace
+{
+    bool on = false;
+    std::string path;
+    std::mutex mu;
+    std::vector<std::pair<long long, const char*>> ev;
+    HostTrace()
+    {
+        if (const char* e = getenv("LBFGSX_HOST_TRACE"))
+            if (e[0])
+            {
+                on = true;
+                path = e;
+                ev.reserve(size_t(1) << 20);
+            }
+    }
+    ~HostTrace()
+    {
+        if (!on)
+            return;
+        if (FILE* f = std::fopen(path.c_str(), "w"))
+        {
+            for (const auto& p : ev)
+                std::fprintf(f, "%lld %s\n", p.first, p.second);
+            std::fclose(f);
+        }
+    }
+};
+HostTrace& host_trace_state()
+{
+    static HostTrace t;
+    return t;
+}
+}  // namespace
+bool host_trace_on() { return host_trace_state().on; }
+void host_trace(const char* tag)
+{
+    HostTrace& t = host_trace_state();
+    const long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    std::lock_guard<std::mutex> lk(t.mu);
+    t.ev.emplace_back(ns, tag);
 }
 
 void live_add(int device, int delta)

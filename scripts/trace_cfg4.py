@@ -69,3 +69,55 @@ for i in range(min(20, len(posts) - 1)):
         ag[short(n_)[:34]] += (e_ - s_) / 1e6
     top = ", ".join("%s %.2f" % (k, v) for k, v in ag.most_common(4))
     print("%2d  %6.2f | %6.2f | %4d | %s" % (i + 1, w, busy_i, len(seg_i), top))
+
+# the early iterations together: kernel totals, and where the device waits for the host
+early = min(17, len(posts) - 1)
+seg_e = rows[posts[0]:posts[early]]
+wall_e = (rows[posts[early]][0] - rows[posts[0]][0]) / 1e6
+busy_e = sum(e - s for s, e, _ in seg_e) / 1e6
+print("\n--- iterations 1..%d together: wall %.2f ms, kernels %.2f ms, idle %.2f ms, launches %d ---"
+      % (early, wall_e, busy_e, wall_e - busy_e, len(seg_e)))
+ag = collections.OrderedDict()
+for s, e, n in seg_e:
+    a = ag.setdefault(short(n), [0, 0])
+    a[0] += 1
+    a[1] += e - s
+for k, (c, t) in sorted(ag.items(), key=lambda kv: -kv[1][1])[:28]:
+    print("%8.3f ms  %5d calls  %8.1f us avg  %s" % (t / 1e6, c, t / c / 1e3, k))
+gaps = collections.OrderedDict()
+prev = None
+for s, e, n in seg_e:
+    if prev is not None:
+        g = s - prev[1]
+        if g > 8000:
+            a = gaps.setdefault((short(prev[2])[:40], short(n)[:40]), [0, 0])
+            a[0] += 1
+            a[1] += g
+    prev = (s, e, n)
+print("\n--- gaps above 8 us in iterations 1..%d, by (kernel before -> kernel after): total ms, count, avg us ---" % early)
+for (a_, b_), (c, t) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:30]:
+    print("%8.3f ms  %5d  %8.1f us  %s -> %s" % (t / 1e6, c, t / c / 1e3, a_, b_))
+
+# single early iterations, kernel by kernel
+for it in (1, 2, 5, 10):
+    if it >= len(posts):
+        continue
+    seg_i = rows[posts[it - 1]:posts[it]]
+    ag = collections.OrderedDict()
+    for s, e, n in seg_i:
+        a = ag.setdefault(short(n), [0, 0])
+        a[0] += 1
+        a[1] += e - s
+    gap_i = 0
+    big = []
+    prev = None
+    for s, e, n in seg_i:
+        if prev is not None and s - prev[1] > 8000:
+            gap_i += s - prev[1]
+            big.append(((s - prev[1]) / 1e3, short(prev[2])[:30], short(n)[:30]))
+        prev = (s, e, n)
+    print("\n--- iteration %d: %d launches, gaps above 8 us %.2f ms ---" % (it, len(seg_i), gap_i / 1e6))
+    for k, (c, t) in sorted(ag.items(), key=lambda kv: -kv[1][1])[:16]:
+        print("%8.3f ms  %5d calls  %8.1f us avg  %s" % (t / 1e6, c, t / c / 1e3, k))
+    big.sort(reverse=True)
+    print("   largest gaps: " + "; ".join("%.0f us %s -> %s" % g for g in big[:8]))

@@ -420,7 +420,7 @@ def test_compact_vectors_of_the_free_rows_change_no_bit(A, monkeypatch, n, m, ma
         except RuntimeError:
             niter, fx = -1, float("nan")
         st = s.stats()
-        cnt = (C.c_int64 * 2)()
+        cnt = (C.c_int64 * 3)()
         core.lbfgsx_b_compact_vec_counts(C.byref(cnt), 0)
         res[on] = (niter, s.last.nfev, x.copy(), tr.xs[:tr.count].copy(), st["submin_sweeps"], st["submin_unconverged"],
                    st["submin_fused_sweeps"], (cnt[0], cnt[1]))
@@ -432,6 +432,44 @@ def test_compact_vectors_of_the_free_rows_change_no_bit(A, monkeypatch, n, m, ma
         assert f[7][1] > 0
     else:
         assert f[7][1] <= f[7][0]
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("n,m,iters,cap", [(70001, 8, 40, None), (70001, 10, 45, None), (65536, 5, 30, None), (200000, 10, 60, None),
+                                           (120000, 10, 40, "8")])
+def test_cauchy_dots_from_the_kept_compact_copy_change_no_bit(A, monkeypatch, n, m, iters, cap, dtype):
+    """p = W'd of the Cauchy search and the deferred dots of add_correction as sums over the positions of the compact copy
+    kept from the previous iteration plus the listed rows outside it (k_multidot2_wf) against the pass over all n rows
+    (LBFGSX_WTD_COMPACT=0): the terms left out are exact zeros and every sum is correctly rounded, so the trajectory is the
+    same bit for bit; the compact form must have run.  With a list of 8 rows (LBFGSX_WTD_LIST_CAP) it overflows now and
+    then and those iterations take the full pass."""
+    import ctypes as C
+    from lbfgspp_amd import _lib
+    core, _ = _lib.load()
+    dt = O.F64 if dtype == "f64" else O.F32
+    npdt = O.NPDT[dt]
+    a, b = O.quad_problem(n, 30.0, 9, dt)
+    if cap:
+        monkeypatch.setenv("LBFGSX_WTD_LIST_CAP", cap)
+    res = {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("LBFGSX_WTD_COMPACT", on)
+        core.lbfgsx_b_compact_vec_counts(None, 1)
+        s = A.LBFGSBSolver(A.LBFGSBParam(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters, max_submin=10), dtype=npdt)
+        tr = A.TraceBuffer(n, cap=256, stride=17)
+        x = np.zeros(n, dtype=npdt)
+        try:
+            niter, fx = s.minimize(A.DiagQuadratic(a, b), x, (-0.7 * np.ones(n)).astype(npdt), (0.9 * np.ones(n)).astype(npdt),
+                                   trace=tr)
+        except RuntimeError:
+            niter, fx = -1, float("nan")
+        cnt = (C.c_int64 * 3)()
+        core.lbfgsx_b_compact_vec_counts(C.byref(cnt), 0)
+        res[on] = (niter, s.last.nfev, x.copy(), tr.xs[:tr.count].copy(), cnt[2])
+    f, u = res["1"], res["0"]
+    assert f[:2] == u[:2]
+    assert np.array_equal(f[2], u[2]) and np.array_equal(f[3], u[3])
+    assert u[4] == 0 and f[4] > 0
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
