@@ -344,8 +344,9 @@ int lbfgsx_b_set_compaction(lbfgsx_ctx* c, int enable);
  * (BFGSMat.h:111,138) are sums over the rows where d or s_new is not zero -- the positions of the copy plus a short list of
  * other rows that lbfgsx_b_cauchy_build* writes on its way -- instead of over all n rows (LBFGSX_WTD_COMPACT=0: all rows).
  * Instrumentation, process-wide: out = {minimisations that ran on compact vectors, times they were put back before the
- * result was assigned, Cauchy searches whose W'd came from the copy}. */
-int lbfgsx_b_compact_vec_counts(int64_t out[3], int reset);
+ * result was assigned, Cauchy searches whose W'd came from the copy, Grams over index lists that were launched behind the
+ * pass before them and cost no round trip of their own (LBFGSX_SYNC_MERGE=0: none)}. */
+int lbfgsx_b_compact_vec_counts(int64_t out[4], int reset);
 /* A BOXCQP solve and the statements of lbfgsx_b_sub_sweep_begin on the rows it writes, in ONE pass (the solve's row of W is
  * in registers; the sweep's pass over n rows disappears).  Bit for bit lbfgsx_b_wcombine(LBFGSX_CB_SOLVE) /
  * lbfgsx_b_solve_wty followed by lbfgsx_b_sub_sweep_begin.

@@ -32,6 +32,18 @@ struct lbfgsb_state
     double* gram_out_host = nullptr;  // same for gram_out
     double* gram_dd = nullptr;        // [3][256][2] un-rounded (hi, lo) sums of the last one-pass Gram (device)
     double* gram_dd_host = nullptr;   // ... host-mapped when the mapped outputs are on (gram_dd is then its device alias)
+    // Grams over index lists launched ahead of their request, behind a pass that is waited for anyway (one round trip less
+    // each): slot 0 = rows of L u U (launched with lbfgsx_b_wtv_lu, asked for by the complement of the next solve), slots
+    // 1, 2 = rows that entered / left the free set (launched with lbfgsx_b_gram_pairs_dd, asked for by
+    // lbfgsx_b_gram_list_dd).  Host-mapped: [slot][3*256 rounded | 3*256*2 (hi, lo)].  Any other bounded entry drops them.
+    double* stash_host = nullptr;
+    double* stash_dev = nullptr;
+    bool stash_use = true;            // LBFGSX_SYNC_MERGE=0: every Gram is launched when it is asked for
+    bool stash_valid[3] = {false, false, false};
+    bool stash_armed[3] = {false, false, false};  // launched, becomes valid with the launcher's wait
+    unsigned stash_phys[3] = {0, 0, 0};
+    int stash_tot[3] = {0, 0, 0};
+    int64_t stash_hits = 0;
     void* coef_dev = nullptr;         // T[80]
     // index list of the rows the last BOXCQP partition put into L or U (k_sub_sweep_begin); lu_valid: it describes the
     // current state bytes (any other writer of ST_L / ST_U clears it)
@@ -188,7 +200,7 @@ static BVecs<T> bvecs(lbfgsx_ctx* c)
 
 // instrumentation, process-wide: {subspace minimisations that ran on compact vectors, times they went back to their rows
 // before the minimisation assigned its result}
-static std::atomic<int64_t> g_cv_starts{0}, g_cv_backs{0}, g_wtdc_runs{0};
+static std::atomic<int64_t> g_cv_starts{0}, g_cv_backs{0}, g_wtdc_runs{0}, g_stash_hits{0};
 // the vectors of the free rows by POSITION (cv_buf): what the fused sweep kernels are handed while cv_live
 template <class T>
 static BVecs<T> bvecs_cv(lbfgsx_ctx* c, T** cli = nullptr, T** cui = nullptr)
@@ -254,13 +266,18 @@ static int run_force_bounds(lbfgsx_ctx* c);
 // every other entry of the bounded path runs it first
 // keep_cv: the caller is one of the fused sweep entries, which work on the compact vectors of the free rows; every other
 // entry gets them back at their rows first
-static int need_bounded(lbfgsx_ctx* c, bool keep_force = false, bool keep_cv = false)
+// keep_stash: the caller launches or consumes the Grams launched ahead (lbfgsb_state::stash_*); any other entry may change
+// what they were computed from and drops them
+static int need_bounded(lbfgsx_ctx* c, bool keep_force = false, bool keep_cv = false, bool keep_stash = false)
 {
     if (!c->bstate)
     {
         set_error("this context was not created with LBFGSX_FLAG_BOUNDED");
         return LBFGSX_E_LOGIC;
     }
+    if (!keep_stash)
+        for (int q = 0; q < 3; q++)
+            c->bstate->stash_valid[q] = c->bstate->stash_armed[q] = false;
     if (c->bstate->cv_live && !keep_cv)
     {
         lbfgsx::DeviceGuard dev_guard_(c->device);
@@ -361,6 +378,8 @@ int bounded_alloc(lbfgsx_ctx* c)
         b->cv_use = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_WTD_COMPACT"))
         b->wtdc_use = atoi(e) != 0;
+    if (const char* e = getenv("LBFGSX_SYNC_MERGE"))
+        b->stash_use = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_WTD_LIST_CAP"))  // test aid: a short list overflows
         b->wtdc_cap = unsigned(std::max(1, std::min(1 << 20, atoi(e))));
     if (const char* e = getenv("LBFGSX_LU_MAX"))
@@ -417,6 +436,8 @@ int bounded_alloc(lbfgsx_ctx* c)
         // the (hi, lo) sums land where the host reads them: a copy into pageable memory is staged and costs ~20 us a fetch
         LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->gram_dd_host), sizeof(double) * 3 * 256 * 2, hipHostMallocMapped));
         LBFGSX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->gram_dd), b->gram_dd_host, 0));
+        LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->stash_host), sizeof(double) * 3 * (3 * 256 * 3), hipHostMallocMapped));
+        LBFGSX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->stash_dev), b->stash_host, 0));
         LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->gram_out_host), sizeof(double) * 3 * 256, hipHostMallocMapped));
         LBFGSX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->gram_out), b->gram_out_host, 0));
     }
@@ -478,6 +499,8 @@ void bounded_free(lbfgsx_ctx* c)
         (void) hipHostFree(b->gram_out_host);
     if (b->gram_dd_host)
         (void) hipHostFree(b->gram_dd_host);
+    if (b->stash_host)
+        (void) hipHostFree(b->stash_host);
     (void) hipFree(b->cv_buf);
     delete b;
     c->bstate = nullptr;
@@ -1585,19 +1608,25 @@ int lbfgsx_b_sub_begin(lbfgsx_ctx* c)
     return LBFGSX_OK;
 }
 
-int lbfgsx_b_compact_vec_counts(int64_t out[3], int reset)
+}  // extern "C"
+static bool gram_stash_launch(lbfgsx_ctx* c, int slot, int mask, const int* list, int64_t nlist);
+static void gram_stash_settle(lbfgsx_ctx* c, bool ok);
+extern "C" {
+int lbfgsx_b_compact_vec_counts(int64_t out[4], int reset)
 {
     if (out)
     {
         out[0] = g_cv_starts.load(std::memory_order_relaxed);
         out[1] = g_cv_backs.load(std::memory_order_relaxed);
         out[2] = g_wtdc_runs.load(std::memory_order_relaxed);
+        out[3] = g_stash_hits.load(std::memory_order_relaxed);
     }
     if (reset)
     {
         g_cv_starts = 0;
         g_cv_backs = 0;
         g_wtdc_runs = 0;
+        g_stash_hits = 0;
     }
     return LBFGSX_OK;
 }
@@ -1666,7 +1695,11 @@ int lbfgsx_b_wtv_lu(lbfgsx_ctx* c, double* out_l, int64_t* nnz_l, double* out_u,
                                c->ws, b->dout, stc, stpos);
     });
     LBFGSX_HIP(hipGetLastError());
+    // the solve that follows asks for the Gram over the same rows (the complement identity, lbfgsx_b_gram_fused_dd): it
+    // rides behind this pass and is there when this pass's wait returns
+    (void) gram_stash_launch(c, 0, ST_L | ST_U, b->lu_ptr(), nl);
     rc = fetch_doubles(c, 2 * (nc + 1), r);
+    gram_stash_settle(c, rc == LBFGSX_OK);
     if (rc)
         return rc;
     for (int k = 0; k < total; k++)
@@ -1860,6 +1893,89 @@ static int launch_gram_vonly(lbfgsx_ctx* c, int64_t nbatch, int tot, int vsel_id
                        mask, nrows, b->gram_partial, pro, gr);
     return blocks;
 }
+// A Gram over the rows of an index list (2c x 2c, no v row) launched ahead of its request into stash slot `slot`; mask != 0:
+// only the listed rows whose state byte has one of its bits.  false: not launched (the request will launch it itself).
+static bool gram_stash_launch(lbfgsx_ctx* c, int slot, int mask, const int* list, int64_t nlist)
+{
+    lbfgsb_state* b = c->bstate;
+    const int tot = 2 * c->ncorr;
+    b->stash_valid[slot] = b->stash_armed[slot] = false;
+    if (!b->stash_use || !b->stash_host || b->gram_mfma || b->gram_mode == 2 || tot < 1 || tot > kGramDDCS || !list || nlist < 1)
+        return false;
+    if (upload_phys(c) != LBFGSX_OK)
+        return false;
+    const int npairs = tot * (tot + 1) / 2;
+    const int kp = (npairs + 63) / 64;
+    const int kpt = kp <= 1 ? 1 : kp <= 2 ? 2 : kp <= 4 ? 4 : kp <= 6 ? 6 : 8;
+    const int ntile = (64 * kpt + 255) / 256;
+    const int64_t nbatch = (nlist + kGramDDRows - 1) / kGramDDRows;
+    int blocks = 1;
+    DISPATCH_T(c, {
+        GramPrologue<T> pro;
+        pro.mode = LBFGSX_GP_NONE;
+        pro.use1 = pro.use2 = 0;
+        for (int k = 0; k < 64; k++)
+            pro.c1[k] = pro.c2[k] = T(0);
+        GramRows<T> gr{};
+        gr.in_idx = list;
+        gr.w_by_row = 1;
+        if (b->cv_live)
+        {
+            gr.st_alt = bvecs_cv<T>(c).st;
+            gr.st_pos = b->wf_pos;
+        }
+        if (kp <= 1) blocks = launch_gram_dd<T, 1>(c, nbatch, tot, -1, mask, pro, gr, nlist);
+        else if (kp <= 2) blocks = launch_gram_dd<T, 2>(c, nbatch, tot, -1, mask, pro, gr, nlist);
+        else if (kp <= 4) blocks = launch_gram_dd<T, 4>(c, nbatch, tot, -1, mask, pro, gr, nlist);
+        else if (kp <= 6) blocks = launch_gram_dd<T, 6>(c, nbatch, tot, -1, mask, pro, gr, nlist);
+        else blocks = launch_gram_dd<T, 8>(c, nbatch, tot, -1, mask, pro, gr, nlist);
+    });
+    double* out = b->stash_dev + size_t(slot) * (3 * 256 * 3);
+    const int nch = std::min(blocks, 32);
+    LBFGSX_LAUNCH(k_gram_finish, dim3(ntile, nch), dim3(kBlock), 0, c->stream, b->gram_partial, blocks, b->gram_partial2, 0);
+    LBFGSX_LAUNCH(k_gram_finish, dim3(ntile, 1), dim3(kBlock), 0, c->stream, b->gram_partial2, nch, out, 1, out + 3 * 256);
+    if (hipGetLastError() != hipSuccess)
+        return false;
+    b->stash_armed[slot] = true;
+    b->stash_phys[slot] = c->phys_version;
+    b->stash_tot[slot] = tot;
+    return true;
+}
+// after the launcher's wait: what was launched ahead is there (ok) or never will be
+static void gram_stash_settle(lbfgsx_ctx* c, bool ok)
+{
+    lbfgsb_state* b = c->bstate;
+    for (int q = 0; q < 3; q++)
+    {
+        b->stash_valid[q] = ok && b->stash_armed[q];
+        b->stash_armed[q] = false;
+    }
+}
+// the (hi, lo) sums of slot `slot` if they are what the caller is about to compute
+static bool gram_stash_take(lbfgsx_ctx* c, int slot, double* gram, double* gram_dd)
+{
+    lbfgsb_state* b = c->bstate;
+    const int tot = 2 * c->ncorr;
+    const bool hit = b->stash_valid[slot] && b->stash_phys[slot] == c->phys_version && b->stash_tot[slot] == tot;
+    b->stash_valid[slot] = false;
+    if (!hit)
+        return false;
+    const double* h = b->stash_host + size_t(slot) * (3 * 256 * 3);
+    if (gram)
+        for (int i = 0; i < tot; i++)
+            for (int j = 0; j <= i; j++)
+            {
+                const double v = h[i * (i + 1) / 2 + j];
+                gram[i * tot + j] = v;
+                gram[j * tot + i] = v;
+            }
+    if (gram_dd)
+        std::memcpy(gram_dd, h + 3 * 256, sizeof(double) * size_t(tot) * size_t(tot + 1));
+    b->stash_hits++;
+    g_stash_hits.fetch_add(1, std::memory_order_relaxed);
+    return true;
+}
+
 // k_vrows: the v row (NA = 1) or the v row and the rows of two columns (NA = 3) of the masked Gram, rounded values in
 // gram_out[r * (NC + 1) + j] and (hi, lo) pairs from gram_out + 256 on (host-mapped when the mapped outputs are on)
 template <class T, int NC, int NA>
@@ -2107,7 +2223,7 @@ int lbfgsx_b_free_delta(lbfgsx_ctx* c, int64_t* n_enter, int64_t* n_leave)
 int lbfgsx_b_gram_list_dd(lbfgsx_ctx* c, int which, double* gram_dd)
 {
     lbfgsx::DeviceGuard dev_guard_(c->device);
-    int rc = need_bounded(c);
+    int rc = need_bounded(c, false, false, /*keep_stash=*/true);
     if (rc)
         return rc;
     lbfgsb_state* b = c->bstate;
@@ -2235,8 +2351,18 @@ int lbfgsx_b_gram_pairs_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
         return rc;
     if (blocks == 0)  // k_vrows: (hi, lo) of row r, entry j at gram_out[256 + 2 (r NP + j)]
     {
+        // the carried first solve goes on to ask for the Grams over the rows that entered and left the free set
+        // (lbfgsx_b_gram_list_dd): they ride behind this pass
+        if (b->fprev)
+        {
+            if (b->dl_n[0] >= 1)
+                (void) gram_stash_launch(c, 1, 0, b->dl_enter, b->dl_n[0]);
+            if (b->dl_n[1] >= 1)
+                (void) gram_stash_launch(c, 2, 0, b->dl_leave, b->dl_n[1]);
+        }
         double h[2 * 64];
         rc = fetch_gram_out(c, 256, 2 * 64, h);
+        gram_stash_settle(c, rc == LBFGSX_OK);
         if (rc)
             return rc;
         for (int z = 0; z < npairs; z++)
@@ -2285,7 +2411,7 @@ int lbfgsx_b_gram_fused_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
 static int gram_dd_core(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, const double* coef1, const double* coef2,
                         double* gram, double* wtv, double* gram_dd, const int* list, int64_t nlist)
 {
-    int rc = need_bounded(c, false, /*keep_cv=*/true);  // the walk over the L u U list reads the partition bits where they are
+    int rc = need_bounded(c, false, /*keep_cv=*/true, /*keep_stash=*/true);  // the walk over the L u U list reads the partition bits where they are
     if (rc)
         return rc;
     lbfgsb_state* b = c->bstate;
@@ -2293,6 +2419,22 @@ static int gram_dd_core(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, cons
     const int ntot = tot + (vsel_id >= 0 ? 1 : 0);
     const bool lu_walk = !list && b->lu_valid && b->lu_use && vsel_id < 0 && prologue == LBFGSX_GP_NONE && mask != 0 &&
                          (mask & ~(ST_L | ST_U)) == 0 && !b->gram_mfma;
+    // launched ahead?  (slot 0: the rows of L u U behind lbfgsx_b_wtv_lu; slots 1, 2: the entered / left rows behind
+    // lbfgsx_b_gram_pairs_dd)
+    {
+        int slot = -1;
+        if (lu_walk && mask == (ST_L | ST_U) && b->lu_n >= 1)
+            slot = 0;
+        else if (list && vsel_id < 0 && prologue == LBFGSX_GP_NONE && list == b->dl_enter)
+            slot = 1;
+        else if (list && vsel_id < 0 && prologue == LBFGSX_GP_NONE && list == b->dl_leave)
+            slot = 2;
+        const bool hit = slot >= 0 && !wtv && gram_stash_take(c, slot, gram, gram_dd);
+        if (slot != 0)  // the sweeps may ask for the L u U Gram only right after lbfgsx_b_wtv_lu
+            b->stash_valid[0] = false;
+        if (hit)
+            return LBFGSX_OK;
+    }
     if (b->cv_live && !lu_walk)
     {
         rc = cv_back(c, false);

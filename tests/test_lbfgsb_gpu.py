@@ -420,7 +420,7 @@ def test_compact_vectors_of_the_free_rows_change_no_bit(A, monkeypatch, n, m, ma
         except RuntimeError:
             niter, fx = -1, float("nan")
         st = s.stats()
-        cnt = (C.c_int64 * 3)()
+        cnt = (C.c_int64 * 4)()
         core.lbfgsx_b_compact_vec_counts(C.byref(cnt), 0)
         res[on] = (niter, s.last.nfev, x.copy(), tr.xs[:tr.count].copy(), st["submin_sweeps"], st["submin_unconverged"],
                    st["submin_fused_sweeps"], (cnt[0], cnt[1]))
@@ -432,6 +432,41 @@ def test_compact_vectors_of_the_free_rows_change_no_bit(A, monkeypatch, n, m, ma
         assert f[7][1] > 0
     else:
         assert f[7][1] <= f[7][0]
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("n,m,iters", [(70001, 8, 40), (70001, 10, 45), (65536, 3, 30), (200000, 10, 60)])
+def test_grams_launched_ahead_of_their_request_change_no_bit(A, monkeypatch, n, m, iters, dtype):
+    """The Gram over the rows of L u U rides behind the W_L'l / W_U'u pass, the Grams over the rows that entered / left the
+    free set behind the selected-entries pass of the carried first solve: the same kernels on the same data, launched
+    earlier and fetched with the wait of the pass before them (one host round trip less each).  Against launching them when
+    they are asked for (LBFGSX_SYNC_MERGE=0): the same bits; and the early launches must have been used."""
+    import ctypes as C
+    from lbfgspp_amd import _lib
+    core, _ = _lib.load()
+    dt = O.F64 if dtype == "f64" else O.F32
+    npdt = O.NPDT[dt]
+    a, b = O.quad_problem(n, 30.0, 9, dt)
+    res = {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("LBFGSX_SYNC_MERGE", on)
+        core.lbfgsx_b_compact_vec_counts(None, 1)
+        s = A.LBFGSBSolver(A.LBFGSBParam(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters, max_submin=10), dtype=npdt)
+        tr = A.TraceBuffer(n, cap=256, stride=17)
+        x = np.zeros(n, dtype=npdt)
+        try:
+            niter, fx = s.minimize(A.DiagQuadratic(a, b), x, (-0.7 * np.ones(n)).astype(npdt), (0.9 * np.ones(n)).astype(npdt),
+                                   trace=tr)
+        except RuntimeError:
+            niter, fx = -1, float("nan")
+        st = s.stats()
+        cnt = (C.c_int64 * 4)()
+        core.lbfgsx_b_compact_vec_counts(C.byref(cnt), 0)
+        res[on] = (niter, s.last.nfev, x.copy(), tr.xs[:tr.count].copy(), st["submin_sweeps"], cnt[3])
+    f, u = res["1"], res["0"]
+    assert f[:2] == u[:2] and f[4] == u[4]
+    assert np.array_equal(f[2], u[2]) and np.array_equal(f[3], u[3])
+    assert u[5] == 0 and f[5] > 0
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
@@ -463,7 +498,7 @@ def test_cauchy_dots_from_the_kept_compact_copy_change_no_bit(A, monkeypatch, n,
                                    trace=tr)
         except RuntimeError:
             niter, fx = -1, float("nan")
-        cnt = (C.c_int64 * 3)()
+        cnt = (C.c_int64 * 4)()
         core.lbfgsx_b_compact_vec_counts(C.byref(cnt), 0)
         res[on] = (niter, s.last.nfev, x.copy(), tr.xs[:tr.count].copy(), cnt[2])
     f, u = res["1"], res["0"]
