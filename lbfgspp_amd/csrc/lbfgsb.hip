@@ -1132,8 +1132,10 @@ __global__ void k_gather_keys(const T* __restrict__ keys, const int* __restrict_
         out[k] = keys[idx[k]];
 }
 }  // namespace lbfgsx
+// the partial sort in two halves: the selection (launched; its count lands in `count_dev`), and the sort of the selected
+// break points once the count is on the host
 template <class T>
-static int partial_sort_t(lbfgsx_ctx* c, double tau, int64_t* nsorted)
+static int partial_select_t(lbfgsx_ctx* c, double tau, unsigned* count_dev)
 {
     lbfgsb_state* b = c->bstate;
     const size_t n = size_t(c->n);
@@ -1143,21 +1145,40 @@ static int partial_sort_t(lbfgsx_ctx* c, double tau, int64_t* nsorted)
         LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->pv), sizeof(int) * n));
         LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->pcount), sizeof(unsigned)));
     }
+    if (!count_dev)
+        count_dev = b->pcount;
     // ordered (deterministic) compaction of the indices whose break point is <= tau ...
     rocprim::counting_iterator<int> ids(0);
     rocprim::transform_iterator<const T*, KeyLE<T>, bool> flags(P<T>(b->keys_in), KeyLE<T>{T(tau)});
     size_t bytes = 0;
-    LBFGSX_HIP(rocprim::select(nullptr, bytes, ids, flags, b->pv, b->pcount, n, c->stream));
+    LBFGSX_HIP(rocprim::select(nullptr, bytes, ids, flags, b->pv, count_dev, n, c->stream));
     if (bytes > b->sel_tmp_bytes)
     {
         (void) hipFree(b->sel_tmp);
         LBFGSX_HIP(hipMalloc(&b->sel_tmp, bytes));
         b->sel_tmp_bytes = bytes;
     }
-    LBFGSX_HIP(rocprim::select(b->sel_tmp, bytes, ids, flags, b->pv, b->pcount, n, c->stream));
+    LBFGSX_HIP(rocprim::select(b->sel_tmp, bytes, ids, flags, b->pv, count_dev, n, c->stream));
+    return LBFGSX_OK;
+}
+template <class T>
+static int partial_sort_tail_t(lbfgsx_ctx* c, unsigned cnt, int64_t* nsorted);
+template <class T>
+static int partial_sort_t(lbfgsx_ctx* c, double tau, int64_t* nsorted)
+{
+    lbfgsb_state* b = c->bstate;
+    int rc = partial_select_t<T>(c, tau, nullptr);
+    if (rc)
+        return rc;
     unsigned cnt = 0;
     LBFGSX_HIP(lbfgsx::copy_async(&cnt, b->pcount, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
+    return partial_sort_tail_t<T>(c, cnt, nsorted);
+}
+template <class T>
+static int partial_sort_tail_t(lbfgsx_ctx* c, unsigned cnt, int64_t* nsorted)
+{
+    lbfgsb_state* b = c->bstate;
     *nsorted = int64_t(cnt);
     if (cnt == 0)
         return LBFGSX_OK;
@@ -1184,6 +1205,7 @@ int lbfgsx_b_cauchy_build_partial(lbfgsx_ctx* c, double tau, int64_t* nfree, int
     const int grid = c->grid_for(c->n);
     double r[4] = {0, 0, 0, -1};
     int64_t ns = 0;
+    const bool sel_ahead = b->stash_use && b->dout_host && tau > 0.0 && std::isfinite(tau);
     DISPATCH_T(c, {
         BVecs<T> bv = bvecs<T>(c);
         const bool wc = wtdc_prepare(c);
@@ -1193,6 +1215,14 @@ int lbfgsx_b_cauchy_build_partial(lbfgsx_ctx* c, double tau, int64_t* nfree, int
                            wc ? static_cast<const T*>(c->col(c->S, c->phys[size_t(newest)])) : static_cast<const T*>(nullptr),
                            wc ? b->wf_pos : static_cast<const int*>(nullptr), b->wtdc_list, b->wtdc_cnt, b->wtdc_cap);
         LBFGSX_HIP(hipGetLastError());
+        // the selection of the partial sort needs nothing from the host: it rides behind the build, its count lands in the
+        // mapped word dout[60] and is read after the same wait (without candidates it selects nothing)
+        if (sel_ahead)
+        {
+            rc = partial_select_t<T>(c, tau, reinterpret_cast<unsigned*>(b->dout + 60));
+            if (rc)
+                return rc;
+        }
         rc = fetch_doubles(c, wc ? 4 : 3, r);
         if (rc)
             return rc;
@@ -1202,7 +1232,10 @@ int lbfgsx_b_cauchy_build_partial(lbfgsx_ctx* c, double tau, int64_t* nfree, int
         {
             if (tau > 0.0 && std::isfinite(tau))
             {
-                rc = partial_sort_t<T>(c, tau, &ns);
+                if (sel_ahead)  // the selection ran behind the build: its count came with the build's sums
+                    rc = partial_sort_tail_t<T>(c, *reinterpret_cast<const volatile unsigned*>(b->dout_host + 60), &ns);
+                else
+                    rc = partial_sort_t<T>(c, tau, &ns);
                 if (rc)
                     return rc;
             }
