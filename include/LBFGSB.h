@@ -247,7 +247,13 @@ public:
         m_dev.ensure(n, m_param.m, LBFGSX_FLAG_BOUNDED, m_device);
         return run<Foo, std::vector<Scalar> >(f, fx);
     }
-    void prepare_resident(std::int64_t n) { m_dev.ensure(n, m_param.m, LBFGSX_FLAG_BOUNDED, m_device); }
+    // creates the context for dimension n and reserves the work sets the solve would otherwise allocate on first use (the
+    // buffers of the break-point search, the compact copy of the free rows, ...: lbfgsx_b_reserve)
+    void prepare_resident(std::int64_t n)
+    {
+        m_dev.ensure(n, m_param.m, LBFGSX_FLAG_BOUNDED, m_device);
+        detail::check(lbfgsx_b_reserve(m_dev.ctx()));
+    }
 
     // Eigen's vector type when Eigen is on the include path, std::vector otherwise (LBFGSpp/Interop.h; LBFGSB.h:271)
     const detail::ResultVector<Scalar>& final_grad() const

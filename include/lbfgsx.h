@@ -347,6 +347,11 @@ int lbfgsx_b_set_compaction(lbfgsx_ctx* c, int enable);
  * result was assigned, Cauchy searches whose W'd came from the copy, Grams over index lists that were launched behind the
  * pass before them and cost no round trip of their own (LBFGSX_SYNC_MERGE=0: none)}. */
 int lbfgsx_b_compact_vec_counts(int64_t out[4], int reset);
+/* Setup: allocates now what the bounded path allocates on first use -- the buffers of the device break-point search, of the
+ * partial sort and of the free-set delta, the compact copy of the free rows and its vectors -- so that a solve on a prepared
+ * context (LBFGSBSolver::prepare_resident) contains no allocation.  Optional: without it the first iterations allocate
+ * (a few milliseconds at n = 10^7).  The optional work sets are skipped silently when there is no room for them. */
+int lbfgsx_b_reserve(lbfgsx_ctx* c);
 /* A BOXCQP solve and the statements of lbfgsx_b_sub_sweep_begin on the rows it writes, in ONE pass (the solve's row of W is
  * in registers; the sweep's pass over n rows disappears).  Bit for bit lbfgsx_b_wcombine(LBFGSX_CB_SOLVE) /
  * lbfgsx_b_solve_wty followed by lbfgsx_b_sub_sweep_begin.

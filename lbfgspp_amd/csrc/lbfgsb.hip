@@ -262,6 +262,9 @@ static int cv_back(lbfgsx_ctx* c, bool assign)
     return LBFGSX_OK;
 }
 static int run_force_bounds(lbfgsx_ctx* c);
+static int scan_alloc(lbfgsx_ctx* c, int64_t count, int NC);
+static int psort_alloc(lbfgsx_ctx* c);
+static int delta_alloc(lbfgsx_ctx* c);
 // keep_force: the caller is the Cauchy build, which evaluates a deferred x = clamp(x) itself (lbfgsx_b_force_bounds_deferred);
 // every other entry of the bounded path runs it first
 // keep_cv: the caller is one of the fused sweep entries, which work on the compact vectors of the free rows; every other
@@ -541,7 +544,7 @@ static inline bool wf_serves(const lbfgsx_ctx* c, int mask)
     return c->bstate->wf_valid && mask != 0 && (mask & ~(ST_FREE | ST_L | ST_U | ST_P)) == 0;
 }
 // buffers of the compact copy and the positions of the 64-row batches for the current free set; false: do without
-static bool wf_prepare(lbfgsx_ctx* c)
+static bool wf_alloc(lbfgsx_ctx* c)
 {
     lbfgsb_state* b = c->bstate;
     const int64_t nbatch = (c->n + 63) / 64;
@@ -574,6 +577,14 @@ static bool wf_prepare(lbfgsx_ctx* c)
             return false;
         }
     }
+    return true;
+}
+static bool wf_prepare(lbfgsx_ctx* c)
+{
+    lbfgsb_state* b = c->bstate;
+    const int64_t nbatch = (c->n + 63) / 64;
+    if (!wf_alloc(c))
+        return false;
     b->wf_live = false;
     if (hipMemsetAsync(b->wf_pos, 0xFF, sizeof(int) * size_t(c->n), c->stream) != hipSuccess)  // every position -1
     {
@@ -785,12 +796,18 @@ static bool wtdc_ready(lbfgsx_ctx* c)
            b->wf_ncorr == c->ncorr && b->wf_epoch == b->sub_epoch && c->ncorr == c->m && c->n < (int64_t(1) << 31) &&
            b->wf_n >= 4096 && b->wf_n * 4 <= c->n * 3;
 }
+static bool wtdc_alloc(lbfgsx_ctx* c);
 static bool wtdc_prepare(lbfgsx_ctx* c)
 {
     lbfgsb_state* b = c->bstate;
     b->wtdc_n = -1;
     if (!wtdc_ready(c))
         return false;
+    return wtdc_alloc(c);
+}
+static bool wtdc_alloc(lbfgsx_ctx* c)
+{
+    lbfgsb_state* b = c->bstate;
     if (!b->wtdc_list)
     {
         if (hipMalloc(reinterpret_cast<void**>(&b->wtdc_list), sizeof(int) * size_t(b->wtdc_cap)) != hipSuccess ||
@@ -1132,6 +1149,20 @@ __global__ void k_gather_keys(const T* __restrict__ keys, const int* __restrict_
         out[k] = keys[idx[k]];
 }
 }  // namespace lbfgsx
+namespace lbfgsx {
+static int psort_alloc(lbfgsx_ctx* c)
+{
+    lbfgsb_state* b = c->bstate;
+    if (!b->pk)
+    {
+        const size_t n = size_t(c->n);
+        LBFGSX_HIP(hipMalloc(&b->pk, c->esz * n));
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->pv), sizeof(int) * n));
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->pcount), sizeof(unsigned)));
+    }
+    return LBFGSX_OK;
+}
+}  // namespace lbfgsx
 // the partial sort in two halves: the selection (launched; its count lands in `count_dev`), and the sort of the selected
 // break points once the count is on the host
 template <class T>
@@ -1139,12 +1170,9 @@ static int partial_select_t(lbfgsx_ctx* c, double tau, unsigned* count_dev)
 {
     lbfgsb_state* b = c->bstate;
     const size_t n = size_t(c->n);
-    if (!b->pk)
-    {
-        LBFGSX_HIP(hipMalloc(&b->pk, sizeof(T) * n));
-        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->pv), sizeof(int) * n));
-        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->pcount), sizeof(unsigned)));
-    }
+    int rca = psort_alloc(c);
+    if (rca)
+        return rca;
     if (!count_dev)
         count_dev = b->pcount;
     // ordered (deterministic) compaction of the indices whose break point is <= tau ...
@@ -1431,22 +1459,12 @@ static int64_t gcp_chain_host(const double* dt, const double* A, const double* B
 }
 extern "C" {
 
-int lbfgsx_b_cauchy_scan(lbfgsx_ctx* c, int64_t first, int64_t count, int64_t nord, const double* Mmat, double theta,
-                         double t_prev, const double* state_in, int64_t* exit_at, double* state_out)
+}  // extern "C"
+// buffers of the device break-point search for chunks of up to `count` crossings and NC components
+namespace lbfgsx {
+static int scan_alloc(lbfgsx_ctx* c, int64_t count, int NC)
 {
-    lbfgsx::DeviceGuard dev_guard_(c->device);
-    int rc = need_bounded(c);
-    if (rc)
-        return rc;
     lbfgsb_state* b = c->bstate;
-    const int nc = c->ncorr, nc2 = 2 * nc;
-    if (nc2 > 80 || count < 1 || first < 0 || first + count > nord)
-    {
-        set_error("lbfgsx_b_cauchy_scan: needs 2*ncorr <= 80 and a non-empty range inside the sorted list");
-        return LBFGSX_E_INVALID;
-    }
-    // component counts the kernels are built for: multiples of 4 up to 32, then 40, 48, 64, 80 (m = 20, 24, 32, 40)
-    const int NC = nc2 <= 32 ? std::max(4, (nc2 + 3) / 4 * 4) : nc2 <= 40 ? 40 : nc2 <= 48 ? 48 : nc2 <= 64 ? 64 : 80;
     if (count > b->s_cap || NC > b->s_nc)
     {
         void* old[] = {b->s_brk, b->s_g, b->s_z, b->s_W, b->s_P, b->s_C, b->s_fpp, b->s_dfp, b->s_fp, b->s_ts, b->s_off};
@@ -1482,6 +1500,30 @@ int lbfgsx_b_cauchy_scan(lbfgsx_ctx* c, int64_t first, int64_t count, int64_t no
         b->s_cap = cap;
         b->s_nc = ncap;
     }
+    return LBFGSX_OK;
+}
+}  // namespace lbfgsx
+extern "C" {
+
+int lbfgsx_b_cauchy_scan(lbfgsx_ctx* c, int64_t first, int64_t count, int64_t nord, const double* Mmat, double theta,
+                         double t_prev, const double* state_in, int64_t* exit_at, double* state_out)
+{
+    lbfgsx::DeviceGuard dev_guard_(c->device);
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    lbfgsb_state* b = c->bstate;
+    const int nc = c->ncorr, nc2 = 2 * nc;
+    if (nc2 > 80 || count < 1 || first < 0 || first + count > nord)
+    {
+        set_error("lbfgsx_b_cauchy_scan: needs 2*ncorr <= 80 and a non-empty range inside the sorted list");
+        return LBFGSX_E_INVALID;
+    }
+    // component counts the kernels are built for: multiples of 4 up to 32, then 40, 48, 64, 80 (m = 20, 24, 32, 40)
+    const int NC = nc2 <= 32 ? std::max(4, (nc2 + 3) / 4 * 4) : nc2 <= 40 ? 40 : nc2 <= 48 ? 48 : nc2 <= 64 ? 64 : 80;
+    rc = scan_alloc(c, count, NC);
+    if (rc)
+        return rc;
     rc = upload_phys(c);
     if (rc)
         return rc;
@@ -1645,6 +1687,37 @@ int lbfgsx_b_sub_begin(lbfgsx_ctx* c)
 static bool gram_stash_launch(lbfgsx_ctx* c, int slot, int mask, const int* list, int64_t nlist);
 static void gram_stash_settle(lbfgsx_ctx* c, bool ok);
 extern "C" {
+int lbfgsx_b_reserve(lbfgsx_ctx* c)
+{
+    lbfgsx::DeviceGuard dev_guard_(c->device);
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    lbfgsb_state* b = c->bstate;
+    const int m2 = 2 * c->m;
+    const int ncap = m2 <= 32 ? std::max(4, (m2 + 3) / 4 * 4) : m2 <= 40 ? 40 : m2 <= 48 ? 48 : m2 <= 64 ? 64 : 80;
+    if (m2 <= 80)
+    {
+        rc = scan_alloc(c, std::min<int64_t>(int64_t(1) << 20, c->n), ncap);
+        if (rc)
+            return rc;
+    }
+    rc = psort_alloc(c);
+    if (rc)
+        return rc;
+    rc = delta_alloc(c);
+    if (rc)
+        return rc;
+    // the optional work sets: without room for them the passes that would use them do without
+    if (b->wf_use && c->n >= 4096 && c->n < (int64_t(1) << 31))
+        (void) wf_alloc(c);
+    if (b->cv_use && b->wf_use)
+        (void) cv_alloc(c);
+    if (b->wtdc_use)
+        (void) wtdc_alloc(c);
+    return LBFGSX_OK;
+}
+
 int lbfgsx_b_compact_vec_counts(int64_t out[4], int reset)
 {
     if (out)
@@ -2190,12 +2263,10 @@ int lbfgsx_b_wtv_prologue(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, co
 
 static int gram_dd_core(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, const double* coef1, const double* coef2,
                         double* gram, double* wtv, double* gram_dd, const int* list, int64_t nlist);
-int lbfgsx_b_free_delta(lbfgsx_ctx* c, int64_t* n_enter, int64_t* n_leave)
+}  // extern "C"
+namespace lbfgsx {
+static int delta_alloc(lbfgsx_ctx* c)
 {
-    lbfgsx::DeviceGuard dev_guard_(c->device);
-    int rc = need_bounded(c);
-    if (rc)
-        return rc;
     lbfgsb_state* b = c->bstate;
     if (!b->fprev)
     {
@@ -2209,6 +2280,20 @@ int lbfgsx_b_free_delta(lbfgsx_ctx* c, int64_t* n_enter, int64_t* n_leave)
         LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->dl_leave), sizeof(int) * size_t(b->dl_cap)));
         LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->dl_cnt), sizeof(unsigned) * 4));
     }
+    return LBFGSX_OK;
+}
+}  // namespace lbfgsx
+extern "C" {
+int lbfgsx_b_free_delta(lbfgsx_ctx* c, int64_t* n_enter, int64_t* n_leave)
+{
+    lbfgsx::DeviceGuard dev_guard_(c->device);
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    lbfgsb_state* b = c->bstate;
+    rc = delta_alloc(c);
+    if (rc)
+        return rc;
     if (b->wf_live && (b->wf_ncorr != c->ncorr || b->wf_epoch + 1 != b->sub_epoch))
         b->wf_live = false;  // the history has grown (another column order), or the copy missed an iteration
     // {rows entered, rows left, rows in the kept compact copy, 1: the copy cannot be kept}

@@ -7,6 +7,17 @@
 #pragma once
 #include "reduce.cuh"
 
+// resident blocks per CU the register kernels of the sweeps are compiled for (scripts/experiments/kernels_isolated.hip)
+#ifndef LBFGSX_VROWS_OCC
+#define LBFGSX_VROWS_OCC 2
+#endif
+#ifndef LBFGSX_SWEEP_OCC
+#define LBFGSX_SWEEP_OCC 2
+#endif
+#ifndef LBFGSX_VROWS_W2
+#define LBFGSX_VROWS_W2 0
+#endif
+
 namespace lbfgsx {
 
 // state byte
@@ -1236,7 +1247,7 @@ struct VrowIn  // what a row needs besides its column values
     unsigned char st;
 };
 template <class T, int NC, int NA>
-__global__ void __launch_bounds__(kBlock, (NA == 1 && NC <= 20) ? 2 : 1)
+__global__ void __launch_bounds__(kBlock, (NA == 1 && NC <= 20) ? LBFGSX_VROWS_OCC : 1)
     k_vrows(Cols<T, 32> cols, int ncols, BVecs<T> b, int vsel_id, int mask, int64_t n, RedWs ws, double* __restrict__ out,
             double* __restrict__ out_dd, GramPrologue<T> pro, GramRows<T> gr, int col_a, int col_b)
 {
@@ -1358,7 +1369,34 @@ __global__ void __launch_bounds__(kBlock, (NA == 1 && NC <= 20) ? 2 : 1)
                 vv.add_prod(v, v);
     };
     const int64_t stride = int64_t(gridDim.x) * kBlock;
-    if (NA == 1)
+    if (NA == 1 && LBFGSX_VROWS_W2 && NC <= 20)
+    {
+        // two rows per trip (t and t + stride): twice the loads in flight per wavefront, which two waves per SIMD need to keep
+        // the memory system busy while the other wave is in its ~300 dependent f64 operations; the second row's index is
+        // clamped (loaded again, dropped) so that every load stays unconditional
+        if (n > 0)
+        {
+            const int64_t last = n - 1;
+            for (int64_t t = int64_t(blockIdx.x) * kBlock + threadIdx.x; t < n; t += 2 * stride)
+            {
+                const int64_t tb = t + stride, tbc = tb < n ? tb : last;
+                int64_t r0 = t, r1 = tbc;
+                if (gr.in_idx)
+                {
+                    r0 = gr.in_idx[t];
+                    r1 = gr.in_idx[tbc];
+                }
+                VrowIn<T> x0, x1;
+                T w0[NC], w1[NC];
+                fetch(r0, x0, w0, t);
+                fetch(r1, x1, w1, tbc);
+                one_row(w0, t, r0, x0);
+                if (tb < n)
+                    one_row(w1, tb, r1, x1);
+            }
+        }
+    }
+    else if (NA == 1)
     {
         for (int64_t t = int64_t(blockIdx.x) * kBlock + threadIdx.x; t < n; t += stride)
         {
@@ -1958,7 +1996,7 @@ __device__ __forceinline__ unsigned char sweep_row_v(const BVecs<T>& b, int64_t 
 // and the state byte of every position included; cv = 2: reads and writes by position (b = bw = the compact set),
 // lb - x0 / ub - x0 from cli / cui, the row number only fetched for a row that enters the L u U list.
 template <class T, int NC, int FIRST>
-__global__ void __launch_bounds__(kBlock, NC <= 24 ? 2 : 1) k_solve_sweep(Cols<T, 32> cols, int ncols, BVecs<T> b, BVecs<T> bw, int vsel_id,
+__global__ void __launch_bounds__(kBlock, NC <= 24 ? LBFGSX_SWEEP_OCC : 1) k_solve_sweep(Cols<T, 32> cols, int ncols, BVecs<T> b, BVecs<T> bw, int vsel_id,
                                                         CoefArg<T> coef, int has_w, T theta, int64_t n, RedWs ws, double* __restrict__ out,
                                                         int* __restrict__ lu_list, unsigned* __restrict__ lu_cnt, unsigned lu_cap,
                                                         const int* __restrict__ ridx, T* __restrict__ cli, T* __restrict__ cui, int cv)
