@@ -16,9 +16,7 @@ python scripts/trace_cfg4.py $O/lbfgsb > $O/cfg4_timeline.txt 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/lbfgsb_pmc_fetch -o b -- $BCMD > $O/lbfgsb_pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/lbfgsb_pmc_write -o b -- $BCMD > $O/lbfgsb_pmc_write.log 2>&1
 python scripts/bench_lbfgsb.py --n 1e7 --iters 40 --cpu-n 2e5 > $O/bench_cfg4_lbfgsb.json 2> /dev/null
-# the default configuration that runs the matrix-core Gram: L-BFGS-B, f64, m = 15
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/lbfgsb_m15 -o b -- python scripts/bench_lbfgsb.py --n 1e7 --m 15 --iters 50 > $O/bench_cfg4_m15.json 2> $O/lbfgsb_m15.log
-LBFGSX_GRAM=dd python scripts/bench_lbfgsb.py --n 1e7 --m 15 --iters 50 > $O/bench_cfg4_m15_dd.json 2> /dev/null
+# the matrix-core Gram question (opt-in) has its own script: scripts/experiments/prof_gram_m.sh (final_r3.sh)
 # cfg5 batch
 KCMD="python bench.py --workload cfg5-batched --steps 50 --no-cpu"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/batched_trace -o bench -- $KCMD > $O/batched_trace.log 2>&1
