@@ -18,6 +18,7 @@
 #define LBFGSX_VROWS_W2 0
 #endif
 
+
 namespace lbfgsx {
 
 // state byte
