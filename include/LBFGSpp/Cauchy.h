@@ -93,7 +93,10 @@ class Cauchy
     static std::int64_t device_switch()
     {
         const char* e = std::getenv("LBFGSX_GCP_DEVICE_MIN");
-        return e ? std::atoll(e) : (sizeof(Scalar) == sizeof(double) ? std::int64_t(4096) : std::int64_t(65536));
+        // f64: 256 -- below it the steady-state searches (10^2 crossings) would pay a device chunk each, above it the early
+        // ones walk crossings on the host that the device form does for a tenth of the cost (same-box sweep at cfg4:
+        // 4096 -> 224 it/s from x0, 256 -> 234, 64 -> steady state -3 %); the hand-over point does not touch parity
+        return e ? std::atoll(e) : (sizeof(Scalar) == sizeof(double) ? std::int64_t(256) : std::int64_t(65536));
     }
 
     // The next search sorts only the break points up to tau = factor * (this search's Cauchy time): in steady state

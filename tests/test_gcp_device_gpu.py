@@ -1,6 +1,6 @@
 """-m gpu: the device form of the generalized-Cauchy-point search (lbfgsx_b_cauchy_scan, csrc/gcp_scan.cuh;
-reference loop Cauchy.h:183-256).  By default the host keeps the reference's sequential form for the first 4096
-crossings of a search; here LBFGSX_GCP_DEVICE_MIN=0 sends the search to the device from the first crossing.  Single
+reference loop Cauchy.h:183-256).  By default the host keeps the reference's sequential form for the first 256
+crossings of a search (f32 problems: 65536); here LBFGSX_GCP_DEVICE_MIN=0 sends the search to the device from the first crossing.  Single
 searches and whole trajectories must agree with the oracle at the same tolerances as the sequential form (1e-10 on
 the iterates): the order-sensitive f' / f'' recurrences run in the reference's left-to-right order over the terms
 the device produces.  The round-1 form (LBFGSX_GCP_CHAIN=scan: tree-order prefix sums for f' and f'' too) is kept as an
