@@ -155,6 +155,11 @@ int lbfgsx_debug_persist_fault(lbfgsx_ctx* c);
 /* instrumentation, process-wide: {kernel launches, stream synchronisations, asynchronous copies} issued by the library
  * since load (or the last call with reset != 0).  bench.py divides them by the iterations of its L-BFGS-B leg. */
 int lbfgsx_counters(int64_t out[3], int reset);
+/* Polled completion (contexts with mapped outputs, i.e. L-BFGS-B ones; LBFGSX_POLL=0 switches it off): the last block of a
+ * kernel whose results the host reads next stores a sequence number in host-mapped memory after the results, and the host
+ * polls that word instead of waiting for the stream (which returns ~9 us after the kernel's end).  out = {waits served by
+ * polling, waits that timed out (50 ms) and fell back to the stream wait -- a kernel that failed to signal} */
+int lbfgsx_poll_counts(const lbfgsx_ctx* c, int64_t out[2]);
 
 /* ---- Gram-space ("vector-free") form of the recursion: opt-in, outside the bit-parity contract ----
  * BFGSMat::apply_Hv (BFGSMat.h:276-302) only combines the 2c+1 vectors [S, Y, g]; with their Gram matrix kept on the

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -159,6 +160,12 @@ struct lbfgsx_ctx
     void* outmap_host = nullptr;
     void* outmap_dev = nullptr;
     lbfgsx::RedWs ws;
+    // polled completion (RedWs::done): one host-mapped word per context; LBFGSX_POLL=0 waits for the stream instead
+    unsigned long long* done_host = nullptr;
+    unsigned long long* done_dev = nullptr;
+    unsigned long long done_seq = 0;
+    long long poll_waits = 0, poll_timeouts = 0;
+    bool poll_pending = false;  // poll_arm ran and no wait has consumed it yet
     int grid_cap = 1024;     // blocks per launch of the streaming kernels (4 per CU; tuned on MI355X, see profiles/)
     int grid_cap_twoloop = 512;
     int unroll = 4;   // 16-byte loads in flight per stream per thread in the two-loop kernels
@@ -229,3 +236,60 @@ struct lbfgsx_ctx
         return int(blocks);
     }
 };
+
+namespace lbfgsx {
+// Polled completion.  poll_arm before the launch of the LAST kernel whose results the host is about to read (the kernel ends
+// with ws_signal, reduce.cuh); poll_wait instead of stream_sync.  The word is monotonic per context, so an un-armed launch
+// that carries an old sequence number changes nothing.  A kernel that never signals costs a time-out (counted) and a wait
+// for the stream: correct, slow, visible in lbfgsx_poll_counts.
+inline void poll_arm(lbfgsx_ctx* c)
+{
+    if (c->done_host)
+    {
+        c->ws.done = c->done_dev;
+        c->ws.seq = ++c->done_seq;
+        c->poll_pending = true;
+    }
+}
+inline bool poll_armed(const lbfgsx_ctx* c) { return c->done_host && c->poll_pending && c->ws.done && c->ws.seq == c->done_seq; }
+inline void poll_disarm(lbfgsx_ctx* c)
+{
+    c->ws.done = nullptr;
+    c->poll_pending = false;
+}
+inline hipError_t poll_wait(lbfgsx_ctx* c)
+{
+    if (!poll_armed(c))
+    {
+        poll_disarm(c);
+        return stream_sync(c->stream);
+    }
+    poll_disarm(c);  // launches from here on carry no completion word until the next poll_arm
+    counters().syncs.fetch_add(1, std::memory_order_relaxed);
+    const bool tr = host_trace_on();
+    if (tr)
+        host_trace(">sync");
+    const volatile unsigned long long* w = c->done_host;
+    const unsigned long long want = c->done_seq;
+    c->poll_waits++;
+    auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0;; spin++)
+    {
+        if (*w >= want)
+            break;
+        if ((spin & 1023u) == 1023u &&
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.05)
+        {
+            c->poll_timeouts++;
+            const hipError_t e = hipStreamSynchronize(c->stream);
+            if (tr)
+                host_trace("<sync");
+            return e;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (tr)
+        host_trace("<sync");
+    return hipSuccess;
+}
+}  // namespace lbfgsx

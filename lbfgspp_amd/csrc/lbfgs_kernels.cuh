@@ -177,6 +177,7 @@ __global__ void __launch_bounds__(kBlock) k_trial(const T* __restrict__ xp, cons
     {
         out[0] = obj.finish(T(acc[0].value()));
         out[1] = T(acc[1].value());
+        ws_signal(ws);
     }
 }
 

@@ -281,6 +281,7 @@ static int need_bounded(lbfgsx_ctx* c, bool keep_force = false, bool keep_cv = f
     if (!keep_stash)
         for (int q = 0; q < 3; q++)
             c->bstate->stash_valid[q] = c->bstate->stash_armed[q] = false;
+    lbfgsx::poll_disarm(c);  // an entry starts with no completion word armed (an error path may have left one)
     if (c->bstate->cv_live && !keep_cv)
     {
         lbfgsx::DeviceGuard dev_guard_(c->device);
@@ -309,8 +310,9 @@ static int fetch_doubles(lbfgsx_ctx* c, int k, double* out)
 {
     if (c->bstate->dout_host)
     {
-        // dout is host-mapped: the kernel's stores are visible once the stream has drained (no copy kernel)
-        LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
+        // dout is host-mapped: the kernel's stores are visible once the stream has drained (no copy kernel) -- or, after a
+        // poll_arm, once the kernel's completion word has arrived
+        LBFGSX_HIP(lbfgsx::poll_wait(c));
         const volatile double* h = c->bstate->dout_host;
         for (int i = 0; i < k; i++)
             out[i] = h[i];
@@ -327,7 +329,7 @@ static int fetch_T(lbfgsx_ctx* c, int idx, int k, double* out)
 {
     if (idx == c->sl.out(0) && c->outmap_dev)
     {
-        LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
+        LBFGSX_HIP(lbfgsx::poll_wait(c));
         const volatile T* h = static_cast<const volatile T*>(c->outmap_host);
         for (int i = 0; i < k; i++)
             out[i] = double(h[i]);
@@ -767,6 +769,7 @@ static int wtd2_wf(lbfgsx_ctx* c, int total, int newest, double* wtd)
     const T* snew = static_cast<const T*>(c->col(c->S, c->phys[size_t(newest)]));
     const T* ynew = static_cast<const T*>(c->col(c->Y, c->phys[size_t(newest)]));
     const int grid = std::max(1, std::min(std::min(c->grid_for(b->wf_n), b->num_cus), c->ws.maxGrid));
+    lbfgsx::poll_arm(c);
     LBFGSX_LAUNCH((k_multidot2_wf<T, NC>), dim3(grid), dim3(kBlock), 0, c->stream, wfc, fresh_a, fresh_b, snew, ynew,
                   static_cast<const T*>(b->dvec), b->wf_idx, b->wf_n, full, b->wtdc_list, int(b->wtdc_n), c->ws, b->dout);
     LBFGSX_HIP(hipGetLastError());
@@ -996,6 +999,7 @@ int lbfgsx_b_dg_maxstep(lbfgsx_ctx* c, double* dg, double* step_max)
     const int grid = c->grid_for(c->n);
     double r[2];
     DISPATCH_T(c, {
+        lbfgsx::poll_arm(c);
         LBFGSX_LAUNCH((k_b_dg_maxstep<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]),
                            P<T>(c->gb[c->cur]), P<T>(c->d), P<T>(c->lb), P<T>(c->ub), c->n, c->ws, c->out_slot<T>());
         LBFGSX_HIP(hipGetLastError());
@@ -1025,6 +1029,7 @@ int lbfgsx_b_post_linesearch(lbfgsx_ctx* c, double* projgnorm, double* xnorm2, d
         c->bstate->colmax_ok[size_t(c->spare)] = 1;
     }
     DISPATCH_T(c, {
+        lbfgsx::poll_arm(c);
         LBFGSX_LAUNCH((k_b_post<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]), P<T>(c->xb[c->xp]),
                            P<T>(c->gb[c->cur]), P<T>(c->gb[c->xp]), P<T>(c->lb), P<T>(c->ub), P<T>(c->col(c->S, c->spare)),
                            P<T>(c->col(c->Y, c->spare)), c->n, c->ws, c->out_slot<T>(),
@@ -1652,6 +1657,7 @@ int lbfgsx_b_cauchy_finish(lbfgsx_ctx* c, double t_cross, double tfinal, int cro
         BVecs<T> bv = bvecs<T>(c);
         c->bstate->lu_valid = false;  // the state bytes are rewritten
         c->bstate->wf_valid = false;
+        lbfgsx::poll_arm(c);
         LBFGSX_LAUNCH((k_cauchy_finish<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, T(t_cross), T(tfinal), crossed_all,
                            c->n, c->ws, c->bstate->dout);
     });
@@ -1684,7 +1690,8 @@ int lbfgsx_b_sub_begin(lbfgsx_ctx* c)
 }
 
 }  // extern "C"
-static bool gram_stash_launch(lbfgsx_ctx* c, int slot, int mask, const int* list, int64_t nlist);
+static bool gram_stash_launch(lbfgsx_ctx* c, int slot, int mask, const int* list, int64_t nlist, bool signal = false);
+static bool gram_stash_feasible(lbfgsx_ctx* c, const int* list, int64_t nlist);
 static void gram_stash_settle(lbfgsx_ctx* c, bool ok);
 extern "C" {
 int lbfgsx_b_reserve(lbfgsx_ctx* c)
@@ -1778,6 +1785,10 @@ int lbfgsx_b_wtv_lu(lbfgsx_ctx* c, double* out_l, int64_t* nnz_l, double* out_u,
         which[k] = k;
     double r[50];
     int nc = 24;
+    // the wait below ends with the last kernel launched before it: the Gram that rides behind this pass, or this pass
+    const bool rides = gram_stash_feasible(c, b->lu_ptr(), nl);
+    if (!rides)
+        lbfgsx::poll_arm(c);
     DISPATCH_T(c, {
         Cols<T, 32> cl = col_list<T, 32>(c, which, total);
         BVecs<T> bv = bvecs<T>(c);
@@ -1803,7 +1814,8 @@ int lbfgsx_b_wtv_lu(lbfgsx_ctx* c, double* out_l, int64_t* nnz_l, double* out_u,
     LBFGSX_HIP(hipGetLastError());
     // the solve that follows asks for the Gram over the same rows (the complement identity, lbfgsx_b_gram_fused_dd): it
     // rides behind this pass and is there when this pass's wait returns
-    (void) gram_stash_launch(c, 0, ST_L | ST_U, b->lu_ptr(), nl);
+    if (rides)
+        (void) gram_stash_launch(c, 0, ST_L | ST_U, b->lu_ptr(), nl, /*signal=*/true);
     rc = fetch_doubles(c, 2 * (nc + 1), r);
     gram_stash_settle(c, rc == LBFGSX_OK);
     if (rc)
@@ -2001,12 +2013,19 @@ static int launch_gram_vonly(lbfgsx_ctx* c, int64_t nbatch, int tot, int vsel_id
 }
 // A Gram over the rows of an index list (2c x 2c, no v row) launched ahead of its request into stash slot `slot`; mask != 0:
 // only the listed rows whose state byte has one of its bits.  false: not launched (the request will launch it itself).
-static bool gram_stash_launch(lbfgsx_ctx* c, int slot, int mask, const int* list, int64_t nlist)
+static bool gram_stash_feasible(lbfgsx_ctx* c, const int* list, int64_t nlist)
+{
+    lbfgsb_state* b = c->bstate;
+    const int tot = 2 * c->ncorr;
+    return b->stash_use && b->stash_host && !b->gram_mfma && b->gram_mode != 2 && tot >= 1 && tot <= kGramDDCS && list && nlist >= 1;
+}
+// signal: this is the last launch before the caller's wait -- its final block carries the completion word (ctx.hpp)
+static bool gram_stash_launch(lbfgsx_ctx* c, int slot, int mask, const int* list, int64_t nlist, bool signal)
 {
     lbfgsb_state* b = c->bstate;
     const int tot = 2 * c->ncorr;
     b->stash_valid[slot] = b->stash_armed[slot] = false;
-    if (!b->stash_use || !b->stash_host || b->gram_mfma || b->gram_mode == 2 || tot < 1 || tot > kGramDDCS || !list || nlist < 1)
+    if (!gram_stash_feasible(c, list, nlist))
         return false;
     if (upload_phys(c) != LBFGSX_OK)
         return false;
@@ -2039,7 +2058,12 @@ static bool gram_stash_launch(lbfgsx_ctx* c, int slot, int mask, const int* list
     double* out = b->stash_dev + size_t(slot) * (3 * 256 * 3);
     const int nch = std::min(blocks, 32);
     LBFGSX_LAUNCH(k_gram_finish, dim3(ntile, nch), dim3(kBlock), 0, c->stream, b->gram_partial, blocks, b->gram_partial2, 0);
-    LBFGSX_LAUNCH(k_gram_finish, dim3(ntile, 1), dim3(kBlock), 0, c->stream, b->gram_partial2, nch, out, 1, out + 3 * 256);
+    if (signal && ntile == 1)
+        lbfgsx::poll_arm(c);
+    else
+        signal = false;
+    LBFGSX_LAUNCH(k_gram_finish, dim3(ntile, 1), dim3(kBlock), 0, c->stream, b->gram_partial2, nch, out, 1, out + 3 * 256,
+                  signal ? c->ws.done : static_cast<unsigned long long*>(nullptr), signal ? c->ws.seq : 0ull);
     if (hipGetLastError() != hipSuccess)
         return false;
     b->stash_armed[slot] = true;
@@ -2118,7 +2142,7 @@ static int fetch_gram_out(lbfgsx_ctx* c, int first, int count, double* h)
     lbfgsb_state* b = c->bstate;
     if (b->gram_out_host)
     {
-        LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
+        LBFGSX_HIP(lbfgsx::poll_wait(c));
         const volatile double* src = b->gram_out_host + first;
         for (int i = 0; i < count; i++)
             h[i] = src[i];
@@ -2220,6 +2244,7 @@ int lbfgsx_b_wtv_prologue(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, co
         if (b->vrows)
         {
             const BVecs<T> cvb = bvecs_cv<T>(c);
+            lbfgsx::poll_arm(c);
             rc = launch_vrows_v<T>(c, tot, vsel_id, mask, pro, gr, nrows, by_pos ? &cvb : nullptr);
             blocks = 0;
         }
@@ -2400,6 +2425,7 @@ int lbfgsx_b_gram_pairs_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
     // the register kernel serves the pass that writes no new copy when the entries are the v row plus the rows of at most
     // two columns (3 (2c + 1) <= 64 sums: one lane per sum in the block reduction)
     int col_a = -1, col_b = -1, slot[64];
+    bool ride_enter = false, ride_leave = false;
     bool use_vrows = b->vrows && !compact_out && vrows_plan(npairs, pair_i, pair_j, tot, (tot <= 20 ? 20 : 32) + 1, col_a, col_b, slot);
     if (use_vrows && col_a >= 0 && (tot > 20 || !compact_in))  // the three-row form walks the compact copy's row list
         use_vrows = false;
@@ -2447,6 +2473,11 @@ int lbfgsx_b_gram_pairs_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
         if (use_vrows)
         {
             blocks = 0;
+            // the wait below ends with the last kernel launched before it: this pass, or the last Gram riding behind it
+            ride_enter = b->fprev && b->dl_n[0] >= 1 && gram_stash_feasible(c, b->dl_enter, b->dl_n[0]);
+            ride_leave = b->fprev && b->dl_n[1] >= 1 && gram_stash_feasible(c, b->dl_leave, b->dl_n[1]);
+            if (!ride_enter && !ride_leave)
+                lbfgsx::poll_arm(c);
             if (col_a < 0)
                 rc = launch_vrows_v<T>(c, tot, vsel_id, mask, pro, gr, nrows);
             else
@@ -2471,13 +2502,10 @@ int lbfgsx_b_gram_pairs_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
     {
         // the carried first solve goes on to ask for the Grams over the rows that entered and left the free set
         // (lbfgsx_b_gram_list_dd): they ride behind this pass
-        if (b->fprev)
-        {
-            if (b->dl_n[0] >= 1)
-                (void) gram_stash_launch(c, 1, 0, b->dl_enter, b->dl_n[0]);
-            if (b->dl_n[1] >= 1)
-                (void) gram_stash_launch(c, 2, 0, b->dl_leave, b->dl_n[1]);
-        }
+        if (ride_enter)
+            (void) gram_stash_launch(c, 1, 0, b->dl_enter, b->dl_n[0], /*signal=*/!ride_leave);
+        if (ride_leave)
+            (void) gram_stash_launch(c, 2, 0, b->dl_leave, b->dl_n[1], /*signal=*/true);
         double h[2 * 64];
         rc = fetch_gram_out(c, 256, 2 * 64, h);
         gram_stash_settle(c, rc == LBFGSX_OK);
@@ -2942,6 +2970,7 @@ static int solve_sweep_t(lbfgsx_ctx* c, int first, int vsel_id, const double* co
     T* cui = nullptr;
     const BVecs<T> full = bvecs<T>(c);
     const BVecs<T> cvb = cv ? bvecs_cv<T>(c, &cli, &cui) : full;
+    lbfgsx::poll_arm(c);
     if (first)
         LBFGSX_LAUNCH((k_solve_sweep<T, NC, 1>), dim3(grid), dim3(kBlock), 0, c->stream, cl, total, full, cvb, vsel_id, cf,
                       coef ? 1 : 0, T(theta), nrows, c->ws, b->dout, lu_dst, b->lu_cnt, lu_cap_now, ridx, cli, cui, cv);
@@ -3060,6 +3089,7 @@ int lbfgsx_b_lu_sweep(lbfgsx_ctx* c, const double* coef, double theta, int64_t s
         T* cli = nullptr;
         T* cui = nullptr;
         const BVecs<T> bv = b->cv_live ? bvecs_cv<T>(c, &cli, &cui) : bvecs<T>(c);
+        lbfgsx::poll_arm(c);
         LBFGSX_LAUNCH((k_lu_sweep<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, P<T>(c->S), P<T>(c->Y), c->ld,
                            b->phys_dev, c->ncorr, cf, has_w, T(theta), b->lu_ptr(), nl, c->ws, b->dout, b->lu_other(), b->lu_cnt,
                            b->lu_cap, b->cv_live ? b->wf_pos : static_cast<const int*>(nullptr), cli, cui);

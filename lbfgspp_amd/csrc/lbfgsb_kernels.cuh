@@ -229,6 +229,7 @@ __global__ void __launch_bounds__(kBlock) k_b_dg_maxstep(const T* __restrict__ x
         {
             out[0] = T(acc[0].value());
             out[1] = T(smin_all);
+            ws_signal(ws);
         }
     }
 }
@@ -278,6 +279,7 @@ __global__ void __launch_bounds__(kBlock) k_b_post(const T* __restrict__ x, cons
             out[3] = T(pgmax);
             *ys_slot = sy;
             *theta_slot = yy / sy;
+            ws_signal(ws);
         }
     }
 }
@@ -383,8 +385,11 @@ __global__ void __launch_bounds__(kBlock) k_multidot_list2(Cols<T, 32> cols, int
         }
     }
     if (grid_reduce<2 * (NC + 1)>(acc, ws) && threadIdx.x == 0)
+    {
         for (int k = 0; k < 2 * (NC + 1); k++)
             out[k] = double(T(acc[k].value()));
+        ws_signal(ws);
+    }
 }
 
 // The same masked multi-dot for ALL 2c columns in one launch (K4): each thread takes one 16-byte vector of
@@ -606,8 +611,11 @@ __global__ void __launch_bounds__(kBlock, 1) k_multidot2_wf(Cols<T, 32> wfc, int
         }
     }
     if (grid_reduce<2 * NC>(acc, ws) && threadIdx.x == 0)
+    {
         for (int k = 0; k < 2 * NC; k++)
             out[k] = double(T(acc[k].value()));
+        ws_signal(ws);
+    }
 }
 
 // ---------------------------------------------------------------- masked Gram block: out[a*TB+c] = sum_{i in mask} I_a[i] * J_c[i]
@@ -1198,7 +1206,8 @@ __global__ void __launch_bounds__(kBlock) k_gram_dd(Cols<T, 32> cols, int ncols,
 // (lane>>4) + 4*reg, column lane&15; with out_dd also the un-rounded double-double sums (hi, lo) per entry, for the
 // complement identity of lbfgsx_b_gram_fused_dd.
 __global__ void __launch_bounds__(kBlock) k_gram_finish(const double* __restrict__ partial, int nblocks,
-                                                        double* __restrict__ out, int final, double* __restrict__ out_dd = nullptr)
+                                                        double* __restrict__ out, int final, double* __restrict__ out_dd = nullptr,
+                                                        unsigned long long* done = nullptr, unsigned long long seq = 0)
 {
     const int tb = blockIdx.x, ch = blockIdx.y, nch = gridDim.y, e = threadIdx.x;
     DD t;
@@ -1214,6 +1223,13 @@ __global__ void __launch_bounds__(kBlock) k_gram_finish(const double* __restrict
         {
             out_dd[(tb * 256 + e) * 2 + 0] = t.hi;
             out_dd[(tb * 256 + e) * 2 + 1] = t.lo;
+        }
+        if (done)  // completion word (RedWs::done); the host passes it only to a single-block final launch
+        {
+            __threadfence_system();
+            __syncthreads();
+            if (e == 0)
+                __hip_atomic_store(done, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     else
@@ -1444,6 +1460,7 @@ __global__ void __launch_bounds__(kBlock, (NA == 1 && NC <= 20) ? LBFGSX_VROWS_O
         if (j == ncols)
             acc[j] = vv;
     if (grid_reduce<NA * NP>(acc, ws) && threadIdx.x == 0)
+    {
 #pragma unroll
         for (int k = 0; k < NA * NP; k++)
         {
@@ -1454,6 +1471,8 @@ __global__ void __launch_bounds__(kBlock, (NA == 1 && NC <= 20) ? LBFGSX_VROWS_O
                 out_dd[2 * k + 1] = acc_lo(acc[k]);
             }
         }
+        ws_signal(ws);
+    }
 }
 
 // append row i to the index list when `app`; one counter update per wavefront, the lanes that append ranked by ballot
@@ -1605,6 +1624,7 @@ __global__ void __launch_bounds__(kBlock) k_cauchy_finish(BVecs<T> b, T t_cross,
     {
         out[0] = acc[0].value();
         out[1] = acc[1].value();
+        ws_signal(ws);
     }
 }
 
@@ -2106,6 +2126,7 @@ __global__ void __launch_bounds__(kBlock, NC <= 24 ? LBFGSX_SWEEP_OCC : 1) k_sol
             out[ND + k] = acc[ND + k].value();
         if (FIRST)
             __hip_atomic_store(lu_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ws_signal(ws);
     }
 }
 
@@ -2161,6 +2182,7 @@ __global__ void __launch_bounds__(kBlock) k_lu_sweep(BVecs<T> b, const T* __rest
         for (int k = 0; k < 7; k++)
             out[k] = acc[k].value();
         __hip_atomic_store(lu_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ws_signal(ws);
     }
 }
 

@@ -194,8 +194,9 @@ static int fetch_scalars(lbfgsx_ctx* c, int idx, int k, double* out)
 {
     if (idx == c->sl.out(0) && c->outmap_dev)
     {
-        // the kernel stored these into host-mapped memory (ctx.hpp): visible once the stream has drained
-        LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
+        // the kernel stored these into host-mapped memory (ctx.hpp): visible once the stream has drained, or -- when the
+        // launch was armed (poll_arm) -- once the kernel's completion word has arrived
+        LBFGSX_HIP(lbfgsx::poll_wait(c));
         const volatile T* h = static_cast<const volatile T*>(c->outmap_host);
         for (int i = 0; i < k; i++)
             out[i] = double(h[i]);
@@ -376,6 +377,14 @@ static int create_fill(lbfgsx_ctx* c, int dtype, int64_t n, int m, int device, i
             LBFGSX_HIP(hipHostMalloc(&c->outmap_host, sizeof(double) * 16, hipHostMallocMapped));
             std::memset(c->outmap_host, 0, sizeof(double) * 16);
             LBFGSX_HIP(hipHostGetDevicePointer(&c->outmap_dev, c->outmap_host, 0));
+            // polled completion of the kernels whose results land there (ctx.hpp: poll_arm / poll_wait)
+            const char* pe = getenv("LBFGSX_POLL");
+            if (!(pe && atoi(pe) == 0))
+            {
+                LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->done_host), 64, hipHostMallocMapped));
+                std::memset(c->done_host, 0, 64);
+                LBFGSX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->done_dev), c->done_host, 0));
+            }
         }
     }
     c->ws.maxGrid = 8192;
@@ -438,6 +447,8 @@ void lbfgsx_destroy(lbfgsx_ctx* c)
     (void) hipHostFree(c->hout);
     if (c->outmap_host)
         (void) hipHostFree(c->outmap_host);
+    if (c->done_host)
+        (void) hipHostFree(c->done_host);
     (void) hipFree(c->ws.partials);
     (void) hipFree(c->gen_dev);
     (void) hipFree(c->ws.ticket);
@@ -1002,6 +1013,7 @@ static int trial_t(lbfgsx_ctx* c, OBJ obj, T step, double* out2)
 {
     const int grid = c->grid_for(c->n);
     const int rev = (c->zigzag && (c->tl_step++ & 1u)) ? 1 : 0;
+    lbfgsx::poll_arm(c);
     // 4 vectors per stream and thread in flight (measured +1 % on the north-star against 2; profiles/r1_mall_policy_ab.txt)
 #define TRIAL_LAUNCH(UU, NTL, NTS)                                                                                            \
     LBFGSX_LAUNCH((k_trial<T, OBJ, UU, NTL, NTS>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->xp]), P<T>(c->d), \
@@ -1315,6 +1327,15 @@ int lbfgsx_debug_persist_fault(lbfgsx_ctx* c)
         return LBFGSX_E_INVALID;
     }
     LBFGSX_HIP(hipMemsetAsync(c->gen_dev + 1, 1, 1, c->stream));  // failure word = 1 (low byte)
+    return LBFGSX_OK;
+}
+
+int lbfgsx_poll_counts(const lbfgsx_ctx* c, int64_t out[2])
+{
+    if (!c || !out)
+        return LBFGSX_E_INVALID;
+    out[0] = c->poll_waits;
+    out[1] = c->poll_timeouts;
     return LBFGSX_OK;
 }
 

@@ -127,7 +127,21 @@ struct RedWs
     double* partials;    // [kMaxRed][2][maxGrid]
     unsigned* ticket;    // zero-initialised, reset by the last block
     int maxGrid;
+    // completion word in host-mapped memory (ctx.hpp: poll_arm / poll_wait): the last block of a kernel whose results the
+    // host is about to read stores `seq` there AFTER the results; the host polls it instead of waiting for the stream
+    // (hipStreamSynchronize returns ~9 us after the kernel ends, the polled word is seen after ~4)
+    unsigned long long* done = nullptr;
+    unsigned long long seq = 0;
 };
+// thread 0 of the last block, after it has written the kernel's results
+__device__ __forceinline__ void ws_signal(const RedWs& ws)
+{
+    if (ws.done)
+    {
+        __threadfence_system();
+        __hip_atomic_store(ws.done, ws.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 
 __device__ __forceinline__ void st_agent(double* p, double v)
 {

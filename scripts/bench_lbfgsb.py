@@ -53,6 +53,10 @@ def main():
     out = dict(n=n, m=args.m, warmup=not args.no_warmup, niter=niter, nfev=s.last.nfev, fx=fx, total_s=t1 - t0, it_per_s=niter / (t1 - t0),
                steady_it_per_s=float(1.0 / np.median(per[len(per) // 2:])) if len(per) > 4 else None,
                per_iter_ms=[round(1e3 * v, 2) for v in per], stats=s.stats())
+    import ctypes as C
+    pc = (C.c_int64 * 2)()
+    core.lbfgsx_poll_counts(ctx, C.byref(pc))
+    out["polled_waits"], out["poll_timeouts"] = int(pc[0]), int(pc[1])
     # algorithmic bytes of an L-BFGS-B iteration with q BOXCQP sweeps and one objective evaluation,
     # [(4m + 19) + (q + 1)(4m + 1)] n elements (history full); the roofline view of the steady state against 8 TB/s
     st = out["stats"]

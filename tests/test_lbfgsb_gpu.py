@@ -434,6 +434,37 @@ def test_compact_vectors_of_the_free_rows_change_no_bit(A, monkeypatch, n, m, ma
         assert f[7][1] <= f[7][0]
 
 
+def test_polled_completion_serves_the_waits_and_changes_no_bit(A, monkeypatch):
+    """The kernels whose results the host reads next end with a sequence number stored in host-mapped memory after the
+    results; the host polls that word instead of waiting for the stream (ctx.hpp: poll_arm / poll_wait).  Against
+    LBFGSX_POLL=0 (every wait is a stream wait): the same trajectory bit for bit; most waits are served by polling and
+    none of them runs into the time-out (which would mean a kernel that was armed and never signalled)."""
+    import ctypes as C
+    from lbfgspp_amd import _lib as L
+    core, _ = L.load()
+    n, iters = 300000, 40
+    res = {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("LBFGSX_POLL", on)
+        s = A.LBFGSBSolver(A.LBFGSBParam(m=10, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters))
+        ctx = s.prepare(n)
+        L.check(core.lbfgsx_gen_diag_quad(ctx, 10.0, 1))
+        L.check(core.lbfgsx_fill(ctx, L.VEC_X, 0.0))
+        L.check(core.lbfgsx_fill(ctx, L.VEC_LB, -1.0))
+        L.check(core.lbfgsx_fill(ctx, L.VEC_UB, 1.0))
+        niter, fx = s.minimize_resident(A.DiagQuadratic(), n)
+        x = np.empty(n)
+        L.check(core.lbfgsx_download(ctx, L.VEC_X, x.ctypes.data_as(C.c_void_p)))
+        pc = (C.c_int64 * 2)()
+        L.check(core.lbfgsx_poll_counts(ctx, C.byref(pc)))
+        res[on] = (niter, s.last.nfev, fx, x, int(pc[0]), int(pc[1]), s.stats()["submin_sweeps"])
+        s.close()
+    f, u = res["1"], res["0"]
+    assert f[:3] == u[:3] and f[6] == u[6] and np.array_equal(f[3], u[3])
+    assert u[4] == 0 and u[5] == 0
+    assert f[4] > 10 * iters and f[5] == 0
+
+
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("n,m,iters", [(70001, 8, 40), (70001, 10, 45), (65536, 3, 30), (200000, 10, 60)])
 def test_grams_launched_ahead_of_their_request_change_no_bit(A, monkeypatch, n, m, iters, dtype):
