@@ -76,6 +76,15 @@ struct lbfgsb_state
     // compact vectors of a subspace minimisation (lbfgsb_kernels.cuh "cv"): y, yfallback, lambda, mu, rhs, cF, lb - x0,
     // ub - x0 and the state byte of the free rows at their POSITION in the compact copy, from the first solve-sweep until
     // the result is assigned (or a pass outside the fused path needs them by row again: cv_back)
+    // candidates of the partial break-point sort collected by the Cauchy build itself (k_cauchy_build's plist)
+    bool psel_use = true;                 // LBFGSX_SELECT_INLINE=0: rocprim::select behind the build
+    int* psel_list = nullptr;             // [psel_cap] rows in arrival order
+    unsigned* psel_cnt = nullptr;
+    unsigned psel_cap = 1u << 21;
+    void* psel_tmp = nullptr;             // radix-sort workspace for psel_cap row numbers
+    size_t psel_tmp_bytes = 0;
+    int64_t psel_last = -1;               // candidates of the previous partial sort: the in-pass list pays while they are few
+    int64_t psel_max = int64_t(1) << 17;  // (appending and ordering 10^6 rows costs more than the separate selection pass)
     // W'd of the Cauchy search (and the deferred dots of add_correction) from the kept compact copy (k_multidot2_wf)
     bool wtdc_use = true;                 // LBFGSX_WTD_COMPACT=0: always the pass over the full-length columns
     int* wtdc_list = nullptr;             // rows outside the copy with d != 0 or s_new != 0 (k_cauchy_build)
@@ -383,6 +392,12 @@ int bounded_alloc(lbfgsx_ctx* c)
         b->cv_use = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_WTD_COMPACT"))
         b->wtdc_use = atoi(e) != 0;
+    if (const char* e = getenv("LBFGSX_SELECT_INLINE"))
+        b->psel_use = atoi(e) != 0;
+    if (const char* e = getenv("LBFGSX_SELECT_MAX"))  // candidates of the previous search up to which the build lists them
+        b->psel_max = std::max<int64_t>(0, atoll(e));
+    if (const char* e = getenv("LBFGSX_SELECT_CAP"))  // test aid: a short list overflows
+        b->psel_cap = unsigned(std::max(1, std::min(1 << 24, atoi(e))));
     if (const char* e = getenv("LBFGSX_SYNC_MERGE"))
         b->stash_use = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_WTD_LIST_CAP"))  // test aid: a short list overflows
@@ -474,6 +489,9 @@ void bounded_free(lbfgsx_ctx* c)
     (void) hipFree(b->wf_pos);
     (void) hipFree(b->wtdc_list);
     (void) hipFree(b->wtdc_cnt);
+    (void) hipFree(b->psel_list);
+    (void) hipFree(b->psel_cnt);
+    (void) hipFree(b->psel_tmp);
     for (hipEvent_t ev : b->chain_ev)
         if (ev)
             (void) hipEventDestroy(ev);
@@ -1109,10 +1127,12 @@ int lbfgsx_b_cauchy_build(lbfgsx_ctx* c, int64_t* nfree, int64_t* nord, double* 
         BVecs<T> bv = bvecs<T>(c);
         const bool wc = wtdc_prepare(c);
         const int newest = (c->ptr + c->m - 1) % c->m;
+        lbfgsx::poll_arm(c);
         LBFGSX_LAUNCH((k_cauchy_build<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, P<T>(b->keys_in), b->vals_in, c->n,
                            c->ws, b->dout, force ? P<T>(c->xb[c->cur]) : static_cast<T*>(nullptr),
                            wc ? static_cast<const T*>(c->col(c->S, c->phys[size_t(newest)])) : static_cast<const T*>(nullptr),
-                           wc ? b->wf_pos : static_cast<const int*>(nullptr), b->wtdc_list, b->wtdc_cnt, b->wtdc_cap);
+                           wc ? b->wf_pos : static_cast<const int*>(nullptr), b->wtdc_list, b->wtdc_cnt, b->wtdc_cap, T(0),
+                           static_cast<int*>(nullptr), static_cast<unsigned*>(nullptr), 0u);
         LBFGSX_HIP(hipGetLastError());
         rc = fetch_doubles(c, wc ? 4 : 3, r);
         if (rc)
@@ -1196,6 +1216,53 @@ static int partial_select_t(lbfgsx_ctx* c, double tau, unsigned* count_dev)
 }
 template <class T>
 static int partial_sort_tail_t(lbfgsx_ctx* c, unsigned cnt, int64_t* nsorted);
+// buffers of the in-pass selection (k_cauchy_build's plist); false: do without
+static bool psel_alloc(lbfgsx_ctx* c)
+{
+    lbfgsb_state* b = c->bstate;
+    if (b->psel_list)
+        return true;
+    b->psel_cap = unsigned(std::min<int64_t>(b->psel_cap, c->n));
+    size_t bytes = 0;
+    const bool ok = psort_alloc(c) == LBFGSX_OK &&
+                    hipMalloc(reinterpret_cast<void**>(&b->psel_list), sizeof(int) * size_t(b->psel_cap)) == hipSuccess &&
+                    hipMalloc(reinterpret_cast<void**>(&b->psel_cnt), sizeof(unsigned)) == hipSuccess &&
+                    hipMemsetAsync(b->psel_cnt, 0, sizeof(unsigned), c->stream) == hipSuccess &&
+                    rocprim::radix_sort_keys(nullptr, bytes, b->psel_list, b->pv, size_t(b->psel_cap), 0, 32, c->stream) == hipSuccess &&
+                    hipMalloc(&b->psel_tmp, std::max<size_t>(bytes, 16)) == hipSuccess;
+    if (!ok)
+    {
+        (void) hipGetLastError();
+        (void) hipFree(b->psel_list);
+        (void) hipFree(b->psel_cnt);
+        (void) hipFree(b->psel_tmp);
+        b->psel_list = nullptr;
+        b->psel_cnt = nullptr;
+        b->psel_tmp = nullptr;
+        b->psel_use = false;
+        return false;
+    }
+    b->psel_tmp_bytes = bytes;
+    return true;
+}
+// the partial sort over the candidates the build listed: rows in ascending order first -- what an ordered compaction
+// delivers, and what makes the stable sort by break point put ties in the reference's order -- then as partial_sort_tail_t
+template <class T>
+static int partial_sort_listed_t(lbfgsx_ctx* c, unsigned cnt, int64_t* nsorted)
+{
+    lbfgsb_state* b = c->bstate;
+    if (cnt > 1)
+    {
+        size_t bytes = b->psel_tmp_bytes;
+        int end_bit = 1;
+        while (end_bit < 32 && (int64_t(1) << end_bit) < c->n)
+            end_bit++;
+        LBFGSX_HIP(rocprim::radix_sort_keys(b->psel_tmp, bytes, b->psel_list, b->pv, size_t(cnt), 0, end_bit, c->stream));
+    }
+    else if (cnt == 1)
+        LBFGSX_HIP(lbfgsx::copy_async(b->pv, b->psel_list, sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+    return partial_sort_tail_t<T>(c, cnt, nsorted);
+}
 template <class T>
 static int partial_sort_t(lbfgsx_ctx* c, double tau, int64_t* nsorted)
 {
@@ -1236,17 +1303,24 @@ int lbfgsx_b_cauchy_build_partial(lbfgsx_ctx* c, double tau, int64_t* nfree, int
     const bool force = b->force_pending;  // a deferred x = clamp(x): evaluated by the build's own pass
     b->force_pending = false;
     const int grid = c->grid_for(c->n);
-    double r[4] = {0, 0, 0, -1};
+    double r[5] = {0, 0, 0, -1, -1};
     int64_t ns = 0;
-    const bool sel_ahead = b->stash_use && b->dout_host && tau > 0.0 && std::isfinite(tau);
+    const bool tau_ok = tau > 0.0 && std::isfinite(tau);
+    // the candidates of the partial sort: collected by the build itself, else selected by a pass that rides behind it
+    const bool sel_inline = tau_ok && b->psel_use && b->psel_last >= 0 && b->psel_last <= b->psel_max &&
+                            c->n < (int64_t(1) << 31) && psel_alloc(c);
+    const bool sel_ahead = !sel_inline && b->stash_use && b->dout_host && tau_ok;
     DISPATCH_T(c, {
         BVecs<T> bv = bvecs<T>(c);
         const bool wc = wtdc_prepare(c);
         const int newest = (c->ptr + c->m - 1) % c->m;
+        if (!sel_ahead)  // nothing rides behind the build: its last block carries the completion word
+            lbfgsx::poll_arm(c);
         LBFGSX_LAUNCH((k_cauchy_build<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, P<T>(b->keys_in), b->vals_in, c->n,
                            c->ws, b->dout, force ? P<T>(c->xb[c->cur]) : static_cast<T*>(nullptr),
                            wc ? static_cast<const T*>(c->col(c->S, c->phys[size_t(newest)])) : static_cast<const T*>(nullptr),
-                           wc ? b->wf_pos : static_cast<const int*>(nullptr), b->wtdc_list, b->wtdc_cnt, b->wtdc_cap);
+                           wc ? b->wf_pos : static_cast<const int*>(nullptr), b->wtdc_list, b->wtdc_cnt, b->wtdc_cap, T(tau),
+                           sel_inline ? b->psel_list : static_cast<int*>(nullptr), b->psel_cnt, b->psel_cap);
         LBFGSX_HIP(hipGetLastError());
         // the selection of the partial sort needs nothing from the host: it rides behind the build, its count lands in the
         // mapped word dout[60] and is read after the same wait (without candidates it selects nothing)
@@ -1256,16 +1330,18 @@ int lbfgsx_b_cauchy_build_partial(lbfgsx_ctx* c, double tau, int64_t* nfree, int
             if (rc)
                 return rc;
         }
-        rc = fetch_doubles(c, wc ? 4 : 3, r);
+        rc = fetch_doubles(c, sel_inline ? 5 : wc ? 4 : 3, r);
         if (rc)
             return rc;
         b->wtdc_n = wc ? int64_t(r[3]) : -1;
         ns = int64_t(r[2]);
         if (r[2] > 0)
         {
-            if (tau > 0.0 && std::isfinite(tau))
+            if (tau_ok)
             {
-                if (sel_ahead)  // the selection ran behind the build: its count came with the build's sums
+                if (sel_inline && r[4] >= 0 && r[4] <= double(b->psel_cap))
+                    rc = partial_sort_listed_t<T>(c, unsigned(r[4]), &ns);
+                else if (sel_ahead)  // the selection ran behind the build: its count came with the build's sums
                     rc = partial_sort_tail_t<T>(c, *reinterpret_cast<const volatile unsigned*>(b->dout_host + 60), &ns);
                 else
                     rc = partial_sort_t<T>(c, tau, &ns);
@@ -1286,6 +1362,7 @@ int lbfgsx_b_cauchy_build_partial(lbfgsx_ctx* c, double tau, int64_t* nfree, int
                 return rc;
         }
     });
+    b->psel_last = tau_ok ? ns : int64_t(-1);
     if (dd) *dd = r[0];
     if (nfree) *nfree = int64_t(r[1]);
     if (nord) *nord = int64_t(r[2]);

@@ -1500,8 +1500,14 @@ template <class T>
 __global__ void __launch_bounds__(kBlock) k_cauchy_build(BVecs<T> b, T* __restrict__ keys, int* __restrict__ vals,
                                                          int64_t n, RedWs ws, double* __restrict__ out, T* __restrict__ xforce,
                                                          const T* __restrict__ snew, const int* __restrict__ pos,
-                                                         int* __restrict__ olist, unsigned* __restrict__ ocnt, unsigned ocap)
+                                                         int* __restrict__ olist, unsigned* __restrict__ ocnt, unsigned ocap,
+                                                         T tau, int* __restrict__ plist, unsigned* __restrict__ pcnt,
+                                                         unsigned pcap)
 {
+    // plist != null: the candidates of the partial sort -- break point <= tau -- go to plist as they are met (their number
+    // in out[4]; the host orders the list by row before the stable sort by break point, which gives the order of an
+    // ordered compaction: lbfgsx_b_cauchy_build_partial).  This pass has every key in a register; a separate selection
+    // pass (rocprim::select: three kernels, 95 us at n = 1e7) read them all again
     // pos != null (k_multidot2_wf follows): the rows without a position in the kept compact copy on which d or s_new is
     // not zero go to olist; out[3] = their number (beyond ocap: the list is incomplete, the full-length pass runs)
     typedef typename AccOf<T>::type A;
@@ -1549,6 +1555,8 @@ __global__ void __launch_bounds__(kBlock) k_cauchy_build(BVecs<T> b, T* __restri
             const bool outside = pos[i] < 0 && (di != T(0) || snew[i] != T(0));
             lu_append(outside, i, olist, ocnt, ocap);
         }
+        if (plist)
+            lu_append(isord && t <= tau, i, plist, pcnt, pcap);
     }
     if (grid_reduce<3>(acc, ws) && threadIdx.x == 0)
     {
@@ -1561,6 +1569,12 @@ __global__ void __launch_bounds__(kBlock) k_cauchy_build(BVecs<T> b, T* __restri
             out[3] = double(__hip_atomic_load(ocnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             __hip_atomic_store(ocnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (plist)
+        {
+            out[4] = double(__hip_atomic_load(pcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            __hip_atomic_store(pcnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        ws_signal(ws);
     }
 }
 

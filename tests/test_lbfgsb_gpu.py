@@ -434,6 +434,36 @@ def test_compact_vectors_of_the_free_rows_change_no_bit(A, monkeypatch, n, m, ma
         assert f[7][1] <= f[7][0]
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("n,m,iters,cap", [(70001, 8, 40, None), (200000, 10, 50, None), (65536, 5, 30, None), (120000, 10, 40, "8")])
+def test_partial_sort_candidates_listed_by_the_cauchy_build_change_no_bit(A, monkeypatch, n, m, iters, cap, dtype):
+    """The break points <= tau that the partial sort orders: listed by the Cauchy build as it meets them, the list put in
+    row order, then the stable sort by break point (lbfgsx_b_cauchy_build_partial) -- against rocprim::select's ordered
+    compaction in a pass of its own (LBFGSX_SELECT_INLINE=0).  The same list in the same order: the same bits.  With room
+    for 8 candidates (LBFGSX_SELECT_CAP) the list overflows and those searches take the separate pass."""
+    dt = O.F64 if dtype == "f64" else O.F32
+    npdt = O.NPDT[dt]
+    a, b = O.quad_problem(n, 30.0, 9, dt)
+    if cap:
+        monkeypatch.setenv("LBFGSX_SELECT_CAP", cap)
+    res = {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("LBFGSX_SELECT_INLINE", on)
+        s = A.LBFGSBSolver(A.LBFGSBParam(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters, max_submin=10), dtype=npdt)
+        tr = A.TraceBuffer(n, cap=256, stride=17)
+        x = np.zeros(n, dtype=npdt)
+        try:
+            niter, fx = s.minimize(A.DiagQuadratic(a, b), x, (-0.7 * np.ones(n)).astype(npdt), (0.9 * np.ones(n)).astype(npdt),
+                                   trace=tr)
+        except RuntimeError:
+            niter, fx = -1, float("nan")
+        st = s.stats()
+        res[on] = (niter, s.last.nfev, x.copy(), tr.xs[:tr.count].copy(), st["gcp_partial_sorts"], st["gcp_sorted"])
+    f, u = res["1"], res["0"]
+    assert f[:2] == u[:2] and f[4:] == u[4:] and f[4] > 0
+    assert np.array_equal(f[2], u[2]) and np.array_equal(f[3], u[3])
+
+
 def test_polled_completion_serves_the_waits_and_changes_no_bit(A, monkeypatch):
     """The kernels whose results the host reads next end with a sequence number stored in host-mapped memory after the
     results; the host polls that word instead of waiting for the stream (ctx.hpp: poll_arm / poll_wait).  Against
