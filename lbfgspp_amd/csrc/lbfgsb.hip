@@ -1,4 +1,17 @@
 // lbfgspp_amd/csrc/lbfgsb.hip -- C ABI of the L-BFGS-B device operators (include/lbfgsx.h, "L-BFGS-B" block).
+//
+// Map of the per-context mechanisms kept in lbfgsb_state (each has an environment switch and a bit-identity test):
+//   wf_*     compact copy of the free rows of the 2c columns (rows of F in order, idx / pos maps); written by the first
+//            solve's Gram pass, kept and patched between iterations
+//   cv_*     the vectors of the free rows by POSITION in that copy while a subspace minimisation sweeps (need_bounded's
+//            keep_cv: the fused sweep entries work on them, every other entry gets them back at their rows first)
+//   lu_*     index list of the rows of L u U of the last BOXCQP partition (ping-pong), dl_* rows that entered / left F
+//   wtdc_*   rows outside the kept copy on which d or s_new is not zero: W'd of the Cauchy search over copy + list
+//   psel_*   candidates of the partial break-point sort, listed by the Cauchy build itself
+//   stash_*  Grams over index lists launched behind the pass before their request (need_bounded's keep_stash)
+//   s_*, g_* buffers of the device / host form of the break-point search;  lbfgsx_b_reserve allocates all of it up front
+// Waits: fetch_doubles / fetch_T / fetch_gram_out read host-mapped results after poll_wait (ctx.hpp) -- a polled completion
+// word when the launch before them was armed (poll_arm), the stream otherwise.
 #include <algorithm>
 #include <atomic>
 #include <cmath>
