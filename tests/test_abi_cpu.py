@@ -55,6 +55,10 @@ def test_null_context_is_an_invalid_argument_not_a_crash(libs):
     assert core.lbfgsx_device(None) == -1
     out = (C.c_int64 * 3)()
     assert core.lbfgsx_counters(C.byref(out), 0) == 0 and all(v >= 0 for v in out)   # process-wide, needs no context
+    out4 = (C.c_int64 * 4)()
+    assert core.lbfgsx_b_compact_vec_counts(C.byref(out4), 0) == 0 and all(v >= 0 for v in out4)  # process-wide as well
+    out2 = (C.c_int64 * 2)()
+    assert core.lbfgsx_poll_counts(None, C.byref(out2)) == L.E_INVALID
 
 
 def test_param_validation_matches_reference_messages():
