@@ -105,10 +105,23 @@ def cpu_baseline_full(args):
     setc(stamps.ctypes.data_as(C.POINTER(C.c_double)), stamps.size)
     t0 = time.perf_counter()
     try:
-        _, r = orc.lbfgs(O.F64, O.LS_MT, O.OBJ_ROSEN, x0, O.lbfgs_params(m=m, epsilon=0, epsilon_rel=0, max_iterations=warm + timed))
+        x_ref, r = orc.lbfgs(O.F64, O.LS_MT, O.OBJ_ROSEN, x0, O.lbfgs_params(m=m, epsilon=0, epsilon_rel=0, max_iterations=warm + timed))
     finally:
         setc(None, 0)
     t1 = time.perf_counter()
+    del x0
+    # the reference's iterate after these iterations is the oracle side of `parity` (north_star_parity): the GPU solver runs
+    # the same instance for the same number of iterations
+    args._ref_run = {"x": x_ref, "niter": r.niter, "nfev": r.nfev, "fx": r.fx, "n": n, "m": m, "kind": kind,
+                     "oracle": "%s, native accumulators (plain f64 sums in index order), 1 core" %
+                               ("reference headers + eigen_shim" if fam == "ref" else "restatement of the reference")}
+    if args.cpu_full_dd and O.available(fam, "dd"):
+        # the same run with the reference built on the parity contract's extended sums: not timed
+        x_dd, r_dd = O.Oracle(fam, "dd").lbfgs(O.F64, O.LS_MT, O.OBJ_ROSEN, O.rosen_x0(n),
+                                               O.lbfgs_params(m=m, epsilon=0, epsilon_rel=0, max_iterations=warm + timed))
+        args._ref_run_dd = {"x": x_dd, "niter": r_dd.niter, "nfev": r_dd.nfev, "fx": r_dd.fx, "n": n, "m": m, "kind": kind,
+                            "oracle": "%s, double-double accumulators (the parity contract's arithmetic), 1 core" %
+                                      ("reference headers + eigen_shim" if fam == "ref" else "restatement of the reference")}
     ts = stamps[:min(r.nfev, stamps.size)]
     gaps = np.diff(ts)
     thr = float(np.sqrt(gaps.min() * gaps.max()))  # geometric middle of "next trial" and "next iteration" gaps
@@ -126,6 +139,49 @@ def cpu_baseline_full(args):
             "timed_iterations": timed if ok else r.niter, "nfev": r.nfev,
             "sample": "the metric's own size n=%d, m=%d: %s; %.1f s of CPU in all; host has %d cores"
                       % (n, m, how, t1 - t0, os.cpu_count())}
+
+
+def north_star_parity(args, local, ref):
+    """north_star: "iterate trajectory matching the CPU reference to 1e-10" on the benchmark's OWN instance (n = 1e8, m = 10,
+    extended Rosenbrock from the counter-hash x0, More-Thuente).  `ref` is what cpu_baseline_full kept of the reference's run
+    (the iterate after K iterations, its evaluation count and objective value); the product path runs the same instance for K
+    iterations here and every coordinate is compared.  The reference side uses its native accumulators, so this is the
+    un-helped comparison: the GPU path (double-double sums) follows it to <= 1e-10 for about 30 iterations (README); with
+    --cpu-full-dd the reference is built with the same extended sums and the expectation is 0."""
+    import numpy as np
+
+    import lbfgspp_amd as A
+    from lbfgspp_amd import _lib as L
+    core, _ = A.load()
+    n, m, K = ref["n"], ref["m"], ref["niter"]
+    s = A.LBFGSSolver(A.LBFGSParam(m=m, epsilon=0.0, epsilon_rel=0.0, past=0, max_iterations=K), linesearch=A.LS_MORE_THUENTE,
+                      dtype="float64", device=local)
+    ctx = s.prepare(n)
+    L.check(core.lbfgsx_gen_rosen_x0(ctx, 7))
+    L.check(core.lbfgsx_sync(ctx))
+    niter, fx = s.minimize_resident(A.ExtendedRosenbrock(), n)
+    x = np.empty(n)
+    L.check(core.lbfgsx_download(ctx, L.VEC_X, x.ctypes.data_as(C.c_void_p)))
+    nfev = s.last.nfev
+    s.close()
+    xr = ref["x"]
+    # all n coordinates, in slabs (no second 800 MB temporary)
+    worst, at = 0.0, 0
+    for lo in range(0, n, 1 << 24):
+        d = np.abs(x[lo:lo + (1 << 24)] - xr[lo:lo + (1 << 24)])
+        k = int(d.argmax())
+        if d[k] > worst:
+            worst, at = float(d[k]), lo + k
+    stride = max(1, n // 4096)
+    return {"n": n, "m": m, "iterations": int(niter), "iterations_equal": bool(niter == ref["niter"]),
+            "nfev": int(nfev), "nfev_equal": bool(nfev == ref["nfev"]),
+            "max_abs_dx": worst, "max_abs_dx_at": at, "max_abs_dx_strided_sample": float(np.abs(x[::stride] - xr[::stride]).max()),
+            "x_inf_norm": float(np.abs(xr[::stride]).max()),
+            "fx": fx, "fx_oracle": ref["fx"], "fx_rel_diff": abs(fx - ref["fx"]) / max(abs(ref["fx"]), 1e-300),
+            "tolerance": 1e-10, "within_tolerance": bool(worst <= 1e-10 and nfev == ref["nfev"] and niter == ref["niter"]),
+            "oracle": ref["oracle"],
+            "instance": "the benchmark's own: extended Rosenbrock n=%d, x0 = -1.2 / 1 + 0.4 u01(counter hash, seed 7), m=%d, "
+                        "LineSearchMoreThuente, %d iterations from x0" % (n, m, K)}
 
 
 def cpu_baseline_all_cores(args):
@@ -305,28 +361,56 @@ def run_batched(args, rank, world, local, comm_dev, dist, steps):
                                "per rank, no data-path collective, one all-gather of the result records" % (P, steps),
                    "problems_total": total, "fevals_total": fev, "failed": int((full["status"] != 0).sum()),
                    "per_rank": per_rank if world > 1 else None},
-        "roofline": {"bound": "hbm", "achieved": model_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": model_gbs / HBM_PEAK_GBS, "traffic": None,
+        "roofline": dict({"bound": "hbm", "achieved": model_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": model_gbs / HBM_PEAK_GBS,
+                     "hbm_model_bytes_per_problem_iteration": hbm_ / max(its, 1),
                      "algorithmic_GBs": alg_ / elapsed / 1e9 / world,
                      "note": "end to end per GPU, host control flow included. achieved = HBM traffic model of the "
                              "one-launch two-loop ((4m+14) n elements per iteration: q stays on the CU) / wall time; "
                              "algorithmic_GBs = SURVEY 8(d)'s (8m+12) n per iteration / wall time, which counts the q "
-                             "traffic that never reaches HBM and may therefore exceed the peak"}}
+                             "traffic that never reaches HBM and may therefore exceed the peak"},
+                     **traffic_fields(leg_traffic("cfg5", n, m)))}
 
 
-def run_cfg4(args, rank, world, local, comm_dev, dist, iters=40):
+def leg_traffic(kind, n, m):
+    """HBM bytes of one leg from a committed rocprofv3 PMC summary (profiles/*_legs_pmc_summary.json, written by
+    scripts/r4/pmc_legs.py from FETCH_SIZE / WRITE_SIZE passes of the leg's own command) -- static, labelled, and only
+    when the summary was taken at exactly this (kind, n, m): counters cannot be read inside the timed process."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_legs_pmc_summary.json"))):
+        try:
+            for e in json.load(open(f)).get("legs", []):
+                if e.get("leg") == kind and int(e.get("n", 0)) == int(n) and int(e.get("m", 0)) == int(m) and e.get("hbm_bytes"):
+                    best = dict(e, source=os.path.relpath(f, ROOT))
+        except Exception:
+            pass
+    return best
+
+
+def traffic_fields(t):
+    """The `traffic*` keys of a leg's roofline object from leg_traffic()'s entry (None: all null)."""
+    if not t:
+        return {"traffic": None, "traffic_static": None, "traffic_source": None}
+    return {"traffic": t["hbm_bytes"], "traffic_static": True, "traffic_per": t.get("per"),
+            "traffic_source": t["source"] + " (" + t.get("how", "rocprofv3 PMC passes of this leg's command, taken separately") + ")"}
+
+
+def run_cfg4(args, rank, world, local, comm_dev, dist, iters=40, m=10):
     """BASELINE.json cfg4: L-BFGS-B (generalized Cauchy point + BOXCQP subspace minimisation) on the box-constrained diag
-    quadratic, n=1e7, m=10, lb=-1, ub=1, x0=0, f64 -- `iters` iterations from x0 on every rank (independent problems,
-    seed 1+rank).  Reports the rate from x0 (Cauchy searches with millions of crossings included) and the steady rate
-    (median of the second half), with SURVEY 8(d)'s q / n_ord / crossings and the launches / host synchronisations / copies
-    per iteration counted by the library.  Returns the object on rank 0."""
+    quadratic, n=1e7, m=10 (or another history length: the `cfg4_m20` leg), lb=-1, ub=1, x0=0, f64 -- `iters` iterations from
+    x0 on every rank (independent problems, seed 1+rank).  Two figures, each with BOTH sides of its roofline fraction taken
+    from the same iterations: the steady state = the second half of the run (mean iteration time of that window; the sweeps q,
+    the sorted break points and the launches / host synchronisations / copies counted by the library are snapshotted at the
+    iteration hook, so they are that window's, too), and the run from x0 (everything over all iterations).  Returns the object
+    on rank 0."""
     import numpy as np
     import torch  # noqa: F401
 
     import lbfgspp_amd as A
     from lbfgspp_amd import _lib as L
     core, _ = A.load()
-    n, m = int(args.cfg4_n), 10
+    n = int(args.cfg4_n)
 
     def setup(solver, nn, seed):
         ctx = solver.prepare(nn)
@@ -337,7 +421,7 @@ def run_cfg4(args, rank, world, local, comm_dev, dist, iters=40):
         L.check(core.lbfgsx_sync(ctx))
         return ctx
     # untimed small solve of the same problem: HIP loads a kernel's code object at its first launch (~60 kernels)
-    w = A.LBFGSBSolver(A.LBFGSBParam(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=12), device=local)
+    w = A.LBFGSBSolver(A.LBFGSBParam(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=m + 4), device=local)
     setup(w, 1 << 18, 1)
     w.minimize_resident(A.DiagQuadratic(), 1 << 18)
     w.close()
@@ -349,9 +433,14 @@ def run_cfg4(args, rank, world, local, comm_dev, dist, iters=40):
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
-    stamps = []
-    s.set_iteration_hook(lambda k: stamps.append(time.perf_counter()))
     cnt = (C.c_int64 * 3)()
+    snaps = []  # (time, solver statistics, library counters) at the end of every iteration
+
+    def hook(k):
+        t = time.perf_counter()
+        core.lbfgsx_counters(C.byref(cnt), 0)
+        snaps.append((t, s.stats(), (cnt[0], cnt[1], cnt[2])))
+    s.set_iteration_hook(hook)
     barrier()
     core.lbfgsx_counters(None, 1)
     t0 = time.perf_counter()
@@ -360,49 +449,84 @@ def run_cfg4(args, rank, world, local, comm_dev, dist, iters=40):
     core.lbfgsx_counters(C.byref(cnt), 0)
     barrier()
     st = s.stats()
+    nfev = s.last.nfev
     s.close()
+    stamps = [v[0] for v in snaps]
     per = np.diff(np.array([t0] + stamps))
-    total, steady_ms = t1 - t0, float(np.median(per[len(per) // 2:])) * 1e3
+    # steady window: iterations w0+1 .. len(snaps) (the hook does not fire after the last iteration, which ends the run)
+    w0 = len(snaps) // 2
+    win = per[w0:]
+    total, steady_ms, steady_med_ms = t1 - t0, float(win.mean()) * 1e3, float(np.median(win)) * 1e3
     first_ms = float(per[0]) * 1e3
     if world > 1:
-        t = torch.tensor([total, steady_ms], dtype=torch.float64, device=comm_dev)
+        t = torch.tensor([total, steady_ms, steady_med_ms], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        total, steady_ms = float(t[0].item()), float(t[1].item())
+        total, steady_ms, steady_med_ms = float(t[0].item()), float(t[1].item()), float(t[2].item())
     if rank != 0:
         return None
-    # algorithmic bytes of an L-BFGS-B iteration with q BOXCQP sweeps and one objective evaluation,
-    # [(4m + 19) + (q + 1)(4m + 1)] n elements (history full); radix-sort traffic (~96 B per sorted break point) on top
+    a_st, b_st = snaps[w0 - 1][1], snaps[-1][1]
+    a_c, b_c = snaps[w0 - 1][2], snaps[-1][2]
+    nwin = len(win)
+
+    def d(key):
+        return b_st[key] - a_st[key]
+
+    def bytes_per_iteration(q, n_sorted):
+        # algorithmic bytes of an L-BFGS-B iteration with q BOXCQP sweeps and one objective evaluation,
+        # [(4m + 19) + (q + 1)(4m + 1)] n elements (history full); radix-sort traffic (~96 B per sorted break point) on top
+        return ((4 * m + 19) + (q + 1.0) * (4 * m + 1)) * n * 8 + 96.0 * n_sorted
+    # the window's own counts
+    q_w = d("submin_sweeps") / max(1, d("submin_calls"))
+    searches_w = max(1, d("gcp_searches"))
+    n_ord_w, n_sorted_w = d("gcp_nord") / searches_w, d("gcp_sorted") / searches_w
+    bytes_w = bytes_per_iteration(q_w, n_sorted_w)
+    # ... and the whole run's, for the from-x0 figure
     q = st["submin_sweeps"] / max(1, st["submin_calls"])
     searches = max(1, st["gcp_searches"])
     n_ord, n_sorted = st["gcp_nord"] / searches, st["gcp_sorted"] / searches
-    bytes_it = ((4 * m + 19) + (q + 1.0) * (4 * m + 1)) * n * 8 + 96.0 * n_sorted
+    bytes_it = bytes_per_iteration(q, n_sorted)
     steady = 1e3 / steady_ms
-    ach_steady, ach_x0 = bytes_it * steady / 1e9, bytes_it * (niter / total) / 1e9
+    ach_steady, ach_x0 = bytes_w * steady / 1e9, bytes_it * (niter / total) / 1e9
+    tr = leg_traffic("cfg4", n, m)
     return {
         "metric": "L-BFGS-B iterations/sec at n=%d, m=%d (box-constrained diag quadratic); steady state" % (n, m),
         "value": world * steady, "unit": "iterations/s", "n_gpus": world, "steps": iters,
-        "ms_per_step": steady_ms, "scaling": "weak", "dtype": "f64",
+        "ms_per_step": steady_ms, "ms_per_step_median": steady_med_ms, "value_median": world * 1e3 / steady_med_ms,
+        "scaling": "weak", "dtype": "f64",
         "from_x0": {"value": world * niter / total, "unit": "iterations/s", "iterations": niter, "seconds": total,
                     "first_iteration_ms": first_ms,
+                    "q": q, "n_ord": n_ord, "n_sorted": n_sorted, "gcp_crossings": st["gcp_crossings"] / max(1, niter),
+                    "launches_per_iteration": cnt[0] / max(1, niter), "host_syncs_per_iteration": cnt[1] / max(1, niter),
+                    "copies_per_iteration": cnt[2] / max(1, niter),
                     "note": "all %d iterations from x0 = 0, the first Cauchy searches (millions of crossings) included" % niter},
         "config": {"workload": "cfg4: L-BFGS-B, f = 0.5 ||diag(a) x - b||^2, kappa=10, lb=-1, ub=1, x0=0, n=%d, m=%d, f64, "
                                "LineSearchMoreThuente, %d iterations from x0 (epsilon=epsilon_rel=0, past=0); value = steady "
-                               "state = 1 / median of the second half of the per-iteration wall times" % (n, m, iters),
-                   "n": n, "m": m, "iterations": niter, "fevals_total": s.last.nfev, "fx": fx,
-                   "q": q, "n_ord": n_ord, "n_sorted": n_sorted, "gcp_crossings": st["gcp_crossings"] / max(1, niter),
+                               "state = 1 / MEAN per-iteration wall time of the second half of the run (value_median beside "
+                               "it); q, n_ord, n_sorted, crossings, launches / synchronisations / copies below are those of "
+                               "the SAME iterations" % (n, m, iters),
+                   "n": n, "m": m, "iterations": niter, "fevals_total": nfev, "fx": fx,
+                   "window": {"first_iteration": w0 + 1, "last_iteration": w0 + nwin, "iterations": nwin,
+                              "history_full": bool(w0 >= m)},
+                   "q": q_w, "n_ord": n_ord_w, "n_sorted": n_sorted_w, "gcp_crossings": d("gcp_crossings") / max(1, nwin),
                    "gcp_crossings_total": st["gcp_crossings"], "gcp_dev_crossings_total": st["gcp_dev_crossings"],
-                   "submin_calls": st["submin_calls"], "submin_sweeps": st["submin_sweeps"], "gram_carried": st["gram_carried"],
-                   "launches_per_iteration": cnt[0] / max(1, niter), "host_syncs_per_iteration": cnt[1] / max(1, niter),
-                   "copies_per_iteration": cnt[2] / max(1, niter),
-                   "phase_ms_per_iteration": {"cauchy": st["gcp_total_us"] / 1e3 / niter, "subspace": st["submin_us"] / 1e3 / niter,
-                                              "linesearch": st["linesearch_us"] / 1e3 / niter}},
-        "roofline": {"bound": "hbm", "kernel": "whole L-BFGS-B iteration (masked W'v / Gram / solve-sweep passes over the compact "
+                   "submin_calls": d("submin_calls"), "submin_sweeps": d("submin_sweeps"), "gram_carried": d("gram_carried"),
+                   "submin_calls_total": st["submin_calls"], "submin_sweeps_total": st["submin_sweeps"],
+                   "gram_carried_total": st["gram_carried"],
+                   "launches_per_iteration": (b_c[0] - a_c[0]) / max(1, nwin),
+                   "host_syncs_per_iteration": (b_c[1] - a_c[1]) / max(1, nwin),
+                   "copies_per_iteration": (b_c[2] - a_c[2]) / max(1, nwin),
+                   "per_iteration_ms": [round(float(v) * 1e3, 3) for v in per],
+                   "phase_ms_per_iteration": {"cauchy": d("gcp_total_us") / 1e3 / max(1, nwin), "subspace": d("submin_us") / 1e3 / max(1, nwin),
+                                              "linesearch": d("linesearch_us") / 1e3 / max(1, nwin)}},
+        "roofline": dict({"bound": "hbm", "kernel": "whole L-BFGS-B iteration (masked W'v / Gram / solve-sweep passes over the compact "
                                                "copy of the free rows dominate; no single kernel holds more than a fifth of the time)",
                      "achieved": ach_steady, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_steady / HBM_PEAK_GBS,
-                     "achieved_from_x0": ach_x0, "frac_from_x0": ach_x0 / HBM_PEAK_GBS, "traffic": None,
-                     "algorithmic_bytes": bytes_it,
+                     "achieved_from_x0": ach_x0, "frac_from_x0": ach_x0 / HBM_PEAK_GBS,
+                     "algorithmic_bytes": bytes_w, "algorithmic_bytes_from_x0": bytes_it,
                      "note": "SURVEY 8(d): [(4m+19) + (q+1)(4m+1)] n sizeof(T) + 96 B per sorted break point, per iteration, "
-                             "divided by the wall time of an iteration (host control flow included)"}}
+                             "divided by the wall time of an iteration (host control flow included); bytes and time of the "
+                             "steady figure both from the second half of the run, of the from-x0 figure both from the whole run"},
+                     **traffic_fields(tr))}
 
 
 def lbfgs_leg(args, rank, world, local, comm_dev, dist, **over):
@@ -822,6 +946,13 @@ def run_all(args, rank, world, local, comm_dev, dist, batched=True):
             leg = run_cfg4(args, rank, world, local, comm_dev, dist, iters=args.cfg4_iters)
             if rank == 0:
                 out["cfg4_lbfgsb"] = leg
+            if not args.no_cfg4_m20:
+                # the same problem with the largest history a BASELINE configuration uses (cfg3's m = 20): the L-BFGS-B path
+                # is generic in m, and this leg is what shows it; 60 iterations so that the steady window (31..59) runs on
+                # a full history
+                leg = run_cfg4(args, rank, world, local, comm_dev, dist, iters=max(args.cfg4_iters, 60), m=20)
+                if rank == 0:
+                    out["cfg4_m20"] = leg
         if rank == 0 and not args.no_cpu and world == 1:  # the CPU baseline is timed on rank 0 of the single-GPU run only
             try:
                 out["cpu_baseline"] = cpu_baseline(args)
@@ -839,6 +970,20 @@ def run_all(args, rank, world, local, comm_dev, dist, batched=True):
                     out["cpu_baseline"] = full
                 else:
                     out["cpu_baseline_full"] = full
+                ref = getattr(args, "_ref_run", None)
+                if ref is not None:
+                    try:
+                        out["parity"] = north_star_parity(args, local, ref)
+                    except Exception as e:
+                        out["parity"] = {"error": repr(e)}
+                    args._ref_run = None
+                ref = getattr(args, "_ref_run_dd", None)
+                if ref is not None:
+                    try:
+                        out["parity_dd"] = north_star_parity(args, local, ref)
+                    except Exception as e:
+                        out["parity_dd"] = {"error": repr(e)}
+                    args._ref_run_dd = None
             try:
                 out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args)
             except Exception as e:
@@ -863,6 +1008,9 @@ def main():
                     help="1-core reference at the metric's own n (m+2 warm-up + --cpu-full-steps timed iterations of one run, "
                          "un-extrapolated); auto: when the host has >= 48 GB available")
     ap.add_argument("--cpu-full-steps", type=int, default=3)
+    ap.add_argument("--cpu-full-dd", action="store_true",
+                    help="with the --cpu-full run: repeat it with the reference built on double-double sums and report the GPU "
+                         "iterate against that one too (`parity_dd`; the expectation is max_abs_dx = 0)")
     ap.add_argument("--workload", default="north-star", choices=["north-star", "cfg5-batched", "sharded"],
                     help="north-star (default, the BASELINE.json metric: one problem per GPU; its line also carries the "
                          "cfg5 batch as `cfg5_batched`), the batched cfg5 shard per GPU alone, or sharded: ONE problem of "
@@ -877,6 +1025,7 @@ def main():
     ap.add_argument("--no-legs", action="store_true", help="skip the cfg2 / cfg3 / cfg4 legs of the default line")
     ap.add_argument("--cfg4-n", type=float, default=1e7, help="problem size of the L-BFGS-B leg (cfg4)")
     ap.add_argument("--cfg4-iters", type=int, default=40, help="iterations from x0 of the L-BFGS-B leg (cfg4)")
+    ap.add_argument("--no-cfg4-m20", action="store_true", help="skip the m = 20 repetition of the L-BFGS-B leg")
     ap.add_argument("--recursion", default="vector", choices=["vector", "gram", "gram-f32h"],
                     help="vector (default): the reference's two-loop recursion statement by statement, the bit-parity "
                          "path the BASELINE metric is quoted on; gram: opt-in Gram-space form (SURVEY 8(f)-3), equal to "

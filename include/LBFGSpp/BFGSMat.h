@@ -39,7 +39,8 @@ class BFGSMatB
     mutable bool m_GF_valid = false;
     // The same sums carried from one iteration to the next.  Between two subspace minimisations add_correction replaces
     // one storage slot (its Y and its S column) and a few rows enter or leave F, so of the 2c (2c + 1) / 2 entries only
-    // those of the two new columns need a pass over F -- together with the v row they are 6c <= 64 entries, one per lane,
+    // those of the two new columns need a pass over F -- together with the v row they are 6c of the 3 (2c + 1) entries one
+    // selected-entries pass serves for any 2c <= 80 (kx_rows; the round-3 kernel: 64 entries, one per lane, i.e. m <= 10),
     // the cost of a v-row pass instead of the full Gram's -- and the others change by the outer products of the rows that
     // moved (lbfgsx_b_free_delta, lbfgsx_b_gram_list_dd).  Everything stays un-rounded double-double, so the rounded
     // entries are those of the direct sums (error ~2^-104 per update; a full pass every carry_max_age() = 32 iterations bounds
@@ -61,6 +62,8 @@ class BFGSMatB
         const char* e = std::getenv("LBFGSX_GRAM_CARRY");
         return !(e && std::atoi(e) == 0);
     }
+    // the v row and the rows of the two columns of one replaced slot: 3 (2c + 1) entries at most (2 (2c) + 2c + 1 asked for)
+    bool carry_fits() const { return 6 * m_ncorr + 1 <= lbfgsx_b_gram_pairs_max(m_c); }
     static bool keep_copy_enabled()
     {
         const char* e = std::getenv("LBFGSX_COMPACT_KEEP");
@@ -108,7 +111,7 @@ class BFGSMatB
     {
         const int c = m_ncorr, t = 2 * c;
         std::int64_t ne = 0, nl = 0;
-        if (6 * c > 64)                                         // more entries than lanes: the full pass every time
+        if (!carry_fits())                                      // more entries than one selected-entries pass serves
             return false;
         if (lbfgsx_b_free_delta(m_c, &ne, &nl) != LBFGSX_OK)   // always: the remembered set must follow F
             return false;
@@ -125,7 +128,7 @@ class BFGSMatB
         if (ndirty > 1)
             return false;
         // entries that need the pass over F: rows of the two new columns (if any), then the v row
-        int pi[64], pj[64], np = 0;
+        int pi[3 * 81], pj[3 * 81], np = 0;
         if (ndirty == 1)
         {
             for (int J = 0; J < t; J++)
@@ -513,7 +516,7 @@ public:
                 fused = (lbfgsx_b_gram_fused_dd(m_c, mask, vsel, prologue, coef1, coef2, G.data(), raw, m_GF_dd.data()) == LBFGSX_OK);
                 m_GF_valid = fused;
                 m_carry_valid = false;
-                if (fused && carry && 6 * c <= 64)   // the remembered free set (lbfgsx_b_free_delta above) is the F of these sums
+                if (fused && carry && carry_fits())   // the remembered free set (lbfgsx_b_free_delta above) is the F of these sums
                 {
                     carry_store(m_GF_dd);
                     m_carry_valid = true;

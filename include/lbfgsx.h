@@ -322,11 +322,15 @@ int lbfgsx_b_free_delta(lbfgsx_ctx* c, int64_t* n_enter, int64_t* n_leave);
  * e = i (i + 1) / 2 + j as lbfgsx_b_gram_fused_dd returns it; LBFGSX_E_INVALID for an empty or overflowed list */
 int lbfgsx_b_gram_list_dd(lbfgsx_ctx* c, int which, double* gram_dd);
 /* selected entries of [Y_P S_P v]'[Y_P S_P v] in one pass with the prologue of lbfgsx_b_gram_fused_ex: entry e is the
- * product of the columns pair_i[e], pair_j[e] (0..2c-1: Y slots then S slots; 2c: v), at most 64 of them (one per lane:
- * the cost of lbfgsx_b_wtv_prologue); out_dd[2 e], out_dd[2 e + 1] = (hi, lo).  Writes the compact copy of the free rows
+ * product of the columns pair_i[e], pair_j[e] (0..2c-1: Y slots then S slots; 2c: v), at most lbfgsx_b_gram_pairs_max()
+ * of them; out_dd[2 e], out_dd[2 e + 1] = (hi, lo).  Writes the compact copy of the free rows
  * under the conditions of lbfgsx_b_set_compaction. */
 int lbfgsx_b_gram_pairs_dd(lbfgsx_ctx* c, int mask, int vsel, int prologue, const double* coef1, const double* coef2,
                            int npairs, const int* pair_i, const int* pair_j, int refresh_slot, double* out_dd);
+/* how many entries one lbfgsx_b_gram_pairs_dd call serves with the current history: 3 (2c + 1) -- the v row and the rows of
+ * two columns, whatever 2c <= 80 is (kernels of csrc/lbfgsb_x.cuh) -- or, with LBFGSX_SPLIT=0, the 64 of the round-3
+ * one-entry-per-lane kernel while 2c + 1 <= 31; 0: the call is not available for this history */
+int lbfgsx_b_gram_pairs_max(lbfgsx_ctx* c);
 /* refresh_slot >= -1: the caller vouches that since the previous subspace minimisation the history changed in at most the
  * storage slot `refresh_slot` (-1: not at all) and that lbfgsx_b_free_delta has been called for the current free set.  The
  * pass may then read the compact copy of the free rows it KEPT from that minimisation (rows that entered F were appended by

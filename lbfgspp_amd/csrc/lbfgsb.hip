@@ -25,6 +25,7 @@
 #include "lbfgsb_kernels.cuh"
 #include "gcp_scan.cuh"
 #include "gram_i8.cuh"
+#include "lbfgsb_x.hpp"
 
 struct lbfgsb_state
 {
@@ -175,6 +176,13 @@ struct lbfgsb_state
     unsigned* pcount = nullptr;
     void* sel_tmp = nullptr;
     size_t sel_tmp_bytes = 0;
+    // the passes for any history length (lbfgsb_x.cuh: a row's columns split over the lanes of a wavefront)
+    bool split = true;                // LBFGSX_SPLIT=0: the one-lane-per-row kernels of round 3 where they exist (2c <= 20 / 24 / 32)
+    double* xp1 = nullptr;            // workspace of grid_reduce_x: per-block and per-group partials, tickets
+    double* xp2 = nullptr;
+    unsigned* xtickets = nullptr;
+    int gtile = 3;                    // 256-entry tiles the Gram buffers hold: >= (2m + 1)(2m + 2) / 2 entries
+    static constexpr int kDout = 256; // doubles of `dout`
 };
 
 namespace lbfgsx {
@@ -380,12 +388,12 @@ int bounded_alloc(lbfgsx_ctx* c)
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->phys_dev), sizeof(int) * size_t(c->m + 1)));
     if (c->outmap_dev)
     {
-        LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->dout_host), sizeof(double) * 64, hipHostMallocMapped));
-        std::memset(b->dout_host, 0, sizeof(double) * 64);
+        LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->dout_host), sizeof(double) * lbfgsb_state::kDout, hipHostMallocMapped));
+        std::memset(b->dout_host, 0, sizeof(double) * lbfgsb_state::kDout);
         LBFGSX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->dout), b->dout_host, 0));
     }
     else
-        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->dout), sizeof(double) * 64));
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->dout), sizeof(double) * lbfgsb_state::kDout));
     LBFGSX_HIP(hipMalloc(&b->coef_dev, sizeof(double) * 80));
     b->lu_cap = unsigned(std::min<int64_t>(c->n, int64_t(1) << 20));
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->lu_list), sizeof(int) * 2 * size_t(b->lu_cap)));
@@ -401,6 +409,13 @@ int bounded_alloc(lbfgsx_ctx* c)
         b->vonly_groups = atoi(e);
     if (const char* e = getenv("LBFGSX_VROWS"))
         b->vrows = atoi(e) != 0;
+    if (const char* e = getenv("LBFGSX_SPLIT"))
+        b->split = atoi(e) != 0;
+    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->xp1), sizeof(double) * size_t(kMaxGridX) * kMaxSumsX * 2));
+    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->xp2), sizeof(double) * size_t(kMaxGridX / kGroupX) * kMaxSumsX * 2));
+    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->xtickets), sizeof(unsigned) * (2 + kMaxGridX / kGroupX)));
+    LBFGSX_HIP(hipMemset(b->xtickets, 0, sizeof(unsigned) * (2 + kMaxGridX / kGroupX)));
+    b->gtile = std::max(3, xl::gram_kpb(2 * c->m + 1));
     if (const char* e = getenv("LBFGSX_COMPACT_VEC"))
         b->cv_use = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_WTD_COMPACT"))
@@ -462,22 +477,23 @@ int bounded_alloc(lbfgsx_ctx* c)
         if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0)
             b->num_cus = prop.multiProcessorCount;
     }
-    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->gram_partial), sizeof(double) * size_t(b->gram_blocks) * 3 * 256 * 2));
-    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->gram_partial2), sizeof(double) * 32 * 3 * 256 * 2));
+    const size_t gent = size_t(b->gtile) * 256;  // entries the Gram buffers hold
+    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->gram_partial), sizeof(double) * size_t(b->gram_blocks) * gent * 2));
+    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->gram_partial2), sizeof(double) * 32 * gent * 2));
     if (c->outmap_dev)
     {
         // the (hi, lo) sums land where the host reads them: a copy into pageable memory is staged and costs ~20 us a fetch
-        LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->gram_dd_host), sizeof(double) * 3 * 256 * 2, hipHostMallocMapped));
+        LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->gram_dd_host), sizeof(double) * gent * 2, hipHostMallocMapped));
         LBFGSX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->gram_dd), b->gram_dd_host, 0));
-        LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->stash_host), sizeof(double) * 3 * (3 * 256 * 3), hipHostMallocMapped));
+        LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->stash_host), sizeof(double) * 3 * (gent * 3), hipHostMallocMapped));
         LBFGSX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->stash_dev), b->stash_host, 0));
-        LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->gram_out_host), sizeof(double) * 3 * 256, hipHostMallocMapped));
+        LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->gram_out_host), sizeof(double) * gent, hipHostMallocMapped));
         LBFGSX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->gram_out), b->gram_out_host, 0));
     }
     else
     {
-        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->gram_out), sizeof(double) * 3 * 256));
-        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->gram_dd), sizeof(double) * 3 * 256 * 2));
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->gram_out), sizeof(double) * gent));
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->gram_dd), sizeof(double) * gent * 2));
     }
     b->sort_tmp_bytes = bytes;
     LBFGSX_HIP(hipMalloc(&b->sort_tmp, bytes ? bytes : 16));
@@ -538,6 +554,9 @@ void bounded_free(lbfgsx_ctx* c)
     if (b->stash_host)
         (void) hipHostFree(b->stash_host);
     (void) hipFree(b->cv_buf);
+    (void) hipFree(b->xp1);
+    (void) hipFree(b->xp2);
+    (void) hipFree(b->xtickets);
     delete b;
     c->bstate = nullptr;
 }
@@ -571,6 +590,38 @@ static Cols<T, 32> wf_cols(lbfgsx_ctx* c, int count)
         cl.p[k] = static_cast<const T*>(c->bstate->wf) + int64_t(k < count ? k : 0) * c->bstate->wf_ld;  // padded with column 0
     return cl;
 }
+// the same lists for the kernels of lbfgsb_x.cuh (2c <= 80), and the workspace of their reductions
+template <class T>
+static ColsX<T> colsx_full(lbfgsx_ctx* c, int count)
+{
+    ColsX<T> cl;
+    for (int k = 0; k < kColsX; k++)
+    {
+        const int w = (k < count) ? k : 0;
+        const int slot = (w < c->ncorr) ? w : w - c->ncorr;
+        void* base = (w < c->ncorr) ? c->Y : c->S;
+        cl.p[k] = static_cast<const T*>(c->col(base, c->phys[size_t(slot)]));
+    }
+    return cl;
+}
+template <class T>
+static ColsX<T> colsx_wf(lbfgsx_ctx* c, int count)
+{
+    ColsX<T> cl;
+    for (int k = 0; k < kColsX; k++)
+        cl.p[k] = static_cast<const T*>(c->bstate->wf) + int64_t(k < count ? k : 0) * c->bstate->wf_ld;
+    return cl;
+}
+static RedWsX wsx(lbfgsx_ctx* c)  // after poll_arm: carries the completion word of this launch
+{
+    RedWsX w;
+    w.p1 = c->bstate->xp1;
+    w.p2 = c->bstate->xp2;
+    w.tickets = c->bstate->xtickets;
+    w.done = c->ws.done;
+    w.seq = c->ws.seq;
+    return w;
+}
 // a mask inside the free set can be served from the compact copy
 static inline bool wf_serves(const lbfgsx_ctx* c, int mask)
 {
@@ -586,7 +637,7 @@ static bool wf_alloc(lbfgsx_ctx* c)
         const size_t esz = (c->dtype == LBFGSX_F64) ? 8 : 4;
         b->wf_ld = c->ld;
         size_t bytes = 0;
-        bool ok = hipMalloc(&b->wf, esz * size_t(b->wf_ld) * 32) == hipSuccess &&
+        bool ok = hipMalloc(&b->wf, esz * size_t(b->wf_ld) * size_t(std::max(32, 2 * c->m))) == hipSuccess &&
                   hipMalloc(reinterpret_cast<void**>(&b->wf_idx), sizeof(int) * size_t(c->n)) == hipSuccess &&
                   hipMalloc(reinterpret_cast<void**>(&b->wf_pos), sizeof(int) * size_t(c->n)) == hipSuccess &&
                   hipMalloc(reinterpret_cast<void**>(&b->wf_cnt), sizeof(int) * size_t(nbatch + 2)) == hipSuccess &&
@@ -679,6 +730,25 @@ static int wtv_t(lbfgsx_ctx* c, int vsel_id, const T* vcol, int mask, double* ou
     const int total = 2 * c->ncorr;
     const int grid = c->grid_for(c->n);
     BVecs<T> b = bvecs<T>(c);
+    if (c->bstate->split && total >= 1 && total <= kColsX && !c->bstate->multidot_chunked &&
+        !(!vcol && c->bstate->lu_valid && mask != 0 && (mask & ~(ST_L | ST_U)) == 0 && total <= 32))
+    {
+        // every column in one launch, whatever 2c is (kx_multidot_mask); sets inside L u U keep the index-list kernel below
+        lbfgsb_state* bs = c->bstate;
+        int rc = xl::multidot_mask<T>(c->stream, bs->num_cus, colsx_full<T>(c, total), total, b, vsel_id, vcol, mask, c->n, wsx(c),
+                                      bs->dout);
+        if (rc)
+            return rc;
+        double r[kColsX + 1];
+        rc = fetch_doubles(c, total + 1, r);
+        if (rc)
+            return rc;
+        for (int k = 0; k < total; k++)
+            out[k] = r[k];
+        if (nnz)
+            *nnz = int64_t(r[total]);
+        return LBFGSX_OK;
+    }
     if (!vcol && c->bstate->lu_valid && mask != 0 && (mask & ~(ST_L | ST_U)) == 0 && total <= 32)
     {
         // rows inside L u U: the index list of the last partition (k_sub_sweep_begin)
@@ -818,6 +888,61 @@ static int wtd2_wf(lbfgsx_ctx* c, int total, int newest, double* wtd)
     g_wtdc_runs.fetch_add(1, std::memory_order_relaxed);
     return LBFGSX_OK;
 }
+// the same two passes through the kernels of lbfgsb_x.cuh (any 2c <= 80); outputs packed by 2c
+template <class T>
+static int wtd2_all_x(lbfgsx_ctx* c, int total, const T* snew, const T* dvec, double* wtd)
+{
+    lbfgsb_state* b = c->bstate;
+    lbfgsx::poll_arm(c);
+    int rc = xl::multidot2<T>(c->stream, b->num_cus, colsx_full<T>(c, total), total, snew, dvec, c->n, wsx(c), b->dout);
+    if (rc)
+        return rc;
+    double r[2 * kColsX];
+    rc = fetch_doubles(c, 2 * total, r);
+    if (rc)
+        return rc;
+    for (int k = 0; k < total; k++)
+    {
+        b->corr_raw[k] = r[k];
+        wtd[k] = r[total + k];
+    }
+    b->corr_stash_valid = true;
+    return LBFGSX_OK;
+}
+template <class T>
+static int wtd2_wf_x(lbfgsx_ctx* c, int total, int newest, double* wtd)
+{
+    lbfgsb_state* b = c->bstate;
+    int rc = upload_phys(c);
+    if (rc)
+        return rc;
+    const ColsX<T> full = colsx_full<T>(c, total);
+    ColsX<T> wfc = colsx_wf<T>(c, total);
+    const int fresh_a = newest, fresh_b = c->ncorr + newest;
+    const int stand_in = (newest == 0) ? 1 : 0;  // another Y column of the copy: read anyway, so the stale pair costs nothing
+    wfc.p[fresh_a] = wfc.p[stand_in];
+    wfc.p[fresh_b] = wfc.p[stand_in];
+    const T* snew = static_cast<const T*>(c->col(c->S, c->phys[size_t(newest)]));
+    const T* ynew = static_cast<const T*>(c->col(c->Y, c->phys[size_t(newest)]));
+    lbfgsx::poll_arm(c);
+    rc = xl::multidot2_wf<T>(c->stream, b->num_cus, wfc, total, fresh_a, fresh_b, snew, ynew, static_cast<const T*>(b->dvec), b->wf_idx,
+                             b->wf_n, full, b->wtdc_list, int(b->wtdc_n), wsx(c), b->dout);
+    if (rc)
+        return rc;
+    double r[2 * kColsX];
+    rc = fetch_doubles(c, 2 * total, r);
+    if (rc)
+        return rc;
+    for (int k = 0; k < total; k++)
+    {
+        b->corr_raw[k] = r[k];
+        wtd[k] = r[total + k];
+    }
+    b->corr_stash_valid = true;
+    b->wtdc_runs++;
+    g_wtdc_runs.fetch_add(1, std::memory_order_relaxed);
+    return LBFGSX_OK;
+}
 // can this iteration's W'd come from the kept compact copy?  Asked before the build (which then writes the list of the
 // rows outside the copy) and again by cauchy_wtd
 static bool wtdc_ready(lbfgsx_ctx* c)
@@ -826,7 +951,8 @@ static bool wtdc_ready(lbfgsx_ctx* c)
     const int total = 2 * c->ncorr;
     // the copy of the previous minimisation, same history length (the commit replaced a slot), not overgrown: the pass must
     // read clearly less than the full-length one
-    return b->wtdc_use && b->corr_defer && total > 8 && total <= 20 && !b->multidot_chunked && b->wf_use && b->wf_live &&
+    return b->wtdc_use && b->corr_defer && (b->split ? (total >= 2 && total <= kColsX) : (total > 8 && total <= 20)) &&
+           !b->multidot_chunked && b->wf_use && b->wf_live &&
            b->wf_ncorr == c->ncorr && b->wf_epoch == b->sub_epoch && c->ncorr == c->m && c->n < (int64_t(1) << 31) &&
            b->wf_n >= 4096 && b->wf_n * 4 <= c->n * 3;
 }
@@ -868,12 +994,20 @@ static int cauchy_wtd(lbfgsx_ctx* c, double* wtd)
     {
         b->corr_defer = false;
         const int newest = (c->ptr + c->m - 1) % c->m;
+        if (b->split)
+            return wtd2_wf_x<T>(c, total, newest, wtd);
         if (total <= 16)
             return wtd2_wf<T, 16>(c, total, newest, wtd);
         return wtd2_wf<T, 20>(c, total, newest, wtd);
     }
     const bool defer = b->corr_defer;
     b->corr_defer = false;
+    if (defer && b->split && total >= 2 && total <= kColsX && !b->multidot_chunked)
+    {
+        const int newest = (c->ptr + c->m - 1) % c->m;
+        const T* snew = static_cast<const T*>(c->col(c->S, c->phys[size_t(newest)]));
+        return wtd2_all_x<T>(c, total, snew, static_cast<const T*>(b->dvec), wtd);
+    }
     if (defer && total > 8 && total <= 20 && !b->multidot_chunked)
     {
         const int newest = (c->ptr + c->m - 1) % c->m;
@@ -1863,22 +1997,35 @@ int lbfgsx_b_wtv_lu(lbfgsx_ctx* c, double* out_l, int64_t* nnz_l, double* out_u,
         return rc;
     lbfgsb_state* b = c->bstate;
     const int total = 2 * c->ncorr;
-    if (!b->lu_valid || total < 1 || total > 24 || b->multidot_chunked)
+    if (!b->lu_valid || total < 1 || total > (b->split ? kColsX : 24) || b->multidot_chunked)
     {
-        set_error("lbfgsx_b_wtv_lu: needs the index list of L u U and 1 <= 2c <= 24; use lbfgsx_b_wtv per set");
+        set_error("lbfgsx_b_wtv_lu: needs the index list of L u U and 1 <= 2c <= 80; use lbfgsx_b_wtv per set");
         return LBFGSX_E_INVALID;
     }
     const int nl = b->lu_n;
     const int lgrid = std::max(1, std::min(32, (nl + kBlock - 1) / kBlock));
-    int which[32];
+    int which[kColsX];
     for (int k = 0; k < total; k++)
         which[k] = k;
-    double r[50];
+    double r[2 * (kColsX + 1)];
     int nc = 24;
     // the wait below ends with the last kernel launched before it: the Gram that rides behind this pass, or this pass
     const bool rides = gram_stash_feasible(c, b->lu_ptr(), nl);
     if (!rides)
         lbfgsx::poll_arm(c);
+    if (b->split)
+    {
+        nc = total;  // kx_list2 packs its outputs by 2c: {L dots, nnz_L, U dots, nnz_U}
+        DISPATCH_T(c, {
+            const unsigned char* stc = b->cv_live ? bvecs_cv<T>(c).st : static_cast<const unsigned char*>(nullptr);
+            const int* stpos = b->cv_live ? b->wf_pos : static_cast<const int*>(nullptr);
+            rc = xl::list2<T>(c->stream, b->num_cus, colsx_full<T>(c, total), total, bvecs<T>(c), b->lu_ptr(), nl, wsx(c), b->dout, stc,
+                              stpos);
+        });
+        if (rc)
+            return rc;
+    }
+    else
     DISPATCH_T(c, {
         Cols<T, 32> cl = col_list<T, 32>(c, which, total);
         BVecs<T> bv = bvecs<T>(c);
@@ -2107,7 +2254,8 @@ static bool gram_stash_feasible(lbfgsx_ctx* c, const int* list, int64_t nlist)
 {
     lbfgsb_state* b = c->bstate;
     const int tot = 2 * c->ncorr;
-    return b->stash_use && b->stash_host && !b->gram_mfma && b->gram_mode != 2 && tot >= 1 && tot <= kGramDDCS && list && nlist >= 1;
+    return b->stash_use && b->stash_host && !b->gram_mfma && b->gram_mode != 2 && tot >= 1 && (tot <= kGramDDCS || b->split) && list &&
+           nlist >= 1;
 }
 // signal: this is the last launch before the caller's wait -- its final block carries the completion word (ctx.hpp)
 static bool gram_stash_launch(lbfgsx_ctx* c, int slot, int mask, const int* list, int64_t nlist, bool signal)
@@ -2125,6 +2273,40 @@ static bool gram_stash_launch(lbfgsx_ctx* c, int slot, int mask, const int* list
     const int ntile = (64 * kpt + 255) / 256;
     const int64_t nbatch = (nlist + kGramDDRows - 1) / kGramDDRows;
     int blocks = 1;
+    double* out = b->stash_dev + size_t(slot) * (size_t(b->gtile) * 256 * 3);
+    if (tot > kGramDDCS)
+    {
+        // more columns than the wave-private tiles hold: the block-tile kernel (lbfgsb_x.cuh)
+        int rcx = LBFGSX_OK;
+        DISPATCH_T(c, {
+            ProX<T> pro{};
+            pro.mode = LBFGSX_GP_NONE;
+            GramRows<T> gr{};
+            gr.in_idx = list;
+            gr.w_by_row = 1;
+            if (b->cv_live)
+            {
+                gr.st_alt = bvecs_cv<T>(c).st;
+                gr.st_pos = b->wf_pos;
+            }
+            blocks = xl::gram<T>(c->stream, b->gram_blocks, colsx_full<T>(c, tot), tot, bvecs<T>(c), -1, mask, nlist, b->gram_partial,
+                                 pro, gr);
+        });
+        if (blocks < 1)
+            return false;
+        const int nt = xl::gram_kpb(tot);
+        if (signal)
+            lbfgsx::poll_arm(c);
+        rcx = xl::gram_finish(c->stream, b->gram_partial, blocks, nt, b->gram_partial2, out, out + size_t(b->gtile) * 256,
+                              signal ? c->ws.done : static_cast<unsigned long long*>(nullptr), signal ? c->ws.seq : 0ull,
+                              b->xtickets + 1 + kMaxGridX / kGroupX);
+        if (rcx != LBFGSX_OK)
+            return false;
+        b->stash_armed[slot] = true;
+        b->stash_phys[slot] = c->phys_version;
+        b->stash_tot[slot] = tot;
+        return true;
+    }
     DISPATCH_T(c, {
         GramPrologue<T> pro;
         pro.mode = LBFGSX_GP_NONE;
@@ -2145,14 +2327,13 @@ static bool gram_stash_launch(lbfgsx_ctx* c, int slot, int mask, const int* list
         else if (kp <= 6) blocks = launch_gram_dd<T, 6>(c, nbatch, tot, -1, mask, pro, gr, nlist);
         else blocks = launch_gram_dd<T, 8>(c, nbatch, tot, -1, mask, pro, gr, nlist);
     });
-    double* out = b->stash_dev + size_t(slot) * (3 * 256 * 3);
     const int nch = std::min(blocks, 32);
     LBFGSX_LAUNCH(k_gram_finish, dim3(ntile, nch), dim3(kBlock), 0, c->stream, b->gram_partial, blocks, b->gram_partial2, 0);
     if (signal && ntile == 1)
         lbfgsx::poll_arm(c);
     else
         signal = false;
-    LBFGSX_LAUNCH(k_gram_finish, dim3(ntile, 1), dim3(kBlock), 0, c->stream, b->gram_partial2, nch, out, 1, out + 3 * 256,
+    LBFGSX_LAUNCH(k_gram_finish, dim3(ntile, 1), dim3(kBlock), 0, c->stream, b->gram_partial2, nch, out, 1, out + size_t(b->gtile) * 256,
                   signal ? c->ws.done : static_cast<unsigned long long*>(nullptr), signal ? c->ws.seq : 0ull);
     if (hipGetLastError() != hipSuccess)
         return false;
@@ -2180,7 +2361,7 @@ static bool gram_stash_take(lbfgsx_ctx* c, int slot, double* gram, double* gram_
     b->stash_valid[slot] = false;
     if (!hit)
         return false;
-    const double* h = b->stash_host + size_t(slot) * (3 * 256 * 3);
+    const double* h = b->stash_host + size_t(slot) * (size_t(b->gtile) * 256 * 3);
     if (gram)
         for (int i = 0; i < tot; i++)
             for (int j = 0; j <= i; j++)
@@ -2190,7 +2371,7 @@ static bool gram_stash_take(lbfgsx_ctx* c, int slot, double* gram, double* gram_
                 gram[j * tot + i] = v;
             }
     if (gram_dd)
-        std::memcpy(gram_dd, h + 3 * 256, sizeof(double) * size_t(tot) * size_t(tot + 1));
+        std::memcpy(gram_dd, h + size_t(b->gtile) * 256, sizeof(double) * size_t(tot) * size_t(tot + 1));
     b->stash_hits++;
     g_stash_hits.fetch_add(1, std::memory_order_relaxed);
     return true;
@@ -2247,8 +2428,8 @@ static int fetch_gram_out(lbfgsx_ctx* c, int first, int count, double* h)
 // in the kernel's output, rows of NP entries: 0 = v row, 1 = column a, 2 = column b.
 static bool vrows_plan(int npairs, const int* pi, const int* pj, int tot, int NP, int& col_a, int& col_b, int* slot)
 {
-    int freq[33];
-    for (int k = 0; k <= 32; k++)
+    int freq[kColsX + 1];
+    for (int k = 0; k <= kColsX; k++)
         freq[k] = 0;
     bool other = false;
     for (int z = 0; z < npairs; z++)
@@ -2296,10 +2477,11 @@ int lbfgsx_b_wtv_prologue(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, co
         return rc;
     lbfgsb_state* b = c->bstate;
     const int tot = 2 * c->ncorr, ntot = tot + 1;
-    if (tot < 1 || ntot > kGramDDCS || vsel_id < 0 || !wtv || b->gram_mfma || b->gram_mode == 2 ||
+    const bool xsplit = b->split && b->vrows;  // kx_rows: any 2c <= 80
+    if (tot < 1 || (ntot > kGramDDCS && !xsplit) || tot > kColsX || vsel_id < 0 || !wtv || b->gram_mfma || b->gram_mode == 2 ||
         prologue < LBFGSX_GP_NONE || prologue > LBFGSX_GP_LINEAR)
     {
-        set_error("lbfgsx_b_wtv_prologue: needs the default one-pass Gram, 1 <= 2c <= 30, a vector selector and a known prologue");
+        set_error("lbfgsx_b_wtv_prologue: needs the default one-pass Gram, 1 <= 2c <= 80, a vector selector and a known prologue");
         return LBFGSX_E_INVALID;
     }
     // the compact vectors serve the pass between two sweeps: rhs += ..., v = -rhs on the P rows of the compact copy
@@ -2318,6 +2500,36 @@ int lbfgsx_b_wtv_prologue(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, co
     if (rc)
         return rc;
     int blocks = 1;
+    if (xsplit)
+    {
+        DISPATCH_T(c, {
+            ProX<T> pro;
+            pro.mode = prologue;
+            pro.use1 = coef1 ? 1 : 0;
+            pro.use2 = coef2 ? 1 : 0;
+            for (int k = 0; k < kColsX; k++)
+            {
+                pro.c1[k] = (coef1 && k < tot) ? T(coef1[k]) : T(0);
+                pro.c2[k] = (coef2 && k < tot) ? T(coef2[k]) : T(0);
+            }
+            RowsX<T> gr{};
+            gr.in_idx = (compact && !by_pos) ? b->wf_idx : nullptr;
+            const BVecs<T> cvb = bvecs_cv<T>(c);
+            const ColsX<T> cl = (gr.in_idx || by_pos) ? colsx_wf<T>(c, tot) : colsx_full<T>(c, tot);
+            lbfgsx::poll_arm(c);
+            rc = xl::rows<T>(c->stream, b->num_cus, 1, cl, tot, by_pos ? cvb : bvecs<T>(c), vsel_id, mask, nrows, wsx(c), b->gram_out,
+                             b->gram_out + 256, pro, gr, -1, -1);
+        });
+        if (rc)
+            return rc;
+        double hx[kColsX];
+        rc = fetch_gram_out(c, 0, tot, hx);
+        if (rc)
+            return rc;
+        for (int j = 0; j < tot; j++)
+            wtv[j] = hx[j];
+        return LBFGSX_OK;
+    }
     DISPATCH_T(c, {
         GramPrologue<T> pro;
         pro.mode = prologue;
@@ -2426,13 +2638,19 @@ int lbfgsx_b_free_delta(lbfgsx_ctx* c, int64_t* n_enter, int64_t* n_leave)
         if (rc)
             return rc;
         const int total = 2 * c->ncorr;
-        int which[32];
+        int which[kColsX];
         for (int k = 0; k < total; k++)
             which[k] = k;
         DISPATCH_T(c, {
+            if (total > 32)
+                (void) xl::wf_append<T>(c->stream, colsx_full<T>(c, total), total, static_cast<T*>(b->wf), b->wf_ld, b->wf_idx, b->wf_pos,
+                                        b->dl_enter, b->dl_cnt, b->dl_cap, unsigned(std::min<int64_t>(c->n, b->wf_ld)));
+            else
+            {
             Cols<T, 32> cl = col_list<T, 32>(c, which, total);
             LBFGSX_LAUNCH((k_wf_append<T>), dim3(16), dim3(kBlock), 0, c->stream, cl, total, static_cast<T*>(b->wf), b->wf_ld,
                                b->wf_idx, b->wf_pos, b->dl_enter, b->dl_cnt, b->dl_cap, unsigned(std::min<int64_t>(c->n, b->wf_ld)));
+            }
         });
         LBFGSX_HIP(hipGetLastError());
     }
@@ -2469,6 +2687,19 @@ int lbfgsx_b_gram_list_dd(lbfgsx_ctx* c, int which, double* gram_dd)
                         b->dl_n[which]);
 }
 
+int lbfgsx_b_gram_pairs_max(lbfgsx_ctx* c)
+{
+    if (!c || !c->bstate)
+        return 0;
+    const lbfgsb_state* b = c->bstate;
+    const int tot = 2 * c->ncorr;
+    if (tot < 1 || tot > kColsX || b->gram_mfma || b->gram_mode == 2)
+        return 0;
+    if (b->split && b->vrows)
+        return 3 * (tot + 1);
+    return tot + 1 <= kGramDDCS ? 64 : 0;
+}
+
 int lbfgsx_b_gram_pairs_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, const double* coef1, const double* coef2,
                            int npairs, const int* pair_i, const int* pair_j, int refresh_slot, double* out_dd)
 {
@@ -2478,10 +2709,11 @@ int lbfgsx_b_gram_pairs_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
         return rc;
     lbfgsb_state* b = c->bstate;
     const int tot = 2 * c->ncorr, ntot = tot + 1;
-    if (tot < 1 || ntot > kGramDDCS || vsel_id < 0 || !out_dd || b->gram_mfma || b->gram_mode == 2 || npairs < 1 || npairs > 64 ||
-        prologue < LBFGSX_GP_NONE || prologue > LBFGSX_GP_LINEAR)
+    const bool xsplit = b->split && b->vrows;  // kx_rows: any 2c <= 80, up to 3 (2c + 1) entries
+    if (tot < 1 || tot > kColsX || vsel_id < 0 || !out_dd || b->gram_mfma || b->gram_mode == 2 || npairs < 1 ||
+        (xsplit ? npairs > 3 * (kColsX + 1) : (npairs > 64 || ntot > kGramDDCS)) || prologue < LBFGSX_GP_NONE || prologue > LBFGSX_GP_LINEAR)
     {
-        set_error("lbfgsx_b_gram_pairs_dd: needs the default one-pass Gram, 1 <= 2c <= 30, a vector selector and 1..64 entries");
+        set_error("lbfgsx_b_gram_pairs_dd: needs the default one-pass Gram, 1 <= 2c <= 80, a vector selector and 1..3 (2c + 1) entries");
         return LBFGSX_E_INVALID;
     }
     for (int e = 0; e < npairs; e++)
@@ -2514,8 +2746,75 @@ int lbfgsx_b_gram_pairs_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
     int blocks = 1;
     // the register kernel serves the pass that writes no new copy when the entries are the v row plus the rows of at most
     // two columns (3 (2c + 1) <= 64 sums: one lane per sum in the block reduction)
-    int col_a = -1, col_b = -1, slot[64];
+    int col_a = -1, col_b = -1, slot[3 * (kColsX + 1)];
     bool ride_enter = false, ride_leave = false;
+    if (xsplit)
+    {
+        // the v row plus the rows of at most two columns, whatever 2c is; a pass that must also write a new compact copy is
+        // the full Gram's business (the caller falls back to it)
+        if (compact_out || !vrows_plan(npairs, pair_i, pair_j, tot, tot + 1, col_a, col_b, slot))
+        {
+            if (ntot > kGramDDCS || npairs > 64)
+            {
+                set_error("lbfgsx_b_gram_pairs_dd: these entries need the full pass");
+                return LBFGSX_E_INVALID;
+            }
+        }
+        else
+        {
+            DISPATCH_T(c, {
+                ProX<T> pro;
+                pro.mode = prologue;
+                pro.use1 = coef1 ? 1 : 0;
+                pro.use2 = coef2 ? 1 : 0;
+                for (int k = 0; k < kColsX; k++)
+                {
+                    pro.c1[k] = (coef1 && k < tot) ? T(coef1[k]) : T(0);
+                    pro.c2[k] = (coef2 && k < tot) ? T(coef2[k]) : T(0);
+                }
+                RowsX<T> gr{};
+                gr.in_idx = compact_in ? b->wf_idx : nullptr;
+                if (kept && refresh_slot >= 0)
+                {
+                    gr.fresh_a = refresh_slot;
+                    gr.fresh_b = c->ncorr + refresh_slot;
+                    gr.src_a = static_cast<const T*>(c->col(c->Y, c->phys[size_t(refresh_slot)]));
+                    gr.src_b = static_cast<const T*>(c->col(c->S, c->phys[size_t(refresh_slot)]));
+                    gr.dst_a = static_cast<T*>(b->wf) + int64_t(gr.fresh_a) * b->wf_ld;
+                    gr.dst_b = static_cast<T*>(b->wf) + int64_t(gr.fresh_b) * b->wf_ld;
+                }
+                ride_enter = b->fprev && b->dl_n[0] >= 1 && gram_stash_feasible(c, b->dl_enter, b->dl_n[0]);
+                ride_leave = b->fprev && b->dl_n[1] >= 1 && gram_stash_feasible(c, b->dl_leave, b->dl_n[1]);
+                if (!ride_enter && !ride_leave)
+                    lbfgsx::poll_arm(c);
+                const ColsX<T> cl = compact_in ? colsx_wf<T>(c, tot) : colsx_full<T>(c, tot);
+                rc = xl::rows<T>(c->stream, b->num_cus, col_a < 0 ? 1 : 3, cl, tot, bvecs<T>(c), vsel_id, mask, nrows, wsx(c), b->gram_out,
+                                 b->gram_out + 256, pro, gr, col_a, col_b);
+            });
+            if (kept)
+            {
+                b->wf_valid = true;  // usable by the passes of this subspace minimisation
+                b->wf_epoch = b->sub_epoch;
+            }
+            if (rc)
+                return rc;
+            if (ride_enter)
+                (void) gram_stash_launch(c, 1, 0, b->dl_enter, b->dl_n[0], /*signal=*/!ride_leave);
+            if (ride_leave)
+                (void) gram_stash_launch(c, 2, 0, b->dl_leave, b->dl_n[1], /*signal=*/true);
+            double hx[2 * 3 * (kColsX + 1)];
+            rc = fetch_gram_out(c, 256, 2 * 3 * (tot + 1), hx);
+            gram_stash_settle(c, rc == LBFGSX_OK);
+            if (rc)
+                return rc;
+            for (int z = 0; z < npairs; z++)
+            {
+                out_dd[2 * z] = hx[2 * slot[z]];
+                out_dd[2 * z + 1] = hx[2 * slot[z] + 1];
+            }
+            return LBFGSX_OK;
+        }
+    }
     bool use_vrows = b->vrows && !compact_out && vrows_plan(npairs, pair_i, pair_j, tot, (tot <= 20 ? 20 : 32) + 1, col_a, col_b, slot);
     if (use_vrows && col_a >= 0 && (tot > 20 || !compact_in))  // the three-row form walks the compact copy's row list
         use_vrows = false;
@@ -2687,12 +2986,14 @@ static int gram_dd_core(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, cons
         set_error("lbfgsx_b_gram_fused_dd: the un-rounded sums exist for the default one-pass Gram only");
         return LBFGSX_E_INVALID;
     }
-    if (tot < 1 || (b->gram_mfma ? tot + 1 > 32 : ntot > kGramDDCS) || b->gram_mode == 2)
+    const bool wide = !b->gram_mfma && ntot > kGramDDCS && b->split;  // kx_gram: the block-tile kernel for 2c + 1 > 31
+    if (tot < 1 || (b->gram_mfma ? tot + 1 > 32 : (ntot > kGramDDCS && !wide)) || b->gram_mode == 2)
     {
         set_error("lbfgsx_b_gram_fused: one-pass Gram not applicable");
         return LBFGSX_E_INVALID;
     }
-    double h[3 * 256];
+    std::vector<double> hbuf(size_t(b->gtile) * 256);
+    double* h = hbuf.data();
     if (b->gram_mfma)
     {
         const int64_t ntiles = (c->n + kGramRows - 1) / kGramRows;
@@ -2713,11 +3014,11 @@ static int gram_dd_core(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, cons
         if (b->gram_out_host)
         {
             LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
-            std::memcpy(h, b->gram_out_host, sizeof(h));
+            std::memcpy(h, b->gram_out_host, sizeof(double) * 3 * 256);
         }
         else
         {
-            LBFGSX_HIP(lbfgsx::copy_async(h, b->gram_out, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+            LBFGSX_HIP(lbfgsx::copy_async(h, b->gram_out, sizeof(double) * 3 * 256, hipMemcpyDeviceToHost, c->stream));
             LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
         }
         // entry (I, J), I >= J, of the padded 32 x 32 Gram
@@ -2793,8 +3094,52 @@ static int gram_dd_core(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, cons
             wf_rebuilt(c);
     }
     const int kpt_ = kp <= 1 ? 1 : kp <= 2 ? 2 : kp <= 4 ? 4 : kp <= 6 ? 6 : 8;
-    const int ntile_ = (64 * kpt_ + 255) / 256;
-    if (!done_i8)
+    const int ntile_ = wide ? xl::gram_kpb(ntot) : (64 * kpt_ + 255) / 256;
+    if (wide)
+    {
+        DISPATCH_T(c, {
+            ProX<T> pro;
+            pro.mode = prologue;
+            pro.use1 = coef1 ? 1 : 0;
+            pro.use2 = coef2 ? 1 : 0;
+            for (int k = 0; k < kColsX; k++)
+            {
+                pro.c1[k] = (coef1 && k < tot) ? T(coef1[k]) : T(0);
+                pro.c2[k] = (coef2 && k < tot) ? T(coef2[k]) : T(0);
+            }
+            GramRows<T> gr{};
+            gr.in_idx = list ? list : compact_in ? b->wf_idx : nullptr;
+            gr.w_by_row = list ? 1 : 0;
+            if (b->cv_live)  // lu_walk
+            {
+                gr.st_alt = bvecs_cv<T>(c).st;
+                gr.st_pos = b->wf_pos;
+            }
+            if (compact_out)
+            {
+                gr.out_w = static_cast<T*>(b->wf);
+                gr.out_ld = b->wf_ld;
+                gr.out_idx = b->wf_idx;
+                gr.out_base = b->wf_base;
+                gr.out_pos = b->wf_pos;
+            }
+            const ColsX<T> cl = (gr.in_idx && !gr.w_by_row) ? colsx_wf<T>(c, tot) : colsx_full<T>(c, tot);
+            blocks = xl::gram<T>(c->stream, b->gram_blocks, cl, tot, bvecs<T>(c), vsel_id, mask, nrows, b->gram_partial, pro, gr);
+        });
+        if (blocks < 1)
+        {
+            set_error("lbfgsx_b_gram_fused: kx_gram launch failed");
+            return LBFGSX_E_HIP;
+        }
+        if (compact_out)
+            wf_rebuilt(c);
+        rc = xl::gram_finish(c->stream, b->gram_partial, blocks, ntile_, b->gram_partial2, b->gram_out,
+                             gram_dd ? b->gram_dd : static_cast<double*>(nullptr), nullptr, 0ull,
+                             b->xtickets + 1 + kMaxGridX / kGroupX);
+        if (rc)
+            return rc;
+    }
+    else if (!done_i8)
     {
     DISPATCH_T(c, {
         GramPrologue<T> pro;
@@ -3086,6 +3431,66 @@ static int solve_sweep_t(lbfgsx_ctx* c, int first, int vsel_id, const double* co
         sums[k] = r[nd + k];
     return LBFGSX_OK;
 }
+// the same through kx_solve_sweep (any 2c <= 80)
+template <class T>
+static int solve_sweep_x(lbfgsx_ctx* c, int first, int vsel_id, const double* coef, double theta, double* wty, double* sums,
+                         unsigned lu_cap_now, int* lu_dst)
+{
+    const int total = 2 * c->ncorr;
+    lbfgsb_state* b = c->bstate;
+    const bool compact = wf_serves(c, ST_FREE);
+    const int64_t nrows = compact ? b->wf_n : c->n;
+    const int* ridx = compact ? b->wf_idx : nullptr;
+    const ColsX<T> cl = compact ? colsx_wf<T>(c, total) : colsx_full<T>(c, total);
+    CoefX<T> cf;
+    for (int k = 0; k < kColsX; k++)
+        cf.c[k] = (coef && k < total) ? T(coef[k]) : T(0);
+    int cv = 0;
+    if (first)
+    {
+        b->cv_live = false;
+        if (compact && b->cv_use && lu_cap_now > 0 && (vsel_id == VS_NEG_CF || vsel_id == VS_NEG_RHS || vsel_id == VS_Y) &&
+            cv_alloc(c) == LBFGSX_OK)
+            cv = 1;
+    }
+    else if (b->cv_live)
+    {
+        if (compact && (vsel_id == VS_NEG_CF || vsel_id == VS_NEG_RHS || vsel_id == VS_Y))
+            cv = 2;
+        else
+        {
+            const int rcb = cv_back(c, false);
+            if (rcb)
+                return rcb;
+        }
+    }
+    T* cli = nullptr;
+    T* cui = nullptr;
+    const BVecs<T> full = bvecs<T>(c);
+    const BVecs<T> cvb = cv ? bvecs_cv<T>(c, &cli, &cui) : full;
+    lbfgsx::poll_arm(c);
+    int rc = xl::solve_sweep<T>(c->stream, b->num_cus, first, cl, total, (first || !cv) ? full : cvb, cvb, vsel_id, cf, coef ? 1 : 0,
+                                T(theta), nrows, wsx(c), b->dout, lu_dst, b->lu_cnt, lu_cap_now, ridx, cli, cui, cv);
+    if (rc)
+        return rc;
+    if (cv == 1)
+    {
+        b->cv_live = true;
+        b->cv_starts++;
+        g_cv_starts.fetch_add(1, std::memory_order_relaxed);
+    }
+    const int nd = first ? 0 : total;
+    double r[kColsX + 7];
+    rc = fetch_doubles(c, nd + 7, r);
+    if (rc)
+        return rc;
+    if (!first)
+        for (int k = 0; k < total; k++)
+            wty[k] = r[k];
+    for (int k = 0; k < 7; k++)
+        sums[k] = r[nd + k];
+    return LBFGSX_OK;
+}
 extern "C" {
 
 int lbfgsx_b_solve_sweep(lbfgsx_ctx* c, int first, int vsel_id, const double* coef, double theta, double* wty, int64_t sums[7])
@@ -3096,9 +3501,9 @@ int lbfgsx_b_solve_sweep(lbfgsx_ctx* c, int first, int vsel_id, const double* co
         return rc;
     lbfgsb_state* b = c->bstate;
     const int total = 2 * c->ncorr;
-    if (total < 1 || total > 32 || b->multidot_chunked || !b->sweep_fuse)
+    if (total < 1 || total > (b->split ? kColsX : 32) || b->multidot_chunked || !b->sweep_fuse)
     {
-        set_error("lbfgsx_b_solve_sweep: not available here (needs 1 <= 2*ncorr <= 32); run the separate passes");
+        set_error("lbfgsx_b_solve_sweep: not available here (needs 1 <= 2*ncorr <= 80); run the separate passes");
         return LBFGSX_E_INVALID;
     }
     unsigned cap;
@@ -3121,7 +3526,8 @@ int lbfgsx_b_solve_sweep(lbfgsx_ctx* c, int first, int vsel_id, const double* co
     }
     double r[7];
     DISPATCH_T(c, {
-        if (total <= 8) rc = solve_sweep_t<T, 8>(c, first, vsel_id, coef, theta, wty, r, cap, dst);
+        if (b->split) rc = solve_sweep_x<T>(c, first, vsel_id, coef, theta, wty, r, cap, dst);
+        else if (total <= 8) rc = solve_sweep_t<T, 8>(c, first, vsel_id, coef, theta, wty, r, cap, dst);
         else if (total <= 16) rc = solve_sweep_t<T, 16>(c, first, vsel_id, coef, theta, wty, r, cap, dst);
         else if (total <= 20) rc = solve_sweep_t<T, 20>(c, first, vsel_id, coef, theta, wty, r, cap, dst);  // m = 10: no idle registers
         else if (total <= 24) rc = solve_sweep_t<T, 24>(c, first, vsel_id, coef, theta, wty, r, cap, dst);

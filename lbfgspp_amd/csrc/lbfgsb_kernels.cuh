@@ -869,7 +869,7 @@ __global__ void __launch_bounds__(kBlock) k_wf_append(Cols<T, 32> orig, int ncol
 // rows whose membership of the free set changed since the last call (prev[] holds that call's free bits): appended to
 // the lists `enter` / `leave` in arrival order, counts in cnt[0..1]; prev := current.  Feeds the carried Gram of the free
 // set (BFGSMatB::solve_PtBP): W_F'W_F changes by the outer products of exactly these rows.
-__global__ void __launch_bounds__(kBlock) k_free_delta(const unsigned char* __restrict__ st, unsigned char* __restrict__ prev,
+static __global__ void __launch_bounds__(kBlock) k_free_delta(const unsigned char* __restrict__ st, unsigned char* __restrict__ prev,
                                                        int64_t n8 /* 8-row groups: ceil(n / 8), the arrays are padded */, int64_t n,
                                                        int* __restrict__ enter, int* __restrict__ leave,
                                                        unsigned* __restrict__ cnt, unsigned cap)
@@ -936,7 +936,7 @@ __global__ void __launch_bounds__(kBlock) k_free_delta(const unsigned char* __re
 }
 
 // free rows per 64-row batch (the exclusive prefix sum over it places the batch in the compact copy)
-__global__ void __launch_bounds__(kBlock) k_free_counts(const unsigned char* __restrict__ st, int64_t n, int64_t nbatch,
+static __global__ void __launch_bounds__(kBlock) k_free_counts(const unsigned char* __restrict__ st, int64_t n, int64_t nbatch,
                                                         int* __restrict__ counts)
 {
     const int lane = threadIdx.x & 63;
@@ -1205,7 +1205,7 @@ __global__ void __launch_bounds__(kBlock) k_gram_dd(Cols<T, 32> cols, int ncols,
 // input); final = 1 (nchunks == 1): writes the rounded entries out[tb*256 + e], e = reg*64 + lane  <->  Gram row
 // (lane>>4) + 4*reg, column lane&15; with out_dd also the un-rounded double-double sums (hi, lo) per entry, for the
 // complement identity of lbfgsx_b_gram_fused_dd.
-__global__ void __launch_bounds__(kBlock) k_gram_finish(const double* __restrict__ partial, int nblocks,
+static __global__ void __launch_bounds__(kBlock) k_gram_finish(const double* __restrict__ partial, int nblocks,
                                                         double* __restrict__ out, int final, double* __restrict__ out_dd = nullptr,
                                                         unsigned long long* done = nullptr, unsigned long long seq = 0)
 {

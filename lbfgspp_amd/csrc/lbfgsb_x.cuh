@@ -1,0 +1,1014 @@
+// lbfgspp_amd/csrc/lbfgsb_x.cuh -- the passes of the L-BFGS-B subspace minimisation for ANY history length (2c <= 80
+// columns): a row's columns are split over G lanes of a wavefront.
+//
+// The round-3 kernels of these passes (k_vrows, k_solve_sweep, k_multidot2_wf, ... in lbfgsb_kernels.cuh) give a lane one
+// row with all of its 2c column values and 2c + 1 double-double accumulators in registers: 165 VGPRs at 2c = 20, i.e. two
+// waves per SIMD, which do not hide the ~300 dependent f64 operations of a row behind the other wave's loads (they ran at
+// 4.1-5.0 TB/s where the same loads alone reach 5.9-6.0), one wave per SIMD from 2c = 24, and no kernel at all beyond
+// 2c = 32 -- so that m = 12 ran at 0.6 and m = 16 / 20 at 0.12 of the m = 10 rate.  The reference is generic in m
+// (BFGSMat.h:529-565, SubspaceMin.h:183-273).
+//
+// Here lane l of a wavefront holds columns [g * NCL, (g + 1) * NCL) of row `base + l % (64 / G)`, g = l / (64 / G):
+// NCL = 8..20 column values and NCL + 1 accumulators per lane whatever 2c is, 3-4 waves per SIMD.  Every load of a row is
+// still issued unconditionally and up front.  Loads stay coalesced: the lanes of a group read 64 / G consecutive rows of
+// one column (256 / 128 bytes at G = 2 / 4).  What a row needs from all of its columns --
+//   * the left-to-right sum (W coef)(row) of the prologue statements and of the solve (the reference accumulates short
+//     products sequentially in plain T), and
+//   * a value every lane of the row must have (v = -rhs after the prologue, y after the solve)
+// -- travels by cross-lane moves: chain_x() adds the groups' terms in column order (group g starts from the partial of
+// group g - 1: the same additions in the same order as one lane walking all 2c columns) and hands every lane the total.
+// The dots end in grid_reduce_x (reduce_x.cuh): NL sums per lane reduced over the lanes of their group only.
+// Results: the same statements, the same correctly rounded sums in another order -- bit-identical to the one-lane
+// kernels, which the tests keep as the reference (LBFGSX_SPLIT=0).
+#pragma once
+#include "lbfgsb_kernels.cuh"
+#include "reduce_x.cuh"
+
+namespace lbfgsx {
+
+constexpr int kColsX = 80;  // 2c <= 80: every m an L-BFGS-B context accepts
+
+template <class T>
+struct ColsX
+{
+    const T* p[kColsX];  // logical order (Y slots, then S slots); entries from 2c on repeat column 0 (valid memory)
+};
+template <class T>
+struct ProX  // GramPrologue for 2c <= 80
+{
+    int mode, use1, use2;
+    T c1[kColsX], c2[kColsX];
+};
+template <class T>
+struct CoefX
+{
+    T c[kColsX];
+};
+template <class T>
+struct RowsX
+{
+    const int* in_idx;     // the columns are the compact copy: row t of the columns is row in_idx[t] of the vectors (null: identity)
+    int fresh_a, fresh_b;  // with dst_a: the two columns add_correction has replaced since the copy was written ...
+    const T *src_a, *src_b;  // ... are read from the full-length columns at the row
+    T *dst_a, *dst_b;        // ... and written to the copy at every position
+};
+
+// Blocks per CU the kernels are compiled for.  Registers: NCL column values, NCL column pointers and NA (NCL + 1) (rows) /
+// NCL + 7 (solve-sweep) / 2 NCL (two-dot passes) double-double accumulators of four registers each; the bound is the
+// largest that compiles without scratch memory (-Rpass-analysis=kernel-resource-usage), LBFGSX_X_OCC_* override it for A/B.
+#ifndef LBFGSX_X_OCC_ROWS
+#define LBFGSX_X_OCC_ROWS 0
+#endif
+#ifndef LBFGSX_X_OCC_SWEEP
+#define LBFGSX_X_OCC_SWEEP 0
+#endif
+constexpr int occ_rows_x(int ncl, int g, int na)
+{
+    return (LBFGSX_X_OCC_ROWS > 0 && na == 1 && ncl <= 12) ? LBFGSX_X_OCC_ROWS
+           : na == 1 ? (ncl <= 8 ? 4 : (ncl == 10 && g == 2) ? 4 : ncl <= 12 ? 3 : 2)
+                     : (ncl <= 4 ? 4 : ncl <= 12 ? 2 : 1);
+}
+constexpr int occ_sweep_x(int ncl, int g, int first)
+{
+    return (LBFGSX_X_OCC_SWEEP > 0 && ncl <= 12) ? LBFGSX_X_OCC_SWEEP
+           : first ? (ncl <= 15 ? 4 : 3) : (ncl <= 4 ? 4 : ncl <= 12 ? 3 : 2);
+}
+constexpr int occ_dots_x(int ncl) { return ncl <= 8 ? 4 : ncl <= 10 ? 3 : ncl <= 12 ? 2 : 1; }   // 2 NCL accumulators
+constexpr int occ_mask_x(int ncl) { return ncl <= 12 ? 4 : ncl <= 15 ? 3 : 2; }                    // NCL + 1
+
+template <int G>
+struct LaneX
+{
+    static constexpr int RPW = 64 / G;  // rows per wavefront and trip
+    int lane, g, rr, wave;
+    __device__ __forceinline__ LaneX()
+    {
+        lane = threadIdx.x & 63;
+        g = lane / RPW;
+        rr = lane % RPW;
+        wave = threadIdx.x >> 6;
+    }
+    __device__ __forceinline__ bool last() const { return g == G - 1; }
+};
+
+// a = 0; for every column j of the row in order: a = a + term_j -- the terms of this lane's columns in p[], `okm` bit k
+// set when column g * NCL + k exists.  Every lane of the row gets the total.
+template <class T, int NCL, int G>
+__device__ __forceinline__ T chain_x(const T (&p)[NCL], unsigned okm, const LaneX<G>& L)
+{
+    T x = T(0);
+#pragma unroll
+    for (int round = 0; round < G; round++)
+    {
+        // group `round` continues from the partial of the group before it; what the other groups compute is dropped
+        if (round > 0)
+            x = __shfl_up(x, LaneX<G>::RPW, 64);
+#pragma unroll
+        for (int k = 0; k < NCL; k++)
+        {
+            const T y = x + p[k];
+            x = ((okm >> k) & 1u) ? y : x;
+        }
+    }
+    return __shfl(x, (G - 1) * LaneX<G>::RPW + L.rr, 64);
+}
+
+// this lane's column pointers (kColsX entries in LDS) and the mask of the columns that exist
+template <class T, int NCL, int G>
+__device__ __forceinline__ unsigned lane_cols_x(const T* const* s_col, int ncols, const LaneX<G>& L, const T* (&cp)[NCL])
+{
+    unsigned okm = 0;
+#pragma unroll
+    for (int k = 0; k < NCL; k++)
+    {
+        const int ci = L.g * NCL + k;
+        cp[k] = s_col[ci];
+        okm |= (ci < ncols) ? (1u << k) : 0u;
+    }
+    return okm;
+}
+
+// ---------------------------------------------------------------- the v row (NA = 1) or the v row and the rows of two columns
+// (NA = 3) of the masked Gram: k_vrows for 2c <= 80.  Statements and outputs as there (lbfgsb_kernels.cuh); the rounded
+// sums land in out[a * (ncols + 1) + j] (a = 0: v row with (v, v) at j = ncols; a = 1, 2: columns col_a, col_b), the
+// (hi, lo) pairs in out_dd at twice that index.
+template <class T, int NCL, int G, int NA>
+__global__ void __launch_bounds__(kBlock, occ_rows_x(NCL, G, NA))
+    kx_rows(ColsX<T> cols, int ncols, BVecs<T> b, int vsel_id, int mask, int64_t n, RedWsX ws, double* __restrict__ out,
+            double* __restrict__ out_dd, ProX<T> pro, RowsX<T> gr, int col_a, int col_b)
+{
+    typedef typename AccOf<T>::type A;
+    constexpr int RPW = 64 / G, NP = NCL + 1, NL = NA * NP;
+    static_assert(NCL * G <= kColsX, "a class holds at most kColsX columns");
+    __shared__ const T* s_col[kColsX];
+    __shared__ T s_c1[kColsX], s_c2[kColsX];
+    if (threadIdx.x < kColsX)
+    {
+        s_col[threadIdx.x] = cols.p[threadIdx.x];
+        s_c1[threadIdx.x] = pro.c1[threadIdx.x];
+        s_c2[threadIdx.x] = pro.c2[threadIdx.x];
+    }
+    __syncthreads();
+    const LaneX<G> L;
+    const T* cp[NCL];
+    const unsigned okm = lane_cols_x<T, NCL, G>(s_col, ncols, L, cp);
+    Accs<A, NL> accs;
+    A(&acc)[NL] = accs.v;
+    // the vectors a row reads, as pointers fixed for the launch (a vector a mode does not use is a valid stand-in)
+    const T* pre_p = pro.mode == GP_LINEAR ? b.g : b.rhs;
+    const T* va_p;
+    const T* vb_p;
+    int vkind;  // 0: v = a, 1: v = -a, 2: v = a - b
+    switch (vsel_id)
+    {
+    case VS_DRT: va_p = b.drt; vb_p = b.drt; vkind = 0; break;
+    case VS_NEG_CF: va_p = b.cF; vb_p = b.cF; vkind = 1; break;
+    case VS_NEG_RHS: va_p = b.rhs; vb_p = b.rhs; vkind = 1; break;
+    case VS_LBOUND: va_p = b.lb; vb_p = b.x0; vkind = 2; break;
+    case VS_UBOUND: va_p = b.ub; vb_p = b.x0; vkind = 2; break;
+    default: va_p = b.y; vb_p = b.y; vkind = 0; break;
+    }
+    const bool patch = gr.dst_a != nullptr;
+    const T* fa_p = patch ? gr.src_a : b.rhs;
+    const T* fb_p = patch ? gr.src_b : b.rhs;
+    const T* xa_p = s_col[(NA > 1 && col_a >= 0) ? col_a : 0];
+    const T* xb_p = s_col[(NA > 1 && col_b >= 0) ? col_b : 0];
+    const int64_t stride = int64_t(gridDim.x) * kWaves * RPW;
+    const int64_t last = n - 1;
+    for (int64_t base = (int64_t(blockIdx.x) * kWaves + L.wave) * RPW; base < n; base += stride)
+    {
+        const int64_t t = base + L.rr;
+        const bool inb = t < n;
+        const int64_t tc = inb ? t : last;  // clamped: loaded again, dropped
+        int64_t r = tc;
+        if (gr.in_idx)
+            r = gr.in_idx[tc];
+        // every load of the row, up front
+        const unsigned char st = b.st[r];
+        const T pre = pre_p[r], va = va_p[r], vb = vb_p[r];
+        T fa = fa_p[r], fb = fb_p[r];
+        T row[NCL];
+#pragma unroll
+        for (int k = 0; k < NCL; k++)
+            row[k] = cp[k][tc];
+        T xa = T(0), xb = T(0);
+        if (NA > 1)
+        {
+            xa = xa_p[tc];
+            xb = xb_p[tc];
+        }
+        if (patch)  // every position of the kept copy gets the two replaced columns, kept or not
+        {
+            if (inb && L.g == 0)
+            {
+                gr.dst_a[t] = fa;
+                gr.dst_b[t] = fb;
+            }
+#pragma unroll
+            for (int k = 0; k < NCL; k++)
+            {
+                const int ci = L.g * NCL + k;
+                row[k] = (ci == gr.fresh_a) ? fa : (ci == gr.fresh_b) ? fb : row[k];
+            }
+            if (NA > 1)
+            {
+                xa = (col_a == gr.fresh_a) ? fa : (col_a == gr.fresh_b) ? fb : xa;
+                xb = (col_b == gr.fresh_a) ? fa : (col_b == gr.fresh_b) ? fb : xb;
+            }
+        }
+        const bool keep = inb && (!mask || (st & mask));
+        T v = vkind == 0 ? va : vkind == 1 ? -va : va - vb;
+        if (pro.mode != GP_NONE)
+        {
+            // (W * coef)(row): columns in order, plain accumulation -- the statement k_wcombine evaluates
+            T a1 = T(0), a2 = T(0);
+            if (pro.use1)
+            {
+                T p[NCL];
+#pragma unroll
+                for (int k = 0; k < NCL; k++)
+                    p[k] = row[k] * s_c1[L.g * NCL + k];
+                a1 = chain_x<T, NCL, G>(p, okm, L);
+            }
+            if (pro.use2)
+            {
+                T p[NCL];
+#pragma unroll
+                for (int k = 0; k < NCL; k++)
+                    p[k] = row[k] * s_c2[L.g * NCL + k];
+                a2 = chain_x<T, NCL, G>(p, okm, L);
+            }
+            if (pro.mode == GP_RHS)
+            {
+                T rh = pre;
+                if (pro.use1)
+                    rh = rh + (-a1);
+                if (pro.use2)
+                    rh = rh + (-a2);
+                if (keep && L.last())
+                    b.rhs[r] = rh;
+                if (vsel_id == VS_NEG_RHS)  // v is read from the vector just written
+                    v = -rh;
+            }
+            else
+            {
+                const T cf = (pro.use1 ? (T(-1) * a1) : T(0)) + pre;
+                if (keep && L.last())
+                    b.cF[r] = cf;
+                if (vsel_id == VS_NEG_CF)
+                    v = -cf;
+            }
+        }
+        if (keep)
+        {
+#pragma unroll
+            for (int k = 0; k < NCL; k++)
+            {
+                acc[k].add_prod(v, row[k]);
+                if (NA > 1)
+                {
+                    acc[NP + k].add_prod(xa, row[k]);
+                    acc[2 * NP + k].add_prod(xb, row[k]);
+                }
+            }
+            acc[NCL].add_prod(v, v);
+        }
+    }
+    A mine;
+    if (grid_reduce_x<NL, G, A>(acc, ws, mine))
+    {
+        const int s = threadIdx.x;
+        if (s < G * NL)
+        {
+            const int gg = s / NL, rem = s % NL, a = rem / NP, k = rem % NP;
+            int idx = -1;
+            if (k < NCL)
+            {
+                const int col = gg * NCL + k;
+                if (col < ncols)
+                    idx = a * (ncols + 1) + col;
+            }
+            else if (gg == 0 && a == 0)
+                idx = ncols;
+            if (idx >= 0)
+            {
+                out[idx] = mine.value();
+                if (out_dd)
+                {
+                    out_dd[2 * idx] = mine.hi;
+                    out_dd[2 * idx + 1] = acc_lo(mine);
+                }
+                __threadfence_system();
+            }
+        }
+        __syncthreads();
+        if (s == 0)
+            wsx_signal(ws);
+    }
+}
+
+// ---------------------------------------------------------------- the solve of a BOXCQP sweep and the sweep's statements on the
+// rows it writes: k_solve_sweep for 2c <= 80 (statements, compact-vector modes `cv` and outputs as there).
+// out = {dots[ncols] (FIRST = 0 only), the 7 sums of k_sub_sweep_begin}
+template <class T, int NCL, int G, int FIRST>
+__global__ void __launch_bounds__(kBlock, occ_sweep_x(NCL, G, FIRST))
+    kx_solve_sweep(ColsX<T> cols, int ncols, BVecs<T> b, BVecs<T> bw, int vsel_id, CoefX<T> coef, int has_w, T theta, int64_t n,
+                   RedWsX ws, double* __restrict__ out, int* __restrict__ lu_list, unsigned* __restrict__ lu_cnt, unsigned lu_cap,
+                   const int* __restrict__ ridx, T* __restrict__ cli, T* __restrict__ cui, int cv)
+{
+    typedef typename AccOf<T>::type A;
+    constexpr int RPW = 64 / G, ND = FIRST ? 0 : NCL, NL = ND + 7;
+    __shared__ const T* s_col[kColsX];
+    __shared__ T sc[kColsX];
+    if (threadIdx.x < kColsX)
+    {
+        s_col[threadIdx.x] = cols.p[threadIdx.x];
+        sc[threadIdx.x] = coef.c[threadIdx.x];
+    }
+    __syncthreads();
+    const LaneX<G> L;
+    const T* cp[NCL];
+    const unsigned okm = lane_cols_x<T, NCL, G>(s_col, ncols, L, cp);
+    const T theta2 = theta * theta;
+    const T* va_p;
+    const T* vb_p;
+    int vkind;
+    switch (vsel_id)
+    {
+    case VS_DRT: va_p = b.drt; vb_p = b.drt; vkind = 0; break;
+    case VS_NEG_CF: va_p = b.cF; vb_p = b.cF; vkind = 1; break;
+    case VS_NEG_RHS: va_p = b.rhs; vb_p = b.rhs; vkind = 1; break;
+    case VS_LBOUND: va_p = b.lb; vb_p = b.x0; vkind = 2; break;
+    case VS_UBOUND: va_p = b.ub; vb_p = b.x0; vkind = 2; break;
+    default: va_p = b.y; vb_p = b.y; vkind = 0; break;
+    }
+    const bool cvt = cv == 2;
+    const T* la_p = cvt ? cli : b.lb;
+    const T* ua_p = cvt ? cui : b.ub;
+    const T* x0_p = cvt ? cli : b.x0;  // by position nothing is subtracted: a stand-in that is loaded anyway
+    Accs<A, NL> accs;
+    A(&acc)[NL] = accs.v;
+    unsigned cnt[7] = {0, 0, 0, 0, 0, 0, 0};
+    const int64_t stride = int64_t(gridDim.x) * kWaves * RPW;
+    const int64_t last = n - 1;
+    for (int64_t base = (int64_t(blockIdx.x) * kWaves + L.wave) * RPW; base < n; base += stride)
+    {
+        const int64_t t = base + L.rr;
+        const bool inb = t < n;
+        const int64_t tc = inb ? t : last;
+        int64_t i = tc;
+        if (ridx && !cvt)
+            i = ridx[tc];
+        const int64_t ir = cvt ? tc : i;  // where this pass reads the vectors of the row
+        const int64_t iw = cv ? tc : i;   // ... and writes them
+        const unsigned char st0 = b.st[ir];
+        T w[NCL];
+#pragma unroll
+        for (int k = 0; k < NCL; k++)
+            w[k] = cp[k][tc];
+        const T xa = va_p[ir], xb = vb_p[ir];
+        const T yold = FIRST ? T(0) : b.y[ir];
+        const T la = la_p[ir], ua = ua_p[ir], x0i = x0_p[ir], cfi = b.cF[ir];
+        const T li = cvt ? la : la - x0i, ui = cvt ? ua : ua - x0i;
+        const bool mine = inb && L.last();  // the lane that writes the row's vectors
+        if (cv == 1 && mine)  // every position gets its constants, free or not
+        {
+            cli[t] = li;
+            cui[t] = ui;
+            bw.cF[t] = cfi;
+            if (!(st0 & ST_FREE))
+                bw.st[t] = st0;
+        }
+        const bool fr = inb && (st0 & ST_FREE);
+        const bool solve = fr && (FIRST || (st0 & ST_P));
+        T a = T(0);
+        if (has_w)
+        {
+            T p[NCL];
+#pragma unroll
+            for (int k = 0; k < NCL; k++)
+                p[k] = w[k] * sc[L.g * NCL + k];
+            a = chain_x<T, NCL, G>(p, okm, L);
+        }
+        const T v = vkind == 0 ? xa : vkind == 1 ? -xa : xa - xb;
+        const T ynew = has_w ? (v / theta + a / theta2) : (v / theta);
+        const T yi = solve ? ynew : yold;
+        if (solve && L.last())
+            bw.y[iw] = yi;
+        if (!FIRST && fr)
+        {
+#pragma unroll
+            for (int k = 0; k < NCL; k++)
+                acc[k].add_prod(w[k], yi);
+        }
+        bool app = false;
+        if (solve && L.last())
+        {
+            // a P row's multipliers are zero (the sweep that made it P stored them); the first sweep sets them
+            const unsigned char s2 = sweep_row_v<T>(bw, iw, st0, yi, T(0), T(0), FIRST != 0, FIRST != 0, cnt, li, ui, cfi);
+            app = (s2 & (ST_L | ST_U)) != 0;
+        }
+        if (lu_cap)
+        {
+            int64_t irow = i;
+            if (cvt && app)
+                irow = ridx[tc];  // the list holds rows
+            lu_append(app, irow, lu_list, lu_cnt, lu_cap);
+        }
+    }
+    sweep_counts<T, A>(cnt, acc + ND);
+    A tot;
+    if (grid_reduce_x<NL, G, A>(acc, ws, tot))
+    {
+        const int s = threadIdx.x;
+        if (s < G * NL)
+        {
+            const int gg = s / NL, k = s % NL;
+            if (k < ND)
+            {
+                const int col = gg * NCL + k;
+                if (col < ncols)
+                {
+                    out[col] = double(T(tot.value()));
+                    __threadfence_system();
+                }
+            }
+            else if (gg == G - 1)
+            {
+                out[(FIRST ? 0 : ncols) + (k - ND)] = tot.value();
+                __threadfence_system();
+            }
+        }
+        if (s == 0 && FIRST)
+            __hip_atomic_store(lu_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (s == 0)
+            wsx_signal(ws);
+    }
+}
+
+// ---------------------------------------------------------------- S's_new / s_new.y_j and p = W'd in one pass over the kept compact
+// copy and the short list of rows outside it: k_multidot2_wf for 2c <= 80.  out[j] = col_j . s_new, out[ncols + j] = col_j . d
+template <class T, int NCL, int G>
+__global__ void __launch_bounds__(kBlock, occ_dots_x(NCL))
+    kx_multidot2_wf(ColsX<T> wfc, int ncols, int fresh_a, int fresh_b, const T* __restrict__ snew, const T* __restrict__ ynew,
+                    const T* __restrict__ dvec, const int* __restrict__ idx, int64_t npos, ColsX<T> full,
+                    const int* __restrict__ list, int nlist, RedWsX ws, double* __restrict__ out)
+{
+    typedef typename AccOf<T>::type A;
+    constexpr int RPW = 64 / G, NL = 2 * NCL;
+    __shared__ const T* s_col[kColsX];
+    __shared__ const T* s_full[kColsX];
+    if (threadIdx.x < kColsX)
+    {
+        s_col[threadIdx.x] = wfc.p[threadIdx.x];
+        s_full[threadIdx.x] = full.p[threadIdx.x];
+    }
+    __syncthreads();
+    const LaneX<G> L;
+    Accs<A, NL> accs;
+    A(&acc)[NL] = accs.v;
+    const int64_t stride = int64_t(gridDim.x) * kWaves * RPW;
+    if (npos > 0)
+    {
+        const T* cp[NCL];
+        (void) lane_cols_x<T, NCL, G>(s_col, ncols, L, cp);
+        const int64_t last = npos - 1;
+        for (int64_t base = (int64_t(blockIdx.x) * kWaves + L.wave) * RPW; base < npos; base += stride)
+        {
+            const int64_t t = base + L.rr;
+            const bool inb = t < npos;
+            const int64_t tc = inb ? t : last;
+            const int64_t r = idx[tc];
+            const T a = snew[r], y = ynew[r], d = dvec[r];
+            T w[NCL];
+#pragma unroll
+            for (int k = 0; k < NCL; k++)
+                w[k] = cp[k][tc];
+            if (inb)
+            {
+#pragma unroll
+                for (int k = 0; k < NCL; k++)
+                {
+                    const int ci = L.g * NCL + k;
+                    const T wk = (ci == fresh_a) ? y : (ci == fresh_b) ? a : w[k];
+                    acc[k].add_prod(wk, a);
+                    acc[NCL + k].add_prod(wk, d);
+                }
+            }
+        }
+    }
+    if (nlist > 0)
+    {
+        // the rows outside the copy: all columns at the row, from the full-length arrays (which hold the new pair)
+        const T* cp[NCL];
+        (void) lane_cols_x<T, NCL, G>(s_full, ncols, L, cp);
+        const int64_t last = nlist - 1;
+        for (int64_t base = (int64_t(blockIdx.x) * kWaves + L.wave) * RPW; base < int64_t(nlist); base += stride)
+        {
+            const int64_t e = base + L.rr;
+            const bool inb = e < int64_t(nlist);
+            const int64_t r = list[inb ? e : last];
+            const T a = snew[r], d = dvec[r];
+            T w[NCL];
+#pragma unroll
+            for (int k = 0; k < NCL; k++)
+                w[k] = cp[k][r];
+            if (inb)
+            {
+#pragma unroll
+                for (int k = 0; k < NCL; k++)
+                {
+                    acc[k].add_prod(w[k], a);
+                    acc[NCL + k].add_prod(w[k], d);
+                }
+            }
+        }
+    }
+    A tot;
+    if (grid_reduce_x<NL, G, A>(acc, ws, tot))
+    {
+        const int s = threadIdx.x;
+        if (s < G * NL)
+        {
+            const int gg = s / NL, rem = s % NL, which = rem / NCL, k = rem % NCL, col = gg * NCL + k;
+            if (col < ncols)
+            {
+                out[which * ncols + col] = double(T(tot.value()));
+                __threadfence_system();
+            }
+        }
+        __syncthreads();
+        if (s == 0)
+            wsx_signal(ws);
+    }
+}
+
+// ---------------------------------------------------------------- the same two dots over the full-length columns (no kept copy):
+// k_multidot2_all for 2c <= 80
+template <class T, int NCL, int G>
+__global__ void __launch_bounds__(kBlock, occ_dots_x(NCL))
+    kx_multidot2(ColsX<T> cols, int ncols, const T* __restrict__ v1, const T* __restrict__ v2, int64_t n, RedWsX ws,
+                 double* __restrict__ out)
+{
+    typedef typename AccOf<T>::type A;
+    constexpr int RPW = 64 / G, NL = 2 * NCL;
+    __shared__ const T* s_col[kColsX];
+    if (threadIdx.x < kColsX)
+        s_col[threadIdx.x] = cols.p[threadIdx.x];
+    __syncthreads();
+    const LaneX<G> L;
+    const T* cp[NCL];
+    (void) lane_cols_x<T, NCL, G>(s_col, ncols, L, cp);
+    Accs<A, NL> accs;
+    A(&acc)[NL] = accs.v;
+    const int64_t stride = int64_t(gridDim.x) * kWaves * RPW;
+    const int64_t last = n - 1;
+    for (int64_t base = (int64_t(blockIdx.x) * kWaves + L.wave) * RPW; base < n; base += stride)
+    {
+        const int64_t t = base + L.rr;
+        const bool inb = t < n;
+        const int64_t tc = inb ? t : last;
+        const T a = v1[tc], d = v2[tc];
+        T w[NCL];
+#pragma unroll
+        for (int k = 0; k < NCL; k++)
+            w[k] = cp[k][tc];
+        if (inb && (a != T(0) || d != T(0)))   // a row where both are zero adds exact zeros to every sum
+        {
+#pragma unroll
+            for (int k = 0; k < NCL; k++)
+            {
+                acc[k].add_prod(w[k], a);
+                acc[NCL + k].add_prod(w[k], d);
+            }
+        }
+    }
+    A tot;
+    if (grid_reduce_x<NL, G, A>(acc, ws, tot))
+    {
+        const int s = threadIdx.x;
+        if (s < G * NL)
+        {
+            const int gg = s / NL, rem = s % NL, which = rem / NCL, k = rem % NCL, col = gg * NCL + k;
+            if (col < ncols)
+            {
+                out[which * ncols + col] = double(T(tot.value()));
+                __threadfence_system();
+            }
+        }
+        __syncthreads();
+        if (s == 0)
+            wsx_signal(ws);
+    }
+}
+
+// ---------------------------------------------------------------- W_L' l and W_U' u over the index list of L u U: k_multidot_list2 for
+// 2c <= 80.  out = {L dots [ncols], nnz_L, U dots [ncols], nnz_U}
+template <class T, int NCL, int G>
+__global__ void __launch_bounds__(kBlock, occ_dots_x(NCL))
+    kx_list2(ColsX<T> cols, int ncols, BVecs<T> b, const int* __restrict__ list, int nlist, RedWsX ws, double* __restrict__ out,
+             const unsigned char* __restrict__ stc, const int* __restrict__ pos)
+{
+    typedef typename AccOf<T>::type A;
+    constexpr int RPW = 64 / G, NP = NCL + 1, NL = 2 * NP;
+    __shared__ const T* s_col[kColsX];
+    if (threadIdx.x < kColsX)
+        s_col[threadIdx.x] = cols.p[threadIdx.x];
+    __syncthreads();
+    const LaneX<G> L;
+    const T* cp[NCL];
+    (void) lane_cols_x<T, NCL, G>(s_col, ncols, L, cp);
+    Accs<A, NL> accs;
+    A(&acc)[NL] = accs.v;
+    const int64_t stride = int64_t(gridDim.x) * kWaves * RPW;
+    for (int64_t base = (int64_t(blockIdx.x) * kWaves + L.wave) * RPW; base < int64_t(nlist); base += stride)
+    {
+        const int64_t e = base + L.rr;
+        const bool inb = e < int64_t(nlist);
+        const int64_t i = list[inb ? e : int64_t(nlist) - 1];
+        const unsigned char st = stc ? stc[pos[i]] : b.st[i];
+        const T lo = b.lb[i], up = b.ub[i], x0 = b.x0[i];
+        T w[NCL];
+#pragma unroll
+        for (int k = 0; k < NCL; k++)
+            w[k] = cp[k][i];
+        if (!inb || !(st & (ST_L | ST_U)))
+            continue;
+        const bool isl = (st & ST_L) != 0;
+        const T v = isl ? lo - x0 : up - x0;
+        if (isl)
+        {
+            if (v != T(0))
+                acc[NCL].add(T(1));
+#pragma unroll
+            for (int k = 0; k < NCL; k++)
+                acc[k].add_prod(w[k], v);
+        }
+        else
+        {
+            if (v != T(0))
+                acc[NP + NCL].add(T(1));
+#pragma unroll
+            for (int k = 0; k < NCL; k++)
+                acc[NP + k].add_prod(w[k], v);
+        }
+    }
+    A tot;
+    if (grid_reduce_x<NL, G, A>(acc, ws, tot))
+    {
+        const int s = threadIdx.x;
+        if (s < G * NL)
+        {
+            const int gg = s / NL, rem = s % NL, which = rem / NP, k = rem % NP;
+            int idx = -1;
+            if (k < NCL)
+            {
+                const int col = gg * NCL + k;
+                if (col < ncols)
+                    idx = which * (ncols + 1) + col;
+            }
+            else if (gg == 0)
+                idx = which * (ncols + 1) + ncols;
+            if (idx >= 0)
+            {
+                out[idx] = double(T(tot.value()));
+                __threadfence_system();
+            }
+        }
+        __syncthreads();
+        if (s == 0)
+            wsx_signal(ws);
+    }
+}
+
+// ---------------------------------------------------------------- masked W'v over the full-length columns: k_multidot_all for 2c <= 80.
+// v = vcol when given, else vsel(b, vsel_id); out = {dots [ncols], nnz of v inside the mask}.  A wavefront first looks at
+// the state bytes of 256 rows (four coalesced byte loads); 64-row pieces without a row inside the mask cost nothing more --
+// the sets this serves (the newly active rows, L, U) hold 10^1..10^4 of 10^7 rows in steady state.
+template <class T, int NCL, int G>
+__global__ void __launch_bounds__(kBlock, occ_mask_x(NCL))
+    kx_multidot_mask(ColsX<T> cols, int ncols, BVecs<T> b, int vsel_id, const T* __restrict__ vcol, int mask, int64_t n,
+                     RedWsX ws, double* __restrict__ out)
+{
+    typedef typename AccOf<T>::type A;
+    constexpr int RPW = 64 / G, NL = NCL + 1;
+    __shared__ const T* s_col[kColsX];
+    if (threadIdx.x < kColsX)
+        s_col[threadIdx.x] = cols.p[threadIdx.x];
+    __syncthreads();
+    const LaneX<G> L;
+    const T* cp[NCL];
+    (void) lane_cols_x<T, NCL, G>(s_col, ncols, L, cp);
+    Accs<A, NL> accs;
+    A(&acc)[NL] = accs.v;
+    const int64_t stride = int64_t(gridDim.x) * kWaves * 256;
+    const int64_t last = n - 1;
+    for (int64_t base = (int64_t(blockIdx.x) * kWaves + L.wave) * 256; base < n; base += stride)
+    {
+        unsigned long long hit[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            const int64_t rq = base + q * 64 + L.lane;
+            const bool in = rq < n && (!mask || (b.st[rq < n ? rq : last] & mask));
+            hit[q] = __ballot(in);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            if (hit[q] == 0ull)
+                continue;
+            for (int sub = 0; sub < G; sub++)
+            {
+                const unsigned long long part = (G == 1) ? hit[q] : ((hit[q] >> (sub * RPW)) & ((1ull << (RPW % 64)) - 1ull));
+                if (part == 0ull)
+                    continue;
+                const int64_t t = base + q * 64 + sub * RPW + L.rr;
+                const bool in = (part >> L.rr) & 1ull;
+                const int64_t tc = t < n ? t : last;
+                const T v = vcol ? vcol[tc] : vsel(b, vsel_id, tc);
+                T w[NCL];
+#pragma unroll
+                for (int k = 0; k < NCL; k++)
+                    w[k] = cp[k][tc];
+                if (in)
+                {
+                    if (v != T(0))
+                        acc[NCL].add(T(1));
+#pragma unroll
+                    for (int k = 0; k < NCL; k++)
+                        acc[k].add_prod(w[k], v);
+                }
+            }
+        }
+    }
+    A tot;
+    if (grid_reduce_x<NL, G, A>(acc, ws, tot))
+    {
+        const int s = threadIdx.x;
+        if (s < G * NL)
+        {
+            const int gg = s / NL, k = s % NL;
+            int idx = -1;
+            if (k < NCL)
+            {
+                const int col = gg * NCL + k;
+                if (col < ncols)
+                    idx = col;
+            }
+            else if (gg == 0)
+                idx = ncols;
+            if (idx >= 0)
+            {
+                out[idx] = double(T(tot.value()));
+                __threadfence_system();
+            }
+        }
+        __syncthreads();
+        if (s == 0)
+            wsx_signal(ws);
+    }
+}
+
+// ---------------------------------------------------------------- the one-pass Gram of [Y_P S_P v] for 2c + 1 > 31 columns
+// (k_gram_dd serves up to 31: its wave-private tiles and its lane-per-entry tables stop there).  Same arithmetic -- every entry
+// a double-double sum of error-free products -- same staging outputs (GramRows: row lists, the compact copy of the free rows),
+// same prologue statements.  What differs is the distribution: the 64-row tile in LDS belongs to the BLOCK, wave w stages a
+// quarter of the columns (every lane one row, the rows outside the mask dropped by ballot / prefix compaction, the same in all
+// four waves), and the (2c + 1)(2c + 2) / 2 entries are spread over all 256 threads, KPB per thread, so that no two threads
+// hold the same entry: the block's partial sums are stored as they are, no block reduction.  partial[block][KPB * 256][2];
+// kx_gram_finish adds the blocks.  Work ~ (2c + 1)^2 / 2 double-double products per kept row: VALU-bound (1.1 ms at 2c = 40,
+// 5 x 10^6 rows); in steady state W_F'W_F is carried between iterations (BFGSMatB::carried_gram) and this pass runs once in 32.
+template <class T, int KPB>
+__global__ void __launch_bounds__(kBlock)
+    kx_gram(ColsX<T> cols, int ncols, BVecs<T> b, int vsel_id, int mask, int64_t n, double* __restrict__ partial, ProX<T> pro,
+            GramRows<T> gr, int cs)
+{
+    extern __shared__ double tile[];  // [64][cs], then the rows' numbers
+    __shared__ T pc1[kColsX], pc2[kColsX];
+    __shared__ const T* s_col[kColsX];
+    int* s_rid = reinterpret_cast<int*>(tile + 64 * cs);
+    if (threadIdx.x < kColsX)
+    {
+        pc1[threadIdx.x] = pro.c1[threadIdx.x];
+        pc2[threadIdx.x] = pro.c2[threadIdx.x];
+        s_col[threadIdx.x] = cols.p[threadIdx.x];
+    }
+    __syncthreads();
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ntot = ncols + (vsel_id >= 0 ? 1 : 0);
+    const int npairs = ntot * (ntot + 1) / 2;
+    int pi[KPB], pj[KPB];
+#pragma unroll
+    for (int k = 0; k < KPB; k++)
+    {
+        int e = tid * KPB + k;
+        if (e >= npairs)
+            e = 0;  // idle slot: accumulates G(0,0) again, never read back
+        int I = 0;
+        while ((I + 1) * (I + 2) / 2 <= e)
+            I++;
+        pi[k] = I;
+        pj[k] = e - I * (I + 1) / 2;
+    }
+    DD acc0[KPB], acc1[KPB];
+    const int cq = (ncols + kWaves - 1) / kWaves, c_lo = wv * cq, c_hi = (c_lo + cq < ncols) ? c_lo + cq : ncols;
+    const int64_t nbatch = (n + 63) / 64;
+    for (int64_t bt = blockIdx.x; bt < nbatch; bt += gridDim.x)
+    {
+        const int64_t rt = bt * 64 + lane;  // row of the columns
+        unsigned char st = 0;
+        if (mask && rt < n)
+        {
+            const int64_t rw = gr.in_idx ? int64_t(gr.in_idx[rt]) : rt;
+            st = gr.st_alt ? gr.st_alt[gr.st_pos[rw]] : b.st[rw];
+        }
+        const bool keep = rt < n && (!mask || (st & mask));
+        const unsigned long long bal = __ballot(keep);  // the same in all four waves: they look at the same rows
+        const int cnt = __popcll(bal);
+        if (cnt == 0)
+            continue;
+        const int pos = __popcll(bal & ((1ull << lane) - 1ull));
+        if (keep)
+        {
+            const int64_t r = gr.in_idx ? int64_t(gr.in_idx[rt]) : rt;  // row of the vectors
+            const int64_t wr = gr.w_by_row ? r : rt;                    // row of the columns
+            double* row = tile + pos * cs;
+            const int64_t ot = gr.out_w ? int64_t(gr.out_base[bt]) + pos : 0;
+            if (wv == 0)
+            {
+                s_rid[pos] = int(r);
+                if (gr.out_w)
+                {
+                    gr.out_idx[ot] = int(r);
+                    if (gr.out_pos)
+                        gr.out_pos[r] = int(ot);
+                }
+                if (pro.mode == GP_NONE && vsel_id >= 0)
+                    row[ncols] = double(vsel(b, vsel_id, r));
+            }
+            for (int c0 = c_lo; c0 < c_hi; c0 += 8)
+            {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    v[u] = (c0 + u < c_hi) ? double(s_col[c0 + u][wr]) : 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (c0 + u < c_hi)
+                    {
+                        row[c0 + u] = v[u];
+                        if (gr.out_w)
+                            gr.out_w[int64_t(c0 + u) * gr.out_ld + ot] = T(v[u]);
+                    }
+            }
+        }
+        __syncthreads();
+        if (pro.mode != GP_NONE)
+        {
+            if (wv == 0 && lane < cnt)
+            {
+                // (W * coef)(row): columns in order, plain accumulation -- the statement k_wcombine evaluates
+                double* row = tile + lane * cs;
+                const int64_t r = s_rid[lane];
+                T a1 = T(0), a2 = T(0);
+                if (pro.use1)
+                    for (int j = 0; j < ncols; j++)
+                        a1 = a1 + T(row[j]) * pc1[j];
+                if (pro.use2)
+                    for (int j = 0; j < ncols; j++)
+                        a2 = a2 + T(row[j]) * pc2[j];
+                if (pro.mode == GP_RHS)
+                {
+                    T rh = b.rhs[r];
+                    if (pro.use1)
+                        rh = rh + (-a1);
+                    if (pro.use2)
+                        rh = rh + (-a2);
+                    b.rhs[r] = rh;
+                }
+                else
+                    b.cF[r] = (pro.use1 ? (T(-1) * a1) : T(0)) + b.g[r];
+                if (vsel_id >= 0)
+                    row[ncols] = double(vsel(b, vsel_id, r));
+            }
+            __syncthreads();
+        }
+        int rr = 0;
+        for (; rr + 1 < cnt; rr += 2)
+        {
+            const double* ra = tile + rr * cs;
+            const double* rb = ra + cs;
+#pragma unroll
+            for (int k = 0; k < KPB; k++)
+            {
+                acc0[k].add_prod(ra[pi[k]], ra[pj[k]]);
+                acc1[k].add_prod(rb[pi[k]], rb[pj[k]]);
+            }
+        }
+        if (rr < cnt)
+        {
+            const double* ra = tile + rr * cs;
+#pragma unroll
+            for (int k = 0; k < KPB; k++)
+                acc0[k].add_prod(ra[pi[k]], ra[pj[k]]);
+        }
+        __syncthreads();  // the tile is staged again
+    }
+    double* part = partial + size_t(blockIdx.x) * (KPB * 256) * 2;
+#pragma unroll
+    for (int k = 0; k < KPB; k++)
+    {
+        acc0[k].merge(acc1[k].hi, acc1[k].lo);
+        const int e = tid * KPB + k;
+        part[e * 2 + 0] = acc0[k].hi;
+        part[e * 2 + 1] = acc0[k].lo;
+    }
+}
+
+// Sum per-block partial tiles of kx_gram.  grid = (ntiles, nchunks): block (tb, ch) adds the partials of input blocks ch,
+// ch + nchunks, ... for its 256 entries.  final = 0: a double-double partial per chunk (second-level input); final = 1
+// (nchunks == 1): the rounded entries out[tb * 256 + e] and, with out_dd, the un-rounded (hi, lo) sums.
+static __global__ void __launch_bounds__(kBlock) kx_gram_finish(const double* __restrict__ partial, int nblocks, double* __restrict__ out,
+                                                         int final, double* __restrict__ out_dd, unsigned long long* done,
+                                                         unsigned long long seq, unsigned* __restrict__ ticket)
+{
+    const int tb = blockIdx.x, ntile = gridDim.x, ch = blockIdx.y, nch = gridDim.y, e = threadIdx.x;
+    DD t;
+    for (int bk = ch; bk < nblocks; bk += nch)
+    {
+        const double* p = partial + (size_t(bk) * ntile * 256 + size_t(tb) * 256 + e) * 2;
+        t.merge(p[0], p[1]);
+    }
+    if (final)
+    {
+        out[tb * 256 + e] = t.value();
+        if (out_dd)
+        {
+            out_dd[(tb * 256 + e) * 2 + 0] = t.hi;
+            out_dd[(tb * 256 + e) * 2 + 1] = t.lo;
+        }
+        if (done)  // completion word (RedWs::done): the last of the ntile blocks to finish publishes it
+        {
+            __threadfence_system();
+            __syncthreads();
+            if (e == 0)
+            {
+                bool lastb = true;
+                if (ntile > 1)
+                {
+                    const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                    lastb = (old == unsigned(ntile - 1));
+                    if (lastb)
+                        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (lastb)
+                    __hip_atomic_store(done, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+    else
+    {
+        double* q = out + (size_t(ch) * ntile * 256 + size_t(tb) * 256 + e) * 2;
+        q[0] = t.hi;
+        q[1] = t.lo;
+    }
+}
+
+// k_wf_append for 2c <= 80: rows that entered the free set and have no position in the kept compact copy are appended to it
+template <class T>
+__global__ void __launch_bounds__(kBlock) kx_wf_append(ColsX<T> orig, int ncols, T* __restrict__ wf, int64_t wf_ld,
+                                                       int* __restrict__ wf_idx, int* __restrict__ pos, const int* __restrict__ enter,
+                                                       unsigned* __restrict__ cnt, unsigned cap, unsigned wf_cap)
+{
+    __shared__ const T* s_col[kColsX];
+    if (threadIdx.x < kColsX)
+        s_col[threadIdx.x] = orig.p[threadIdx.x];
+    __syncthreads();
+    const unsigned ne = __hip_atomic_load(cnt + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ne > cap)
+    {
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            cnt[3] = 1u;
+        return;
+    }
+    for (unsigned e = blockIdx.x * kBlock + threadIdx.x; e < ne; e += gridDim.x * kBlock)
+    {
+        const int row = enter[e];
+        if (pos[row] >= 0)
+            continue;
+        const unsigned slot = atomicAdd(cnt + 2, 1u);
+        if (slot >= wf_cap)
+        {
+            cnt[3] = 1u;
+            continue;
+        }
+        wf_idx[slot] = row;
+        pos[row] = int(slot);
+        for (int k = 0; k < ncols; k++)
+            wf[int64_t(k) * wf_ld + slot] = s_col[k][row];
+    }
+}
+
+}  // namespace lbfgsx

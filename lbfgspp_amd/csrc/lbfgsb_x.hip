@@ -1,0 +1,218 @@
+// lbfgspp_amd/csrc/lbfgsb_x.hip -- instantiations and launchers of the m-generic L-BFGS-B passes (lbfgsb_x.cuh).
+#include <algorithm>
+
+#include "lbfgsb_x.hpp"
+
+namespace lbfgsx {
+namespace xl {
+
+// column classes: (NCL columns per lane, G lanes per row) for 2c <= NCL * G
+#define LBFGSX_XCLASS(ncols, CALL)             \
+    do                                         \
+    {                                          \
+        if ((ncols) <= 8) { CALL(4, 2); }      \
+        else if ((ncols) <= 16) { CALL(8, 2); }  \
+        else if ((ncols) <= 20) { CALL(10, 2); } \
+        else if ((ncols) <= 24) { CALL(12, 2); } \
+        else if ((ncols) <= 32) { CALL(8, 4); }  \
+        else if ((ncols) <= 40) { CALL(10, 4); } \
+        else if ((ncols) <= 60) { CALL(15, 4); } \
+        else { CALL(20, 4); }                  \
+    } while (0)
+
+static inline int grid_rows(int64_t n, int rpw, int per_cu, int num_cus)
+{
+    const int64_t per_block = int64_t(kWaves) * rpw;
+    const int64_t want = (n + per_block - 1) / per_block;
+    return int(std::max<int64_t>(1, std::min<int64_t>(want, std::min<int64_t>(int64_t(per_cu) * num_cus, kMaxGridX))));
+}
+
+template <class T>
+int rows(hipStream_t s, int num_cus, int na, const ColsX<T>& cols, int ncols, const BVecs<T>& b, int vsel_id, int mask, int64_t n,
+         const RedWsX& ws, double* out, double* out_dd, const ProX<T>& pro, const RowsX<T>& gr, int col_a, int col_b)
+{
+    if (ncols < 1 || ncols > kColsX || (na != 1 && na != 3))
+        return LBFGSX_E_INVALID;
+#define CALL(NCL, G)                                                                                                           \
+    if (na == 1)                                                                                                               \
+        LBFGSX_LAUNCH((kx_rows<T, NCL, G, 1>), dim3(grid_rows(n, 64 / G, occ_rows_x(NCL, G, 1), num_cus)), dim3(kBlock), 0, s, cols, ncols, \
+                      b, vsel_id, mask, n, ws, out, out_dd, pro, gr, col_a, col_b);                                            \
+    else                                                                                                                       \
+        LBFGSX_LAUNCH((kx_rows<T, NCL, G, 3>), dim3(grid_rows(n, 64 / G, occ_rows_x(NCL, G, 3), num_cus)), dim3(kBlock), 0, s, cols, ncols, \
+                      b, vsel_id, mask, n, ws, out, out_dd, pro, gr, col_a, col_b)
+    LBFGSX_XCLASS(ncols, CALL);
+#undef CALL
+    LBFGSX_HIP(hipGetLastError());
+    return LBFGSX_OK;
+}
+
+template <class T>
+int solve_sweep(hipStream_t s, int num_cus, int first, const ColsX<T>& cols, int ncols, const BVecs<T>& b, const BVecs<T>& bw,
+                int vsel_id, const CoefX<T>& coef, int has_w, T theta, int64_t n, const RedWsX& ws, double* out, int* lu_list,
+                unsigned* lu_cnt, unsigned lu_cap, const int* ridx, T* cli, T* cui, int cv)
+{
+    if (ncols < 1 || ncols > kColsX)
+        return LBFGSX_E_INVALID;
+#define CALL(NCL, G)                                                                                                              \
+    if (first)                                                                                                                    \
+        LBFGSX_LAUNCH((kx_solve_sweep<T, NCL, G, 1>), dim3(grid_rows(n, 64 / G, occ_sweep_x(NCL, G, 1), num_cus)), dim3(kBlock), 0, s, cols,    \
+                      ncols, b, bw, vsel_id, coef, has_w, theta, n, ws, out, lu_list, lu_cnt, lu_cap, ridx, cli, cui, cv);        \
+    else                                                                                                                          \
+        LBFGSX_LAUNCH((kx_solve_sweep<T, NCL, G, 0>), dim3(grid_rows(n, 64 / G, occ_sweep_x(NCL, G, 0), num_cus)), dim3(kBlock), 0, s, cols,    \
+                      ncols, b, bw, vsel_id, coef, has_w, theta, n, ws, out, lu_list, lu_cnt, lu_cap, ridx, cli, cui, cv)
+    LBFGSX_XCLASS(ncols, CALL);
+#undef CALL
+    LBFGSX_HIP(hipGetLastError());
+    return LBFGSX_OK;
+}
+
+template <class T>
+int multidot2_wf(hipStream_t s, int num_cus, const ColsX<T>& wfc, int ncols, int fresh_a, int fresh_b, const T* snew, const T* ynew,
+                 const T* dvec, const int* idx, int64_t npos, const ColsX<T>& full, const int* list, int nlist, const RedWsX& ws,
+                 double* out)
+{
+    if (ncols < 1 || ncols > kColsX)
+        return LBFGSX_E_INVALID;
+#define CALL(NCL, G)                                                                                                          \
+    LBFGSX_LAUNCH((kx_multidot2_wf<T, NCL, G>), dim3(grid_rows(std::max<int64_t>(npos, nlist), 64 / G, occ_dots_x(NCL), num_cus)),  \
+                  dim3(kBlock), 0, s, wfc, ncols, fresh_a, fresh_b, snew, ynew, dvec, idx, npos, full, list, nlist, ws, out)
+    LBFGSX_XCLASS(ncols, CALL);
+#undef CALL
+    LBFGSX_HIP(hipGetLastError());
+    return LBFGSX_OK;
+}
+
+template <class T>
+int multidot2(hipStream_t s, int num_cus, const ColsX<T>& cols, int ncols, const T* v1, const T* v2, int64_t n, const RedWsX& ws,
+              double* out)
+{
+    if (ncols < 1 || ncols > kColsX)
+        return LBFGSX_E_INVALID;
+#define CALL(NCL, G)                                                                                                        \
+    LBFGSX_LAUNCH((kx_multidot2<T, NCL, G>), dim3(grid_rows(n, 64 / G, occ_dots_x(NCL), num_cus)), dim3(kBlock), 0, s, cols, ncols, \
+                  v1, v2, n, ws, out)
+    LBFGSX_XCLASS(ncols, CALL);
+#undef CALL
+    LBFGSX_HIP(hipGetLastError());
+    return LBFGSX_OK;
+}
+
+template <class T>
+int list2(hipStream_t s, int num_cus, const ColsX<T>& cols, int ncols, const BVecs<T>& b, const int* list, int nlist, const RedWsX& ws,
+          double* out, const unsigned char* stc, const int* pos)
+{
+    if (ncols < 1 || ncols > kColsX)
+        return LBFGSX_E_INVALID;
+    // a short list: few blocks keep the reduction tail short
+#define CALL(NCL, G)                                                                                                      \
+    LBFGSX_LAUNCH((kx_list2<T, NCL, G>), dim3(std::min(32, grid_rows(nlist, 64 / G, 1, num_cus))), dim3(kBlock), 0, s, cols,   \
+                  ncols, b, list, nlist, ws, out, stc, pos)
+    LBFGSX_XCLASS(ncols, CALL);
+#undef CALL
+    LBFGSX_HIP(hipGetLastError());
+    return LBFGSX_OK;
+}
+
+template <class T>
+int multidot_mask(hipStream_t s, int num_cus, const ColsX<T>& cols, int ncols, const BVecs<T>& b, int vsel_id, const T* vcol, int mask,
+                  int64_t n, const RedWsX& ws, double* out)
+{
+    if (ncols < 1 || ncols > kColsX)
+        return LBFGSX_E_INVALID;
+    const int64_t want = (n + int64_t(kWaves) * 256 - 1) / (int64_t(kWaves) * 256);
+#define CALL(NCL, G)                                                                                                   \
+    LBFGSX_LAUNCH((kx_multidot_mask<T, NCL, G>),                                                                        \
+                  dim3(int(std::max<int64_t>(1, std::min<int64_t>(want, std::min(occ_mask_x(NCL) * num_cus, kMaxGridX))))), \
+                  dim3(kBlock), 0, s, cols, ncols, b, vsel_id, vcol, mask, n, ws, out)
+    LBFGSX_XCLASS(ncols, CALL);
+#undef CALL
+    LBFGSX_HIP(hipGetLastError());
+    return LBFGSX_OK;
+}
+
+template <class T>
+int wf_append(hipStream_t s, const ColsX<T>& orig, int ncols, T* wf, int64_t wf_ld, int* wf_idx, int* pos, const int* enter,
+              unsigned* cnt, unsigned cap, unsigned wf_cap)
+{
+    LBFGSX_LAUNCH((kx_wf_append<T>), dim3(16), dim3(kBlock), 0, s, orig, ncols, wf, wf_ld, wf_idx, pos, enter, cnt, cap, wf_cap);
+    LBFGSX_HIP(hipGetLastError());
+    return LBFGSX_OK;
+}
+
+int gram_kpb(int ntot)
+{
+    const int npairs = ntot * (ntot + 1) / 2;
+    const int kp = (npairs + 255) / 256;
+    return kp <= 3 ? 3 : kp <= 4 ? 4 : kp <= 6 ? 6 : kp <= 9 ? 9 : 13;
+}
+
+template <class T, int KPB>
+static int gram_kp(hipStream_t s, int max_blocks, const ColsX<T>& cols, int ncols, const BVecs<T>& b, int vsel_id, int mask,
+                   int64_t n, double* partial, const ProX<T>& pro, const GramRows<T>& gr)
+{
+    const int ntot = ncols + (vsel_id >= 0 ? 1 : 0);
+    const int cs = ntot | 1;  // odd row stride: the lanes of a wave that read one row hit distinct banks
+    const size_t lds = size_t(64) * size_t(cs) * sizeof(double) + 64 * sizeof(int);
+    if (lds > 48 * 1024)  // per device and cheap: not cached
+        (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kx_gram<T, KPB>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    const int64_t nbatch = (n + 63) / 64;
+    const int blocks = int(std::max<int64_t>(1, std::min<int64_t>(max_blocks, nbatch)));
+    LBFGSX_LAUNCH((kx_gram<T, KPB>), dim3(blocks), dim3(kBlock), lds, s, cols, ncols, b, vsel_id, mask, n, partial, pro, gr, cs);
+    if (hipGetLastError() != hipSuccess)
+        return -1;
+    return blocks;
+}
+
+template <class T>
+int gram(hipStream_t s, int max_blocks, const ColsX<T>& cols, int ncols, const BVecs<T>& b, int vsel_id, int mask, int64_t n,
+         double* partial, const ProX<T>& pro, const GramRows<T>& gr)
+{
+    if (ncols < 1 || ncols > kColsX)
+        return -1;
+    switch (gram_kpb(ncols + (vsel_id >= 0 ? 1 : 0)))
+    {
+    case 3: return gram_kp<T, 3>(s, max_blocks, cols, ncols, b, vsel_id, mask, n, partial, pro, gr);
+    case 4: return gram_kp<T, 4>(s, max_blocks, cols, ncols, b, vsel_id, mask, n, partial, pro, gr);
+    case 6: return gram_kp<T, 6>(s, max_blocks, cols, ncols, b, vsel_id, mask, n, partial, pro, gr);
+    case 9: return gram_kp<T, 9>(s, max_blocks, cols, ncols, b, vsel_id, mask, n, partial, pro, gr);
+    default: return gram_kp<T, 13>(s, max_blocks, cols, ncols, b, vsel_id, mask, n, partial, pro, gr);
+    }
+}
+
+int gram_finish(hipStream_t s, const double* partial, int blocks, int ntile, double* partial2, double* out, double* out_dd,
+                unsigned long long* done, unsigned long long seq, unsigned* ticket)
+{
+    const int nch = std::min(blocks, 32);
+    if (blocks > 1)
+    {
+        LBFGSX_LAUNCH(kx_gram_finish, dim3(ntile, nch), dim3(kBlock), 0, s, partial, blocks, partial2, 0, static_cast<double*>(nullptr),
+                      static_cast<unsigned long long*>(nullptr), 0ull, ticket);
+        LBFGSX_LAUNCH(kx_gram_finish, dim3(ntile, 1), dim3(kBlock), 0, s, partial2, nch, out, 1, out_dd, done, seq, ticket);
+    }
+    else
+        LBFGSX_LAUNCH(kx_gram_finish, dim3(ntile, 1), dim3(kBlock), 0, s, partial, 1, out, 1, out_dd, done, seq, ticket);
+    LBFGSX_HIP(hipGetLastError());
+    return LBFGSX_OK;
+}
+
+#define INST(T)                                                                                                                  \
+    template int rows<T>(hipStream_t, int, int, const ColsX<T>&, int, const BVecs<T>&, int, int, int64_t, const RedWsX&, double*,    \
+                         double*, const ProX<T>&, const RowsX<T>&, int, int);                                                    \
+    template int solve_sweep<T>(hipStream_t, int, int, const ColsX<T>&, int, const BVecs<T>&, const BVecs<T>&, int, const CoefX<T>&, \
+                                int, T, int64_t, const RedWsX&, double*, int*, unsigned*, unsigned, const int*, T*, T*, int);    \
+    template int multidot2_wf<T>(hipStream_t, int, const ColsX<T>&, int, int, int, const T*, const T*, const T*, const int*, int64_t, \
+                                 const ColsX<T>&, const int*, int, const RedWsX&, double*);                                      \
+    template int multidot2<T>(hipStream_t, int, const ColsX<T>&, int, const T*, const T*, int64_t, const RedWsX&, double*);        \
+    template int list2<T>(hipStream_t, int, const ColsX<T>&, int, const BVecs<T>&, const int*, int, const RedWsX&, double*,         \
+                          const unsigned char*, const int*);                                                                     \
+    template int multidot_mask<T>(hipStream_t, int, const ColsX<T>&, int, const BVecs<T>&, int, const T*, int, int64_t,            \
+                                  const RedWsX&, double*);                                                                       \
+    template int gram<T>(hipStream_t, int, const ColsX<T>&, int, const BVecs<T>&, int, int, int64_t, double*, const ProX<T>&,      \
+                         const GramRows<T>&);                                                                                    \
+    template int wf_append<T>(hipStream_t, const ColsX<T>&, int, T*, int64_t, int*, int*, const int*, unsigned*, unsigned, unsigned)
+INST(double);
+INST(float);
+#undef INST
+
+}  // namespace xl
+}  // namespace lbfgsx

@@ -328,12 +328,12 @@ def test_fused_subspace_passes_are_bit_identical_to_the_unfused_sequence(A, monk
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
-@pytest.mark.parametrize("m,max_submin", [(8, 10), (10, 3), (3, 10), (14, 10)])
+@pytest.mark.parametrize("m,max_submin", [(8, 10), (10, 3), (3, 10), (14, 10), (12, 10), (20, 10), (40, 4)])
 def test_sweep_statements_riding_on_the_solve_change_no_bit(A, monkeypatch, m, max_submin, dtype):
     """lbfgsx_b_solve_sweep / lbfgsx_b_lu_sweep (the sweep's element-wise statements inside the solve's pass, the rows of
     L and U through the index list) against the separate passes (LBFGSX_SWEEP_SOLVE_FUSE=0): same statements on the same
     values, so the same trajectory bit for bit and the same sweep counts; the fused form must actually have run."""
-    n, iters = 40003, 20
+    n, iters = 40003, max(20, m + 8)
     dt = O.F64 if dtype == "f64" else O.F32
     npdt = O.NPDT[dt]
     a, b = O.quad_problem(n, 30.0, 5, dt)
@@ -359,12 +359,13 @@ def test_sweep_statements_riding_on_the_solve_change_no_bit(A, monkeypatch, m, m
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
-@pytest.mark.parametrize("n,m,max_submin", [(70001, 8, 10), (70001, 10, 2), (65536, 3, 10), (90000, 14, 10)])
+@pytest.mark.parametrize("n,m,max_submin", [(70001, 8, 10), (70001, 10, 2), (65536, 3, 10), (90000, 14, 10), (70001, 12, 10),
+                                            (90000, 20, 10), (65536, 40, 10)])
 def test_compact_copy_of_the_free_rows_changes_no_bit(A, monkeypatch, n, m, max_submin, dtype):
     """The passes of the BOXCQP sweeps reading the compact copy of the free rows that the first solve's Gram pass leaves
     (lbfgsx_b_set_compaction) against the same passes reading all n rows through the state-byte mask
     (LBFGSX_COMPACT_FREE=0): the same rows in the same order, so the same trajectory bit for bit."""
-    iters = 20
+    iters = max(20, m + 8)
     dt = O.F64 if dtype == "f64" else O.F32
     npdt = O.NPDT[dt]
     a, b = O.quad_problem(n, 30.0, 9, dt)
@@ -389,7 +390,8 @@ def test_compact_copy_of_the_free_rows_changes_no_bit(A, monkeypatch, n, m, max_
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("n,m,max_submin,leave", [(70001, 8, 10, False), (70001, 10, 2, False), (65536, 3, 10, False),
-                                                 (90000, 14, 10, False), (120000, 10, 10, True)])
+                                                 (90000, 14, 10, False), (120000, 10, 10, True), (70001, 12, 10, False),
+                                                 (90000, 20, 10, False), (65536, 40, 10, False), (90000, 20, 10, True)])
 def test_compact_vectors_of_the_free_rows_change_no_bit(A, monkeypatch, n, m, max_submin, leave, dtype):
     """While the BOXCQP sweeps walk the compact copy, vecy / yfallback / lambda / mu / rhs / c_F / l - x0 / u - x0 and the
     partition bits of the free rows sit at the rows' positions (lbfgsx_b_compact_vec_counts) instead of at the rows
@@ -400,7 +402,7 @@ def test_compact_vectors_of_the_free_rows_change_no_bit(A, monkeypatch, n, m, ma
     import ctypes as C
     from lbfgspp_amd import _lib
     core, _ = _lib.load()
-    iters = 25
+    iters = max(25, m + 10)
     dt = O.F64 if dtype == "f64" else O.F32
     npdt = O.NPDT[dt]
     a, b = O.quad_problem(n, 30.0, 9, dt)
@@ -496,7 +498,8 @@ def test_polled_completion_serves_the_waits_and_changes_no_bit(A, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
-@pytest.mark.parametrize("n,m,iters", [(70001, 8, 40), (70001, 10, 45), (65536, 3, 30), (200000, 10, 60)])
+@pytest.mark.parametrize("n,m,iters", [(70001, 8, 40), (70001, 10, 45), (65536, 3, 30), (200000, 10, 60), (70001, 12, 40),
+                                       (90000, 20, 60), (65536, 40, 100)])
 def test_grams_launched_ahead_of_their_request_change_no_bit(A, monkeypatch, n, m, iters, dtype):
     """The Gram over the rows of L u U rides behind the W_L'l / W_U'u pass, the Grams over the rows that entered / left the
     free set behind the selected-entries pass of the carried first solve: the same kernels on the same data, launched
@@ -531,7 +534,8 @@ def test_grams_launched_ahead_of_their_request_change_no_bit(A, monkeypatch, n, 
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
-@pytest.mark.parametrize("n,m,iters,cap", [(70001, 8, 40, None), (70001, 10, 45, None), (65536, 5, 30, None), (200000, 10, 60, None),
+@pytest.mark.parametrize("n,m,iters,cap", [(70001, 12, 40, None), (90000, 20, 60, None), (65536, 40, 100, None),
+                                           (70001, 8, 40, None), (70001, 10, 45, None), (65536, 5, 30, None), (200000, 10, 60, None),
                                            (120000, 10, 40, "8")])
 def test_cauchy_dots_from_the_kept_compact_copy_change_no_bit(A, monkeypatch, n, m, iters, cap, dtype):
     """p = W'd of the Cauchy search and the deferred dots of add_correction as sums over the positions of the compact copy
@@ -569,15 +573,16 @@ def test_cauchy_dots_from_the_kept_compact_copy_change_no_bit(A, monkeypatch, n,
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
-@pytest.mark.parametrize("n,m,iters,age", [(70001, 8, 60, 32), (70001, 10, 45, 32), (65536, 3, 40, 32), (90000, 12, 20, 32),
-                                           (200000, 10, 80, 32), (70001, 8, 40, 2), (120000, 10, 40, 5), (65536, 5, 40, 3)])
+@pytest.mark.parametrize("n,m,iters,age", [(70001, 8, 60, 32), (70001, 10, 45, 32), (65536, 3, 40, 32), (90000, 12, 40, 32),
+                                           (200000, 10, 80, 32), (70001, 8, 40, 2), (120000, 10, 40, 5), (65536, 5, 40, 3),
+                                           (90000, 20, 60, 32), (65536, 40, 100, 32), (120000, 20, 50, 3)])
 def test_carried_gram_of_the_free_set_changes_no_bit(A, monkeypatch, n, m, iters, age, dtype):
     """W_F'W_F of the first BOXCQP solve from the sums of the previous iteration -- the rows of the two replaced columns
     computed afresh, the other entries corrected by the outer products of the rows that entered or left the free set, all
     in double-double (BFGSMatB::carried_gram) -- against the full Gram pass every iteration (LBFGSX_GRAM_CARRY=0): the
-    rounded entries are the same, so the trajectory is bit for bit the same; for m <= 10 the carried form must have run
-    (m = 12 has more entries than lanes and always takes the full pass), across its periodic refresh (every 32
-    iterations) and the growth of the history."""
+    rounded entries are the same, so the trajectory is bit for bit the same; the carried form must have run -- at every m
+    (round 3: m <= 10 only, one lane per entry; the split-row kernel serves 3 (2c + 1) entries for any 2c <= 80) -- across
+    its periodic refresh (every 32 iterations) and the growth of the history."""
     dt = O.F64 if dtype == "f64" else O.F32
     npdt = O.NPDT[dt]
     a, b = O.quad_problem(n, 30.0, 11, dt)
@@ -602,12 +607,14 @@ def test_carried_gram_of_the_free_set_changes_no_bit(A, monkeypatch, n, m, iters
     assert f[:2] == u[:2] and f[4] == u[4]
     assert np.array_equal(f[2], u[2]) and np.array_equal(f[3], u[3])
     assert k[:2] == u[:2] and k[4] == u[4] and np.array_equal(k[2], u[2]) and np.array_equal(k[3], u[3])
-    assert u[5] == 0 and k[5] == f[5]
-    if m <= 10 and dtype == "f64":
-        assert f[5] >= f[6] // 3, "the carried form ran in %d of %d subspace minimisations" % (f[5], f[6])
+    # without the kept copy a carried pass would have to write a new one, which the selected-entries kernel only does through
+    # the round-3 tile form (64 entries: m <= 10); beyond that "nokeep" takes the full pass (same bits either way)
+    assert u[5] == 0 and (k[5] == f[5] if m <= 10 else k[5] <= f[5])
+    if dtype == "f64":
+        assert f[5] >= f[6] // 4, "the carried form ran in %d of %d subspace minimisations" % (f[5], f[6])
 
 
-@pytest.mark.parametrize("m", [3, 5, 8, 10, 12])
+@pytest.mark.parametrize("m", [3, 5, 8, 10, 12, 20, 40])
 def test_deferred_correction_dots_change_no_bit(A, monkeypatch, m):
     """add_correction's S's_new / s_new.y_j dots taken by the W'd pass of the following Cauchy search
     (lbfgsx_b_correction_dots_defer, k_multidot2_all for 8 < 2c <= 20) against the pass of their own
@@ -743,7 +750,8 @@ def test_integer_mfma_gram_reads_and_writes_the_compact_copy(A, oracle, monkeypa
     assert (r.niter, r.nfev) == res["default"][:2] and np.abs(res["default"][3] - x_ref).max() <= 1e-10
 
 
-@pytest.mark.parametrize("n,m,npairs", [(50000, 10, 10), (300001, 6, 4), (65536, 10, 7)])
+@pytest.mark.parametrize("n,m,npairs", [(50000, 10, 10), (300001, 6, 4), (65536, 10, 7), (50000, 12, 12), (70001, 20, 20),
+                                        (40000, 40, 40), (30000, 16, 9)])
 def test_selected_entries_and_list_grams_equal_the_full_pass(A, n, m, npairs):
     """The pieces of the carried first solve against the full one-pass Gram on the same data: the entries
     lbfgsx_b_gram_pairs_dd returns (one per lane) round to the full pass's entries; with the free set changed by some
@@ -813,8 +821,10 @@ def test_selected_entries_and_list_grams_equal_the_full_pass(A, n, m, npairs):
         vrow = len(pi)
         for J in range(t + 1):
             pi.append(t); pj.append(J)
-        if len(pi) <= 64:
-            api, apj = (i32 * 64)(*pi), (i32 * 64)(*pj)
+        core.lbfgsx_b_gram_pairs_max.restype, core.lbfgsx_b_gram_pairs_max.argtypes = i32, [vp]
+        assert core.lbfgsx_b_gram_pairs_max(h) == 3 * (t + 1)     # the split-row kernel: the v row and the rows of two columns
+        if len(pi) <= core.lbfgsx_b_gram_pairs_max(h):
+            api, apj = (i32 * len(pi))(*pi), (i32 * len(pi))(*pj)
             pd = np.zeros(2 * len(pi))
             L.check(fpairs(h, ST_FREE, VS_DRT, 0, None, None, len(pi), api, apj, -2, pd.ctypes.data_as(vp)))
             got = pd[0::2] + pd[1::2]
@@ -848,3 +858,39 @@ def test_selected_entries_and_list_grams_equal_the_full_pass(A, n, m, npairs):
         assert fss(h, 0, VS_DRT, None, 1.0, wtd.ctypes.data_as(vp), C.cast(s7, vp)) == L.E_INVALID   # no index list yet
     finally:
         core.lbfgsx_destroy(h)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("n,m,iters,max_submin", [(70001, 3, 30, 10), (70001, 8, 40, 10), (90000, 10, 45, 10), (70001, 12, 40, 10),
+                                                  (65536, 16, 50, 10), (90000, 20, 60, 10), (65536, 40, 100, 10), (70001, 10, 40, 2)])
+def test_rows_split_over_lanes_change_no_bit(A, monkeypatch, n, m, iters, max_submin, dtype):
+    """The passes of the subspace minimisation and of the Cauchy dots with a row's 2c columns split over 2 or 4 lanes
+    (csrc/lbfgsb_x.cuh, every 2c <= 80) against the round-3 kernels that give a lane a whole row (LBFGSX_SPLIT=0; beyond
+    2c = 20 / 24 / 32 those hand over to the multi-launch forms): the same statements -- the left-to-right sums of the prologue
+    and of the solve handed from group to group in column order -- and the same correctly rounded dots, so the same
+    trajectory bit for bit, the same sweeps; the carried Gram must have run at every m."""
+    dt = O.F64 if dtype == "f64" else O.F32
+    npdt = O.NPDT[dt]
+    a, b = O.quad_problem(n, 30.0, 13, dt)
+    res = {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("LBFGSX_SPLIT", on)
+        s = A.LBFGSBSolver(A.LBFGSBParam(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters, max_submin=max_submin),
+                           dtype=npdt)
+        tr = A.TraceBuffer(n, cap=512, stride=23)
+        x = np.zeros(n, dtype=npdt)
+        try:
+            niter, fx = s.minimize(A.DiagQuadratic(a, b), x, (-0.7 * np.ones(n)).astype(npdt), (0.9 * np.ones(n)).astype(npdt),
+                                   trace=tr)
+        except RuntimeError:
+            niter, fx = -1, float("nan")
+        st = s.stats()
+        res[on] = (niter, s.last.nfev, x.copy(), tr.xs[:tr.count].copy(), st["submin_sweeps"], st["submin_unconverged"],
+                   st["gram_carried"], st["submin_calls"])
+    f, u = res["1"], res["0"]
+    assert f[:2] == u[:2] and f[4:6] == u[4:6] and f[4] > 0
+    assert np.array_equal(f[2], u[2]) and np.array_equal(f[3], u[3])
+    if dtype == "f64":
+        assert f[6] >= f[7] // 4, "the carried form ran in %d of %d subspace minimisations" % (f[6], f[7])
+    if m > 10:
+        assert u[6] == 0   # the one-entry-per-lane kernel has 64 lanes
