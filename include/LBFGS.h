@@ -302,18 +302,50 @@ private:
             throw std::invalid_argument("set_devices: fewer than 4 rows per device");
         lbfgsx_comm* comm = nullptr;
         detail::check(lbfgsx_comm_create_local(&comm, m_devices.data(), G));
+        struct CommGuard  // the communicator goes whatever leaves this function (a std::thread constructor may throw, too)
+        {
+            lbfgsx_comm* c;
+            ~CommGuard() { lbfgsx_comm_destroy(c); }
+        } comm_guard{comm};
         const size_t ng = size_t(G);
         std::vector<int> niter(ng, 0), nfev(ng, 0);
         std::vector<Scalar> fxs(ng, Scalar(0)), gns(ng, Scalar(0));
         std::vector<std::exception_ptr> err(ng);
         m_grad_host.resize(n);
         std::vector<std::thread> th;
+        struct Joiner
+        {
+            std::vector<std::thread>& t;
+            lbfgsx_comm* c;
+            ~Joiner()
+            {
+                for (auto& x : t)
+                    if (x.joinable())
+                    {
+                        (void) lbfgsx_comm_abort(c);  // only reached with threads still running when something threw here
+                        x.join();
+                    }
+            }
+        } joiner{th, comm};
         for (int g = 0; g < G; g++)
             th.emplace_back([&, g]() {
+                const std::int64_t lo = std::int64_t(g) * per, len = (g == G - 1) ? n - lo : per;
                 try
                 {
-                    const std::int64_t lo = std::int64_t(g) * per, len = (g == G - 1) ? n - lo : per;
                     LBFGSSolver<Scalar, LineSearch> s(m_param);
+                    // as minimize(): whatever is thrown, the caller's x receives this shard's trial point (a line search that
+                    // threw after writing one) or its current iterate
+                    struct XBack
+                    {
+                        LBFGSSolver<Scalar, LineSearch>& s;
+                        Scalar* dst;
+                        bool armed = true;
+                        ~XBack()
+                        {
+                            if (armed && s.device_state().ctx())
+                                (void) lbfgsx_download(s.device_state().ctx(), s.m_x_at_throw, dst);
+                        }
+                    } xback{s, x.data() + lo};
                     s.set_device(m_devices[size_t(g)]);
                     s.set_recursion(m_recursion == RECURSION_VECTOR ? RECURSION_GRAM_SPACE : m_recursion);
                     s.set_reducer([comm, g](double* v, int k) {
@@ -329,18 +361,22 @@ private:
                     niter[size_t(g)] = s.template minimize_resident_as<Vec>(fl, len, fxs[size_t(g)]);
                     nfev[size_t(g)] = s.num_evaluations();
                     gns[size_t(g)] = s.final_grad_norm();
+                    xback.armed = false;
                     s.device_state().download(LBFGSX_VEC_X, x.data() + lo);
                     s.device_state().download(LBFGSX_VEC_G, m_grad_host.data() + lo);
                 }
                 catch (...)
                 {
                     err[size_t(g)] = std::current_exception();
-                    (void) lbfgsx_comm_abort(comm);  // the other shards must not wait for this one
+                    (void) lbfgsx_comm_abort_from(comm, g);  // the other shards must not wait for this one
                 }
             });
         for (auto& t : th)
             t.join();
-        lbfgsx_comm_destroy(comm);
+        // the shard that failed FIRST holds the root cause; the others only report "aborted by another rank"
+        const int first = lbfgsx_comm_first_abort(comm);
+        if (first >= 0 && first < G && err[size_t(first)])
+            std::rethrow_exception(err[size_t(first)]);
         for (int g = 0; g < G; g++)
             if (err[size_t(g)])
                 std::rethrow_exception(err[size_t(g)]);

@@ -397,6 +397,10 @@ private:
                     }
                     catch (const std::runtime_error& e)  // what the single solve's search would throw (Nocedal-Wright)
                     {
+                        // as the single-problem solver (and the reference's policies, which write every trial into x
+                        // itself: LineSearchNocedalWright.h:146,219): the point returned is the last trial, not the iterate
+                        // the search started from
+                        q.cur = q.trial;
                         fail(q, out[size_t(p)], LBFGSX_E_RUNTIME, e.what(), k);
                         q.fx = fx;
                         searching--;

@@ -480,6 +480,12 @@ int lbfgsx_comm_create_rank(lbfgsx_comm** out, int device, int rank, int nranks,
 int lbfgsx_comm_create_local(lbfgsx_comm** out, const int* devices, int ndev);
 int lbfgsx_comm_allreduce_sum(lbfgsx_comm* comm, int local_rank, double* buf, int count);
 int lbfgsx_comm_abort(lbfgsx_comm* comm);
+/* the same, remembering WHICH local rank failed first (the one whose error is the root cause; the others then fail with
+ * "aborted by another rank"): lbfgsx_comm_first_abort returns it, -1 when nobody called lbfgsx_comm_abort_from.  A rank of
+ * another PROCESS that dies cannot call either: the surviving ranks leave their wait through RCCL's asynchronous error or
+ * after LBFGSX_COMM_TIMEOUT_S seconds (default 300) and abort their own communicator. */
+int lbfgsx_comm_abort_from(lbfgsx_comm* comm, int local_rank);
+int lbfgsx_comm_first_abort(const lbfgsx_comm* comm);
 /* info = {ranks, ranks driven by this process, 1 when RCCL carries the sums (0: host emulation), RCCL version code} */
 int lbfgsx_comm_info(const lbfgsx_comm* comm, int info[4]);
 int64_t lbfgsx_comm_calls(const lbfgsx_comm* comm, int local_rank);

@@ -138,6 +138,9 @@ def load():
     sig(core, "lbfgsx_comm_create_local", i32, C.POINTER(vp), C.POINTER(i32), i32)
     sig(core, "lbfgsx_comm_allreduce_sum", i32, vp, i32, pd, i32)
     sig(core, "lbfgsx_comm_abort", i32, vp)
+    sig(core, "lbfgsx_comm_abort_from", i32, vp, i32)
+    sig(core, "lbfgsx_comm_first_abort", i32, vp)
+    sig(core, "lbfgsx_b_gram_pairs_max", i32, vp)
     sig(core, "lbfgsx_comm_info", i32, vp, C.POINTER(i32 * 4))
     sig(core, "lbfgsx_comm_calls", i64, vp, i32)
     sig(core, "lbfgsx_comm_hook_arg", vp, vp, i32)

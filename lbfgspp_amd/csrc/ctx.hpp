@@ -166,6 +166,7 @@ struct lbfgsx_ctx
     unsigned long long done_seq = 0;
     long long poll_waits = 0, poll_timeouts = 0;
     bool poll_pending = false;  // poll_arm ran and no wait has consumed it yet
+    bool poll_off = false;      // two waits timed out: this context waits for its stream from now on
     int grid_cap = 1024;     // blocks per launch of the streaming kernels (4 per CU; tuned on MI355X, see profiles/)
     int grid_cap_twoloop = 512;
     int unroll = 4;   // 16-byte loads in flight per stream per thread in the two-loop kernels
@@ -244,7 +245,7 @@ namespace lbfgsx {
 // for the stream: correct, slow, visible in lbfgsx_poll_counts.
 inline void poll_arm(lbfgsx_ctx* c)
 {
-    if (c->done_host)
+    if (c->done_host && !c->poll_off)
     {
         c->ws.done = c->done_dev;
         c->ws.seq = ++c->done_seq;
@@ -280,7 +281,11 @@ inline hipError_t poll_wait(lbfgsx_ctx* c)
         if ((spin & 1023u) == 1023u &&
             std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.05)
         {
-            c->poll_timeouts++;
+            // the word did not arrive: the kernel's system-scope store is not visible while the kernel runs (memory that is
+            // not fine-grained), or the kernel never signals.  Either way polling only burns 50 ms per wait: after the second
+            // miss this context waits for its stream like everybody else (visible in lbfgsx_poll_counts)
+            if (++c->poll_timeouts >= 2)
+                c->poll_off = true;
             const hipError_t e = hipStreamSynchronize(c->stream);
             if (tr)
                 host_trace("<sync");

@@ -388,7 +388,7 @@ int bounded_alloc(lbfgsx_ctx* c)
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->phys_dev), sizeof(int) * size_t(c->m + 1)));
     if (c->outmap_dev)
     {
-        LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->dout_host), sizeof(double) * lbfgsb_state::kDout, hipHostMallocMapped));
+        LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->dout_host), sizeof(double) * lbfgsb_state::kDout, hipHostMallocMapped | hipHostMallocCoherent));
         std::memset(b->dout_host, 0, sizeof(double) * lbfgsb_state::kDout);
         LBFGSX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->dout), b->dout_host, 0));
     }
@@ -483,11 +483,11 @@ int bounded_alloc(lbfgsx_ctx* c)
     if (c->outmap_dev)
     {
         // the (hi, lo) sums land where the host reads them: a copy into pageable memory is staged and costs ~20 us a fetch
-        LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->gram_dd_host), sizeof(double) * gent * 2, hipHostMallocMapped));
+        LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->gram_dd_host), sizeof(double) * gent * 2, hipHostMallocMapped | hipHostMallocCoherent));
         LBFGSX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->gram_dd), b->gram_dd_host, 0));
-        LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->stash_host), sizeof(double) * 3 * (gent * 3), hipHostMallocMapped));
+        LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->stash_host), sizeof(double) * 3 * (gent * 3), hipHostMallocMapped | hipHostMallocCoherent));
         LBFGSX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->stash_dev), b->stash_host, 0));
-        LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->gram_out_host), sizeof(double) * gent, hipHostMallocMapped));
+        LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->gram_out_host), sizeof(double) * gent, hipHostMallocMapped | hipHostMallocCoherent));
         LBFGSX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->gram_out), b->gram_out_host, 0));
     }
     else
@@ -2788,8 +2788,9 @@ int lbfgsx_b_gram_pairs_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
                 if (!ride_enter && !ride_leave)
                     lbfgsx::poll_arm(c);
                 const ColsX<T> cl = compact_in ? colsx_wf<T>(c, tot) : colsx_full<T>(c, tot);
-                rc = xl::rows<T>(c->stream, b->num_cus, col_a < 0 ? 1 : 3, cl, tot, bvecs<T>(c), vsel_id, mask, nrows, wsx(c), b->gram_out,
-                                 b->gram_out + 256, pro, gr, col_a, col_b);
+                // the three-row form also patches the two replaced columns of the kept copy (the one-row form never does)
+                rc = xl::rows<T>(c->stream, b->num_cus, (col_a < 0 && !gr.dst_a) ? 1 : 3, cl, tot, bvecs<T>(c), vsel_id, mask, nrows,
+                                 wsx(c), b->gram_out, b->gram_out + 256, pro, gr, col_a, col_b);
             });
             if (kept)
             {

@@ -62,18 +62,23 @@ struct RowsX
 #ifndef LBFGSX_X_OCC_SWEEP
 #define LBFGSX_X_OCC_SWEEP 0
 #endif
+// experiment builds only (scripts/experiments/kernels_x.hip): bit 0 no left-to-right sums, 1 no double-double products,
+// 2 no stores, 3 no cross-lane moves -- what each part of a trip costs.  0 in the product.
+#ifndef LBFGSX_X_DBG
+#define LBFGSX_X_DBG 0
+#endif
 constexpr int occ_rows_x(int ncl, int g, int na)
 {
     return (LBFGSX_X_OCC_ROWS > 0 && na == 1 && ncl <= 12) ? LBFGSX_X_OCC_ROWS
-           : na == 1 ? (ncl <= 8 ? 4 : (ncl == 10 && g == 2) ? 4 : ncl <= 12 ? 3 : 2)
-                     : (ncl <= 4 ? 4 : ncl <= 12 ? 2 : 1);
+           : na == 1 ? (ncl <= 4 ? 4 : ncl <= 10 ? 3 : 2)
+                     : (ncl <= 4 ? 3 : ncl <= 10 ? 2 : 1);
 }
 constexpr int occ_sweep_x(int ncl, int g, int first)
 {
     return (LBFGSX_X_OCC_SWEEP > 0 && ncl <= 12) ? LBFGSX_X_OCC_SWEEP
-           : first ? (ncl <= 15 ? 4 : 3) : (ncl <= 4 ? 4 : ncl <= 12 ? 3 : 2);
+           : first ? (ncl <= 10 ? 3 : 2) : (ncl <= 4 ? 3 : ncl <= 12 ? 2 : 1);
 }
-constexpr int occ_dots_x(int ncl) { return ncl <= 8 ? 4 : ncl <= 10 ? 3 : ncl <= 12 ? 2 : 1; }   // 2 NCL accumulators
+constexpr int occ_dots_x(int ncl) { return ncl <= 4 ? 4 : ncl <= 10 ? 2 : 1; }   // 2 NCL accumulators, two register sets
 constexpr int occ_mask_x(int ncl) { return ncl <= 12 ? 4 : ncl <= 15 ? 3 : 2; }                    // NCL + 1
 
 template <int G>
@@ -91,48 +96,48 @@ struct LaneX
     __device__ __forceinline__ bool last() const { return g == G - 1; }
 };
 
-// a = 0; for every column j of the row in order: a = a + term_j -- the terms of this lane's columns in p[], `okm` bit k
-// set when column g * NCL + k exists.  Every lane of the row gets the total.
+// a = 0; for every column j of the row in order: a = a + term_j -- the terms of this lane's columns in p[].  Every lane of
+// the row gets the total.  Columns beyond 2c need no test: their coefficient is an exact zero (the hosts pad with zeros) and
+// their value is column 0's, so the term is +-0, and x + (+-0) == x bit for bit -- a sum that starts at +0 is never -0
+// (round-to-nearest gives -0 only for (-0) + (-0)).
 template <class T, int NCL, int G>
-__device__ __forceinline__ T chain_x(const T (&p)[NCL], unsigned okm, const LaneX<G>& L)
+__device__ __forceinline__ T chain_x(const T (&p)[NCL], const LaneX<G>& L)
 {
     T x = T(0);
 #pragma unroll
     for (int round = 0; round < G; round++)
     {
         // group `round` continues from the partial of the group before it; what the other groups compute is dropped
-        if (round > 0)
+        if (round > 0 && !(LBFGSX_X_DBG & 8))
             x = __shfl_up(x, LaneX<G>::RPW, 64);
 #pragma unroll
         for (int k = 0; k < NCL; k++)
-        {
-            const T y = x + p[k];
-            x = ((okm >> k) & 1u) ? y : x;
-        }
+            x = x + p[k];
     }
+    if (LBFGSX_X_DBG & 8)
+        return x;
     return __shfl(x, (G - 1) * LaneX<G>::RPW + L.rr, 64);
 }
 
-// this lane's column pointers (kColsX entries in LDS) and the mask of the columns that exist
+// A column pointer as the compiler must see it to emit global_load: the lists travel through LDS, and a pointer loaded from
+// memory is a generic one (flat_load: both address paths, both counters) unless its address space is stated.
+template <class T>
+using gptr_x = const T __attribute__((address_space(1)))*;
+
+// this lane's column pointers (kColsX entries in LDS)
 template <class T, int NCL, int G>
-__device__ __forceinline__ unsigned lane_cols_x(const T* const* s_col, int ncols, const LaneX<G>& L, const T* (&cp)[NCL])
+__device__ __forceinline__ void lane_cols_x(const T* const* s_col, const LaneX<G>& L, gptr_x<T> (&cp)[NCL])
 {
-    unsigned okm = 0;
 #pragma unroll
     for (int k = 0; k < NCL; k++)
-    {
-        const int ci = L.g * NCL + k;
-        cp[k] = s_col[ci];
-        okm |= (ci < ncols) ? (1u << k) : 0u;
-    }
-    return okm;
+        cp[k] = (gptr_x<T>) s_col[L.g * NCL + k];
 }
 
 // ---------------------------------------------------------------- the v row (NA = 1) or the v row and the rows of two columns
 // (NA = 3) of the masked Gram: k_vrows for 2c <= 80.  Statements and outputs as there (lbfgsb_kernels.cuh); the rounded
 // sums land in out[a * (ncols + 1) + j] (a = 0: v row with (v, v) at j = ncols; a = 1, 2: columns col_a, col_b), the
 // (hi, lo) pairs in out_dd at twice that index.
-template <class T, int NCL, int G, int NA>
+template <class T, int NCL, int G, int NA, bool IDX>
 __global__ void __launch_bounds__(kBlock, occ_rows_x(NCL, G, NA))
     kx_rows(ColsX<T> cols, int ncols, BVecs<T> b, int vsel_id, int mask, int64_t n, RedWsX ws, double* __restrict__ out,
             double* __restrict__ out_dd, ProX<T> pro, RowsX<T> gr, int col_a, int col_b)
@@ -150,8 +155,16 @@ __global__ void __launch_bounds__(kBlock, occ_rows_x(NCL, G, NA))
     }
     __syncthreads();
     const LaneX<G> L;
-    const T* cp[NCL];
-    const unsigned okm = lane_cols_x<T, NCL, G>(s_col, ncols, L, cp);
+    // the lane's column pointers live in registers, or -- where the accumulators leave no room for them (the three-row form,
+    // the widest classes) -- are read from LDS again by every fetch
+    constexpr bool PTR_LDS = NA > 1 || NCL > 12;
+    gptr_x<T> cp[PTR_LDS ? 1 : NCL];
+    if (!PTR_LDS)
+    {
+#pragma unroll
+        for (int k = 0; k < (PTR_LDS ? 1 : NCL); k++)
+            cp[k] = (gptr_x<T>) s_col[L.g * NCL + k];
+    }
     Accs<A, NL> accs;
     A(&acc)[NL] = accs.v;
     // the vectors a row reads, as pointers fixed for the launch (a vector a mode does not use is a valid stand-in)
@@ -168,110 +181,166 @@ __global__ void __launch_bounds__(kBlock, occ_rows_x(NCL, G, NA))
     case VS_UBOUND: va_p = b.ub; vb_p = b.x0; vkind = 2; break;
     default: va_p = b.y; vb_p = b.y; vkind = 0; break;
     }
-    const bool patch = gr.dst_a != nullptr;
+    // the two replaced columns are patched by the three-row form only (the carried first solve); NA = 1 never carries them
+    const bool patch = NA > 1 && gr.dst_a != nullptr;
     const T* fa_p = patch ? gr.src_a : b.rhs;
     const T* fb_p = patch ? gr.src_b : b.rhs;
-    const T* xa_p = s_col[(NA > 1 && col_a >= 0) ? col_a : 0];
-    const T* xb_p = s_col[(NA > 1 && col_b >= 0) ? col_b : 0];
+    gptr_x<T> xa_p = (gptr_x<T>) s_col[(NA > 1 && col_a >= 0) ? col_a : 0];
+    gptr_x<T> xb_p = (gptr_x<T>) s_col[(NA > 1 && col_b >= 0) ? col_b : 0];
     const int64_t stride = int64_t(gridDim.x) * kWaves * RPW;
     const int64_t last = n - 1;
-    for (int64_t base = (int64_t(blockIdx.x) * kWaves + L.wave) * RPW; base < n; base += stride)
+    // Two register sets.  A wavefront that loads a trip, waits, computes, and only then loads the next one keeps nothing in
+    // flight while it computes -- and the wavefronts of a SIMD bunch up: their data arrives together, the SIMD interleaves
+    // their ~300 instructions each, they finish together and ask for their next trips together, so a trip costs the memory
+    // latency PLUS (waves per SIMD) x (compute of a trip): 207 us where the same loads alone take 146
+    // (scripts/experiments/kernels_x.hip).  With the next trip's loads issued before the current trip's arithmetic a trip
+    // costs max(latency, waves x compute).  Indices beyond the end are clamped (loaded again, dropped); the row numbers of the
+    // compact copy run one trip further ahead, so that no load waits for another.
+    struct Buf
     {
+        T pre, va, vb, fa, fb, xa, xb;
+        T row[NCL];
+        unsigned char st;
+    };
+    auto rowof = [&](int64_t base) __attribute__((always_inline)) -> int64_t {
+        const int64_t t = base + L.rr, tc = t < n ? t : last;
+        return IDX ? int64_t(gr.in_idx[tc]) : tc;
+    };
+    auto fetch = [&](int64_t base, int64_t r, Buf& x) __attribute__((always_inline)) {
+        const int64_t t = base + L.rr, tc = t < n ? t : last;
+        x.st = b.st[r];
+        x.pre = pre_p[r];
+        x.va = va_p[r];
+        x.vb = vb_p[r];
+        if (NA > 1)
+        {
+            x.fa = fa_p[r];
+            x.fb = fb_p[r];
+            x.xa = xa_p[tc];
+            x.xb = xb_p[tc];
+        }
+        if (PTR_LDS)
+        {
+            asm volatile("" ::: "memory");  // the pointers are read here, not kept across the loop
+#pragma unroll
+            for (int k = 0; k < NCL; k++)
+                x.row[k] = ((gptr_x<T>) s_col[L.g * NCL + k])[tc];
+        }
+        else
+        {
+#pragma unroll
+            for (int k = 0; k < NCL; k++)
+                x.row[k] = cp[PTR_LDS ? 0 : k][tc];
+        }
+    };
+    auto compute = [&](int64_t base, int64_t r, Buf& x) __attribute__((always_inline)) {
         const int64_t t = base + L.rr;
         const bool inb = t < n;
-        const int64_t tc = inb ? t : last;  // clamped: loaded again, dropped
-        int64_t r = tc;
-        if (gr.in_idx)
-            r = gr.in_idx[tc];
-        // every load of the row, up front
-        const unsigned char st = b.st[r];
-        const T pre = pre_p[r], va = va_p[r], vb = vb_p[r];
-        T fa = fa_p[r], fb = fb_p[r];
-        T row[NCL];
-#pragma unroll
-        for (int k = 0; k < NCL; k++)
-            row[k] = cp[k][tc];
         T xa = T(0), xb = T(0);
         if (NA > 1)
         {
-            xa = xa_p[tc];
-            xb = xb_p[tc];
+            xa = x.xa;
+            xb = x.xb;
         }
         if (patch)  // every position of the kept copy gets the two replaced columns, kept or not
         {
             if (inb && L.g == 0)
             {
-                gr.dst_a[t] = fa;
-                gr.dst_b[t] = fb;
+                gr.dst_a[t] = x.fa;
+                gr.dst_b[t] = x.fb;
             }
 #pragma unroll
             for (int k = 0; k < NCL; k++)
             {
                 const int ci = L.g * NCL + k;
-                row[k] = (ci == gr.fresh_a) ? fa : (ci == gr.fresh_b) ? fb : row[k];
+                x.row[k] = (ci == gr.fresh_a) ? x.fa : (ci == gr.fresh_b) ? x.fb : x.row[k];
             }
-            if (NA > 1)
-            {
-                xa = (col_a == gr.fresh_a) ? fa : (col_a == gr.fresh_b) ? fb : xa;
-                xb = (col_b == gr.fresh_a) ? fa : (col_b == gr.fresh_b) ? fb : xb;
-            }
+            xa = (col_a == gr.fresh_a) ? x.fa : (col_a == gr.fresh_b) ? x.fb : xa;
+            xb = (col_b == gr.fresh_a) ? x.fa : (col_b == gr.fresh_b) ? x.fb : xb;
         }
-        const bool keep = inb && (!mask || (st & mask));
-        T v = vkind == 0 ? va : vkind == 1 ? -va : va - vb;
+        const bool keep = inb && (!mask || (x.st & mask));
+        T v = vkind == 0 ? x.va : vkind == 1 ? -x.va : x.va - x.vb;
         if (pro.mode != GP_NONE)
         {
             // (W * coef)(row): columns in order, plain accumulation -- the statement k_wcombine evaluates
             T a1 = T(0), a2 = T(0);
-            if (pro.use1)
+            if (pro.use1 && !(LBFGSX_X_DBG & 1))
             {
                 T p[NCL];
 #pragma unroll
                 for (int k = 0; k < NCL; k++)
-                    p[k] = row[k] * s_c1[L.g * NCL + k];
-                a1 = chain_x<T, NCL, G>(p, okm, L);
+                    p[k] = x.row[k] * s_c1[L.g * NCL + k];
+                a1 = chain_x<T, NCL, G>(p, L);
             }
-            if (pro.use2)
+            if (pro.use2 && !(LBFGSX_X_DBG & 1))
             {
                 T p[NCL];
 #pragma unroll
                 for (int k = 0; k < NCL; k++)
-                    p[k] = row[k] * s_c2[L.g * NCL + k];
-                a2 = chain_x<T, NCL, G>(p, okm, L);
+                    p[k] = x.row[k] * s_c2[L.g * NCL + k];
+                a2 = chain_x<T, NCL, G>(p, L);
             }
             if (pro.mode == GP_RHS)
             {
-                T rh = pre;
+                T rh = x.pre;
                 if (pro.use1)
                     rh = rh + (-a1);
                 if (pro.use2)
                     rh = rh + (-a2);
-                if (keep && L.last())
+                if (keep && L.last() && !(LBFGSX_X_DBG & 4))
                     b.rhs[r] = rh;
                 if (vsel_id == VS_NEG_RHS)  // v is read from the vector just written
                     v = -rh;
             }
             else
             {
-                const T cf = (pro.use1 ? (T(-1) * a1) : T(0)) + pre;
+                const T cf = (pro.use1 ? (T(-1) * a1) : T(0)) + x.pre;
                 if (keep && L.last())
                     b.cF[r] = cf;
                 if (vsel_id == VS_NEG_CF)
                     v = -cf;
             }
         }
-        if (keep)
+        if (keep && (LBFGSX_X_DBG & 2))
+        {
+#pragma unroll
+            for (int k = 0; k < NCL; k++)
+                acc[k].add(v + x.row[k]);
+        }
+        if (keep && !(LBFGSX_X_DBG & 2))
         {
 #pragma unroll
             for (int k = 0; k < NCL; k++)
             {
-                acc[k].add_prod(v, row[k]);
+                acc[k].add_prod(v, x.row[k]);
                 if (NA > 1)
                 {
-                    acc[NP + k].add_prod(xa, row[k]);
-                    acc[2 * NP + k].add_prod(xb, row[k]);
+                    acc[NP + k].add_prod(xa, x.row[k]);
+                    acc[2 * NP + k].add_prod(xb, x.row[k]);
                 }
             }
             acc[NCL].add_prod(v, v);
+        }
+    };
+    {
+        int64_t base = (int64_t(blockIdx.x) * kWaves + L.wave) * RPW;
+        if (base < n)
+        {
+            int64_t r0 = rowof(base), r1 = rowof(base + stride);
+            Buf A0, A1;
+            fetch(base, r0, A0);
+            for (; base < n; base += 2 * stride)
+            {
+                const int64_t b1 = base + stride, b2 = b1 + stride, b3 = b2 + stride;
+                const int64_t r2 = rowof(b2);
+                fetch(b1, r1, A1);
+                compute(base, r0, A0);
+                const int64_t r3 = rowof(b3);
+                fetch(b2, r2, A0);
+                compute(b1, r1, A1);   // beyond the end: every lane out of bounds, nothing kept
+                r0 = r2;
+                r1 = r3;
+            }
         }
     }
     A mine;
@@ -310,7 +379,7 @@ __global__ void __launch_bounds__(kBlock, occ_rows_x(NCL, G, NA))
 // ---------------------------------------------------------------- the solve of a BOXCQP sweep and the sweep's statements on the
 // rows it writes: k_solve_sweep for 2c <= 80 (statements, compact-vector modes `cv` and outputs as there).
 // out = {dots[ncols] (FIRST = 0 only), the 7 sums of k_sub_sweep_begin}
-template <class T, int NCL, int G, int FIRST>
+template <class T, int NCL, int G, int FIRST, bool IDX>
 __global__ void __launch_bounds__(kBlock, occ_sweep_x(NCL, G, FIRST))
     kx_solve_sweep(ColsX<T> cols, int ncols, BVecs<T> b, BVecs<T> bw, int vsel_id, CoefX<T> coef, int has_w, T theta, int64_t n,
                    RedWsX ws, double* __restrict__ out, int* __restrict__ lu_list, unsigned* __restrict__ lu_cnt, unsigned lu_cap,
@@ -327,8 +396,14 @@ __global__ void __launch_bounds__(kBlock, occ_sweep_x(NCL, G, FIRST))
     }
     __syncthreads();
     const LaneX<G> L;
-    const T* cp[NCL];
-    const unsigned okm = lane_cols_x<T, NCL, G>(s_col, ncols, L, cp);
+    constexpr bool PTR_LDS = NCL > 12;  // see kx_rows
+    gptr_x<T> cp[PTR_LDS ? 1 : NCL];
+    if (!PTR_LDS)
+    {
+#pragma unroll
+        for (int k = 0; k < (PTR_LDS ? 1 : NCL); k++)
+            cp[k] = (gptr_x<T>) s_col[L.g * NCL + k];
+    }
     const T theta2 = theta * theta;
     const T* va_p;
     const T* vb_p;
@@ -351,31 +426,55 @@ __global__ void __launch_bounds__(kBlock, occ_sweep_x(NCL, G, FIRST))
     unsigned cnt[7] = {0, 0, 0, 0, 0, 0, 0};
     const int64_t stride = int64_t(gridDim.x) * kWaves * RPW;
     const int64_t last = n - 1;
-    for (int64_t base = (int64_t(blockIdx.x) * kWaves + L.wave) * RPW; base < n; base += stride)
+    // two register sets, the next trip's loads issued before this trip's arithmetic (see kx_rows); IDX: the columns are the
+    // compact copy and `ridx` holds the row of every position -- fetched one trip further ahead, so that no load waits
+    struct Buf
     {
+        T w[NCL];
+        T xa, xb, yold, la, ua, x0i, cfi;
+        unsigned char st0;
+    };
+    auto rowof = [&](int64_t base) __attribute__((always_inline)) -> int64_t {
+        const int64_t t = base + L.rr, tc = t < n ? t : last;
+        return IDX ? int64_t(ridx[tc]) : tc;
+    };
+    auto fetch = [&](int64_t base, int64_t i, Buf& x) __attribute__((always_inline)) {
+        const int64_t t = base + L.rr, tc = t < n ? t : last;
+        const int64_t ir = cvt ? tc : i;  // where this pass reads the vectors of the row
+        x.st0 = b.st[ir];
+        if (PTR_LDS)
+        {
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < NCL; k++)
+                x.w[k] = ((gptr_x<T>) s_col[L.g * NCL + k])[tc];
+        }
+        else
+        {
+#pragma unroll
+            for (int k = 0; k < NCL; k++)
+                x.w[k] = cp[PTR_LDS ? 0 : k][tc];
+        }
+        x.xa = va_p[ir];
+        x.xb = vb_p[ir];
+        x.yold = FIRST ? T(0) : b.y[ir];
+        x.la = la_p[ir];
+        x.ua = ua_p[ir];
+        x.x0i = x0_p[ir];
+        x.cfi = b.cF[ir];
+    };
+    auto compute = [&](int64_t base, int64_t i, Buf& x) __attribute__((always_inline)) {
         const int64_t t = base + L.rr;
         const bool inb = t < n;
-        const int64_t tc = inb ? t : last;
-        int64_t i = tc;
-        if (ridx && !cvt)
-            i = ridx[tc];
-        const int64_t ir = cvt ? tc : i;  // where this pass reads the vectors of the row
-        const int64_t iw = cv ? tc : i;   // ... and writes them
-        const unsigned char st0 = b.st[ir];
-        T w[NCL];
-#pragma unroll
-        for (int k = 0; k < NCL; k++)
-            w[k] = cp[k][tc];
-        const T xa = va_p[ir], xb = vb_p[ir];
-        const T yold = FIRST ? T(0) : b.y[ir];
-        const T la = la_p[ir], ua = ua_p[ir], x0i = x0_p[ir], cfi = b.cF[ir];
-        const T li = cvt ? la : la - x0i, ui = cvt ? ua : ua - x0i;
+        const int64_t iw = cv ? t : i;   // where this pass writes the vectors of the row
+        const unsigned char st0 = x.st0;
+        const T li = cvt ? x.la : x.la - x.x0i, ui = cvt ? x.ua : x.ua - x.x0i;
         const bool mine = inb && L.last();  // the lane that writes the row's vectors
         if (cv == 1 && mine)  // every position gets its constants, free or not
         {
             cli[t] = li;
             cui[t] = ui;
-            bw.cF[t] = cfi;
+            bw.cF[t] = x.cfi;
             if (!(st0 & ST_FREE))
                 bw.st[t] = st0;
         }
@@ -387,33 +486,49 @@ __global__ void __launch_bounds__(kBlock, occ_sweep_x(NCL, G, FIRST))
             T p[NCL];
 #pragma unroll
             for (int k = 0; k < NCL; k++)
-                p[k] = w[k] * sc[L.g * NCL + k];
-            a = chain_x<T, NCL, G>(p, okm, L);
+                p[k] = x.w[k] * sc[L.g * NCL + k];
+            a = chain_x<T, NCL, G>(p, L);
         }
-        const T v = vkind == 0 ? xa : vkind == 1 ? -xa : xa - xb;
+        const T v = vkind == 0 ? x.xa : vkind == 1 ? -x.xa : x.xa - x.xb;
         const T ynew = has_w ? (v / theta + a / theta2) : (v / theta);
-        const T yi = solve ? ynew : yold;
+        const T yi = solve ? ynew : x.yold;
         if (solve && L.last())
             bw.y[iw] = yi;
         if (!FIRST && fr)
         {
 #pragma unroll
             for (int k = 0; k < NCL; k++)
-                acc[k].add_prod(w[k], yi);
+                acc[k].add_prod(x.w[k], yi);
         }
         bool app = false;
         if (solve && L.last())
         {
             // a P row's multipliers are zero (the sweep that made it P stored them); the first sweep sets them
-            const unsigned char s2 = sweep_row_v<T>(bw, iw, st0, yi, T(0), T(0), FIRST != 0, FIRST != 0, cnt, li, ui, cfi);
+            const unsigned char s2 = sweep_row_v<T>(bw, iw, st0, yi, T(0), T(0), FIRST != 0, FIRST != 0, cnt, li, ui, x.cfi);
             app = (s2 & (ST_L | ST_U)) != 0;
         }
         if (lu_cap)
+            lu_append(app, i, lu_list, lu_cnt, lu_cap);  // the list holds rows
+    };
+    {
+        int64_t base = (int64_t(blockIdx.x) * kWaves + L.wave) * RPW;
+        if (base < n)
         {
-            int64_t irow = i;
-            if (cvt && app)
-                irow = ridx[tc];  // the list holds rows
-            lu_append(app, irow, lu_list, lu_cnt, lu_cap);
+            int64_t i0 = rowof(base), i1 = rowof(base + stride);
+            Buf A0, A1;
+            fetch(base, i0, A0);
+            for (; base < n; base += 2 * stride)
+            {
+                const int64_t b1 = base + stride, b2 = b1 + stride, b3 = b2 + stride;
+                const int64_t i2 = rowof(b2);
+                fetch(b1, i1, A1);
+                compute(base, i0, A0);
+                const int64_t i3 = rowof(b3);
+                fetch(b2, i2, A0);
+                compute(b1, i1, A1);
+                i0 = i2;
+                i1 = i3;
+            }
         }
     }
     sweep_counts<T, A>(cnt, acc + ND);
@@ -471,38 +586,66 @@ __global__ void __launch_bounds__(kBlock, occ_dots_x(NCL))
     const int64_t stride = int64_t(gridDim.x) * kWaves * RPW;
     if (npos > 0)
     {
-        const T* cp[NCL];
-        (void) lane_cols_x<T, NCL, G>(s_col, ncols, L, cp);
+        gptr_x<T> cp[NCL];
+        lane_cols_x<T, NCL, G>(s_col, L, cp);
         const int64_t last = npos - 1;
-        for (int64_t base = (int64_t(blockIdx.x) * kWaves + L.wave) * RPW; base < npos; base += stride)
+        // two register sets, the row numbers one trip further ahead (see kx_rows)
+        struct Buf
         {
-            const int64_t t = base + L.rr;
-            const bool inb = t < npos;
-            const int64_t tc = inb ? t : last;
-            const int64_t r = idx[tc];
-            const T a = snew[r], y = ynew[r], d = dvec[r];
+            T a, y, d;
             T w[NCL];
+        };
+        auto rowof = [&](int64_t base) __attribute__((always_inline)) -> int64_t {
+            const int64_t t = base + L.rr;
+            return int64_t(idx[t < npos ? t : last]);
+        };
+        auto fetch = [&](int64_t base, int64_t r, Buf& x) __attribute__((always_inline)) {
+            const int64_t t = base + L.rr, tc = t < npos ? t : last;
+            x.a = snew[r];
+            x.y = ynew[r];
+            x.d = dvec[r];
 #pragma unroll
             for (int k = 0; k < NCL; k++)
-                w[k] = cp[k][tc];
-            if (inb)
+                x.w[k] = cp[k][tc];
+        };
+        auto compute = [&](int64_t base, Buf& x) __attribute__((always_inline)) {
+            if (base + L.rr < npos)
             {
 #pragma unroll
                 for (int k = 0; k < NCL; k++)
                 {
                     const int ci = L.g * NCL + k;
-                    const T wk = (ci == fresh_a) ? y : (ci == fresh_b) ? a : w[k];
-                    acc[k].add_prod(wk, a);
-                    acc[NCL + k].add_prod(wk, d);
+                    const T wk = (ci == fresh_a) ? x.y : (ci == fresh_b) ? x.a : x.w[k];
+                    acc[k].add_prod(wk, x.a);
+                    acc[NCL + k].add_prod(wk, x.d);
                 }
+            }
+        };
+        int64_t base = (int64_t(blockIdx.x) * kWaves + L.wave) * RPW;
+        if (base < npos)
+        {
+            int64_t r0 = rowof(base), r1 = rowof(base + stride);
+            Buf A0, A1;
+            fetch(base, r0, A0);
+            for (; base < npos; base += 2 * stride)
+            {
+                const int64_t b1 = base + stride, b2 = b1 + stride, b3 = b2 + stride;
+                const int64_t r2 = rowof(b2);
+                fetch(b1, r1, A1);
+                compute(base, A0);
+                const int64_t r3 = rowof(b3);
+                fetch(b2, r2, A0);
+                compute(b1, A1);
+                r1 = r3;
+                r0 = r2;
             }
         }
     }
     if (nlist > 0)
     {
         // the rows outside the copy: all columns at the row, from the full-length arrays (which hold the new pair)
-        const T* cp[NCL];
-        (void) lane_cols_x<T, NCL, G>(s_full, ncols, L, cp);
+        gptr_x<T> cp[NCL];
+        lane_cols_x<T, NCL, G>(s_full, L, cp);
         const int64_t last = nlist - 1;
         for (int64_t base = (int64_t(blockIdx.x) * kWaves + L.wave) * RPW; base < int64_t(nlist); base += stride)
         {
@@ -558,8 +701,8 @@ __global__ void __launch_bounds__(kBlock, occ_dots_x(NCL))
         s_col[threadIdx.x] = cols.p[threadIdx.x];
     __syncthreads();
     const LaneX<G> L;
-    const T* cp[NCL];
-    (void) lane_cols_x<T, NCL, G>(s_col, ncols, L, cp);
+    gptr_x<T> cp[NCL];
+    lane_cols_x<T, NCL, G>(s_col, L, cp);
     Accs<A, NL> accs;
     A(&acc)[NL] = accs.v;
     const int64_t stride = int64_t(gridDim.x) * kWaves * RPW;
@@ -617,8 +760,8 @@ __global__ void __launch_bounds__(kBlock, occ_dots_x(NCL))
         s_col[threadIdx.x] = cols.p[threadIdx.x];
     __syncthreads();
     const LaneX<G> L;
-    const T* cp[NCL];
-    (void) lane_cols_x<T, NCL, G>(s_col, ncols, L, cp);
+    gptr_x<T> cp[NCL];
+    lane_cols_x<T, NCL, G>(s_col, L, cp);
     Accs<A, NL> accs;
     A(&acc)[NL] = accs.v;
     const int64_t stride = int64_t(gridDim.x) * kWaves * RPW;
@@ -698,8 +841,8 @@ __global__ void __launch_bounds__(kBlock, occ_mask_x(NCL))
         s_col[threadIdx.x] = cols.p[threadIdx.x];
     __syncthreads();
     const LaneX<G> L;
-    const T* cp[NCL];
-    (void) lane_cols_x<T, NCL, G>(s_col, ncols, L, cp);
+    gptr_x<T> cp[NCL];
+    lane_cols_x<T, NCL, G>(s_col, L, cp);
     Accs<A, NL> accs;
     A(&acc)[NL] = accs.v;
     const int64_t stride = int64_t(gridDim.x) * kWaves * 256;
@@ -853,7 +996,7 @@ __global__ void __launch_bounds__(kBlock)
                 double v[8];
 #pragma unroll
                 for (int u = 0; u < 8; u++)
-                    v[u] = (c0 + u < c_hi) ? double(s_col[c0 + u][wr]) : 0.0;
+                    v[u] = (c0 + u < c_hi) ? double(((gptr_x<T>) s_col[c0 + u])[wr]) : 0.0;
 #pragma unroll
                 for (int u = 0; u < 8; u++)
                     if (c0 + u < c_hi)
@@ -1007,7 +1150,7 @@ __global__ void __launch_bounds__(kBlock) kx_wf_append(ColsX<T> orig, int ncols,
         wf_idx[slot] = row;
         pos[row] = int(slot);
         for (int k = 0; k < ncols; k++)
-            wf[int64_t(k) * wf_ld + slot] = s_col[k][row];
+            wf[int64_t(k) * wf_ld + slot] = ((gptr_x<T>) s_col[k])[row];
     }
 }
 

@@ -34,12 +34,18 @@ int rows(hipStream_t s, int num_cus, int na, const ColsX<T>& cols, int ncols, co
     if (ncols < 1 || ncols > kColsX || (na != 1 && na != 3))
         return LBFGSX_E_INVALID;
 #define CALL(NCL, G)                                                                                                           \
-    if (na == 1)                                                                                                               \
-        LBFGSX_LAUNCH((kx_rows<T, NCL, G, 1>), dim3(grid_rows(n, 64 / G, occ_rows_x(NCL, G, 1), num_cus)), dim3(kBlock), 0, s, cols, ncols, \
-                      b, vsel_id, mask, n, ws, out, out_dd, pro, gr, col_a, col_b);                                            \
+    if (na == 1 && gr.in_idx)                                                                                                  \
+        LBFGSX_LAUNCH((kx_rows<T, NCL, G, 1, true>), dim3(grid_rows(n, 64 / G, occ_rows_x(NCL, G, 1), num_cus)), dim3(kBlock), 0, s, \
+                      cols, ncols, b, vsel_id, mask, n, ws, out, out_dd, pro, gr, col_a, col_b);                               \
+    else if (na == 1)                                                                                                          \
+        LBFGSX_LAUNCH((kx_rows<T, NCL, G, 1, false>), dim3(grid_rows(n, 64 / G, occ_rows_x(NCL, G, 1), num_cus)), dim3(kBlock), 0, s, \
+                      cols, ncols, b, vsel_id, mask, n, ws, out, out_dd, pro, gr, col_a, col_b);                               \
+    else if (gr.in_idx)                                                                                                        \
+        LBFGSX_LAUNCH((kx_rows<T, NCL, G, 3, true>), dim3(grid_rows(n, 64 / G, occ_rows_x(NCL, G, 3), num_cus)), dim3(kBlock), 0, s, \
+                      cols, ncols, b, vsel_id, mask, n, ws, out, out_dd, pro, gr, col_a, col_b);                               \
     else                                                                                                                       \
-        LBFGSX_LAUNCH((kx_rows<T, NCL, G, 3>), dim3(grid_rows(n, 64 / G, occ_rows_x(NCL, G, 3), num_cus)), dim3(kBlock), 0, s, cols, ncols, \
-                      b, vsel_id, mask, n, ws, out, out_dd, pro, gr, col_a, col_b)
+        LBFGSX_LAUNCH((kx_rows<T, NCL, G, 3, false>), dim3(grid_rows(n, 64 / G, occ_rows_x(NCL, G, 3), num_cus)), dim3(kBlock), 0, s, \
+                      cols, ncols, b, vsel_id, mask, n, ws, out, out_dd, pro, gr, col_a, col_b)
     LBFGSX_XCLASS(ncols, CALL);
 #undef CALL
     LBFGSX_HIP(hipGetLastError());
@@ -53,15 +59,21 @@ int solve_sweep(hipStream_t s, int num_cus, int first, const ColsX<T>& cols, int
 {
     if (ncols < 1 || ncols > kColsX)
         return LBFGSX_E_INVALID;
-#define CALL(NCL, G)                                                                                                              \
-    if (first)                                                                                                                    \
-        LBFGSX_LAUNCH((kx_solve_sweep<T, NCL, G, 1>), dim3(grid_rows(n, 64 / G, occ_sweep_x(NCL, G, 1), num_cus)), dim3(kBlock), 0, s, cols,    \
-                      ncols, b, bw, vsel_id, coef, has_w, theta, n, ws, out, lu_list, lu_cnt, lu_cap, ridx, cli, cui, cv);        \
-    else                                                                                                                          \
-        LBFGSX_LAUNCH((kx_solve_sweep<T, NCL, G, 0>), dim3(grid_rows(n, 64 / G, occ_sweep_x(NCL, G, 0), num_cus)), dim3(kBlock), 0, s, cols,    \
-                      ncols, b, bw, vsel_id, coef, has_w, theta, n, ws, out, lu_list, lu_cnt, lu_cap, ridx, cli, cui, cv)
+#define SWEEP(FIRST, IDX)                                                                                                         \
+    LBFGSX_LAUNCH((kx_solve_sweep<T, NCL_, G_, FIRST, IDX>), dim3(grid_rows(n, 64 / G_, occ_sweep_x(NCL_, G_, FIRST), num_cus)),        \
+                  dim3(kBlock), 0, s, cols, ncols, b, bw, vsel_id, coef, has_w, theta, n, ws, out, lu_list, lu_cnt, lu_cap, ridx, cli,  \
+                  cui, cv)
+#define CALL(NCL, G)                            \
+    {                                           \
+        constexpr int NCL_ = NCL, G_ = G;       \
+        if (first && ridx) SWEEP(1, true);      \
+        else if (first) SWEEP(1, false);        \
+        else if (ridx) SWEEP(0, true);          \
+        else SWEEP(0, false);                   \
+    }
     LBFGSX_XCLASS(ncols, CALL);
 #undef CALL
+#undef SWEEP
     LBFGSX_HIP(hipGetLastError());
     return LBFGSX_OK;
 }

@@ -374,14 +374,14 @@ static int create_fill(lbfgsx_ctx* c, int dtype, int64_t n, int m, int device, i
         const char* e = getenv("LBFGSX_MAPPED_OUT");
         if (e ? atoi(e) != 0 : (flags & LBFGSX_FLAG_BOUNDED) != 0)
         {
-            LBFGSX_HIP(hipHostMalloc(&c->outmap_host, sizeof(double) * 16, hipHostMallocMapped));
+            LBFGSX_HIP(hipHostMalloc(&c->outmap_host, sizeof(double) * 16, hipHostMallocMapped | hipHostMallocCoherent));
             std::memset(c->outmap_host, 0, sizeof(double) * 16);
             LBFGSX_HIP(hipHostGetDevicePointer(&c->outmap_dev, c->outmap_host, 0));
             // polled completion of the kernels whose results land there (ctx.hpp: poll_arm / poll_wait)
             const char* pe = getenv("LBFGSX_POLL");
             if (!(pe && atoi(pe) == 0))
             {
-                LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->done_host), 64, hipHostMallocMapped));
+                LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->done_host), 64, hipHostMallocMapped | hipHostMallocCoherent));
                 std::memset(c->done_host, 0, 64);
                 LBFGSX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->done_dev), c->done_host, 0));
             }

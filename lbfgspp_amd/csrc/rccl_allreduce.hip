@@ -17,9 +17,13 @@
 #include <dlfcn.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
+#include <cstdlib>
+#include <thread>
 #include <cstdint>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -45,6 +49,7 @@ struct Rccl2
     ncclResult_t (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GetVersion)(int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;
     bool ok() const { return CommInitAll && CommInitRank && GetUniqueId && CommDestroy && AllReduce; }
 };
 Rccl2& rccl2()
@@ -66,6 +71,7 @@ Rccl2& rccl2()
         SYM(AllReduce, "ncclAllReduce");
         SYM(GetVersion, "ncclGetVersion");
         SYM(GetErrorString, "ncclGetErrorString");
+        SYM(CommGetAsyncError, "ncclCommGetAsyncError");
 #undef SYM
     });
     return r;
@@ -76,12 +82,23 @@ constexpr int kNcclFloat64 = 8, kNcclSum = 0;
 struct Rank
 {
     int device = 0;
+    // `comm` is used by the rank's own thread (the all-reduce) and taken away by whichever thread aborts the communicator:
+    // both under `mu`, so that a reducer never hands RCCL a communicator that lbfgsx_comm_abort has just freed
+    std::mutex mu;
     ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr;
     double* dev = nullptr;      // [kMaxBundle] send = receive buffer (in place)
     double* host = nullptr;     // pinned staging [kMaxBundle]
-    int64_t calls = 0;
+    std::atomic<int64_t> calls{0};
 };
+// how long a rank waits for its all-reduce before it gives the communicator up (a peer PROCESS that died cannot call
+// lbfgsx_comm_abort for us; LBFGSX_COMM_TIMEOUT_S, default 300 s)
+double comm_timeout_s()
+{
+    const char* e = std::getenv("LBFGSX_COMM_TIMEOUT_S");
+    const double v = e ? std::atof(e) : 300.0;
+    return v > 0.0 ? v : 300.0;
+}
 
 }  // namespace
 
@@ -91,8 +108,9 @@ struct lbfgsx_comm
     int nlocal = 0;      // of which driven by this process
     int first_rank = 0;  // global rank of local rank 0
     bool use_rccl = false;
-    std::vector<Rank> ranks;
+    std::vector<std::unique_ptr<Rank> > ranks;  // (a Rank holds a mutex: not movable)
     std::atomic<int> aborted{0};
+    std::atomic<int> first_abort{-1};  // local rank whose failure aborted the communicator (-1: none / unknown)
     // host-side emulation (a device listed twice): the ranks' bundles summed in rank order behind a barrier
     std::mutex mu;
     std::condition_variable cv;
@@ -125,7 +143,24 @@ void destroy_rank(Rank& k, bool rccl_up)
         (void) hipHostFree(k.host);
     if (k.stream)
         (void) hipStreamDestroy(k.stream);
-    k = Rank();
+    k.comm = nullptr;
+    k.stream = nullptr;
+    k.dev = k.host = nullptr;
+}
+// take the rank's communicator away and abort it (idempotent; any thread)
+void abort_rank(Rank& k)
+{
+    ncclComm_t cm = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(k.mu);
+        cm = k.comm;
+        k.comm = nullptr;
+    }
+    if (cm && rccl2().CommAbort)
+    {
+        lbfgsx::DeviceGuard g(k.device);
+        (void) rccl2().CommAbort(cm);
+    }
 }
 
 int alloc_rank(Rank& k, int device)
@@ -178,14 +213,14 @@ int lbfgsx_comm_create_rank(lbfgsx_comm** out, int device, int rank, int nranks,
     c->nlocal = 1;
     c->first_rank = rank;
     c->use_rccl = true;
-    c->ranks.resize(1);
-    int rc = alloc_rank(c->ranks[0], device);
+    c->ranks.emplace_back(new Rank);
+    int rc = alloc_rank(*c->ranks[0], device);
     if (rc == LBFGSX_OK)
     {
         lbfgsx::DeviceGuard g(device);
         NcclId u;
         std::memcpy(u.internal, id, 128);
-        const ncclResult_t r = R.CommInitRank(&c->ranks[0].comm, nranks, u, rank);
+        const ncclResult_t r = R.CommInitRank(&c->ranks[0]->comm, nranks, u, rank);
         if (r != 0)
         {
             lbfgsx::set_error(std::string("ncclCommInitRank: ") + (R.GetErrorString ? R.GetErrorString(r) : "RCCL error"));
@@ -194,7 +229,7 @@ int lbfgsx_comm_create_rank(lbfgsx_comm** out, int device, int rank, int nranks,
     }
     if (rc != LBFGSX_OK)
     {
-        destroy_rank(c->ranks[0], false);
+        destroy_rank(*c->ranks[0], false);
         delete c;
         return rc;
     }
@@ -236,12 +271,13 @@ int lbfgsx_comm_create_local(lbfgsx_comm** out, const int* devices, int ndev)
         lbfgsx::set_error("lbfgsx_comm_create_local: librccl.so could not be loaded");
         return LBFGSX_E_RUNTIME;
     }
-    c->ranks.resize(size_t(ndev));
+    for (int r = 0; r < ndev; r++)
+        c->ranks.emplace_back(new Rank);
     c->slots.assign(size_t(ndev) * kMaxBundle, 0.0);
     c->total.assign(kMaxBundle, 0.0);
     int rc = LBFGSX_OK;
     for (int r = 0; r < ndev && rc == LBFGSX_OK; r++)
-        rc = alloc_rank(c->ranks[size_t(r)], devices[r]);
+        rc = alloc_rank(*c->ranks[size_t(r)], devices[r]);
     bool up = false;
     if (rc == LBFGSX_OK && c->use_rccl)
     {
@@ -256,13 +292,13 @@ int lbfgsx_comm_create_local(lbfgsx_comm** out, const int* devices, int ndev)
         {
             up = true;
             for (int k = 0; k < ndev; k++)
-                c->ranks[size_t(k)].comm = comms[size_t(k)];
+                c->ranks[size_t(k)]->comm = comms[size_t(k)];
         }
     }
     if (rc != LBFGSX_OK)
     {
         for (auto& k : c->ranks)
-            destroy_rank(k, up);
+            destroy_rank(*k, up);
         delete c;
         return rc;
     }
@@ -282,8 +318,8 @@ int lbfgsx_comm_allreduce_sum(lbfgsx_comm* c, int local_rank, double* buf, int c
         lbfgsx::set_error("lbfgsx_comm_allreduce_sum: the communicator was aborted by another rank");
         return LBFGSX_E_RUNTIME;
     }
-    Rank& k = c->ranks[size_t(local_rank)];
-    k.calls++;
+    Rank& k = *c->ranks[size_t(local_rank)];
+    k.calls.fetch_add(1, std::memory_order_relaxed);
     if (c->nranks == 1 && !c->use_rccl)
         return LBFGSX_OK;
     if (c->use_rccl)  // also with a single rank: the call is the same, the sum trivial
@@ -292,14 +328,66 @@ int lbfgsx_comm_allreduce_sum(lbfgsx_comm* c, int local_rank, double* buf, int c
         Rccl2& R = rccl2();
         std::memcpy(k.host, buf, sizeof(double) * size_t(count));
         LBFGSX_HIP(lbfgsx::copy_async(k.dev, k.host, sizeof(double) * size_t(count), hipMemcpyHostToDevice, k.stream));
-        const ncclResult_t r = R.AllReduce(k.dev, k.dev, size_t(count), kNcclFloat64, kNcclSum, k.comm, k.stream);
-        if (r != 0)
         {
-            lbfgsx::set_error(std::string("ncclAllReduce: ") + (R.GetErrorString ? R.GetErrorString(r) : "RCCL error"));
-            return LBFGSX_E_RUNTIME;
+            // the communicator is handed to RCCL under the rank's lock: lbfgsx_comm_abort takes it away under the same lock, so
+            // it is either still whole here or gone (null) -- never freed in between
+            std::lock_guard<std::mutex> lock(k.mu);
+            if (c->aborted.load() || !k.comm)
+            {
+                lbfgsx::set_error("lbfgsx_comm_allreduce_sum: the communicator was aborted by another rank");
+                return LBFGSX_E_RUNTIME;
+            }
+            const ncclResult_t r = R.AllReduce(k.dev, k.dev, size_t(count), kNcclFloat64, kNcclSum, k.comm, k.stream);
+            if (r != 0)
+            {
+                lbfgsx::set_error(std::string("ncclAllReduce: ") + (R.GetErrorString ? R.GetErrorString(r) : "RCCL error"));
+                return LBFGSX_E_RUNTIME;
+            }
         }
         LBFGSX_HIP(lbfgsx::copy_async(k.host, k.dev, sizeof(double) * size_t(count), hipMemcpyDeviceToHost, k.stream));
-        LBFGSX_HIP(lbfgsx::stream_sync(k.stream));
+        // Wait for the collective with an eye on the communicator: a peer thread that fails aborts it (the flag), a peer
+        // PROCESS that dies cannot -- RCCL's asynchronous error and, as the last resort, a time-out end the wait; this rank then
+        // aborts its own communicator, which also releases the kernel that is stuck on the stream.
+        lbfgsx::counters().syncs.fetch_add(1, std::memory_order_relaxed);
+        const auto t0 = std::chrono::steady_clock::now();
+        const double limit = comm_timeout_s();
+        for (unsigned spin = 0;; spin++)
+        {
+            const hipError_t q = hipStreamQuery(k.stream);
+            if (q == hipSuccess)
+                break;
+            if (q != hipErrorNotReady)
+            {
+                (void) hipGetLastError();
+                lbfgsx::set_error(std::string("lbfgsx_comm_allreduce_sum: ") + hipGetErrorString(q));
+                return LBFGSX_E_HIP;
+            }
+            if ((spin & 255u) != 255u)
+                continue;
+            const char* why = nullptr;
+            if (c->aborted.load())
+                why = "the communicator was aborted by another rank";
+            else if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit)
+                why = "timed out waiting for the other ranks (LBFGSX_COMM_TIMEOUT_S)";
+            else if (R.CommGetAsyncError)
+            {
+                ncclResult_t ae = 0;
+                std::lock_guard<std::mutex> lock(k.mu);
+                if (k.comm && R.CommGetAsyncError(k.comm, &ae) == 0 && ae != 0)
+                    why = "RCCL reported an asynchronous error (a peer rank is gone?)";
+            }
+            if (why)
+            {
+                c->aborted.store(1);
+                abort_rank(k);
+                (void) hipStreamSynchronize(k.stream);
+                (void) hipGetLastError();
+                lbfgsx::set_error(std::string("lbfgsx_comm_allreduce_sum: ") + why);
+                return LBFGSX_E_RUNTIME;
+            }
+            if (spin > 200000u)
+                std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
         std::memcpy(buf, k.host, sizeof(double) * size_t(count));
         return LBFGSX_OK;
     }
@@ -340,17 +428,27 @@ int lbfgsx_comm_abort(lbfgsx_comm* c)
     if (!c)
         return LBFGSX_E_INVALID;
     c->aborted.store(1);
-    if (c->use_rccl && rccl2().CommAbort)
+    // every rank's communicator is taken under that rank's lock (see lbfgsx_comm_allreduce_sum): a reducer that is about to
+    // call RCCL finds it whole or gone.  Ranks of other PROCESSES are not reached from here: they leave through RCCL's
+    // asynchronous error or the time-out of their own wait.
+    if (c->use_rccl)
         for (auto& k : c->ranks)
-            if (k.comm)
-            {
-                (void) rccl2().CommAbort(k.comm);
-                k.comm = nullptr;
-            }
+            abort_rank(*k);
     std::lock_guard<std::mutex> lock(c->mu);
     c->cv.notify_all();
     return LBFGSX_OK;
 }
+
+int lbfgsx_comm_abort_from(lbfgsx_comm* c, int local_rank)
+{
+    if (!c)
+        return LBFGSX_E_INVALID;
+    int none = -1;
+    (void) c->first_abort.compare_exchange_strong(none, local_rank);
+    return lbfgsx_comm_abort(c);
+}
+
+int lbfgsx_comm_first_abort(const lbfgsx_comm* c) { return c ? c->first_abort.load() : -1; }
 
 int lbfgsx_comm_info(const lbfgsx_comm* c, int info[4])
 {
@@ -367,7 +465,7 @@ int lbfgsx_comm_info(const lbfgsx_comm* c, int info[4])
 
 int64_t lbfgsx_comm_calls(const lbfgsx_comm* c, int local_rank)
 {
-    return (c && local_rank >= 0 && local_rank < c->nlocal) ? c->ranks[size_t(local_rank)].calls : -1;
+    return (c && local_rank >= 0 && local_rank < c->nlocal) ? c->ranks[size_t(local_rank)]->calls.load() : -1;
 }
 
 void* lbfgsx_comm_hook_arg(lbfgsx_comm* c, int local_rank)
@@ -388,7 +486,7 @@ void lbfgsx_comm_allreduce_hook(double* buf, int count, void* hook_arg)
         // the hook has no way to return an error: poison the bundle, the driver's line search then stops with a NaN
         // objective on every rank that still runs, and mark the communicator so that the other ranks do not wait
         if (h)
-            (void) lbfgsx_comm_abort(h->comm);
+            (void) lbfgsx_comm_abort_from(h->comm, h->rank);
         for (int j = 0; j < count; j++)
             buf[j] = __builtin_nan("");
     }
@@ -408,7 +506,7 @@ void lbfgsx_comm_destroy(lbfgsx_comm* c)
             }
     }
     for (auto& k : c->ranks)
-        destroy_rank(k, c->use_rccl && !c->aborted.load());
+        destroy_rank(*k, c->use_rccl);  // an aborted rank's communicator is already gone (null)
     delete c;
 }
 

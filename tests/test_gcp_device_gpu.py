@@ -89,6 +89,44 @@ def test_cfg4_parity_at_size(A, boracle, monkeypatch, n, iters, devmin):
     assert abs(fx - r_ref.fx) <= 1e-11 * abs(r_ref.fx)
 
 
+def test_cfg4_parity_at_size_over_14_iterations_against_the_cached_reference_trace(A):
+    """The same comparison over 14 iterations (35 objective evaluations) of the benchmark's own instance without paying the
+    reference's ~280 s of one host core on every run: tests/golden/cfg4_1e7_trace.npz holds what oracle/_ref produced for
+    it (tests/golden/make_cfg4_trace.py: the objective value and every 4000th coordinate at every evaluation, every 500th
+    coordinate of the final iterate, the counts, the size of the active set) and the key of the oracle build it came from
+    (oracle/_ref/build_key.txt: reference headers + stand-in Eigen + driver + flags).  A stale key means the reference side
+    has changed since the trace was taken: the test then refuses to judge instead of comparing against the wrong thing."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg4_1e7_trace.npz")
+    keyf = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "build_key.txt")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/cfg4_1e7_trace.npz missing (python tests/golden/make_cfg4_trace.py)")
+    g = np.load(path)
+    if os.path.exists(keyf) and open(keyf).read().strip() != str(g["key"]):
+        pytest.fail("tests/golden/cfg4_1e7_trace.npz was taken from another oracle build: regenerate it "
+                    "(python tests/golden/make_cfg4_trace.py)")
+    n, m, iters, stride, fstride = int(g["n"]), int(g["m"]), int(g["iters"]), int(g["stride"]), int(g["final_stride"])
+    assert (n, m) == (10_000_000, 10) and iters >= 12
+    a, b = O.quad_problem(n, 10.0, 1, O.F64)
+    lb, ub = -np.ones(n), np.ones(n)
+    s = A.LBFGSBSolver(A.LBFGSBParam(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters))
+    tr = A.TraceBuffer(n, cap=256, stride=stride)
+    x = np.zeros(n)
+    niter, fx = s.minimize(A.DiagQuadratic(a, b), x, lb, ub, trace=tr)
+    nfev = s.last.nfev
+    s.close()
+    k = tr.count
+    assert (niter, nfev, k) == (int(g["niter"]), int(g["nfev"]), g["xs"].shape[0])
+    per_eval = np.abs(tr.xs[:k] - g["xs"]).max(axis=1)
+    assert per_eval[:21].max() == 0.0, "first line search: %r" % per_eval[:21]
+    assert per_eval.max() <= 1e-10, "iterates deviate by %.3g at evaluation %d" % (per_eval.max(), int(per_eval.argmax()))
+    frel = np.abs(tr.fx[:k] - g["fx_per_eval"]) / np.abs(g["fx_per_eval"])
+    assert frel.max() <= 1e-11, "objective values deviate by %.3g (relative)" % frel.max()
+    assert np.abs(x[::fstride] - g["x_final"]).max() <= 1e-10
+    assert np.array_equal(np.abs(x[::fstride]) == 1.0, g["active_sample"]) and int((np.abs(x) == 1.0).sum()) == int(g["n_active"])
+    assert abs(fx - float(g["fx"])) <= 1e-11 * abs(float(g["fx"]))
+
+
 @pytest.mark.parametrize("n,m,npairs,mode", [(50000, 6, 6, "hard"), (200000, 10, 10, "edge"), (4096, 8, 0, "hard")])
 def test_device_and_host_search_agree(A, monkeypatch, n, m, npairs, mode):
     """same instance through both forms: identical crossing count and sets; xcp / c agree up to the summation-order

@@ -287,6 +287,45 @@ def test_persistent_two_loop_is_bit_identical(A, oracle, monkeypatch, dtype, n, 
     assert (r.niter, r.nfev) == res["1"][:2] and np.array_equal(res["1"][3], x_ref)
 
 
+@pytest.mark.parametrize("dtype,n,m,ls", [(O.F64, 1000, 6, O.LS_MT), (O.F32, 2050, 5, O.LS_MT), (O.F64, 4094, 10, O.LS_NW),
+                                          (O.F64, 4096, 10, O.LS_NW)])
+def test_default_switch_between_the_step_launches_and_the_persistent_kernel(A, oracle, monkeypatch, dtype, n, m, ls):
+    """The PRODUCT's default: below LBFGSX_PERSIST_MIN_N = 4096 elements apply_Hv is the 2c+1 step launches, from there on the
+    persistent kernel (tests/conftest.py lifts the threshold for the rest of the suite).  With the environment variable
+    removed the switch must sit exactly there, and both forms must give the bits of the other and of the oracle."""
+    import ctypes as C
+    import gc
+    core, _ = A.load()
+    core.lbfgsx_persistent_launches.restype = C.c_int64
+    core.lbfgsx_persistent_launches.argtypes = [C.c_void_p]
+    obj, oobj = (A.ExtendedRosenbrock(), O.OBJ_ROSEN) if ls == O.LS_MT else (None, O.OBJ_QUAD)
+    a = b = None
+    if obj is None:
+        a, b = O.quad_problem(n, 10.0, 1, dtype)
+        obj = A.DiagQuadratic(a, b)
+    x0 = O.rosen_x0(n + (n % 2), 11, dtype)[:n] if ls == O.LS_MT else np.zeros(n, O.NPDT[dtype])
+    if ls == O.LS_MT and n % 2:
+        pytest.skip("the extended Rosenbrock objective needs an even n")
+    res = {}
+    for mode in ("default", "lifted"):
+        if mode == "default":
+            monkeypatch.delenv("LBFGSX_PERSIST_MIN_N", raising=False)
+        else:
+            monkeypatch.setenv("LBFGSX_PERSIST_MIN_N", "0")
+        gc.collect()
+        s = A.LBFGSSolver(A.LBFGSParam(m=m, epsilon=0.0, epsilon_rel=0.0, max_iterations=2 * m + 5), linesearch=ls, dtype=O.NPDT[dtype])
+        x = x0.copy()
+        niter, fx = s.minimize(obj, x)
+        res[mode] = (niter, s.last.nfev, fx, x, int(core.lbfgsx_persistent_launches(s.ctx)))
+        del s
+        gc.collect()
+    assert res["lifted"][4] > 0
+    assert (res["default"][4] == 0) == (n < 4096), "n = %d: %d persistent launches by default" % (n, res["default"][4])
+    assert res["default"][:3] == res["lifted"][:3] and np.array_equal(res["default"][3], res["lifted"][3])
+    x_ref, r = oracle.lbfgs(dtype, ls, oobj, x0, O.lbfgs_params(m=m, epsilon=0, epsilon_rel=0, max_iterations=2 * m + 5), a=a, b=b)
+    assert (r.niter, r.nfev) == res["default"][:2] and np.array_equal(res["default"][3], x_ref)
+
+
 def _spec_counts(A, s):
     import ctypes as C
     core, _ = A.load()

@@ -893,4 +893,4 @@ def test_rows_split_over_lanes_change_no_bit(A, monkeypatch, n, m, iters, max_su
     if dtype == "f64":
         assert f[6] >= f[7] // 4, "the carried form ran in %d of %d subspace minimisations" % (f[6], f[7])
     if m > 10:
-        assert u[6] == 0   # the one-entry-per-lane kernel has 64 lanes
+        assert u[6] <= 10   # the one-entry-per-lane kernel has 64 lanes: only while the history holds <= 10 pairs

@@ -280,3 +280,137 @@ def test_set_devices_refuses_what_it_cannot_shard(A):
     sb = A.LBFGSBSolver(A.LBFGSBParam(m=4))
     with pytest.raises(ValueError):
         sb.set_devices([0, 0])
+
+
+# ---- real peers: run as soon as a box has two GPUs (the 1-GPU test box skips them; the driver's 8-GPU node does not) -------
+def _need_two_gpus(A):
+    core, _ = A.load()
+    ndev = core.lbfgsx_device_count()
+    if ndev < 2:
+        pytest.skip("needs >= 2 GPUs: RCCL between distinct devices (this box has %d)" % ndev)
+    return ndev
+
+
+def test_multi_gpu_allreduce_over_distinct_devices(A):
+    """lbfgsx_comm_create_local over ALL devices of the node (ncclCommInitAll with distinct peers, xGMI), one host thread per
+    device: 40 all-reduces of the solver's bundle size in a row; every rank ends with the same bits and the sums are right."""
+    from lbfgspp_amd import _lib as L
+    core, _ = A.load()
+    ndev = _need_two_gpus(A)
+    comm, info = _comm_local(A, list(range(ndev)))
+    assert info[:3] == (ndev, ndev, 1)
+    rng = np.random.default_rng(11)
+    rounds = [[rng.standard_normal(67) for _ in range(ndev)] for _ in range(40)]
+    got = [[None] * 40 for _ in range(ndev)]
+    errs = []
+
+    def worker(r):
+        try:
+            for k in range(40):
+                v = rounds[k][r].copy()
+                L.check(core.lbfgsx_comm_allreduce_sum(comm, r, v.ctypes.data_as(C.POINTER(C.c_double)), 67))
+                got[r][k] = v
+        except BaseException as e:  # noqa: B902
+            errs.append(e)
+            core.lbfgsx_comm_abort(comm)
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(ndev)]
+    [t.start() for t in th]
+    [t.join(120) for t in th]
+    assert not errs, errs
+    for k in range(40):
+        want = np.sum(rounds[k], axis=0)
+        for r in range(ndev):
+            assert np.array_equal(got[r][k], got[0][k])                    # identical bits on every rank
+            assert np.allclose(got[r][k], want, rtol=1e-14, atol=1e-14)     # RCCL's order of additions is its own
+    assert all(core.lbfgsx_comm_calls(comm, r) == 40 for r in range(ndev))
+    core.lbfgsx_comm_destroy(comm)
+
+
+def test_multi_gpu_record_allgather_over_distinct_devices(A):
+    """lbfgsx_rccl_allgather_records with one rank per physical GPU: every device ends with all records, in problem-id
+    order, bit for bit."""
+    from lbfgspp_amd import _lib as L
+    core, _ = A.load()
+    ndev = _need_two_gpus(A)
+    count, rec = 1000 * ndev + 7, 40                                        # not a multiple of the device count
+    raw = np.random.default_rng(5).integers(0, 256, size=(count, rec), dtype=np.uint8)
+    dv = (C.c_int * ndev)(*range(ndev))
+    outp = (C.c_void_p * ndev)()
+    L.check(core.lbfgsx_rccl_allgather_records(dv, ndev, raw.ctypes.data_as(C.c_void_p), count, rec, outp))
+    try:
+        for k in range(ndev):
+            back = np.zeros_like(raw)
+            L.check(core.lbfgsx_device_download(k, outp[k], raw.size, back.ctypes.data_as(C.c_void_p)))
+            assert np.array_equal(back, raw), "device %d" % k
+    finally:
+        for k in range(ndev):
+            core.lbfgsx_device_free(k, outp[k])
+
+
+@pytest.mark.parametrize("obj,n,m,iters", [("rosen", 400000, 6, 25), ("quad", 300004, 10, 20)])
+def test_multi_gpu_set_devices_against_the_oracle(A, oracle, obj, n, m, iters):
+    """LBFGSSolver::set_devices over two and over all physical GPUs: the row-sharded run (sums through ncclAllReduce over
+    xGMI) against the oracle's vector two-loop -- same counts, every coordinate within 1e-8 (the stated window of the opt-in
+    Gram-space recursion) -- and against the single-device Gram-space run (1e-9)."""
+    from lbfgspp_amd import _lib as L
+    ndev = _need_two_gpus(A)
+    ls = O.LS_MT if obj == "rosen" else O.LS_NW
+    a, b = O.quad_problem(n) if obj == "quad" else (None, None)
+    x0 = O.rosen_x0(n, 9) if obj == "rosen" else np.zeros(n)
+    f = A.ExtendedRosenbrock() if obj == "rosen" else A.DiagQuadratic(a, b)
+    par = A.LBFGSParam(m=m, epsilon=0.0, epsilon_rel=0.0, max_iterations=iters)
+    x_ref, r = oracle.lbfgs(O.F64, ls, O.OBJ_ROSEN if obj == "rosen" else O.OBJ_QUAD, x0,
+                            O.lbfgs_params(m=m, epsilon=0, epsilon_rel=0, max_iterations=iters), a=a, b=b)
+    s = A.LBFGSSolver(par, linesearch=ls)
+    s.set_recursion(L.RECURSION_GRAM_SPACE)
+    x1 = x0.copy()
+    niter1, fx1 = s.minimize(f, x1)
+    for devs in sorted({(0, 1), tuple(range(ndev))}):
+        s.set_devices(list(devs))
+        x = x0.copy()
+        niter, fx = s.minimize(f, x)
+        assert (niter, s.last.nfev) == (r.niter, r.nfev) == (niter1, s.last.nfev)
+        assert np.abs(x - x1).max() <= 1e-9 and np.abs(x - x_ref).max() <= 1e-8
+        assert abs(fx - r.fx) <= 1e-8 * max(1.0, abs(r.fx))
+    s.set_devices([])
+
+
+def test_abort_while_ranks_reduce_is_safe(A):
+    """lbfgsx_comm_abort used to free a rank's RCCL communicator while that rank's thread could be between
+    its `aborted` check and ncclAllReduce.  The communicator is now handed to RCCL and taken away under the rank's lock: ranks
+    that reduce in a loop while another thread aborts must all come back with LBFGSX_E_RUNTIME (or success for calls that
+    completed before), never crash; lbfgsx_comm_first_abort names the rank that reported its failure."""
+    from lbfgspp_amd import _lib as L
+    core, _ = A.load()
+    core.lbfgsx_comm_abort_from.restype, core.lbfgsx_comm_abort_from.argtypes = C.c_int, [C.c_void_p, C.c_int]
+    core.lbfgsx_comm_first_abort.restype, core.lbfgsx_comm_first_abort.argtypes = C.c_int, [C.c_void_p]
+    ndev = core.lbfgsx_device_count()
+    for devices in ([0], list(range(ndev)) if ndev > 1 else [0, 0]):
+        comm, info = _comm_local(A, devices)
+        assert core.lbfgsx_comm_first_abort(comm) == -1
+        world = len(devices)
+        codes = [[] for _ in range(world)]
+        stop = threading.Event()
+
+        def worker(r):
+            v = np.ones(16)
+            while not stop.is_set():
+                rc = core.lbfgsx_comm_allreduce_sum(comm, r, v.ctypes.data_as(C.POINTER(C.c_double)), 16)
+                codes[r].append(rc)
+                if rc != 0:
+                    break
+                v[:] = 1.0
+        th = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+        [t.start() for t in th]
+        import time
+        time.sleep(0.05)
+        core.lbfgsx_comm_abort_from(comm, world - 1)
+        stop.set()
+        [t.join(30) for t in th]
+        assert not any(t.is_alive() for t in th)
+        for r in range(world):
+            assert all(c == 0 for c in codes[r][:-1]) and codes[r][-1] in (0, L.E_RUNTIME)
+        assert core.lbfgsx_comm_first_abort(comm) == world - 1
+        v = np.ones(4)
+        assert core.lbfgsx_comm_allreduce_sum(comm, 0, v.ctypes.data_as(C.POINTER(C.c_double)), 4) == L.E_RUNTIME
+        core.lbfgsx_comm_destroy(comm)
