@@ -182,6 +182,14 @@ struct lbfgsb_state
     double* xp2 = nullptr;
     unsigned* xtickets = nullptr;
     int gtile = 3;                    // 256-entry tiles the Gram buffers hold: >= (2m + 1)(2m + 2) / 2 entries
+    // lbfgsx_b_cauchy_finish also evaluates drt = xcp - x0 (the statement lbfgsx_b_sub_begin would run next) and lists the rows
+    // it made newly active; both hold until another bounded entry runs (need_bounded's keep_fin)
+    bool fin_fuse = true;             // LBFGSX_FINISH_FUSE=0: the separate passes
+    bool drt_ready = false;
+    int* na_list = nullptr;           // [na_cap] newly active rows, in arrival order
+    unsigned* na_cnt = nullptr;
+    unsigned na_cap = 1u << 16;
+    int64_t na_n = -1;                // entries of the list, -1: none / overflowed
     static constexpr int kDout = 256; // doubles of `dout`
 };
 
@@ -301,12 +309,17 @@ static int delta_alloc(lbfgsx_ctx* c);
 // entry gets them back at their rows first
 // keep_stash: the caller launches or consumes the Grams launched ahead (lbfgsb_state::stash_*); any other entry may change
 // what they were computed from and drops them
-static int need_bounded(lbfgsx_ctx* c, bool keep_force = false, bool keep_cv = false, bool keep_stash = false)
+static int need_bounded(lbfgsx_ctx* c, bool keep_force = false, bool keep_cv = false, bool keep_stash = false, bool keep_fin = false)
 {
     if (!c->bstate)
     {
         set_error("this context was not created with LBFGSX_FLAG_BOUNDED");
         return LBFGSX_E_LOGIC;
+    }
+    if (!keep_fin)  // what lbfgsx_b_cauchy_finish left for the two entries that follow it (sub_begin, W_A'(A'd))
+    {
+        c->bstate->drt_ready = false;
+        c->bstate->na_n = -1;
     }
     if (!keep_stash)
         for (int q = 0; q < 3; q++)
@@ -411,6 +424,13 @@ int bounded_alloc(lbfgsx_ctx* c)
         b->vrows = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_SPLIT"))
         b->split = atoi(e) != 0;
+    if (const char* e = getenv("LBFGSX_FINISH_FUSE"))
+        b->fin_fuse = atoi(e) != 0;
+    if (const char* e = getenv("LBFGSX_NEWACT_CAP"))  // test aid: a short list overflows
+        b->na_cap = unsigned(std::max(1, std::min(1 << 20, atoi(e))));
+    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->na_list), sizeof(int) * size_t(b->na_cap)));
+    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->na_cnt), sizeof(unsigned)));
+    LBFGSX_HIP(hipMemset(b->na_cnt, 0, sizeof(unsigned)));
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->xp1), sizeof(double) * size_t(kMaxGridX) * kMaxSumsX * 2));
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->xp2), sizeof(double) * size_t(kMaxGridX / kGroupX) * kMaxSumsX * 2));
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->xtickets), sizeof(unsigned) * (2 + kMaxGridX / kGroupX)));
@@ -554,6 +574,8 @@ void bounded_free(lbfgsx_ctx* c)
     if (b->stash_host)
         (void) hipHostFree(b->stash_host);
     (void) hipFree(b->cv_buf);
+    (void) hipFree(b->na_list);
+    (void) hipFree(b->na_cnt);
     (void) hipFree(b->xp1);
     (void) hipFree(b->xp2);
     (void) hipFree(b->xtickets);
@@ -1876,35 +1898,45 @@ int lbfgsx_b_cauchy_finish(lbfgsx_ctx* c, double t_cross, double tfinal, int cro
     if (rc)
         return rc;
     const int grid = c->grid_for(c->n);
-    double r[2];
+    double r[3] = {0, 0, -1};
+    lbfgsb_state* b = c->bstate;
+    const bool fuse = b->fin_fuse && c->n < (int64_t(1) << 31);
     DISPATCH_T(c, {
         BVecs<T> bv = bvecs<T>(c);
-        c->bstate->lu_valid = false;  // the state bytes are rewritten
-        c->bstate->wf_valid = false;
+        b->lu_valid = false;  // the state bytes are rewritten
+        b->wf_valid = false;
         lbfgsx::poll_arm(c);
         LBFGSX_LAUNCH((k_cauchy_finish<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, T(t_cross), T(tfinal), crossed_all,
-                           c->n, c->ws, c->bstate->dout);
+                           c->n, c->ws, b->dout, fuse ? P<T>(c->d) : static_cast<T*>(nullptr),
+                           fuse ? b->na_list : static_cast<int*>(nullptr), b->na_cnt, b->na_cap);
     });
     LBFGSX_HIP(hipGetLastError());
-    rc = fetch_doubles(c, 2, r);
+    rc = fetch_doubles(c, fuse ? 3 : 2, r);
     if (rc)
         return rc;
     if (nact) *nact = int64_t(r[0]);
     if (nfree) *nfree = int64_t(r[1]);
-    c->bstate->nfree_last = int64_t(r[1]);
+    b->nfree_last = int64_t(r[1]);
+    b->drt_ready = fuse;
+    b->na_n = (fuse && r[2] >= 0 && r[2] <= double(b->na_cap)) ? int64_t(r[2]) : -1;
     return LBFGSX_OK;
 }
 
 int lbfgsx_b_sub_begin(lbfgsx_ctx* c)
 {
     lbfgsx::DeviceGuard dev_guard_(c->device);
-    int rc = need_bounded(c);
+    int rc = need_bounded(c, false, false, false, /*keep_fin=*/true);
     if (rc)
         return rc;
     const int grid = c->grid_for(c->n);
     c->bstate->sub_epoch++;
     c->bstate->wf_valid = false;  // a compact copy of the free rows belongs to one subspace minimisation
     c->bstate->wf_on = false;
+    if (c->bstate->drt_ready)  // lbfgsx_b_cauchy_finish, the entry right before this one, has evaluated the statement
+    {
+        c->bstate->drt_ready = false;
+        return LBFGSX_OK;
+    }
     DISPATCH_T(c, {
         BVecs<T> bv = bvecs<T>(c);
         LBFGSX_LAUNCH((k_sub_begin<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, c->n);
@@ -1982,9 +2014,32 @@ int lbfgsx_b_set_compaction(lbfgsx_ctx* c, int enable)
 int lbfgsx_b_wtv(lbfgsx_ctx* c, int vsel_id, int mask, double* out, int64_t* nnz)
 {
     lbfgsx::DeviceGuard dev_guard_(c->device);
+    const int64_t na_keep = c->bstate ? c->bstate->na_n : -1;
     int rc = need_bounded(c);
     if (rc)
         return rc;
+    // the newly active rows of the Cauchy search that has just ended, listed by its last pass: W_A'(A'd) over the list
+    if (mask == ST_NEWACT && na_keep >= 0 && c->bstate->split && 2 * c->ncorr >= 1 && 2 * c->ncorr <= kColsX)
+    {
+        lbfgsb_state* b = c->bstate;
+        const int total = 2 * c->ncorr;
+        lbfgsx::poll_arm(c);
+        DISPATCH_T(c, {
+            rc = xl::list1<T>(c->stream, b->num_cus, colsx_full<T>(c, total), total, bvecs<T>(c), vsel_id, mask, b->na_list, int(na_keep),
+                              wsx(c), b->dout);
+        });
+        if (rc)
+            return rc;
+        double r[kColsX + 1];
+        rc = fetch_doubles(c, total + 1, r);
+        if (rc)
+            return rc;
+        for (int k = 0; k < total; k++)
+            out[k] = r[k];
+        if (nnz)
+            *nnz = int64_t(r[total]);
+        return LBFGSX_OK;
+    }
     DISPATCH_T(c, { rc = wtv_t<T>(c, vsel_id, static_cast<const T*>(nullptr), mask, out, nnz); });
     return rc;
 }
@@ -2250,6 +2305,7 @@ static int launch_gram_vonly(lbfgsx_ctx* c, int64_t nbatch, int tot, int vsel_id
 }
 // A Gram over the rows of an index list (2c x 2c, no v row) launched ahead of its request into stash slot `slot`; mask != 0:
 // only the listed rows whose state byte has one of its bits.  false: not launched (the request will launch it itself).
+constexpr int64_t kListOneBlock = 1024;  // rows a single block of kx_gram takes in less time than the three launches of the multi-block form
 static bool gram_stash_feasible(lbfgsx_ctx* c, const int* list, int64_t nlist)
 {
     lbfgsb_state* b = c->bstate;
@@ -2274,10 +2330,15 @@ static bool gram_stash_launch(lbfgsx_ctx* c, int slot, int mask, const int* list
     const int64_t nbatch = (nlist + kGramDDRows - 1) / kGramDDRows;
     int blocks = 1;
     double* out = b->stash_dev + size_t(slot) * (size_t(b->gtile) * 256 * 3);
-    if (tot > kGramDDCS)
+    const bool single = b->split && nlist <= kListOneBlock;
+    if (tot > kGramDDCS || single)
     {
-        // more columns than the wave-private tiles hold: the block-tile kernel (lbfgsb_x.cuh)
+        // the block-tile kernel (lbfgsb_x.cuh): more columns than the wave-private tiles hold, or a list short enough for ONE
+        // block, whose launch then leaves the finished sums itself (no kx_gram_finish launches: one launch instead of three)
         int rcx = LBFGSX_OK;
+        double* out_dd = out + size_t(b->gtile) * 256;
+        if (signal && single)
+            lbfgsx::poll_arm(c);
         DISPATCH_T(c, {
             ProX<T> pro{};
             pro.mode = LBFGSX_GP_NONE;
@@ -2289,17 +2350,21 @@ static bool gram_stash_launch(lbfgsx_ctx* c, int slot, int mask, const int* list
                 gr.st_alt = bvecs_cv<T>(c).st;
                 gr.st_pos = b->wf_pos;
             }
-            blocks = xl::gram<T>(c->stream, b->gram_blocks, colsx_full<T>(c, tot), tot, bvecs<T>(c), -1, mask, nlist, b->gram_partial,
-                                 pro, gr);
+            blocks = xl::gram<T>(c->stream, single ? 1 : b->gram_blocks, colsx_full<T>(c, tot), tot, bvecs<T>(c), -1, mask, nlist,
+                                 b->gram_partial, pro, gr, out, out_dd, (signal && single) ? c->ws.done : static_cast<unsigned long long*>(nullptr),
+                                 (signal && single) ? c->ws.seq : 0ull);
         });
         if (blocks < 1)
             return false;
-        const int nt = xl::gram_kpb(tot);
-        if (signal)
-            lbfgsx::poll_arm(c);
-        rcx = xl::gram_finish(c->stream, b->gram_partial, blocks, nt, b->gram_partial2, out, out + size_t(b->gtile) * 256,
-                              signal ? c->ws.done : static_cast<unsigned long long*>(nullptr), signal ? c->ws.seq : 0ull,
-                              b->xtickets + 1 + kMaxGridX / kGroupX);
+        if (blocks > 1)
+        {
+            const int nt = xl::gram_kpb(tot);
+            if (signal)
+                lbfgsx::poll_arm(c);
+            rcx = xl::gram_finish(c->stream, b->gram_partial, blocks, nt, b->gram_partial2, out, out_dd,
+                                  signal ? c->ws.done : static_cast<unsigned long long*>(nullptr), signal ? c->ws.seq : 0ull,
+                                  b->xtickets + 1 + kMaxGridX / kGroupX);
+        }
         if (rcx != LBFGSX_OK)
             return false;
         b->stash_armed[slot] = true;
@@ -2987,7 +3052,8 @@ static int gram_dd_core(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, cons
         set_error("lbfgsx_b_gram_fused_dd: the un-rounded sums exist for the default one-pass Gram only");
         return LBFGSX_E_INVALID;
     }
-    const bool wide = !b->gram_mfma && ntot > kGramDDCS && b->split;  // kx_gram: the block-tile kernel for 2c + 1 > 31
+    // kx_gram, the block-tile kernel: 2c + 1 > 31, and (decided below) short row lists, which one block finishes by itself
+    bool wide = !b->gram_mfma && ntot > kGramDDCS && b->split;
     if (tot < 1 || (b->gram_mfma ? tot + 1 > 32 : (ntot > kGramDDCS && !wide)) || b->gram_mode == 2)
     {
         set_error("lbfgsx_b_gram_fused: one-pass Gram not applicable");
@@ -3095,6 +3161,8 @@ static int gram_dd_core(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, cons
             wf_rebuilt(c);
     }
     const int kpt_ = kp <= 1 ? 1 : kp <= 2 ? 2 : kp <= 4 ? 4 : kp <= 6 ? 6 : 8;
+    const bool one_block = list && b->split && !b->gram_mfma && !b->gram_i8 && nlist <= kListOneBlock && prologue == LBFGSX_GP_NONE;
+    wide = wide || one_block;
     const int ntile_ = wide ? xl::gram_kpb(ntot) : (64 * kpt_ + 255) / 256;
     if (wide)
     {
@@ -3125,7 +3193,8 @@ static int gram_dd_core(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, cons
                 gr.out_pos = b->wf_pos;
             }
             const ColsX<T> cl = (gr.in_idx && !gr.w_by_row) ? colsx_wf<T>(c, tot) : colsx_full<T>(c, tot);
-            blocks = xl::gram<T>(c->stream, b->gram_blocks, cl, tot, bvecs<T>(c), vsel_id, mask, nrows, b->gram_partial, pro, gr);
+            blocks = xl::gram<T>(c->stream, one_block ? 1 : b->gram_blocks, cl, tot, bvecs<T>(c), vsel_id, mask, nrows, b->gram_partial, pro,
+                                 gr, b->gram_out, gram_dd ? b->gram_dd : static_cast<double*>(nullptr));
         });
         if (blocks < 1)
         {
@@ -3134,11 +3203,14 @@ static int gram_dd_core(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, cons
         }
         if (compact_out)
             wf_rebuilt(c);
-        rc = xl::gram_finish(c->stream, b->gram_partial, blocks, ntile_, b->gram_partial2, b->gram_out,
-                             gram_dd ? b->gram_dd : static_cast<double*>(nullptr), nullptr, 0ull,
-                             b->xtickets + 1 + kMaxGridX / kGroupX);
-        if (rc)
-            return rc;
+        if (blocks > 1)
+        {
+            rc = xl::gram_finish(c->stream, b->gram_partial, blocks, ntile_, b->gram_partial2, b->gram_out,
+                                 gram_dd ? b->gram_dd : static_cast<double*>(nullptr), nullptr, 0ull,
+                                 b->xtickets + 1 + kMaxGridX / kGroupX);
+            if (rc)
+                return rc;
+        }
     }
     else if (!done_i8)
     {

@@ -1606,9 +1606,15 @@ __global__ void k_cauchy_gather(BVecs<T> b, const T* __restrict__ keys, const in
 
 // xcp and the free / newly-active state from the crossing threshold (Cauchy.h:201-206,219-233,265-282)
 // out[0] = #newact, out[1] = #free
+// drt != null: the statement that opens the subspace minimisation, drt = xcp - x0 (SubspaceMin.h:130, k_sub_begin), is
+// evaluated here on the values this pass has in registers -- same subtraction on the same operands, one pass over xcp and x0
+// and one launch less.  na_list != null: the rows this pass makes newly active (10^1..10^3 of 10^7 in steady state) are listed
+// (their number in out[2], beyond na_cap the list is incomplete), so that W_A'(A'd) of compute_FtBAb (BFGSMat.h:503-507) walks
+// the list instead of scanning n state bytes.
 template <class T>
 __global__ void __launch_bounds__(kBlock) k_cauchy_finish(BVecs<T> b, T t_cross, T tfinal, int crossed_all, int64_t n,
-                                                          RedWs ws, double* __restrict__ out)
+                                                          RedWs ws, double* __restrict__ out, T* __restrict__ drt,
+                                                          int* __restrict__ na_list, unsigned* __restrict__ na_cnt, unsigned na_cap)
 {
     typedef typename AccOf<T>::type A;
     A acc[2];
@@ -1616,28 +1622,43 @@ __global__ void __launch_bounds__(kBlock) k_cauchy_finish(BVecs<T> b, T t_cross,
     for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
     {
         const T t = b.brk[i];
+        const T x0i = b.x0[i];
+        T xc = x0i;  // what k_cauchy_build left in xcp: x0 (Cauchy.h:95)
         unsigned char s = 0;
         if (t == T(0))
             s = 0;  // on its bound from the start: neither free nor newly active; xcp = x0
         else if (t <= t_cross)
         {
-            b.xcp[i] = (b.dvec[i] > T(0)) ? b.ub[i] : b.lb[i];
+            xc = (b.dvec[i] > T(0)) ? b.ub[i] : b.lb[i];
+            b.xcp[i] = xc;
             s = ST_NEWACT;
             acc[0].add(T(1));
         }
         else
         {
             if (!crossed_all)
-                b.xcp[i] = b.x0[i] + tfinal * b.dvec[i];
+            {
+                xc = x0i + tfinal * b.dvec[i];
+                b.xcp[i] = xc;
+            }
             s = ST_FREE;
             acc[1].add(T(1));
         }
         b.st[i] = s;
+        if (drt)
+            drt[i] = xc - x0i;
+        if (na_list)
+            lu_append(s == ST_NEWACT, i, na_list, na_cnt, na_cap);
     }
     if (grid_reduce<2>(acc, ws) && threadIdx.x == 0)
     {
         out[0] = acc[0].value();
         out[1] = acc[1].value();
+        if (na_list)
+        {
+            out[2] = double(__hip_atomic_load(na_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            __hip_atomic_store(na_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         ws_signal(ws);
     }
 }

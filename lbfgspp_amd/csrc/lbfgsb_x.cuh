@@ -825,6 +825,72 @@ __global__ void __launch_bounds__(kBlock, occ_dots_x(NCL))
     }
 }
 
+// ---------------------------------------------------------------- masked W'v over the rows of an index list (the newly active rows of
+// a Cauchy search): out = {dots [ncols], nnz of v inside the mask}
+template <class T, int NCL, int G>
+__global__ void __launch_bounds__(kBlock, occ_mask_x(NCL))
+    kx_list1(ColsX<T> cols, int ncols, BVecs<T> b, int vsel_id, int mask, const int* __restrict__ list, int nlist, RedWsX ws,
+             double* __restrict__ out)
+{
+    typedef typename AccOf<T>::type A;
+    constexpr int RPW = 64 / G, NL = NCL + 1;
+    __shared__ const T* s_col[kColsX];
+    if (threadIdx.x < kColsX)
+        s_col[threadIdx.x] = cols.p[threadIdx.x];
+    __syncthreads();
+    const LaneX<G> L;
+    gptr_x<T> cp[NCL];
+    lane_cols_x<T, NCL, G>(s_col, L, cp);
+    Accs<A, NL> accs;
+    A(&acc)[NL] = accs.v;
+    const int64_t stride = int64_t(gridDim.x) * kWaves * RPW;
+    for (int64_t base = (int64_t(blockIdx.x) * kWaves + L.wave) * RPW; base < int64_t(nlist); base += stride)
+    {
+        const int64_t e = base + L.rr;
+        const bool inb = e < int64_t(nlist);
+        const int64_t i = list[inb ? e : int64_t(nlist) - 1];
+        const unsigned char st = b.st[i];
+        const T v = vsel(b, vsel_id, i);
+        T w[NCL];
+#pragma unroll
+        for (int k = 0; k < NCL; k++)
+            w[k] = cp[k][i];
+        if (!inb || (mask && !(st & mask)))
+            continue;
+        if (v != T(0))
+            acc[NCL].add(T(1));
+#pragma unroll
+        for (int k = 0; k < NCL; k++)
+            acc[k].add_prod(w[k], v);
+    }
+    A tot;
+    if (grid_reduce_x<NL, G, A>(acc, ws, tot))
+    {
+        const int s = threadIdx.x;
+        if (s < G * NL)
+        {
+            const int gg = s / NL, k = s % NL;
+            int idx = -1;
+            if (k < NCL)
+            {
+                const int col = gg * NCL + k;
+                if (col < ncols)
+                    idx = col;
+            }
+            else if (gg == 0)
+                idx = ncols;
+            if (idx >= 0)
+            {
+                out[idx] = double(T(tot.value()));
+                __threadfence_system();
+            }
+        }
+        __syncthreads();
+        if (s == 0)
+            wsx_signal(ws);
+    }
+}
+
 // ---------------------------------------------------------------- masked W'v over the full-length columns: k_multidot_all for 2c <= 80.
 // v = vcol when given, else vsel(b, vsel_id); out = {dots [ncols], nnz of v inside the mask}.  A wavefront first looks at
 // the state bytes of 256 rows (four coalesced byte loads); 64-row pieces without a row inside the mask cost nothing more --
@@ -926,8 +992,11 @@ __global__ void __launch_bounds__(kBlock, occ_mask_x(NCL))
 template <class T, int KPB>
 __global__ void __launch_bounds__(kBlock)
     kx_gram(ColsX<T> cols, int ncols, BVecs<T> b, int vsel_id, int mask, int64_t n, double* __restrict__ partial, ProX<T> pro,
-            GramRows<T> gr, int cs)
+            GramRows<T> gr, int cs, double* __restrict__ fin_out, double* __restrict__ fin_dd, unsigned long long* done,
+            unsigned long long seq)
 {
+    // fin_out (a launch of ONE block only: the Grams over the short row lists of the sweeps): the block's sums are the sums --
+    // rounded entries to fin_out[e], (hi, lo) to fin_dd, the completion word last; no kx_gram_finish launches
     extern __shared__ double tile[];  // [64][cs], then the rows' numbers
     __shared__ T pc1[kColsX], pc2[kColsX];
     __shared__ const T* s_col[kColsX];
@@ -1058,6 +1127,29 @@ __global__ void __launch_bounds__(kBlock)
                 acc0[k].add_prod(ra[pi[k]], ra[pj[k]]);
         }
         __syncthreads();  // the tile is staged again
+    }
+    if (fin_out && gridDim.x == 1)
+    {
+#pragma unroll
+        for (int k = 0; k < KPB; k++)
+        {
+            acc0[k].merge(acc1[k].hi, acc1[k].lo);
+            const int e = tid * KPB + k;
+            fin_out[e] = acc0[k].value();
+            if (fin_dd)
+            {
+                fin_dd[e * 2 + 0] = acc0[k].hi;
+                fin_dd[e * 2 + 1] = acc0[k].lo;
+            }
+        }
+        if (done)
+        {
+            __threadfence_system();
+            __syncthreads();
+            if (tid == 0)
+                __hip_atomic_store(done, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
     }
     double* part = partial + size_t(blockIdx.x) * (KPB * 256) * 2;
 #pragma unroll

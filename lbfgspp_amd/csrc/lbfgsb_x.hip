@@ -1,5 +1,6 @@
 // lbfgspp_amd/csrc/lbfgsb_x.hip -- instantiations and launchers of the m-generic L-BFGS-B passes (lbfgsb_x.cuh).
 #include <algorithm>
+#include <cstdlib>
 
 #include "lbfgsb_x.hpp"
 
@@ -20,8 +21,16 @@ namespace xl {
         else { CALL(20, 4); }                  \
     } while (0)
 
+// blocks per CU: what the kernel was compiled for, but no more than two -- with the next trip's loads always in flight two
+// blocks per CU saturate the memory system (a bare pass reads 6.27 TB/s at two, 6.1 at four / six), and every further
+// block adds to the reduction's partials and to the bunching of the waves (scripts/experiments/kernels_x.hip: kx_rows 185 /
+// 190 / 199 us at 2 / 3 / 4 blocks per CU)
 static inline int grid_rows(int64_t n, int rpw, int per_cu, int num_cus)
 {
+    if (const char* e = getenv("LBFGSX_X_PER_CU"))  // A/B
+        per_cu = std::max(1, atoi(e));
+    else
+        per_cu = std::min(per_cu, 2);
     const int64_t per_block = int64_t(kWaves) * rpw;
     const int64_t want = (n + per_block - 1) / per_block;
     return int(std::max<int64_t>(1, std::min<int64_t>(want, std::min<int64_t>(int64_t(per_cu) * num_cus, kMaxGridX))));
@@ -126,6 +135,21 @@ int list2(hipStream_t s, int num_cus, const ColsX<T>& cols, int ncols, const BVe
 }
 
 template <class T>
+int list1(hipStream_t s, int num_cus, const ColsX<T>& cols, int ncols, const BVecs<T>& b, int vsel_id, int mask, const int* list, int nlist,
+          const RedWsX& ws, double* out)
+{
+    if (ncols < 1 || ncols > kColsX)
+        return LBFGSX_E_INVALID;
+#define CALL(NCL, G)                                                                                                      \
+    LBFGSX_LAUNCH((kx_list1<T, NCL, G>), dim3(std::min(32, grid_rows(nlist, 64 / G, 1, num_cus))), dim3(kBlock), 0, s, cols,   \
+                  ncols, b, vsel_id, mask, list, nlist, ws, out)
+    LBFGSX_XCLASS(ncols, CALL);
+#undef CALL
+    LBFGSX_HIP(hipGetLastError());
+    return LBFGSX_OK;
+}
+
+template <class T>
 int multidot_mask(hipStream_t s, int num_cus, const ColsX<T>& cols, int ncols, const BVecs<T>& b, int vsel_id, const T* vcol, int mask,
                   int64_t n, const RedWsX& ws, double* out)
 {
@@ -155,12 +179,13 @@ int gram_kpb(int ntot)
 {
     const int npairs = ntot * (ntot + 1) / 2;
     const int kp = (npairs + 255) / 256;
-    return kp <= 3 ? 3 : kp <= 4 ? 4 : kp <= 6 ? 6 : kp <= 9 ? 9 : 13;
+    return kp <= 1 ? 1 : kp <= 2 ? 2 : kp <= 3 ? 3 : kp <= 4 ? 4 : kp <= 6 ? 6 : kp <= 9 ? 9 : 13;
 }
 
 template <class T, int KPB>
 static int gram_kp(hipStream_t s, int max_blocks, const ColsX<T>& cols, int ncols, const BVecs<T>& b, int vsel_id, int mask,
-                   int64_t n, double* partial, const ProX<T>& pro, const GramRows<T>& gr)
+                   int64_t n, double* partial, const ProX<T>& pro, const GramRows<T>& gr, double* fin_out, double* fin_dd,
+                   unsigned long long* done, unsigned long long seq)
 {
     const int ntot = ncols + (vsel_id >= 0 ? 1 : 0);
     const int cs = ntot | 1;  // odd row stride: the lanes of a wave that read one row hit distinct banks
@@ -169,7 +194,8 @@ static int gram_kp(hipStream_t s, int max_blocks, const ColsX<T>& cols, int ncol
         (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kx_gram<T, KPB>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     const int64_t nbatch = (n + 63) / 64;
     const int blocks = int(std::max<int64_t>(1, std::min<int64_t>(max_blocks, nbatch)));
-    LBFGSX_LAUNCH((kx_gram<T, KPB>), dim3(blocks), dim3(kBlock), lds, s, cols, ncols, b, vsel_id, mask, n, partial, pro, gr, cs);
+    LBFGSX_LAUNCH((kx_gram<T, KPB>), dim3(blocks), dim3(kBlock), lds, s, cols, ncols, b, vsel_id, mask, n, partial, pro, gr, cs,
+                  blocks == 1 ? fin_out : static_cast<double*>(nullptr), fin_dd, done, seq);
     if (hipGetLastError() != hipSuccess)
         return -1;
     return blocks;
@@ -177,18 +203,23 @@ static int gram_kp(hipStream_t s, int max_blocks, const ColsX<T>& cols, int ncol
 
 template <class T>
 int gram(hipStream_t s, int max_blocks, const ColsX<T>& cols, int ncols, const BVecs<T>& b, int vsel_id, int mask, int64_t n,
-         double* partial, const ProX<T>& pro, const GramRows<T>& gr)
+         double* partial, const ProX<T>& pro, const GramRows<T>& gr, double* fin_out, double* fin_dd, unsigned long long* done,
+         unsigned long long seq)
 {
     if (ncols < 1 || ncols > kColsX)
         return -1;
+#define GK(K) return gram_kp<T, K>(s, max_blocks, cols, ncols, b, vsel_id, mask, n, partial, pro, gr, fin_out, fin_dd, done, seq)
     switch (gram_kpb(ncols + (vsel_id >= 0 ? 1 : 0)))
     {
-    case 3: return gram_kp<T, 3>(s, max_blocks, cols, ncols, b, vsel_id, mask, n, partial, pro, gr);
-    case 4: return gram_kp<T, 4>(s, max_blocks, cols, ncols, b, vsel_id, mask, n, partial, pro, gr);
-    case 6: return gram_kp<T, 6>(s, max_blocks, cols, ncols, b, vsel_id, mask, n, partial, pro, gr);
-    case 9: return gram_kp<T, 9>(s, max_blocks, cols, ncols, b, vsel_id, mask, n, partial, pro, gr);
-    default: return gram_kp<T, 13>(s, max_blocks, cols, ncols, b, vsel_id, mask, n, partial, pro, gr);
+    case 1: GK(1);
+    case 2: GK(2);
+    case 3: GK(3);
+    case 4: GK(4);
+    case 6: GK(6);
+    case 9: GK(9);
+    default: GK(13);
     }
+#undef GK
 }
 
 int gram_finish(hipStream_t s, const double* partial, int blocks, int ntile, double* partial2, double* out, double* out_dd,
@@ -217,10 +248,12 @@ int gram_finish(hipStream_t s, const double* partial, int blocks, int ntile, dou
     template int multidot2<T>(hipStream_t, int, const ColsX<T>&, int, const T*, const T*, int64_t, const RedWsX&, double*);        \
     template int list2<T>(hipStream_t, int, const ColsX<T>&, int, const BVecs<T>&, const int*, int, const RedWsX&, double*,         \
                           const unsigned char*, const int*);                                                                     \
+    template int list1<T>(hipStream_t, int, const ColsX<T>&, int, const BVecs<T>&, int, int, const int*, int, const RedWsX&,         \
+                          double*);                                                                                              \
     template int multidot_mask<T>(hipStream_t, int, const ColsX<T>&, int, const BVecs<T>&, int, const T*, int, int64_t,            \
                                   const RedWsX&, double*);                                                                       \
     template int gram<T>(hipStream_t, int, const ColsX<T>&, int, const BVecs<T>&, int, int, int64_t, double*, const ProX<T>&,      \
-                         const GramRows<T>&);                                                                                    \
+                         const GramRows<T>&, double*, double*, unsigned long long*, unsigned long long);                                                                                    \
     template int wf_append<T>(hipStream_t, const ColsX<T>&, int, T*, int64_t, int*, int*, const int*, unsigned*, unsigned, unsigned)
 INST(double);
 INST(float);

@@ -26,6 +26,9 @@ template <class T>
 int list2(hipStream_t s, int num_cus, const ColsX<T>& cols, int ncols, const BVecs<T>& b, const int* list, int nlist, const RedWsX& ws,
           double* out, const unsigned char* stc, const int* pos);
 template <class T>
+int list1(hipStream_t s, int num_cus, const ColsX<T>& cols, int ncols, const BVecs<T>& b, int vsel_id, int mask, const int* list, int nlist,
+          const RedWsX& ws, double* out);
+template <class T>
 int multidot_mask(hipStream_t s, int num_cus, const ColsX<T>& cols, int ncols, const BVecs<T>& b, int vsel_id, const T* vcol, int mask,
                   int64_t n, const RedWsX& ws, double* out);
 template <class T>
@@ -33,10 +36,13 @@ int wf_append(hipStream_t s, const ColsX<T>& orig, int ncols, T* wf, int64_t wf_
               unsigned* cnt, unsigned cap, unsigned wf_cap);
 // entries per thread of kx_gram for 2c + 1 (+ v) = ntot columns; the partial buffer holds [blocks][gram_kpb * 256][2] doubles
 int gram_kpb(int ntot);
-// returns the number of blocks launched (their partials wait for gram_finish), < 0: error
+// returns the number of blocks launched, < 0: error.  More than one block: their partials wait for gram_finish.  ONE block
+// (max_blocks = 1: the Grams over the short row lists of the sweeps) and fin_out given: the launch itself leaves the rounded
+// entries in fin_out, the (hi, lo) pairs in fin_dd and stores the completion word -- no gram_finish
 template <class T>
 int gram(hipStream_t s, int max_blocks, const ColsX<T>& cols, int ncols, const BVecs<T>& b, int vsel_id, int mask, int64_t n,
-         double* partial, const ProX<T>& pro, const GramRows<T>& gr);
+         double* partial, const ProX<T>& pro, const GramRows<T>& gr, double* fin_out = nullptr, double* fin_dd = nullptr,
+         unsigned long long* done = nullptr, unsigned long long seq = 0);
 // two-level sum of `blocks` partial sets of `ntile` tiles each: rounded entries to out[ntile * 256], (hi, lo) to out_dd
 int gram_finish(hipStream_t s, const double* partial, int blocks, int ntile, double* partial2, double* out, double* out_dd,
                 unsigned long long* done, unsigned long long seq, unsigned* ticket);

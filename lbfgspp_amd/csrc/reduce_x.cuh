@@ -89,6 +89,36 @@ __device__ __forceinline__ A block_reduce_x(A (&v)[NL], double (*sh)[2][kWaves])
     return t;
 }
 
+// Sum `count` double-double partials (hi, lo pairs `stride` doubles apart): the loads of a batch of 16 are issued together and
+// only then merged -- a loop that loads, merges, loads pays a memory round trip (~1 us) per partial, which made the tail of a
+// 512-block launch cost ~14 us (scripts/experiments/kernels_x.hip, "tail")
+template <class A>
+__device__ __forceinline__ A sum_partials_x(const double* p, size_t stride, int count)
+{
+    A t0, t1;
+    for (int b0 = 0; b0 < count; b0 += 16)
+    {
+        double h[16], l[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+        {
+            const int b = (b0 + j < count) ? b0 + j : count - 1;  // clamped: loaded again, dropped
+            h[j] = ld_agent(p + size_t(b) * stride);
+            l[j] = ld_agent(p + size_t(b) * stride + 1);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j += 2)
+        {
+            if (b0 + j < count)
+                t0.merge(h[j], l[j]);
+            if (b0 + j + 1 < count)
+                t1.merge(h[j + 1], l[j + 1]);
+        }
+    }
+    t0.merge(t1.hi, acc_lo(t1));
+    return t0;
+}
+
 // Reduce NL accumulators per lane over the whole grid.  Returns true in every thread of the block that ends up with the
 // grand totals; `mine` then holds the total of sum id threadIdx.x (threads < G * NL).  The caller writes its outputs from
 // those threads, then __syncthreads() and wsx_signal() from one thread (each writer fencing its own stores).
@@ -129,22 +159,7 @@ __device__ __forceinline__ bool grid_reduce_x(A (&acc)[NL], const RedWsX& ws, A&
     if (!s_last)
         return false;
     if (tid < NS)
-    {
-        A t0, t1;   // two chains: a merge is ~10 dependent operations
-        const double* p = ws.p1 + (size_t(grp) * kGroupX * kMaxSumsX + size_t(tid)) * 2;
-        int b = 0;
-        for (; b + 1 < gsize; b += 2)
-        {
-            const double h0 = ld_agent(p + size_t(b) * kMaxSumsX * 2), l0 = ld_agent(p + size_t(b) * kMaxSumsX * 2 + 1);
-            const double h1 = ld_agent(p + size_t(b + 1) * kMaxSumsX * 2), l1 = ld_agent(p + size_t(b + 1) * kMaxSumsX * 2 + 1);
-            t0.merge(h0, l0);
-            t1.merge(h1, l1);
-        }
-        if (b < gsize)
-            t0.merge(ld_agent(p + size_t(b) * kMaxSumsX * 2), ld_agent(p + size_t(b) * kMaxSumsX * 2 + 1));
-        t0.merge(t1.hi, acc_lo(t1));
-        mine = t0;
-    }
+        mine = sum_partials_x<A>(ws.p1 + (size_t(grp) * kGroupX * kMaxSumsX + size_t(tid)) * 2, size_t(kMaxSumsX) * 2, gsize);
     if (ngrp == 1)
         return true;
     // ---- second level: the groups
@@ -171,22 +186,7 @@ __device__ __forceinline__ bool grid_reduce_x(A (&acc)[NL], const RedWsX& ws, A&
     if (!s_last)
         return false;
     if (tid < NS)
-    {
-        A t0, t1;
-        const double* p = ws.p2 + size_t(tid) * 2;
-        int b = 0;
-        for (; b + 1 < ngrp; b += 2)
-        {
-            const double h0 = ld_agent(p + size_t(b) * kMaxSumsX * 2), l0 = ld_agent(p + size_t(b) * kMaxSumsX * 2 + 1);
-            const double h1 = ld_agent(p + size_t(b + 1) * kMaxSumsX * 2), l1 = ld_agent(p + size_t(b + 1) * kMaxSumsX * 2 + 1);
-            t0.merge(h0, l0);
-            t1.merge(h1, l1);
-        }
-        if (b < ngrp)
-            t0.merge(ld_agent(p + size_t(b) * kMaxSumsX * 2), ld_agent(p + size_t(b) * kMaxSumsX * 2 + 1));
-        t0.merge(t1.hi, acc_lo(t1));
-        mine = t0;
-    }
+        mine = sum_partials_x<A>(ws.p2 + size_t(tid) * 2, size_t(kMaxSumsX) * 2, ngrp);
     return true;
 }
 

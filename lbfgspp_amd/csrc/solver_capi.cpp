@@ -181,10 +181,40 @@ struct LbfgsbImpl : lbfgsx_solver
     }
     void prepare(int64_t n) override { solver->prepare_resident(n); }
     lbfgsx_ctx* ctx() override { return solver->device_state().ctx(); }
+    // the solver's statistics as lbfgsx_solver_stats* serve them: refreshed at the end of minimize() and before every call of
+    // the iteration hook, so that a hook can difference them per iteration (bench.py: the sweeps, sorted break points and
+    // launches of the SAME iterations it times)
+    void publish_stats()
+    {
+        const auto& st = solver->stats();
+        stats[0] = st.gcp_crossings;
+        stats[1] = st.submin_sweeps;
+        stats[2] = st.submin_calls;
+        stats[3] = st.submin_unconverged;
+        stats[4] = st.resets;
+        stats[5] = (long long) (st.gcp_build_s * 1e6);
+        stats[6] = (long long) (st.gcp_fetch_s * 1e6);
+        stats[7] = (long long) (st.gcp_total_s * 1e6);
+        stats_submin_us = (long long) (st.submin_s * 1e6);
+        stats2[0] = st.gcp_dev_crossings;
+        stats2[1] = st.gcp_sort_fallbacks;
+        stats2[2] = st.gcp_partial_sorts;
+        stats2[3] = (long long) (st.submin_s * 1e6);
+        stats2[4] = (long long) (st.linesearch_s * 1e6);
+        stats2[5] = (long long) (st.correction_s * 1e6);
+        stats2[6] = st.submin_fused_sweeps;
+        stats2[7] = st.gram_carried;
+        stats3[0] = st.gcp_searches;
+        stats3[1] = st.gcp_nord;
+        stats3[2] = st.gcp_sorted;
+    }
     void set_hook(void (*fn)(int, void*), void* user) override
     {
         if (fn)
-            solver->set_iteration_hook([fn, user](int k) { fn(k, user); });
+            solver->set_iteration_hook([this, fn, user](int k) {
+                publish_stats();
+                fn(k, user);
+            });
         else
             solver->set_iteration_hook(nullptr);
     }
@@ -218,27 +248,7 @@ struct LbfgsbImpl : lbfgsx_solver
         out->fx = double(fx);
         out->gnorm = double(solver->final_grad_norm());
         out->nfev = solver->num_evaluations();
-        const auto& st = solver->stats();
-        stats[0] = st.gcp_crossings;
-        stats[1] = st.submin_sweeps;
-        stats[2] = st.submin_calls;
-        stats[3] = st.submin_unconverged;
-        stats[4] = st.resets;
-        stats[5] = (long long) (st.gcp_build_s * 1e6);
-        stats[6] = (long long) (st.gcp_fetch_s * 1e6);
-        stats[7] = (long long) (st.gcp_total_s * 1e6);
-        stats_submin_us = (long long) (st.submin_s * 1e6);
-        stats2[0] = st.gcp_dev_crossings;
-        stats2[1] = st.gcp_sort_fallbacks;
-        stats2[2] = st.gcp_partial_sorts;
-        stats2[3] = (long long) (st.submin_s * 1e6);
-        stats2[4] = (long long) (st.linesearch_s * 1e6);
-        stats2[5] = (long long) (st.correction_s * 1e6);
-        stats2[6] = st.submin_fused_sweeps;
-        stats2[7] = st.gram_carried;
-        stats3[0] = st.gcp_searches;
-        stats3[1] = st.gcp_nord;
-        stats3[2] = st.gcp_sorted;
+        publish_stats();
     }
 };
 

@@ -169,6 +169,15 @@ int main()
         printf("split (%d, %d), grid %4d: kx_rows<1> %6.1f us (%.2f TB/s)  kx_solve_sweep<0> %6.1f us (%.2f TB/s)  <1> %6.1f us  kx_rows<3> %6.1f us\n", NCL, G, grid, t1, bytes_rows / t1 / 1e6, t2, bytes_sweep / t2 / 1e6, t3, t4); \
     }
         if (tot == 20) { RUNX(10, 2) } else { RUNX(10, 4) }
+        if (tot == 20)
+            for (int grid : {1, 16, 256, 512, 1024})
+            {
+                // 64 rows per block: what a launch costs besides its rows (launch, the reduction's tickets and tail)
+                const int64_t tiny = int64_t(grid) * 64;
+                float t1 = timeit([&] { hipLaunchKernelGGL((kx_rows<double, 10, 2, 1, false>), dim3(grid), dim3(kBlock), 0, 0, cx, tot, b2, int(VS_NEG_RHS), int(ST_P), tiny, wx, out, out + 256, px, gx, -1, -1); }, 20);
+                float t2 = timeit([&] { hipLaunchKernelGGL((k_vrows<double, 20, 1>), dim3(grid), dim3(kBlock), 0, 0, cl, tot, b2, int(VS_NEG_RHS), int(ST_P), tiny, ws, out, out + 256, pro, gr, 0, 0); }, 20);
+                printf("tail: grid %4d, %lld rows: kx_rows<1> %6.1f us   k_vrows<20,1> %6.1f us\n", grid, (long long) tiny, t1, t2);
+            }
 #define BARE(NCL, G, OCC)                                                                                                               \
     {                                                                                                                                   \
         float t = timeit([&] { hipLaunchKernelGGL((k_bare_x<NCL, G, OCC>), dim3(OCC * 256), dim3(256), 0, 0, cx, b2.rhs, b2.y, b2.st, npos, out); }); \

@@ -32,7 +32,7 @@ def short(n):
 
 posts = [i for i, r in enumerate(rows) if "k_b_post" in r[2]]
 # the warm-up solve comes first: keep the posts of the big run = the last 40
-posts = posts[-40:]
+posts = posts[-(int(os.environ.get("TL_ITERS", "40"))):]
 lo, hi = posts[-tail - 1], posts[-1]
 seg = rows[lo:hi]
 wall = (rows[hi][0] - rows[lo][0]) / tail

@@ -64,6 +64,29 @@ def test_default_line_has_the_contract_keys():
     assert r4["bound"] == "hbm" and r4["kernel"] and abs(r4["frac"] - r4["achieved"] / 8000.0) < 1e-12 and 0.1 < r4["frac"] < 1.0
     assert abs(r4["achieved"] - r4["algorithmic_bytes"] * c4["value"] / 1e9) < 1e-6 * r4["achieved"]
     assert r4["frac_from_x0"] < r4["frac"]
+    # both sides of the steady fraction come from the SAME iterations: the second half of the run (the library's counters and
+    # the solver's statistics snapshotted at the iteration hook), value = 1 / mean, the median beside it
+    w = cc["window"]
+    assert w["first_iteration"] == 20 and w["last_iteration"] == 39 and w["iterations"] == 20 and w["history_full"] is True
+    per = cc["per_iteration_ms"]
+    assert len(per) == 39 and abs(sum(per[19:]) / 20 - c4["ms_per_step"]) < 2e-3
+    assert abs(c4["ms_per_step"] * c4["value"] - 1e3) < 1e-6 * 1e3 and abs(c4["ms_per_step_median"] * c4["value_median"] - 1e3) < 1e-3
+    assert cc["submin_sweeps"] <= cc["submin_sweeps_total"] and cc["submin_calls"] == 20
+    assert abs(cc["q"] - cc["submin_sweeps"] / cc["submin_calls"]) < 1e-12
+    m_, n_ = cc["m"], cc["n"]
+    want = ((4 * m_ + 19) + (cc["q"] + 1.0) * (4 * m_ + 1)) * n_ * 8 + 96.0 * cc["n_sorted"]
+    assert abs(r4["algorithmic_bytes"] - want) < 1e-9 * want
+    fx0 = c4["from_x0"]
+    assert fx0["q"] >= 1.0 and fx0["launches_per_iteration"] > cc["launches_per_iteration"] * 0.5
+    assert (r4["traffic"] is None) == (r4["traffic_source"] is None)
+    # the same problem with the largest history a BASELINE configuration uses: the L-BFGS-B path is generic in m
+    c20 = d["cfg4_m20"]
+    assert c20["config"]["m"] == 20 and c20["steps"] == 60 and c20["config"]["window"]["history_full"] is True
+    assert c20["config"]["window"]["first_iteration"] == 30 and c20["config"]["gram_carried"] >= 15
+    assert c20["value"] > 0.45 * c4["value"], "m = 20 moves 1.9x the bytes of m = 10: %.1f vs %.1f it/s" % (c20["value"], c4["value"])
+    for leg in ("cfg2", "cfg3", "cfg5_batched"):
+        rr = d[leg]["roofline"]
+        assert (rr["traffic"] is None) == (rr.get("traffic_source") is None)
 
 
 def test_cpu_baseline_at_the_metric_size_is_measured_not_scaled():
@@ -123,7 +146,7 @@ def test_small_problem_reports_the_hbm_model_fraction():
     d = _run("--objective", "quadratic", "--n", "10000000", "--no-cpu", "--no-batched", "--no-legs")
     r = d["roofline"]
     assert r["frac"] < 1.0 and r["q_resident_elems"] == 10000000 and r["hbm_model_GBs"] < r["algorithmic_GBs"]
-    assert r["traffic"] is None   # no committed PMC profile at this (n, m)
+    assert (r["traffic"] is None) == (r["traffic_source"] is None)   # quoted only from a committed PMC summary of this (n, m)
 
 
 def test_gpus_2_starts_two_ranks_or_refuses():
@@ -171,3 +194,17 @@ def test_single_process_drives_every_listed_device():
         env0 = {k: v for k, v in os.environ.items() if k not in ("LBFGSX_BENCH_DEVICES", "WORLD_SIZE", "RANK")}
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, cwd=ROOT, env=env0)
         assert r.returncode != 0 and not r.stdout.strip()
+
+
+def test_north_star_parity_object_at_a_size_this_test_can_afford():
+    """`parity` of the default line: the reference's own run (native accumulators, the same instance, --cpu-full) against the
+    GPU solver, all n coordinates.  Here at n = 1e7 (the default line does it at n = 1e8); --cpu-full-dd adds the comparison
+    with the reference built on the parity contract's extended sums, where nothing may differ."""
+    d = _run("--n", "10000000", "--cpu-full", "on", "--cpu-full-dd", "--cpu-n", "1000000", "--cpu-steps", "3", "--cpu-n-all", "1000000",
+             "--no-batched", "--no-legs")
+    p = d["parity"]
+    assert p["n"] == 10000000 and p["m"] == 10 and p["iterations"] == 15 and p["iterations_equal"] and p["nfev_equal"]
+    assert p["max_abs_dx"] <= 1e-10 and p["within_tolerance"] is True and p["fx_rel_diff"] <= 1e-11
+    assert "native accumulators" in p["oracle"] and p["max_abs_dx_strided_sample"] <= p["max_abs_dx"]
+    q = d["parity_dd"]
+    assert q["iterations_equal"] and q["nfev_equal"] and q["max_abs_dx"] == 0.0 and q["fx"] == q["fx_oracle"]

@@ -894,3 +894,34 @@ def test_rows_split_over_lanes_change_no_bit(A, monkeypatch, n, m, iters, max_su
         assert f[6] >= f[7] // 4, "the carried form ran in %d of %d subspace minimisations" % (f[6], f[7])
     if m > 10:
         assert u[6] <= 10   # the one-entry-per-lane kernel has 64 lanes: only while the history holds <= 10 pairs
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("n,m,iters,cap", [(70001, 8, 40, None), (90000, 10, 45, None), (65536, 20, 50, None), (120000, 10, 40, "8")])
+def test_cauchy_finish_carrying_the_next_statements_changes_no_bit(A, monkeypatch, n, m, iters, cap, dtype):
+    """lbfgsx_b_cauchy_finish also evaluates drt = xcp - x0 (the statement that opens the subspace minimisation,
+    SubspaceMin.h:130) on the values it holds, and lists the rows it made newly active so that W_A'(A'd) of compute_FtBAb
+    (BFGSMat.h:503-507) walks a list instead of n state bytes -- against the separate passes (LBFGSX_FINISH_FUSE=0): the same
+    statements, the same correctly rounded dots, so the same trajectory bit for bit.  cap = 8: the list overflows and the scan
+    takes over."""
+    dt = O.F64 if dtype == "f64" else O.F32
+    npdt = O.NPDT[dt]
+    a, b = O.quad_problem(n, 30.0, 17, dt)
+    if cap:
+        monkeypatch.setenv("LBFGSX_NEWACT_CAP", cap)
+    res = {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("LBFGSX_FINISH_FUSE", on)
+        s = A.LBFGSBSolver(A.LBFGSBParam(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters), dtype=npdt)
+        tr = A.TraceBuffer(n, cap=512, stride=19)
+        x = np.zeros(n, dtype=npdt)
+        try:
+            niter, fx = s.minimize(A.DiagQuadratic(a, b), x, (-0.7 * np.ones(n)).astype(npdt), (0.9 * np.ones(n)).astype(npdt),
+                                   trace=tr)
+        except RuntimeError:
+            niter, fx = -1, float("nan")
+        st = s.stats()
+        res[on] = (niter, s.last.nfev, x.copy(), tr.xs[:tr.count].copy(), st["submin_sweeps"], st["gcp_crossings"])
+    f, u = res["1"], res["0"]
+    assert f[:2] == u[:2] and f[4:] == u[4:]
+    assert np.array_equal(f[2], u[2]) and np.array_equal(f[3], u[3])
