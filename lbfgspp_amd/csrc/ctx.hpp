@@ -179,6 +179,8 @@ struct lbfgsx_ctx
     unsigned tl_step = 0;  // launches issued so far (parity selects the direction)
     // persistent one-launch apply_Hv (k_twoloop_persist)
     bool persist = true;           // LBFGSX_PERSIST=0: always the 2c+1 step launches
+    bool meet_all = true;          // how the blocks of the persistent launch meet between steps (lbfgs_kernels.cuh, persist_meet):
+                                   // every block adds the partials up itself (default), or LBFGSX_MEET=last: the last block does
     // A persistent launch whose meeting points timed out (CUs held by another process) is redone with the step launches,
     // which the context then keeps for `persist_cooldown` products before it tries the persistent form again; every
     // further time-out quadruples the pause (8, 32, ... 8192 products), a clean persistent product resets it.

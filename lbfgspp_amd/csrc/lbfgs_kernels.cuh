@@ -660,7 +660,93 @@ __device__ __forceinline__ void hv_post_step(Pack<T> (&rq)[NR], typename Vec16<T
 constexpr int kPersistNR = 30;
 constexpr int kPersistNL = 15;
 
-template <class T, bool FUSE = false>
+// Meeting point of the persistent launch, second form (MEET): every block works the dot out for itself.
+// The first form hands the partials to the LAST block to arrive: ticket -> that block reads the G partials, reduces, stores
+// the rounded dot in sc[] and bumps a generation word -> the others, which have been polling that word, go on and fetch the
+// coefficient back from sc[].  Four dependent trips through the memory system after the last arrival (ticket, partials,
+// publish, coefficient): ~12 us per step, which is a third of a step at n = 1e7 (cfg2: 0.039 ms per step against 0.027 ms of
+// data).  Here a block stores its partial, counts itself in (one atomic add on a counter that only ever grows: the target of
+// meeting k of a launch is base + G (k + 1)), polls the COUNTER until everybody is in, and then reads the G partials and adds
+// them up itself -- every block the same partials in the same order, hence the same bits, which are also the bits the last
+// block of the first form produces.  Two trips (counter, partials), no publish, and the coefficients of the later steps come
+// from the block's own table of dots in LDS instead of sc[].  The partials of consecutive meetings alternate between two
+// row sets (a fast block's next partial must not land where a slow block still reads the previous ones).
+// wait = false (the last step: nobody needs the dot inside the launch): only the last block to arrive goes on.
+// Returns false in blocks that have nothing more to do; totals: sum r in tot[r][0..1] (hi, lo), valid after the call.
+template <int NS, class A>
+__device__ __forceinline__ bool persist_meet(A (&acc)[NS], const RedWs& ws, unsigned* __restrict__ arrive, unsigned target, int parity,
+                                             int* __restrict__ err, bool wait, double (*sh)[2][kWaves], double (*tot)[2], int* s_flag)
+{
+    const int tid = threadIdx.x, G = gridDim.x;
+    const int rb = parity * 16;  // rows of this meeting: (hi, lo) of sum r in rows rb + 2 r, rb + 2 r + 1 (NS <= 8)
+    A mine = block_reduce_all<NS, A>(acc, sh);
+    if (tid < NS)
+    {
+        st_agent(ws.partials + size_t(rb + 2 * tid) * ws.maxGrid + blockIdx.x, mine.hi);
+        st_agent(ws.partials + size_t(rb + 2 * tid + 1) * ws.maxGrid + blockIdx.x, acc_lo(mine));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // write-through stores drained before this block counts itself in
+    }
+    __syncthreads();
+    if (tid == 0)
+    {
+        const unsigned old = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int flag = 1;
+        if (!wait)
+            flag = (old == target - 1u) ? 1 : 0;
+        else if (old != target - 1u)
+        {
+            unsigned spins = 0;
+            const unsigned long long t_begin = wall_clock64();  // constant 100 MHz counter (s_memrealtime)
+            while (int(__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0)
+            {
+                __builtin_amdgcn_s_sleep(1);
+                // never hang the device: after 100 ms of wall-clock waiting (or as soon as another block gave up) the blocks
+                // are not all resident -- some other process holds CUs.  Flag the launch as failed and run to the end; the
+                // host redoes the product with the step launches.
+                if ((++spins & 1023u) == 0u &&
+                    (wall_clock64() - t_begin > 10000000ull || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
+                {
+                    __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    flag = 2;
+                    break;
+                }
+            }
+        }
+        *s_flag = flag;
+    }
+    __syncthreads();
+    if (*s_flag == 0)
+        return false;
+    // every thread gathers a strided share of the G partials of every sum, then the block sum as in grid_reduce
+    A t[NS];
+    for (int b = tid; b < G; b += kHvThreads)
+    {
+        double h[NS], l[NS];
+#pragma unroll
+        for (int r = 0; r < NS; r++)
+        {
+            h[r] = ld_agent(ws.partials + size_t(rb + 2 * r) * ws.maxGrid + b);
+            l[r] = ld_agent(ws.partials + size_t(rb + 2 * r + 1) * ws.maxGrid + b);
+        }
+#pragma unroll
+        for (int r = 0; r < NS; r++)
+            t[r].merge(h[r], l[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < NS; r++)
+        acc[r] = t[r];
+    __syncthreads();  // sh[] reuse
+    mine = block_reduce_all<NS, A>(acc, sh);
+    if (tid < NS)
+    {
+        tot[tid][0] = mine.hi;
+        tot[tid][1] = acc_lo(mine);
+    }
+    __syncthreads();
+    return true;
+}
+
+template <class T, bool FUSE = false, bool MEET = false>
 __global__ void __launch_bounds__(kHvThreads, 2)
     k_twoloop_persist(T* __restrict__ q, const T* __restrict__ vin, T a, const T* __restrict__ S, const T* __restrict__ Y,
                       int64_t n, T* __restrict__ sc, PersistArgs pa, RedWs ws, unsigned* __restrict__ gen,
@@ -672,6 +758,12 @@ __global__ void __launch_bounds__(kHvThreads, 2)
     __shared__ typename Vec16<T>::type lq[NL * kHvThreads];
     __shared__ int s_pcol[kPersistMaxM];  // dynamic indexing: keep the column list out of scratch
     __shared__ int s_verdict;
+    // MEET: the block's own tables of what the first form fetches from sc[] after every meeting point
+    __shared__ T s_dotv[MEET ? 2 * kPersistMaxM + 2 : 1];   // the dots of the steps
+    __shared__ T s_ys[MEET ? kPersistMaxM : 1];             // s.y of the columns, by position in pcol
+    __shared__ T s_theta0;
+    __shared__ double s_red[5][2][kWaves], s_tot[5][2];
+    __shared__ int s_flag;
     const int tid = threadIdx.x;
     if (tid < kPersistMaxM)
         s_pcol[tid] = pa.pcol[tid];
@@ -695,6 +787,18 @@ __global__ void __launch_bounds__(kHvThreads, 2)
     const int64_t res_end = nres * gthreads < nv ? nres * gthreads : nv;  // vectors [0, res_end) are resident
     const int DOT0 = 2 * (m + 1) + 1;  // ScLayout::dot(0); ys(col) = col; theta(col) = m + 1 + col
     auto sload = [&](int idx) { return T(__hip_atomic_load(sc + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); };
+    if (MEET)
+    {
+        // s.y of the stored pairs and theta of the newest: read once (FUSE: entry 0 and theta are produced by step 0 below)
+        if (tid < cn)
+            s_ys[tid] = sload(s_pcol[tid]);
+        if (tid == 0)
+            s_theta0 = cn > 0 ? sload(m + 1 + s_pcol[0]) : T(1);
+        __syncthreads();
+    }
+    // the dot of step k / s.y of the pair at position i of the list / theta, wherever this form keeps them
+    auto dotv = [&](int k) { return MEET ? s_dotv[MEET ? k : 0] : sload(DOT0 + k); };
+    auto ysv = [&](int i) { return MEET ? s_ys[MEET ? i : 0] : sload(s_pcol[i]); };
     auto col = [&](const T* base, int c) { return base + int64_t(c) * pa.ld; };
 
     Pack<T> rq[NR];
@@ -773,6 +877,42 @@ __global__ void __launch_bounds__(kHvThreads, 2)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         const unsigned want0 = pa.gen_base + 1u;
+        if (MEET)
+        {
+            (void) persist_meet<5, A>(accp, ws, gen, pa.gen_base + gridDim.x, 0, err, true, s_red, s_tot, &s_flag);
+            if (tid == 0)
+            {
+                A z[5];
+#pragma unroll
+                for (int r = 0; r < 5; r++)
+                {
+                    z[r].hi = s_tot[r][0];
+                    z[r].lo = s_tot[r][1];
+                }
+                const T sy = T(z[2].value()), yy = T(z[3].value());
+                s_ys[0] = sy;
+                s_theta0 = yy / sy;
+                s_dotv[0] = T(z[4].value());
+                // a block that gave up must not act on the verdict: its totals are not the totals
+                s_verdict = (s_flag == 2) ? 2 : ((sy > pf.eps * yy) ? 1 : 2);
+                if (blockIdx.x == 0)  // for the host
+                {
+                    pf.out[0] = T(z[0].value());
+                    pf.out[1] = T(z[1].value());
+                    pf.out[2] = sy;
+                    pf.out[3] = yy;
+                    __hip_atomic_store(pf.ys_slot, sy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(pf.theta_slot, yy / sy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(sc + DOT0, T(z[4].value()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(pf.verdict, (sy > pf.eps * yy) ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            __syncthreads();
+            if (s_verdict != 1)
+                return;
+        }
+        else
+        {
         if (grid_reduce<5>(accp, ws))
         {
             if (tid == 0)
@@ -813,6 +953,7 @@ __global__ void __launch_bounds__(kHvThreads, 2)
         __syncthreads();
         if (s_verdict != 1)
             return;  // pair rejected (or the launch timed out): q is not needed, the host takes over
+        }
     }
     for (int L = FUSE ? 1 : 0; L <= 2 * cn; L++)
     {
@@ -829,14 +970,14 @@ __global__ void __launch_bounds__(kHvThreads, 2)
         {
             u = col(Y, s_pcol[L - 1]);
             w = col(S, s_pcol[L]);
-            c = -(sload(DOT0 + L - 1) / sload(s_pcol[L - 1]));
+            c = -(dotv(L - 1) / ysv(L - 1));
         }
         else if (L == cn)
         {
             u = col(Y, s_pcol[cn - 1]);
             w = u;
-            c = -(sload(DOT0 + cn - 1) / sload(s_pcol[cn - 1]));
-            theta = sload(m + 1 + s_pcol[0]);
+            c = -(dotv(cn - 1) / ysv(cn - 1));
+            theta = MEET ? s_theta0 : sload(m + 1 + s_pcol[0]);
             div = true;
         }
         else
@@ -844,7 +985,7 @@ __global__ void __launch_bounds__(kHvThreads, 2)
             const int t = L - cn - 1, i = cn - 1 - t;
             u = col(S, s_pcol[i]);
             w = (t < cn - 1) ? col(Y, s_pcol[i - 1]) : vin;
-            c = sload(DOT0 + i) / sload(s_pcol[i]) - sload(DOT0 + L - 1) / sload(s_pcol[i]);
+            c = dotv(i) / ysv(i) - dotv(L - 1) / ysv(i);
         }
         A acc4[4];
         // resident slots (vectors beyond res_end are zero-weighted inside hv_step through nv = res_end)
@@ -923,6 +1064,25 @@ __global__ void __launch_bounds__(kHvThreads, 2)
         for (int k = 1; k < 4; k++)
             acc[0].merge(acc4[k].hi, acc_lo(acc4[k]));
         const unsigned want = pa.gen_base + unsigned(L) + 1u;
+        if (MEET)
+        {
+            // meeting k of the launch (k = L, counting the fused post step as meeting 0): base + G (k + 1) arrivals
+            const unsigned target = pa.gen_base + unsigned(gridDim.x) * (unsigned(L) + 1u);
+            // (the last step: nobody needs the dot inside the launch, only the last block to arrive works it out)
+            const bool have = persist_meet<1, A>(acc, ws, gen, target, L & 1, err, L < 2 * cn, s_red, s_tot, &s_flag);
+            if (have && tid == 0)
+            {
+                A z;
+                z.hi = s_tot[0][0];
+                z.lo = s_tot[0][1];
+                const T dv = T(z.value());
+                s_dotv[L] = dv;
+                if (blockIdx.x == 0 || L == 2 * cn)  // for the host (and the step launches that may follow a time-out)
+                    __hip_atomic_store(sc + DOT0 + L, dv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            continue;
+        }
         if (grid_reduce<1>(acc, ws))
         {
             if (tid == 0)

@@ -2305,7 +2305,8 @@ static int launch_gram_vonly(lbfgsx_ctx* c, int64_t nbatch, int tot, int vsel_id
 }
 // A Gram over the rows of an index list (2c x 2c, no v row) launched ahead of its request into stash slot `slot`; mask != 0:
 // only the listed rows whose state byte has one of its bits.  false: not launched (the request will launch it itself).
-constexpr int64_t kListOneBlock = 1024;  // rows a single block of kx_gram takes in less time than the three launches of the multi-block form
+constexpr int64_t kListOneBlock = 512 * kGramSelfFinish;  // rows of a list whose Gram ONE kx_gram launch forms and finishes (<= 512 per block)
+static inline int list_blocks(int64_t nlist) { return int(std::max<int64_t>(1, std::min<int64_t>(kGramSelfFinish, (nlist + 127) / 128))); }
 static bool gram_stash_feasible(lbfgsx_ctx* c, const int* list, int64_t nlist)
 {
     lbfgsb_state* b = c->bstate;
@@ -2350,13 +2351,14 @@ static bool gram_stash_launch(lbfgsx_ctx* c, int slot, int mask, const int* list
                 gr.st_alt = bvecs_cv<T>(c).st;
                 gr.st_pos = b->wf_pos;
             }
-            blocks = xl::gram<T>(c->stream, single ? 1 : b->gram_blocks, colsx_full<T>(c, tot), tot, bvecs<T>(c), -1, mask, nlist,
-                                 b->gram_partial, pro, gr, out, out_dd, (signal && single) ? c->ws.done : static_cast<unsigned long long*>(nullptr),
-                                 (signal && single) ? c->ws.seq : 0ull);
+            blocks = xl::gram<T>(c->stream, single ? list_blocks(nlist) : b->gram_blocks, colsx_full<T>(c, tot),
+                                 tot, bvecs<T>(c), -1, mask, nlist, b->gram_partial, pro, gr, out, out_dd,
+                                 (signal && single) ? c->ws.done : static_cast<unsigned long long*>(nullptr),
+                                 (signal && single) ? c->ws.seq : 0ull, b->xtickets + 1 + kMaxGridX / kGroupX);
         });
         if (blocks < 1)
             return false;
-        if (blocks > 1)
+        if (blocks > kGramSelfFinish)
         {
             const int nt = xl::gram_kpb(tot);
             if (signal)
@@ -3193,8 +3195,10 @@ static int gram_dd_core(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, cons
                 gr.out_pos = b->wf_pos;
             }
             const ColsX<T> cl = (gr.in_idx && !gr.w_by_row) ? colsx_wf<T>(c, tot) : colsx_full<T>(c, tot);
-            blocks = xl::gram<T>(c->stream, one_block ? 1 : b->gram_blocks, cl, tot, bvecs<T>(c), vsel_id, mask, nrows, b->gram_partial, pro,
-                                 gr, b->gram_out, gram_dd ? b->gram_dd : static_cast<double*>(nullptr));
+            blocks = xl::gram<T>(c->stream, one_block ? list_blocks(nrows) : b->gram_blocks, cl, tot, bvecs<T>(c),
+                                 vsel_id, mask, nrows, b->gram_partial, pro, gr, b->gram_out,
+                                 gram_dd ? b->gram_dd : static_cast<double*>(nullptr), nullptr, 0ull,
+                                 one_block ? b->xtickets + 1 + kMaxGridX / kGroupX : static_cast<unsigned*>(nullptr));
         });
         if (blocks < 1)
         {
@@ -3203,7 +3207,7 @@ static int gram_dd_core(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, cons
         }
         if (compact_out)
             wf_rebuilt(c);
-        if (blocks > 1)
+        if (blocks > kGramSelfFinish || !one_block)
         {
             rc = xl::gram_finish(c->stream, b->gram_partial, blocks, ntile_, b->gram_partial2, b->gram_out,
                                  gram_dd ? b->gram_dd : static_cast<double*>(nullptr), nullptr, 0ull,

@@ -27,6 +27,7 @@
 namespace lbfgsx {
 
 constexpr int kColsX = 80;  // 2c <= 80: every m an L-BFGS-B context accepts
+constexpr int kGramSelfFinish = 16;  // blocks up to which a kx_gram launch adds its partials itself (no kx_gram_finish)
 
 template <class T>
 struct ColsX
@@ -993,10 +994,11 @@ template <class T, int KPB>
 __global__ void __launch_bounds__(kBlock)
     kx_gram(ColsX<T> cols, int ncols, BVecs<T> b, int vsel_id, int mask, int64_t n, double* __restrict__ partial, ProX<T> pro,
             GramRows<T> gr, int cs, double* __restrict__ fin_out, double* __restrict__ fin_dd, unsigned long long* done,
-            unsigned long long seq)
+            unsigned long long seq, unsigned* __restrict__ ticket)
 {
-    // fin_out (a launch of ONE block only: the Grams over the short row lists of the sweeps): the block's sums are the sums --
-    // rounded entries to fin_out[e], (hi, lo) to fin_dd, the completion word last; no kx_gram_finish launches
+    // fin_out (launches of at most kGramSelfFinish blocks: the Grams over the short row lists of the sweeps): the launch
+    // finishes its sums itself -- the last block to arrive (ticket) adds the blocks' partials; rounded entries to fin_out[e],
+    // (hi, lo) to fin_dd, the completion word last; no kx_gram_finish launches
     extern __shared__ double tile[];  // [64][cs], then the rows' numbers
     __shared__ T pc1[kColsX], pc2[kColsX];
     __shared__ const T* s_col[kColsX];
@@ -1128,12 +1130,50 @@ __global__ void __launch_bounds__(kBlock)
         }
         __syncthreads();  // the tile is staged again
     }
-    if (fin_out && gridDim.x == 1)
+#pragma unroll
+    for (int k = 0; k < KPB; k++)
+        acc0[k].merge(acc1[k].hi, acc1[k].lo);
+    const int nb = gridDim.x;
+    if (fin_out && nb > 1)
+    {
+        // this block's sums where the last block finds them (write-through, drained before the ticket: reduce.cuh)
+        double* part = partial + size_t(blockIdx.x) * (KPB * 256) * 2;
+#pragma unroll
+        for (int k = 0; k < KPB; k++)
+        {
+            const int e = tid * KPB + k;
+            st_agent(part + e * 2 + 0, acc0[k].hi);
+            st_agent(part + e * 2 + 1, acc0[k].lo);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __shared__ int s_last;
+        __syncthreads();
+        if (tid == 0)
+        {
+            const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (old == unsigned(nb - 1));
+            if (last)
+            {
+                __threadfence();
+                __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            s_last = last;
+        }
+        __syncthreads();
+        if (!s_last)
+            return;
+#pragma unroll
+        for (int k = 0; k < KPB; k++)
+        {
+            const int e = tid * KPB + k;
+            acc0[k] = sum_partials_x<DD>(partial + size_t(e) * 2, size_t(KPB * 256) * 2, nb);
+        }
+    }
+    if (fin_out)
     {
 #pragma unroll
         for (int k = 0; k < KPB; k++)
         {
-            acc0[k].merge(acc1[k].hi, acc1[k].lo);
             const int e = tid * KPB + k;
             fin_out[e] = acc0[k].value();
             if (fin_dd)
@@ -1155,7 +1195,6 @@ __global__ void __launch_bounds__(kBlock)
 #pragma unroll
     for (int k = 0; k < KPB; k++)
     {
-        acc0[k].merge(acc1[k].hi, acc1[k].lo);
         const int e = tid * KPB + k;
         part[e * 2 + 0] = acc0[k].hi;
         part[e * 2 + 1] = acc0[k].lo;

@@ -185,7 +185,7 @@ int gram_kpb(int ntot)
 template <class T, int KPB>
 static int gram_kp(hipStream_t s, int max_blocks, const ColsX<T>& cols, int ncols, const BVecs<T>& b, int vsel_id, int mask,
                    int64_t n, double* partial, const ProX<T>& pro, const GramRows<T>& gr, double* fin_out, double* fin_dd,
-                   unsigned long long* done, unsigned long long seq)
+                   unsigned long long* done, unsigned long long seq, unsigned* ticket)
 {
     const int ntot = ncols + (vsel_id >= 0 ? 1 : 0);
     const int cs = ntot | 1;  // odd row stride: the lanes of a wave that read one row hit distinct banks
@@ -195,7 +195,7 @@ static int gram_kp(hipStream_t s, int max_blocks, const ColsX<T>& cols, int ncol
     const int64_t nbatch = (n + 63) / 64;
     const int blocks = int(std::max<int64_t>(1, std::min<int64_t>(max_blocks, nbatch)));
     LBFGSX_LAUNCH((kx_gram<T, KPB>), dim3(blocks), dim3(kBlock), lds, s, cols, ncols, b, vsel_id, mask, n, partial, pro, gr, cs,
-                  blocks == 1 ? fin_out : static_cast<double*>(nullptr), fin_dd, done, seq);
+                  (blocks <= kGramSelfFinish && ticket) ? fin_out : static_cast<double*>(nullptr), fin_dd, done, seq, ticket);
     if (hipGetLastError() != hipSuccess)
         return -1;
     return blocks;
@@ -204,11 +204,11 @@ static int gram_kp(hipStream_t s, int max_blocks, const ColsX<T>& cols, int ncol
 template <class T>
 int gram(hipStream_t s, int max_blocks, const ColsX<T>& cols, int ncols, const BVecs<T>& b, int vsel_id, int mask, int64_t n,
          double* partial, const ProX<T>& pro, const GramRows<T>& gr, double* fin_out, double* fin_dd, unsigned long long* done,
-         unsigned long long seq)
+         unsigned long long seq, unsigned* ticket)
 {
     if (ncols < 1 || ncols > kColsX)
         return -1;
-#define GK(K) return gram_kp<T, K>(s, max_blocks, cols, ncols, b, vsel_id, mask, n, partial, pro, gr, fin_out, fin_dd, done, seq)
+#define GK(K) return gram_kp<T, K>(s, max_blocks, cols, ncols, b, vsel_id, mask, n, partial, pro, gr, fin_out, fin_dd, done, seq, ticket)
     switch (gram_kpb(ncols + (vsel_id >= 0 ? 1 : 0)))
     {
     case 1: GK(1);
@@ -253,7 +253,7 @@ int gram_finish(hipStream_t s, const double* partial, int blocks, int ntile, dou
     template int multidot_mask<T>(hipStream_t, int, const ColsX<T>&, int, const BVecs<T>&, int, const T*, int, int64_t,            \
                                   const RedWsX&, double*);                                                                       \
     template int gram<T>(hipStream_t, int, const ColsX<T>&, int, const BVecs<T>&, int, int, int64_t, double*, const ProX<T>&,      \
-                         const GramRows<T>&, double*, double*, unsigned long long*, unsigned long long);                                                                                    \
+                         const GramRows<T>&, double*, double*, unsigned long long*, unsigned long long, unsigned*);                                                                                    \
     template int wf_append<T>(hipStream_t, const ColsX<T>&, int, T*, int64_t, int*, int*, const int*, unsigned*, unsigned, unsigned)
 INST(double);
 INST(float);

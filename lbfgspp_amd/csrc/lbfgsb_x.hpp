@@ -36,13 +36,14 @@ int wf_append(hipStream_t s, const ColsX<T>& orig, int ncols, T* wf, int64_t wf_
               unsigned* cnt, unsigned cap, unsigned wf_cap);
 // entries per thread of kx_gram for 2c + 1 (+ v) = ntot columns; the partial buffer holds [blocks][gram_kpb * 256][2] doubles
 int gram_kpb(int ntot);
-// returns the number of blocks launched, < 0: error.  More than one block: their partials wait for gram_finish.  ONE block
-// (max_blocks = 1: the Grams over the short row lists of the sweeps) and fin_out given: the launch itself leaves the rounded
-// entries in fin_out, the (hi, lo) pairs in fin_dd and stores the completion word -- no gram_finish
+// returns the number of blocks launched, < 0: error.  More than kGramSelfFinish blocks (or no ticket word): their partials
+// wait for gram_finish.  Up to kGramSelfFinish blocks (max_blocks: the Grams over the short row lists of the sweeps) with
+// fin_out and a zeroed ticket word given: the launch itself leaves the rounded entries in fin_out, the (hi, lo) pairs in fin_dd
+// and stores the completion word -- no gram_finish
 template <class T>
 int gram(hipStream_t s, int max_blocks, const ColsX<T>& cols, int ncols, const BVecs<T>& b, int vsel_id, int mask, int64_t n,
          double* partial, const ProX<T>& pro, const GramRows<T>& gr, double* fin_out = nullptr, double* fin_dd = nullptr,
-         unsigned long long* done = nullptr, unsigned long long seq = 0);
+         unsigned long long* done = nullptr, unsigned long long seq = 0, unsigned* ticket = nullptr);
 // two-level sum of `blocks` partial sets of `ntile` tiles each: rounded entries to out[ntile * 256], (hi, lo) to out_dd
 int gram_finish(hipStream_t s, const double* partial, int blocks, int ntile, double* partial2, double* out, double* out_dd,
                 unsigned long long* done, unsigned long long seq, unsigned* ticket);

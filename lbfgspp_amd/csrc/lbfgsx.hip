@@ -336,6 +336,8 @@ static int create_fill(lbfgsx_ctx* c, int dtype, int64_t n, int m, int device, i
     }
     if (const char* e = getenv("LBFGSX_PERSIST"))
         c->persist = atoi(e) != 0 && c->persist;
+    if (const char* e = getenv("LBFGSX_MEET"))  // "last": the round-1..3 meeting points (the last block reduces and publishes)
+        c->meet_all = std::strcmp(e, "last") != 0;
     if (const char* e = getenv("LBFGSX_TRIAL_POLICY"))
         c->trial_policy = atoi(e);
     if (const char* e = getenv("LBFGSX_FUSE_POST"))
@@ -346,9 +348,9 @@ static int create_fill(lbfgsx_ctx* c, int dtype, int64_t n, int m, int device, i
         hipDeviceProp_t prop;
         LBFGSX_HIP(hipGetDeviceProperties(&prop, device));
         if (dtype == LBFGSX_F64)
-            (void) hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_twoloop_persist<double, true>, kHvThreads, 0);
+            (void) hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_twoloop_persist<double, true, true>, kHvThreads, 0);
         else
-            (void) hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_twoloop_persist<float, true>, kHvThreads, 0);
+            (void) hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_twoloop_persist<float, true, true>, kHvThreads, 0);
         c->persist_grid = occ * prop.multiProcessorCount;
         LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&c->gen_dev), 4 * sizeof(unsigned)));  // generation, time-out flag, verdict
         LBFGSX_HIP(hipMemset(c->gen_dev, 0, 4 * sizeof(unsigned)));
@@ -760,7 +762,9 @@ static int apply_Hv_t(lbfgsx_ctx* c, const T* v, T a, double* dg)
         pa.zigzag = c->zigzag ? 1 : 0;
         pa.first_rev = c->tl_step;
         pa.ld = c->ld;
-        c->gen_count += unsigned(2 * cn + 1);
+        // the word the blocks meet at: a generation number (+1 per meeting point), or -- LBFGSX_MEET=all, the default -- a
+        // count of arrivals (+ grid per meeting point)
+        c->gen_count += unsigned(2 * cn + 1) * (c->meet_all ? unsigned(c->persist_grid) : 1u);
         c->tl_step += unsigned(2 * cn + 1);
         // A plain launch of exactly occupancy * CUs blocks.  No other persistent kernel of this process is in flight on
         // the device (the lock above, held until the synchronisation below), so every block becomes resident as soon
@@ -768,9 +772,14 @@ static int apply_Hv_t(lbfgsx_ctx* c, const T* v, T a, double* dg)
         // process and rocprofv3 crashes at exit after cooperative launches on this stack; a device shared with another
         // PROCESS is caught by the wall-clock bound of the kernel's meeting points (the product is then redone with
         // the step launches), never by a hang.
-        LBFGSX_LAUNCH((k_twoloop_persist<T, false>), dim3(c->persist_grid), dim3(kHvThreads), 0, c->stream, q, v, a,
-                           P<T>(c->S), P<T>(c->Y), c->n, sc, pa, c->ws, c->gen_dev, reinterpret_cast<int*>(c->gen_dev + 1),
-                           PostFuse<T>());
+        if (c->meet_all)
+            LBFGSX_LAUNCH((k_twoloop_persist<T, false, true>), dim3(c->persist_grid), dim3(kHvThreads), 0, c->stream, q, v, a,
+                               P<T>(c->S), P<T>(c->Y), c->n, sc, pa, c->ws, c->gen_dev, reinterpret_cast<int*>(c->gen_dev + 1),
+                               PostFuse<T>());
+        else
+            LBFGSX_LAUNCH((k_twoloop_persist<T, false, false>), dim3(c->persist_grid), dim3(kHvThreads), 0, c->stream, q, v, a,
+                               P<T>(c->S), P<T>(c->Y), c->n, sc, pa, c->ws, c->gen_dev, reinterpret_cast<int*>(c->gen_dev + 1),
+                               PostFuse<T>());
         LBFGSX_HIP(hipGetLastError());
         int* err = reinterpret_cast<int*>(c->gen_dev + 1);
         c->persist_launches++;
@@ -1162,7 +1171,7 @@ static int post_spec_t(lbfgsx_ctx* c, T a, double* r4)
     pa.zigzag = c->zigzag ? 1 : 0;
     pa.first_rev = c->tl_step;
     pa.ld = c->ld;
-    c->gen_count += unsigned(2 * cn + 1);
+    c->gen_count += unsigned(2 * cn + 1) * (c->meet_all ? unsigned(c->persist_grid) : 1u);
     c->tl_step += unsigned(2 * cn + 1);
     T* sc = P<T>(c->sc);
     PostFuse<T> pf;
@@ -1183,9 +1192,14 @@ static int post_spec_t(lbfgsx_ctx* c, T a, double* r4)
         LBFGSX_HIP(hipEventCreate(&hv.b));
         LBFGSX_HIP(hipEventRecord(hv.a, c->stream));
     }
-    LBFGSX_LAUNCH((k_twoloop_persist<T, true>), dim3(c->persist_grid), dim3(kHvThreads), 0, c->stream, P<T>(c->d),
-                       P<T>(c->gb[c->cur]), a, P<T>(c->S), P<T>(c->Y), c->n, sc, pa, c->ws, c->gen_dev,
-                       reinterpret_cast<int*>(c->gen_dev + 1), pf);
+    if (c->meet_all)
+        LBFGSX_LAUNCH((k_twoloop_persist<T, true, true>), dim3(c->persist_grid), dim3(kHvThreads), 0, c->stream, P<T>(c->d),
+                           P<T>(c->gb[c->cur]), a, P<T>(c->S), P<T>(c->Y), c->n, sc, pa, c->ws, c->gen_dev,
+                           reinterpret_cast<int*>(c->gen_dev + 1), pf);
+    else
+        LBFGSX_LAUNCH((k_twoloop_persist<T, true, false>), dim3(c->persist_grid), dim3(kHvThreads), 0, c->stream, P<T>(c->d),
+                           P<T>(c->gb[c->cur]), a, P<T>(c->S), P<T>(c->Y), c->n, sc, pa, c->ws, c->gen_dev,
+                           reinterpret_cast<int*>(c->gen_dev + 1), pf);
     LBFGSX_HIP(hipGetLastError());
     if (c->timing)
     {
@@ -1236,6 +1250,8 @@ static int post_spec_t(lbfgsx_ctx* c, T a, double* r4)
     else
     {
         c->spec_rejected++;
+        if (c->meet_all)  // only the first of the 2c+1 meeting points took place: the arrival count stands at base + grid
+            c->gen_count = pa.gen_base + unsigned(c->persist_grid);
         if (c->timing && !c->ev_hv.empty())  // only step 0 ran: not an apply_Hv to be averaged
         {
             (void) hipEventDestroy(c->ev_hv.back().a);

@@ -326,6 +326,43 @@ def test_default_switch_between_the_step_launches_and_the_persistent_kernel(A, o
     assert (r.niter, r.nfev) == res["default"][:2] and np.array_equal(res["default"][3], x_ref)
 
 
+@pytest.mark.parametrize("dtype,n,m,ls", [(O.F64, 300002, 7, O.LS_MT), (O.F32, 100002, 5, O.LS_MT), (O.F64, 2051, 12, O.LS_NW),
+                                          (O.F64, 20_000_002, 4, O.LS_MT), (O.F64, 10_000_000, 10, O.LS_NW)])
+def test_both_forms_of_the_meeting_points_give_the_same_bits(A, oracle, monkeypatch, dtype, n, m, ls):
+    """Between two steps of the persistent launch the blocks meet.  Default (round 4): every block counts itself in on a
+    counter, waits for the count and adds the G partials up itself, keeping the dots of the steps in its own LDS table.
+    LBFGSX_MEET=last (rounds 1-3): the last block to arrive reduces, publishes the dot and a generation word the others poll,
+    and every block fetches the coefficient back.  Same partials, same order of additions: the same trajectory bit for bit,
+    with the post statements fused (step 0 of the launch, five sums) and without; n = 2e7 has a streamed part, n = 1e7 is
+    cfg2's size (q fully resident), n = 2051 a scalar tail; the oracle pins both."""
+    import gc
+    obj, oobj = (A.ExtendedRosenbrock(), O.OBJ_ROSEN) if ls == O.LS_MT else (None, O.OBJ_QUAD)
+    a = b = None
+    if obj is None:
+        a, b = O.quad_problem(n, 10.0, 1, dtype)
+        obj = A.DiagQuadratic(a, b)
+    x0 = O.rosen_x0(n, 11, dtype) if ls == O.LS_MT else np.zeros(n, O.NPDT[dtype])
+    iters = 2 * m + 6
+    res = {}
+    for meet, fuse in (("all", "1"), ("last", "1"), ("all", "0")):
+        monkeypatch.setenv("LBFGSX_MEET", meet)
+        monkeypatch.setenv("LBFGSX_FUSE_POST", fuse)
+        gc.collect()
+        s = A.LBFGSSolver(A.LBFGSParam(m=m, epsilon=0.0, epsilon_rel=0.0, max_iterations=iters), linesearch=ls, dtype=O.NPDT[dtype])
+        x = x0.copy()
+        tr = A.TraceBuffer(n, cap=256, with_x=False)
+        niter, fx = s.minimize(obj, x, trace=tr)
+        res[(meet, fuse)] = (niter, s.last.nfev, fx, x, tr.fx[:tr.count].copy())
+        del s
+        gc.collect()
+    ref = res[("last", "1")]
+    for k, r in res.items():
+        assert r[:3] == ref[:3] and np.array_equal(r[3], ref[3]) and np.array_equal(r[4], ref[4]), k
+    if n <= 300002:
+        x_ref, rr = oracle.lbfgs(dtype, ls, oobj, x0, O.lbfgs_params(m=m, epsilon=0, epsilon_rel=0, max_iterations=iters), a=a, b=b)
+        assert (rr.niter, rr.nfev) == ref[:2] and np.array_equal(ref[3], x_ref)
+
+
 def _spec_counts(A, s):
     import ctypes as C
     core, _ = A.load()
