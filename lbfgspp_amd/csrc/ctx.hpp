@@ -179,8 +179,9 @@ struct lbfgsx_ctx
     unsigned tl_step = 0;  // launches issued so far (parity selects the direction)
     // persistent one-launch apply_Hv (k_twoloop_persist)
     bool persist = true;           // LBFGSX_PERSIST=0: always the 2c+1 step launches
-    bool meet_all = true;          // how the blocks of the persistent launch meet between steps (lbfgs_kernels.cuh, persist_meet):
-                                   // every block adds the partials up itself (default), or LBFGSX_MEET=last: the last block does
+    bool meet_all = true;          // how the blocks of the persistent launch learn a step's dot (lbfgs_kernels.cuh, persist_publish):
+                                   // one tagged 16-byte word polled after the next step's loads are issued (default), or
+                                   // LBFGSX_MEET=last: generation word + scalar table, waited for at the end of the step
     // A persistent launch whose meeting points timed out (CUs held by another process) is redone with the step launches,
     // which the context then keeps for `persist_cooldown` products before it tries the persistent form again; every
     // further time-out quadruples the pause (8, 32, ... 8192 products), a clean persistent product resets it.
@@ -189,7 +190,8 @@ struct lbfgsx_ctx
     int64_t persist_timeouts = 0;  // instrumentation (lbfgsx_persist_counts)
     int64_t step_products = 0;     // products computed with the 2c+1 step launches
     int persist_grid = 0;          // co-resident blocks (occupancy * CUs), 0 = unavailable
-    unsigned* gen_dev = nullptr;   // generation word + error word
+    unsigned* gen_dev = nullptr;   // generation word, error word, verdict, -; three tagged 16-byte slots {tag, 0, double}
+    size_t gen_words = 0;          // its size (the blocks' tagged partial sums follow the 16 header words)
     unsigned gen_count = 0;
     int64_t persist_steps_timed = 0;
     int64_t coarse_steps_timed = 0;

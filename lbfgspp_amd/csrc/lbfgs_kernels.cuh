@@ -478,13 +478,28 @@ constexpr int kHvThreads = 256;
 //                                                      exactly) or alpha - beta (second loop, :299)
 //   always          q = q / theta afterwards           (:293; theta = 1 outside the division step)
 //   dot operand     w, or u itself when dot_u (the SUBDIV step reduces against the column it just subtracted)
-template <class T, int NR, int NL, class A>
+constexpr int kHvChunk = 6;  // slots per chunk of hv_step: 2 x 6 16-byte loads in flight per thread, then the arithmetic
+// the loads of the first chunk of a step, issued by the caller ahead of the step (while it waits for the step's coefficient)
+template <class T>
+__device__ __forceinline__ void hv_prefetch(const T* u, const T* w, int64_t nv, int64_t vbase, int64_t vstride,
+                                            Pack<T> (&pu)[kHvChunk], Pack<T> (&pw)[kHvChunk])
+{
+#pragma unroll
+    for (int k = 0; k < kHvChunk; k++)
+    {
+        const int64_t vi = int64_t(k) * vstride + vbase;
+        const int64_t vc = vi < nv ? vi : int64_t(0);
+        pu[k] = ldv<T, true>(u, vc);
+        pw[k] = ldv<T, true>(w, vc);
+    }
+}
+template <class T, int NR, int NL, class A, bool PRE = false>
 __device__ __forceinline__ void hv_step(Pack<T> (&rq)[NR], typename Vec16<T>::type* lq, const T* u, const T* w,
                                         bool init, T a, T c, T theta, int64_t nv, int64_t vbase, int64_t vstride,
-                                        int ltid, A (&acc)[4])
+                                        int ltid, A (&acc)[4], const Pack<T>* pre_u = nullptr, const Pack<T>* pre_w = nullptr)
 {
     constexpr int W = Vec16<T>::W;
-    constexpr int U = 6;  // slots per chunk: 2 U 16-byte loads in flight per thread, then the arithmetic
+    constexpr int U = kHvChunk;
 #pragma unroll
     for (int s0 = 0; s0 < NR + NL; s0 += U)
     {
@@ -497,8 +512,16 @@ __device__ __forceinline__ void hv_step(Pack<T> (&rq)[NR], typename Vec16<T>::ty
                 const int64_t vi = int64_t(s0 + k) * vstride + vbase;
                 ok[k] = vi < nv;
                 const int64_t vc = ok[k] ? vi : int64_t(0);  // always a valid address; zero-weighted below
-                pu[k] = ldv<T, true>(u, vc);
-                pw[k] = ldv<T, true>(w, vc);
+                if (PRE && s0 == 0)  // hv_prefetch has them
+                {
+                    pu[k] = pre_u[k];
+                    pw[k] = pre_w[k];
+                }
+                else
+                {
+                    pu[k] = ldv<T, true>(u, vc);
+                    pw[k] = ldv<T, true>(w, vc);
+                }
             }
 #pragma unroll
         for (int k = 0; k < U; k++)
@@ -660,90 +683,161 @@ __device__ __forceinline__ void hv_post_step(Pack<T> (&rq)[NR], typename Vec16<T
 constexpr int kPersistNR = 30;
 constexpr int kPersistNL = 15;
 
-// Meeting point of the persistent launch, second form (MEET): every block works the dot out for itself.
-// The first form hands the partials to the LAST block to arrive: ticket -> that block reads the G partials, reduces, stores
-// the rounded dot in sc[] and bumps a generation word -> the others, which have been polling that word, go on and fetch the
-// coefficient back from sc[].  Four dependent trips through the memory system after the last arrival (ticket, partials,
-// publish, coefficient): ~12 us per step, which is a third of a step at n = 1e7 (cfg2: 0.039 ms per step against 0.027 ms of
-// data).  Here a block stores its partial, counts itself in (one atomic add on a counter that only ever grows: the target of
-// meeting k of a launch is base + G (k + 1)), polls the COUNTER until everybody is in, and then reads the G partials and adds
-// them up itself -- every block the same partials in the same order, hence the same bits, which are also the bits the last
-// block of the first form produces.  Two trips (counter, partials), no publish, and the coefficients of the later steps come
-// from the block's own table of dots in LDS instead of sc[].  The partials of consecutive meetings alternate between two
-// row sets (a fast block's next partial must not land where a slow block still reads the previous ones).
-// wait = false (the last step: nobody needs the dot inside the launch): only the last block to arrive goes on.
-// Returns false in blocks that have nothing more to do; totals: sum r in tot[r][0..1] (hi, lo), valid after the call.
-template <int NS, class A>
-__device__ __forceinline__ bool persist_meet(A (&acc)[NS], const RedWs& ws, unsigned* __restrict__ arrive, unsigned target, int parity,
-                                             int* __restrict__ err, bool wait, double (*sh)[2][kWaves], double (*tot)[2], int* s_flag)
+// Meeting point of the persistent launch, second form (MEET).
+// First form: the last block to arrive reduces the partials, stores the rounded dot in sc[] and bumps a generation word; the
+// others poll that word, meet at a block barrier, fetch the step's coefficient back from sc[] (dot and s.y: one more trip through
+// memory) and only then issue the first loads of the next step: ~12 us between the last arrival and the first arithmetic of the
+// next step -- a third of a step at n = 1e7 (cfg2: 0.039 ms per step against 0.027 ms of data).
+// Here the last block publishes {generation, dot} in ONE 16-byte store and the others poll those 16 bytes: whoever sees the
+// generation has the dot.  s.y of the stored pairs and theta never change during a launch, so they sit in LDS from the start,
+// and so does every dot a block has seen -- no coefficient is fetched from sc[].  And the wait moves from the end of a step to
+// the beginning of the next one, behind the loads of that step's first chunk of u and w (their addresses do not depend on the
+// dot): the memory latency of the first loads runs while the block waits.
+// (A form in which every block adds the G partials up itself -- no publish at all -- was measured first: bit-identical, but
+// 512 blocks reading the same 8 KB made it 17 us per meeting point SLOWER: profiles/r4_meet_ab.txt.)
+__device__ __forceinline__ void persist_publish(unsigned* slot /* 16-byte aligned */, unsigned tag, double v)
 {
-    const int tid = threadIdx.x, G = gridDim.x;
-    const int rb = parity * 16;  // rows of this meeting: (hi, lo) of sum r in rows rb + 2 r, rb + 2 r + 1 (NS <= 8)
-    A mine = block_reduce_all<NS, A>(acc, sh);
-    if (tid < NS)
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(slot, 0, 16, 0x00020000);
+    i4_t w;
+    const unsigned long long bits = (unsigned long long) __double_as_longlong(v);
+    w.x = int(tag);
+    w.y = 0;
+    w.z = int(unsigned(bits & 0xFFFFFFFFull));
+    w.w = int(unsigned(bits >> 32));
+    // everything this thread stored before (the re-armed ticket of grid_reduce, the scalars for the host) is out first
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_raw_buffer_store_b128(w, r, 0, 0, kSc1);
+}
+// polls the slot until its tag reaches `want` (wrap-safe); false: gave up (time-out / another block gave up)
+__device__ __forceinline__ bool persist_await(unsigned* slot, unsigned want, int* __restrict__ err, double& v)
+{
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(slot, 0, 16, 0x00020000);
+    unsigned spins = 0;
+    const unsigned long long t_begin = wall_clock64();  // constant 100 MHz counter (s_memrealtime)
+    for (;;)
     {
-        st_agent(ws.partials + size_t(rb + 2 * tid) * ws.maxGrid + blockIdx.x, mine.hi);
-        st_agent(ws.partials + size_t(rb + 2 * tid + 1) * ws.maxGrid + blockIdx.x, acc_lo(mine));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // write-through stores drained before this block counts itself in
+        asm volatile("" ::: "memory");  // the buffer load is an ordinary read to the compiler: keep it inside the loop
+        const i4_t w = __builtin_amdgcn_raw_buffer_load_b128(r, 0, 0, kSc1);
+        if (int(unsigned(w.x) - want) >= 0)
+        {
+            v = __longlong_as_double((long long) ((unsigned long long) unsigned(w.z) | ((unsigned long long) unsigned(w.w) << 32)));
+            return true;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        // never hang the device: after 100 ms of wall-clock waiting (or as soon as another block gave up) the blocks are not
+        // all resident -- some other process holds CUs.  Flag the launch as failed and run to the end; the host redoes the
+        // product with the step launches.
+        if ((++spins & 1023u) == 0u &&
+            (wall_clock64() - t_begin > 10000000ull || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
+        {
+            __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v = 0.0;
+            return false;
+        }
+    }
+}
+
+// The sums of a meeting point without a ticket: every block leaves its NRED partial sums as tagged 16-byte words
+// ({tag, 0, hi} and {tag, 0, lo}, laid out [(2 r + h) G + block] after the three slots above) and moves on -- no drain, no
+// atomic, no wait for an answer; block 0 polls the G blocks' words until they carry this meeting point's tag, adds them up
+// and returns true with the totals in acc[] of thread 0.  (The ticket of grid_reduce is an agent-scope atomic on one
+// address: 512 of them queue up at one memory channel, and every block sat out its round trip before it could issue the
+// next step's loads.)  A block's streamed q stores are drained by its waves before the __syncthreads inside
+// block_reduce_all, i.e. before its words go out, so the meeting point still orders q.
+template <int NRED, class A>
+__device__ __forceinline__ bool persist_gather(A (&acc)[NRED], unsigned* gen, unsigned tag, int* __restrict__ err)
+{
+    __shared__ double sh[NRED][2][kWaves];
+    __shared__ double sfin[NRED][2];
+    __shared__ int s_bad;
+    const int G = gridDim.x, tid = threadIdx.x;
+    const __amdgpu_buffer_rsrc_t r =
+        __builtin_amdgcn_make_buffer_rsrc(gen + 16, 0, int(2 * NRED * G * 16), 0x00020000);
+    A mine = block_reduce_all<NRED, A>(acc, sh);
+    if (tid < NRED)
+    {
+        const unsigned long long bh = (unsigned long long) __double_as_longlong(mine.hi);
+        const unsigned long long bl = (unsigned long long) __double_as_longlong(acc_lo(mine));
+        i4_t w;
+        w.x = int(tag);
+        w.y = 0;
+        w.z = int(unsigned(bh & 0xFFFFFFFFull));
+        w.w = int(unsigned(bh >> 32));
+        __builtin_amdgcn_raw_buffer_store_b128(w, r, int(((2 * tid + 0) * G + blockIdx.x) * 16), 0, kSc1);
+        w.z = int(unsigned(bl & 0xFFFFFFFFull));
+        w.w = int(unsigned(bl >> 32));
+        __builtin_amdgcn_raw_buffer_store_b128(w, r, int(((2 * tid + 1) * G + blockIdx.x) * 16), 0, kSc1);
+    }
+    if (blockIdx.x != 0)
+        return false;
+    if (tid == 0)
+        s_bad = 0;
+    __syncthreads();  // and sh[] may be written again
+    A t[NRED];
+    bool bad = false;
+    // two blocks per thread and pass (G = 512: one pass), their words requested together: one round trip, not two
+    for (int b0 = tid; b0 < G && !bad; b0 += 2 * kHvThreads)
+    {
+        const bool two = b0 + kHvThreads < G;
+        const int b1 = two ? b0 + kHvThreads : b0;
+        i4_t w[2][2 * NRED];
+        unsigned spins = 0;
+        const unsigned long long t_begin = wall_clock64();
+        for (;;)
+        {
+            asm volatile("" ::: "memory");  // keeps the loads inside the loop (see persist_await)
+            bool all = true;
+#pragma unroll
+            for (int j = 0; j < 2 * NRED; j++)
+            {
+                w[0][j] = __builtin_amdgcn_raw_buffer_load_b128(r, int((j * G + b0) * 16), 0, kSc1);
+                w[1][j] = __builtin_amdgcn_raw_buffer_load_b128(r, int((j * G + b1) * 16), 0, kSc1);
+            }
+#pragma unroll
+            for (int j = 0; j < 2 * NRED; j++)
+                all = all && (unsigned(w[0][j].x) == tag) && (unsigned(w[1][j].x) == tag);
+            if (all)
+                break;
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 1023u) == 0u &&
+                (wall_clock64() - t_begin > 10000000ull || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
+            {
+                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // see persist_await
+                bad = true;
+                break;
+            }
+        }
+        auto dbl = [](const i4_t& v) {
+            return __longlong_as_double((long long) ((unsigned long long) unsigned(v.z) | ((unsigned long long) unsigned(v.w) << 32)));
+        };
+        if (!bad)
+#pragma unroll
+            for (int j = 0; j < NRED; j++)
+            {
+                t[j].merge(dbl(w[0][2 * j]), dbl(w[0][2 * j + 1]));
+                if (two)
+                    t[j].merge(dbl(w[1][2 * j]), dbl(w[1][2 * j + 1]));
+            }
+    }
+    if (bad)
+        s_bad = 1;
+    mine = block_reduce_all<NRED, A>(t, sh);
+    if (tid < NRED)
+    {
+        sfin[tid][0] = mine.hi;
+        sfin[tid][1] = acc_lo(mine);
     }
     __syncthreads();
     if (tid == 0)
-    {
-        const unsigned old = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int flag = 1;
-        if (!wait)
-            flag = (old == target - 1u) ? 1 : 0;
-        else if (old != target - 1u)
+#pragma unroll
+        for (int k = 0; k < NRED; k++)
         {
-            unsigned spins = 0;
-            const unsigned long long t_begin = wall_clock64();  // constant 100 MHz counter (s_memrealtime)
-            while (int(__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0)
-            {
-                __builtin_amdgcn_s_sleep(1);
-                // never hang the device: after 100 ms of wall-clock waiting (or as soon as another block gave up) the blocks
-                // are not all resident -- some other process holds CUs.  Flag the launch as failed and run to the end; the
-                // host redoes the product with the step launches.
-                if ((++spins & 1023u) == 0u &&
-                    (wall_clock64() - t_begin > 10000000ull || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
-                {
-                    __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    flag = 2;
-                    break;
-                }
-            }
+            A z;
+            z.hi = sfin[k][0];
+            z.lo = sfin[k][1];
+            acc[k] = z;
         }
-        *s_flag = flag;
-    }
-    __syncthreads();
-    if (*s_flag == 0)
-        return false;
-    // every thread gathers a strided share of the G partials of every sum, then the block sum as in grid_reduce
-    A t[NS];
-    for (int b = tid; b < G; b += kHvThreads)
-    {
-        double h[NS], l[NS];
-#pragma unroll
-        for (int r = 0; r < NS; r++)
-        {
-            h[r] = ld_agent(ws.partials + size_t(rb + 2 * r) * ws.maxGrid + b);
-            l[r] = ld_agent(ws.partials + size_t(rb + 2 * r + 1) * ws.maxGrid + b);
-        }
-#pragma unroll
-        for (int r = 0; r < NS; r++)
-            t[r].merge(h[r], l[r]);
-    }
-#pragma unroll
-    for (int r = 0; r < NS; r++)
-        acc[r] = t[r];
-    __syncthreads();  // sh[] reuse
-    mine = block_reduce_all<NS, A>(acc, sh);
-    if (tid < NS)
-    {
-        tot[tid][0] = mine.hi;
-        tot[tid][1] = acc_lo(mine);
-    }
-    __syncthreads();
-    return true;
+    return s_bad == 0;
 }
 
 template <class T, bool FUSE = false, bool MEET = false>
@@ -759,11 +853,9 @@ __global__ void __launch_bounds__(kHvThreads, 2)
     __shared__ int s_pcol[kPersistMaxM];  // dynamic indexing: keep the column list out of scratch
     __shared__ int s_verdict;
     // MEET: the block's own tables of what the first form fetches from sc[] after every meeting point
-    __shared__ T s_dotv[MEET ? 2 * kPersistMaxM + 2 : 1];   // the dots of the steps
+    __shared__ T s_dotv[MEET ? kPersistMaxM + 1 : 1];       // the dots of the first loop's steps; entry cn: the latest later dot
     __shared__ T s_ys[MEET ? kPersistMaxM : 1];             // s.y of the columns, by position in pcol
     __shared__ T s_theta0;
-    __shared__ double s_red[5][2][kWaves], s_tot[5][2];
-    __shared__ int s_flag;
     const int tid = threadIdx.x;
     if (tid < kPersistMaxM)
         s_pcol[tid] = pa.pcol[tid];
@@ -797,7 +889,8 @@ __global__ void __launch_bounds__(kHvThreads, 2)
         __syncthreads();
     }
     // the dot of step k / s.y of the pair at position i of the list / theta, wherever this form keeps them
-    auto dotv = [&](int k) { return MEET ? s_dotv[MEET ? k : 0] : sload(DOT0 + k); };
+    auto dslot = [&](int k) { return MEET ? (k < cn ? k : cn) : 0; };  // (static LDS stays under the 64 KB a launch may have)
+    auto dotv = [&](int k) { return MEET ? s_dotv[dslot(k)] : sload(DOT0 + k); };
     auto ysv = [&](int i) { return MEET ? s_ys[MEET ? i : 0] : sload(s_pcol[i]); };
     auto col = [&](const T* base, int c) { return base + int64_t(c) * pa.ld; };
 
@@ -879,37 +972,50 @@ __global__ void __launch_bounds__(kHvThreads, 2)
         const unsigned want0 = pa.gen_base + 1u;
         if (MEET)
         {
-            (void) persist_meet<5, A>(accp, ws, gen, pa.gen_base + gridDim.x, 0, err, true, s_red, s_tot, &s_flag);
+            // the last block publishes s.y, y.y and the first dot in three tagged 16-byte slots (the first one last, behind a
+            // drain: whoever sees its tag finds the other two); the others poll instead of a generation word + sc[]
+            const bool lastb = persist_gather<5, A>(accp, gen, want0, err);
             if (tid == 0)
             {
-                A z[5];
-#pragma unroll
-                for (int r = 0; r < 5; r++)
+                T sy = T(0), yy = T(0), d0 = T(0);
+                bool ok = true;
+                if (lastb)
                 {
-                    z[r].hi = s_tot[r][0];
-                    z[r].lo = s_tot[r][1];
-                }
-                const T sy = T(z[2].value()), yy = T(z[3].value());
-                s_ys[0] = sy;
-                s_theta0 = yy / sy;
-                s_dotv[0] = T(z[4].value());
-                // a block that gave up must not act on the verdict: its totals are not the totals
-                s_verdict = (s_flag == 2) ? 2 : ((sy > pf.eps * yy) ? 1 : 2);
-                if (blockIdx.x == 0)  // for the host
-                {
-                    pf.out[0] = T(z[0].value());
-                    pf.out[1] = T(z[1].value());
+                    sy = T(accp[2].value());
+                    yy = T(accp[3].value());
+                    d0 = T(accp[4].value());
+                    pf.out[0] = T(accp[0].value());
+                    pf.out[1] = T(accp[1].value());
                     pf.out[2] = sy;
                     pf.out[3] = yy;
                     __hip_atomic_store(pf.ys_slot, sy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(pf.theta_slot, yy / sy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(sc + DOT0, T(z[4].value()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(sc + DOT0, d0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(pf.verdict, (sy > pf.eps * yy) ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    persist_publish(gen + 8, want0, double(sy));
+                    persist_publish(gen + 12, want0, double(yy));
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    persist_publish(gen + 4, want0, double(d0));
                 }
+                else
+                {
+                    double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+                    ok = persist_await(gen + 4, want0, err, v0);
+                    if (ok)
+                        ok = persist_await(gen + 8, want0, err, v1) && persist_await(gen + 12, want0, err, v2);
+                    d0 = T(v0);
+                    sy = T(v1);
+                    yy = T(v2);
+                }
+                s_ys[0] = sy;
+                s_theta0 = yy / sy;
+                s_dotv[0] = d0;
+                // a block that gave up must not act on a verdict: what it holds are not the sums
+                s_verdict = !ok ? 2 : ((sy > pf.eps * yy) ? 1 : 2);
             }
             __syncthreads();
             if (s_verdict != 1)
-                return;
+                return;  // pair rejected (or the launch timed out): q is not needed, the host takes over
         }
         else
         {
@@ -955,12 +1061,12 @@ __global__ void __launch_bounds__(kHvThreads, 2)
             return;  // pair rejected (or the launch timed out): q is not needed, the host takes over
         }
     }
+    bool was_last = false;  // MEET: this block closed the previous meeting point (it holds the dot already)
     for (int L = FUSE ? 1 : 0; L <= 2 * cn; L++)
     {
         const T* u;
         const T* w;
-        T c = T(0), theta = T(1);
-        bool div = false;
+        // the step's vectors depend on L alone, its coefficient on the previous step's dot
         if (L == 0)
         {
             u = vin;
@@ -970,30 +1076,56 @@ __global__ void __launch_bounds__(kHvThreads, 2)
         {
             u = col(Y, s_pcol[L - 1]);
             w = col(S, s_pcol[L]);
-            c = -(dotv(L - 1) / ysv(L - 1));
         }
         else if (L == cn)
         {
             u = col(Y, s_pcol[cn - 1]);
             w = u;
-            c = -(dotv(cn - 1) / ysv(cn - 1));
-            theta = MEET ? s_theta0 : sload(m + 1 + s_pcol[0]);
-            div = true;
         }
         else
         {
             const int t = L - cn - 1, i = cn - 1 - t;
             u = col(S, s_pcol[i]);
             w = (t < cn - 1) ? col(Y, s_pcol[i - 1]) : vin;
+        }
+        int64_t gt = gtid;
+        asm volatile("" : "+v"(gt));  // see kb_twoloop_full: keeps per-slot address math inside the step
+        Pack<T> pu0[kHvChunk], pw0[kHvChunk];
+        if (MEET)
+        {
+            // the first loads of this step are in flight while the block waits for the previous step's dot
+            hv_prefetch<T>(u, w, res_end, gt, gthreads, pu0, pw0);
+            if (L > (FUSE ? 1 : 0))
+            {
+                if (tid == 0 && !was_last)
+                {
+                    double dv = 0.0;
+                    (void) persist_await(gen + 4, pa.gen_base + unsigned(L), err, dv);
+                    s_dotv[dslot(L - 1)] = T(dv);
+                }
+                __syncthreads();
+            }
+        }
+        T c = T(0), theta = T(1);
+        bool div = false;
+        if (L == 0)
+            ;
+        else if (L < cn)
+            c = -(dotv(L - 1) / ysv(L - 1));
+        else if (L == cn)
+        {
+            c = -(dotv(cn - 1) / ysv(cn - 1));
+            theta = MEET ? s_theta0 : sload(m + 1 + s_pcol[0]);
+            div = true;
+        }
+        else
+        {
+            const int i = cn - 1 - (L - cn - 1);
             c = dotv(i) / ysv(i) - dotv(L - 1) / ysv(i);
         }
         A acc4[4];
         // resident slots (vectors beyond res_end are zero-weighted inside hv_step through nv = res_end)
-        {
-            int64_t gt = gtid;
-            asm volatile("" : "+v"(gt));  // see kb_twoloop_full: keeps per-slot address math inside the step
-            hv_step<T, NR, NL>(rq, lq, u, w, L == 0, a, c, theta, res_end, gt, gthreads, tid, acc4);
-        }
+        hv_step<T, NR, NL, A, MEET>(rq, lq, u, w, L == 0, a, c, theta, res_end, gt, gthreads, tid, acc4, pu0, pw0);
         // streamed remainder [res_end, nv): tiles of U vectors per stream, q read and written in HBM
         {
             const bool rev = pa.zigzag && (((pa.first_rev + unsigned(L)) & 1u) != 0u);
@@ -1066,21 +1198,17 @@ __global__ void __launch_bounds__(kHvThreads, 2)
         const unsigned want = pa.gen_base + unsigned(L) + 1u;
         if (MEET)
         {
-            // meeting k of the launch (k = L, counting the fused post step as meeting 0): base + G (k + 1) arrivals
-            const unsigned target = pa.gen_base + unsigned(gridDim.x) * (unsigned(L) + 1u);
-            // (the last step: nobody needs the dot inside the launch, only the last block to arrive works it out)
-            const bool have = persist_meet<1, A>(acc, ws, gen, target, L & 1, err, L < 2 * cn, s_red, s_tot, &s_flag);
-            if (have && tid == 0)
+            // the block that closes the meeting point works the dot out, leaves it for the host (and for the step launches
+            // that may follow a time-out) and publishes {generation, dot} in one 16-byte word; nobody waits here
+            was_last = persist_gather<1, A>(acc, gen, want, err);
+            if (was_last && tid == 0)
             {
-                A z;
-                z.hi = s_tot[0][0];
-                z.lo = s_tot[0][1];
-                const T dv = T(z.value());
-                s_dotv[L] = dv;
-                if (blockIdx.x == 0 || L == 2 * cn)  // for the host (and the step launches that may follow a time-out)
-                    __hip_atomic_store(sc + DOT0 + L, dv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const T dv = T(acc[0].value());
+                s_dotv[dslot(L)] = dv;
+                __hip_atomic_store(sc + DOT0 + L, dv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (L < 2 * cn)  // the last dot is only read by the host
+                    persist_publish(gen + 4, want, double(dv));
             }
-            __syncthreads();
             continue;
         }
         if (grid_reduce<1>(acc, ws))

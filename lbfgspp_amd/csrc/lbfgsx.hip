@@ -352,8 +352,11 @@ static int create_fill(lbfgsx_ctx* c, int dtype, int64_t n, int m, int device, i
         else
             (void) hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_twoloop_persist<float, true, true>, kHvThreads, 0);
         c->persist_grid = occ * prop.multiProcessorCount;
-        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&c->gen_dev), 4 * sizeof(unsigned)));  // generation, time-out flag, verdict
-        LBFGSX_HIP(hipMemset(c->gen_dev, 0, 4 * sizeof(unsigned)));
+        // generation, time-out flag, verdict, -; three tagged 16-byte slots; the blocks' tagged partial sums (persist_gather:
+        // 5 sums x {hi, lo} x 16 bytes per block)
+        c->gen_words = 16 + size_t(10) * size_t(c->persist_grid) * 4;
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&c->gen_dev), c->gen_words * sizeof(unsigned)));
+        LBFGSX_HIP(hipMemset(c->gen_dev, 0, c->gen_words * sizeof(unsigned)));
     }
     const size_t vbytes = size_t(c->ld) * c->esz;
     for (int k = 0; k < 3; k++)
@@ -764,7 +767,7 @@ static int apply_Hv_t(lbfgsx_ctx* c, const T* v, T a, double* dg)
         pa.ld = c->ld;
         // the word the blocks meet at: a generation number (+1 per meeting point), or -- LBFGSX_MEET=all, the default -- a
         // count of arrivals (+ grid per meeting point)
-        c->gen_count += unsigned(2 * cn + 1) * (c->meet_all ? unsigned(c->persist_grid) : 1u);
+        c->gen_count += unsigned(2 * cn + 1);
         c->tl_step += unsigned(2 * cn + 1);
         // A plain launch of exactly occupancy * CUs blocks.  No other persistent kernel of this process is in flight on
         // the device (the lock above, held until the synchronisation below), so every block becomes resident as soon
@@ -799,7 +802,7 @@ static int apply_Hv_t(lbfgsx_ctx* c, const T* v, T a, double* dg)
             // a meeting point timed out (the blocks were not all resident: the device is shared after all).  Nothing
             // was lost -- v and the history are untouched: reset the words the kernel uses and redo this product
             // with the step launches, which this context keeps using for a while (persist_cooldown, ctx.hpp)
-            LBFGSX_HIP(hipMemsetAsync(c->gen_dev, 0, 4 * sizeof(unsigned), c->stream));
+            LBFGSX_HIP(hipMemsetAsync(c->gen_dev, 0, c->gen_words * sizeof(unsigned), c->stream));
             LBFGSX_HIP(hipMemsetAsync(c->ws.ticket, 0, sizeof(unsigned), c->stream));
             c->gen_count = 0;
             persist_timed_out(c);
@@ -1171,7 +1174,7 @@ static int post_spec_t(lbfgsx_ctx* c, T a, double* r4)
     pa.zigzag = c->zigzag ? 1 : 0;
     pa.first_rev = c->tl_step;
     pa.ld = c->ld;
-    c->gen_count += unsigned(2 * cn + 1) * (c->meet_all ? unsigned(c->persist_grid) : 1u);
+    c->gen_count += unsigned(2 * cn + 1);
     c->tl_step += unsigned(2 * cn + 1);
     T* sc = P<T>(c->sc);
     PostFuse<T> pf;
@@ -1222,7 +1225,7 @@ static int post_spec_t(lbfgsx_ctx* c, T a, double* r4)
     if (hflags[0])
     {
         // a meeting point timed out (device shared with another process): reset, never speculate again, redo with k_post
-        LBFGSX_HIP(hipMemsetAsync(c->gen_dev, 0, 4 * sizeof(unsigned), c->stream));
+        LBFGSX_HIP(hipMemsetAsync(c->gen_dev, 0, c->gen_words * sizeof(unsigned), c->stream));
         LBFGSX_HIP(hipMemsetAsync(c->ws.ticket, 0, sizeof(unsigned), c->stream));
         c->gen_count = 0;
         persist_timed_out(c);
@@ -1250,8 +1253,6 @@ static int post_spec_t(lbfgsx_ctx* c, T a, double* r4)
     else
     {
         c->spec_rejected++;
-        if (c->meet_all)  // only the first of the 2c+1 meeting points took place: the arrival count stands at base + grid
-            c->gen_count = pa.gen_base + unsigned(c->persist_grid);
         if (c->timing && !c->ev_hv.empty())  // only step 0 ran: not an apply_Hv to be averaged
         {
             (void) hipEventDestroy(c->ev_hv.back().a);

@@ -329,12 +329,15 @@ def test_default_switch_between_the_step_launches_and_the_persistent_kernel(A, o
 @pytest.mark.parametrize("dtype,n,m,ls", [(O.F64, 300002, 7, O.LS_MT), (O.F32, 100002, 5, O.LS_MT), (O.F64, 2051, 12, O.LS_NW),
                                           (O.F64, 20_000_002, 4, O.LS_MT), (O.F64, 10_000_000, 10, O.LS_NW)])
 def test_both_forms_of_the_meeting_points_give_the_same_bits(A, oracle, monkeypatch, dtype, n, m, ls):
-    """Between two steps of the persistent launch the blocks meet.  Default (round 4): every block counts itself in on a
-    counter, waits for the count and adds the G partials up itself, keeping the dots of the steps in its own LDS table.
-    LBFGSX_MEET=last (rounds 1-3): the last block to arrive reduces, publishes the dot and a generation word the others poll,
-    and every block fetches the coefficient back.  Same partials, same order of additions: the same trajectory bit for bit,
-    with the post statements fused (step 0 of the launch, five sums) and without; n = 2e7 has a streamed part, n = 1e7 is
-    cfg2's size (q fully resident), n = 2051 a scalar tail; the oracle pins both."""
+    """Between two steps of the persistent launch the blocks meet.  Default (round 4): every block leaves its partial sums
+    as tagged 16-byte words and moves on, block 0 polls them, adds them up and publishes {generation, dot} in one tagged
+    word, which the others poll AFTER issuing the next step's first loads, keeping the dots in their own LDS table.
+    LBFGSX_MEET=last (rounds 1-3): a ticket, the last block to arrive reduces, publishes the dot and a generation word the
+    others wait for at the end of the step, and every block fetches the coefficient back.  Double-double partials, correctly
+    rounded totals: the same trajectory bit for bit, with the post statements fused (step 0 of the launch, five sums) and
+    without; n = 2e7 has a streamed part, n = 1e7 is cfg2's size (q fully resident), n = 2051 a scalar tail; the oracle
+    pins both.  No launch may have timed out (a time-out is redone with the step launches: same bits, so only the counter
+    shows it)."""
     import gc
     obj, oobj = (A.ExtendedRosenbrock(), O.OBJ_ROSEN) if ls == O.LS_MT else (None, O.OBJ_QUAD)
     a = b = None
@@ -353,6 +356,10 @@ def test_both_forms_of_the_meeting_points_give_the_same_bits(A, oracle, monkeypa
         tr = A.TraceBuffer(n, cap=256, with_x=False)
         niter, fx = s.minimize(obj, x, trace=tr)
         res[(meet, fuse)] = (niter, s.last.nfev, fx, x, tr.fx[:tr.count].copy())
+        import ctypes as C
+        pc = (C.c_int64 * 4)()
+        A.load()[0].lbfgsx_persist_counts(s.ctx, C.byref(pc))
+        assert pc[0] >= iters - 1 and pc[1] == 0 and pc[3] == 0, (meet, fuse, tuple(pc))
         del s
         gc.collect()
     ref = res[("last", "1")]
