@@ -775,12 +775,11 @@ __device__ __forceinline__ bool persist_gather(A (&acc)[NRED], unsigned* gen, un
     __syncthreads();  // and sh[] may be written again
     A t[NRED];
     bool bad = false;
-    // two blocks per thread and pass (G = 512: one pass), their words requested together: one round trip, not two
-    for (int b0 = tid; b0 < G && !bad; b0 += 2 * kHvThreads)
+    // (both of a thread's blocks in one pass -- one round trip instead of two -- costs the fused kernel 48 bytes more scratch
+    // per lane and measured no faster)
+    for (int b = tid; b < G && !bad; b += kHvThreads)
     {
-        const bool two = b0 + kHvThreads < G;
-        const int b1 = two ? b0 + kHvThreads : b0;
-        i4_t w[2][2 * NRED];
+        i4_t w[2 * NRED];
         unsigned spins = 0;
         const unsigned long long t_begin = wall_clock64();
         for (;;)
@@ -789,13 +788,10 @@ __device__ __forceinline__ bool persist_gather(A (&acc)[NRED], unsigned* gen, un
             bool all = true;
 #pragma unroll
             for (int j = 0; j < 2 * NRED; j++)
-            {
-                w[0][j] = __builtin_amdgcn_raw_buffer_load_b128(r, int((j * G + b0) * 16), 0, kSc1);
-                w[1][j] = __builtin_amdgcn_raw_buffer_load_b128(r, int((j * G + b1) * 16), 0, kSc1);
-            }
+                w[j] = __builtin_amdgcn_raw_buffer_load_b128(r, int((j * G + b) * 16), 0, kSc1);
 #pragma unroll
             for (int j = 0; j < 2 * NRED; j++)
-                all = all && (unsigned(w[0][j].x) == tag) && (unsigned(w[1][j].x) == tag);
+                all = all && (unsigned(w[j].x) == tag);
             if (all)
                 break;
             __builtin_amdgcn_s_sleep(1);
@@ -813,11 +809,7 @@ __device__ __forceinline__ bool persist_gather(A (&acc)[NRED], unsigned* gen, un
         if (!bad)
 #pragma unroll
             for (int j = 0; j < NRED; j++)
-            {
-                t[j].merge(dbl(w[0][2 * j]), dbl(w[0][2 * j + 1]));
-                if (two)
-                    t[j].merge(dbl(w[1][2 * j]), dbl(w[1][2 * j + 1]));
-            }
+                t[j].merge(dbl(w[2 * j]), dbl(w[2 * j + 1]));
     }
     if (bad)
         s_bad = 1;
