@@ -9,7 +9,7 @@
 //     :163-164,191 drt = xcp - x [normalize] -> lbfgsx_b_dir_from_xcp
 //     :174-179 xp=x, gradp=grad, dg, step_max-> lbfgsx_ls_begin (rotation) + lbfgsx_b_dg_maxstep
 //     :203    LineSearchMoreThuente          -> LineSearch policy over lbfgsx_trial
-//     :206,235-237 proj norm, s, y, s.y, y.y -> lbfgsx_b_post_linesearch
+//     :206,235-237 proj norm, s, y, s.y, y.y -> lbfgsx_b_post_linesearch_build (+ the element-wise part of :241)
 //     :238    add_correction                 -> BFGSMatB::add_correction (commit + lbfgsx_b_correction_dots)
 //     :249    SubspaceMin::subspace_minimize -> LBFGSpp::SubspaceMin (lbfgsx_b_wtv / _gram / _wcombine / ...)
 #ifndef LBFGSX_DROPIN_LBFGSB_H
@@ -145,7 +145,9 @@ private:
             m_stats.linesearch_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_ls).count();
 
             double pg = 0, x2 = 0, syd = 0, yyd = 0;
-            detail::check(lbfgsx_b_post_linesearch(c, &pg, &x2, &syd, &yyd));   // (:206,235-237)
+            // (:206,235-237); the pass also takes the element-wise part of the Cauchy search below (:241) along, with the
+            // threshold get_cauchy_point will ask for
+            detail::check(lbfgsx_b_post_linesearch_build(c, Cauchy<Scalar>::build_tau(gcp), &pg, &x2, &syd, &yyd));
             m_projgnorm = Scalar(pg);
             if (m_projgnorm <= m_param.epsilon || m_projgnorm <= m_param.epsilon_rel * sqrt(Scalar(x2)))
                 return k;

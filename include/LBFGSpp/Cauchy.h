@@ -122,6 +122,9 @@ public:
         double t_build = 0, t_fetch = 0, t_total = 0;  // seconds (instrumentation)
     };
 
+    // the threshold the next call will hand to the build (the solver's post pass takes that build along: LBFGSB.h)
+    static double build_tau(const Result& r) { return tau_factor() > 0.0 ? r.tau_hint : 0.0; }
+
     // xcp and the state byte are left on the device; vecc and the set sizes are returned
     static void get_cauchy_point(BFGSMatB<Scalar>& bfgs, Result& out)
     {
@@ -137,7 +140,7 @@ public:
         double wtd[80];
         const auto t_begin = std::chrono::steady_clock::now();
         const double factor = tau_factor();
-        double tau = (factor > 0.0) ? out.tau_hint : 0.0;
+        double tau = build_tau(out);
         detail::check(lbfgsx_b_cauchy_build_partial(c, tau, &nfree, &nord, &lim, &dd, wtd));
         bfgs.finish_correction();  // a deferred add_correction tail: its dots came with the W'd pass of the build
         out.t_build = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();

@@ -224,6 +224,16 @@ int lbfgsx_b_norms(lbfgsx_ctx* c, double* projgnorm, double* xnorm2);
 int lbfgsx_b_dg_maxstep(lbfgsx_ctx* c, double* dg, double* step_max);
 /* after the line search: proj_grad_norm, x.x, s, y (into the spare column), s.y, y.y  (LBFGSB.h:206,213,235-237) */
 int lbfgsx_b_post_linesearch(lbfgsx_ctx* c, double* projgnorm, double* xnorm2, double* sy, double* yy);
+/* the same, and in the same pass over x and g the element-wise part of the Cauchy search that follows when the iteration goes
+ * on (Cauchy.h:95,111-129; what lbfgsx_b_cauchy_build_partial(c, tau, ...) launches first): that call then finds its
+ * break points, d, xcp = x0 and counts ready -- provided nothing has moved x since, the threshold is the same and the
+ * deferred x = clamp(x) (LBFGSB.h:240) has nothing to move; otherwise it runs its own pass.  LBFGSX_POST_BUILD=0, contexts
+ * without mapped outputs and the integer Gram keep the two passes.  (Replaces nothing new in the reference: LBFGSB.h:206-241
+ * in one sweep over the vectors instead of two.) */
+int lbfgsx_b_post_linesearch_build(lbfgsx_ctx* c, double tau, double* projgnorm, double* xnorm2, double* sy, double* yy);
+/* instrumentation, process-wide: {passes of lbfgsx_b_post_linesearch_build that carried the Cauchy half, Cauchy searches that
+ * used it} */
+int lbfgsx_b_post_build_counts(int64_t out[2], int reset);
 /* add_correction tail: sdots[j] = S_j.s_new, ydots[j] = Y_j.s_new for slots j < ncorr  (BFGSMat.h:111,138) */
 int lbfgsx_b_correction_dots(lbfgsx_ctx* c, double* sdots, double* ydots);
 /* ask the next lbfgsx_b_cauchy_build* to take those dots in the pass that computes W'd (Cauchy.h:152) -- the same 2c

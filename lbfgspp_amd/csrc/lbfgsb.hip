@@ -91,6 +91,13 @@ struct lbfgsb_state
     // ub - x0 and the state byte of the free rows at their POSITION in the compact copy, from the first solve-sweep until
     // the result is assigned (or a pass outside the fused path needs them by row again: cv_back)
     // candidates of the partial break-point sort collected by the Cauchy build itself (k_cauchy_build's plist)
+    // lbfgsx_b_post_linesearch_build: the Cauchy search's element-wise pass, taken by the pass of the post statements
+    bool pb_use = true;                   // LBFGSX_POST_BUILD=0: two passes, as rounds 1-3
+    bool pb_valid = false;                // pb_r holds what k_cauchy_build would deliver for the state described below
+    int pb_cur = -1;                      // the iterate buffer the pass read
+    double pb_tau = 0.0;
+    bool pb_wc = false, pb_sel_inline = false;
+    double pb_r[6] = {0, 0, 0, -1, -1, 0};  // d.d, #free, #ordered, #listed outside rows, #sort candidates | #rows the clamp moves
     bool psel_use = true;                 // LBFGSX_SELECT_INLINE=0: rocprim::select behind the build
     int* psel_list = nullptr;             // [psel_cap] rows in arrival order
     unsigned* psel_cnt = nullptr;
@@ -442,6 +449,8 @@ int bounded_alloc(lbfgsx_ctx* c)
         b->wtdc_use = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_SELECT_INLINE"))
         b->psel_use = atoi(e) != 0;
+    if (const char* e = getenv("LBFGSX_POST_BUILD"))
+        b->pb_use = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_SELECT_MAX"))  // candidates of the previous search up to which the build lists them
         b->psel_max = std::max<int64_t>(0, atoll(e));
     if (const char* e = getenv("LBFGSX_SELECT_CAP"))  // test aid: a short list overflows
@@ -967,13 +976,13 @@ static int wtd2_wf_x(lbfgsx_ctx* c, int total, int newest, double* wtd)
 }
 // can this iteration's W'd come from the kept compact copy?  Asked before the build (which then writes the list of the
 // rows outside the copy) and again by cauchy_wtd
-static bool wtdc_ready(lbfgsx_ctx* c)
+static bool wtdc_ready(lbfgsx_ctx* c, bool assume_defer = false)
 {
     lbfgsb_state* b = c->bstate;
     const int total = 2 * c->ncorr;
     // the copy of the previous minimisation, same history length (the commit replaced a slot), not overgrown: the pass must
     // read clearly less than the full-length one
-    return b->wtdc_use && b->corr_defer && (b->split ? (total >= 2 && total <= kColsX) : (total > 8 && total <= 20)) &&
+    return b->wtdc_use && (b->corr_defer || assume_defer) && (b->split ? (total >= 2 && total <= kColsX) : (total > 8 && total <= 20)) &&
            !b->multidot_chunked && b->wf_use && b->wf_live &&
            b->wf_ncorr == c->ncorr && b->wf_epoch == b->sub_epoch && c->ncorr == c->m && c->n < (int64_t(1) << 31) &&
            b->wf_n >= 4096 && b->wf_n * 4 <= c->n * 3;
@@ -1107,6 +1116,7 @@ int lbfgsx_b_force_bounds_deferred(lbfgsx_ctx* c)
 namespace lbfgsx {
 static int run_force_bounds(lbfgsx_ctx* c)
 {
+    c->bstate->pb_valid = false;  // x may change: what the post pass computed ahead for the Cauchy search no longer holds
     lbfgsx::DeviceGuard dev_guard_(c->device);
     const int grid = c->grid_for(c->n);
     DISPATCH_T(c, {
@@ -1130,6 +1140,7 @@ static int b_eval_t(lbfgsx_ctx* c, OBJ obj, double* r3)
 }
 }  // namespace lbfgsx
 
+static bool psel_alloc(lbfgsx_ctx* c);  // (defined with the partial sort below)
 extern "C" {
 
 int lbfgsx_b_eval(lbfgsx_ctx* c, int objective, double* fx, double* projgnorm, double* xnorm2)
@@ -1226,6 +1237,71 @@ int lbfgsx_b_post_linesearch(lbfgsx_ctx* c, double* projgnorm, double* xnorm2, d
     });
     if (rc)
         return rc;
+    c->pend_sy = r[1];
+    c->pend_yy = r[2];
+    c->pending = true;
+    if (xnorm2) *xnorm2 = r[0];
+    if (sy) *sy = r[1];
+    if (yy) *yy = r[2];
+    if (projgnorm) *projgnorm = r[3];
+    return LBFGSX_OK;
+}
+
+static std::atomic<int64_t> g_pb_runs{0}, g_pb_hits{0};
+int lbfgsx_b_post_build_counts(int64_t out[2], int reset)
+{
+    if (out)
+    {
+        out[0] = g_pb_runs.load();
+        out[1] = g_pb_hits.load();
+    }
+    if (reset)
+        g_pb_runs = g_pb_hits = 0;
+    return LBFGSX_OK;
+}
+
+int lbfgsx_b_post_linesearch_build(lbfgsx_ctx* c, double tau, double* projgnorm, double* xnorm2, double* sy, double* yy)
+{
+    lbfgsx::DeviceGuard dev_guard_(c->device);
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    lbfgsb_state* b = c->bstate;
+    b->pb_valid = false;
+    // One wait has to serve both halves (mapped outputs); the integer Gram wants the column maxima of k_b_post; a partial
+    // sort whose selection rides behind the build keeps the two-pass form.  The build half is computed for the state the
+    // solver will be in if it goes on and accepts the pair: lbfgsx_b_cauchy_build_partial checks that it is.
+    const bool tau_ok = tau > 0.0 && std::isfinite(tau);
+    const bool sel_inline = tau_ok && b->psel_use && b->psel_last >= 0 && b->psel_last <= b->psel_max &&
+                            c->n < (int64_t(1) << 31) && psel_alloc(c);
+    const bool sel_ahead = !sel_inline && b->stash_use && b->dout_host && tau_ok;
+    if (!(b->pb_use && c->outmap_dev && b->dout_host && !b->gram_i8 && !sel_ahead))
+        return lbfgsx_b_post_linesearch(c, projgnorm, xnorm2, sy, yy);
+    const int grid = c->grid_for(c->n);
+    double r[4];
+    DISPATCH_T(c, {
+        BVecs<T> bv = bvecs<T>(c);
+        const bool wc = wtdc_ready(c, true) && wtdc_alloc(c);
+        lbfgsx::poll_arm(c);
+        LBFGSX_LAUNCH((k_b_post_build<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, P<T>(c->xb[c->xp]), P<T>(c->gb[c->xp]),
+                           P<T>(c->col(c->S, c->spare)), P<T>(c->col(c->Y, c->spare)), c->out_slot<T>(),
+                           P<T>(c->sc) + c->sl.ys(c->spare), P<T>(c->sc) + c->sl.theta(c->spare), P<T>(b->keys_in), b->vals_in,
+                           c->n, c->ws, b->dout, wc ? b->wf_pos : static_cast<const int*>(nullptr), b->wtdc_list, b->wtdc_cnt,
+                           b->wtdc_cap, T(tau), sel_inline ? b->psel_list : static_cast<int*>(nullptr), b->psel_cnt, b->psel_cap);
+        LBFGSX_HIP(hipGetLastError());
+        rc = fetch_T<T>(c, c->sl.out(0), 4, r);
+        if (rc)
+            return rc;
+        const volatile double* h = b->dout_host;  // same completion word: the build half's numbers have arrived, too
+        for (int i = 0; i < 6; i++)
+            b->pb_r[i] = h[i];
+        b->pb_wc = wc;
+    });
+    b->pb_valid = true;
+    b->pb_cur = c->cur;
+    b->pb_tau = tau;
+    b->pb_sel_inline = sel_inline;
+    g_pb_runs++;
     c->pend_sy = r[1];
     c->pend_yy = r[2];
     c->pending = true;
@@ -1483,6 +1559,19 @@ int lbfgsx_b_cauchy_build_partial(lbfgsx_ctx* c, double tau, int64_t* nfree, int
         BVecs<T> bv = bvecs<T>(c);
         const bool wc = wtdc_prepare(c);
         const int newest = (c->ptr + c->m - 1) % c->m;
+        // the pass of the post statements has done this one's work (lbfgsx_b_post_linesearch_build) -- if the solver is where
+        // that pass assumed it would be: same iterate, same threshold and lists, and nothing for the clamp to move
+        const bool from_post = b->pb_valid && b->pb_cur == c->cur && b->pb_tau == tau && b->pb_sel_inline == sel_inline &&
+                               b->pb_wc == wc && !sel_ahead && (!force || b->pb_r[5] == 0.0);
+        b->pb_valid = false;
+        if (from_post)
+        {
+            for (int i = 0; i < 5; i++)
+                r[i] = b->pb_r[i];
+            g_pb_hits++;
+        }
+        else
+        {
         if (!sel_ahead)  // nothing rides behind the build: its last block carries the completion word
             lbfgsx::poll_arm(c);
         LBFGSX_LAUNCH((k_cauchy_build<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, P<T>(b->keys_in), b->vals_in, c->n,
@@ -1502,6 +1591,7 @@ int lbfgsx_b_cauchy_build_partial(lbfgsx_ctx* c, double tau, int64_t* nfree, int
         rc = fetch_doubles(c, sel_inline ? 5 : wc ? 4 : 3, r);
         if (rc)
             return rc;
+        }
         b->wtdc_n = wc ? int64_t(r[3]) : -1;
         ns = int64_t(r[2]);
         if (r[2] > 0)

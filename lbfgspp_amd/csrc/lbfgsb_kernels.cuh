@@ -1578,6 +1578,107 @@ __global__ void __launch_bounds__(kBlock) k_cauchy_build(BVecs<T> b, T* __restri
     }
 }
 
+// k_b_post and k_cauchy_build in one pass (lbfgsx_b_post_linesearch_build): the statements after the line search
+// (LBFGSB.h:206,213,235-237) and the element-wise part of the Cauchy search that follows them in every iteration that goes
+// on (Cauchy.h:95,111-129) read the same x and g -- and lb, ub for the projected gradient here, the break points there.  One
+// pass reads x, xp, g, gp, lb, ub (+ pos) and writes s, y, brk, d, xcp instead of two that read 6 n and 5.5 n elements; one
+// launch tail, one host wait.  Same statements on the same operands, sums as in the two kernels.
+// Between the two stands x = clamp(x) (LBFGSB.h:240), which a deferred build evaluates on its way: here the coordinates it
+// would move are only counted (out[5]) -- the solver may still leave at the convergence tests, with x as it is -- and a
+// count other than zero makes the host drop this pass's Cauchy half and run k_cauchy_build (a feasible line search never
+// leaves the box; the reference clamps all the same).  s_new of the build's list condition is the s this pass has in a
+// register.  out_post / ys_slot / theta_slot: as k_b_post; out[0..4]: as k_cauchy_build.
+template <class T>
+__global__ void __launch_bounds__(kBlock) k_b_post_build(BVecs<T> b, const T* __restrict__ xp, const T* __restrict__ gp,
+                                                         T* __restrict__ s, T* __restrict__ y, T* __restrict__ out_post,
+                                                         T* __restrict__ ys_slot, T* __restrict__ theta_slot,
+                                                         T* __restrict__ keys, int* __restrict__ vals, int64_t n, RedWs ws,
+                                                         double* __restrict__ out, const int* __restrict__ pos,
+                                                         int* __restrict__ olist, unsigned* __restrict__ ocnt, unsigned ocap,
+                                                         T tau, int* __restrict__ plist, unsigned* __restrict__ pcnt,
+                                                         unsigned pcap)
+{
+    typedef typename AccOf<T>::type A;
+    A acc[7];  // x.x, s.y, y.y | d.d, #free, #ordered | #coordinates the clamp would move
+    double pg = 0.0;
+    const T inf = T(__longlong_as_double(0x7FF0000000000000ll));
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
+    {
+        const T xi = b.x0[i], gi = b.g[i], lo = b.lb[i], up = b.ub[i];
+        const T si = xi - xp[i], yi = gi - gp[i];
+        s[i] = si;
+        y[i] = yi;
+        acc[0].add_prod(xi, xi);
+        acc[1].add_prod(si, yi);
+        acc[2].add_prod(yi, yi);
+        pg = fmax(pg, double(projg_term(xi, gi, lo, up)));
+        {
+            T v = xi;
+            v = (v < lo) ? lo : v;
+            v = (up < v) ? up : v;
+            if (!(v == xi))
+                acc[6].add(T(1));
+        }
+        T t;
+        if (lo == up)
+            t = T(0);
+        else if (gi < T(0))
+            t = (xi - up) / gi;
+        else if (gi > T(0))
+            t = (xi - lo) / gi;
+        else
+            t = inf;
+        const bool iszero = (t == T(0));
+        const T di = iszero ? T(0) : -gi;
+        b.brk[i] = t;
+        b.dvec[i] = di;
+        b.xcp[i] = xi;  // xcp = x0 (Cauchy.h:95)
+        acc[3].add_prod(di, di);
+        const bool isfree = (t == inf);
+        const bool isord = !isfree && !iszero;
+        if (isfree)
+            acc[4].add(T(1));
+        if (isord)
+            acc[5].add(T(1));
+        keys[i] = isord ? t : inf;
+        vals[i] = int(i);
+        if (pos)
+        {
+            const bool outside = pos[i] < 0 && (di != T(0) || si != T(0));
+            lu_append(outside, i, olist, ocnt, ocap);
+        }
+        if (plist)
+            lu_append(isord && t <= tau, i, plist, pcnt, pcap);
+    }
+    ext_publish<false>(pg, ws, 14);
+    if (grid_reduce<7>(acc, ws))
+    {
+        const double pgmax = ext_collect<false>(ws, 14);
+        if (threadIdx.x == 0)
+        {
+            const T sy = T(acc[1].value()), yy = T(acc[2].value());
+            out_post[0] = T(acc[0].value());
+            out_post[1] = sy;
+            out_post[2] = yy;
+            out_post[3] = T(pgmax);
+            *ys_slot = sy;
+            *theta_slot = yy / sy;
+            out[0] = double(T(acc[3].value()));
+            out[1] = acc[4].value();
+            out[2] = acc[5].value();
+            out[3] = pos ? double(__hip_atomic_load(ocnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : -1.0;
+            if (pos)
+                __hip_atomic_store(ocnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out[4] = plist ? double(__hip_atomic_load(pcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : -1.0;
+            if (plist)
+                __hip_atomic_store(pcnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out[5] = acc[6].value();
+            ws_signal(ws);
+        }
+    }
+}
+
 // gather the data the sequential GCP scan needs for sorted positions [first, first+count)
 // (Cauchy.h:203-231: brk, g, z = bound - x0, W row = [y_0..y_{c-1}, s_0..s_{c-1}] un-scaled)
 template <class T>

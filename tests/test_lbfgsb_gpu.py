@@ -925,3 +925,51 @@ def test_cauchy_finish_carrying_the_next_statements_changes_no_bit(A, monkeypatc
     f, u = res["1"], res["0"]
     assert f[:2] == u[:2] and f[4:] == u[4:]
     assert np.array_equal(f[2], u[2]) and np.array_equal(f[3], u[3])
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("n,m,iters,env", [(70001, 8, 40, {}), (90000, 10, 45, {}), (65536, 20, 50, {}),
+                                           (120000, 10, 40, {"LBFGSX_GCP_TAU_FACTOR": "0"}),
+                                           (120000, 6, 30, {"LBFGSX_SELECT_INLINE": "0"}),
+                                           (300000, 10, 30, {"LBFGSX_FORCE_FUSE": "0"})])
+def test_post_statements_carrying_the_cauchy_build_change_no_bit(A, monkeypatch, n, m, iters, env, dtype):
+    """lbfgsx_b_post_linesearch_build: the statements after the line search (LBFGSB.h:206,235-237) and the element-wise part
+    of the Cauchy search of the same iteration (Cauchy.h:95,111-129) in one pass over x and g -- against the two passes of
+    rounds 1-3 (LBFGSX_POST_BUILD=0): the same statements on the same operands, so the same trajectory bit for bit, and the
+    searches did use what the post pass left them.  Without a threshold for the partial sort (TAU_FACTOR=0) the full sort
+    follows; with the selection behind the build (SELECT_INLINE=0) and with the clamp as a pass of its own (FORCE_FUSE=0:
+    x may have moved) the two passes stay, by themselves."""
+    import ctypes as C
+    core, _ = A.load()
+    dt = O.F64 if dtype == "f64" else O.F32
+    npdt = O.NPDT[dt]
+    a, b = O.quad_problem(n, 30.0, 17, dt)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    res = {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("LBFGSX_POST_BUILD", on)
+        core.lbfgsx_b_post_build_counts(None, 1)
+        s = A.LBFGSBSolver(A.LBFGSBParam(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters), dtype=npdt)
+        tr = A.TraceBuffer(n, cap=512, stride=19)
+        x = np.zeros(n, dtype=npdt)
+        try:
+            niter, fx = s.minimize(A.DiagQuadratic(a, b), x, (-0.7 * np.ones(n)).astype(npdt), (0.9 * np.ones(n)).astype(npdt),
+                                   trace=tr)
+        except RuntimeError:
+            niter, fx = -1, float("nan")
+        st = s.stats()
+        pc = (C.c_int64 * 2)()
+        core.lbfgsx_b_post_build_counts(pc, 0)
+        res[on] = (niter, s.last.nfev, x.copy(), tr.xs[:tr.count].copy(), st["submin_sweeps"], st["gcp_crossings"], st["gcp_sorted"],
+                   tuple(pc))
+    f, u = res["1"], res["0"]
+    assert f[:2] == u[:2] and f[4:7] == u[4:7]
+    assert np.array_equal(f[2], u[2]) and np.array_equal(f[3], u[3])
+    assert u[7] == (0, 0)
+    if "LBFGSX_FORCE_FUSE" in env:
+        assert f[7][1] == 0 or f[7][1] <= f[7][0]       # an explicit clamp pass in between drops what the post pass prepared
+    elif "LBFGSX_SELECT_INLINE" in env:
+        assert f[7][1] <= f[7][0]
+    elif f[0] > 3:
+        assert f[7][0] >= f[0] - 1 and f[7][1] >= f[0] - 3, f[7]   # every iteration but the last searches with it
