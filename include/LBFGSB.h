@@ -112,7 +112,12 @@ private:
         {
             detail::check(lbfgsx_ls_begin(c));                          // xp = x; gradp = grad (:174-175)
             double dgd = 0, smax = 0;
-            detail::check(lbfgsx_b_dg_maxstep(c, &dgd, &smax));         // (:176-179)
+            // (:176-179); for a built-in objective the pass also evaluates the line search's first trial, which starts at
+            // min(1, step_max) (:200-203): lbfgsx_trial hands it over if that is the step the search asks for
+            if (ev.builtin_id() >= 0 && !ev.reduce)
+                detail::check(lbfgsx_b_dg_maxstep_trial(c, ev.builtin_id(), double(std::min(Scalar(1), m_param.max_step)), &dgd, &smax));
+            else
+                detail::check(lbfgsx_b_dg_maxstep(c, &dgd, &smax));
             Scalar dg = Scalar(dgd), step_max = Scalar(smax);
             if (dg >= Scalar(0) || step_max <= m_param.min_step)        // pathological direction (:188-197)
             {

@@ -186,6 +186,14 @@ public:
     bool trial_written = false;
 
     Evaluator(Foo& f, DeviceState<Scalar>& s) : m_f(f), m_s(s) {}
+    // the id of a built-in objective (the fused kernels know it), -1 for a functor
+    int builtin_id() const
+    {
+        if constexpr (is_builtin)
+            return m_f.id;
+        else
+            return -1;
+    }
     int nfev() const { return m_nfev; }
 
     void prepare()

@@ -222,6 +222,14 @@ int lbfgsx_b_eval(lbfgsx_ctx* c, int objective, double* fx, double* projgnorm, d
 int lbfgsx_b_norms(lbfgsx_ctx* c, double* projgnorm, double* xnorm2);
 /* dg = grad.dot(drt); step_max = max_step_size(x,drt,lb,ub)   (LBFGSB.h:68-86,176-179,195-196) */
 int lbfgsx_b_dg_maxstep(lbfgsx_ctx* c, double* dg, double* step_max);
+/* the same, and in the same pass the line search's first trial at step0 (the caller's min(1, max_step): LBFGSB.h:200-203 start
+ * the search at min(1, step_max)): x_trial = xp + step0 * drt, f and grad there, grad.drt (LineSearchMoreThuente.h:261-262) --
+ * kept inside the context and handed to the next lbfgsx_trial() iff it asks for this objective at exactly this step; any other
+ * call drops them.  Built-in objectives on contexts with mapped outputs; everything else, LBFGSX_TRIAL_AHEAD=0 and the four
+ * iterations after an unused trial behave as lbfgsx_b_dg_maxstep.  To be called right after lbfgsx_ls_begin. */
+int lbfgsx_b_dg_maxstep_trial(lbfgsx_ctx* c, int objective, double step0, double* dg, double* step_max);
+/* instrumentation: {trials evaluated ahead, of which the line search used} */
+int lbfgsx_b_trial_ahead_counts(const lbfgsx_ctx* c, int64_t out[2]);
 /* after the line search: proj_grad_norm, x.x, s, y (into the spare column), s.y, y.y  (LBFGSB.h:206,213,235-237) */
 int lbfgsx_b_post_linesearch(lbfgsx_ctx* c, double* projgnorm, double* xnorm2, double* sy, double* yy);
 /* the same, and in the same pass over x and g the element-wise part of the Cauchy search that follows when the iteration goes

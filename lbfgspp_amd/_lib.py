@@ -143,6 +143,8 @@ def load():
     sig(core, "lbfgsx_b_gram_pairs_max", i32, vp)
     sig(core, "lbfgsx_b_post_linesearch_build", i32, vp, dbl, pd, pd, pd, pd)
     sig(core, "lbfgsx_b_post_build_counts", i32, C.POINTER(i64 * 2), i32)
+    sig(core, "lbfgsx_b_dg_maxstep_trial", i32, vp, i32, dbl, pd, pd)
+    sig(core, "lbfgsx_b_trial_ahead_counts", i32, vp, C.POINTER(i64 * 2))
     sig(core, "lbfgsx_comm_info", i32, vp, C.POINTER(i32 * 4))
     sig(core, "lbfgsx_comm_calls", i64, vp, i32)
     sig(core, "lbfgsx_comm_hook_arg", vp, vp, i32)

@@ -201,6 +201,13 @@ struct lbfgsx_ctx
     // lbfgsx_post_linesearch_spec: the post statements ran as step 0 of a persistent launch that went on to compute the
     // direction for "history + the pending pair"; lbfgsx_apply_Hv returns that result when the pair was committed
     bool fuse_post = true;         // LBFGSX_FUSE_POST=0: never speculate
+    // the line search's first trial, evaluated ahead by lbfgsx_b_dg_maxstep_trial (L-BFGS-B): what lbfgsx_trial returns when it
+    // is asked for exactly this step of this objective between these buffers -- and forgets otherwise
+    bool st_valid = false;
+    int st_obj = -1, st_xp = -1, st_trial = -1;
+    double st_step = 0.0, st_f = 0.0, st_dg = 0.0;
+    int st_cooldown = 0;           // iterations without the speculation after one that was not used
+    int64_t st_runs = 0, st_hits = 0;
     bool spec_valid = false;
     unsigned spec_version = 0;     // phys_version the speculation is valid for (= after the commit)
     int spec_cur = 0;              // point whose gradient it used

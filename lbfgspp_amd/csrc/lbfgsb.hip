@@ -93,6 +93,7 @@ struct lbfgsb_state
     // candidates of the partial break-point sort collected by the Cauchy build itself (k_cauchy_build's plist)
     // lbfgsx_b_post_linesearch_build: the Cauchy search's element-wise pass, taken by the pass of the post statements
     bool pb_use = true;                   // LBFGSX_POST_BUILD=0: two passes, as rounds 1-3
+    bool st_use = true;                   // LBFGSX_TRIAL_AHEAD=0: lbfgsx_b_dg_maxstep_trial never evaluates the first trial ahead
     bool pb_valid = false;                // pb_r holds what k_cauchy_build would deliver for the state described below
     int pb_cur = -1;                      // the iterate buffer the pass read
     double pb_tau = 0.0;
@@ -323,6 +324,7 @@ static int need_bounded(lbfgsx_ctx* c, bool keep_force = false, bool keep_cv = f
         set_error("this context was not created with LBFGSX_FLAG_BOUNDED");
         return LBFGSX_E_LOGIC;
     }
+    c->st_valid = false;  // any entry of the bounded path may change what a trial evaluated ahead was computed from
     if (!keep_fin)  // what lbfgsx_b_cauchy_finish left for the two entries that follow it (sub_begin, W_A'(A'd))
     {
         c->bstate->drt_ready = false;
@@ -451,6 +453,8 @@ int bounded_alloc(lbfgsx_ctx* c)
         b->psel_use = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_POST_BUILD"))
         b->pb_use = atoi(e) != 0;
+    if (const char* e = getenv("LBFGSX_TRIAL_AHEAD"))
+        b->st_use = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_SELECT_MAX"))  // candidates of the previous search up to which the build lists them
         b->psel_max = std::max<int64_t>(0, atoll(e));
     if (const char* e = getenv("LBFGSX_SELECT_CAP"))  // test aid: a short list overflows
@@ -1207,6 +1211,70 @@ int lbfgsx_b_dg_maxstep(lbfgsx_ctx* c, double* dg, double* step_max)
         return rc;
     if (dg) *dg = r[0];
     if (step_max) *step_max = r[1];
+    return LBFGSX_OK;
+}
+
+}  // extern "C"
+namespace lbfgsx {
+template <class T, class OBJ>
+static int dg_maxstep_trial_t(lbfgsx_ctx* c, OBJ obj, T step, double* r4)
+{
+    const int grid = c->grid_for(c->n);
+    const int rev = (c->zigzag && (c->tl_step & 1u)) ? 1 : 0;  // the order the trial launch it stands for would have taken
+    lbfgsx::poll_arm(c);
+    LBFGSX_LAUNCH((k_b_dg_maxstep_trial<T, OBJ>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->xp]), P<T>(c->gb[c->cur]),
+                       P<T>(c->d), P<T>(c->lb), P<T>(c->ub), step, P<T>(c->xb[c->trial]), P<T>(c->gb[c->trial]), c->n, obj, c->ws,
+                       c->out_slot<T>(), rev);
+    LBFGSX_HIP(hipGetLastError());
+    return fetch_T<T>(c, c->sl.out(0), 4, r4);
+}
+}  // namespace lbfgsx
+extern "C" {
+
+int lbfgsx_b_dg_maxstep_trial(lbfgsx_ctx* c, int objective, double step0, double* dg, double* step_max)
+{
+    lbfgsx::DeviceGuard dev_guard_(c->device);
+    const bool use = c->bstate && c->bstate->st_use;
+    const bool builtin = objective == LBFGSX_OBJ_DIAG_QUAD || objective == LBFGSX_OBJ_EXT_ROSENBROCK;
+    // after a trial that was evaluated ahead and not used (step_max < 1: the early iterations) a few iterations go without
+    if (!use || !builtin || !c->outmap_dev || c->xp != c->cur || !(step0 > 0.0) || c->st_cooldown > 0)
+    {
+        if (c->st_cooldown > 0)
+            c->st_cooldown--;
+        return lbfgsx_b_dg_maxstep(c, dg, step_max);
+    }
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    double r[4];
+    rc = LBFGSX_E_INVALID;
+    DISPATCH_T(c, {
+        if (objective == LBFGSX_OBJ_DIAG_QUAD)
+            rc = dg_maxstep_trial_t<T>(c, ObjQuad<T>{P<T>(c->a), P<T>(c->b)}, T(step0), r);
+        else
+            rc = dg_maxstep_trial_t<T>(c, ObjRosen<T>{}, T(step0), r);
+    });
+    if (rc)
+        return rc;
+    c->st_valid = true;
+    c->st_obj = objective;
+    c->st_xp = c->xp;
+    c->st_trial = c->trial;
+    c->st_step = step0;
+    c->st_f = r[2];
+    c->st_dg = r[3];
+    c->st_runs++;
+    if (dg) *dg = r[0];
+    if (step_max) *step_max = r[1];
+    return LBFGSX_OK;
+}
+
+int lbfgsx_b_trial_ahead_counts(const lbfgsx_ctx* c, int64_t out[2])
+{
+    if (!c || !out)
+        return LBFGSX_E_INVALID;
+    out[0] = c->st_runs;
+    out[1] = c->st_hits;
     return LBFGSX_OK;
 }
 

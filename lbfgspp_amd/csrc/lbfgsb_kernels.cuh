@@ -234,6 +234,99 @@ __global__ void __launch_bounds__(kBlock) k_b_dg_maxstep(const T* __restrict__ x
     }
 }
 
+// k_b_dg_maxstep and the line search's first trial (k_trial) in one pass: the search starts at step = min(1, step_max)
+// (LBFGSB.h:200-203), and step_max >= 1 once the iterates have settled, so the pass that works out dg and step_max also writes
+// the trial point x = xp + step0 * d and evaluates f and grad there (LineSearchMoreThuente.h:261-262 as k_trial has them).
+// The host hands the values to the first lbfgsx_trial that asks for exactly this step (lbfgsx_b_dg_maxstep_trial) and
+// throws them away otherwise.  Reads xp, d, g, lb, ub (+ the objective's data) once instead of xp and d twice; one launch,
+// one wait.  out[0] = g.d, out[1] = step_max, out[2] = f(x), out[3] = grad(x).d -- each the same statement on the same
+// operands as in the two kernels.
+template <class T, class OBJ, int U = 4>
+__global__ void __launch_bounds__(kBlock) k_b_dg_maxstep_trial(const T* __restrict__ xp, const T* __restrict__ g0,
+                                                               const T* __restrict__ d, const T* __restrict__ lb,
+                                                               const T* __restrict__ ub, T step, T* __restrict__ x,
+                                                               T* __restrict__ g, int64_t n, OBJ obj, RedWs ws,
+                                                               T* __restrict__ out, int rev)
+{
+    typedef typename AccOf<T>::type A;
+    constexpr int W = Vec16<T>::W;
+    A acc[3];  // f's sum, grad(x).d, g.d
+    double smin = __longlong_as_double(0x7FF0000000000000ll);
+    auto feas = [&](T xi, T di, T lo, T up) __attribute__((always_inline)) {
+        if (di > T(0))
+            smin = fmin(smin, double((up - xi) / di) + 0.0);
+        else if (di < T(0))
+            smin = fmin(smin, double((lo - xi) / di) + 0.0);
+    };
+    const int64_t nv = n / W;
+    const int64_t tile = int64_t(kBlock) * U;
+    const int64_t top = ((nv + tile - 1) / tile - 1) * tile;
+    for (int64_t t0 = int64_t(blockIdx.x) * tile; t0 < nv; t0 += int64_t(gridDim.x) * tile)
+    {
+        const int64_t base = (rev ? top - t0 : t0) + threadIdx.x;
+        Pack<T> pxp[U], pd[U], pg0[U], plo[U], pup[U];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (base + u * kBlock < nv)
+            {
+                pxp[u] = ldv<T>(xp, base + u * kBlock);
+                pd[u] = ldv<T>(d, base + u * kBlock);
+                pg0[u] = ldv<T>(g0, base + u * kBlock);
+                plo[u] = ldv<T>(lb, base + u * kBlock);
+                pup[u] = ldv<T>(ub, base + u * kBlock);
+            }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+        {
+            const int64_t vi = base + u * kBlock;
+            if (vi < nv)
+            {
+                Pack<T> px, pg;
+#pragma unroll
+                for (int k = 0; k < W; k++)
+                {
+                    acc[2].add_prod(pg0[u].e[k], pd[u].e[k]);
+                    feas(pxp[u].e[k], pd[u].e[k], plo[u].e[k], pup[u].e[k]);
+                    px.e[k] = pxp[u].e[k] + step * pd[u].e[k];
+                }
+                obj.pack(vi, px, pg, acc[0]);
+                stv<T>(x, vi, px);
+                stv<T>(g, vi, pg);
+#pragma unroll
+                for (int k = 0; k < W; k++)
+                    acc[1].add_prod(pg.e[k], pd[u].e[k]);
+            }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+    {
+        for (int64_t i = nv * W; i < n; i++)
+        {
+            acc[2].add_prod(g0[i], d[i]);
+            feas(xp[i], d[i], lb[i], ub[i]);
+            x[i] = xp[i] + step * d[i];
+        }
+        for (int64_t i = nv * W; i < n; i++)
+        {
+            obj.tail(i, n, x, g, acc[0]);
+            acc[1].add_prod(g[i], d[i]);
+        }
+    }
+    ext_publish<true>(smin, ws, 6);
+    if (grid_reduce<3>(acc, ws))
+    {
+        const double smin_all = ext_collect<true>(ws, 6);
+        if (threadIdx.x == 0)
+        {
+            out[0] = T(acc[2].value());
+            out[1] = T(smin_all);
+            out[2] = obj.finish(T(acc[0].value()));
+            out[3] = T(acc[1].value());
+            ws_signal(ws);
+        }
+    }
+}
+
 // after the line search (LBFGSB.h:206,213,235-237): projected-gradient norm, x.x, s, y, s.y, y.y
 template <class T>
 __global__ void __launch_bounds__(kBlock) k_b_post(const T* __restrict__ x, const T* __restrict__ xp,

@@ -1013,6 +1013,7 @@ int lbfgsx_norms(lbfgsx_ctx* c, double* gnorm2, double* xnorm2)
 
 int lbfgsx_ls_begin(lbfgsx_ctx* c)
 {
+    c->st_valid = false;
     c->xp = c->cur;
     c->lo = c->xp;
     c->trial = (c->xp + 1) % 3;
@@ -1051,6 +1052,21 @@ int lbfgsx_trial(lbfgsx_ctx* c, int objective, double step, double* fx, double* 
     c->spec_valid = false;  // a buffer the stored speculative direction was computed from may change (lbfgsx_apply_Hv)
     double r[2];
     int rc = LBFGSX_E_INVALID;
+    if (c->st_valid)  // evaluated ahead by the pass that worked out dg and step_max (lbfgsx_b_dg_maxstep_trial)?
+    {
+        c->st_valid = false;
+        bool same = objective == c->st_obj && c->xp == c->st_xp && c->trial == c->st_trial;
+        DISPATCH_T(c, { same = same && T(step) == T(c->st_step); });
+        if (same)
+        {
+            c->st_hits++;
+            c->tl_step++;  // the traversal order alternates between trial launches: this was one
+            if (fx) *fx = c->st_f;
+            if (dg) *dg = c->st_dg;
+            return LBFGSX_OK;
+        }
+        c->st_cooldown = 4;
+    }
     DISPATCH_T(c, {
         if (objective == LBFGSX_OBJ_DIAG_QUAD)
             rc = trial_t<T>(c, ObjQuad<T>{P<T>(c->a), P<T>(c->b)}, T(step), r);

@@ -973,3 +973,47 @@ def test_post_statements_carrying_the_cauchy_build_change_no_bit(A, monkeypatch,
         assert f[7][1] <= f[7][0]
     elif f[0] > 3:
         assert f[7][0] >= f[0] - 1 and f[7][1] >= f[0] - 3, f[7]   # every iteration but the last searches with it
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("obj,n,m,iters", [("quad", 70001, 8, 40), ("quad", 90000, 10, 45), ("rosen", 65536, 6, 40),
+                                           ("rosen", 100002, 20, 50)])
+def test_first_trial_evaluated_with_dg_and_step_max_changes_no_bit(A, monkeypatch, obj, n, m, iters, dtype):
+    """lbfgsx_b_dg_maxstep_trial: the pass that works out dg and step_max (LBFGSB.h:176-179) also evaluates the line search's
+    first trial at min(1, max_step) (:200-203, LineSearchMoreThuente.h:261-262) and lbfgsx_trial hands it over when the
+    search asks for exactly that step -- against the two passes (LBFGSX_TRIAL_AHEAD=0): the same statements on the same
+    operands, the same trajectory bit for bit; most searches do start at step 1 and use it, the others (step_max < 1) throw
+    it away and the next four iterations go without.  n = 70001: a scalar tail."""
+    import ctypes as C
+    core, _ = A.load()
+    dt = O.F64 if dtype == "f64" else O.F32
+    npdt = O.NPDT[dt]
+    if obj == "quad":
+        a, b = O.quad_problem(n, 30.0, 17, dt)
+        f = A.DiagQuadratic(a, b)
+        x0 = np.zeros(n, dtype=npdt)
+        lb, ub = (-0.7 * np.ones(n)).astype(npdt), (0.9 * np.ones(n)).astype(npdt)
+    else:
+        f = A.ExtendedRosenbrock()
+        x0 = O.rosen_x0(n, 5, dt)
+        lb, ub = (-1.5 * np.ones(n)).astype(npdt), (0.8 * np.ones(n)).astype(npdt)
+        x0 = np.minimum(np.maximum(x0, lb), ub)
+    res = {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("LBFGSX_TRIAL_AHEAD", on)
+        s = A.LBFGSBSolver(A.LBFGSBParam(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters), dtype=npdt)
+        tr = A.TraceBuffer(n, cap=512, stride=19)
+        x = x0.copy()
+        try:
+            niter, fx = s.minimize(f, x, lb, ub, trace=tr)
+        except RuntimeError:
+            niter, fx = -1, float("nan")
+        pc = (C.c_int64 * 2)()
+        core.lbfgsx_b_trial_ahead_counts(s.ctx, pc)
+        res[on] = (niter, s.last.nfev, x.copy(), tr.xs[:tr.count].copy(), tr.fx[:tr.count].copy(), tuple(pc))
+    f1, f0 = res["1"], res["0"]
+    assert f1[:2] == f0[:2]
+    assert np.array_equal(f1[2], f0[2]) and np.array_equal(f1[3], f0[3]) and np.array_equal(f1[4], f0[4])
+    assert f0[5] == (0, 0)
+    if f1[0] > 8:
+        assert f1[5][0] >= f1[0] // 3 and f1[5][1] >= f1[5][0] // 2, f1[5]
