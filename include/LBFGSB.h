@@ -58,6 +58,7 @@ public:
         long long gcp_dev_crossings = 0, gcp_sort_fallbacks = 0, gcp_partial_sorts = 0;
         long long submin_fused_sweeps = 0;
         long long gram_carried = 0;  // first solves whose W_F'W_F came from the carried sums
+        long long rhs_identities = 0;  // sweep solves whose W_P' rhs came from held sums instead of a pass over P (BFGSMat.h)
         long long gcp_searches = 0;  // generalized-Cauchy-point searches
         long long gcp_nord = 0;      // sum over the searches of the finite positive break points (the reference's |ord|)
         long long gcp_sorted = 0;    // ... of which were actually sorted (partial sort)
@@ -66,6 +67,7 @@ public:
 private:
     Stats m_stats;
     long long m_carried0 = 0;
+    long long m_ident0 = 0;
 
     template <typename Foo, typename HostVec>
     int run(Foo& f, Scalar& fx)
@@ -78,6 +80,7 @@ private:
         lbfgsx_ctx* c = m_dev.ctx();
         m_stats = Stats();
         m_carried0 = m_bfgs.carried_grams();
+        m_ident0 = m_bfgs.rhs_identities();
 
         detail::check(lbfgsx_b_force_bounds(c));                        // (:128)
         m_bfgs.reset(c, m_param.m);                                     // (:131)
@@ -192,6 +195,7 @@ private:
             m_stats.submin_unconverged += st.converged ? 0 : 1;
             m_stats.submin_fused_sweeps += st.fused_sweeps;
             m_stats.gram_carried = m_bfgs.carried_grams() - m_carried0;
+            m_stats.rhs_identities = m_bfgs.rhs_identities() - m_ident0;
             if (m_trace_phases)
                 std::fprintf(stderr, "[lbfgsb] it %d: ls %.3f ms (cum) corr %.3f gcp %.3f (build %.3f fetch %.3f) submin %.3f | crossings %lld dev %lld sweeps %lld\n",
                              k, m_stats.linesearch_s * 1e3, m_stats.correction_s * 1e3, m_stats.gcp_total_s * 1e3,

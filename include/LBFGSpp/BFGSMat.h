@@ -11,6 +11,7 @@
 #define LBFGSX_DROPIN_BFGSMAT_H
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <vector>
 
@@ -37,6 +38,19 @@ class BFGSMatB
     // rows of L u U instead of the ~n/2 rows of P (both sums carry ~100 bits, the difference rounds like the direct sum)
     mutable std::vector<double> m_GF_dd;
     mutable bool m_GF_valid = false;
+    // W_P' rhs without a pass.  Before a sweep's solve the reference updates rhs_P = c_P + B[P,L] l + B[P,U] u row by row
+    // (SubspaceMin.h:232-241) and solve_PtBP opens with W_P' rhs (BFGSMat.h:560) -- a pass over the ~n/2 rows of P for 2c
+    // numbers.  Row i of the updates is rhs_i = c_i - (W coef1)_i - (W coef2)_i, so
+    //     W_P'(-rhs) = W_P'(-c) + (W_P'W_P) coef1 + (W_P'W_P) coef2,   W_P'(-c) = W_F'(-c) - W_{L u U}'(-c),
+    // and every piece is at hand un-rounded: W_F'(-c) from the first solve's pass (m_vF_dd), W_{L u U}'(-c) from a pass over
+    // the list of L u U (m_luc_dd, lbfgsx_b_wtv_lu_c), W_P'W_P from the complement identity above.  The sums are formed in
+    // double-double and rounded once; the row-wise rhs itself -- same statements, same roundings -- is written by the solve's
+    // pass (lbfgsx_b_solve_sweep_rhs).  What differs from the pass: it summed the ROUNDED rows W_ij fl(rhs_i), this is the
+    // exact sum of the un-rounded ones; the two agree to ~sqrt(n) eps^2 relative, i.e. to the last bit or the one before.
+    // LBFGSX_RHS_IDENTITY=0 keeps the pass.
+    mutable std::vector<double> m_vF_dd, m_luc_dd;
+    mutable bool m_vF_valid = false, m_luc_valid = false;
+    mutable long long m_rhs_identities = 0;
     // The same sums carried from one iteration to the next.  Between two subspace minimisations add_correction replaces
     // one storage slot (its Y and its S column) and a few rows enter or leave F, so of the 2c (2c + 1) / 2 entries only
     // those of the two new columns need a pass over F -- together with the v row they are 6c of the 3 (2c + 1) entries one
@@ -203,6 +217,11 @@ class BFGSMatB
             m_carry_col[size_t(carry_index(i))] = 1;
         for (int J = 0; J < t; J++)
             raw[J] = pd[size_t(2 * (vrow + J))] + pd[size_t(2 * (vrow + J) + 1)];
+        if (vsel == LBFGSX_VS_NEG_CF)  // W_F'(-c), un-rounded: a sweep's W_P'(-rhs) starts from it (see m_vF_dd)
+        {
+            m_vF_dd.assign(pd.begin() + 2 * vrow, pd.begin() + 2 * (vrow + t));
+            m_vF_valid = true;
+        }
         m_carry_age++;
         m_carried++;
         return true;
@@ -356,9 +375,15 @@ public:
     // W_L' l and W_U' u of a BOXCQP sweep in one launch (lbfgsx_b_wtv_lu); false: not available here, use Wtv per set
     bool Wtv_lu(std::vector<Scalar>& res_l, std::int64_t& nnz_l, std::vector<Scalar>& res_u, std::int64_t& nnz_u) const
     {
-        double rl[80], ru[80];
-        if (m_ncorr < 1 || lbfgsx_b_wtv_lu(m_c, rl, &nnz_l, ru, &nnz_u) != LBFGSX_OK)
+        double rl[80], ru[80], cdd[160];
+        m_luc_valid = false;
+        if (m_ncorr < 1 || lbfgsx_b_wtv_lu_c(m_c, rl, &nnz_l, ru, &nnz_u, m_vF_valid ? cdd : nullptr) != LBFGSX_OK)
             return false;
+        if (m_vF_valid && !std::isnan(cdd[0]))
+        {
+            m_luc_dd.assign(cdd, cdd + 4 * m_ncorr);
+            m_luc_valid = true;
+        }
         res_l.assign(size_t(2 * m_ncorr), Scalar(0));
         res_u.assign(size_t(2 * m_ncorr), Scalar(0));
         for (int j = 0; j < m_ncorr; j++)
@@ -420,7 +445,8 @@ public:
     //
     // `keep_as_F`: this is the solve over the whole free set; its un-rounded Gram is kept.  `comp_mask` / `ncomp`: the
     // sets that make up F \ mask and their size; when they are small the Gram comes from the complement identity above.
-    void gram_cache_reset() const { m_GF_valid = false; }
+    void gram_cache_reset() const { m_GF_valid = m_vF_valid = m_luc_valid = false; }
+    long long rhs_identities() const { return m_rhs_identities; }
     long long carried_grams() const { return m_carried; }
     void solve_PtBP(int mask, std::int64_t nP, int vsel, int prologue = LBFGSX_GP_NONE, const double* coef1 = nullptr,
                     const double* coef2 = nullptr, std::vector<Scalar>* Fy = nullptr, int fy_mask = 0,
@@ -429,11 +455,15 @@ public:
     {
         // `sweep` (optional, 7 sums): let the pass that writes y also run the statements of the sweep that follows on the
         // rows it writes (lbfgsx_b_solve_sweep); *swept tells whether it did
+        bool rhs_in_sweep = false;  // the rhs updates of the prologue are left to the solve's own pass (see m_vF_dd)
         auto finish = [&](const double* coef) {
             double raw[80];
-            if (sweep && swept && m_ncorr >= 1 &&
-                (sweep_first ? (mask == LBFGSX_ST_FREE && !Fy) : (mask == LBFGSX_ST_P && Fy && fy_mask == LBFGSX_ST_FREE)) &&
-                lbfgsx_b_solve_sweep(m_c, sweep_first ? 1 : 0, vsel, coef, double(m_theta), raw, sweep) == LBFGSX_OK)
+            if (rhs_in_sweep)  // the conditions were checked when the identity was chosen: no other way on from here
+                detail::check(lbfgsx_b_solve_sweep_rhs(m_c, 0, vsel, coef, double(m_theta), coef1, coef2, raw, sweep));
+            if (rhs_in_sweep ||
+                (sweep && swept && m_ncorr >= 1 &&
+                 (sweep_first ? (mask == LBFGSX_ST_FREE && !Fy) : (mask == LBFGSX_ST_P && Fy && fy_mask == LBFGSX_ST_FREE)) &&
+                 lbfgsx_b_solve_sweep(m_c, sweep_first ? 1 : 0, vsel, coef, double(m_theta), raw, sweep) == LBFGSX_OK))
             {
                 *swept = true;
                 if (Fy)
@@ -491,7 +521,38 @@ public:
             std::vector<double> cdd(size_t(t) * size_t(t + 1), 0.0);
             const bool ok = (ncomp == 0) || lbfgsx_b_gram_fused_dd(m_c, comp_mask, -1, LBFGSX_GP_NONE, nullptr, nullptr,
                                                                     nullptr, nullptr, cdd.data()) == LBFGSX_OK;
-            if (ok && lbfgsx_b_wtv_prologue(m_c, mask, vsel, prologue, coef1, coef2, raw) == LBFGSX_OK)
+            const bool ident = ok && ncomp > 0 && prologue == LBFGSX_GP_RHS && vsel == LBFGSX_VS_NEG_RHS && (coef1 || coef2) &&
+                               m_vF_valid && m_luc_valid && m_vF_dd.size() == size_t(2 * t) && m_luc_dd.size() == size_t(2 * t) &&
+                               sweep && swept && !sweep_first && mask == LBFGSX_ST_P && Fy && fy_mask == LBFGSX_ST_FREE &&
+                               lbfgsx_b_solve_sweep_rhs_ready(m_c) == 1;
+            if (ident)
+            {
+                // W_P'(-rhs) = [W_F'(-c) - W_{L u U}'(-c)] + (W_F'W_F - W_{L u U}'W_{L u U}) (coef1 + coef2 terms), in double-double
+                auto acc_prod = [](double& h, double& l, double gh, double gl, double cf) {
+                    const double p = gh * cf, pe = std::fma(gh, cf, -p) + gl * cf;  // (gh + gl) cf = p + pe (+ O(eps^2))
+                    dd_acc(h, l, p, pe, 1.0);
+                };
+                for (int i = 0; i < t; i++)
+                {
+                    double h = m_vF_dd[size_t(2 * i)], l = m_vF_dd[size_t(2 * i + 1)];
+                    dd_acc(h, l, m_luc_dd[size_t(2 * i)], m_luc_dd[size_t(2 * i + 1)], -1.0);
+                    for (int k = 0; k < t; k++)
+                    {
+                        const size_t e = (i >= k) ? size_t(i) * size_t(i + 1) / 2 + size_t(k) : size_t(k) * size_t(k + 1) / 2 + size_t(i);
+                        double gh = m_GF_dd[2 * e], gl = m_GF_dd[2 * e + 1];
+                        dd_acc(gh, gl, cdd[2 * e], cdd[2 * e + 1], -1.0);
+                        if (coef1)
+                            acc_prod(h, l, gh, gl, double(Scalar(coef1[k])));
+                        if (coef2)
+                            acc_prod(h, l, gh, gl, double(Scalar(coef2[k])));
+                    }
+                    raw[i] = double(Scalar(h + l));
+                }
+                rhs_in_sweep = true;
+                m_luc_valid = false;
+                m_rhs_identities++;
+            }
+            if (ident || (ok && lbfgsx_b_wtv_prologue(m_c, mask, vsel, prologue, coef1, coef2, raw) == LBFGSX_OK))
             {
                 for (int i = 0; i < t; i++)
                     for (int j = 0; j <= i; j++)

@@ -328,6 +328,10 @@ int lbfgsx_b_sub_sweep_begin(lbfgsx_ctx* c, int first, int64_t* nL, int64_t* nU,
  * apply_PtBQv statements of a BOXCQP sweep (SubspaceMin.h:236-241, BFGSMat.h:570-594) -- in one launch over the index list of
  * L u U.  LBFGSX_E_INVALID when there is no list or 2c > 24: call lbfgsx_b_wtv per set. */
 int lbfgsx_b_wtv_lu(lbfgsx_ctx* c, double* out_l, int64_t* nnz_l, double* out_u, int64_t* nnz_u);
+/* the same, plus negc_dd[2 k], [2 k + 1] = the un-rounded (hi, lo) sum of column k of W_{L u U}'(-c) (c = vecc of
+ * SubspaceMin.h on the rows of L u U); negc_dd[0] = NaN when this context cannot deliver it (LBFGSX_RHS_IDENTITY=0, no
+ * split-row kernels, no mapped outputs) */
+int lbfgsx_b_wtv_lu_c(lbfgsx_ctx* c, double* out_l, int64_t* nnz_l, double* out_u, int64_t* nnz_u, double* negc_dd);
 /* ---- pieces of the carried Gram of the free set (BFGSMatB::solve_PtBP): W_F'W_F of one iteration from that of the one
  * before -- the entries of the columns add_correction replaced computed afresh, the others corrected by the outer products
  * of the rows that entered or left F.  All sums un-rounded double-doubles (hi, lo).
@@ -392,6 +396,14 @@ int lbfgsx_b_reserve(lbfgsx_ctx* c);
  * LBFGSX_E_INVALID when the fused form does not apply here (2c > 32, no list, LBFGSX_SWEEP_SOLVE_FUSE=0): nothing has
  * been changed, run the separate calls. */
 int lbfgsx_b_solve_sweep(lbfgsx_ctx* c, int first, int vsel, const double* coef, double theta, double* wty, int64_t sums[7]);
+/* the same with the two rhs updates that precede a sweep's solve (SubspaceMin.h:236-241; the LBFGSX_GP_RHS prologue of
+ * lbfgsx_b_wtv_prologue with these coefficients) evaluated by the solve's own pass on the W rows it holds: first = 0 and
+ * vsel = LBFGSX_VS_NEG_RHS only, split-row kernels only.  The caller then needs W_P'(-rhs) from elsewhere -- BFGSMatB::solve_PtBP
+ * forms it from sums it holds (W_F'(-c), W_{L u U}'(-c) of lbfgsx_b_wtv_lu_c, the Gram of the complement identity) -- and the pass
+ * over P that lbfgsx_b_wtv_prologue makes for it is saved.  _ready: 1 when this context can do it now. */
+int lbfgsx_b_solve_sweep_rhs(lbfgsx_ctx* c, int first, int vsel, const double* coef, double theta, const double* rhs_c1,
+                             const double* rhs_c2, double* wty, int64_t sums[7]);
+int lbfgsx_b_solve_sweep_rhs_ready(lbfgsx_ctx* c);
 /* completes lbfgsx_b_solve_sweep(first == 0): lambda on the rows of L, mu on the rows of U (SubspaceMin.h:256-267, the two
  * lbfgsx_b_wcombine calls) and the sweep's statements on those rows, walking the index list;
  * sums = {#L, #U, #P, 0, 0, #L with lambda < 0, #U with mu < 0} over those rows */

@@ -94,6 +94,7 @@ struct lbfgsb_state
     // lbfgsx_b_post_linesearch_build: the Cauchy search's element-wise pass, taken by the pass of the post statements
     bool pb_use = true;                   // LBFGSX_POST_BUILD=0: two passes, as rounds 1-3
     bool st_use = true;                   // LBFGSX_TRIAL_AHEAD=0: lbfgsx_b_dg_maxstep_trial never evaluates the first trial ahead
+    bool rhs_identity = true;             // LBFGSX_RHS_IDENTITY=0: a sweep gets W_P'(-rhs) from a pass over P (kx_rows<NA = 1>), as before
     bool pb_valid = false;                // pb_r holds what k_cauchy_build would deliver for the state described below
     int pb_cur = -1;                      // the iterate buffer the pass read
     double pb_tau = 0.0;
@@ -198,7 +199,7 @@ struct lbfgsb_state
     unsigned* na_cnt = nullptr;
     unsigned na_cap = 1u << 16;
     int64_t na_n = -1;                // entries of the list, -1: none / overflowed
-    static constexpr int kDout = 256; // doubles of `dout`
+    static constexpr int kDout = 640; // doubles of `dout`
 };
 
 namespace lbfgsx {
@@ -455,6 +456,8 @@ int bounded_alloc(lbfgsx_ctx* c)
         b->pb_use = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_TRIAL_AHEAD"))
         b->st_use = atoi(e) != 0;
+    if (const char* e = getenv("LBFGSX_RHS_IDENTITY"))
+        b->rhs_identity = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_SELECT_MAX"))  // candidates of the previous search up to which the build lists them
         b->psel_max = std::max<int64_t>(0, atoll(e));
     if (const char* e = getenv("LBFGSX_SELECT_CAP"))  // test aid: a short list overflows
@@ -2204,6 +2207,11 @@ int lbfgsx_b_wtv(lbfgsx_ctx* c, int vsel_id, int mask, double* out, int64_t* nnz
 
 int lbfgsx_b_wtv_lu(lbfgsx_ctx* c, double* out_l, int64_t* nnz_l, double* out_u, int64_t* nnz_u)
 {
+    return lbfgsx_b_wtv_lu_c(c, out_l, nnz_l, out_u, nnz_u, nullptr);
+}
+
+int lbfgsx_b_wtv_lu_c(lbfgsx_ctx* c, double* out_l, int64_t* nnz_l, double* out_u, int64_t* nnz_u, double* negc_dd)
+{
     lbfgsx::DeviceGuard dev_guard_(c->device);
     int rc = need_bounded(c, false, /*keep_cv=*/true);
     if (rc)
@@ -2222,6 +2230,21 @@ int lbfgsx_b_wtv_lu(lbfgsx_ctx* c, double* out_l, int64_t* nnz_l, double* out_u,
         which[k] = k;
     double r[2 * (kColsX + 1)];
     int nc = 24;
+    // W_{L u U}'(-c) un-rounded (negc_dd; the split-row kernels only): a launch of its own ahead of the pass below, read after
+    // the same wait.  What BFGSMatB::solve_PtBP subtracts from W_F'(-c) to have W_P'(-c) without a pass over P.
+    bool have_c = false;
+    if (negc_dd && b->split && b->rhs_identity && b->dout_host)
+    {
+        DISPATCH_T(c, {
+            const unsigned char* stc = b->cv_live ? bvecs_cv<T>(c).st : static_cast<const unsigned char*>(nullptr);
+            const int* stpos = b->cv_live ? b->wf_pos : static_cast<const int*>(nullptr);
+            rc = xl::list1<T>(c->stream, b->num_cus, colsx_full<T>(c, total), total, bvecs<T>(c), VS_NEG_CF, ST_L | ST_U, b->lu_ptr(), nl,
+                              wsx(c), b->dout + 256, stc, stpos, b->dout + 352);
+        });
+        if (rc)
+            return rc;
+        have_c = true;
+    }
     // the wait below ends with the last kernel launched before it: the Gram that rides behind this pass, or this pass
     const bool rides = gram_stash_feasible(c, b->lu_ptr(), nl);
     if (!rides)
@@ -2277,6 +2300,17 @@ int lbfgsx_b_wtv_lu(lbfgsx_ctx* c, double* out_l, int64_t* nnz_l, double* out_u,
     }
     *nnz_l = int64_t(r[nc]);
     *nnz_u = int64_t(r[2 * nc + 1]);
+    if (negc_dd)
+    {
+        if (have_c)
+        {
+            const volatile double* h = b->dout_host + 352;
+            for (int k = 0; k < 2 * total; k++)
+                negc_dd[k] = h[k];
+        }
+        else
+            negc_dd[0] = std::numeric_limits<double>::quiet_NaN();  // not available here: the caller keeps the pass
+    }
     return LBFGSX_OK;
 }
 
@@ -3669,7 +3703,7 @@ static int solve_sweep_t(lbfgsx_ctx* c, int first, int vsel_id, const double* co
 // the same through kx_solve_sweep (any 2c <= 80)
 template <class T>
 static int solve_sweep_x(lbfgsx_ctx* c, int first, int vsel_id, const double* coef, double theta, double* wty, double* sums,
-                         unsigned lu_cap_now, int* lu_dst)
+                         unsigned lu_cap_now, int* lu_dst, const double* rc1 = nullptr, const double* rc2 = nullptr)
 {
     const int total = 2 * c->ncorr;
     lbfgsb_state* b = c->bstate;
@@ -3703,9 +3737,20 @@ static int solve_sweep_x(lbfgsx_ctx* c, int first, int vsel_id, const double* co
     T* cui = nullptr;
     const BVecs<T> full = bvecs<T>(c);
     const BVecs<T> cvb = cv ? bvecs_cv<T>(c, &cli, &cui) : full;
+    ProX<T> pro;
+    pro.mode = (rc1 || rc2) ? LBFGSX_GP_RHS : LBFGSX_GP_NONE;
+    pro.use1 = rc1 ? 1 : 0;
+    pro.use2 = rc2 ? 1 : 0;
+    if (rc1 || rc2)
+        for (int k = 0; k < kColsX; k++)
+        {
+            pro.c1[k] = (rc1 && k < total) ? T(rc1[k]) : T(0);
+            pro.c2[k] = (rc2 && k < total) ? T(rc2[k]) : T(0);
+        }
     lbfgsx::poll_arm(c);
     int rc = xl::solve_sweep<T>(c->stream, b->num_cus, first, cl, total, (first || !cv) ? full : cvb, cvb, vsel_id, cf, coef ? 1 : 0,
-                                T(theta), nrows, wsx(c), b->dout, lu_dst, b->lu_cnt, lu_cap_now, ridx, cli, cui, cv);
+                                T(theta), nrows, wsx(c), b->dout, lu_dst, b->lu_cnt, lu_cap_now, ridx, cli, cui, cv,
+                                (rc1 || rc2) ? &pro : static_cast<const ProX<T>*>(nullptr));
     if (rc)
         return rc;
     if (cv == 1)
@@ -3730,12 +3775,33 @@ extern "C" {
 
 int lbfgsx_b_solve_sweep(lbfgsx_ctx* c, int first, int vsel_id, const double* coef, double theta, double* wty, int64_t sums[7])
 {
+    return lbfgsx_b_solve_sweep_rhs(c, first, vsel_id, coef, theta, nullptr, nullptr, wty, sums);
+}
+
+int lbfgsx_b_solve_sweep_rhs_ready(lbfgsx_ctx* c)
+{
+    if (!c || !c->bstate)
+        return 0;
+    const lbfgsb_state* b = c->bstate;
+    const int total = 2 * c->ncorr;
+    return (b->rhs_identity && b->split && total >= 1 && total <= kColsX && !b->multidot_chunked && b->sweep_fuse && b->lu_valid &&
+            b->lu_n >= 1) ? 1 : 0;
+}
+
+int lbfgsx_b_solve_sweep_rhs(lbfgsx_ctx* c, int first, int vsel_id, const double* coef, double theta, const double* rhs_c1,
+                             const double* rhs_c2, double* wty, int64_t sums[7])
+{
     lbfgsx::DeviceGuard dev_guard_(c->device);
     int rc = need_bounded(c, false, /*keep_cv=*/first == 0);
     if (rc)
         return rc;
     lbfgsb_state* b = c->bstate;
     const int total = 2 * c->ncorr;
+    if ((rhs_c1 || rhs_c2) && (first || vsel_id != VS_NEG_RHS || !b->split))
+    {
+        set_error("lbfgsx_b_solve_sweep_rhs: the rhs updates ride on a sweep's solve of -rhs (split-row kernels) only");
+        return LBFGSX_E_INVALID;
+    }
     if (total < 1 || total > (b->split ? kColsX : 32) || b->multidot_chunked || !b->sweep_fuse)
     {
         set_error("lbfgsx_b_solve_sweep: not available here (needs 1 <= 2*ncorr <= 80); run the separate passes");
@@ -3761,7 +3827,7 @@ int lbfgsx_b_solve_sweep(lbfgsx_ctx* c, int first, int vsel_id, const double* co
     }
     double r[7];
     DISPATCH_T(c, {
-        if (b->split) rc = solve_sweep_x<T>(c, first, vsel_id, coef, theta, wty, r, cap, dst);
+        if (b->split) rc = solve_sweep_x<T>(c, first, vsel_id, coef, theta, wty, r, cap, dst, rhs_c1, rhs_c2);
         else if (total <= 8) rc = solve_sweep_t<T, 8>(c, first, vsel_id, coef, theta, wty, r, cap, dst);
         else if (total <= 16) rc = solve_sweep_t<T, 16>(c, first, vsel_id, coef, theta, wty, r, cap, dst);
         else if (total <= 20) rc = solve_sweep_t<T, 20>(c, first, vsel_id, coef, theta, wty, r, cap, dst);  // m = 10: no idle registers

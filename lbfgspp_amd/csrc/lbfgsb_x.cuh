@@ -380,20 +380,31 @@ __global__ void __launch_bounds__(kBlock, occ_rows_x(NCL, G, NA))
 // ---------------------------------------------------------------- the solve of a BOXCQP sweep and the sweep's statements on the
 // rows it writes: k_solve_sweep for 2c <= 80 (statements, compact-vector modes `cv` and outputs as there).
 // out = {dots[ncols] (FIRST = 0 only), the 7 sums of k_sub_sweep_begin}
-template <class T, int NCL, int G, int FIRST, bool IDX>
+// RHSK (sweeps only, v = -rhs): the two rhs updates that precede the solve (SubspaceMin.h:236-241, rhs += B[P,L] l, rhs +=
+// B[P,U] u as row-wise W * coef products: the GP_RHS prologue of kx_rows) are evaluated HERE, on the W row this pass holds
+// anyway -- same products, same order, same rounded rhs, which is stored as kx_rows stores it.  The pass kx_rows<NA = 1> made
+// over the whole compact copy only to get W_P'(-rhs) for the 2c x 2c solve is then not needed: the host has those 2c sums
+// from sums it already holds (BFGSMatB::solve_PtBP, "W_P' rhs without a pass").
+template <class T, int NCL, int G, int FIRST, bool IDX, bool RHSK = false>
 __global__ void __launch_bounds__(kBlock, occ_sweep_x(NCL, G, FIRST))
     kx_solve_sweep(ColsX<T> cols, int ncols, BVecs<T> b, BVecs<T> bw, int vsel_id, CoefX<T> coef, int has_w, T theta, int64_t n,
                    RedWsX ws, double* __restrict__ out, int* __restrict__ lu_list, unsigned* __restrict__ lu_cnt, unsigned lu_cap,
-                   const int* __restrict__ ridx, T* __restrict__ cli, T* __restrict__ cui, int cv)
+                   const int* __restrict__ ridx, T* __restrict__ cli, T* __restrict__ cui, int cv, ProX<T> pro)
 {
     typedef typename AccOf<T>::type A;
     constexpr int RPW = 64 / G, ND = FIRST ? 0 : NCL, NL = ND + 7;
     __shared__ const T* s_col[kColsX];
     __shared__ T sc[kColsX];
+    __shared__ T s_c1[RHSK ? kColsX : 1], s_c2[RHSK ? kColsX : 1];
     if (threadIdx.x < kColsX)
     {
         s_col[threadIdx.x] = cols.p[threadIdx.x];
         sc[threadIdx.x] = coef.c[threadIdx.x];
+        if (RHSK)
+        {
+            s_c1[RHSK ? threadIdx.x : 0] = pro.c1[threadIdx.x];
+            s_c2[RHSK ? threadIdx.x : 0] = pro.c2[threadIdx.x];
+        }
     }
     __syncthreads();
     const LaneX<G> L;
@@ -490,7 +501,31 @@ __global__ void __launch_bounds__(kBlock, occ_sweep_x(NCL, G, FIRST))
                 p[k] = x.w[k] * sc[L.g * NCL + k];
             a = chain_x<T, NCL, G>(p, L);
         }
-        const T v = vkind == 0 ? x.xa : vkind == 1 ? -x.xa : x.xa - x.xb;
+        T v = vkind == 0 ? x.xa : vkind == 1 ? -x.xa : x.xa - x.xb;
+        if (RHSK)
+        {
+            // rhs = rhs + (-(W * c1)(row)) [+ (-(W * c2)(row))], v = -rhs: kx_rows' GP_RHS statements (x.xa is the rhs read)
+            T rh = x.xa;
+            if (pro.use1)
+            {
+                T p[NCL];
+#pragma unroll
+                for (int k = 0; k < NCL; k++)
+                    p[k] = x.w[k] * s_c1[RHSK ? L.g * NCL + k : 0];
+                rh = rh + (-chain_x<T, NCL, G>(p, L));
+            }
+            if (pro.use2)
+            {
+                T p[NCL];
+#pragma unroll
+                for (int k = 0; k < NCL; k++)
+                    p[k] = x.w[k] * s_c2[RHSK ? L.g * NCL + k : 0];
+                rh = rh + (-chain_x<T, NCL, G>(p, L));
+            }
+            if (solve && L.last())
+                bw.rhs[iw] = rh;
+            v = -rh;
+        }
         const T ynew = has_w ? (v / theta + a / theta2) : (v / theta);
         const T yi = solve ? ynew : x.yold;
         if (solve && L.last())
@@ -831,8 +866,11 @@ __global__ void __launch_bounds__(kBlock, occ_dots_x(NCL))
 template <class T, int NCL, int G>
 __global__ void __launch_bounds__(kBlock, occ_mask_x(NCL))
     kx_list1(ColsX<T> cols, int ncols, BVecs<T> b, int vsel_id, int mask, const int* __restrict__ list, int nlist, RedWsX ws,
-             double* __restrict__ out)
+             double* __restrict__ out, const unsigned char* __restrict__ stc, const int* __restrict__ pos,
+             double* __restrict__ out_dd)
 {
+    // stc / pos: the state bytes live at the rows' positions in the compact copy (see kx_list2); out_dd: the un-rounded
+    // (hi, lo) sums of column k at out_dd[2 k], [2 k + 1] -- for the sums that are subtracted from others before rounding
     typedef typename AccOf<T>::type A;
     constexpr int RPW = 64 / G, NL = NCL + 1;
     __shared__ const T* s_col[kColsX];
@@ -850,7 +888,7 @@ __global__ void __launch_bounds__(kBlock, occ_mask_x(NCL))
         const int64_t e = base + L.rr;
         const bool inb = e < int64_t(nlist);
         const int64_t i = list[inb ? e : int64_t(nlist) - 1];
-        const unsigned char st = b.st[i];
+        const unsigned char st = stc ? stc[pos[i]] : b.st[i];
         const T v = vsel(b, vsel_id, i);
         T w[NCL];
 #pragma unroll
@@ -883,6 +921,11 @@ __global__ void __launch_bounds__(kBlock, occ_mask_x(NCL))
             if (idx >= 0)
             {
                 out[idx] = double(T(tot.value()));
+                if (out_dd && idx < ncols)
+                {
+                    out_dd[2 * idx] = tot.hi;
+                    out_dd[2 * idx + 1] = acc_lo(tot);
+                }
                 __threadfence_system();
             }
         }

@@ -64,21 +64,30 @@ int rows(hipStream_t s, int num_cus, int na, const ColsX<T>& cols, int ncols, co
 template <class T>
 int solve_sweep(hipStream_t s, int num_cus, int first, const ColsX<T>& cols, int ncols, const BVecs<T>& b, const BVecs<T>& bw,
                 int vsel_id, const CoefX<T>& coef, int has_w, T theta, int64_t n, const RedWsX& ws, double* out, int* lu_list,
-                unsigned* lu_cnt, unsigned lu_cap, const int* ridx, T* cli, T* cui, int cv)
+                unsigned* lu_cnt, unsigned lu_cap, const int* ridx, T* cli, T* cui, int cv, const ProX<T>* pro)
 {
     if (ncols < 1 || ncols > kColsX)
         return LBFGSX_E_INVALID;
-#define SWEEP(FIRST, IDX)                                                                                                         \
-    LBFGSX_LAUNCH((kx_solve_sweep<T, NCL_, G_, FIRST, IDX>), dim3(grid_rows(n, 64 / G_, occ_sweep_x(NCL_, G_, FIRST), num_cus)),        \
+    const bool rhsk = pro && pro->mode == LBFGSX_GP_RHS && (pro->use1 || pro->use2);
+    if (rhsk && (first || vsel_id != VS_NEG_RHS))
+        return LBFGSX_E_INVALID;
+    ProX<T> none;
+    none.mode = LBFGSX_GP_NONE;
+    none.use1 = none.use2 = 0;
+    const ProX<T>& pr = rhsk ? *pro : none;  // (the arrays of `none` are never read)
+#define SWEEP(FIRST, IDX, RHSK)                                                                                                   \
+    LBFGSX_LAUNCH((kx_solve_sweep<T, NCL_, G_, FIRST, IDX, RHSK>), dim3(grid_rows(n, 64 / G_, occ_sweep_x(NCL_, G_, FIRST), num_cus)),  \
                   dim3(kBlock), 0, s, cols, ncols, b, bw, vsel_id, coef, has_w, theta, n, ws, out, lu_list, lu_cnt, lu_cap, ridx, cli,  \
-                  cui, cv)
-#define CALL(NCL, G)                            \
-    {                                           \
-        constexpr int NCL_ = NCL, G_ = G;       \
-        if (first && ridx) SWEEP(1, true);      \
-        else if (first) SWEEP(1, false);        \
-        else if (ridx) SWEEP(0, true);          \
-        else SWEEP(0, false);                   \
+                  cui, cv, pr)
+#define CALL(NCL, G)                                   \
+    {                                                  \
+        constexpr int NCL_ = NCL, G_ = G;              \
+        if (first && ridx) SWEEP(1, true, false);      \
+        else if (first) SWEEP(1, false, false);        \
+        else if (rhsk && ridx) SWEEP(0, true, true);   \
+        else if (rhsk) SWEEP(0, false, true);          \
+        else if (ridx) SWEEP(0, true, false);          \
+        else SWEEP(0, false, false);                   \
     }
     LBFGSX_XCLASS(ncols, CALL);
 #undef CALL
@@ -136,13 +145,13 @@ int list2(hipStream_t s, int num_cus, const ColsX<T>& cols, int ncols, const BVe
 
 template <class T>
 int list1(hipStream_t s, int num_cus, const ColsX<T>& cols, int ncols, const BVecs<T>& b, int vsel_id, int mask, const int* list, int nlist,
-          const RedWsX& ws, double* out)
+          const RedWsX& ws, double* out, const unsigned char* stc, const int* pos, double* out_dd)
 {
     if (ncols < 1 || ncols > kColsX)
         return LBFGSX_E_INVALID;
 #define CALL(NCL, G)                                                                                                      \
     LBFGSX_LAUNCH((kx_list1<T, NCL, G>), dim3(std::min(32, grid_rows(nlist, 64 / G, 1, num_cus))), dim3(kBlock), 0, s, cols,   \
-                  ncols, b, vsel_id, mask, list, nlist, ws, out)
+                  ncols, b, vsel_id, mask, list, nlist, ws, out, stc, pos, out_dd)
     LBFGSX_XCLASS(ncols, CALL);
 #undef CALL
     LBFGSX_HIP(hipGetLastError());
@@ -242,14 +251,15 @@ int gram_finish(hipStream_t s, const double* partial, int blocks, int ntile, dou
     template int rows<T>(hipStream_t, int, int, const ColsX<T>&, int, const BVecs<T>&, int, int, int64_t, const RedWsX&, double*,    \
                          double*, const ProX<T>&, const RowsX<T>&, int, int);                                                    \
     template int solve_sweep<T>(hipStream_t, int, int, const ColsX<T>&, int, const BVecs<T>&, const BVecs<T>&, int, const CoefX<T>&, \
-                                int, T, int64_t, const RedWsX&, double*, int*, unsigned*, unsigned, const int*, T*, T*, int);    \
+                                int, T, int64_t, const RedWsX&, double*, int*, unsigned*, unsigned, const int*, T*, T*, int,     \
+                                const ProX<T>*);                                                                                 \
     template int multidot2_wf<T>(hipStream_t, int, const ColsX<T>&, int, int, int, const T*, const T*, const T*, const int*, int64_t, \
                                  const ColsX<T>&, const int*, int, const RedWsX&, double*);                                      \
     template int multidot2<T>(hipStream_t, int, const ColsX<T>&, int, const T*, const T*, int64_t, const RedWsX&, double*);        \
     template int list2<T>(hipStream_t, int, const ColsX<T>&, int, const BVecs<T>&, const int*, int, const RedWsX&, double*,         \
                           const unsigned char*, const int*);                                                                     \
     template int list1<T>(hipStream_t, int, const ColsX<T>&, int, const BVecs<T>&, int, int, const int*, int, const RedWsX&,         \
-                          double*);                                                                                              \
+                          double*, const unsigned char*, const int*, double*);                                                   \
     template int multidot_mask<T>(hipStream_t, int, const ColsX<T>&, int, const BVecs<T>&, int, const T*, int, int64_t,            \
                                   const RedWsX&, double*);                                                                       \
     template int gram<T>(hipStream_t, int, const ColsX<T>&, int, const BVecs<T>&, int, int, int64_t, double*, const ProX<T>&,      \

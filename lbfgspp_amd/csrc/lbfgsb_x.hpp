@@ -14,7 +14,7 @@ int rows(hipStream_t s, int num_cus, int na, const ColsX<T>& cols, int ncols, co
 template <class T>
 int solve_sweep(hipStream_t s, int num_cus, int first, const ColsX<T>& cols, int ncols, const BVecs<T>& b, const BVecs<T>& bw,
                 int vsel_id, const CoefX<T>& coef, int has_w, T theta, int64_t n, const RedWsX& ws, double* out, int* lu_list,
-                unsigned* lu_cnt, unsigned lu_cap, const int* ridx, T* cli, T* cui, int cv);
+                unsigned* lu_cnt, unsigned lu_cap, const int* ridx, T* cli, T* cui, int cv, const ProX<T>* pro = nullptr);
 template <class T>
 int multidot2_wf(hipStream_t s, int num_cus, const ColsX<T>& wfc, int ncols, int fresh_a, int fresh_b, const T* snew, const T* ynew,
                  const T* dvec, const int* idx, int64_t npos, const ColsX<T>& full, const int* list, int nlist, const RedWsX& ws,
@@ -27,7 +27,7 @@ int list2(hipStream_t s, int num_cus, const ColsX<T>& cols, int ncols, const BVe
           double* out, const unsigned char* stc, const int* pos);
 template <class T>
 int list1(hipStream_t s, int num_cus, const ColsX<T>& cols, int ncols, const BVecs<T>& b, int vsel_id, int mask, const int* list, int nlist,
-          const RedWsX& ws, double* out);
+          const RedWsX& ws, double* out, const unsigned char* stc = nullptr, const int* pos = nullptr, double* out_dd = nullptr);
 template <class T>
 int multidot_mask(hipStream_t s, int num_cus, const ColsX<T>& cols, int ncols, const BVecs<T>& b, int vsel_id, const T* vcol, int mask,
                   int64_t n, const RedWsX& ws, double* out);

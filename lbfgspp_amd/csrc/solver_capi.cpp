@@ -207,6 +207,7 @@ struct LbfgsbImpl : lbfgsx_solver
         stats3[0] = st.gcp_searches;
         stats3[1] = st.gcp_nord;
         stats3[2] = st.gcp_sorted;
+        stats3[3] = st.rhs_identities;
     }
     void set_hook(void (*fn)(int, void*), void* user) override
     {

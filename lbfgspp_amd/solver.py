@@ -245,5 +245,5 @@ class LBFGSBSolver(_SolverBase):
                       "correction_us", "submin_fused_sweeps", "gram_carried"), list(arr2)[:8]))
         arr3 = (C.c_longlong * 8)()
         L.check(self._sol.lbfgsx_solver_stats3(self._h, C.byref(arr3)))
-        d.update(zip(("gcp_searches", "gcp_nord", "gcp_sorted"), list(arr3)[:3]))
+        d.update(zip(("gcp_searches", "gcp_nord", "gcp_sorted", "rhs_identities"), list(arr3)[:4]))
         return d

@@ -63,7 +63,12 @@ for k, c in sorted(agg.items()):
 tl = {k: v for k, v in out["kernels"].items() if k.startswith("k_twoloop") and "persist" not in k}
 ps = {k: v for k, v in out["kernels"].items() if k.startswith("k_twoloop_persist")}
 calls = sum(v["calls"] for v in tl.values())
-fused = {k: v for k, v in ps.items() if "true" in k}
+def _fused_post(name):  # k_twoloop_persist<T, FUSE[, MEET]>: the second template argument
+    args = name[name.index("<") + 1:name.rindex(">")].split(",") if "<" in name else []
+    return len(args) >= 2 and args[1].strip() == "true"
+
+
+fused = {k: v for k, v in ps.items() if _fused_post(k)}
 if fused:
     # round 2: every apply_Hv after the first rides in the launch that also carries K3 (k_twoloop_persist<T, true>,
     # lbfgsx_post_linesearch_spec).  Launch k (k = 1, 2, ...) runs 2*min(k, 10)+1 steps, step 0 being the post statements.

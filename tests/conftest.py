@@ -16,6 +16,8 @@ def pytest_configure(config):
     # tail, ...), so the threshold is lifted for the test processes.  Programs the tests start as stand-alone binaries
     # (the reference's examples) get the product's default back (tests/test_reference_examples_gpu.py).
     os.environ.setdefault("LBFGSX_PERSIST_MIN_N", "0")
+    config.addinivalue_line("markers", "rhs_pass: bit-identity test of a mechanism the sweeps' \"W_P' rhs from held sums\" depends on "
+                                       "(runs with LBFGSX_RHS_IDENTITY=0, see the fixture below)")
 
 
 def pytest_sessionstart(session):
@@ -42,3 +44,17 @@ def oracle():
     if O.available("port", "dd"):
         return O.Oracle("port", "dd")
     pytest.skip("no oracle library built (make -C oracle)")
+
+
+@pytest.fixture(autouse=True)
+def _rhs_pass_for_bit_identity_tests(request, monkeypatch):
+    """Round 4: a BOXCQP sweep's W_P' rhs comes from sums the host holds (BFGSMat.h, m_vF_dd) when the split-row kernels, the
+    carried Gram, the compact copy and the sweep riding on the solve are all in play -- correct to the last bit or the one
+    before, not bit-identical to the pass over P it replaces.  A test that switches ONE of those mechanisms off and demands
+    the same bits from both runs would compare a run with the identity against one without it; such tests are marked
+    `rhs_pass` and run both sides with the pass (LBFGSX_RHS_IDENTITY=0).  What the identity itself does to a trajectory is
+    test_sweep_rhs_products_from_held_sums_stay_within_an_ulp_of_the_pass's business; every comparison with the oracle runs
+    with the product's default."""
+    if request.node.get_closest_marker("rhs_pass"):
+        monkeypatch.setenv("LBFGSX_RHS_IDENTITY", "0")
+    yield

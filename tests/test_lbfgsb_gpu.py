@@ -298,6 +298,7 @@ def test_mfma_gram_mode_solves_the_box_qp(A, monkeypatch):
     assert niter < 400 and np.abs(x - np.clip(b / a, lb, ub)).max() < 1e-4
 
 
+@pytest.mark.rhs_pass
 @pytest.mark.parametrize("max_submin", [10, 2, 1])
 def test_fused_subspace_passes_are_bit_identical_to_the_unfused_sequence(A, monkeypatch, max_submin):
     """Default path (one-pass Gram with the rhs / linear-term prologue, solve fused with W_F'y, one-launch
@@ -327,6 +328,7 @@ def test_fused_subspace_passes_are_bit_identical_to_the_unfused_sequence(A, monk
     assert f[6] == u[6] and (max_submin >= 10 or f[6] > 0)
 
 
+@pytest.mark.rhs_pass
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("m,max_submin", [(8, 10), (10, 3), (3, 10), (14, 10), (12, 10), (20, 10), (40, 4)])
 def test_sweep_statements_riding_on_the_solve_change_no_bit(A, monkeypatch, m, max_submin, dtype):
@@ -358,6 +360,7 @@ def test_sweep_statements_riding_on_the_solve_change_no_bit(A, monkeypatch, m, m
     assert u[6] == 0 and f[6] > 0
 
 
+@pytest.mark.rhs_pass
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("n,m,max_submin", [(70001, 8, 10), (70001, 10, 2), (65536, 3, 10), (90000, 14, 10), (70001, 12, 10),
                                             (90000, 20, 10), (65536, 40, 10)])
@@ -572,6 +575,7 @@ def test_cauchy_dots_from_the_kept_compact_copy_change_no_bit(A, monkeypatch, n,
     assert u[4] == 0 and f[4] > 0
 
 
+@pytest.mark.rhs_pass
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("n,m,iters,age", [(70001, 8, 60, 32), (70001, 10, 45, 32), (65536, 3, 40, 32), (90000, 12, 40, 32),
                                            (200000, 10, 80, 32), (70001, 8, 40, 2), (120000, 10, 40, 5), (65536, 5, 40, 3),
@@ -860,6 +864,7 @@ def test_selected_entries_and_list_grams_equal_the_full_pass(A, n, m, npairs):
         core.lbfgsx_destroy(h)
 
 
+@pytest.mark.rhs_pass
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("n,m,iters,max_submin", [(70001, 3, 30, 10), (70001, 8, 40, 10), (90000, 10, 45, 10), (70001, 12, 40, 10),
                                                   (65536, 16, 50, 10), (90000, 20, 60, 10), (65536, 40, 100, 10), (70001, 10, 40, 2)])
@@ -1017,3 +1022,44 @@ def test_first_trial_evaluated_with_dg_and_step_max_changes_no_bit(A, monkeypatc
     assert f0[5] == (0, 0)
     if f1[0] > 8:
         assert f1[5][0] >= f1[0] // 3 and f1[5][1] >= f1[5][0] // 2, f1[5]
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("n,m,iters", [(70001, 8, 40), (90000, 10, 45), (65536, 20, 50), (400000, 10, 30)])
+def test_sweep_rhs_products_from_held_sums_stay_within_an_ulp_of_the_pass(A, boracle, monkeypatch, n, m, iters, dtype):
+    """A BOXCQP sweep's solve opens with W_P' rhs (BFGSMat.h:560) after rhs_P = c_P + B[P,L] l + B[P,U] u (SubspaceMin.h:232-241).
+    Rounds 1-3 made a pass over P for those 2c numbers; now they come from sums the host holds un-rounded -- W_F'(-c) of the
+    first solve, W_{L u U}'(-c) and the Gram of the complement identity -- and the row-wise rhs is written by the solve's own
+    pass (lbfgsx_b_solve_sweep_rhs).  NOT bit-identical: the pass summed the rounded rows, this is the exact sum rounded once,
+    a difference in the last bit of some of the 2c numbers, which the 2c x 2c solve carries into y.  So: the same iteration and
+    evaluation counts and the same sweeps as LBFGSX_RHS_IDENTITY=0, iterates within 1e-10 (f64; north_star's tolerance) of it
+    at every evaluation -- and both as close to the reference (extended-precision sums) as each other."""
+    dt = O.F64 if dtype == "f64" else O.F32
+    npdt = O.NPDT[dt]
+    a, b = O.quad_problem(n, 30.0, 17, dt)
+    lb, ub = (-0.7 * np.ones(n)).astype(npdt), (0.9 * np.ones(n)).astype(npdt)
+    res = {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("LBFGSX_RHS_IDENTITY", on)
+        s = A.LBFGSBSolver(A.LBFGSBParam(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters), dtype=npdt)
+        tr = A.TraceBuffer(n, cap=512, stride=19)
+        x = np.zeros(n, dtype=npdt)
+        niter, fx = s.minimize(A.DiagQuadratic(a, b), x, lb, ub, trace=tr)
+        st = s.stats()
+        res[on] = (niter, s.last.nfev, x.copy(), tr.xs[:tr.count].copy(), st["submin_sweeps"], st["rhs_identities"])
+    f, u = res["1"], res["0"]
+    tol = 1e-10 if dtype == "f64" else 2e-4
+    assert u[5] == 0
+    if dtype == "f64":
+        assert f[:2] == u[:2] and f[4] == u[4]
+        assert f[5] > 0 and f[5] >= f[4] // 4, (f[4], f[5])      # most sweeps of the iterations with a carried Gram
+        assert np.abs(f[3] - u[3]).max() <= tol and np.abs(f[2] - u[2]).max() <= tol
+        p = O.lbfgsb_params(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters)
+        x_ref, r_ref = boracle.lbfgsb(dt, O.OBJ_QUAD, np.zeros(n, dtype=npdt), lb, ub, p, a=a, b=b)
+        assert (r_ref.niter, r_ref.nfev) == f[:2]
+        d1, d0 = np.abs(f[2] - x_ref).max(), np.abs(u[2] - x_ref).max()
+        assert d1 <= tol and d0 <= tol, (d1, d0)
+    else:
+        # f32: a last-bit difference in W_P' rhs may move a line search by an evaluation; the minimiser stays the same
+        assert f[5] > 0
+        assert np.abs(f[2] - u[2]).max() <= tol
