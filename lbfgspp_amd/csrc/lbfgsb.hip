@@ -156,7 +156,6 @@ struct lbfgsb_state
     double* gram_partial2 = nullptr;  // [32][3][256][2]
     double* gram_out = nullptr;       // [3][256]
     int gram_blocks = 1024;  // 4 resident blocks per CU (33 KB of LDS each)
-    bool gram_mfma = false;  // opt-in (LBFGSX_GRAM=mfma): ~1 ulp per entry instead of the correctly rounded sums
     // exact Gram on the matrix cores (gram_i8.cuh): radix-256 digits, v_mfma_i32_32x32x32_i8, integer sums
     bool gram_i8 = false;                    // LBFGSX_GRAM=i8
     int i8_min_tot = 1;                      // fewer columns than this: the double-double kernel (LBFGSX_GRAM_I8_MIN)
@@ -492,7 +491,6 @@ int bounded_alloc(lbfgsx_ctx* c)
     // double-double kernel stays the default at every m and the matrix-core kernel an option that changes no bit.
     if (const char* e = getenv("LBFGSX_GRAM"))
     {
-        b->gram_mfma = (std::strcmp(e, "mfma") == 0);
         b->gram_i8 = (std::strcmp(e, "i8") == 0);
         if (const char* e2 = getenv("LBFGSX_GRAM_I8_MIN"))
             b->i8_min_tot = std::max(1, atoi(e2));
@@ -2503,7 +2501,7 @@ static bool gram_stash_feasible(lbfgsx_ctx* c, const int* list, int64_t nlist)
 {
     lbfgsb_state* b = c->bstate;
     const int tot = 2 * c->ncorr;
-    return b->stash_use && b->stash_host && !b->gram_mfma && b->gram_mode != 2 && tot >= 1 && (tot <= kGramDDCS || b->split) && list &&
+    return b->stash_use && b->stash_host && b->gram_mode != 2 && tot >= 1 && (tot <= kGramDDCS || b->split) && list &&
            nlist >= 1;
 }
 // signal: this is the last launch before the caller's wait -- its final block carries the completion word (ctx.hpp)
@@ -2737,7 +2735,7 @@ int lbfgsx_b_wtv_prologue(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, co
     lbfgsb_state* b = c->bstate;
     const int tot = 2 * c->ncorr, ntot = tot + 1;
     const bool xsplit = b->split && b->vrows;  // kx_rows: any 2c <= 80
-    if (tot < 1 || (ntot > kGramDDCS && !xsplit) || tot > kColsX || vsel_id < 0 || !wtv || b->gram_mfma || b->gram_mode == 2 ||
+    if (tot < 1 || (ntot > kGramDDCS && !xsplit) || tot > kColsX || vsel_id < 0 || !wtv || b->gram_mode == 2 ||
         prologue < LBFGSX_GP_NONE || prologue > LBFGSX_GP_LINEAR)
     {
         set_error("lbfgsx_b_wtv_prologue: needs the default one-pass Gram, 1 <= 2c <= 80, a vector selector and a known prologue");
@@ -2952,7 +2950,7 @@ int lbfgsx_b_gram_pairs_max(lbfgsx_ctx* c)
         return 0;
     const lbfgsb_state* b = c->bstate;
     const int tot = 2 * c->ncorr;
-    if (tot < 1 || tot > kColsX || b->gram_mfma || b->gram_mode == 2)
+    if (tot < 1 || tot > kColsX || b->gram_mode == 2)
         return 0;
     if (b->split && b->vrows)
         return 3 * (tot + 1);
@@ -2969,7 +2967,7 @@ int lbfgsx_b_gram_pairs_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
     lbfgsb_state* b = c->bstate;
     const int tot = 2 * c->ncorr, ntot = tot + 1;
     const bool xsplit = b->split && b->vrows;  // kx_rows: any 2c <= 80, up to 3 (2c + 1) entries
-    if (tot < 1 || tot > kColsX || vsel_id < 0 || !out_dd || b->gram_mfma || b->gram_mode == 2 || npairs < 1 ||
+    if (tot < 1 || tot > kColsX || vsel_id < 0 || !out_dd || b->gram_mode == 2 || npairs < 1 ||
         (xsplit ? npairs > 3 * (kColsX + 1) : (npairs > 64 || ntot > kGramDDCS)) || prologue < LBFGSX_GP_NONE || prologue > LBFGSX_GP_LINEAR)
     {
         set_error("lbfgsx_b_gram_pairs_dd: needs the default one-pass Gram, 1 <= 2c <= 80, a vector selector and 1..3 (2c + 1) entries");
@@ -3213,7 +3211,7 @@ static int gram_dd_core(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, cons
     const int tot = 2 * c->ncorr;
     const int ntot = tot + (vsel_id >= 0 ? 1 : 0);
     const bool lu_walk = !list && b->lu_valid && b->lu_use && vsel_id < 0 && prologue == LBFGSX_GP_NONE && mask != 0 &&
-                         (mask & ~(ST_L | ST_U)) == 0 && !b->gram_mfma;
+                         (mask & ~(ST_L | ST_U)) == 0;
     // launched ahead?  (slot 0: the rows of L u U behind lbfgsx_b_wtv_lu; slots 1, 2: the entered / left rows behind
     // lbfgsx_b_gram_pairs_dd)
     {
@@ -3236,71 +3234,20 @@ static int gram_dd_core(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, cons
         if (rc)
             return rc;
     }
-    if (prologue != LBFGSX_GP_NONE && (b->gram_mfma || prologue < 0 || prologue > LBFGSX_GP_LINEAR))
+    if (prologue != LBFGSX_GP_NONE && (prologue < 0 || prologue > LBFGSX_GP_LINEAR))
     {
         set_error("lbfgsx_b_gram_fused_ex: the prologue needs the default one-pass Gram");
         return LBFGSX_E_INVALID;
     }
-    if (gram_dd && b->gram_mfma)
-    {
-        set_error("lbfgsx_b_gram_fused_dd: the un-rounded sums exist for the default one-pass Gram only");
-        return LBFGSX_E_INVALID;
-    }
     // kx_gram, the block-tile kernel: 2c + 1 > 31, and (decided below) short row lists, which one block finishes by itself
-    bool wide = !b->gram_mfma && ntot > kGramDDCS && b->split;
-    if (tot < 1 || (b->gram_mfma ? tot + 1 > 32 : (ntot > kGramDDCS && !wide)) || b->gram_mode == 2)
+    bool wide = ntot > kGramDDCS && b->split;
+    if (tot < 1 || (ntot > kGramDDCS && !wide) || b->gram_mode == 2)
     {
         set_error("lbfgsx_b_gram_fused: one-pass Gram not applicable");
         return LBFGSX_E_INVALID;
     }
     std::vector<double> hbuf(size_t(b->gtile) * 256);
     double* h = hbuf.data();
-    if (b->gram_mfma)
-    {
-        const int64_t ntiles = (c->n + kGramRows - 1) / kGramRows;
-        const int blocks = int(std::min<int64_t>(b->gram_blocks, ntiles));
-        DISPATCH_T(c, {
-            int which[32];
-            for (int k = 0; k < tot; k++)
-                which[k] = k;
-            Cols<T, 32> cl = col_list<T, 32>(c, which, tot);
-            LBFGSX_LAUNCH((k_gram_mfma<T>), dim3(blocks), dim3(kBlock), 0, c->stream, cl, tot, bvecs<T>(c), vsel_id, mask,
-                               c->n, b->gram_partial);
-        });
-        // two-level sum of the per-block partials: 32 chunks in parallel, then the final rounding
-        const int nch = std::min(blocks, 32);
-        LBFGSX_LAUNCH(k_gram_finish, dim3(3, nch), dim3(kBlock), 0, c->stream, b->gram_partial, blocks, b->gram_partial2, 0);
-        LBFGSX_LAUNCH(k_gram_finish, dim3(3, 1), dim3(kBlock), 0, c->stream, b->gram_partial2, nch, b->gram_out, 1);
-        LBFGSX_HIP(hipGetLastError());
-        if (b->gram_out_host)
-        {
-            LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
-            std::memcpy(h, b->gram_out_host, sizeof(double) * 3 * 256);
-        }
-        else
-        {
-            LBFGSX_HIP(lbfgsx::copy_async(h, b->gram_out, sizeof(double) * 3 * 256, hipMemcpyDeviceToHost, c->stream));
-            LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
-        }
-        // entry (I, J), I >= J, of the padded 32 x 32 Gram
-        auto G = [&](int I, int J) {
-            const int tb = (I < 16) ? 0 : (J < 16 ? 1 : 2);
-            const int mrow = I & 15, ncol = J & 15;
-            const int reg = mrow >> 2, lane = ((mrow & 3) << 4) | ncol;
-            return h[tb * 256 + reg * 64 + lane];
-        };
-        for (int i = 0; i < tot; i++)
-            for (int j = 0; j <= i; j++)
-            {
-                const double v = G(i, j);
-                gram[i * tot + j] = v;
-                gram[j * tot + i] = v;
-            }
-        if (wtv && vsel_id >= 0)
-            for (int j = 0; j < tot; j++)
-                wtv[j] = G(tot, j);
-        return LBFGSX_OK;
-    }
     const int npairs = ntot * (ntot + 1) / 2;
     const int kp = (npairs + 63) / 64;  // pairs per lane: 1, 2, 4, 6 or 8 (ntot <= 31 -> 496 pairs)
     int blocks = 1;
@@ -3355,7 +3302,7 @@ static int gram_dd_core(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, cons
             wf_rebuilt(c);
     }
     const int kpt_ = kp <= 1 ? 1 : kp <= 2 ? 2 : kp <= 4 ? 4 : kp <= 6 ? 6 : 8;
-    const bool one_block = list && b->split && !b->gram_mfma && !b->gram_i8 && nlist <= kListOneBlock && prologue == LBFGSX_GP_NONE;
+    const bool one_block = list && b->split && !b->gram_i8 && nlist <= kListOneBlock && prologue == LBFGSX_GP_NONE;
     wide = wide || one_block;
     const int ntile_ = wide ? xl::gram_kpb(ntot) : (64 * kpt_ + 255) / 256;
     if (wide)

@@ -743,118 +743,12 @@ __global__ void __launch_bounds__(kBlock) k_gram(Cols<T, TB> ci, int ni, Cols<T,
             out[k] = double(T(acc[k].value()));
 }
 
-// ---------------------------------------------------------------- masked Gram on the matrix cores
-// G = [Y_P S_P v_P]' [Y_P S_P v_P]  ((2c+1) x (2c+1), 2c+1 <= 32): the one genuine contraction of the path
-// (solve_PtBP, BFGSMat.h:543-556,560).  ONE pass over the 2c columns: each 128-row slab is staged through LDS
-// (coalesced 16-byte loads along the columns, masked rows zeroed) and consumed by v_mfma_f64_16x16x4_f64
-// (A = slab' (16 cols x 4 rows), B = slab (4 rows x 16 cols)); three 16x16 output tiles cover the lower
-// triangle of the padded 32 x 32 Gram.  f32 data is widened to f64 in the slab (products exact).  The MFMA
-// accumulators are flushed into per-lane double-double sums after every slab (8 MFMA steps), so the only
-// un-compensated additions are 8-term partial sums: the result is accurate to ~1 ulp (measured <= 1.5e-16
-// relative against the correctly rounded VALU Gram) but not bit-identical to it.  Ill-conditioned `mid`
-// systems amplify even that, so the parity default stays the VALU Gram and this kernel is the opt-in fast path.
-// LDS slab layout [col][row] with column stride 130 doubles: the MFMA operand read (lane -> col = l&15,
-// row = r0 + (l>>4)) then touches all 64 banks exactly once per 32-lane group (conflict-free ds_read_b64).
-constexpr int kGramRows = 128;
-constexpr int kGramRS = kGramRows + 2;
-typedef double d4_t __attribute__((ext_vector_type(4)));
-
-template <class T>
-__global__ void __launch_bounds__(kBlock) k_gram_mfma(Cols<T, 32> cols, int ncols, BVecs<T> b, int vsel_id, int mask,
-                                                      int64_t n, double* __restrict__ partial)
-{
-    __shared__ __attribute__((aligned(16))) double slab[32 * kGramRS];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int ntot = ncols + (vsel_id >= 0 ? 1 : 0);
-    const bool two = ntot > 16;
-    for (int i = tid; i < 32 * kGramRS; i += kBlock)
-        slab[i] = 0.0;  // padded columns stay zero
-    DD a00[4], a10[4], a11[4];
-    const int64_t ntiles = (n + kGramRows - 1) / kGramRows;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
-    {
-        __syncthreads();
-        const int64_t row0 = tile * kGramRows;
-        for (int idx = tid; idx < ntot * (kGramRows / 2); idx += kBlock)
-        {
-            const int col = idx / (kGramRows / 2), r2 = idx % (kGramRows / 2);
-            const int64_t r = row0 + 2 * r2;
-            double v0 = 0.0, v1 = 0.0;
-            const bool ok0 = r < n && (!mask || (b.st[r] & mask));
-            const bool ok1 = r + 1 < n && (!mask || (b.st[r + 1] & mask));
-            if (col < ncols)
-            {
-                const T* p = cols.p[col];
-                if (r + 1 < n)
-                {
-                    // rows r, r+1 of one column: r is even and the column base is 16-byte aligned
-                    T two[2];
-                    if (sizeof(T) == 8)
-                        *reinterpret_cast<d2_t*>(two) = *reinterpret_cast<const d2_t*>(p + r);
-                    else
-                        *reinterpret_cast<float2*>(two) = *reinterpret_cast<const float2*>(p + r);
-                    if (ok0) v0 = double(two[0]);
-                    if (ok1) v1 = double(two[1]);
-                }
-                else if (ok0)
-                    v0 = double(p[r]);
-            }
-            else
-            {
-                if (ok0) v0 = double(vsel(b, vsel_id, r));
-                if (ok1) v1 = double(vsel(b, vsel_id, r + 1));
-            }
-            d2_t pk;
-            pk.x = v0;
-            pk.y = v1;
-            *reinterpret_cast<d2_t*>(&slab[col * kGramRS + 2 * r2]) = pk;
-        }
-        __syncthreads();
-        d4_t d00 = {0, 0, 0, 0}, d10 = {0, 0, 0, 0}, d11 = {0, 0, 0, 0};
-#pragma unroll
-        for (int t = 0; t < 8; t++)
-        {
-            const int r = wv * 32 + 4 * t + (lane >> 4);
-            const double x0 = slab[(lane & 15) * kGramRS + r];
-            d00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, d00, 0, 0, 0);
-            if (two)
-            {
-                const double x1 = slab[(16 + (lane & 15)) * kGramRS + r];
-                d10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x0, d10, 0, 0, 0);
-                d11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, d11, 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int v = 0; v < 4; v++)
-        {
-            a00[v].add(d00[v]);
-            a10[v].add(d10[v]);
-            a11[v].add(d11[v]);
-        }
-    }
-    // block reduction over the 4 waves, one output tile at a time (re-using the slab as scratch)
-    double* part = partial + size_t(blockIdx.x) * 3 * 256 * 2;
-    for (int tb = 0; tb < 3; tb++)
-    {
-        __syncthreads();
-        DD* src = (tb == 0) ? a00 : (tb == 1) ? a10 : a11;
-#pragma unroll
-        for (int v = 0; v < 4; v++)
-        {
-            slab[((wv * 4 + v) * 64 + lane) * 2 + 0] = src[v].hi;
-            slab[((wv * 4 + v) * 64 + lane) * 2 + 1] = src[v].lo;
-        }
-        __syncthreads();
-        DD t;  // entry e = v*64 + lane handled by thread e
-        for (int w = 0; w < 4; w++)
-            t.merge(slab[((w * 4 + (tid >> 6)) * 64 + (tid & 63)) * 2 + 0], slab[((w * 4 + (tid >> 6)) * 64 + (tid & 63)) * 2 + 1]);
-        part[(tb * 256 + tid) * 2 + 0] = t.hi;
-        part[(tb * 256 + tid) * 2 + 1] = t.lo;
-    }
-}
-
+// (Rounds 1-3 kept a plain f64 MFMA form of this Gram, k_gram_mfma / LBFGSX_GRAM=mfma: ~1 ulp per entry, which the 2c x 2c
+// solves amplify beyond the 1e-10 contract, per-block sums in launch order, and -- measured in round 4, profiles/
+// r4_gram_modes_by_m.txt -- 3.4x (m = 10) to 6.5x (m = 20) slower end to end than the default, which no longer makes a full Gram
+// pass per iteration.  Removed.  The exact integer MFMA form is csrc/gram_i8.cuh, opt-in.)
 // ---------------------------------------------------------------- masked Gram, correctly rounded, ONE pass (default K6)
-// Same matrix as k_gram_mfma, G = [Y_P S_P v_P]' [Y_P S_P v_P] with ntot = 2c (+1) <= 31 columns, but every entry
+// G = [Y_P S_P v_P]' [Y_P S_P v_P] ((2c+1) x (2c+1); solve_PtBP, BFGSMat.h:543-556,560) with ntot = 2c (+1) <= 31 columns: every entry
 // is a double-double sum of error-free products (TwoProd + TwoSum), i.e. the order-independent result the parity
 // contract is written against.  The columns are read exactly once (algorithmic traffic ntot * n elements); the
 // npairs = ntot (ntot + 1) / 2 products per row make the kernel VALU-bound (~10 f64 instructions per product), so

@@ -253,51 +253,6 @@ def test_lbfgsb_trajectory_golden(A, case, tol=1e-10):
     assert abs(fx - float.fromhex(case["fx"])) <= 1e-12 * abs(fx)
 
 
-def test_mfma_gram_matches_correctly_rounded_gram(A, monkeypatch):
-    """opt-in matrix-core Gram (LBFGSX_GRAM=mfma): every entry of W_P'W_P and W_P'v within 4 ulp-of-scale of the
-    correctly rounded VALU path, for a masked and an unmasked row set"""
-    from lbfgspp_amd import _lib as L
-    core, _ = A.load()
-    monkeypatch.setenv("LBFGSX_GRAM", "mfma")
-    vp = C.c_void_p
-    for n, m, npairs in ((5000, 10, 10), (300001, 6, 4), (1 << 20, 15, 15)):
-        h = C.c_void_p()
-        L.check(core.lbfgsx_create(C.byref(h), 0, n, m, 0, 1))
-        rng = np.random.default_rng(n)
-        for k in range(npairs):
-            s_ = rng.standard_normal(n)
-            y_ = s_ * (1 + rng.random(n))
-            L.check(core.lbfgsx_bfgs_add_correction_host(h, s_.ctypes.data_as(vp), y_.ctypes.data_as(vp)))
-        d = rng.standard_normal(n)
-        L.check(core.lbfgsx_upload(h, L.VEC_D, d.ctypes.data_as(vp)))
-        t = 2 * min(npairs, m)
-        g1, g2, w1, w2 = np.zeros((t, t)), np.zeros((t, t)), np.zeros(t), np.zeros(t)
-        f = core.lbfgsx_b_gram
-        f.restype, f.argtypes = C.c_int, [vp, C.c_int, vp]
-        L.check(f(h, 0, g1.ctypes.data_as(vp)))
-        f = core.lbfgsx_b_wtv
-        f.restype, f.argtypes = C.c_int, [vp, C.c_int, C.c_int, vp, vp]
-        L.check(f(h, 0, 0, w1.ctypes.data_as(vp), None))
-        f = core.lbfgsx_b_gram_fused
-        f.restype, f.argtypes = C.c_int, [vp, C.c_int, C.c_int, vp, vp]
-        L.check(f(h, 0, 0, g2.ctypes.data_as(vp), w2.ctypes.data_as(vp)))
-        core.lbfgsx_destroy(h)
-        eps = np.finfo(np.float64).eps
-        assert np.abs(g2 - g1).max() <= 4 * eps * np.abs(g1).max()
-        assert np.abs(w2 - w1).max() <= 4 * eps * np.abs(w1).max()
-
-
-def test_mfma_gram_mode_solves_the_box_qp(A, monkeypatch):
-    monkeypatch.setenv("LBFGSX_GRAM", "mfma")
-    n = 20000
-    a, b = O.quad_problem(n)
-    lb, ub = -np.ones(n), np.ones(n)
-    s = A.LBFGSBSolver(A.LBFGSBParam(m=10, epsilon=1e-5, epsilon_rel=0.0, past=0, max_iterations=400))
-    x = np.zeros(n)
-    niter, fx = s.minimize(A.DiagQuadratic(a, b), x, lb, ub)
-    assert niter < 400 and np.abs(x - np.clip(b / a, lb, ub)).max() < 1e-4
-
-
 @pytest.mark.rhs_pass
 @pytest.mark.parametrize("max_submin", [10, 2, 1])
 def test_fused_subspace_passes_are_bit_identical_to_the_unfused_sequence(A, monkeypatch, max_submin):
