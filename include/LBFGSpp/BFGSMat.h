@@ -57,12 +57,12 @@ class BFGSMatB
     // selected-entries pass serves for any 2c <= 80 (kx_rows; the round-3 kernel: 64 entries, one per lane, i.e. m <= 10),
     // the cost of a v-row pass instead of the full Gram's -- and the others change by the outer products of the rows that
     // moved (lbfgsx_b_free_delta, lbfgsx_b_gram_list_dd).  Everything stays un-rounded double-double, so the rounded
-    // entries are those of the direct sums (error ~2^-104 per update; a full pass every carry_max_age() = 32 iterations bounds
+    // entries are those of the direct sums (error ~2^-104 per update; a full pass every carry_max_age() = 256 iterations bounds
     // what can build up).  Indexed by u = family * m + slot (family 0: Y, 1: S), lower triangle u >= v.
     static int carry_max_age()   // iterations between two full passes; LBFGSX_GRAM_CARRY_AGE for the tests
     {
         const char* e = std::getenv("LBFGSX_GRAM_CARRY_AGE");
-        const int v = e ? std::atoi(e) : 32;
+        const int v = e ? std::atoi(e) : 256;
         return v < 1 ? 1 : v;
     }
     mutable std::vector<double> m_carry;      // [2m (2m + 1) / 2][2]

@@ -39,8 +39,8 @@ for t in cfg2 cfg3 cfg4_m20; do cp $O/$t/*kernel_stats.csv profiles/${R}_${t}_ke
 cp $O/cfg4_m20_timeline.txt profiles/${R}_cfg4_m20_timeline.txt 2>/dev/null
 find $O -name "*kernel_trace.csv" -delete
 du -sh $O
-# the benchmark's own 40 iterations of cfg4 against the reference (about 5 minutes of one host core)
-python scripts/drift_curves.py cfg4 --n 1e7 --iters 40 --devmin default > $O/drift_cfg4_1e7_40it.json 2> $O/drift.err
-python3 -c "
+# the benchmark's own 40 iterations of cfg4 against the reference (about 5 minutes of one host core): DRIFT=1
+[ "${DRIFT:-0}" = 1 ] && python scripts/drift_curves.py cfg4 --n 1e7 --iters 40 --devmin default > $O/drift_cfg4_1e7_40it.json 2> $O/drift.err
+[ "${DRIFT:-0}" = 1 ] && python3 -c "
 import json; d=json.load(open('$O/drift_cfg4_1e7_40it.json')); r=d['runs'][0]
 print('drift 40 it: counts', r['same_counts'], 'max per-eval', max(r['max_dx_per_evaluation']), 'final', r['max_dx_final_all_coordinates'])"

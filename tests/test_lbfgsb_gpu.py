@@ -534,14 +534,15 @@ def test_cauchy_dots_from_the_kept_compact_copy_change_no_bit(A, monkeypatch, n,
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("n,m,iters,age", [(70001, 8, 60, 32), (70001, 10, 45, 32), (65536, 3, 40, 32), (90000, 12, 40, 32),
                                            (200000, 10, 80, 32), (70001, 8, 40, 2), (120000, 10, 40, 5), (65536, 5, 40, 3),
-                                           (90000, 20, 60, 32), (65536, 40, 100, 32), (120000, 20, 50, 3)])
+                                           (90000, 20, 60, 32), (65536, 40, 100, 32), (120000, 20, 50, 3), (70001, 10, 330, 256)])
 def test_carried_gram_of_the_free_set_changes_no_bit(A, monkeypatch, n, m, iters, age, dtype):
     """W_F'W_F of the first BOXCQP solve from the sums of the previous iteration -- the rows of the two replaced columns
     computed afresh, the other entries corrected by the outer products of the rows that entered or left the free set, all
     in double-double (BFGSMatB::carried_gram) -- against the full Gram pass every iteration (LBFGSX_GRAM_CARRY=0): the
     rounded entries are the same, so the trajectory is bit for bit the same; the carried form must have run -- at every m
     (round 3: m <= 10 only, one lane per entry; the split-row kernel serves 3 (2c + 1) entries for any 2c <= 80) -- across
-    its periodic refresh (every 32 iterations) and the growth of the history."""
+    its periodic refresh (every 256 iterations by default since round 4 -- 2^-104 per update leaves 2^-96 after 256 -- every
+    32 before; both periods and much shorter ones here) and the growth of the history."""
     dt = O.F64 if dtype == "f64" else O.F32
     npdt = O.NPDT[dt]
     a, b = O.quad_problem(n, 30.0, 11, dt)
