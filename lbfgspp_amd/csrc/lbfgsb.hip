@@ -10,6 +10,15 @@
 //   psel_*   candidates of the partial break-point sort, listed by the Cauchy build itself
 //   stash_*  Grams over index lists launched behind the pass before their request (need_bounded's keep_stash)
 //   s_*, g_* buffers of the device / host form of the break-point search;  lbfgsx_b_reserve allocates all of it up front
+// Round 4:
+//   split    the passes over the 2c columns with a row's columns split over lane groups (lbfgsb_x.cuh / lbfgsb_x.hip, namespace
+//            xl: any 2c <= 80); xp1, xp2, xtickets = the workspace of their grid reduction (reduce_x.cuh, wsx())
+//   na_*     rows lbfgsx_b_cauchy_finish made newly active (a list for W_A'(A'd)); drt_ready: it also wrote drt = xcp - x0
+//   pb_*     what the post statements' pass computed ahead for the Cauchy search (lbfgsx_b_post_linesearch_build) and the
+//            state it assumed; lbfgsx_b_cauchy_build_partial uses it iff the solver is in that state
+//   st_*     (ctx.hpp) the line search's first trial, evaluated by lbfgsx_b_dg_maxstep_trial; any bounded entry drops it
+//   rhs_identity  a sweep's solve evaluates the rhs updates itself (lbfgsx_b_solve_sweep_rhs) and W_{L u U}'(-c) is delivered
+//            un-rounded (lbfgsx_b_wtv_lu_c): BFGSMatB::solve_PtBP forms W_P' rhs on the host, no pass over P
 // Waits: fetch_doubles / fetch_T / fetch_gram_out read host-mapped results after poll_wait (ctx.hpp) -- a polled completion
 // word when the launch before them was armed (poll_arm), the stream otherwise.
 #include <algorithm>
