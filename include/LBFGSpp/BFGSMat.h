@@ -576,6 +576,11 @@ public:
                 m_GF_dd.assign(size_t(t) * size_t(t + 1), 0.0);
                 fused = (lbfgsx_b_gram_fused_dd(m_c, mask, vsel, prologue, coef1, coef2, G.data(), raw, m_GF_dd.data()) == LBFGSX_OK);
                 m_GF_valid = fused;
+                if (fused && vsel == LBFGSX_VS_NEG_CF)  // W_F'(-c) un-rounded, as the carried form keeps it (see m_vF_dd)
+                {
+                    m_vF_dd.assign(size_t(2 * t), 0.0);
+                    m_vF_valid = lbfgsx_b_gram_last_vrow_dd(m_c, m_vF_dd.data()) == LBFGSX_OK;
+                }
                 m_carry_valid = false;
                 if (fused && carry && carry_fits())   // the remembered free set (lbfgsx_b_free_delta above) is the F of these sums
                 {

@@ -353,6 +353,11 @@ int lbfgsx_b_gram_pairs_dd(lbfgsx_ctx* c, int mask, int vsel, int prologue, cons
  * two columns, whatever 2c <= 80 is (kernels of csrc/lbfgsb_x.cuh) -- or, with LBFGSX_SPLIT=0, the 64 of the round-3
  * one-entry-per-lane kernel while 2c + 1 <= 31; 0: the call is not available for this history */
 int lbfgsx_b_gram_pairs_max(lbfgsx_ctx* c);
+/* the un-rounded (hi, lo) sums of the v row W_P'v of the one-pass Gram this context ran last (lbfgsx_b_gram_fused_dd with a
+ * vector selector, not a list): out_dd[2 k], [2 k + 1] for column k < 2c.
+ * LBFGSX_E_INVALID when there is none.  BFGSMatB::solve_PtBP keeps W_F'(-c) of a first solve that took the full pass, so
+ * that its sweeps can form W_P' rhs on the host (see lbfgsx_b_solve_sweep_rhs). */
+int lbfgsx_b_gram_last_vrow_dd(lbfgsx_ctx* c, double* out_dd);
 /* refresh_slot >= -1: the caller vouches that since the previous subspace minimisation the history changed in at most the
  * storage slot `refresh_slot` (-1: not at all) and that lbfgsx_b_free_delta has been called for the current free set.  The
  * pass may then read the compact copy of the free rows it KEPT from that minimisation (rows that entered F were appended by

@@ -146,6 +146,7 @@ def load():
     sig(core, "lbfgsx_b_dg_maxstep_trial", i32, vp, i32, dbl, pd, pd)
     sig(core, "lbfgsx_b_solve_sweep_rhs", i32, vp, i32, i32, pd, dbl, pd, pd, pd, C.POINTER(i64 * 7))
     sig(core, "lbfgsx_b_solve_sweep_rhs_ready", i32, vp)
+    sig(core, "lbfgsx_b_gram_last_vrow_dd", i32, vp, pd)
     sig(core, "lbfgsx_b_wtv_lu_c", i32, vp, pd, C.POINTER(i64), pd, C.POINTER(i64), pd)
     sig(core, "lbfgsx_b_trial_ahead_counts", i32, vp, C.POINTER(i64 * 2))
     sig(core, "lbfgsx_comm_info", i32, vp, C.POINTER(i32 * 4))

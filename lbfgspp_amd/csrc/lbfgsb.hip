@@ -103,6 +103,8 @@ struct lbfgsb_state
     // lbfgsx_b_post_linesearch_build: the Cauchy search's element-wise pass, taken by the pass of the post statements
     bool pb_use = true;                   // LBFGSX_POST_BUILD=0: two passes, as rounds 1-3
     bool st_use = true;                   // LBFGSX_TRIAL_AHEAD=0: lbfgsx_b_dg_maxstep_trial never evaluates the first trial ahead
+    double vrow_dd[2 * 80];               // un-rounded (hi, lo) v row of the last full one-pass Gram (lbfgsx_b_gram_last_vrow_dd)
+    bool vrow_dd_valid = false;
     bool rhs_identity = true;             // LBFGSX_RHS_IDENTITY=0: a sweep gets W_P'(-rhs) from a pass over P (kx_rows<NA = 1>), as before
     bool pb_valid = false;                // pb_r holds what k_cauchy_build would deliver for the state described below
     int pb_cur = -1;                      // the iterate buffer the pass read
@@ -3217,6 +3219,7 @@ static int gram_dd_core(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, cons
     if (rc)
         return rc;
     lbfgsb_state* b = c->bstate;
+    b->vrow_dd_valid = false;
     const int tot = 2 * c->ncorr;
     const int ntot = tot + (vsel_id >= 0 ? 1 : 0);
     const bool lu_walk = !list && b->lu_valid && b->lu_use && vsel_id < 0 && prologue == LBFGSX_GP_NONE && mask != 0 &&
@@ -3436,6 +3439,27 @@ static int gram_dd_core(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, cons
             wtv[j] = h[tot * (tot + 1) / 2 + j];
     if (gram_dd)  // packed lower triangle of the 2c x 2c block, e = i (i + 1) / 2 + j: (hi, lo)
         std::memcpy(gram_dd, b->gram_dd_host ? b->gram_dd_host : hdd.data(), sizeof(double) * size_t(tot) * size_t(tot + 1));
+    if (gram_dd && wtv && vsel_id >= 0 && !list)  // the v row of the same tile, un-rounded: entries e = tot (tot + 1) / 2 + j (the integer kernel
+                                                  // leaves its exact sums in the same places)
+    {
+        const double* dd = b->gram_dd_host ? b->gram_dd_host : hdd.data();
+        std::memcpy(b->vrow_dd, dd + size_t(tot) * size_t(tot + 1), sizeof(double) * size_t(2 * tot));
+        b->vrow_dd_valid = true;
+    }
+    return LBFGSX_OK;
+}
+
+int lbfgsx_b_gram_last_vrow_dd(lbfgsx_ctx* c, double* out_dd)
+{
+    if (!c || !c->bstate || !out_dd)
+        return LBFGSX_E_INVALID;
+    lbfgsb_state* b = c->bstate;
+    if (!b->vrow_dd_valid)
+    {
+        set_error("lbfgsx_b_gram_last_vrow_dd: the last Gram pass left no un-rounded v row (no v, a list, or another pass since)");
+        return LBFGSX_E_INVALID;
+    }
+    std::memcpy(out_dd, b->vrow_dd, sizeof(double) * size_t(4 * c->ncorr));
     return LBFGSX_OK;
 }
 
