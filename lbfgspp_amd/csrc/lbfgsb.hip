@@ -157,6 +157,12 @@ struct lbfgsb_state
     long long wf_epoch = -2;              // the one that last wrote or patched the copy
     int* wf_pos = nullptr;                // [n] row -> position, -1: none
     double* g_host = nullptr;             // pinned landing zone of lbfgsx_b_cauchy_chunk
+    // the first chunk of the sorted break points, gathered and copied behind the build's sort and ahead of its W'd pass: it
+    // has landed when that pass's wait returns, and the host search's first lbfgsx_b_cauchy_chunk costs no round trip
+    bool gpre_use = true;                 // LBFGSX_CHUNK_AHEAD=0
+    bool gpre_valid = false;
+    int64_t gpre_count = 0;
+    int gpre_nc = -1;
     size_t g_host_cap = 0;
     // chunk staging for the sequential GCP scan
     double *g_brk = nullptr, *g_g = nullptr, *g_z = nullptr, *g_w = nullptr;
@@ -468,6 +474,8 @@ int bounded_alloc(lbfgsx_ctx* c)
         b->st_use = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_RHS_IDENTITY"))
         b->rhs_identity = atoi(e) != 0;
+    if (const char* e = getenv("LBFGSX_CHUNK_AHEAD"))
+        b->gpre_use = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_SELECT_MAX"))  // candidates of the previous search up to which the build lists them
         b->psel_max = std::max<int64_t>(0, atoll(e));
     if (const char* e = getenv("LBFGSX_SELECT_CAP"))  // test aid: a short list overflows
@@ -1157,6 +1165,8 @@ static int b_eval_t(lbfgsx_ctx* c, OBJ obj, double* r3)
 }  // namespace lbfgsx
 
 static bool psel_alloc(lbfgsx_ctx* c);  // (defined with the partial sort below)
+static int cauchy_chunk_launch(lbfgsx_ctx* c, int64_t first, int64_t count, bool with_w, int* idx, double** land,
+                               std::vector<double>* pageable);  // (with lbfgsx_b_cauchy_chunk below)
 extern "C" {
 
 int lbfgsx_b_eval(lbfgsx_ctx* c, int objective, double* fx, double* projgnorm, double* xnorm2)
@@ -1696,9 +1706,28 @@ int lbfgsx_b_cauchy_build_partial(lbfgsx_ctx* c, double tau, int64_t* nfree, int
         }
         if (wtd && c->ncorr > 0)  // p = W'd raw dots (Cauchy.h:152)
         {
+            // the host search opens with the first 512 sorted break points (Cauchy<Scalar>::Stream): their gather and copy ride
+            // here, behind the sort and ahead of the W'd pass whose wait follows
+            b->gpre_valid = false;
+            if (b->gpre_use && ns >= 1)
+            {
+                double* land = nullptr;
+                const int64_t cnt = std::min<int64_t>(512, ns);
+                if (cauchy_chunk_launch(c, 0, cnt, true, nullptr, &land, nullptr) == LBFGSX_OK)
+                {
+                    b->gpre_valid = true;
+                    b->gpre_count = cnt;
+                    b->gpre_nc = c->ncorr;
+                }
+                else
+                    (void) hipGetLastError();
+            }
             rc = cauchy_wtd<T>(c, wtd);
             if (rc)
+            {
+                b->gpre_valid = false;
                 return rc;
+            }
         }
     });
     b->psel_last = tau_ok ? ns : int64_t(-1);
@@ -1717,6 +1746,7 @@ int lbfgsx_b_cauchy_sort_full(lbfgsx_ctx* c)
     if (rc)
         return rc;
     lbfgsb_state* b = c->bstate;
+    b->gpre_valid = false;
     DISPATCH_T(c, {
         size_t bytes = b->sort_tmp_bytes;
         LBFGSX_HIP(rocprim::radix_sort_pairs(b->sort_tmp, bytes, P<T>(b->keys_in), P<T>(b->keys_out), b->vals_in, b->vals_out,
@@ -1725,16 +1755,13 @@ int lbfgsx_b_cauchy_sort_full(lbfgsx_ctx* c)
     return LBFGSX_OK;
 }
 
-int lbfgsx_b_cauchy_chunk(lbfgsx_ctx* c, int64_t first, int64_t count, double* brk, double* g, double* z, int* idx,
-                          double* wrows)
+}  // extern "C"
+// gather kernel + ONE copy of [brk | g | z | W rows] of sorted positions [first, first + count) into the landing zone `*land`
+// (pinned when it fits, else `pageable`); nothing is waited for
+static int cauchy_chunk_launch(lbfgsx_ctx* c, int64_t first, int64_t count, bool with_w, int* idx, double** land,
+                               std::vector<double>* pageable)
 {
-    lbfgsx::DeviceGuard dev_guard_(c->device);
-    int rc = need_bounded(c);
-    if (rc)
-        return rc;
     lbfgsb_state* b = c->bstate;
-    if (count <= 0)
-        return LBFGSX_OK;
     const int nc = c->ncorr;
     // one packed device buffer [brk | g | z | W rows] of (3 + 2c) * count doubles and ONE copy back (four separate copies
     // were four blit kernels per chunk); the pinned landing zone serves the chunks the host form actually asks for
@@ -1759,7 +1786,7 @@ int lbfgsx_b_cauchy_chunk(lbfgsx_ctx* c, int64_t first, int64_t count, double* b
     double* d_g = d_brk + count;
     double* d_z = d_g + count;
     double* d_w = d_z + count;
-    rc = upload_phys(c);
+    int rc = upload_phys(c);
     if (rc)
         return rc;
     const int grid = int(std::min<int64_t>((count + 255) / 256, 2048));
@@ -1769,7 +1796,7 @@ int lbfgsx_b_cauchy_chunk(lbfgsx_ctx* c, int64_t first, int64_t count, double* b
                            count, P<T>(c->S), P<T>(c->Y), c->ld, b->phys_dev, nc, d_brk, d_g, d_z, b->g_idx, d_w);
     });
     LBFGSX_HIP(hipGetLastError());
-    const size_t ndbl = size_t(count) * ((nc > 0 && wrows) ? per : size_t(3));
+    const size_t ndbl = size_t(count) * ((nc > 0 && with_w) ? per : size_t(3));
     if (ndbl > b->g_host_cap)
     {
         if (b->g_host)
@@ -1783,17 +1810,45 @@ int lbfgsx_b_cauchy_chunk(lbfgsx_ctx* c, int64_t first, int64_t count, double* b
             b->g_host_cap = want;
         }
     }
-    std::vector<double> pageable;
-    double* land = b->g_host;
+    *land = b->g_host;
     if (ndbl > b->g_host_cap)
     {
-        pageable.resize(ndbl);
-        land = pageable.data();
+        if (!pageable)
+            return LBFGSX_E_INVALID;
+        pageable->resize(ndbl);
+        *land = pageable->data();
     }
-    LBFGSX_HIP(lbfgsx::copy_async(land, d_brk, sizeof(double) * ndbl, hipMemcpyDeviceToHost, c->stream));
+    LBFGSX_HIP(lbfgsx::copy_async(*land, d_brk, sizeof(double) * ndbl, hipMemcpyDeviceToHost, c->stream));
     if (idx)
         LBFGSX_HIP(lbfgsx::copy_async(idx, b->g_idx, sizeof(int) * size_t(count), hipMemcpyDeviceToHost, c->stream));
-    LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
+    return LBFGSX_OK;
+}
+extern "C" {
+
+int lbfgsx_b_cauchy_chunk(lbfgsx_ctx* c, int64_t first, int64_t count, double* brk, double* g, double* z, int* idx,
+                          double* wrows)
+{
+    lbfgsx::DeviceGuard dev_guard_(c->device);
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    lbfgsb_state* b = c->bstate;
+    if (count <= 0)
+        return LBFGSX_OK;
+    const int nc = c->ncorr;
+    double* land = nullptr;
+    std::vector<double> pageable;
+    const bool ahead = b->gpre_valid && first == 0 && count == b->gpre_count && nc == b->gpre_nc && !idx && (wrows || nc == 0);
+    b->gpre_valid = false;
+    if (ahead)
+        land = b->g_host;  // launched by the build, landed with the wait of its W'd pass
+    else
+    {
+        rc = cauchy_chunk_launch(c, first, count, wrows != nullptr, idx, &land, &pageable);
+        if (rc)
+            return rc;
+        LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
+    }
     std::memcpy(brk, land, sizeof(double) * size_t(count));
     std::memcpy(g, land + count, sizeof(double) * size_t(count));
     std::memcpy(z, land + 2 * count, sizeof(double) * size_t(count));

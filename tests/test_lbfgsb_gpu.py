@@ -1019,3 +1019,34 @@ def test_sweep_rhs_products_from_held_sums_stay_within_an_ulp_of_the_pass(A, bor
         # f32: a last-bit difference in W_P' rhs may move a line search by an evaluation; the minimiser stays the same
         assert f[5] > 0
         assert np.abs(f[2] - u[2]).max() <= tol
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("n,m,iters", [(70001, 8, 40), (300000, 10, 30), (65536, 20, 40)])
+def test_first_chunk_of_the_break_points_gathered_ahead_changes_no_bit(A, monkeypatch, n, m, iters, dtype):
+    """The host form of the Cauchy search opens with the first 512 sorted break points (Cauchy<Scalar>::Stream).  Their gather
+    and copy ride behind the build's sort, ahead of its W'd pass, and have landed when that pass's wait returns
+    (LBFGSX_CHUNK_AHEAD=0: a round trip of their own, as before).  Same data either way: same trajectory bit for bit, one
+    wait less per iteration."""
+    import ctypes as C
+    core, _ = A.load()
+    dt = O.F64 if dtype == "f64" else O.F32
+    npdt = O.NPDT[dt]
+    a, b = O.quad_problem(n, 30.0, 17, dt)
+    res = {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("LBFGSX_CHUNK_AHEAD", on)
+        cnt0 = (C.c_int64 * 3)()
+        core.lbfgsx_counters(cnt0, 1)
+        s = A.LBFGSBSolver(A.LBFGSBParam(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters), dtype=npdt)
+        tr = A.TraceBuffer(n, cap=512, stride=19)
+        x = np.zeros(n, dtype=npdt)
+        niter, fx = s.minimize(A.DiagQuadratic(a, b), x, (-0.7 * np.ones(n)).astype(npdt), (0.9 * np.ones(n)).astype(npdt), trace=tr)
+        cnt = (C.c_int64 * 3)()
+        core.lbfgsx_counters(cnt, 0)
+        st = s.stats()
+        res[on] = (niter, s.last.nfev, x.copy(), tr.xs[:tr.count].copy(), st["gcp_crossings"], int(cnt[1]))
+    f, u = res["1"], res["0"]
+    assert f[:2] == u[:2] and f[4] == u[4]
+    assert np.array_equal(f[2], u[2]) and np.array_equal(f[3], u[3])
+    assert f[5] <= u[5] - (f[0] - m - 2), (f[5], u[5])   # a stream wait less in (at least) every iteration with a full history
