@@ -160,6 +160,10 @@ struct lbfgsb_state
     // the first chunk of the sorted break points, gathered and copied behind the build's sort and ahead of its W'd pass: it
     // has landed when that pass's wait returns, and the host search's first lbfgsx_b_cauchy_chunk costs no round trip
     bool gpre_use = true;                 // LBFGSX_CHUNK_AHEAD=0
+    // lbfgsx_b_free_delta launched ahead, behind the pass over the newly active rows (LBFGSX_DELTA_AHEAD=0: on request)
+    bool fd_use = true, fd_ahead = false;
+    long long fd_epoch = -1;
+    unsigned* fd_host = nullptr;          // pinned: its four counters
     bool gpre_valid = false;
     int64_t gpre_count = 0;
     int gpre_nc = -1;
@@ -476,6 +480,8 @@ int bounded_alloc(lbfgsx_ctx* c)
         b->rhs_identity = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_CHUNK_AHEAD"))
         b->gpre_use = atoi(e) != 0;
+    if (const char* e = getenv("LBFGSX_DELTA_AHEAD"))
+        b->fd_use = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_SELECT_MAX"))  // candidates of the previous search up to which the build lists them
         b->psel_max = std::max<int64_t>(0, atoll(e));
     if (const char* e = getenv("LBFGSX_SELECT_CAP"))  // test aid: a short list overflows
@@ -567,6 +573,8 @@ void bounded_free(lbfgsx_ctx* c)
         (void) hipHostFree(b->h_chain);
     if (b->g_host)
         (void) hipHostFree(b->g_host);
+    if (b->fd_host)
+        (void) hipHostFree(b->fd_host);
     (void) hipFree(b->lu_list);
     (void) hipFree(b->wf_pos);
     (void) hipFree(b->wtdc_list);
@@ -1165,6 +1173,7 @@ static int b_eval_t(lbfgsx_ctx* c, OBJ obj, double* r3)
 }  // namespace lbfgsx
 
 static bool psel_alloc(lbfgsx_ctx* c);  // (defined with the partial sort below)
+static int free_delta_launch(lbfgsx_ctx* c);  // (with lbfgsx_b_free_delta below)
 static int cauchy_chunk_launch(lbfgsx_ctx* c, int64_t first, int64_t count, bool with_w, int* idx, double** land,
                                std::vector<double>* pageable);  // (with lbfgsx_b_cauchy_chunk below)
 extern "C" {
@@ -2248,6 +2257,14 @@ int lbfgsx_b_wtv(lbfgsx_ctx* c, int vsel_id, int mask, double* out, int64_t* nnz
     {
         lbfgsb_state* b = c->bstate;
         const int total = 2 * c->ncorr;
+        // the free-set delta the carried Gram asks for next needs nothing from the host: it rides ahead of this pass and its
+        // counters are there when this pass's wait returns (contexts that have used the carried form before)
+        b->fd_ahead = false;
+        if (b->fd_use && b->fprev && free_delta_launch(c) == LBFGSX_OK)
+        {
+            b->fd_ahead = true;
+            b->fd_epoch = b->sub_epoch;
+        }
         lbfgsx::poll_arm(c);
         DISPATCH_T(c, {
             rc = xl::list1<T>(c->stream, b->num_cus, colsx_full<T>(c, total), total, bvecs<T>(c), vsel_id, mask, b->na_list, int(na_keep),
@@ -2934,16 +2951,16 @@ static int delta_alloc(lbfgsx_ctx* c)
 }
 }  // namespace lbfgsx
 extern "C" {
-int lbfgsx_b_free_delta(lbfgsx_ctx* c, int64_t* n_enter, int64_t* n_leave)
+}  // extern "C"
+// everything of lbfgsx_b_free_delta up to the copy of its four counters into pinned memory (fd_host); nothing is waited for
+static int free_delta_launch(lbfgsx_ctx* c)
 {
-    lbfgsx::DeviceGuard dev_guard_(c->device);
-    int rc = need_bounded(c);
-    if (rc)
-        return rc;
     lbfgsb_state* b = c->bstate;
-    rc = delta_alloc(c);
+    int rc = delta_alloc(c);
     if (rc)
         return rc;
+    if (!b->fd_host)
+        LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->fd_host), sizeof(unsigned) * 4, hipHostMallocDefault));
     if (b->wf_live && (b->wf_ncorr != c->ncorr || b->wf_epoch + 1 != b->sub_epoch))
         b->wf_live = false;  // the history has grown (another column order), or the copy missed an iteration
     // {rows entered, rows left, rows in the kept compact copy, 1: the copy cannot be kept}
@@ -2977,9 +2994,30 @@ int lbfgsx_b_free_delta(lbfgsx_ctx* c, int64_t* n_enter, int64_t* n_leave)
         });
         LBFGSX_HIP(hipGetLastError());
     }
-    unsigned* h = static_cast<unsigned*>(c->hout);
-    LBFGSX_HIP(lbfgsx::copy_async(h, b->dl_cnt, sizeof(unsigned) * 4, hipMemcpyDeviceToHost, c->stream));
-    LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
+    LBFGSX_HIP(lbfgsx::copy_async(b->fd_host, b->dl_cnt, sizeof(unsigned) * 4, hipMemcpyDeviceToHost, c->stream));
+    return LBFGSX_OK;
+}
+extern "C" {
+
+int lbfgsx_b_free_delta(lbfgsx_ctx* c, int64_t* n_enter, int64_t* n_leave)
+{
+    lbfgsx::DeviceGuard dev_guard_(c->device);
+    int rc = need_bounded(c);
+    if (rc)
+        return rc;
+    lbfgsb_state* b = c->bstate;
+    // launched ahead, behind the pass over the newly active rows (lbfgsx_b_wtv), for this subspace minimisation?  Then its
+    // counters landed with that pass's wait
+    const bool ahead = b->fd_ahead && b->fd_epoch == b->sub_epoch;
+    b->fd_ahead = false;
+    if (!ahead)
+    {
+        rc = free_delta_launch(c);
+        if (rc)
+            return rc;
+        LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
+    }
+    const unsigned* h = b->fd_host;
     for (int d = 0; d < 2; d++)
         b->dl_n[d] = (h[d] <= b->dl_cap) ? int64_t(h[d]) : -1;
     if (b->wf_live)

@@ -1050,3 +1050,35 @@ def test_first_chunk_of_the_break_points_gathered_ahead_changes_no_bit(A, monkey
     assert f[:2] == u[:2] and f[4] == u[4]
     assert np.array_equal(f[2], u[2]) and np.array_equal(f[3], u[3])
     assert f[5] <= u[5] - (f[0] - m - 2), (f[5], u[5])   # a stream wait less in (at least) every iteration with a full history
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("n,m,iters", [(70001, 8, 40), (300000, 10, 30), (65536, 20, 40)])
+def test_free_set_delta_launched_ahead_changes_no_bit(A, monkeypatch, n, m, iters, dtype):
+    """lbfgsx_b_free_delta (the rows that entered / left the free set since the last iteration: what the carried Gram patches
+    its sums with) needs nothing from the host, so it rides ahead of the pass over the newly active rows of the same
+    subspace minimisation and its counters are there when that pass's wait returns (LBFGSX_DELTA_AHEAD=0: launched on
+    request, with a stream wait of its own).  Same kernels on the same state bytes: same trajectory bit for bit, fewer
+    stream waits, and the carried form runs as often."""
+    import ctypes as C
+    core, _ = A.load()
+    dt = O.F64 if dtype == "f64" else O.F32
+    npdt = O.NPDT[dt]
+    a, b = O.quad_problem(n, 30.0, 17, dt)
+    res = {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("LBFGSX_DELTA_AHEAD", on)
+        cnt0 = (C.c_int64 * 3)()
+        core.lbfgsx_counters(cnt0, 1)
+        s = A.LBFGSBSolver(A.LBFGSBParam(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters), dtype=npdt)
+        tr = A.TraceBuffer(n, cap=512, stride=19)
+        x = np.zeros(n, dtype=npdt)
+        niter, fx = s.minimize(A.DiagQuadratic(a, b), x, (-0.7 * np.ones(n)).astype(npdt), (0.9 * np.ones(n)).astype(npdt), trace=tr)
+        cnt = (C.c_int64 * 3)()
+        core.lbfgsx_counters(cnt, 0)
+        st = s.stats()
+        res[on] = (niter, s.last.nfev, x.copy(), tr.xs[:tr.count].copy(), st["gram_carried"], st["submin_sweeps"], int(cnt[1]))
+    f, u = res["1"], res["0"]
+    assert f[:2] == u[:2] and f[4:6] == u[4:6]
+    assert np.array_equal(f[2], u[2]) and np.array_equal(f[3], u[3])
+    assert f[6] < u[6], (f[6], u[6])
