@@ -214,3 +214,32 @@ def test_lockstep_batch_refuses_policies_without_a_state_machine(A):
         B.solve_local_lockstep(par, 1024, 0, 4, linesearch=L.LS_BACKTRACKING)
     with pytest.raises(ValueError, match="objective"):
         B.solve_local_lockstep(par, 1024, 0, 4, objective=7)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_threaded_batch_of_lbfgsb_problems_equals_single_solves_and_is_deterministic(A, dtype):
+    """Batched L-BFGS-B (lbfgsx_batch_minimize with LBFGSX_ALGO_LBFGSB): independent box-constrained problems, each on its own
+    context and stream, `nthreads` of them resident at a time -- while one problem's host algebra or Cauchy chain runs, the
+    others' kernels fill the GPU.  Not a lock-step kernel batch (the reference solves one problem per call, LBFGSB.h:116-262;
+    DESIGN 4c): every problem is the stand-alone solve, so the records are identical whatever the thread count, and equal
+    to LBFGSBSolver::minimize on the same generated instance -- with every per-context mechanism of the bounded path
+    (kept compact copy, carried Gram, the passes launched ahead) running concurrently in several contexts."""
+    from lbfgspp_amd import batched as B
+    from lbfgspp_amd import _lib as L
+    core, _ = A.load()
+    n, m, iters, count, first, seed = 60000, 8, 25, 10, 3, 700
+    par = A.LBFGSBParam(m=m, epsilon=0.0, epsilon_rel=0.0, past=0, max_iterations=iters)
+    r1 = B.solve_local(par, A.DiagQuadratic.objective, n, first, count, seed_base=seed, algo=L.ALGO_LBFGSB, dtype=dtype, nthreads=1)
+    r6 = B.solve_local(par, A.DiagQuadratic.objective, n, first, count, seed_base=seed, algo=L.ALGO_LBFGSB, dtype=dtype, nthreads=6)
+    assert np.array_equal(r1, r6)
+    assert (r1["status"] == 0).all() and (r1["niter"] == iters).all()
+    s = A.LBFGSBSolver(par, dtype=dtype)
+    for k in (0, 4, 9):
+        ctx = s.prepare(n)
+        L.check(core.lbfgsx_gen_diag_quad(ctx, 10.0, seed + first + k))
+        L.check(core.lbfgsx_fill(ctx, L.VEC_X, 0.0))
+        L.check(core.lbfgsx_fill(ctx, L.VEC_LB, -1.0))
+        L.check(core.lbfgsx_fill(ctx, L.VEC_UB, 1.0))
+        niter, fx = s.minimize_resident(A.DiagQuadratic(), n)
+        assert (r1["niter"][k], r1["nfev"][k]) == (niter, s.last.nfev) and r1["fx"][k] == fx
+    s.close()
