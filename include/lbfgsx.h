@@ -283,11 +283,10 @@ int lbfgsx_b_sub_begin(lbfgsx_ctx* c);
 int lbfgsx_b_wtv(lbfgsx_ctx* c, int vsel, int mask, double* out, int64_t* nnz);
 /* masked Gram of [Y_P, S_P] (2c x 2c, row-major, symmetric) for solve_PtBP (BFGSMat.h:543-556) */
 int lbfgsx_b_gram(lbfgsx_ctx* c, int mask, double* gram);
-/* the same Gram plus W_P'v (v = on-the-fly vector `vsel`, or -1) in ONE pass on the matrix cores
- * (v_mfma_f64_16x16x4_f64 over LDS-staged slabs, ~9x faster than the tiled VALU Gram).  Entries are accurate to
- * about 1 ulp but not correctly rounded, which ill-conditioned subspace systems amplify beyond the 1e-10
- * iterate-parity contract, so the path is opt-in: environment LBFGSX_GRAM=mfma at context creation.  Returns
- * LBFGSX_E_INVALID when not enabled or 2c+1 > 32 -- callers then use lbfgsx_b_gram + lbfgsx_b_wtv. */
+/* the same Gram plus W_P'v (v = on-the-fly vector `vsel`, or -1) in ONE pass over the 2c columns: correctly rounded
+ * double-double sums (the default kernels), or the exact integer-MFMA form with LBFGSX_GRAM=i8.  (Rounds 1-3 had a plain
+ * f64 MFMA form behind this entry, LBFGSX_GRAM=mfma: ~1 ulp per entry, not exact, removed in round 4.)  Returns
+ * LBFGSX_E_INVALID when the one-pass form does not apply -- callers then use lbfgsx_b_gram + lbfgsx_b_wtv. */
 int lbfgsx_b_gram_fused(lbfgsx_ctx* c, int mask, int vsel, double* gram, double* wtv);
 /* The same with the combine statement that produces v fused in as a prologue (one pass instead of two or three):
  *   LBFGSX_GP_RHS     rhs = (rhs + -(W_mask coef1)) + -(W_mask coef2), then v = -rhs   (two apply_PtBQv, BFGSMat.h:570-594;

@@ -2435,9 +2435,8 @@ int lbfgsx_b_gram(lbfgsx_ctx* c, int mask, double* gram)
 }
 
 // Gram of [Y_P S_P v_P] in ONE pass over the history; gram = 2c x 2c row-major, wtv = [Y'v, S'v] raw.
-// Default: k_gram_dd (correctly rounded double-double sums, 2c+1 <= 31).  LBFGSX_GRAM=mfma selects the matrix-core
-// kernel (~1 ulp per entry, 2c+1 <= 32).  Returns LBFGSX_E_INVALID (outputs untouched) when neither applies; the
-// caller then falls back to lbfgsx_b_gram + lbfgsx_b_wtv.
+// k_gram_dd (correctly rounded double-double sums, 2c+1 <= 31), kx_gram beyond; LBFGSX_GRAM=i8 the exact integer-MFMA form.
+// Returns LBFGSX_E_INVALID (outputs untouched) when none applies; the caller then falls back to lbfgsx_b_gram + lbfgsx_b_wtv.
 }  // extern "C"
 namespace lbfgsx {
 int bounded_note_column(lbfgsx_ctx* c, int col)

@@ -765,8 +765,8 @@ static int apply_Hv_t(lbfgsx_ctx* c, const T* v, T a, double* dg)
         pa.zigzag = c->zigzag ? 1 : 0;
         pa.first_rev = c->tl_step;
         pa.ld = c->ld;
-        // the word the blocks meet at: a generation number (+1 per meeting point), or -- LBFGSX_MEET=all, the default -- a
-        // count of arrivals (+ grid per meeting point)
+        // one generation number per meeting point: the word the blocks wait for (LBFGSX_MEET=last) or the tag of the
+        // 16-byte words they exchange (the default)
         c->gen_count += unsigned(2 * cn + 1);
         c->tl_step += unsigned(2 * cn + 1);
         // A plain launch of exactly occupancy * CUs blocks.  No other persistent kernel of this process is in flight on
