@@ -433,20 +433,20 @@ def run_cfg4(args, rank, world, local, comm_dev, dist, iters=40, m=10):
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
-    cnt = (C.c_int64 * 3)()
+    cnt = (C.c_int64 * 8)()
     snaps = []  # (time, solver statistics, library counters) at the end of every iteration
 
     def hook(k):
         t = time.perf_counter()
-        core.lbfgsx_counters(C.byref(cnt), 0)
-        snaps.append((t, s.stats(), (cnt[0], cnt[1], cnt[2])))
+        core.lbfgsx_counters_ex(C.byref(cnt), 0)
+        snaps.append((t, s.stats(), tuple(cnt[i] for i in range(6))))
     s.set_iteration_hook(hook)
     barrier()
-    core.lbfgsx_counters(None, 1)
+    core.lbfgsx_counters_ex(None, 1)
     t0 = time.perf_counter()
     niter, fx = s.minimize_resident(A.DiagQuadratic(), n)
     t1 = time.perf_counter()
-    core.lbfgsx_counters(C.byref(cnt), 0)
+    core.lbfgsx_counters_ex(C.byref(cnt), 0)
     barrier()
     st = s.stats()
     nfev = s.last.nfev
@@ -454,7 +454,9 @@ def run_cfg4(args, rank, world, local, comm_dev, dist, iters=40, m=10):
     stamps = [v[0] for v in snaps]
     per = np.diff(np.array([t0] + stamps))
     # steady window: iterations w0+1 .. len(snaps) (the hook does not fire after the last iteration, which ends the run)
-    w0 = len(snaps) // 2
+    if len(snaps) < 2:
+        raise SystemExit("bench.py: the cfg4 leg needs at least 3 iterations (--cfg4-iters)")
+    w0 = max(1, len(snaps) // 2)
     win = per[w0:]
     total, steady_ms, steady_med_ms = t1 - t0, float(win.mean()) * 1e3, float(np.median(win)) * 1e3
     first_ms = float(per[0]) * 1e3
@@ -486,7 +488,16 @@ def run_cfg4(args, rank, world, local, comm_dev, dist, iters=40, m=10):
     n_ord, n_sorted = st["gcp_nord"] / searches, st["gcp_sorted"] / searches
     bytes_it = bytes_per_iteration(q, n_sorted)
     steady = 1e3 / steady_ms
-    ach_steady, ach_x0 = bytes_w * steady / 1e9, bytes_it * (niter / total) / 1e9
+    # The byte model of the path AS BUILT (lbfgsx_counters_ex): every launch adds what its pass has to
+    # move for the rows and columns it was launched over -- the compact copy holds the free rows only, a carried Gram and a
+    # sweep's W_P'rhs from held sums need no pass, so this is well below the reference's statement count above.  The
+    # roofline fraction is model bytes of the window / wall time of the window / peak: at most 1 by construction.
+    model_w = (b_c[3] - a_c[3]) / max(1, nwin)
+    model_x0 = cnt[3] / max(1, niter)
+    passes_w = (b_c[4] - a_c[4]) / max(1, nwin)
+    n_free_w = (b_c[5] - a_c[5]) / max(1, b_c[4] - a_c[4])
+    ach_steady, ach_x0 = model_w * steady / 1e9, model_x0 * (niter / total) / 1e9
+    ref_steady, ref_x0 = bytes_w * steady / 1e9, bytes_it * (niter / total) / 1e9
     tr = leg_traffic("cfg4", n, m)
     return {
         "metric": "L-BFGS-B iterations/sec at n=%d, m=%d (box-constrained diag quadratic); steady state" % (n, m),
@@ -513,26 +524,31 @@ def run_cfg4(args, rank, world, local, comm_dev, dist, iters=40, m=10):
                    "submin_calls_total": st["submin_calls"], "submin_sweeps_total": st["submin_sweeps"],
                    "gram_carried_total": st["gram_carried"], "rhs_identities": d("rhs_identities"),
                    "rhs_identities_total": st.get("rhs_identities"),
+                   "n_free": n_free_w, "compact_passes_per_iteration": passes_w,
                    "launches_per_iteration": (b_c[0] - a_c[0]) / max(1, nwin),
                    "host_syncs_per_iteration": (b_c[1] - a_c[1]) / max(1, nwin),
                    "copies_per_iteration": (b_c[2] - a_c[2]) / max(1, nwin),
                    "per_iteration_ms": [round(float(v) * 1e3, 3) for v in per],
                    "phase_ms_per_iteration": {"cauchy": d("gcp_total_us") / 1e3 / max(1, nwin), "subspace": d("submin_us") / 1e3 / max(1, nwin),
                                               "linesearch": d("linesearch_us") / 1e3 / max(1, nwin)}},
-        "roofline": dict({"bound": "hbm", "kernel": "whole L-BFGS-B iteration (masked W'v / Gram / solve-sweep passes over the compact "
-                                               "copy of the free rows dominate; no single kernel holds more than a fifth of the time)",
+        "roofline": dict({"bound": "hbm", "kernel": "whole L-BFGS-B iteration (passes over the compact copy of the free rows dominate; no "
+                                               "single kernel holds more than a fifth of the time)",
                      "achieved": ach_steady, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_steady / HBM_PEAK_GBS,
                      "achieved_from_x0": ach_x0, "frac_from_x0": ach_x0 / HBM_PEAK_GBS,
-                     "algorithmic_bytes": bytes_w, "algorithmic_bytes_from_x0": bytes_it,
-                     # what the counters saw (static, from the committed PMC summary of this leg): the compact copy holds only
-                     # the free rows (about half of n here) and a sweep's W_P' rhs needs no pass, so the path moves FEWER bytes
-                     # than the reference's statement count above -- `frac` (algorithmic bytes / time / peak) may then exceed 1;
-                     # traffic_GBs / traffic_frac are the honest occupancy of the memory system
+                     "model_bytes": model_w, "model_bytes_from_x0": model_x0,
+                     # SURVEY 8(d)'s count of the reference's statements, kept for comparison only: the path as built moves
+                     # fewer bytes than that, so "statement bytes / time" is not a fraction of anything (it exceeds the peak)
+                     "reference_statement_bytes": bytes_w, "reference_statement_bytes_from_x0": bytes_it,
+                     "reference_statement_GBs": ref_steady, "reference_statement_GBs_from_x0": ref_x0,
+                     # what the counters saw (static, from the committed PMC summary of this leg)
                      "traffic_GBs": (tr["hbm_bytes"] * steady / 1e9) if tr else None,
                      "traffic_frac": (tr["hbm_bytes"] * steady / 1e9 / HBM_PEAK_GBS) if tr else None,
-                     "note": "SURVEY 8(d): [(4m+19) + (q+1)(4m+1)] n sizeof(T) + 96 B per sorted break point, per iteration, "
-                             "divided by the wall time of an iteration (host control flow included); bytes and time of the "
-                             "steady figure both from the second half of the run, of the from-x0 figure both from the whole run"},
+                     "model_over_traffic": (model_w / tr["hbm_bytes"]) if tr else None,
+                     "note": "achieved = bytes the launches of the window had to move (lbfgsx_counters_ex: columns x rows of the compact "
+                             "copy + the vectors each pass reads / writes per row, gathers at 64 B sectors; DESIGN.md section 5) / wall "
+                             "time of the same iterations (host control flow included); the steady figure from the second half "
+                             "of the run, the from-x0 figure from the whole run; no full Gram pass falls into the steady "
+                             "window (the carried Gram refreshes every 256 iterations)"},
                      **traffic_fields(tr))}
 
 
@@ -998,6 +1014,77 @@ def run_all(args, rank, world, local, comm_dev, dist, batched=True):
     return out
 
 
+# Keys that only the --verbose line carries: paragraph-long explanations and per-iteration lists.  The driver keeps the last
+# 8 KB of the one JSON line; the default line is held under 7 KB and ends with `legs_digest`, so that every leg's figures are
+# in whatever tail survives.
+VERBOSE_ONLY = ("note", "per_iteration_ms", "traffic_source", "traffic_per", "achieved_is", "instance", "how")
+FULL_PRECISION = ("fx", "value", "ms_per_step", "max_abs_dx", "fx_rel", "seconds")
+
+
+def compact_line(o, key=None, depth=0):
+    """The default line: explanations dropped below the top level (the headline's own stay), strings cut at 200 characters,
+    floats to 7 significant digits except the ones compared digit by digit (FULL_PRECISION)."""
+    if isinstance(o, dict):
+        return {k: compact_line(v, k, depth + 1) for k, v in o.items() if not (depth >= 1 and k in VERBOSE_ONLY)}
+    if isinstance(o, list):
+        return [compact_line(v, key, depth + 1) for v in o]
+    if isinstance(o, float) and key not in FULL_PRECISION:
+        return float("%.7g" % o)
+    if isinstance(o, str) and len(o) > 160 and depth > 1:
+        return o[:157] + "..."
+    return o
+
+
+LEG_KEEP = {
+    "": ("value", "unit", "steps", "warmup", "ms_per_step", "value_median", "dtype", "from_x0", "config", "roofline"),
+    "config": ("workload", "n", "m", "q", "n_free", "n_ord", "window", "iterations", "fevals_total", "fx", "history_full",
+               "problems_total", "failed", "host_syncs_per_iteration", "launches_per_iteration", "compact_passes_per_iteration"),
+    "roofline": ("bound", "achieved", "peak", "unit", "frac", "frac_from_x0", "traffic", "traffic_frac", "traffic_GBs",
+                 "model_bytes", "model_bytes_from_x0", "reference_statement_bytes", "avg_launch_ms", "hbm_model_GBs",
+                 "algorithmic_GBs", "frac_of_stream_copy"),
+    "from_x0": ("value", "first_iteration_ms", "host_syncs_per_iteration", "q"),
+}
+
+
+def compact_leg(leg):
+    """A leg of the default line: the figures and what is needed to recompute them; everything else is --verbose."""
+    if not isinstance(leg, dict):
+        return leg
+    out = {}
+    for k in LEG_KEEP[""]:
+        if k not in leg:
+            continue
+        v = leg[k]
+        if k in LEG_KEEP and isinstance(v, dict):
+            v = {kk: v[kk] for kk in LEG_KEEP[k] if kk in v}
+            if isinstance(v.get("workload"), str) and len(v["workload"]) > 120:
+                v["workload"] = v["workload"][:117] + "..."
+        out[k] = v
+    return out
+
+
+LEGS = ("cfg2", "cfg3", "cfg4_lbfgsb", "cfg4_m20", "cfg5_batched")
+
+
+def legs_digest(out):
+    """{leg: value, ms_per_step, roofline fractions} -- the LAST key of the line."""
+    dig = {}
+    for name in ("north_star", "cfg2", "cfg3", "cfg4_lbfgsb", "cfg4_m20", "cfg5_batched"):
+        leg = out if name == "north_star" else out.get(name)
+        if not isinstance(leg, dict) or "value" not in leg:
+            continue
+        r = leg.get("roofline") or {}
+        e = {"value": float("%.6g" % leg["value"]), "unit": leg.get("unit"), "ms_per_step": float("%.6g" % leg["ms_per_step"]),
+             "frac": None if r.get("frac") is None else float("%.4g" % r["frac"])}
+        if r.get("traffic_frac") is not None:
+            e["traffic_frac"] = float("%.4g" % r["traffic_frac"])
+        if isinstance(leg.get("from_x0"), dict):
+            e["from_x0"] = float("%.6g" % leg["from_x0"]["value"])
+            e["frac_from_x0"] = None if r.get("frac_from_x0") is None else float("%.4g" % r["frac_from_x0"])
+        dig[name] = e
+    return dig
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None,
@@ -1029,6 +1116,9 @@ def main():
     ap.add_argument("--single-process", action="store_true",
                     help="--gpus N from ONE process: one host thread + one context per GPU, the batch through "
                          "lbfgsx_batch_minimize_lockstep_multi and its record gather natively over RCCL")
+    ap.add_argument("--verbose", action="store_true",
+                    help="the full line (~15 KB: explanatory notes, per-iteration times); the default line drops them (< 7 KB)")
+    ap.add_argument("--full-json", default=None, help="also write the full (verbose) object to this file")
     ap.add_argument("--no-legs", action="store_true", help="skip the cfg2 / cfg3 / cfg4 legs of the default line")
     ap.add_argument("--cfg4-n", type=float, default=1e7, help="problem size of the L-BFGS-B leg (cfg4)")
     ap.add_argument("--cfg4-iters", type=int, default=40, help="iterations from x0 of the L-BFGS-B leg (cfg4)")
@@ -1067,7 +1157,22 @@ def main():
         out = run_all(args, rank, world, local, comm_dev, dist)
     if rank == 0:
         sys.stdout.flush()
-        os.write(result_fd, (json.dumps(out) + "\n").encode())
+        if args.full_json:
+            with open(args.full_json, "w") as f:
+                json.dump(out, f, indent=1)
+        if args.verbose:
+            line = out
+        else:
+            line = dict(out)
+            for name in LEGS:
+                if name in line:
+                    line[name] = compact_leg(line[name])
+            if isinstance(line.get("cpu_baseline_sample"), dict):  # the scaled small-n sample beside the measured full-size one
+                line["cpu_baseline_sample"] = {k: line["cpu_baseline_sample"].get(k) for k in ("value", "unit", "cores", "kind")}
+            line = compact_line(line)
+        line.pop("legs_digest", None)
+        line["legs_digest"] = legs_digest(out)  # last key: survives a tail cut
+        os.write(result_fd, (json.dumps(line) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

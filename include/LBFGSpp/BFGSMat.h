@@ -33,6 +33,12 @@ class BFGSMatB
     Scalar m_pend_sy = Scalar(0);
     lbfgsx_ctx* m_c = nullptr;
     mutable std::vector<Scalar> m_pad;  // scratch of apply_Mv
+    // scratch of solve_PtBP / Mv_scaled, kept between calls: the host runs these between a wait and the next launch, and a
+    // fresh std::vector for every temporary of every call (the 2c x 2c Gram, its double-double copy, the middle matrix, its
+    // factorisation's lists) was a dozen allocations per solve
+    mutable std::vector<double> m_G, m_cdd, m_coef;
+    mutable std::vector<Scalar> m_mid, m_WPv, m_mv;
+    mutable BKLDLT<Scalar> m_midsolver;
     // Un-rounded (double-double) W_F'W_F of the subspace problem in progress, kept by the first solve_PtBP of
     // subspace_minimize: a BOXCQP sweep then gets W_P'W_P = W_F'W_F - W_{L u U}'W_{L u U} from a Gram over the few
     // rows of L u U instead of the ~n/2 rows of P (both sums carry ~100 bits, the difference rounds like the direct sum)
@@ -424,7 +430,7 @@ public:
     // M*v with the theta scaling of the S half that precedes a W_P * (.) product (:446,475,591,612)
     void Mv_scaled(const std::vector<Scalar>& v, std::vector<double>& coef) const
     {
-        std::vector<Scalar> r;
+        std::vector<Scalar>& r = m_mv;
         apply_Mv(v, r);
         coef.assign(size_t(2 * m_ncorr), 0.0);
         for (int j = 0; j < m_ncorr; j++)
@@ -456,6 +462,11 @@ public:
         // `sweep` (optional, 7 sums): let the pass that writes y also run the statements of the sweep that follows on the
         // rows it writes (lbfgsx_b_solve_sweep); *swept tells whether it did
         bool rhs_in_sweep = false;  // the rhs updates of the prologue are left to the solve's own pass (see m_vF_dd)
+        // W_{L u U}'(-c) belongs to the partition of the sweep whose Wtv_lu produced it: only the solve that follows that call
+        // may use it.  (Left set, a later sweep with an empty L or U -- which takes the PtBQv path and never calls Wtv_lu --
+        // would have combined the old partition's sums with the new partition's Gram.)
+        const bool luc_fresh = m_luc_valid;
+        m_luc_valid = false;
         auto finish = [&](const double* coef) {
             double raw[80];
             if (rhs_in_sweep)  // the conditions were checked when the identity was chosen: no other way on from here
@@ -510,7 +521,8 @@ public:
             return;
         }
         const int c = m_ncorr, t = 2 * c;
-        std::vector<double> G(size_t(t) * size_t(t), 0.0);
+        std::vector<double>& G = m_G;
+        G.assign(size_t(t) * size_t(t), 0.0);
         double raw[80];
         bool fused = false;
         if (comp_mask && ncomp >= 0 && ncomp * 8 < nP && m_GF_valid && m_GF_dd.size() == size_t(t) * size_t(t + 1) &&
@@ -518,11 +530,12 @@ public:
         {
             // complement identity: Gram over the rows of F \ mask first (it has no side effects), then the v row with
             // the prologue
-            std::vector<double> cdd(size_t(t) * size_t(t + 1), 0.0);
+            std::vector<double>& cdd = m_cdd;
+            cdd.assign(size_t(t) * size_t(t + 1), 0.0);
             const bool ok = (ncomp == 0) || lbfgsx_b_gram_fused_dd(m_c, comp_mask, -1, LBFGSX_GP_NONE, nullptr, nullptr,
                                                                     nullptr, nullptr, cdd.data()) == LBFGSX_OK;
             const bool ident = ok && ncomp > 0 && prologue == LBFGSX_GP_RHS && vsel == LBFGSX_VS_NEG_RHS && (coef1 || coef2) &&
-                               m_vF_valid && m_luc_valid && m_vF_dd.size() == size_t(2 * t) && m_luc_dd.size() == size_t(2 * t) &&
+                               m_vF_valid && luc_fresh && m_vF_dd.size() == size_t(2 * t) && m_luc_dd.size() == size_t(2 * t) &&
                                sweep && swept && !sweep_first && mask == LBFGSX_ST_P && Fy && fy_mask == LBFGSX_ST_FREE &&
                                lbfgsx_b_solve_sweep_rhs_ready(m_c) == 1;
             if (ident)
@@ -564,7 +577,6 @@ public:
                     raw[i] = double(Scalar(h + l));
                 }
                 rhs_in_sweep = true;
-                m_luc_valid = false;
                 m_rhs_identities++;
             }
             if (ident || (ok && lbfgsx_b_wtv_prologue(m_c, mask, vsel, prologue, coef1, coef2, raw) == LBFGSX_OK))
@@ -610,12 +622,13 @@ public:
         if (!fused && prologue != LBFGSX_GP_NONE)
         {
             prologue_unfused();
-            fused = (lbfgsx_b_gram_fused(m_c, mask, vsel, G.data(), raw) == LBFGSX_OK);  // e.g. the MFMA kernel
+            fused = (lbfgsx_b_gram_fused(m_c, mask, vsel, G.data(), raw) == LBFGSX_OK);  // e.g. the exact i8 kernel
         }
         if (!fused)
             detail::check(lbfgsx_b_gram(m_c, mask, G.data()));
         auto Gm = [&](int i, int j) { return Scalar(G[size_t(i) * size_t(t) + size_t(j)]); };
-        std::vector<Scalar> mid(size_t(t) * size_t(t), Scalar(0));
+        std::vector<Scalar>& mid = m_mid;
+        mid.assign(size_t(t) * size_t(t), Scalar(0));
         auto Mid = [&](int i, int j) -> Scalar& { return mid[size_t(j) * size_t(t) + size_t(i)]; };
         for (int j = 0; j < c; j++)
             for (int i = j; i < c; i++)
@@ -626,8 +639,9 @@ public:
         for (int j = 0; j < c; j++)
             for (int i = j; i < c; i++)
                 Mid(c + i, c + j) = m_theta * (Minv(m_m + i, m_m + j) - Gm(c + i, c + j));  // (:552-556)
-        BKLDLT<Scalar> midsolver(mid.data(), t, t);
-        std::vector<Scalar> WPv;
+        BKLDLT<Scalar>& midsolver = m_midsolver;
+        midsolver.compute(mid.data(), t, t);
+        std::vector<Scalar>& WPv = m_WPv;
         if (fused)                            // WP'v ; tail *= theta        (:560-561)
         {
             WPv.assign(size_t(t), Scalar(0));
@@ -640,7 +654,8 @@ public:
         else
             Wtv(vsel, mask, false, WPv);
         midsolver.solve_inplace(WPv.data());
-        std::vector<double> coef(static_cast<size_t>(t));
+        std::vector<double>& coef = m_coef;
+        coef.resize(static_cast<size_t>(t));
         for (int j = 0; j < c; j++)
         {
             coef[size_t(j)] = double(WPv[size_t(j)]);

@@ -69,6 +69,7 @@ class BKLDLT
     // skipping exact zeros leaves every result bit unchanged (x - 0*v == x, and a zero product adds nothing
     // to the accumulator) and makes the per-break-point solve of the GCP scan O(c^2) instead of O(m^2).
     std::vector<std::vector<int> > m_nz;
+    std::vector<Scalar> m_x0, m_x1;  // scratch of eliminate_2x2
     bool m_computed = false;
     int m_info = NOT_COMPUTED;
 
@@ -200,7 +201,9 @@ class BKLDLT
         const int ld = m_n - k - 2;
         Scalar* l1 = &at(k + 2, k);
         Scalar* l2 = &at(k + 2, k + 1);
-        std::vector<Scalar> x0(size_t(ld > 0 ? ld : 0)), x1(size_t(ld > 0 ? ld : 0));
+        std::vector<Scalar>&x0 = m_x0, &x1 = m_x1;   // scratch kept between factorisations (no allocation per 2x2 pivot)
+        x0.resize(size_t(ld > 0 ? ld : 0));
+        x1.resize(size_t(ld > 0 ? ld : 0));
         for (int i = 0; i < ld; i++)
             x0[size_t(i)] = l1[i] * e11 + l2[i] * e21;
         for (int i = 0; i < ld; i++)
@@ -275,7 +278,9 @@ public:
             if (p != i)
                 m_swaps.push_back(std::make_pair(i, p));
         }
-        m_nz.assign(size_t(n), std::vector<int>());
+        m_nz.resize(size_t(n));   // the lists keep their capacity: a solver object that factorises once per solve allocates nothing
+        for (int j = 0; j < n; j++)
+            m_nz[size_t(j)].clear();
         for (int j = 0; j < n; j++)
             for (int t = j + 1; t < n; t++)
                 if (at(t, j) != Scalar(0))

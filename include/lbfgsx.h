@@ -155,6 +155,12 @@ int lbfgsx_debug_persist_fault(lbfgsx_ctx* c);
 /* instrumentation, process-wide: {kernel launches, stream synchronisations, asynchronous copies} issued by the library
  * since load (or the last call with reset != 0).  bench.py divides them by the iterations of its L-BFGS-B leg. */
 int lbfgsx_counters(int64_t out[3], int reset);
+/* the same three and the byte model of the L-BFGS-B path as built: out[3] = bytes the launches of the path had to move for
+ * the rows and columns they were launched over (columns x rows of the compact copy of the free rows + the vectors each
+ * pass reads and writes per row, gathers at 64-byte sectors; DESIGN.md section 5 lists the per-kernel terms), out[4] =
+ * passes over the compact copy, out[5] = rows those passes walked, out[6..7] = 0.  bench.py's cfg4 roofline fraction is
+ * out[3] of its window / time / HBM peak.  No reference counterpart (instrumentation). */
+int lbfgsx_counters_ex(int64_t out[8], int reset);
 /* Polled completion (contexts with mapped outputs, i.e. L-BFGS-B ones; LBFGSX_POLL=0 switches it off): the last block of a
  * kernel whose results the host reads next stores a sequence number in host-mapped memory after the results, and the host
  * polls that word instead of waiting for the stream (which returns ~9 us after the kernel's end).  out = {waits served by

@@ -118,6 +118,7 @@ def load():
     sig(core, "lbfgsx_device_free", None, i32, vp)
     sig(core, "lbfgsx_spec_counts", i32, vp, C.POINTER(i64 * 3))
     sig(core, "lbfgsx_counters", i32, C.POINTER(i64 * 3), i32)
+    sig(core, "lbfgsx_counters_ex", i32, C.POINTER(i64 * 8), i32)
     sig(core, "lbfgsx_poll_counts", i32, vp, C.POINTER(i64 * 2))
     sig(core, "lbfgsx_b_compact_vec_counts", i32, C.POINTER(i64 * 4), i32)
     sig(core, "lbfgsx_b_reserve", i32, vp)

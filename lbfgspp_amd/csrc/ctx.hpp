@@ -32,8 +32,27 @@ void set_error(const std::string& msg);
 struct Counters
 {
     std::atomic<int64_t> launches{0}, syncs{0}, copies{0};
+    // Byte model of the L-BFGS-B path AS BUILT (lbfgsx_counters_ex): every launch of the path adds the
+    // bytes its pass must move for the rows and columns it was launched over -- columns x rows of the (compact) copy, the
+    // vectors it reads and writes per row, gathers at sector granularity -- so that bench.py's roofline fraction of the
+    // cfg4 legs is "what this design has to move" / time / peak, at most 1 by construction.  compact_passes / compact_rows:
+    // passes over the compact copy of the free rows and the rows they walked.
+    std::atomic<int64_t> model_bytes{0}, compact_passes{0}, compact_rows{0};
 };
 Counters& counters();  // lbfgsx.hip
+inline void model_add(double bytes) { counters().model_bytes.fetch_add(int64_t(bytes), std::memory_order_relaxed); }
+inline void model_compact_pass(int64_t rows)
+{
+    counters().compact_passes.fetch_add(1, std::memory_order_relaxed);
+    counters().compact_rows.fetch_add(rows, std::memory_order_relaxed);
+}
+// a vector of `rows` elements of `esz` bytes gathered out of `span` rows through an index list: whole 64-byte sectors move,
+// so a list that touches more than one row in eight costs the full span
+inline double model_gather(int64_t rows, int64_t span, int esz)
+{
+    const double sect = double(rows) * 64.0, full = double(span) * esz;
+    return sect < full ? sect : full;
+}
 // Host-side timeline (LBFGSX_HOST_TRACE=<file>): one line "<ns> <tag>" per launch (tag = the kernel expression), copy
 // and synchronisation (">sync" when the wait starts, "<sync" when it returns), written when the process ends.  What
 // scripts/host_trace.py turns into "host time between a wait and the next launch".  Off: one relaxed load per event.
@@ -164,7 +183,7 @@ struct lbfgsx_ctx
     unsigned long long* done_host = nullptr;
     unsigned long long* done_dev = nullptr;
     unsigned long long done_seq = 0;
-    long long poll_waits = 0, poll_timeouts = 0;
+    long long poll_waits = 0, poll_timeouts = 0, poll_lost = 0;  // lost: the word was still unset after the stream had drained
     bool poll_pending = false;  // poll_arm ran and no wait has consumed it yet
     bool poll_off = false;      // two waits timed out: this context waits for its stream from now on
     int grid_cap = 1024;     // blocks per launch of the streaming kernels (4 per CU; tuned on MI355X, see profiles/)
@@ -292,12 +311,15 @@ inline hipError_t poll_wait(lbfgsx_ctx* c)
         if ((spin & 1023u) == 1023u &&
             std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.05)
         {
-            // the word did not arrive: the kernel's system-scope store is not visible while the kernel runs (memory that is
-            // not fine-grained), or the kernel never signals.  Either way polling only burns 50 ms per wait: after the second
-            // miss this context waits for its stream like everybody else (visible in lbfgsx_poll_counts)
-            if (++c->poll_timeouts >= 2)
-                c->poll_off = true;
+            // 50 ms without the word: wait for the stream.  A long wait is legitimate (a pass over 1e8 rows queued behind a
+            // full radix sort, contexts sharing the GPU): it is counted but changes nothing.  Only a word that is STILL unset
+            // once the stream has drained -- the kernel never signals, or its system-scope store does not reach this
+            // mapping -- says that polling cannot work here; after the second such miss this context waits for its
+            // stream like everybody else (visible in lbfgsx_poll_counts).
+            c->poll_timeouts++;
             const hipError_t e = hipStreamSynchronize(c->stream);
+            if (e == hipSuccess && *w < want && ++c->poll_lost >= 2)
+                c->poll_off = true;
             if (tr)
                 host_trace("<sync");
             return e;

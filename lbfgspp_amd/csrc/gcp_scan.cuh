@@ -105,26 +105,67 @@ __device__ __forceinline__ void gcp_load_w(const GcpBufs& b, int64_t k, int64_t 
     }
 }
 
+// ---- the same scans, one component at a time (round 5).  block_scan<NCOMP> keeps three NCOMP-element arrays per thread (values,
+// exclusive prefixes, totals) on top of the kernels' own w / p / increment vectors: five to seven 2c-element arrays, i.e.
+// 400-1100 VGPRs for 2c = 40..80 -- the kernels of the long histories ran out of scratch memory (k_gcp_b3c1<80>: 1.9 KB per
+// lane).  The scans of different components are independent, so a component's in-wave scan can run as soon as its value
+// exists and only what a later statement reads is kept.  Same operations in the same order per component (Hillis-Steele in
+// the wave, the four wave totals left to right): bit-identical to block_scan.
+__device__ __forceinline__ double wave_scan_x(double x, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1)
+    {
+        const double y = __shfl_up(x, off, 64);
+        if (lane >= off)
+            x = x + y;
+    }
+    return x;
+}
+// what block_scan adds to the wave-level results of wave wv, and the block total, from the four wave totals in lds[4]
+__device__ __forceinline__ void wave_prefix_x(const double* lds4, int wv, double& add, double& run)
+{
+    add = 0.0;
+    run = 0.0;
+#pragma unroll
+    for (int w = 0; w < 4; w++)
+    {
+        if (w == wv)
+            add = run;
+        run = run + lds4[w];
+    }
+}
+// w_k component j (scaled), zero outside the chunk / beyond 2c
+__device__ __forceinline__ double gcp_w1(const GcpBufs& b, int64_t k, bool ok, int j, int ncorr, double theta)
+{
+    double x = (ok && j < 2 * ncorr) ? b.W[int64_t(j) * b.cap + k] : 0.0;
+    if (j >= ncorr)
+        x = x * theta;  // Wb(): tail *= theta (BFGSMat.h:333)
+    return x;
+}
+
 template <int NC>
 __global__ void __launch_bounds__(kGcpTile) k_gcp_a1(GcpBufs b, int64_t count, int ncorr, double theta,
                                                      double* __restrict__ ts)
 {
     __shared__ double lds[NC * 4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t k = int64_t(blockIdx.x) * kGcpTile + threadIdx.x;
-    double w[NC], ex[NC], tot[NC], g;
-    gcp_load_w<NC>(b, k, count, ncorr, theta, w, g);
-#pragma unroll
+    const bool ok = k < count;
+    const double g = ok ? b.g[k] : 0.0;
+#pragma unroll 8
     for (int j = 0; j < NC; j++)
-        w[j] = g * w[j];
-    block_scan<NC>(w, ex, tot, lds);
+    {
+        const double x = wave_scan_x(g * gcp_w1(b, k, ok, j, ncorr, theta), lane);
+        if (lane == 63)
+            lds[j * 4 + wv] = x;
+    }
+    __syncthreads();
     if (threadIdx.x < NC)
     {
-        double t = 0.0;
-#pragma unroll
-        for (int j = 0; j < NC; j++)
-            if (j == threadIdx.x)
-                t = tot[j];
-        ts[int64_t(blockIdx.x) * NC + threadIdx.x] = t;
+        double add, run;
+        wave_prefix_x(lds + threadIdx.x * 4, 0, add, run);
+        ts[int64_t(blockIdx.x) * NC + threadIdx.x] = run;
     }
 }
 
@@ -210,41 +251,84 @@ __global__ void __launch_bounds__(kGcpTile) k_gcp_a3b1(GcpBufs b, int64_t count,
                                                        const double* __restrict__ Mg, const double* __restrict__ offA,
                                                        double* __restrict__ tsB)
 {
-    __shared__ double lds[(NC + 1) * 4];
+    // live per thread: w and p_{k-1} (2 NC doubles); everything else streams (see wave_scan_x)
+    __shared__ double lds[NC * 4], lds2[(NC + 1) * 4];
     __shared__ double M[NC * NC];
     for (int i = threadIdx.x; i < NC * NC; i += kGcpTile)
         M[i] = Mg[i];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t k = int64_t(blockIdx.x) * kGcpTile + threadIdx.x;
-    double w[NC], gw[NC], pprev[NC], tot[NC], g;
-    gcp_load_w<NC>(b, k, count, ncorr, theta, w, g);
-#pragma unroll
-    for (int j = 0; j < NC; j++)
-        gw[j] = g * w[j];
-    block_scan<NC>(gw, pprev, tot, lds);  // also orders the M staging before its use
+    const bool ok = k < count;
+    double w[NC], pprev[NC];
+    const double g = ok ? b.g[k] : 0.0;
 #pragma unroll
     for (int j = 0; j < NC; j++)
     {
-        pprev[j] = offA[int64_t(blockIdx.x) * NC + j] + pprev[j];
-        if (k < count)
+        w[j] = gcp_w1(b, k, ok, j, ncorr, theta);
+        const double x = wave_scan_x(g * w[j], lane);
+        const double xe = __shfl_up(x, 1, 64);
+        pprev[j] = lane ? xe : 0.0;
+        if (lane == 63)
+            lds[j * 4 + wv] = x;
+    }
+    __syncthreads();  // also orders the M staging before its use
+    // p_{k-1} complete; the scan of dt p_{k-1} (tile totals only) follows each component at once -- left after the (M w) loops
+    // below, the 2c independent scans are scheduled into them and their temporaries spill
+    const double dt = gcp_dt(b, k, count, t_prev);
+#pragma unroll
+    for (int j = 0; j < NC; j++)
+    {
+        double add, run;
+        wave_prefix_x(lds + j * 4, wv, add, run);
+        pprev[j] = offA[int64_t(blockIdx.x) * NC + j] + (add + pprev[j]);
+        if (ok)
             b.P[int64_t(j) * b.cap + k] = pprev[j];
+        double inc = dt * pprev[j];
+        if (!ok)
+            inc = 0.0;
+        const double x = wave_scan_x(inc, lane);
+        if (lane == 63)
+            lds2[j * 4 + wv] = x;
     }
-    double inc[NC + 1], ex[NC + 1], tb[NC + 1];
-    gcp_stage_b<NC>(w, pprev, g, gcp_dt(b, k, count, t_prev), theta, M, inc);
-    if (k >= count)
-    {
+    // the f'' increment of the crossing (gcp_stage_b's statements) and its tile total
+    // (two loops over the rows of M: fully unrolled as one, NC = 80 passes the optimiser's limit for a pragma-unrolled loop,
+    // which then indexes w[] by a loop variable -- an array in scratch memory)
+    double d_p = 0.0, d_w = 0.0;
 #pragma unroll
-        for (int j = 0; j <= NC; j++)
-            inc[j] = 0.0;
+    for (int i = 0; i < NC / 2; i++)
+    {
+        double u = 0.0;  // (M w)_i
+#pragma unroll
+        for (int j = 0; j < NC; j++)
+            u = u + M[i * NC + j] * w[j];
+        d_p = d_p + u * pprev[i];
+        d_w = d_w + u * w[i];
     }
-    block_scan<NC + 1>(inc, ex, tb, lds);
+#pragma unroll
+    for (int i = NC / 2; i < NC; i++)
+    {
+        double u = 0.0;
+#pragma unroll
+        for (int j = 0; j < NC; j++)
+            u = u + M[i * NC + j] * w[j];
+        d_p = d_p + u * pprev[i];
+        d_w = d_w + u * w[i];
+    }
+    const double gg = g * g;
+    {
+        double inc = -(theta * gg + 2 * g * d_p + gg * d_w);
+        if (!ok)
+            inc = 0.0;
+        const double x = wave_scan_x(inc, lane);
+        if (lane == 63)
+            lds2[NC * 4 + wv] = x;
+    }
+    __syncthreads();
     if (threadIdx.x <= NC)
     {
-        double t = 0.0;
-#pragma unroll
-        for (int j = 0; j <= NC; j++)
-            if (j == threadIdx.x)
-                t = tb[j];
-        tsB[int64_t(blockIdx.x) * (NC + 1) + threadIdx.x] = t;
+        double add, run;
+        wave_prefix_x(lds2 + threadIdx.x * 4, 0, add, run);
+        tsB[int64_t(blockIdx.x) * (NC + 1) + threadIdx.x] = run;
     }
 }
 
@@ -267,6 +351,131 @@ __global__ void __launch_bounds__(kGcpTile) k_gcp_b3c1(GcpBufs b, int64_t count,
         M[i] = Mg[i];
     __syncthreads();
     const int64_t k = int64_t(blockIdx.x) * kGcpTile + threadIdx.x;
+    if constexpr (CHAIN)
+    {
+        // Round 5, the default mode without scratch memory.  p_{k-1} is read where it is used (k_gcp_a3b1 stored it), the scan
+        // of dt p_{k-1} runs a component at a time (wave_scan_x), the f'' increment's scan -- whose results only the scan mode
+        // reads -- is not run, and (M w)_i is formed once for the three sums that use it instead of twice.  Every stored
+        // number comes from the same operations in the same order as before.
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const bool ok = k < count;
+        const double g = ok ? b.g[k] : 0.0;
+        const double dt = gcp_dt(b, k, count, t_prev);
+        // 2c <= 64: w and c_k live together (2 NC doubles).  Beyond, a lane's 512 registers do not hold both next to the rows
+        // of M in flight: (M w)_i is formed FIRST, while only w is live, and parked in this crossing's slot of C; the scan
+        // then needs c_k alone, and each c_i meets its (M w)_i again -- read back by the thread that stored it -- before it
+        // takes the slot.
+        constexpr bool PARK = NC > 64;
+        double d_c = 0.0, d_p = 0.0, d_w = 0.0;
+        double cc[NC];
+        if constexpr (PARK)
+        {
+            if (ok)
+            {
+                double w[NC];
+#pragma unroll
+                for (int j = 0; j < NC; j++)
+                    w[j] = gcp_w1(b, k, ok, j, ncorr, theta);
+#pragma unroll
+                for (int i = 0; i < NC / 2; i++)   // two loops: see k_gcp_a3b1
+                {
+                    double u = 0.0;  // (M w)_i
+#pragma unroll
+                    for (int j = 0; j < NC; j++)
+                        u = u + M[i * NC + j] * w[j];
+                    d_p = d_p + u * b.P[int64_t(i) * b.cap + k];
+                    d_w = d_w + u * w[i];
+                    b.C[int64_t(i) * b.cap + k] = u;
+                }
+#pragma unroll
+                for (int i = NC / 2; i < NC; i++)
+                {
+                    double u = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NC; j++)
+                        u = u + M[i * NC + j] * w[j];
+                    d_p = d_p + u * b.P[int64_t(i) * b.cap + k];
+                    d_w = d_w + u * w[i];
+                    b.C[int64_t(i) * b.cap + k] = u;
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the parked values are in memory before they are read back
+#pragma unroll
+            for (int j = 0; j < NC; j++)
+            {
+                const double pj = ok ? b.P[int64_t(j) * b.cap + k] : 0.0;
+                double inc = dt * pj;
+                if (!ok)
+                    inc = 0.0;
+                const double x = wave_scan_x(inc, lane);
+                cc[j] = x;
+                if (lane == 63)
+                    lds[j * 4 + wv] = x;
+            }
+            __syncthreads();
+            if (!ok)
+                return;
+#pragma unroll
+            for (int j = 0; j < NC; j++)
+            {
+                double add, run;
+                wave_prefix_x(lds + j * 4, wv, add, run);
+                const double ck = offB[int64_t(blockIdx.x) * (NC + 1) + j] + (add + cc[j]);
+                const double u = b.C[int64_t(j) * b.cap + k];
+                d_c = d_c + u * ck;
+                b.C[int64_t(j) * b.cap + k] = ck;
+            }
+        }
+        else
+        {
+            double w[NC];
+#pragma unroll
+            for (int j = 0; j < NC; j++)
+            {
+                w[j] = gcp_w1(b, k, ok, j, ncorr, theta);
+                const double pj = ok ? b.P[int64_t(j) * b.cap + k] : 0.0;
+                double inc = dt * pj;
+                if (!ok)
+                    inc = 0.0;
+                const double x = wave_scan_x(inc, lane);
+                cc[j] = x;
+                if (lane == 63)
+                    lds[j * 4 + wv] = x;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < NC; j++)
+            {
+                double add, run;
+                wave_prefix_x(lds + j * 4, wv, add, run);
+                cc[j] = offB[int64_t(blockIdx.x) * (NC + 1) + j] + (add + cc[j]);
+                if (ok)
+                    b.C[int64_t(j) * b.cap + k] = cc[j];
+            }
+            if (!ok)
+                return;
+            // p_{k-1} is read AGAIN below, not kept from the scan above (the compiler would hold all 2c values across the loops)
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < NC; i++)
+            {
+                double u = 0.0;  // (M w)_i
+#pragma unroll
+                for (int j = 0; j < NC; j++)
+                    u = u + M[i * NC + j] * w[j];
+                d_c = d_c + u * cc[i];
+                d_p = d_p + u * b.P[int64_t(i) * b.cap + k];
+                d_w = d_w + u * w[i];
+            }
+        }
+        const double gg = g * g;
+        b.dfp[k] = g * g + theta * g * b.z[k] - g * d_c;
+        b.fpp[k] = theta * gg + 2 * g * d_p + gg * d_w;
+        b.fp[k] = dt;
+        if (k == count - 1)
+            b.fp[count] = (first + count < nord) ? b.brk[count] - b.brk[count - 1] : -1.0;
+        return;
+    }
     double w[NC], pprev[NC], g;
     gcp_load_w<NC>(b, k, count, ncorr, theta, w, g);
 #pragma unroll

@@ -25,6 +25,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -319,6 +320,10 @@ static int cv_back(lbfgsx_ctx* c, bool assign)
     }
     const int64_t npos = b->wf_n;
     const int grid = std::max(1, std::min(c->grid_for(2 * npos), 1024));
+    // byte model: state byte, row number and y of every position read; written by row (sectors): the state byte and drt, or the
+    // five compact vectors
+    lbfgsx::model_add(double(npos) * (1 + 4 + double(c->esz) * (assign ? 1 : 5)) + lbfgsx::model_gather(npos, c->n, 1) +
+                      (assign ? 1 : 5) * lbfgsx::model_gather(npos, c->n, int(c->esz)));
     DISPATCH_T(c, {
         if (assign)
             LBFGSX_LAUNCH((k_cv_back<T, 1>), dim3(grid), dim3(kBlock), 0, c->stream, bvecs<T>(c), bvecs_cv<T>(c), b->wf_idx, npos);
@@ -520,6 +525,15 @@ int bounded_alloc(lbfgsx_ctx* c)
         if (const char* e2 = getenv("LBFGSX_GRAM_I8_MIN"))
             b->i8_min_tot = std::max(1, atoi(e2));
         b->gram_mode = (std::strcmp(e, "blocked") == 0) ? 2 : 0;
+        // "dd" / "" name the default; anything else (e.g. the removed "mfma") is a typo that would silently measure the
+        // default path under another name
+        if (!b->gram_i8 && b->gram_mode == 0 && e[0] != 0 && std::strcmp(e, "dd") != 0)
+        {
+            static bool warned = false;
+            if (!warned)
+                fprintf(stderr, "lbfgsx: LBFGSX_GRAM=%s is not a Gram kernel (i8, blocked, dd): using the default\n", e);
+            warned = true;
+        }
     }
     if (const char* e = getenv("LBFGSX_GCP_CHAIN"))
         b->chain_host = std::strcmp(e, "scan") != 0;
@@ -1233,6 +1247,7 @@ int lbfgsx_b_dg_maxstep(lbfgsx_ctx* c, double* dg, double* step_max)
     double r[2];
     DISPATCH_T(c, {
         lbfgsx::poll_arm(c);
+        lbfgsx::model_add(double(c->n) * 5 * sizeof(T));  // byte model: x, g, d, lb, ub
         LBFGSX_LAUNCH((k_b_dg_maxstep<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]),
                            P<T>(c->gb[c->cur]), P<T>(c->d), P<T>(c->lb), P<T>(c->ub), c->n, c->ws, c->out_slot<T>());
         LBFGSX_HIP(hipGetLastError());
@@ -1253,6 +1268,8 @@ static int dg_maxstep_trial_t(lbfgsx_ctx* c, OBJ obj, T step, double* r4)
     const int grid = c->grid_for(c->n);
     const int rev = (c->zigzag && (c->tl_step & 1u)) ? 1 : 0;  // the order the trial launch it stands for would have taken
     lbfgsx::poll_arm(c);
+    // byte model: xp, g, d, lb, ub read, x and grad written, + the objective's own vectors (a, b of the quadratic)
+    lbfgsx::model_add(double(c->n) * sizeof(T) * (7 + (sizeof(OBJ) >= 2 * sizeof(void*) ? 2 : 0)));
     LBFGSX_LAUNCH((k_b_dg_maxstep_trial<T, OBJ>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->xp]), P<T>(c->gb[c->cur]),
                        P<T>(c->d), P<T>(c->lb), P<T>(c->ub), step, P<T>(c->xb[c->trial]), P<T>(c->gb[c->trial]), c->n, obj, c->ws,
                        c->out_slot<T>(), rev);
@@ -1327,6 +1344,7 @@ int lbfgsx_b_post_linesearch(lbfgsx_ctx* c, double* projgnorm, double* xnorm2, d
     }
     DISPATCH_T(c, {
         lbfgsx::poll_arm(c);
+        lbfgsx::model_add(double(c->n) * 8 * sizeof(T));  // byte model: x, xp, g, gp, lb, ub read, s and y written
         LBFGSX_LAUNCH((k_b_post<T>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->cur]), P<T>(c->xb[c->xp]),
                            P<T>(c->gb[c->cur]), P<T>(c->gb[c->xp]), P<T>(c->lb), P<T>(c->ub), P<T>(c->col(c->S, c->spare)),
                            P<T>(c->col(c->Y, c->spare)), c->n, c->ws, c->out_slot<T>(),
@@ -1382,6 +1400,8 @@ int lbfgsx_b_post_linesearch_build(lbfgsx_ctx* c, double tau, double* projgnorm,
         BVecs<T> bv = bvecs<T>(c);
         const bool wc = wtdc_ready(c, true) && wtdc_alloc(c);
         lbfgsx::poll_arm(c);
+        // byte model: x, xp, g, gp, lb, ub and the positions read; s, y, brk, d, xcp written
+        lbfgsx::model_add(double(c->n) * (11 * sizeof(T) + 4));
         LBFGSX_LAUNCH((k_b_post_build<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, P<T>(c->xb[c->xp]), P<T>(c->gb[c->xp]),
                            P<T>(c->col(c->S, c->spare)), P<T>(c->col(c->Y, c->spare)), c->out_slot<T>(),
                            P<T>(c->sc) + c->sl.ys(c->spare), P<T>(c->sc) + c->sl.theta(c->spare), P<T>(b->keys_in), b->vals_in,
@@ -1472,6 +1492,7 @@ int lbfgsx_b_cauchy_build(lbfgsx_ctx* c, int64_t* nfree, int64_t* nord, double* 
         const bool wc = wtdc_prepare(c);
         const int newest = (c->ptr + c->m - 1) % c->m;
         lbfgsx::poll_arm(c);
+        lbfgsx::model_add(double(c->n) * (7 * sizeof(T) + 4));  // byte model: x, g, lb, ub read; brk, d, xcp and the index written
         LBFGSX_LAUNCH((k_cauchy_build<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, P<T>(b->keys_in), b->vals_in, c->n,
                            c->ws, b->dout, force ? P<T>(c->xb[c->cur]) : static_cast<T*>(nullptr),
                            wc ? static_cast<const T*>(c->col(c->S, c->phys[size_t(newest)])) : static_cast<const T*>(nullptr),
@@ -1485,6 +1506,7 @@ int lbfgsx_b_cauchy_build(lbfgsx_ctx* c, int64_t* nfree, int64_t* nord, double* 
         if (r[2] > 0)
         {
             size_t bytes = b->sort_tmp_bytes;
+            lbfgsx::model_add(96.0 * double(c->n));  // byte model: SURVEY 8(d)'s radix-sort figure per (key, index) pair
             LBFGSX_HIP(rocprim::radix_sort_pairs(b->sort_tmp, bytes, P<T>(b->keys_in), P<T>(b->keys_out), b->vals_in,
                                                  b->vals_out, size_t(c->n), 0, int(sizeof(T) * 8), c->stream));
         }
@@ -1630,6 +1652,7 @@ static int partial_sort_tail_t(lbfgsx_ctx* c, unsigned cnt, int64_t* nsorted)
     const int grid = int(std::min<int64_t>((int64_t(cnt) + 255) / 256, 1024));
     LBFGSX_LAUNCH((k_gather_keys<T>), dim3(grid), dim3(256), 0, c->stream, P<T>(b->keys_in), b->pv, P<T>(b->pk), int64_t(cnt));
     size_t sbytes = b->sort_tmp_bytes;
+    lbfgsx::model_add(double(cnt) * (96.0 + 64.0 + 2 * sizeof(T)));  // byte model: the candidates' keys gathered (a sector each) and sorted
     LBFGSX_HIP(rocprim::radix_sort_pairs(b->sort_tmp, sbytes, P<T>(b->pk), P<T>(b->keys_out), b->pv, b->vals_out, size_t(cnt), 0,
                                          int(sizeof(T) * 8), c->stream));
     return LBFGSX_OK;
@@ -1673,6 +1696,7 @@ int lbfgsx_b_cauchy_build_partial(lbfgsx_ctx* c, double tau, int64_t* nfree, int
         {
         if (!sel_ahead)  // nothing rides behind the build: its last block carries the completion word
             lbfgsx::poll_arm(c);
+        lbfgsx::model_add(double(c->n) * (7 * sizeof(T) + 4));  // byte model: x, g, lb, ub read; brk, d, xcp and the index written
         LBFGSX_LAUNCH((k_cauchy_build<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, P<T>(b->keys_in), b->vals_in, c->n,
                            c->ws, b->dout, force ? P<T>(c->xb[c->cur]) : static_cast<T*>(nullptr),
                            wc ? static_cast<const T*>(c->col(c->S, c->phys[size_t(newest)])) : static_cast<const T*>(nullptr),
@@ -1709,6 +1733,7 @@ int lbfgsx_b_cauchy_build_partial(lbfgsx_ctx* c, double tau, int64_t* nfree, int
             else
             {
                 size_t bytes = b->sort_tmp_bytes;
+                lbfgsx::model_add(96.0 * double(c->n));  // byte model: SURVEY 8(d)'s radix-sort figure per (key, index) pair
                 LBFGSX_HIP(rocprim::radix_sort_pairs(b->sort_tmp, bytes, P<T>(b->keys_in), P<T>(b->keys_out), b->vals_in,
                                                      b->vals_out, size_t(c->n), 0, int(sizeof(T) * 8), c->stream));
             }
@@ -1758,6 +1783,7 @@ int lbfgsx_b_cauchy_sort_full(lbfgsx_ctx* c)
     b->gpre_valid = false;
     DISPATCH_T(c, {
         size_t bytes = b->sort_tmp_bytes;
+        lbfgsx::model_add(96.0 * double(c->n));  // byte model: SURVEY 8(d)'s radix-sort figure per (key, index) pair
         LBFGSX_HIP(rocprim::radix_sort_pairs(b->sort_tmp, bytes, P<T>(b->keys_in), P<T>(b->keys_out), b->vals_in, b->vals_out,
                                              size_t(c->n), 0, int(sizeof(T) * 8), c->stream));
     });
@@ -2140,6 +2166,7 @@ int lbfgsx_b_cauchy_finish(lbfgsx_ctx* c, double t_cross, double tfinal, int cro
         b->lu_valid = false;  // the state bytes are rewritten
         b->wf_valid = false;
         lbfgsx::poll_arm(c);
+        lbfgsx::model_add(double(c->n) * (5 * sizeof(T) + 1));  // byte model: brk, x0, d read; xcp, drt and the state byte written
         LBFGSX_LAUNCH((k_cauchy_finish<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, T(t_cross), T(tfinal), crossed_all,
                            c->n, c->ws, b->dout, fuse ? P<T>(c->d) : static_cast<T*>(nullptr),
                            fuse ? b->na_list : static_cast<int*>(nullptr), b->na_cnt, b->na_cap);
@@ -2173,6 +2200,7 @@ int lbfgsx_b_sub_begin(lbfgsx_ctx* c)
     }
     DISPATCH_T(c, {
         BVecs<T> bv = bvecs<T>(c);
+        lbfgsx::model_add(double(c->n) * 3 * sizeof(T));
         LBFGSX_LAUNCH((k_sub_begin<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, c->n);
     });
     LBFGSX_HIP(hipGetLastError());
@@ -2552,6 +2580,10 @@ static int launch_gram_dd(lbfgsx_ctx* c, int64_t nbatch, int tot, int vsel_id, i
     for (int k = 0; k < tot; k++)
         which[k] = k;
     Cols<T, 32> cl = (gr.in_idx && !gr.w_by_row) ? wf_cols<T>(c, tot) : col_list<T, 32>(c, which, tot);
+    // byte model: state bytes (and row numbers) of every row walked, the columns and v of the rows kept (nrows), the compact copy when written
+    lbfgsx::model_add(double(nbatch) * 64.0 * (1 + (gr.in_idx ? 4 : 0)) +
+                      double((!gr.in_idx && mask && b->nfree_last > 0) ? std::min<int64_t>(nrows, b->nfree_last) : nrows) * sizeof(T) *
+                          (tot * (gr.out_w ? 2 : 1) + 1));
     LBFGSX_LAUNCH((k_gram_dd<T, KP>), dim3(blocks), dim3(kBlock), lds, c->stream, cl, tot, bvecs<T>(c), vsel_id, mask,
                        nrows, b->gram_partial, pro, gr);
     return blocks;
@@ -2571,6 +2603,10 @@ static int launch_gram_vonly(lbfgsx_ctx* c, int64_t nbatch, int tot, int vsel_id
     for (int k = 0; k < tot; k++)
         which[k] = k;
     Cols<T, 32> cl = (gr.in_idx && !gr.w_by_row) ? wf_cols<T>(c, tot) : col_list<T, 32>(c, which, tot);
+    // byte model: state bytes (and row numbers) of every row walked, the columns and v of the rows kept (nrows), the compact copy when written
+    lbfgsx::model_add(double(nbatch) * 64.0 * (1 + (gr.in_idx ? 4 : 0)) +
+                      double((!gr.in_idx && mask && b->nfree_last > 0) ? std::min<int64_t>(nrows, b->nfree_last) : nrows) * sizeof(T) *
+                          (tot * (gr.out_w ? 2 : 1) + 1));
     LBFGSX_LAUNCH((k_gram_dd<T, 1, CS, true>), dim3(blocks), dim3(kBlock), lds, c->stream, cl, tot, bvecs<T>(c), vsel_id,
                        mask, nrows, b->gram_partial, pro, gr);
     return blocks;
@@ -2967,6 +3003,7 @@ static int free_delta_launch(lbfgsx_ctx* c)
     LBFGSX_HIP(lbfgsx::copy_async(b->dl_cnt, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
     const int64_t n8 = (c->n + 7) / 8;
     const int grid = c->grid_for(n8);
+    lbfgsx::model_add(double(c->n) * 2.125);  // byte model: the state bytes read, the remembered free bits read and written
     LBFGSX_LAUNCH(k_free_delta, dim3(grid), dim3(kBlock), 0, c->stream, b->st, b->fprev, n8, c->n, b->dl_enter, b->dl_leave,
                        b->dl_cnt, b->dl_cap);
     LBFGSX_HIP(hipGetLastError());
@@ -3680,6 +3717,7 @@ int lbfgsx_b_sub_sweep_begin(lbfgsx_ctx* c, int first, int64_t* nL, int64_t* nU,
     const unsigned lu_cap_now = (c->bstate->lu_use && c->bstate->lu_pred <= c->bstate->lu_max) ? c->bstate->lu_cap : 0u;
     DISPATCH_T(c, {
         BVecs<T> bv = bvecs<T>(c);
+        lbfgsx::model_add(double(c->n) * (7 * sizeof(T) + 2));  // byte model: y, lam, mu, lb, ub, x0, cF and the state byte; state and rhs written
         LBFGSX_LAUNCH((k_sub_sweep_begin<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, first ? 1 : 0, c->n, c->ws,
                            c->bstate->dout, c->bstate->lu_ptr(), c->bstate->lu_cnt, lu_cap_now);
     });
@@ -3959,6 +3997,7 @@ int lbfgsx_b_lu_sweep(lbfgsx_ctx* c, const double* coef, double theta, int64_t s
         T* cui = nullptr;
         const BVecs<T> bv = b->cv_live ? bvecs_cv<T>(c, &cli, &cui) : bvecs<T>(c);
         lbfgsx::poll_arm(c);
+        lbfgsx::model_add(double(nl) * 64.0 * (2 * c->ncorr + 8));  // byte model: a sector per column and vector at every listed row
         LBFGSX_LAUNCH((k_lu_sweep<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, P<T>(c->S), P<T>(c->Y), c->ld,
                            b->phys_dev, c->ncorr, cf, has_w, T(theta), b->lu_ptr(), nl, c->ws, b->dout, b->lu_other(), b->lu_cnt,
                            b->lu_cap, b->cv_live ? b->wf_pos : static_cast<const int*>(nullptr), cli, cui);

@@ -1699,45 +1699,106 @@ __global__ void k_cauchy_gather(BVecs<T> b, const T* __restrict__ keys, const in
 // and one launch less.  na_list != null: the rows this pass makes newly active (10^1..10^3 of 10^7 in steady state) are listed
 // (their number in out[2], beyond na_cap the list is incomplete), so that W_A'(A'd) of compute_FtBAb (BFGSMat.h:503-507) walks
 // the list instead of scanning n state bytes.
+// lu_append for a list that is useless once it overflows (the caller only asks "how many, and all of them if <= cap"): a wave
+// looks at the counter first and stops adding to it beyond the capacity.  In the first iterations of a box-constrained run
+// millions of rows become active in one search -- 10^5 waves serialising on one counter cost the pass 0.6-1.0 ms
+// (profiles/r4_cfg4_timeline.txt) for a list nobody reads; in steady state (10^1..10^3 rows) nothing changes.  The counter
+// ends above the capacity whenever more than `cap` rows were met, which is all the host tests.
+__device__ inline void lu_append_capped(bool app, int64_t i, int* __restrict__ lu_list, unsigned* __restrict__ lu_cnt, unsigned lu_cap)
+{
+    const unsigned long long am = __ballot(app);
+    if (am)
+    {
+        const int leader = __ffsll((long long) am) - 1;
+        unsigned basep = 0;
+        if (int(threadIdx.x & 63) == leader)
+        {
+            basep = __hip_atomic_load(lu_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (basep <= lu_cap)
+                basep = atomicAdd(lu_cnt, unsigned(__popcll(am)));
+        }
+        basep = unsigned(__shfl(int(basep), leader, 64));
+        const unsigned pos = basep + unsigned(__popcll(am & ((1ull << (threadIdx.x & 63)) - 1ull)));
+        if (app && pos < lu_cap)
+            lu_list[pos] = int(i);
+    }
+}
+
+// Round 5: 16 bytes per lane and access (two rows in double, four in float) instead of one element -- the pass is pure
+// streaming (brk, x0, d in; xcp, drt, the state byte out).  xcp is stored on every row: where the reference leaves it alone
+// (t = 0, or an uncrossed row of a search that crossed everything: Cauchy.h:201-213) it holds x0 since k_cauchy_build, which
+// is the value stored.
 template <class T>
 __global__ void __launch_bounds__(kBlock) k_cauchy_finish(BVecs<T> b, T t_cross, T tfinal, int crossed_all, int64_t n,
                                                           RedWs ws, double* __restrict__ out, T* __restrict__ drt,
                                                           int* __restrict__ na_list, unsigned* __restrict__ na_cnt, unsigned na_cap)
 {
     typedef typename AccOf<T>::type A;
+    constexpr int W = Vec16<T>::W;
     A acc[2];
-    const int64_t stride = int64_t(gridDim.x) * kBlock;
-    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
-    {
-        const T t = b.brk[i];
-        const T x0i = b.x0[i];
-        T xc = x0i;  // what k_cauchy_build left in xcp: x0 (Cauchy.h:95)
-        unsigned char s = 0;
+    auto row = [&](int64_t i, T t, T x0i, T di, T& xc, unsigned char& s) __attribute__((always_inline)) {
+        xc = x0i;  // what k_cauchy_build left in xcp: x0 (Cauchy.h:95)
         if (t == T(0))
             s = 0;  // on its bound from the start: neither free nor newly active; xcp = x0
         else if (t <= t_cross)
         {
-            xc = (b.dvec[i] > T(0)) ? b.ub[i] : b.lb[i];
-            b.xcp[i] = xc;
+            xc = (di > T(0)) ? b.ub[i] : b.lb[i];
             s = ST_NEWACT;
             acc[0].add(T(1));
         }
         else
         {
             if (!crossed_all)
-            {
-                xc = x0i + tfinal * b.dvec[i];
-                b.xcp[i] = xc;
-            }
+                xc = x0i + tfinal * di;
             s = ST_FREE;
             acc[1].add(T(1));
         }
-        b.st[i] = s;
+    };
+    const int64_t nv = n / W;
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t vi = int64_t(blockIdx.x) * kBlock + threadIdx.x; vi < nv; vi += stride)
+    {
+        const Pack<T> pt = ldv(b.brk, vi), px0 = ldv(b.x0, vi), pd = ldv(b.dvec, vi);
+        Pack<T> pxc, pdr;
+        unsigned char s[W];
+#pragma unroll
+        for (int k = 0; k < W; k++)
+        {
+            row(vi * W + k, pt.e[k], px0.e[k], pd.e[k], pxc.e[k], s[k]);
+            pdr.e[k] = pxc.e[k] - px0.e[k];
+        }
+        stv(b.xcp, vi, pxc);
         if (drt)
-            drt[i] = xc - x0i;
+            stv(drt, vi, pdr);
+        if (W == 2)
+            reinterpret_cast<unsigned short*>(b.st)[vi] = (unsigned short) (unsigned(s[0]) | (unsigned(s[1]) << 8));
+        else
+            reinterpret_cast<unsigned*>(b.st)[vi] = unsigned(s[0]) | (unsigned(s[1 % W]) << 8) | (unsigned(s[2 % W]) << 16) |
+                                                     (unsigned(s[3 % W]) << 24);
         if (na_list)
-            lu_append(s == ST_NEWACT, i, na_list, na_cnt, na_cap);
+        {
+#pragma unroll
+            for (int k = 0; k < W; k++)
+                lu_append_capped(s[k] == ST_NEWACT, vi * W + k, na_list, na_cnt, na_cap);
+        }
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int64_t i = nv * W; i < n; i++)
+        {
+            T xc;
+            unsigned char s;
+            row(i, b.brk[i], b.x0[i], b.dvec[i], xc, s);
+            b.xcp[i] = xc;
+            b.st[i] = s;
+            if (drt)
+                drt[i] = xc - b.x0[i];
+            if (na_list && s == ST_NEWACT)
+            {
+                const unsigned pos = atomicAdd(na_cnt, 1u);
+                if (pos < na_cap)
+                    na_list[pos] = int(i);
+            }
+        }
     if (grid_reduce<2>(acc, ws) && threadIdx.x == 0)
     {
         out[0] = acc[0].value();

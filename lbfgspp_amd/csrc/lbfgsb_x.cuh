@@ -64,7 +64,9 @@ struct RowsX
 #define LBFGSX_X_OCC_SWEEP 0
 #endif
 // experiment builds only (scripts/experiments/kernels_x.hip): bit 0 no left-to-right sums, 1 no double-double products,
-// 2 no stores, 3 no cross-lane moves -- what each part of a trip costs.  0 in the product.
+// 2 no stores, 3 no cross-lane moves -- what each part of a trip costs (kx_rows); kx_solve_sweep: 16 no sweep statements (and
+// their stores), 32 no y / rhs stores, 64 no double-double products, 128 no left-to-right sums, 256 no list appends.
+// 0 in the product.
 #ifndef LBFGSX_X_DBG
 #define LBFGSX_X_DBG 0
 #endif
@@ -493,7 +495,7 @@ __global__ void __launch_bounds__(kBlock, occ_sweep_x(NCL, G, FIRST))
         const bool fr = inb && (st0 & ST_FREE);
         const bool solve = fr && (FIRST || (st0 & ST_P));
         T a = T(0);
-        if (has_w)
+        if (has_w && !(LBFGSX_X_DBG & 128))
         {
             T p[NCL];
 #pragma unroll
@@ -506,7 +508,7 @@ __global__ void __launch_bounds__(kBlock, occ_sweep_x(NCL, G, FIRST))
         {
             // rhs = rhs + (-(W * c1)(row)) [+ (-(W * c2)(row))], v = -rhs: kx_rows' GP_RHS statements (x.xa is the rhs read)
             T rh = x.xa;
-            if (pro.use1)
+            if (pro.use1 && !(LBFGSX_X_DBG & 128))
             {
                 T p[NCL];
 #pragma unroll
@@ -514,7 +516,7 @@ __global__ void __launch_bounds__(kBlock, occ_sweep_x(NCL, G, FIRST))
                     p[k] = x.w[k] * s_c1[RHSK ? L.g * NCL + k : 0];
                 rh = rh + (-chain_x<T, NCL, G>(p, L));
             }
-            if (pro.use2)
+            if (pro.use2 && !(LBFGSX_X_DBG & 128))
             {
                 T p[NCL];
 #pragma unroll
@@ -522,28 +524,28 @@ __global__ void __launch_bounds__(kBlock, occ_sweep_x(NCL, G, FIRST))
                     p[k] = x.w[k] * s_c2[RHSK ? L.g * NCL + k : 0];
                 rh = rh + (-chain_x<T, NCL, G>(p, L));
             }
-            if (solve && L.last())
+            if (solve && L.last() && !(LBFGSX_X_DBG & 32))
                 bw.rhs[iw] = rh;
             v = -rh;
         }
         const T ynew = has_w ? (v / theta + a / theta2) : (v / theta);
         const T yi = solve ? ynew : x.yold;
-        if (solve && L.last())
+        if (solve && L.last() && !(LBFGSX_X_DBG & 32))
             bw.y[iw] = yi;
-        if (!FIRST && fr)
+        if (!FIRST && fr && !(LBFGSX_X_DBG & 64))
         {
 #pragma unroll
             for (int k = 0; k < NCL; k++)
                 acc[k].add_prod(x.w[k], yi);
         }
         bool app = false;
-        if (solve && L.last())
+        if (solve && L.last() && !(LBFGSX_X_DBG & 16))
         {
             // a P row's multipliers are zero (the sweep that made it P stored them); the first sweep sets them
             const unsigned char s2 = sweep_row_v<T>(bw, iw, st0, yi, T(0), T(0), FIRST != 0, FIRST != 0, cnt, li, ui, x.cfi);
             app = (s2 & (ST_L | ST_U)) != 0;
         }
-        if (lu_cap)
+        if (lu_cap && !(LBFGSX_X_DBG & 256))
             lu_append(app, i, lu_list, lu_cnt, lu_cap);  // the list holds rows
     };
     {

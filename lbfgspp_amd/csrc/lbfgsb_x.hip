@@ -42,6 +42,25 @@ int rows(hipStream_t s, int num_cus, int na, const ColsX<T>& cols, int ncols, co
 {
     if (ncols < 1 || ncols > kColsX || (na != 1 && na != 3))
         return LBFGSX_E_INVALID;
+    {
+        // byte model (ctx.hpp Counters::model_bytes): the columns over the rows walked; per row the state byte, the prologue's
+        // vector and v (two vectors for the bound selectors), the position's row number where the columns are the compact
+        // copy; written: rhs / cF where a prologue runs; the patching form reads the two fresh columns at the row and writes them
+        // at the position
+        const double e = sizeof(T);
+        double per = double(ncols) * e + 1 + e;
+        if (pro.mode != GP_NONE)
+            per += 2 * e;                                   // pre read, rhs / cF written
+        if (vsel_id == VS_LBOUND || vsel_id == VS_UBOUND)
+            per += e;
+        if (gr.in_idx)
+            per += 4;
+        if (na == 3 && gr.dst_a)
+            per += 4 * e;
+        model_add(per * double(n));
+        if (gr.in_idx)
+            model_compact_pass(n);
+    }
 #define CALL(NCL, G)                                                                                                           \
     if (na == 1 && gr.in_idx)                                                                                                  \
         LBFGSX_LAUNCH((kx_rows<T, NCL, G, 1, true>), dim3(grid_rows(n, 64 / G, occ_rows_x(NCL, G, 1), num_cus)), dim3(kBlock), 0, s, \
@@ -75,6 +94,22 @@ int solve_sweep(hipStream_t s, int num_cus, int first, const ColsX<T>& cols, int
     none.mode = LBFGSX_GP_NONE;
     none.use1 = none.use2 = 0;
     const ProX<T>& pr = rhsk ? *pro : none;  // (the arrays of `none` are never read)
+    {
+        // byte model: columns; read st, v's vector, cF, the two bounds (and x0 where they are not yet differences), y of the
+        // sweep before; written y, rhs, st -- the first pass also yfallback and the two multipliers, and when it starts the
+        // compact vectors (cv = 1) cF and the two bound differences of every position; vectors by row are gathers
+        const double e = sizeof(T);
+        double per = double(ncols) * e;
+        const double rd = (1 + 4 * e) + (first ? 0 : e) + (cv == 2 ? 0 : e);
+        const double wr = (1 + 2 * e) + (first ? 3 * e : 0) + (cv == 1 ? 3 * e : 0);
+        per += wr + ((cv == 2 || !ridx) ? rd : 4.0);
+        double tot = per * double(n);
+        if (ridx && cv != 2)  // reads by row through the list of the positions' rows
+            tot += (rd / e) * model_gather(n, n * 2, int(e)) + model_gather(n, n * 2, 1) - double(n);
+        model_add(tot);
+        if (ridx || cv)
+            model_compact_pass(n);
+    }
 #define SWEEP(FIRST, IDX, RHSK)                                                                                                   \
     LBFGSX_LAUNCH((kx_solve_sweep<T, NCL_, G_, FIRST, IDX, RHSK>), dim3(grid_rows(n, 64 / G_, occ_sweep_x(NCL_, G_, FIRST), num_cus)),  \
                   dim3(kBlock), 0, s, cols, ncols, b, bw, vsel_id, coef, has_w, theta, n, ws, out, lu_list, lu_cnt, lu_cap, ridx, cli,  \
@@ -103,6 +138,11 @@ int multidot2_wf(hipStream_t s, int num_cus, const ColsX<T>& wfc, int ncols, int
 {
     if (ncols < 1 || ncols > kColsX)
         return LBFGSX_E_INVALID;
+    // byte model: the compact columns over their positions + s_new, y_new, d gathered by the positions' rows + the row numbers;
+    // the rows outside the copy: every column and two vectors at the row (one sector each)
+    model_add(double(npos) * (double(ncols) * sizeof(T) + 4) + 3.0 * model_gather(npos, npos * 2, int(sizeof(T))) +
+              double(nlist) * 64.0 * (ncols + 2));
+    model_compact_pass(npos);
 #define CALL(NCL, G)                                                                                                          \
     LBFGSX_LAUNCH((kx_multidot2_wf<T, NCL, G>), dim3(grid_rows(std::max<int64_t>(npos, nlist), 64 / G, occ_dots_x(NCL), num_cus)),  \
                   dim3(kBlock), 0, s, wfc, ncols, fresh_a, fresh_b, snew, ynew, dvec, idx, npos, full, list, nlist, ws, out)
@@ -118,6 +158,7 @@ int multidot2(hipStream_t s, int num_cus, const ColsX<T>& cols, int ncols, const
 {
     if (ncols < 1 || ncols > kColsX)
         return LBFGSX_E_INVALID;
+    model_add(double(n) * (ncols + 2) * sizeof(T));  // byte model: full-length columns and the two vectors
 #define CALL(NCL, G)                                                                                                        \
     LBFGSX_LAUNCH((kx_multidot2<T, NCL, G>), dim3(grid_rows(n, 64 / G, occ_dots_x(NCL), num_cus)), dim3(kBlock), 0, s, cols, ncols, \
                   v1, v2, n, ws, out)
@@ -133,6 +174,7 @@ int list2(hipStream_t s, int num_cus, const ColsX<T>& cols, int ncols, const BVe
 {
     if (ncols < 1 || ncols > kColsX)
         return LBFGSX_E_INVALID;
+    model_add(double(nlist) * (64.0 * (ncols + 3) + 4 + 64));  // byte model: a sector per column and vector at every listed row
     // a short list: few blocks keep the reduction tail short
 #define CALL(NCL, G)                                                                                                      \
     LBFGSX_LAUNCH((kx_list2<T, NCL, G>), dim3(std::min(32, grid_rows(nlist, 64 / G, 1, num_cus))), dim3(kBlock), 0, s, cols,   \
@@ -149,6 +191,7 @@ int list1(hipStream_t s, int num_cus, const ColsX<T>& cols, int ncols, const BVe
 {
     if (ncols < 1 || ncols > kColsX)
         return LBFGSX_E_INVALID;
+    model_add(double(nlist) * (64.0 * (ncols + 1) + 4 + 64));  // byte model: as list2, one vector
 #define CALL(NCL, G)                                                                                                      \
     LBFGSX_LAUNCH((kx_list1<T, NCL, G>), dim3(std::min(32, grid_rows(nlist, 64 / G, 1, num_cus))), dim3(kBlock), 0, s, cols,   \
                   ncols, b, vsel_id, mask, list, nlist, ws, out, stc, pos, out_dd)
@@ -165,6 +208,7 @@ int multidot_mask(hipStream_t s, int num_cus, const ColsX<T>& cols, int ncols, c
     if (ncols < 1 || ncols > kColsX)
         return LBFGSX_E_INVALID;
     const int64_t want = (n + int64_t(kWaves) * 256 - 1) / (int64_t(kWaves) * 256);
+    model_add(double(n));  // byte model: the state bytes (the rows inside the mask are 10^1..10^4 of n)
 #define CALL(NCL, G)                                                                                                   \
     LBFGSX_LAUNCH((kx_multidot_mask<T, NCL, G>),                                                                        \
                   dim3(int(std::max<int64_t>(1, std::min<int64_t>(want, std::min(occ_mask_x(NCL) * num_cus, kMaxGridX))))), \
@@ -203,6 +247,17 @@ static int gram_kp(hipStream_t s, int max_blocks, const ColsX<T>& cols, int ncol
         (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kx_gram<T, KPB>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     const int64_t nbatch = (n + 63) / 64;
     const int blocks = int(std::max<int64_t>(1, std::min<int64_t>(max_blocks, nbatch)));
+    {
+        // byte model: a list of rows -> a sector per column at every row; a masked pass over n rows -> the state bytes, the row
+        // numbers and the columns of the rows kept (counted as all of them: an upper bound the full passes of the first
+        // iterations reach), plus the compact copy it writes
+        const double e = sizeof(T);
+        if (gr.w_by_row && gr.in_idx)
+            model_add(double(n) * (64.0 * ncols + 4 + 64));
+        else
+            model_add(double(n) * (double(ncols) * e * (gr.out_w ? 2 : 1) + 1 + (gr.in_idx ? 4 : 0) + (vsel_id >= 0 ? e : 0) +
+                                   (gr.out_w ? 8 : 0)));
+    }
     LBFGSX_LAUNCH((kx_gram<T, KPB>), dim3(blocks), dim3(kBlock), lds, s, cols, ncols, b, vsel_id, mask, n, partial, pro, gr, cs,
                   (blocks <= kGramSelfFinish && ticket) ? fin_out : static_cast<double*>(nullptr), fin_dd, done, seq, ticket);
     if (hipGetLastError() != hipSuccess)

@@ -1027,6 +1027,8 @@ static int trial_t(lbfgsx_ctx* c, OBJ obj, T step, double* out2)
     const int grid = c->grid_for(c->n);
     const int rev = (c->zigzag && (c->tl_step++ & 1u)) ? 1 : 0;
     lbfgsx::poll_arm(c);
+    // byte model (counters, L-BFGS-B legs): xp and d read, x and grad written, + the objective's own vectors
+    lbfgsx::model_add(double(c->n) * sizeof(T) * (4 + (sizeof(OBJ) >= 2 * sizeof(void*) ? 2 : 0)));
     // 4 vectors per stream and thread in flight (measured +1 % on the north-star against 2; profiles/r1_mall_policy_ab.txt)
 #define TRIAL_LAUNCH(UU, NTL, NTS)                                                                                            \
     LBFGSX_LAUNCH((k_trial<T, OBJ, UU, NTL, NTS>), dim3(grid), dim3(kBlock), 0, c->stream, P<T>(c->xb[c->xp]), P<T>(c->d), \
@@ -1386,7 +1388,28 @@ int lbfgsx_counters(int64_t out[3], int reset)
         g.launches = 0;
         g.syncs = 0;
         g.copies = 0;
+        g.model_bytes = 0;
+        g.compact_passes = 0;
+        g.compact_rows = 0;
     }
+    return LBFGSX_OK;
+}
+
+int lbfgsx_counters_ex(int64_t out[8], int reset)
+{
+    auto& g = lbfgsx::counters();
+    if (out)
+    {
+        out[0] = g.launches.load(std::memory_order_relaxed);
+        out[1] = g.syncs.load(std::memory_order_relaxed);
+        out[2] = g.copies.load(std::memory_order_relaxed);
+        out[3] = g.model_bytes.load(std::memory_order_relaxed);
+        out[4] = g.compact_passes.load(std::memory_order_relaxed);
+        out[5] = g.compact_rows.load(std::memory_order_relaxed);
+        out[6] = out[7] = 0;
+    }
+    if (reset)
+        return lbfgsx_counters(nullptr, 1);
     return LBFGSX_OK;
 }
 

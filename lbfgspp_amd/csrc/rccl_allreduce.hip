@@ -84,7 +84,13 @@ struct Rank
     int device = 0;
     // `comm` is used by the rank's own thread (the all-reduce) and taken away by whichever thread aborts the communicator:
     // both under `mu`, so that a reducer never hands RCCL a communicator that lbfgsx_comm_abort has just freed
+    // The RCCL call itself runs OUTSIDE the lock (a rank's first collective may block inside ncclAllReduce until its peers
+    // connect, and the abort that would release it must not queue behind it): `in_call` says a reducer holds the handle; an
+    // abort waits for it briefly -- an enqueue returns in microseconds -- and then aborts regardless, which is what releases
+    // a reducer that is stuck in the call.
     std::mutex mu;
+    std::condition_variable cv;
+    bool in_call = false;
     ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr;
     double* dev = nullptr;      // [kMaxBundle] send = receive buffer (in place)
@@ -152,9 +158,11 @@ void abort_rank(Rank& k)
 {
     ncclComm_t cm = nullptr;
     {
-        std::lock_guard<std::mutex> lock(k.mu);
+        std::unique_lock<std::mutex> lock(k.mu);
         cm = k.comm;
-        k.comm = nullptr;
+        k.comm = nullptr;  // no new call starts with it
+        if (cm)
+            (void) k.cv.wait_for(lock, std::chrono::seconds(2), [&] { return !k.in_call; });
     }
     if (cm && rccl2().CommAbort)
     {
@@ -329,15 +337,28 @@ int lbfgsx_comm_allreduce_sum(lbfgsx_comm* c, int local_rank, double* buf, int c
         std::memcpy(k.host, buf, sizeof(double) * size_t(count));
         LBFGSX_HIP(lbfgsx::copy_async(k.dev, k.host, sizeof(double) * size_t(count), hipMemcpyHostToDevice, k.stream));
         {
-            // the communicator is handed to RCCL under the rank's lock: lbfgsx_comm_abort takes it away under the same lock, so
-            // it is either still whole here or gone (null) -- never freed in between
-            std::lock_guard<std::mutex> lock(k.mu);
-            if (c->aborted.load() || !k.comm)
+            // the handle is taken under the rank's lock and marked in use; lbfgsx_comm_abort takes it away under the same lock and
+            // lets a call in progress return before it frees the communicator (Rank::in_call)
+            ncclComm_t cm = nullptr;
+            {
+                std::lock_guard<std::mutex> lock(k.mu);
+                if (!c->aborted.load() && k.comm)
+                {
+                    cm = k.comm;
+                    k.in_call = true;
+                }
+            }
+            if (!cm)
             {
                 lbfgsx::set_error("lbfgsx_comm_allreduce_sum: the communicator was aborted by another rank");
                 return LBFGSX_E_RUNTIME;
             }
-            const ncclResult_t r = R.AllReduce(k.dev, k.dev, size_t(count), kNcclFloat64, kNcclSum, k.comm, k.stream);
+            const ncclResult_t r = R.AllReduce(k.dev, k.dev, size_t(count), kNcclFloat64, kNcclSum, cm, k.stream);
+            {
+                std::lock_guard<std::mutex> lock(k.mu);
+                k.in_call = false;
+            }
+            k.cv.notify_all();
             if (r != 0)
             {
                 lbfgsx::set_error(std::string("ncclAllReduce: ") + (R.GetErrorString ? R.GetErrorString(r) : "RCCL error"));

@@ -96,6 +96,11 @@ int main()
     BVecs<double> b2{};
     b2.x0 = cv; b2.g = cv; b2.lb = cv; b2.ub = cv; b2.xcp = cv; b2.drt = cv; b2.brk = cv; b2.dvec = cv;
     b2.y = cv; b2.yfb = cv + ld; b2.lam = cv + 2 * ld; b2.mu = cv + 3 * ld; b2.rhs = cv + 4 * ld; b2.cF = cv + 5 * ld;
+    double* cv2;
+    CK(hipMalloc(&cv2, sizeof(double) * ld * 9));
+    BVecs<double> b3 = b2;
+    b3.y = cv2; b3.yfb = cv2 + ld; b3.lam = cv2 + 2 * ld; b3.mu = cv2 + 3 * ld; b3.rhs = cv2 + 4 * ld; b3.cF = cv2 + 5 * ld;
+    b3.st = reinterpret_cast<unsigned char*>(cv2 + 8 * ld);
     double* cli = cv + 6 * ld;
     double* cui = cv + 7 * ld;
     hipLaunchKernelGGL(k_fill_rand, dim3(4096), dim3(256), 0, 0, cli, npos, 0.0, -1e6);
@@ -122,6 +127,14 @@ int main()
     int* ridx;
     CK(hipMalloc(&ridx, sizeof(int) * npos));
     CK(hipMemset(ridx, 0, sizeof(int) * npos));
+    int* ridx2;
+    CK(hipMalloc(&ridx2, sizeof(int) * npos));
+    {
+        std::vector<int> h(npos);
+        for (int64_t i = 0; i < npos; i++)
+            h[i] = int((i * 2 < ld) ? i * 2 : i);  // every other row: the rows of a half-free set
+        CK(hipMemcpy(ridx2, h.data(), sizeof(int) * npos, hipMemcpyHostToDevice));
+    }
     CK(hipDeviceSynchronize());
     const bool quick = getenv("KX_QUICK") != nullptr;
     for (int tot : {20, 40})
@@ -137,6 +150,9 @@ int main()
         GramPrologue<double> pro;
         pro.mode = GP_RHS; pro.use1 = 1; pro.use2 = 1;
         for (int k = 0; k < 64; k++) { pro.c1[k] = k < tot ? 1e-9 * k : 0; pro.c2[k] = k < tot ? -1e-9 * k : 0; }
+        ProX<double> pnone;
+        pnone.mode = GP_NONE; pnone.use1 = 0; pnone.use2 = 0;
+        for (int k = 0; k < kColsX; k++) { pnone.c1[k] = 0; pnone.c2[k] = 0; }
         ProX<double> px;
         px.mode = GP_RHS; px.use1 = 1; px.use2 = 1;
         for (int k = 0; k < kColsX; k++) { px.c1[k] = k < tot ? 1e-9 * k : 0; px.c2[k] = k < tot ? -1e-9 * k : 0; }
@@ -159,14 +175,17 @@ int main()
             }
         }
 #define RUNX(NCL, G)                                                                                                                    \
-    for (int per_cu : {2, 3, 4})                                                                                                        \
+    for (int per_cu : {1, 2, 3})                                                                                                        \
     {                                                                                                                                   \
         const int grid = per_cu * 256;                                                                                                  \
         float t1 = timeit([&] { hipLaunchKernelGGL((kx_rows<double, NCL, G, 1, false>), dim3(grid), dim3(kBlock), 0, 0, cx, tot, b2, int(VS_NEG_RHS), int(ST_P), npos, wx, out, out + 256, px, gx, -1, -1); }); \
-        float t2 = timeit([&] { hipLaunchKernelGGL((kx_solve_sweep<double, NCL, G, 0, true>), dim3(grid), dim3(kBlock), 0, 0, cx, tot, b2, b2, int(VS_NEG_RHS), cfx, 1, 1.5, npos, wx, out, lu_list, lu_cnt, 1u << 18, ridx, cli, cui, 2); }); \
-        float t3 = timeit([&] { hipLaunchKernelGGL((kx_solve_sweep<double, NCL, G, 1, true>), dim3(grid), dim3(kBlock), 0, 0, cx, tot, b2, b2, int(VS_NEG_CF), cfx, 1, 1.5, npos, wx, out, lu_list, lu_cnt, 1u << 18, ridx, cli, cui, 2); }); \
+        float t2 = timeit([&] { hipLaunchKernelGGL((kx_solve_sweep<double, NCL, G, 0, true>), dim3(grid), dim3(kBlock), 0, 0, cx, tot, b2, b2, int(VS_NEG_RHS), cfx, 1, 1.5, npos, wx, out, lu_list, lu_cnt, 1u << 18, ridx, cli, cui, 2, pnone); }); \
+        float t3 = timeit([&] { hipLaunchKernelGGL((kx_solve_sweep<double, NCL, G, 1, true>), dim3(grid), dim3(kBlock), 0, 0, cx, tot, b2, b2, int(VS_NEG_CF), cfx, 1, 1.5, npos, wx, out, lu_list, lu_cnt, 1u << 18, ridx, cli, cui, 2, pnone); }); \
+        float t7 = timeit([&] { hipLaunchKernelGGL((kx_solve_sweep<double, NCL, G, 1, true>), dim3(grid), dim3(kBlock), 0, 0, cx, tot, b2, b3, int(VS_NEG_CF), cfx, 1, 1.5, npos, wx, out, lu_list, lu_cnt, 1u << 18, ridx2, cli, cui, 1, pnone); }); \
         float t4 = timeit([&] { hipLaunchKernelGGL((kx_rows<double, NCL, G, 3, false>), dim3(grid), dim3(kBlock), 0, 0, cx, tot, b2, int(VS_NEG_CF), int(ST_FREE), npos, wx, out, out + 256, px, gx, 3, tot / 2 + 3); }); \
-        printf("split (%d, %d), grid %4d: kx_rows<1> %6.1f us (%.2f TB/s)  kx_solve_sweep<0> %6.1f us (%.2f TB/s)  <1> %6.1f us  kx_rows<3> %6.1f us\n", NCL, G, grid, t1, bytes_rows / t1 / 1e6, t2, bytes_sweep / t2 / 1e6, t3, t4); \
+        float t5 = timeit([&] { hipLaunchKernelGGL((kx_solve_sweep<double, NCL, G, 0, true, true>), dim3(grid), dim3(kBlock), 0, 0, cx, tot, b2, b2, int(VS_NEG_RHS), cfx, 1, 1.5, npos, wx, out, lu_list, lu_cnt, 1u << 18, ridx, cli, cui, 2, px); }); \
+        float t6 = timeit([&] { hipLaunchKernelGGL((kx_multidot2_wf<double, NCL, G>), dim3(grid), dim3(kBlock), 0, 0, cx, tot, 3, tot / 2 + 3, b2.rhs, b2.y, b2.cF, ridx2, npos, cx, ridx2, 0, wx, out); }); \
+        printf("split (%d, %d), grid %4d: kx_rows<1> %6.1f us (%.2f TB/s)  kx_solve_sweep<0> %6.1f us (%.2f TB/s)  <1> %6.1f us  kx_rows<3> %6.1f us  solve_sweep<0,RHSK> %6.1f us (%.2f TB/s)  multidot2_wf %6.1f us  solve_sweep<1,cv=1 by row> %6.1f us\n", NCL, G, grid, t1, bytes_rows / t1 / 1e6, t2, bytes_sweep / t2 / 1e6, t3, t4, t5, (bytes_sweep + 8.0 * npos) / t5 / 1e6, t6, t7); \
     }
         if (tot == 20) { RUNX(10, 2) } else { RUNX(10, 4) }
         if (tot == 20)

@@ -19,7 +19,6 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/f32h_pmc_fetch -o bench -- 
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/f32h_pmc_write -o bench -- $HCMD > $O/f32h_pmc_write.log 2>&1
 # secondary workloads: kernel-trace stats only
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/lbfgsb -o b -- python scripts/bench_lbfgsb.py --n 1e7 --iters 40 > $O/lbfgsb.log 2>&1
-LBFGSX_GRAM=mfma rocprofv3 --kernel-trace --stats --output-format csv -d $O/lbfgsb_mfma -o b -- python scripts/bench_lbfgsb.py --n 1e7 --iters 40 > $O/lbfgsb_mfma.log 2>&1
 BCMD="python bench.py --workload cfg5-batched --steps 50 --no-cpu"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/batched_trace -o bench -- $BCMD > $O/batched_trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/batched_pmc_fetch -o bench -- $BCMD > $O/batched_pmc_fetch.log 2>&1
@@ -34,6 +33,5 @@ python bench.py --m 20 --steps 10 --warmup 22 --no-cpu > $O/bench_cfg3_m20.json 
 python bench.py --objective quadratic --n 10000000 --no-cpu > $O/bench_cfg2_quad1e7.json 2> /dev/null
 python bench.py --workload cfg5-batched --steps 50 > $O/bench_cfg5_batched.json 2> /dev/null
 python scripts/bench_lbfgsb.py --n 1e7 --iters 40 --cpu-n 2e5 > $O/bench_cfg4_lbfgsb.json 2> /dev/null
-LBFGSX_GRAM=mfma python scripts/bench_lbfgsb.py --n 1e7 --iters 40 > $O/bench_cfg4_lbfgsb_mfma.json 2> /dev/null
 LBFGSX_GCP_DEVICE_MIN=4096 python scripts/bench_lbfgsb.py --n 1e7 --iters 40 > $O/bench_cfg4_lbfgsb_devmin4096.json 2> /dev/null
 find $O -type f | wc -l

@@ -10,7 +10,10 @@ oracle's build key (oracle/_ref/build_key.txt: a hash of the reference headers, 
 compiler flags, written by oracle/Makefile): tests/test_gcp_device_gpu.py uses it only while the key matches the library
 it would otherwise have called.
 
-    python tests/golden/make_cfg4_trace.py [--iters 14]
+    python tests/golden/make_cfg4_trace.py [--iters 40] [--m 10]
+
+Round 5: the default is the benchmark's own 40 iterations (62 evaluations, ~5 minutes of one core), so that the always-on
+GPU test covers every iteration bench.py times; `--m 20 --iters 30` writes cfg4_1e7_m20_trace.npz for the m = 20 leg.
 """
 import argparse
 import os
@@ -24,7 +27,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as O  # noqa: E402
 
-N, M, STRIDE, FINAL_STRIDE = 10_000_000, 10, 4000, 500
+N, STRIDE, FINAL_STRIDE = 10_000_000, 4000, 500
 
 
 def build_key():
@@ -34,8 +37,10 @@ def build_key():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--iters", type=int, default=14)
+    ap.add_argument("--iters", type=int, default=40)
+    ap.add_argument("--m", type=int, default=10)
     args = ap.parse_args()
+    M = args.m
     key = build_key()
     if key is None or not O.available("ref", "dd"):
         raise SystemExit("oracle/_ref is not built (make -C oracle ref)")
@@ -48,7 +53,7 @@ def main():
     x, r = orc.lbfgsb(O.F64, O.OBJ_QUAD, np.zeros(N), lb, ub, p, a=a, b=b, trace=tr)
     dt = time.perf_counter() - t0
     k = tr.count
-    out = os.path.join(HERE, "cfg4_1e7_trace.npz")
+    out = os.path.join(HERE, "cfg4_1e7_trace.npz" if M == 10 else "cfg4_1e7_m%d_trace.npz" % M)
     np.savez(out, key=np.array(key), n=N, m=M, iters=args.iters, stride=STRIDE, final_stride=FINAL_STRIDE, niter=r.niter,
              nfev=r.nfev, fx=r.fx, fx_per_eval=tr.fx[:k].copy(), xs=tr.xs[:k].copy(), x_final=x[::FINAL_STRIDE].copy(),
              n_active=int((np.abs(x) == 1.0).sum()), active_sample=(np.abs(x[::FINAL_STRIDE]) == 1.0),

@@ -20,8 +20,29 @@ def _run(*extra, gpus=1, warmup=12, env=None):
     return json.loads(lines[0])
 
 
-def test_default_line_has_the_contract_keys():
-    d = _run("--cpu-n", "2000000", "--cpu-steps", "4", "--cpu-n-all", "2000000", "--cpu-full", "off")
+def test_default_line_has_the_contract_keys(tmp_path):
+    full = str(tmp_path / "full.json")
+    line = _run("--cpu-n", "2000000", "--cpu-steps", "4", "--cpu-n-all", "2000000", "--cpu-full", "off", "--full-json", full)
+    # The default line is the compact one: under 7 KB (the driver keeps the last 8 KB of it), the contract keys and the two
+    # required objects at the top, every leg reduced to its figures, and `legs_digest` as the LAST key so that whatever tail
+    # survives holds every leg's value and fractions.  The full object (--verbose prints it, --full-json writes it) is what
+    # the rest of this test reads.
+    raw = json.dumps(line)
+    assert len(raw) < 7168, "the default line has grown to %d bytes" % len(raw)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert list(line)[-1] == "legs_digest"
+    dig = line["legs_digest"]
+    assert sorted(dig) == sorted(["north_star", "cfg2", "cfg3", "cfg4_lbfgsb", "cfg4_m20", "cfg5_batched"])
+    for name, e in dig.items():
+        assert e["value"] > 0 and e["ms_per_step"] > 0 and 0.0 < e["frac"] <= 1.0, (name, e)   # a fraction is at most 1
+    assert dig["cfg4_lbfgsb"]["from_x0"] < dig["cfg4_lbfgsb"]["value"] and 0.0 < dig["cfg4_lbfgsb"]["frac_from_x0"] <= 1.0
+    assert abs(dig["north_star"]["value"] - line["value"]) < 1e-3 * line["value"]
+    for leg in ("cfg2", "cfg3", "cfg4_lbfgsb", "cfg4_m20", "cfg5_batched"):
+        assert line[leg]["value"] > 0 and 0.0 < line[leg]["roofline"]["frac"] <= 1.0 and "workload" in line[leg]["config"]
+    d = json.load(open(full))
+    assert abs(d["value"] - line["value"]) < 1e-12 * d["value"] and d["ms_per_step"] == line["ms_per_step"]
     assert d["metric"] == "L-BFGS iterations/sec at n=10^8, m=10; achieved HBM GB/s vs peak"   # BASELINE.json's metric
     assert d["unit"] == "iterations/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 12
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
@@ -62,8 +83,16 @@ def test_default_line_has_the_contract_keys():
     assert 10 < cc["launches_per_iteration"] < 500 and 1 < cc["host_syncs_per_iteration"] < 200 and cc["copies_per_iteration"] >= 0
     r4 = c4["roofline"]
     assert r4["bound"] == "hbm" and r4["kernel"] and abs(r4["frac"] - r4["achieved"] / 8000.0) < 1e-12 and 0.1 < r4["frac"] < 1.0
-    assert abs(r4["achieved"] - r4["algorithmic_bytes"] * c4["value"] / 1e9) < 1e-6 * r4["achieved"]
-    assert r4["frac_from_x0"] < r4["frac"]
+    # the numerator is the byte model of the path as built (lbfgsx_counters_ex): what the launches of the window had to move
+    assert abs(r4["achieved"] - r4["model_bytes"] * c4["value"] / 1e9) < 1e-6 * r4["achieved"]
+    assert r4["frac_from_x0"] < r4["frac"] <= 1.0
+    assert 2.0 <= cc["compact_passes_per_iteration"] <= 12.0 and 0.2 * cc["n"] < cc["n_free"] < 0.8 * cc["n"]
+    # ... at least the columns of those passes, and within 10 % of what the counters saw where a PMC summary of this very
+    # leg is committed (profiles/*_legs_pmc_summary.json)
+    assert r4["model_bytes"] > cc["compact_passes_per_iteration"] * cc["n_free"] * 2 * cc["m"] * 8
+    if r4["traffic"] is not None:
+        assert abs(r4["model_over_traffic"] - r4["model_bytes"] / r4["traffic"]) < 1e-12
+        assert 0.90 <= r4["model_over_traffic"] <= 1.10, "byte model %.3g vs counters %.3g" % (r4["model_bytes"], r4["traffic"])
     # both sides of the steady fraction come from the SAME iterations: the second half of the run (the library's counters and
     # the solver's statistics snapshotted at the iteration hook), value = 1 / mean, the median beside it
     w = cc["window"]
@@ -75,7 +104,8 @@ def test_default_line_has_the_contract_keys():
     assert abs(cc["q"] - cc["submin_sweeps"] / cc["submin_calls"]) < 1e-12
     m_, n_ = cc["m"], cc["n"]
     want = ((4 * m_ + 19) + (cc["q"] + 1.0) * (4 * m_ + 1)) * n_ * 8 + 96.0 * cc["n_sorted"]
-    assert abs(r4["algorithmic_bytes"] - want) < 1e-9 * want
+    assert abs(r4["reference_statement_bytes"] - want) < 1e-9 * want   # SURVEY 8(d)'s statement count, for comparison only
+    assert r4["model_bytes"] < r4["reference_statement_bytes"]
     fx0 = c4["from_x0"]
     assert fx0["q"] >= 1.0 and fx0["launches_per_iteration"] > cc["launches_per_iteration"] * 0.5
     assert (r4["traffic"] is None) == (r4["traffic_source"] is None)
@@ -84,6 +114,7 @@ def test_default_line_has_the_contract_keys():
     assert c20["config"]["m"] == 20 and c20["steps"] == 60 and c20["config"]["window"]["history_full"] is True
     assert c20["config"]["window"]["first_iteration"] == 30 and c20["config"]["gram_carried"] >= 15
     assert c20["value"] > 0.45 * c4["value"], "m = 20 moves 1.9x the bytes of m = 10: %.1f vs %.1f it/s" % (c20["value"], c4["value"])
+    assert 0.1 < c20["roofline"]["frac"] <= 1.0 and 1.3 * r4["model_bytes"] < c20["roofline"]["model_bytes"] < 2.2 * r4["model_bytes"]
     for leg in ("cfg2", "cfg3", "cfg5_batched"):
         rr = d[leg]["roofline"]
         assert (rr["traffic"] is None) == (rr.get("traffic_source") is None)

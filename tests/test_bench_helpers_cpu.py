@@ -63,3 +63,25 @@ def test_pmc_legs_matches_the_two_counter_passes_dispatch_by_dispatch(tmp_path):
     per_kernel = (2 * 100.0 + 50.0) * 1024
     assert abs(legs[0]["hbm_bytes"] - 2 * 2 * per_kernel) < 1e-6          # window: 2 kernels per iteration at scale 2
     assert abs(legs[0]["hbm_bytes_from_x0"] - 2 * per_kernel * 1.5) < 1e-6  # 20 iterations at 1, 20 at 2
+
+
+def test_the_default_line_is_compact_and_ends_with_the_digest_of_every_leg():
+    """The driver keeps the last 8 KB of bench.py's one line.  The default line is the compact form of the full object: notes and
+    per-iteration lists dropped, every leg reduced to its figures, `legs_digest` appended as the last key.  Checked here on the
+    full line of an earlier round (profiles/r4_bench_default.json, 15 KB)."""
+    b = _bench()
+    full = json.load(open(os.path.join(ROOT, "profiles", "r4_bench_default.json")))
+    line = dict(full)
+    for name in b.LEGS:
+        line[name] = b.compact_leg(line[name])
+    line = b.compact_line(line)
+    line["legs_digest"] = b.legs_digest(full)
+    raw = json.dumps(line)
+    assert len(raw) < 7168 and list(line)[-1] == "legs_digest"
+    tail = raw[-1500:]                       # what survives a cut well inside the driver's 8 KB
+    for name in ("north_star", "cfg2", "cfg3", "cfg4_lbfgsb", "cfg4_m20", "cfg5_batched"):
+        assert '"%s": {"value"' % name in tail
+    assert line["value"] == full["value"] and line["ms_per_step"] == full["ms_per_step"]          # digit for digit
+    assert line["cfg4_lbfgsb"]["config"]["fx"] == full["cfg4_lbfgsb"]["config"]["fx"]
+    assert "note" not in line["cfg4_lbfgsb"]["roofline"] and "per_iteration_ms" not in line["cfg4_lbfgsb"]["config"]
+    assert line["roofline"]["frac"] == float("%.7g" % full["roofline"]["frac"]) and "sample" in line["cpu_baseline"]

@@ -89,24 +89,26 @@ def test_cfg4_parity_at_size(A, boracle, monkeypatch, n, iters, devmin):
     assert abs(fx - r_ref.fx) <= 1e-11 * abs(r_ref.fx)
 
 
-def test_cfg4_parity_at_size_over_14_iterations_against_the_cached_reference_trace(A):
-    """The same comparison over 14 iterations (35 objective evaluations) of the benchmark's own instance without paying the
-    reference's ~280 s of one host core on every run: tests/golden/cfg4_1e7_trace.npz holds what oracle/_ref produced for
-    it (tests/golden/make_cfg4_trace.py: the objective value and every 4000th coordinate at every evaluation, every 500th
-    coordinate of the final iterate, the counts, the size of the active set) and the key of the oracle build it came from
-    (oracle/_ref/build_key.txt: reference headers + stand-in Eigen + driver + flags).  A stale key means the reference side
-    has changed since the trace was taken: the test then refuses to judge instead of comparing against the wrong thing."""
+@pytest.mark.parametrize("m,fname,min_iters", [(10, "cfg4_1e7_trace.npz", 40), (20, "cfg4_1e7_m20_trace.npz", 30)])
+def test_cfg4_parity_at_size_over_the_benchmark_iterations_against_the_cached_reference_trace(A, m, fname, min_iters):
+    """The same comparison over ALL 40 iterations (62 objective evaluations) bench.py's cfg4 leg times -- and over 30
+    iterations of the m = 20 leg -- without paying the reference's 15-20 minutes of one host core on every run:
+    tests/golden/cfg4_1e7*_trace.npz hold what oracle/_ref produced (tests/golden/make_cfg4_trace.py: the objective value and
+    every 4000th coordinate at every evaluation, every 500th coordinate of the final iterate, the counts, the size of the
+    active set) and the key of the oracle build they came from (oracle/_ref/build_key.txt: reference headers + stand-in
+    Eigen + driver + flags).  A stale key means the reference side has changed since the trace was taken: the test then
+    refuses to judge instead of comparing against the wrong thing.  Covers HEAD by construction: every driver run repeats it."""
     import os
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg4_1e7_trace.npz")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", fname)
     keyf = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "build_key.txt")
     if not os.path.exists(path):
-        pytest.skip("tests/golden/cfg4_1e7_trace.npz missing (python tests/golden/make_cfg4_trace.py)")
+        pytest.skip("tests/golden/%s missing (python tests/golden/make_cfg4_trace.py --m %d)" % (fname, m))
     g = np.load(path)
     if os.path.exists(keyf) and open(keyf).read().strip() != str(g["key"]):
-        pytest.fail("tests/golden/cfg4_1e7_trace.npz was taken from another oracle build: regenerate it "
-                    "(python tests/golden/make_cfg4_trace.py)")
-    n, m, iters, stride, fstride = int(g["n"]), int(g["m"]), int(g["iters"]), int(g["stride"]), int(g["final_stride"])
-    assert (n, m) == (10_000_000, 10) and iters >= 12
+        pytest.fail("tests/golden/%s was taken from another oracle build: regenerate it "
+                    "(python tests/golden/make_cfg4_trace.py --m %d --iters %d)" % (fname, m, min_iters))
+    n, iters, stride, fstride = int(g["n"]), int(g["iters"]), int(g["stride"]), int(g["final_stride"])
+    assert (n, int(g["m"])) == (10_000_000, m) and iters >= min_iters
     a, b = O.quad_problem(n, 10.0, 1, O.F64)
     lb, ub = -np.ones(n), np.ones(n)
     s = A.LBFGSBSolver(A.LBFGSBParam(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters))
@@ -125,6 +127,8 @@ def test_cfg4_parity_at_size_over_14_iterations_against_the_cached_reference_tra
     assert np.abs(x[::fstride] - g["x_final"]).max() <= 1e-10
     assert np.array_equal(np.abs(x[::fstride]) == 1.0, g["active_sample"]) and int((np.abs(x) == 1.0).sum()) == int(g["n_active"])
     assert abs(fx - float(g["fx"])) <= 1e-11 * abs(float(g["fx"]))
+    print("cfg4 m=%d: %d iterations / %d evaluations against the cached reference trace: max |dx| per evaluation %.3g, final %.3g"
+          % (m, niter, k, per_eval.max(), np.abs(x[::fstride] - g["x_final"]).max()))
 
 
 @pytest.mark.parametrize("n,m,npairs,mode", [(50000, 6, 6, "hard"), (200000, 10, 10, "edge"), (4096, 8, 0, "hard")])
