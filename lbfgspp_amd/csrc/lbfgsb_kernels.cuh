@@ -1213,7 +1213,7 @@ static __global__ void __launch_bounds__(kBlock) k_gram_finish(const double* __r
         }
         if (done)  // completion word (RedWs::done); the host passes it only to a single-block final launch
         {
-            __threadfence_system();
+            out_fence_sys();
             __syncthreads();
             if (e == 0)
                 __hip_atomic_store(done, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

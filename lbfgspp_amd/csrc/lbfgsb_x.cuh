@@ -370,7 +370,7 @@ __global__ void __launch_bounds__(kBlock, occ_rows_x(NCL, G, NA))
                     out_dd[2 * idx] = mine.hi;
                     out_dd[2 * idx + 1] = acc_lo(mine);
                 }
-                __threadfence_system();
+                out_fence_sys();
             }
         }
         __syncthreads();
@@ -448,9 +448,12 @@ __global__ void __launch_bounds__(kBlock, occ_sweep_x(NCL, G, FIRST))
         T xa, xb, yold, la, ua, x0i, cfi;
         unsigned char st0;
     };
+    // (with the vectors at the positions -- cv = 2, every sweep of the steady state -- the row number is only needed by a row
+    // that enters the L u U list: it is fetched there, by the few lanes that append, not for every position: 4 bytes per
+    // position and two registers per set less, ~10 % of the pass in scripts/experiments/kernels_x.hip)
     auto rowof = [&](int64_t base) __attribute__((always_inline)) -> int64_t {
         const int64_t t = base + L.rr, tc = t < n ? t : last;
-        return IDX ? int64_t(ridx[tc]) : tc;
+        return (IDX && !cvt) ? int64_t(ridx[tc]) : tc;
     };
     auto fetch = [&](int64_t base, int64_t i, Buf& x) __attribute__((always_inline)) {
         const int64_t t = base + L.rr, tc = t < n ? t : last;
@@ -546,7 +549,15 @@ __global__ void __launch_bounds__(kBlock, occ_sweep_x(NCL, G, FIRST))
             app = (s2 & (ST_L | ST_U)) != 0;
         }
         if (lu_cap && !(LBFGSX_X_DBG & 256))
-            lu_append(app, i, lu_list, lu_cnt, lu_cap);  // the list holds rows
+        {
+            if (IDX && cvt)
+            {
+                if (__ballot(app))  // wave-uniform; rare in steady state
+                    lu_append(app, app ? int64_t(ridx[t]) : int64_t(0), lu_list, lu_cnt, lu_cap);
+            }
+            else
+                lu_append(app, i, lu_list, lu_cnt, lu_cap);  // the list holds rows
+        }
     };
     {
         int64_t base = (int64_t(blockIdx.x) * kWaves + L.wave) * RPW;
@@ -583,13 +594,13 @@ __global__ void __launch_bounds__(kBlock, occ_sweep_x(NCL, G, FIRST))
                 if (col < ncols)
                 {
                     out[col] = double(T(tot.value()));
-                    __threadfence_system();
+                    out_fence_sys();
                 }
             }
             else if (gg == G - 1)
             {
                 out[(FIRST ? 0 : ncols) + (k - ND)] = tot.value();
-                __threadfence_system();
+                out_fence_sys();
             }
         }
         if (s == 0 && FIRST)
@@ -716,7 +727,7 @@ __global__ void __launch_bounds__(kBlock, occ_dots_x(NCL))
             if (col < ncols)
             {
                 out[which * ncols + col] = double(T(tot.value()));
-                __threadfence_system();
+                out_fence_sys();
             }
         }
         __syncthreads();
@@ -775,7 +786,7 @@ __global__ void __launch_bounds__(kBlock, occ_dots_x(NCL))
             if (col < ncols)
             {
                 out[which * ncols + col] = double(T(tot.value()));
-                __threadfence_system();
+                out_fence_sys();
             }
         }
         __syncthreads();
@@ -854,7 +865,7 @@ __global__ void __launch_bounds__(kBlock, occ_dots_x(NCL))
             if (idx >= 0)
             {
                 out[idx] = double(T(tot.value()));
-                __threadfence_system();
+                out_fence_sys();
             }
         }
         __syncthreads();
@@ -928,7 +939,7 @@ __global__ void __launch_bounds__(kBlock, occ_mask_x(NCL))
                     out_dd[2 * idx] = tot.hi;
                     out_dd[2 * idx + 1] = acc_lo(tot);
                 }
-                __threadfence_system();
+                out_fence_sys();
             }
         }
         __syncthreads();
@@ -1017,7 +1028,7 @@ __global__ void __launch_bounds__(kBlock, occ_mask_x(NCL))
             if (idx >= 0)
             {
                 out[idx] = double(T(tot.value()));
-                __threadfence_system();
+                out_fence_sys();
             }
         }
         __syncthreads();
@@ -1229,7 +1240,7 @@ __global__ void __launch_bounds__(kBlock)
         }
         if (done)
         {
-            __threadfence_system();
+            out_fence_sys();
             __syncthreads();
             if (tid == 0)
                 __hip_atomic_store(done, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1270,7 +1281,7 @@ static __global__ void __launch_bounds__(kBlock) kx_gram_finish(const double* __
         }
         if (done)  // completion word (RedWs::done): the last of the ntile blocks to finish publishes it
         {
-            __threadfence_system();
+            out_fence_sys();
             __syncthreads();
             if (e == 0)
             {

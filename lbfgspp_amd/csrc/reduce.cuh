@@ -133,12 +133,18 @@ struct RedWs
     unsigned long long* done = nullptr;
     unsigned long long seq = 0;
 };
+// What a thread does between storing results the host will read and the completion word: a system-scope release.  (Round 5
+// tried to do with less -- the results live in host-mapped coherent memory, so wait for the stores' acknowledgement only and
+// skip the write-back of the L2 that __threadfence_system() performs.  Wrong on gfx950: a plain store to fine-grained memory
+// may still sit in the L2 until a system-scope write-back; the host then reads stale sums.  Coherence comes from the sc0 sc1
+// bits of the instruction or from this fence, not from the page.)
+__device__ __forceinline__ void out_fence_sys() { __threadfence_system(); }
 // thread 0 of the last block, after it has written the kernel's results
 __device__ __forceinline__ void ws_signal(const RedWs& ws)
 {
     if (ws.done)
     {
-        __threadfence_system();
+        out_fence_sys();
         __hip_atomic_store(ws.done, ws.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }

@@ -44,8 +44,16 @@ def main():
     L.check(core.lbfgsx_fill(ctx, L.VEC_LB, -1.0))
     L.check(core.lbfgsx_fill(ctx, L.VEC_UB, 1.0))
     L.check(core.lbfgsx_sync(ctx))
-    stamps = []
-    s.set_iteration_hook(lambda k: stamps.append(time.perf_counter()))
+    import ctypes as C
+    stamps, csnaps = [], []
+    cnt = (C.c_int64 * 8)()
+
+    def hook(k):
+        stamps.append(time.perf_counter())
+        core.lbfgsx_counters_ex(C.byref(cnt), 0)
+        csnaps.append(tuple(cnt[i] for i in range(6)))
+    s.set_iteration_hook(hook)
+    core.lbfgsx_counters_ex(None, 1)
     t0 = time.perf_counter()
     niter, fx = s.minimize_resident(A.DiagQuadratic(), n)
     t1 = time.perf_counter()
@@ -53,7 +61,18 @@ def main():
     out = dict(n=n, m=args.m, warmup=not args.no_warmup, niter=niter, nfev=s.last.nfev, fx=fx, total_s=t1 - t0, it_per_s=niter / (t1 - t0),
                steady_it_per_s=float(1.0 / np.median(per[len(per) // 2:])) if len(per) > 4 else None,
                per_iter_ms=[round(1e3 * v, 2) for v in per], stats=s.stats())
-    import ctypes as C
+    if len(csnaps) >= 4:
+        # the byte model of the path as built (lbfgsx_counters_ex) over the steady window = the second half of the iterations,
+        # and what it gives against the mean iteration time of the same window (bench.py's cfg4 leg does the same)
+        w0 = len(csnaps) // 2
+        a_c, b_c = csnaps[w0 - 1], csnaps[-1]
+        nwin = len(csnaps) - w0
+        win_s = float(np.mean(per[w0:w0 + nwin]))
+        out["model"] = dict(bytes_per_iteration=(b_c[3] - a_c[3]) / nwin, compact_passes_per_iteration=(b_c[4] - a_c[4]) / nwin,
+                            n_free=(b_c[5] - a_c[5]) / max(1, b_c[4] - a_c[4]), launches_per_iteration=(b_c[0] - a_c[0]) / nwin,
+                            host_syncs_per_iteration=(b_c[1] - a_c[1]) / nwin, window_ms_per_iteration=win_s * 1e3,
+                            model_GBs=(b_c[3] - a_c[3]) / nwin / win_s / 1e9, frac=(b_c[3] - a_c[3]) / nwin / win_s / 8e12,
+                            bytes_per_iteration_from_x0=csnaps[-1][3] / len(csnaps))
     pc = (C.c_int64 * 2)()
     core.lbfgsx_poll_counts(ctx, C.byref(pc))
     out["polled_waits"], out["poll_timeouts"] = int(pc[0]), int(pc[1])

@@ -121,3 +121,39 @@ for it in (1, 2, 5, 10):
         print("%8.3f ms  %5d calls  %8.1f us avg  %s" % (t / 1e6, c, t / c / 1e3, k))
     big.sort(reverse=True)
     print("   largest gaps: " + "; ".join("%.0f us %s -> %s" % g for g in big[:8]))
+
+# Round 5: what the benchmark calls the FIRST iteration -- everything of the big run before its second post-line-search
+# launch (the initial evaluation, the first Cauchy search over all n break points, the first line search with its 20 trials,
+# the first post) -- which the iteration boundaries above leave out.  The big run starts at the first kernel after the
+# warm-up solve's last post.
+allposts = [i for i, r in enumerate(rows) if "k_b_post" in r[2]]
+first_big = allposts[-(int(os.environ.get("TL_ITERS", "40")))]
+prev_small = [i for i in allposts if i < first_big]
+start = (prev_small[-1] + 1) if prev_small else 0
+# skip the tail of the warm-up solve (its last line search etc.): the big run begins with the generator / fill kernels
+for i in range(start, first_big):
+    if "k_gen" in rows[i][2] or "fill" in rows[i][2].lower():
+        start = i
+        break
+seg0 = rows[start:first_big + 1]
+if seg0:
+    wall0 = (rows[first_big][1] - seg0[0][0]) / 1e6
+    busy0 = sum(e - s for s, e, _ in seg0) / 1e6
+    print("\n--- before and including the first post launch of the big run: wall %.2f ms, kernels %.2f ms, idle %.2f ms, %d launches ---"
+          % (wall0, busy0, wall0 - busy0, len(seg0)))
+    agg0 = collections.OrderedDict()
+    for s, e, n in seg0:
+        a = agg0.setdefault(short(n), [0, 0])
+        a[0] += 1
+        a[1] += e - s
+    for k, (c, t) in sorted(agg0.items(), key=lambda kv: -kv[1][1])[:16]:
+        print("%8.3f ms  %5d calls  %8.1f us avg  %s" % (t / 1e6, c, t / c / 1e3, k))
+    gaps0 = []
+    prev_end = seg0[0][0]
+    for s, e, n in seg0:
+        if s - prev_end > 20e3:
+            gaps0.append(((s - prev_end) / 1e3, (s - seg0[0][0]) / 1e6, short(n)))
+        prev_end = max(prev_end, e)
+    print("gaps above 20 us (us, at ms, before kernel):")
+    for g in sorted(gaps0, reverse=True)[:14]:
+        print("  %9.1f us at %7.2f ms before %s" % g)

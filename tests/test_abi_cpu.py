@@ -55,6 +55,9 @@ def test_null_context_is_an_invalid_argument_not_a_crash(libs):
     assert core.lbfgsx_device(None) == -1
     out = (C.c_int64 * 3)()
     assert core.lbfgsx_counters(C.byref(out), 0) == 0 and all(v >= 0 for v in out)   # process-wide, needs no context
+    ex = (C.c_int64 * 8)()
+    assert core.lbfgsx_counters_ex(C.byref(ex), 1) == 0 and list(ex)[:3] == list(out) and all(v >= 0 for v in ex)
+    assert core.lbfgsx_counters_ex(C.byref(ex), 0) == 0 and list(ex) == [0] * 8          # reset by the call before
     out4 = (C.c_int64 * 4)()
     assert core.lbfgsx_b_compact_vec_counts(C.byref(out4), 0) == 0 and all(v >= 0 for v in out4)  # process-wide as well
     out2 = (C.c_int64 * 2)()

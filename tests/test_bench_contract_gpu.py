@@ -114,7 +114,7 @@ def test_default_line_has_the_contract_keys(tmp_path):
     assert c20["config"]["m"] == 20 and c20["steps"] == 60 and c20["config"]["window"]["history_full"] is True
     assert c20["config"]["window"]["first_iteration"] == 30 and c20["config"]["gram_carried"] >= 15
     assert c20["value"] > 0.45 * c4["value"], "m = 20 moves 1.9x the bytes of m = 10: %.1f vs %.1f it/s" % (c20["value"], c4["value"])
-    assert 0.1 < c20["roofline"]["frac"] <= 1.0 and 1.3 * r4["model_bytes"] < c20["roofline"]["model_bytes"] < 2.2 * r4["model_bytes"]
+    assert 0.1 < c20["roofline"]["frac"] <= 1.0 and 1.15 * r4["model_bytes"] < c20["roofline"]["model_bytes"] < 2.2 * r4["model_bytes"]
     for leg in ("cfg2", "cfg3", "cfg5_batched"):
         rr = d[leg]["roofline"]
         assert (rr["traffic"] is None) == (rr.get("traffic_source") is None)

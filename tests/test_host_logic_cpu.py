@@ -245,3 +245,24 @@ def test_gram_space_direction_equals_vector_two_loop(hl, n, m, K, reject):
             d = d + coef[j] * S[slots[j]] + coef[m + j] * Y[slots[j]]
     ref = _two_loop(S, Y, kept[::-1], G[K], -1.0)
     assert np.linalg.norm(d - ref) <= 1e-9 * np.linalg.norm(ref)
+
+
+def test_sums_over_L_u_U_are_used_by_the_solve_that_follows_their_pass_only(tmp_path):
+    """Advisor finding (round 4): W_{L u U}'(-c), left un-rounded by Wtv_lu for the 'W_P'rhs without a pass' identity of
+    BFGSMatB::solve_PtBP, must not survive a solve that does not consume it -- a later sweep with an empty L or U never
+    calls Wtv_lu, and would have combined the OLD partition's sums with the new partition's Gram.  Host code against a mock of
+    the C ABI (tests/cpp/mock_bfgsmat_capi.cpp); the log lists the device entries each sweep's solve called."""
+    out = str(tmp_path / "libmockbfgs.so")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(HERE, "cpp", "mock_bfgsmat_capi.cpp"), "-o", out])
+    lib = C.CDLL(out)
+    lib.mock_sweep_sequence.restype = C.c_char_p
+    lib.mock_sweep_sequence.argtypes = [C.c_int]
+    env = dict(os.environ)
+    first, second = [s.split() for s in lib.mock_sweep_sequence(0).decode().split("|")]
+    assert "wtv_lu_c" in first and "gram_fused_ex" in first and "solve_sweep_rhs" not in first        # sweep k: the one-pass Gram
+    assert "solve_sweep_rhs" not in second, "sweep k + 1 used the sums of sweep k's partition: %r" % second
+    assert "wtv_prologue" in second and "gram_fused_dd" in second                                     # complement branch, v row by a pass
+    # control: with Wtv_lu right before it the same solve does use the identity (and no v-row pass)
+    first, second = [s.split() for s in lib.mock_sweep_sequence(1).decode().split("|")]
+    assert "solve_sweep_rhs" in second and "wtv_prologue" not in second, second
