@@ -1018,6 +1018,10 @@ def run_all(args, rank, world, local, comm_dev, dist, batched=True):
 # 8 KB of the one JSON line; the default line is held under 7 KB and ends with `legs_digest`, so that every leg's figures are
 # in whatever tail survives.
 VERBOSE_ONLY = ("note", "per_iteration_ms", "traffic_source", "traffic_per", "achieved_is", "instance", "how")
+# secondary figures of the headline's own objects that only the --verbose line carries
+VERBOSE_ONLY_TOP = ("max_abs_dx_at", "x_inf_norm", "max_abs_dx_strided_sample", "stream_triad_GBs", "apply_Hv_GBs",
+                    "hbm_model_bytes_per_launch", "fused_post_launches_timed", "warmup_run", "problems_per_gpu", "traffic_static",
+                    "algorithmic_GBs", "timed_iterations", "seconds_per_iteration", "measured_value")
 FULL_PRECISION = ("fx", "value", "ms_per_step", "max_abs_dx", "fx_rel", "seconds")
 
 
@@ -1025,10 +1029,11 @@ def compact_line(o, key=None, depth=0):
     """The default line: explanations dropped below the top level (the headline's own stay), strings cut at 200 characters,
     floats to 7 significant digits except the ones compared digit by digit (FULL_PRECISION)."""
     if isinstance(o, dict):
-        return {k: compact_line(v, k, depth + 1) for k, v in o.items() if not (depth >= 1 and k in VERBOSE_ONLY)}
+        return {k: compact_line(v, k, depth + 1) for k, v in o.items()
+                if not (depth >= 2 and k in VERBOSE_ONLY) and not (depth >= 1 and k in VERBOSE_ONLY_TOP)}
     if isinstance(o, list):
         return [compact_line(v, key, depth + 1) for v in o]
-    if isinstance(o, float) and key not in FULL_PRECISION:
+    if isinstance(o, float) and key not in FULL_PRECISION and not str(key).startswith("fx"):
         return float("%.7g" % o)
     if isinstance(o, str) and len(o) > 160 and depth > 1:
         return o[:157] + "..."
@@ -1036,8 +1041,8 @@ def compact_line(o, key=None, depth=0):
 
 
 LEG_KEEP = {
-    "": ("value", "unit", "steps", "warmup", "ms_per_step", "value_median", "dtype", "from_x0", "config", "roofline"),
-    "config": ("workload", "n", "m", "q", "n_free", "n_ord", "window", "iterations", "fevals_total", "fx", "history_full",
+    "": ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "from_x0", "config", "roofline"),
+    "config": ("workload", "n", "m", "q", "n_free", "iterations", "fevals_total", "fx", "history_full",
                "problems_total", "failed", "host_syncs_per_iteration", "launches_per_iteration", "compact_passes_per_iteration"),
     "roofline": ("bound", "achieved", "peak", "unit", "frac", "frac_from_x0", "traffic", "traffic_frac", "traffic_GBs",
                  "model_bytes", "model_bytes_from_x0", "reference_statement_bytes", "avg_launch_ms", "hbm_model_GBs",
@@ -1057,8 +1062,8 @@ def compact_leg(leg):
         v = leg[k]
         if k in LEG_KEEP and isinstance(v, dict):
             v = {kk: v[kk] for kk in LEG_KEEP[k] if kk in v}
-            if isinstance(v.get("workload"), str) and len(v["workload"]) > 120:
-                v["workload"] = v["workload"][:117] + "..."
+            if isinstance(v.get("workload"), str) and len(v["workload"]) > 90:
+                v["workload"] = v["workload"][:87] + "..."
         out[k] = v
     return out
 

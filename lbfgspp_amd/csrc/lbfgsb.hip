@@ -44,6 +44,9 @@ struct lbfgsb_state
     unsigned char* st = nullptr;
     void *keys_in = nullptr, *keys_out = nullptr;
     int *vals_in = nullptr, *vals_out = nullptr;
+    bool keys_valid = false;   // keys_in holds the sort keys of the break points in brk (a build may leave them out: ensure_keys)
+    bool vals_iota = false;    // vals_in holds 0..n-1 (written by the first build, never changed by the sorts, which write vals_out)
+    bool keys_lazy = true;     // LBFGSX_KEYS_LAZY=0: every build writes keys and indices (A/B, tests)
     void* sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     int* phys_dev = nullptr;          // logical slot -> physical column, device copy
@@ -156,6 +159,9 @@ struct lbfgsb_state
     // neither (no sweeps expected, a fallback Gram, an early return) leaves a copy that misses that iteration's new columns
     long long sub_epoch = 0;              // subspace minimisations opened (lbfgsx_b_sub_begin)
     long long wf_epoch = -2;              // the one that last wrote or patched the copy
+    long long wf_patched_epoch = -2;      // sub_epoch at which the W'd pass wrote the replaced pair into the copy ...
+    int wf_patched_slot = -1;             // ... and the storage slot it wrote
+    bool wf_prepatch = true;              // LBFGSX_WF_PREPATCH=0: leave the patch to the carried Gram's pass (A/B, tests)
     int* wf_pos = nullptr;                // [n] row -> position, -1: none
     double* g_host = nullptr;             // pinned landing zone of lbfgsx_b_cauchy_chunk
     // the first chunk of the sorted break points, gathered and copied behind the build's sort and ahead of its W'd pass: it
@@ -535,6 +541,10 @@ int bounded_alloc(lbfgsx_ctx* c)
             warned = true;
         }
     }
+    if (const char* e = getenv("LBFGSX_KEYS_LAZY"))
+        b->keys_lazy = atoi(e) != 0;
+    if (const char* e = getenv("LBFGSX_WF_PREPATCH"))
+        b->wf_prepatch = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_GCP_CHAIN"))
         b->chain_host = std::strcmp(e, "scan") != 0;
     if (const char* e = getenv("LBFGSX_DOTS_GRID"))
@@ -698,6 +708,24 @@ static RedWsX wsx(lbfgsx_ctx* c)  // after poll_arm: carries the completion word
     w.done = c->ws.done;
     w.seq = c->ws.seq;
     return w;
+}
+// keys_in / vals_in as a full radix sort (or a selection over all n keys) reads them: rebuilt from brk when the build left them
+// out (k_b_post_build with the partial sort's candidates listed in the pass: lbfgsx_b_post_linesearch_build)
+static int ensure_keys(lbfgsx_ctx* c)
+{
+    lbfgsb_state* b = c->bstate;
+    if (b->keys_valid && b->vals_iota)
+        return LBFGSX_OK;
+    const int grid = c->grid_for(c->n);
+    DISPATCH_T(c, {
+        lbfgsx::model_add(double(c->n) * (2 * sizeof(T) + (b->vals_iota ? 0 : 4)));
+        LBFGSX_LAUNCH((k_keys_from_brk<T>), dim3(grid), dim3(kBlock), 0, c->stream, static_cast<const T*>(b->brk),
+                      static_cast<T*>(b->keys_in), b->vals_iota ? static_cast<int*>(nullptr) : b->vals_in, c->n);
+    });
+    LBFGSX_HIP(hipGetLastError());
+    b->keys_valid = true;
+    b->vals_iota = true;
+    return LBFGSX_OK;
 }
 // a mask inside the free set can be served from the compact copy
 static inline bool wf_serves(const lbfgsx_ctx* c, int mask)
@@ -1001,11 +1029,17 @@ static int wtd2_wf_x(lbfgsx_ctx* c, int total, int newest, double* wtd)
     wfc.p[fresh_b] = wfc.p[stand_in];
     const T* snew = static_cast<const T*>(c->col(c->S, c->phys[size_t(newest)]));
     const T* ynew = static_cast<const T*>(c->col(c->Y, c->phys[size_t(newest)]));
+    // the pass also writes the new pair into the copy (lbfgsb_x.cuh: kx_multidot2_wf, dst_a / dst_b): the carried Gram's pass of
+    // this iteration's subspace minimisation (lbfgsx_b_gram_pairs_dd) then has nothing to patch.  Remembered by epoch and slot.
+    T* dst_a = b->wf_prepatch ? static_cast<T*>(b->wf) + int64_t(fresh_a) * b->wf_ld : nullptr;
+    T* dst_b = b->wf_prepatch ? static_cast<T*>(b->wf) + int64_t(fresh_b) * b->wf_ld : nullptr;
     lbfgsx::poll_arm(c);
     rc = xl::multidot2_wf<T>(c->stream, b->num_cus, wfc, total, fresh_a, fresh_b, snew, ynew, static_cast<const T*>(b->dvec), b->wf_idx,
-                             b->wf_n, full, b->wtdc_list, int(b->wtdc_n), wsx(c), b->dout);
+                             b->wf_n, full, b->wtdc_list, int(b->wtdc_n), wsx(c), b->dout, dst_a, dst_b);
     if (rc)
         return rc;
+    b->wf_patched_epoch = dst_a ? b->sub_epoch : -2;
+    b->wf_patched_slot = newest;
     double r[2 * kColsX];
     rc = fetch_doubles(c, 2 * total, r);
     if (rc)
@@ -1400,11 +1434,19 @@ int lbfgsx_b_post_linesearch_build(lbfgsx_ctx* c, double tau, double* projgnorm,
         BVecs<T> bv = bvecs<T>(c);
         const bool wc = wtdc_ready(c, true) && wtdc_alloc(c);
         lbfgsx::poll_arm(c);
-        // byte model: x, xp, g, gp, lb, ub and the positions read; s, y, brk, d, xcp written
-        lbfgsx::model_add(double(c->n) * (11 * sizeof(T) + 4));
+        // the sort keys over all n rows are only wanted when the candidates of the partial sort are NOT listed by this pass; the
+        // indices once (ensure_keys rebuilds either on demand)
+        const bool lazy_keys = b->keys_lazy && sel_inline;
+        T* keys_arg = lazy_keys ? static_cast<T*>(nullptr) : P<T>(b->keys_in);
+        int* vals_arg = (b->keys_lazy && b->vals_iota) ? static_cast<int*>(nullptr) : b->vals_in;
+        // byte model: x, xp, g, gp, lb, ub and the positions read; s, y, brk, d, xcp (and the keys / indices, when wanted) written
+        lbfgsx::model_add(double(c->n) * (11 * sizeof(T) + 4 + (keys_arg ? sizeof(T) : 0) + (vals_arg ? 4 : 0)));
+        b->keys_valid = keys_arg != nullptr;
+        if (vals_arg)
+            b->vals_iota = true;
         LBFGSX_LAUNCH((k_b_post_build<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, P<T>(c->xb[c->xp]), P<T>(c->gb[c->xp]),
                            P<T>(c->col(c->S, c->spare)), P<T>(c->col(c->Y, c->spare)), c->out_slot<T>(),
-                           P<T>(c->sc) + c->sl.ys(c->spare), P<T>(c->sc) + c->sl.theta(c->spare), P<T>(b->keys_in), b->vals_in,
+                           P<T>(c->sc) + c->sl.ys(c->spare), P<T>(c->sc) + c->sl.theta(c->spare), keys_arg, vals_arg,
                            c->n, c->ws, b->dout, wc ? b->wf_pos : static_cast<const int*>(nullptr), b->wtdc_list, b->wtdc_cnt,
                            b->wtdc_cap, T(tau), sel_inline ? b->psel_list : static_cast<int*>(nullptr), b->psel_cnt, b->psel_cap);
         LBFGSX_HIP(hipGetLastError());
@@ -1493,6 +1535,7 @@ int lbfgsx_b_cauchy_build(lbfgsx_ctx* c, int64_t* nfree, int64_t* nord, double* 
         const int newest = (c->ptr + c->m - 1) % c->m;
         lbfgsx::poll_arm(c);
         lbfgsx::model_add(double(c->n) * (7 * sizeof(T) + 4));  // byte model: x, g, lb, ub read; brk, d, xcp and the index written
+        b->keys_valid = b->vals_iota = true;
         LBFGSX_LAUNCH((k_cauchy_build<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, P<T>(b->keys_in), b->vals_in, c->n,
                            c->ws, b->dout, force ? P<T>(c->xb[c->cur]) : static_cast<T*>(nullptr),
                            wc ? static_cast<const T*>(c->col(c->S, c->phys[size_t(newest)])) : static_cast<const T*>(nullptr),
@@ -1560,6 +1603,11 @@ template <class T>
 static int partial_select_t(lbfgsx_ctx* c, double tau, unsigned* count_dev)
 {
     lbfgsb_state* b = c->bstate;
+    {
+        const int rk = ensure_keys(c);
+        if (rk)
+            return rk;
+    }
     const size_t n = size_t(c->n);
     int rca = psort_alloc(c);
     if (rca)
@@ -1650,7 +1698,9 @@ static int partial_sort_tail_t(lbfgsx_ctx* c, unsigned cnt, int64_t* nsorted)
         return LBFGSX_OK;
     // ... their keys, and a stable sort of that short list: the same order the full sort gives these entries
     const int grid = int(std::min<int64_t>((int64_t(cnt) + 255) / 256, 1024));
-    LBFGSX_LAUNCH((k_gather_keys<T>), dim3(grid), dim3(256), 0, c->stream, P<T>(b->keys_in), b->pv, P<T>(b->pk), int64_t(cnt));
+    // (the listed candidates are ordered break points: their key IS their break point, whether or not the build wrote keys_in)
+    LBFGSX_LAUNCH((k_gather_keys<T>), dim3(grid), dim3(256), 0, c->stream, b->keys_valid ? P<T>(b->keys_in) : static_cast<T*>(b->brk),
+                  b->pv, P<T>(b->pk), int64_t(cnt));
     size_t sbytes = b->sort_tmp_bytes;
     lbfgsx::model_add(double(cnt) * (96.0 + 64.0 + 2 * sizeof(T)));  // byte model: the candidates' keys gathered (a sector each) and sorted
     LBFGSX_HIP(rocprim::radix_sort_pairs(b->sort_tmp, sbytes, P<T>(b->pk), P<T>(b->keys_out), b->pv, b->vals_out, size_t(cnt), 0,
@@ -1697,6 +1747,7 @@ int lbfgsx_b_cauchy_build_partial(lbfgsx_ctx* c, double tau, int64_t* nfree, int
         if (!sel_ahead)  // nothing rides behind the build: its last block carries the completion word
             lbfgsx::poll_arm(c);
         lbfgsx::model_add(double(c->n) * (7 * sizeof(T) + 4));  // byte model: x, g, lb, ub read; brk, d, xcp and the index written
+        b->keys_valid = b->vals_iota = true;
         LBFGSX_LAUNCH((k_cauchy_build<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, P<T>(b->keys_in), b->vals_in, c->n,
                            c->ws, b->dout, force ? P<T>(c->xb[c->cur]) : static_cast<T*>(nullptr),
                            wc ? static_cast<const T*>(c->col(c->S, c->phys[size_t(newest)])) : static_cast<const T*>(nullptr),
@@ -1781,6 +1832,9 @@ int lbfgsx_b_cauchy_sort_full(lbfgsx_ctx* c)
         return rc;
     lbfgsb_state* b = c->bstate;
     b->gpre_valid = false;
+    rc = ensure_keys(c);
+    if (rc)
+        return rc;
     DISPATCH_T(c, {
         size_t bytes = b->sort_tmp_bytes;
         lbfgsx::model_add(96.0 * double(c->n));  // byte model: SURVEY 8(d)'s radix-sort figure per (key, index) pair
@@ -3171,7 +3225,9 @@ int lbfgsx_b_gram_pairs_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
                 }
                 RowsX<T> gr{};
                 gr.in_idx = compact_in ? b->wf_idx : nullptr;
-                if (kept && refresh_slot >= 0)
+                // (the W'd pass of this iteration may have written the replaced pair into the copy already: wtd2_wf_x)
+                const bool prepatched = b->wf_patched_epoch + 1 == b->sub_epoch && b->wf_patched_slot == refresh_slot;
+                if (kept && refresh_slot >= 0 && !prepatched)
                 {
                     gr.fresh_a = refresh_slot;
                     gr.fresh_b = c->ncorr + refresh_slot;

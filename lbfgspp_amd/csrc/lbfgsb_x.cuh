@@ -617,8 +617,14 @@ template <class T, int NCL, int G>
 __global__ void __launch_bounds__(kBlock, occ_dots_x(NCL))
     kx_multidot2_wf(ColsX<T> wfc, int ncols, int fresh_a, int fresh_b, const T* __restrict__ snew, const T* __restrict__ ynew,
                     const T* __restrict__ dvec, const int* __restrict__ idx, int64_t npos, ColsX<T> full,
-                    const int* __restrict__ list, int nlist, RedWsX ws, double* __restrict__ out)
+                    const int* __restrict__ list, int nlist, RedWsX ws, double* __restrict__ out, T* __restrict__ dst_a,
+                    T* __restrict__ dst_b)
 {
+    // dst_a / dst_b (round 5): this pass has the new pair at every position of the kept copy in registers -- it reads y_new and
+    // s_new by row for exactly the two columns the copy holds stale -- so it also WRITES them to the copy (16 bytes per
+    // position).  The pass over the copy that follows in the same iteration (kx_rows<NA = 3>) then finds the copy whole: no
+    // gathers of the two columns by row, no stores, and none of the per-column selects that made it the one pass of the
+    // iteration bound by its arithmetic.  Same values at the same places as kx_rows' own patch (RowsX::dst_a).
     typedef typename AccOf<T>::type A;
     constexpr int RPW = 64 / G, NL = 2 * NCL;
     __shared__ const T* s_col[kColsX];
@@ -660,6 +666,11 @@ __global__ void __launch_bounds__(kBlock, occ_dots_x(NCL))
         auto compute = [&](int64_t base, Buf& x) __attribute__((always_inline)) {
             if (base + L.rr < npos)
             {
+                if (dst_a && L.g == 0)
+                {
+                    dst_a[base + L.rr] = x.y;
+                    dst_b[base + L.rr] = x.a;
+                }
 #pragma unroll
                 for (int k = 0; k < NCL; k++)
                 {

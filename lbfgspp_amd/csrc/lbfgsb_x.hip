@@ -134,18 +134,18 @@ int solve_sweep(hipStream_t s, int num_cus, int first, const ColsX<T>& cols, int
 template <class T>
 int multidot2_wf(hipStream_t s, int num_cus, const ColsX<T>& wfc, int ncols, int fresh_a, int fresh_b, const T* snew, const T* ynew,
                  const T* dvec, const int* idx, int64_t npos, const ColsX<T>& full, const int* list, int nlist, const RedWsX& ws,
-                 double* out)
+                 double* out, T* dst_a, T* dst_b)
 {
     if (ncols < 1 || ncols > kColsX)
         return LBFGSX_E_INVALID;
     // byte model: the compact columns over their positions + s_new, y_new, d gathered by the positions' rows + the row numbers;
     // the rows outside the copy: every column and two vectors at the row (one sector each)
-    model_add(double(npos) * (double(ncols) * sizeof(T) + 4) + 3.0 * model_gather(npos, npos * 2, int(sizeof(T))) +
-              double(nlist) * 64.0 * (ncols + 2));
+    model_add(double(npos) * (double(ncols) * sizeof(T) + 4 + (dst_a ? 2.0 * sizeof(T) : 0.0)) +
+              3.0 * model_gather(npos, npos * 2, int(sizeof(T))) + double(nlist) * 64.0 * (ncols + 2));
     model_compact_pass(npos);
 #define CALL(NCL, G)                                                                                                          \
     LBFGSX_LAUNCH((kx_multidot2_wf<T, NCL, G>), dim3(grid_rows(std::max<int64_t>(npos, nlist), 64 / G, occ_dots_x(NCL), num_cus)),  \
-                  dim3(kBlock), 0, s, wfc, ncols, fresh_a, fresh_b, snew, ynew, dvec, idx, npos, full, list, nlist, ws, out)
+                  dim3(kBlock), 0, s, wfc, ncols, fresh_a, fresh_b, snew, ynew, dvec, idx, npos, full, list, nlist, ws, out, dst_a, dst_b)
     LBFGSX_XCLASS(ncols, CALL);
 #undef CALL
     LBFGSX_HIP(hipGetLastError());
@@ -309,7 +309,7 @@ int gram_finish(hipStream_t s, const double* partial, int blocks, int ntile, dou
                                 int, T, int64_t, const RedWsX&, double*, int*, unsigned*, unsigned, const int*, T*, T*, int,     \
                                 const ProX<T>*);                                                                                 \
     template int multidot2_wf<T>(hipStream_t, int, const ColsX<T>&, int, int, int, const T*, const T*, const T*, const int*, int64_t, \
-                                 const ColsX<T>&, const int*, int, const RedWsX&, double*);                                      \
+                                 const ColsX<T>&, const int*, int, const RedWsX&, double*, T*, T*);                              \
     template int multidot2<T>(hipStream_t, int, const ColsX<T>&, int, const T*, const T*, int64_t, const RedWsX&, double*);        \
     template int list2<T>(hipStream_t, int, const ColsX<T>&, int, const BVecs<T>&, const int*, int, const RedWsX&, double*,         \
                           const unsigned char*, const int*);                                                                     \

@@ -18,7 +18,7 @@ int solve_sweep(hipStream_t s, int num_cus, int first, const ColsX<T>& cols, int
 template <class T>
 int multidot2_wf(hipStream_t s, int num_cus, const ColsX<T>& wfc, int ncols, int fresh_a, int fresh_b, const T* snew, const T* ynew,
                  const T* dvec, const int* idx, int64_t npos, const ColsX<T>& full, const int* list, int nlist, const RedWsX& ws,
-                 double* out);
+                 double* out, T* dst_a = nullptr, T* dst_b = nullptr);
 template <class T>
 int multidot2(hipStream_t s, int num_cus, const ColsX<T>& cols, int ncols, const T* v1, const T* v2, int64_t n, const RedWsX& ws,
               double* out);

@@ -10,8 +10,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(*extra, gpus=1, warmup=12, env=None):
+def _run(*extra, gpus=1, warmup=12, env=None, verbose=True):
+    # verbose: the full line (every key the schema tests read); the default, compact line is checked by the first test
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup", str(warmup)] + list(extra)
+    if verbose:
+        cmd.append("--verbose")
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT,
                        env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, r.stderr[-2000:]
@@ -22,7 +25,8 @@ def _run(*extra, gpus=1, warmup=12, env=None):
 
 def test_default_line_has_the_contract_keys(tmp_path):
     full = str(tmp_path / "full.json")
-    line = _run("--cpu-n", "2000000", "--cpu-steps", "4", "--cpu-n-all", "2000000", "--cpu-full", "off", "--full-json", full)
+    line = _run("--cpu-n", "2000000", "--cpu-steps", "4", "--cpu-n-all", "2000000", "--cpu-full", "off", "--full-json", full,
+                verbose=False)
     # The default line is the compact one: under 7 KB (the driver keeps the last 8 KB of it), the contract keys and the two
     # required objects at the top, every leg reduced to its figures, and `legs_digest` as the LAST key so that whatever tail
     # survives holds every leg's value and fractions.  The full object (--verbose prints it, --full-json writes it) is what
