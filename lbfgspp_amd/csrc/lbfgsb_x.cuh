@@ -217,8 +217,11 @@ __global__ void __launch_bounds__(kBlock, occ_rows_x(NCL, G, NA))
         x.vb = vb_p[r];
         if (NA > 1)
         {
-            x.fa = fa_p[r];
-            x.fb = fb_p[r];
+            if (patch)  // uniform: without a patch (the W'd pass has written the pair into the copy) the two gathers by row are not issued
+            {
+                x.fa = fa_p[r];
+                x.fb = fb_p[r];
+            }
             x.xa = xa_p[tc];
             x.xb = xb_p[tc];
         }
