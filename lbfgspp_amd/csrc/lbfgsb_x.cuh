@@ -140,7 +140,11 @@ __device__ __forceinline__ void lane_cols_x(const T* const* s_col, const LaneX<G
 // (NA = 3) of the masked Gram: k_vrows for 2c <= 80.  Statements and outputs as there (lbfgsb_kernels.cuh); the rounded
 // sums land in out[a * (ncols + 1) + j] (a = 0: v row with (v, v) at j = ncols; a = 1, 2: columns col_a, col_b), the
 // (hi, lo) pairs in out_dd at twice that index.
-template <class T, int NCL, int G, int NA, bool IDX>
+// PATCH (NA = 3 only): the pass also replaces the two columns add_correction has changed since the copy was written (RowsX);
+// a template parameter, not a run-time flag: since the W'd pass writes the new pair into the copy itself (kx_multidot2_wf,
+// dst_a / dst_b) the steady state never patches here, and its kernel carries neither the two gathered values of a row nor
+// the branches around them (8 registers per lane; the (10, 4) class spilled 20 bytes with them).
+template <class T, int NCL, int G, int NA, bool IDX, bool PATCH = false>
 __global__ void __launch_bounds__(kBlock, occ_rows_x(NCL, G, NA))
     kx_rows(ColsX<T> cols, int ncols, BVecs<T> b, int vsel_id, int mask, int64_t n, RedWsX ws, double* __restrict__ out,
             double* __restrict__ out_dd, ProX<T> pro, RowsX<T> gr, int col_a, int col_b)
@@ -185,7 +189,7 @@ __global__ void __launch_bounds__(kBlock, occ_rows_x(NCL, G, NA))
     default: va_p = b.y; vb_p = b.y; vkind = 0; break;
     }
     // the two replaced columns are patched by the three-row form only (the carried first solve); NA = 1 never carries them
-    const bool patch = NA > 1 && gr.dst_a != nullptr;
+    constexpr bool patch = NA > 1 && PATCH;
     const T* fa_p = patch ? gr.src_a : b.rhs;
     const T* fb_p = patch ? gr.src_b : b.rhs;
     gptr_x<T> xa_p = (gptr_x<T>) s_col[(NA > 1 && col_a >= 0) ? col_a : 0];
@@ -201,7 +205,8 @@ __global__ void __launch_bounds__(kBlock, occ_rows_x(NCL, G, NA))
     // compact copy run one trip further ahead, so that no load waits for another.
     struct Buf
     {
-        T pre, va, vb, fa, fb, xa, xb;
+        T pre, va, vb, xa, xb;
+        T fab[patch ? 2 : 1];  // fa, fb
         T row[NCL];
         unsigned char st;
     };
@@ -217,10 +222,10 @@ __global__ void __launch_bounds__(kBlock, occ_rows_x(NCL, G, NA))
         x.vb = vb_p[r];
         if (NA > 1)
         {
-            if (patch)  // uniform: without a patch (the W'd pass has written the pair into the copy) the two gathers by row are not issued
+            if (patch)
             {
-                x.fa = fa_p[r];
-                x.fb = fb_p[r];
+                x.fab[0] = fa_p[r];
+                x.fab[patch ? 1 : 0] = fb_p[r];
             }
             x.xa = xa_p[tc];
             x.xb = xb_p[tc];
@@ -250,19 +255,20 @@ __global__ void __launch_bounds__(kBlock, occ_rows_x(NCL, G, NA))
         }
         if (patch)  // every position of the kept copy gets the two replaced columns, kept or not
         {
+            const T fa = x.fab[0], fb = x.fab[patch ? 1 : 0];
             if (inb && L.g == 0)
             {
-                gr.dst_a[t] = x.fa;
-                gr.dst_b[t] = x.fb;
+                gr.dst_a[t] = fa;
+                gr.dst_b[t] = fb;
             }
 #pragma unroll
             for (int k = 0; k < NCL; k++)
             {
                 const int ci = L.g * NCL + k;
-                x.row[k] = (ci == gr.fresh_a) ? x.fa : (ci == gr.fresh_b) ? x.fb : x.row[k];
+                x.row[k] = (ci == gr.fresh_a) ? fa : (ci == gr.fresh_b) ? fb : x.row[k];
             }
-            xa = (col_a == gr.fresh_a) ? x.fa : (col_a == gr.fresh_b) ? x.fb : xa;
-            xb = (col_b == gr.fresh_a) ? x.fa : (col_b == gr.fresh_b) ? x.fb : xb;
+            xa = (col_a == gr.fresh_a) ? fa : (col_a == gr.fresh_b) ? fb : xa;
+            xb = (col_b == gr.fresh_a) ? fa : (col_b == gr.fresh_b) ? fb : xb;
         }
         const bool keep = inb && (!mask || (x.st & mask));
         T v = vkind == 0 ? x.va : vkind == 1 ? -x.va : x.va - x.vb;
