@@ -226,6 +226,9 @@ struct lbfgsb_state
     unsigned* na_cnt = nullptr;
     unsigned na_cap = 1u << 16;
     int64_t na_n = -1;                // entries of the list, -1: none / overflowed
+    int64_t na_prev = -1;             // rows the previous search made newly active (-1: no search yet): the list is only asked for
+                                      // when that fitted it -- a search that activates millions of rows (the first iterations)
+                                      // otherwise has 10^5 waves meeting at one counter for a list nobody reads
     static constexpr int kDout = 640; // doubles of `dout`
 };
 
@@ -2215,6 +2218,7 @@ int lbfgsx_b_cauchy_finish(lbfgsx_ctx* c, double t_cross, double tfinal, int cro
     double r[3] = {0, 0, -1};
     lbfgsb_state* b = c->bstate;
     const bool fuse = b->fin_fuse && c->n < (int64_t(1) << 31);
+    const bool want_list = fuse && b->na_prev >= 0 && b->na_prev <= int64_t(b->na_cap);
     DISPATCH_T(c, {
         BVecs<T> bv = bvecs<T>(c);
         b->lu_valid = false;  // the state bytes are rewritten
@@ -2223,17 +2227,18 @@ int lbfgsx_b_cauchy_finish(lbfgsx_ctx* c, double t_cross, double tfinal, int cro
         lbfgsx::model_add(double(c->n) * (5 * sizeof(T) + 1));  // byte model: brk, x0, d read; xcp, drt and the state byte written
         LBFGSX_LAUNCH((k_cauchy_finish<T>), dim3(grid), dim3(kBlock), 0, c->stream, bv, T(t_cross), T(tfinal), crossed_all,
                            c->n, c->ws, b->dout, fuse ? P<T>(c->d) : static_cast<T*>(nullptr),
-                           fuse ? b->na_list : static_cast<int*>(nullptr), b->na_cnt, b->na_cap);
+                           want_list ? b->na_list : static_cast<int*>(nullptr), b->na_cnt, b->na_cap);
     });
     LBFGSX_HIP(hipGetLastError());
-    rc = fetch_doubles(c, fuse ? 3 : 2, r);
+    rc = fetch_doubles(c, want_list ? 3 : 2, r);
     if (rc)
         return rc;
     if (nact) *nact = int64_t(r[0]);
     if (nfree) *nfree = int64_t(r[1]);
     b->nfree_last = int64_t(r[1]);
     b->drt_ready = fuse;
-    b->na_n = (fuse && r[2] >= 0 && r[2] <= double(b->na_cap)) ? int64_t(r[2]) : -1;
+    b->na_prev = int64_t(r[0]);
+    b->na_n = (want_list && r[2] >= 0 && r[2] <= double(b->na_cap)) ? int64_t(r[2]) : -1;
     return LBFGSX_OK;
 }
 

@@ -9,8 +9,11 @@
 // (BFGSMat.h:529-565, SubspaceMin.h:183-273).
 //
 // Here lane l of a wavefront holds columns [g * NCL, (g + 1) * NCL) of row `base + l % (64 / G)`, g = l / (64 / G):
-// NCL = 8..20 column values and NCL + 1 accumulators per lane whatever 2c is, 3-4 waves per SIMD.  Every load of a row is
-// still issued unconditionally and up front.  Loads stay coalesced: the lanes of a group read 64 / G consecutive rows of
+// NCL = 8..20 column values and NCL + 1 accumulators per lane whatever 2c is.  Waves per SIMD as built (scripts/r5/
+// kernel_resources.py, profiles/r5_kernel_resources.tsv; class (10, 2), double): kx_rows<NA = 1> 163-166 VGPRs = 3,
+// kx_solve_sweep<FIRST> 164 = 3, kx_solve_sweep<0, RHSK> 212 = 2, kx_rows<NA = 3> 238 = 2 (3 x 11 double-double sums alone are
+// 132 registers), kx_multidot2_wf 240 = 2; the 15- and 20-column classes one wave.  No scratch memory in any class.  Every load
+// of a row is still issued unconditionally and up front.  Loads stay coalesced: the lanes of a group read 64 / G consecutive rows of
 // one column (256 / 128 bytes at G = 2 / 4).  What a row needs from all of its columns --
 //   * the left-to-right sum (W coef)(row) of the prologue statements and of the solve (the reference accumulates short
 //     products sequentially in plain T), and
