@@ -106,23 +106,84 @@ struct LaneX
 // the row gets the total.  Columns beyond 2c need no test: their coefficient is an exact zero (the hosts pad with zeros) and
 // their value is column 0's, so the term is +-0, and x + (+-0) == x bit for bit -- a sum that starts at +0 is never -0
 // (round-to-nearest gives -0 only for (-0) + (-0)).
+// The hand-over between the lane groups.  __shfl_up / __shfl compile to ds_bpermute_b32 -- a trip through the LDS crossbar and
+// the lgkmcnt counter, twice per chain and word -- although the movement is always the same: whole groups of 32 or 16 lanes
+// change places.  gfx950 has that as two VALU instructions (round 5):
+//   v_permlane32_swap a, b : the upper 32 lanes of a <-> the lower 32 lanes of b
+//   v_permlane16_swap a, b : the odd 16-lane rows of a <-> the even rows of b
+// With a = b = x the first result holds the lower half (even rows) in both halves (row pairs), the second the upper half
+// (odd rows): a shift up by one group and the broadcast of the last group come out of one or two of them.
+// (LBFGSX_X_PERMLANE=0 at compile time: the shuffles as before; the tests compare bits either way.)
+#ifndef LBFGSX_X_PERMLANE
+#define LBFGSX_X_PERMLANE 1
+#endif
+template <int WHICH, bool HALF32>
+__device__ __forceinline__ double swap_x(double v)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = unsigned(b), hi = unsigned(b >> 32);
+    unsigned rl, rh;
+    if (HALF32)
+    {
+        rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false)[WHICH];
+        rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false)[WHICH];
+    }
+    else
+    {
+        rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false)[WHICH];
+        rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false)[WHICH];
+    }
+    return __builtin_bit_cast(double, (static_cast<unsigned long long>(rh) << 32) | rl);
+}
+template <int WHICH, bool HALF32>
+__device__ __forceinline__ float swap_x(float v)
+{
+    const unsigned b = __builtin_bit_cast(unsigned, v);
+    const unsigned r = HALF32 ? __builtin_amdgcn_permlane32_swap(b, b, false, false)[WHICH]
+                              : __builtin_amdgcn_permlane16_swap(b, b, false, false)[WHICH];
+    return __builtin_bit_cast(float, r);
+}
+// the value of the group before (the lanes of group 0 get something they do not use), for the hand-over into group `round`
+template <class T, int G>
+__device__ __forceinline__ T from_prev_group_x(T x, int round)
+{
+    if (!LBFGSX_X_PERMLANE)
+        return __shfl_up(x, 64 / G, 64);
+    if (G == 2)
+        return swap_x<0, true>(x);                       // [lower, lower]
+    // G == 4, rows r0..r3: round 1 and 3 need row r <- row r - 1 for odd r: [r0, r0, r2, r2]; round 2 needs r2 <- r1
+    if (round == 2)
+        return swap_x<0, true>(swap_x<1, false>(x));     // [r1, r1, r3, r3] -> lower half everywhere: [r1, r1, r1, r1]
+    return swap_x<0, false>(x);
+}
+// the value of the last group in every lane of the row
+template <class T, int G>
+__device__ __forceinline__ T from_last_group_x(T x, int rr)
+{
+    if (!LBFGSX_X_PERMLANE)
+        return __shfl(x, (G - 1) * (64 / G) + rr, 64);
+    if (G == 2)
+        return swap_x<1, true>(x);                       // [upper, upper]
+    return swap_x<1, true>(swap_x<1, false>(x));         // [r1, r1, r3, r3] -> upper half everywhere: [r3, r3, r3, r3]
+}
 template <class T, int NCL, int G>
 __device__ __forceinline__ T chain_x(const T (&p)[NCL], const LaneX<G>& L)
 {
+    static_assert(G == 2 || G == 4, "lane groups of 32 or 16");
     T x = T(0);
 #pragma unroll
     for (int round = 0; round < G; round++)
     {
         // group `round` continues from the partial of the group before it; what the other groups compute is dropped
         if (round > 0 && !(LBFGSX_X_DBG & 8))
-            x = __shfl_up(x, LaneX<G>::RPW, 64);
+            x = from_prev_group_x<T, G>(x, round);
 #pragma unroll
         for (int k = 0; k < NCL; k++)
             x = x + p[k];
     }
     if (LBFGSX_X_DBG & 8)
         return x;
-    return __shfl(x, (G - 1) * LaneX<G>::RPW + L.rr, 64);
+    return from_last_group_x<T, G>(x, L.rr);
 }
 
 // A column pointer as the compiler must see it to emit global_load: the lists travel through LDS, and a pointer loaded from
