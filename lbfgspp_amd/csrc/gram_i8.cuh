@@ -44,6 +44,7 @@ struct GramI8Args
     // full-length columns: row kept at position pos of batch bt goes to position out_base[bt] + pos.  Null: not written.
     double* out_w;
     int64_t out_ld;
+    int out_split, out_gap;  // slot-stable columns: GramRows::out_split
     int* out_idx;
     const int* out_base;
     int* out_pos;
@@ -214,7 +215,7 @@ __global__ void __launch_bounds__(kBlock, 1)
 #pragma unroll
                         for (int j = 0; j < CS; j++)
                             if (j < ncols)
-                                ga.out_w[int64_t(j) * ga.out_ld + ot] = vn[j];
+                                ga.out_w[int64_t(j + (j >= ga.out_split ? ga.out_gap : 0)) * ga.out_ld + ot] = vn[j];
                     }
                     double rhs_new = an0, cF_new = an1;
                     if (pro.mode != GP_NONE)

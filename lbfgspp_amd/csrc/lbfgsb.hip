@@ -671,13 +671,22 @@ static Cols<T, NC> col_list(lbfgsx_ctx* c, const int* which /* 0..2c-1: Y slots 
     return cl;
 }
 
+// Column of the compact copy that holds logical column k (Y slots, then S slots) of a history of `count / 2` pairs: slot-stable
+// (round 5) -- Y slot j in column j, S slot j in column m + j whatever the history length, so that a copy written while the
+// history fills stays valid when the next pair arrives (only the new slot's two columns are missing: the patch of the
+// carried Gram's pass).  Until round 4 the S slots followed the Y slots directly and every new pair moved them.
+static inline int wf_col(const lbfgsx_ctx* c, int k, int count)
+{
+    const int cc = count / 2;
+    return k < cc ? k : c->m + (k - cc);
+}
 // columns of the compact copy of the free rows, logical order (Y slots then S slots)
 template <class T>
 static Cols<T, 32> wf_cols(lbfgsx_ctx* c, int count)
 {
     Cols<T, 32> cl;
     for (int k = 0; k < 32; k++)
-        cl.p[k] = static_cast<const T*>(c->bstate->wf) + int64_t(k < count ? k : 0) * c->bstate->wf_ld;  // padded with column 0
+        cl.p[k] = static_cast<const T*>(c->bstate->wf) + int64_t(wf_col(c, k < count ? k : 0, count)) * c->bstate->wf_ld;  // padded with column 0
     return cl;
 }
 // the same lists for the kernels of lbfgsb_x.cuh (2c <= 80), and the workspace of their reductions
@@ -699,7 +708,7 @@ static ColsX<T> colsx_wf(lbfgsx_ctx* c, int count)
 {
     ColsX<T> cl;
     for (int k = 0; k < kColsX; k++)
-        cl.p[k] = static_cast<const T*>(c->bstate->wf) + int64_t(k < count ? k : 0) * c->bstate->wf_ld;
+        cl.p[k] = static_cast<const T*>(c->bstate->wf) + int64_t(wf_col(c, k < count ? k : 0, count)) * c->bstate->wf_ld;
     return cl;
 }
 static RedWsX wsx(lbfgsx_ctx* c)  // after poll_arm: carries the completion word of this launch
@@ -1034,8 +1043,8 @@ static int wtd2_wf_x(lbfgsx_ctx* c, int total, int newest, double* wtd)
     const T* ynew = static_cast<const T*>(c->col(c->Y, c->phys[size_t(newest)]));
     // the pass also writes the new pair into the copy (lbfgsb_x.cuh: kx_multidot2_wf, dst_a / dst_b): the carried Gram's pass of
     // this iteration's subspace minimisation (lbfgsx_b_gram_pairs_dd) then has nothing to patch.  Remembered by epoch and slot.
-    T* dst_a = b->wf_prepatch ? static_cast<T*>(b->wf) + int64_t(fresh_a) * b->wf_ld : nullptr;
-    T* dst_b = b->wf_prepatch ? static_cast<T*>(b->wf) + int64_t(fresh_b) * b->wf_ld : nullptr;
+    T* dst_a = b->wf_prepatch ? static_cast<T*>(b->wf) + int64_t(wf_col(c, fresh_a, total)) * b->wf_ld : nullptr;
+    T* dst_b = b->wf_prepatch ? static_cast<T*>(b->wf) + int64_t(wf_col(c, fresh_b, total)) * b->wf_ld : nullptr;
     lbfgsx::poll_arm(c);
     rc = xl::multidot2_wf<T>(c->stream, b->num_cus, wfc, total, fresh_a, fresh_b, snew, ynew, static_cast<const T*>(b->dvec), b->wf_idx,
                              b->wf_n, full, b->wtdc_list, int(b->wtdc_n), wsx(c), b->dout, dst_a, dst_b);
@@ -2571,6 +2580,8 @@ static int gram_i8_run(lbfgsx_ctx* c, int tot, int vsel_id, int mask, const Gram
     ga.colmax = b->colmax;
     ga.out_w = compact_out ? static_cast<double*>(b->wf) : nullptr;
     ga.out_ld = b->wf_ld;
+    ga.out_split = c->ncorr;   // slot-stable columns of the copy (wf_col)
+    ga.out_gap = c->m - c->ncorr;
     ga.out_idx = b->wf_idx;
     ga.out_base = b->wf_base;
     ga.out_pos = b->wf_pos;
@@ -3055,8 +3066,10 @@ static int free_delta_launch(lbfgsx_ctx* c)
         return rc;
     if (!b->fd_host)
         LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->fd_host), sizeof(unsigned) * 4, hipHostMallocDefault));
-    if (b->wf_live && (b->wf_ncorr != c->ncorr || b->wf_epoch + 1 != b->sub_epoch))
-        b->wf_live = false;  // the history has grown (another column order), or the copy missed an iteration
+    // (a history that has grown by the one pair of this iteration keeps the copy: its columns are slot-stable, wf_col; the new
+    // slot's two columns are the patch of the carried Gram's pass)
+    if (b->wf_live && (!(b->wf_ncorr == c->ncorr || b->wf_ncorr + 1 == c->ncorr) || b->wf_epoch + 1 != b->sub_epoch))
+        b->wf_live = false;  // the copy missed an iteration (or the history was reset)
     // {rows entered, rows left, rows in the kept compact copy, 1: the copy cannot be kept}
     const unsigned init[4] = {0u, 0u, unsigned(b->wf_live ? b->wf_n : 0), 0u};
     LBFGSX_HIP(lbfgsx::copy_async(b->dl_cnt, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
@@ -3079,12 +3092,14 @@ static int free_delta_launch(lbfgsx_ctx* c)
         DISPATCH_T(c, {
             if (total > 32)
                 (void) xl::wf_append<T>(c->stream, colsx_full<T>(c, total), total, static_cast<T*>(b->wf), b->wf_ld, b->wf_idx, b->wf_pos,
-                                        b->dl_enter, b->dl_cnt, b->dl_cap, unsigned(std::min<int64_t>(c->n, b->wf_ld)));
+                                        b->dl_enter, b->dl_cnt, b->dl_cap, unsigned(std::min<int64_t>(c->n, b->wf_ld)), c->ncorr,
+                                        c->m - c->ncorr);
             else
             {
             Cols<T, 32> cl = col_list<T, 32>(c, which, total);
             LBFGSX_LAUNCH((k_wf_append<T>), dim3(16), dim3(kBlock), 0, c->stream, cl, total, static_cast<T*>(b->wf), b->wf_ld,
-                               b->wf_idx, b->wf_pos, b->dl_enter, b->dl_cnt, b->dl_cap, unsigned(std::min<int64_t>(c->n, b->wf_ld)));
+                               b->wf_idx, b->wf_pos, b->dl_enter, b->dl_cnt, b->dl_cap, unsigned(std::min<int64_t>(c->n, b->wf_ld)),
+                               c->ncorr, c->m - c->ncorr);
             }
         });
         LBFGSX_HIP(hipGetLastError());
@@ -3185,8 +3200,9 @@ int lbfgsx_b_gram_pairs_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
     }
     // the copy kept from the previous iteration serves when the caller vouches for the history (refresh_slot >= -1), the
     // mask is the free set and the copy is not overgrown with rows that have left it
+    const bool same_hist = b->wf_ncorr == c->ncorr || (b->wf_ncorr + 1 == c->ncorr && refresh_slot == c->ncorr - 1);
     const bool kept = refresh_slot >= -1 && b->wf_live && b->wf_use && mask == ST_FREE && b->wf_n * 8 <= b->nfree_last * 9 &&
-                      b->wf_n >= b->nfree_last && b->wf_ncorr == c->ncorr && b->wf_epoch + 1 == b->sub_epoch;
+                      b->wf_n >= b->nfree_last && same_hist && b->wf_epoch + 1 == b->sub_epoch;
     if (!kept)
         b->wf_live = false;
     const bool compact_in = kept || wf_serves(c, mask);
@@ -3238,8 +3254,8 @@ int lbfgsx_b_gram_pairs_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
                     gr.fresh_b = c->ncorr + refresh_slot;
                     gr.src_a = static_cast<const T*>(c->col(c->Y, c->phys[size_t(refresh_slot)]));
                     gr.src_b = static_cast<const T*>(c->col(c->S, c->phys[size_t(refresh_slot)]));
-                    gr.dst_a = static_cast<T*>(b->wf) + int64_t(gr.fresh_a) * b->wf_ld;
-                    gr.dst_b = static_cast<T*>(b->wf) + int64_t(gr.fresh_b) * b->wf_ld;
+                    gr.dst_a = static_cast<T*>(b->wf) + int64_t(wf_col(c, gr.fresh_a, 2 * c->ncorr)) * b->wf_ld;
+                    gr.dst_b = static_cast<T*>(b->wf) + int64_t(wf_col(c, gr.fresh_b, 2 * c->ncorr)) * b->wf_ld;
                 }
                 ride_enter = b->fprev && b->dl_n[0] >= 1 && gram_stash_feasible(c, b->dl_enter, b->dl_n[0]);
                 ride_leave = b->fprev && b->dl_n[1] >= 1 && gram_stash_feasible(c, b->dl_leave, b->dl_n[1]);
@@ -3254,6 +3270,7 @@ int lbfgsx_b_gram_pairs_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
             {
                 b->wf_valid = true;  // usable by the passes of this subspace minimisation
                 b->wf_epoch = b->sub_epoch;
+                b->wf_ncorr = c->ncorr;  // (a pair that arrived since the copy was written has been patched in)
             }
             if (rc)
                 return rc;
@@ -3300,6 +3317,8 @@ int lbfgsx_b_gram_pairs_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
         {
             gr.out_w = static_cast<T*>(b->wf);
             gr.out_ld = b->wf_ld;
+            gr.out_split = c->ncorr;   // slot-stable columns of the copy (wf_col)
+            gr.out_gap = c->m - c->ncorr;
             gr.out_idx = b->wf_idx;
             gr.out_base = b->wf_base;
             gr.out_pos = b->wf_pos;
@@ -3310,8 +3329,8 @@ int lbfgsx_b_gram_pairs_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
             gr.fresh_b = c->ncorr + refresh_slot;
             gr.src_a = static_cast<const T*>(c->col(c->Y, c->phys[size_t(refresh_slot)]));
             gr.src_b = static_cast<const T*>(c->col(c->S, c->phys[size_t(refresh_slot)]));
-            gr.dst_a = static_cast<T*>(b->wf) + int64_t(gr.fresh_a) * b->wf_ld;
-            gr.dst_b = static_cast<T*>(b->wf) + int64_t(gr.fresh_b) * b->wf_ld;
+            gr.dst_a = static_cast<T*>(b->wf) + int64_t(wf_col(c, gr.fresh_a, 2 * c->ncorr)) * b->wf_ld;
+            gr.dst_b = static_cast<T*>(b->wf) + int64_t(wf_col(c, gr.fresh_b, 2 * c->ncorr)) * b->wf_ld;
         }
         for (int e = 0; e < 64; e++)
         {
@@ -3343,6 +3362,7 @@ int lbfgsx_b_gram_pairs_dd(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, c
     {
         b->wf_valid = true;  // usable by the passes of this subspace minimisation
         b->wf_epoch = b->sub_epoch;
+        b->wf_ncorr = c->ncorr;
     }
     if (rc)
         return rc;
@@ -3531,6 +3551,8 @@ static int gram_dd_core(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, cons
             {
                 gr.out_w = static_cast<T*>(b->wf);
                 gr.out_ld = b->wf_ld;
+            gr.out_split = c->ncorr;   // slot-stable columns of the copy (wf_col)
+            gr.out_gap = c->m - c->ncorr;
                 gr.out_idx = b->wf_idx;
                 gr.out_base = b->wf_base;
                 gr.out_pos = b->wf_pos;
@@ -3581,6 +3603,8 @@ static int gram_dd_core(lbfgsx_ctx* c, int mask, int vsel_id, int prologue, cons
         {
             gr.out_w = static_cast<T*>(b->wf);
             gr.out_ld = b->wf_ld;
+            gr.out_split = c->ncorr;   // slot-stable columns of the copy (wf_col)
+            gr.out_gap = c->m - c->ncorr;
             gr.out_idx = b->wf_idx;
             gr.out_base = b->wf_base;
             gr.out_pos = b->wf_pos;

@@ -799,8 +799,12 @@ template <class T>
 struct GramRows
 {
     const int* in_idx;    // input is the compact copy: row t of the columns is row in_idx[t] of the vectors (null: identity)
-    T* out_w;             // write the kept rows to out_w[k * out_ld + out_base[batch] + position in the batch]
+    T* out_w;             // write the kept rows to out_w[col(k) * out_ld + out_base[batch] + position in the batch]
     int64_t out_ld;
+    // Slot-stable columns of the compact copy (round 5): logical column k (Y slots, then S slots of a history of c pairs) lives
+    // in column col(k) = k + (k >= out_split ? out_gap : 0), out_split = c, out_gap = m - c: Y slot j in column j, S slot j in
+    // column m + j whatever c is -- a copy written while the history fills stays valid when the next pair arrives.
+    int out_split, out_gap;
     int* out_idx;
     const int* out_base;
     int vgroups;          // VONLY: 1 = one row per step for all lanes (the single-group form), 0 = as many groups as fit
@@ -826,7 +830,7 @@ struct GramRows
 template <class T>
 __global__ void __launch_bounds__(kBlock) k_wf_append(Cols<T, 32> orig, int ncols, T* __restrict__ wf, int64_t wf_ld,
                                                       int* __restrict__ wf_idx, int* __restrict__ pos, const int* __restrict__ enter,
-                                                      unsigned* __restrict__ cnt, unsigned cap, unsigned wf_cap)
+                                                      unsigned* __restrict__ cnt, unsigned cap, unsigned wf_cap, int split, int gap)
 {
     const unsigned ne = __hip_atomic_load(cnt + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (ne > cap)
@@ -849,7 +853,7 @@ __global__ void __launch_bounds__(kBlock) k_wf_append(Cols<T, 32> orig, int ncol
         wf_idx[slot] = row;
         pos[row] = int(slot);
         for (int k = 0; k < ncols; k++)
-            wf[int64_t(k) * wf_ld + slot] = orig.p[k][row];
+            wf[int64_t(k + (k >= split ? gap : 0)) * wf_ld + slot] = orig.p[k][row];  // slot-stable columns (GramRows::out_split)
     }
 }
 
@@ -1054,7 +1058,7 @@ __global__ void __launch_bounds__(kBlock) k_gram_dd(Cols<T, 32> cols, int ncols,
                     {
                         row[c0 + u] = v[u];
                         if (gr.out_w)
-                            gr.out_w[int64_t(c0 + u) * gr.out_ld + ot] = T(v[u]);
+                            gr.out_w[int64_t(c0 + u + ((c0 + u) >= gr.out_split ? gr.out_gap : 0)) * gr.out_ld + ot] = T(v[u]);
                     }
             }
             if (gr.dst_a)

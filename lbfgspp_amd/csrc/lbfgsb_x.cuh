@@ -1214,7 +1214,7 @@ __global__ void __launch_bounds__(kBlock)
                     {
                         row[c0 + u] = v[u];
                         if (gr.out_w)
-                            gr.out_w[int64_t(c0 + u) * gr.out_ld + ot] = T(v[u]);
+                            gr.out_w[int64_t(c0 + u + ((c0 + u) >= gr.out_split ? gr.out_gap : 0)) * gr.out_ld + ot] = T(v[u]);
                     }
             }
         }
@@ -1394,7 +1394,7 @@ static __global__ void __launch_bounds__(kBlock) kx_gram_finish(const double* __
 template <class T>
 __global__ void __launch_bounds__(kBlock) kx_wf_append(ColsX<T> orig, int ncols, T* __restrict__ wf, int64_t wf_ld,
                                                        int* __restrict__ wf_idx, int* __restrict__ pos, const int* __restrict__ enter,
-                                                       unsigned* __restrict__ cnt, unsigned cap, unsigned wf_cap)
+                                                       unsigned* __restrict__ cnt, unsigned cap, unsigned wf_cap, int split, int gap)
 {
     __shared__ const T* s_col[kColsX];
     if (threadIdx.x < kColsX)
@@ -1421,7 +1421,7 @@ __global__ void __launch_bounds__(kBlock) kx_wf_append(ColsX<T> orig, int ncols,
         wf_idx[slot] = row;
         pos[row] = int(slot);
         for (int k = 0; k < ncols; k++)
-            wf[int64_t(k) * wf_ld + slot] = ((gptr_x<T>) s_col[k])[row];
+            wf[int64_t(k + (k >= split ? gap : 0)) * wf_ld + slot] = ((gptr_x<T>) s_col[k])[row];
     }
 }
 

@@ -227,9 +227,10 @@ int multidot_mask(hipStream_t s, int num_cus, const ColsX<T>& cols, int ncols, c
 
 template <class T>
 int wf_append(hipStream_t s, const ColsX<T>& orig, int ncols, T* wf, int64_t wf_ld, int* wf_idx, int* pos, const int* enter,
-              unsigned* cnt, unsigned cap, unsigned wf_cap)
+              unsigned* cnt, unsigned cap, unsigned wf_cap, int split, int gap)
 {
-    LBFGSX_LAUNCH((kx_wf_append<T>), dim3(16), dim3(kBlock), 0, s, orig, ncols, wf, wf_ld, wf_idx, pos, enter, cnt, cap, wf_cap);
+    LBFGSX_LAUNCH((kx_wf_append<T>), dim3(16), dim3(kBlock), 0, s, orig, ncols, wf, wf_ld, wf_idx, pos, enter, cnt, cap, wf_cap, split,
+                  gap);
     LBFGSX_HIP(hipGetLastError());
     return LBFGSX_OK;
 }
@@ -325,7 +326,8 @@ int gram_finish(hipStream_t s, const double* partial, int blocks, int ntile, dou
                                   const RedWsX&, double*);                                                                       \
     template int gram<T>(hipStream_t, int, const ColsX<T>&, int, const BVecs<T>&, int, int, int64_t, double*, const ProX<T>&,      \
                          const GramRows<T>&, double*, double*, unsigned long long*, unsigned long long, unsigned*);                                                                                    \
-    template int wf_append<T>(hipStream_t, const ColsX<T>&, int, T*, int64_t, int*, int*, const int*, unsigned*, unsigned, unsigned)
+    template int wf_append<T>(hipStream_t, const ColsX<T>&, int, T*, int64_t, int*, int*, const int*, unsigned*, unsigned, unsigned, int, \
+                              int)
 INST(double);
 INST(float);
 #undef INST

@@ -33,7 +33,7 @@ int multidot_mask(hipStream_t s, int num_cus, const ColsX<T>& cols, int ncols, c
                   int64_t n, const RedWsX& ws, double* out);
 template <class T>
 int wf_append(hipStream_t s, const ColsX<T>& orig, int ncols, T* wf, int64_t wf_ld, int* wf_idx, int* pos, const int* enter,
-              unsigned* cnt, unsigned cap, unsigned wf_cap);
+              unsigned* cnt, unsigned cap, unsigned wf_cap, int split, int gap);
 // entries per thread of kx_gram for 2c + 1 (+ v) = ntot columns; the partial buffer holds [blocks][gram_kpb * 256][2] doubles
 int gram_kpb(int ntot);
 // returns the number of blocks launched, < 0: error.  More than kGramSelfFinish blocks (or no ticket word): their partials
