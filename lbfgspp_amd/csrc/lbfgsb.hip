@@ -1072,11 +1072,12 @@ static bool wtdc_ready(lbfgsx_ctx* c, bool assume_defer = false)
 {
     lbfgsb_state* b = c->bstate;
     const int total = 2 * c->ncorr;
-    // the copy of the previous minimisation, same history length (the commit replaced a slot), not overgrown: the pass must
-    // read clearly less than the full-length one
+    // the copy of the previous minimisation -- same history length (the commit replaced a slot) or one pair shorter (the commit
+    // added one while the history fills: the copy's columns are slot-stable, wf_col, and the new pair is the "fresh" one of the
+    // pass either way) -- not overgrown: the pass must read clearly less than the full-length one
     return b->wtdc_use && (b->corr_defer || assume_defer) && (b->split ? (total >= 2 && total <= kColsX) : (total > 8 && total <= 20)) &&
            !b->multidot_chunked && b->wf_use && b->wf_live &&
-           b->wf_ncorr == c->ncorr && b->wf_epoch == b->sub_epoch && c->ncorr == c->m && c->n < (int64_t(1) << 31) &&
+           (b->wf_ncorr == c->ncorr || b->wf_ncorr + 1 == c->ncorr) && b->wf_epoch == b->sub_epoch && c->n < (int64_t(1) << 31) &&
            b->wf_n >= 4096 && b->wf_n * 4 <= c->n * 3;
 }
 static bool wtdc_alloc(lbfgsx_ctx* c);
