@@ -574,6 +574,30 @@ def test_carried_gram_of_the_free_set_changes_no_bit(A, monkeypatch, n, m, iters
         assert f[5] >= f[6] // 4, "the carried form ran in %d of %d subspace minimisations" % (f[5], f[6])
 
 
+@pytest.mark.rhs_pass
+@pytest.mark.parametrize("n,m,iters", [(70001, 10, 14), (65536, 20, 24), (65536, 40, 44)])
+def test_kept_copy_and_carried_gram_serve_the_iterations_in_which_the_history_fills(A, monkeypatch, n, m, iters):
+    """Round 5: the columns of the compact copy are slot-stable (Y slot j in column j, S slot j in column m + j whatever the
+    history length), so a copy written at c pairs is the kept copy at c + 1 and the carried Gram -- with the new slot as its one
+    fresh pair -- serves the first m iterations too, where until round 4 every new pair moved the S columns and forced a full
+    Gram pass and a new copy (at m = 40: 40 of the first 60 iterations).  Same bits as the full pass every iteration, and the
+    carried form runs in all but the first few minimisations (no history yet; the first full pass)."""
+    a, b = O.quad_problem(n, 30.0, 11, O.F64)
+    res = {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("LBFGSX_GRAM_CARRY", on)
+        s = A.LBFGSBSolver(A.LBFGSBParam(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters))
+        tr = A.TraceBuffer(n, cap=512, stride=29)
+        x = np.zeros(n)
+        niter, fx = s.minimize(A.DiagQuadratic(a, b), x, -0.7 * np.ones(n), 0.9 * np.ones(n), trace=tr)
+        st = s.stats()
+        res[on] = (niter, s.last.nfev, x.copy(), tr.xs[:tr.count].copy(), st["gram_carried"], st["submin_calls"])
+    f, u = res["1"], res["0"]
+    assert f[:2] == u[:2] and np.array_equal(f[2], u[2]) and np.array_equal(f[3], u[3])
+    assert u[4] == 0 and f[5] >= iters - 1
+    assert f[4] >= f[5] - 4, "the carried form ran in %d of %d subspace minimisations while the history filled" % (f[4], f[5])
+
+
 @pytest.mark.parametrize("m", [3, 5, 8, 10, 12, 20, 40])
 def test_deferred_correction_dots_change_no_bit(A, monkeypatch, m):
     """add_correction's S's_new / s_new.y_j dots taken by the W'd pass of the following Cauchy search
