@@ -73,11 +73,13 @@ struct RowsX
 #ifndef LBFGSX_X_DBG
 #define LBFGSX_X_DBG 0
 #endif
-constexpr int occ_rows_x(int ncl, int g, int na)
+constexpr int occ_rows_x(int ncl, int g, int na, bool patch = false)
 {
+    // (the patching three-row form of the (10, 4) class needs 12 bytes more than 256 registers hold: one block per CU for it --
+    // it only runs when the W'd pass could not write the new pair into the copy itself)
     return (LBFGSX_X_OCC_ROWS > 0 && na == 1 && ncl <= 12) ? LBFGSX_X_OCC_ROWS
            : na == 1 ? (ncl <= 4 ? 4 : ncl <= 10 ? 3 : 2)
-                     : (ncl <= 4 ? 3 : ncl <= 10 ? 2 : 1);
+                     : (ncl <= 4 ? 3 : ncl <= 10 ? ((patch && g == 4 && ncl == 10) ? 1 : 2) : 1);
 }
 constexpr int occ_sweep_x(int ncl, int g, int first)
 {
@@ -209,7 +211,7 @@ __device__ __forceinline__ void lane_cols_x(const T* const* s_col, const LaneX<G
 // dst_a / dst_b) the steady state never patches here, and its kernel carries neither the two gathered values of a row nor
 // the branches around them (8 registers per lane; the (10, 4) class spilled 20 bytes with them).
 template <class T, int NCL, int G, int NA, bool IDX, bool PATCH = false>
-__global__ void __launch_bounds__(kBlock, occ_rows_x(NCL, G, NA))
+__global__ void __launch_bounds__(kBlock, occ_rows_x(NCL, G, NA, PATCH))
     kx_rows(ColsX<T> cols, int ncols, BVecs<T> b, int vsel_id, int mask, int64_t n, RedWsX ws, double* __restrict__ out,
             double* __restrict__ out_dd, ProX<T> pro, RowsX<T> gr, int col_a, int col_b)
 {

@@ -69,13 +69,13 @@ int rows(hipStream_t s, int num_cus, int na, const ColsX<T>& cols, int ncols, co
         LBFGSX_LAUNCH((kx_rows<T, NCL, G, 1, false>), dim3(grid_rows(n, 64 / G, occ_rows_x(NCL, G, 1), num_cus)), dim3(kBlock), 0, s, \
                       cols, ncols, b, vsel_id, mask, n, ws, out, out_dd, pro, gr, col_a, col_b);                               \
     else if (gr.in_idx && gr.dst_a)                                                                                            \
-        LBFGSX_LAUNCH((kx_rows<T, NCL, G, 3, true, true>), dim3(grid_rows(n, 64 / G, occ_rows_x(NCL, G, 3), num_cus)), dim3(kBlock), 0, s, \
+        LBFGSX_LAUNCH((kx_rows<T, NCL, G, 3, true, true>), dim3(grid_rows(n, 64 / G, occ_rows_x(NCL, G, 3, true), num_cus)), dim3(kBlock), 0, s, \
                       cols, ncols, b, vsel_id, mask, n, ws, out, out_dd, pro, gr, col_a, col_b);                               \
     else if (gr.in_idx)                                                                                                        \
         LBFGSX_LAUNCH((kx_rows<T, NCL, G, 3, true, false>), dim3(grid_rows(n, 64 / G, occ_rows_x(NCL, G, 3), num_cus)), dim3(kBlock), 0, s, \
                       cols, ncols, b, vsel_id, mask, n, ws, out, out_dd, pro, gr, col_a, col_b);                               \
     else if (gr.dst_a)                                                                                                         \
-        LBFGSX_LAUNCH((kx_rows<T, NCL, G, 3, false, true>), dim3(grid_rows(n, 64 / G, occ_rows_x(NCL, G, 3), num_cus)), dim3(kBlock), 0, s, \
+        LBFGSX_LAUNCH((kx_rows<T, NCL, G, 3, false, true>), dim3(grid_rows(n, 64 / G, occ_rows_x(NCL, G, 3, true), num_cus)), dim3(kBlock), 0, s, \
                       cols, ncols, b, vsel_id, mask, n, ws, out, out_dd, pro, gr, col_a, col_b);                               \
     else                                                                                                                       \
         LBFGSX_LAUNCH((kx_rows<T, NCL, G, 3, false, false>), dim3(grid_rows(n, 64 / G, occ_rows_x(NCL, G, 3), num_cus)), dim3(kBlock), 0, s, \
