@@ -331,7 +331,7 @@ static int cv_back(lbfgsx_ctx* c, bool assign)
     const int grid = std::max(1, std::min(c->grid_for(2 * npos), 1024));
     // byte model: state byte, row number and y of every position read; written by row (sectors): the state byte and drt, or the
     // five compact vectors
-    lbfgsx::model_add(double(npos) * (1 + 4 + double(c->esz) * (assign ? 1 : 5)) + lbfgsx::model_gather(npos, c->n, 1) +
+    lbfgsx::model_add(double(npos) * (1 + 4 + double(c->esz) * (assign ? 1 : 5)) + (assign ? 0.0 : lbfgsx::model_gather(npos, c->n, 1)) +
                       (assign ? 1 : 5) * lbfgsx::model_gather(npos, c->n, int(c->esz)));
     DISPATCH_T(c, {
         if (assign)

@@ -2493,11 +2493,14 @@ __global__ void __launch_bounds__(kBlock) k_cv_back(BVecs<T> full, BVecs<T> cvb,
         if (!(s & ST_FREE))
             continue;
         const int64_t r = idx[t];
-        full.st[r] = s;
         if (ASSIGN)
+            // (the state bytes stay where they are: the minimisation is over, the partition bits of the rows mean nothing any
+            // more and the free / newly-active bits -- all that is read until the next Cauchy search rewrites every byte --
+            // were never changed by the sweeps.  One scattered byte per row less.)
             full.drt[r] = cvb.y[t];
         else
         {
+            full.st[r] = s;
             full.y[r] = cvb.y[t];
             full.yfb[r] = cvb.yfb[t];
             full.lam[r] = cvb.lam[t];
