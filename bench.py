@@ -1083,6 +1083,8 @@ def legs_digest(out):
              "frac": None if r.get("frac") is None else float("%.4g" % r["frac"])}
         if r.get("traffic_frac") is not None:
             e["traffic_frac"] = float("%.4g" % r["traffic_frac"])
+        if leg.get("value_median") is not None:  # cfg4 legs: value = 1 / MEAN iteration time of the window (rounds 1-3 quoted 1 / median)
+            e["value_median"] = float("%.6g" % leg["value_median"])
         if isinstance(leg.get("from_x0"), dict):
             e["from_x0"] = float("%.6g" % leg["from_x0"]["value"])
             e["frac_from_x0"] = None if r.get("frac_from_x0") is None else float("%.4g" % r["frac_from_x0"])
