@@ -70,6 +70,9 @@ struct RowsX
 // 2 no stores, 3 no cross-lane moves -- what each part of a trip costs (kx_rows); kx_solve_sweep: 16 no sweep statements (and
 // their stores), 32 no y / rhs stores, 64 no double-double products, 128 no left-to-right sums, 256 no list appends.
 // 0 in the product.
+#ifndef LBFGSX_X_NBUF
+#define LBFGSX_X_NBUF 2
+#endif
 #ifndef LBFGSX_X_DBG
 #define LBFGSX_X_DBG 0
 #endif
@@ -79,14 +82,14 @@ constexpr int occ_rows_x(int ncl, int g, int na, bool patch = false)
     // it only runs when the W'd pass could not write the new pair into the copy itself)
     return (LBFGSX_X_OCC_ROWS > 0 && na == 1 && ncl <= 12) ? LBFGSX_X_OCC_ROWS
            : na == 1 ? (ncl <= 4 ? 4 : ncl <= 10 ? 3 : 2)
-                     : (ncl <= 4 ? 3 : ncl <= 10 ? ((patch && g == 4 && ncl == 10) ? 1 : 2) : 1);
+                     : (ncl <= 5 ? 3 : ncl <= 10 ? ((patch && g == 4 && ncl == 10) ? 1 : 2) : 1);
 }
 constexpr int occ_sweep_x(int ncl, int g, int first)
 {
     return (LBFGSX_X_OCC_SWEEP > 0 && ncl <= 12) ? LBFGSX_X_OCC_SWEEP
-           : first ? (ncl <= 10 ? 3 : 2) : (ncl <= 4 ? 3 : ncl <= 12 ? 2 : 1);
+           : first ? (ncl <= 10 ? 3 : 2) : (ncl <= 5 ? 3 : ncl <= 12 ? 2 : 1);
 }
-constexpr int occ_dots_x(int ncl) { return ncl <= 4 ? 4 : ncl <= 10 ? 2 : 1; }   // 2 NCL accumulators, two register sets
+constexpr int occ_dots_x(int ncl) { return ncl <= 4 ? 4 : ncl <= 5 ? 3 : ncl <= 10 ? 2 : 1; }   // 2 NCL accumulators, two register sets
 constexpr int occ_mask_x(int ncl) { return ncl <= 12 ? 4 : ncl <= 15 ? 3 : 2; }                    // NCL + 1
 
 template <int G>
@@ -462,7 +465,11 @@ __global__ void __launch_bounds__(kBlock, occ_rows_x(NCL, G, NA, PATCH))
 // anyway -- same products, same order, same rounded rhs, which is stored as kx_rows stores it.  The pass kx_rows<NA = 1> made
 // over the whole compact copy only to get W_P'(-rhs) for the 2c x 2c solve is then not needed: the host has those 2c sums
 // from sums it already holds (BFGSMatB::solve_PtBP, "W_P' rhs without a pass").
-template <class T, int NCL, int G, int FIRST, bool IDX, bool RHSK = false>
+// CVT (round 5): cv == 2 as a template parameter -- the sweeps of the steady state read and write by position, the bounds are
+// differences already (no x0), and v is one vector (-cF or -rhs: the launcher refuses the bound selectors, which no caller
+// passes), so a row's buffer holds five vectors instead of seven: 8 registers per lane over the two register sets, and two
+// loads per trip that only re-read a line another load had brought.
+template <class T, int NCL, int G, int FIRST, bool IDX, bool RHSK = false, bool CVT = false>
 __global__ void __launch_bounds__(kBlock, occ_sweep_x(NCL, G, FIRST))
     kx_solve_sweep(ColsX<T> cols, int ncols, BVecs<T> b, BVecs<T> bw, int vsel_id, CoefX<T> coef, int has_w, T theta, int64_t n,
                    RedWsX ws, double* __restrict__ out, int* __restrict__ lu_list, unsigned* __restrict__ lu_cnt, unsigned lu_cap,
@@ -495,21 +502,18 @@ __global__ void __launch_bounds__(kBlock, occ_sweep_x(NCL, G, FIRST))
     }
     const T theta2 = theta * theta;
     const T* va_p;
-    const T* vb_p;
-    int vkind;
+    int vkind;  // 0: v = a, 1: v = -a (the bound selectors' a - b: refused by the launcher)
     switch (vsel_id)
     {
-    case VS_DRT: va_p = b.drt; vb_p = b.drt; vkind = 0; break;
-    case VS_NEG_CF: va_p = b.cF; vb_p = b.cF; vkind = 1; break;
-    case VS_NEG_RHS: va_p = b.rhs; vb_p = b.rhs; vkind = 1; break;
-    case VS_LBOUND: va_p = b.lb; vb_p = b.x0; vkind = 2; break;
-    case VS_UBOUND: va_p = b.ub; vb_p = b.x0; vkind = 2; break;
-    default: va_p = b.y; vb_p = b.y; vkind = 0; break;
+    case VS_DRT: va_p = b.drt; vkind = 0; break;
+    case VS_NEG_CF: va_p = b.cF; vkind = 1; break;
+    case VS_NEG_RHS: va_p = b.rhs; vkind = 1; break;
+    default: va_p = b.y; vkind = 0; break;
     }
-    const bool cvt = cv == 2;
+    constexpr bool cvt = CVT;   // == (cv == 2): the launcher's business
     const T* la_p = cvt ? cli : b.lb;
     const T* ua_p = cvt ? cui : b.ub;
-    const T* x0_p = cvt ? cli : b.x0;  // by position nothing is subtracted: a stand-in that is loaded anyway
+    const T* x0_p = b.x0;
     Accs<A, NL> accs;
     A(&acc)[NL] = accs.v;
     unsigned cnt[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -520,7 +524,8 @@ __global__ void __launch_bounds__(kBlock, occ_sweep_x(NCL, G, FIRST))
     struct Buf
     {
         T w[NCL];
-        T xa, xb, yold, la, ua, x0i, cfi;
+        T xa, yold, la, ua, cfi;
+        T x0i[cvt ? 1 : 2];  // [0]: x0 of the row (not by position: the bounds are differences there)
         unsigned char st0;
     };
     // (with the vectors at the positions -- cv = 2, every sweep of the steady state -- the row number is only needed by a row
@@ -548,11 +553,11 @@ __global__ void __launch_bounds__(kBlock, occ_sweep_x(NCL, G, FIRST))
                 x.w[k] = cp[PTR_LDS ? 0 : k][tc];
         }
         x.xa = va_p[ir];
-        x.xb = vb_p[ir];
         x.yold = FIRST ? T(0) : b.y[ir];
         x.la = la_p[ir];
         x.ua = ua_p[ir];
-        x.x0i = x0_p[ir];
+        if (!cvt)
+            x.x0i[0] = x0_p[ir];
         x.cfi = b.cF[ir];
     };
     auto compute = [&](int64_t base, int64_t i, Buf& x) __attribute__((always_inline)) {
@@ -560,7 +565,7 @@ __global__ void __launch_bounds__(kBlock, occ_sweep_x(NCL, G, FIRST))
         const bool inb = t < n;
         const int64_t iw = cv ? t : i;   // where this pass writes the vectors of the row
         const unsigned char st0 = x.st0;
-        const T li = cvt ? x.la : x.la - x.x0i, ui = cvt ? x.ua : x.ua - x.x0i;
+        const T li = cvt ? x.la : x.la - x.x0i[0], ui = cvt ? x.ua : x.ua - x.x0i[0];
         const bool mine = inb && L.last();  // the lane that writes the row's vectors
         if (cv == 1 && mine)  // every position gets its constants, free or not
         {
@@ -581,7 +586,7 @@ __global__ void __launch_bounds__(kBlock, occ_sweep_x(NCL, G, FIRST))
                 p[k] = x.w[k] * sc[L.g * NCL + k];
             a = chain_x<T, NCL, G>(p, L);
         }
-        T v = vkind == 0 ? x.xa : vkind == 1 ? -x.xa : x.xa - x.xb;
+        T v = vkind == 0 ? x.xa : -x.xa;  // (vkind 2, the bound selectors: refused by the launcher)
         if (RHSK)
         {
             // rhs = rhs + (-(W * c1)(row)) [+ (-(W * c2)(row))], v = -rhs: kx_rows' GP_RHS statements (x.xa is the rhs read)
@@ -638,6 +643,33 @@ __global__ void __launch_bounds__(kBlock, occ_sweep_x(NCL, G, FIRST))
         int64_t base = (int64_t(blockIdx.x) * kWaves + L.wave) * RPW;
         if (base < n)
         {
+#if LBFGSX_X_NBUF == 3
+            // three register sets: two trips of loads in the air while a third is worked on (the passes are bound by the
+            // bytes a CU keeps in flight, and at 2 waves per SIMD there are registers to spare for it)
+            int64_t i0 = rowof(base), i1 = rowof(base + stride), i2 = rowof(base + 2 * stride);
+            Buf A0, A1, A2;
+            fetch(base, i0, A0);
+            fetch(base + stride, i1, A1);
+            for (; base < n; base += 3 * stride)
+            {
+                const int64_t b1 = base + stride, b2 = b1 + stride, b3 = b2 + stride, b4 = b3 + stride, b5 = b4 + stride;
+                fetch(b2, i2, A2);
+                compute(base, i0, A0);
+                const int64_t i3 = rowof(b3);
+                if (b1 >= n)
+                    break;
+                fetch(b3, i3, A0);
+                compute(b1, i1, A1);
+                const int64_t i4 = rowof(b4);
+                if (b2 >= n)
+                    break;
+                fetch(b4, i4, A1);
+                compute(b2, i2, A2);
+                i0 = i3;
+                i1 = i4;
+                i2 = rowof(b5);
+            }
+#else
             int64_t i0 = rowof(base), i1 = rowof(base + stride);
             Buf A0, A1;
             fetch(base, i0, A0);
@@ -653,6 +685,7 @@ __global__ void __launch_bounds__(kBlock, occ_sweep_x(NCL, G, FIRST))
                 i0 = i2;
                 i1 = i3;
             }
+#endif
         }
     }
     sweep_counts<T, A>(cnt, acc + ND);

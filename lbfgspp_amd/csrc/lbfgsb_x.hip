@@ -96,6 +96,8 @@ int solve_sweep(hipStream_t s, int num_cus, int first, const ColsX<T>& cols, int
     const bool rhsk = pro && pro->mode == LBFGSX_GP_RHS && (pro->use1 || pro->use2);
     if (rhsk && (first || vsel_id != VS_NEG_RHS))
         return LBFGSX_E_INVALID;
+    if (vsel_id == VS_LBOUND || vsel_id == VS_UBOUND || (cv == 2 && first) || (cv == 1 && !first))
+        return LBFGSX_E_INVALID;  // v is one vector here; the compact vectors start with the first solve and are by position after it
     ProX<T> none;
     none.mode = LBFGSX_GP_NONE;
     none.use1 = none.use2 = 0;
@@ -116,19 +118,26 @@ int solve_sweep(hipStream_t s, int num_cus, int first, const ColsX<T>& cols, int
         if (ridx || cv)
             model_compact_pass(n);
     }
-#define SWEEP(FIRST, IDX, RHSK)                                                                                                   \
-    LBFGSX_LAUNCH((kx_solve_sweep<T, NCL_, G_, FIRST, IDX, RHSK>), dim3(grid_rows(n, 64 / G_, occ_sweep_x(NCL_, G_, FIRST), num_cus)),  \
+#define SWEEP(FIRST, IDX, RHSK, CVT)                                                                                              \
+    LBFGSX_LAUNCH((kx_solve_sweep<T, NCL_, G_, FIRST, IDX, RHSK, CVT>), dim3(grid_rows(n, 64 / G_, occ_sweep_x(NCL_, G_, FIRST), num_cus)), \
                   dim3(kBlock), 0, s, cols, ncols, b, bw, vsel_id, coef, has_w, theta, n, ws, out, lu_list, lu_cnt, lu_cap, ridx, cli,  \
                   cui, cv, pr)
-#define CALL(NCL, G)                                   \
-    {                                                  \
-        constexpr int NCL_ = NCL, G_ = G;              \
-        if (first && ridx) SWEEP(1, true, false);      \
-        else if (first) SWEEP(1, false, false);        \
-        else if (rhsk && ridx) SWEEP(0, true, true);   \
-        else if (rhsk) SWEEP(0, false, true);          \
-        else if (ridx) SWEEP(0, true, false);          \
-        else SWEEP(0, false, false);                   \
+#define CALL(NCL, G)                                                      \
+    {                                                                     \
+        constexpr int NCL_ = NCL, G_ = G;                                 \
+        if (first && ridx) SWEEP(1, true, false, false);                  \
+        else if (first) SWEEP(1, false, false, false);                    \
+        else if (cv == 2)                                                 \
+        {                                                                 \
+            if (rhsk && ridx) SWEEP(0, true, true, true);                 \
+            else if (rhsk) SWEEP(0, false, true, true);                   \
+            else if (ridx) SWEEP(0, true, false, true);                   \
+            else SWEEP(0, false, false, true);                            \
+        }                                                                 \
+        else if (rhsk && ridx) SWEEP(0, true, true, false);               \
+        else if (rhsk) SWEEP(0, false, true, false);                      \
+        else if (ridx) SWEEP(0, true, false, false);                      \
+        else SWEEP(0, false, false, false);                               \
     }
     LBFGSX_XCLASS(ncols, CALL);
 #undef CALL

@@ -179,15 +179,15 @@ int main()
     {                                                                                                                                   \
         const int grid = per_cu * 256;                                                                                                  \
         float t1 = timeit([&] { hipLaunchKernelGGL((kx_rows<double, NCL, G, 1, false>), dim3(grid), dim3(kBlock), 0, 0, cx, tot, b2, int(VS_NEG_RHS), int(ST_P), npos, wx, out, out + 256, px, gx, -1, -1); }); \
-        float t2 = timeit([&] { hipLaunchKernelGGL((kx_solve_sweep<double, NCL, G, 0, true>), dim3(grid), dim3(kBlock), 0, 0, cx, tot, b2, b2, int(VS_NEG_RHS), cfx, 1, 1.5, npos, wx, out, lu_list, lu_cnt, 1u << 18, ridx, cli, cui, 2, pnone); }); \
+        float t2 = timeit([&] { hipLaunchKernelGGL((kx_solve_sweep<double, NCL, G, 0, true, false, true>), dim3(grid), dim3(kBlock), 0, 0, cx, tot, b2, b2, int(VS_NEG_RHS), cfx, 1, 1.5, npos, wx, out, lu_list, lu_cnt, 1u << 18, ridx, cli, cui, 2, pnone); }); \
         float t3 = timeit([&] { hipLaunchKernelGGL((kx_solve_sweep<double, NCL, G, 1, true>), dim3(grid), dim3(kBlock), 0, 0, cx, tot, b2, b2, int(VS_NEG_CF), cfx, 1, 1.5, npos, wx, out, lu_list, lu_cnt, 1u << 18, ridx, cli, cui, 2, pnone); }); \
         float t7 = timeit([&] { hipLaunchKernelGGL((kx_solve_sweep<double, NCL, G, 1, true>), dim3(grid), dim3(kBlock), 0, 0, cx, tot, b2, b3, int(VS_NEG_CF), cfx, 1, 1.5, npos, wx, out, lu_list, lu_cnt, 1u << 18, ridx2, cli, cui, 1, pnone); }); \
         float t4 = timeit([&] { hipLaunchKernelGGL((kx_rows<double, NCL, G, 3, false, false>), dim3(grid), dim3(kBlock), 0, 0, cx, tot, b2, int(VS_NEG_CF), int(ST_FREE), npos, wx, out, out + 256, px, gx, 3, tot / 2 + 3); }); \
-        float t5 = timeit([&] { hipLaunchKernelGGL((kx_solve_sweep<double, NCL, G, 0, true, true>), dim3(grid), dim3(kBlock), 0, 0, cx, tot, b2, b2, int(VS_NEG_RHS), cfx, 1, 1.5, npos, wx, out, lu_list, lu_cnt, 1u << 18, ridx, cli, cui, 2, px); }); \
+        float t5 = timeit([&] { hipLaunchKernelGGL((kx_solve_sweep<double, NCL, G, 0, true, true, true>), dim3(grid), dim3(kBlock), 0, 0, cx, tot, b2, b2, int(VS_NEG_RHS), cfx, 1, 1.5, npos, wx, out, lu_list, lu_cnt, 1u << 18, ridx, cli, cui, 2, px); }); \
         float t6 = timeit([&] { hipLaunchKernelGGL((kx_multidot2_wf<double, NCL, G>), dim3(grid), dim3(kBlock), 0, 0, cx, tot, 3, tot / 2 + 3, b2.rhs, b2.y, b2.cF, ridx2, npos, cx, ridx2, 0, wx, out, (double*) nullptr, (double*) nullptr); }); \
         printf("split (%d, %d), grid %4d: kx_rows<1> %6.1f us (%.2f TB/s)  kx_solve_sweep<0> %6.1f us (%.2f TB/s)  <1> %6.1f us  kx_rows<3> %6.1f us  solve_sweep<0,RHSK> %6.1f us (%.2f TB/s)  multidot2_wf %6.1f us  solve_sweep<1,cv=1 by row> %6.1f us\n", NCL, G, grid, t1, bytes_rows / t1 / 1e6, t2, bytes_sweep / t2 / 1e6, t3, t4, t5, (bytes_sweep + 8.0 * npos) / t5 / 1e6, t6, t7); \
     }
-        if (tot == 20) { RUNX(10, 2) } else { RUNX(10, 4) }
+        if (tot == 20) { RUNX(10, 2) if (getenv("KX_54")) RUNX(5, 4) } else { RUNX(10, 4) }
         if (tot == 20)
             for (int grid : {1, 16, 256, 512, 1024})
             {
