@@ -201,6 +201,7 @@ struct lbfgsx_ctx
     bool meet_all = true;          // how the blocks of the persistent launch learn a step's dot (lbfgs_kernels.cuh, persist_publish):
                                    // one tagged 16-byte word polled after the next step's loads are issued (default), or
                                    // LBFGSX_MEET=last: generation word + scalar table, waited for at the end of the step
+    bool meet_pub_first = true;    // the polled word before the dot's copy for the host (LBFGSX_MEET_PUB=0: after it, as in round 4)
     // A persistent launch whose meeting points timed out (CUs held by another process) is redone with the step launches,
     // which the context then keeps for `persist_cooldown` products before it tries the persistent form again; every
     // further time-out quadruples the pause (8, 32, ... 8192 products), a clean persistent product resets it.

@@ -581,6 +581,7 @@ struct PersistArgs
     int zigzag;
     unsigned first_rev;    // direction parity of the first step
     int64_t ld;            // column stride of S / Y (elements)
+    int pub_first;         // MEET: a step's {generation, dot} goes out before the dot's copy for the host (LBFGSX_MEET_PUB=0: after it)
 };
 
 constexpr int kSc1 = 16;  // cache-policy bit of the buffer instructions: agent scope (loads bypass L1, stores write through)
@@ -695,6 +696,7 @@ constexpr int kPersistNL = 15;
 // dot): the memory latency of the first loads runs while the block waits.
 // (A form in which every block adds the G partials up itself -- no publish at all -- was measured first: bit-identical, but
 // 512 blocks reading the same 8 KB made it 17 us per meeting point SLOWER: profiles/r4_meet_ab.txt.)
+template <bool DRAIN = true>
 __device__ __forceinline__ void persist_publish(unsigned* slot /* 16-byte aligned */, unsigned tag, double v)
 {
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(slot, 0, 16, 0x00020000);
@@ -705,7 +707,9 @@ __device__ __forceinline__ void persist_publish(unsigned* slot /* 16-byte aligne
     w.z = int(unsigned(bits & 0xFFFFFFFFull));
     w.w = int(unsigned(bits >> 32));
     // everything this thread stored before (the re-armed ticket of grid_reduce, the scalars for the host) is out first
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (DRAIN = false: the caller has nothing outstanding that a reader of this word goes on to read)
+    if (DRAIN)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_raw_buffer_store_b128(w, r, 0, 0, kSc1);
 }
 // polls the slot until its tag reaches `want` (wrap-safe); false: gave up (time-out / another block gave up)
@@ -1197,8 +1201,17 @@ __global__ void __launch_bounds__(kHvThreads, 2)
             {
                 const T dv = T(acc[0].value());
                 s_dotv[dslot(L)] = dv;
+                // The word the other blocks poll goes out FIRST (round 5): the dot's copy in sc[] is read by the host (and by
+                // the step launches after a time-out) when the kernel has ended, no block reads it -- and with the copy first
+                // the publish sat behind the s_waitcnt for the copy's round trip to memory, on the critical path of every
+                // meeting point.  This thread's q stores were drained before the block's partials went out.
+                // (The word in 2 / 8 / 16 copies in different memory channels, block b polling copy b % copies -- in case 512
+                // pollers of one address were the cost: 1184 / 1175 / 1204 it/s against 1200 on cfg2, nothing:
+                // profiles/r5_meet_ab.txt.)
+                if (pa.pub_first && L < 2 * cn)
+                    persist_publish<false>(gen + 4, want, double(dv));
                 __hip_atomic_store(sc + DOT0 + L, dv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (L < 2 * cn)  // the last dot is only read by the host
+                if (!pa.pub_first && L < 2 * cn)  // the last dot is only read by the host
                     persist_publish(gen + 4, want, double(dv));
             }
             continue;

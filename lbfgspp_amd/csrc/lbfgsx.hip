@@ -338,6 +338,8 @@ static int create_fill(lbfgsx_ctx* c, int dtype, int64_t n, int m, int device, i
         c->persist = atoi(e) != 0 && c->persist;
     if (const char* e = getenv("LBFGSX_MEET"))  // "last": the round-1..3 meeting points (the last block reduces and publishes)
         c->meet_all = std::strcmp(e, "last") != 0;
+    if (const char* e = getenv("LBFGSX_MEET_PUB"))  // 0: the dot's copy for the host before the word the blocks poll (rounds 4)
+        c->meet_pub_first = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_TRIAL_POLICY"))
         c->trial_policy = atoi(e);
     if (const char* e = getenv("LBFGSX_FUSE_POST"))
@@ -764,6 +766,7 @@ static int apply_Hv_t(lbfgsx_ctx* c, const T* v, T a, double* dg)
         pa.gen_base = c->gen_count;
         pa.zigzag = c->zigzag ? 1 : 0;
         pa.first_rev = c->tl_step;
+    pa.pub_first = c->meet_pub_first ? 1 : 0;
         pa.ld = c->ld;
         // one generation number per meeting point: the word the blocks wait for (LBFGSX_MEET=last) or the tag of the
         // 16-byte words they exchange (the default)
@@ -1191,6 +1194,7 @@ static int post_spec_t(lbfgsx_ctx* c, T a, double* r4)
     pa.gen_base = c->gen_count;
     pa.zigzag = c->zigzag ? 1 : 0;
     pa.first_rev = c->tl_step;
+    pa.pub_first = c->meet_pub_first ? 1 : 0;
     pa.ld = c->ld;
     c->gen_count += unsigned(2 * cn + 1);
     c->tl_step += unsigned(2 * cn + 1);
