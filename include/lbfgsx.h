@@ -248,6 +248,10 @@ int lbfgsx_b_post_linesearch_build(lbfgsx_ctx* c, double tau, double* projgnorm,
 /* instrumentation, process-wide: {passes of lbfgsx_b_post_linesearch_build that carried the Cauchy half, Cauchy searches that
  * used it} */
 int lbfgsx_b_post_build_counts(int64_t out[2], int reset);
+/* Instrumentation of the short partial sort (round 5; no reference counterpart): out[0] = candidate lists of <= 4096 rows
+ * (the break points below the search's threshold, Cauchy.h:183-199) ordered by one block (k_psel_sort_small) instead of three
+ * launches.  LBFGSX_PSEL_SMALL=0 switches the one-block form off. */
+int lbfgsx_b_psel_counts(int64_t out[1], int reset);
 /* add_correction tail: sdots[j] = S_j.s_new, ydots[j] = Y_j.s_new for slots j < ncorr  (BFGSMat.h:111,138) */
 int lbfgsx_b_correction_dots(lbfgsx_ctx* c, double* sdots, double* ydots);
 /* ask the next lbfgsx_b_cauchy_build* to take those dots in the pass that computes W'd (Cauchy.h:152) -- the same 2c

@@ -144,6 +144,7 @@ def load():
     sig(core, "lbfgsx_b_gram_pairs_max", i32, vp)
     sig(core, "lbfgsx_b_post_linesearch_build", i32, vp, dbl, pd, pd, pd, pd)
     sig(core, "lbfgsx_b_post_build_counts", i32, C.POINTER(i64 * 2), i32)
+    sig(core, "lbfgsx_b_psel_counts", i32, C.POINTER(i64 * 1), i32)
     sig(core, "lbfgsx_b_dg_maxstep_trial", i32, vp, i32, dbl, pd, pd)
     sig(core, "lbfgsx_b_solve_sweep_rhs", i32, vp, i32, i32, pd, dbl, pd, pd, pd, C.POINTER(i64 * 7))
     sig(core, "lbfgsx_b_solve_sweep_rhs_ready", i32, vp)

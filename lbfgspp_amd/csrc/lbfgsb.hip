@@ -122,6 +122,7 @@ struct lbfgsb_state
     void* psel_tmp = nullptr;             // radix-sort workspace for psel_cap row numbers
     size_t psel_tmp_bytes = 0;
     int64_t psel_last = -1;               // candidates of the previous partial sort: the in-pass list pays while they are few
+    bool psel_small = true;               // <= kPselSmallCap listed candidates: ordered by one block (LBFGSX_PSEL_SMALL=0: the three launches)
     int64_t psel_max = int64_t(1) << 17;  // (appending and ordering 10^6 rows costs more than the separate selection pass)
     // W'd of the Cauchy search (and the deferred dots of add_correction) from the kept compact copy (k_multidot2_wf)
     bool wtdc_use = true;                 // LBFGSX_WTD_COMPACT=0: always the pass over the full-length columns
@@ -498,6 +499,8 @@ int bounded_alloc(lbfgsx_ctx* c)
         b->fd_use = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_SELECT_MAX"))  // candidates of the previous search up to which the build lists them
         b->psel_max = std::max<int64_t>(0, atoll(e));
+    if (const char* e = getenv("LBFGSX_PSEL_SMALL"))  // 0: a short candidate list is ordered by the three launches of round 4
+        b->psel_small = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_SELECT_CAP"))  // test aid: a short list overflows
         b->psel_cap = unsigned(std::max(1, std::min(1 << 24, atoi(e))));
     if (const char* e = getenv("LBFGSX_SYNC_MERGE"))
@@ -1411,6 +1414,16 @@ int lbfgsx_b_post_linesearch(lbfgsx_ctx* c, double* projgnorm, double* xnorm2, d
     return LBFGSX_OK;
 }
 
+static std::atomic<int64_t> g_psel_small{0};
+int lbfgsx_b_psel_counts(int64_t out[1], int reset)
+{
+    if (out)
+        out[0] = g_psel_small.load();
+    if (reset)
+        g_psel_small = 0;
+    return LBFGSX_OK;
+}
+
 static std::atomic<int64_t> g_pb_runs{0}, g_pb_hits{0};
 int lbfgsx_b_post_build_counts(int64_t out[2], int reset)
 {
@@ -1595,6 +1608,102 @@ __global__ void k_gather_keys(const T* __restrict__ keys, const int* __restrict_
     for (int64_t k = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; k < count; k += stride)
         out[k] = keys[idx[k]];
 }
+// The partial sort of a SHORT candidate list in one block (round 5).  In steady state the build lists 10^1..10^3 rows whose
+// break point is below the threshold; ordering them took three launches -- a radix sort of the row numbers, the gather of their
+// keys, a stable radix sort by key: 30 us of launches and passes for a few KB, every iteration, ahead of the W'd pass.  Here one
+// block sorts the (key, row) pairs in LDS by the order those two sorts produce together -- by key in the radix sort's own order
+// (the sign-magnitude bits made monotone; -0.0 and +0.0 equal, as rocprim's codec has it), rows ascending among equal keys;
+// rows are distinct, so the order is total and the bitonic network's lack of stability does not matter.  9-19 us less per
+// iteration (scripts/r5/chain_ab.sh, profiles/r5_chain_ab.txt).
+// (The same block also gathering the first chunk of the host search -- [brk | g | z | W rows] of the first 512 sorted break
+// points, instead of the column table's upload + k_cauchy_gather -- was measured in two forms, into the copy's source buffer
+// and straight into host-mapped memory: 4-7 us SLOWER than the separate launches either way, one CU's worth of outstanding
+// loads against two and an upload that overlaps the sort.  Not kept.)
+// Steps whose partners are less than 64 apart stay inside the 128 elements one wavefront handles: no block barrier there.
+constexpr int kPselSmallCap = 4096;
+constexpr int kPselSmallThreads = 1024;
+template <class T>
+struct KeyBits;
+template <>
+struct KeyBits<double>
+{
+    typedef unsigned long long U;
+    static constexpr U sign = 0x8000000000000000ull;
+};
+template <>
+struct KeyBits<float>
+{
+    typedef unsigned U;
+    static constexpr U sign = 0x80000000u;
+};
+template <class T>
+__global__ void __launch_bounds__(kPselSmallThreads)
+    k_psel_sort_small(const int* __restrict__ list, int cnt, const T* __restrict__ keys, T* __restrict__ keys_out,
+                      int* __restrict__ vals_out)
+{
+    typedef typename KeyBits<T>::U U;
+    constexpr U sign = KeyBits<T>::sign;
+    __shared__ U sk[kPselSmallCap];
+    __shared__ int si[kPselSmallCap];
+    int P = 128;  // at least one wavefront's span
+    while (P < cnt)
+        P <<= 1;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < P; i += kPselSmallThreads)
+    {
+        U e = ~U(0);
+        int r = 0x7FFFFFFF;
+        if (i < cnt)
+        {
+            r = list[i];
+            const U bits = __builtin_bit_cast(U, keys[r]);
+            e = bits ^ ((bits & sign) ? ~U(0) : sign);
+        }
+        sk[i] = e;
+        si[i] = r;
+    }
+    // (the padding sorts behind every real pair: its row is larger than any row, its key not smaller than any key)
+    auto canon = [](U e) { return e == U(~sign) ? sign : e; };  // -0.0 as +0.0
+    int prev_j = 64;  // the loads above were by other wavefronts
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1)
+        {
+            // pair t of a step touches elements 2 (t - t % j) + t % j and that + j: for j < 64 the 64 pairs of a wavefront's
+            // pass stay inside one aligned run of 128 elements, the same run for every such j -- a wavefront's LDS
+            // operations execute in order, so only the compiler has to be kept from moving them
+            if (j >= 64 || prev_j >= 64)
+                __syncthreads();
+            else
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            prev_j = j;
+            for (int t = tid; t < (P >> 1); t += kPselSmallThreads)
+            {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), x = i | j;
+                const U a = sk[i], b = sk[x];
+                const int ra = si[i], rb = si[x];
+                const U ca = canon(a), cb = canon(b);
+                const bool gt = ca > cb || (ca == cb && ra > rb);
+                const bool asc = (i & k) == 0;
+                if (gt == asc)
+                {
+                    sk[i] = b;
+                    sk[x] = a;
+                    si[i] = rb;
+                    si[x] = ra;
+                }
+            }
+        }
+    __syncthreads();
+    auto key_at = [&](int i) {
+        const U e = sk[i];
+        return __builtin_bit_cast(T, U(e ^ ((e & sign) ? sign : ~U(0))));
+    };
+    for (int i = tid; i < cnt; i += kPselSmallThreads)
+    {
+        keys_out[i] = key_at(i);
+        vals_out[i] = si[i];
+    }
+}
 }  // namespace lbfgsx
 namespace lbfgsx {
 static int psort_alloc(lbfgsx_ctx* c)
@@ -1678,6 +1787,17 @@ template <class T>
 static int partial_sort_listed_t(lbfgsx_ctx* c, unsigned cnt, int64_t* nsorted)
 {
     lbfgsb_state* b = c->bstate;
+    if (b->psel_small && cnt >= 1 && cnt <= unsigned(kPselSmallCap))
+    {
+        // (the listed candidates are ordered break points: their key IS their break point, whether or not the build wrote keys_in)
+        *nsorted = int64_t(cnt);
+        g_psel_small++;
+        lbfgsx::model_add(double(cnt) * (64.0 + 4 + 2 * (sizeof(T) + 4)));  // byte model: the list, a sector per key, the sorted pairs out
+        LBFGSX_LAUNCH((k_psel_sort_small<T>), dim3(1), dim3(kPselSmallThreads), 0, c->stream, b->psel_list, int(cnt),
+                      b->keys_valid ? P<T>(b->keys_in) : static_cast<T*>(b->brk), P<T>(b->keys_out), b->vals_out);
+        LBFGSX_HIP(hipGetLastError());
+        return LBFGSX_OK;
+    }
     if (cnt > 1)
     {
         size_t bytes = b->psel_tmp_bytes;

@@ -913,6 +913,47 @@ def test_cauchy_finish_carrying_the_next_statements_changes_no_bit(A, monkeypatc
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("n,m,iters,ties", [(70001, 8, 40, False), (300000, 10, 45, False), (120000, 6, 40, True)])
+def test_short_candidate_lists_ordered_by_one_block_change_no_bit(A, monkeypatch, n, m, iters, ties, dtype):
+    """The partial sort of <= 4096 listed candidates in one block (k_psel_sort_small: (key, row) pairs ordered in LDS by the
+    radix sort's key order, rows ascending among equal keys) against the three launches it replaces (LBFGSX_PSEL_SMALL=0: radix
+    sort of the rows, gather of the keys, stable radix sort by key): the same sorted break points, so the same searches and the
+    same trajectory bit for bit (lbfgsx_b_psel_counts tells that the one-block form ran).  ties: blocks of coordinates share a,
+    b, x0 and the bounds, so whole groups of break points are EQUAL and only the row order separates them (Cauchy.h:193-199
+    walks them in that order)."""
+    dt = O.F64 if dtype == "f64" else O.F32
+    npdt = O.NPDT[dt]
+    a, b = O.quad_problem(n, 30.0, 29, dt)
+    if ties:
+        a = np.repeat(a[::8], 8)[:n].copy()
+        b = np.repeat(b[::8], 8)[:n].copy()
+    from lbfgspp_amd import _lib as L
+    core, _ = L.load()
+    res = {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("LBFGSX_PSEL_SMALL", on)
+        s = A.LBFGSBSolver(A.LBFGSBParam(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters), dtype=npdt)
+        tr = A.TraceBuffer(n, cap=512, stride=31)
+        x = np.zeros(n, dtype=npdt)
+        pc = (C.c_longlong * 1)()
+        core.lbfgsx_b_psel_counts(None, 1)
+        try:
+            niter, fx = s.minimize(A.DiagQuadratic(a, b), x, (-0.7 * np.ones(n)).astype(npdt), (0.9 * np.ones(n)).astype(npdt),
+                                   trace=tr)
+        except RuntimeError:
+            niter, fx = -1, float("nan")
+        core.lbfgsx_b_psel_counts(C.byref(pc), 0)
+        st = s.stats()
+        res[on] = (niter, s.last.nfev, x.copy(), tr.xs[:tr.count].copy(), st["submin_sweeps"], st["gcp_crossings"],
+                   st["gcp_partial_sorts"], list(pc))
+    f, u = res["1"], res["0"]
+    assert f[:2] == u[:2] and f[4:7] == u[4:7] and f[0] > 0
+    assert np.array_equal(f[2], u[2]) and np.array_equal(f[3], u[3])
+    assert f[6] > 0, "no search took the partial sort"
+    assert f[7][0] > 0 and u[7] == [0], "candidate lists ordered by one block: %s with, %s without" % (f[7], u[7])
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("n,m,iters,env", [(70001, 8, 40, {}), (90000, 10, 45, {}), (65536, 20, 50, {}),
                                            (120000, 10, 40, {"LBFGSX_GCP_TAU_FACTOR": "0"}),
                                            (120000, 6, 30, {"LBFGSX_SELECT_INLINE": "0"}),
