@@ -25,6 +25,11 @@ namespace xl {
 // blocks per CU saturate the memory system (a bare pass reads 6.27 TB/s at two, 6.1 at four / six), and every further
 // block adds to the reduction's partials and to the bunching of the waves (scripts/experiments/kernels_x.hip: kx_rows 185 /
 // 190 / 199 us at 2 / 3 / 4 blocks per CU)
+// Blocks per CU, measured inside cfg4's iteration (the host's wait behind each pass, scripts/r5/waits_ab.sh,
+// profiles/r5_grid_per_cu.txt): the passes that only stream -- by position over the compact copy -- are fastest at two blocks
+// per CU (kx_solve_sweep<0>: 273 / 247 / 264 us at 1 / 2 / 3); the two that also GATHER vectors by row number -- the first sweep,
+// which starts the compact vectors (293 / 312 / 319 us), and the W'd pass (260 / 273 / 282 us) -- are fastest at one: half as
+// many gather streams in the air.  (scripts/experiments/kernels_x.hip, where everything is by position, says two for all.)
 static inline int grid_rows(int64_t n, int rpw, int per_cu, int num_cus)
 {
     if (const char* e = getenv("LBFGSX_X_PER_CU"))  // A/B
@@ -119,7 +124,8 @@ int solve_sweep(hipStream_t s, int num_cus, int first, const ColsX<T>& cols, int
             model_compact_pass(n);
     }
 #define SWEEP(FIRST, IDX, RHSK, CVT)                                                                                              \
-    LBFGSX_LAUNCH((kx_solve_sweep<T, NCL_, G_, FIRST, IDX, RHSK, CVT>), dim3(grid_rows(n, 64 / G_, occ_sweep_x(NCL_, G_, FIRST), num_cus)), \
+    LBFGSX_LAUNCH((kx_solve_sweep<T, NCL_, G_, FIRST, IDX, RHSK, CVT>),                                                            \
+                  dim3(grid_rows(n, 64 / G_, FIRST ? 1 : occ_sweep_x(NCL_, G_, FIRST), num_cus)),                                      \
                   dim3(kBlock), 0, s, cols, ncols, b, bw, vsel_id, coef, has_w, theta, n, ws, out, lu_list, lu_cnt, lu_cap, ridx, cli,  \
                   cui, cv, pr)
 #define CALL(NCL, G)                                                      \
@@ -158,8 +164,10 @@ int multidot2_wf(hipStream_t s, int num_cus, const ColsX<T>& wfc, int ncols, int
     model_add(double(npos) * (double(ncols) * sizeof(T) + 4 + (dst_a ? 2.0 * sizeof(T) : 0.0)) +
               3.0 * model_gather(npos, npos * 2, int(sizeof(T))) + double(nlist) * 64.0 * (ncols + 2));
     model_compact_pass(npos);
+    static const int dots_per_cu = [] { const char* e = getenv("LBFGSX_X_DOTS_PER_CU"); return e ? std::max(1, atoi(e)) : 1; }();  // see grid_rows
 #define CALL(NCL, G)                                                                                                          \
-    LBFGSX_LAUNCH((kx_multidot2_wf<T, NCL, G>), dim3(grid_rows(std::max<int64_t>(npos, nlist), 64 / G, occ_dots_x(NCL), num_cus)),  \
+    LBFGSX_LAUNCH((kx_multidot2_wf<T, NCL, G>),                                                                               \
+                  dim3(grid_rows(std::max<int64_t>(npos, nlist), 64 / G, std::min(dots_per_cu, occ_dots_x(NCL)), num_cus)),   \
                   dim3(kBlock), 0, s, wfc, ncols, fresh_a, fresh_b, snew, ynew, dvec, idx, npos, full, list, nlist, ws, out, dst_a, dst_b)
     LBFGSX_XCLASS(ncols, CALL);
 #undef CALL
