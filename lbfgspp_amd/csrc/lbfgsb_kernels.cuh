@@ -1483,6 +1483,58 @@ __device__ inline void lu_append(bool app, int64_t i, int* __restrict__ lu_list,
     }
 }
 
+// The same through a buffer of the block (round 5).  With 10^4..10^5 rows to list -- the first dozen iterations of a
+// box-constrained run -- one counter update per wavefront is 10^4..10^5 atomics on ONE address: k_cauchy_finish took 0.26-0.59 ms
+// instead of 0.07, k_b_post_build 0.30-0.42 instead of 0.17 (profiles/r5_cfg4_timeline.txt).  Here a wavefront reserves its
+// places in an LDS buffer (an LDS atomic), and the block moves the buffer to the list once, at the end of its rows: one global
+// atomic per block and list.  Rows that do not fit the buffer go to the list directly, as before.  The order of a list is
+// arbitrary either way (the lists are sorted, or summed in double-double); the counter still ends at the number of rows met.
+// s_n must be zero (and visible to the block) before the first call; lu_flush_lds is called by every thread of the block.
+constexpr int kListBuf = 1024;
+__device__ inline void lu_append_capped(bool app, int64_t i, int* __restrict__ lu_list, unsigned* __restrict__ lu_cnt, unsigned lu_cap);
+template <bool CAPPED>
+__device__ inline void lu_append_lds(bool app, int64_t i, int* s_buf, unsigned* s_n, int* __restrict__ lu_list,
+                                     unsigned* __restrict__ lu_cnt, unsigned lu_cap)
+{
+    const unsigned long long am = __ballot(app);
+    if (am)
+    {
+        const int leader = __ffsll((long long) am) - 1;
+        const unsigned na = unsigned(__popcll(am));
+        unsigned basep = 0;
+        if (int(threadIdx.x & 63) == leader)
+            basep = atomicAdd(s_n, na);
+        basep = unsigned(__shfl(int(basep), leader, 64));
+        const unsigned pos = basep + unsigned(__popcll(am & ((1ull << (threadIdx.x & 63)) - 1ull)));
+        const bool fits = pos < unsigned(kListBuf);
+        if (app && fits)
+            s_buf[pos] = int(i);
+        if (basep + na > unsigned(kListBuf))  // (the same for every lane of the wavefront)
+        {
+            if (CAPPED)
+                lu_append_capped(app && !fits, i, lu_list, lu_cnt, lu_cap);
+            else
+                lu_append(app && !fits, i, lu_list, lu_cnt, lu_cap);
+        }
+    }
+}
+__device__ inline void lu_flush_lds(const int* s_buf, const unsigned* s_n, unsigned* s_base, int* __restrict__ lu_list,
+                                    unsigned* __restrict__ lu_cnt, unsigned lu_cap)
+{
+    __syncthreads();
+    const unsigned held = *s_n;
+    const unsigned m = held < unsigned(kListBuf) ? held : unsigned(kListBuf);
+    if (m == 0)  // (the same for every thread of the block)
+        return;
+    if (threadIdx.x == 0)
+        *s_base = atomicAdd(lu_cnt, m);
+    __syncthreads();
+    const unsigned base = *s_base;
+    for (unsigned j = threadIdx.x; j < m; j += blockDim.x)
+        if (base + j < lu_cap)
+            lu_list[base + j] = s_buf[j];
+}
+
 // ---------------------------------------------------------------- Cauchy build (Cauchy.h:111-129,154)
 // brk, vecd, sort keys/values; out[0] = d.d, out[1] = #free (brk = inf), out[2] = #ord (0 < brk < inf)
 // xforce != null: x = x.cwiseMax(lb).cwiseMin(ub) (LBFGSB.h:240, k_force_bounds) evaluated on the way -- this pass reads
@@ -1503,6 +1555,11 @@ __global__ void __launch_bounds__(kBlock) k_cauchy_build(BVecs<T> b, T* __restri
     // not zero go to olist; out[3] = their number (beyond ocap: the list is incomplete, the full-length pass runs)
     typedef typename AccOf<T>::type A;
     A acc[3];
+    __shared__ int s_ob[kListBuf], s_pb[kListBuf];  // the two lists' buffers (lu_append_lds)
+    __shared__ unsigned s_on, s_pn, s_lbase;
+    if (threadIdx.x == 0)
+        s_on = s_pn = 0;
+    __syncthreads();
     const T inf = T(__longlong_as_double(0x7FF0000000000000ll));
     const int64_t stride = int64_t(gridDim.x) * kBlock;
     for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
@@ -1544,11 +1601,15 @@ __global__ void __launch_bounds__(kBlock) k_cauchy_build(BVecs<T> b, T* __restri
         if (pos)
         {
             const bool outside = pos[i] < 0 && (di != T(0) || snew[i] != T(0));
-            lu_append(outside, i, olist, ocnt, ocap);
+            lu_append_lds<false>(outside, i, s_ob, &s_on, olist, ocnt, ocap);
         }
         if (plist)
-            lu_append(isord && t <= tau, i, plist, pcnt, pcap);
+            lu_append_lds<false>(isord && t <= tau, i, s_pb, &s_pn, plist, pcnt, pcap);
     }
+    if (pos)
+        lu_flush_lds(s_ob, &s_on, &s_lbase, olist, ocnt, ocap);
+    if (plist)
+        lu_flush_lds(s_pb, &s_pn, &s_lbase, plist, pcnt, pcap);
     if (grid_reduce<3>(acc, ws) && threadIdx.x == 0)
     {
         out[0] = double(T(acc[0].value()));
@@ -1594,6 +1655,11 @@ __global__ void __launch_bounds__(kBlock) k_b_post_build(BVecs<T> b, const T* __
     typedef typename AccOf<T>::type A;
     constexpr int W = Vec16<T>::W;
     A acc[7];  // x.x, s.y, y.y | d.d, #free, #ordered | #coordinates the clamp would move
+    __shared__ int s_ob[kListBuf], s_pb[kListBuf];  // the two lists' buffers (lu_append_lds)
+    __shared__ unsigned s_on, s_pn, s_lbase;
+    if (threadIdx.x == 0)
+        s_on = s_pn = 0;
+    __syncthreads();
     double pg = 0.0;
     const T inf = T(__longlong_as_double(0x7FF0000000000000ll));
     auto row = [&](int64_t i, T xi, T gi, T lo, T up, T xpi, T gpi, int posi, T& si, T& yi, T& t, T& di, T& key)
@@ -1632,10 +1698,10 @@ __global__ void __launch_bounds__(kBlock) k_b_post_build(BVecs<T> b, const T* __
         if (pos)
         {
             const bool outside = posi < 0 && (di != T(0) || si != T(0));
-            lu_append(outside, i, olist, ocnt, ocap);
+            lu_append_lds<false>(outside, i, s_ob, &s_on, olist, ocnt, ocap);
         }
         if (plist)
-            lu_append(isord && t <= tau, i, plist, pcnt, pcap);
+            lu_append_lds<false>(isord && t <= tau, i, s_pb, &s_pn, plist, pcnt, pcap);
     };
     const int64_t nv = n / W;
     const int64_t stride = int64_t(gridDim.x) * kBlock;
@@ -1685,6 +1751,10 @@ __global__ void __launch_bounds__(kBlock) k_b_post_build(BVecs<T> b, const T* __
             if (vals)
                 vals[i] = int(i);
         }
+    if (pos)
+        lu_flush_lds(s_ob, &s_on, &s_lbase, olist, ocnt, ocap);
+    if (plist)
+        lu_flush_lds(s_pb, &s_pn, &s_lbase, plist, pcnt, pcap);
     ext_publish<false>(pg, ws, 14);
     if (grid_reduce<7>(acc, ws))
     {
@@ -1800,6 +1870,11 @@ __global__ void __launch_bounds__(kBlock) k_cauchy_finish(BVecs<T> b, T t_cross,
     typedef typename AccOf<T>::type A;
     constexpr int W = Vec16<T>::W;
     A acc[2];
+    __shared__ int s_nb[kListBuf];  // the newly-active list's buffer (lu_append_lds)
+    __shared__ unsigned s_nn, s_lbase;
+    if (threadIdx.x == 0)
+        s_nn = 0;
+    __syncthreads();
     auto row = [&](int64_t i, T t, T x0i, T di, T& xc, unsigned char& s) __attribute__((always_inline)) {
         xc = x0i;  // what k_cauchy_build left in xcp: x0 (Cauchy.h:95)
         if (t == T(0))
@@ -1843,7 +1918,7 @@ __global__ void __launch_bounds__(kBlock) k_cauchy_finish(BVecs<T> b, T t_cross,
         {
 #pragma unroll
             for (int k = 0; k < W; k++)
-                lu_append_capped(s[k] == ST_NEWACT, vi * W + k, na_list, na_cnt, na_cap);
+                lu_append_lds<true>(s[k] == ST_NEWACT, vi * W + k, s_nb, &s_nn, na_list, na_cnt, na_cap);
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0)
@@ -1863,6 +1938,8 @@ __global__ void __launch_bounds__(kBlock) k_cauchy_finish(BVecs<T> b, T t_cross,
                     na_list[pos] = int(i);
             }
         }
+    if (na_list)
+        lu_flush_lds(s_nb, &s_nn, &s_lbase, na_list, na_cnt, na_cap);
     if (grid_reduce<2>(acc, ws) && threadIdx.x == 0)
     {
         out[0] = acc[0].value();
