@@ -2251,6 +2251,11 @@ __global__ void __launch_bounds__(kBlock) k_sub_sweep_begin(BVecs<T> b, int firs
     // instead of scanning n state bytes).  The count is nL + nU, known to the host from the sums below.
     typedef typename AccOf<T>::type A;
     unsigned cnt[7] = {0, 0, 0, 0, 0, 0, 0};
+    __shared__ int s_lb[kListBuf];  // the list's buffer (lu_append_lds)
+    __shared__ unsigned s_ln, s_lbase;
+    if (threadIdx.x == 0)
+        s_ln = 0;
+    __syncthreads();
     const int64_t stride = int64_t(gridDim.x) * kBlock;
     for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
     {
@@ -2261,8 +2266,10 @@ __global__ void __launch_bounds__(kBlock) k_sub_sweep_begin(BVecs<T> b, int firs
         const T lam = first ? T(0) : b.lam[i], mu = first ? T(0) : b.mu[i];
         s = sweep_row<T>(b, i, s, yi, lam, mu, first != 0, true, cnt);
         if (lu_cap)
-            lu_append((s & (ST_L | ST_U)) != 0, i, lu_list, lu_cnt, lu_cap);
+            lu_append_lds<false>((s & (ST_L | ST_U)) != 0, i, s_lb, &s_ln, lu_list, lu_cnt, lu_cap);
     }
+    if (lu_cap)
+        lu_flush_lds(s_lb, &s_ln, &s_lbase, lu_list, lu_cnt, lu_cap);
     A acc[7];
     sweep_counts<T, A>(cnt, acc);
     if (grid_reduce<7>(acc, ws) && threadIdx.x == 0)

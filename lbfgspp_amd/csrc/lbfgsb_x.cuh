@@ -480,6 +480,10 @@ __global__ void __launch_bounds__(kBlock, occ_sweep_x(NCL, G, FIRST))
     __shared__ const T* s_col[kColsX];
     __shared__ T sc[kColsX];
     __shared__ T s_c1[RHSK ? kColsX : 1], s_c2[RHSK ? kColsX : 1];
+    __shared__ int s_lb[kListBuf];  // the L u U list's buffer (lu_append_lds: one global atomic per block, not per wavefront --
+    __shared__ unsigned s_ln, s_lbase;  // in the first iterations a sweep lists 10^5 rows)
+    if (threadIdx.x == 0)
+        s_ln = 0;
     if (threadIdx.x < kColsX)
     {
         s_col[threadIdx.x] = cols.p[threadIdx.x];
@@ -633,10 +637,10 @@ __global__ void __launch_bounds__(kBlock, occ_sweep_x(NCL, G, FIRST))
             if (IDX && cvt)
             {
                 if (__ballot(app))  // wave-uniform; rare in steady state
-                    lu_append(app, app ? int64_t(ridx[t]) : int64_t(0), lu_list, lu_cnt, lu_cap);
+                    lu_append_lds<false>(app, app ? int64_t(ridx[t]) : int64_t(0), s_lb, &s_ln, lu_list, lu_cnt, lu_cap);
             }
             else
-                lu_append(app, i, lu_list, lu_cnt, lu_cap);  // the list holds rows
+                lu_append_lds<false>(app, i, s_lb, &s_ln, lu_list, lu_cnt, lu_cap);  // the list holds rows
         }
     };
     {
@@ -688,6 +692,8 @@ __global__ void __launch_bounds__(kBlock, occ_sweep_x(NCL, G, FIRST))
 #endif
         }
     }
+    if (lu_cap)
+        lu_flush_lds(s_lb, &s_ln, &s_lbase, lu_list, lu_cnt, lu_cap);
     sweep_counts<T, A>(cnt, acc + ND);
     A tot;
     if (grid_reduce_x<NL, G, A>(acc, ws, tot))
