@@ -10,9 +10,12 @@
 //
 // Here lane l of a wavefront holds columns [g * NCL, (g + 1) * NCL) of row `base + l % (64 / G)`, g = l / (64 / G):
 // NCL = 8..20 column values and NCL + 1 accumulators per lane whatever 2c is.  Waves per SIMD as built (scripts/r5/
-// kernel_resources.py, profiles/r5_kernel_resources.tsv; class (10, 2), double): kx_rows<NA = 1> 163-166 VGPRs = 3,
-// kx_solve_sweep<FIRST> 164 = 3, kx_solve_sweep<0, RHSK> 212 = 2, kx_rows<NA = 3> 238 = 2 (3 x 11 double-double sums alone are
-// 132 registers), kx_multidot2_wf 240 = 2; the 15- and 20-column classes one wave.  No scratch memory in any class.  Every load
+// kernel_resources.py, profiles/r5_kernel_resources.tsv; class (10, 2), double): kx_rows<NA = 1> 160-164 VGPRs = 3,
+// kx_solve_sweep<FIRST> 152 = 3, kx_solve_sweep<0, RHSK> 204 = 2, kx_rows<NA = 3> 236 = 2 (3 x 11 double-double sums alone are
+// 132 registers), kx_multidot2_wf 240 = 2; the 15- and 20-column classes one wave.  No scratch memory in any class.  (Two waves
+// are enough where a pass only streams: kx_solve_sweep<0> runs at 6.15 TB/s against 6.2 for bare loads of its pattern, a third
+// register set adds nothing and the (5, 4) class -- three waves -- is slower on every pass: profiles/r5_kernels_x_harness.txt.)
+// Every load
 // of a row is still issued unconditionally and up front.  Loads stay coalesced: the lanes of a group read 64 / G consecutive rows of
 // one column (256 / 128 bytes at G = 2 / 4).  What a row needs from all of its columns --
 //   * the left-to-right sum (W coef)(row) of the prologue statements and of the solve (the reference accumulates short
@@ -70,6 +73,8 @@ struct RowsX
 // 2 no stores, 3 no cross-lane moves -- what each part of a trip costs (kx_rows); kx_solve_sweep: 16 no sweep statements (and
 // their stores), 32 no y / rhs stores, 64 no double-double products, 128 no left-to-right sums, 256 no list appends.
 // 0 in the product.
+// experiment builds only: 3 = kx_solve_sweep with three register sets (two trips of loads in the air): 250-256 VGPRs, no
+// scratch, and no faster (182 -> 187 us) -- the pass is at the floor of its access pattern with two
 #ifndef LBFGSX_X_NBUF
 #define LBFGSX_X_NBUF 2
 #endif
