@@ -122,6 +122,7 @@ struct lbfgsb_state
     void* psel_tmp = nullptr;             // radix-sort workspace for psel_cap row numbers
     size_t psel_tmp_bytes = 0;
     int64_t psel_last = -1;               // candidates of the previous partial sort: the in-pass list pays while they are few
+    bool list12 = true;                   // W_{L u U}'(-c) inside the pass that computes W_L'l and W_U'u (LBFGSX_LIST12=0: a launch of its own)
     bool psel_small = true;               // <= kPselSmallCap listed candidates: ordered by one block (LBFGSX_PSEL_SMALL=0: the three launches)
     int64_t psel_max = int64_t(1) << 17;  // (appending and ordering 10^6 rows costs more than the separate selection pass)
     // W'd of the Cauchy search (and the deferred dots of add_correction) from the kept compact copy (k_multidot2_wf)
@@ -499,6 +500,8 @@ int bounded_alloc(lbfgsx_ctx* c)
         b->fd_use = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_SELECT_MAX"))  // candidates of the previous search up to which the build lists them
         b->psel_max = std::max<int64_t>(0, atoll(e));
+    if (const char* e = getenv("LBFGSX_LIST12"))
+        b->list12 = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_PSEL_SMALL"))  // 0: a short candidate list is ordered by the three launches of round 4
         b->psel_small = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_SELECT_CAP"))  // test aid: a short list overflows
@@ -2531,7 +2534,12 @@ int lbfgsx_b_wtv_lu_c(lbfgsx_ctx* c, double* out_l, int64_t* nnz_l, double* out_
     // W_{L u U}'(-c) un-rounded (negc_dd; the split-row kernels only): a launch of its own ahead of the pass below, read after
     // the same wait.  What BFGSMatB::solve_PtBP subtracts from W_F'(-c) to have W_P'(-c) without a pass over P.
     bool have_c = false;
-    if (negc_dd && b->split && b->rhs_identity && b->dout_host)
+    // (round 5) ... or a third set of sums inside the pass below, which walks the same rows (kx_list2<..., WITHC>;
+    // LBFGSX_LIST12=0: the launch of its own)
+    const bool c_inside = negc_dd && b->split && b->rhs_identity && b->dout_host && b->list12;
+    if (c_inside)
+        have_c = true;
+    else if (negc_dd && b->split && b->rhs_identity && b->dout_host)
     {
         DISPATCH_T(c, {
             const unsigned char* stc = b->cv_live ? bvecs_cv<T>(c).st : static_cast<const unsigned char*>(nullptr);
@@ -2554,7 +2562,8 @@ int lbfgsx_b_wtv_lu_c(lbfgsx_ctx* c, double* out_l, int64_t* nnz_l, double* out_
             const unsigned char* stc = b->cv_live ? bvecs_cv<T>(c).st : static_cast<const unsigned char*>(nullptr);
             const int* stpos = b->cv_live ? b->wf_pos : static_cast<const int*>(nullptr);
             rc = xl::list2<T>(c->stream, b->num_cus, colsx_full<T>(c, total), total, bvecs<T>(c), b->lu_ptr(), nl, wsx(c), b->dout, stc,
-                              stpos);
+                              stpos, c_inside ? b->dout + 256 : static_cast<double*>(nullptr),
+                              c_inside ? b->dout + 352 : static_cast<double*>(nullptr));
         });
         if (rc)
             return rc;

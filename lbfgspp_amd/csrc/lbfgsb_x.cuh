@@ -927,13 +927,18 @@ __global__ void __launch_bounds__(kBlock, occ_dots_x(NCL))
 
 // ---------------------------------------------------------------- W_L' l and W_U' u over the index list of L u U: k_multidot_list2 for
 // 2c <= 80.  out = {L dots [ncols], nnz_L, U dots [ncols], nnz_U}
-template <class T, int NCL, int G>
-__global__ void __launch_bounds__(kBlock, occ_dots_x(NCL))
+// WITHC (round 5): also W_{L u U}'(-c) -- kx_list1 with VS_NEG_CF over the same list and mask, which a sweep launched right
+// ahead of this pass: the same rows, the same column values, one vector more.  A third set of sums (the same rows in the same
+// lanes and blocks as kx_list1 had them, so the same un-rounded pairs), outputs where kx_list1 wrote them (out_c: {dots [ncols],
+// nnz}, out_c_dd: (hi, lo) of every dot); one launch of ~10 us less per sweep.
+template <class T, int NCL, int G, bool WITHC = false>
+__global__ void __launch_bounds__(kBlock, WITHC ? 1 : occ_dots_x(NCL))
     kx_list2(ColsX<T> cols, int ncols, BVecs<T> b, const int* __restrict__ list, int nlist, RedWsX ws, double* __restrict__ out,
-             const unsigned char* __restrict__ stc, const int* __restrict__ pos)
+             const unsigned char* __restrict__ stc, const int* __restrict__ pos, double* __restrict__ out_c,
+             double* __restrict__ out_c_dd)
 {
     typedef typename AccOf<T>::type A;
-    constexpr int RPW = 64 / G, NP = NCL + 1, NL = 2 * NP;
+    constexpr int RPW = 64 / G, NP = NCL + 1, NL = (WITHC ? 3 : 2) * NP;
     __shared__ const T* s_col[kColsX];
     if (threadIdx.x < kColsX)
         s_col[threadIdx.x] = cols.p[threadIdx.x];
@@ -951,12 +956,23 @@ __global__ void __launch_bounds__(kBlock, occ_dots_x(NCL))
         const int64_t i = list[inb ? e : int64_t(nlist) - 1];
         const unsigned char st = stc ? stc[pos[i]] : b.st[i];
         const T lo = b.lb[i], up = b.ub[i], x0 = b.x0[i];
+        T vc = T(0);
+        if (WITHC)
+            vc = -b.cF[i];  // vsel(b, VS_NEG_CF, i)
         T w[NCL];
 #pragma unroll
         for (int k = 0; k < NCL; k++)
             w[k] = cp[k][i];
         if (!inb || !(st & (ST_L | ST_U)))
             continue;
+        if (WITHC)
+        {
+            if (vc != T(0))
+                acc[(WITHC ? 2 : 0) * NP + NCL].add(T(1));
+#pragma unroll
+            for (int k = 0; k < NCL; k++)
+                acc[(WITHC ? 2 : 0) * NP + k].add_prod(w[k], vc);
+        }
         const bool isl = (st & ST_L) != 0;
         const T v = isl ? lo - x0 : up - x0;
         if (isl)
@@ -988,13 +1004,23 @@ __global__ void __launch_bounds__(kBlock, occ_dots_x(NCL))
             {
                 const int col = gg * NCL + k;
                 if (col < ncols)
-                    idx = which * (ncols + 1) + col;
+                    idx = col;
             }
             else if (gg == 0)
-                idx = which * (ncols + 1) + ncols;
+                idx = ncols;
             if (idx >= 0)
             {
-                out[idx] = double(T(tot.value()));
+                if (WITHC && which == 2)
+                {
+                    out_c[idx] = double(T(tot.value()));
+                    if (idx < ncols)
+                    {
+                        out_c_dd[2 * idx] = tot.hi;
+                        out_c_dd[2 * idx + 1] = acc_lo(tot);
+                    }
+                }
+                else
+                    out[which * (ncols + 1) + idx] = double(T(tot.value()));
                 out_fence_sys();
             }
         }

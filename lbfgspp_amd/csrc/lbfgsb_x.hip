@@ -193,15 +193,20 @@ int multidot2(hipStream_t s, int num_cus, const ColsX<T>& cols, int ncols, const
 
 template <class T>
 int list2(hipStream_t s, int num_cus, const ColsX<T>& cols, int ncols, const BVecs<T>& b, const int* list, int nlist, const RedWsX& ws,
-          double* out, const unsigned char* stc, const int* pos)
+          double* out, const unsigned char* stc, const int* pos, double* out_c, double* out_c_dd)
 {
-    if (ncols < 1 || ncols > kColsX)
+    if (ncols < 1 || ncols > kColsX || (out_c != nullptr) != (out_c_dd != nullptr))
         return LBFGSX_E_INVALID;
-    model_add(double(nlist) * (64.0 * (ncols + 3) + 4 + 64));  // byte model: a sector per column and vector at every listed row
+    // byte model: a sector per column and vector at every listed row (out_c: cF too)
+    model_add(double(nlist) * (64.0 * (ncols + 3 + (out_c ? 1 : 0)) + 4 + 64));
     // a short list: few blocks keep the reduction tail short
 #define CALL(NCL, G)                                                                                                      \
-    LBFGSX_LAUNCH((kx_list2<T, NCL, G>), dim3(std::min(32, grid_rows(nlist, 64 / G, 1, num_cus))), dim3(kBlock), 0, s, cols,   \
-                  ncols, b, list, nlist, ws, out, stc, pos)
+    if (out_c)                                                                                                            \
+        LBFGSX_LAUNCH((kx_list2<T, NCL, G, true>), dim3(std::min(32, grid_rows(nlist, 64 / G, 1, num_cus))), dim3(kBlock), 0, s, \
+                      cols, ncols, b, list, nlist, ws, out, stc, pos, out_c, out_c_dd);                                   \
+    else                                                                                                                  \
+        LBFGSX_LAUNCH((kx_list2<T, NCL, G, false>), dim3(std::min(32, grid_rows(nlist, 64 / G, 1, num_cus))), dim3(kBlock), 0, s, \
+                      cols, ncols, b, list, nlist, ws, out, stc, pos, out_c, out_c_dd)
     LBFGSX_XCLASS(ncols, CALL);
 #undef CALL
     LBFGSX_HIP(hipGetLastError());
@@ -336,7 +341,7 @@ int gram_finish(hipStream_t s, const double* partial, int blocks, int ntile, dou
                                  const ColsX<T>&, const int*, int, const RedWsX&, double*, T*, T*);                              \
     template int multidot2<T>(hipStream_t, int, const ColsX<T>&, int, const T*, const T*, int64_t, const RedWsX&, double*);        \
     template int list2<T>(hipStream_t, int, const ColsX<T>&, int, const BVecs<T>&, const int*, int, const RedWsX&, double*,         \
-                          const unsigned char*, const int*);                                                                     \
+                          const unsigned char*, const int*, double*, double*);                                                   \
     template int list1<T>(hipStream_t, int, const ColsX<T>&, int, const BVecs<T>&, int, int, const int*, int, const RedWsX&,         \
                           double*, const unsigned char*, const int*, double*);                                                   \
     template int multidot_mask<T>(hipStream_t, int, const ColsX<T>&, int, const BVecs<T>&, int, const T*, int, int64_t,            \

@@ -24,7 +24,7 @@ int multidot2(hipStream_t s, int num_cus, const ColsX<T>& cols, int ncols, const
               double* out);
 template <class T>
 int list2(hipStream_t s, int num_cus, const ColsX<T>& cols, int ncols, const BVecs<T>& b, const int* list, int nlist, const RedWsX& ws,
-          double* out, const unsigned char* stc, const int* pos);
+          double* out, const unsigned char* stc, const int* pos, double* out_c = nullptr, double* out_c_dd = nullptr);
 template <class T>
 int list1(hipStream_t s, int num_cus, const ColsX<T>& cols, int ncols, const BVecs<T>& b, int vsel_id, int mask, const int* list, int nlist,
           const RedWsX& ws, double* out, const unsigned char* stc = nullptr, const int* pos = nullptr, double* out_dd = nullptr);

@@ -913,6 +913,37 @@ def test_cauchy_finish_carrying_the_next_statements_changes_no_bit(A, monkeypatc
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("n,m,iters", [(70001, 8, 40), (300000, 10, 45), (90000, 20, 50), (65536, 40, 70)])
+def test_sums_over_the_L_u_U_list_in_one_pass_change_no_bit(A, monkeypatch, n, m, iters, dtype):
+    """A BOXCQP sweep's W_{L u U}'(-c) as a third set of sums inside the pass that computes W_L'l and W_U'u over the same index
+    list (kx_list2<..., WITHC>) against the launch of its own that preceded that pass (LBFGSX_LIST12=0: kx_list1): the same rows
+    in the same lanes, so the same un-rounded (hi, lo) pairs -- which the "W_P'rhs without a pass" identity subtracts from
+    others before rounding (BFGSMatB::solve_PtBP) -- and the same trajectory bit for bit; the identity must have run."""
+    dt = O.F64 if dtype == "f64" else O.F32
+    npdt = O.NPDT[dt]
+    a, b = O.quad_problem(n, 30.0, 41, dt)
+    res = {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("LBFGSX_LIST12", on)
+        s = A.LBFGSBSolver(A.LBFGSBParam(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters), dtype=npdt)
+        tr = A.TraceBuffer(n, cap=512, stride=37)
+        x = np.zeros(n, dtype=npdt)
+        try:
+            niter, fx = s.minimize(A.DiagQuadratic(a, b), x, (-0.7 * np.ones(n)).astype(npdt), (0.9 * np.ones(n)).astype(npdt),
+                                   trace=tr)
+        except RuntimeError:
+            niter, fx = -1, float("nan")
+        st = s.stats()
+        res[on] = (niter, s.last.nfev, x.copy(), tr.xs[:tr.count].copy(), st["submin_sweeps"], st["gcp_crossings"],
+                   st["rhs_identities"])
+    f, u = res["1"], res["0"]
+    assert f[:2] == u[:2] and f[4:] == u[4:] and f[0] > 0
+    assert np.array_equal(f[2], u[2]) and np.array_equal(f[3], u[3])
+    if dtype == "f64":
+        assert f[6] > 0, "no sweep took the identity that reads these sums"
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("n,m,iters,ties", [(70001, 8, 40, False), (300000, 10, 45, False), (120000, 6, 40, True)])
 def test_short_candidate_lists_ordered_by_one_block_change_no_bit(A, monkeypatch, n, m, iters, ties, dtype):
     """The partial sort of <= 4096 listed candidates in one block (k_psel_sort_small: (key, row) pairs ordered in LDS by the
