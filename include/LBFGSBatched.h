@@ -65,6 +65,29 @@ public:
 private:
     typedef typename LineSearch<Scalar>::Machine Machine;
     const LBFGSParam<Scalar>& m_param;
+    // The batch (about (2m + 9) n P scalars of device memory) stays alive between minimisations of the same shape on the
+    // same device: a second minimize() re-uses it (lbfgsx_bat_reset) instead of allocating ~12 GB again.
+    lbfgsx_batch* m_ctx = nullptr;
+    std::int64_t m_ctx_n = 0;
+    int m_ctx_P = 0, m_ctx_dev = -1;
+    bool m_timing = false;
+
+    lbfgsx_batch* acquire(std::int64_t n, int P, int device)
+    {
+        if (m_ctx && (m_ctx_n != n || m_ctx_P != P || m_ctx_dev != device))
+            release();
+        if (!m_ctx)
+        {
+            detail::check(lbfgsx_bat_create(&m_ctx, detail::dtype_of<Scalar>::value, n, m_param.m, P, device));
+            m_ctx_n = n;
+            m_ctx_P = P;
+            m_ctx_dev = device;
+        }
+        else
+            detail::check(lbfgsx_bat_reset(m_ctx));
+        detail::check(lbfgsx_bat_timing(m_ctx, m_timing ? 1 : 0));
+        return m_ctx;
+    }
 
     struct Prob
     {
@@ -94,7 +117,32 @@ private:
     }
 
 public:
+    // what the last single-device minimize() did: lock-step iterations (= launches of the one-launch form), and -- with
+    // set_timing(true) -- the sum of the durations of its kernels, its launches and its host waits
+    struct Stats
+    {
+        int lockstep_iterations = 0;
+        bool fused = false;
+        double kernel_ms = 0.0;
+        std::int64_t launches = 0, waits = 0, wait_timeouts = 0;
+    };
+    Stats stats;
+
     LBFGSBatchedSolver(const LBFGSParam<Scalar>& param) : m_param(param) { m_param.check_param(); }
+    ~LBFGSBatchedSolver() { release(); }
+    LBFGSBatchedSolver(const LBFGSBatchedSolver&) = delete;
+    LBFGSBatchedSolver& operator=(const LBFGSBatchedSolver&) = delete;
+
+    // allocate the batch for `count` problems of dimension n on `device` now (otherwise the first minimize() does)
+    void prepare(std::int64_t n, int count, int device) { (void) acquire(n, count, device); }
+    void release()
+    {
+        if (m_ctx)
+            lbfgsx_bat_destroy(m_ctx);
+        m_ctx = nullptr;
+    }
+    // events around every launch of the following minimisations (instrumentation: `stats.kernel_ms`)
+    void set_timing(bool on) { m_timing = on; }
 
     // problems first .. first+count-1, problem id -> extended-Rosenbrock start point of seed seed_base + id
     // optional x_out: count*n scalars, the final iterates
@@ -128,13 +176,30 @@ private:
         if (count <= 0)
             return;
         const int m = m_param.m, P = count;
-        lbfgsx_batch* c = nullptr;
-        detail::check(lbfgsx_bat_create(&c, detail::dtype_of<Scalar>::value, n, m, P, device));
-        struct Guard
+        lbfgsx_batch* c = acquire(n, P, device);
+        stats = Stats();
+        struct Finish  // the instrumentation of this minimisation, also when it throws
         {
+            LBFGSBatchedSolver* self;
             lbfgsx_batch* c;
-            ~Guard() { lbfgsx_bat_destroy(c); }
-        } guard{c};
+            ~Finish()
+            {
+                double t[4] = {0, 0, 0, 0};
+                if (lbfgsx_bat_timing_read(c, t) == LBFGSX_OK)
+                {
+                    self->stats.kernel_ms = t[0];
+                    self->stats.launches = std::int64_t(t[1]);
+                    self->stats.waits = std::int64_t(t[2]);
+                    self->stats.wait_timeouts = std::int64_t(t[3]);
+                }
+            }
+        } finish{this, c};
+        if (lbfgsx_bat_iterate_ok(c))
+        {
+            stats.fused = true;
+            run_fused(c, n, seed_base, first, count, out, x_out, bobj, fun);
+            return;
+        }
         auto YS = [&](int col) { return lbfgsx_bat_scalar_index(c, 0, col); };
         auto TH = [&](int col) { return lbfgsx_bat_scalar_index(c, 1, col); };
         auto DOT = [&](int k) { return lbfgsx_bat_scalar_index(c, 2, k); };
@@ -348,6 +413,7 @@ private:
 
         for (int k = 1; remaining > 0; k++)
         {
+            stats.lockstep_iterations++;
             // ---- line searches, one trial per launch for every problem still searching (LBFGS.h:121-127)
             int searching = 0;
             for (int p = 0; p < P; p++)
@@ -504,6 +570,294 @@ private:
         }
     }
 
+private:
+    // The same control flow over lbfgsx_bat_iterate: ONE launch per lock-step iteration carries the statements after the
+    // line search of iteration k-1 (LBFGS.h:130,137,159-161), the recursion (:165) and the first trial of the line search
+    // of iteration k (:121-127, step known: :108,168); further trials of a search are the statement-wise launches.  The
+    // host applies the reference's tests to the sums in the reference's order; a problem that stops has had its direction
+    // and first trial computed in vain, nothing else.
+    void run_fused(lbfgsx_batch* c, std::int64_t n, std::uint64_t seed_base, std::int64_t first, int count, std::vector<Item>& out,
+                   Scalar* x_out, const BatchObjective& bobj, const BatchFunctor<Scalar>* fun)
+    {
+        using std::abs;
+        using std::sqrt;
+        const int m = m_param.m, P = count;
+        const int OUT0 = lbfgsx_bat_scalar_index(c, 3, 0);
+        const int fpast = m_param.past;
+        constexpr Scalar eps = std::numeric_limits<Scalar>::epsilon();
+        const bool fuse_trial = (fun == nullptr);
+
+        std::vector<Prob> pr(static_cast<size_t>(P));
+        for (int p = 0; p < P; p++)
+        {
+            pr[size_t(p)].phys.resize(size_t(m));
+            for (int j = 0; j < m; j++)
+                pr[size_t(p)].phys[size_t(j)] = j;
+            pr[size_t(p)].spare = m;
+            pr[size_t(p)].ptr = m;
+            if (fpast > 0)
+                pr[size_t(p)].fxh.assign(size_t(fpast), Scalar(0));
+        }
+        std::vector<lbfgsx_bat_desc> desc(static_cast<size_t>(P));
+        std::vector<lbfgsx_bat_itdesc> itd(static_cast<size_t>(P));
+        std::vector<double> res(size_t(P) * 4), ires(size_t(P) * LBFGSX_BAT_NRES);
+        auto clear_desc = [&]() {
+            for (auto& d : desc)
+            {
+                d = lbfgsx_bat_desc();
+                d.i_out = OUT0;
+            }
+        };
+        std::vector<int> fpoint(static_cast<size_t>(P));
+        std::vector<Scalar> ffx(static_cast<size_t>(P));
+        std::vector<double> res1(static_cast<size_t>(P) * 2);
+        auto user_eval = [&](bool at_out) {
+            for (int p = 0; p < P; p++)
+                fpoint[size_t(p)] = desc[size_t(p)].active ? (at_out ? desc[size_t(p)].x_out : desc[size_t(p)].x_in) : -1;
+            detail::check(lbfgsx_bat_sync(c));  // the points are written: the functor may use any stream
+            fun->eval(c, fpoint.data(), ffx.data());
+        };
+        auto launch_eval = [&]() {  // {f, grad.grad, x.x} at x_in of every active problem
+            if (!fun)
+            {
+                detail::check(lbfgsx_bat_launch(c, LBFGSX_BAT_EVAL, bobj.id, desc.data(), 3, res.data()));
+                return;
+            }
+            user_eval(false);
+            detail::check(lbfgsx_bat_launch(c, LBFGSX_BAT_NORMS, bobj.id, desc.data(), 2, res1.data()));
+            for (int p = 0; p < P; p++)
+            {
+                res[size_t(p) * 3 + 0] = double(ffx[size_t(p)]);
+                res[size_t(p) * 3 + 1] = res1[size_t(p) * 2 + 0];
+                res[size_t(p) * 3 + 2] = res1[size_t(p) * 2 + 1];
+            }
+        };
+        auto launch_trial = [&]() {  // x_out = x_in + step * drt; {f, grad.drt} there
+            if (!fun)
+            {
+                detail::check(lbfgsx_bat_launch(c, LBFGSX_BAT_TRIAL, bobj.id, desc.data(), 2, res.data()));
+                return;
+            }
+            detail::check(lbfgsx_bat_launch(c, LBFGSX_BAT_POINT, bobj.id, desc.data(), 0, nullptr));
+            user_eval(true);
+            detail::check(lbfgsx_bat_launch(c, LBFGSX_BAT_GDOT, bobj.id, desc.data(), 1, res1.data()));
+            for (int p = 0; p < P; p++)
+            {
+                res[size_t(p) * 2 + 0] = double(ffx[size_t(p)]);
+                res[size_t(p) * 2 + 1] = res1[size_t(p)];
+            }
+        };
+
+        // fx = f(x, grad); gnorm                                                   (LBFGS.h:91-103)
+        if (fun)
+            fun->start(c);
+        else if (bobj.id == LBFGSX_OBJ_DIAG_QUAD)
+            detail::check(lbfgsx_bat_gen_diag_quad(c, bobj.kappa, seed_base + std::uint64_t(first)));
+        else if (bobj.id == LBFGSX_OBJ_EXT_ROSENBROCK)
+            detail::check(lbfgsx_bat_gen_rosen_x0(c, seed_base + std::uint64_t(first)));
+        else
+            throw std::invalid_argument("LBFGSBatchedSolver::minimize: unknown built-in objective");
+        clear_desc();
+        for (auto& d : desc)
+            d.active = 1;
+        launch_eval();
+        int remaining = 0;
+        for (int p = 0; p < P; p++)
+        {
+            Prob& q = pr[size_t(p)];
+            Item& it = out[size_t(p)];
+            q.fx = Scalar(res[size_t(p) * 3 + 0]);
+            q.gnorm = sqrt(Scalar(res[size_t(p) * 3 + 1]));
+            it.nfev = 1;
+            if (fpast > 0)
+                q.fxh[0] = q.fx;
+            if (q.gnorm <= m_param.epsilon || q.gnorm <= m_param.epsilon_rel * sqrt(Scalar(res[size_t(p) * 3 + 2])))
+            {
+                q.done = true;
+                it.niter = 1;
+            }
+            else
+                remaining++;
+            q.step = Scalar(1) / q.gnorm;  // LBFGS.h:108 (drt = -grad before the first correction)
+        }
+
+        int searching = 0;
+        // one evaluated trial of problem p's search (LineSearchMoreThuente.h / LineSearchNocedalWright.h drivers)
+        auto consume = [&](int p, Scalar fx, Scalar dg, int k) {
+            Prob& q = pr[size_t(p)];
+            out[size_t(p)].nfev++;
+            bool keep = false;
+            typename Machine::Action a;
+            try
+            {
+                a = q.mt.feed(fx, dg, keep);
+            }
+            catch (const std::runtime_error& e)  // what the single solve's search would throw (Nocedal-Wright)
+            {
+                // as the single-problem solver (and the reference's policies, which write every trial into x itself:
+                // LineSearchNocedalWright.h:146,219): the point returned is the last trial, not the iterate the search started from
+                q.cur = q.trial;
+                fail(q, out[size_t(p)], LBFGSX_E_RUNTIME, e.what(), k);
+                q.fx = fx;
+                searching--;
+                remaining--;
+                return;
+            }
+            if (keep)
+            {
+                if (q.lo == q.xp)
+                {
+                    q.lo = q.trial;
+                    q.trial = third(q.xp, q.lo);
+                }
+                else
+                    std::swap(q.lo, q.trial);
+            }
+            if (a == Machine::TRIAL)
+                return;
+            q.in_ls = false;
+            searching--;
+            if (a == Machine::DONE_TRIAL)
+            {
+                q.cur = q.trial;
+                q.fx = fx;
+                q.dg = dg;
+            }
+            else
+            {
+                q.cur = q.lo;
+                q.fx = q.mt.fx();
+                q.dg = q.mt.dg();
+            }
+        };
+
+        for (int k = 1; remaining > 0; k++)
+        {
+            stats.lockstep_iterations++;
+            const int kk = k - 1;  // the iteration whose line search has just finished (k > 1)
+            const bool last = (k > 1 && m_param.max_iterations != 0 && kk >= m_param.max_iterations);
+            // ---- one launch: [statements after search kk] + drt = -H grad + [first trial of search k]
+            for (int p = 0; p < P; p++)
+            {
+                Prob& q = pr[size_t(p)];
+                lbfgsx_bat_itdesc& d = itd[size_t(p)];
+                d = lbfgsx_bat_itdesc();
+                if (q.done)
+                    continue;
+                d.active = 1;
+                d.cur = q.cur;
+                d.ncorr = q.ncorr;
+                int j = q.ptr % m;
+                for (int i = 0; i < q.ncorr; i++)
+                {
+                    j = (j + m - 1) % m;
+                    d.pcol[i] = q.phys[size_t(j)];
+                }
+                if (k > 1)
+                {
+                    q.step = Scalar(1);  // LBFGS.h:168: every search after the first opens with the unit step
+                    d.flags |= LBFGSX_BAT_IT_POST;
+                    d.xp = q.xp;
+                    d.spare = q.spare;
+                    if (last)  // every problem still running stops at max_iterations (LBFGS.h:152-155): sums only
+                        d.flags |= LBFGSX_BAT_IT_POST_ONLY;
+                }
+                if (fuse_trial && !last)
+                {
+                    d.flags |= LBFGSX_BAT_IT_TRIAL;
+                    d.trial = (q.cur + 1) % 3;
+                    d.step = double(q.step);
+                }
+            }
+            detail::check(lbfgsx_bat_iterate(c, bobj.id, itd.data(), ires.data()));
+
+            // ---- the reference's statements on the sums, then the start of search k
+            for (int p = 0; p < P; p++)
+            {
+                Prob& q = pr[size_t(p)];
+                if (q.done)
+                    continue;
+                const double* r = &ires[size_t(p) * LBFGSX_BAT_NRES];
+                Item& it = out[size_t(p)];
+                if (k > 1)
+                {
+                    // gnorm, x.norm, s.y, y.y                                           (LBFGS.h:130,137,159-161)
+                    const Scalar g2 = Scalar(r[0]), x2 = Scalar(r[1]), sy = Scalar(r[2]), yy = Scalar(r[3]);
+                    q.gnorm = sqrt(g2);
+                    bool stop = (q.gnorm <= m_param.epsilon || q.gnorm <= m_param.epsilon_rel * sqrt(x2));
+                    if (!stop && fpast > 0)
+                    {
+                        const Scalar old = q.fxh[size_t(kk % fpast)];
+                        if (kk >= fpast && abs(old - q.fx) <= m_param.delta * std::max(std::max(abs(q.fx), abs(old)), Scalar(1)))
+                            stop = true;
+                        else
+                            q.fxh[size_t(kk % fpast)] = q.fx;
+                    }
+                    if (!stop && m_param.max_iterations != 0 && kk >= m_param.max_iterations)
+                        stop = true;
+                    if (stop)
+                    {
+                        q.done = true;
+                        it.niter = kk;
+                        remaining--;
+                        continue;
+                    }
+                    if (sy > eps * yy)  // add_correction: index rotation (BFGSMat.h:83-97); the kernel took the same decision
+                    {
+                        const int loc = q.ptr % m;
+                        std::swap(q.phys[size_t(loc)], q.spare);
+                        if (q.ncorr < m)
+                            q.ncorr++;
+                        q.ptr = loc + 1;
+                    }
+                }
+                q.dg = Scalar(r[4]);  // grad . drt (LBFGS.h:106,123,165)
+                // the line search of iteration k                                        (LBFGS.h:121-127)
+                q.xp = q.cur;
+                q.lo = q.xp;
+                q.trial = (q.xp + 1) % 3;
+                try
+                {
+                    q.mt.start(m_param, m_param.max_step, q.step, q.fx, q.dg);
+                    q.in_ls = true;
+                    searching++;
+                }
+                catch (const std::invalid_argument& e) { fail(q, it, LBFGSX_E_INVALID, e.what(), k); remaining--; }
+                catch (const std::logic_error& e) { fail(q, it, LBFGSX_E_LOGIC, e.what(), k); remaining--; }
+                if (q.in_ls && fuse_trial)
+                    consume(p, Scalar(r[5]), Scalar(r[6]), k);
+            }
+            // ---- the searches that need more trials, one per launch
+            while (searching > 0)
+            {
+                clear_desc();
+                for (int p = 0; p < P; p++)
+                {
+                    Prob& q = pr[size_t(p)];
+                    if (!q.in_ls)
+                        continue;
+                    lbfgsx_bat_desc& d = desc[size_t(p)];
+                    d.active = 1;
+                    d.x_in = q.xp;
+                    d.x_out = q.trial;
+                    d.step = double(q.mt.step());
+                }
+                launch_trial();
+                for (int p = 0; p < P; p++)
+                    if (pr[size_t(p)].in_ls)
+                        consume(p, Scalar(res[size_t(p) * 2 + 0]), Scalar(res[size_t(p) * 2 + 1]), k);
+            }
+        }
+
+        for (int p = 0; p < P; p++)
+        {
+            out[size_t(p)].fx = pr[size_t(p)].fx;
+            out[size_t(p)].gnorm = pr[size_t(p)].gnorm;
+            if (x_out)
+                detail::check(lbfgsx_bat_download_x(c, p, pr[size_t(p)].cur, x_out + std::int64_t(p) * n));
+        }
+    }
+
 public:
 
     // contiguous, balanced block of `count` problems for shard r of w (remainder to the low shards) -- the partition
@@ -545,8 +899,11 @@ public:
                 try
                 {
                     if (len > 0)
-                        minimize(obj, n, seed_base, first + lo, int(len), devices[size_t(r)], part[size_t(r)],
-                                 x_out ? x_out + lo * n : nullptr);
+                    {
+                        LBFGSBatchedSolver shard(m_param);  // its own batch (this object's cached one belongs to one device)
+                        shard.minimize(obj, n, seed_base, first + lo, int(len), devices[size_t(r)], part[size_t(r)],
+                                       x_out ? x_out + lo * n : nullptr);
+                    }
                 }
                 catch (...)
                 {

@@ -166,6 +166,10 @@ int lbfgsx_counters_ex(int64_t out[8], int reset);
  * polls that word instead of waiting for the stream (which returns ~9 us after the kernel's end).  out = {waits served by
  * polling, waits that timed out (50 ms) and fell back to the stream wait -- a kernel that failed to signal} */
 int lbfgsx_poll_counts(const lbfgsx_ctx* c, int64_t out[2]);
+/* The same with the reasons polling was given up: out = {waits, time-outs, time-outs that said "polling cannot work here"
+ * (the word still unset after the stream drained, or the stream wait returned at once because the kernel had ended long
+ * before its store became visible), 1 if this context now waits for its stream instead of polling (after two of those)} */
+int lbfgsx_poll_counts_ex(const lbfgsx_ctx* c, int64_t out[4]);
 
 /* ---- Gram-space ("vector-free") form of the recursion: opt-in, outside the bit-parity contract ----
  * BFGSMat::apply_Hv (BFGSMat.h:276-302) only combines the 2c+1 vectors [S, Y, g]; with their Gram matrix kept on the
@@ -467,8 +471,32 @@ typedef struct
     int ncorr;
     int pcol[32];
 } lbfgsx_bat_hvdesc;
+/* per-problem description of a whole lock-step iteration (lbfgsx_bat_iterate) */
+enum
+{
+    LBFGSX_BAT_IT_POST = 1,      /* the statements after a finished line search first (xp -> cur, pair into column `spare`) */
+    LBFGSX_BAT_IT_POST_ONLY = 2, /* ... and nothing else: the caller already knows that this problem stops */
+    LBFGSX_BAT_IT_TRIAL = 4      /* the first trial of the next line search last (built-in objectives only) */
+};
+#define LBFGSX_BAT_NRES 8        /* doubles per problem in the result table of a launch */
+typedef struct
+{
+    int active;
+    int flags;    /* LBFGSX_BAT_IT_* */
+    int cur;      /* point (0..2) holding the accepted iterate and its gradient */
+    int xp;       /* POST: the point the finished line search started from */
+    int trial;    /* TRIAL: the point that receives cur + step * drt and the gradient there */
+    int ncorr;    /* pairs stored BEFORE this launch */
+    int spare;    /* POST: physical column that receives (s, y) */
+    int pad;
+    double step;  /* TRIAL: the step */
+    int pcol[32]; /* physical columns of the stored pairs, newest -> oldest */
+} lbfgsx_bat_itdesc;
 int lbfgsx_bat_create(lbfgsx_batch** out, int dtype, int64_t n, int m, int nproblems, int device);
 void lbfgsx_bat_destroy(lbfgsx_batch* c);
+/* a created batch made ready for another set of problems of the same shape (scalars and counters cleared, nothing
+ * re-allocated): what lets a caller keep the ~(2m+9) n P elements of one batch alive across minimisations */
+int lbfgsx_bat_reset(lbfgsx_batch* c);
 /* index of a scalar inside a problem's table: kind 0 = ys[col], 1 = theta[col], 2 = two-loop dot k, 3 = output k */
 int lbfgsx_bat_scalar_index(const lbfgsx_batch* c, int kind, int k);
 /* x0 of problem p (point 0) = extended-Rosenbrock start for seed seed0 + p */
@@ -491,6 +519,25 @@ int lbfgsx_bat_launch(lbfgsx_batch* c, int kind, int objective, const lbfgsx_bat
  * registers (n a multiple of the 16-byte vector width and n <= 256 * 98 * width: 100352 floats / 50176 doubles);
  * LBFGSX_E_INVALID otherwise -- the caller then issues the LBFGSX_BAT_TWOLOOP steps. */
 int lbfgsx_bat_apply_Hv(lbfgsx_batch* c, const lbfgsx_bat_hvdesc* desc);
+/* ONE launch per lock-step iteration: for every active problem, one 256-thread block runs
+ *   [POST]   s = x - xp, y = grad - gradp into the spare column; grad.grad, x.x, s.y, y.y      (LBFGS.h:130,137,159-161)
+ *            and decides add_correction's test s.y > eps * y.y itself (LBFGS.h:161, BFGSMat.h:83-97)
+ *   always   drt = -H grad by the two-loop recursion over the history that results (BFGSMat.h:276-302), the direction
+ *            held in registers / LDS from the first statement to the last; grad . drt
+ *   [TRIAL]  x_trial = x + step * drt, f and grad there, grad_trial . drt   (LineSearchMoreThuente.h:412-414,
+ *            LineSearchNocedalWright.h:146-148) -- the first trial of the next line search, whose step the caller knows
+ * with the element-wise arithmetic and the order-independent sums of the statement-wise launches, hence the same bits.
+ * out[p * LBFGSX_BAT_NRES + k], k = 0..6: grad.grad, x.x, s.y, y.y (POST), grad.drt, f_trial, grad_trial.drt (TRIAL).
+ * The caller's host logic stays the reference's: it reads the sums, applies the stopping tests (a problem that stops has
+ * had its direction and trial computed in vain, nothing else), rotates the ring when s.y > eps * y.y, and feeds the trial to the
+ * line search it starts.  Applicable as lbfgsx_bat_apply_Hv is (lbfgsx_bat_iterate_ok); LBFGSX_E_INVALID otherwise. */
+int lbfgsx_bat_iterate(lbfgsx_batch* c, int objective, const lbfgsx_bat_itdesc* desc, double* out);
+int lbfgsx_bat_iterate_ok(const lbfgsx_batch* c);
+/* instrumentation: enable != 0 brackets every launch of the batch with a pair of events; lbfgsx_bat_timing_read waits for
+ * the stream and returns {sum of the launches' durations in ms, launches, host waits, waits that timed out} since the
+ * last read */
+int lbfgsx_bat_timing(lbfgsx_batch* c, int enable);
+int lbfgsx_bat_timing_read(lbfgsx_batch* c, double out[4]);
 /* out[p] = scalar idx[p] of problem p */
 int lbfgsx_bat_fetch(lbfgsx_batch* c, const int* idx, double* out);
 int lbfgsx_bat_download_x(lbfgsx_batch* c, int p, int point, void* host);

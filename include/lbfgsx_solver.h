@@ -141,6 +141,20 @@ int lbfgsx_batch_minimize_lockstep_ex(int dtype, int linesearch, int objective, 
                                       int64_t first, int count, uint64_t seed_base, const int* devices, int ndev,
                                       lbfgsx_batch_item* out, void* x_out, char* errbuf, int errlen);
 
+/* A lock-step batch kept alive across minimisations: `count` problems of dimension n resident on `device` (about
+ * (2m + 9) n count scalars of HBM, allocated here once).  Every lbfgsx_lockstep_minimize solves the problems of ids
+ * [first, first + count) of seed_base from their start points again -- what a service that solves batch after batch of the
+ * same shape calls, and what bench.py times (the allocation of ~12 GB is setup, not solve).  timing != 0: events around
+ * every launch; stats = {lock-step iterations, 1 if the one-launch-per-iteration form ran, sum of the launches'
+ * durations in ms (timing), launches, host waits, waits that timed out, 0, 0}.  No reference counterpart. */
+typedef struct lbfgsx_lockstep lbfgsx_lockstep;
+int lbfgsx_lockstep_create(lbfgsx_lockstep** out, int dtype, int linesearch, const lbfgsx_params* p, int64_t n, int count,
+                           int device, int timing, char* errbuf, int errlen);
+int lbfgsx_lockstep_minimize(lbfgsx_lockstep* h, int objective, double kappa, uint64_t seed_base, int64_t first,
+                             lbfgsx_batch_item* out, void* x_out, double stats[8], char* errbuf, int errlen);
+int lbfgsx_lockstep_set_timing(lbfgsx_lockstep* h, int on);  /* for the minimisations that follow */
+void lbfgsx_lockstep_destroy(lbfgsx_lockstep* h);
+
 #ifdef __cplusplus
 }
 #endif

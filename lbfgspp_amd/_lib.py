@@ -120,6 +120,7 @@ def load():
     sig(core, "lbfgsx_counters", i32, C.POINTER(i64 * 3), i32)
     sig(core, "lbfgsx_counters_ex", i32, C.POINTER(i64 * 8), i32)
     sig(core, "lbfgsx_poll_counts", i32, vp, C.POINTER(i64 * 2))
+    sig(core, "lbfgsx_poll_counts_ex", i32, vp, C.POINTER(i64 * 4))
     sig(core, "lbfgsx_b_compact_vec_counts", i32, C.POINTER(i64 * 4), i32)
     sig(core, "lbfgsx_b_reserve", i32, vp)
     sig(core, "lbfgsx_device", i32, vp)
@@ -165,6 +166,11 @@ def load():
         C.POINTER(i32), i32, C.POINTER(BatchItem), vp, C.c_char_p, i32)
     sig(sol, "lbfgsx_batch_minimize_lockstep_ex", i32, i32, i32, i32, dbl, C.POINTER(Params), i64, i64, i32, C.c_uint64,
         C.POINTER(i32), i32, C.POINTER(BatchItem), vp, C.c_char_p, i32)
+    sig(sol, "lbfgsx_lockstep_create", i32, C.POINTER(vp), i32, i32, C.POINTER(Params), i64, i32, i32, i32, C.c_char_p, i32)
+    sig(sol, "lbfgsx_lockstep_minimize", i32, vp, i32, dbl, C.c_uint64, i64, C.POINTER(BatchItem), vp, C.POINTER(dbl * 8),
+        C.c_char_p, i32)
+    sig(sol, "lbfgsx_lockstep_destroy", None, vp)
+    sig(sol, "lbfgsx_lockstep_set_timing", i32, vp, i32)
     sig(sol, "lbfgsx_solver_hessians", i32, vp, vp, vp)
     sig(sol, "lbfgsx_solver_stats", i32, vp, C.POINTER(C.c_longlong * 8))
     sig(sol, "lbfgsx_solver_stats2", i32, vp, C.POINTER(C.c_longlong * 8))

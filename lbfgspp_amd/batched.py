@@ -67,6 +67,55 @@ def solve_local_lockstep(param, n, first, count, seed_base=1000, dtype=np.float3
     return (out, xs) if return_x else out
 
 
+class LockstepBatch:
+    """A lock-step batch kept resident across minimisations (lbfgsx_lockstep_create): `count` problems of dimension n on one
+    GPU.  minimize() solves the problems of ids [first, first + count) from their start points and returns the RECORD array
+    [, the final iterates]; `stats` then holds what that minimisation did (lock-step iterations, launches, host waits and --
+    with timing=True -- the sum of the kernels' durations)."""
+
+    def __init__(self, param, n, count, dtype=np.float32, device=0, linesearch=L.LS_MORE_THUENTE, timing=False):
+        _, self._sol = L.load()
+        self.n, self.count, self.dtype = int(n), int(count), np.dtype(dtype)
+        self._h = C.c_void_p()
+        self._items = (L.BatchItem * max(self.count, 1))()
+        self.stats = None
+        err = C.create_string_buffer(256)
+        cp = param._c()
+        dt = L.F64 if self.dtype == np.float64 else L.F32
+        rc = self._sol.lbfgsx_lockstep_create(C.byref(self._h), dt, int(linesearch), C.byref(cp), self.n, self.count,
+                                              int(device), 1 if timing else 0, err, 256)
+        L.check(rc, err.value.decode())
+
+    def minimize(self, first=0, seed_base=1000, objective=L.OBJ_EXT_ROSENBROCK, kappa=10.0, return_x=False):
+        xs = np.empty((self.count, self.n), dtype=self.dtype) if return_x else None
+        st = (C.c_double * 8)()
+        err = C.create_string_buffer(256)
+        rc = self._sol.lbfgsx_lockstep_minimize(self._h, int(objective), float(kappa), int(seed_base), int(first), self._items,
+                                                xs.ctypes.data_as(C.c_void_p) if return_x else None, C.byref(st), err, 256)
+        L.check(rc, err.value.decode())
+        self.stats = {"lockstep_iterations": int(st[0]), "fused": bool(st[1]), "kernel_ms": float(st[2]),
+                      "launches": int(st[3]), "waits": int(st[4]), "wait_timeouts": int(st[5])}
+        out = np.zeros(self.count, dtype=RECORD)
+        for k in range(self.count):
+            it = self._items[k]
+            out[k] = (it.niter, it.nfev, it.status, it.fx, it.gnorm)
+        return (out, xs) if return_x else out
+
+    def set_timing(self, on):
+        L.check(self._sol.lbfgsx_lockstep_set_timing(self._h, 1 if on else 0))
+
+    def close(self):
+        if self._h:
+            self._sol.lbfgsx_lockstep_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def gather_records(local, nproblems, rank, world, dist=None, device=None):
     """All ranks obtain the full RECORD array in problem-id order.  `dist` is torch.distributed (initialised)."""
     if world == 1 or dist is None:

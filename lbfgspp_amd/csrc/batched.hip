@@ -13,125 +13,9 @@
 #include <cstring>
 #include <vector>
 
-#include "ctx.hpp"
-#include "lbfgs_kernels.cuh"
+#include "batched.hpp"
 
 namespace lbfgsx {
-
-typedef lbfgsx_bat_desc BatDesc;  // per-problem description of one launch (include/lbfgsx.h)
-
-struct BatWs
-{
-    double* partials;  // [P][kMaxRedB][2][GX]
-    unsigned* ticket;  // [P]
-    int gx;
-};
-constexpr int kMaxRedB = 4;
-
-// per-problem grid reduction (same protocol as grid_reduce, with blockIdx.y-indexed workspace)
-template <int NRED, class A>
-__device__ __forceinline__ bool bat_reduce(A (&acc)[NRED], const BatWs& ws)
-{
-    __shared__ double sh[NRED][2][kWaves];
-    __shared__ int s_last;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int G = gridDim.x, p = blockIdx.y;
-    double* part = ws.partials + size_t(p) * kMaxRedB * 2 * ws.gx;
-#pragma unroll
-    for (int r = 0; r < NRED; r++)
-    {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1)
-        {
-            const double ohi = __shfl_down(acc[r].hi, off, 64);
-            const double olo = __shfl_down(acc_lo(acc[r]), off, 64);
-            acc[r].merge(ohi, olo);
-        }
-        if (lane == 0)
-        {
-            sh[r][0][wave] = acc[r].hi;
-            sh[r][1][wave] = acc_lo(acc[r]);
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0)
-    {
-#pragma unroll
-        for (int r = 0; r < NRED; r++)
-        {
-            A t;
-            for (int w = 0; w < kWaves; w++)
-                t.merge(sh[r][0][w], sh[r][1][w]);
-            st_agent(part + (size_t(r) * 2 + 0) * ws.gx + blockIdx.x, t.hi);
-            st_agent(part + (size_t(r) * 2 + 1) * ws.gx + blockIdx.x, acc_lo(t));
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // partials are sc1 stores: drain, then ticket (R1 form)
-        const unsigned old = __hip_atomic_fetch_add(ws.ticket + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = (old == unsigned(G - 1));
-        if (last)
-            __threadfence();
-        s_last = last;
-    }
-    __syncthreads();
-    if (!s_last)
-        return false;
-#pragma unroll
-    for (int r = 0; r < NRED; r++)
-    {
-        A t;
-        for (int b = threadIdx.x; b < G; b += kBlock)
-            t.merge(ld_agent(part + (size_t(r) * 2 + 0) * ws.gx + b), ld_agent(part + (size_t(r) * 2 + 1) * ws.gx + b));
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1)
-        {
-            const double ohi = __shfl_down(t.hi, off, 64);
-            const double olo = __shfl_down(acc_lo(t), off, 64);
-            t.merge(ohi, olo);
-        }
-        acc[r] = t;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < NRED; r++)
-        if (lane == 0)
-        {
-            sh[r][0][wave] = acc[r].hi;
-            sh[r][1][wave] = acc_lo(acc[r]);
-        }
-    __syncthreads();
-    if (threadIdx.x == 0)
-    {
-#pragma unroll
-        for (int r = 0; r < NRED; r++)
-        {
-            A t;
-            for (int w = 0; w < kWaves; w++)
-                t.merge(sh[r][0][w], sh[r][1][w]);
-            acc[r] = t;
-        }
-        __hip_atomic_store(ws.ticket + p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    return true;
-}
-
-template <class T>
-struct BatBufs
-{
-    T* X;    // [3][P][ld]
-    T* G;    // [3][P][ld]
-    T* D;    // [P][ld]
-    T* S;    // [m+1][P][ld]
-    T* Y;    // [m+1][P][ld]
-    T* sc;   // [P][scn]
-    int64_t ld;
-    int P, scn;
-    __device__ __forceinline__ T* x(int pt, int p) const { return X + (int64_t(pt) * P + p) * ld; }
-    __device__ __forceinline__ T* g(int pt, int p) const { return G + (int64_t(pt) * P + p) * ld; }
-    __device__ __forceinline__ T* d(int p) const { return D + int64_t(p) * ld; }
-    __device__ __forceinline__ T* s(int col, int p) const { return S + (int64_t(col) * P + p) * ld; }
-    __device__ __forceinline__ T* y(int col, int p) const { return Y + (int64_t(col) * P + p) * ld; }
-    __device__ __forceinline__ T* scal(int p) const { return sc + int64_t(p) * scn; }
-};
 
 __device__ __forceinline__ uint64_t b_splitmix64(uint64_t z)
 {
@@ -155,23 +39,6 @@ __global__ void __launch_bounds__(kBlock) kb_gen_rosen(BatBufs<T> b, int64_t n, 
         x[i] = T(((i & 1) ? 1.0 : -1.2) + 0.4 * u);
     }
 }
-
-// The objective of problem p.  The extended Rosenbrock function has no data; the diagonal quadratic reads the rows of
-// problem p of the batch's a, b arrays ([P][ld], lbfgsx_bat_gen_diag_quad).  Per problem these are the single-problem
-// objects of lbfgs_kernels.cuh: the arithmetic of a batch member IS that of a stand-alone solve.
-template <class T>
-struct BatRosen
-{
-    __device__ __forceinline__ ObjRosen<T> bind(int) const { return ObjRosen<T>{}; }
-};
-template <class T>
-struct BatQuad
-{
-    const T* A;
-    const T* B;
-    int64_t ld;
-    __device__ __forceinline__ ObjQuad<T> bind(int p) const { return ObjQuad<T>{A + int64_t(p) * ld, B + int64_t(p) * ld}; }
-};
 
 // a, b of problem p = the diagonal quadratic of seed (seed0 + p) (lbfgsx_gen_diag_quad); x0 = 0
 template <class T>
@@ -240,8 +107,13 @@ __global__ void __launch_bounds__(kBlock) kb_gdot(BatBufs<T> b, const BatDesc* _
     {
         T* o = b.scal(p) + de.i_out;
         o[0] = T(acc[0].value());
+        bat_result(ws, p, 0, double(o[0]));
         if (NORMS)
+        {
             o[1] = T(acc[1].value());
+            bat_result(ws, p, 1, double(o[1]));
+        }
+        bat_signal(ws);
     }
 }
 
@@ -286,6 +158,10 @@ __global__ void __launch_bounds__(kBlock) kb_eval(BatBufs<T> b, const BatDesc* _
         o[0] = obj.finish(T(acc[0].value()));
         o[1] = T(acc[1].value());
         o[2] = T(acc[2].value());
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            bat_result(ws, p, k, double(o[k]));
+        bat_signal(ws);
     }
 }
 
@@ -356,6 +232,9 @@ __global__ void __launch_bounds__(kBlock) kb_trial(BatBufs<T> b, const BatDesc* 
         T* o = b.scal(p) + de.i_out;
         o[0] = obj.finish(T(acc[0].value()));
         o[1] = T(acc[1].value());
+        bat_result(ws, p, 0, double(o[0]));
+        bat_result(ws, p, 1, double(o[1]));
+        bat_signal(ws);
     }
 }
 
@@ -435,6 +314,10 @@ __global__ void __launch_bounds__(kBlock) kb_post(BatBufs<T> b, const BatDesc* _
         sc[de.i_out + 3] = yy;
         sc[de.i_den] = sy;           // ys slot of the column
         sc[de.i_theta] = yy / sy;    // theta slot of the column
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            bat_result(ws, p, k, double(sc[de.i_out + k]));
+        bat_signal(ws);
     }
 }
 
@@ -493,8 +376,6 @@ __global__ void __launch_bounds__(kBlock) kb_twoloop(BatBufs<T> b, const BatDesc
 // around) so that the scheduler keeps as many loads in flight as registers allow.  The step sequence, the
 // coefficient formulas and the rounding points (every dot is rounded to T before use) are those of
 // kb_twoloop / apply_Hv_t, so the result is bit-identical to the step-wise launches.
-typedef lbfgsx_bat_hvdesc BatHvDesc;
-constexpr int kHvRegSlots = 83;
 
 template <class T, int NQ>
 __global__ void __launch_bounds__(kHvThreads) kb_twoloop_full(BatBufs<T> b, const BatHvDesc* __restrict__ desc, int64_t n,
@@ -560,7 +441,7 @@ __global__ void __launch_bounds__(kHvThreads) kb_twoloop_full(BatBufs<T> b, cons
         // recomputed inside the step instead of being hoisted out of the L loop and kept in ~4 registers per slot
         int tid_step = tid;
         asm volatile("" : "+v"(tid_step));
-        hv_step<T, NR, NL>(rq, lq, u, w, L == 0, T(-1), c, theta, nv, int64_t(tid_step), int64_t(kHvThreads), tid, acc4);
+        hv_step<T, NR, NL, A, false, 14>(rq, lq, u, w, L == 0, T(-1), c, theta, nv, int64_t(tid_step), int64_t(kHvThreads), tid, acc4);  // 14-slot chunks: profiles/r6_cfg5_chunk_ab.txt
         A acc = acc4[0];
         for (int k = 1; k < 4; k++)
             acc.merge(acc4[k].hi, acc_lo(acc4[k]));
@@ -610,61 +491,29 @@ __global__ void __launch_bounds__(kHvThreads) kb_twoloop_full(BatBufs<T> b, cons
 
 using namespace lbfgsx;
 
-struct lbfgsx_batch
-{
-    int dtype = LBFGSX_F64, device = 0, m = 0, P = 0, gx = 1, scn = 0;
-    size_t esz = 8;
-    int64_t n = 0, ld = 0;
-    hipStream_t stream = nullptr;
-    void *X = nullptr, *G = nullptr, *D = nullptr, *S = nullptr, *Y = nullptr, *sc = nullptr;
-    void *QA = nullptr, *QB = nullptr;  // a, b of the diagonal quadratics, [P][ld] each (lbfgsx_bat_gen_diag_quad)
-    BatWs ws;
-    BatDesc* desc_dev = nullptr;
-    void* hout = nullptr;  // pinned staging for the scalar table
-    size_t hout_cap = 0;
-    lbfgsx_bat_desc* hdesc = nullptr;  // pinned staging for the descriptors
-    ScLayout sl;
-    bool zigzag = true;
-    unsigned tl_step = 0;
-    bool fused_hv = true;  // LBFGSX_BAT_FUSED_HV=0: always the step-wise two-loop launches
-    lbfgsx_bat_hvdesc* hvdesc_dev = nullptr;
-    lbfgsx_bat_hvdesc* hvdesc_host = nullptr;
-};
-
-#define BAT_DISPATCH(c, ...)          \
-    do                                \
-    {                                 \
-        if ((c)->dtype == LBFGSX_F64) \
-        {                             \
-            typedef double T;         \
-            __VA_ARGS__               \
-        }                             \
-        else                          \
-        {                             \
-            typedef float T;          \
-            __VA_ARGS__               \
-        }                             \
-    } while (0)
-
 namespace lbfgsx {
-template <class T>
-static BatBufs<T> bufs(lbfgsx_batch* c)
+hipError_t bat_ev_begin(lbfgsx_batch* c)
 {
-    BatBufs<T> b;
-    b.X = static_cast<T*>(c->X);
-    b.G = static_cast<T*>(c->G);
-    b.D = static_cast<T*>(c->D);
-    b.S = static_cast<T*>(c->S);
-    b.Y = static_cast<T*>(c->Y);
-    b.sc = static_cast<T*>(c->sc);
-    b.ld = c->ld;
-    b.P = c->P;
-    b.scn = c->scn;
-    return b;
+    EventPair e;
+    for (hipEvent_t* p : {&e.a, &e.b})
+    {
+        if (!c->ev_pool.empty())
+        {
+            *p = c->ev_pool.back();
+            c->ev_pool.pop_back();
+        }
+        else if (hipEventCreate(p) != hipSuccess)
+            return hipErrorUnknown;
+    }
+    c->ev.push_back(e);
+    return hipEventRecord(e.a, c->stream);
 }
+hipError_t bat_ev_end(lbfgsx_batch* c) { return hipEventRecord(c->ev.back().b, c->stream); }
 }  // namespace lbfgsx
 
 extern "C" {
+
+static int bat_alloc(lbfgsx_batch* c);
 
 int lbfgsx_bat_create(lbfgsx_batch** out, int dtype, int64_t n, int m, int nproblems, int device)
 {
@@ -702,9 +551,27 @@ int lbfgsx_bat_create(lbfgsx_batch** out, int dtype, int64_t n, int m, int nprob
         c->zigzag = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_BAT_FUSED_HV"))
         c->fused_hv = atoi(e) != 0;
+    if (const char* e = getenv("LBFGSX_BAT_FUSED_ITER"))
+        c->fused_iter = atoi(e) != 0;
+    if (const char* e = getenv("LBFGSX_BAT_POLL"))
+        c->poll = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_BAT_GX"))
         gx = std::max(1, std::min(atoi(e), 256));
     c->gx = int(gx);
+    live_add(c->device, +1);
+    const int rc = bat_alloc(c);
+    if (rc != LBFGSX_OK)
+    {
+        lbfgsx_bat_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return LBFGSX_OK;
+}
+
+static int bat_alloc(lbfgsx_batch* c)
+{
+    const int nproblems = c->P, m = c->m;
     LBFGSX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     const size_t vb = size_t(c->ld) * c->esz * size_t(nproblems);
     LBFGSX_HIP(hipMalloc(&c->X, 3 * vb));
@@ -713,15 +580,34 @@ int lbfgsx_bat_create(lbfgsx_batch** out, int dtype, int64_t n, int m, int nprob
     LBFGSX_HIP(hipMalloc(&c->S, size_t(m + 1) * vb));
     LBFGSX_HIP(hipMalloc(&c->Y, size_t(m + 1) * vb));
     LBFGSX_HIP(hipMalloc(&c->sc, sizeof(double) * size_t(c->scn) * size_t(nproblems)));
-    LBFGSX_HIP(hipMemset(c->sc, 0, sizeof(double) * size_t(c->scn) * size_t(nproblems)));
     c->ws.gx = c->gx;
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&c->ws.partials), sizeof(double) * size_t(nproblems) * kMaxRedB * 2 * size_t(c->gx)));
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&c->ws.ticket), sizeof(unsigned) * size_t(nproblems)));
-    LBFGSX_HIP(hipMemset(c->ws.ticket, 0, sizeof(unsigned) * size_t(nproblems)));
-    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&c->desc_dev), sizeof(BatDesc) * size_t(nproblems)));
-    LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->hdesc), sizeof(BatDesc) * size_t(nproblems), hipHostMallocDefault));
-    live_add(c->device, +1);
-    *out = c;
+    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&c->ws.done_cnt), 64));
+    // host-mapped: descriptor staging (read by the kernels in place), result table, completion word
+    c->stage_bytes = (std::max(std::max(sizeof(BatDesc), sizeof(BatHvDesc)), sizeof(BatItDesc)) * size_t(nproblems) + 255) / 256 * 256;
+    LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->stage_host), c->stage_bytes * kBatStages, hipHostMallocMapped | hipHostMallocCoherent));
+    LBFGSX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->stage_dev), c->stage_host, 0));
+    const size_t rb = sizeof(double) * size_t(kBatRes) * size_t(nproblems);
+    LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->res_host), rb, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(c->res_host, 0, rb);
+    LBFGSX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->ws.res), c->res_host, 0));
+    LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->done_host), 64, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(c->done_host, 0, 64);
+    LBFGSX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->done_dev), c->done_host, 0));
+    return lbfgsx_bat_reset(c);
+}
+
+int lbfgsx_bat_reset(lbfgsx_batch* c)
+{
+    if (!c)
+        return LBFGSX_E_INVALID;
+    lbfgsx::DeviceGuard dev_guard_(c->device);
+    LBFGSX_HIP(hipMemsetAsync(c->sc, 0, sizeof(double) * size_t(c->scn) * size_t(c->P), c->stream));
+    LBFGSX_HIP(hipMemsetAsync(c->ws.ticket, 0, sizeof(unsigned) * size_t(c->P), c->stream));
+    LBFGSX_HIP(hipMemsetAsync(c->ws.done_cnt, 0, 64, c->stream));
+    c->tl_step = 0;
+    c->armed = false;
     return LBFGSX_OK;
 }
 
@@ -730,17 +616,61 @@ void lbfgsx_bat_destroy(lbfgsx_batch* c)
     if (!c)
         return;
     lbfgsx::DeviceGuard dev_guard_(c->device);
-    (void) lbfgsx::stream_sync(c->stream);
+    if (c->stream)
+        (void) lbfgsx::stream_sync(c->stream);
     live_add(c->device, -1);
-    void* ptrs[] = {c->X, c->G, c->D, c->S, c->Y, c->sc, c->QA, c->QB, c->ws.partials, c->ws.ticket, c->desc_dev, c->hvdesc_dev};
-    if (c->hvdesc_host)
-        (void) hipHostFree(c->hvdesc_host);
+    void* ptrs[] = {c->X, c->G, c->D, c->S, c->Y, c->sc, c->QA, c->QB, c->ws.partials, c->ws.ticket, c->ws.done_cnt};
     for (void* p : ptrs)
-        (void) hipFree(p);
-    (void) hipHostFree(c->hout);
-    (void) hipHostFree(c->hdesc);
-    (void) hipStreamDestroy(c->stream);
+        if (p)
+            (void) hipFree(p);
+    void* hptrs[] = {c->hout, c->stage_host, c->res_host, c->done_host};
+    for (void* p : hptrs)
+        if (p)
+            (void) hipHostFree(p);
+    for (auto& e : c->ev)
+    {
+        (void) hipEventDestroy(e.a);
+        (void) hipEventDestroy(e.b);
+    }
+    for (hipEvent_t e : c->ev_pool)
+        (void) hipEventDestroy(e);
+    if (c->stream)
+        (void) hipStreamDestroy(c->stream);
     delete c;
+}
+
+int lbfgsx_bat_timing(lbfgsx_batch* c, int enable)
+{
+    if (!c)
+        return LBFGSX_E_INVALID;
+    c->timing = enable != 0;
+    return LBFGSX_OK;
+}
+
+int lbfgsx_bat_timing_read(lbfgsx_batch* c, double out[4])
+{
+    if (!c || !out)
+        return LBFGSX_E_INVALID;
+    lbfgsx::DeviceGuard dev_guard_(c->device);
+    LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
+    double ms = 0.0;
+    for (auto& e : c->ev)
+    {
+        float t = 0.f;
+        LBFGSX_HIP(hipEventElapsedTime(&t, e.a, e.b));
+        ms += double(t);
+        c->ev_pool.push_back(e.a);
+        c->ev_pool.push_back(e.b);
+    }
+    c->ev.clear();
+    out[0] = ms;
+    out[1] = double(c->launches);
+    out[2] = double(c->waits);
+    out[3] = double(c->wait_timeouts);
+    c->launches = 0;
+    c->waits = 0;
+    c->wait_timeouts = 0;
+    return LBFGSX_OK;
 }
 
 int lbfgsx_bat_scalar_index(const lbfgsx_batch* c, int kind, int k)
@@ -794,14 +724,12 @@ int64_t lbfgsx_bat_ld(const lbfgsx_batch* c) { return c ? c->ld : 0; }
 void* lbfgsx_bat_stream(lbfgsx_batch* c) { return c ? static_cast<void*>(c->stream) : nullptr; }
 
 // kind: 0 eval, 1 trial, 2 post, 3 two-loop step, 4 trial point only, 5 grad . drt, 6 grad . grad and x . x.
-// `desc` = host array of P descriptors (uploaded here).
-// After the launch `nout` scalars starting at each problem's desc.i_out are copied back into out[p*nout + k].
+// `desc` = host array of P descriptors (staged here, read by the kernel in place).
+// With nout > 0 the host waits for the launch and out[p*nout + k] = result k of every ACTIVE problem p (the others' entries
+// are left alone): the kernel's final threads store them in the host-mapped result table.
 int lbfgsx_bat_launch(lbfgsx_batch* c, int kind, int objective, const lbfgsx_bat_desc* desc, int nout, double* out)
 {
     lbfgsx::DeviceGuard dev_guard_(c->device);
-    LBFGSX_HIP(lbfgsx::stream_sync(c->stream));  // the pinned descriptor staging may still be in flight
-    std::memcpy(c->hdesc, desc, sizeof(BatDesc) * size_t(c->P));
-    LBFGSX_HIP(lbfgsx::copy_async(c->desc_dev, c->hdesc, sizeof(BatDesc) * size_t(c->P), hipMemcpyHostToDevice, c->stream));
     const dim3 grid(unsigned(c->gx), unsigned(c->P));
     const bool fused_obj = (kind == 0 || kind == 1);
     if (fused_obj && objective != LBFGSX_OBJ_EXT_ROSENBROCK && objective != LBFGSX_OBJ_DIAG_QUAD)
@@ -815,11 +743,21 @@ int lbfgsx_bat_launch(lbfgsx_batch* c, int kind, int objective, const lbfgsx_bat
         set_error("lbfgsx_bat_launch: the diagonal quadratic needs its data (lbfgsx_bat_gen_diag_quad)");
         return LBFGSX_E_LOGIC;
     }
-    if (kind < 0 || kind > 6)
+    if (kind < 0 || kind > 6 || nout < 0 || nout > kBatRes)
     {
-        set_error("lbfgsx_bat_launch: unknown kind");
+        set_error("lbfgsx_bat_launch: unknown kind / more results than a launch has");
         return LBFGSX_E_INVALID;
     }
+    int nactive = 0;
+    for (int p = 0; p < c->P; p++)
+        nactive += desc[p].active ? 1 : 0;
+    if (nactive == 0)
+        return LBFGSX_OK;
+    const void* dd = nullptr;
+    LBFGSX_HIP(lbfgsx::bat_stage(c, desc, sizeof(BatDesc) * size_t(c->P), &dd));
+    const BatDesc* desc_dev = static_cast<const BatDesc*>(dd);
+    const bool wait = nout > 0 && out && kind != 3 && kind != 4;
+    const BatWs ws = wait ? lbfgsx::bat_arm(c, nactive) : lbfgsx::bat_unarmed(c);
     BAT_DISPATCH(c, {
         BatBufs<T> b = bufs<T>(c);
         const BatQuad<T> quad = {static_cast<const T*>(c->QA), static_cast<const T*>(c->QB), c->ld};
@@ -827,43 +765,30 @@ int lbfgsx_bat_launch(lbfgsx_batch* c, int kind, int objective, const lbfgsx_bat
         switch (kind)
         {
         case 0:
-            if (q) LBFGSX_LAUNCH((kb_eval<T, BatQuad<T> >), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n, quad, c->ws);
-            else LBFGSX_LAUNCH((kb_eval<T, BatRosen<T> >), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n, BatRosen<T>{}, c->ws);
+            if (q) BAT_LAUNCH(c, (kb_eval<T, BatQuad<T> >), grid, dim3(kBlock), 0, c->stream, b, desc_dev, c->n, quad, ws);
+            else BAT_LAUNCH(c, (kb_eval<T, BatRosen<T> >), grid, dim3(kBlock), 0, c->stream, b, desc_dev, c->n, BatRosen<T>{}, ws);
             break;
         case 1:
-            if (q) LBFGSX_LAUNCH((kb_trial<T, BatQuad<T> >), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n, quad, c->ws);
-            else LBFGSX_LAUNCH((kb_trial<T, BatRosen<T> >), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n, BatRosen<T>{}, c->ws);
+            if (q) BAT_LAUNCH(c, (kb_trial<T, BatQuad<T> >), grid, dim3(kBlock), 0, c->stream, b, desc_dev, c->n, quad, ws);
+            else BAT_LAUNCH(c, (kb_trial<T, BatRosen<T> >), grid, dim3(kBlock), 0, c->stream, b, desc_dev, c->n, BatRosen<T>{}, ws);
             break;
-        case 4: LBFGSX_LAUNCH((kb_point<T>), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n); break;
-        case 5: LBFGSX_LAUNCH((kb_gdot<T, 0>), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n, c->ws); break;
-        case 6: LBFGSX_LAUNCH((kb_gdot<T, 1>), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n, c->ws); break;
-        case 2: LBFGSX_LAUNCH((kb_post<T>), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n, c->ws); break;
-        default: LBFGSX_LAUNCH((kb_twoloop<T>), grid, dim3(kBlock), 0, c->stream, b, c->desc_dev, c->n, c->ws,
+        case 4: BAT_LAUNCH(c, (kb_point<T>), grid, dim3(kBlock), 0, c->stream, b, desc_dev, c->n); break;
+        case 5: BAT_LAUNCH(c, (kb_gdot<T, 0>), grid, dim3(kBlock), 0, c->stream, b, desc_dev, c->n, ws); break;
+        case 6: BAT_LAUNCH(c, (kb_gdot<T, 1>), grid, dim3(kBlock), 0, c->stream, b, desc_dev, c->n, ws); break;
+        case 2: BAT_LAUNCH(c, (kb_post<T>), grid, dim3(kBlock), 0, c->stream, b, desc_dev, c->n, ws); break;
+        default: BAT_LAUNCH(c, (kb_twoloop<T>), grid, dim3(kBlock), 0, c->stream, b, desc_dev, c->n, ws,
                                     (c->zigzag && (c->tl_step++ & 1u)) ? 1 : 0); break;
         }
     });
     LBFGSX_HIP(hipGetLastError());
-    if (nout > 0 && out)
+    if (wait)
     {
-        // one contiguous copy of the whole per-problem scalar table (P * scn scalars, a few hundred KB): far
-        // cheaper than a strided copy of P tiny rows
-        const BatDesc* hd = desc;
-        BAT_DISPATCH(c, {
-            const size_t tot = size_t(c->P) * size_t(c->scn);
-            if (c->hout_cap < tot * sizeof(T))
-            {
-                if (c->hout)
-                    LBFGSX_HIP(hipHostFree(c->hout));
-                LBFGSX_HIP(hipHostMalloc(&c->hout, tot * sizeof(T), hipHostMallocDefault));
-                c->hout_cap = tot * sizeof(T);
-            }
-            LBFGSX_HIP(lbfgsx::copy_async(c->hout, c->sc, tot * sizeof(T), hipMemcpyDeviceToHost, c->stream));
-            LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
-            const T* tab = static_cast<const T*>(c->hout);
-            for (int p = 0; p < c->P; p++)
+        LBFGSX_HIP(lbfgsx::bat_wait(c));
+        const volatile double* tab = c->res_host;
+        for (int p = 0; p < c->P; p++)
+            if (desc[p].active)
                 for (int k = 0; k < nout; k++)
-                    out[size_t(p) * nout + k] = double(tab[size_t(p) * size_t(c->scn) + size_t(hd[p].i_out + k)]);
-        });
+                    out[size_t(p) * nout + k] = tab[size_t(p) * kBatRes + k];
     }
     return LBFGSX_OK;
 }
@@ -878,25 +803,20 @@ int lbfgsx_bat_apply_Hv(lbfgsx_batch* c, const lbfgsx_bat_hvdesc* desc)
         set_error("lbfgsx_bat_apply_Hv: vector does not fit one block's registers");
         return LBFGSX_E_INVALID;
     }
-    LBFGSX_HIP(lbfgsx::stream_sync(c->stream));  // the pinned staging may still be in flight
-    if (!c->hvdesc_dev)
-    {
-        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&c->hvdesc_dev), sizeof(BatHvDesc) * size_t(c->P)));
-        LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->hvdesc_host), sizeof(BatHvDesc) * size_t(c->P), hipHostMallocDefault));
-    }
-    std::memcpy(c->hvdesc_host, desc, sizeof(BatHvDesc) * size_t(c->P));
-    LBFGSX_HIP(lbfgsx::copy_async(c->hvdesc_dev, c->hvdesc_host, sizeof(BatHvDesc) * size_t(c->P), hipMemcpyHostToDevice, c->stream));
+    const void* dd = nullptr;
+    LBFGSX_HIP(lbfgsx::bat_stage(c, desc, sizeof(BatHvDesc) * size_t(c->P), &dd));
+    const BatHvDesc* hv = static_cast<const BatHvDesc*>(dd);
     const int slots = int((nv + kHvThreads - 1) / kHvThreads);
     BAT_DISPATCH(c, {
         BatBufs<T> b = bufs<T>(c);
         if (slots <= 14)
-            LBFGSX_LAUNCH((kb_twoloop_full<T, 14>), dim3(c->P), dim3(kHvThreads), 0, c->stream, b, c->hvdesc_dev, c->n, c->m);
+            BAT_LAUNCH(c, (kb_twoloop_full<T, 14>), dim3(c->P), dim3(kHvThreads), 0, c->stream, b, hv, c->n, c->m);
         else if (slots <= 28)
-            LBFGSX_LAUNCH((kb_twoloop_full<T, 28>), dim3(c->P), dim3(kHvThreads), 0, c->stream, b, c->hvdesc_dev, c->n, c->m);
+            BAT_LAUNCH(c, (kb_twoloop_full<T, 28>), dim3(c->P), dim3(kHvThreads), 0, c->stream, b, hv, c->n, c->m);
         else if (slots <= 56)
-            LBFGSX_LAUNCH((kb_twoloop_full<T, 56>), dim3(c->P), dim3(kHvThreads), 0, c->stream, b, c->hvdesc_dev, c->n, c->m);
+            BAT_LAUNCH(c, (kb_twoloop_full<T, 56>), dim3(c->P), dim3(kHvThreads), 0, c->stream, b, hv, c->n, c->m);
         else
-            LBFGSX_LAUNCH((kb_twoloop_full<T, 98>), dim3(c->P), dim3(kHvThreads), 0, c->stream, b, c->hvdesc_dev, c->n, c->m);
+            BAT_LAUNCH(c, (kb_twoloop_full<T, 98>), dim3(c->P), dim3(kHvThreads), 0, c->stream, b, hv, c->n, c->m);
     });
     LBFGSX_HIP(hipGetLastError());
     return LBFGSX_OK;
@@ -916,6 +836,7 @@ int lbfgsx_bat_fetch(lbfgsx_batch* c, const int* idx, double* out)
         }
         LBFGSX_HIP(lbfgsx::copy_async(c->hout, c->sc, tot * sizeof(T), hipMemcpyDeviceToHost, c->stream));
         LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
+        c->stage_unwaited = 0;
         const T* tab = static_cast<const T*>(c->hout);
         for (int p = 0; p < c->P; p++)
             out[p] = double(tab[size_t(p) * size_t(c->scn) + size_t(idx[p])]);
@@ -930,6 +851,7 @@ int lbfgsx_bat_download_x(lbfgsx_batch* c, int p, int pt, void* host)
     const char* base = static_cast<const char*>(c->X) + (size_t(pt) * c->P + size_t(p)) * size_t(c->ld) * c->esz;
     LBFGSX_HIP(lbfgsx::copy_async(host, base, size_t(c->n) * c->esz, hipMemcpyDeviceToHost, c->stream));
     LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
+    c->stage_unwaited = 0;
     return LBFGSX_OK;
 }
 
@@ -937,6 +859,7 @@ int lbfgsx_bat_sync(lbfgsx_batch* c)
 {
     lbfgsx::DeviceGuard dev_guard_(c->device);
     LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
+    c->stage_unwaited = 0;
     return LBFGSX_OK;
 }
 }

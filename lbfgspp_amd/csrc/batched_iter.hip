@@ -1,0 +1,460 @@
+// lbfgspp_amd/csrc/batched_iter.hip -- a whole lock-step iteration of the batched L-BFGS (BASELINE.json cfg5) as ONE launch.
+//
+// Between two line searches the reference's driver (LBFGS.h:121-168) runs, per problem,
+//     s = x - xp, y = grad - gradp, grad.norm(), x.norm(), s.y, y.y            (:130,137,159-161; BFGSMat.h:85-92)
+//     add_correction unless s.y <= eps y.y                                     (:161; BFGSMat.h:83-97)
+//     drt = -H grad                                                            (:165; BFGSMat.h:276-302)
+// and the next line search opens with a trial at a step the driver already knows (1, LBFGS.h:168; 1/|grad| at the start,
+// :108):  x = xp + step drt, f, grad, grad.drt (LineSearchMoreThuente.h:412-414, LineSearchNocedalWright.h:146-148).
+// Statement-wise that is three launches and three host waits per lock-step iteration (post, recursion, first trial),
+// (6 + 4c+3 + 4) n elements.  Here one 256-thread block per problem runs all three with the direction held on the CU
+// from the first step of the recursion to its last use (the trial):
+//     post       reads x, xp, grad, gradp; writes s, y                              6 n
+//     2c+1 steps each reads the two vectors of the step                             (4c+2) n
+//     trial      reads x; writes drt (later trials need it), x_trial, grad_trial    4 n
+// one launch, one wait.  (The post pass as the PRODUCER of q = -grad -- it has grad in registers -- would save the 2 n of step
+// 0; measured at compile time: a second producer of the 98 resident slots, straight-line or branch-free, sends the register
+// allocator to scratch memory (2 000+ spilled registers), so the post pass streams and step 0 re-reads grad.)  The host keeps the reference's control flow: it reads the sums, applies the stopping tests,
+// rotates the ring when the pair was accepted (the kernel applied the same test to the same rounded scalars) and feeds the
+// trial to the state machine of the search it starts.  Element-wise arithmetic and the order-independent sums are those of
+// kb_post / kb_twoloop / kb_trial (batched.hip), hence bit-identical results (tests/test_batched_gpu.py).
+#include <algorithm>
+#include <limits>
+
+#include "batched.hpp"
+
+namespace lbfgsx {
+
+constexpr int kItWaves = kHvThreads / 64;
+// Loads in flight.  A block owns its CU (one wave per SIMD), so the bandwidth a CU draws is (bytes its four waves have
+// in flight) / latency: with hv_step's 6-slot chunks (2 x 6 16-byte loads per thread) the launch ran at 5.05 TB/s; 14-slot
+// chunks (7 equal chunks of the 98 slots, 28 loads per thread, 112 of the ~170 registers the resident q leaves) 5.94 TB/s
+// -- measured interleaved on one box, profiles/r6_cfg5_chunk_ab.txt.
+#ifndef LBFGSX_IT_CHUNK
+#define LBFGSX_IT_CHUNK 14
+#endif
+#ifndef LBFGSX_IT_PU
+#define LBFGSX_IT_PU 6
+#endif
+#ifndef LBFGSX_IT_TU
+#define LBFGSX_IT_TU 6
+#endif
+
+// sums of NS per-thread accumulators over the block; the totals are valid in thread 0.  `sh` is reused by the caller's next
+// reduction only after a block barrier.
+template <int NS, class A>
+__device__ __forceinline__ void it_block_sum(A (&acc)[NS], double (*sh)[2][kItWaves])
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < NS; r++)
+    {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+        {
+            const double ohi = __shfl_down(acc[r].hi, off, 64);
+            const double olo = __shfl_down(acc_lo(acc[r]), off, 64);
+            acc[r].merge(ohi, olo);
+        }
+        if (lane == 0)
+        {
+            sh[r][0][wave] = acc[r].hi;
+            sh[r][1][wave] = acc_lo(acc[r]);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+#pragma unroll
+        for (int r = 0; r < NS; r++)
+        {
+            A t;
+            for (int wv = 0; wv < kItWaves; wv++)
+                t.merge(sh[r][0][wv], sh[r][1][wv]);
+            acc[r] = t;
+        }
+    }
+}
+
+// the first trial of the next search on the direction the block holds: x_t = x + step * d, f and grad there, grad_t . d;
+// d itself goes to memory on the way (later trials of the search read it)
+template <class T, int NR, int NL, class OBJ, class A>
+__device__ __forceinline__ void it_trial(const Pack<T> (&rq)[NR], const typename Vec16<T>::type* lq, const T* x, T step,
+                                         T* xt, T* gt, T* dout, const OBJ& obj, bool trial, int64_t nv, int tid, A& accf,
+                                         A& accd)
+{
+    constexpr int W = Vec16<T>::W;
+    constexpr int U = LBFGSX_IT_TU;
+#pragma unroll
+    for (int s0 = 0; s0 < NR + NL; s0 += U)
+    {
+        Pack<T> px[U];
+        bool ok[U];
+#pragma unroll
+        for (int k = 0; k < U; k++)
+            if (s0 + k < NR + NL)
+            {
+                const int64_t vi = int64_t(s0 + k) * kHvThreads + tid;
+                ok[k] = vi < nv;
+                if (trial)
+                    px[k] = ldv<T, true>(x, ok[k] ? vi : int64_t(0));
+            }
+#pragma unroll
+        for (int k = 0; k < U; k++)
+            if (s0 + k < NR + NL)
+            {
+                constexpr int dummy = 0;
+                const int s = s0 + k;
+                const int64_t vi = int64_t(s) * kHvThreads + tid;
+                Pack<T> cur;
+                if (s < NR)
+                    cur = rq[s < NR ? s : dummy];
+                else
+                    cur.v = lq[(s < NR ? dummy : s - NR) * kHvThreads + tid];
+                if (ok[k])  // d is only read here: a branch costs no second copy of the resident slots
+                {
+                    stv<T, false>(dout, vi, cur);
+                    if (trial)
+                    {
+                        Pack<T> xn, gn;
+#pragma unroll
+                        for (int e = 0; e < W; e++)
+                            xn.e[e] = px[k].e[e] + step * cur.e[e];
+                        obj.pack(vi, xn, gn, accf);
+                        stv(xt, vi, xn);
+                        stv(gt, vi, gn);
+#pragma unroll
+                        for (int e = 0; e < W; e++)
+                            accd.add_prod(gn.e[e], cur.e[e]);
+                    }
+                }
+            }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <class T, class OBJS, int NQ>
+__global__ void __launch_bounds__(kHvThreads) kb_iter(BatBufs<T> b, const BatItDesc* __restrict__ desc, int64_t n, int m,
+                                                     OBJS objs, BatWs ws, T eps)
+{
+    const int p = blockIdx.x;
+    const int tid = threadIdx.x;
+    __shared__ BatItDesc de;  // dynamic indexing of pcol[]: keep it out of scratch
+    {
+        constexpr int NI = int(sizeof(BatItDesc) / sizeof(int));
+        static_assert(NI <= kHvThreads, "descriptor words");
+        if (tid < NI)
+            reinterpret_cast<int*>(&de)[tid] = reinterpret_cast<const int*>(desc + p)[tid];
+    }
+    __syncthreads();
+    if (!de.active)
+        return;
+    typedef typename AccOf<T>::type A;
+    constexpr int W = Vec16<T>::W;
+    constexpr int NR = NQ > kHvRegSlots ? kHvRegSlots : NQ;
+    constexpr int NL = NQ - NR;
+    __shared__ typename Vec16<T>::type lq[(NL > 0 ? NL : 1) * kHvThreads];
+    __shared__ double sh[4][2][kItWaves];
+    __shared__ T sdot[2 * 32 + 2];
+    __shared__ T s_ys[32];
+    __shared__ int s_pcol[32];
+    __shared__ T s_theta0;
+    __shared__ int s_cn;
+    T* sc = b.scal(p);
+    const T* g = b.g(de.cur, p);
+    const T* x = b.x(de.cur, p);
+    const int64_t nv = n / W;
+    const int DOT0 = 2 * (m + 1) + 1;  // ScLayout::dot(0); ys(col) = col; theta(col) = m + 1 + col
+    const bool post = (de.flags & LBFGSX_BAT_IT_POST) != 0;
+    const bool post_only = (de.flags & LBFGSX_BAT_IT_POST_ONLY) != 0;
+    const bool trial = (de.flags & LBFGSX_BAT_IT_TRIAL) != 0;
+
+    Pack<T> rq[NR];
+    if (post)
+    {
+        // ---- the statements after the line search (kb_post's), streamed: nothing of q is resident yet
+        const T* xp = b.x(de.xp, p);
+        const T* gp = b.g(de.xp, p);
+        T* sv = b.s(de.spare, p);
+        T* yv = b.y(de.spare, p);
+        A accp[4];
+        constexpr int PU = LBFGSX_IT_PU;  // 4 PU 16-byte loads in flight per thread
+        for (int64_t v0 = tid; v0 < nv; v0 += int64_t(kHvThreads) * PU)
+        {
+            Pack<T> px[PU], pxp[PU], pg[PU], pgp[PU];
+#pragma unroll
+            for (int k = 0; k < PU; k++)
+            {
+                const int64_t vi = v0 + int64_t(k) * kHvThreads;
+                const int64_t vc = vi < nv ? vi : int64_t(0);
+                px[k] = ldv<T, true>(x, vc);
+                pxp[k] = ldv<T, true>(xp, vc);
+                pg[k] = ldv<T, true>(g, vc);
+                pgp[k] = ldv<T, true>(gp, vc);
+            }
+#pragma unroll
+            for (int k = 0; k < PU; k++)
+            {
+                const int64_t vi = v0 + int64_t(k) * kHvThreads;
+                if (vi < nv)
+                {
+                    Pack<T> ps, py;
+#pragma unroll
+                    for (int e = 0; e < W; e++)
+                    {
+                        ps.e[e] = px[k].e[e] - pxp[k].e[e];
+                        py.e[e] = pg[k].e[e] - pgp[k].e[e];
+                        accp[0].add_prod(pg[k].e[e], pg[k].e[e]);
+                        accp[1].add_prod(px[k].e[e], px[k].e[e]);
+                        accp[2].add_prod(ps.e[e], py.e[e]);
+                        accp[3].add_prod(py.e[e], py.e[e]);
+                    }
+                    stv(sv, vi, ps);
+                    stv(yv, vi, py);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // s, y are re-read by this block below
+        it_block_sum<4>(accp, sh);
+        if (tid == 0)
+        {
+            const T gg = T(accp[0].value()), xx = T(accp[1].value());
+            const T sy = T(accp[2].value()), yy = T(accp[3].value());
+            sc[de.spare] = sy;                 // ScLayout::ys(spare)
+            sc[(m + 1) + de.spare] = yy / sy;  // ScLayout::theta(spare)
+            bat_result(ws, p, 0, double(gg));
+            bat_result(ws, p, 1, double(xx));
+            bat_result(ws, p, 2, double(sy));
+            bat_result(ws, p, 3, double(yy));
+            const bool accept = sy > eps * yy;  // LBFGS.h:161
+            int cn;
+            if (accept)
+            {
+                cn = de.ncorr + 1 < m ? de.ncorr + 1 : m;
+                s_pcol[0] = de.spare;
+                for (int i = 1; i < cn; i++)
+                    s_pcol[i] = de.pcol[i - 1];
+                s_ys[0] = sy;
+                for (int i = 1; i < cn; i++)
+                    s_ys[i] = sc[s_pcol[i]];
+                s_theta0 = yy / sy;
+            }
+            else
+            {
+                cn = de.ncorr;
+                for (int i = 0; i < cn; i++)
+                {
+                    s_pcol[i] = de.pcol[i];
+                    s_ys[i] = sc[de.pcol[i]];
+                }
+                s_theta0 = cn > 0 ? sc[(m + 1) + de.pcol[0]] : T(1);
+            }
+            s_cn = cn;
+            if (post_only)
+                bat_signal(ws);
+        }
+        __syncthreads();
+        if (post_only)
+            return;
+    }
+    else
+    {
+        if (tid == 0)
+        {
+            const int cn = de.ncorr;
+            for (int i = 0; i < cn; i++)
+            {
+                s_pcol[i] = de.pcol[i];
+                s_ys[i] = sc[de.pcol[i]];
+            }
+            s_theta0 = cn > 0 ? sc[(m + 1) + de.pcol[0]] : T(1);
+            s_cn = cn;
+        }
+        __syncthreads();
+    }
+    const int cn = s_cn;
+
+    // ---- the recursion (BFGSMat.h:276-302): steps 0 .. 2 cn, step sequence and coefficients of kb_twoloop_full
+    auto operands = [&](int L, const T*& u, const T*& w) {
+        if (L == 0)
+        {
+            u = g;
+            w = cn > 0 ? b.s(s_pcol[0], p) : g;
+        }
+        else if (L < cn)
+        {
+            u = b.y(s_pcol[L - 1], p);
+            w = b.s(s_pcol[L], p);
+        }
+        else if (L == cn)
+        {
+            u = b.y(s_pcol[cn - 1], p);
+            w = u;
+        }
+        else
+        {
+            const int t = L - cn - 1, i = cn - 1 - t;
+            u = b.s(s_pcol[i], p);
+            w = (t < cn - 1) ? b.y(s_pcol[i - 1], p) : g;
+        }
+    };
+    // (Loading the next step's first chunk ahead of this step's reduction -- hv_prefetch, as k_twoloop_persist does with 30
+    // resident slots -- was tried: with 83 the 48 extra live registers send the allocator to scratch, 1400 spills.)
+    for (int L = 0; L <= 2 * cn; L++)
+    {
+        A acc4[4];  // independent chains: the order-independent sums make any split legal
+        const T* u;
+        const T* w;
+        operands(L, u, w);
+        T c = T(0), theta = T(1);
+        if (L == 0)
+            ;
+        else if (L < cn)
+            c = -(sdot[L - 1] / s_ys[L - 1]);
+        else if (L == cn)
+        {
+            c = -(sdot[cn - 1] / s_ys[cn - 1]);
+            theta = s_theta0;
+        }
+        else
+        {
+            const int i = cn - 1 - (L - cn - 1);
+            c = sdot[i] / s_ys[i] - sdot[L - 1] / s_ys[i];
+        }
+        // an opaque copy of the thread index per step: everything derived from it (slot addresses, range masks) is
+        // recomputed inside the step instead of being hoisted out of the L loop and kept in ~4 registers per slot
+        int tid_step = tid;
+        asm volatile("" : "+v"(tid_step));
+        hv_step<T, NR, NL, A, false, LBFGSX_IT_CHUNK>(rq, lq, u, w, L == 0, T(-1), c, theta, nv, int64_t(tid_step), int64_t(kHvThreads), tid, acc4);
+        A acc[1];
+        acc[0] = acc4[0];
+        for (int k = 1; k < 4; k++)
+            acc[0].merge(acc4[k].hi, acc_lo(acc4[k]));
+        it_block_sum<1>(acc, sh);
+        if (tid == 0)
+        {
+            const T r = T(acc[0].value());
+            sdot[L] = r;
+            sc[DOT0 + L] = r;
+        }
+        __syncthreads();
+    }
+
+    // ---- drt to memory; the first trial of the next search
+    A accf, accd;
+    const auto obj = objs.bind(p);
+    it_trial<T, NR, NL>(rq, lq, x, T(de.step), b.x(de.trial, p), b.g(de.trial, p), b.d(p), obj, trial, nv, tid, accf, accd);
+    if (trial)
+    {
+        A acc2[2];
+        acc2[0] = accf;
+        acc2[1] = accd;
+        it_block_sum<2>(acc2, sh);
+        accf = acc2[0];
+        accd = acc2[1];
+    }
+    if (tid == 0)
+    {
+        bat_result(ws, p, 4, double(sdot[2 * cn]));
+        if (trial)
+        {
+            bat_result(ws, p, 5, double(obj.finish(T(accf.value()))));
+            bat_result(ws, p, 6, double(T(accd.value())));
+        }
+        bat_signal(ws);
+    }
+}
+
+template <class T, class OBJS, int NQ>
+static void launch_iter(lbfgsx_batch* c, const BatItDesc* dd, const OBJS& objs, const BatWs& ws)
+{
+    BAT_LAUNCH(c, (kb_iter<T, OBJS, NQ>), dim3(c->P), dim3(kHvThreads), 0, c->stream, bufs<T>(c), dd, c->n, c->m, objs, ws,
+               std::numeric_limits<T>::epsilon());
+}
+template <class T, class OBJS>
+static void launch_iter_slots(lbfgsx_batch* c, int slots, const BatItDesc* dd, const OBJS& objs, const BatWs& ws)
+{
+    if (slots <= 14)
+        launch_iter<T, OBJS, 14>(c, dd, objs, ws);
+    else if (slots <= 28)
+        launch_iter<T, OBJS, 28>(c, dd, objs, ws);
+    else if (slots <= 56)
+        launch_iter<T, OBJS, 56>(c, dd, objs, ws);
+    else
+        launch_iter<T, OBJS, 98>(c, dd, objs, ws);
+}
+
+}  // namespace lbfgsx
+
+using namespace lbfgsx;
+
+extern "C" {
+
+int lbfgsx_bat_iterate_ok(const lbfgsx_batch* c)
+{
+    if (!c)
+        return 0;
+    const int64_t w = (c->dtype == LBFGSX_F64) ? 2 : 4;
+    return (c->fused_iter && c->fused_hv && (c->n % w) == 0 && c->n / w <= int64_t(kHvThreads) * 98 && c->m <= 32) ? 1 : 0;
+}
+
+int lbfgsx_bat_iterate(lbfgsx_batch* c, int objective, const lbfgsx_bat_itdesc* desc, double* out)
+{
+    if (!c || !desc || !out)
+        return LBFGSX_E_INVALID;
+    lbfgsx::DeviceGuard dev_guard_(c->device);
+    if (!lbfgsx_bat_iterate_ok(c))
+    {
+        set_error("lbfgsx_bat_iterate: vector does not fit one block's registers");
+        return LBFGSX_E_INVALID;
+    }
+    int nactive = 0;
+    bool any_trial = false;
+    for (int p = 0; p < c->P; p++)
+        if (desc[p].active)
+        {
+            nactive++;
+            any_trial = any_trial || (desc[p].flags & LBFGSX_BAT_IT_TRIAL) != 0;
+            if (desc[p].ncorr < 0 || desc[p].ncorr > c->m || desc[p].ncorr > 32)
+            {
+                set_error("lbfgsx_bat_iterate: ncorr out of range");
+                return LBFGSX_E_INVALID;
+            }
+        }
+    if (nactive == 0)
+        return LBFGSX_OK;
+    if (any_trial && objective != LBFGSX_OBJ_EXT_ROSENBROCK && objective != LBFGSX_OBJ_DIAG_QUAD)
+    {
+        set_error("lbfgsx_bat_iterate: the fused trial evaluates the extended Rosenbrock function or the diagonal quadratic");
+        return LBFGSX_E_INVALID;
+    }
+    if (any_trial && objective == LBFGSX_OBJ_DIAG_QUAD && !c->QA)
+    {
+        set_error("lbfgsx_bat_iterate: the diagonal quadratic needs its data (lbfgsx_bat_gen_diag_quad)");
+        return LBFGSX_E_LOGIC;
+    }
+    const void* dd = nullptr;
+    LBFGSX_HIP(lbfgsx::bat_stage(c, desc, sizeof(BatItDesc) * size_t(c->P), &dd));
+    const BatWs ws = lbfgsx::bat_arm(c, nactive);
+    const int64_t w = (c->dtype == LBFGSX_F64) ? 2 : 4;
+    const int slots = int((c->n / w + kHvThreads - 1) / kHvThreads);
+    BAT_DISPATCH(c, {
+        if (any_trial && objective == LBFGSX_OBJ_DIAG_QUAD)
+        {
+            const BatQuad<T> quad = {static_cast<const T*>(c->QA), static_cast<const T*>(c->QB), c->ld};
+            launch_iter_slots<T, BatQuad<T> >(c, slots, static_cast<const BatItDesc*>(dd), quad, ws);
+        }
+        else
+            launch_iter_slots<T, BatRosen<T> >(c, slots, static_cast<const BatItDesc*>(dd), BatRosen<T>{}, ws);
+    });
+    LBFGSX_HIP(hipGetLastError());
+    LBFGSX_HIP(lbfgsx::bat_wait(c));
+    const volatile double* tab = c->res_host;
+    for (int p = 0; p < c->P; p++)
+        if (desc[p].active)
+            for (int k = 0; k < kBatRes; k++)
+                out[size_t(p) * kBatRes + k] = tab[size_t(p) * kBatRes + k];
+    return LBFGSX_OK;
+}
+}

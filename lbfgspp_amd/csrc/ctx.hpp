@@ -184,8 +184,9 @@ struct lbfgsx_ctx
     unsigned long long* done_dev = nullptr;
     unsigned long long done_seq = 0;
     long long poll_waits = 0, poll_timeouts = 0, poll_lost = 0;  // lost: the word was still unset after the stream had drained
+    long long poll_late = 0;    // consecutive time-outs whose stream wait returned at once (store visible only at kernel end)
     bool poll_pending = false;  // poll_arm ran and no wait has consumed it yet
-    bool poll_off = false;      // two waits timed out: this context waits for its stream from now on
+    bool poll_off = false;      // two lost / late waits: this context waits for its stream from now on
     int grid_cap = 1024;     // blocks per launch of the streaming kernels (4 per CU; tuned on MI355X, see profiles/)
     int grid_cap_twoloop = 512;
     int unroll = 4;   // 16-byte loads in flight per stream per thread in the two-loop kernels
@@ -313,19 +314,33 @@ inline hipError_t poll_wait(lbfgsx_ctx* c)
             std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.05)
         {
             // 50 ms without the word: wait for the stream.  A long wait is legitimate (a pass over 1e8 rows queued behind a
-            // full radix sort, contexts sharing the GPU): it is counted but changes nothing.  Only a word that is STILL unset
-            // once the stream has drained -- the kernel never signals, or its system-scope store does not reach this
-            // mapping -- says that polling cannot work here; after the second such miss this context waits for its
-            // stream like everybody else (visible in lbfgsx_poll_counts).
+            // full radix sort, contexts sharing the GPU): it is counted but changes nothing.  Two things say that polling
+            // cannot work on this platform, and after the second such miss the context waits for its stream like everybody
+            // else (visible in lbfgsx_poll_counts_ex): the word is STILL unset once the stream has drained (the kernel never
+            // signals, or its system-scope store does not reach this mapping: poll_lost), or the stream wait returns at
+            // once -- the kernel had ended long ago and its store only became visible to the host at the kernel's end
+            // (poll_late); without the second test every wait of such a platform would burn the whole time-out.
             c->poll_timeouts++;
+            const auto s0 = std::chrono::steady_clock::now();
             const hipError_t e = hipStreamSynchronize(c->stream);
-            if (e == hipSuccess && *w < want && ++c->poll_lost >= 2)
-                c->poll_off = true;
+            const double sync_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - s0).count();
+            if (e == hipSuccess)
+            {
+                if (*w < want)
+                    c->poll_lost++;
+                else if (sync_s < 1e-3)
+                    c->poll_late++;
+                else
+                    c->poll_late = 0;  // a kernel that really ran for > 50 ms: consecutive "late" misses only
+                if (c->poll_lost >= 2 || c->poll_late >= 2)
+                    c->poll_off = true;
+            }
             if (tr)
                 host_trace("<sync");
             return e;
         }
     }
+    c->poll_late = 0;
     std::atomic_thread_fence(std::memory_order_acquire);
     if (tr)
         host_trace("<sync");

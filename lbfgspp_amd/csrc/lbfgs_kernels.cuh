@@ -493,13 +493,13 @@ __device__ __forceinline__ void hv_prefetch(const T* u, const T* w, int64_t nv, 
         pw[k] = ldv<T, true>(w, vc);
     }
 }
-template <class T, int NR, int NL, class A, bool PRE = false>
+template <class T, int NR, int NL, class A, bool PRE = false, int CH = kHvChunk>
 __device__ __forceinline__ void hv_step(Pack<T> (&rq)[NR], typename Vec16<T>::type* lq, const T* u, const T* w,
                                         bool init, T a, T c, T theta, int64_t nv, int64_t vbase, int64_t vstride,
                                         int ltid, A (&acc)[4], const Pack<T>* pre_u = nullptr, const Pack<T>* pre_w = nullptr)
 {
     constexpr int W = Vec16<T>::W;
-    constexpr int U = kHvChunk;
+    constexpr int U = CH;
 #pragma unroll
     for (int s0 = 0; s0 < NR + NL; s0 += U)
     {
@@ -611,14 +611,14 @@ struct PostFuse
 
 // the post statements + q = a * g for the resident slots of a thread (slot s = vector s * vstride + vbase)
 // (vbase = bbase + ltid; bbase is the block's first vector, wave-uniform: it forms the buffer descriptors of the stores)
-template <class T, int NR, int NL, class A>
+template <class T, int NR, int NL, class A, int PU = 2>
 __device__ __forceinline__ void hv_post_step(Pack<T> (&rq)[NR], typename Vec16<T>::type* lq, const PostFuse<T>& pf,
                                              const T* g, T a, int64_t nv, int64_t bbase, int64_t vstride, int ltid,
                                              A (&acc)[5])
 {
     const int64_t vbase = bbase + ltid;
     constexpr int W = Vec16<T>::W;
-    constexpr int U = 2;  // slots per chunk: 4 U 16-byte loads in flight per thread
+    constexpr int U = PU;  // slots per chunk: 4 U 16-byte loads in flight per thread
     // one descriptor per column for all slots of the block (slot offsets < (NR + NL) * vstride * 16 bytes < 2^30 ride
     // in the scalar offset; the range is 2^30 bytes so that the "dropped" offset 0x7FFFFFF0 below lies well outside it): write-through (sc1) stores -- later steps read these columns from other XCDs
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pf.s + W * bbase, 0, 0x40000000, 0x00020000);

@@ -1378,6 +1378,17 @@ int lbfgsx_poll_counts(const lbfgsx_ctx* c, int64_t out[2])
     return LBFGSX_OK;
 }
 
+int lbfgsx_poll_counts_ex(const lbfgsx_ctx* c, int64_t out[4])
+{
+    if (!c || !out)
+        return LBFGSX_E_INVALID;
+    out[0] = c->poll_waits;
+    out[1] = c->poll_timeouts;
+    out[2] = c->poll_lost + c->poll_late;
+    out[3] = c->poll_off ? 1 : 0;
+    return LBFGSX_OK;
+}
+
 int lbfgsx_counters(int64_t out[3], int reset)
 {
     auto& g = lbfgsx::counters();

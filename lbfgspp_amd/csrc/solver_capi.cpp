@@ -516,6 +516,147 @@ int lbfgsx_batch_minimize_lockstep_ex(int dtype, int linesearch, int objective, 
     return rc;
 }
 
+}  // extern "C"
+
+// A lock-step batch that outlives one minimisation: the LBFGSBatchedSolver and its resident batch for `count` problems of
+// dimension n on one device (lbfgsx_lockstep_create), reused by every lbfgsx_lockstep_minimize.
+struct lbfgsx_lockstep
+{
+    int dtype = LBFGSX_F64, linesearch = LBFGSX_LS_MORE_THUENTE, count = 0, device = 0;
+    int64_t n = 0;
+    lbfgsx_params prm;
+    LBFGSParam<double> pd;
+    LBFGSParam<float> pf;
+    void* solver = nullptr;  // LBFGSBatchedSolver<T, LS>*
+    void (*destroy)(void*) = nullptr;
+    void (*timing)(void*, int) = nullptr;
+    void (*run)(lbfgsx_lockstep*, int, double, uint64_t, int64_t, lbfgsx_batch_item*, void*, double*) = nullptr;
+};
+
+template <class T, template <class> class LS>
+static void lockstep_bind(lbfgsx_lockstep* h, LBFGSParam<T>& param, int timing)
+{
+    typedef LBFGSBatchedSolver<T, LS> S;
+    fill_common<T>(param, &h->prm);
+    param.linesearch = h->prm.linesearch;
+    S* s = new S(param);
+    h->solver = s;
+    h->destroy = [](void* p) { delete static_cast<S*>(p); };
+    h->timing = [](void* p, int on) { static_cast<S*>(p)->set_timing(on != 0); };
+    s->set_timing(timing != 0);
+    s->prepare(h->n, h->count, h->device);
+    h->run = [](lbfgsx_lockstep* hh, int objective, double kappa, uint64_t seed_base, int64_t first, lbfgsx_batch_item* out,
+                void* x_out, double* st) {
+        S* sv = static_cast<S*>(hh->solver);
+        std::vector<typename S::Item> items;
+        BatchObjective obj;
+        obj.id = objective;
+        obj.kappa = kappa;
+        sv->minimize(obj, hh->n, seed_base, first, hh->count, hh->device, items, static_cast<T*>(x_out));
+        for (int k = 0; k < hh->count; k++)
+        {
+            out[k].niter = items[size_t(k)].niter;
+            out[k].nfev = items[size_t(k)].nfev;
+            out[k].status = items[size_t(k)].status;
+            out[k].fx = double(items[size_t(k)].fx);
+            out[k].gnorm = double(items[size_t(k)].gnorm);
+        }
+        if (st)
+        {
+            st[0] = double(sv->stats.lockstep_iterations);
+            st[1] = sv->stats.fused ? 1.0 : 0.0;
+            st[2] = sv->stats.kernel_ms;
+            st[3] = double(sv->stats.launches);
+            st[4] = double(sv->stats.waits);
+            st[5] = double(sv->stats.wait_timeouts);
+            st[6] = st[7] = 0.0;
+        }
+    };
+}
+
+extern "C" {
+
+int lbfgsx_lockstep_create(lbfgsx_lockstep** out, int dtype, int linesearch, const lbfgsx_params* p, int64_t n, int count,
+                           int device, int timing, char* errbuf, int errlen)
+{
+    lbfgsx_result r;
+    lbfgsx_lockstep* h = nullptr;
+    const int rc = guarded(&r, [&]() {
+        if (!out || !p || count <= 0 || n <= 0)
+            throw std::invalid_argument("lbfgsx_lockstep_create: invalid argument");
+        if (linesearch != LBFGSX_LS_MORE_THUENTE && linesearch != LBFGSX_LS_NOCEDAL_WRIGHT)
+            throw std::invalid_argument("lbfgsx_lockstep_create: the lock-step batch runs LineSearchMoreThuente or "
+                                        "LineSearchNocedalWright (the policies that exist as state machines)");
+        if (dtype != LBFGSX_F64 && dtype != LBFGSX_F32)
+            throw std::invalid_argument("lbfgsx_lockstep_create: unknown dtype");
+        h = new lbfgsx_lockstep();
+        h->dtype = dtype;
+        h->linesearch = linesearch;
+        h->count = count;
+        h->device = device;
+        h->n = n;
+        h->prm = *p;
+        const bool nw = linesearch == LBFGSX_LS_NOCEDAL_WRIGHT;
+        if (dtype == LBFGSX_F64)
+        {
+            if (nw) lockstep_bind<double, LineSearchNocedalWright>(h, h->pd, timing);
+            else lockstep_bind<double, LineSearchMoreThuente>(h, h->pd, timing);
+        }
+        else
+        {
+            if (nw) lockstep_bind<float, LineSearchNocedalWright>(h, h->pf, timing);
+            else lockstep_bind<float, LineSearchMoreThuente>(h, h->pf, timing);
+        }
+    });
+    if (errbuf && errlen > 0)
+        std::snprintf(errbuf, size_t(errlen), "%s", r.msg);
+    if (rc != LBFGSX_OK)
+    {
+        if (h)
+        {
+            if (h->solver && h->destroy)
+                h->destroy(h->solver);
+            delete h;
+        }
+        return rc;
+    }
+    *out = h;
+    return LBFGSX_OK;
+}
+
+int lbfgsx_lockstep_minimize(lbfgsx_lockstep* h, int objective, double kappa, uint64_t seed_base, int64_t first,
+                             lbfgsx_batch_item* out, void* x_out, double stats[8], char* errbuf, int errlen)
+{
+    lbfgsx_result r;
+    const int rc = guarded(&r, [&]() {
+        if (!h || !out)
+            throw std::invalid_argument("lbfgsx_lockstep_minimize: invalid argument");
+        if (objective != LBFGSX_OBJ_EXT_ROSENBROCK && objective != LBFGSX_OBJ_DIAG_QUAD)
+            throw std::invalid_argument("lbfgsx_lockstep_minimize: unknown built-in objective");
+        h->run(h, objective, kappa, seed_base, first, out, x_out, stats);
+    });
+    if (errbuf && errlen > 0)
+        std::snprintf(errbuf, size_t(errlen), "%s", r.msg);
+    return rc;
+}
+
+int lbfgsx_lockstep_set_timing(lbfgsx_lockstep* h, int on)
+{
+    if (!h || !h->solver)
+        return LBFGSX_E_INVALID;
+    h->timing(h->solver, on);
+    return LBFGSX_OK;
+}
+
+void lbfgsx_lockstep_destroy(lbfgsx_lockstep* h)
+{
+    if (!h)
+        return;
+    if (h->solver && h->destroy)
+        h->destroy(h->solver);
+    delete h;
+}
+
 int lbfgsx_batch_minimize_lockstep_multi(int dtype, const lbfgsx_params* p, int64_t n, int64_t first, int count,
                                          uint64_t seed_base, const int* devices, int ndev, lbfgsx_batch_item* out,
                                          void* x_out, char* errbuf, int errlen)

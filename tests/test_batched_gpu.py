@@ -103,6 +103,49 @@ def test_one_launch_two_loop_equals_step_wise_launches(monkeypatch, dtype, n):
         assert np.array_equal(u, v)
 
 
+@pytest.mark.parametrize("dtype,n,m,eps", [(np.float32, 100000, 10, 0.0), (np.float64, 50176, 6, 0.0), (np.float32, 4096, 3, 0.0),
+                                            (np.float64, 2048, 5, 1e-3), (np.float32, 100352, 31, 0.0)])
+def test_one_launch_iteration_equals_statement_wise_launches(monkeypatch, dtype, n, m, eps):
+    """lbfgsx_bat_iterate (post statements + recursion + first trial of the next search in ONE launch per lock-step iteration,
+    the direction resident on the CU) against the three statement-wise forms it replaces: identical records and iterates.
+    eps > 0: problems converge at different iterations, so finished problems sit out of later launches."""
+    import lbfgspp_amd as A
+    from lbfgspp_amd import batched as B
+    par = A.LBFGSParam(m=m, epsilon=eps, epsilon_rel=0.0, max_iterations=(400 if eps > 0 else m + 6))
+    got = {}
+    for name, it, hv in (("iterate", "1", "1"), ("apply_Hv", "0", "1"), ("steps", "0", "0")):
+        monkeypatch.setenv("LBFGSX_BAT_FUSED_ITER", it)
+        monkeypatch.setenv("LBFGSX_BAT_FUSED_HV", hv)
+        got[name] = B.solve_local_lockstep(par, n, first=3, count=7, seed_base=5, dtype=dtype, return_x=True)
+    for name in ("apply_Hv", "steps"):
+        assert np.array_equal(got["iterate"][0], got[name][0]), name
+        assert np.array_equal(got["iterate"][1], got[name][1]), name
+    if eps > 0:
+        assert len(set(got["iterate"][0]["niter"])) > 1, got["iterate"][0]["niter"]  # the case the parameter is there for
+
+
+def test_resident_batch_is_reused_across_minimisations(A):
+    """lbfgsx_lockstep_create / _minimize: the batch allocated once; a second minimisation of the same ids repeats the first
+    bit for bit, other ids give other problems, and both equal the one-shot call; the stats say which form ran"""
+    from lbfgspp_amd import batched as B
+    par = A.LBFGSParam(m=5, epsilon=0.0, epsilon_rel=0.0, max_iterations=9)
+    n, count = 20000, 6
+    batch = B.LockstepBatch(par, n, count, dtype=np.float32, device=0)
+    a, xa = batch.minimize(first=0, seed_base=11, return_x=True)
+    assert batch.stats["fused"] and batch.stats["lockstep_iterations"] == 10 and batch.stats["kernel_ms"] == 0.0
+    b, xb = batch.minimize(first=10, seed_base=11, return_x=True)
+    batch.set_timing(True)
+    c, xc = batch.minimize(first=0, seed_base=11, return_x=True)
+    st = batch.stats
+    batch.close()
+    assert np.array_equal(a, c) and np.array_equal(xa, xc)
+    assert not np.array_equal(xa, xb)
+    one, xo = B.solve_local_lockstep(par, n, first=10, count=count, seed_base=11, dtype=np.float32, return_x=True)
+    assert np.array_equal(b, one) and np.array_equal(xb, xo)
+    # 1 evaluation + one launch per lock-step iteration + the further trials; every launch with results is waited for once
+    assert st["kernel_ms"] > 0.0 and st["launches"] >= 11 and st["waits"] == st["launches"] and st["wait_timeouts"] == 0
+
+
 @pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0], None])
 def test_multi_device_batch_equals_the_single_device_batch(devices):
     """SURVEY 8(e) behind the C ABI: lbfgsx_batch_minimize_lockstep_multi gives every listed device a contiguous block of
