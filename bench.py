@@ -740,6 +740,13 @@ def run_north_star(args, rank, world, local, comm_dev, dist):
     import gc
     gc.collect()
     # N > 1: what every rank saw, so that the aggregate explains itself (which device, its own rate, its copy probe)
+    ranks_counted = None
+    if world > 1:
+        # the ranks the collective library itself counts: a sum of ones over the timing communicator (N on an N-GPU run --
+        # what lets a SCALE line prove that N ranks took part, whatever the launcher claims)
+        one = torch.ones(1, dtype=torch.float64, device=comm_dev)
+        dist.all_reduce(one)
+        ranks_counted = int(round(float(one.item())))
     per_rank = gather_objects({"rank": rank, "device": local, "value": K / local_elapsed, "ms_per_step": local_elapsed / K * 1e3,
                                "stream_copy_GBs": copy_gbs.value, "rows": n}, rank, world, dist)
     if rank != 0:
@@ -824,7 +831,8 @@ def run_north_star(args, rank, world, local, comm_dev, dist):
     }
     if world > 1:
         out["per_rank"] = per_rank
-        out["collective"] = collective_info(dist, world)
+        out["collective"] = dict(collective_info(dist, world), ranks_counted_by_allreduce=ranks_counted,
+                                 devices=[r["device"] for r in per_rank])
     if gram:
         out["config"]["recursion"] = "gram-space, f32 history" if f32h else "gram-space"
         if sharded:

@@ -556,7 +556,12 @@ int lbfgsx_bat_create(lbfgsx_batch** out, int dtype, int64_t n, int m, int nprob
     if (const char* e = getenv("LBFGSX_BAT_POLL"))
         c->poll = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_BAT_GX"))
+    {
         gx = std::max(1, std::min(atoi(e), 256));
+        c->adaptive_gx = false;
+    }
+    if (const char* e = getenv("LBFGSX_BAT_ADAPTIVE_GX"))
+        c->adaptive_gx = atoi(e) != 0;
     c->gx = int(gx);
     live_add(c->device, +1);
     const int rc = bat_alloc(c);
@@ -580,8 +585,8 @@ static int bat_alloc(lbfgsx_batch* c)
     LBFGSX_HIP(hipMalloc(&c->S, size_t(m + 1) * vb));
     LBFGSX_HIP(hipMalloc(&c->Y, size_t(m + 1) * vb));
     LBFGSX_HIP(hipMalloc(&c->sc, sizeof(double) * size_t(c->scn) * size_t(nproblems)));
-    c->ws.gx = c->gx;
-    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&c->ws.partials), sizeof(double) * size_t(nproblems) * kMaxRedB * 2 * size_t(c->gx)));
+    c->ws.gx = std::max(c->gx, kBatGxMax);  // stride of a problem's partials: a launch may use up to that many blocks per problem
+    LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&c->ws.partials), sizeof(double) * size_t(nproblems) * kMaxRedB * 2 * size_t(c->ws.gx)));
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&c->ws.ticket), sizeof(unsigned) * size_t(nproblems)));
     LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&c->ws.done_cnt), 64));
     // host-mapped: descriptor staging (read by the kernels in place), result table, completion word
@@ -730,7 +735,7 @@ void* lbfgsx_bat_stream(lbfgsx_batch* c) { return c ? static_cast<void*>(c->stre
 int lbfgsx_bat_launch(lbfgsx_batch* c, int kind, int objective, const lbfgsx_bat_desc* desc, int nout, double* out)
 {
     lbfgsx::DeviceGuard dev_guard_(c->device);
-    const dim3 grid(unsigned(c->gx), unsigned(c->P));
+    int grid_x = c->gx;
     const bool fused_obj = (kind == 0 || kind == 1);
     if (fused_obj && objective != LBFGSX_OBJ_EXT_ROSENBROCK && objective != LBFGSX_OBJ_DIAG_QUAD)
     {
@@ -756,6 +761,19 @@ int lbfgsx_bat_launch(lbfgsx_batch* c, int kind, int objective, const lbfgsx_bat
     const void* dd = nullptr;
     LBFGSX_HIP(lbfgsx::bat_stage(c, desc, sizeof(BatDesc) * size_t(c->P), &dd));
     const BatDesc* desc_dev = static_cast<const BatDesc*>(dd);
+    // Blocks per problem of THIS launch.  The batch's gx assumes that every problem takes part; the launches after the first
+    // trial of a lock-step iteration carry the quarter of the problems whose search goes on, and with one block each they
+    // leave most CUs idle and are latency-bound (163 us for 0.47 GB on the cfg5 batch).  The blocks of the problems that
+    // sit out return at once, so the active ones get up to kBatGxMax blocks each, ~1024 working blocks per launch.  The sums
+    // are order independent: any block count gives the same bits.
+    {
+        const int64_t w = (c->dtype == LBFGSX_F64) ? 2 : 4;
+        const int64_t tiles = std::max<int64_t>(1, (c->n / w + 4 * kBlock - 1) / (4 * kBlock));
+        const int64_t want = std::max<int64_t>(c->gx, std::min<int64_t>(std::min<int64_t>(1024 / nactive, kBatGxMax), tiles));
+        if (c->adaptive_gx && kind != 3)
+            grid_x = int(want);
+    }
+    const dim3 grid(unsigned(grid_x), unsigned(c->P));
     const bool wait = nout > 0 && out && kind != 3 && kind != 4;
     const BatWs ws = wait ? lbfgsx::bat_arm(c, nactive) : lbfgsx::bat_unarmed(c);
     BAT_DISPATCH(c, {

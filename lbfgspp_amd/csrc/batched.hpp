@@ -194,6 +194,7 @@ struct BatQuad
 };
 
 constexpr int kHvRegSlots = 83;  // 16-byte slots of q a thread of the one-block-per-problem kernels keeps in registers
+constexpr int kBatGxMax = 16;   // blocks per problem a launch may use when few problems take part
 constexpr int kBatStages = 4;    // descriptor staging buffers (host-mapped, read by the kernels in place)
 
 }  // namespace lbfgsx
@@ -214,6 +215,7 @@ struct lbfgsx_batch
     unsigned tl_step = 0;
     bool fused_hv = true;    // LBFGSX_BAT_FUSED_HV=0: always the step-wise two-loop launches
     bool fused_iter = true;  // LBFGSX_BAT_FUSED_ITER=0: never the one-launch lock-step iteration
+    bool adaptive_gx = true; // LBFGSX_BAT_ADAPTIVE_GX=0: every launch with the batch's blocks per problem
     bool poll = true;        // LBFGSX_BAT_POLL=0: wait for the stream instead of polling the completion word
     // Descriptor staging: kBatStages host-mapped buffers the kernels read in place (no copy in the stream, nothing to wait
     // for before the host fills the next one); a launch takes the next buffer, and the stream is drained before a buffer

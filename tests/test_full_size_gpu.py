@@ -71,6 +71,54 @@ def test_extended_rosenbrock_full_size_is_bit_identical_to_the_replicated_oracle
         sv.close()
 
 
+def test_cfg3_own_instance_at_size_against_the_cached_reference_trace(A):
+    """cfg3's BENCHMARK instance -- n = 1e8, m = 20, the counter-hash start point bench.py times, not a tiled base problem --
+    against the unmodified reference (oracle/_ref/libref_dd.so) at that size: tests/golden/cfg3_1e8_m20_trace.npz holds what
+    the reference produced (tests/golden/make_cfg3_trace.py: ~45 GB and minutes of one host core, so it is computed once in
+    the build container): the objective value and every 40 000th coordinate at every evaluation, every 2 500th coordinate of
+    the final iterate, the counts, keyed by oracle/_ref/build_key.txt.  The GPU side generates the start point on the device
+    (lbfgsx_gen_rosen_x0(ctx, 7)), as bench.py does.  Bar: the north star's 1e-10 on the iterates (double), same counts."""
+    import ctypes as C
+    import os
+    from lbfgspp_amd import _lib as L
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg3_1e8_m20_trace.npz")
+    keyf = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "build_key.txt")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/cfg3_1e8_m20_trace.npz missing (python tests/golden/make_cfg3_trace.py)")
+    g = np.load(path)
+    if os.path.exists(keyf) and open(keyf).read().strip() != str(g["key"]):
+        pytest.fail("tests/golden/cfg3_1e8_m20_trace.npz was taken from another oracle build: regenerate it "
+                    "(python tests/golden/make_cfg3_trace.py)")
+    n, m, iters, stride, fstride = int(g["n"]), int(g["m"]), int(g["iters"]), int(g["stride"]), int(g["final_stride"])
+    assert (n, m) == (100_000_000, 20) and iters >= 12
+    core, _ = A.load()
+    s = A.LBFGSSolver(A.LBFGSParam(m=m, epsilon=0.0, epsilon_rel=0.0, past=0, max_iterations=iters), linesearch=A.LS_MORE_THUENTE,
+                      dtype="float64")
+    try:
+        ctx = s.prepare(n)
+        L.check(core.lbfgsx_gen_rosen_x0(ctx, 7))
+        L.check(core.lbfgsx_sync(ctx))
+        tr = A.TraceBuffer(n, cap=256, stride=stride)
+        niter, fx = s.minimize_resident(A.ExtendedRosenbrock(), n, trace=tr)
+        nfev = s.last.nfev
+        x = np.empty(n)
+        L.check(core.lbfgsx_download(ctx, L.VEC_X, x.ctypes.data_as(C.c_void_p)))
+        gnorm = s.final_grad_norm()
+    finally:
+        s.close()
+    k = tr.count
+    assert (niter, nfev, k) == (int(g["niter"]), int(g["nfev"]), g["xs"].shape[0])
+    per_eval = np.abs(tr.xs[:k] - g["xs"]).max(axis=1)
+    assert per_eval.max() <= 1e-10, "iterates deviate by %.3g at evaluation %d" % (per_eval.max(), int(per_eval.argmax()))
+    frel = np.abs(tr.fx[:k] - g["fx_per_eval"]) / np.abs(g["fx_per_eval"])
+    assert frel.max() <= 1e-11, "objective values deviate by %.3g (relative)" % frel.max()
+    assert np.abs(x[::fstride] - g["x_final"]).max() <= 1e-10
+    assert abs(fx - float(g["fx"])) <= 1e-11 * abs(float(g["fx"])) and abs(gnorm - float(g["gnorm"])) <= 1e-9 * float(g["gnorm"])
+    print("cfg3 own instance: %d iterations / %d evaluations against the cached reference trace: max |dx| per evaluation %.3g, "
+          "final %.3g, bit-equal evaluations %d of %d" % (niter, k, per_eval.max(), np.abs(x[::fstride] - g["x_final"]).max(),
+                                                          int((per_eval == 0.0).sum()), k))
+
+
 def test_cfg2_quadratic_full_size_replicated_oracle_and_closed_form(A, port):
     n, R, m = 10_000_000, 64, 10
     p = n // R

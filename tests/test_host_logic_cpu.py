@@ -12,12 +12,16 @@ import oracle_lib as O
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
+# LBFGSX_TEST_SANITIZE=1 (scripts/sanitize_host.sh, with libasan preloaded into the interpreter): the host templates under
+# AddressSanitizer + UndefinedBehaviorSanitizer, any finding aborts the test process
+SAN = (["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-g"]
+       if os.environ.get("LBFGSX_TEST_SANITIZE") == "1" else [])
 
 
 @pytest.fixture(scope="module")
 def hl(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("hl") / "libhostlogic.so")
-    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"),
+    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off"] + SAN + ["-I", os.path.join(ROOT, "include"),
            os.path.join(HERE, "cpp", "host_logic_capi.cpp"), "-o", out]
     subprocess.check_call(cmd)
     lib = C.CDLL(out)
@@ -253,8 +257,8 @@ def test_sums_over_L_u_U_are_used_by_the_solve_that_follows_their_pass_only(tmp_
     calls Wtv_lu, and would have combined the OLD partition's sums with the new partition's Gram.  Host code against a mock of
     the C ABI (tests/cpp/mock_bfgsmat_capi.cpp); the log lists the device entries each sweep's solve called."""
     out = str(tmp_path / "libmockbfgs.so")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"),
-                           os.path.join(HERE, "cpp", "mock_bfgsmat_capi.cpp"), "-o", out])
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-ffp-contract=off"] + SAN +
+                          ["-I", os.path.join(ROOT, "include"), os.path.join(HERE, "cpp", "mock_bfgsmat_capi.cpp"), "-o", out])
     lib = C.CDLL(out)
     lib.mock_sweep_sequence.restype = C.c_char_p
     lib.mock_sweep_sequence.argtypes = [C.c_int]
