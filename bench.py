@@ -317,7 +317,7 @@ def run_batched(args, rank, world, local, comm_dev, dist, steps):
 
     import lbfgspp_amd as A
     from lbfgspp_amd import batched as B
-    n, m, P = 100000, 10, args.problems_per_gpu
+    n, m, P = int(args.batched_n), 10, args.problems_per_gpu
     total = P * world
     first, count = B.shard_range(total, rank, world)
     par = A.LBFGSParam(m=m, epsilon=0.0, epsilon_rel=0.0, max_iterations=steps)
@@ -371,13 +371,13 @@ def run_batched(args, rank, world, local, comm_dev, dist, steps):
     hbm_ *= n * 4.0
     model_gbs = hbm_ / elapsed / 1e9 / world
     return {
-        "metric": "batched L-BFGS problem-iterations/sec (cfg5: n=1e5, m=10, f32)", "value": its / elapsed,
+        "metric": "batched L-BFGS problem-iterations/sec (cfg5: n=%g, m=10, f32)" % n, "value": its / elapsed,
         "unit": "problem-iterations/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
         "ms_per_step": elapsed / max(steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "cfg5: %d independent extended-Rosenbrock problems per GPU, n=1e5, m=10, f32, "
+        "config": {"workload": "cfg5: %d independent extended-Rosenbrock problems per GPU, n=%g, m=10, f32, "
                                "LineSearchMoreThuente, %d iterations each, lock-step batch; contiguous problem-id blocks "
-                               "per rank, no data-path collective, one all-gather of the result records" % (P, steps),
+                               "per rank, no data-path collective, one all-gather of the result records" % (P, n, steps),
                    "problems_total": total, "fevals_total": fev, "failed": int((full["status"] != 0).sum()),
                    "one_launch_per_iteration": bool(st.get("fused")), "lockstep_iterations": st.get("lockstep_iterations"),
                    "setup_seconds": setup_s,
@@ -1160,6 +1160,7 @@ def main():
                          "--n rows row-sharded over the ranks (strong scaling; opt-in Gram-space recursion, all-reduces "
                          "of <= 6m+7 doubles over RCCL)")
     ap.add_argument("--problems-per-gpu", type=int, default=1024)
+    ap.add_argument("--batched-n", type=float, default=1e5, help="dimension of the batched leg's problems (cfg5: 1e5)")
     ap.add_argument("--batched-steps", type=int, default=50, help="iterations per problem of the cfg5 leg of the default line")
     ap.add_argument("--no-batched", action="store_true", help="skip the cfg5 leg of the default line")
     ap.add_argument("--single-process", action="store_true",

@@ -553,6 +553,8 @@ int lbfgsx_bat_create(lbfgsx_batch** out, int dtype, int64_t n, int m, int nprob
         c->fused_hv = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_BAT_FUSED_ITER"))
         c->fused_iter = atoi(e) != 0;
+    if (const char* e = getenv("LBFGSX_BAT_MAX_PARTS"))
+        c->max_parts = std::max(0, atoi(e));
     if (const char* e = getenv("LBFGSX_BAT_POLL"))
         c->poll = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_BAT_GX"))
@@ -624,7 +626,7 @@ void lbfgsx_bat_destroy(lbfgsx_batch* c)
     if (c->stream)
         (void) lbfgsx::stream_sync(c->stream);
     live_add(c->device, -1);
-    void* ptrs[] = {c->X, c->G, c->D, c->S, c->Y, c->sc, c->QA, c->QB, c->ws.partials, c->ws.ticket, c->ws.done_cnt};
+    void* ptrs[] = {c->X, c->G, c->D, c->S, c->Y, c->sc, c->QA, c->QB, c->ws.partials, c->ws.ticket, c->ws.done_cnt, c->xch};
     for (void* p : ptrs)
         if (p)
             (void) hipFree(p);

@@ -76,13 +76,69 @@ __device__ __forceinline__ void it_block_sum(A (&acc)[NS], double (*sh)[2][kItWa
     }
 }
 
+// A problem too long for one CU's registers is split over G consecutive blocks ("parts": part r owns the vectors
+// [r nvp, (r + 1) nvp)); only the sums cross parts.  After its block reduction thread 0 of every part publishes the part's
+// NS partial sums as tagged 16-byte words {tag, 0, double} (write-through stores, as k_twoloop_persist's meeting points) and
+// collects the siblings' words of this tag; all parts add the G partials in part order from zero, so every part holds the
+// same total.  Two buffers alternate: a part can be at most one exchange ahead of a sibling (it needs the sibling's word of
+// exchange e + 1, which the sibling writes only after it has read everybody's word of exchange e).  The parts of a problem are
+// consecutive block ids and blocks are dispatched in id order, so whatever holds the CUs a missing sibling waits for
+// belongs to problems whose parts are all resident: they finish.  The wait is bounded all the same (0.5 s): a part that
+// gives up poisons the launch's error word, the host sees it in the results and fails loudly.
+struct ItXch
+{
+    unsigned* base;  // [P][2][kItMaxParts][4][2] 16-byte words
+    int* err;        // launch-wide error word (device memory)
+    unsigned tag0;   // tag of this launch's exchange 0
+    int G;
+};
+constexpr int kItMaxParts = 8;
+constexpr int kItXchWords = 2 * kItMaxParts * 4 * 2;  // 16-byte words per problem
+
+template <int NS, class A>
+__device__ __forceinline__ bool it_exchange(A (&acc)[NS], const ItXch& xc, int p, int r, unsigned e)
+{
+    static_assert(NS <= 4, "exchange rows");
+    unsigned* area = xc.base + size_t(p) * kItXchWords * 4;
+    const unsigned tag = xc.tag0 + e;
+    const int par = int(e & 1u);
+    auto word = [&](int part, int k, int h) { return area + size_t(((par * kItMaxParts + part) * 4 + k) * 2 + h) * 4; };
+#pragma unroll
+    for (int k = 0; k < NS; k++)
+    {
+        persist_publish<false>(word(r, k, 0), tag, acc[k].hi);
+        persist_publish<false>(word(r, k, 1), tag, acc_lo(acc[k]));
+    }
+    A tot[NS];
+    bool ok = true;
+    for (int q = 0; q < xc.G; q++)
+    {
+#pragma unroll
+        for (int k = 0; k < NS; k++)
+        {
+            double hi = acc[k].hi, lo = acc_lo(acc[k]);
+            if (q != r)
+            {
+                if (ok)
+                    ok = persist_await(word(q, k, 0), tag, xc.err, hi) && persist_await(word(q, k, 1), tag, xc.err, lo);
+            }
+            tot[k].merge(hi, lo);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NS; k++)
+        acc[k] = tot[k];
+    return ok;
+}
+
 // the first trial of the next search on the direction the block holds: x_t = x + step * d, f and grad there, grad_t . d;
 // d itself goes to memory on the way (later trials of the search read it)
 template <class T, int NR, int NL, class OBJ, class A>
 __device__ __forceinline__ void it_trial(const Pack<T> (&rq)[NR], const typename Vec16<T>::type* lq, const T* x, T step,
-                                         T* xt, T* gt, T* dout, const OBJ& obj, bool trial, int64_t nv, int tid, A& accf,
-                                         A& accd)
+                                         T* xt, T* gt, T* dout, const OBJ& obj, bool trial, int64_t voff, int64_t nv, int tid,
+                                         A& accf, A& accd)
 {
+    // x, xt, gt, dout: the problem's whole vectors; this part's slot s of thread tid is vector voff + s * 256 + tid of them
     constexpr int W = Vec16<T>::W;
     constexpr int U = LBFGSX_IT_TU;
 #pragma unroll
@@ -94,10 +150,10 @@ __device__ __forceinline__ void it_trial(const Pack<T> (&rq)[NR], const typename
         for (int k = 0; k < U; k++)
             if (s0 + k < NR + NL)
             {
-                const int64_t vi = int64_t(s0 + k) * kHvThreads + tid;
-                ok[k] = vi < nv;
+                const int64_t vl = int64_t(s0 + k) * kHvThreads + tid;
+                ok[k] = vl < nv;
                 if (trial)
-                    px[k] = ldv<T, true>(x, ok[k] ? vi : int64_t(0));
+                    px[k] = ldv<T, true>(x, ok[k] ? voff + vl : int64_t(0));
             }
 #pragma unroll
         for (int k = 0; k < U; k++)
@@ -105,7 +161,7 @@ __device__ __forceinline__ void it_trial(const Pack<T> (&rq)[NR], const typename
             {
                 constexpr int dummy = 0;
                 const int s = s0 + k;
-                const int64_t vi = int64_t(s) * kHvThreads + tid;
+                const int64_t vi = voff + int64_t(s) * kHvThreads + tid;
                 Pack<T> cur;
                 if (s < NR)
                     cur = rq[s < NR ? s : dummy];
@@ -136,9 +192,10 @@ __device__ __forceinline__ void it_trial(const Pack<T> (&rq)[NR], const typename
 
 template <class T, class OBJS, int NQ>
 __global__ void __launch_bounds__(kHvThreads) kb_iter(BatBufs<T> b, const BatItDesc* __restrict__ desc, int64_t n, int m,
-                                                     OBJS objs, BatWs ws, T eps)
+                                                     OBJS objs, BatWs ws, T eps, ItXch xc)
 {
-    const int p = blockIdx.x;
+    const int G = xc.G;
+    const int p = blockIdx.x / G, r = blockIdx.x % G;  // problem, part
     const int tid = threadIdx.x;
     __shared__ BatItDesc de;  // dynamic indexing of pcol[]: keep it out of scratch
     {
@@ -160,24 +217,32 @@ __global__ void __launch_bounds__(kHvThreads) kb_iter(BatBufs<T> b, const BatItD
     __shared__ T s_ys[32];
     __shared__ int s_pcol[32];
     __shared__ T s_theta0;
-    __shared__ int s_cn;
+    __shared__ int s_cn, s_bad;
     T* sc = b.scal(p);
-    const T* g = b.g(de.cur, p);
-    const T* x = b.x(de.cur, p);
-    const int64_t nv = n / W;
+    // this part's vectors: [voff, voff + nv) of the problem's n / W (one part: all of them)
+    const int64_t nv_all = n / W;
+    const int64_t nvp = G > 1 ? ((nv_all + G - 1) / G + kHvThreads - 1) / kHvThreads * kHvThreads : nv_all;
+    const int64_t voff = int64_t(r) * nvp;
+    const int64_t nv = nv_all - voff < nvp ? (nv_all - voff > 0 ? nv_all - voff : 0) : nvp;
+    const int64_t eoff = voff * W;
+    const T* g = b.g(de.cur, p) + eoff;
+    const T* x = b.x(de.cur, p) + eoff;
     const int DOT0 = 2 * (m + 1) + 1;  // ScLayout::dot(0); ys(col) = col; theta(col) = m + 1 + col
     const bool post = (de.flags & LBFGSX_BAT_IT_POST) != 0;
     const bool post_only = (de.flags & LBFGSX_BAT_IT_POST_ONLY) != 0;
     const bool trial = (de.flags & LBFGSX_BAT_IT_TRIAL) != 0;
+    unsigned xe = 0;  // exchanges of this launch so far (uniform over the parts of a problem)
+    if (tid == 0)
+        s_bad = 0;
 
     Pack<T> rq[NR];
     if (post)
     {
         // ---- the statements after the line search (kb_post's), streamed: nothing of q is resident yet
-        const T* xp = b.x(de.xp, p);
-        const T* gp = b.g(de.xp, p);
-        T* sv = b.s(de.spare, p);
-        T* yv = b.y(de.spare, p);
+        const T* xp = b.x(de.xp, p) + eoff;
+        const T* gp = b.g(de.xp, p) + eoff;
+        T* sv = b.s(de.spare, p) + eoff;
+        T* yv = b.y(de.spare, p) + eoff;
         A accp[4];
         constexpr int PU = LBFGSX_IT_PU;  // 4 PU 16-byte loads in flight per thread
         for (int64_t v0 = tid; v0 < nv; v0 += int64_t(kHvThreads) * PU)
@@ -219,14 +284,19 @@ __global__ void __launch_bounds__(kHvThreads) kb_iter(BatBufs<T> b, const BatItD
         it_block_sum<4>(accp, sh);
         if (tid == 0)
         {
+            if (G > 1 && !it_exchange<4>(accp, xc, p, r, xe))
+                s_bad = 1;
             const T gg = T(accp[0].value()), xx = T(accp[1].value());
             const T sy = T(accp[2].value()), yy = T(accp[3].value());
-            sc[de.spare] = sy;                 // ScLayout::ys(spare)
-            sc[(m + 1) + de.spare] = yy / sy;  // ScLayout::theta(spare)
-            bat_result(ws, p, 0, double(gg));
-            bat_result(ws, p, 1, double(xx));
-            bat_result(ws, p, 2, double(sy));
-            bat_result(ws, p, 3, double(yy));
+            if (r == 0)
+            {
+                sc[de.spare] = sy;                 // ScLayout::ys(spare)
+                sc[(m + 1) + de.spare] = yy / sy;  // ScLayout::theta(spare)
+                bat_result(ws, p, 0, double(gg));
+                bat_result(ws, p, 1, double(xx));
+                bat_result(ws, p, 2, double(sy));
+                bat_result(ws, p, 3, double(yy));
+            }
             const bool accept = sy > eps * yy;  // LBFGS.h:161
             int cn;
             if (accept)
@@ -251,9 +321,13 @@ __global__ void __launch_bounds__(kHvThreads) kb_iter(BatBufs<T> b, const BatItD
                 s_theta0 = cn > 0 ? sc[(m + 1) + de.pcol[0]] : T(1);
             }
             s_cn = cn;
-            if (post_only)
+            if (post_only && r == 0)
+            {
+                bat_result(ws, p, 7, s_bad ? 1.0 : 0.0);
                 bat_signal(ws);
+            }
         }
+        xe++;
         __syncthreads();
         if (post_only)
             return;
@@ -280,23 +354,23 @@ __global__ void __launch_bounds__(kHvThreads) kb_iter(BatBufs<T> b, const BatItD
         if (L == 0)
         {
             u = g;
-            w = cn > 0 ? b.s(s_pcol[0], p) : g;
+            w = cn > 0 ? b.s(s_pcol[0], p) + eoff : g;
         }
         else if (L < cn)
         {
-            u = b.y(s_pcol[L - 1], p);
-            w = b.s(s_pcol[L], p);
+            u = b.y(s_pcol[L - 1], p) + eoff;
+            w = b.s(s_pcol[L], p) + eoff;
         }
         else if (L == cn)
         {
-            u = b.y(s_pcol[cn - 1], p);
+            u = b.y(s_pcol[cn - 1], p) + eoff;
             w = u;
         }
         else
         {
             const int t = L - cn - 1, i = cn - 1 - t;
-            u = b.s(s_pcol[i], p);
-            w = (t < cn - 1) ? b.y(s_pcol[i - 1], p) : g;
+            u = b.s(s_pcol[i], p) + eoff;
+            w = (t < cn - 1) ? b.y(s_pcol[i - 1], p) + eoff : g;
         }
     };
     // (Loading the next step's first chunk ahead of this step's reduction -- hv_prefetch, as k_twoloop_persist does with 30
@@ -326,7 +400,8 @@ __global__ void __launch_bounds__(kHvThreads) kb_iter(BatBufs<T> b, const BatItD
         // recomputed inside the step instead of being hoisted out of the L loop and kept in ~4 registers per slot
         int tid_step = tid;
         asm volatile("" : "+v"(tid_step));
-        hv_step<T, NR, NL, A, false, LBFGSX_IT_CHUNK>(rq, lq, u, w, L == 0, T(-1), c, theta, nv, int64_t(tid_step), int64_t(kHvThreads), tid, acc4);
+        hv_step<T, NR, NL, A, false, LBFGSX_IT_CHUNK>(rq, lq, u, w, L == 0, T(-1), c, theta, nv, int64_t(tid_step),
+                                                       int64_t(kHvThreads), tid, acc4);
         A acc[1];
         acc[0] = acc4[0];
         for (int k = 1; k < 4; k++)
@@ -334,27 +409,34 @@ __global__ void __launch_bounds__(kHvThreads) kb_iter(BatBufs<T> b, const BatItD
         it_block_sum<1>(acc, sh);
         if (tid == 0)
         {
-            const T r = T(acc[0].value());
-            sdot[L] = r;
-            sc[DOT0 + L] = r;
+            if (G > 1 && !it_exchange<1>(acc, xc, p, r, xe + unsigned(L)))
+                s_bad = 1;
+            const T rr = T(acc[0].value());
+            sdot[L] = rr;
+            if (r == 0)
+                sc[DOT0 + L] = rr;
         }
         __syncthreads();
     }
+    xe += unsigned(2 * cn + 1);
 
     // ---- drt to memory; the first trial of the next search
     A accf, accd;
     const auto obj = objs.bind(p);
-    it_trial<T, NR, NL>(rq, lq, x, T(de.step), b.x(de.trial, p), b.g(de.trial, p), b.d(p), obj, trial, nv, tid, accf, accd);
+    it_trial<T, NR, NL>(rq, lq, b.x(de.cur, p), T(de.step), b.x(de.trial, p), b.g(de.trial, p), b.d(p), obj, trial, voff, nv, tid,
+                        accf, accd);
     if (trial)
     {
         A acc2[2];
         acc2[0] = accf;
         acc2[1] = accd;
         it_block_sum<2>(acc2, sh);
+        if (tid == 0 && G > 1 && !it_exchange<2>(acc2, xc, p, r, xe))
+            s_bad = 1;
         accf = acc2[0];
         accd = acc2[1];
     }
-    if (tid == 0)
+    if (tid == 0 && r == 0)
     {
         bat_result(ws, p, 4, double(sdot[2 * cn]));
         if (trial)
@@ -362,27 +444,44 @@ __global__ void __launch_bounds__(kHvThreads) kb_iter(BatBufs<T> b, const BatItD
             bat_result(ws, p, 5, double(obj.finish(T(accf.value()))));
             bat_result(ws, p, 6, double(T(accd.value())));
         }
+        bat_result(ws, p, 7, s_bad ? 1.0 : 0.0);
         bat_signal(ws);
     }
 }
 
 template <class T, class OBJS, int NQ>
-static void launch_iter(lbfgsx_batch* c, const BatItDesc* dd, const OBJS& objs, const BatWs& ws)
+static void launch_iter(lbfgsx_batch* c, const BatItDesc* dd, const OBJS& objs, const BatWs& ws, const ItXch& xc)
 {
-    BAT_LAUNCH(c, (kb_iter<T, OBJS, NQ>), dim3(c->P), dim3(kHvThreads), 0, c->stream, bufs<T>(c), dd, c->n, c->m, objs, ws,
-               std::numeric_limits<T>::epsilon());
+    BAT_LAUNCH(c, (kb_iter<T, OBJS, NQ>), dim3(unsigned(c->P) * unsigned(xc.G)), dim3(kHvThreads), 0, c->stream, bufs<T>(c), dd, c->n,
+               c->m, objs, ws, std::numeric_limits<T>::epsilon(), xc);
 }
 template <class T, class OBJS>
-static void launch_iter_slots(lbfgsx_batch* c, int slots, const BatItDesc* dd, const OBJS& objs, const BatWs& ws)
+static void launch_iter_slots(lbfgsx_batch* c, int slots, const BatItDesc* dd, const OBJS& objs, const BatWs& ws, const ItXch& xc)
 {
     if (slots <= 14)
-        launch_iter<T, OBJS, 14>(c, dd, objs, ws);
+        launch_iter<T, OBJS, 14>(c, dd, objs, ws, xc);
     else if (slots <= 28)
-        launch_iter<T, OBJS, 28>(c, dd, objs, ws);
+        launch_iter<T, OBJS, 28>(c, dd, objs, ws, xc);
     else if (slots <= 56)
-        launch_iter<T, OBJS, 56>(c, dd, objs, ws);
+        launch_iter<T, OBJS, 56>(c, dd, objs, ws, xc);
     else
-        launch_iter<T, OBJS, 98>(c, dd, objs, ws);
+        launch_iter<T, OBJS, 98>(c, dd, objs, ws, xc);
+}
+
+// parts per problem: the fewest consecutive blocks whose share of the vector fits a block's 98 slots; 0: too long
+static int iter_parts(const lbfgsx_batch* c)
+{
+    const int64_t w = (c->dtype == LBFGSX_F64) ? 2 : 4;
+    if (c->n % w != 0)
+        return 0;
+    const int64_t nv = c->n / w;
+    for (int g = 1; g <= kItMaxParts; g++)
+    {
+        const int64_t nvp = g > 1 ? ((nv + g - 1) / g + kHvThreads - 1) / kHvThreads * kHvThreads : nv;
+        if (nvp <= int64_t(kHvThreads) * 98)
+            return (c->max_parts > 0 && g > c->max_parts) ? 0 : g;
+    }
+    return 0;
 }
 
 }  // namespace lbfgsx
@@ -395,8 +494,7 @@ int lbfgsx_bat_iterate_ok(const lbfgsx_batch* c)
 {
     if (!c)
         return 0;
-    const int64_t w = (c->dtype == LBFGSX_F64) ? 2 : 4;
-    return (c->fused_iter && c->fused_hv && (c->n % w) == 0 && c->n / w <= int64_t(kHvThreads) * 98 && c->m <= 32) ? 1 : 0;
+    return (c->fused_iter && c->fused_hv && c->m <= 32 && iter_parts(c) > 0) ? 1 : 0;
 }
 
 int lbfgsx_bat_iterate(lbfgsx_batch* c, int objective, const lbfgsx_bat_itdesc* desc, double* out)
@@ -406,7 +504,7 @@ int lbfgsx_bat_iterate(lbfgsx_batch* c, int objective, const lbfgsx_bat_itdesc* 
     lbfgsx::DeviceGuard dev_guard_(c->device);
     if (!lbfgsx_bat_iterate_ok(c))
     {
-        set_error("lbfgsx_bat_iterate: vector does not fit one block's registers");
+        set_error("lbfgsx_bat_iterate: vector does not fit the registers of the blocks a problem may use");
         return LBFGSX_E_INVALID;
     }
     int nactive = 0;
@@ -434,27 +532,60 @@ int lbfgsx_bat_iterate(lbfgsx_batch* c, int objective, const lbfgsx_bat_itdesc* 
         set_error("lbfgsx_bat_iterate: the diagonal quadratic needs its data (lbfgsx_bat_gen_diag_quad)");
         return LBFGSX_E_LOGIC;
     }
+    ItXch xc;
+    xc.G = iter_parts(c);
+    xc.base = nullptr;
+    xc.err = nullptr;
+    xc.tag0 = 0;
+    if (xc.G > 1)
+    {
+        if (!c->xch)
+        {
+            const size_t bytes = size_t(c->P) * kItXchWords * 16 + 64;
+            LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&c->xch), bytes));
+            LBFGSX_HIP(hipMemsetAsync(c->xch, 0, bytes, c->stream));
+        }
+        xc.err = reinterpret_cast<int*>(c->xch);  // the first 64 bytes: the error word
+        xc.base = c->xch + 16;
+        c->xch_seq += 128;  // more than the 2 * 32 + 3 exchanges a launch can make
+        xc.tag0 = c->xch_seq;
+    }
     const void* dd = nullptr;
     LBFGSX_HIP(lbfgsx::bat_stage(c, desc, sizeof(BatItDesc) * size_t(c->P), &dd));
     const BatWs ws = lbfgsx::bat_arm(c, nactive);
     const int64_t w = (c->dtype == LBFGSX_F64) ? 2 : 4;
-    const int slots = int((c->n / w + kHvThreads - 1) / kHvThreads);
+    const int64_t nv = c->n / w;
+    const int64_t nvp = xc.G > 1 ? ((nv + xc.G - 1) / xc.G + kHvThreads - 1) / kHvThreads * kHvThreads : nv;
+    const int slots = int((nvp + kHvThreads - 1) / kHvThreads);
     BAT_DISPATCH(c, {
         if (any_trial && objective == LBFGSX_OBJ_DIAG_QUAD)
         {
             const BatQuad<T> quad = {static_cast<const T*>(c->QA), static_cast<const T*>(c->QB), c->ld};
-            launch_iter_slots<T, BatQuad<T> >(c, slots, static_cast<const BatItDesc*>(dd), quad, ws);
+            launch_iter_slots<T, BatQuad<T> >(c, slots, static_cast<const BatItDesc*>(dd), quad, ws, xc);
         }
         else
-            launch_iter_slots<T, BatRosen<T> >(c, slots, static_cast<const BatItDesc*>(dd), BatRosen<T>{}, ws);
+            launch_iter_slots<T, BatRosen<T> >(c, slots, static_cast<const BatItDesc*>(dd), BatRosen<T>{}, ws, xc);
     });
     LBFGSX_HIP(hipGetLastError());
     LBFGSX_HIP(lbfgsx::bat_wait(c));
     const volatile double* tab = c->res_host;
+    bool bad = false;
     for (int p = 0; p < c->P; p++)
         if (desc[p].active)
+        {
             for (int k = 0; k < kBatRes; k++)
                 out[size_t(p) * kBatRes + k] = tab[size_t(p) * kBatRes + k];
+            bad = bad || tab[size_t(p) * kBatRes + 7] != 0.0;
+        }
+    if (bad)
+    {
+        // a part waited 100 ms for a sibling that never showed up (CUs held by something else for that long): the sums of
+        // this launch are not sums.  Clear the error word; the caller gets an error, never wrong numbers.
+        LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
+        LBFGSX_HIP(hipMemsetAsync(c->xch, 0, 64, c->stream));
+        set_error("lbfgsx_bat_iterate: the blocks of a problem split over several CUs were not resident together (exchange timed out)");
+        return LBFGSX_E_RUNTIME;
+    }
     return LBFGSX_OK;
 }
 }

@@ -104,7 +104,11 @@ def test_one_launch_two_loop_equals_step_wise_launches(monkeypatch, dtype, n):
 
 
 @pytest.mark.parametrize("dtype,n,m,eps", [(np.float32, 100000, 10, 0.0), (np.float64, 50176, 6, 0.0), (np.float32, 4096, 3, 0.0),
-                                            (np.float64, 2048, 5, 1e-3), (np.float32, 100352, 31, 0.0)])
+                                            (np.float64, 2048, 5, 1e-3), (np.float32, 100352, 31, 0.0),
+                                            # problems longer than one CU's registers: 2, 3 and 8 blocks per problem with the
+                                            # sums exchanged between them at every step
+                                            (np.float32, 200000, 10, 0.0), (np.float64, 150016, 6, 0.0),
+                                            (np.float32, 800000, 4, 0.0), (np.float64, 60000, 5, 1e-3)])
 def test_one_launch_iteration_equals_statement_wise_launches(monkeypatch, dtype, n, m, eps):
     """lbfgsx_bat_iterate (post statements + recursion + first trial of the next search in ONE launch per lock-step iteration,
     the direction resident on the CU) against the three statement-wise forms it replaces: identical records and iterates.
