@@ -63,6 +63,12 @@ def test_default_line_has_the_contract_keys(tmp_path):
     b = d["cfg5_batched"]   # the batched mode of BASELINE.json's cfg5 rides in the same line
     assert b["unit"] == "problem-iterations/s" and b["n_gpus"] == 1 and b["value"] > 1e4 and b["config"]["failed"] == 0
     assert 0.1 < b["roofline"]["frac"] < 1.0
+    # the leg times the solve alone (resident batch, setup outside the window) and shows the kernels' share of a step
+    bc = b["config"]
+    assert bc["one_launch_per_iteration"] is True and bc["setup_seconds"] > 0 and bc["wait_timeouts"] == 0
+    assert 0.5 * bc["wall_ms_per_step"] < bc["kernel_ms_per_step"] <= 1.10 * bc["wall_ms_per_step"]
+    assert line["cfg5_batched"]["kernel_ms_per_step"] == pytest.approx(bc["kernel_ms_per_step"], rel=1e-5)
+    assert line["legs_digest"]["cfg5_batched"]["kernel_ms_per_step"] > 0
     c = d["cpu_baseline"]
     assert c["unit"] == "iterations/s" and c["cores"] == 1 and c["kind"] in ("reference", "port") and c["value"] > 0 and c["sample"]
     assert c["extrapolated"] is True and c["measured_n"] == 2000000
@@ -199,6 +205,8 @@ def test_gpus_2_starts_two_ranks_or_refuses():
     assert [p["rank"] for p in d["per_rank"]] == [0, 1] and all(p["value"] > 0 and p["stream_copy_GBs"] > 0 for p in d["per_rank"])
     assert d["collective"]["world_size"] == 2 and d["collective"]["backend"] in ("nccl", "gloo")
     assert d["collective"]["data_path_collectives"] == 0
+    # the rank count is the collective library's own (a sum of ones over the timing communicator), not the launcher's claim
+    assert d["collective"]["ranks_counted_by_allreduce"] == 2 and len(d["collective"]["devices"]) == 2
     pr = d["cfg5_batched"]["config"]["per_rank"]
     assert [(p["first_problem"], p["problems"]) for p in pr] == [(0, 256), (256, 256)]
     if ndev < 2:
