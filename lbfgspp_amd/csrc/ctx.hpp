@@ -77,6 +77,17 @@ inline hipError_t copy_async(void* dst, const void* src, size_t bytes, hipMemcpy
         host_trace(kind == hipMemcpyDeviceToHost ? "copy_d2h" : kind == hipMemcpyHostToDevice ? "copy_h2d" : "copy");
     return hipMemcpyAsync(dst, src, bytes, kind, s);
 }
+// the same with the call site in the host trace ("copy@<line>"): a translation unit that wants its copies told apart defines
+//   #define copy_async(...) copy_async_at("copy@" LBFGSX_STR(__LINE__), __VA_ARGS__)
+inline hipError_t copy_async_at(const char* where, void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s)
+{
+    counters().copies.fetch_add(1, std::memory_order_relaxed);
+    if (host_trace_on())
+        host_trace(where);
+    return hipMemcpyAsync(dst, src, bytes, kind, s);
+}
+#define LBFGSX_STR_(x) #x
+#define LBFGSX_STR(x) LBFGSX_STR_(x)
 #define LBFGSX_FIRST_STR_(first, ...) #first
 #define LBFGSX_FIRST_STR(...) LBFGSX_FIRST_STR_(__VA_ARGS__, 0)
 #define LBFGSX_LAUNCH(...)                                                        \

@@ -204,6 +204,13 @@ struct lbfgsb_state
     double *s_brk = nullptr, *s_g = nullptr, *s_z = nullptr, *s_W = nullptr, *s_P = nullptr, *s_C = nullptr,
            *s_fpp = nullptr, *s_dfp = nullptr, *s_fp = nullptr, *s_ts = nullptr, *s_off = nullptr, *s_small = nullptr;
     unsigned long long* s_exit = nullptr;
+    // host-order chain (chain_host): the exit index goes to k_gcp_extract and its 2 NC + 4 results come back through
+    // host-mapped memory instead of a copy each way (three copies fewer per scan call)
+    unsigned long long* exit_map_host = nullptr;
+    unsigned long long* exit_map_dev = nullptr;
+    double* gout_host = nullptr;
+    double* gout_dev = nullptr;
+    double* s_chain = nullptr;  // s_fp | s_dfp | s_fpp in ONE allocation, pitch s_cap + 1: a piece of the three travels as one 2-D copy
     double* h_chain = nullptr;   // pinned: [3][s_cap + 1] per-crossing terms of the f' / f'' chains (exact-order mode)
     bool chain_host = true;      // LBFGSX_GCP_CHAIN=scan: tree-order f' / f'' on the device instead
     int64_t s_cap = 0;
@@ -233,6 +240,9 @@ struct lbfgsb_state
                                       // otherwise has 10^5 waves meeting at one counter for a list nobody reads
     static constexpr int kDout = 640; // doubles of `dout`
 };
+
+// copies of this file carry their line in the host trace (LBFGSX_HOST_TRACE; scripts/host_trace.py)
+#define copy_async(...) copy_async_at("copy@" LBFGSX_STR(__LINE__), __VA_ARGS__)
 
 namespace lbfgsx {
 
@@ -600,10 +610,14 @@ void bounded_free(lbfgsx_ctx* c)
     void* ptrs[] = {b->brk, b->dvec, b->cF, b->y, b->yfb, b->lam, b->mu, b->rhs, b->keys_in, b->keys_out, b->st,
                     b->vals_in, b->vals_out, b->phys_dev, b->dout, b->coef_dev, b->sort_tmp, b->g_brk,
                     b->g_g, b->g_z, b->g_w, b->g_idx, b->gram_partial, b->gram_partial2, b->gram_out, b->gram_dd,
-                    b->s_brk, b->s_g, b->s_z, b->s_W, b->s_P, b->s_C, b->s_fpp, b->s_dfp, b->s_fp, b->s_ts, b->s_off,
+                    b->s_brk, b->s_g, b->s_z, b->s_W, b->s_P, b->s_C, b->s_chain, b->s_ts, b->s_off,
                     b->s_small, b->s_exit, b->pk, b->pv, b->pcount, b->sel_tmp};
     if (b->h_chain)
         (void) hipHostFree(b->h_chain);
+    if (b->exit_map_host)
+        (void) hipHostFree(b->exit_map_host);
+    if (b->gout_host)
+        (void) hipHostFree(b->gout_host);
     if (b->g_host)
         (void) hipHostFree(b->g_host);
     if (b->fd_host)
@@ -2122,8 +2136,7 @@ template <int NC>
 static void gcp_extract_nc(lbfgsx_ctx* c, const GcpBufs& gb, int64_t count, double theta)
 {
     lbfgsb_state* b = c->bstate;
-    double* out = b->s_small + (NC * NC + NC + (NC + 1) + 1 + (NC + 1));
-    LBFGSX_LAUNCH((k_gcp_extract<NC>), dim3(1), dim3(64), 0, c->stream, gb, count, c->ncorr, theta, b->s_exit, out);
+    LBFGSX_LAUNCH((k_gcp_extract<NC>), dim3(1), dim3(64), 0, c->stream, gb, count, c->ncorr, theta, b->exit_map_dev, b->gout_dev);
 }
 
 // The f' / f'' recurrences of the break-point search in the reference's own order (Cauchy.h:218,227-228,240-256) over
@@ -2168,7 +2181,7 @@ static int scan_alloc(lbfgsx_ctx* c, int64_t count, int NC)
     lbfgsb_state* b = c->bstate;
     if (count > b->s_cap || NC > b->s_nc)
     {
-        void* old[] = {b->s_brk, b->s_g, b->s_z, b->s_W, b->s_P, b->s_C, b->s_fpp, b->s_dfp, b->s_fp, b->s_ts, b->s_off};
+        void* old[] = {b->s_brk, b->s_g, b->s_z, b->s_W, b->s_P, b->s_C, b->s_chain, b->s_ts, b->s_off};
         for (void* p : old)
             (void) hipFree(p);
         // sized once for the largest chunk the search asks for (2^20 crossings, or all n coordinates) and the full
@@ -2184,9 +2197,12 @@ static int scan_alloc(lbfgsx_ctx* c, int64_t count, int NC)
         LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_W), sizeof(double) * size_t(cap) * size_t(ncap)));
         LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_P), sizeof(double) * size_t(cap) * size_t(ncap)));
         LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_C), sizeof(double) * size_t(cap) * size_t(ncap)));
-        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_fpp), sizeof(double) * size_t(cap)));
-        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_dfp), sizeof(double) * size_t(cap)));
-        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_fp), sizeof(double) * size_t(cap + 1)));
+        // the three per-crossing arrays the host-order chain reads, laid out as the host's landing buffer is (h_chain:
+        // dt | A | B with pitch cap + 1), so that a piece of all three is ONE 2-D copy instead of three copies
+        LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_chain), sizeof(double) * 3 * size_t(cap + 1)));
+        b->s_fp = b->s_chain;
+        b->s_dfp = b->s_chain + (cap + 1);
+        b->s_fpp = b->s_chain + 2 * (cap + 1);
         if (b->h_chain)
             (void) hipHostFree(b->h_chain);
         b->h_chain = nullptr;
@@ -2197,6 +2213,10 @@ static int scan_alloc(lbfgsx_ctx* c, int64_t count, int NC)
         {
             LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_small), sizeof(double) * (80 * 80 + 6 * 88)));
             LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_exit), sizeof(unsigned long long)));
+            LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->exit_map_host), 64, hipHostMallocMapped | hipHostMallocCoherent));
+            LBFGSX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->exit_map_dev), b->exit_map_host, 0));
+            LBFGSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->gout_host), sizeof(double) * (2 * 80 + 8), hipHostMallocMapped | hipHostMallocCoherent));
+            LBFGSX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->gout_dev), b->gout_host, 0));
         }
         b->s_cap = cap;
         b->s_nc = ncap;
@@ -2246,7 +2266,8 @@ int lbfgsx_b_cauchy_scan(lbfgsx_ctx* c, int64_t first, int64_t count, int64_t no
     initC[0] = state_in[2 * nc2];       // f'
     const size_t nsmall = size_t(NC * NC + NC + NC + 1 + 1);
     LBFGSX_HIP(lbfgsx::copy_async(b->s_small, h, sizeof(double) * nsmall, hipMemcpyHostToDevice, c->stream));
-    LBFGSX_HIP(hipMemsetAsync(b->s_exit, 0xFF, sizeof(unsigned long long), c->stream));
+    if (!b->chain_host)
+        LBFGSX_HIP(hipMemsetAsync(b->s_exit, 0xFF, sizeof(unsigned long long), c->stream));
     const int grid = int(std::min<int64_t>((count + 256) / 256, 2048));
     // f32 problems: the sorted list is gathered into doubles and the search runs in double (the reference would run it in
     // float; the north_star tolerance for f32 is 1e-4, the difference is at the 1e-7 level)
@@ -2289,9 +2310,16 @@ int lbfgsx_b_cauchy_scan(lbfgsx_ctx* c, int64_t first, int64_t count, int64_t no
         {
             const int64_t lo = count * q / nsub, hi = count * (q + 1) / nsub;
             const int64_t dlo = q ? lo + 1 : lo;  // dt[k + 1] closes crossing k: the piece ends with dt[hi]
-            LBFGSX_HIP(lbfgsx::copy_async(hdt + dlo, b->s_fp + dlo, sizeof(double) * size_t(hi + 1 - dlo), hipMemcpyDeviceToHost, c->stream));
-            LBFGSX_HIP(lbfgsx::copy_async(hA + lo, b->s_dfp + lo, sizeof(double) * size_t(hi - lo), hipMemcpyDeviceToHost, c->stream));
-            LBFGSX_HIP(lbfgsx::copy_async(hB + lo, b->s_fpp + lo, sizeof(double) * size_t(hi - lo), hipMemcpyDeviceToHost, c->stream));
+            // rows dt | A | B of positions [dlo, hi]: one 2-D copy (A and B carry one position more than the walk reads)
+            lbfgsx::counters().copies.fetch_add(1, std::memory_order_relaxed);
+            if (lbfgsx::host_trace_on())
+                lbfgsx::host_trace("copy2d_chain");
+            LBFGSX_HIP(hipMemcpy2DAsync(hdt + dlo, sizeof(double) * size_t(b->s_cap + 1), b->s_chain + dlo,
+                                        sizeof(double) * size_t(b->s_cap + 1), sizeof(double) * size_t(hi + 1 - dlo), 3,
+                                        hipMemcpyDeviceToHost, c->stream));
+            (void) hA;
+            (void) hB;
+            (void) lo;
             if (nsub > 1)
                 LBFGSX_HIP(hipEventRecord(b->chain_ev[q], c->stream));
         }
@@ -2306,8 +2334,10 @@ int lbfgsx_b_cauchy_scan(lbfgsx_ctx* c, int64_t first, int64_t count, int64_t no
             e = (c->dtype == LBFGSX_F32) ? gcp_chain_host<float>(hdt, hA, hB, lo, hi, fp_h, fpp_h)
                                          : gcp_chain_host<double>(hdt, hA, hB, lo, hi, fp_h, fpp_h);
         }
-        const unsigned long long ex = (e >= 0) ? (unsigned long long) e : ~0ull;
-        LBFGSX_HIP(lbfgsx::copy_async(b->s_exit, &ex, sizeof(ex), hipMemcpyHostToDevice, c->stream));
+        // every copy of this chunk has landed (the walk waited for the pieces it read; the others belong to the same stream
+        // and are drained by the wait below): the exit index travels through the mapped word
+        *b->exit_map_host = (e >= 0) ? (unsigned long long) e : ~0ull;
+        std::atomic_thread_fence(std::memory_order_release);
         switch (NC)
         {
         case 4: gcp_extract_nc<4>(c, gb, count, theta); break;
@@ -2326,9 +2356,18 @@ int lbfgsx_b_cauchy_scan(lbfgsx_ctx* c, int64_t first, int64_t count, int64_t no
         LBFGSX_HIP(hipGetLastError());
     }
     double o[2 * 80 + 4];
-    const double* dout = b->s_small + (NC * NC + NC + (NC + 1) + 1 + (NC + 1));
-    LBFGSX_HIP(lbfgsx::copy_async(o, dout, sizeof(double) * size_t(2 * NC + 4), hipMemcpyDeviceToHost, c->stream));
-    LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
+    if (b->chain_host)
+    {
+        LBFGSX_HIP(lbfgsx::stream_sync(c->stream));  // k_gcp_extract's stores into the mapped block are out when the stream has drained
+        for (int j = 0; j < 2 * NC + 4; j++)
+            o[j] = static_cast<const volatile double*>(b->gout_host)[j];
+    }
+    else
+    {
+        const double* dout = b->s_small + (NC * NC + NC + (NC + 1) + 1 + (NC + 1));
+        LBFGSX_HIP(lbfgsx::copy_async(o, dout, sizeof(double) * size_t(2 * NC + 4), hipMemcpyDeviceToHost, c->stream));
+        LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
+    }
     for (int j = 0; j < nc2; j++)
     {
         state_out[j] = o[j];
