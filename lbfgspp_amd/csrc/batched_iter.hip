@@ -207,6 +207,8 @@ __global__ void __launch_bounds__(kHvThreads) kb_iter(BatBufs<T> b, const BatItD
     __syncthreads();
     if (!de.active)
         return;
+    // (The blocks of a round run in lock step -- identical work -- so their reduction bubbles coincide; delaying every other
+    // block by 8 / 16 / 24 us at its start changed nothing, interleaved A/B: the launch is not limited by coinciding bubbles.)
     typedef typename AccOf<T>::type A;
     constexpr int W = Vec16<T>::W;
     constexpr int NR = NQ > kHvRegSlots ? kHvRegSlots : NQ;

@@ -86,12 +86,15 @@ def cfg4(prefix, n, m, iters, warm_iters=12):
 def cfg5(prefix, n, m, problems, iters):
     d = hbm_by_dispatch(prefix, "bench")
     tot = sum(v for k, v in d if k.startswith("kb_"))
-    full = [v for k, v in d if k.startswith("kb_twoloop_full")]
-    return {"leg": "cfg5", "n": n, "m": m, "hbm_bytes": tot / float(problems * iters),
-            "per": "problem-iteration, mean over the %d lock-step iterations from x0 of %d problems (history filling during the first %d); "
-                   "all kb_* launches counted" % (iters, problems, m),
+    # round 6: the leg's command minimises the same batch several times (warm-ups, the timed solve, the instrumented one);
+    # every minimisation evaluates the start points once (kb_eval)
+    solves = max(1, sum(1 for k, _ in d if k.startswith("kb_eval")))
+    full = [v for k, v in d if k.startswith("kb_iter") or k.startswith("kb_twoloop_full")]
+    return {"leg": "cfg5", "n": n, "m": m, "hbm_bytes": tot / float(problems * iters * solves),
+            "per": "problem-iteration, mean over the %d lock-step iterations from x0 of %d problems (history filling during the first %d), "
+                   "%d identical minimisations in the profiled command; all kb_* launches counted" % (iters, problems, m, solves),
             "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of bench.py --workload cfg5-batched --steps %d --no-cpu, taken separately" % iters,
-            "twoloop_full_history_hbm_bytes_per_problem": (max(full) / problems) if full else None}
+            "one_launch_iteration_full_history_hbm_bytes_per_problem": (max(full) / problems) if full else None}
 
 
 def twoloop(prefix, n, m, tag, command):
