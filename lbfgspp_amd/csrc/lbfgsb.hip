@@ -210,7 +210,7 @@ struct lbfgsb_state
     unsigned long long* exit_map_dev = nullptr;
     double* gout_host = nullptr;
     double* gout_dev = nullptr;
-    double* s_chain = nullptr;  // s_fp | s_dfp | s_fpp in ONE allocation, pitch s_cap + 1: a piece of the three travels as one 2-D copy
+    double* s_chain = nullptr;  // s_fp | s_dfp | s_fpp in ONE allocation, laid out per call with pitch count + 1
     double* h_chain = nullptr;   // pinned: [3][s_cap + 1] per-crossing terms of the f' / f'' chains (exact-order mode)
     bool chain_host = true;      // LBFGSX_GCP_CHAIN=scan: tree-order f' / f'' on the device instead
     int64_t s_cap = 0;
@@ -2197,8 +2197,8 @@ static int scan_alloc(lbfgsx_ctx* c, int64_t count, int NC)
         LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_W), sizeof(double) * size_t(cap) * size_t(ncap)));
         LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_P), sizeof(double) * size_t(cap) * size_t(ncap)));
         LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_C), sizeof(double) * size_t(cap) * size_t(ncap)));
-        // the three per-crossing arrays the host-order chain reads, laid out as the host's landing buffer is (h_chain:
-        // dt | A | B with pitch cap + 1), so that a piece of all three is ONE 2-D copy instead of three copies
+        // the three per-crossing arrays the host-order chain reads share one allocation: every call lays them out back to
+        // back for its own count (lbfgsx_b_cauchy_scan), so that a chunk that travels whole is one copy instead of three
         LBFGSX_HIP(hipMalloc(reinterpret_cast<void**>(&b->s_chain), sizeof(double) * 3 * size_t(cap + 1)));
         b->s_fp = b->s_chain;
         b->s_dfp = b->s_chain + (cap + 1);
@@ -2276,6 +2276,11 @@ int lbfgsx_b_cauchy_scan(lbfgsx_ctx* c, int64_t first, int64_t count, int64_t no
                            first, count, nord, P<T>(c->S), P<T>(c->Y), c->ld, b->phys_dev, nc, b->s_brk, b->s_g, b->s_z, b->s_W,
                            b->s_cap);
     });
+    // the three per-crossing arrays of this call, back to back in s_chain (pitch count + 1, not the capacity): a chunk that
+    // travels whole is ONE linear copy (hipMemcpy2DAsync over a capacity pitch was tried: it stalls for 20 ms now and then)
+    b->s_fp = b->s_chain;
+    b->s_dfp = b->s_chain + (count + 1);
+    b->s_fpp = b->s_chain + 2 * (count + 1);
     GcpBufs gb = {b->s_brk, b->s_g, b->s_z, b->s_W, b->s_P, b->s_C, b->s_fpp, b->s_dfp, b->s_fp, b->s_cap};
     switch (NC)
     {
@@ -2297,9 +2302,9 @@ int lbfgsx_b_cauchy_scan(lbfgsx_ctx* c, int64_t first, int64_t count, int64_t no
     double fp_h = state_in[2 * nc2], fpp_h = state_in[2 * nc2 + 1];
     if (b->chain_host)
     {
-        double* hdt = b->h_chain;
-        double* hA = hdt + (b->s_cap + 1);
-        double* hB = hA + (b->s_cap + 1);
+        double* hdt = b->h_chain;  // the host's copy has the layout of this call's device arrays
+        double* hA = hdt + (count + 1);
+        double* hB = hA + (count + 1);
         // 24 bytes per crossing over PCIe and ~1.4 ns of host arithmetic per crossing are about the same time: the chunk
         // travels in pieces and the host walks a piece while the next ones are still on the way
         const int nsub = (count >= (int64_t(1) << 17) && b->chain_pieces > 1) ? b->chain_pieces : 1;
@@ -2310,16 +2315,14 @@ int lbfgsx_b_cauchy_scan(lbfgsx_ctx* c, int64_t first, int64_t count, int64_t no
         {
             const int64_t lo = count * q / nsub, hi = count * (q + 1) / nsub;
             const int64_t dlo = q ? lo + 1 : lo;  // dt[k + 1] closes crossing k: the piece ends with dt[hi]
-            // rows dt | A | B of positions [dlo, hi]: one 2-D copy (A and B carry one position more than the walk reads)
-            lbfgsx::counters().copies.fetch_add(1, std::memory_order_relaxed);
-            if (lbfgsx::host_trace_on())
-                lbfgsx::host_trace("copy2d_chain");
-            LBFGSX_HIP(hipMemcpy2DAsync(hdt + dlo, sizeof(double) * size_t(b->s_cap + 1), b->s_chain + dlo,
-                                        sizeof(double) * size_t(b->s_cap + 1), sizeof(double) * size_t(hi + 1 - dlo), 3,
-                                        hipMemcpyDeviceToHost, c->stream));
-            (void) hA;
-            (void) hB;
-            (void) lo;
+            if (nsub == 1)  // dt (count + 1) | A | B: contiguous, one copy
+                LBFGSX_HIP(lbfgsx::copy_async(hdt, b->s_chain, sizeof(double) * 3 * size_t(count + 1), hipMemcpyDeviceToHost, c->stream));
+            else
+            {
+                LBFGSX_HIP(lbfgsx::copy_async(hdt + dlo, b->s_fp + dlo, sizeof(double) * size_t(hi + 1 - dlo), hipMemcpyDeviceToHost, c->stream));
+                LBFGSX_HIP(lbfgsx::copy_async(hA + lo, b->s_dfp + lo, sizeof(double) * size_t(hi - lo), hipMemcpyDeviceToHost, c->stream));
+                LBFGSX_HIP(lbfgsx::copy_async(hB + lo, b->s_fpp + lo, sizeof(double) * size_t(hi - lo), hipMemcpyDeviceToHost, c->stream));
+            }
             if (nsub > 1)
                 LBFGSX_HIP(hipEventRecord(b->chain_ev[q], c->stream));
         }
