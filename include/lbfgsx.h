@@ -411,8 +411,12 @@ int lbfgsx_b_reserve(lbfgsx_ctx* c);
  *               rows of the old L and U follow in lbfgsx_b_lu_sweep, which needs the multipliers' coefficients the caller
  *               derives from wty; the totals are the sums of the two calls.  Needs the index list of L u U that the
  *               previous sweep kept (small sets).
- * LBFGSX_E_INVALID when the fused form does not apply here (2c > 32, no list, LBFGSX_SWEEP_SOLVE_FUSE=0): nothing has
- * been changed, run the separate calls. */
+ * vsel: the selector of the ONE vector v solved for (LBFGSX_VS_NEG_CF, LBFGSX_VS_NEG_RHS, ...); LBFGSX_VS_LBOUND / _UBOUND
+ * (the bound vectors of lbfgsx_b_wtv_lu) are refused.
+ * LBFGSX_E_INVALID when the fused form does not apply here (2c > 80, no list, LBFGSX_SWEEP_SOLVE_FUSE=0, a bound selector):
+ * nothing has been changed, run the separate calls.
+ * After LBFGSX_SO_ASSIGN_Y has run on live compact vectors the partition bits (LBFGSX_ST_P / _L / _U) of the state byte
+ * are not written back (only the free / active bits are read afterwards): lbfgsx_b_download_state returns them undefined. */
 int lbfgsx_b_solve_sweep(lbfgsx_ctx* c, int first, int vsel, const double* coef, double theta, double* wty, int64_t sums[7]);
 /* the same with the two rhs updates that precede a sweep's solve (SubspaceMin.h:236-241; the LBFGSX_GP_RHS prologue of
  * lbfgsx_b_wtv_prologue with these coefficients) evaluated by the solve's own pass on the W rows it holds: first = 0 and
@@ -492,6 +496,15 @@ typedef struct
     double step;  /* TRIAL: the step */
     int pcol[32]; /* physical columns of the stored pairs, newest -> oldest */
 } lbfgsx_bat_itdesc;
+/* history lengths: the reference puts no upper bound on m (Param.h:350-376); here
+ *   LBFGSX_MAX_M_BOUNDED  an L-BFGS-B context passes the 2c coefficients of a W product in kernel arguments (80 slots) and keeps
+ *                         the host's 2c-vectors in arrays of that size: lbfgsx_create(LBFGSX_FLAG_BOUNDED) refuses m > 40
+ *                         (tests/test_lbfgsb_gpu.py: trajectories at m = 40, the refusal at 41);
+ *   LBFGSX_MAX_M_BATCH    the lock-step batch's descriptors carry 32 column ids: lbfgsx_bat_create refuses m > 31;
+ * unconstrained L-BFGS contexts take any m (the persistent one-launch recursion describes up to 128 pairs, beyond that the
+ * step launches run). */
+#define LBFGSX_MAX_M_BOUNDED 40
+#define LBFGSX_MAX_M_BATCH 31
 int lbfgsx_bat_create(lbfgsx_batch** out, int dtype, int64_t n, int m, int nproblems, int device);
 void lbfgsx_bat_destroy(lbfgsx_batch* c);
 /* a created batch made ready for another set of problems of the same shape (scalars and counters cleared, nothing

@@ -517,7 +517,7 @@ static int bat_alloc(lbfgsx_batch* c);
 
 int lbfgsx_bat_create(lbfgsx_batch** out, int dtype, int64_t n, int m, int nproblems, int device)
 {
-    if (!out || n <= 0 || m <= 0 || m > 31 || nproblems <= 0 || (dtype != LBFGSX_F64 && dtype != LBFGSX_F32))
+    if (!out || n <= 0 || m <= 0 || m > LBFGSX_MAX_M_BATCH || nproblems <= 0 || (dtype != LBFGSX_F64 && dtype != LBFGSX_F32))
     {
         set_error("lbfgsx_bat_create: invalid argument");
         return LBFGSX_E_INVALID;

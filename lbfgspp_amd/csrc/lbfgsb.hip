@@ -1933,6 +1933,13 @@ int lbfgsx_b_cauchy_build_partial(lbfgsx_ctx* c, double tau, int64_t* nfree, int
             }
             else
             {
+                // keys_in / vals_in may have been left out by a lazy-key build (today only when tau_ok, i.e. not on this
+                // branch): a no-op when they are valid, the rebuild otherwise -- never a sort of stale keys
+                {
+                    const int rk = ensure_keys(c);
+                    if (rk)
+                        return rk;
+                }
                 size_t bytes = b->sort_tmp_bytes;
                 lbfgsx::model_add(96.0 * double(c->n));  // byte model: SURVEY 8(d)'s radix-sort figure per (key, index) pair
                 LBFGSX_HIP(rocprim::radix_sort_pairs(b->sort_tmp, bytes, P<T>(b->keys_in), P<T>(b->keys_out), b->vals_in,
@@ -4172,6 +4179,13 @@ int lbfgsx_b_solve_sweep_rhs(lbfgsx_ctx* c, int first, int vsel_id, const double
     if (total < 1 || total > (b->split ? kColsX : 32) || b->multidot_chunked || !b->sweep_fuse)
     {
         set_error("lbfgsx_b_solve_sweep: not available here (needs 1 <= 2*ncorr <= 80); run the separate passes");
+        return LBFGSX_E_INVALID;
+    }
+    // selectors, before anything changes state (the compact vectors, the armed completion word): v of a fused solve is ONE
+    // vector -- the bound selectors of lbfgsx_b_wtv_lu are not solved for (include/lbfgsx.h)
+    if (b->split && (vsel_id == VS_LBOUND || vsel_id == VS_UBOUND))
+    {
+        set_error("lbfgsx_b_solve_sweep: LBFGSX_VS_LBOUND / LBFGSX_VS_UBOUND are not right-hand sides of a fused solve");
         return LBFGSX_E_INVALID;
     }
     unsigned cap;

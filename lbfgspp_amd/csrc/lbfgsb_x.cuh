@@ -33,6 +33,7 @@
 namespace lbfgsx {
 
 constexpr int kColsX = 80;  // 2c <= 80: every m an L-BFGS-B context accepts
+static_assert(kColsX == 2 * LBFGSX_MAX_M_BOUNDED, "include/lbfgsx.h documents the cap");
 constexpr int kGramSelfFinish = 16;  // blocks up to which a kx_gram launch adds its partials itself (no kx_gram_finish)
 
 template <class T>

@@ -405,7 +405,7 @@ static int create_fill(lbfgsx_ctx* c, int dtype, int64_t n, int m, int device, i
         return rc;
     if (flags & LBFGSX_FLAG_BOUNDED)
     {
-        if (m > 40)
+        if (m > LBFGSX_MAX_M_BOUNDED)
         {
             // the masked operators pass the 2c coefficients of a W product in the kernel arguments (80 slots) and the
             // host side keeps 2c-vectors in fixed arrays of that size

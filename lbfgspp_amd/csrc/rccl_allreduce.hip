@@ -87,7 +87,11 @@ struct Rank
     // The RCCL call itself runs OUTSIDE the lock (a rank's first collective may block inside ncclAllReduce until its peers
     // connect, and the abort that would release it must not queue behind it): `in_call` says a reducer holds the handle; an
     // abort waits for it briefly -- an enqueue returns in microseconds -- and then aborts regardless, which is what releases
-    // a reducer that is stuck in the call.
+    // a reducer that is stuck in the call.  That last step RELIES on ncclCommAbort being callable while another thread is
+    // inside a collective on the same communicator: it is the documented purpose of the call (NCCL >= 2.4 / every RCCL that
+    // ships it, 2.26 here: "frees resources ... will abort any uncompleted operations"), the in-flight call returns an error
+    // and the reducer's later stream wait ends because the abort releases the kernel.  The abort does NOT destroy the handle
+    // a second time: destroy_rank sees comm == nullptr.
     std::mutex mu;
     std::condition_variable cv;
     bool in_call = false;
@@ -353,12 +357,22 @@ int lbfgsx_comm_allreduce_sum(lbfgsx_comm* c, int local_rank, double* buf, int c
                 lbfgsx::set_error("lbfgsx_comm_allreduce_sum: the communicator was aborted by another rank");
                 return LBFGSX_E_RUNTIME;
             }
-            const ncclResult_t r = R.AllReduce(k.dev, k.dev, size_t(count), kNcclFloat64, kNcclSum, cm, k.stream);
+            ncclResult_t r;
             {
-                std::lock_guard<std::mutex> lock(k.mu);
-                k.in_call = false;
+                struct InCall  // cleared on every way out of the call, early returns and exceptions included
+                {
+                    Rank& k;
+                    ~InCall()
+                    {
+                        {
+                            std::lock_guard<std::mutex> lock(k.mu);
+                            k.in_call = false;
+                        }
+                        k.cv.notify_all();
+                    }
+                } in_call_guard{k};
+                r = R.AllReduce(k.dev, k.dev, size_t(count), kNcclFloat64, kNcclSum, cm, k.stream);
             }
-            k.cv.notify_all();
             if (r != 0)
             {
                 lbfgsx::set_error(std::string("ncclAllReduce: ") + (R.GetErrorString ? R.GetErrorString(r) : "RCCL error"));

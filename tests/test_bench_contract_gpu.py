@@ -60,6 +60,12 @@ def test_default_line_has_the_contract_keys(tmp_path):
     assert d["config"]["apply_Hv_persistent_launches"] > 0
     # the timed window holds full-history products only: 3 iterations x (2m+1) steps
     assert d["config"]["history_full"] is True and r["launches_timed"] == 3 * 21
+    # the cfg4 legs' `frac` is the library's own byte model over time; the PMC-measured traffic of the same leg rides beside
+    # it (`traffic_frac`) and the two must agree: a kernel change that moves bytes shows up as a model / traffic mismatch
+    for leg in ("cfg4_lbfgsb", "cfg4_m20"):
+        rr = d[leg]["roofline"]
+        if rr.get("model_over_traffic") is not None and d[leg]["steps"] >= 40:
+            assert 0.9 < rr["model_over_traffic"] < 1.1, (leg, rr["model_over_traffic"])
     b = d["cfg5_batched"]   # the batched mode of BASELINE.json's cfg5 rides in the same line
     assert b["unit"] == "problem-iterations/s" and b["n_gpus"] == 1 and b["value"] > 1e4 and b["config"]["failed"] == 0
     assert 0.1 < b["roofline"]["frac"] < 1.0
