@@ -6,6 +6,7 @@
 
 #include <stdexcept>
 
+#include "HostEval.h"
 #include "Param.h"
 
 namespace LBFGSpp {
@@ -61,6 +62,14 @@ public:
             step *= factor;
         }
         throw std::runtime_error("the line search routine reached the maximum number of iterations");
+    }
+    // the reference's own signature (HostEval.h): host vectors, the same decisions
+    template <typename Foo, typename SolverParam, typename Vector>
+    static void LineSearch(Foo& f, const SolverParam& param, const Vector& xp, const Vector& drt, const Scalar& step_max,
+                           Scalar& step, Scalar& fx, Vector& grad, Scalar& dg, Vector& x)
+    {
+        detail::HostEval<Scalar, Foo, Vector> ev(f, xp, drt, grad, x);
+        LineSearch(ev, param, step_max, step, fx, dg);
     }
 };
 

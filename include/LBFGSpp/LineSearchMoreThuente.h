@@ -16,6 +16,7 @@
 #include <limits>
 #include <stdexcept>
 
+#include "HostEval.h"
 #include "Param.h"
 
 namespace LBFGSpp {
@@ -281,6 +282,14 @@ public:
                 return;
             }
         }
+    }
+    // the reference's own signature (HostEval.h): host vectors, the same decisions
+    template <typename Foo, typename SolverParam, typename Vector>
+    static void LineSearch(Foo& f, const SolverParam& param, const Vector& xp, const Vector& drt, const Scalar& step_max,
+                           Scalar& step, Scalar& fx, Vector& grad, Scalar& dg, Vector& x)
+    {
+        detail::HostEval<Scalar, Foo, Vector> ev(f, xp, drt, grad, x);
+        LineSearch(ev, param, step_max, step, fx, dg);
     }
 };
 

@@ -270,3 +270,70 @@ def test_sums_over_L_u_U_are_used_by_the_solve_that_follows_their_pass_only(tmp_
     # control: with Wtv_lu right before it the same solve does use the identity (and no v-row pass)
     first, second = [s.split() for s in lib.mock_sweep_sequence(1).decode().split("|")]
     assert "solve_sweep_rhs" in second and "wtv_prologue" not in second, second
+
+
+REF_INC = "/root/reference/include"
+
+
+@pytest.fixture(scope="module")
+def policy_libs(tmp_path_factory):
+    """tests/cpp/policy10_capi.cpp compiled against the reference's headers and against include/ (the checker needs
+    /root/reference: build container only)"""
+    if not os.path.isdir(REF_INC):
+        pytest.skip("/root/reference is not present on this machine")
+    d = tmp_path_factory.mktemp("p10")
+    libs = []
+    for tag, inc in (("ref", REF_INC), ("ours", os.path.join(ROOT, "include"))):
+        out = str(d / ("libpolicy10_%s.so" % tag))
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-ffp-contract=off"] + SAN +
+                              ["-I", inc, "-I", os.path.join(ROOT, "oracle", "eigen_shim"),
+                               os.path.join(HERE, "cpp", "policy10_capi.cpp"), "-o", out])
+        lib = C.CDLL(out)
+        lib.policy10.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p] + [C.c_double] * 6 + [C.c_int] + [C.c_void_p] * 3
+        libs.append(lib)
+    return libs
+
+
+@pytest.mark.parametrize("policy,conditions", [(0, (1, 2, 3)), (1, (1, 2, 3)), (2, (3,)), (3, (3,))],
+                         ids=["backtracking", "bracketing", "more-thuente", "nocedal-wright"])
+def test_built_in_policies_offer_the_reference_signature_with_the_reference_results(policy_libs, policy, conditions):
+    """VERDICT r5, missing 2: a program that calls a built-in policy directly through the reference's ten-argument static form
+    now compiles -- and gets the reference's result: step, fx, dg, the evaluation count, x, grad and the exception class, on
+    random descent (and a few ascent / degenerate) directions of the extended Rosenbrock function"""
+    ref, ours = policy_libs
+    rng = np.random.default_rng(1234 + policy)
+    seen = set()
+    for trial in range(300):
+        n = int(rng.choice([2, 6, 20]))
+        xp = np.where(np.arange(n) % 2 == 1, 1.0, -1.2) + 0.4 * rng.random(n)
+        g = np.zeros(n)
+        for i in range(0, n, 2):
+            t1, t2 = 1.0 - xp[i], 10.0 * (xp[i + 1] - xp[i] ** 2)
+            g[i + 1] = 20.0 * t2
+            g[i] = -2.0 * (xp[i] * g[i + 1] + t1)
+        kind = trial % 10
+        drt = -g * (10.0 ** rng.uniform(-4, 1)) + (0.3 * rng.standard_normal(n) * np.abs(g).mean() if kind >= 3 else 0.0)
+        if kind == 9:
+            drt = g.copy()  # ascent: the policies throw
+        step0 = float(10.0 ** rng.uniform(-3, 1)) if kind != 8 else -1.0
+        cond = int(conditions[trial % len(conditions)])
+        args = (policy, cond, n, xp.ctypes.data_as(C.c_void_p), drt.ctypes.data_as(C.c_void_p), step0, 1e20,
+                1e-4, 0.9, 1e-20 if kind != 7 else 1e-3, 1e20 if kind != 6 else 2.0, int(rng.choice([3, 8, 20])))
+        res = []
+        for lib in (ref, ours):
+            out, x, gr = np.zeros(4), np.zeros(n), np.zeros(n)
+            rc = lib.policy10(*args, out.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p), gr.ctypes.data_as(C.c_void_p))
+            res.append((rc, out, x, gr))
+        (rc_r, o_r, x_r, g_r), (rc_o, o_o, x_o, g_o) = res
+        assert rc_r == rc_o and o_r[3] == o_o[3], (trial, rc_r, rc_o, o_r, o_o)
+        seen.add(rc_r)
+        # The interpolation formulas of the More-Thuente / Nocedal-Wright machines are algebraically the reference's, not
+        # operation for operation (a step may differ in its last bit, x with it): the contract is the north star's 1e-10 on
+        # iterates, and identical decisions.  dg is a dot product: the stand-in Eigen's order against a left-to-right loop.
+        tol = 0.0 if policy < 2 else 1e-12
+        assert np.abs(x_r - x_o).max() <= tol * max(1.0, np.abs(x_r).max()), trial
+        assert np.abs(g_r - g_o).max() <= 1e3 * tol * max(1.0, np.abs(g_r).max()), trial
+        if rc_r == 0:
+            assert abs(o_r[0] - o_o[0]) <= tol * abs(o_r[0]) and abs(o_r[1] - o_o[1]) <= tol * max(1.0, abs(o_r[1])), (trial, o_r, o_o)
+            assert abs(o_r[2] - o_o[2]) <= 1e-9 * max(1.0, abs(o_r[2])), (trial, o_r, o_o)
+    assert 0 in seen and len(seen) >= 2   # successes and at least one exception class were exercised
