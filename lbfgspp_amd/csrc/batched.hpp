@@ -310,13 +310,13 @@ inline BatWs bat_unarmed(lbfgsx_batch* c)
 inline hipError_t bat_wait(lbfgsx_batch* c)
 {
     c->stage_unwaited = 0;  // everything up to the armed launch has finished when this returns
+    c->waits++;             // host waits of the batch, however they are served
     if (!c->armed || !c->poll)
     {
         c->armed = false;
         return stream_sync(c->stream);
     }
     c->armed = false;
-    c->waits++;
     counters().syncs.fetch_add(1, std::memory_order_relaxed);
     const volatile unsigned long long* w = c->done_host;
     const unsigned long long want = c->done_seq;
