@@ -39,6 +39,17 @@ constexpr int kItWaves = kHvThreads / 64;
 #ifndef LBFGSX_IT_TU
 #define LBFGSX_IT_TU 6
 #endif
+// Slots of q a thread keeps in registers when the problem needs all 98 (the rest in LDS: 23 slots = 92 KB, dynamic LDS), and
+// whether the first chunk of the next step is loaded AHEAD of this step's block reduction (the 98-slot class only: it needs
+// the registers the smaller register share frees, and the smaller classes want their occupancy).  +1.2-1.5 % on cfg5,
+// interleaved over five repetitions (profiles/r6_cfg5_chunk_ab.txt); what made it compile without scratch is in the step loop.
+#ifndef LBFGSX_IT_REGSLOTS
+#define LBFGSX_IT_REGSLOTS 75
+#endif
+#ifndef LBFGSX_IT_PRE
+#define LBFGSX_IT_PRE 1
+#endif
+constexpr int kItStaticLdsSlots = 15;  // 60 KB: what a launch may have as static LDS; more comes from the dynamic region
 
 // sums of NS per-thread accumulators over the block; the totals are valid in thread 0.  `sh` is reused by the caller's next
 // reduction only after a block barrier.
@@ -211,9 +222,12 @@ __global__ void __launch_bounds__(kHvThreads) kb_iter(BatBufs<T> b, const BatItD
     // block by 8 / 16 / 24 us at its start changed nothing, interleaved A/B: the launch is not limited by coinciding bubbles.)
     typedef typename AccOf<T>::type A;
     constexpr int W = Vec16<T>::W;
-    constexpr int NR = NQ > kHvRegSlots ? kHvRegSlots : NQ;
+    constexpr int NR = NQ > LBFGSX_IT_REGSLOTS ? LBFGSX_IT_REGSLOTS : NQ;
     constexpr int NL = NQ - NR;
-    __shared__ typename Vec16<T>::type lq[(NL > 0 ? NL : 1) * kHvThreads];
+    constexpr bool DYN = NL > kItStaticLdsSlots;
+    __shared__ typename Vec16<T>::type lq_static[(DYN || NL < 1 ? 1 : NL) * kHvThreads];
+    extern __shared__ __attribute__((aligned(16))) char it_dyn_lds[];
+    typename Vec16<T>::type* lq = DYN ? reinterpret_cast<typename Vec16<T>::type*>(it_dyn_lds) : lq_static;
     __shared__ double sh[4][2][kItWaves];
     __shared__ T sdot[2 * 32 + 2];
     __shared__ T s_ys[32];
@@ -375,8 +389,15 @@ __global__ void __launch_bounds__(kHvThreads) kb_iter(BatBufs<T> b, const BatItD
             w = (t < cn - 1) ? b.y(s_pcol[i - 1], p) + eoff : g;
         }
     };
-    // (Loading the next step's first chunk ahead of this step's reduction -- hv_prefetch, as k_twoloop_persist does with 30
-    // resident slots -- was tried: with 83 the 48 extra live registers send the allocator to scratch, 1400 spills.)
+    constexpr bool PRE = (LBFGSX_IT_PRE != 0) && NQ > 56;
+    Pack<T> pfu[LBFGSX_IT_CHUNK], pfw[LBFGSX_IT_CHUNK];  // the first chunk of the next step, loaded ahead of this step's reduction
+    if (PRE)
+    {
+        const T* u;
+        const T* w;
+        operands(0, u, w);
+        hv_prefetch<T, LBFGSX_IT_CHUNK>(u, w, nv, int64_t(tid), int64_t(kHvThreads), pfu, pfw);
+    }
     for (int L = 0; L <= 2 * cn; L++)
     {
         A acc4[4];  // independent chains: the order-independent sums make any split legal
@@ -402,8 +423,18 @@ __global__ void __launch_bounds__(kHvThreads) kb_iter(BatBufs<T> b, const BatItD
         // recomputed inside the step instead of being hoisted out of the L loop and kept in ~4 registers per slot
         int tid_step = tid;
         asm volatile("" : "+v"(tid_step));
-        hv_step<T, NR, NL, A, false, LBFGSX_IT_CHUNK>(rq, lq, u, w, L == 0, T(-1), c, theta, nv, int64_t(tid_step),
-                                                       int64_t(kHvThreads), tid, acc4);
+        // the next step's operands, worked out BEFORE this step's pass: anything computed between hv_step and the loads that
+        // follow it (the column ids come from LDS) splits the live ranges of the resident slots -- 1 100 spilled registers
+        const T* un = u;
+        const T* wn = w;
+        if (PRE)
+            operands(L < 2 * cn ? L + 1 : L, un, wn);
+        hv_step<T, NR, NL, A, PRE, LBFGSX_IT_CHUNK>(rq, lq, u, w, L == 0, T(-1), c, theta, nv, int64_t(tid_step), int64_t(kHvThreads),
+                                                     tid, acc4, pfu, pfw);
+        // no branch around the loads (a conditional block behind hv_step costs a second copy of the resident slots): the last
+        // step re-loads its own first chunk
+        if (PRE)
+            hv_prefetch<T, LBFGSX_IT_CHUNK>(un, wn, nv, int64_t(tid_step), int64_t(kHvThreads), pfu, pfw);
         A acc[1];
         acc[0] = acc4[0];
         for (int k = 1; k < 4; k++)
@@ -454,7 +485,20 @@ __global__ void __launch_bounds__(kHvThreads) kb_iter(BatBufs<T> b, const BatItD
 template <class T, class OBJS, int NQ>
 static void launch_iter(lbfgsx_batch* c, const BatItDesc* dd, const OBJS& objs, const BatWs& ws, const ItXch& xc)
 {
-    BAT_LAUNCH(c, (kb_iter<T, OBJS, NQ>), dim3(unsigned(c->P) * unsigned(xc.G)), dim3(kHvThreads), 0, c->stream, bufs<T>(c), dd, c->n,
+    constexpr int NRh = NQ > LBFGSX_IT_REGSLOTS ? LBFGSX_IT_REGSLOTS : NQ;
+    constexpr int NLh = NQ - NRh;
+    constexpr size_t dyn = NLh > kItStaticLdsSlots ? size_t(NLh) * kHvThreads * 16 : 0;
+    if (dyn)
+    {
+        static bool once = false;  // per instantiation: the kernel may use more than the default 64 KB of LDS
+        if (!once)
+        {
+            (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_iter<T, OBJS, NQ>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       int(dyn));
+            once = true;
+        }
+    }
+    BAT_LAUNCH(c, (kb_iter<T, OBJS, NQ>), dim3(unsigned(c->P) * unsigned(xc.G)), dim3(kHvThreads), dyn, c->stream, bufs<T>(c), dd, c->n,
                c->m, objs, ws, std::numeric_limits<T>::epsilon(), xc);
 }
 template <class T, class OBJS>

@@ -480,12 +480,12 @@ constexpr int kHvThreads = 256;
 //   dot operand     w, or u itself when dot_u (the SUBDIV step reduces against the column it just subtracted)
 constexpr int kHvChunk = 6;  // slots per chunk of hv_step: 2 x 6 16-byte loads in flight per thread, then the arithmetic
 // the loads of the first chunk of a step, issued by the caller ahead of the step (while it waits for the step's coefficient)
-template <class T>
+template <class T, int CH = kHvChunk>
 __device__ __forceinline__ void hv_prefetch(const T* u, const T* w, int64_t nv, int64_t vbase, int64_t vstride,
-                                            Pack<T> (&pu)[kHvChunk], Pack<T> (&pw)[kHvChunk])
+                                            Pack<T> (&pu)[CH], Pack<T> (&pw)[CH])
 {
 #pragma unroll
-    for (int k = 0; k < kHvChunk; k++)
+    for (int k = 0; k < CH; k++)
     {
         const int64_t vi = int64_t(k) * vstride + vbase;
         const int64_t vc = vi < nv ? vi : int64_t(0);
