@@ -893,7 +893,7 @@ class ThreadDist:
 
 def run_single_process(args, ndev_asked):
     """--single-process --gpus N: ONE process drives all N GPUs -- one host thread and one solver context per device for the
-    single-problem legs, lbfgsx_batch_minimize_lockstep_multi for the batch, and the batch's one exchange step natively over
+    single-problem legs, one resident lock-step batch per device (lbfgsx_lockstep_*) for the batch, and the batch's one exchange step natively over
     RCCL (lbfgsx_rccl_allgather_records: ncclCommInitAll + a grouped ncclAllGather).  LBFGSX_BENCH_DEVICES=0,0 lists the
     devices explicitly (a device twice: protocol test on a one-GPU box)."""
     import threading
@@ -938,10 +938,35 @@ def run_single_process(args, ndev_asked):
         n, m, P, steps = 100000, 10, args.problems_per_gpu, args.batched_steps
         total = P * world
         par = A.LBFGSParam(m=m, epsilon=0.0, epsilon_rel=0.0, max_iterations=steps)
-        B.solve_local_lockstep(par, n, 0, min(total, 64 * world), dtype=np.float32, devices=devices)  # warm-up
+        # one resident batch per listed device (allocated and warmed up outside the timed window, as in the one-process-per-GPU
+        # form), each driven by its own host thread over its contiguous block of problem ids
+        import threading
+        shards = [B.shard_range(total, r, world) for r in range(world)]
+        batches = [B.LockstepBatch(par, n, cnt, dtype=np.float32, device=devices[r]) for r, (_, cnt) in enumerate(shards)]
+        parts = [None] * world
+
+        def solve_all():
+            errs = []
+
+            def one(r):
+                try:
+                    parts[r] = batches[r].minimize(first=shards[r][0], seed_base=1000)
+                except BaseException as e:  # noqa: BLE001
+                    errs.append(e)
+            ths = [threading.Thread(target=one, args=(r,)) for r in range(world)]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+            if errs:
+                raise errs[0]
+        solve_all()  # warm-up of the timed instance
         t0 = time.perf_counter()
-        recs = B.solve_local_lockstep(par, n, 0, total, seed_base=1000, dtype=np.float32, devices=devices)
+        solve_all()
         t1 = time.perf_counter()
+        recs = np.concatenate(parts)
+        for bt in batches:
+            bt.close()
         # the exchange step: every device ends up with all records (one rank per distinct device)
         uniq = sorted(set(devices))
         raw = np.ascontiguousarray(recs).view(np.uint8).reshape(total, -1)
@@ -966,8 +991,8 @@ def run_single_process(args, ndev_asked):
             "unit": "problem-iterations/s", "n_gpus": world, "steps": steps, "ms_per_step": elapsed / max(steps, 1) * 1e3,
             "scaling": "weak", "dtype": "f32",
             "config": {"workload": "cfg5: %d independent extended-Rosenbrock problems per GPU, n=1e5, m=10, f32, "
-                                   "LineSearchMoreThuente, %d iterations each; ONE process: lbfgsx_batch_minimize_lockstep_multi "
-                                   "(contiguous problem-id blocks, one host thread + one lock-step batch per device) and the "
+                                   "LineSearchMoreThuente, %d iterations each; ONE process: one resident lock-step batch per device "
+                                   "(lbfgsx_lockstep_*; contiguous problem-id blocks, one host thread per device) and the "
                                    "records all-gathered natively over RCCL" % (P, steps),
                        "problems_total": total, "fevals_total": fev, "failed": int((recs["status"] != 0).sum()),
                        "devices": devices, "solve_seconds": t1 - t0, "rccl_allgather_seconds": t2 - t1,
@@ -1165,7 +1190,7 @@ def main():
     ap.add_argument("--no-batched", action="store_true", help="skip the cfg5 leg of the default line")
     ap.add_argument("--single-process", action="store_true",
                     help="--gpus N from ONE process: one host thread + one context per GPU, the batch through "
-                         "lbfgsx_batch_minimize_lockstep_multi and its record gather natively over RCCL")
+                         "one resident lock-step batch per device and the record gather natively over RCCL")
     ap.add_argument("--verbose", action="store_true",
                     help="the full line (~15 KB: explanatory notes, per-iteration times); the default line drops them (< 7 KB)")
     ap.add_argument("--full-json", default=None, help="also write the full (verbose) object to this file")

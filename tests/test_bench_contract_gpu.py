@@ -224,7 +224,7 @@ def test_gpus_2_starts_two_ranks_or_refuses():
 
 def test_single_process_drives_every_listed_device():
     """--single-process --gpus 2: ONE process, one host thread + context per listed device, the batch through
-    lbfgsx_batch_minimize_lockstep_multi and its records gathered natively over RCCL.  On the one-GPU box the device list
+    one resident lock-step batch per listed device and its records gathered natively over RCCL.  On the one-GPU box the device list
     is {0, 0} (LBFGSX_BENCH_DEVICES)."""
     sys.path.insert(0, ROOT)
     import lbfgspp_amd as A
