@@ -195,7 +195,8 @@ struct BatQuad
 
 constexpr int kHvRegSlots = 83;  // 16-byte slots of q a thread of the one-block-per-problem kernels keeps in registers
 constexpr int kBatGxMax = 16;   // blocks per problem a launch may use when few problems take part
-constexpr int kBatStages = 4;    // descriptor staging buffers (host-mapped, read by the kernels in place)
+constexpr int kBatStages = 24;   // descriptor staging buffers (host-mapped, read by the kernels in place): more than the
+                                 // 2 * 10 + 1 un-waited step launches of a statement-wise recursion at m = 10
 
 }  // namespace lbfgsx
 

@@ -490,12 +490,15 @@ static void launch_iter(lbfgsx_batch* c, const BatItDesc* dd, const OBJS& objs, 
     constexpr size_t dyn = NLh > kItStaticLdsSlots ? size_t(NLh) * kHvThreads * 16 : 0;
     if (dyn)
     {
-        static bool once = false;  // per instantiation: the kernel may use more than the default 64 KB of LDS
-        if (!once)
+        // per instantiation AND device (a function's attributes belong to the device its module is loaded on): the kernel
+        // may use more than the default 64 KB of LDS
+        static std::atomic<unsigned long long> done{0};
+        const unsigned long long bit = 1ull << (unsigned(c->device) & 63u);
+        if (!(done.load(std::memory_order_relaxed) & bit))
         {
             (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_iter<T, OBJS, NQ>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        int(dyn));
-            once = true;
+            done.fetch_or(bit, std::memory_order_relaxed);
         }
     }
     BAT_LAUNCH(c, (kb_iter<T, OBJS, NQ>), dim3(unsigned(c->P) * unsigned(xc.G)), dim3(kHvThreads), dyn, c->stream, bufs<T>(c), dd, c->n,
