@@ -39,6 +39,9 @@ constexpr int kItWaves = kHvThreads / 64;
 #ifndef LBFGSX_IT_TU
 #define LBFGSX_IT_TU 6
 #endif
+#ifndef LBFGSX_IT_NTS
+#define LBFGSX_IT_NTS 0  // non-temporal hint on the stores of the trial (1) and post (2) passes: measured within the noise (+-1 %), off
+#endif
 // Slots of q a thread keeps in registers when the problem needs all 98 (the rest in LDS: 23 slots = 92 KB, dynamic LDS), and
 // whether the first chunk of the next step is loaded AHEAD of this step's block reduction (the 98-slot class only: it needs
 // the registers the smaller register share frees, and the smaller classes want their occupancy).  +1.2-1.5 % on cfg5,
@@ -180,7 +183,7 @@ __device__ __forceinline__ void it_trial(const Pack<T> (&rq)[NR], const typename
                     cur.v = lq[(s < NR ? dummy : s - NR) * kHvThreads + tid];
                 if (ok[k])  // d is only read here: a branch costs no second copy of the resident slots
                 {
-                    stv<T, false>(dout, vi, cur);
+                    stv<T, LBFGSX_IT_NTS != 0>(dout, vi, cur);
                     if (trial)
                     {
                         Pack<T> xn, gn;
@@ -188,8 +191,8 @@ __device__ __forceinline__ void it_trial(const Pack<T> (&rq)[NR], const typename
                         for (int e = 0; e < W; e++)
                             xn.e[e] = px[k].e[e] + step * cur.e[e];
                         obj.pack(vi, xn, gn, accf);
-                        stv(xt, vi, xn);
-                        stv(gt, vi, gn);
+                        stv<T, LBFGSX_IT_NTS != 0>(xt, vi, xn);
+                        stv<T, LBFGSX_IT_NTS != 0>(gt, vi, gn);
 #pragma unroll
                         for (int e = 0; e < W; e++)
                             accd.add_prod(gn.e[e], cur.e[e]);
@@ -291,8 +294,8 @@ __global__ void __launch_bounds__(kHvThreads) kb_iter(BatBufs<T> b, const BatItD
                         accp[2].add_prod(ps.e[e], py.e[e]);
                         accp[3].add_prod(py.e[e], py.e[e]);
                     }
-                    stv(sv, vi, ps);
-                    stv(yv, vi, py);
+                    stv<T, (LBFGSX_IT_NTS & 2) != 0>(sv, vi, ps);
+                    stv<T, (LBFGSX_IT_NTS & 2) != 0>(yv, vi, py);
                 }
             }
         }

@@ -2,7 +2,7 @@
 # A/B of library variants (variants/liblbfgsx_<tag>.so, built in the container) on ONE box, interleaved: the cfg5 leg's line per variant
 cd $GRAFT_REPO_ROOT
 cp lbfgspp_amd/liblbfgsx.so /tmp/liblbfgsx_base.so
-for rep in 1 2 3 4 5; do
+for rep in 1 2 3; do
 for v in base $(ls variants | sed 's/liblbfgsx_//; s/.so//'); do
   if [ $v = base ]; then cp /tmp/liblbfgsx_base.so lbfgspp_amd/liblbfgsx.so; else cp variants/liblbfgsx_$v.so lbfgspp_amd/liblbfgsx.so; fi
   python bench.py --workload cfg5-batched --steps 50 --no-cpu --verbose 2>/dev/null | python -c "
