@@ -33,6 +33,10 @@ constexpr int kItWaves = kHvThreads / 64;
 #ifndef LBFGSX_IT_CHUNK
 #define LBFGSX_IT_CHUNK 14
 #endif
+#ifndef LBFGSX_IT_CHUNK_SMALL
+#define LBFGSX_IT_CHUNK_SMALL 7   // the chunk of the 14- and 28-slot classes: short problems want two blocks per CU, not 28 loads per
+                                  // thread (n = 16 384: 1.04 -> 1.40 M problem-iterations/s, n = 8 192: +5 %; profiles/r6_cfg5_by_n.txt)
+#endif
 #ifndef LBFGSX_IT_PU
 #define LBFGSX_IT_PU 6
 #endif
@@ -51,6 +55,9 @@ constexpr int kItWaves = kHvThreads / 64;
 #endif
 #ifndef LBFGSX_IT_PRE
 #define LBFGSX_IT_PRE 1
+#endif
+#ifndef LBFGSX_IT_PRE_MIN
+#define LBFGSX_IT_PRE_MIN 57  // smallest slot class that prefetches
 #endif
 constexpr int kItStaticLdsSlots = 15;  // 60 KB: what a launch may have as static LDS; more comes from the dynamic region
 
@@ -392,14 +399,15 @@ __global__ void __launch_bounds__(kHvThreads) kb_iter(BatBufs<T> b, const BatItD
             w = (t < cn - 1) ? b.y(s_pcol[i - 1], p) + eoff : g;
         }
     };
-    constexpr bool PRE = (LBFGSX_IT_PRE != 0) && NQ > 56;
-    Pack<T> pfu[LBFGSX_IT_CHUNK], pfw[LBFGSX_IT_CHUNK];  // the first chunk of the next step, loaded ahead of this step's reduction
+    constexpr bool PRE = (LBFGSX_IT_PRE != 0) && NQ >= LBFGSX_IT_PRE_MIN;
+    constexpr int CHK = NQ > 28 ? LBFGSX_IT_CHUNK : LBFGSX_IT_CHUNK_SMALL;
+    Pack<T> pfu[CHK], pfw[CHK];  // the first chunk of the next step, loaded ahead of this step's reduction
     if (PRE)
     {
         const T* u;
         const T* w;
         operands(0, u, w);
-        hv_prefetch<T, LBFGSX_IT_CHUNK>(u, w, nv, int64_t(tid), int64_t(kHvThreads), pfu, pfw);
+        hv_prefetch<T, CHK>(u, w, nv, int64_t(tid), int64_t(kHvThreads), pfu, pfw);
     }
     for (int L = 0; L <= 2 * cn; L++)
     {
@@ -432,12 +440,12 @@ __global__ void __launch_bounds__(kHvThreads) kb_iter(BatBufs<T> b, const BatItD
         const T* wn = w;
         if (PRE)
             operands(L < 2 * cn ? L + 1 : L, un, wn);
-        hv_step<T, NR, NL, A, PRE, LBFGSX_IT_CHUNK>(rq, lq, u, w, L == 0, T(-1), c, theta, nv, int64_t(tid_step), int64_t(kHvThreads),
+        hv_step<T, NR, NL, A, PRE, CHK>(rq, lq, u, w, L == 0, T(-1), c, theta, nv, int64_t(tid_step), int64_t(kHvThreads),
                                                      tid, acc4, pfu, pfw);
         // no branch around the loads (a conditional block behind hv_step costs a second copy of the resident slots): the last
         // step re-loads its own first chunk
         if (PRE)
-            hv_prefetch<T, LBFGSX_IT_CHUNK>(un, wn, nv, int64_t(tid_step), int64_t(kHvThreads), pfu, pfw);
+            hv_prefetch<T, CHK>(un, wn, nv, int64_t(tid_step), int64_t(kHvThreads), pfu, pfw);
         A acc[1];
         acc[0] = acc4[0];
         for (int k = 1; k < 4; k++)
