@@ -1,5 +1,5 @@
 #!/bin/bash
-# cfg5 leg with an environment switch off / on, interleaved on one box: bash scripts/r6_cfg5_env_ab.sh VAR [reps]
+# cfg5 leg with an environment switch off / on, interleaved on one box: bash scripts/r6/cfg5_env_ab.sh VAR [reps]
 cd $GRAFT_REPO_ROOT
 V=$1; R=${2:-3}
 for rep in $(seq 1 $R); do for val in 0 1; do

@@ -1,5 +1,5 @@
 #!/bin/bash
-# as r6_cfg5_variants.sh for another problem size: bash scripts/r6_cfg5_variants_n.sh N P [reps]
+# as r6/cfg5_variants.sh for another problem size: bash scripts/r6/cfg5_variants_n.sh N P [reps]
 cd $GRAFT_REPO_ROOT
 N=$1; P=$2; R=${3:-2}
 cp lbfgspp_amd/liblbfgsx.so /tmp/liblbfgsx_base.so
