@@ -234,7 +234,8 @@ struct lbfgsx_batch
     unsigned long long* done_dev = nullptr;
     unsigned long long done_seq = 0;
     bool armed = false;
-    int64_t waits = 0, wait_timeouts = 0, launches = 0;
+    int64_t waits = 0, wait_timeouts = 0, launches = 0;  // instrumentation, cleared by lbfgsx_bat_timing_read
+    int poll_bad = 0;  // time-outs that said "polling cannot work here" (never cleared): two switch it off
     // instrumentation (lbfgsx_bat_timing): events around every launch
     bool timing = false;
     std::vector<lbfgsx::EventPair> ev;
@@ -334,7 +335,7 @@ inline hipError_t bat_wait(lbfgsx_batch* c)
             const auto s0 = std::chrono::steady_clock::now();
             const hipError_t e = hipStreamSynchronize(c->stream);
             const double ss = std::chrono::duration<double>(std::chrono::steady_clock::now() - s0).count();
-            if (e == hipSuccess && (*w < want || ss < 1e-3) && c->wait_timeouts >= 2)
+            if (e == hipSuccess && (*w < want || ss < 1e-3) && ++c->poll_bad >= 2)
                 c->poll = false;
             return e;
         }
