@@ -104,7 +104,7 @@ __device__ __forceinline__ void it_block_sum(A (&acc)[NS], double (*sh)[2][kItWa
 // same total.  Two buffers alternate: a part can be at most one exchange ahead of a sibling (it needs the sibling's word of
 // exchange e + 1, which the sibling writes only after it has read everybody's word of exchange e).  The parts of a problem are
 // consecutive block ids and blocks are dispatched in id order, so whatever holds the CUs a missing sibling waits for
-// belongs to problems whose parts are all resident: they finish.  The wait is bounded all the same (0.5 s): a part that
+// belongs to problems whose parts are all resident: they finish.  The wait is bounded all the same (100 ms, persist_await): a part that
 // gives up poisons the launch's error word, the host sees it in the results and fails loudly.
 struct ItXch
 {
