@@ -535,7 +535,7 @@ static int iter_parts(const lbfgsx_batch* c)
     if (c->n % w != 0)
         return 0;
     const int64_t nv = c->n / w;
-    for (int g = 1; g <= kItMaxParts; g++)
+    for (int g = c->min_parts > 1 ? c->min_parts : 1; g <= kItMaxParts; g++)
     {
         const int64_t nvp = g > 1 ? ((nv + g - 1) / g + kHvThreads - 1) / kHvThreads * kHvThreads : nv;
         if (nvp <= int64_t(kHvThreads) * 98)
