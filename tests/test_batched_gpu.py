@@ -108,14 +108,17 @@ def test_one_launch_two_loop_equals_step_wise_launches(monkeypatch, dtype, n):
                                             # problems longer than one CU's registers: 2, 3 and 8 blocks per problem with the
                                             # sums exchanged between them at every step
                                             (np.float32, 200000, 10, 0.0), (np.float64, 150016, 6, 0.0),
-                                            (np.float32, 800000, 4, 0.0), (np.float64, 60000, 5, 1e-3)])
+                                            (np.float32, 800000, 4, 0.0), (np.float64, 60000, 5, 1e-3),
+                                            # run far past convergence (eps < 0: 600 iterations asked for): searches that give
+                                            # up, steps at rounding level, pairs the curvature test rejects
+                                            (np.float32, 4096, 5, -1.0), (np.float64, 512, 3, -1.0)])
 def test_one_launch_iteration_equals_statement_wise_launches(monkeypatch, dtype, n, m, eps):
     """lbfgsx_bat_iterate (post statements + recursion + first trial of the next search in ONE launch per lock-step iteration,
     the direction resident on the CU) against the three statement-wise forms it replaces: identical records and iterates.
     eps > 0: problems converge at different iterations, so finished problems sit out of later launches."""
     import lbfgspp_amd as A
     from lbfgspp_amd import batched as B
-    par = A.LBFGSParam(m=m, epsilon=eps, epsilon_rel=0.0, max_iterations=(400 if eps > 0 else m + 6))
+    par = A.LBFGSParam(m=m, epsilon=max(eps, 0.0), epsilon_rel=0.0, max_iterations=(400 if eps > 0 else 600 if eps < 0 else m + 6))
     got = {}
     for name, it, hv in (("iterate", "1", "1"), ("apply_Hv", "0", "1"), ("steps", "0", "0")):
         monkeypatch.setenv("LBFGSX_BAT_FUSED_ITER", it)
@@ -124,6 +127,8 @@ def test_one_launch_iteration_equals_statement_wise_launches(monkeypatch, dtype,
     for name in ("apply_Hv", "steps"):
         assert np.array_equal(got["iterate"][0], got[name][0]), name
         assert np.array_equal(got["iterate"][1], got[name][1]), name
+    if eps < 0:
+        print("far past convergence: niter", got["iterate"][0]["niter"], "status", got["iterate"][0]["status"])
     if eps > 0:
         assert len(set(got["iterate"][0]["niter"])) > 1, got["iterate"][0]["niter"]  # the case the parameter is there for
 
@@ -290,3 +295,104 @@ def test_threaded_batch_of_lbfgsb_problems_equals_single_solves_and_is_determini
         niter, fx = s.minimize_resident(A.DiagQuadratic(), n)
         assert (r1["niter"][k], r1["nfev"][k]) == (niter, s.last.nfev) and r1["fx"][k] == fx
     s.close()
+
+
+def test_one_launch_iteration_takes_the_curvature_decision_of_the_reference(A):
+    """lbfgsx_bat_iterate on hand-made states (no objective involved): the post statements of three problems whose new pair
+    is (0) usable, (1) flat -- y = 0, s.y = 0 <= eps y.y -- and (2) of negative curvature.  The kernel must store the pair
+    and report its sums in every case, but build the direction from "history + pair" only for problem 0 (LBFGS.h:161,
+    BFGSMat.h:83-97): the others get -H g of the history they had (none here: -g), exactly what the host concludes from the
+    same sums.  A second launch on top of a stored pair checks the two-loop coefficients against numpy."""
+    core, _ = A.load()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemcpy.restype = C.c_int
+    H2D, D2H = 1, 2
+
+    class ItDesc(C.Structure):
+        _fields_ = [("active", C.c_int), ("flags", C.c_int), ("cur", C.c_int), ("xp", C.c_int), ("trial", C.c_int),
+                    ("ncorr", C.c_int), ("spare", C.c_int), ("pad", C.c_int), ("step", C.c_double), ("pcol", C.c_int * 32)]
+    n, m, P = 8192, 4, 3
+    bat = C.c_void_p()
+    core.lbfgsx_bat_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int]
+    core.lbfgsx_bat_vec.restype = C.c_void_p
+    core.lbfgsx_bat_vec.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    core.lbfgsx_bat_iterate.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    core.lbfgsx_bat_iterate_ok.argtypes = [C.c_void_p]
+    core.lbfgsx_bat_destroy.argtypes = [C.c_void_p]
+    core.lbfgsx_bat_sync.argtypes = [C.c_void_p]
+    L = __import__("lbfgspp_amd")._lib
+    L.check(core.lbfgsx_bat_create(C.byref(bat), L.F64, n, m, P, 0))
+    try:
+        assert core.lbfgsx_bat_iterate_ok(bat) == 1
+        rng = np.random.default_rng(3)
+
+        def put(kind, point, p, v):
+            v = np.ascontiguousarray(v, dtype=np.float64)
+            assert hip.hipMemcpy(core.lbfgsx_bat_vec(bat, kind, point, p), v.ctypes.data_as(C.c_void_p), v.nbytes, H2D) == 0
+
+        def get(kind, point, p):
+            v = np.empty(n)
+            L.check(core.lbfgsx_bat_sync(bat))
+            assert hip.hipMemcpy(v.ctypes.data_as(C.c_void_p), core.lbfgsx_bat_vec(bat, kind, point, p), v.nbytes, D2H) == 0
+            return v
+        xp = [rng.standard_normal(n) for _ in range(P)]
+        gp = [rng.standard_normal(n) for _ in range(P)]
+        s = [0.1 * rng.standard_normal(n) for _ in range(P)]
+        y = [2.0 * s[0] + 0.01 * rng.standard_normal(n), np.zeros(n), -1.5 * s[2]]
+        x = [xp[p] + s[p] for p in range(P)]
+        g = [gp[p] + y[p] for p in range(P)]
+        for p in range(P):
+            put(0, 0, p, xp[p]); put(1, 0, p, gp[p]); put(0, 1, p, x[p]); put(1, 1, p, g[p])
+        desc = (ItDesc * P)()
+        for p in range(P):
+            desc[p].active, desc[p].flags, desc[p].cur, desc[p].xp, desc[p].ncorr, desc[p].spare = 1, 1, 1, 0, 0, m  # POST
+        out = np.zeros(P * 8)
+        L.check(core.lbfgsx_bat_iterate(bat, L.OBJ_EXT_ROSENBROCK, desc, out.ctypes.data_as(C.c_void_p)))
+        out = out.reshape(P, 8)
+        eps = np.finfo(np.float64).eps
+        for p in range(P):
+            sp, yp = x[p] - xp[p], g[p] - gp[p]   # the kernel's s and y: differences of the stored points
+            gg, xx, sy, yy = g[p] @ g[p], x[p] @ x[p], sp @ yp, yp @ yp
+            assert np.allclose(out[p, :4], [gg, xx, sy, yy], rtol=1e-13, atol=1e-13)
+            accept = out[p, 2] > eps * out[p, 3]
+            assert accept == (p == 0)
+            d = get(2, 0, p)
+            if accept:   # one pair: alpha = s.q / s.y, q -= alpha y, q /= theta, q += (alpha - y.q / s.y) s
+                q = -g[p]
+                alpha = (sp @ q) / sy
+                q = q - alpha * yp
+                q = q / (yy / sy)
+                q = q + (alpha - (yp @ q) / sy) * sp
+                assert np.abs(d - q).max() <= 1e-12 * np.abs(q).max()
+            else:
+                assert np.array_equal(d, -g[p])
+            assert abs(out[p, 4] - g[p] @ d) <= 1e-11 * abs(g[p] @ d)   # grad . drt
+            # the pair is stored either way (the host decides whether the ring takes it)
+            assert out[p, 7] == 0.0
+        # second launch: problem 0 has taken its pair (column m), the others still have none; new points on top
+        for p in range(P):
+            put(0, 2, p, x[p] + 0.05 * s[p]); put(1, 2, p, g[p] + 0.1 * s[p])
+            desc[p].cur, desc[p].xp, desc[p].spare = 2, 1, 0
+            desc[p].ncorr = 1 if p == 0 else 0
+            desc[p].pcol[0] = m
+        out = np.zeros(P * 8)
+        L.check(core.lbfgsx_bat_iterate(bat, L.OBJ_EXT_ROSENBROCK, desc, out.ctypes.data_as(C.c_void_p)))
+        out = out.reshape(P, 8)
+        assert all(out[p, 2] > eps * out[p, 3] for p in range(P))   # s = 0.05 s, y = 0.1 s: usable everywhere now
+        d0 = get(2, 0, 0)
+        # problem 0: two pairs, newest first (numpy two-loop, BFGSMat.h:276-302)
+        S = [0.05 * s[0], x[0] - xp[0]]
+        Y = [(g[0] + 0.1 * s[0]) - g[0], g[0] - gp[0]]
+        q = -(g[0] + 0.1 * s[0])
+        al = []
+        for si, yi in zip(S, Y):
+            a_ = (si @ q) / (si @ yi)
+            al.append(a_)
+            q = q - a_ * yi
+        q = q / ((Y[0] @ Y[0]) / (S[0] @ Y[0]))
+        for si, yi, a_ in reversed(list(zip(S, Y, al))):
+            q = q + (a_ - (yi @ q) / (si @ yi)) * si
+        assert np.abs(d0 - q).max() <= 1e-11 * np.abs(q).max()
+    finally:
+        core.lbfgsx_bat_destroy(bat)
