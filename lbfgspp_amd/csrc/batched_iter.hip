@@ -116,6 +116,10 @@ struct ItXch
 constexpr int kItMaxParts = 8;
 constexpr int kItXchWords = 2 * kItMaxParts * 4 * 2;  // 16-byte words per problem
 
+// Called by ALL 64 lanes of wave 0; the part's partial sums are in lane 0 (it_block_sum), the totals come back in lane 0.
+// Lane 0 publishes; lane q (q < G, q != r) polls sibling q's words -- the G - 1 round trips run side by side instead of one
+// after the other (G = 8: 14 dependent polls per exchange before) -- and the partials are added in part order from lane 0's
+// point of view by cross-lane reads.
 template <int NS, class A>
 __device__ __forceinline__ bool it_exchange(A (&acc)[NS], const ItXch& xc, int p, int r, unsigned e)
 {
@@ -123,33 +127,45 @@ __device__ __forceinline__ bool it_exchange(A (&acc)[NS], const ItXch& xc, int p
     unsigned* area = xc.base + size_t(p) * kItXchWords * 4;
     const unsigned tag = xc.tag0 + e;
     const int par = int(e & 1u);
+    const int lane = threadIdx.x & 63;
     auto word = [&](int part, int k, int h) { return area + size_t(((par * kItMaxParts + part) * 4 + k) * 2 + h) * 4; };
-#pragma unroll
-    for (int k = 0; k < NS; k++)
-    {
-        persist_publish<false>(word(r, k, 0), tag, acc[k].hi);
-        persist_publish<false>(word(r, k, 1), tag, acc_lo(acc[k]));
-    }
-    A tot[NS];
-    bool ok = true;
-    for (int q = 0; q < xc.G; q++)
+    if (lane == 0)
     {
 #pragma unroll
         for (int k = 0; k < NS; k++)
         {
-            double hi = acc[k].hi, lo = acc_lo(acc[k]);
-            if (q != r)
-            {
-                if (ok)
-                    ok = persist_await(word(q, k, 0), tag, xc.err, hi) && persist_await(word(q, k, 1), tag, xc.err, lo);
-            }
-            tot[k].merge(hi, lo);
+            persist_publish<false>(word(r, k, 0), tag, acc[k].hi);
+            persist_publish<false>(word(r, k, 1), tag, acc_lo(acc[k]));
         }
+    }
+    double hi[NS], lo[NS];
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < NS; k++)
+    {
+        hi[k] = acc[k].hi;  // lane 0: the part's own partial (read back below at position r)
+        lo[k] = acc_lo(acc[k]);
+    }
+    if (lane > 0 && lane <= xc.G - 1)
+    {
+        const int q = lane <= r ? lane - 1 : lane;  // lanes 1 .. G-1 take the siblings 0 .. G-1 without r, in order
+#pragma unroll
+        for (int k = 0; k < NS; k++)
+            if (ok)
+                ok = persist_await(word(q, k, 0), tag, xc.err, hi[k]) && persist_await(word(q, k, 1), tag, xc.err, lo[k]);
+    }
+    A tot[NS];
+    for (int q = 0; q < xc.G; q++)
+    {
+        const int src = q == r ? 0 : (q < r ? q + 1 : q);  // the lane that holds part q's partial
+#pragma unroll
+        for (int k = 0; k < NS; k++)
+            tot[k].merge(__shfl(hi[k], src, 64), __shfl(lo[k], src, 64));
     }
 #pragma unroll
     for (int k = 0; k < NS; k++)
         acc[k] = tot[k];
-    return ok;
+    return __ballot(!ok) == 0ull;
 }
 
 // the first trial of the next search on the direction the block holds: x_t = x + step * d, f and grad there, grad_t . d;
@@ -308,10 +324,10 @@ __global__ void __launch_bounds__(kHvThreads) kb_iter(BatBufs<T> b, const BatItD
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // s, y are re-read by this block below
         it_block_sum<4>(accp, sh);
+        if (G > 1 && tid < 64 && !it_exchange<4>(accp, xc, p, r, xe) && tid == 0)
+            s_bad = 1;
         if (tid == 0)
         {
-            if (G > 1 && !it_exchange<4>(accp, xc, p, r, xe))
-                s_bad = 1;
             const T gg = T(accp[0].value()), xx = T(accp[1].value());
             const T sy = T(accp[2].value()), yy = T(accp[3].value());
             if (r == 0)
@@ -451,10 +467,10 @@ __global__ void __launch_bounds__(kHvThreads) kb_iter(BatBufs<T> b, const BatItD
         for (int k = 1; k < 4; k++)
             acc[0].merge(acc4[k].hi, acc_lo(acc4[k]));
         it_block_sum<1>(acc, sh);
+        if (G > 1 && tid < 64 && !it_exchange<1>(acc, xc, p, r, xe + unsigned(L)) && tid == 0)
+            s_bad = 1;
         if (tid == 0)
         {
-            if (G > 1 && !it_exchange<1>(acc, xc, p, r, xe + unsigned(L)))
-                s_bad = 1;
             const T rr = T(acc[0].value());
             sdot[L] = rr;
             if (r == 0)
@@ -475,7 +491,7 @@ __global__ void __launch_bounds__(kHvThreads) kb_iter(BatBufs<T> b, const BatItD
         acc2[0] = accf;
         acc2[1] = accd;
         it_block_sum<2>(acc2, sh);
-        if (tid == 0 && G > 1 && !it_exchange<2>(acc2, xc, p, r, xe))
+        if (G > 1 && tid < 64 && !it_exchange<2>(acc2, xc, p, r, xe) && tid == 0)
             s_bad = 1;
         accf = acc2[0];
         accd = acc2[1];
