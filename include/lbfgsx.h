@@ -544,8 +544,8 @@ int lbfgsx_bat_apply_Hv(lbfgsx_batch* c, const lbfgsx_bat_hvdesc* desc);
  * The caller's host logic stays the reference's: it reads the sums, applies the stopping tests (a problem that stops has
  * had its direction and trial computed in vain, nothing else), rotates the ring when s.y > eps * y.y, and feeds the trial to the
  * line search it starts.  A problem longer than one block's registers hold (100 352 floats / 50 176 doubles) is split over
- * 2..8 consecutive blocks, each with its share of the direction resident, and the blocks exchange their partial sums at every
- * step (n up to 802 816 floats / 401 408 doubles, a multiple of the 16-byte vector width; m <= 31): lbfgsx_bat_iterate_ok.
+ * 2..16 consecutive blocks, each with its share of the direction resident, and the blocks exchange their partial sums at every
+ * step (n up to 1 605 632 floats / 802 816 doubles, a multiple of the 16-byte vector width; m <= 31): lbfgsx_bat_iterate_ok.
  * LBFGSX_E_INVALID otherwise -- the caller then issues the statement-wise launches.  LBFGSX_E_RUNTIME: the blocks of a split
  * problem were not resident together within 100 ms (something else held the CUs); no sums are returned. */
 int lbfgsx_bat_iterate(lbfgsx_batch* c, int objective, const lbfgsx_bat_itdesc* desc, double* out);

@@ -554,7 +554,7 @@ int lbfgsx_bat_create(lbfgsx_batch** out, int dtype, int64_t n, int m, int nprob
     if (const char* e = getenv("LBFGSX_BAT_FUSED_ITER"))
         c->fused_iter = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_BAT_MIN_PARTS"))
-        c->min_parts = std::max(0, std::min(atoi(e), 8));
+        c->min_parts = std::max(0, std::min(atoi(e), 16));
     if (const char* e = getenv("LBFGSX_BAT_MAX_PARTS"))
         c->max_parts = std::max(0, atoi(e));
     if (const char* e = getenv("LBFGSX_BAT_POLL"))

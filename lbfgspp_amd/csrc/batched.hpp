@@ -217,7 +217,7 @@ struct lbfgsx_batch
     bool fused_hv = true;    // LBFGSX_BAT_FUSED_HV=0: always the step-wise two-loop launches
     bool fused_iter = true;  // LBFGSX_BAT_FUSED_ITER=0: never the one-launch lock-step iteration
     int min_parts = 0;       // LBFGSX_BAT_MIN_PARTS=k: split every problem over at least k blocks (experiments: shorter blocks, several per CU)
-    int max_parts = 0;       // LBFGSX_BAT_MAX_PARTS=k: a problem may be split over at most k blocks (0: as many as it needs, <= 8)
+    int max_parts = 0;       // LBFGSX_BAT_MAX_PARTS=k: a problem may be split over at most k blocks (0: as many as it needs, <= 16)
     unsigned* xch = nullptr; // exchange area of the parts of a problem (batched_iter.hip), allocated on first use
     unsigned xch_seq = 0;
     bool adaptive_gx = true; // LBFGSX_BAT_ADAPTIVE_GX=0: every launch with the batch's blocks per problem

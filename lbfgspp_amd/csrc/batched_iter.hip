@@ -113,7 +113,7 @@ struct ItXch
     unsigned tag0;   // tag of this launch's exchange 0
     int G;
 };
-constexpr int kItMaxParts = 8;
+constexpr int kItMaxParts = 16;
 constexpr int kItXchWords = 2 * kItMaxParts * 4 * 2;  // 16-byte words per problem
 
 // Called by ALL 64 lanes of wave 0; the part's partial sums are in lane 0 (it_block_sum), the totals come back in lane 0.

@@ -105,10 +105,10 @@ def test_one_launch_two_loop_equals_step_wise_launches(monkeypatch, dtype, n):
 
 @pytest.mark.parametrize("dtype,n,m,eps", [(np.float32, 100000, 10, 0.0), (np.float64, 50176, 6, 0.0), (np.float32, 4096, 3, 0.0),
                                             (np.float64, 2048, 5, 1e-3), (np.float32, 100352, 31, 0.0),
-                                            # problems longer than one CU's registers: 2, 3 and 8 blocks per problem with the
+                                            # problems longer than one CU's registers: 2, 3, 8 and 16 blocks per problem with the
                                             # sums exchanged between them at every step
                                             (np.float32, 200000, 10, 0.0), (np.float64, 150016, 6, 0.0),
-                                            (np.float32, 800000, 4, 0.0), (np.float64, 60000, 5, 1e-3),
+                                            (np.float32, 800000, 4, 0.0), (np.float64, 60000, 5, 1e-3), (np.float32, 1600000, 3, 0.0),
                                             # run far past convergence (eps < 0: 600 iterations asked for): searches that give
                                             # up, steps at rounding level, pairs the curvature test rejects
                                             (np.float32, 4096, 5, -1.0), (np.float64, 512, 3, -1.0)])
