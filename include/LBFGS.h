@@ -128,11 +128,13 @@ class LBFGSSolver
         int k = 1;
         for (;;)
         {
+            detail::Range range_iteration("lbfgs:iteration");
             detail::check(lbfgsx_ls_begin(c));
             const Scalar step_max = m_param.max_step;
             ev.trial_written = false;
             try
             {
+                detail::Range range_ls("lbfgs:line_search");
                 // the device form of the built-in policies, or the reference's ten-argument form of a user policy
                 // staged through host vectors (LBFGSpp/Interop.h)
                 detail::run_line_search<Scalar, LineSearch<Scalar>, HostVec>(ev, m_param, step_max, step, fx, dg);
@@ -172,7 +174,10 @@ class LBFGSSolver
                 yyd = gs_scal[3];
             }
             else  // K3, with the recursion of :165 speculated on top of it in the same launch (lbfgsx.h)
+            {
+                detail::Range range_post("lbfgs:post+apply_Hv");
                 detail::check(lbfgsx_post_linesearch_spec(c, -1.0, &g2, &x2, &syd, &yyd));
+            }
             m_gnorm = sqrt(Scalar(g2));
             if (m_gnorm <= m_param.epsilon || m_gnorm <= m_param.epsilon_rel * sqrt(Scalar(x2)))
                 return k;

@@ -113,6 +113,7 @@ private:
         int k = 1;
         for (;;)
         {
+            detail::Range range_iteration("lbfgsb:iteration");
             detail::check(lbfgsx_ls_begin(c));                          // xp = x; gradp = grad (:174-175)
             double dgd = 0, smax = 0;
             // (:176-179); for a built-in objective the pass also evaluates the line search's first trial, which starts at
@@ -140,6 +141,7 @@ private:
             {
                 // the device form of the built-in policies, or the reference's ten-argument form of a user policy
                 // staged through host vectors (LBFGSpp/Interop.h)
+                detail::Range range_ls("lbfgsb:line_search");
                 detail::run_line_search<Scalar, LineSearch<Scalar>, HostVec>(ev, m_param, step_max, step, fx, dg);
             }
             catch (...)
@@ -175,7 +177,10 @@ private:
             m_stats.correction_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_corr).count();
 
             detail::check(lbfgsx_b_force_bounds_deferred(c));           // (:240), evaluated inside the build's pass
-            Cauchy<Scalar>::get_cauchy_point(m_bfgs, gcp);              // (:241)
+            {
+                detail::Range range_gcp("lbfgsb:cauchy_point");
+                Cauchy<Scalar>::get_cauchy_point(m_bfgs, gcp);          // (:241)
+            }
             m_stats.gcp_crossings += gcp.crossings;
             m_stats.gcp_dev_crossings += gcp.dev_crossings;
             m_stats.gcp_sort_fallbacks = gcp.sort_fallbacks;
@@ -188,7 +193,10 @@ private:
             m_stats.gcp_total_s += gcp.t_total;
             typename SubspaceMin<Scalar>::Stats st;
             const auto t_sub = std::chrono::steady_clock::now();
-            SubspaceMin<Scalar>::subspace_minimize(m_bfgs, gcp, m_param.max_submin, &st);  // (:249-250)
+            {
+                detail::Range range_sub("lbfgsb:subspace_min");
+                SubspaceMin<Scalar>::subspace_minimize(m_bfgs, gcp, m_param.max_submin, &st);  // (:249-250)
+            }
             m_stats.submin_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_sub).count();
             m_stats.submin_calls++;
             m_stats.submin_sweeps += st.sweeps;

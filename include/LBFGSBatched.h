@@ -769,7 +769,10 @@ private:
                     d.step = double(q.step);
                 }
             }
-            detail::check(lbfgsx_bat_iterate(c, bobj.id, itd.data(), ires.data()));
+            {
+                detail::Range range_it("batch:iterate");  // [post] + direction + [first trial] of every running problem
+                detail::check(lbfgsx_bat_iterate(c, bobj.id, itd.data(), ires.data()));
+            }
 
             // ---- the reference's statements on the sums, then the start of search k
             for (int p = 0; p < P; p++)
@@ -830,6 +833,7 @@ private:
             // ---- the searches that need more trials, one per launch
             while (searching > 0)
             {
+                detail::Range range_tr("batch:further_trial");
                 clear_desc();
                 for (int p = 0; p < P; p++)
                 {

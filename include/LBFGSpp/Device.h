@@ -32,6 +32,14 @@ inline void check(int rc)
     default: throw std::runtime_error(msg);
     }
 }
+// a phase of the solver as a trace range (lbfgsx_range_push / _pop: ROCTx ranges under LBFGSX_ROCTX=1, else one branch)
+struct Range
+{
+    explicit Range(const char* name) { lbfgsx_range_push(name); }
+    ~Range() { lbfgsx_range_pop(); }
+    Range(const Range&) = delete;
+    Range& operator=(const Range&) = delete;
+};
 template <typename Scalar> struct dtype_of;
 template <> struct dtype_of<double> { static constexpr int value = LBFGSX_F64; };
 template <> struct dtype_of<float> { static constexpr int value = LBFGSX_F32; };

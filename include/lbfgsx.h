@@ -170,6 +170,13 @@ int lbfgsx_poll_counts(const lbfgsx_ctx* c, int64_t out[2]);
  * (the word still unset after the stream drained, or the stream wait returned at once because the kernel had ended long
  * before its store became visible), 1 if this context now waits for its stream instead of polling (after two of those)} */
 int lbfgsx_poll_counts_ex(const lbfgsx_ctx* c, int64_t out[4]);
+/* Tracing: the drop-in solvers bracket their phases -- iteration, line search, post + apply_Hv, the
+ * generalized Cauchy point, the subspace minimisation, a lock-step iteration of the batch -- with these calls.  With
+ * LBFGSX_ROCTX=1 they become ROCTx ranges (roctxRangePushA / roctxRangePop, the marker library loaded with dlopen), which
+ * `rocprofv3 --marker-trace --kernel-trace` shows beside the kernels; otherwise they cost one branch.  `name` must be a string
+ * with static storage duration.  No reference counterpart (the reference has no tracing). */
+void lbfgsx_range_push(const char* name);
+void lbfgsx_range_pop(void);
 
 /* ---- Gram-space ("vector-free") form of the recursion: opt-in, outside the bit-parity contract ----
  * BFGSMat::apply_Hv (BFGSMat.h:276-302) only combines the 2c+1 vectors [S, Y, g]; with their Gram matrix kept on the

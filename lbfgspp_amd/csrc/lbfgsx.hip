@@ -1,5 +1,7 @@
 // lbfgspp_amd/csrc/lbfgsx.hip -- C ABI (include/lbfgsx.h) over the CDNA4 kernels: context, history
 // bookkeeping, unconstrained L-BFGS statements.  Built with hipcc --offload-arch=gfx950 -ffp-contract=off.
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -62,6 +64,40 @@ HostTrace& host_trace_state()
 }
 }  // namespace
 bool host_trace_on() { return host_trace_state().on; }
+
+// ROCTx ranges around the solver's phases (LBFGSX_ROCTX=1; rocprofv3 --marker-trace shows them beside the kernels): the marker
+// library is loaded on first use, so the product has no link-time dependency on a profiler
+namespace {
+struct Roctx
+{
+    bool on = false;
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        const char* e = getenv("LBFGSX_ROCTX");
+        if (!e || e[0] == '0' || !e[0])
+            return;
+        for (const char* lib : {"librocprofiler-sdk-roctx.so", "libroctx64.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so",
+                                "/opt/rocm/lib/libroctx64.so"})
+            if (void* h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL))
+            {
+                push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+                pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (push && pop)
+                {
+                    on = true;
+                    return;
+                }
+            }
+    }
+};
+Roctx& roctx_state()
+{
+    static Roctx r;
+    return r;
+}
+}  // namespace
 void host_trace(const char* tag)
 {
     HostTrace& t = host_trace_state();
@@ -1376,6 +1412,21 @@ int lbfgsx_poll_counts(const lbfgsx_ctx* c, int64_t out[2])
     out[0] = c->poll_waits;
     out[1] = c->poll_timeouts;
     return LBFGSX_OK;
+}
+
+void lbfgsx_range_push(const char* name)
+{
+    Roctx& r = roctx_state();
+    if (r.on && name)
+        (void) r.push(name);
+    if (lbfgsx::host_trace_on() && name)
+        lbfgsx::host_trace(name);  // phase names are string literals of the callers: they outlive the trace
+}
+void lbfgsx_range_pop(void)
+{
+    Roctx& r = roctx_state();
+    if (r.on)
+        (void) r.pop();
 }
 
 int lbfgsx_poll_counts_ex(const lbfgsx_ctx* c, int64_t out[4])
