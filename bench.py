@@ -325,7 +325,9 @@ def run_batched(args, rank, world, local, comm_dev, dist, steps):
     # kept across minimisations (lbfgsx_lockstep_create); then full-size warm-up solves of the very instance that is timed.
     # Inputs (the start points) are generated in HBM by the solve itself, as in every other leg.
     ts = time.perf_counter()
-    batch = B.LockstepBatch(par, n, count, dtype=np.float32, device=local)
+    bdt = np.float64 if args.batched_dtype == "f64" else np.float32
+    esz = 8.0 if args.batched_dtype == "f64" else 4.0
+    batch = B.LockstepBatch(par, n, count, dtype=bdt, device=local)
     for _ in range(max(1, min(args.warmup, 2))):
         batch.minimize(first=first, seed_base=1000)
     setup_s = time.perf_counter() - ts
@@ -360,7 +362,7 @@ def run_batched(args, rank, world, local, comm_dev, dist, steps):
         return None
     its, fev = int(full["niter"].sum()), int(full["nfev"].sum())
     # SURVEY 8(d) algorithmic bytes: (8m+12) n per iteration + 4n per extra trial
-    alg_ = (its * (8 * m + 12) + (fev - its) * 4) * n * 4.0
+    alg_ = (its * (8 * m + 12) + (fev - its) * 4) * n * esz
     # HBM traffic model of the one-launch lock-step iteration (batched_iter.hip; the direction stays on the CU): per problem and
     # iteration k the post pass 6 n, the recursion over c = min(k-1, m) pairs (4c+2) n, drt + the first trial 4 n; 4 n per
     # further trial; 2 n for the evaluation at x0
@@ -368,16 +370,17 @@ def run_batched(args, rank, world, local, comm_dev, dist, steps):
     for it_, fe_ in zip(full["niter"], full["nfev"]):
         it_, fe_ = int(it_), int(fe_)
         hbm_ += sum(6 + 4 * min(k - 1, m) + 2 + 4 for k in range(1, it_ + 1)) + 4 * max(fe_ - 1 - it_, 0) + 2
-    hbm_ *= n * 4.0
+    hbm_ *= n * esz
     model_gbs = hbm_ / elapsed / 1e9 / world
     return {
         "metric": "batched L-BFGS problem-iterations/sec (cfg5: n=%g, m=10, f32)" % n, "value": its / elapsed,
         "unit": "problem-iterations/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
         "ms_per_step": elapsed / max(steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "cfg5: %d independent extended-Rosenbrock problems per GPU, n=%g, m=10, f32, "
-                               "LineSearchMoreThuente, %d iterations each, lock-step batch; contiguous problem-id blocks "
-                               "per rank, no data-path collective, one all-gather of the result records" % (P, n, steps),
+        "vs_baseline": None, "dtype": args.batched_dtype, "data": "synthetic",
+        "config": {"workload": ("cfg5: %d independent extended-Rosenbrock problems per GPU, n=%g, m=10, {DT}, "
+                                "LineSearchMoreThuente, %d iterations each, lock-step batch; contiguous problem-id blocks "
+                                "per rank, no data-path collective, one all-gather of the result records"
+                                % (P, n, steps)).replace("{DT}", args.batched_dtype),
                    "problems_total": total, "fevals_total": fev, "failed": int((full["status"] != 0).sum()),
                    "one_launch_per_iteration": bool(st.get("fused")), "lockstep_iterations": st.get("lockstep_iterations"),
                    "setup_seconds": setup_s,
@@ -399,7 +402,7 @@ def run_batched(args, rank, world, local, comm_dev, dist, steps):
                              "one-launch lock-step iteration ((4c+12) n elements per iteration: the direction stays on the CU) / wall time; "
                              "algorithmic_GBs = SURVEY 8(d)'s (8m+12) n per iteration / wall time, which counts the q "
                              "traffic that never reaches HBM and may therefore exceed the peak"},
-                     **traffic_fields(leg_traffic("cfg5", n, m)))}
+                     **traffic_fields(leg_traffic("cfg5", n, m) if args.batched_dtype == "f32" else None))}
 
 
 def leg_traffic(kind, n, m):
@@ -1186,6 +1189,7 @@ def main():
                          "of <= 6m+7 doubles over RCCL)")
     ap.add_argument("--problems-per-gpu", type=int, default=1024)
     ap.add_argument("--batched-n", type=float, default=1e5, help="dimension of the batched leg's problems (cfg5: 1e5)")
+    ap.add_argument("--batched-dtype", default="f32", choices=["f32", "f64"], help="scalar type of the batched leg (cfg5: f32)")
     ap.add_argument("--batched-steps", type=int, default=50, help="iterations per problem of the cfg5 leg of the default line")
     ap.add_argument("--no-batched", action="store_true", help="skip the cfg5 leg of the default line")
     ap.add_argument("--single-process", action="store_true",
