@@ -69,12 +69,12 @@ private:
     // same device: a second minimize() re-uses it (lbfgsx_bat_reset) instead of allocating ~12 GB again.
     lbfgsx_batch* m_ctx = nullptr;
     std::int64_t m_ctx_n = 0;
-    int m_ctx_P = 0, m_ctx_dev = -1;
+    int m_ctx_P = 0, m_ctx_dev = -1, m_ctx_m = 0;  // (the param object is held by reference: its m may change between calls)
     bool m_timing = false;
 
     lbfgsx_batch* acquire(std::int64_t n, int P, int device)
     {
-        if (m_ctx && (m_ctx_n != n || m_ctx_P != P || m_ctx_dev != device))
+        if (m_ctx && (m_ctx_n != n || m_ctx_P != P || m_ctx_dev != device || m_ctx_m != m_param.m))
             release();
         if (!m_ctx)
         {
@@ -82,6 +82,7 @@ private:
             m_ctx_n = n;
             m_ctx_P = P;
             m_ctx_dev = device;
+            m_ctx_m = m_param.m;
         }
         else
             detail::check(lbfgsx_bat_reset(m_ctx));
