@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <functional>
 #include <limits>
 #include <exception>
@@ -732,12 +733,23 @@ private:
             }
         };
 
-        for (int k = 1; remaining > 0; k++)
+        // Every problem carries its own iteration counter: with a built-in objective a problem whose search needs a further
+        // trial rides the NEXT launch with a trial-only descriptor while the others go on with their next iteration, so a
+        // step of the batch is one launch and one host wait whatever the searches do (the problems are independent: each
+        // follows the trajectory of its stand-alone solve).  With a user objective (evaluated by the caller for the whole
+        // batch between two launches) the further trials stay statement-wise launches behind the one that opened the search.
+        // Measured on cfg5 (1024 problems = 4 x 256 CUs): the asynchronous form needs 69 launches instead of 100 but is 8 % SLOWER
+        // (277 k against 300 k problem-iterations/s) -- in lock step every launch is four full rounds of equal blocks, out of
+        // step the long blocks of a launch fill 3.x rounds and the last one runs mostly empty.  So it is opt-in
+        // (LBFGSX_BAT_ASYNC_TRIALS=1; it pays when the batch is not a multiple of the CU count or searches are long).
+        const char* async_env = std::getenv("LBFGSX_BAT_ASYNC_TRIALS");
+        const bool async_trials = fuse_trial && async_env && async_env[0] == '1';
+        std::vector<int> kit(static_cast<size_t>(P), 1);  // iteration whose line search is next / running
+        while (remaining > 0)
         {
             stats.lockstep_iterations++;
-            const int kk = k - 1;  // the iteration whose line search has just finished (k > 1)
-            const bool last = (k > 1 && m_param.max_iterations != 0 && kk >= m_param.max_iterations);
-            // ---- one launch: [statements after search kk] + drt = -H grad + [first trial of search k]
+            // ---- one launch: per problem either [statements after search k-1] + drt = -H grad + [first trial of search k],
+            //      or a further trial of the search that is running
             for (int p = 0; p < P; p++)
             {
                 Prob& q = pr[size_t(p)];
@@ -746,6 +758,16 @@ private:
                 if (q.done)
                     continue;
                 d.active = 1;
+                if (q.in_ls)  // (only with async_trials: the statement-wise loop below leaves no search open)
+                {
+                    d.flags = LBFGSX_BAT_IT_TRIAL_ONLY;
+                    d.xp = q.xp;
+                    d.trial = q.trial;
+                    d.step = double(q.mt.step());
+                    continue;
+                }
+                const int k = kit[size_t(p)];
+                const bool last = (k > 1 && m_param.max_iterations != 0 && k - 1 >= m_param.max_iterations);
                 d.cur = q.cur;
                 d.ncorr = q.ncorr;
                 int j = q.ptr % m;
@@ -760,7 +782,7 @@ private:
                     d.flags |= LBFGSX_BAT_IT_POST;
                     d.xp = q.xp;
                     d.spare = q.spare;
-                    if (last)  // every problem still running stops at max_iterations (LBFGS.h:152-155): sums only
+                    if (last)  // a problem still running stops at max_iterations (LBFGS.h:152-155): sums only
                         d.flags |= LBFGSX_BAT_IT_POST_ONLY;
                 }
                 if (fuse_trial && !last)
@@ -771,11 +793,11 @@ private:
                 }
             }
             {
-                detail::Range range_it("batch:iterate");  // [post] + direction + [first trial] of every running problem
+                detail::Range range_it("batch:iterate");
                 detail::check(lbfgsx_bat_iterate(c, bobj.id, itd.data(), ires.data()));
             }
 
-            // ---- the reference's statements on the sums, then the start of search k
+            // ---- the reference's statements on the sums
             for (int p = 0; p < P; p++)
             {
                 Prob& q = pr[size_t(p)];
@@ -783,8 +805,17 @@ private:
                     continue;
                 const double* r = &ires[size_t(p) * LBFGSX_BAT_NRES];
                 Item& it = out[size_t(p)];
+                int& k = kit[size_t(p)];
+                if (q.in_ls)  // a further trial of search k (async_trials)
+                {
+                    consume(p, Scalar(r[5]), Scalar(r[6]), k);
+                    if (!q.in_ls && !q.done)
+                        k++;
+                    continue;
+                }
                 if (k > 1)
                 {
+                    const int kk = k - 1;  // the iteration whose line search has finished
                     // gnorm, x.norm, s.y, y.y                                           (LBFGS.h:130,137,159-161)
                     const Scalar g2 = Scalar(r[0]), x2 = Scalar(r[1]), sy = Scalar(r[2]), yy = Scalar(r[3]);
                     q.gnorm = sqrt(g2);
@@ -829,9 +860,15 @@ private:
                 catch (const std::invalid_argument& e) { fail(q, it, LBFGSX_E_INVALID, e.what(), k); remaining--; }
                 catch (const std::logic_error& e) { fail(q, it, LBFGSX_E_LOGIC, e.what(), k); remaining--; }
                 if (q.in_ls && fuse_trial)
+                {
                     consume(p, Scalar(r[5]), Scalar(r[6]), k);
+                    if (async_trials && !q.in_ls && !q.done)
+                        k++;
+                }
             }
-            // ---- the searches that need more trials, one per launch
+            if (async_trials)
+                continue;
+            // ---- the searches' further trials, one per launch (lock step: every search ends before the next iteration starts)
             while (searching > 0)
             {
                 detail::Range range_tr("batch:further_trial");
@@ -850,8 +887,11 @@ private:
                 launch_trial();
                 for (int p = 0; p < P; p++)
                     if (pr[size_t(p)].in_ls)
-                        consume(p, Scalar(res[size_t(p) * 2 + 0]), Scalar(res[size_t(p) * 2 + 1]), k);
+                        consume(p, Scalar(res[size_t(p) * 2 + 0]), Scalar(res[size_t(p) * 2 + 1]), kit[size_t(p)]);
             }
+            for (int p = 0; p < P; p++)  // every search of this step has ended
+                if (!pr[size_t(p)].done)
+                    kit[size_t(p)]++;
         }
 
         for (int p = 0; p < P; p++)

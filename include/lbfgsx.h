@@ -487,7 +487,10 @@ enum
 {
     LBFGSX_BAT_IT_POST = 1,      /* the statements after a finished line search first (xp -> cur, pair into column `spare`) */
     LBFGSX_BAT_IT_POST_ONLY = 2, /* ... and nothing else: the caller already knows that this problem stops */
-    LBFGSX_BAT_IT_TRIAL = 4      /* the first trial of the next line search last (built-in objectives only) */
+    LBFGSX_BAT_IT_TRIAL = 4,     /* the first trial of the next line search last (built-in objectives only) */
+    LBFGSX_BAT_IT_TRIAL_ONLY = 8 /* nothing but a further trial of a search that goes on: x_trial = x(xp) + step * drt (drt as
+                                  * the launch that opened the search left it), results 5 and 6.  Lets problems at different
+                                  * points of their iteration share the launch */
 };
 #define LBFGSX_BAT_NRES 8        /* doubles per problem in the result table of a launch */
 typedef struct

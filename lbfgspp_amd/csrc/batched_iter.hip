@@ -277,6 +277,63 @@ __global__ void __launch_bounds__(kHvThreads) kb_iter(BatBufs<T> b, const BatItD
     if (tid == 0)
         s_bad = 0;
 
+    if (de.flags & LBFGSX_BAT_IT_TRIAL_ONLY)
+    {
+        // ---- a further trial of a search that goes on (kb_trial's statements): x_t = xp + step * drt from memory, f, grad, grad.drt.
+        // Problems at different points of their iteration share a launch: the ones whose search has ended run the full
+        // sequence below, the others this pass -- one launch and one host wait per step instead of two.
+        const T* xs = b.x(de.xp, p);
+        const T* dv = b.d(p);
+        T* xt = b.x(de.trial, p);
+        T* gt = b.g(de.trial, p);
+        const T step = T(de.step);
+        const auto obj = objs.bind(p);
+        A acc2[2];
+        constexpr int TU = 8;
+        for (int64_t v0 = tid; v0 < nv; v0 += int64_t(kHvThreads) * TU)
+        {
+            Pack<T> pxp[TU], pd[TU];
+#pragma unroll
+            for (int k = 0; k < TU; k++)
+            {
+                const int64_t vl = v0 + int64_t(k) * kHvThreads;
+                const int64_t vc = vl < nv ? voff + vl : int64_t(0);
+                pxp[k] = ldv<T, true>(xs, vc);
+                pd[k] = ldv<T, true>(dv, vc);
+            }
+#pragma unroll
+            for (int k = 0; k < TU; k++)
+            {
+                const int64_t vl = v0 + int64_t(k) * kHvThreads;
+                if (vl < nv)
+                {
+                    const int64_t vi = voff + vl;
+                    Pack<T> xn, gn;
+#pragma unroll
+                    for (int e = 0; e < W; e++)
+                        xn.e[e] = pxp[k].e[e] + step * pd[k].e[e];
+                    obj.pack(vi, xn, gn, acc2[0]);
+                    stv(xt, vi, xn);
+                    stv(gt, vi, gn);
+#pragma unroll
+                    for (int e = 0; e < W; e++)
+                        acc2[1].add_prod(gn.e[e], pd[k].e[e]);
+                }
+            }
+        }
+        it_block_sum<2>(acc2, sh);
+        if (G > 1 && tid < 64 && !it_exchange<2>(acc2, xc, p, r, xe) && tid == 0)
+            s_bad = 1;
+        if (tid == 0 && r == 0)
+        {
+            bat_result(ws, p, 5, double(obj.finish(T(acc2[0].value()))));
+            bat_result(ws, p, 6, double(T(acc2[1].value())));
+            bat_result(ws, p, 7, s_bad ? 1.0 : 0.0);
+            bat_signal(ws);
+        }
+        return;
+    }
+
     Pack<T> rq[NR];
     if (post)
     {
@@ -589,7 +646,7 @@ int lbfgsx_bat_iterate(lbfgsx_batch* c, int objective, const lbfgsx_bat_itdesc* 
         if (desc[p].active)
         {
             nactive++;
-            any_trial = any_trial || (desc[p].flags & LBFGSX_BAT_IT_TRIAL) != 0;
+            any_trial = any_trial || (desc[p].flags & (LBFGSX_BAT_IT_TRIAL | LBFGSX_BAT_IT_TRIAL_ONLY)) != 0;
             if (desc[p].ncorr < 0 || desc[p].ncorr > c->m || desc[p].ncorr > 32)
             {
                 set_error("lbfgsx_bat_iterate: ncorr out of range");

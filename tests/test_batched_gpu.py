@@ -120,11 +120,13 @@ def test_one_launch_iteration_equals_statement_wise_launches(monkeypatch, dtype,
     from lbfgspp_amd import batched as B
     par = A.LBFGSParam(m=m, epsilon=max(eps, 0.0), epsilon_rel=0.0, max_iterations=(400 if eps > 0 else 600 if eps < 0 else m + 6))
     got = {}
-    for name, it, hv in (("iterate", "1", "1"), ("apply_Hv", "0", "1"), ("steps", "0", "0")):
+    for name, it, hv, asy in (("iterate", "1", "1", "0"), ("apply_Hv", "0", "1", "0"), ("steps", "0", "0", "0"),
+                              ("async", "1", "1", "1")):
         monkeypatch.setenv("LBFGSX_BAT_FUSED_ITER", it)
         monkeypatch.setenv("LBFGSX_BAT_FUSED_HV", hv)
+        monkeypatch.setenv("LBFGSX_BAT_ASYNC_TRIALS", asy)  # problems still searching ride the next launch (trial-only mode)
         got[name] = B.solve_local_lockstep(par, n, first=3, count=7, seed_base=5, dtype=dtype, return_x=True)
-    for name in ("apply_Hv", "steps"):
+    for name in ("apply_Hv", "steps", "async"):
         assert np.array_equal(got["iterate"][0], got[name][0]), name
         assert np.array_equal(got["iterate"][1], got[name][1]), name
     if eps < 0:
@@ -141,7 +143,7 @@ def test_resident_batch_is_reused_across_minimisations(A):
     n, count = 20000, 6
     batch = B.LockstepBatch(par, n, count, dtype=np.float32, device=0)
     a, xa = batch.minimize(first=0, seed_base=11, return_x=True)
-    assert batch.stats["fused"] and batch.stats["lockstep_iterations"] == 10 and batch.stats["kernel_ms"] == 0.0
+    assert batch.stats["fused"] and batch.stats["lockstep_iterations"] >= 10 and batch.stats["kernel_ms"] == 0.0
     b, xb = batch.minimize(first=10, seed_base=11, return_x=True)
     batch.set_timing(True)
     c, xc = batch.minimize(first=0, seed_base=11, return_x=True)
