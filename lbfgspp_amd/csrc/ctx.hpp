@@ -233,6 +233,7 @@ struct lbfgsx_ctx
     // lbfgsx_post_linesearch_spec: the post statements ran as step 0 of a persistent launch that went on to compute the
     // direction for "history + the pending pair"; lbfgsx_apply_Hv returns that result when the pair was committed
     bool fuse_post = true;         // LBFGSX_FUSE_POST=0: never speculate
+    bool fast_persist_out = true;  // LBFGSX_PERSIST_POLL=0: the fused launch's scalars by copies + stream wait (round 5)
     // the line search's first trial, evaluated ahead by lbfgsx_b_dg_maxstep_trial (L-BFGS-B): what lbfgsx_trial returns when it
     // is asked for exactly this step of this objective between these buffers -- and forgets otherwise
     bool st_valid = false;

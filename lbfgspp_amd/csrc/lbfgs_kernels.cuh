@@ -980,14 +980,24 @@ __global__ void __launch_bounds__(kHvThreads, 2)
                     sy = T(accp[2].value());
                     yy = T(accp[3].value());
                     d0 = T(accp[4].value());
-                    pf.out[0] = T(accp[0].value());
-                    pf.out[1] = T(accp[1].value());
-                    pf.out[2] = sy;
-                    pf.out[3] = yy;
+                    // the host's copies: write-through system-scope stores (the slot may be host-mapped, and the block that
+                    // signals the host at the END of the launch is another one, possibly in another XCD: a plain store could
+                    // still sit in this XCD's L2 then)
+                    __hip_atomic_store(pf.out + 0, T(accp[0].value()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(pf.out + 1, T(accp[1].value()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(pf.out + 2, sy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(pf.out + 3, yy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     __hip_atomic_store(pf.ys_slot, sy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(pf.theta_slot, yy / sy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(sc + DOT0, d0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(pf.verdict, (sy > pf.eps * yy) ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (!(sy > pf.eps * yy))
+                    {
+                        // pair rejected: the launch ends here -- tell a polling host now (slot 5: 2 = rejected, 1 = the
+                        // recursion ran to its end; slot 4: grad . d)
+                        __hip_atomic_store(pf.out + 5, T(2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        ws_signal(ws);
+                    }
                     persist_publish(gen + 8, want0, double(sy));
                     persist_publish(gen + 12, want0, double(yy));
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1213,6 +1223,15 @@ __global__ void __launch_bounds__(kHvThreads, 2)
                 __hip_atomic_store(sc + DOT0 + L, dv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (!pa.pub_first && L < 2 * cn)  // the last dot is only read by the host
                     persist_publish(gen + 4, want, double(dv));
+                if (FUSE && L == 2 * cn)
+                {
+                    // the launch's last meeting point: everything the host reads next is known -- grad . d here, the post
+                    // statements' sums since step 0.  A polling host (poll_arm) goes on while the blocks store the
+                    // resident part of d; the kernels it launches are ordered behind this one by the stream.
+                    __hip_atomic_store(pf.out + 4, dv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(pf.out + 5, T(1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    ws_signal(ws);
+                }
             }
             continue;
         }

@@ -378,6 +378,8 @@ static int create_fill(lbfgsx_ctx* c, int dtype, int64_t n, int m, int device, i
         c->meet_pub_first = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_TRIAL_POLICY"))
         c->trial_policy = atoi(e);
+    if (const char* e = getenv("LBFGSX_PERSIST_POLL"))
+        c->fast_persist_out = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_FUSE_POST"))
         c->fuse_post = atoi(e) != 0;
     {
@@ -412,10 +414,11 @@ static int create_fill(lbfgsx_ctx* c, int dtype, int64_t n, int m, int device, i
     LBFGSX_HIP(hipHostMalloc(&c->hout, sizeof(double) * 64, hipHostMallocDefault));
     {
         // measured (round 1g): L-BFGS-B, ~50 scalar fetches per iteration: +1 % steady state, +3.5 % from a cold start;
-        // L-BFGS north-star, 3 fetches per 12 ms iteration: -0.3 % (a store over PCIe at the end of a kernel costs more
-        // than the copy it saves).  Hence on for bounded contexts only; LBFGSX_MAPPED_OUT=0|1 forces either way.
+        // L-BFGS north-star, 3 fetches per 12 ms iteration: -0.3 % then (stream waits only).  Re-measured in round 6 with the
+        // polled completion word serving the trial's wait: cfg2 1184 -> 1197 it/s (+1.1 %, twice, interleaved), north-star
+        // 91.55 -> 91.65 (three pairs), cfg3 unchanged.  On for every context; LBFGSX_MAPPED_OUT=0|1 forces either way.
         const char* e = getenv("LBFGSX_MAPPED_OUT");
-        if (e ? atoi(e) != 0 : (flags & LBFGSX_FLAG_BOUNDED) != 0)
+        if (e ? atoi(e) != 0 : true)
         {
             LBFGSX_HIP(hipHostMalloc(&c->outmap_host, sizeof(double) * 16, hipHostMallocMapped | hipHostMallocCoherent));
             std::memset(c->outmap_host, 0, sizeof(double) * 16);
@@ -1253,6 +1256,14 @@ static int post_spec_t(lbfgsx_ctx* c, T a, double* r4)
         LBFGSX_HIP(hipEventCreate(&hv.b));
         LBFGSX_HIP(hipEventRecord(hv.a, c->stream));
     }
+    // With host-mapped outputs the launch's closing block tells a polling host when the six scalars it reads next are out
+    // (round 6): no copies, no stream wait -- the resident part of d is still being stored then, which only kernels need.
+    const bool fast_out = c->meet_all && c->outmap_dev && c->done_host && !c->poll_off && c->fast_persist_out;
+    if (fast_out)
+    {
+        static_cast<volatile T*>(c->outmap_host)[5] = T(0);
+        lbfgsx::poll_arm(c);
+    }
     if (c->meet_all)
         LBFGSX_LAUNCH((k_twoloop_persist<T, true, true>), dim3(c->persist_grid), dim3(kHvThreads), 0, c->stream, P<T>(c->d),
                            P<T>(c->gb[c->cur]), a, P<T>(c->S), P<T>(c->Y), c->n, sc, pa, c->ws, c->gen_dev,
@@ -1270,16 +1281,37 @@ static int post_spec_t(lbfgsx_ctx* c, T a, double* r4)
         c->fused_timed++;
     }
     int hflags[2] = {0, 0};  // time-out flag, verdict
-    LBFGSX_HIP(lbfgsx::copy_async(hflags, c->gen_dev + 1, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    // the five scalars the host needs, one synchronisation: dg = grad . d, then {g.g, x.x, s.y, y.y}
-    T* h = static_cast<T*>(c->hout);
-    LBFGSX_HIP(lbfgsx::copy_async(h, sc + c->sl.dot(2 * cn), sizeof(T), hipMemcpyDeviceToHost, c->stream));
-    if (!c->outmap_dev)
-        LBFGSX_HIP(lbfgsx::copy_async(h + 8, sc + c->sl.out(0), 4 * sizeof(T), hipMemcpyDeviceToHost, c->stream));
-    LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
-    const double dgv = double(h[0]);
-    for (int i = 0; i < 4; i++)
-        r4[i] = c->outmap_dev ? double(static_cast<const volatile T*>(c->outmap_host)[i]) : double(h[8 + i]);
+    double dgv = 0.0;
+    bool have = false;
+    if (fast_out)
+    {
+        const unsigned long long want = c->done_seq;
+        LBFGSX_HIP(lbfgsx::poll_wait(c));
+        const volatile T* o = static_cast<const volatile T*>(c->outmap_host);
+        // signalled (and not a stale word): the scalars are there.  Otherwise -- a meeting point timed out and the blocks left
+        // without a word -- the stream has drained inside poll_wait and the copies below tell what happened.
+        if (*static_cast<volatile unsigned long long*>(c->done_host) >= want && (o[5] == T(1) || o[5] == T(2)))
+        {
+            hflags[1] = int(o[5]);
+            dgv = double(o[4]);
+            for (int i = 0; i < 4; i++)
+                r4[i] = double(o[i]);
+            have = true;
+        }
+    }
+    if (!have)
+    {
+        LBFGSX_HIP(lbfgsx::copy_async(hflags, c->gen_dev + 1, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        // the five scalars the host needs, one synchronisation: dg = grad . d, then {g.g, x.x, s.y, y.y}
+        T* h = static_cast<T*>(c->hout);
+        LBFGSX_HIP(lbfgsx::copy_async(h, sc + c->sl.dot(2 * cn), sizeof(T), hipMemcpyDeviceToHost, c->stream));
+        if (!c->outmap_dev)
+            LBFGSX_HIP(lbfgsx::copy_async(h + 8, sc + c->sl.out(0), 4 * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+        LBFGSX_HIP(lbfgsx::stream_sync(c->stream));
+        dgv = double(h[0]);
+        for (int i = 0; i < 4; i++)
+            r4[i] = c->outmap_dev ? double(static_cast<const volatile T*>(c->outmap_host)[i]) : double(h[8 + i]);
+    }
     if (hflags[0])
     {
         // a meeting point timed out (device shared with another process): reset, never speculate again, redo with k_post
