@@ -1,7 +1,7 @@
 #!/bin/bash
 # the north-star's timed iterations, in order: launches and waits with the host time between them (LBFGSX_HOST_TRACE)
 cd $GRAFT_REPO_ROOT
-LBFGSX_HOST_TRACE=/tmp/htn.txt python bench.py --no-cpu --no-batched --no-legs --steps 6 --warmup 11 > /dev/null 2>&1
+LBFGSX_HOST_TRACE=/tmp/htn.txt python bench.py --no-cpu --no-batched --no-legs --steps 6 --warmup 11 $NS_ARGS > /dev/null 2>&1
 python - <<'PY'
 ev=[l.rstrip("\n").split(" ",1) for l in open("/tmp/htn.txt")]
 ev=[(int(t),g) for t,g in ev]
