@@ -614,3 +614,34 @@ def test_drift_against_the_native_accumulator_reference(A, obj, ls, window, tol)
     err = np.abs(tg.xs[:k] - tn.xs[:k]).max(axis=1)
     assert err.max() <= tol, "evaluation %d deviates by %.3g" % (int(err.argmax()), err.max())
     assert err[:8].max() <= 1e-13                          # SURVEY probe: 1.7e-13 at K = 10
+
+
+def test_fused_persistent_launch_signals_a_polling_host_and_changes_no_bit(A, monkeypatch):
+    """Round 6: with host-mapped outputs the fused persistent launch's closing block stores the six scalars the host reads next
+    with system-scope stores and then the completion word; the host polls (no copies, no stream wait) while the blocks still
+    store the resident part of d.  Against LBFGSX_PERSIST_POLL=0 (copies + stream wait) and LBFGSX_MAPPED_OUT=0 (round 5's
+    L-BFGS path): the same trajectory bit for bit; the waits are served by polling and none runs into the time-out."""
+    import ctypes as C
+    from lbfgspp_amd import _lib as L
+    core, _ = L.load()
+    n, iters = 6_000_000, 30
+    res = {}
+    for name, mapped, ppoll in (("poll", "1", "1"), ("copies", "1", "0"), ("round5", "0", "0")):
+        monkeypatch.setenv("LBFGSX_MAPPED_OUT", mapped)
+        monkeypatch.setenv("LBFGSX_PERSIST_POLL", ppoll)
+        s = A.LBFGSSolver(A.LBFGSParam(m=7, epsilon=0.0, epsilon_rel=0.0, max_iterations=iters), linesearch=A.LS_MORE_THUENTE)
+        ctx = s.prepare(n)
+        L.check(core.lbfgsx_gen_rosen_x0(ctx, 7))
+        niter, fx = s.minimize_resident(A.ExtendedRosenbrock(), n)
+        x = np.empty(n)
+        L.check(core.lbfgsx_download(ctx, L.VEC_X, x.ctypes.data_as(C.c_void_p)))
+        pc = (C.c_int64 * 4)()
+        L.check(core.lbfgsx_poll_counts_ex(ctx, C.byref(pc)))
+        res[name] = (niter, s.last.nfev, fx, x, [int(v) for v in pc])
+        s.close()
+    for other in ("copies", "round5"):
+        assert res["poll"][:3] == res[other][:3] and np.array_equal(res["poll"][3], res[other][3]), other
+    waits, timeouts, bad, off = res["poll"][4]
+    assert waits >= 2 * iters - 4 and timeouts == 0 and bad == 0 and off == 0   # every trial and every fused launch
+    assert res["round5"][4][0] == 0
+    assert res["copies"][4][0] < waits
