@@ -1087,7 +1087,7 @@ def run_all(args, rank, world, local, comm_dev, dist, batched=True):
 VERBOSE_ONLY = ("note", "per_iteration_ms", "traffic_source", "traffic_per", "achieved_is", "instance", "how")
 # secondary figures of the headline's own objects that only the --verbose line carries
 VERBOSE_ONLY_TOP = ("max_abs_dx_at", "x_inf_norm", "max_abs_dx_strided_sample", "stream_triad_GBs", "apply_Hv_GBs",
-                    "hbm_model_bytes_per_launch", "fused_post_launches_timed", "warmup_run", "problems_per_gpu", "traffic_static",
+                    "hbm_model_bytes_per_launch", "fused_post_launches_timed", "warmup_run", "problems_per_gpu",
                     "algorithmic_GBs", "timed_iterations", "seconds_per_iteration", "measured_value")
 FULL_PRECISION = ("fx", "value", "ms_per_step", "max_abs_dx", "fx_rel", "seconds")
 

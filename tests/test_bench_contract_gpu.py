@@ -37,6 +37,8 @@ def test_default_line_has_the_contract_keys(tmp_path):
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in line, k
     assert list(line)[-1] == "legs_digest"
+    # `traffic` comes from committed PMC passes of the same command, not from this run: the default line says so itself
+    assert line["roofline"]["traffic"] is None or line["roofline"]["traffic_static"] is True
     dig = line["legs_digest"]
     assert sorted(dig) == sorted(["north_star", "cfg2", "cfg3", "cfg4_lbfgsb", "cfg4_m20", "cfg5_batched"])
     for name, e in dig.items():
