@@ -13,10 +13,13 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <stdexcept>
+#include <string>
 #include <vector>
 
 #include "BKLDLT.h"
 #include "Device.h"
+#include "Interop.h"
 
 namespace LBFGSpp {
 
@@ -665,6 +668,85 @@ public:
     }
 
     lbfgsx_ctx* ctx() const { return m_c; }
+};
+
+
+// ---------------------------------------------------------------- the reference's own class, for a program that drives it
+// BFGSMat<Scalar> (LBFGSB = false) with the reference's member signatures over HOST vectors
+// (/root/reference/include/LBFGSpp/BFGSMat.h:61 reset, :81 add_correction, :276 apply_Hv, :307 theta, :310 num_corrections,
+// :150 get_Bmat, :211 get_Hmat).  The solvers of this build do not go through it -- they keep x, grad and the search on the
+// device (LBFGS.h) -- but a program that owns its own outer loop and calls the matrix directly compiles and runs: S and Y live
+// in HBM inside a device context, add_correction uploads the pair (2n elements over PCIe), apply_Hv uploads v, runs the same
+// two-loop kernels as the solvers (persistent launch when it fits) and downloads the product.  Any vector type with data(),
+// size() and resize() works (Eigen::Matrix, std::vector).
+// The L-BFGS-B half (apply_Wtv ... apply_PtBQv over index sets, :315-615) is the device-side BFGSMatB above: its operators take
+// the free / active sets as the state bytes the device Cauchy search leaves in HBM, not as std::vector<int>.
+template <typename Scalar, bool LBFGSB = false>
+class BFGSMat
+{
+    static_assert(!LBFGSB, "BFGSMat<Scalar, true>: the L-BFGS-B operators of this build are LBFGSpp::BFGSMatB (device-side index sets)");
+    DeviceState<Scalar> m_dev;
+    int m_device = 0;
+
+    void need() const
+    {
+        if (!m_dev.ctx())
+            throw std::logic_error("BFGSMat: reset(n, m) has not been called");
+    }
+    template <typename Vec>
+    void same_size(const Vec& v, const char* what) const
+    {
+        if (std::int64_t(v.size()) != m_dev.size())
+            throw std::invalid_argument(std::string("BFGSMat: '") + what + "' must have the dimension given to reset()");
+    }
+
+public:
+    BFGSMat() {}
+    void set_device(int device) { m_device = device; }  // takes effect at the next reset()
+
+    // allocate (or keep) the n x m stores; theta = 1, no corrections (:61-78)
+    void reset(int n, int m)
+    {
+        if (n < 1 || m < 1)
+            throw std::invalid_argument("BFGSMat: n and m must be positive");
+        m_dev.ensure(n, m, 0, m_device);
+        detail::check(lbfgsx_bfgs_reset(m_dev.ctx()));
+    }
+    // the pair goes into slot ptr % m; ys = s.y, theta = y.y / ys (:81-97)
+    template <typename VecS, typename VecY>
+    void add_correction(const VecS& s, const VecY& y)
+    {
+        need();
+        same_size(s, "s");
+        same_size(y, "y");
+        detail::check(lbfgsx_bfgs_add_correction_host(m_dev.ctx(), s.data(), y.data()));
+    }
+    // res = a * H * v, the two-loop recursion (:276-302)
+    template <typename VecV, typename VecR>
+    void apply_Hv(const VecV& v, const Scalar& a, VecR& res)
+    {
+        need();
+        same_size(v, "v");
+        m_dev.upload(LBFGSX_VEC_G, v.data());
+        double dg = 0;
+        detail::check(lbfgsx_apply_Hv(m_dev.ctx(), LBFGSX_VEC_G, double(a), &dg));
+        res.resize(m_dev.size());
+        m_dev.download(LBFGSX_VEC_D, res.data());
+    }
+    Scalar theta() const { need(); return Scalar(lbfgsx_bfgs_theta(m_dev.ctx())); }
+    int num_corrections() const { need(); return lbfgsx_bfgs_ncorr(m_dev.ctx()); }
+    // explicit n x n matrices from a copy of the history: a debugging aid for small n, as in the reference (:150-271)
+    detail::ResultMatrix<Scalar> get_Bmat() const
+    {
+        need();
+        return detail::to_result_matrix(detail::dense_B(detail::fetch_history<Scalar>(m_dev.ctx(), int(m_dev.size()), m_dev.m())));
+    }
+    detail::ResultMatrix<Scalar> get_Hmat() const
+    {
+        need();
+        return detail::to_result_matrix(detail::dense_H(detail::fetch_history<Scalar>(m_dev.ctx(), int(m_dev.size()), m_dev.m())));
+    }
+    lbfgsx_ctx* ctx() const { return m_dev.ctx(); }
 };
 
 }  // namespace LBFGSpp
