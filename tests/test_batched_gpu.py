@@ -135,6 +135,37 @@ def test_one_launch_iteration_equals_statement_wise_launches(monkeypatch, dtype,
         assert len(set(got["iterate"][0]["niter"])) > 1, got["iterate"][0]["niter"]  # the case the parameter is there for
 
 
+@pytest.mark.parametrize("dtype,n,m,count", [(np.float32, 8, 1, 1), (np.float64, 4, 2, 3), (np.float32, 260, 2, 1), (np.float64, 2, 1, 2),
+                                              (np.float32, 4, 31, 5), (np.float32, 100352, 1, 1)])
+def test_one_launch_iteration_at_the_edges(monkeypatch, dtype, n, m, count):
+    """the smallest shapes the one-launch iteration accepts -- a single problem, one 16-byte vector per problem, m = 1 (the
+    recursion is three steps), m far above what n can fill, the largest n of one block with the shortest history -- against
+    the statement-wise launches and against the single-problem solver"""
+    import lbfgspp_amd as A
+    from lbfgspp_amd import batched as B
+    par = A.LBFGSParam(m=m, epsilon=0.0, epsilon_rel=0.0, max_iterations=12)
+    got = {}
+    for name, it, hv in (("iterate", "1", "1"), ("steps", "0", "0")):
+        monkeypatch.setenv("LBFGSX_BAT_FUSED_ITER", it)
+        monkeypatch.setenv("LBFGSX_BAT_FUSED_HV", hv)
+        got[name] = B.solve_local_lockstep(par, n, first=2, count=count, seed_base=9, dtype=dtype, return_x=True)
+    assert np.array_equal(got["iterate"][0], got["steps"][0])
+    assert np.array_equal(got["iterate"][1], got["steps"][1])
+    recs = got["iterate"][0]
+    s = A.LBFGSSolver(par, linesearch=A.LS_MORE_THUENTE, dtype=dtype)
+    for k in range(count):
+        x = O.rosen_x0(n, 9 + 2 + k, O.F32 if dtype == np.float32 else O.F64).copy()
+        try:
+            niter, fx = s.minimize(A.ExtendedRosenbrock(), x)
+            status = 0
+        except (RuntimeError, ArithmeticError, ValueError):
+            status, niter, fx = s.last.status, s.last.niter, s.last.fx
+        assert recs["status"][k] == status, k
+        if status == 0:
+            assert (recs["niter"][k], recs["nfev"][k]) == (niter, s.last.nfev), k
+            assert recs["fx"][k] == fx and np.array_equal(got["iterate"][1][k], x)
+
+
 def test_resident_batch_is_reused_across_minimisations(A):
     """lbfgsx_lockstep_create / _minimize: the batch allocated once; a second minimisation of the same ids repeats the first
     bit for bit, other ids give other problems, and both equal the one-shot call; the stats say which form ran"""
