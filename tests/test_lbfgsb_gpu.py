@@ -168,6 +168,46 @@ def test_lbfgsb_argument_errors(A):
         s.prepare(2 ** 31)
 
 
+_INF = float("inf")
+
+
+@pytest.mark.parametrize("name,lb,ub,x0", [
+    ("n1", [-0.25], [0.5], [0.4]),
+    ("n1_fixed", [0.3], [0.3], [0.3]),                                   # lb == ub: nothing is free, the search ends at once
+    ("n2_unbounded", [-_INF, -_INF], [_INF, _INF], [0.0, 0.0]),          # no finite bound: the L-BFGS-B machinery on a free problem
+    ("n3_one_fixed", [-1.0, 0.2, -1.0], [1.0, 0.2, 1.0], [0.0, 0.2, 0.5]),
+    ("n7_half_lines", [-_INF, -0.1, -_INF, 0.0, -2.0, -_INF, 0.05], [0.1, _INF, _INF, 0.0, _INF, -0.3, 0.06],
+     [0.0, 0.0, 3.0, 0.0, -1.0, -0.5, 0.055]),
+    ("n5_start_outside", [-0.5] * 5, [0.5] * 5, [-3.0, 3.0, 0.0, 0.7, -0.7]),
+])
+@pytest.mark.parametrize("dtype", [O.F64, O.F32])
+def test_smallest_problems_and_infinite_bounds_match_the_reference(A, boracle, name, lb, ub, x0, dtype):
+    """n = 1 ... 7 with bounds at +-inf, lb == ub and a start outside the box (LBFGSB.h:55-66 force_bounds, Cauchy.h:93-133 break
+    points of half-lines): same outcome as the reference's solver -- counts, minimiser, or the same failure"""
+    dt = O.NPDT[dtype]
+    n = len(lb)
+    rng = np.random.default_rng(n)
+    a = (1.0 + 9.0 * rng.random(n)).astype(dt)
+    b = (4.0 * rng.random(n) - 2.0).astype(dt)
+    lb, ub, x0 = np.array(lb, dt), np.array(ub, dt), np.array(x0, dt)
+    kw = dict(m=4, epsilon=1e-6 if dtype == O.F64 else 1e-4, epsilon_rel=0, past=0, max_iterations=40)
+    x_ref, r_ref = boracle.lbfgsb(dtype, O.OBJ_QUAD, x0, lb, ub, O.lbfgsb_params(**kw), a=a, b=b)
+    s = A.LBFGSBSolver(A.LBFGSBParam(**kw), dtype=dt)
+    x = x0.copy()
+    try:
+        niter, fx = s.minimize(A.DiagQuadratic(a, b), x, lb, ub)
+        status = 0
+    except (RuntimeError, ArithmeticError, ValueError):
+        status, niter, fx = s.last.status, s.last.niter, s.last.fx
+    assert (status == 0) == (r_ref.status == 0), (name, status, r_ref.status, r_ref.msg)
+    assert (niter, s.last.nfev) == (r_ref.niter, r_ref.nfev), name
+    tol = 1e-10 if dtype == O.F64 else 1e-5
+    assert np.abs(x - x_ref).max() <= tol, name
+    if status == 0:
+        assert np.all(x >= lb) and np.all(x <= ub)
+        assert np.abs(x - np.clip(b / a, lb, ub)).max() <= (1e-5 if dtype == O.F64 else 1e-3)
+
+
 @pytest.mark.parametrize("m,iters", [(20, 30), (36, 45), (40, 50)])
 def test_lbfgsb_long_histories_match_oracle(A, boracle, m, iters):
     """2c beyond the single-launch widths (multi-dot chunks of 8 columns, blocked Gram, host Cauchy search) up to the
