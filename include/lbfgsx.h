@@ -557,7 +557,9 @@ int lbfgsx_bat_apply_Hv(lbfgsx_batch* c, const lbfgsx_bat_hvdesc* desc);
  * 2..16 consecutive blocks, each with its share of the direction resident, and the blocks exchange their partial sums at every
  * step (n up to 1 605 632 floats / 802 816 doubles, a multiple of the 16-byte vector width; m <= 31): lbfgsx_bat_iterate_ok.
  * LBFGSX_E_INVALID otherwise -- the caller then issues the statement-wise launches.  LBFGSX_E_RUNTIME: the blocks of a split
- * problem were not resident together within 100 ms (something else held the CUs); no sums are returned. */
+ * problem were not resident together within 100 ms (something else held the CUs); no sums are returned -- a part that gives up
+ * stops publishing and sets the launch's error word, its siblings give up on seeing it, the reporting part checks the word
+ * (environment LBFGSX_BAT_DEBUG_XCH_FAULT=k at lbfgsx_bat_create: the k-th such launch of the batch behaves like that). */
 int lbfgsx_bat_iterate(lbfgsx_batch* c, int objective, const lbfgsx_bat_itdesc* desc, double* out);
 int lbfgsx_bat_iterate_ok(const lbfgsx_batch* c);
 /* instrumentation: enable != 0 brackets every launch of the batch with a pair of events; lbfgsx_bat_timing_read waits for

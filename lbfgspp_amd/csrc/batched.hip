@@ -557,6 +557,8 @@ int lbfgsx_bat_create(lbfgsx_batch** out, int dtype, int64_t n, int m, int nprob
         c->min_parts = std::max(0, std::min(atoi(e), 16));
     if (const char* e = getenv("LBFGSX_BAT_MAX_PARTS"))
         c->max_parts = std::max(0, atoi(e));
+    if (const char* e = getenv("LBFGSX_BAT_DEBUG_XCH_FAULT"))
+        c->dbg_xch_fault = std::max(0, atoi(e));
     if (const char* e = getenv("LBFGSX_BAT_POLL"))
         c->poll = atoi(e) != 0;
     if (const char* e = getenv("LBFGSX_BAT_GX"))

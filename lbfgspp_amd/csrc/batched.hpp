@@ -218,6 +218,9 @@ struct lbfgsx_batch
     bool fused_iter = true;  // LBFGSX_BAT_FUSED_ITER=0: never the one-launch lock-step iteration
     int min_parts = 0;       // LBFGSX_BAT_MIN_PARTS=k: split every problem over at least k blocks (experiments: shorter blocks, several per CU)
     int max_parts = 0;       // LBFGSX_BAT_MAX_PARTS=k: a problem may be split over at most k blocks (0: as many as it needs, <= 16)
+    int dbg_xch_fault = 0;   // test hook, LBFGSX_BAT_DEBUG_XCH_FAULT=k: the k-th split-problem launch of this batch runs with part 1 of
+                             // every problem "timed out" from the start (it publishes nothing) and the error word set
+    int xch_launches = 0;
     unsigned* xch = nullptr; // exchange area of the parts of a problem (batched_iter.hip), allocated on first use
     unsigned xch_seq = 0;
     bool adaptive_gx = true; // LBFGSX_BAT_ADAPTIVE_GX=0: every launch with the batch's blocks per problem

@@ -112,6 +112,7 @@ struct ItXch
     int* err;        // launch-wide error word (device memory)
     unsigned tag0;   // tag of this launch's exchange 0
     int G;
+    int dead_part;   // -1; test hook: this part of every problem starts the launch as if an exchange had timed out for it
 };
 constexpr int kItMaxParts = 16;
 constexpr int kItXchWords = 2 * kItMaxParts * 4 * 2;  // 16-byte words per problem
@@ -120,8 +121,11 @@ constexpr int kItXchWords = 2 * kItMaxParts * 4 * 2;  // 16-byte words per probl
 // Lane 0 publishes; lane q (q < G, q != r) polls sibling q's words -- the G - 1 round trips run side by side instead of one
 // after the other (G = 8: 14 dependent polls per exchange before) -- and the partials are added in part order from lane 0's
 // point of view by cross-lane reads.
+// A part that has given up (dead: an earlier exchange of this launch timed out for it) publishes nothing any more: its sums
+// are not sums, and siblings that would go on with them must time out as well (they see the launch's error word within a
+// thousand polls) -- part 0 among them, which is the one that reports to the host.
 template <int NS, class A>
-__device__ __forceinline__ bool it_exchange(A (&acc)[NS], const ItXch& xc, int p, int r, unsigned e)
+__device__ __forceinline__ bool it_exchange(A (&acc)[NS], const ItXch& xc, int p, int r, unsigned e, bool dead)
 {
     static_assert(NS <= 4, "exchange rows");
     unsigned* area = xc.base + size_t(p) * kItXchWords * 4;
@@ -129,7 +133,7 @@ __device__ __forceinline__ bool it_exchange(A (&acc)[NS], const ItXch& xc, int p
     const int par = int(e & 1u);
     const int lane = threadIdx.x & 63;
     auto word = [&](int part, int k, int h) { return area + size_t(((par * kItMaxParts + part) * 4 + k) * 2 + h) * 4; };
-    if (lane == 0)
+    if (lane == 0 && !dead)
     {
 #pragma unroll
         for (int k = 0; k < NS; k++)
@@ -275,7 +279,7 @@ __global__ void __launch_bounds__(kHvThreads) kb_iter(BatBufs<T> b, const BatItD
     const bool trial = (de.flags & LBFGSX_BAT_IT_TRIAL) != 0;
     unsigned xe = 0;  // exchanges of this launch so far (uniform over the parts of a problem)
     if (tid == 0)
-        s_bad = 0;
+        s_bad = (r == xc.dead_part) ? 1 : 0;
 
     if (de.flags & LBFGSX_BAT_IT_TRIAL_ONLY)
     {
@@ -322,13 +326,13 @@ __global__ void __launch_bounds__(kHvThreads) kb_iter(BatBufs<T> b, const BatItD
             }
         }
         it_block_sum<2>(acc2, sh);
-        if (G > 1 && tid < 64 && !it_exchange<2>(acc2, xc, p, r, xe) && tid == 0)
+        if (G > 1 && tid < 64 && !it_exchange<2>(acc2, xc, p, r, xe, s_bad != 0) && tid == 0)
             s_bad = 1;
         if (tid == 0 && r == 0)
         {
             bat_result(ws, p, 5, double(obj.finish(T(acc2[0].value()))));
             bat_result(ws, p, 6, double(T(acc2[1].value())));
-            bat_result(ws, p, 7, s_bad ? 1.0 : 0.0);
+            bat_result(ws, p, 7, (s_bad || (G > 1 && __hip_atomic_load(xc.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) ? 1.0 : 0.0);
             bat_signal(ws);
         }
         return;
@@ -381,7 +385,7 @@ __global__ void __launch_bounds__(kHvThreads) kb_iter(BatBufs<T> b, const BatItD
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // s, y are re-read by this block below
         it_block_sum<4>(accp, sh);
-        if (G > 1 && tid < 64 && !it_exchange<4>(accp, xc, p, r, xe) && tid == 0)
+        if (G > 1 && tid < 64 && !it_exchange<4>(accp, xc, p, r, xe, s_bad != 0) && tid == 0)
             s_bad = 1;
         if (tid == 0)
         {
@@ -422,7 +426,7 @@ __global__ void __launch_bounds__(kHvThreads) kb_iter(BatBufs<T> b, const BatItD
             s_cn = cn;
             if (post_only && r == 0)
             {
-                bat_result(ws, p, 7, s_bad ? 1.0 : 0.0);
+                bat_result(ws, p, 7, (s_bad || (G > 1 && __hip_atomic_load(xc.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) ? 1.0 : 0.0);
                 bat_signal(ws);
             }
         }
@@ -524,7 +528,7 @@ __global__ void __launch_bounds__(kHvThreads) kb_iter(BatBufs<T> b, const BatItD
         for (int k = 1; k < 4; k++)
             acc[0].merge(acc4[k].hi, acc_lo(acc4[k]));
         it_block_sum<1>(acc, sh);
-        if (G > 1 && tid < 64 && !it_exchange<1>(acc, xc, p, r, xe + unsigned(L)) && tid == 0)
+        if (G > 1 && tid < 64 && !it_exchange<1>(acc, xc, p, r, xe + unsigned(L), s_bad != 0) && tid == 0)
             s_bad = 1;
         if (tid == 0)
         {
@@ -548,7 +552,7 @@ __global__ void __launch_bounds__(kHvThreads) kb_iter(BatBufs<T> b, const BatItD
         acc2[0] = accf;
         acc2[1] = accd;
         it_block_sum<2>(acc2, sh);
-        if (G > 1 && tid < 64 && !it_exchange<2>(acc2, xc, p, r, xe) && tid == 0)
+        if (G > 1 && tid < 64 && !it_exchange<2>(acc2, xc, p, r, xe, s_bad != 0) && tid == 0)
             s_bad = 1;
         accf = acc2[0];
         accd = acc2[1];
@@ -561,7 +565,9 @@ __global__ void __launch_bounds__(kHvThreads) kb_iter(BatBufs<T> b, const BatItD
             bat_result(ws, p, 5, double(obj.finish(T(accf.value()))));
             bat_result(ws, p, 6, double(T(accd.value())));
         }
-        bat_result(ws, p, 7, s_bad ? 1.0 : 0.0);
+        // (a sibling that gave up set the launch's error word before it stopped publishing)
+        const bool any_bad = s_bad || (G > 1 && __hip_atomic_load(xc.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0);
+        bat_result(ws, p, 7, any_bad ? 1.0 : 0.0);
         bat_signal(ws);
     }
 }
@@ -670,6 +676,7 @@ int lbfgsx_bat_iterate(lbfgsx_batch* c, int objective, const lbfgsx_bat_itdesc* 
     xc.base = nullptr;
     xc.err = nullptr;
     xc.tag0 = 0;
+    xc.dead_part = -1;
     if (xc.G > 1)
     {
         if (!c->xch)
@@ -682,6 +689,12 @@ int lbfgsx_bat_iterate(lbfgsx_batch* c, int objective, const lbfgsx_bat_itdesc* 
         xc.base = c->xch + 16;
         c->xch_seq += 128;  // more than the 2 * 32 + 3 exchanges a launch can make
         xc.tag0 = c->xch_seq;
+        if (c->dbg_xch_fault > 0 && ++c->xch_launches == c->dbg_xch_fault)
+        {
+            // test hook: what the launch looks like to the siblings of a part that gave up
+            xc.dead_part = 1;
+            LBFGSX_HIP(hipMemsetAsync(c->xch, 1, sizeof(int), c->stream));
+        }
     }
     const void* dd = nullptr;
     LBFGSX_HIP(lbfgsx::bat_stage(c, desc, sizeof(BatItDesc) * size_t(c->P), &dd));

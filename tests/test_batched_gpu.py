@@ -166,6 +166,27 @@ def test_one_launch_iteration_at_the_edges(monkeypatch, dtype, n, m, count):
             assert recs["fx"][k] == fx and np.array_equal(got["iterate"][1][k], x)
 
 
+def test_split_problem_whose_parts_lose_each_other_fails_loudly_and_recovers(A, monkeypatch):
+    """a problem split over several blocks exchanges its partial sums at every step; a part that waits in vain gives up, stops
+    publishing and poisons the launch's error word, so its siblings give up too and part 0 reports the launch as failed:
+    lbfgsx_bat_iterate answers LBFGSX_E_RUNTIME instead of sums.  LBFGSX_BAT_DEBUG_XCH_FAULT=k makes the k-th such launch of a
+    batch look like that (part 1 of every problem mute from the start).  The batch stays usable: the next minimisation on it
+    equals an undisturbed one."""
+    from lbfgspp_amd import batched as B
+    par = A.LBFGSParam(m=4, epsilon=0.0, epsilon_rel=0.0, max_iterations=8)
+    n, count = 200000, 3  # f32: two blocks per problem
+    want, xw = B.solve_local_lockstep(par, n, first=1, count=count, seed_base=21, dtype=np.float32, return_x=True)
+    monkeypatch.setenv("LBFGSX_BAT_DEBUG_XCH_FAULT", "3")
+    batch = B.LockstepBatch(par, n, count, dtype=np.float32, device=0)
+    monkeypatch.delenv("LBFGSX_BAT_DEBUG_XCH_FAULT")
+    with pytest.raises(RuntimeError, match="exchange timed out"):
+        batch.minimize(first=1, seed_base=21, return_x=True)
+    got, xg = batch.minimize(first=1, seed_base=21, return_x=True)
+    assert batch.stats["fused"]
+    batch.close()
+    assert np.array_equal(got, want) and np.array_equal(xg, xw)
+
+
 def test_resident_batch_is_reused_across_minimisations(A):
     """lbfgsx_lockstep_create / _minimize: the batch allocated once; a second minimisation of the same ids repeats the first
     bit for bit, other ids give other problems, and both equal the one-shot call; the stats say which form ran"""
