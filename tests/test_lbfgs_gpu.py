@@ -43,7 +43,8 @@ class Ctx:
 
 @pytest.mark.parametrize("dtype", [O.F64, O.F32])
 @pytest.mark.parametrize("n,m,npairs", [(1000, 6, 0), (1000, 6, 3), (4099, 6, 6), (4099, 5, 13), (65537, 10, 10),
-                                        (2, 3, 2), (7, 3, 5), (3001, 32, 35), (3001, 33, 33), (2050, 70, 75)])
+                                        (2, 3, 2), (7, 3, 5), (3001, 32, 35), (3001, 33, 33), (2050, 70, 75),
+                                        (1030, 128, 131), (1030, 129, 133), (515, 200, 60)])  # around the persistent launch's column list (128)
 def test_apply_Hv_matches_oracle(A, oracle, dtype, n, m, npairs):
     rng = np.random.default_rng(1234 + n + npairs)
     dt = O.NPDT[dtype]
@@ -144,7 +145,8 @@ def test_trajectory_quadratic_f64(A, oracle, ls):
 
 
 @pytest.mark.parametrize("ls", [O.LS_NW, O.LS_MT])
-@pytest.mark.parametrize("n,m,iters", [(20000, 10, 60), (200000, 20, 30), (6000, 40, 55)])
+@pytest.mark.parametrize("n,m,iters", [(20000, 10, 60), (200000, 20, 30), (6000, 40, 55),
+                                       (3000, 140, 160)])  # a history longer than the persistent launch's column list: step launches
 def test_trajectory_rosenbrock_f64(A, oracle, ls, n, m, iters):
     r = _trajectory(A, oracle, O.F64, ls, O.OBJ_ROSEN, n, m, iters, O.rosen_x0(n))
     assert r["status"] == r["r_ref"].status == 0
