@@ -517,7 +517,14 @@ static int bat_alloc(lbfgsx_batch* c);
 
 int lbfgsx_bat_create(lbfgsx_batch** out, int dtype, int64_t n, int m, int nproblems, int device)
 {
-    if (!out || n <= 0 || m <= 0 || m > LBFGSX_MAX_M_BATCH || nproblems <= 0 || (dtype != LBFGSX_F64 && dtype != LBFGSX_F32))
+    if (out && m > LBFGSX_MAX_M_BATCH)
+    {
+        // the reference has no limit on m (Param.h:193-217); this one is the batch's, and it says so
+        set_error("lbfgsx_bat_create: the lock-step batch keeps m <= 31 correction pairs (LBFGSX_MAX_M_BATCH); longer histories: "
+                  "lbfgsx_batch_minimize (one context per problem)");
+        return LBFGSX_E_INVALID;
+    }
+    if (!out || n <= 0 || m <= 0 || nproblems <= 0 || (dtype != LBFGSX_F64 && dtype != LBFGSX_F32))
     {
         set_error("lbfgsx_bat_create: invalid argument");
         return LBFGSX_E_INVALID;

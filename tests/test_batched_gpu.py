@@ -187,6 +187,17 @@ def test_split_problem_whose_parts_lose_each_other_fails_loudly_and_recovers(A, 
     assert np.array_equal(got, want) and np.array_equal(xg, xw)
 
 
+def test_lockstep_batch_history_limit_is_reported(A):
+    """the lock-step batch's descriptors carry 32 column ids (include/lbfgsx.h, LBFGSX_MAX_M_BATCH = 31): m = 31 runs (the 98-slot
+    case above), m = 32 is refused with a message that names the limit and the form that has none"""
+    from lbfgspp_amd import batched as B
+    par = A.LBFGSParam(m=32, epsilon=0.0, epsilon_rel=0.0, max_iterations=3)
+    with pytest.raises(ValueError, match="m <= 31"):
+        B.solve_local_lockstep(par, 4096, first=0, count=2, seed_base=1, dtype=np.float32)
+    recs = B.solve_local(par, A.ExtendedRosenbrock.objective, 4096, 0, 2, dtype=np.float32, nthreads=2)  # concurrent contexts: any m
+    assert list(recs["niter"]) == [3, 3]
+
+
 def test_resident_batch_is_reused_across_minimisations(A):
     """lbfgsx_lockstep_create / _minimize: the batch allocated once; a second minimisation of the same ids repeats the first
     bit for bit, other ids give other problems, and both equal the one-shot call; the stats say which form ran"""
