@@ -89,7 +89,12 @@ public:
         bfgs.gram_cache_reset();
         const char* fuse_env = std::getenv("LBFGSX_SUB_FUSE");
         const bool fuse = !(fuse_env && fuse_env[0] == '0');
-        const bool early = fuse && bfgs.sweeps_expected();
+        // The first solve takes its sweep form (one pass: y, the in-bounds test, the partition) whether or not the previous call
+        // needed sweeps: until round 6 a call that followed one without sweeps ran the solve, the test and -- when it did need
+        // sweeps after all -- the partition as three passes (m = 20: +1.3 %, m = 10: even; LBFGSX_SUB_EARLY=0: as before).
+        const char* early_env = std::getenv("LBFGSX_SUB_EARLY");
+        const int early_mode = early_env ? std::atoi(early_env) : 1;
+        const bool early = fuse && (early_mode == 1 || bfgs.sweeps_expected());
         std::int64_t s7[7] = {0, 0, 0, 0, 0, 0, 0};
         bool swept = false;
         if (early)  // sweeps ahead: the first solve's Gram pass leaves a compact copy of the free rows for their passes
@@ -155,7 +160,13 @@ public:
                 bool hasL, hasU;
                 std::vector<Scalar> wl, wu;
                 std::int64_t zl = 0, zu = 0;
-                if (nL > 0 && nU > 0 && bfgs.Wtv_lu(wl, zl, wu, zu))    // both inner products from one launch
+                // both inner products from one launch over the index list of L u U -- also when one of the two sets is empty
+                // (its sum and its count are zero then, i.e. hasL / hasU false exactly as PtBQv_coef answers for nQ = 0): the
+                // list pass is what leaves the sums the solve below needs to do without a Gram pass over P
+                // (LBFGSX_LU_ONE_SIDED=0: only when both are non-empty, as before round 6 -- the A/B switch)
+                const char* os_env = std::getenv("LBFGSX_LU_ONE_SIDED");
+                const bool one_sided = !(os_env && os_env[0] == '0');
+                if ((one_sided ? (nL > 0 || nU > 0) : (nL > 0 && nU > 0)) && bfgs.Wtv_lu(wl, zl, wu, zu))
                 {
                     hasL = zl >= 1;                                     // test_zero (BFGSMat.h:388-412), as PtBQv_coef
                     hasU = zu >= 1;

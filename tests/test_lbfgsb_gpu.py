@@ -1158,6 +1158,43 @@ def test_sweep_rhs_products_from_held_sums_stay_within_an_ulp_of_the_pass(A, bor
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("n,m,iters,lo,hi", [(70001, 8, 40, -0.7, 0.9), (90000, 20, 60, -0.7, 0.9), (65536, 10, 45, -0.05, 30.0),
+                                            (120000, 16, 50, -30.0, 0.05)])
+def test_list_pass_over_L_u_U_with_one_empty_set_changes_no_bit(A, monkeypatch, n, m, iters, lo, hi, dtype):
+    """A BOXCQP sweep needs W_L' l and W_U' u (SubspaceMin.h:236-241).  The pass over the index list of L u U delivers both and
+    leaves the sums the solve's identity uses; until round 6 it ran only when BOTH sets were non-empty, and late sweeps -- a
+    handful of rows on one side -- fell back to a masked pass over all rows plus a Gram pass over P (m = 20: 0.6 ms of a 3 ms
+    iteration).  Now it runs whenever the list is non-empty (LBFGSX_LU_ONE_SIDED=0: as before); an empty set contributes a zero
+    sum and a zero count, which is what the per-set form answers for it.  With the identity off (LBFGSX_RHS_IDENTITY=0) the two
+    forms must agree bit for bit -- same dots by order-independent sums; with it on, to the identity's own tolerance
+    (test_sweep_rhs_products_from_held_sums...).  The last two boxes are one-sided by construction (only one bound is ever met)."""
+    dt = O.F64 if dtype == "f64" else O.F32
+    npdt = O.NPDT[dt]
+    a, b = O.quad_problem(n, 30.0, 17, dt)
+    lb, ub = (lo * np.ones(n)).astype(npdt), (hi * np.ones(n)).astype(npdt)
+    res = {}
+    for ident in ("0", "1"):
+        for on in ("1", "0"):
+            monkeypatch.setenv("LBFGSX_RHS_IDENTITY", ident)
+            monkeypatch.setenv("LBFGSX_LU_ONE_SIDED", on)
+            s = A.LBFGSBSolver(A.LBFGSBParam(m=m, epsilon=0, epsilon_rel=0, past=0, max_iterations=iters), dtype=npdt)
+            tr = A.TraceBuffer(n, cap=512, stride=19)
+            x = np.zeros(n, dtype=npdt)
+            niter, fx = s.minimize(A.DiagQuadratic(a, b), x, lb, ub, trace=tr)
+            st = s.stats()
+            res[ident, on] = (niter, s.last.nfev, x.copy(), tr.xs[:tr.count].copy(), st["submin_sweeps"], st["rhs_identities"])
+    f, u = res["0", "1"], res["0", "0"]
+    assert f[:2] == u[:2] and f[4] == u[4] and f[4] > 0
+    assert np.array_equal(f[2], u[2]) and np.array_equal(f[3], u[3])
+    g, v = res["1", "1"], res["1", "0"]
+    assert g[5] >= v[5]                     # the identity serves at least the sweeps it served before
+    tol = 1e-10 if dtype == "f64" else 2e-4
+    assert np.abs(g[2] - f[2]).max() <= tol
+    if dtype == "f64":
+        assert g[:2] == f[:2] and g[4] == f[4] and np.abs(g[3] - f[3]).max() <= tol
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("n,m,iters", [(70001, 8, 40), (300000, 10, 30), (65536, 20, 40)])
 def test_first_chunk_of_the_break_points_gathered_ahead_changes_no_bit(A, monkeypatch, n, m, iters, dtype):
     """The host form of the Cauchy search opens with the first 512 sorted break points (Cauchy<Scalar>::Stream).  Their gather
