@@ -537,7 +537,10 @@ public:
             cdd.assign(size_t(t) * size_t(t + 1), 0.0);
             const bool ok = (ncomp == 0) || lbfgsx_b_gram_fused_dd(m_c, comp_mask, -1, LBFGSX_GP_NONE, nullptr, nullptr,
                                                                     nullptr, nullptr, cdd.data()) == LBFGSX_OK;
-            const bool ident = ok && ncomp > 0 && prologue == LBFGSX_GP_RHS && vsel == LBFGSX_VS_NEG_RHS && (coef1 || coef2) &&
+            // (a sweep whose L and U rows all sit on their bounds already -- l - x0 = 0, u - x0 = 0: test_zero, no update of rhs --
+            // asks for W_P'(-c_P) with no prologue: the same identity with both coefficient vectors absent)
+            const bool rhs_form = (prologue == LBFGSX_GP_RHS && (coef1 || coef2)) || (prologue == LBFGSX_GP_NONE && !coef1 && !coef2);
+            const bool ident = ok && ncomp > 0 && rhs_form && vsel == LBFGSX_VS_NEG_RHS &&
                                m_vF_valid && luc_fresh && m_vF_dd.size() == size_t(2 * t) && m_luc_dd.size() == size_t(2 * t) &&
                                sweep && swept && !sweep_first && mask == LBFGSX_ST_P && Fy && fy_mask == LBFGSX_ST_FREE &&
                                lbfgsx_b_solve_sweep_rhs_ready(m_c) == 1;
