@@ -8,6 +8,9 @@ namespace lbfgsx {
 namespace xl {
 
 // column classes: (NCL columns per lane, G lanes per row) for 2c <= NCL * G
+#ifndef LBFGSX_X40
+#define LBFGSX_X40(CALL) CALL(10, 4)  // 2c in 33..40 (m = 17..20); -D'LBFGSX_X40(CALL)=CALL(20, 2)' builds the other split
+#endif
 #define LBFGSX_XCLASS(ncols, CALL)             \
     do                                         \
     {                                          \
@@ -16,9 +19,22 @@ namespace xl {
         else if ((ncols) <= 20) { CALL(10, 2); } \
         else if ((ncols) <= 24) { CALL(12, 2); } \
         else if ((ncols) <= 32) { CALL(8, 4); }  \
-        else if ((ncols) <= 40) { CALL(10, 4); } \
+        else if ((ncols) <= 40) { LBFGSX_X40(CALL); } \
         else if ((ncols) <= 60) { CALL(15, 4); } \
         else { CALL(20, 4); }                  \
+    } while (0)
+
+// The sweeps' solves at 2c = 33..40 split a row over two lanes of 20 columns: kx_solve_sweep<.., 0 ..> 472 -> 450 us, <.., 1 ..>
+// 518 -> 469 us at m = 20 against four lanes of 10, while kx_rows goes the other way (438 -> 468 us) and the W'd pass is even
+// (profiles/r6_cfg4_m20_ab.txt) -- so only the solves take the other split.  Any split gives the same bits (order-independent sums).
+#ifndef LBFGSX_X40_SWEEP
+#define LBFGSX_X40_SWEEP(CALL) CALL(20, 2)
+#endif
+#define LBFGSX_XCLASS_SWEEP(ncols, CALL)                                  \
+    do                                                                    \
+    {                                                                     \
+        if ((ncols) > 32 && (ncols) <= 40) { LBFGSX_X40_SWEEP(CALL); }    \
+        else LBFGSX_XCLASS(ncols, CALL);                                  \
     } while (0)
 
 // blocks per CU: what the kernel was compiled for, but no more than two -- with the next trip's loads always in flight two
@@ -145,7 +161,7 @@ int solve_sweep(hipStream_t s, int num_cus, int first, const ColsX<T>& cols, int
         else if (ridx) SWEEP(0, true, false, false);                      \
         else SWEEP(0, false, false, false);                               \
     }
-    LBFGSX_XCLASS(ncols, CALL);
+    LBFGSX_XCLASS_SWEEP(ncols, CALL);
 #undef CALL
 #undef SWEEP
     LBFGSX_HIP(hipGetLastError());
