@@ -180,7 +180,7 @@ __device__ __forceinline__ T from_last_group_x(T x, int rr)
 template <class T, int NCL, int G>
 __device__ __forceinline__ T chain_x(const T (&p)[NCL], const LaneX<G>& L)
 {
-    static_assert(G == 2 || G == 4, "lane groups of 32 or 16");
+    static_assert(G == 1 || G == 2 || G == 4, "a whole row per lane, or lane groups of 32 or 16");
     T x = T(0);
 #pragma unroll
     for (int round = 0; round < G; round++)
@@ -192,7 +192,7 @@ __device__ __forceinline__ T chain_x(const T (&p)[NCL], const LaneX<G>& L)
         for (int k = 0; k < NCL; k++)
             x = x + p[k];
     }
-    if (LBFGSX_X_DBG & 8)
+    if ((LBFGSX_X_DBG & 8) || G == 1)
         return x;
     return from_last_group_x<T, G>(x, L.rr);
 }

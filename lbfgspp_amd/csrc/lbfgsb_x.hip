@@ -30,10 +30,14 @@ namespace xl {
 #ifndef LBFGSX_X40_SWEEP
 #define LBFGSX_X40_SWEEP(CALL) CALL(20, 2)
 #endif
+#ifndef LBFGSX_X20_SWEEP
+#define LBFGSX_X20_SWEEP(CALL) CALL(10, 2)
+#endif
 #define LBFGSX_XCLASS_SWEEP(ncols, CALL)                                  \
     do                                                                    \
     {                                                                     \
         if ((ncols) > 32 && (ncols) <= 40) { LBFGSX_X40_SWEEP(CALL); }    \
+        else if ((ncols) > 16 && (ncols) <= 20) { LBFGSX_X20_SWEEP(CALL); } \
         else LBFGSX_XCLASS(ncols, CALL);                                  \
     } while (0)
 
