@@ -1,0 +1,151 @@
+"""-m gpu: the solvers against the reference build (oracle/_ref) over the PARAMETER space of LBFGSParam / LBFGSBParam
+(/root/reference/include/LBFGSpp/Param.h:67-343): the `past` / `delta` stopping test (LBFGS.h:141-149, LBFGSB.h:212-220), the
+three termination conditions of the backtracking / bracketing policies (Param.h:27-56), short searches (max_linesearch), step
+limits that bite (min_step / max_step), loose and tight ftol / wolfe, relative and absolute gradient tolerances -- drawn from a
+seeded generator, each draw compared with the reference's outcome: same status (and the same exception text when the reference
+throws), same iteration and evaluation counts, iterates within the north-star tolerance."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+TOL = {O.F64: 1e-10, O.F32: 1e-4}
+
+
+@pytest.fixture(scope="module")
+def A():
+    import lbfgspp_amd as A
+    A.load()
+    return A
+
+
+@pytest.fixture(scope="module")
+def ref():
+    if not O.available("ref"):
+        pytest.skip("oracle/_ref not built")
+    return O.Oracle("ref")
+
+
+def _draw(rng, bounded):
+    ls = int(rng.integers(0, 4)) if not bounded else O.LS_MT
+    kw = dict(m=int(rng.choice([1, 2, 3, 6, 10, 17])),
+              epsilon=float(rng.choice([0.0, 1e-6, 1e-3])),
+              epsilon_rel=float(rng.choice([0.0, 1e-6, 1e-2])),
+              past=int(rng.choice([0, 0, 1, 3])),
+              delta=float(rng.choice([1e-12, 1e-6, 1e-2])),
+              max_iterations=int(rng.choice([3, 12, 40])),
+              # backtracking / bracketing honour all three conditions; the interpolating searches want strong Wolfe (Param.h:203-206)
+              linesearch=int(rng.choice([1, 2, 3])) if ls in (O.LS_BT, O.LS_BR) else 3,
+              max_linesearch=int(rng.choice([2, 5, 20])),
+              min_step=float(rng.choice([1e-20, 1e-20, 1e-4])),
+              max_step=float(rng.choice([1e20, 1e20, 0.7])),
+              ftol=float(rng.choice([1e-4, 1e-2, 0.3])),
+              wolfe=float(rng.choice([0.9, 0.5, 0.35])))
+    if bounded:
+        kw["max_submin"] = int(rng.choice([0, 1, 3, 10]))
+    return ls, kw
+
+
+def _compare(A, got_status, s, x, x_ref, r_ref, dtype, what, bounded=False):
+    assert (got_status == 0) == (r_ref.status == 0), (what, s.last.msg, r_ref.msg)
+    if r_ref.status != 0:
+        assert s.last.msg.strip() == r_ref.msg.decode().strip(), what   # the same exception text (the classes map one to one)
+    scale = max(1.0, float(np.abs(x_ref).max()))
+    dx = np.abs(np.asarray(x, np.float64) - np.asarray(x_ref, np.float64)).max()
+    if bounded and r_ref.niter > 60:
+        # Beyond the horizon of the trajectory contract: some 2c-vectors of the L-BFGS-B path are the exact
+        # sum rounded once where the reference rounds row by row (the held-sums identities, section 4b) -- last-bit differences
+        # that a run amplifies by about a decade per ten evaluations (scripts/r6/long_run_check.py: 2e-15 at evaluation 10, 6e-11 at
+        # 60, 3e-6 at 120 on an ill-conditioned box QP that is still 0.23 away from its minimiser after 200 iterations -- as far
+        # as the reference is); north_star's 1e-10 is stated, and tested at size, over the benchmark's 40 iterations.  A run of
+        # 80-200 iterations must still end the same way, after as many iterations, at the same objective value.
+        assert abs(s.last.niter - r_ref.niter) <= max(2, r_ref.niter // 20), (what, s.last.niter, r_ref.niter)
+        assert abs(s.last.fx - r_ref.fx) <= 1e-8 * max(1.0, abs(r_ref.fx)), (what, s.last.fx, r_ref.fx)
+        return
+    assert (s.last.niter, s.last.nfev) == (r_ref.niter, r_ref.nfev), (what, s.last.msg)
+    assert dx <= TOL[dtype] * scale, (what, dx)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_lbfgs_parameter_draws_match_the_reference(A, ref, seed):
+    rng = np.random.default_rng(1000 + seed)
+    ls, kw = _draw(rng, bounded=False)
+    dtype = O.F64 if seed % 4 else O.F32
+    obj = O.OBJ_ROSEN if seed % 2 else O.OBJ_QUAD
+    n = int(rng.choice([10, 1000, 4098]))
+    if obj == O.OBJ_ROSEN and n % 2:
+        n += 1
+    dt = O.NPDT[dtype]
+    a = b = None
+    if obj == O.OBJ_QUAD:
+        a, b = O.quad_problem(n, 30.0, seed, dtype)
+        x0 = np.zeros(n, dt)
+    else:
+        x0 = O.rosen_x0(n, seed, dtype)
+    x_ref, r_ref = ref.lbfgs(dtype, ls, obj, x0, O.lbfgs_params(**kw), a=a, b=b)
+    s = A.LBFGSSolver(A.LBFGSParam(**kw), linesearch=ls, dtype=dt)
+    x = x0.copy()
+    status = 0
+    try:
+        s.minimize(A.DiagQuadratic(a, b) if obj == O.OBJ_QUAD else A.ExtendedRosenbrock(), x)
+    except (RuntimeError, ArithmeticError, ValueError):
+        status = 1
+    _compare(A, status, s, x, x_ref, r_ref, dtype, (seed, ls, obj, n, kw))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_lbfgsb_parameter_draws_match_the_reference(A, ref, seed):
+    rng = np.random.default_rng(5000 + seed)
+    _, kw = _draw(rng, bounded=True)
+    dtype = O.F64
+    n = int(rng.choice([25, 1000, 5001]))
+    a, b = O.quad_problem(n, 30.0, seed, dtype)
+    lo, hi = float(rng.choice([-0.7, -0.05, -30.0])), float(rng.choice([0.9, 0.05, 30.0]))
+    lb, ub = lo * np.ones(n), hi * np.ones(n)
+    x0 = np.clip(rng.standard_normal(n), 2 * lo, 2 * hi) if seed % 3 == 0 else np.zeros(n)   # every third start: outside the box
+    x_ref, r_ref = ref.lbfgsb(dtype, O.OBJ_QUAD, x0, lb, ub, O.lbfgsb_params(**kw), a=a, b=b)
+    s = A.LBFGSBSolver(A.LBFGSBParam(**kw), dtype=np.float64)
+    x = x0.copy()
+    status = 0
+    try:
+        s.minimize(A.DiagQuadratic(a, b), x, lb, ub)
+    except (RuntimeError, ArithmeticError, ValueError):
+        status = 1
+    _compare(A, status, s, x, x_ref, r_ref, dtype, (seed, n, lo, hi, kw), bounded=True)
+
+
+def _draw_stop(rng):
+    """default searches; what varies is how the run ENDS: the gradient tests (LBFGS.h:137), the past / delta test (:141-149)"""
+    return dict(m=int(rng.choice([3, 6, 10])), epsilon=float(rng.choice([0.0, 1e-8, 1e-4, 1e-2])),
+                epsilon_rel=float(rng.choice([0.0, 1e-7, 1e-3])), past=int(rng.choice([0, 1, 2, 5])),
+                delta=float(rng.choice([1e-14, 1e-8, 1e-4, 1e-1])), max_iterations=200)
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_stopping_tests_end_the_run_where_the_reference_ends_it(A, ref, seed):
+    rng = np.random.default_rng(9000 + seed)
+    kw = _draw_stop(rng)
+    bounded = seed % 2 == 1
+    dtype = O.F64
+    n = int(rng.choice([10, 500, 3000]))
+    a, b = O.quad_problem(n, float(rng.choice([3.0, 30.0, 300.0])), seed, dtype)
+    x0 = np.zeros(n)
+    if bounded:
+        lb, ub = -0.6 * np.ones(n), 0.8 * np.ones(n)
+        x_ref, r_ref = ref.lbfgsb(dtype, O.OBJ_QUAD, x0, lb, ub, O.lbfgsb_params(**kw), a=a, b=b)
+        s = A.LBFGSBSolver(A.LBFGSBParam(**kw), dtype=np.float64)
+    else:
+        ls = int(rng.integers(0, 4))
+        x_ref, r_ref = ref.lbfgs(dtype, ls, O.OBJ_QUAD, x0, O.lbfgs_params(**kw), a=a, b=b)
+        s = A.LBFGSSolver(A.LBFGSParam(**kw), linesearch=ls, dtype=np.float64)
+    x = x0.copy()
+    status = 0
+    try:
+        if bounded:
+            s.minimize(A.DiagQuadratic(a, b), x, lb, ub)
+        else:
+            s.minimize(A.DiagQuadratic(a, b), x)
+    except (RuntimeError, ArithmeticError, ValueError):
+        status = 1
+    _compare(A, status, s, x, x_ref, r_ref, dtype, (seed, bounded, n, kw), bounded=bounded)
