@@ -152,3 +152,35 @@ def test_stopping_tests_end_the_run_where_the_reference_ends_it(A, ref, seed):
     except (RuntimeError, ArithmeticError, ValueError):
         status = 1
     _compare(A, status, s, x, x_ref, r_ref, dtype, (seed, bounded, n, kw), bounded=bounded)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_lockstep_batch_parameter_draws_equal_single_solves(A, seed, monkeypatch):
+    """the batched mode's state machines under the same draws (More-Thuente and Nocedal-Wright searches, LBFGSBatched.h): every
+    member of a lock-step batch -- one launch per iteration, or the statement-wise launches for odd n -- must be the
+    single-problem solver's run on the same start point bit for bit, whatever the parameters make it do (stop early by
+    `past` / `delta` or the gradient tests, run out of trials, leave the step limits)"""
+    from lbfgspp_amd import batched as B
+    rng = np.random.default_rng(7000 + seed)
+    _, kw = _draw(rng, bounded=False)
+    kw["linesearch"] = 3
+    kw["m"] = min(kw["m"], 10)
+    ls = O.LS_MT if seed % 2 else O.LS_NW
+    dtype = np.float32 if seed % 3 == 0 else np.float64
+    n = int(rng.choice([64, 4096, 20000, 4098]))
+    count = 5
+    par = A.LBFGSParam(**kw)
+    recs, xs = B.solve_local_lockstep(par, n, first=2, count=count, seed_base=300 + seed, dtype=dtype, return_x=True, linesearch=ls)
+    s = A.LBFGSSolver(par, linesearch=ls, dtype=dtype)
+    odt = O.F32 if dtype == np.float32 else O.F64
+    for k in range(count):
+        x = O.rosen_x0(n, 300 + seed + 2 + k, odt)
+        try:
+            niter, fx = s.minimize(A.ExtendedRosenbrock(), x)
+            status = 0
+        except (RuntimeError, ArithmeticError, ValueError):
+            status, niter, fx = s.last.status, s.last.niter, s.last.fx
+        assert recs["status"][k] == status, (seed, k, kw, s.last.msg)
+        assert recs["nfev"][k] == s.last.nfev, (seed, k, kw, status)
+        if status == 0:   # (a failed member's record keeps the iteration its search failed in; minimize() returns nothing then)
+            assert recs["niter"][k] == niter and recs["fx"][k] == fx and np.array_equal(xs[k], x), (seed, k, kw)
