@@ -184,3 +184,32 @@ def test_lockstep_batch_parameter_draws_equal_single_solves(A, seed, monkeypatch
         assert recs["nfev"][k] == s.last.nfev, (seed, k, kw, status)
         if status == 0:   # (a failed member's record keeps the iteration its search failed in; minimize() returns nothing then)
             assert recs["niter"][k] == niter and recs["fx"][k] == fx and np.array_equal(xs[k], x), (seed, k, kw)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_lbfgsb_rosenbrock_with_per_coordinate_bounds_matches_the_reference(A, ref, seed):
+    """a non-quadratic objective and a box that differs by coordinate -- half-lines, free coordinates, coordinates pinned by
+    lb == ub, a start outside the box -- under the parameter draws above"""
+    rng = np.random.default_rng(11000 + seed)
+    _, kw = _draw(rng, bounded=True)
+    kw["max_iterations"] = min(kw["max_iterations"], 25)
+    dtype = O.F64 if seed % 4 else O.F32
+    dt = O.NPDT[dtype]
+    n = int(rng.choice([10, 1000, 4098]))
+    lb = rng.choice([-np.inf, -1.5, -0.5, 0.3], size=n).astype(dt)
+    ub = rng.choice([np.inf, 0.8, 2.0, 0.3], size=n).astype(dt)
+    ub = np.maximum(ub, lb)                       # (0.3, 0.3): pinned
+    x0 = O.rosen_x0(n, 40 + seed, dtype)
+    if seed % 3:
+        x0 = np.minimum(np.maximum(x0, lb), ub)   # two of three starts inside the box
+    x_ref, r_ref = ref.lbfgsb(dtype, O.OBJ_ROSEN, x0, lb, ub, O.lbfgsb_params(**kw))
+    s = A.LBFGSBSolver(A.LBFGSBParam(**kw), dtype=dt)
+    x = x0.copy()
+    status = 0
+    try:
+        s.minimize(A.ExtendedRosenbrock(), x, lb, ub)
+    except (RuntimeError, ArithmeticError, ValueError):
+        status = 1
+    _compare(A, status, s, x, x_ref, r_ref, dtype, (seed, n, kw), bounded=True)
+    if status == 0:
+        assert np.all(x >= lb) and np.all(x <= ub)
