@@ -90,10 +90,13 @@ constexpr int occ_rows_x(int ncl, int g, int na, bool patch = false)
            : na == 1 ? (ncl <= 4 ? 4 : ncl <= 10 ? 3 : 2)
                      : (ncl <= 5 ? 3 : ncl <= 10 ? ((patch && g == 4 && ncl == 10) ? 1 : 2) : 1);
 }
+#ifndef LBFGSX_X_OCC2_NCL
+#define LBFGSX_X_OCC2_NCL 12  // two-lane classes up to this many columns per lane are compiled for two waves per SIMD (20: the m = 20 solves at 256 registers with 16-26 spilled: +0.8 %, within the noise -- profiles/r6_cfg4_m20_ab.txt)
+#endif
 constexpr int occ_sweep_x(int ncl, int g, int first)
 {
     return (LBFGSX_X_OCC_SWEEP > 0 && ncl <= 12) ? LBFGSX_X_OCC_SWEEP
-           : first ? (ncl <= 10 ? 3 : 2) : (ncl <= 5 ? 3 : ncl <= 12 ? 2 : 1);
+           : first ? (ncl <= 10 ? 3 : 2) : (ncl <= 5 ? 3 : ncl <= 12 ? 2 : (ncl <= LBFGSX_X_OCC2_NCL && g == 2) ? 2 : 1);
 }
 constexpr int occ_dots_x(int ncl) { return ncl <= 4 ? 4 : ncl <= 5 ? 3 : ncl <= 10 ? 2 : 1; }   // 2 NCL accumulators, two register sets
 constexpr int occ_mask_x(int ncl) { return ncl <= 12 ? 4 : ncl <= 15 ? 3 : 2; }                    // NCL + 1
