@@ -30,6 +30,9 @@ namespace xl {
 #ifndef LBFGSX_X40_SWEEP
 #define LBFGSX_X40_SWEEP(CALL) CALL(20, 2)
 #endif
+#ifndef LBFGSX_X60_SWEEP
+#define LBFGSX_X60_SWEEP(CALL) CALL(30, 2)  // 2c = 41..60 (m = 21..30)
+#endif
 #ifndef LBFGSX_X32_SWEEP
 #define LBFGSX_X32_SWEEP(CALL) CALL(16, 2)  // 2c = 25..32 (m = 13..16): the same question, the same answer (profiles/r6_cfg4_m20_ab.txt)
 #endif
@@ -39,7 +42,8 @@ namespace xl {
 #define LBFGSX_XCLASS_SWEEP(ncols, CALL)                                  \
     do                                                                    \
     {                                                                     \
-        if ((ncols) > 32 && (ncols) <= 40) { LBFGSX_X40_SWEEP(CALL); }    \
+        if ((ncols) > 40 && (ncols) <= 60) { LBFGSX_X60_SWEEP(CALL); }    \
+        else if ((ncols) > 32 && (ncols) <= 40) { LBFGSX_X40_SWEEP(CALL); } \
         else if ((ncols) > 24 && (ncols) <= 32) { LBFGSX_X32_SWEEP(CALL); } \
         else if ((ncols) > 16 && (ncols) <= 20) { LBFGSX_X20_SWEEP(CALL); } \
         else LBFGSX_XCLASS(ncols, CALL);                                  \
