@@ -20,6 +20,7 @@ namespace xl {
         else if ((ncols) <= 24) { CALL(12, 2); } \
         else if ((ncols) <= 32) { CALL(8, 4); }  \
         else if ((ncols) <= 40) { LBFGSX_X40(CALL); } \
+        else if ((ncols) <= 48) { CALL(12, 4); } \
         else if ((ncols) <= 60) { CALL(15, 4); } \
         else { CALL(20, 4); }                  \
     } while (0)
@@ -42,7 +43,8 @@ namespace xl {
 #define LBFGSX_XCLASS_SWEEP(ncols, CALL)                                  \
     do                                                                    \
     {                                                                     \
-        if ((ncols) > 40 && (ncols) <= 60) { LBFGSX_X60_SWEEP(CALL); }    \
+        if ((ncols) > 40 && (ncols) <= 48) { CALL(24, 2); }               \
+        else if ((ncols) > 48 && (ncols) <= 60) { LBFGSX_X60_SWEEP(CALL); } \
         else if ((ncols) > 32 && (ncols) <= 40) { LBFGSX_X40_SWEEP(CALL); } \
         else if ((ncols) > 24 && (ncols) <= 32) { LBFGSX_X32_SWEEP(CALL); } \
         else if ((ncols) > 16 && (ncols) <= 20) { LBFGSX_X20_SWEEP(CALL); } \

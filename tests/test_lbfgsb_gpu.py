@@ -208,7 +208,7 @@ def test_smallest_problems_and_infinite_bounds_match_the_reference(A, boracle, n
         assert np.abs(x - np.clip(b / a, lb, ub)).max() <= (1e-5 if dtype == O.F64 else 1e-3)
 
 
-@pytest.mark.parametrize("m,iters", [(20, 30), (36, 45), (40, 50)])
+@pytest.mark.parametrize("m,iters", [(20, 30), (22, 34), (24, 36), (27, 40), (30, 45), (36, 45), (40, 50)])
 def test_lbfgsb_long_histories_match_oracle(A, boracle, m, iters):
     """2c beyond the single-launch widths (multi-dot chunks of 8 columns, blocked Gram, host Cauchy search) up to the
     limit 2m = 80 of the masked operators: same iteration / evaluation counts and iterates as the reference."""
