@@ -15,6 +15,7 @@ namespace xl {
     do                                         \
     {                                          \
         if ((ncols) <= 8) { CALL(4, 2); }      \
+        else if ((ncols) <= 12) { CALL(6, 2); }  \
         else if ((ncols) <= 16) { CALL(8, 2); }  \
         else if ((ncols) <= 20) { CALL(10, 2); } \
         else if ((ncols) <= 24) { CALL(12, 2); } \
